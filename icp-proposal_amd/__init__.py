@@ -1,0 +1,9 @@
+"""icp-proposal_amd — MI355X-native closest-point-proposal path.
+
+The directory name carries a hyphen (it mirrors the reference repository's name), so import it through
+`tests/conftest.py:load_package()` / `__graft_entry__.load_package()`, which register it as `icp_proposal_amd`.
+"""
+from . import data  # noqa: F401
+from . import _native  # noqa: F401
+from .api import *  # noqa: F401,F403
+from .api import chain_eval_step, initial_parameters  # noqa: F401

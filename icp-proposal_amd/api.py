@@ -1,0 +1,310 @@
+"""Host-side mirror of the reference's plug-in surface for the closest-point-proposal path.
+
+Same names, argument meaning and error behaviour as the reference's Scala classes (paths relative to the
+reference's src/main/scala/), implemented as thin wrappers over the C ABI (include/icp_proposal.h):
+
+    ModelFittingParameters                 api/sampling/ModelFittingParameters.scala:47-66
+    NonRigidIcpProposal                    api/sampling/proposals/NonRigidIcpProposal.scala:30-155
+    IndependentPointDistanceEvaluator      api/sampling/evaluators/IndependentPointDistanceEvaluator.scala:27-67
+    HausdorffDistanceEvaluator             api/sampling/evaluators/HausdorffDistanceEvaluator.scala:25-36
+    CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator   …/CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:27-79
+    ModelPriorEvaluator                    api/sampling/evaluators/ModelPriorEvaluator.scala:24-31
+    ModelSampling / TargetSampling / ModelAndTargetSampling    api/other/IcpProjectionDirection.scala:19-25
+    ModelToTargetEvaluation / …            api/sampling/evaluators/EvaluationModeType.scala:20-26
+
+Differences forced by the boundary: the Scalismo mesh decimations inside the reference's
+constructors stay with the caller (here: `data.decimated_point_subset`, a deterministic stand-in), and the
+standard normals of `posterior.sample()` are passed in explicitly (`propose(theta, z)`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+
+import numpy as np
+
+from . import _native as nat
+from . import data as _data
+
+# api/other/IcpProjectionDirection.scala:19-25
+ModelSampling, TargetSampling, ModelAndTargetSampling = "ModelSampling", "TargetSampling", "ModelAndTargetSampling"
+# api/sampling/evaluators/EvaluationModeType.scala:20-26
+ModelToTargetEvaluation, TargetToModelEvaluation, SymmetricEvaluation = 0, 1, 2
+
+
+def _d(a):
+    return a.ctypes.data_as(nat.c_double_p)
+
+
+def _i(a):
+    return a.ctypes.data_as(nat.c_int_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+@dataclasses.dataclass(frozen=True)
+class ModelFittingParameters:
+    """Chain state: scale, pose (translation, Euler rotation, rotation centre), shape coefficients."""
+    scale: float
+    translation: tuple
+    rotation: tuple
+    rotation_center: tuple
+    shape: tuple
+    generatedBy: str = "Anonymous"
+
+    @property
+    def allParameters(self) -> np.ndarray:
+        """ModelFittingParameters.scala:64 — [s | t | (phi,theta,psi) | centre | c]."""
+        return np.asarray([self.scale, *self.translation, *self.rotation, *self.rotation_center, *self.shape],
+                          dtype=np.float64)
+
+    @classmethod
+    def from_vector(cls, v, generatedBy="Anonymous"):
+        v = np.asarray(v, dtype=np.float64)
+        return cls(float(v[0]), tuple(v[1:4]), tuple(v[4:7]), tuple(v[7:10]), tuple(v[10:]), generatedBy)
+
+    def copy_shape(self, shape, generatedBy):
+        return dataclasses.replace(self, shape=tuple(np.asarray(shape, dtype=np.float64)), generatedBy=generatedBy)
+
+
+def _theta(x) -> np.ndarray:
+    return _f64(x.allParameters if isinstance(x, ModelFittingParameters) else x)
+
+
+def initial_parameters(model) -> np.ndarray:
+    """api/sampling/SamplingRegistration.scala:40-43: zero pose and shape, rotation centre = mean reference point."""
+    theta = np.zeros(10 + model.rank)
+    theta[0] = 1.0
+    theta[7:10] = model.ref_points.sum(axis=0) * 1.0 / model.n_points
+    return theta
+
+
+class IcpContext:
+    """One StatisticalMeshModel + one target TriangleMesh3D resident on one MI355X (icp_ctx)."""
+
+    def __init__(self, model, target, device: int = -1):
+        self.model, self.target = model, target
+        L = nat.lib()
+        md = nat.ModelDesc(model.n_points, model.cells.shape[0], model.rank, _d(model.ref_points), _d(model.mean_def),
+                           _d(model.basis), _d(model.variance), _i(model.cells))
+        td = nat.MeshDesc(target.n_points, target.n_cells, _d(target.points), _i(target.cells))
+        h = C.c_void_p()
+        nat.check(L.icp_ctx_create(C.byref(md), C.byref(td), device, C.byref(h)), "icp_ctx_create")
+        self.h = h
+        self.rank, self.N = model.rank, model.n_points
+
+    def close(self):
+        if getattr(self, "h", None):
+            nat.lib().icp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def transformedMesh(self, theta) -> np.ndarray:
+        """ModelFittingParameters.transformedMesh (ModelFittingParameters.scala:108-110) -> points [N,3]."""
+        th = _theta(theta)
+        out = np.empty((self.N, 3))
+        nat.check(nat.lib().icp_transformed_mesh(self.h, _d(th), _d(out)), "icp_transformed_mesh")
+        return out
+
+    def vertexNormals(self, theta) -> np.ndarray:
+        th = _theta(theta)
+        out = np.empty((self.N, 3))
+        nat.check(nat.lib().icp_vertex_normals(self.h, _d(th), _d(out)), "icp_vertex_normals")
+        return out
+
+    def closestPointOnTarget(self, pts):
+        q = _f64(pts).reshape(-1, 3)
+        n = q.shape[0]
+        cp, tri, d2 = np.empty((n, 3)), np.empty(n, dtype=np.int32), np.empty(n)
+        nat.check(nat.lib().icp_closest_point_on_target(self.h, n, _d(q), _d(cp), _i(tri), _d(d2)), "icp_closest_point_on_target")
+        return cp, tri, d2
+
+    def closestTargetVertex(self, pts):
+        q = _f64(pts).reshape(-1, 3)
+        n = q.shape[0]
+        idx, d2 = np.empty(n, dtype=np.int32), np.empty(n)
+        nat.check(nat.lib().icp_closest_target_vertex(self.h, n, _d(q), _i(idx), _d(d2)), "icp_closest_target_vertex")
+        return idx, d2
+
+    def closestModelVertex(self, theta, pts):
+        th, q = _theta(theta), _f64(pts).reshape(-1, 3)
+        n = q.shape[0]
+        idx, d2 = np.empty(n, dtype=np.int32), np.empty(n)
+        nat.check(nat.lib().icp_closest_model_vertex(self.h, _d(th), n, _d(q), _i(idx), _d(d2)), "icp_closest_model_vertex")
+        return idx, d2
+
+    def closestPointOnModel(self, theta, pts):
+        th, q = _theta(theta), _f64(pts).reshape(-1, 3)
+        n = q.shape[0]
+        cp, tri, d2 = np.empty((n, 3)), np.empty(n, dtype=np.int32), np.empty(n)
+        nat.check(nat.lib().icp_closest_point_on_model(self.h, _d(th), n, _d(q), _d(cp), _i(tri), _d(d2)), "icp_closest_point_on_model")
+        return cp, tri, d2
+
+
+@dataclasses.dataclass
+class IcpPosterior:
+    corr_id: np.ndarray
+    corr_aux: np.ndarray
+    corr_point: np.ndarray
+    keep: np.ndarray
+    alpha: np.ndarray
+    M: np.ndarray
+    V: np.ndarray
+    S: np.ndarray
+
+
+class NonRigidIcpProposal:
+    """NonRigidIcpProposal.scala:30-41.  `projectionDirection` is ModelSampling or TargetSampling."""
+
+    def __init__(self, ctx: IcpContext, stepLength: float, tangentialNoise: float, noiseAlongNormal: float,
+                 numOfSamplePoints: int, projectionDirection=ModelSampling, boundaryAware: bool = True,
+                 generatedBy: str = "ShapeIcpProposal", decimatedTargetPoints=None, numDecimatedModelPoints=None):
+        self.ctx, self.stepLength, self.generatedBy = ctx, stepLength, generatedBy
+        self.projectionDirection = projectionDirection
+        if projectionDirection == TargetSampling:
+            # :46 target.operations.decimate(numOfSamplePoints) — the caller's decimation outcome
+            tp = _f64(decimatedTargetPoints if decimatedTargetPoints is not None
+                      else _data.decimated_point_subset(ctx.target, numOfSamplePoints)).reshape(-1, 3)
+            prm = nat.ProposalParams(stepLength, tangentialNoise, noiseAlongNormal, 1, int(boundaryAware), 0, tp.shape[0], _d(tp))
+        elif projectionDirection == ModelSampling:
+            # :45 model.decimate(numOfSamplePoints): only its point COUNT matters (:94-96)
+            k = int(numDecimatedModelPoints if numDecimatedModelPoints is not None else min(numOfSamplePoints, ctx.N))
+            prm = nat.ProposalParams(stepLength, tangentialNoise, noiseAlongNormal, 0, int(boundaryAware), k, 0, None)
+        else:
+            raise ValueError("a NonRigidIcpProposal samples one direction; mix two for ModelAndTargetSampling "
+                             "(MixedProposalDistributions.scala:52-65)")
+        h = C.c_void_p()
+        nat.check(nat.lib().icp_proposal_create(ctx.h, C.byref(prm), C.byref(h)), "icp_proposal_create")
+        self.h = h
+        self.K = nat.lib().icp_proposal_num_candidates(h)
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            nat.lib().icp_proposal_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def propose(self, theta, z, return_correspondences: bool = False):
+        """:53-68.  z = the r standard normals `posterior.sample()` draws (:55)."""
+        th, z = _theta(theta), _f64(z)
+        out = np.empty_like(th)
+        corr = np.empty(max(self.K, 1), dtype=np.int32)
+        nat.check(nat.lib().icp_proposal_propose(self.h, _d(th), _d(z), _d(out), _i(corr)), "icp_proposal_propose")
+        res = out
+        if isinstance(theta, ModelFittingParameters):
+            res = theta.copy_shape(out[10:], self.generatedBy)
+        return (res, corr[:self.K]) if return_correspondences else res
+
+    def logTransitionProbability(self, theta_from, theta_to) -> float:
+        """:71-85 (−inf when anything but the shape differs)."""
+        a, b = _theta(theta_from), _theta(theta_to)
+        out = C.c_double()
+        nat.check(nat.lib().icp_proposal_log_transition(self.h, _d(a), _d(b), C.byref(out)), "icp_proposal_log_transition")
+        return out.value
+
+    def icpPosterior(self, theta, with_aux: bool = True) -> IcpPosterior:
+        """:88-153, diagnostic view."""
+        th = _theta(theta)
+        r, K = self.ctx.rank, max(self.K, 1)
+        p = IcpPosterior(np.empty(K, dtype=np.int32), np.empty(K, dtype=np.int32), np.empty((K, 3)),
+                         np.empty(K, dtype=np.uint8), np.empty(r), np.empty((r, r)), np.empty((r, r)), np.empty(r))
+        view = nat.PosteriorView(0, _i(p.corr_id), _i(p.corr_aux) if with_aux else None, _d(p.corr_point),
+                                 p.keep.ctypes.data_as(nat.c_ubyte_p), _d(p.alpha), _d(p.M), _d(p.V), _d(p.S))
+        nat.check(nat.lib().icp_proposal_posterior(self.h, _d(th), C.byref(view)), "icp_proposal_posterior")
+        k = view.n_candidates
+        p.corr_id, p.corr_aux, p.corr_point, p.keep = p.corr_id[:k], p.corr_aux[:k], p.corr_point[:k], p.keep[:k]
+        if not with_aux:
+            p.corr_aux = np.full(k, -1, dtype=np.int32)
+        return p
+
+
+class _Evaluator:
+    def __init__(self, ctx: IcpContext, kind, mode, n_model_ids, target_pts, gauss_mean, gauss_sigma, exp_rate):
+        self.ctx = ctx
+        tp = _f64(target_pts).reshape(-1, 3) if target_pts is not None else np.zeros((0, 3))
+        prm = nat.EvaluatorParams(kind, mode, int(n_model_ids), tp.shape[0], _d(tp), gauss_mean, gauss_sigma, exp_rate)
+        h = C.c_void_p()
+        nat.check(nat.lib().icp_evaluator_create(ctx.h, C.byref(prm), C.byref(h)), "icp_evaluator_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            nat.lib().icp_evaluator_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def logValue(self, sample, return_aux: bool = False):
+        th = _theta(sample)
+        out = C.c_double()
+        aux = np.zeros(4)
+        nat.check(nat.lib().icp_evaluator_log_value(self.h, _d(th), C.byref(out), _d(aux)), "icp_evaluator_log_value")
+        return (out.value, aux) if return_aux else out.value
+
+
+def _sides(ctx, numberOfPointsForComparison, decimatedTargetPoints, numDecimatedModelPoints):
+    tp = (decimatedTargetPoints if decimatedTargetPoints is not None
+          else _data.decimated_point_subset(ctx.target, numberOfPointsForComparison))
+    k = int(numDecimatedModelPoints if numDecimatedModelPoints is not None else min(numberOfPointsForComparison, ctx.N))
+    return k, tp
+
+
+class IndependentPointDistanceEvaluator(_Evaluator):
+    """IndependentPointDistanceEvaluator.scala:27-31; likelihoodModel = breeze Gaussian(mean, sigma)
+    (ProductEvaluators.scala:39 uses Gaussian(0, uncertainty))."""
+
+    def __init__(self, ctx, likelihoodMean: float, likelihoodSigma: float, evaluationMode, numberOfPointsForComparison: int,
+                 decimatedTargetPoints=None, numDecimatedModelPoints=None):
+        k, tp = _sides(ctx, numberOfPointsForComparison, decimatedTargetPoints, numDecimatedModelPoints)
+        super().__init__(ctx, 0, evaluationMode, k, tp, likelihoodMean, likelihoodSigma, 1.0)
+
+
+class HausdorffDistanceEvaluator(_Evaluator):
+    """HausdorffDistanceEvaluator.scala:25-28; likelihoodModel = breeze Exponential(rate) (ProductEvaluators.scala:58)."""
+
+    def __init__(self, ctx, likelihoodRate: float):
+        super().__init__(ctx, 1, 2, 0, None, 0.0, 1.0, likelihoodRate)
+
+
+class CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator(_Evaluator):
+    """CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:27-32; likelihoodModelAvg = Gaussian(mean, sigma),
+    likelihoodModelMax = Exponential(rate) (ProductEvaluators.scala:77-78)."""
+
+    def __init__(self, ctx, avgMean: float, avgSigma: float, maxRate: float, evaluationMode, numberOfPointsForComparison: int,
+                 decimatedTargetPoints=None, numDecimatedModelPoints=None):
+        k, tp = _sides(ctx, numberOfPointsForComparison, decimatedTargetPoints, numDecimatedModelPoints)
+        super().__init__(ctx, 2, evaluationMode, k, tp, avgMean, avgSigma, maxRate)
+
+
+class ModelPriorEvaluator:
+    """ModelPriorEvaluator.scala:24-31 — MultivariateNormalDistribution(0, I_rank).logpdf(shape coefficients)."""
+
+    def __init__(self, rank: int):
+        self.rank = rank
+
+    def logValue(self, theta) -> float:
+        th = _theta(theta)
+        out = C.c_double()
+        nat.check(nat.lib().icp_prior_log_value(self.rank, _d(th), C.byref(out)), "icp_prior_log_value")
+        return out.value
+
+
+def chain_eval_step(evaluator: _Evaluator, proposals, theta_cur, theta_prop):
+    """icp_chain_eval_step: likelihood of theta_prop + forward/backward transition log-densities of every proposal,
+    one device submission, one synchronisation."""
+    a, b = _theta(theta_cur), _theta(theta_prop)
+    n = len(proposals)
+    arr = (C.c_void_p * max(n, 1))(*[p.h for p in proposals])
+    val = C.c_double()
+    fwd, bwd = np.zeros(max(n, 1)), np.zeros(max(n, 1))
+    nat.check(nat.lib().icp_chain_eval_step(evaluator.h, n, arr, _d(a), _d(b), C.byref(val), _d(fwd), _d(bwd)),
+              "icp_chain_eval_step")
+    return val.value, fwd[:n], bwd[:n]

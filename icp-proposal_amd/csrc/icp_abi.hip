@@ -1,0 +1,1097 @@
+// icp_abi.hip — host side of libicp_proposal_amd.so: the C ABI of include/icp_proposal.h.
+//
+// Owns device memory, the per-context HIP stream, the state / posterior / likelihood caches that stand in
+// for the reference's Memoize wrappers (NonRigidIcpProposal.scala:49, evaluators/EvaluationCaching.scala:32),
+// and the order in which kernels are enqueued.  Every entry point enqueues its whole kernel sequence on the
+// context stream and synchronises ONCE, when results are copied back.  No CPU fallback exists: without a HIP
+// device icp_ctx_create fails.
+#include "../../include/icp_proposal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "icp_kernels.hpp"
+
+using namespace icp;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct IcpError {
+  int code;
+  std::string msg;
+};
+
+[[noreturn]] void fail(int code, const std::string& msg) { throw IcpError{code, msg}; }
+
+#define HIP_OK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) fail(ICP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+template <class T>
+struct DBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DBuf() = default;
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  ~DBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    HIP_OK(hipMalloc((void**)&p, sizeof(T) * (count ? count : 1)));
+  }
+  void upload(const T* src, size_t count) {
+    alloc(count);
+    if (count) HIP_OK(hipMemcpy(p, src, sizeof(T) * count, hipMemcpyHostToDevice));
+  }
+  void fill_bytes(int v) { HIP_OK(hipMemset(p, v, sizeof(T) * (n ? n : 1))); }
+};
+
+constexpr double kSigma2 = 1e-5;  // regularisation of Scalismo's DiscreteLowRankGaussianProcess.coefficients
+constexpr int kStateSlots = 8;
+constexpr int kPosteriorMemo = 20;  // NonRigidIcpProposal.scala:49
+constexpr int kEvalMemo = 3;        // evaluators/EvaluationCaching.scala:32
+constexpr int kMaxRank = 500;
+
+// ---- host-side mesh preprocessing (one-off, at context creation)
+
+void boundary_flags(int V, int T, const int32_t* tris, std::vector<uint8_t>& flags) {
+  std::vector<int64_t> keys(3 * (size_t)T);
+  for (int t = 0; t < T; ++t)
+    for (int e = 0; e < 3; ++e) {
+      int64_t a = tris[3 * t + e], b = tris[3 * t + (e + 1) % 3];
+      if (a > b) std::swap(a, b);
+      keys[3 * (size_t)t + e] = a * (int64_t)V + b;
+    }
+  std::sort(keys.begin(), keys.end());
+  flags.assign(V, 0);
+  for (size_t i = 0; i < keys.size();) {
+    size_t j = i + 1;
+    while (j < keys.size() && keys[j] == keys[i]) ++j;
+    if (j - i == 1) {  // edge owned by exactly one triangle (Scalismo pointIsOnBoundary)
+      flags[keys[i] / V] = 1;
+      flags[keys[i] % V] = 1;
+    }
+    i = j;
+  }
+}
+
+void vertex_adjacency(int V, int T, const int32_t* tris, std::vector<int>& off, std::vector<int>& adj) {
+  off.assign(V + 1, 0);
+  for (int i = 0; i < 3 * T; ++i) off[tris[i] + 1]++;
+  for (int v = 0; v < V; ++v) off[v + 1] += off[v];
+  adj.assign(std::max(3 * T, 1), 0);
+  std::vector<int> fill(V, 0);
+  for (int t = 0; t < T; ++t)
+    for (int e = 0; e < 3; ++e) {
+      int v = tris[3 * t + e];
+      adj[off[v] + fill[v]++] = t;  // ascending triangle id per vertex
+    }
+}
+
+bool host_cholesky(int n, std::vector<double>& a) {
+  for (int j = 0; j < n; ++j) {
+    double s = a[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) s -= a[(size_t)j * n + k] * a[(size_t)j * n + k];
+    if (!(s > 0.0)) return false;
+    double l = std::sqrt(s);
+    a[(size_t)j * n + j] = l;
+    for (int i = j + 1; i < n; ++i) {
+      double v = a[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) v -= a[(size_t)i * n + k] * a[(size_t)j * n + k];
+      a[(size_t)i * n + j] = v / l;
+    }
+  }
+  return true;
+}
+
+void check_triangles(int V, int T, const int32_t* tris, const char* what) {
+  for (int i = 0; i < 3 * T; ++i)
+    if (tris[i] < 0 || tris[i] >= V) fail(ICP_ERR_INVALID_ARG, std::string(what) + ": triangle vertex id out of range");
+}
+
+// Rotation(phi,theta,psi,centre) = Rz(phi)·Ry(theta)·Rx(psi); host libm so every kernel sees
+// the same matrix a CPU evaluation of the reference's transform would use.
+Pose pose_from_theta(const double* th) {
+  Pose p;
+  double phi = th[4], theta = th[5], psi = th[6];
+  double cph = std::cos(phi), sph = std::sin(phi), cth = std::cos(theta), sth = std::sin(theta), cps = std::cos(psi),
+         sps = std::sin(psi);
+  p.R[0] = cth * cph; p.R[1] = sps * sth * cph - cps * sph; p.R[2] = sps * sph + cps * sth * cph;
+  p.R[3] = cth * sph; p.R[4] = cps * cph + sps * sth * sph; p.R[5] = cps * sth * sph - sps * cph;
+  p.R[6] = -sth;      p.R[7] = sps * cth;                   p.R[8] = cps * cth;
+  for (int d = 0; d < 3; ++d) { p.t[d] = th[1 + d]; p.ctr[d] = th[7 + d]; }
+  p.s = th[0];
+  return p;
+}
+
+struct DeviceMesh {
+  int V = 0, T = 0, n_boundary = 0;
+  DBuf<double> verts;
+  DBuf<int> tris;
+  DBuf<double4> spheres;
+  DBuf<uint8_t> boundary;
+};
+
+struct QueryScratch {
+  DBuf<double> thr;
+  DBuf<unsigned long long> best_d2;
+  DBuf<int> best_idx;
+  size_t cap = 0;
+  QueryBuffers get() const { return QueryBuffers{thr.p, best_d2.p, best_idx.p}; }
+};
+
+struct StateSlot {
+  std::vector<double> theta;
+  bool valid = false;
+  uint64_t stamp = 0;
+  Pose pose;
+  DBuf<double> coeffs, x;
+  DBuf<double4> spheres;
+  bool spheres_valid = false;
+  int n_surf = 0;  // model ids [0, n_surf) already projected onto the target surface
+  DBuf<double> surf_cp, surf_d2;
+  DBuf<int> surf_tri;
+  int n_nnv = 0;   // ... and their surface points already matched to the nearest target vertex
+  DBuf<int> surf_nnv;
+};
+
+}  // namespace
+
+struct icp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::recursive_mutex mu;
+  int N = 0, T = 0, r = 0;
+  DBuf<double> ref, mean, Q, Qp, sqrt_lambda, inv_sqrt_lambda, G, Lg;
+  DBuf<int> tris, adj_off, adj;
+  DBuf<uint8_t> boundary;
+  int n_boundary = 0;
+  DeviceMesh target;
+  DBuf<int> hint_surf;  // [N] last target triangle of model id i
+  DBuf<int> hint_nnv;   // [N] last nearest target vertex of that surface point
+  StateSlot slots[kStateSlots];
+  uint64_t clock = 0;
+  QueryScratch scratch;
+  // staging for small host<->device transfers of one API call
+  double* h_stage = nullptr;  // pinned
+  DBuf<double> d_stage;
+  size_t stage_cap = 0, stage_used = 0;
+  double* h_res = nullptr;    // pinned results
+  DBuf<double> d_res;
+  int* h_status = nullptr;
+  DBuf<int> d_status;
+
+  void bind() { HIP_OK(hipSetDevice(device)); }
+
+  QueryBuffers query_scratch(size_t K) {
+    if (K > scratch.cap) {
+      HIP_OK(hipStreamSynchronize(stream));
+      size_t cap = std::max<size_t>(K, 4096);
+      scratch.thr.alloc(cap);
+      scratch.best_d2.alloc(cap);
+      scratch.best_idx.alloc(cap);
+      scratch.cap = cap;
+    }
+    return scratch.get();
+  }
+
+  // copies `count` doubles to the device through the pinned staging area (valid until the call's final sync)
+  const double* stage(const double* src, size_t count) {
+    if (stage_used + count > stage_cap) fail(ICP_ERR_INVALID_ARG, "internal: staging area exhausted");
+    double* h = h_stage + stage_used;
+    double* d = d_stage.p + stage_used;
+    std::memcpy(h, src, sizeof(double) * count);
+    HIP_OK(hipMemcpyAsync(d, h, sizeof(double) * count, hipMemcpyHostToDevice, stream));
+    stage_used += count;
+    return d;
+  }
+
+  void finish(size_t n_res, size_t n_status) {
+    if (n_res) HIP_OK(hipMemcpyAsync(h_res, d_res.p, sizeof(double) * n_res, hipMemcpyDeviceToHost, stream));
+    if (n_status) HIP_OK(hipMemcpyAsync(h_status, d_status.p, sizeof(int) * n_status, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    stage_used = 0;
+  }
+
+  StateSlot& state(const double* theta);
+  void ensure_model_spheres(StateSlot& s);
+  void ensure_surface_prefix(StateSlot& s, int K);
+  void ensure_nnv_prefix(StateSlot& s, int K);
+};
+
+StateSlot& icp_ctx::state(const double* theta) {
+  const size_t P = 10 + (size_t)r;
+  StateSlot* lru = &slots[0];
+  for (auto& s : slots) {
+    if (s.valid && std::memcmp(s.theta.data(), theta, sizeof(double) * P) == 0) {
+      s.stamp = ++clock;
+      return s;
+    }
+    if (!s.valid) { if (lru->valid) lru = &s; }
+    else if (lru->valid && s.stamp < lru->stamp) lru = &s;
+  }
+  StateSlot& s = *lru;
+  if (!s.x.p) {
+    s.coeffs.alloc(r);
+    s.x.alloc(3 * (size_t)N);
+    s.spheres.alloc(T);
+    s.surf_cp.alloc(3 * (size_t)N);
+    s.surf_d2.alloc(N);
+    s.surf_tri.alloc(N);
+    s.surf_nnv.alloc(N);
+  }
+  s.theta.assign(theta, theta + P);
+  s.valid = true;
+  s.stamp = ++clock;
+  s.pose = pose_from_theta(theta);
+  s.spheres_valid = false;
+  s.n_surf = 0;
+  s.n_nnv = 0;
+  const double* dc = stage(theta + 10, r);
+  HIP_OK(hipMemcpyAsync(s.coeffs.p, dc, sizeof(double) * r, hipMemcpyDeviceToDevice, stream));
+  launch_instance(stream, N, r, Qp.p, ref.p, mean.p, s.pose, s.coeffs.p, s.x.p);  // ModelFittingParameters.scala:108-110
+  return s;
+}
+
+void icp_ctx::ensure_model_spheres(StateSlot& s) {
+  if (s.spheres_valid) return;
+  launch_tri_spheres(stream, T, s.x.p, tris.p, s.spheres.p);
+  s.spheres_valid = true;
+}
+
+// target.operations.closestPointOnSurface(currentMesh.point(id)) for id in [0, K) (NonRigidIcpProposal.scala:96-97,
+// IndependentPointDistanceEvaluator.scala:41-43): shared by every proposal / evaluator of this context.
+void icp_ctx::ensure_surface_prefix(StateSlot& s, int K) {
+  if (K > N) fail(ICP_ERR_INVALID_ARG, "model id count exceeds the number of model points");
+  if (K <= s.n_surf) return;
+  const int k0 = s.n_surf, n = K - k0;
+  QueryBuffers qb = query_scratch(n);
+  launch_surface_query(stream, target.T, target.verts.p, target.tris.p, target.spheres.p, n, s.x.p + 3 * (size_t)k0,
+                       hint_surf.p + k0, qb, s.surf_cp.p + 3 * (size_t)k0, s.surf_d2.p + k0, s.surf_tri.p + k0);
+  s.n_surf = K;
+}
+
+// target.pointSet.findClosestPoint(targetPoint).id (NonRigidIcpProposal.scala:98)
+void icp_ctx::ensure_nnv_prefix(StateSlot& s, int K) {
+  ensure_surface_prefix(s, K);
+  if (K <= s.n_nnv) return;
+  const int k0 = s.n_nnv, n = K - k0;
+  QueryBuffers qb = query_scratch(n);
+  launch_vertex_query(stream, target.V, target.verts.p, n, s.surf_cp.p + 3 * (size_t)k0, hint_nnv.p + k0, qb, nullptr,
+                      s.surf_nnv.p + k0);
+  s.n_nnv = K;
+}
+
+namespace {
+
+struct PosteriorEntry {
+  std::vector<double> theta;
+  bool valid = false, eig_valid = false;
+  uint64_t stamp = 0;
+  DBuf<int> id, aux;
+  DBuf<double> pt, nhat, e;
+  DBuf<uint8_t> keep;
+  DBuf<double> coeffs, Maug, M, L, alpha, L2, V, S;
+  int status_off = 0;  // this entry's 3 ints inside the proposal's status buffer
+  CorrBuffers corr() const { return CorrBuffers{id.p, aux.p, pt.p, keep.p, nhat.p, e.p}; }
+};
+
+}  // namespace
+
+struct icp_proposal {
+  icp_ctx* ctx = nullptr;
+  icp_proposal_params prm{};
+  int K = 0;
+  DBuf<double> target_pts;
+  DBuf<int> hint_nn;      // TargetSampling: last nearest model vertex of each target point
+  DBuf<int> nn_id;
+  DBuf<double> work;      // r*r scratch of the eigen kernel
+  DBuf<int> status;       // 3 ints per memo entry: {chol(M), chol(G+σ²M), eigen}
+  std::vector<int> h_status;
+  std::unique_ptr<PosteriorEntry[]> memo;
+  uint64_t clock = 0;
+
+  PosteriorEntry& posterior(const double* theta, bool want_aux);
+  void ensure_eigen(PosteriorEntry& e);
+  void check_status(PosteriorEntry& e);
+};
+
+struct icp_evaluator {
+  icp_ctx* ctx = nullptr;
+  icp_evaluator_params prm{};
+  DBuf<double> target_pts;
+  // target-side queries against the CURRENT model surface
+  int Kt = 0;              // number of target-side query points (decimated target, or all target vertices for Hausdorff)
+  const double* d_tpts = nullptr;
+  DBuf<int> hint_tri, hint_nnv, t2m_tri, t2m_nnv;
+  DBuf<double> t2m_cp, t2m_d2;
+  struct Memo {
+    std::vector<double> theta;
+    bool valid = false;
+    uint64_t stamp = 0;
+    double value = 0.0, aux[4] = {0, 0, 0, 0};
+    int status = 0;
+  } memo[kEvalMemo];
+  uint64_t clock = 0;
+};
+
+namespace {
+
+template <class F>
+int guard(F&& f) {
+  try {
+    f();
+    return ICP_OK;
+  } catch (const IcpError& e) {
+    g_err = e.msg;
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    g_err = "host out of memory";
+    return ICP_ERR_DEVICE;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return ICP_ERR_DEVICE;
+  }
+}
+
+void require(bool ok, const char* msg) {
+  if (!ok) fail(ICP_ERR_INVALID_ARG, msg);
+}
+
+void check_theta_finite(const icp_ctx* ctx, const double* theta) {
+  require(theta != nullptr, "theta is null");
+  for (int i = 0; i < 10 + ctx->r; ++i)
+    if (!std::isfinite(theta[i])) fail(ICP_ERR_NOT_FINITE, "theta contains a non-finite value");
+}
+
+}  // namespace
+
+// ===================================================================== posterior (NonRigidIcpProposal.scala:88-153)
+
+PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
+  icp_ctx& c = *ctx;
+  const int r = c.r;
+  const size_t P = 10 + (size_t)r;
+  PosteriorEntry* lru = &memo[0];
+  for (int i = 0; i < kPosteriorMemo; ++i) {
+    PosteriorEntry& e = memo[i];
+    if (e.valid && std::memcmp(e.theta.data(), theta, sizeof(double) * P) == 0) {
+      e.stamp = ++clock;
+      if (want_aux && prm.direction == ICP_MODEL_SAMPLING) {
+        // diagnostic request for corr_aux on a cached entry: recompute the nearest-vertex ids into it
+        StateSlot& s = c.state(theta);
+        c.ensure_nnv_prefix(s, K);
+        HIP_OK(hipMemcpyAsync(e.aux.p, s.surf_nnv.p, sizeof(int) * K, hipMemcpyDeviceToDevice, c.stream));
+      }
+      return e;
+    }
+    if (!e.valid) { if (lru->valid) lru = &e; }
+    else if (lru->valid && e.stamp < lru->stamp) lru = &e;
+  }
+  PosteriorEntry& e = *lru;
+  const int Ka = std::max(K, 1);
+  if (!e.M.p) {
+    e.id.alloc(Ka); e.aux.alloc(Ka); e.pt.alloc(3 * (size_t)Ka); e.nhat.alloc(3 * (size_t)Ka); e.e.alloc(3 * (size_t)Ka);
+    e.keep.alloc(Ka);
+    e.coeffs.alloc(r); e.Maug.alloc((size_t)(r + 1) * (r + 1)); e.M.alloc((size_t)r * r); e.L.alloc((size_t)r * r);
+    e.alpha.alloc(r); e.L2.alloc((size_t)r * r); e.V.alloc((size_t)r * r); e.S.alloc(r);
+    e.status_off = 3 * (int)(&e - &memo[0]);
+  }
+  e.theta.assign(theta, theta + P);
+  e.valid = true;
+  e.eig_valid = false;
+  e.stamp = ++clock;
+  StateSlot& s = c.state(theta);  // :141 currentMesh
+  HIP_OK(hipMemcpyAsync(e.coeffs.p, s.coeffs.p, sizeof(double) * r, hipMemcpyDeviceToDevice, c.stream));
+  HIP_OK(hipMemsetAsync(status.p + e.status_off, 0, sizeof(int) * 3, c.stream));
+  if (prm.direction == ICP_TARGET_SAMPLING) {
+    // :117-118 nearest vertex of the current mesh for every decimated-target point
+    QueryBuffers qb = c.query_scratch(K);
+    launch_vertex_query(c.stream, c.N, s.x.p, K, target_pts.p, hint_nn.p, qb, nullptr, nn_id.p);
+    launch_correspond_target(c.stream, K, s.x.p, target_pts.p, nn_id.p, c.boundary.p, prm.boundary_aware, s.pose, c.ref.p,
+                             c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, e.corr());
+  } else {
+    // :94-99 closest surface point of the target for model ids 0 until K; nearest target vertex only when the
+    // boundary test can change anything (the target has boundary vertices) or the caller asked for it
+    c.ensure_surface_prefix(s, K);
+    const bool need_nnv = want_aux || (prm.boundary_aware && c.target.n_boundary > 0);
+    if (need_nnv) c.ensure_nnv_prefix(s, K);
+    launch_correspond_model(c.stream, K, s.x.p, s.surf_cp.p, need_nnv ? s.surf_nnv.p : nullptr, c.target.boundary.p,
+                            prm.boundary_aware, s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, e.corr());
+  }
+  // :152 interpolatedModel.posterior(uncertainDisplacements)
+  const double wt = 1.0 / (prm.tangential_noise * prm.tangential_noise);
+  const double kappa = 1.0 / (prm.noise_along_normal * prm.noise_along_normal) - wt;
+  launch_regression(c.stream, K, r, c.Q.p, e.corr(), wt, kappa, e.Maug.p);
+  launch_posterior_factor(c.stream, r, e.Maug.p, c.G.p, kSigma2, e.M.p, e.L.p, e.alpha.p, e.L2.p, status.p + e.status_off);
+  return e;
+}
+
+void icp_proposal::ensure_eigen(PosteriorEntry& e) {
+  if (e.eig_valid) return;
+  icp_ctx& c = *ctx;
+  launch_posterior_eigen(c.stream, c.r, e.M.p, c.sqrt_lambda.p, e.V.p, e.S.p, work.p, status.p + e.status_off + 2);
+  e.eig_valid = true;
+}
+
+// must be called after a synchronising copy of `status` into h_status
+void icp_proposal::check_status(PosteriorEntry& e) {
+  const int* st = h_status.data() + e.status_off;
+  if (st[0] || st[1]) {
+    e.valid = false;
+    fail(ICP_ERR_NOT_SPD, "posterior normal equations are not positive definite (non-finite correspondences?)");
+  }
+  if (st[2]) {
+    e.eig_valid = false;
+    fail(ICP_ERR_NOT_FINITE, "posterior eigen-decomposition did not converge");
+  }
+}
+
+namespace {
+
+void sync_proposal_status(icp_proposal* p) {
+  icp_ctx& c = *p->ctx;
+  HIP_OK(hipMemcpyAsync(p->h_status.data(), p->status.p, sizeof(int) * 3 * kPosteriorMemo, hipMemcpyDeviceToHost, c.stream));
+}
+
+// ===================================================================== evaluators
+
+// enqueue everything logValue(theta) needs; partial results land in d_res[base .. base+8)
+void enqueue_eval(icp_evaluator* ev, StateSlot& s, int base) {
+  icp_ctx& c = *ev->ctx;
+  const icp_evaluator_params& p = ev->prm;
+  double* out = c.d_res.p + base;
+  HIP_OK(hipMemsetAsync(out, 0, sizeof(double) * 8, c.stream));
+  const bool m2t = p.kind == ICP_EVAL_HAUSDORFF || p.mode != ICP_TARGET_TO_MODEL;
+  const bool t2m = p.kind == ICP_EVAL_HAUSDORFF || p.mode != ICP_MODEL_TO_TARGET;
+  const int Km = p.kind == ICP_EVAL_HAUSDORFF ? c.N : p.n_model_ids;
+  if (m2t) {
+    c.ensure_surface_prefix(s, Km);
+    if (p.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE) {
+      launch_sum_gauss_logpdf(c.stream, Km, s.surf_d2.p, p.gauss_mean, p.gauss_sigma, out + 0);  // IndependentPointDistanceEvaluator.scala:40-46
+    } else if (p.kind == ICP_EVAL_HAUSDORFF) {
+      launch_dist_stats(c.stream, Km, s.surf_d2.p, nullptr, nullptr, 0, out + 0);
+    } else {
+      const bool flags = c.target.n_boundary > 0;  // Collective…Evaluator.scala:44-48
+      if (flags) c.ensure_nnv_prefix(s, Km);
+      launch_dist_stats(c.stream, Km, s.surf_d2.p, flags ? c.target.boundary.p : nullptr, flags ? s.surf_nnv.p : nullptr,
+                        c.target.V, out + 0);
+    }
+  }
+  if (t2m) {
+    const int Kt = ev->Kt;
+    c.ensure_model_spheres(s);
+    QueryBuffers qb = c.query_scratch(Kt);
+    launch_surface_query(c.stream, c.T, s.x.p, c.tris.p, s.spheres.p, Kt, ev->d_tpts, ev->hint_tri.p, qb, ev->t2m_cp.p,
+                         ev->t2m_d2.p, ev->t2m_tri.p);
+    if (p.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE) {
+      launch_sum_gauss_logpdf(c.stream, Kt, ev->t2m_d2.p, p.gauss_mean, p.gauss_sigma, out + 4);  // :49-54
+    } else if (p.kind == ICP_EVAL_HAUSDORFF) {
+      launch_dist_stats(c.stream, Kt, ev->t2m_d2.p, nullptr, nullptr, 0, out + 4);
+    } else {
+      // Collective…Evaluator.scala:56-60: nearest MODEL-sample vertex of the surface point, tested against the
+      // TARGET's boundary flags (sic); ids beyond the target's vertex count count as interior.
+      const bool flags = c.target.n_boundary > 0;
+      if (flags) {
+        QueryBuffers qb2 = c.query_scratch(Kt);
+        launch_vertex_query(c.stream, c.N, s.x.p, Kt, ev->t2m_cp.p, ev->hint_nnv.p, qb2, nullptr, ev->t2m_nnv.p);
+      }
+      launch_dist_stats(c.stream, Kt, ev->t2m_d2.p, flags ? c.target.boundary.p : nullptr, flags ? ev->t2m_nnv.p : nullptr,
+                        c.target.V, out + 4);
+    }
+  }
+}
+
+double gauss_logpdf(double x, double mu, double sigma) {  // Breeze Gaussian.logPdf
+  double d = (x - mu) / sigma;
+  return -d * d / 2.0 - (std::log(std::sqrt(2.0 * M_PI)) + std::log(sigma));
+}
+double expo_logpdf(double x, double rate) { return -rate * x + std::log(rate); }  // Breeze Exponential.logPdf
+
+// combine the partial reductions exactly as the reference's computeLogValue does
+int finish_eval(const icp_evaluator* ev, const double* res, double* value, double* aux) {
+  const icp_evaluator_params& p = ev->prm;
+  int status = ICP_OK;
+  aux[0] = aux[1] = aux[2] = aux[3] = 0.0;
+  if (p.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE) {
+    double m2t = res[0], t2m = res[4];
+    aux[0] = m2t; aux[1] = t2m;
+    *value = p.mode == ICP_MODEL_TO_TARGET ? m2t : p.mode == ICP_TARGET_TO_MODEL ? t2m : 0.5 * m2t + 0.5 * t2m;  // :60-64
+  } else if (p.kind == ICP_EVAL_HAUSDORFF) {
+    double hd = std::max(res[1], res[5]);
+    aux[0] = hd; aux[1] = res[1]; aux[2] = res[5];
+    *value = expo_logpdf(hd, p.exp_rate);  // HausdorffDistanceEvaluator.scala:33-34
+  } else {
+    double a, h;
+    const double a0 = res[0] / res[2], h0 = res[1], a1 = res[4] / res[6], h1 = res[5];
+    if (p.mode == ICP_MODEL_TO_TARGET) { a = a0; h = h0; if (res[2] == 0.0) status = ICP_ERR_EMPTY; }
+    else if (p.mode == ICP_TARGET_TO_MODEL) { a = a1; h = h1; if (res[6] == 0.0) status = ICP_ERR_EMPTY; }
+    else {
+      a = 0.5 * a0 + 0.5 * a1; h = std::max(h0, h1);  // :71-75
+      if (res[2] == 0.0 || res[6] == 0.0) status = ICP_ERR_EMPTY;
+    }
+    aux[0] = a; aux[1] = h; aux[2] = res[2]; aux[3] = res[6];
+    *value = gauss_logpdf(a, p.gauss_mean, p.gauss_sigma) + expo_logpdf(h, p.exp_rate);  // :77
+  }
+  if (status == ICP_OK && std::isnan(*value)) status = ICP_ERR_NOT_FINITE;
+  return status;
+}
+
+icp_evaluator::Memo* eval_lookup(icp_evaluator* ev, const double* theta) {
+  const size_t P = 10 + (size_t)ev->ctx->r;
+  for (auto& m : ev->memo)
+    if (m.valid && std::memcmp(m.theta.data(), theta, sizeof(double) * P) == 0) {
+      m.stamp = ++ev->clock;
+      return &m;
+    }
+  return nullptr;
+}
+
+icp_evaluator::Memo* eval_store(icp_evaluator* ev, const double* theta) {
+  const size_t P = 10 + (size_t)ev->ctx->r;
+  icp_evaluator::Memo* lru = &ev->memo[0];
+  for (auto& m : ev->memo) {
+    if (!m.valid) { lru = &m; break; }
+    if (m.stamp < lru->stamp) lru = &m;
+  }
+  lru->theta.assign(theta, theta + P);
+  lru->valid = true;
+  lru->stamp = ++ev->clock;
+  return lru;
+}
+
+bool pose_equal(const double* a, const double* b) {  // NonRigidIcpProposal.scala:72: everything but the shape must match
+  for (int i = 0; i < 10; ++i)
+    if (a[i] != b[i]) return false;
+  return true;
+}
+
+}  // namespace
+
+// ===================================================================== C ABI
+
+extern "C" {
+
+const char* icp_status_string(int status) {
+  switch (status) {
+    case ICP_OK: return "ok";
+    case ICP_ERR_INVALID_ARG: return "invalid argument";
+    case ICP_ERR_DEVICE: return "HIP device error";
+    case ICP_ERR_NOT_FINITE: return "non-finite result";
+    case ICP_ERR_NOT_SPD: return "matrix not positive definite";
+    case ICP_ERR_EMPTY: return "no points left after the boundary filter";
+    default: return "unknown status";
+  }
+}
+
+const char* icp_last_error(void) { return g_err.c_str(); }
+
+int icp_ctx_rank(const icp_ctx* ctx) { return ctx ? ctx->r : ICP_ERR_INVALID_ARG; }
+int icp_ctx_device(const icp_ctx* ctx) { return ctx ? ctx->device : ICP_ERR_INVALID_ARG; }
+
+int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int device, icp_ctx** out) {
+  if (out) *out = nullptr;
+  icp_ctx* ctx = nullptr;
+  int rc = guard([&] {
+    require(model && target && out, "null argument");
+    require(model->n_points > 0 && model->n_triangles >= 0 && model->rank > 0 && model->rank <= kMaxRank,
+            "model sizes out of range (rank must be in [1,500])");
+    require(model->ref_points && model->basis && model->variance && (model->triangles || model->n_triangles == 0),
+            "model arrays missing");
+    require(target->n_points > 0 && target->n_triangles >= 0 && target->points &&
+                (target->triangles || target->n_triangles == 0),
+            "target arrays missing");
+    const int N = model->n_points, T = model->n_triangles, r = model->rank;
+    check_triangles(N, T, model->triangles, "model");
+    check_triangles(target->n_points, target->n_triangles, target->triangles, "target");
+    for (int j = 0; j < r; ++j) require(model->variance[j] > 0.0 && std::isfinite(model->variance[j]), "variance must be positive");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+      fail(ICP_ERR_DEVICE, std::string("no usable HIP device (this library has no CPU fallback): ") + hipGetErrorString(e));
+    if (device < 0) {
+      const char* lr = std::getenv("LOCAL_RANK");
+      device = lr ? std::atoi(lr) % ndev : 0;
+    }
+    require(device < ndev, "device ordinal out of range");
+
+    ctx = new icp_ctx();
+    ctx->device = device;
+    ctx->N = N; ctx->T = T; ctx->r = r;
+    ctx->bind();
+    HIP_OK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+
+    // ---- model: Q = Φ·diag(√λ) in two layouts, Gram matrix G = QᵀQ and chol(G + σ²I) (one-off host work)
+    std::vector<double> Q((size_t)3 * N * r), Qp((size_t)3 * N * r), sl(r), isl(r);
+    for (int j = 0; j < r; ++j) { sl[j] = std::sqrt(model->variance[j]); isl[j] = 1.0 / sl[j]; }
+    for (size_t row = 0; row < (size_t)3 * N; ++row)
+      for (int j = 0; j < r; ++j) {
+        double q = model->basis[row * r + j] * sl[j];
+        Q[row * r + j] = q;
+        size_t i = row / 3, d = row % 3;
+        Qp[((size_t)j * 3 + d) * N + i] = q;
+      }
+    std::vector<double> G((size_t)r * r, 0.0);
+    for (size_t row = 0; row < (size_t)3 * N; ++row) {
+      const double* q = &Q[row * r];
+      for (int a = 0; a < r; ++a) {
+        double qa = q[a];
+        double* g = &G[(size_t)a * r];
+        for (int b = 0; b <= a; ++b) g[b] += qa * q[b];
+      }
+    }
+    for (int a = 0; a < r; ++a)
+      for (int b = a + 1; b < r; ++b) G[(size_t)a * r + b] = G[(size_t)b * r + a];
+    std::vector<double> Lg = G;
+    for (int a = 0; a < r; ++a) Lg[(size_t)a * r + a] += kSigma2;
+    if (!host_cholesky(r, Lg)) fail(ICP_ERR_NOT_SPD, "Q^T Q + sigma^2 I is not positive definite");
+    std::vector<double> mean((size_t)3 * N, 0.0);
+    if (model->mean_deformation) std::memcpy(mean.data(), model->mean_deformation, sizeof(double) * 3 * N);
+    std::vector<uint8_t> mb;
+    boundary_flags(N, T, model->triangles, mb);
+    std::vector<int> off, adj;
+    vertex_adjacency(N, T, model->triangles, off, adj);
+    ctx->n_boundary = (int)std::count(mb.begin(), mb.end(), (uint8_t)1);
+
+    ctx->ref.upload(model->ref_points, (size_t)3 * N);
+    ctx->mean.upload(mean.data(), mean.size());
+    ctx->Q.upload(Q.data(), Q.size());
+    ctx->Qp.upload(Qp.data(), Qp.size());
+    ctx->sqrt_lambda.upload(sl.data(), r);
+    ctx->inv_sqrt_lambda.upload(isl.data(), r);
+    ctx->G.upload(G.data(), G.size());
+    ctx->Lg.upload(Lg.data(), Lg.size());
+    ctx->tris.upload(model->triangles, (size_t)3 * T);
+    ctx->adj_off.upload(off.data(), off.size());
+    ctx->adj.upload(adj.data(), adj.size());
+    ctx->boundary.upload(mb.data(), mb.size());
+
+    // ---- target (static): vertices, triangles, boundary flags, bounding spheres
+    DeviceMesh& tg = ctx->target;
+    tg.V = target->n_points; tg.T = target->n_triangles;
+    std::vector<uint8_t> tb;
+    boundary_flags(tg.V, tg.T, target->triangles, tb);
+    tg.n_boundary = (int)std::count(tb.begin(), tb.end(), (uint8_t)1);
+    tg.verts.upload(target->points, (size_t)3 * tg.V);
+    tg.tris.upload(target->triangles, (size_t)3 * tg.T);
+    tg.boundary.upload(tb.data(), tb.size());
+    tg.spheres.alloc(tg.T);
+    launch_tri_spheres(ctx->stream, tg.T, tg.verts.p, tg.tris.p, tg.spheres.p);
+
+    ctx->hint_surf.alloc(N); ctx->hint_surf.fill_bytes(0xFF);
+    ctx->hint_nnv.alloc(N); ctx->hint_nnv.fill_bytes(0xFF);
+    ctx->stage_cap = 64 * (size_t)(10 + r) + 4096;
+    HIP_OK(hipHostMalloc((void**)&ctx->h_stage, sizeof(double) * ctx->stage_cap, hipHostMallocDefault));
+    ctx->d_stage.alloc(ctx->stage_cap);
+    const size_t res_cap = std::max<size_t>(1024, 3 * (size_t)N + 64);
+    HIP_OK(hipHostMalloc((void**)&ctx->h_res, sizeof(double) * res_cap, hipHostMallocDefault));
+    ctx->d_res.alloc(res_cap);
+    HIP_OK(hipHostMalloc((void**)&ctx->h_status, sizeof(int) * 64, hipHostMallocDefault));
+    ctx->d_status.alloc(64);
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    *out = ctx;
+  });
+  if (rc != ICP_OK && ctx) {
+    icp_ctx_destroy(ctx);
+  }
+  return rc;
+}
+
+void icp_ctx_destroy(icp_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+  if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+  delete ctx;
+}
+
+int icp_transformed_mesh(icp_ctx* ctx, const double* theta, double* points_out) {
+  return guard([&] {
+    require(ctx && points_out, "null argument");
+    check_theta_finite(ctx, theta);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->bind();
+    StateSlot& s = ctx->state(theta);
+    HIP_OK(hipMemcpyAsync(points_out, s.x.p, sizeof(double) * 3 * ctx->N, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->finish(0, 0);
+  });
+}
+
+int icp_vertex_normals(icp_ctx* ctx, const double* theta, double* normals_out) {
+  return guard([&] {
+    require(ctx && normals_out, "null argument");
+    check_theta_finite(ctx, theta);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->bind();
+    StateSlot& s = ctx->state(theta);
+    DBuf<double> nrm;
+    nrm.alloc(3 * (size_t)ctx->N);
+    launch_vertex_normals(ctx->stream, ctx->N, s.x.p, ctx->tris.p, ctx->adj_off.p, ctx->adj.p, nrm.p);
+    HIP_OK(hipMemcpyAsync(normals_out, nrm.p, sizeof(double) * 3 * ctx->N, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->finish(0, 0);
+  });
+}
+
+namespace {
+// shared body of the four stand-alone search entry points
+void run_search(icp_ctx* ctx, bool surface, int V, int T, const double* verts, const int* tris, const double4* spheres,
+                int32_t n, const double* queries, double* points_out, int32_t* index_out, double* dist2_out) {
+  require(n >= 0 && (queries || n == 0), "bad query array");
+  if (n == 0) return;
+  DBuf<double> q, cp, d2;
+  DBuf<int> idx;
+  q.upload(queries, 3 * (size_t)n);
+  cp.alloc(3 * (size_t)n);
+  d2.alloc(n);
+  idx.alloc(n);
+  QueryBuffers qb = ctx->query_scratch(n);
+  if (surface) launch_surface_query(ctx->stream, T, verts, tris, spheres, n, q.p, nullptr, qb, cp.p, d2.p, idx.p);
+  else launch_vertex_query(ctx->stream, V, verts, n, q.p, nullptr, qb, d2.p, idx.p);
+  if (points_out && surface) HIP_OK(hipMemcpyAsync(points_out, cp.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (index_out) HIP_OK(hipMemcpyAsync(index_out, idx.p, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (dist2_out) HIP_OK(hipMemcpyAsync(dist2_out, d2.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->finish(0, 0);
+}
+}  // namespace
+
+int icp_closest_point_on_target(icp_ctx* ctx, int32_t n, const double* queries, double* points_out, int32_t* triangle_out,
+                                double* dist2_out) {
+  return guard([&] {
+    require(ctx, "null context");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->bind();
+    const DeviceMesh& t = ctx->target;
+    run_search(ctx, true, t.V, t.T, t.verts.p, t.tris.p, t.spheres.p, n, queries, points_out, triangle_out, dist2_out);
+  });
+}
+
+int icp_closest_target_vertex(icp_ctx* ctx, int32_t n, const double* queries, int32_t* id_out, double* dist2_out) {
+  return guard([&] {
+    require(ctx, "null context");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->bind();
+    const DeviceMesh& t = ctx->target;
+    run_search(ctx, false, t.V, t.T, t.verts.p, t.tris.p, t.spheres.p, n, queries, nullptr, id_out, dist2_out);
+  });
+}
+
+int icp_closest_model_vertex(icp_ctx* ctx, const double* theta, int32_t n, const double* queries, int32_t* id_out,
+                             double* dist2_out) {
+  return guard([&] {
+    require(ctx, "null context");
+    check_theta_finite(ctx, theta);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->bind();
+    StateSlot& s = ctx->state(theta);
+    run_search(ctx, false, ctx->N, ctx->T, s.x.p, ctx->tris.p, nullptr, n, queries, nullptr, id_out, dist2_out);
+  });
+}
+
+int icp_closest_point_on_model(icp_ctx* ctx, const double* theta, int32_t n, const double* queries, double* points_out,
+                               int32_t* triangle_out, double* dist2_out) {
+  return guard([&] {
+    require(ctx, "null context");
+    check_theta_finite(ctx, theta);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->bind();
+    StateSlot& s = ctx->state(theta);
+    ctx->ensure_model_spheres(s);
+    run_search(ctx, true, ctx->N, ctx->T, s.x.p, ctx->tris.p, s.spheres.p, n, queries, points_out, triangle_out, dist2_out);
+  });
+}
+
+// --------------------------------------------------------------------- proposal
+
+int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_proposal** out) {
+  if (out) *out = nullptr;
+  icp_proposal* p = nullptr;
+  int rc = guard([&] {
+    require(ctx && params && out, "null argument");
+    require(params->direction == ICP_MODEL_SAMPLING || params->direction == ICP_TARGET_SAMPLING, "unknown direction");
+    require(params->step_length != 0.0 && std::isfinite(params->step_length), "step_length must be finite and non-zero");
+    require(params->tangential_noise > 0.0 && params->noise_along_normal > 0.0, "noise standard deviations must be positive");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->bind();
+    p = new icp_proposal();
+    p->ctx = ctx;
+    p->prm = *params;
+    if (params->direction == ICP_TARGET_SAMPLING) {
+      require(params->n_target_points >= 0 && (params->target_points || params->n_target_points == 0), "bad target points");
+      p->K = params->n_target_points;
+      p->target_pts.upload(params->target_points, 3 * (size_t)p->K);
+      p->hint_nn.alloc(std::max(p->K, 1));
+      p->hint_nn.fill_bytes(0xFF);
+      p->nn_id.alloc(std::max(p->K, 1));
+    } else {
+      require(params->n_model_ids >= 0 && params->n_model_ids <= ctx->N, "n_model_ids out of range");
+      p->K = params->n_model_ids;
+    }
+    p->prm.target_points = nullptr;  // caller memory is not retained
+    p->work.alloc((size_t)ctx->r * ctx->r);
+    p->status.alloc(3 * kPosteriorMemo);
+    p->status.fill_bytes(0);
+    p->h_status.assign(3 * kPosteriorMemo, 0);
+    p->memo.reset(new PosteriorEntry[kPosteriorMemo]);
+    *out = p;
+  });
+  if (rc != ICP_OK && p) delete p;
+  return rc;
+}
+
+void icp_proposal_destroy(icp_proposal* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    delete p;
+  }
+}
+
+int icp_proposal_num_candidates(const icp_proposal* p) { return p ? p->K : ICP_ERR_INVALID_ARG; }
+
+int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, double* theta_out, int32_t* corr_id_out) {
+  return guard([&] {
+    require(p && z && theta_out, "null argument");
+    icp_ctx& c = *p->ctx;
+    check_theta_finite(&c, theta);
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    c.bind();
+    const int r = c.r;
+    PosteriorEntry& e = p->posterior(theta, false);  // NonRigidIcpProposal.scala:54
+    p->ensure_eigen(e);
+    const double* dz = c.stage(z, r);                 // :55 the caller's standard normals
+    launch_propose(c.stream, r, e.alpha.p, e.V.p, e.S.p, c.inv_sqrt_lambda.p, c.G.p, c.Lg.p, e.coeffs.p, dz,
+                   p->prm.step_length, c.d_res.p);
+    std::vector<int> ids;
+    std::vector<uint8_t> keep;
+    if (corr_id_out && p->K > 0) {
+      ids.resize(p->K);
+      keep.resize(p->K);
+      HIP_OK(hipMemcpyAsync(ids.data(), e.id.p, sizeof(int) * p->K, hipMemcpyDeviceToHost, c.stream));
+      HIP_OK(hipMemcpyAsync(keep.data(), e.keep.p, p->K, hipMemcpyDeviceToHost, c.stream));
+    }
+    sync_proposal_status(p);
+    c.finish(r, 0);
+    p->check_status(e);
+    std::memcpy(theta_out, theta, sizeof(double) * 10);
+    for (int j = 0; j < r; ++j) {
+      if (!std::isfinite(c.h_res[j])) fail(ICP_ERR_NOT_FINITE, "proposed coefficients are not finite");
+      theta_out[10 + j] = c.h_res[j];
+    }
+    if (corr_id_out)
+      for (int k = 0; k < p->K; ++k) corr_id_out[k] = keep[k] ? ids[k] : -1;
+  });
+}
+
+int icp_proposal_log_transition(icp_proposal* p, const double* theta_from, const double* theta_to, double* out) {
+  return guard([&] {
+    require(p && out, "null argument");
+    icp_ctx& c = *p->ctx;
+    check_theta_finite(&c, theta_from);
+    check_theta_finite(&c, theta_to);
+    if (!pose_equal(theta_from, theta_to)) {  // NonRigidIcpProposal.scala:72-74
+      *out = -INFINITY;
+      return;
+    }
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    c.bind();
+    PosteriorEntry& e = p->posterior(theta_from, false);  // :76
+    const double* dto = c.stage(theta_to + 10, c.r);
+    launch_transition_tail(c.stream, c.r, e.alpha.p, e.M.p, e.L2.p, c.G.p, e.coeffs.p, dto, p->prm.step_length, c.d_res.p);
+    sync_proposal_status(p);
+    c.finish(1, 0);
+    p->check_status(e);
+    if (std::isnan(c.h_res[0])) fail(ICP_ERR_NOT_FINITE, "NaN transition probability");
+    *out = c.h_res[0];
+  });
+}
+
+int icp_proposal_posterior(icp_proposal* p, const double* theta, icp_posterior_view* view) {
+  return guard([&] {
+    require(p && view, "null argument");
+    icp_ctx& c = *p->ctx;
+    check_theta_finite(&c, theta);
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    c.bind();
+    const int r = c.r, K = p->K;
+    PosteriorEntry& e = p->posterior(theta, view->corr_aux != nullptr);
+    if (view->V || view->S) p->ensure_eigen(e);
+    view->n_candidates = K;
+    auto d2h = [&](void* dst, const void* src, size_t bytes) {
+      if (dst && bytes) HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
+    };
+    d2h(view->corr_id, e.id.p, sizeof(int) * K);
+    d2h(view->corr_aux, e.aux.p, sizeof(int) * K);
+    d2h(view->corr_point, e.pt.p, sizeof(double) * 3 * K);
+    d2h(view->keep, e.keep.p, K);
+    d2h(view->alpha, e.alpha.p, sizeof(double) * r);
+    d2h(view->M, e.M.p, sizeof(double) * r * r);
+    d2h(view->V, e.V.p, sizeof(double) * r * r);
+    d2h(view->S, e.S.p, sizeof(double) * r);
+    sync_proposal_status(p);
+    c.finish(0, 0);
+    p->check_status(e);
+  });
+}
+
+// --------------------------------------------------------------------- evaluators
+
+int icp_evaluator_create(icp_ctx* ctx, const icp_evaluator_params* params, icp_evaluator** out) {
+  if (out) *out = nullptr;
+  icp_evaluator* ev = nullptr;
+  int rc = guard([&] {
+    require(ctx && params && out, "null argument");
+    require(params->kind >= 0 && params->kind <= 2, "unknown evaluator kind");
+    require(params->kind == ICP_EVAL_HAUSDORFF || (params->mode >= 0 && params->mode <= 2), "unknown evaluation mode");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->bind();
+    ev = new icp_evaluator();
+    ev->ctx = ctx;
+    ev->prm = *params;
+    if (params->kind == ICP_EVAL_HAUSDORFF) {
+      require(params->exp_rate > 0.0, "exp_rate must be positive");
+      ev->Kt = ctx->target.V;  // MeshMetrics.hausdorffDistance: every target vertex against the model surface
+      ev->d_tpts = ctx->target.verts.p;
+    } else {
+      require(params->gauss_sigma > 0.0, "gauss_sigma must be positive");
+      require(params->kind != ICP_EVAL_COLLECTIVE_AVG_HAUSDORFF_BOUNDARY_AWARE || params->exp_rate > 0.0, "exp_rate must be positive");
+      require(params->n_model_ids >= 0 && params->n_model_ids <= ctx->N, "n_model_ids out of range");
+      require(params->n_target_points >= 0 && (params->target_points || params->n_target_points == 0), "bad target points");
+      ev->Kt = params->n_target_points;
+      ev->target_pts.upload(params->target_points, 3 * (size_t)ev->Kt);
+      ev->d_tpts = ev->target_pts.p;
+    }
+    ev->prm.target_points = nullptr;
+    const size_t Ka = std::max(ev->Kt, 1);
+    ev->hint_tri.alloc(Ka); ev->hint_tri.fill_bytes(0xFF);
+    ev->hint_nnv.alloc(Ka); ev->hint_nnv.fill_bytes(0xFF);
+    ev->t2m_tri.alloc(Ka); ev->t2m_nnv.alloc(Ka);
+    ev->t2m_cp.alloc(3 * Ka); ev->t2m_d2.alloc(Ka);
+    *out = ev;
+  });
+  if (rc != ICP_OK && ev) delete ev;
+  return rc;
+}
+
+void icp_evaluator_destroy(icp_evaluator* e) {
+  if (!e) return;
+  std::lock_guard<std::recursive_mutex> lk(e->ctx->mu);
+  (void)hipSetDevice(e->ctx->device);
+  (void)hipStreamSynchronize(e->ctx->stream);
+  delete e;
+}
+
+int icp_evaluator_log_value(icp_evaluator* e, const double* theta, double* out, double* aux) {
+  int status = ICP_OK;
+  int rc = guard([&] {
+    require(e && out, "null argument");
+    icp_ctx& c = *e->ctx;
+    check_theta_finite(&c, theta);
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    c.bind();
+    icp_evaluator::Memo* m = eval_lookup(e, theta);  // evaluators/EvaluationCaching.scala:32-36
+    if (!m) {
+      StateSlot& s = c.state(theta);
+      enqueue_eval(e, s, 0);
+      c.finish(8, 0);
+      m = eval_store(e, theta);
+      m->status = finish_eval(e, c.h_res, &m->value, m->aux);
+    }
+    *out = m->value;
+    if (aux) std::memcpy(aux, m->aux, sizeof(double) * 4);
+    status = m->status;
+    if (status != ICP_OK) g_err = icp_status_string(status);
+  });
+  return rc != ICP_OK ? rc : status;
+}
+
+int icp_prior_log_value(int32_t rank, const double* theta, double* out) {
+  return guard([&] {
+    require(rank > 0 && theta && out, "bad argument");
+    double nn = 0.0;
+    for (int j = 0; j < rank; ++j) nn += theta[10 + j] * theta[10 + j];
+    *out = -0.5 * nn - 0.5 * rank * std::log(2.0 * M_PI);  // MultivariateNormalDistribution(0, I).logpdf
+  });
+}
+
+// --------------------------------------------------------------------- fused chain step
+
+int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, const double* theta_cur,
+                        const double* theta_prop, double* log_value_prop, double* fwd, double* bwd) {
+  int status = ICP_OK;
+  int rc = guard([&] {
+    require(e && theta_cur && theta_prop && log_value_prop, "null argument");
+    require(n_props >= 0 && n_props <= 8 && (n_props == 0 || (props && fwd && bwd)), "bad proposal list");
+    icp_ctx& c = *e->ctx;
+    for (int i = 0; i < n_props; ++i) require(props[i] && props[i]->ctx == &c, "proposal belongs to another context");
+    check_theta_finite(&c, theta_cur);
+    check_theta_finite(&c, theta_prop);
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    c.bind();
+    const int r = c.r;
+    icp_evaluator::Memo* m = eval_lookup(e, theta_prop);
+    const bool need_eval = m == nullptr;
+    if (need_eval) {
+      StateSlot& s = c.state(theta_prop);
+      enqueue_eval(e, s, 0);
+    }
+    const bool shape_only = pose_equal(theta_cur, theta_prop);
+    PosteriorEntry* ec[8];
+    PosteriorEntry* ep[8];
+    if (shape_only && n_props > 0) {
+      const double* d_cur = c.stage(theta_cur + 10, r);
+      const double* d_prop = c.stage(theta_prop + 10, r);
+      for (int i = 0; i < n_props; ++i) {
+        icp_proposal* p = props[i];
+        ec[i] = &p->posterior(theta_cur, false);
+        ep[i] = &p->posterior(theta_prop, false);
+        launch_transition_tail(c.stream, r, ec[i]->alpha.p, ec[i]->M.p, ec[i]->L2.p, c.G.p, d_cur, d_prop, p->prm.step_length,
+                               c.d_res.p + 8 + 2 * i);
+        launch_transition_tail(c.stream, r, ep[i]->alpha.p, ep[i]->M.p, ep[i]->L2.p, c.G.p, d_prop, d_cur, p->prm.step_length,
+                               c.d_res.p + 9 + 2 * i);
+        sync_proposal_status(p);
+      }
+    }
+    c.finish(8 + 2 * (size_t)n_props, 0);
+    if (need_eval) {
+      m = eval_store(e, theta_prop);
+      m->status = finish_eval(e, c.h_res, &m->value, m->aux);
+    }
+    *log_value_prop = m->value;
+    status = m->status;
+    for (int i = 0; i < n_props; ++i) {
+      if (!shape_only) { fwd[i] = -INFINITY; bwd[i] = -INFINITY; continue; }
+      props[i]->check_status(*ec[i]);
+      props[i]->check_status(*ep[i]);
+      fwd[i] = c.h_res[8 + 2 * i];
+      bwd[i] = c.h_res[9 + 2 * i];
+      if (std::isnan(fwd[i]) || std::isnan(bwd[i])) fail(ICP_ERR_NOT_FINITE, "NaN transition probability");
+    }
+  });
+  return rc != ICP_OK ? rc : status;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// icp_kernels.hpp — host-callable launchers of the HIP kernels (all asynchronous on the given stream).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "icp_device.hpp"
+
+namespace icp {
+
+// ---- geometry (kernels_geometry.hip)
+
+// K1: x = s(R(x̄ + μ + Q c − ctr) + ctr + t).  Qp = scaled basis in planes [(j*3+d)*N + i]; coeffs on device.
+void launch_instance(hipStream_t st, int N, int r, const double* Qp, const double* ref, const double* mean,
+                     const Pose& pose, const double* coeffs, double* x);
+
+// K2: all vertex normals (diagnostic entry point; the posterior kernels compute normals on demand)
+void launch_vertex_normals(hipStream_t st, int N, const double* x, const int* tris, const int* adj_off,
+                           const int* adj, double* normals);
+
+// bounding sphere (centroid, inflated max corner distance) of every triangle: spheres[t] = {cx,cy,cz,R}
+void launch_tri_spheres(hipStream_t st, int T, const double* verts, const int* tris, double4* spheres);
+
+// One brute-force query batch against a triangle mesh or a vertex set.  `hint` carries the previous winner of
+// each query (any valid index gives a valid upper bound; kNoIndex/-1 = none) and receives the new winner.
+struct QueryBuffers {
+  double* thr;                 // [K] pruning bound (surface: inflated distance; vertex: squared distance)
+  unsigned long long* best_d2; // [K] bit pattern of the exact minimum squared distance
+  int* best_idx;               // [K] lowest index attaining it
+};
+
+// K4: closest point on surface.  Outputs (any may be null): cp [K*3], d2 [K], tri [K].
+void launch_surface_query(hipStream_t st, int T, const double* verts, const int* tris, const double4* spheres,
+                          int K, const double* P, int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);
+
+// K3: nearest vertex.  Outputs (any may be null): d2 [K], idx [K].
+void launch_vertex_query(hipStream_t st, int V, const double* verts, int K, const double* P, int* hint,
+                         const QueryBuffers& qb, double* d2, int* idx);
+
+// ---- posterior assembly + r-space algebra (kernels_posterior.hip)
+
+struct CorrBuffers {   // per-correspondence data of one ICP posterior (device)
+  int* id;             // [K] model vertex id
+  int* aux;            // [K] nearest target vertex of the surface point (ModelSampling) or -1
+  double* pt;          // [K*3] target-side point
+  unsigned char* keep; // [K]
+  double* nhat;        // [K*3] unit vertex normal at id on the current mesh
+  double* e;           // [K*3] observation minus mean: R^T((pt − t) − ctr) + ctr − x̄_id − μ_id
+};
+
+// NonRigidIcpProposal.scala:89-110 (ModelSampling): ids 0..K-1, surface points cp, optional nearest-vertex ids
+void launch_correspond_model(hipStream_t st, int K, const double* x, const double* cp, const int* nnv,
+                             const unsigned char* tgt_boundary, int boundary_aware, const Pose& pose,
+                             const double* ref, const double* mean, const int* tris, const int* adj_off,
+                             const int* adj, const CorrBuffers& cb);
+// NonRigidIcpProposal.scala:112-131 (TargetSampling): target points + nearest model vertex ids
+void launch_correspond_target(hipStream_t st, int K, const double* x, const double* tpts, const int* nn_id,
+                              const unsigned char* model_boundary, int boundary_aware, const Pose& pose,
+                              const double* ref, const double* mean, const int* tris, const int* adj_off,
+                              const int* adj, const CorrBuffers& cb);
+
+// K5a: Maug[(r+1)x(r+1)] = Σ_kept [Q_i | e_i]^T Σ_i^-1 [Q_i | e_i]  (M = I + Maug[:r,:r], b = Maug[:r,r])
+void launch_regression(hipStream_t st, int K, int r, const double* Q, const CorrBuffers& cb, double w_tangent,
+                       double kappa, double* Maug);
+
+// K5b: block 0: M = I + Maug, L = chol(M), alpha = M^-1 b;  block 1: L2 = chol(G + sigma2·M).  status[0..1] != 0 on failure.
+void launch_posterior_factor(hipStream_t st, int r, const double* Maug, const double* G, double sigma2, double* M,
+                             double* L, double* alpha, double* L2, int* status);
+
+// a9 tail: out = −½ γ^T M γ − (r/2) ln 2π with (G + σ²M) γ = G (c_from + (c_to − c_from)/step − α)
+void launch_transition_tail(hipStream_t st, int r, const double* alpha, const double* M, const double* L2,
+                            const double* G, const double* c_from, const double* c_to, double step, double* out);
+
+// eigen-decomposition of D M^-1 D (posterior KL basis): V columns, S descending, canonical signs
+void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, double* V, double* S,
+                            double* work /* r*r */, int* status);
+
+// a8: c' = c + step·((G+σ²I)^-1 G (α + D^-1 V √S z) − c)
+void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,
+                    const double* inv_sqrt_lambda, const double* G, const double* Lg, const double* c,
+                    const double* z, double step, double* c_out);
+
+// ---- evaluator reductions (kernels_posterior.hip)
+// out[0] = Σ log N(sqrt(d2_k); mean, sigma)
+void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mean, double sigma, double* out);
+// out[0] = Σ kept distances, out[1] = max kept distance, out[2] = number kept;  flag[k] != 0 drops the point
+// (flags may be null; idx (optional) indexes flags: flag = flags[idx[k]] if idx[k] < n_flags else 0)
+void launch_dist_stats(hipStream_t st, int K, const double* d2, const unsigned char* flags, const int* idx,
+                       int n_flags, double* out);
+
+}  // namespace icp

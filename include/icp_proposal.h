@@ -1,0 +1,197 @@
+/*
+ * icp_proposal.h — C ABI of the MI355X-native closest-point-proposal path (libicp_proposal_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of unibas-gravis/icp-proposal: the three Scalismo plug-in
+ * methods the Metropolis–Hastings chain calls per step,
+ *
+ *     ProposalGenerator[ModelFittingParameters].propose(current)
+ *     TransitionProbability[ModelFittingParameters].logTransitionProbability(from, to)
+ *     DistributionEvaluator[ModelFittingParameters].logValue(sample)
+ *
+ * as implemented by the reference classes cited at each entry point below (paths relative to the reference's
+ * src/main/scala/).  The reference has no FFI of its own (pure Scala on Scalismo); INTEGRATION.md shows the
+ * JNI stub + Scala adapters a maintainer would add to bind these symbols.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all floating point is IEEE double, all ids int32; arrays are row-major.
+ *   - theta = ModelFittingParameters.allParameters (ModelFittingParameters.scala:64):
+ *       [ s | tx ty tz | phi theta psi | cx cy cz | c_0 .. c_{r-1} ]      (10 + rank doubles)
+ *     pose = translation ∘ rotation(phi,theta,psi about c) with R = Rz(phi)·Ry(theta)·Rx(psi)
+ *     (ModelFittingParameters.scala:79-86), scale applied last (:88-106).
+ *   - every function returns an icp_status (0 = ok, < 0 = error); outputs are written into caller-owned buffers;
+ *     the library copies model/target to the GPU once at icp_ctx_create and keeps no pointer to caller memory.
+ *   - -inf is a VALID value of icp_proposal_log_transition (NonRigidIcpProposal.scala:72-74).
+ *   - entry points are thread-safe (calls on one context are serialised internally); the random numbers of
+ *     posterior.sample() (NonRigidIcpProposal.scala:55) are drawn by the CALLER and passed in as z.
+ *   - there is no CPU fallback: if no HIP device is usable, icp_ctx_create fails with ICP_ERR_DEVICE.
+ */
+#ifndef ICP_PROPOSAL_H
+#define ICP_PROPOSAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICP_API __attribute__((visibility("default")))
+
+typedef struct icp_ctx icp_ctx;             /* one statistical mesh model + one target mesh, resident on one GPU */
+typedef struct icp_proposal icp_proposal;   /* api/sampling/proposals/NonRigidIcpProposal.scala:30-41 */
+typedef struct icp_evaluator icp_evaluator; /* the classes under api/sampling/evaluators/ */
+
+typedef enum {
+  ICP_OK = 0,
+  ICP_ERR_INVALID_ARG = -1, /* null pointer, negative size, id out of range, unknown enum */
+  ICP_ERR_DEVICE = -2,      /* HIP runtime / no device / out of memory (icp_last_error() has the HIP string) */
+  ICP_ERR_NOT_FINITE = -3,  /* a result is NaN (the Scalismo chain throws on NaN transition probabilities) */
+  ICP_ERR_NOT_SPD = -4,     /* a normal-equation matrix failed to factor */
+  ICP_ERR_EMPTY = -5        /* boundary-aware evaluator dropped every point (reference: empty .max throws) */
+} icp_status;
+
+/* api/other/IcpProjectionDirection.scala:19-25.  ModelAndTargetSampling is not a proposal direction: the
+ * reference builds TWO proposals and mixes them (api/sampling/MixedProposalDistributions.scala:52-65). */
+typedef enum { ICP_MODEL_SAMPLING = 0, ICP_TARGET_SAMPLING = 1 } icp_direction;
+
+/* api/sampling/evaluators/EvaluationModeType.scala:20-26 */
+typedef enum { ICP_MODEL_TO_TARGET = 0, ICP_TARGET_TO_MODEL = 1, ICP_SYMMETRIC = 2 } icp_eval_mode;
+
+typedef enum {
+  ICP_EVAL_INDEPENDENT_POINT_DISTANCE = 0, /* evaluators/IndependentPointDistanceEvaluator.scala:27-67 */
+  ICP_EVAL_HAUSDORFF = 1,                  /* evaluators/HausdorffDistanceEvaluator.scala:25-36 */
+  ICP_EVAL_COLLECTIVE_AVG_HAUSDORFF_BOUNDARY_AWARE = 2 /* evaluators/CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:27-79 */
+} icp_eval_kind;
+
+/* What crosses the boundary of a Scalismo StatisticalMeshModel (Statismo layout). */
+typedef struct {
+  int32_t n_points;               /* N */
+  int32_t n_triangles;            /* T */
+  int32_t rank;                   /* r */
+  const double *ref_points;       /* [N*3]  reference mesh vertices */
+  const double *mean_deformation; /* [N*3]  GP mean at the reference vertices (NULL = zero) */
+  const double *basis;            /* [3N*r] UNSCALED eigenfunctions, row 3i+d = vertex i axis d */
+  const double *variance;         /* [r]    eigenvalues */
+  const int32_t *triangles;       /* [T*3] */
+} icp_model_desc;
+
+typedef struct {
+  int32_t n_points;
+  int32_t n_triangles;
+  const double *points;     /* [M*3] */
+  const int32_t *triangles; /* [Tt*3] */
+} icp_mesh_desc;
+
+/* Constructor arguments of NonRigidIcpProposal (NonRigidIcpProposal.scala:30-41).  The two decimations at
+ * :45-46 stay with the caller (Scalismo): only their outcome crosses the boundary — the COUNT of points of the
+ * decimated model (the reference uses ids 0 until K of the full mesh, :94-96) and the POINTS of the decimated
+ * target (:117). */
+typedef struct {
+  double step_length;        /* :33 */
+  double tangential_noise;   /* :34 stddev in the tangent plane */
+  double noise_along_normal; /* :35 stddev along the vertex normal */
+  int32_t direction;         /* :37 icp_direction */
+  int32_t boundary_aware;    /* :38 */
+  int32_t n_model_ids;       /* ModelSampling: number of points of model.decimate(numOfSamplePoints) */
+  int32_t n_target_points;   /* TargetSampling: number of points of target.operations.decimate(numOfSamplePoints) */
+  const double *target_points; /* [n_target_points*3] */
+} icp_proposal_params;
+
+/* Constructor arguments of the three likelihood evaluators; the likelihood distributions are the Breeze
+ * objects built in api/sampling/ProductEvaluators.scala:39,58,77-78. */
+typedef struct {
+  int32_t kind;            /* icp_eval_kind */
+  int32_t mode;            /* icp_eval_mode (ignored by ICP_EVAL_HAUSDORFF) */
+  int32_t n_model_ids;     /* number of points of model.decimate(numberOfPointsForComparison); ids 0 until K */
+  int32_t n_target_points; /* points of targetMesh.operations.decimate(numberOfPointsForComparison) */
+  const double *target_points;
+  double gauss_mean;       /* Gaussian(mean, sigma): kind 0 (per-point distance) and kind 2 (average distance) */
+  double gauss_sigma;
+  double exp_rate;         /* Exponential(rate): kind 1 (Hausdorff distance) and kind 2 (max distance) */
+} icp_evaluator_params;
+
+/* Diagnostic view of one ICP posterior (NonRigidIcpProposal.scala:88-153); any pointer may be NULL. */
+typedef struct {
+  int32_t n_candidates;   /* out: K (before the boundary filter) */
+  int32_t *corr_id;       /* [K]   model vertex id of each correspondence — THE correspondence index (:118 / :94) */
+  int32_t *corr_aux;      /* [K]   ModelSampling: target vertex nearest to the surface point (:98), else -1 */
+  double *corr_point;     /* [K*3] target-side point (:97 / :117) */
+  uint8_t *keep;          /* [K]   1 = survives the boundary filter (:104 / :124) */
+  double *alpha;          /* [r]   posterior mean coefficients */
+  double *M;              /* [r*r] I + sum_i Q_i^T Sigma_i^-1 Q_i */
+  double *V;              /* [r*r] eigenvectors (columns) of D M^-1 D — the posterior KL basis is Phi·V */
+  double *S;              /* [r]   its eigenvalues, descending */
+} icp_posterior_view;
+
+/* ---------------------------------------------------------------- context */
+
+/* device: HIP ordinal, or -1 = use LOCAL_RANK from the environment (0 if unset). */
+ICP_API int icp_ctx_create(const icp_model_desc *model, const icp_mesh_desc *target, int device, icp_ctx **out);
+ICP_API void icp_ctx_destroy(icp_ctx *ctx);
+ICP_API const char *icp_status_string(int status);
+ICP_API const char *icp_last_error(void); /* thread-local detail of the last failing call */
+ICP_API int icp_ctx_rank(const icp_ctx *ctx);
+ICP_API int icp_ctx_device(const icp_ctx *ctx);
+
+/* ModelFittingParameters.transformedMesh (ModelFittingParameters.scala:108-110): points_out [N*3]. */
+ICP_API int icp_transformed_mesh(icp_ctx *ctx, const double *theta, double *points_out);
+/* vertex normals of that mesh (Scalismo vertexNormals, used at NonRigidIcpProposal.scala:100,120): [N*3]. */
+ICP_API int icp_vertex_normals(icp_ctx *ctx, const double *theta, double *normals_out);
+
+/* The two brute-force searches, exposed for parity tests and micro-benchmarks.
+ * icp_closest_point_on_target : target.operations.closestPointOnSurface(p).point (NonRigidIcpProposal.scala:97);
+ * icp_closest_target_vertex   : target.pointSet.findClosestPoint(p).id            (:98);
+ * icp_closest_model_vertex    : currentMesh.pointSet.findClosestPoint(p).id for the mesh of theta (:118);
+ * icp_closest_point_on_model  : modelSample.operations.closestPointOnSurface(p) (IndependentPointDistanceEvaluator.scala:51).
+ * Ties: lowest squared distance, then lowest index.  Any output pointer may be NULL. */
+ICP_API int icp_closest_point_on_target(icp_ctx *ctx, int32_t n, const double *queries, double *points_out,
+                                        int32_t *triangle_out, double *dist2_out);
+ICP_API int icp_closest_target_vertex(icp_ctx *ctx, int32_t n, const double *queries, int32_t *id_out, double *dist2_out);
+ICP_API int icp_closest_model_vertex(icp_ctx *ctx, const double *theta, int32_t n, const double *queries,
+                                     int32_t *id_out, double *dist2_out);
+ICP_API int icp_closest_point_on_model(icp_ctx *ctx, const double *theta, int32_t n, const double *queries,
+                                       double *points_out, int32_t *triangle_out, double *dist2_out);
+
+/* ---------------------------------------------------------------- NonRigidIcpProposal */
+
+ICP_API int icp_proposal_create(icp_ctx *ctx, const icp_proposal_params *params, icp_proposal **out);
+ICP_API void icp_proposal_destroy(icp_proposal *p);
+
+/* propose (NonRigidIcpProposal.scala:53-68).  z[r] = the standard normals posterior.sample() draws (:55);
+ * theta_out[10+r] = theta with the shape coefficients replaced (:61-66).  corr_id_out (optional, [K]) receives
+ * the correspondence indices of the posterior that was used, -1 where the boundary filter dropped one. */
+ICP_API int icp_proposal_propose(icp_proposal *p, const double *theta, const double *z, double *theta_out,
+                                 int32_t *corr_id_out);
+
+/* logTransitionProbability(from, to) (NonRigidIcpProposal.scala:71-85). */
+ICP_API int icp_proposal_log_transition(icp_proposal *p, const double *theta_from, const double *theta_to, double *out);
+
+/* icpPosterior(theta) (NonRigidIcpProposal.scala:88-153), diagnostic. */
+ICP_API int icp_proposal_posterior(icp_proposal *p, const double *theta, icp_posterior_view *view);
+ICP_API int icp_proposal_num_candidates(const icp_proposal *p);
+
+/* ---------------------------------------------------------------- evaluators */
+
+ICP_API int icp_evaluator_create(icp_ctx *ctx, const icp_evaluator_params *params, icp_evaluator **out);
+ICP_API void icp_evaluator_destroy(icp_evaluator *e);
+
+/* logValue(sample) of the likelihood evaluator (computeLogValue of the three evaluator classes).
+ * aux (optional, [4]): kind 0 -> {modelToTarget sum, targetToModel sum, 0, 0}; kind 1 -> {hausdorff, m2t max, t2m max, 0};
+ * kind 2 -> {avg, max, n kept model->target, n kept target->model}. */
+ICP_API int icp_evaluator_log_value(icp_evaluator *e, const double *theta, double *out, double *aux);
+
+/* ModelPriorEvaluator.logValue (evaluators/ModelPriorEvaluator.scala:24-31): O(r) host arithmetic. */
+ICP_API int icp_prior_log_value(int32_t rank, const double *theta, double *out);
+
+/* ---------------------------------------------------------------- fused chain step (measurement harness)
+ * One call = all device work one Metropolis–Hastings step needs for a NEW state theta_prop proposed from
+ * theta_cur, submitted as one stream sequence with a single synchronisation: the likelihood of theta_prop and,
+ * for each of the n_props proposals, logT(cur -> prop) and logT(prop -> cur).  Results are identical to the
+ * per-method entry points above (same kernels, same caches); only the number of host round trips differs.
+ * fwd/bwd: [n_props]. */
+ICP_API int icp_chain_eval_step(icp_evaluator *e, int32_t n_props, icp_proposal *const *props, const double *theta_cur,
+                                const double *theta_prop, double *log_value_prop, double *fwd, double *bwd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICP_PROPOSAL_H */

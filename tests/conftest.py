@@ -1,0 +1,71 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_package():
+    return graft.load_package()
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def femur50(pkg):
+    """config 0 of BASELINE.json: femur-50 GPMM + landmark-aligned bundled target (N = M = 1622)."""
+    return pkg.data.load_femur_model_and_target(50)
+
+
+@pytest.fixture(scope="session")
+def femur50_oracle(oracle, femur50):
+    model, target = femur50
+    return oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+
+
+def make_theta(model, seed, shape_scale=0.5, pose=True):
+    """Seeded chain state in the value ranges of SURVEY.md §8d."""
+    rng = np.random.default_rng(seed)
+    theta = np.zeros(10 + model.rank)
+    theta[0] = 1.0
+    theta[7:10] = model.ref_points.sum(axis=0) / model.n_points
+    theta[10:] = np.clip(rng.normal(size=model.rank) * shape_scale, -2.0, 2.0)
+    if pose:
+        theta[1:4] = rng.normal(size=3) * 0.5
+        theta[4:7] = rng.normal(size=3) * 0.01
+    return theta
+
+
+def open_patch_target(target, n_remove=150):
+    """A target with a hole (boundary vertices), for the boundary-aware paths: drop the triangles touching the
+    n_remove vertices nearest to vertex 0 and compact the vertex list."""
+    pts, cells = target.points, target.cells
+    d = np.linalg.norm(pts - pts[0], axis=1)
+    drop = np.zeros(pts.shape[0], dtype=bool)
+    drop[np.argsort(d)[:n_remove]] = True
+    keep_cells = cells[~drop[cells].any(axis=1)]
+    used = np.zeros(pts.shape[0], dtype=bool)
+    used[keep_cells.ravel()] = True
+    remap = -np.ones(pts.shape[0], dtype=np.int64)
+    remap[used] = np.arange(used.sum())
+    return pts[used].copy(), remap[keep_cells].astype(np.int32)

@@ -1,0 +1,240 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): correspondence / nearest indices BIT-EXACT; coefficients, transition densities
+and likelihood values within 1e-5 relative (observed ~1e-12; the tighter bound used here is the regression guard).
+"""
+import numpy as np
+import pytest
+
+from conftest import make_theta, open_patch_target
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9  # far inside the 1e-5 contract
+
+
+@pytest.fixture(scope="module")
+def ctx50(pkg, femur50):
+    model, target = femur50
+    c = pkg.IcpContext(model, target, device=0)
+    yield c
+    c.close()
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_transformed_mesh_bit_exact(ctx50, femur50, femur50_oracle):
+    model, _ = femur50
+    om, _ = femur50_oracle
+    for seed in range(3):
+        theta = make_theta(model, seed)
+        assert np.array_equal(ctx50.transformedMesh(theta), om.instance(theta))
+
+
+def test_vertex_normals(ctx50, femur50, femur50_oracle):
+    model, _ = femur50
+    om, _ = femur50_oracle
+    theta = make_theta(model, 3)
+    n = ctx50.vertexNormals(theta)
+    no = om.vertex_normals(om.instance(theta))
+    assert np.abs(n - no).max() < 1e-12
+
+
+def test_closest_target_vertex_bit_exact(ctx50, femur50, oracle):
+    model, target = femur50
+    rng = np.random.default_rng(11)
+    q = model.ref_points[rng.integers(0, model.n_points, 300)] + rng.normal(size=(300, 3)) * 3.0
+    idx, d2 = ctx50.closestTargetVertex(q)
+    io, d2o = oracle.nearest_vertex(q, target.points)
+    assert np.array_equal(idx, io)
+    assert np.array_equal(d2, d2o)
+    # queries exactly ON vertices and exactly between two vertices (ties -> lowest index)
+    q2 = np.concatenate([target.points[:5], 0.5 * (target.points[target.cells[:5, 0]] + target.points[target.cells[:5, 1]])])
+    idx, d2 = ctx50.closestTargetVertex(q2)
+    io, d2o = oracle.nearest_vertex(q2, target.points)
+    assert np.array_equal(idx, io) and np.array_equal(d2, d2o)
+
+
+def test_closest_point_on_target_bit_exact(ctx50, femur50, oracle):
+    model, target = femur50
+    rng = np.random.default_rng(12)
+    q = model.ref_points[rng.integers(0, model.n_points, 200)] + rng.normal(size=(200, 3)) * 4.0
+    cp, tri, d2 = ctx50.closestPointOnTarget(q)
+    cpo, trio, d2o = oracle.closest_point_on_surface(q, target.points, target.cells)
+    assert np.array_equal(tri, trio)
+    assert np.array_equal(d2, d2o)
+    assert np.array_equal(cp, cpo)
+    # degenerate placements: on vertices, on edge midpoints, at triangle centroids (exact ties between triangles)
+    c = target.cells[:40]
+    q2 = np.concatenate([target.points[c[:, 0]], 0.5 * (target.points[c[:, 0]] + target.points[c[:, 1]]),
+                         target.points[c].mean(axis=1)])
+    cp, tri, d2 = ctx50.closestPointOnTarget(q2)
+    cpo, trio, d2o = oracle.closest_point_on_surface(q2, target.points, target.cells)
+    assert np.array_equal(tri, trio) and np.array_equal(d2, d2o) and np.array_equal(cp, cpo)
+
+
+def test_queries_against_current_model_bit_exact(ctx50, femur50, femur50_oracle, oracle, pkg):
+    model, target = femur50
+    om, _ = femur50_oracle
+    theta = make_theta(model, 5)
+    x = om.instance(theta)
+    tp = pkg.data.decimated_point_subset(target, 204)
+    idx, d2 = ctx50.closestModelVertex(theta, tp)
+    io, d2o = oracle.nearest_vertex(tp, x)
+    assert np.array_equal(idx, io) and np.array_equal(d2, d2o)
+    cp, tri, d2 = ctx50.closestPointOnModel(theta, tp)
+    cpo, trio, d2o = oracle.closest_point_on_surface(tp, x, model.cells)
+    assert np.array_equal(tri, trio) and np.array_equal(d2, d2o) and np.array_equal(cp, cpo)
+
+
+def test_empty_and_single_queries(ctx50, femur50, oracle):
+    _, target = femur50
+    cp, tri, d2 = ctx50.closestPointOnTarget(np.zeros((0, 3)))
+    assert cp.shape == (0, 3) and tri.shape == (0,)
+    q = np.array([[1.0, 2.0, 3.0]])
+    cp, tri, d2 = ctx50.closestPointOnTarget(q)
+    cpo, trio, d2o = oracle.closest_point_on_surface(q, target.points, target.cells)
+    assert tri[0] == trio[0] and d2[0] == d2o[0]
+
+
+@pytest.mark.parametrize("direction", ["ModelSampling", "TargetSampling"])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_posterior_propose_transition(pkg, ctx50, femur50, femur50_oracle, oracle, direction, seed):
+    """a4/a5/a7/a8/a9 for the femur configuration (K = 2·rank, σt = 10, σn = 5, step 0.1)."""
+    model, target = femur50
+    om, ot = femur50_oracle
+    r = model.rank
+    theta = make_theta(model, 100 + seed)
+    tp = pkg.data.decimated_point_subset(target, 2 * r)
+    if direction == "ModelSampling":
+        pp = oracle.proposal_params(0.1, 10.0, 5.0, oracle.MODEL_SAMPLING, True, n_model_ids=2 * r)
+    else:
+        pp = oracle.proposal_params(0.1, 10.0, 5.0, oracle.TARGET_SAMPLING, True, target_pts=tp)
+    prop = pkg.NonRigidIcpProposal(ctx50, 0.1, 10.0, 5.0, 2 * r, direction, True, decimatedTargetPoints=tp)
+    post = prop.icpPosterior(theta)
+    po = oracle.icp_posterior(om, ot, pp, theta)
+    assert np.array_equal(post.corr_id, po.corr_id)          # correspondence indices: bit-exact
+    assert np.array_equal(post.keep, po.keep)
+    assert np.array_equal(post.corr_aux, po.corr_aux)
+    assert np.array_equal(post.corr_point, po.corr_pt)
+    assert rel_err(post.M, po.M) < REL
+    assert rel_err(post.alpha, po.alpha) < REL
+    assert rel_err(post.S, po.S) < REL
+    assert np.abs(post.V - po.V).max() < 1e-7                # eigenvectors: conditioning ~ eps / relative gap
+    rng = np.random.default_rng(200 + seed)
+    for z in (np.zeros(r), rng.normal(size=r)):
+        got, corr = prop.propose(theta, z, return_correspondences=True)
+        want = oracle.propose(om, ot, pp, theta, z)
+        assert np.array_equal(got[:10], theta[:10])
+        assert rel_err(got[10:], want[10:]) < 1e-7
+        assert np.array_equal(corr, np.where(po.keep == 1, po.corr_id, -1))
+        lt = prop.logTransitionProbability(theta, got)
+        lo = oracle.log_transition(om, ot, pp, theta, want)
+        assert abs(lt - lo) <= 1e-8 * abs(lo)
+        lb = prop.logTransitionProbability(got, theta)
+        lbo = oracle.log_transition(om, ot, pp, want, theta)
+        assert abs(lb - lbo) <= 1e-8 * abs(lbo)
+    # z = 0: the proposal moves the coefficients towards the posterior mean by exactly stepLength
+    got0 = prop.propose(theta, np.zeros(r))
+    assert rel_err(got0[10:], theta[10:] + 0.1 * (po.alpha - theta[10:])) < 1e-6
+    # anything but the shape differs -> -inf (NonRigidIcpProposal.scala:72-74)
+    other = got.copy()
+    other[1] += 0.1
+    assert prop.logTransitionProbability(theta, other) == -np.inf
+    prop.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_independent_point_distance_evaluator(pkg, ctx50, femur50, femur50_oracle, oracle, mode):
+    model, target = femur50
+    om, ot = femur50_oracle
+    r = model.rank
+    tp = pkg.data.decimated_point_subset(target, 4 * r)
+    ev = pkg.IndependentPointDistanceEvaluator(ctx50, 0.0, 2.0, mode, 4 * r, decimatedTargetPoints=tp)
+    ep = oracle.evaluator_params(oracle.EVAL_INDEPENDENT, mode, n_model_ids=4 * r, target_pts=tp, p0=0.0, p1=2.0)
+    for seed in (0, 1):
+        theta = make_theta(model, 300 + seed)
+        want, rc = oracle.evaluator_log_value(om, ot, ep, theta)
+        got = ev.logValue(theta)
+        assert rc == 0 and abs(got - want) <= 1e-11 * abs(want)
+        assert ev.logValue(theta) == got  # memoised (EvaluationCaching.scala:32-36)
+    ev.close()
+
+
+def test_hausdorff_evaluator(pkg, ctx50, femur50, femur50_oracle, oracle):
+    model, _ = femur50
+    om, ot = femur50_oracle
+    ev = pkg.HausdorffDistanceEvaluator(ctx50, 1.0)
+    ep = oracle.evaluator_params(oracle.EVAL_HAUSDORFF, 2, p0=1.0)
+    for seed in (0, 1):
+        theta = make_theta(model, 400 + seed)
+        want, rc = oracle.evaluator_log_value(om, ot, ep, theta)
+        got, aux = ev.logValue(theta, return_aux=True)
+        assert rc == 0 and abs(got - want) <= 1e-12 * abs(want)
+    ev.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_boundary_aware_paths_on_open_target(pkg, femur50, oracle, mode):
+    """Collective boundary-aware evaluator + boundary-aware ModelSampling proposal on a target with a hole."""
+    model, target = femur50
+    pts, cells = open_patch_target(target)
+    tgt = pkg.data.TriangleMesh(pts, cells)
+    assert pkg.data.boundary_vertex_flags(tgt).sum() > 0
+    ctx = pkg.IcpContext(model, tgt, device=0)
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(pts, cells)
+    r = model.rank
+    tp = pkg.data.decimated_point_subset(tgt, 4 * r)
+    ev = pkg.CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator(ctx, 0.1, 0.3, 1.0, mode, 4 * r, decimatedTargetPoints=tp)
+    ep = oracle.evaluator_params(oracle.EVAL_COLLECTIVE, mode, n_model_ids=4 * r, target_pts=tp, p0=0.1, p1=0.3, p2=1.0)
+    theta = make_theta(model, 500)
+    want, rc = oracle.evaluator_log_value(om, ot, ep, theta)
+    got, aux = ev.logValue(theta, return_aux=True)
+    assert rc == 0 and abs(got - want) <= 1e-11 * abs(want)
+    if mode == 0:
+        pp = oracle.proposal_params(0.1, 6.0, 3.0, oracle.MODEL_SAMPLING, True, n_model_ids=2 * r)
+        prop = pkg.NonRigidIcpProposal(ctx, 0.1, 6.0, 3.0, 2 * r, "ModelSampling", True)
+        post, po = prop.icpPosterior(theta), oracle.icp_posterior(om, ot, pp, theta)
+        assert po.keep.sum() < po.keep.size, "test target should drop some correspondences"
+        assert np.array_equal(post.keep, po.keep) and np.array_equal(post.corr_aux, po.corr_aux)
+        assert rel_err(post.alpha, po.alpha) < REL
+        z = np.random.default_rng(5).normal(size=r)
+        assert rel_err(prop.propose(theta, z)[10:], oracle.propose(om, ot, pp, theta, z)[10:]) < 1e-7
+        prop.close()
+    ev.close()
+    ctx.close()
+
+
+def test_chain_eval_step_matches_separate_calls(pkg, ctx50, femur50):
+    model, target = femur50
+    r = model.rank
+    tp = pkg.data.decimated_point_subset(target, 2 * r)
+    props = [pkg.NonRigidIcpProposal(ctx50, 0.1, 10.0, 5.0, 2 * r, d, True, decimatedTargetPoints=tp)
+             for d in ("TargetSampling", "ModelSampling")]
+    ev = pkg.IndependentPointDistanceEvaluator(ctx50, 0.0, 2.0, 0, 4 * r)
+    cur = make_theta(model, 600, pose=False)
+    prop_theta = props[0].propose(cur, np.random.default_rng(1).normal(size=r))
+    val, fwd, bwd = pkg.chain_eval_step(ev, props, cur, prop_theta)
+    assert val == ev.logValue(prop_theta)
+    for i, p in enumerate(props):
+        assert fwd[i] == p.logTransitionProbability(cur, prop_theta)
+        assert bwd[i] == p.logTransitionProbability(prop_theta, cur)
+    for p in props:
+        p.close()
+    ev.close()
+
+
+def test_error_behaviour(pkg, ctx50, femur50):
+    model, _ = femur50
+    theta = make_theta(model, 1)
+    bad = theta.copy()
+    bad[12] = np.nan
+    with pytest.raises(pkg._native.IcpNativeError) as e:
+        ctx50.transformedMesh(bad)
+    assert e.value.status == -3
+    with pytest.raises(pkg._native.IcpNativeError) as e:
+        pkg.NonRigidIcpProposal(ctx50, 0.1, -1.0, 5.0, 10, "ModelSampling")
+    assert e.value.status == -1
