@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — MH iterations/s of the closest-point-proposal path on MI355X (BASELINE.json metric).
+
+One "step" = one Metropolis–Hastings step of the femur configuration of the reference's
+apps/femur/IcpProposalRegistration.scala:59-85 (0.9 ICP mixture [TargetSampling + ModelSampling, K = 2·rank,
+σt = 10, σn = 5, step 0.1] + 0.1 random walk; prior × independent Gaussian(0, 2) likelihood on 4·rank points)
+against the synthetic ~50k-vertex target of BASELINE.json configs[1] (the bundled femur target
+subdivided 6-way per edge, 58,322 vertices / 116,640 triangles, seeded 0.05 mm jitter).  Model, target and all
+chain state are resident in HBM before the timed region starts; the per-step host<->device traffic is the
+(10 + r)-double state vector in and a handful of doubles out.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): every rank runs an independent chain on its own GPU
+(weak scaling, no data-path collective); the fixed-size per-step log records are gathered ONCE with an RCCL
+all_gather at log-write time, inside the timed region.
+
+Prints ONE JSON line (rank 0).  Extra legs after the timed region (rank 0, N = 1 only): the roofline of the
+dominant kernel measured with HIP events on the library's stream, and the CPU baseline (oracle/, "port", 1 core)
+on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+DOMINANT = "k_surface_pass<0>"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--profile-steps", type=int, default=300, help="steps of the HIP-event roofline leg (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=16, help="steps of the CPU-oracle baseline leg (0 = skip)")
+    ap.add_argument("--subdiv", type=int, default=6, help="edge subdivision of the synthetic target (6 -> 58,322 vertices)")
+    ap.add_argument("--no-fused", action="store_true", help="per-method calls only (no icp_chain_eval_step prefetch)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    dist = torch = None
+    if world > 1:
+        import torch  # noqa: F811
+        import torch.distributed as dist  # noqa: F811
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+
+    # ---- workload (identical on every rank; synthetic target built from the bundled femur data)
+    model, target = pkg.data.synthetic_femur_target(n_subdiv=args.subdiv)
+    r = model.rank
+    ctx = pkg.IcpContext(model, target, device=local_rank)
+    setup = pkg.femur_icp_proposal_registration(model, target, fused=not args.no_fused)
+    theta0 = pkg.initial_parameters(model)
+    if rank > 0:  # apps/femur/RandomSamplesFromModel.scala:28-35: chain i > 0 starts from c ~ N(0, 0.1·I)
+        theta0[10:] = np.random.default_rng(1024 + rank).normal(size=r) * np.sqrt(0.1)
+    chain = pkg.SamplingRegistration(ctx, setup, theta0, seed=1024 + rank)
+    rec_len = 4 + 10 + r
+
+    def barrier():
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def gather_logs(rec):
+        """single RCCL gather of the fixed-size per-step records"""
+        if dist is None:
+            return rec
+        t = torch.from_numpy(rec).cuda()
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        torch.cuda.synchronize()
+        return out
+
+    # ---- warmup (also builds the RCCL communicator)
+    w = chain.run(max(args.warmup, 1))
+    gather_logs(w)
+
+    # ---- timed region: exactly K steps per rank + the log gather
+    barrier()
+    t0 = time.perf_counter()
+    rec = chain.run(args.steps)
+    gather_logs(rec)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    n_acc = int(rec[:, 1].sum())
+    n_icp = int((rec[:, 2] < 2).sum())
+
+    line = {
+        "metric": "ICP-proposal MH iterations/sec (femur GPMM r=50, ~50k-vtx target)",
+        "value": world * args.steps / dt,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[1]: femur 50-basis GPMM (N=%d, rank %d) vs synthetic target M=%d vertices / %d triangles; "
+                        "1 chain per GPU; 0.9 ICP(Target+Model sampling, K=%d) + 0.1 random walk; prior x independent Gaussian(0,2) on %d points"
+                        % (model.n_points, r, target.n_points, target.n_cells, 2 * r, 4 * r),
+            "chains_per_gpu": 1,
+            "fused_step_call": not args.no_fused,
+            "accepted": n_acc,
+            "icp_proposals": n_icp,
+        },
+        "roofline": None,
+        "cpu_baseline": None,
+    }
+
+    if rank == 0 and world == 1:
+        # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on (the library's stream)
+        if args.profile_steps > 0:
+            ctx.profile_start(max_launches=64 * args.profile_steps + 1024)
+            chain.run(args.profile_steps, want_records=False)
+            stats = ctx.profile_stop()
+            if DOMINANT in stats:
+                k = stats[DOMINANT]
+                n_queries = setup.eval["n_model_ids"]  # ids 0..4r-1 (the proposal's 0..2r-1 are a subset, shared)
+                # algorithmic bytes per launch: target vertices 3·M·8 + target triangles 3·Tt·4 + queries K·3·8
+                alg_bytes = 3 * target.n_points * 8 + 3 * target.n_cells * 4 + n_queries * 24
+                avg_s = k["avg_us"] * 1e-6
+                achieved = alg_bytes / avg_s / 1e9
+                traffic = None
+                tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+                if os.path.exists(tfile):
+                    traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": DOMINANT,
+                                    "avg_launch_us": k["avg_us"], "launches": k["calls"], "algorithmic_bytes": alg_bytes,
+                                    "note": "brute-force search is VALU-bound by construction (SURVEY.md §8d); HBM fraction reported as north_star asks"}
+                line["kernel_us_per_step"] = {name: round(s["total_ms"] * 1e3 / args.profile_steps, 2) for name, s in stats.items()}
+        # ---- CPU baseline: the oracle's chain (same math, brute force, 1 thread) on a bounded sample
+        if args.cpu_steps > 0:
+            from oracle import oracle as O
+            om, ot = O.OracleModel.from_model(model), O.OracleMesh(target.points, target.cells)
+            icp = [O.proposal_params(p["step"], p["sigma_t"], p["sigma_n"], p["direction"], p.get("boundary_aware", True),
+                                     n_model_ids=p.get("n_model_ids", 0), target_pts=p.get("target_pts")) for p in setup.icp]
+            e = setup.eval
+            ep = O.evaluator_params(e["kind"], e["mode"], n_model_ids=e["n_model_ids"], target_pts=e["target_pts"],
+                                    p0=e["gauss_mean"], p1=e["gauss_sigma"], p2=e["exp_rate"])
+            cfg = O.chain_config(icp, [p.get("weight", 0.5) for p in setup.icp], setup.w_icp, setup.w_rw, setup.rw_sigma, ep)
+            t1 = time.perf_counter()
+            acc_o, comp_o, _, states_o = O.run_chain(om, ot, cfg, theta0, 1024, args.cpu_steps)
+            cdt = time.perf_counter() - t1
+            # the first cpu_steps records of a fresh GPU chain must reproduce the oracle's decisions
+            chk = pkg.SamplingRegistration(ctx, setup, theta0, seed=1024)
+            crec = chk.run(args.cpu_steps)
+            same = bool(np.array_equal(crec[:, 1].astype(np.uint8), acc_o)) and \
+                float(np.abs(crec[:, 14:] - states_o[:, 10:]).max()) <= 1e-5 * max(float(np.abs(states_o[:, 10:]).max()), 1e-30)
+            chk.close()
+            line["cpu_baseline"] = {"value": args.cpu_steps / cdt, "unit": "iterations/s", "cores": 1, "kind": "port",
+                                    "sample": "%d MH steps of the same workload, oracle/icp_oracle.c (brute-force f64, single thread, "
+                                              "posterior/likelihood of the current state carried over like the reference's Memoize); "
+                                              "host has %d logical cores" % (args.cpu_steps, os.cpu_count()),
+                                    "gpu_matches_oracle_on_sample": same}
+    if rank == 0:
+        print(json.dumps(line))
+    chain.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

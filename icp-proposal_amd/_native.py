@@ -43,6 +43,11 @@ class PosteriorView(C.Structure):
                 ("keep", c_ubyte_p), ("alpha", c_double_p), ("M", c_double_p), ("V", c_double_p), ("S", c_double_p)]
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 40), ("calls", C.c_int64), ("total_ms", C.c_double), ("min_ms", C.c_double),
+                ("max_ms", C.c_double)]
+
+
 # every symbol include/icp_proposal.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "icp_ctx_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(MeshDesc), C.c_int, C.POINTER(C.c_void_p)]),
@@ -67,6 +72,8 @@ SIGNATURES = {
     "icp_evaluator_destroy": (None, [C.c_void_p]),
     "icp_evaluator_log_value": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "icp_prior_log_value": (C.c_int, [C.c_int32, c_double_p, c_double_p]),
+    "icp_ctx_profile_start": (C.c_int, [C.c_void_p, C.c_int32]),
+    "icp_ctx_profile_stop": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),
     "icp_chain_eval_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_double_p]),
 }

@@ -104,6 +104,21 @@ class IcpContext:
     def __del__(self):
         self.close()
 
+    def profile_start(self, max_launches: int = 200000):
+        nat.check(nat.lib().icp_ctx_profile_start(self.h, max_launches), "icp_ctx_profile_start")
+
+    def profile_stop(self):
+        """-> {kernel name: dict(calls, total_ms, avg_us, min_us, max_us)} measured with HIP events on the context stream."""
+        stats = (nat.KernelStat * 64)()
+        n = C.c_int32()
+        nat.check(nat.lib().icp_ctx_profile_stop(self.h, stats, 64, C.byref(n)), "icp_ctx_profile_stop")
+        out = {}
+        for i in range(n.value):
+            s = stats[i]
+            out[s.name.decode()] = dict(calls=s.calls, total_ms=s.total_ms, avg_us=1e3 * s.total_ms / s.calls,
+                                        min_us=1e3 * s.min_ms, max_us=1e3 * s.max_ms)
+        return out
+
     def transformedMesh(self, theta) -> np.ndarray:
         """ModelFittingParameters.transformedMesh (ModelFittingParameters.scala:108-110) -> points [N,3]."""
         th = _theta(theta)

@@ -197,6 +197,9 @@ struct icp_ctx {
   int* h_status = nullptr;
   DBuf<int> d_status;
 
+  Profiler prof;
+  bool profiling = false;
+
   void bind() { HIP_OK(hipSetDevice(device)); }
 
   QueryBuffers query_scratch(size_t K) {
@@ -234,6 +237,16 @@ struct icp_ctx {
   void ensure_surface_prefix(StateSlot& s, int K);
   void ensure_nnv_prefix(StateSlot& s, int K);
 };
+
+namespace {
+struct Bound {  // selects the context's device and (if enabled) its profiler for the calling thread
+  explicit Bound(icp_ctx* c) {
+    c->bind();
+    g_prof = c->profiling ? &c->prof : nullptr;
+  }
+  ~Bound() { g_prof = nullptr; }
+};
+}  // namespace
 
 StateSlot& icp_ctx::state(const double* theta) {
   const size_t P = 10 + (size_t)r;
@@ -721,10 +734,60 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
+  for (auto& r : ctx->prof.pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   delete ctx;
+}
+
+int icp_ctx_profile_start(icp_ctx* ctx, int32_t max_launches) {
+  return guard([&] {
+    require(ctx && max_launches > 0, "bad argument");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->bind();
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    while (ctx->prof.pool.size() < (size_t)max_launches) {
+      Profiler::Rec r;
+      HIP_OK(hipEventCreate(&r.a));
+      HIP_OK(hipEventCreate(&r.b));
+      r.id = 0;
+      ctx->prof.pool.push_back(r);
+    }
+    ctx->prof.used = 0;
+    ctx->prof.overflow = false;
+    ctx->profiling = true;
+  });
+}
+
+int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity, int32_t* n_out) {
+  return guard([&] {
+    require(ctx && stats && n_out && capacity >= KID_COUNT, "bad argument (capacity must be >= 32)");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->bind();
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    ctx->profiling = false;
+    std::vector<icp_kernel_stat> acc(KID_COUNT);
+    for (int i = 0; i < KID_COUNT; ++i) {
+      std::memset(&acc[i], 0, sizeof(icp_kernel_stat));
+      std::strncpy(acc[i].name, kKernelNames[i], sizeof(acc[i].name) - 1);
+      acc[i].min_ms = 1e300;
+    }
+    for (size_t i = 0; i < ctx->prof.used; ++i) {
+      float ms = 0.f;
+      HIP_OK(hipEventElapsedTime(&ms, ctx->prof.pool[i].a, ctx->prof.pool[i].b));
+      icp_kernel_stat& a = acc[ctx->prof.pool[i].id];
+      a.calls++;
+      a.total_ms += ms;
+      a.min_ms = std::min(a.min_ms, (double)ms);
+      a.max_ms = std::max(a.max_ms, (double)ms);
+    }
+    int n = 0;
+    for (int i = 0; i < KID_COUNT; ++i)
+      if (acc[i].calls > 0) stats[n++] = acc[i];
+    *n_out = n;
+    if (ctx->prof.overflow) fail(ICP_ERR_INVALID_ARG, "profiler event pool too small: raise max_launches");
+  });
 }
 
 int icp_transformed_mesh(icp_ctx* ctx, const double* theta, double* points_out) {
@@ -732,7 +795,7 @@ int icp_transformed_mesh(icp_ctx* ctx, const double* theta, double* points_out) 
     require(ctx && points_out, "null argument");
     check_theta_finite(ctx, theta);
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    ctx->bind();
+    Bound _b(ctx);
     StateSlot& s = ctx->state(theta);
     HIP_OK(hipMemcpyAsync(points_out, s.x.p, sizeof(double) * 3 * ctx->N, hipMemcpyDeviceToHost, ctx->stream));
     ctx->finish(0, 0);
@@ -744,7 +807,7 @@ int icp_vertex_normals(icp_ctx* ctx, const double* theta, double* normals_out) {
     require(ctx && normals_out, "null argument");
     check_theta_finite(ctx, theta);
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    ctx->bind();
+    Bound _b(ctx);
     StateSlot& s = ctx->state(theta);
     DBuf<double> nrm;
     nrm.alloc(3 * (size_t)ctx->N);
@@ -781,7 +844,7 @@ int icp_closest_point_on_target(icp_ctx* ctx, int32_t n, const double* queries, 
   return guard([&] {
     require(ctx, "null context");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    ctx->bind();
+    Bound _b(ctx);
     const DeviceMesh& t = ctx->target;
     run_search(ctx, true, t.V, t.T, t.verts.p, t.tris.p, t.spheres.p, n, queries, points_out, triangle_out, dist2_out);
   });
@@ -791,7 +854,7 @@ int icp_closest_target_vertex(icp_ctx* ctx, int32_t n, const double* queries, in
   return guard([&] {
     require(ctx, "null context");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    ctx->bind();
+    Bound _b(ctx);
     const DeviceMesh& t = ctx->target;
     run_search(ctx, false, t.V, t.T, t.verts.p, t.tris.p, t.spheres.p, n, queries, nullptr, id_out, dist2_out);
   });
@@ -803,7 +866,7 @@ int icp_closest_model_vertex(icp_ctx* ctx, const double* theta, int32_t n, const
     require(ctx, "null context");
     check_theta_finite(ctx, theta);
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    ctx->bind();
+    Bound _b(ctx);
     StateSlot& s = ctx->state(theta);
     run_search(ctx, false, ctx->N, ctx->T, s.x.p, ctx->tris.p, nullptr, n, queries, nullptr, id_out, dist2_out);
   });
@@ -815,7 +878,7 @@ int icp_closest_point_on_model(icp_ctx* ctx, const double* theta, int32_t n, con
     require(ctx, "null context");
     check_theta_finite(ctx, theta);
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    ctx->bind();
+    Bound _b(ctx);
     StateSlot& s = ctx->state(theta);
     ctx->ensure_model_spheres(s);
     run_search(ctx, true, ctx->N, ctx->T, s.x.p, ctx->tris.p, s.spheres.p, n, queries, points_out, triangle_out, dist2_out);
@@ -833,7 +896,7 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     require(params->step_length != 0.0 && std::isfinite(params->step_length), "step_length must be finite and non-zero");
     require(params->tangential_noise > 0.0 && params->noise_along_normal > 0.0, "noise standard deviations must be positive");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    ctx->bind();
+    Bound _b(ctx);
     p = new icp_proposal();
     p->ctx = ctx;
     p->prm = *params;
@@ -878,7 +941,7 @@ int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, 
     icp_ctx& c = *p->ctx;
     check_theta_finite(&c, theta);
     std::lock_guard<std::recursive_mutex> lk(c.mu);
-    c.bind();
+    Bound _b(&c);
     const int r = c.r;
     PosteriorEntry& e = p->posterior(theta, false);  // NonRigidIcpProposal.scala:54
     p->ensure_eigen(e);
@@ -917,7 +980,7 @@ int icp_proposal_log_transition(icp_proposal* p, const double* theta_from, const
       return;
     }
     std::lock_guard<std::recursive_mutex> lk(c.mu);
-    c.bind();
+    Bound _b(&c);
     PosteriorEntry& e = p->posterior(theta_from, false);  // :76
     const double* dto = c.stage(theta_to + 10, c.r);
     launch_transition_tail(c.stream, c.r, e.alpha.p, e.M.p, e.L2.p, c.G.p, e.coeffs.p, dto, p->prm.step_length, c.d_res.p);
@@ -935,7 +998,7 @@ int icp_proposal_posterior(icp_proposal* p, const double* theta, icp_posterior_v
     icp_ctx& c = *p->ctx;
     check_theta_finite(&c, theta);
     std::lock_guard<std::recursive_mutex> lk(c.mu);
-    c.bind();
+    Bound _b(&c);
     const int r = c.r, K = p->K;
     PosteriorEntry& e = p->posterior(theta, view->corr_aux != nullptr);
     if (view->V || view->S) p->ensure_eigen(e);
@@ -967,7 +1030,7 @@ int icp_evaluator_create(icp_ctx* ctx, const icp_evaluator_params* params, icp_e
     require(params->kind >= 0 && params->kind <= 2, "unknown evaluator kind");
     require(params->kind == ICP_EVAL_HAUSDORFF || (params->mode >= 0 && params->mode <= 2), "unknown evaluation mode");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    ctx->bind();
+    Bound _b(ctx);
     ev = new icp_evaluator();
     ev->ctx = ctx;
     ev->prm = *params;
@@ -1011,7 +1074,7 @@ int icp_evaluator_log_value(icp_evaluator* e, const double* theta, double* out, 
     icp_ctx& c = *e->ctx;
     check_theta_finite(&c, theta);
     std::lock_guard<std::recursive_mutex> lk(c.mu);
-    c.bind();
+    Bound _b(&c);
     icp_evaluator::Memo* m = eval_lookup(e, theta);  // evaluators/EvaluationCaching.scala:32-36
     if (!m) {
       StateSlot& s = c.state(theta);
@@ -1050,7 +1113,7 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
     check_theta_finite(&c, theta_cur);
     check_theta_finite(&c, theta_prop);
     std::lock_guard<std::recursive_mutex> lk(c.mu);
-    c.bind();
+    Bound _b(&c);
     const int r = c.r;
     icp_evaluator::Memo* m = eval_lookup(e, theta_prop);
     const bool need_eval = m == nullptr;

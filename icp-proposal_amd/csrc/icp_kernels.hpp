@@ -4,7 +4,35 @@
 #include <stdint.h>
 #include "icp_device.hpp"
 
+#include <vector>
+
 namespace icp {
+
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+// Off by default: when `g_prof` is null the launch wrappers add nothing.
+enum KernelId {
+  KID_INSTANCE = 0, KID_SURFACE_INIT, KID_SURFACE_PASS_A, KID_SURFACE_BOUND, KID_SURFACE_PASS_B, KID_SURFACE_FINAL,
+  KID_VERTEX_INIT, KID_VERTEX_PASS_A, KID_VERTEX_PASS_B, KID_VERTEX_FINAL, KID_TRI_SPHERES, KID_CORRESPOND,
+  KID_REGRESSION, KID_FACTOR, KID_TAIL, KID_EIGEN, KID_PROPOSE, KID_REDUCE, KID_COUNT
+};
+extern const char* const kKernelNames[KID_COUNT];
+
+struct Profiler {
+  struct Rec { hipEvent_t a, b; int id; };
+  std::vector<Rec> pool;
+  size_t used = 0;
+  bool overflow = false;
+  void begin(hipStream_t st, int id);
+  void end(hipStream_t st);
+};
+extern thread_local Profiler* g_prof;
+
+struct ProfScope {  // RAII: events around one kernel launch
+  hipStream_t st;
+  bool on;
+  ProfScope(hipStream_t st, int id) : st(st), on(g_prof != nullptr) { if (on) g_prof->begin(st, id); }
+  ~ProfScope() { if (on) g_prof->end(st); }
+};
 
 // ---- geometry (kernels_geometry.hip)
 

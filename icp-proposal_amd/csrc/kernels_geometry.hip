@@ -15,6 +15,23 @@
 
 namespace icp {
 
+thread_local Profiler* g_prof = nullptr;
+const char* const kKernelNames[KID_COUNT] = {
+    "k_instance", "k_surface_init", "k_surface_pass<0>", "k_bound_from_best", "k_surface_pass<1>", "k_surface_final",
+    "k_vertex_init", "k_vertex_pass<0>", "k_vertex_pass<1>", "k_vertex_final", "k_tri_spheres", "k_correspond",
+    "k_regression", "k_posterior_factor", "k_transition_tail", "k_posterior_eigen", "k_propose", "k_reduce"};
+
+void Profiler::begin(hipStream_t st, int id) {
+  if (used >= pool.size()) { overflow = true; return; }
+  pool[used].id = id;
+  (void)hipEventRecord(pool[used].a, st);
+}
+void Profiler::end(hipStream_t st) {
+  if (used >= pool.size()) return;
+  (void)hipEventRecord(pool[used].b, st);
+  ++used;
+}
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -218,7 +235,8 @@ inline void split_queries(int n_elem_blocks, int K, int* ksplit, int* kchunk) {
 
 void launch_instance(hipStream_t st, int N, int r, const double* Qp, const double* ref, const double* mean,
                      const Pose& pose, const double* coeffs, double* x) {
-  hipLaunchKernelGGL(k_instance, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, st, N, r, Qp, ref, mean, pose, coeffs, x);
+  { ProfScope _ps(st, KID_INSTANCE);
+    hipLaunchKernelGGL(k_instance, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, st, N, r, Qp, ref, mean, pose, coeffs, x); }
 }
 
 void launch_vertex_normals(hipStream_t st, int N, const double* x, const int* tris, const int* adj_off,
@@ -228,45 +246,55 @@ void launch_vertex_normals(hipStream_t st, int N, const double* x, const int* tr
 
 void launch_tri_spheres(hipStream_t st, int T, const double* verts, const int* tris, double4* spheres) {
   if (T <= 0) return;
-  hipLaunchKernelGGL(k_tri_spheres, dim3(cdiv(T, kBlock)), dim3(kBlock), 0, st, T, verts, tris, spheres);
+  { ProfScope _ps(st, KID_TRI_SPHERES);
+    hipLaunchKernelGGL(k_tri_spheres, dim3(cdiv(T, kBlock)), dim3(kBlock), 0, st, T, verts, tris, spheres); }
 }
 
 void launch_surface_query(hipStream_t st, int T, const double* verts, const int* tris, const double4* spheres,
                           int K, const double* P, int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri) {
   if (K <= 0) return;
   const int qblocks = cdiv(K, kBlock);
-  hipLaunchKernelGGL(k_surface_init, dim3(qblocks), dim3(kBlock), 0, st, K, P, T, verts, tris, hint, qb.thr,
-                     qb.best_d2, qb.best_idx);
+  { ProfScope _ps(st, KID_SURFACE_INIT);
+    hipLaunchKernelGGL(k_surface_init, dim3(qblocks), dim3(kBlock), 0, st, K, P, T, verts, tris, hint, qb.thr,
+                     qb.best_d2, qb.best_idx); }
   if (T > 0) {
     const int tblocks = cdiv(T, kBlock);
     int ksplit, kchunk;
     split_queries(tblocks, K, &ksplit, &kchunk);
-    hipLaunchKernelGGL(k_surface_pass<0>, dim3(tblocks, ksplit), dim3(kBlock), 0, st, T, spheres, verts, tris, K,
-                       kchunk, P, qb.thr, (const unsigned long long*)nullptr, qb.best_d2, (int*)nullptr);
-    hipLaunchKernelGGL(k_bound_from_best, dim3(qblocks), dim3(kBlock), 0, st, K, qb.best_d2, qb.thr);
-    hipLaunchKernelGGL(k_surface_pass<1>, dim3(tblocks, ksplit), dim3(kBlock), 0, st, T, spheres, verts, tris, K,
-                       kchunk, P, qb.thr, qb.best_d2, (unsigned long long*)nullptr, qb.best_idx);
+    { ProfScope _ps(st, KID_SURFACE_PASS_A);
+      hipLaunchKernelGGL(k_surface_pass<0>, dim3(tblocks, ksplit), dim3(kBlock), 0, st, T, spheres, verts, tris, K,
+                       kchunk, P, qb.thr, (const unsigned long long*)nullptr, qb.best_d2, (int*)nullptr); }
+    { ProfScope _ps(st, KID_SURFACE_BOUND);
+      hipLaunchKernelGGL(k_bound_from_best, dim3(qblocks), dim3(kBlock), 0, st, K, qb.best_d2, qb.thr); }
+    { ProfScope _ps(st, KID_SURFACE_PASS_B);
+      hipLaunchKernelGGL(k_surface_pass<1>, dim3(tblocks, ksplit), dim3(kBlock), 0, st, T, spheres, verts, tris, K,
+                       kchunk, P, qb.thr, qb.best_d2, (unsigned long long*)nullptr, qb.best_idx); }
   }
-  hipLaunchKernelGGL(k_surface_final, dim3(qblocks), dim3(kBlock), 0, st, K, P, verts, tris, qb.best_d2, qb.best_idx,
-                     hint, cp, d2, tri);
+  { ProfScope _ps(st, KID_SURFACE_FINAL);
+    hipLaunchKernelGGL(k_surface_final, dim3(qblocks), dim3(kBlock), 0, st, K, P, verts, tris, qb.best_d2, qb.best_idx,
+                     hint, cp, d2, tri); }
 }
 
 void launch_vertex_query(hipStream_t st, int V, const double* verts, int K, const double* P, int* hint,
                          const QueryBuffers& qb, double* d2, int* idx) {
   if (K <= 0) return;
   const int qblocks = cdiv(K, kBlock);
-  hipLaunchKernelGGL(k_vertex_init, dim3(qblocks), dim3(kBlock), 0, st, K, P, V, verts, hint, qb.thr, qb.best_d2,
-                     qb.best_idx);
+  { ProfScope _ps(st, KID_VERTEX_INIT);
+    hipLaunchKernelGGL(k_vertex_init, dim3(qblocks), dim3(kBlock), 0, st, K, P, V, verts, hint, qb.thr, qb.best_d2,
+                     qb.best_idx); }
   if (V > 0) {
     const int vblocks = cdiv(V, kBlock);
     int ksplit, kchunk;
     split_queries(vblocks, K, &ksplit, &kchunk);
-    hipLaunchKernelGGL(k_vertex_pass<0>, dim3(vblocks, ksplit), dim3(kBlock), 0, st, V, verts, K, kchunk, P, qb.thr,
-                       (const unsigned long long*)nullptr, qb.best_d2, (int*)nullptr);
-    hipLaunchKernelGGL(k_vertex_pass<1>, dim3(vblocks, ksplit), dim3(kBlock), 0, st, V, verts, K, kchunk, P, qb.thr,
-                       qb.best_d2, (unsigned long long*)nullptr, qb.best_idx);
+    { ProfScope _ps(st, KID_VERTEX_PASS_A);
+      hipLaunchKernelGGL(k_vertex_pass<0>, dim3(vblocks, ksplit), dim3(kBlock), 0, st, V, verts, K, kchunk, P, qb.thr,
+                       (const unsigned long long*)nullptr, qb.best_d2, (int*)nullptr); }
+    { ProfScope _ps(st, KID_VERTEX_PASS_B);
+      hipLaunchKernelGGL(k_vertex_pass<1>, dim3(vblocks, ksplit), dim3(kBlock), 0, st, V, verts, K, kchunk, P, qb.thr,
+                       qb.best_d2, (unsigned long long*)nullptr, qb.best_idx); }
   }
-  hipLaunchKernelGGL(k_vertex_final, dim3(qblocks), dim3(kBlock), 0, st, K, qb.best_d2, qb.best_idx, hint, d2, idx);
+  { ProfScope _ps(st, KID_VERTEX_FINAL);
+    hipLaunchKernelGGL(k_vertex_final, dim3(qblocks), dim3(kBlock), 0, st, K, qb.best_d2, qb.best_idx, hint, d2, idx); }
 }
 
 }  // namespace icp

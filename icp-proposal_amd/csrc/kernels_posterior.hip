@@ -429,8 +429,9 @@ void launch_correspond_model(hipStream_t st, int K, const double* x, const doubl
                              const double* ref, const double* mean, const int* tris, const int* adj_off,
                              const int* adj, const CorrBuffers& cb) {
   if (K <= 0) return;
-  hipLaunchKernelGGL(k_correspond_model, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, K, x, cp, nnv, tgt_boundary,
-                     boundary_aware, pose, ref, mean, tris, adj_off, adj, cb);
+  { ProfScope _ps(st, KID_CORRESPOND);
+    hipLaunchKernelGGL(k_correspond_model, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, K, x, cp, nnv, tgt_boundary,
+                     boundary_aware, pose, ref, mean, tris, adj_off, adj, cb); }
 }
 
 void launch_correspond_target(hipStream_t st, int K, const double* x, const double* tpts, const int* nn_id,
@@ -438,26 +439,30 @@ void launch_correspond_target(hipStream_t st, int K, const double* x, const doub
                               const double* ref, const double* mean, const int* tris, const int* adj_off,
                               const int* adj, const CorrBuffers& cb) {
   if (K <= 0) return;
-  hipLaunchKernelGGL(k_correspond_target, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, K, x, tpts, nn_id, model_boundary,
-                     boundary_aware, pose, ref, mean, tris, adj_off, adj, cb);
+  { ProfScope _ps(st, KID_CORRESPOND);
+    hipLaunchKernelGGL(k_correspond_target, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, K, x, tpts, nn_id, model_boundary,
+                     boundary_aware, pose, ref, mean, tris, adj_off, adj, cb); }
 }
 
 void launch_regression(hipStream_t st, int K, int r, const double* Q, const CorrBuffers& cb, double w_tangent,
                        double kappa, double* Maug) {
   int nb = cdiv(r + 1, 16);
-  hipLaunchKernelGGL(k_regression, dim3(nb, nb), dim3(kBlock), 0, st, K, r, Q, cb, w_tangent, kappa, Maug);
+  { ProfScope _ps(st, KID_REGRESSION);
+    hipLaunchKernelGGL(k_regression, dim3(nb, nb), dim3(kBlock), 0, st, K, r, Q, cb, w_tangent, kappa, Maug); }
 }
 
 void launch_posterior_factor(hipStream_t st, int r, const double* Maug, const double* G, double sigma2, double* M,
                              double* L, double* alpha, double* L2, int* status) {
   int use_lds = r * r <= kLdsDoubles;
   size_t shmem = use_lds ? sizeof(double) * r * r : 0;
-  hipLaunchKernelGGL(k_posterior_factor, dim3(2), dim3(kBlock), shmem, st, r, Maug, G, sigma2, M, L, alpha, L2, status, use_lds);
+  { ProfScope _ps(st, KID_FACTOR);
+    hipLaunchKernelGGL(k_posterior_factor, dim3(2), dim3(kBlock), shmem, st, r, Maug, G, sigma2, M, L, alpha, L2, status, use_lds); }
 }
 
 void launch_transition_tail(hipStream_t st, int r, const double* alpha, const double* M, const double* L2,
                             const double* G, const double* c_from, const double* c_to, double step, double* out) {
-  hipLaunchKernelGGL(k_transition_tail, dim3(1), dim3(kBlock), 0, st, r, alpha, M, L2, G, c_from, c_to, step, out);
+  { ProfScope _ps(st, KID_TAIL);
+    hipLaunchKernelGGL(k_transition_tail, dim3(1), dim3(kBlock), 0, st, r, alpha, M, L2, G, c_from, c_to, step, out); }
 }
 
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, double* V, double* S,
@@ -465,22 +470,26 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
   int a_in_lds = r * r <= kLdsDoubles;
   int v_in_lds = 2 * r * r <= kLdsDoubles;
   size_t shmem = sizeof(double) * ((a_in_lds ? r * r : 0) + (v_in_lds ? r * r : 0));
-  hipLaunchKernelGGL(k_posterior_eigen, dim3(1), dim3(kBlock), shmem, st, r, M, sqrt_lambda, V, S, work, status, a_in_lds, v_in_lds);
+  { ProfScope _ps(st, KID_EIGEN);
+    hipLaunchKernelGGL(k_posterior_eigen, dim3(1), dim3(kBlock), shmem, st, r, M, sqrt_lambda, V, S, work, status, a_in_lds, v_in_lds); }
 }
 
 void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,
                     const double* inv_sqrt_lambda, const double* G, const double* Lg, const double* c,
                     const double* z, double step, double* c_out) {
-  hipLaunchKernelGGL(k_propose, dim3(1), dim3(kBlock), 0, st, r, alpha, V, S, inv_sqrt_lambda, G, Lg, c, z, step, c_out);
+  { ProfScope _ps(st, KID_PROPOSE);
+    hipLaunchKernelGGL(k_propose, dim3(1), dim3(kBlock), 0, st, r, alpha, V, S, inv_sqrt_lambda, G, Lg, c, z, step, c_out); }
 }
 
 void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mean, double sigma, double* out) {
-  hipLaunchKernelGGL(k_sum_gauss_logpdf, dim3(1), dim3(kBlock), 0, st, K, d2, mean, sigma, out);
+  { ProfScope _ps(st, KID_REDUCE);
+    hipLaunchKernelGGL(k_sum_gauss_logpdf, dim3(1), dim3(kBlock), 0, st, K, d2, mean, sigma, out); }
 }
 
 void launch_dist_stats(hipStream_t st, int K, const double* d2, const unsigned char* flags, const int* idx,
                        int n_flags, double* out) {
-  hipLaunchKernelGGL(k_dist_stats, dim3(1), dim3(kBlock), 0, st, K, d2, flags, idx, n_flags, out);
+  { ProfScope _ps(st, KID_REDUCE);
+    hipLaunchKernelGGL(k_dist_stats, dim3(1), dim3(kBlock), 0, st, K, d2, flags, idx, n_flags, out); }
 }
 
 }  // namespace icp

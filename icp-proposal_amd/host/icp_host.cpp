@@ -1,0 +1,170 @@
+// icp_host.cpp — SamplingRegistration.runfitting mirrored over the C ABI (see icp_host.hpp / icp_host.h).
+#include "icp_host.h"
+
+#include <memory>
+#include <string>
+
+#include "icp_host.hpp"
+
+using namespace icphost;
+
+namespace {
+thread_local std::string g_host_err;
+
+struct RecordLogger : AcceptRejectLogger {
+  double* out = nullptr;
+  int64_t index = 0, n_accept = 0;
+  int P = 0;
+  void write(int status, const ModelFittingParameters& state, int leaf, double logp) {
+    if (out) {
+      out[0] = (double)index;
+      out[1] = status;
+      out[2] = leaf;
+      out[3] = logp;
+      std::memcpy(out + ICP_HOST_RECORD_HEADER, state.data(), sizeof(double) * P);
+      out += ICP_HOST_RECORD_HEADER + P;
+    }
+    ++index;
+  }
+  void accept(const ModelFittingParameters&, const ModelFittingParameters& sample, int leaf, double logp) override {
+    ++n_accept;
+    write(1, sample, leaf, logp);
+  }
+  void reject(const ModelFittingParameters& current, const ModelFittingParameters&, int leaf, double logp) override {
+    write(0, current, leaf, logp);
+  }
+};
+}  // namespace
+
+struct icp_host_chain {
+  icp_ctx* ctx = nullptr;
+  int r = 0;
+  uint64_t seed = 0;
+  std::vector<std::unique_ptr<ProposalGeneratorWithTransition>> owned;
+  std::vector<NonRigidIcpProposal*> icp;
+  MixtureProposal* root = nullptr;
+  std::unique_ptr<ModelPriorEvaluator> prior;
+  std::unique_ptr<NativeLikelihoodEvaluator> likelihood;
+  ProductEvaluator product;
+  std::unique_ptr<MetropolisHastings> mh;
+  ChainPrefetcher prefetcher;
+  ModelFittingParameters current;
+  RecordLogger logger;
+  double current_p = 0.0;
+};
+
+template <class F>
+static int host_guard(F&& f) {
+  try {
+    f();
+    return ICP_OK;
+  } catch (const NativeError& e) {
+    g_host_err = e.what();
+    return e.status;
+  } catch (const std::exception& e) {
+    g_host_err = e.what();
+    return ICP_ERR_NOT_FINITE;
+  }
+}
+
+extern "C" {
+
+const char* icp_host_last_error(void) { return g_host_err.c_str(); }
+
+int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const double* theta0, uint64_t seed,
+                          icp_host_chain** out) {
+  if (out) *out = nullptr;
+  icp_host_chain* ch = nullptr;
+  int rc = host_guard([&] {
+    if (!ctx || !cfg || !theta0 || !out || cfg->n_icp < 0 || cfg->n_icp > 2) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chain_create");
+    ch = new icp_host_chain();
+    ch->ctx = ctx;
+    ch->r = icp_ctx_rank(ctx);
+    ch->seed = seed;
+    auto own = [&](ProposalGeneratorWithTransition* p) { ch->owned.emplace_back(p); return p; };
+    // MixedProposalDistributions.mixedProposalICP (MixedProposalDistributions.scala:48-68)
+    MixtureProposal* icpMix = nullptr;
+    if (cfg->n_icp > 0 && cfg->w_icp > 0) {
+      icpMix = static_cast<MixtureProposal*>(own(new MixtureProposal()));
+      for (int i = 0; i < cfg->n_icp; ++i) {
+        const char* dir = cfg->icp[i].direction == ICP_TARGET_SAMPLING ? "TargetSampling" : "ModelSampling";
+        auto* p = new NonRigidIcpProposal(ctx, cfg->icp[i], std::string("IcpProposal-") + dir + "-" + std::to_string(cfg->icp[i].step_length) + "Step");
+        p->leafId = i;
+        own(p);
+        ch->icp.push_back(p);
+        icpMix->add(cfg->icp_weight[i], p);
+      }
+    }
+    // MixedProposalDistributions.mixedRandomShapeProposal (:41-46): a one-component mixture
+    MixtureProposal* rwMix = nullptr;
+    if (cfg->w_rw > 0) {
+      rwMix = static_cast<MixtureProposal*>(own(new MixtureProposal()));
+      auto* p = new RandomShapeUpdateProposal(cfg->rw_sigma, "RandomShape-" + std::to_string(cfg->rw_sigma));
+      p->leafId = 2;
+      own(p);
+      rwMix->add(0.5, p);
+    }
+    // MixedProposalDistributions.mixedRandomPoseProposal (:29-39): six equally weighted 1-D walks
+    MixtureProposal* poseMix = nullptr;
+    if (cfg->w_pose > 0) {
+      poseMix = static_cast<MixtureProposal*>(own(new MixtureProposal()));
+      static const char* names[6] = {"RotationYaw", "RotationPitch", "RotationRoll", "TranslationX", "TranslationY", "TranslationZ"};
+      for (int a = 0; a < 6; ++a) {
+        const double sd = a < 3 ? cfg->pose_rot_sigma[a] : cfg->pose_trans_sigma[a - 3];
+        // YawAxis/PitchAxis/RollAxis perturb phi/theta/psi (PoseProposals.scala:40-48) = theta[4..6]; translations theta[1..3]
+        auto* p = new GaussianAxisPoseProposal(a < 3 ? 4 + a : 1 + (a - 3), sd, std::string(names[a]) + "-" + std::to_string(sd));
+        p->leafId = 3 + a;
+        own(p);
+        poseMix->add(0.5, p);
+      }
+    }
+    // outer mixture (IcpProposalRegistration.scala:72 / BfmFittingPartial.scala:70)
+    ch->root = static_cast<MixtureProposal*>(own(new MixtureProposal()));
+    if (poseMix) ch->root->add(cfg->w_pose, poseMix);
+    if (icpMix) ch->root->add(cfg->w_icp, icpMix);
+    if (rwMix) ch->root->add(cfg->w_rw, rwMix);
+    if (ch->root->generators.empty()) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chain_create: no proposals");
+    // ProductEvaluators.proximityAnd* (ProductEvaluators.scala:38-94): prior × likelihood
+    ch->prior.reset(new ModelPriorEvaluator(ch->r));
+    ch->likelihood.reset(new NativeLikelihoodEvaluator(ctx, cfg->eval));
+    ch->product.parts = {ch->prior.get(), ch->likelihood.get()};
+    ch->mh.reset(new MetropolisHastings(ch->root, &ch->product));
+    if (cfg->fused) {
+      ch->prefetcher.evaluator = ch->likelihood.get();
+      ch->prefetcher.icp = ch->icp;
+      ch->mh->prefetcher = &ch->prefetcher;
+    }
+    ch->current.allParameters.assign(theta0, theta0 + 10 + ch->r);
+    ch->logger.P = 10 + ch->r;
+    ch->current_p = ch->product.logValue(ch->current);
+    *out = ch;
+  });
+  if (rc != ICP_OK && ch) delete ch;
+  return rc;
+}
+
+int icp_host_chain_run(icp_host_chain* ch, int32_t n_steps, double* records) {
+  return host_guard([&] {
+    if (!ch || n_steps < 0) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chain_run");
+    ch->logger.out = records;
+    for (int s = 0; s < n_steps; ++s) {  // SamplingRegistration.scala:58-85: chain.iterator(...).take(n)
+      StepRandom rnd{ch->seed, (uint64_t)ch->logger.index};
+      ch->current = ch->mh->next(ch->current, rnd, &ch->logger);
+      ch->current_p = ch->mh->cached_current_p;
+    }
+    ch->logger.out = nullptr;
+  });
+}
+
+int icp_host_chain_state(icp_host_chain* ch, double* theta_out, double* logp_out, int64_t* steps_done, int64_t* accepted) {
+  if (!ch) return ICP_ERR_INVALID_ARG;
+  if (theta_out) std::memcpy(theta_out, ch->current.data(), sizeof(double) * (10 + ch->r));
+  if (logp_out) *logp_out = ch->current_p;
+  if (steps_done) *steps_done = ch->logger.index;
+  if (accepted) *accepted = ch->logger.n_accept;
+  return ICP_OK;
+}
+
+void icp_host_chain_destroy(icp_host_chain* ch) { delete ch; }
+
+}  // extern "C"

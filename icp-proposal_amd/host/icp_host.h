@@ -1,0 +1,46 @@
+/* icp_host.h — C entry points of libicp_host.so, the C++ host harness (see icp_host.hpp).
+ * NOT part of the drop-in boundary (that is include/icp_proposal.h): this is the build's own caller, mirroring
+ * SamplingRegistration.runfitting (api/sampling/SamplingRegistration.scala:45-93) so bench.py and the tests can
+ * drive whole chains without a Python interpreter in the per-step loop. */
+#ifndef ICP_HOST_H
+#define ICP_HOST_H
+#include <stdint.h>
+#include "../../include/icp_proposal.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icp_host_chain icp_host_chain;
+
+typedef struct {
+  int32_t n_icp;                 /* 0..2 NonRigidIcpProposal components (MixedProposalDistributions.scala:48-68) */
+  icp_proposal_params icp[2];
+  double icp_weight[2];          /* inner mixture weights (0.5 / 0.5) */
+  double w_icp;                  /* outer mixture: ICP mixture            (IcpProposalRegistration.scala:72: 0.90) */
+  double w_rw;                   /*                random shape walk       (0.10) */
+  double w_pose;                 /*                6-component pose walk   (BfmFittingPartial.scala:70: 0.55; 0 = none) */
+  double rw_sigma;               /* RandomShapeUpdateProposal stdev (0.1) */
+  double pose_rot_sigma[3];      /* yaw/pitch/roll stdevs (MixedProposalDistributions.scala:29: 0.01) */
+  double pose_trans_sigma[3];    /* x/y/z stdevs (0.1) */
+  icp_evaluator_params eval;     /* likelihood; the shape prior is always multiplied in (ProductEvaluators.scala:38-55) */
+  int32_t fused;                 /* 1 = prefetch each step's device work with ONE icp_chain_eval_step call */
+} icp_host_chain_config;
+
+/* fixed-size per-step record (the layout the multi-GPU log gather ships; mirrors jsonLogFormat,
+ * api/sampling/loggers/JSONAcceptRejectLogger.scala:35): [index, status(1 accept/0 reject), leaf proposal id,
+ * log product value of the chain state after the step, theta(10+r)]  =>  14 + r doubles */
+#define ICP_HOST_RECORD_HEADER 4
+
+ICP_API int icp_host_chain_create(icp_ctx *ctx, const icp_host_chain_config *cfg, const double *theta0, uint64_t seed,
+                                  icp_host_chain **out);
+/* runs n_steps more steps; records [n_steps * (4 + 10 + r)] may be NULL */
+ICP_API int icp_host_chain_run(icp_host_chain *chain, int32_t n_steps, double *records);
+ICP_API int icp_host_chain_state(icp_host_chain *chain, double *theta_out, double *logp_out, int64_t *steps_done,
+                                 int64_t *accepted);
+ICP_API void icp_host_chain_destroy(icp_host_chain *chain);
+ICP_API const char *icp_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

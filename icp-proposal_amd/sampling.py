@@ -1,0 +1,145 @@
+"""Chain driver: Python face of libicp_host.so (C++ mirror of SamplingRegistration.runfitting,
+api/sampling/SamplingRegistration.scala:45-93) plus the reference's experiment configurations.
+
+The per-step loop runs in C++ (icp-proposal_amd/host/); Python only builds the configuration and receives the
+fixed-size per-step records (layout: host/icp_host.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _native as nat
+from . import data as _data
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "libicp_host.so")
+RECORD_HEADER = 4
+_HOST = None
+
+
+class HostChainConfig(C.Structure):
+    _fields_ = [("n_icp", C.c_int32), ("icp", nat.ProposalParams * 2), ("icp_weight", C.c_double * 2),
+                ("w_icp", C.c_double), ("w_rw", C.c_double), ("w_pose", C.c_double), ("rw_sigma", C.c_double),
+                ("pose_rot_sigma", C.c_double * 3), ("pose_trans_sigma", C.c_double * 3),
+                ("eval", nat.EvaluatorParams), ("fused", C.c_int32)]
+
+
+def host_lib():
+    global _HOST
+    if _HOST is None:
+        nat.lib()  # the C ABI library first (no fallback if it is missing)
+        if not os.path.exists(HOST_LIB_PATH):
+            raise nat.IcpNativeError(-2, "load", f"{HOST_LIB_PATH} not built")
+        L = C.CDLL(HOST_LIB_PATH)
+        L.icp_host_chain_create.restype = C.c_int
+        L.icp_host_chain_create.argtypes = [C.c_void_p, C.POINTER(HostChainConfig), nat.c_double_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.icp_host_chain_run.restype = C.c_int
+        L.icp_host_chain_run.argtypes = [C.c_void_p, C.c_int32, nat.c_double_p]
+        L.icp_host_chain_state.restype = C.c_int
+        L.icp_host_chain_state.argtypes = [C.c_void_p, nat.c_double_p, nat.c_double_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.icp_host_chain_destroy.restype = None
+        L.icp_host_chain_destroy.argtypes = [C.c_void_p]
+        L.icp_host_last_error.restype = C.c_char_p
+        _HOST = L
+    return _HOST
+
+
+def _dp(a):
+    return a.ctypes.data_as(nat.c_double_p)
+
+
+class ChainSetup:
+    """Plain description of one experiment: proposals + evaluator (everything the reference sets in a `main`)."""
+
+    def __init__(self):
+        self.icp = []          # list of dicts: direction, step, sigma_t, sigma_n, boundary_aware, n_model_ids, target_pts, weight
+        self.w_icp, self.w_rw, self.w_pose = 0.9, 0.1, 0.0
+        self.rw_sigma = 0.1
+        self.pose_rot_sigma = (0.01, 0.01, 0.01)
+        self.pose_trans_sigma = (0.1, 0.1, 0.1)
+        self.eval = dict(kind=0, mode=0, n_model_ids=0, target_pts=np.zeros((0, 3)), gauss_mean=0.0, gauss_sigma=1.0, exp_rate=1.0)
+        self.fused = True
+
+    def to_c(self):
+        cfg = HostChainConfig()
+        keep = []
+        cfg.n_icp = len(self.icp)
+        for i, p in enumerate(self.icp):
+            tp = np.ascontiguousarray(p.get("target_pts", np.zeros((0, 3))), dtype=np.float64).reshape(-1, 3)
+            keep.append(tp)
+            cfg.icp[i] = nat.ProposalParams(p["step"], p["sigma_t"], p["sigma_n"], p["direction"], int(p.get("boundary_aware", True)),
+                                            int(p.get("n_model_ids", 0)), tp.shape[0], _dp(tp))
+            cfg.icp_weight[i] = p.get("weight", 0.5)
+        cfg.w_icp, cfg.w_rw, cfg.w_pose, cfg.rw_sigma = self.w_icp, self.w_rw, self.w_pose, self.rw_sigma
+        for a in range(3):
+            cfg.pose_rot_sigma[a] = self.pose_rot_sigma[a]
+            cfg.pose_trans_sigma[a] = self.pose_trans_sigma[a]
+        e = self.eval
+        tp = np.ascontiguousarray(e["target_pts"], dtype=np.float64).reshape(-1, 3)
+        keep.append(tp)
+        cfg.eval = nat.EvaluatorParams(e["kind"], e["mode"], int(e["n_model_ids"]), tp.shape[0], _dp(tp), e["gauss_mean"],
+                                       e["gauss_sigma"], e["exp_rate"])
+        cfg.fused = int(self.fused)
+        cfg._keep = keep
+        return cfg
+
+
+def femur_icp_proposal_registration(model, target, n_icp_points=None, n_eval_points=None, direction="ModelAndTargetSampling",
+                                    eval_mode=0, fused=True) -> ChainSetup:
+    """The configuration of apps/femur/IcpProposalRegistration.scala:59-85: K = 2·rank proposal points, 4·rank evaluator
+    points, 0.9 ICP(Model+Target, σt=10, σn=5, step 0.1) + 0.1 random walk(0.1), prior × independent Gaussian(0, 2)."""
+    r = model.rank
+    k_icp = 2 * r if n_icp_points is None else n_icp_points
+    k_ev = 4 * r if n_eval_points is None else n_eval_points
+    s = ChainSetup()
+    tp = _data.decimated_point_subset(target, k_icp)
+    if direction in ("TargetSampling", "ModelAndTargetSampling"):  # MixedProposalDistributions.scala:56-65 order
+        s.icp.append(dict(direction=1, step=0.1, sigma_t=10.0, sigma_n=5.0, boundary_aware=True, target_pts=tp, weight=0.5))
+    if direction in ("ModelSampling", "ModelAndTargetSampling"):
+        s.icp.append(dict(direction=0, step=0.1, sigma_t=10.0, sigma_n=5.0, boundary_aware=True, n_model_ids=min(k_icp, model.n_points), weight=0.5))
+    s.eval = dict(kind=0, mode=eval_mode, n_model_ids=min(k_ev, model.n_points), target_pts=_data.decimated_point_subset(target, k_ev),
+                  gauss_mean=0.0, gauss_sigma=2.0, exp_rate=1.0)
+    s.fused = fused
+    return s
+
+
+class SamplingRegistration:
+    """SamplingRegistration (api/sampling/SamplingRegistration.scala:37-93) over one IcpContext."""
+
+    def __init__(self, ctx, setup: ChainSetup, initial_parameters=None, seed: int = 1024):
+        from .api import initial_parameters as _init
+        self.ctx, self.setup = ctx, setup
+        self.P = 10 + ctx.rank
+        theta0 = np.ascontiguousarray(initial_parameters if initial_parameters is not None else _init(ctx.model), dtype=np.float64)
+        self._cfg = setup.to_c()
+        h = C.c_void_p()
+        st = host_lib().icp_host_chain_create(ctx.h, C.byref(self._cfg), _dp(theta0), seed, C.byref(h))
+        if st != 0:
+            raise nat.IcpNativeError(st, "icp_host_chain_create", (host_lib().icp_host_last_error() or b"").decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            host_lib().icp_host_chain_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def run(self, n_steps: int, want_records: bool = True):
+        """n_steps more MH steps; returns records [n_steps, 4 + 10 + r] (index, accepted, leaf id, log value, theta)."""
+        rec = np.zeros((n_steps, RECORD_HEADER + self.P)) if want_records else None
+        st = host_lib().icp_host_chain_run(self.h, n_steps, _dp(rec) if want_records else None)
+        if st != 0:
+            raise nat.IcpNativeError(st, "icp_host_chain_run", (host_lib().icp_host_last_error() or b"").decode())
+        return rec
+
+    def state(self):
+        theta = np.zeros(self.P)
+        logp = C.c_double()
+        n, a = C.c_int64(), C.c_int64()
+        host_lib().icp_host_chain_state(self.h, _dp(theta), C.byref(logp), C.byref(n), C.byref(a))
+        return theta, logp.value, n.value, a.value

@@ -191,6 +191,17 @@ ICP_API int icp_prior_log_value(int32_t rank, const double *theta, double *out);
 ICP_API int icp_chain_eval_step(icp_evaluator *e, int32_t n_props, icp_proposal *const *props, const double *theta_cur,
                                 const double *theta_prop, double *log_value_prop, double *fwd, double *bwd);
 
+/* ---------------------------------------------------------------- instrumentation (bench.py's roofline leg)
+ * Between start and stop every kernel the context launches is bracketed by HIP events on the context stream;
+ * stop returns one row per kernel name.  Off by default (adds nothing to the launch path). */
+typedef struct {
+  char name[40];
+  int64_t calls;
+  double total_ms, min_ms, max_ms;
+} icp_kernel_stat;
+ICP_API int icp_ctx_profile_start(icp_ctx *ctx, int32_t max_launches);
+ICP_API int icp_ctx_profile_stop(icp_ctx *ctx, icp_kernel_stat *stats, int32_t capacity /* >= 32 */, int32_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif
