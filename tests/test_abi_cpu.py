@@ -1,0 +1,91 @@
+"""CPU: the drop-in boundary itself — the C ABI library builds for gfx950, loads, and exports every symbol that
+include/icp_proposal.h declares; without a GPU it refuses to work instead of falling back to a CPU path."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_theta
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "icp_proposal.h")).read()
+    return sorted(set(re.findall(r"ICP_API\s+[\w\s\*]+?\b(icp_\w+)\s*\(", text)))
+
+
+def test_header_symbols_exported(pkg):
+    lib = pkg._native.lib()
+    names = declared_symbols()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/icp_proposal.h but not exported"
+    assert set(names) == set(pkg._native.SIGNATURES), "ctypes binding and header disagree"
+
+
+def test_library_is_gfx950_only(pkg):
+    """the fat binary inside the shared library carries exactly one GPU target: gfx950"""
+    blob = open(pkg._native.LIB_PATH, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_struct_layouts_match_header(pkg):
+    nat = pkg._native
+    assert ctypes.sizeof(nat.ModelDesc) == 56 and ctypes.sizeof(nat.MeshDesc) == 24
+    assert ctypes.sizeof(nat.ProposalParams) == 48 and ctypes.sizeof(nat.EvaluatorParams) == 48
+    assert ctypes.sizeof(nat.PosteriorView) == 72 and ctypes.sizeof(nat.KernelStat) == 72
+
+
+def test_prior_is_host_arithmetic(pkg, femur50):
+    model, _ = femur50
+    theta = make_theta(model, 3)
+    got = pkg.ModelPriorEvaluator(model.rank).logValue(theta)
+    assert np.isclose(got, -0.5 * theta[10:] @ theta[10:] - 0.5 * model.rank * np.log(2 * np.pi), rtol=1e-14)
+
+
+def test_status_strings(pkg):
+    lib = pkg._native.lib()
+    assert lib.icp_status_string(0) == b"ok" and b"HIP" in lib.icp_status_string(-2)
+
+
+def _gpu_present():
+    try:
+        return subprocess.run(["/opt/rocm/bin/rocminfo"], capture_output=True, text=True, timeout=30).stdout.count("gfx950") > 0
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_gpu_present(), reason="a GPU is present; this checks the no-GPU behaviour")
+def test_no_cpu_fallback(pkg, femur50):
+    model, target = femur50
+    with pytest.raises(pkg._native.IcpNativeError) as e:
+        pkg.IcpContext(model, target)
+    assert e.value.status == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_invalid_arguments_rejected_before_device(pkg, femur50):
+    model, target = femur50
+    lib, nat = pkg._native.lib(), pkg._native
+    h = ctypes.c_void_p()
+    assert lib.icp_ctx_create(None, None, 0, ctypes.byref(h)) == -1
+    bad = model.cells.copy()
+    bad[0, 0] = model.n_points + 5
+    md = nat.ModelDesc(model.n_points, bad.shape[0], model.rank, model.ref_points.ctypes.data_as(nat.c_double_p), None,
+                       model.basis.ctypes.data_as(nat.c_double_p), model.variance.ctypes.data_as(nat.c_double_p),
+                       bad.ctypes.data_as(nat.c_int_p))
+    td = nat.MeshDesc(target.n_points, target.n_cells, target.points.ctypes.data_as(nat.c_double_p),
+                      target.cells.ctypes.data_as(nat.c_int_p))
+    assert lib.icp_ctx_create(ctypes.byref(md), ctypes.byref(td), 0, ctypes.byref(h)) == -1
+    assert b"out of range" in lib.icp_last_error()
+
+
+def test_synthetic_target_sizes(pkg):
+    """BASELINE.json configs[1]: 6-way subdivision of the femur target -> 58,322 vertices / 116,640 triangles."""
+    _, big = pkg.data.synthetic_femur_target()
+    assert (big.n_points, big.n_cells) == (58322, 116640)
+    assert pkg.data.boundary_vertex_flags(big).sum() == 0
+    _, again = pkg.data.synthetic_femur_target()
+    assert np.array_equal(big.points, again.points)  # seeded
