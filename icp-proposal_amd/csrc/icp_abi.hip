@@ -120,6 +120,35 @@ bool host_cholesky(int n, std::vector<double>& a) {
   return true;
 }
 
+// inverse of an SPD matrix from its Cholesky factor (one-off host work at context creation)
+bool host_spd_inverse(int n, const std::vector<double>& a, std::vector<double>& inv) {
+  std::vector<double> l = a;
+  if (!host_cholesky(n, l)) return false;
+  inv.assign((size_t)n * n, 0.0);
+  std::vector<double> e(n);
+  for (int c = 0; c < n; ++c) {
+    std::fill(e.begin(), e.end(), 0.0);
+    e[c] = 1.0;
+    for (int i = 0; i < n; ++i) {
+      double v = e[i];
+      for (int k = 0; k < i; ++k) v -= l[(size_t)i * n + k] * e[k];
+      e[i] = v / l[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double v = e[i];
+      for (int k = i + 1; k < n; ++k) v -= l[(size_t)k * n + i] * e[k];
+      e[i] = v / l[(size_t)i * n + i];
+    }
+    for (int i = 0; i < n; ++i) inv[(size_t)i * n + c] = e[i];
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      double v = 0.5 * (inv[(size_t)i * n + j] + inv[(size_t)j * n + i]);
+      inv[(size_t)i * n + j] = inv[(size_t)j * n + i] = v;
+    }
+  return true;
+}
+
 void check_triangles(int V, int T, const int32_t* tris, const char* what) {
   for (int i = 0; i < 3 * T; ++i)
     if (tris[i] < 0 || tris[i] >= V) fail(ICP_ERR_INVALID_ARG, std::string(what) + ": triangle vertex id out of range");
@@ -178,7 +207,7 @@ struct icp_ctx {
   hipStream_t stream = nullptr;
   std::recursive_mutex mu;
   int N = 0, T = 0, r = 0;
-  DBuf<double> ref, mean, Q, Qp, sqrt_lambda, inv_sqrt_lambda, G, Lg;
+  DBuf<double> ref, mean, Q, Qp, sqrt_lambda, inv_sqrt_lambda, G, Ginv, P;  // P = (G + σ²I)⁻¹
   DBuf<int> tris, adj_off, adj;
   DBuf<uint8_t> boundary;
   int n_boundary = 0;
@@ -320,7 +349,7 @@ struct PosteriorEntry {
   DBuf<int> id, aux;
   DBuf<double> pt, nhat, e;
   DBuf<uint8_t> keep;
-  DBuf<double> coeffs, Maug, M, L, alpha, L2, V, S;
+  DBuf<double> coeffs, M, alpha, V, Vt, S;
   int status_off = 0;  // this entry's 3 ints inside the proposal's status buffer
   CorrBuffers corr() const { return CorrBuffers{id.p, aux.p, pt.p, keep.p, nhat.p, e.p}; }
 };
@@ -334,7 +363,11 @@ struct icp_proposal {
   DBuf<double> target_pts;
   DBuf<int> hint_nn;      // TargetSampling: last nearest model vertex of each target point
   DBuf<int> nn_id;
-  DBuf<double> work;      // r*r scratch of the eigen kernel
+  DBuf<double> work;      // r*r scratch of the eigen / direct-tail kernels
+  DBuf<double> Mpart;     // split-K partial normal matrices of the regression kernel
+  DBuf<double> fscratch;  // (r+1)·r factorisation scratch (ranks too large for LDS)
+  DBuf<double> warmV;     // eigenvectors of the most recent posterior: warm start of the next eigen-decomposition
+  bool warm_valid = false;
   DBuf<int> status;       // 3 ints per memo entry: {chol(M), chol(G+σ²M), eigen}
   std::vector<int> h_status;
   std::unique_ptr<PosteriorEntry[]> memo;
@@ -422,8 +455,8 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
   if (!e.M.p) {
     e.id.alloc(Ka); e.aux.alloc(Ka); e.pt.alloc(3 * (size_t)Ka); e.nhat.alloc(3 * (size_t)Ka); e.e.alloc(3 * (size_t)Ka);
     e.keep.alloc(Ka);
-    e.coeffs.alloc(r); e.Maug.alloc((size_t)(r + 1) * (r + 1)); e.M.alloc((size_t)r * r); e.L.alloc((size_t)r * r);
-    e.alpha.alloc(r); e.L2.alloc((size_t)r * r); e.V.alloc((size_t)r * r); e.S.alloc(r);
+    e.coeffs.alloc(r); e.M.alloc((size_t)r * r);
+    e.alpha.alloc(r); e.V.alloc((size_t)r * r); e.Vt.alloc((size_t)r * r); e.S.alloc(r);
     e.status_off = 3 * (int)(&e - &memo[0]);
   }
   e.theta.assign(theta, theta + P);
@@ -451,27 +484,33 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
   // :152 interpolatedModel.posterior(uncertainDisplacements)
   const double wt = 1.0 / (prm.tangential_noise * prm.tangential_noise);
   const double kappa = 1.0 / (prm.noise_along_normal * prm.noise_along_normal) - wt;
-  launch_regression(c.stream, K, r, c.Q.p, e.corr(), wt, kappa, e.Maug.p);
-  launch_posterior_factor(c.stream, r, e.Maug.p, c.G.p, kSigma2, e.M.p, e.L.p, e.alpha.p, e.L2.p, status.p + e.status_off);
+  int splits = 1;
+  launch_regression(c.stream, K, r, c.Q.p, e.corr(), wt, kappa, Mpart.p, &splits);
+  PosteriorFactorIO io{Mpart.p, splits, e.M.p, e.alpha.p, status.p + e.status_off, fscratch.p};
+  launch_posterior_factor(c.stream, r, 1, &io);
   return e;
 }
 
 void icp_proposal::ensure_eigen(PosteriorEntry& e) {
   if (e.eig_valid) return;
   icp_ctx& c = *ctx;
-  launch_posterior_eigen(c.stream, c.r, e.M.p, c.sqrt_lambda.p, e.V.p, e.S.p, work.p, status.p + e.status_off + 2);
+  launch_posterior_eigen(c.stream, c.r, e.M.p, c.sqrt_lambda.p, warm_valid ? warmV.p : nullptr, e.V.p, e.Vt.p, e.S.p, work.p,
+                         status.p + e.status_off + 2);
+  HIP_OK(hipMemcpyAsync(warmV.p, e.V.p, sizeof(double) * c.r * c.r, hipMemcpyDeviceToDevice, c.stream));
+  warm_valid = true;
   e.eig_valid = true;
 }
 
 // must be called after a synchronising copy of `status` into h_status
 void icp_proposal::check_status(PosteriorEntry& e) {
   const int* st = h_status.data() + e.status_off;
-  if (st[0] || st[1]) {
+  if (st[0]) {
     e.valid = false;
     fail(ICP_ERR_NOT_SPD, "posterior normal equations are not positive definite (non-finite correspondences?)");
   }
   if (st[2]) {
     e.eig_valid = false;
+    warm_valid = false;
     fail(ICP_ERR_NOT_FINITE, "posterior eigen-decomposition did not converge");
   }
 }
@@ -672,9 +711,10 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     }
     for (int a = 0; a < r; ++a)
       for (int b = a + 1; b < r; ++b) G[(size_t)a * r + b] = G[(size_t)b * r + a];
-    std::vector<double> Lg = G;
-    for (int a = 0; a < r; ++a) Lg[(size_t)a * r + a] += kSigma2;
-    if (!host_cholesky(r, Lg)) fail(ICP_ERR_NOT_SPD, "Q^T Q + sigma^2 I is not positive definite");
+    std::vector<double> Gs = G, Ginv, Pinv;
+    for (int a = 0; a < r; ++a) Gs[(size_t)a * r + a] += kSigma2;
+    if (!host_spd_inverse(r, Gs, Pinv)) fail(ICP_ERR_NOT_SPD, "Q^T Q + sigma^2 I is not positive definite");
+    if (!host_spd_inverse(r, G, Ginv)) fail(ICP_ERR_NOT_SPD, "Q^T Q is not positive definite (linearly dependent basis functions)");
     std::vector<double> mean((size_t)3 * N, 0.0);
     if (model->mean_deformation) std::memcpy(mean.data(), model->mean_deformation, sizeof(double) * 3 * N);
     std::vector<uint8_t> mb;
@@ -690,7 +730,8 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->sqrt_lambda.upload(sl.data(), r);
     ctx->inv_sqrt_lambda.upload(isl.data(), r);
     ctx->G.upload(G.data(), G.size());
-    ctx->Lg.upload(Lg.data(), Lg.size());
+    ctx->Ginv.upload(Ginv.data(), Ginv.size());
+    ctx->P.upload(Pinv.data(), Pinv.size());
     ctx->tris.upload(model->triangles, (size_t)3 * T);
     ctx->adj_off.upload(off.data(), off.size());
     ctx->adj.upload(adj.data(), adj.size());
@@ -913,6 +954,9 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     }
     p->prm.target_points = nullptr;  // caller memory is not retained
     p->work.alloc((size_t)ctx->r * ctx->r);
+    p->Mpart.alloc((size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1));
+    p->fscratch.alloc((size_t)(ctx->r + 1) * ctx->r);
+    p->warmV.alloc((size_t)ctx->r * ctx->r);
     p->status.alloc(3 * kPosteriorMemo);
     p->status.fill_bytes(0);
     p->h_status.assign(3 * kPosteriorMemo, 0);
@@ -946,7 +990,7 @@ int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, 
     PosteriorEntry& e = p->posterior(theta, false);  // NonRigidIcpProposal.scala:54
     p->ensure_eigen(e);
     const double* dz = c.stage(z, r);                 // :55 the caller's standard normals
-    launch_propose(c.stream, r, e.alpha.p, e.V.p, e.S.p, c.inv_sqrt_lambda.p, c.G.p, c.Lg.p, e.coeffs.p, dz,
+    launch_propose(c.stream, r, e.alpha.p, e.V.p, e.S.p, c.inv_sqrt_lambda.p, c.P.p, kSigma2, e.coeffs.p, dz,
                    p->prm.step_length, c.d_res.p);
     std::vector<int> ids;
     std::vector<uint8_t> keep;
@@ -983,10 +1027,18 @@ int icp_proposal_log_transition(icp_proposal* p, const double* theta_from, const
     Bound _b(&c);
     PosteriorEntry& e = p->posterior(theta_from, false);  // :76
     const double* dto = c.stage(theta_to + 10, c.r);
-    launch_transition_tail(c.stream, c.r, e.alpha.p, e.M.p, e.L2.p, c.G.p, e.coeffs.p, dto, p->prm.step_length, c.d_res.p);
+    TransitionTailIO io{e.alpha.p, e.M.p, e.coeffs.p, dto, p->prm.step_length, c.d_res.p, c.d_status.p};
+    launch_transition_tails(c.stream, c.r, 1, &io, c.Ginv.p, kSigma2);
     sync_proposal_status(p);
-    c.finish(1, 0);
+    c.finish(1, 1);
     p->check_status(e);
+    if (c.h_status[0] != 0) {  // the fixed-point form did not contract for this model/noise: direct factorisation
+      const double* dto2 = c.stage(theta_to + 10, c.r);
+      io.c_to = dto2;
+      launch_transition_tail_direct(c.stream, c.r, io, c.G.p, kSigma2, p->work.p);
+      c.finish(1, 1);
+      if (c.h_status[0] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
+    }
     if (std::isnan(c.h_res[0])) fail(ICP_ERR_NOT_FINITE, "NaN transition probability");
     *out = c.h_res[0];
   });
@@ -1124,6 +1176,8 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
     const bool shape_only = pose_equal(theta_cur, theta_prop);
     PosteriorEntry* ec[8];
     PosteriorEntry* ep[8];
+    TransitionTailIO tails[16];
+    int n_tails = 0;
     if (shape_only && n_props > 0) {
       const double* d_cur = c.stage(theta_cur + 10, r);
       const double* d_prop = c.stage(theta_prop + 10, r);
@@ -1131,14 +1185,33 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         icp_proposal* p = props[i];
         ec[i] = &p->posterior(theta_cur, false);
         ep[i] = &p->posterior(theta_prop, false);
-        launch_transition_tail(c.stream, r, ec[i]->alpha.p, ec[i]->M.p, ec[i]->L2.p, c.G.p, d_cur, d_prop, p->prm.step_length,
-                               c.d_res.p + 8 + 2 * i);
-        launch_transition_tail(c.stream, r, ep[i]->alpha.p, ep[i]->M.p, ep[i]->L2.p, c.G.p, d_prop, d_cur, p->prm.step_length,
-                               c.d_res.p + 9 + 2 * i);
+        tails[n_tails] = TransitionTailIO{ec[i]->alpha.p, ec[i]->M.p, d_cur, d_prop, p->prm.step_length, c.d_res.p + 8 + n_tails,
+                                          c.d_status.p + n_tails};
+        ++n_tails;
+        tails[n_tails] = TransitionTailIO{ep[i]->alpha.p, ep[i]->M.p, d_prop, d_cur, p->prm.step_length, c.d_res.p + 8 + n_tails,
+                                          c.d_status.p + n_tails};
+        ++n_tails;
         sync_proposal_status(p);
       }
+      for (int t0 = 0; t0 < n_tails; t0 += 8)
+        launch_transition_tails(c.stream, r, std::min(8, n_tails - t0), tails + t0, c.Ginv.p, kSigma2);
     }
-    c.finish(8 + 2 * (size_t)n_props, 0);
+    c.finish(8 + (size_t)n_tails, (size_t)n_tails);
+    for (int t = 0; t < n_tails; ++t)
+      if (c.h_status[t] != 0) {  // rare: fixed-point tail did not contract -> direct kernel, one at a time
+        std::vector<double> saved(c.h_res, c.h_res + 8 + n_tails);
+        icp_proposal* p = props[t / 2];
+        TransitionTailIO io = tails[t];
+        io.c_from = c.stage((t % 2 == 0 ? theta_cur : theta_prop) + 10, r);
+        io.c_to = c.stage((t % 2 == 0 ? theta_prop : theta_cur) + 10, r);
+        io.out = c.d_res.p;
+        io.status = c.d_status.p + 32;
+        launch_transition_tail_direct(c.stream, r, io, c.G.p, kSigma2, p->work.p);
+        c.finish(1, 64);
+        if (c.h_status[32] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
+        saved[8 + t] = c.h_res[0];
+        std::memcpy(c.h_res, saved.data(), sizeof(double) * saved.size());
+      }
     if (need_eval) {
       m = eval_store(e, theta_prop);
       m->status = finish_eval(e, c.h_res, &m->value, m->aux);

@@ -85,25 +85,30 @@ void launch_correspond_target(hipStream_t st, int K, const double* x, const doub
                               const double* ref, const double* mean, const int* tris, const int* adj_off,
                               const int* adj, const CorrBuffers& cb);
 
-// K5a: Maug[(r+1)x(r+1)] = Σ_kept [Q_i | e_i]^T Σ_i^-1 [Q_i | e_i]  (M = I + Maug[:r,:r], b = Maug[:r,r])
+// K5a (f64 MFMA): partial sums Mpart[s][(r+1)x(r+1)] of Σ_kept [Q_i | e_i]^T Σ_i^-1 [Q_i | e_i]; *splits_out = number of partials.
+// Mpart must hold regression_splits(K)·(r+1)² doubles.
+int regression_splits(int K);
 void launch_regression(hipStream_t st, int K, int r, const double* Q, const CorrBuffers& cb, double w_tangent,
-                       double kappa, double* Maug);
+                       double kappa, double* Mpart, int* splits_out);
 
-// K5b: block 0: M = I + Maug, L = chol(M), alpha = M^-1 b;  block 1: L2 = chol(G + sigma2·M).  status[0..1] != 0 on failure.
-void launch_posterior_factor(hipStream_t st, int r, const double* Maug, const double* G, double sigma2, double* M,
-                             double* L, double* alpha, double* L2, int* status);
+// K5b, up to 4 posteriors per launch: M = I + Σ partials, alpha = M^-1 b (Cholesky); status[0] != 0 if M is not SPD.
+struct PosteriorFactorIO { const double* Mpart; int splits; double* M; double* alpha; int* status; double* scratch /* (r+1)·r, large ranks only */; };
+void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io);
 
-// a9 tail: out = −½ γ^T M γ − (r/2) ln 2π with (G + σ²M) γ = G (c_from + (c_to − c_from)/step − α)
-void launch_transition_tail(hipStream_t st, int r, const double* alpha, const double* M, const double* L2,
-                            const double* G, const double* c_from, const double* c_to, double step, double* out);
+// a9 tails, up to 8 per launch: out = −½ γ^T M γ − (r/2) ln 2π with (G + σ²M) γ = G (c_from + (c_to − c_from)/step − α).
+// Iterative (needs Ginv = G^-1); status[0] != 0 = did not contract -> use the direct kernel.
+struct TransitionTailIO { const double* alpha; const double* M; const double* c_from; const double* c_to; double step; double* out; int* status; };
+void launch_transition_tails(hipStream_t st, int r, int n, const TransitionTailIO* io, const double* Ginv, double sigma2);
+void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO& io, const double* G, double sigma2, double* work /* r*r */);
 
-// eigen-decomposition of D M^-1 D (posterior KL basis): V columns, S descending, canonical signs
-void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, double* V, double* S,
-                            double* work /* r*r */, int* status);
+// eigen-decomposition of D M^-1 D (posterior KL basis): V columns (and its transpose Vt), S descending, canonical signs
+// Vwarm (optional): eigenvectors of a nearby posterior, used as the starting basis of the Jacobi iteration
+void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
+                            double* Vt, double* S, double* work /* r*r */, int* status);
 
-// a8: c' = c + step·((G+σ²I)^-1 G (α + D^-1 V √S z) − c)
+// a8: c' = c + step·((G+σ²I)^-1 G (α + D^-1 V √S z) − c), with P = (G+σ²I)^-1
 void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,
-                    const double* inv_sqrt_lambda, const double* G, const double* Lg, const double* c,
+                    const double* inv_sqrt_lambda, const double* P, double sigma2, const double* c,
                     const double* z, double step, double* c_out);
 
 // ---- evaluator reductions (kernels_posterior.hip)

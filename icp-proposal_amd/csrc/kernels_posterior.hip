@@ -63,89 +63,72 @@ __global__ void __launch_bounds__(kBlock) k_correspond_target(int K, const doubl
   write_corr(cb, k, id, -1, ld3(tpts + 3 * k), boundary_aware ? !on_boundary : true, n, pose, ref, mean);
 }
 
-// ---------------------------------------------------------------- K5a regression assembly
-// One thread per entry (a,b) of the augmented (r+1)x(r+1) normal matrix, 16x16 entries per workgroup; the
-// correspondence loop is wave-uniform (ids, normals, keep flags via the scalar unit).
+// ---------------------------------------------------------------- K5a regression assembly on the f64 matrix cores
+// Maug = Σ_i X_iᵀ W_i X_i with X_i = the 4×(r+1) block of correspondence i: rows 0-2 = [Q_i | e_i] (the three
+// coordinate rows, weight w_t), row 3 = n̂_iᵀ[Q_i | e_i] (weight κ).  The contraction length per correspondence is
+// exactly the K = 4 of v_mfma_f64_16x16x4_f64: one MFMA per correspondence per 16×16 output tile.
+// Operand maps (cdna_hip_programming.md §3): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+// result register g of lane l is D[row = (l>>4) + 4g][col = l&15].
+// grid = (tiles, splits); block = one wave; partial sums per split are reduced by the factor kernel (deterministic).
+// The correspondence loop is unrolled ×4 so that the 24 gathered basis values of four correspondences are in flight
+// together (the loop is L2-latency bound, not bandwidth bound).
 
-__global__ void __launch_bounds__(kBlock) k_regression(int K, int r, const double* __restrict__ Q, CorrBuffers cb,
-                                                        double wt, double kappa, double* __restrict__ Maug) {
-  const int a = blockIdx.y * 16 + (threadIdx.x >> 4);
-  const int b = blockIdx.x * 16 + (threadIdx.x & 15);
-  const int n = r + 1;
-  const bool live = a < n && b < n;
-  const int ca = a < r ? a : 0, cb_ = b < r ? b : 0;
-  double acc = 0.0;
-  for (int k = 0; k < K; ++k) {
-    if (!cb.keep[k]) continue;
-    const double* q = Q + (size_t)3 * cb.id[k] * r;
-    const double n0 = cb.nhat[3 * k], n1 = cb.nhat[3 * k + 1], n2 = cb.nhat[3 * k + 2];
-    double a0, a1, a2, b0, b1, b2;
-    if (a < r) { a0 = q[ca]; a1 = q[r + ca]; a2 = q[2 * r + ca]; }
-    else { a0 = cb.e[3 * k]; a1 = cb.e[3 * k + 1]; a2 = cb.e[3 * k + 2]; }
-    if (b < r) { b0 = q[cb_]; b1 = q[r + cb_]; b2 = q[2 * r + cb_]; }
-    else { b0 = cb.e[3 * k]; b1 = cb.e[3 * k + 1]; b2 = cb.e[3 * k + 2]; }
-    double va = fma(a2, n2, fma(a1, n1, a0 * n0));
-    double vb = fma(b2, n2, fma(b1, n1, b0 * n0));
-    double dab = fma(a2, b2, fma(a1, b1, a0 * b0));
-    acc = fma(wt, dab, fma(kappa * va, vb, acc));
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+struct RegOperands { double A, B; };
+
+__device__ __forceinline__ void regression_load(int k, int r, const double* __restrict__ Q, const CorrBuffers& cb, int ca, int cbi,
+                                                double ma, double mb, double ea, double eb, double* a, double* b) {
+  const double* q = Q + (size_t)3 * cb.id[k] * r;
+  const double e0 = cb.e[3 * k], e1 = cb.e[3 * k + 1], e2 = cb.e[3 * k + 2];
+  a[0] = fma(ma, q[ca], ea * e0); a[1] = fma(ma, q[r + ca], ea * e1); a[2] = fma(ma, q[2 * r + ca], ea * e2);
+  b[0] = fma(mb, q[cbi], eb * e0); b[1] = fma(mb, q[r + cbi], eb * e1); b[2] = fma(mb, q[2 * r + cbi], eb * e2);
+}
+
+__device__ __forceinline__ d4_t regression_mac(int k, const CorrBuffers& cb, const double* a, const double* b, int kk, double wt,
+                                               double kappa, d4_t acc) {
+  const double on = cb.keep[k] ? 1.0 : 0.0;  // boundary-filtered correspondences contribute weight 0
+  const double n0 = cb.nhat[3 * k], n1 = cb.nhat[3 * k + 1], n2 = cb.nhat[3 * k + 2];
+  const double va = fma(a[2], n2, fma(a[1], n1, a[0] * n0));
+  const double vb = fma(b[2], n2, fma(b[1], n1, b[0] * n0));
+  const double A_op = kk == 0 ? a[0] : kk == 1 ? a[1] : kk == 2 ? a[2] : va;
+  const double B_op = (kk == 0 ? b[0] : kk == 1 ? b[1] : kk == 2 ? b[2] : vb) * (kk == 3 ? kappa : wt) * on;
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(A_op, B_op, acc, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(64) k_regression_mfma(int K, int kchunk, int r, const double* __restrict__ Q, CorrBuffers cb,
+                                                         double wt, double kappa, double* __restrict__ Mpart) {
+  const int n = r + 1, nt = (n + 15) >> 4;
+  const int ti = blockIdx.x / nt, tj = blockIdx.x - ti * nt;
+  const int l = threadIdx.x, i16 = l & 15, kk = l >> 4;
+  const int a = 16 * ti + i16, b = 16 * tj + i16;
+  const int ca = a < r ? a : 0, cbi = b < r ? b : 0;
+  const double ma = a < r ? 1.0 : 0.0, mb = b < r ? 1.0 : 0.0;      // basis column?
+  const double ea = a == r ? 1.0 : 0.0, eb = b == r ? 1.0 : 0.0;    // the appended observation column?
+  const int k0 = blockIdx.y * kchunk, k1 = min(K, k0 + kchunk);
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+  int k = k0;
+  for (; k + 4 <= k1; k += 4) {
+    double xa[4][3], xb[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) regression_load(k + u, r, Q, cb, ca, cbi, ma, mb, ea, eb, xa[u], xb[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = regression_mac(k + u, cb, xa[u], xb[u], kk, wt, kappa, acc);
   }
-  if (live) Maug[(size_t)a * n + b] = acc;
+  for (; k < k1; ++k) {
+    double xa[3], xb[3];
+    regression_load(k, r, Q, cb, ca, cbi, ma, mb, ea, eb, xa, xb);
+    acc = regression_mac(k, cb, xa, xb, kk, wt, kappa, acc);
+  }
+  double* out = Mpart + (size_t)blockIdx.y * n * n;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int row = 16 * ti + kk + 4 * g, col = 16 * tj + i16;
+    if (row < n && col < n) out[(size_t)row * n + col] = acc[g];
+  }
 }
 
 // ---------------------------------------------------------------- dense helpers (one workgroup, matrix behind a generic pointer)
-
-// in-place lower Cholesky of the n×n matrix A (leading dimension n); returns false if not SPD
-__device__ bool block_cholesky(double* A, int n, int* s_flag) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  if (tid == 0) *s_flag = 0;
-  __syncthreads();
-  for (int j = 0; j < n; ++j) {
-    // column j: subtract the contributions of columns < j was already applied (right-looking)
-    double ajj = A[(size_t)j * n + j];
-    if (!(ajj > 0.0)) {
-      if (tid == 0) *s_flag = 1;
-    }
-    __syncthreads();
-    if (*s_flag) return false;
-    double l = sqrt(ajj);
-    for (int i = j + 1 + tid; i < n; i += nt) A[(size_t)i * n + j] = A[(size_t)i * n + j] / l;
-    __syncthreads();
-    if (tid == 0) A[(size_t)j * n + j] = l;
-    // trailing update of the lower triangle: A[i][k] -= L[i][j]·L[k][j], j < k <= i < n
-    const int m = n - j - 1;
-    const int total = m * (m + 1) / 2;
-    for (int e = tid; e < total; e += nt) {
-      // unrank e -> (ii >= kk) within the m×m lower triangle
-      int ii = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-      while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
-      while (ii * (ii + 1) / 2 > e) --ii;
-      int kk = e - ii * (ii + 1) / 2;
-      int i = j + 1 + ii, k = j + 1 + kk;
-      A[(size_t)i * n + k] = fma(-A[(size_t)i * n + j], A[(size_t)k * n + j], A[(size_t)i * n + k]);
-    }
-    __syncthreads();
-  }
-  return true;
-}
-
-// solve L Lᵀ x = b in place (x in shared/global vector v of length n); L lower (leading dimension n)
-__device__ void block_chol_solve(const double* L, int n, double* v) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int j = 0; j < n; ++j) {  // forward, column oriented
-    if (tid == 0) v[j] = v[j] / L[(size_t)j * n + j];
-    __syncthreads();
-    double vj = v[j];
-    for (int i = j + 1 + tid; i < n; i += nt) v[i] = fma(-L[(size_t)i * n + j], vj, v[i]);
-    __syncthreads();
-  }
-  for (int j = n - 1; j >= 0; --j) {  // backward: Lᵀ x = y, row j of Lᵀ = column j of L
-    if (tid == 0) v[j] = v[j] / L[(size_t)j * n + j];
-    __syncthreads();
-    double vj = v[j];
-    for (int i = tid; i < j; i += nt) v[i] = fma(-L[(size_t)j * n + i], vj, v[i]);
-    __syncthreads();
-  }
-}
 
 __device__ double block_sum(double v, double* s_red) {
   const int tid = threadIdx.x;
@@ -154,7 +137,7 @@ __device__ double block_sum(double v, double* s_red) {
   if ((tid & 63) == 0) s_red[tid >> 6] = v;
   __syncthreads();
   double t = 0.0;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_red[w];
+  for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) t += s_red[w];
   return t;
 }
 __device__ double block_max(double v, double* s_red) {
@@ -164,78 +147,269 @@ __device__ double block_max(double v, double* s_red) {
   if ((tid & 63) == 0) s_red[tid >> 6] = v;
   __syncthreads();
   double t = s_red[0];
-  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, s_red[w]);
+  for (int w = 1; w < (int)((blockDim.x + 63) >> 6); ++w) t = fmax(t, s_red[w]);
   return t;
 }
 
-// ---------------------------------------------------------------- K5b factorisations
+// hardware reciprocal / reciprocal square root seeds + two Newton steps (≈ 1 ulp); the dependent chains of these small
+// factorisations are latency bound, and the IEEE division / sqrt expansions are 3-5× longer
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  double e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-h * y, y, 0.5);
+  return fma(y, e, y);
+}
+
+// y = A x for a row-major r×r matrix A (leading dimension lda; LDS or global), x and y in LDS.  2^tpr_log2 threads share
+// a row (their partial sums meet through wave shuffles), blockDim/2^tpr_log2 rows per pass.  Ends with a barrier.
+__device__ void block_matvec(int r, const double* A, int lda, const double* x, double* y, int tpr_log2) {
+  const int tid = threadIdx.x, tpr = 1 << tpr_log2, sub = tid & (tpr - 1);
+  const int rows_per_pass = blockDim.x >> tpr_log2;
+  for (int row0 = 0; row0 < r; row0 += rows_per_pass) {  // uniform trip count: every lane reaches the shuffles
+    const int row = row0 + (tid >> tpr_log2);
+    double acc = 0.0;
+    if (row < r) {
+      const double* a = A + (size_t)row * lda;
+#pragma unroll 8
+      for (int j = sub; j < r; j += tpr) acc = fma(a[j], x[j], acc);
+    }
+    for (int o = tpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (row < r && sub == 0) y[row] = acc;
+  }
+  __syncthreads();
+}
+
+// threads per row for block_matvec: enough rows in flight to occupy the block, at least ~8 terms per thread
+inline int matvec_tpr_log2(int r, int block) {
+  int t = 0;
+  while (t < 6 && (r << (t + 1)) <= block && (r >> (t + 1)) >= 8) ++t;
+  return t;
+}
+
+// copy a row-major r×r matrix into LDS with leading dimension ld
+__device__ void stage_matrix(int r, const double* __restrict__ src, double* dst, int ld) {
+  for (int e = threadIdx.x; e < r * r; e += blockDim.x) {
+    const int i = e / r, j = e - i * r;
+    dst[(size_t)i * ld + j] = src[e];
+  }
+}
+
+// Root-free right-looking Cholesky of the leading n×n block of W (leading dimension ld), in place, carrying `extra`
+// more rows below it through the same eliminations.  Column j is left UNSCALED (U[i][j] = L[i][j]·l_jj) and the
+// trailing update uses U[i][j]·U[k][j]/U[j][j], so each column costs ONE reciprocal and ONE barrier.
+// Afterwards L[i][j] = W[i][j]·dinv[j] with dinv[j] = 1/sqrt(W[j][j]).  2-D thread grid of tw×tw (tw² = blockDim).
+__device__ bool block_cholesky_rootfree(double* W, int n, int ld, int extra, int tw_log2) {
+  const int tid = threadIdx.x, tw = 1 << tw_log2, ty = tid >> tw_log2, tx = tid & (tw - 1);
+  const int rows = n + extra;
+  for (int j = 0; j < n; ++j) {
+    const double ajj = W[(size_t)j * ld + j];
+    if (!(ajj > 0.0)) return false;  // same value in every thread: uniform exit
+    const double inv = fast_rcp(ajj);
+    for (int i = j + 1 + ty; i < rows; i += tw) {
+      const double uij = W[(size_t)i * ld + j] * inv;
+      const int kmax = i < n ? i : n - 1;
+      for (int k = j + 1 + tx; k <= kmax; k += tw) W[(size_t)i * ld + k] = fma(-uij, W[(size_t)k * ld + j], W[(size_t)i * ld + k]);
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------- K5b: M = I + Σ partials, chol(M), α = M⁻¹ b
 
 extern __shared__ double s_dyn[];
 
-__global__ void __launch_bounds__(kBlock) k_posterior_factor(int r, const double* __restrict__ Maug, const double* __restrict__ G,
-                                                              double sigma2, double* __restrict__ M, double* __restrict__ L,
-                                                              double* __restrict__ alpha, double* __restrict__ L2,
-                                                              int* __restrict__ status, int use_lds) {
-  __shared__ int s_flag;
-  const int tid = threadIdx.x, nt = blockDim.x, n = r + 1;
-  const bool second = blockIdx.x == 1;
-  double* out = second ? L2 : L;
-  double* W = use_lds ? s_dyn : out;  // factor in LDS when it fits, else in place in global memory
-  for (int e = tid; e < r * r; e += nt) {
-    int i = e / r, j = e - i * r;
-    double m = Maug[(size_t)i * n + j] + (i == j ? 1.0 : 0.0);
-    if (!second) M[e] = m;
-    W[e] = second ? fma(sigma2, m, G[e]) : m;
+struct FactorArgs {  // up to 4 posteriors per launch (both ICP directions of one or two states)
+  const double* Mpart[4];
+  int splits[4];
+  double* M[4];
+  double* alpha[4];
+  int* status[4];
+  double* scratch[4];  // (r+1)·r doubles, used only when the matrix does not fit in LDS
+};
+
+constexpr int kFactorThreads = 1024;
+
+__global__ void __launch_bounds__(kFactorThreads) k_posterior_factor(int r, FactorArgs fa, int use_lds) {
+  __shared__ double s_dinv[512], s_v[512];
+  const int tid = threadIdx.x, nt = blockDim.x, n = r + 1, p = blockIdx.x;
+  const double* Mpart = fa.Mpart[p];
+  const int S = fa.splits[p];
+  const int ld = use_lds ? (r | 1) : r;   // odd leading dimension in LDS: conflict-free column walks
+  double* W = use_lds ? s_dyn : fa.scratch[p];  // rows 0..r-1 = M, row r = bᵀ
+  double* M = fa.M[p];
+  for (int e = tid; e < n * r; e += nt) {
+    const int i = e / r, j = e - i * r;   // i == r: the appended row bᵀ = Maug[r][0..r-1]
+    double m = 0.0;
+    for (int s = 0; s < S; ++s) m += Mpart[(size_t)s * n * n + (size_t)i * n + j];
+    if (i < r) {
+      m += i == j ? 1.0 : 0.0;
+      M[e] = m;
+    }
+    W[(size_t)i * ld + j] = m;
   }
   __syncthreads();
-  bool ok = block_cholesky(W, r, &s_flag);
-  if (tid == 0) status[blockIdx.x] = ok ? 0 : 1;
+  const bool ok = block_cholesky_rootfree(W, r, ld, 1, 5);
+  if (tid == 0) fa.status[p][0] = ok ? 0 : 1;
   if (!ok) return;
-  if (!second) {
-    __shared__ double s_v[256];
-    double* v = r <= 256 ? s_v : alpha;
-    for (int i = tid; i < r; i += nt) v[i] = Maug[(size_t)i * n + r];
-    __syncthreads();
-    block_chol_solve(W, r, v);
-    if (v != alpha)
-      for (int i = tid; i < r; i += nt) alpha[i] = v[i];
+  // y = L⁻¹ b sits (unscaled) in row r: y_j = W[r][j]·dinv_j
+  for (int j = tid; j < r; j += nt) {
+    const double d = fast_rsqrt(W[(size_t)j * ld + j]);
+    s_dinv[j] = d;
+    s_v[j] = W[(size_t)r * ld + j] * d;
   }
-  if (use_lds) {
-    __syncthreads();
-    for (int e = tid; e < r * r; e += nt) out[e] = W[e];
+  __syncthreads();
+  // back substitution Lᵀ α = y with L[j][i] = W[j][i]·dinv_i:  α_j = (y_j − Σ_{k>j} L[k][j] α_k)·dinv_j
+  if (r <= 64) {
+    if (tid < 64) {  // one wave, registers + readlane: no barriers on the sequential chain
+      const int i = tid;
+      double v = i < r ? s_v[i] : 0.0;
+      const double di = i < r ? s_dinv[i] : 0.0;
+      for (int j = r - 1; j >= 0; --j) {
+        const double xj = __shfl(v, j, 64) * s_dinv[j];
+        if (i == j) v = xj;
+        else if (i < j) v = fma(-(W[(size_t)j * ld + i] * di), xj, v);
+      }
+      if (i < r) fa.alpha[p][i] = v;
+    }
+  } else {
+    for (int j = r - 1; j >= 0; --j) {
+      if (tid == 0) s_v[j] = s_v[j] * s_dinv[j];
+      __syncthreads();
+      const double xj = s_v[j];
+      for (int i = tid; i < j; i += nt) s_v[i] = fma(-(W[(size_t)j * ld + i] * s_dinv[i]), xj, s_v[i]);
+      __syncthreads();
+    }
+    for (int i = tid; i < r; i += nt) fa.alpha[p][i] = s_v[i];
   }
 }
 
-// ---------------------------------------------------------------- a9 transition tail
+// ---------------------------------------------------------------- a9 transition tails (batched, one workgroup each)
+// (G + σ²M) γ = G d  ⇔  γ = d − σ² G⁻¹ M γ : fixed-point iteration with contraction factor ρ(σ² G⁻¹ M) (≈ 4e-8 for the
+// femur model), run to machine precision; status != 0 if it does not contract, and the host then uses the direct
+// (Cholesky) kernel below.  M and G⁻¹ are staged in LDS when they fit.
 
-__global__ void __launch_bounds__(kBlock) k_transition_tail(int r, const double* __restrict__ alpha, const double* __restrict__ M,
-                                                             const double* __restrict__ L2, const double* __restrict__ G,
-                                                             const double* __restrict__ c_from, const double* __restrict__ c_to,
-                                                             double step, double* __restrict__ out) {
-  __shared__ double s_d[512], s_g[512], s_red[8];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int j = tid; j < r; j += nt) s_d[j] = (c_from[j] + (c_to[j] - c_from[j]) / step) - alpha[j];  // :79 minus posterior mean
-  __syncthreads();
+struct TailArgs {
+  int n;
+  const double* alpha[8];
+  const double* M[8];
+  const double* c_from[8];
+  const double* c_to[8];
+  double step[8];
+  double* out[8];
+  int* status[8];
+};
+
+__global__ void __launch_bounds__(256) k_transition_tails(int r, TailArgs ta, const double* __restrict__ Ginv, double sigma2,
+                                                           int n_lds, int tpr_log2) {
+  __shared__ double s_d[512], s_g[512], s_t[512], s_u[512], s_red[16];
+  const int tid = threadIdx.x, nt = blockDim.x, t = blockIdx.x;
+  const int ld = r | 1;
+  const double* M = ta.M[t];
+  const double* Gi = Ginv;
+  int ldm = r, ldg = r;
+  if (n_lds >= 1) { stage_matrix(r, ta.M[t], s_dyn, ld); M = s_dyn; ldm = ld; }
+  if (n_lds >= 2) { stage_matrix(r, Ginv, s_dyn + (size_t)r * ld, ld); Gi = s_dyn + (size_t)r * ld; ldg = ld; }
   for (int i = tid; i < r; i += nt) {
-    double s = 0.0;
-    for (int j = 0; j < r; ++j) s = fma(G[(size_t)i * r + j], s_d[j], s);
-    s_g[i] = s;
+    const double d = (ta.c_from[t][i] + (ta.c_to[t][i] - ta.c_from[t][i]) / ta.step[t]) - ta.alpha[t][i];  // :79 minus posterior mean
+    s_d[i] = d;
+    s_g[i] = d;
   }
   __syncthreads();
-  block_chol_solve(L2, r, s_g);  // γ
+  int converged = 0;
+  for (int it = 0; it < 12 && !converged; ++it) {
+    block_matvec(r, M, ldm, s_g, s_t, tpr_log2);
+    block_matvec(r, Gi, ldg, s_t, s_u, tpr_log2);
+    double delta = 0.0, gmax = 0.0;
+    for (int i = tid; i < r; i += nt) {
+      const double gn = fma(-sigma2, s_u[i], s_d[i]);
+      delta = fmax(delta, fabs(gn - s_g[i]));
+      gmax = fmax(gmax, fabs(gn));
+      s_g[i] = gn;
+    }
+    delta = block_max(delta, s_red);
+    gmax = block_max(gmax, s_red);
+    converged = delta <= 1e-15 * gmax || gmax == 0.0;
+    __syncthreads();
+  }
+  block_matvec(r, M, ldm, s_g, s_t, tpr_log2);
+  double part = 0.0;
+  for (int i = tid; i < r; i += nt) part = fma(s_g[i], s_t[i], part);
+  const double q = block_sum(part, s_red);
+  if (tid == 0) {
+    ta.out[t][0] = -0.5 * q - 0.5 * (double)r * 1.8378770664093453;  // ln(2π); no log-det term
+    ta.status[t][0] = converged ? 0 : 3;
+  }
+}
+
+// direct version: factor G + σ²M, solve, quadratic form.  Used only if the iteration above reports non-contraction.
+__global__ void __launch_bounds__(1024) k_transition_tail_direct(int r, const double* __restrict__ alpha, const double* __restrict__ M,
+                                                                  const double* __restrict__ G, double sigma2,
+                                                                  const double* __restrict__ c_from, const double* __restrict__ c_to,
+                                                                  double step, double* __restrict__ work, double* __restrict__ out,
+                                                                  int* __restrict__ status, int use_lds) {
+  __shared__ double s_d[512], s_dinv[512], s_red[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int ld = use_lds ? (r | 1) : r;
+  double* W = use_lds ? s_dyn : work;  // rows 0..r-1 = G + σ²M, row r = (G d)ᵀ
+  for (int j = tid; j < r; j += nt) s_d[j] = (c_from[j] + (c_to[j] - c_from[j]) / step) - alpha[j];
+  __syncthreads();
+  for (int e = tid; e < r * r; e += nt) {
+    const int i = e / r, j = e - i * r;
+    W[(size_t)i * ld + j] = fma(sigma2, M[e], G[e]);
+  }
+  for (int i = tid; i < r; i += nt) {
+    double s = 0.0;
+    for (int j = 0; j < r; ++j) s = fma(G[(size_t)j * r + i], s_d[j], s);
+    W[(size_t)r * ld + i] = s;
+  }
+  __syncthreads();
+  const bool ok = block_cholesky_rootfree(W, r, ld, 1, 5);
+  if (!ok) { if (tid == 0) status[0] = 1; return; }
+  for (int j = tid; j < r; j += nt) {
+    const double d = fast_rsqrt(W[(size_t)j * ld + j]);
+    s_dinv[j] = d;
+    s_d[j] = W[(size_t)r * ld + j] * d;
+  }
+  __syncthreads();
+  for (int j = r - 1; j >= 0; --j) {
+    if (tid == 0) s_d[j] = s_d[j] * s_dinv[j];
+    __syncthreads();
+    const double xj = s_d[j];
+    for (int i = tid; i < j; i += nt) s_d[i] = fma(-(W[(size_t)j * ld + i] * s_dinv[i]), xj, s_d[i]);
+    __syncthreads();
+  }
   double part = 0.0;
   for (int i = tid; i < r; i += nt) {
     double s = 0.0;
-    for (int j = 0; j < r; ++j) s = fma(M[(size_t)i * r + j], s_g[j], s);
-    part = fma(s_g[i], s, part);
+    for (int j = 0; j < r; ++j) s = fma(M[(size_t)j * r + i], s_d[j], s);
+    part = fma(s_d[i], s, part);
   }
-  double q = block_sum(part, s_red);
-  if (tid == 0) out[0] = -0.5 * q - 0.5 * (double)r * 1.8378770664093453;  // ln(2π)
+  const double q = block_sum(part, s_red);
+  if (tid == 0) { out[0] = -0.5 * q - 0.5 * (double)r * 1.8378770664093453; status[0] = 0; }
 }
 
 // ---------------------------------------------------------------- posterior KL basis: parallel two-sided Jacobi
+// Eigen-decomposition of N = D⁻¹ M D⁻¹ (same eigenvectors as D M⁻¹ D, reciprocal eigenvalues) in one workgroup of
+// 1024 threads, matrices in LDS (odd leading dimension).  Round-robin ordering: each round rotates n/2 disjoint
+// index pairs concurrently:
+//   phase 1: one thread per pair computes (c, s) from three matrix entries (reciprocal/rsqrt seeds + Newton: the
+//            f64 division/sqrt expansions would dominate the round), barrier;
+//   phase 2: every 2×2 block (rows of pair P1 × columns of pair P2) is transformed as R1ᵀ·B·R2 by ONE thread, so each
+//            matrix element is read and written once per round; other threads rotate the column pairs of V; barrier.
+// Warm start: if `Vwarm` is given, the iteration starts from Vwarmᵀ N Vwarm (nearly diagonal when Vwarm diagonalised a
+// nearby posterior) with V = Vwarm, which cuts the number of sweeps roughly in half; the result is the same
+// eigen-decomposition (to rounding) either way.
 
-// round-robin (circle method) pairing of n2 (even) players in round `rnd`; slot 0..n2/2-1
 __device__ __forceinline__ void rr_pair(int n2, int rnd, int slot, int* p, int* q) {
   const int m = n2 - 1;
   int a, b;
@@ -245,23 +419,53 @@ __device__ __forceinline__ void rr_pair(int n2, int rnd, int slot, int* p, int* 
   *q = a < b ? b : a;
 }
 
-__global__ void __launch_bounds__(kBlock) k_posterior_eigen(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
-                                                             double* __restrict__ Vout, double* __restrict__ Sout,
-                                                             double* __restrict__ work, int* __restrict__ status, int a_in_lds, int v_in_lds) {
-  __shared__ double s_c[256], s_s[256], s_red[8], s_mu[512], s_sgn[512];
-  __shared__ int s_p[256], s_q[256], s_rank[512];
+__global__ void __launch_bounds__(1024) k_posterior_eigen(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
+                                                           const double* __restrict__ Vwarm, double* __restrict__ Vout,
+                                                           double* __restrict__ Vtout, double* __restrict__ Sout,
+                                                           double* __restrict__ work, int* __restrict__ status, int a_in_lds, int v_in_lds) {
+  __shared__ double s_red[16], s_mu[512], s_sgn[512], s_c[256], s_s[256];
+  __shared__ int s_rank[512];
+  __shared__ short s_p[256], s_q[256];
   const int tid = threadIdx.x, nt = blockDim.x;
+  const int lda = a_in_lds ? (r | 1) : r, ldv = v_in_lds ? (r | 1) : r;
   double* A = a_in_lds ? s_dyn : work;
-  double* V = v_in_lds ? (s_dyn + (a_in_lds ? r * r : 0)) : Vout;
-  // A = D⁻¹ M D⁻¹ (same eigenvectors as D M⁻¹ D, reciprocal eigenvalues); V = I
+  double* V = v_in_lds ? (s_dyn + (a_in_lds ? (size_t)r * lda : 0)) : Vout;
   for (int e = tid; e < r * r; e += nt) {
-    int i = e / r, j = e - i * r;
-    double mij = 0.5 * (M[e] + M[(size_t)j * r + i]);
-    A[e] = mij / (sqrt_lambda[i] * sqrt_lambda[j]);
-    V[e] = i == j ? 1.0 : 0.0;
+    const int i = e / r, j = e - i * r;
+    const double mij = 0.5 * (M[e] + M[(size_t)j * r + i]);
+    A[(size_t)i * lda + j] = mij / (sqrt_lambda[i] * sqrt_lambda[j]);
+    V[(size_t)i * ldv + j] = Vwarm ? Vwarm[e] : (i == j ? 1.0 : 0.0);
   }
   __syncthreads();
-  const int n2 = (r + 1) & ~1, half = n2 / 2;
+  if (Vwarm) {
+    // A <- Vᵀ A V in two passes through `work` (T = A V, then A = Vᵀ T); `work` is free when A lives in LDS,
+    // otherwise the warm start is skipped by the launcher.
+    for (int e = tid; e < r * r; e += nt) {
+      const int i = e / r, j = e - i * r;
+      double s = 0.0;
+      for (int k = 0; k < r; ++k) s = fma(A[(size_t)i * lda + k], V[(size_t)k * ldv + j], s);
+      work[e] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < r * r; e += nt) {
+      const int i = e / r, j = e - i * r;
+      double s = 0.0;
+      for (int k = 0; k < r; ++k) s = fma(V[(size_t)k * ldv + i], work[(size_t)k * r + j], s);
+      A[(size_t)i * lda + j] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < r * r; e += nt) {  // symmetrise against rounding
+      const int i = e / r, j = e - i * r;
+      if (i < j) {
+        const double v = 0.5 * (A[(size_t)i * lda + j] + A[(size_t)j * lda + i]);
+        A[(size_t)i * lda + j] = v;
+        A[(size_t)j * lda + i] = v;
+      }
+    }
+    __syncthreads();
+  }
+  const int n2 = (r + 1) & ~1, half = n2 >> 1;
+  const int n_blocks = half * half, n_vitems = r * half;
   int converged = 0;
   for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
     for (int rnd = 0; rnd < n2 - 1; ++rnd) {
@@ -270,125 +474,121 @@ __global__ void __launch_bounds__(kBlock) k_posterior_eigen(int r, const double*
         rr_pair(n2, rnd, tid, &p, &q);
         double c = 1.0, s = 0.0;
         if (q < r) {
-          double apq = A[(size_t)p * r + q], app = A[(size_t)p * r + p], aqq = A[(size_t)q * r + q];
-          if (fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * sqrt(fabs(app * aqq))) {
-            double tau = (aqq - app) / (2.0 * apq);
-            double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-            c = 1.0 / sqrt(1.0 + t * t);
+          const double apq = A[(size_t)p * lda + q], app = A[(size_t)p * lda + p], aqq = A[(size_t)q * lda + q];
+          if (fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq)) {
+            // t = sgn(a)·b / (|a| + sqrt(a² + b²)),  a = (aqq − app)/2, b = apq  (smaller root of t² + 2τt − 1 = 0)
+            const double a = 0.5 * (aqq - app);
+            const double h2 = fma(a, a, apq * apq);
+            const double h = h2 * fast_rsqrt(h2);
+            const double t = (a >= 0.0 ? apq : -apq) * fast_rcp(fabs(a) + h);
+            c = fast_rsqrt(fma(t, t, 1.0));
             s = t * c;
           }
-        } else {
-          p = -1;
         }
-        s_p[tid] = p; s_q[tid] = q; s_c[tid] = c; s_s[tid] = s;
+        s_p[tid] = (short)p; s_q[tid] = (short)q; s_c[tid] = c; s_s[tid] = s;
       }
       __syncthreads();
-      // rows p,q of A:  A' = Jᵀ A
-      for (int e = tid; e < half * r; e += nt) {
-        int pr = e / r, k = e - pr * r, p = s_p[pr], q = s_q[pr];
-        if (p < 0) continue;
-        double c = s_c[pr], s = s_s[pr];
-        double apk = A[(size_t)p * r + k], aqk = A[(size_t)q * r + k];
-        A[(size_t)p * r + k] = c * apk - s * aqk;
-        A[(size_t)q * r + k] = s * apk + c * aqk;
-      }
-      __syncthreads();
-      // columns p,q of A and V:  A'' = A' J,  V' = V J
-      for (int e = tid; e < half * r; e += nt) {
-        int pr = e / r, k = e - pr * r, p = s_p[pr], q = s_q[pr];
-        if (p < 0) continue;
-        double c = s_c[pr], s = s_s[pr];
-        double akp = A[(size_t)k * r + p], akq = A[(size_t)k * r + q];
-        A[(size_t)k * r + p] = c * akp - s * akq;
-        A[(size_t)k * r + q] = s * akp + c * akq;
-        double vkp = V[(size_t)k * r + p], vkq = V[(size_t)k * r + q];
-        V[(size_t)k * r + p] = c * vkp - s * vkq;
-        V[(size_t)k * r + q] = s * vkp + c * vkq;
+      for (int w = tid; w < n_blocks + n_vitems; w += nt) {
+        if (w < n_blocks) {
+          const int P1 = w / half, P2 = w - P1 * half;
+          const int p1 = s_p[P1], q1 = s_q[P1], p2 = s_p[P2], q2 = s_q[P2];
+          const double c1 = s_c[P1], s1 = s_s[P1], c2 = s_c[P2], s2 = s_s[P2];
+          const bool hq1 = q1 < r, hq2 = q2 < r;
+          double bpp = A[(size_t)p1 * lda + p2];
+          double bpq = hq2 ? A[(size_t)p1 * lda + q2] : 0.0;
+          double bqp = hq1 ? A[(size_t)q1 * lda + p2] : 0.0;
+          double bqq = (hq1 && hq2) ? A[(size_t)q1 * lda + q2] : 0.0;
+          // rows (pair P1):  [p; q] <- [c −s; s c][p; q]
+          const double tpp = c1 * bpp - s1 * bqp, tpq = c1 * bpq - s1 * bqq;
+          const double tqp = s1 * bpp + c1 * bqp, tqq = s1 * bpq + c1 * bqq;
+          // columns (pair P2): [p q] <- [p q][c s; −s c]
+          A[(size_t)p1 * lda + p2] = c2 * tpp - s2 * tpq;
+          if (hq2) A[(size_t)p1 * lda + q2] = s2 * tpp + c2 * tpq;
+          if (hq1) A[(size_t)q1 * lda + p2] = c2 * tqp - s2 * tqq;
+          if (hq1 && hq2) A[(size_t)q1 * lda + q2] = s2 * tqp + c2 * tqq;
+        } else {
+          const int v = w - n_blocks;
+          const int k = v / half, P = v - k * half;
+          const int p = s_p[P], q = s_q[P];
+          if (q < r) {
+            const double c = s_c[P], s = s_s[P];
+            const double vkp = V[(size_t)k * ldv + p], vkq = V[(size_t)k * ldv + q];
+            V[(size_t)k * ldv + p] = c * vkp - s * vkq;
+            V[(size_t)k * ldv + q] = s * vkp + c * vkq;
+          }
+        }
       }
       __syncthreads();
     }
     double off = 0.0, dg = 0.0;
     for (int e = tid; e < r * r; e += nt) {
-      int i = e / r, j = e - i * r;
-      double v = A[e];
+      const int i = e / r, j = e - i * r;
+      const double v = A[(size_t)i * lda + j];
       if (i == j) dg = fma(v, v, dg);
       else off = fma(v, v, off);
     }
     off = block_sum(off, s_red);
     dg = block_sum(dg, s_red);
-    converged = off <= 1e-30 * dg;
+    converged = off <= 1e-29 * dg;
   }
   if (tid == 0) status[0] = converged ? 0 : 2;
-  // eigenvalues of D M⁻¹ D are 1/μ; order S descending = μ ascending (ties: lower original index first)
-  for (int i = tid; i < r; i += nt) s_mu[i] = A[(size_t)i * r + i];
+  // eigenvalues of D M⁻¹ D are 1/μ; S descending = μ ascending (ties: lower original index first)
+  for (int i = tid; i < r; i += nt) s_mu[i] = A[(size_t)i * lda + i];
   __syncthreads();
   for (int i = tid; i < r; i += nt) {
     int rank = 0;
-    double mi = s_mu[i];
+    const double mi = s_mu[i];
     for (int j = 0; j < r; ++j) rank += (s_mu[j] < mi) || (s_mu[j] == mi && j < i);
     s_rank[i] = rank;
-  }
-  __syncthreads();
-  // column i of V -> column rank[i] of Vout, with the largest-|.| component made positive
-  for (int i = tid; i < r; i += nt) {
-    int best = 0;
+    int best = 0;  // canonical sign: the largest-|.| component of each eigenvector is positive
     double bv = fabs(V[i]);
     for (int k = 1; k < r; ++k) {
-      double a = fabs(V[(size_t)k * r + i]);
+      const double a = fabs(V[(size_t)k * ldv + i]);
       if (a > bv) { bv = a; best = k; }
     }
-    s_sgn[i] = V[(size_t)best * r + i] < 0.0 ? -1.0 : 1.0;
-    Sout[s_rank[i]] = 1.0 / s_mu[i];
+    s_sgn[i] = V[(size_t)best * ldv + i] < 0.0 ? -1.0 : 1.0;
+    Sout[rank] = 1.0 / mi;
   }
   __syncthreads();
-  if (v_in_lds) {
-    for (int e = tid; e < r * r; e += nt) {
-      int k = e / r, i = e - k * r;
-      Vout[(size_t)k * r + s_rank[i]] = V[e] * s_sgn[i];
-    }
-  } else {
-    // V aliases Vout: permute through `work` (free if A sat in LDS; otherwise A lived there and is dead now)
+  if (!v_in_lds) {  // V aliases Vout: permute through `work` (free if A sat in LDS; otherwise A lived there and is dead now)
     for (int e = tid; e < r * r; e += nt) work[e] = V[e];
     __syncthreads();
-    for (int e = tid; e < r * r; e += nt) {
-      int k = e / r, i = e - k * r;
-      Vout[(size_t)k * r + s_rank[i]] = work[e] * s_sgn[i];
-    }
+    V = work;
+  }
+  for (int e = tid; e < r * r; e += nt) {
+    const int k = e / r, i = e - k * r;
+    const double v = V[(size_t)k * ldv + i] * s_sgn[i];
+    Vout[(size_t)k * r + s_rank[i]] = v;
+    Vtout[(size_t)s_rank[i] * r + k] = v;
   }
 }
 
 // ---------------------------------------------------------------- a8 propose
+// c_new = (G + σ²I)⁻¹ G w = w − σ² P w with P = (G + σ²I)⁻¹ precomputed;  w = α + D⁻¹ V (√S ∘ z)
 
-__global__ void __launch_bounds__(kBlock) k_propose(int r, const double* __restrict__ alpha, const double* __restrict__ V,
-                                                     const double* __restrict__ S, const double* __restrict__ inv_sqrt_lambda,
-                                                     const double* __restrict__ G, const double* __restrict__ Lg,
-                                                     const double* __restrict__ c, const double* __restrict__ z, double step,
-                                                     double* __restrict__ c_out) {
-  __shared__ double s_w[512], s_g[512], s_z[512];
+__global__ void __launch_bounds__(256) k_propose(int r, const double* __restrict__ alpha, const double* __restrict__ V,
+                                                  const double* __restrict__ S, const double* __restrict__ inv_sqrt_lambda,
+                                                  const double* __restrict__ P, double sigma2, const double* __restrict__ c,
+                                                  const double* __restrict__ z, double step, double* __restrict__ c_out, int tpr_log2) {
+  __shared__ double s_x[512], s_y[512], s_w[512];
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int j = tid; j < r; j += nt) s_z[j] = sqrt(S[j]) * z[j];
+  for (int j = tid; j < r; j += nt) s_x[j] = sqrt(S[j]) * z[j];
   __syncthreads();
-  for (int i = tid; i < r; i += nt) {  // w = α + D⁻¹ V (√S ∘ z): coefficients of the sampled field in the scaled basis
-    double s = 0.0;
-    for (int j = 0; j < r; ++j) s = fma(V[(size_t)i * r + j], s_z[j], s);
-    s_w[i] = fma(s, inv_sqrt_lambda[i], alpha[i]);
-  }
+  block_matvec(r, V, r, s_x, s_y, tpr_log2);
+  for (int i = tid; i < r; i += nt) s_w[i] = fma(s_y[i], inv_sqrt_lambda[i], alpha[i]);
   __syncthreads();
+  block_matvec(r, P, r, s_w, s_y, tpr_log2);
   for (int i = tid; i < r; i += nt) {
-    double s = 0.0;
-    for (int j = 0; j < r; ++j) s = fma(G[(size_t)i * r + j], s_w[j], s);
-    s_g[i] = s;
+    const double cnew = fma(-sigma2, s_y[i], s_w[i]);  // model.coefficients(...) with σ² = 1e-5 (:59)
+    c_out[i] = c[i] + (cnew - c[i]) * step;            // :61-62
   }
-  __syncthreads();
-  block_chol_solve(Lg, r, s_g);  // model.coefficients(...) with σ² = 1e-5 (:59)
-  for (int j = tid; j < r; j += nt) c_out[j] = c[j] + (s_g[j] - c[j]) * step;  // :61-62
 }
 
 // ---------------------------------------------------------------- evaluator reductions
 
 __global__ void __launch_bounds__(kBlock) k_sum_gauss_logpdf(int K, const double* __restrict__ d2, double mean, double sigma,
                                                               double* __restrict__ out) {
-  __shared__ double s_red[8];
+  __shared__ double s_red[16];
   const double lognorm = log(sqrt(2.0 * 3.14159265358979323846)) + log(sigma);  // Breeze Gaussian.logNormalizer
   double part = 0.0;
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -401,7 +601,7 @@ __global__ void __launch_bounds__(kBlock) k_sum_gauss_logpdf(int K, const double
 
 __global__ void __launch_bounds__(kBlock) k_dist_stats(int K, const double* __restrict__ d2, const unsigned char* __restrict__ flags,
                                                         const int* __restrict__ idx, int n_flags, double* __restrict__ out) {
-  __shared__ double s_red[8];
+  __shared__ double s_red[16];
   double sum = 0.0, mx = -__builtin_inf(), cnt = 0.0;
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     bool drop = false;
@@ -444,41 +644,86 @@ void launch_correspond_target(hipStream_t st, int K, const double* x, const doub
                      boundary_aware, pose, ref, mean, tris, adj_off, adj, cb); }
 }
 
+int regression_splits(int K) {
+  int s = (K + 23) / 24;  // ~24 correspondences per wave: short dependent chains, enough waves to overlap the gathers
+  return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
 void launch_regression(hipStream_t st, int K, int r, const double* Q, const CorrBuffers& cb, double w_tangent,
-                       double kappa, double* Maug) {
-  int nb = cdiv(r + 1, 16);
+                       double kappa, double* Mpart, int* splits_out) {
+  const int n = r + 1, nt = (n + 15) / 16;
+  const int S = regression_splits(K);
+  int kchunk = (K + S - 1) / S;
+  if (kchunk < 1) kchunk = 1;
+  *splits_out = S;
   { ProfScope _ps(st, KID_REGRESSION);
-    hipLaunchKernelGGL(k_regression, dim3(nb, nb), dim3(kBlock), 0, st, K, r, Q, cb, w_tangent, kappa, Maug); }
+    hipLaunchKernelGGL(k_regression_mfma, dim3(nt * nt, S), dim3(64), 0, st, K, kchunk, r, Q, cb, w_tangent, kappa, Mpart); }
 }
 
-void launch_posterior_factor(hipStream_t st, int r, const double* Maug, const double* G, double sigma2, double* M,
-                             double* L, double* alpha, double* L2, int* status) {
-  int use_lds = r * r <= kLdsDoubles;
-  size_t shmem = use_lds ? sizeof(double) * r * r : 0;
+static void set_dyn_lds(const void* fn, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io) {
+  FactorArgs fa{};
+  for (int p = 0; p < n_post; ++p) {
+    fa.Mpart[p] = io[p].Mpart; fa.splits[p] = io[p].splits; fa.M[p] = io[p].M; fa.alpha[p] = io[p].alpha;
+    fa.status[p] = io[p].status; fa.scratch[p] = io[p].scratch;
+  }
+  const int ld = r | 1;
+  const int use_lds = (size_t)(r + 1) * ld <= (size_t)kLdsDoubles;
+  const size_t shmem = use_lds ? sizeof(double) * (size_t)(r + 1) * ld : 0;
+  set_dyn_lds((const void*)k_posterior_factor, shmem);
   { ProfScope _ps(st, KID_FACTOR);
-    hipLaunchKernelGGL(k_posterior_factor, dim3(2), dim3(kBlock), shmem, st, r, Maug, G, sigma2, M, L, alpha, L2, status, use_lds); }
+    hipLaunchKernelGGL(k_posterior_factor, dim3(n_post), dim3(kFactorThreads), shmem, st, r, fa, use_lds); }
 }
 
-void launch_transition_tail(hipStream_t st, int r, const double* alpha, const double* M, const double* L2,
-                            const double* G, const double* c_from, const double* c_to, double step, double* out) {
+void launch_transition_tails(hipStream_t st, int r, int n, const TransitionTailIO* io, const double* Ginv, double sigma2) {
+  TailArgs ta{};
+  ta.n = n;
+  for (int t = 0; t < n; ++t) {
+    ta.alpha[t] = io[t].alpha; ta.M[t] = io[t].M; ta.c_from[t] = io[t].c_from; ta.c_to[t] = io[t].c_to;
+    ta.step[t] = io[t].step; ta.out[t] = io[t].out; ta.status[t] = io[t].status;
+  }
+  const int ld = r | 1;
+  const size_t one = (size_t)r * ld;
+  const int n_lds = 2 * one <= (size_t)kLdsDoubles - 2560 ? 2 : (one <= (size_t)kLdsDoubles - 2560 ? 1 : 0);
+  const size_t shmem = sizeof(double) * one * n_lds;
+  set_dyn_lds((const void*)k_transition_tails, shmem);
   { ProfScope _ps(st, KID_TAIL);
-    hipLaunchKernelGGL(k_transition_tail, dim3(1), dim3(kBlock), 0, st, r, alpha, M, L2, G, c_from, c_to, step, out); }
+    hipLaunchKernelGGL(k_transition_tails, dim3(n), dim3(256), shmem, st, r, ta, Ginv, sigma2, n_lds, matvec_tpr_log2(r, 256)); }
 }
 
-void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, double* V, double* S,
-                            double* work, int* status) {
-  int a_in_lds = r * r <= kLdsDoubles;
-  int v_in_lds = 2 * r * r <= kLdsDoubles;
-  size_t shmem = sizeof(double) * ((a_in_lds ? r * r : 0) + (v_in_lds ? r * r : 0));
+void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO& io, const double* G, double sigma2, double* work) {
+  const int ld = r | 1;
+  const int use_lds = (size_t)(r + 1) * ld <= (size_t)kLdsDoubles - 1200;
+  const size_t shmem = use_lds ? sizeof(double) * (size_t)(r + 1) * ld : 0;
+  set_dyn_lds((const void*)k_transition_tail_direct, shmem);
+  { ProfScope _ps(st, KID_TAIL);
+    hipLaunchKernelGGL(k_transition_tail_direct, dim3(1), dim3(1024), shmem, st, r, io.alpha, io.M, G, sigma2, io.c_from, io.c_to,
+                       io.step, work, io.out, io.status, use_lds); }
+}
+
+void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
+                            double* Vt, double* S, double* work, int* status) {
+  const int ld = r | 1;
+  const size_t budget = (size_t)kLdsDoubles - 1800;  // static LDS of the kernel
+  const int a_in_lds = (size_t)r * ld <= budget;
+  const int v_in_lds = 2 * (size_t)r * ld <= budget;
+  const size_t shmem = sizeof(double) * ((a_in_lds ? (size_t)r * ld : 0) + (v_in_lds ? (size_t)r * ld : 0));
+  if (!a_in_lds) Vwarm = nullptr;  // the warm-start transform needs `work` as scratch
+  set_dyn_lds((const void*)k_posterior_eigen, shmem);
   { ProfScope _ps(st, KID_EIGEN);
-    hipLaunchKernelGGL(k_posterior_eigen, dim3(1), dim3(kBlock), shmem, st, r, M, sqrt_lambda, V, S, work, status, a_in_lds, v_in_lds); }
+    hipLaunchKernelGGL(k_posterior_eigen, dim3(1), dim3(1024), shmem, st, r, M, sqrt_lambda, Vwarm, V, Vt, S, work, status, a_in_lds,
+                       v_in_lds); }
 }
 
 void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,
-                    const double* inv_sqrt_lambda, const double* G, const double* Lg, const double* c,
+                    const double* inv_sqrt_lambda, const double* P, double sigma2, const double* c,
                     const double* z, double step, double* c_out) {
   { ProfScope _ps(st, KID_PROPOSE);
-    hipLaunchKernelGGL(k_propose, dim3(1), dim3(kBlock), 0, st, r, alpha, V, S, inv_sqrt_lambda, G, Lg, c, z, step, c_out); }
+    hipLaunchKernelGGL(k_propose, dim3(1), dim3(256), 0, st, r, alpha, V, S, inv_sqrt_lambda, P, sigma2, c, z, step, c_out,
+                       matvec_tpr_log2(r, 256)); }
 }
 
 void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mean, double sigma, double* out) {
