@@ -173,17 +173,20 @@ struct DeviceMesh {
   int V = 0, T = 0, n_boundary = 0;
   DBuf<double> verts;
   DBuf<int> tris;
-  DBuf<double4> spheres;
+  DBuf<float4> spheres;
   DBuf<uint8_t> boundary;
 };
 
 struct QueryScratch {
-  DBuf<double> thr;
-  DBuf<unsigned long long> best_d2;
-  DBuf<int> best_idx;
-  size_t cap = 0;
-  QueryBuffers get() const { return QueryBuffers{thr.p, best_d2.p, best_idx.p}; }
+  DBuf<double> thr2;
+  DBuf<float4> qrec;
+  DBuf<float> thrA;
+  DBuf<int> cnt, cand;
+  size_t cap = 0, cand_cap = 0;
+  QueryBuffers get() const { return QueryBuffers{thr2.p, qrec.p, thrA.p, cnt.p, cand.p, cand_cap}; }
 };
+
+constexpr size_t kMaxCandidates = (size_t)256 << 20;  // ints (1 GiB): larger query×element products are batched
 
 struct StateSlot {
   std::vector<double> theta;
@@ -191,7 +194,7 @@ struct StateSlot {
   uint64_t stamp = 0;
   Pose pose;
   DBuf<double> coeffs, x;
-  DBuf<double4> spheres;
+  DBuf<float4> spheres;
   bool spheres_valid = false;
   int n_surf = 0;  // model ids [0, n_surf) already projected onto the target surface
   DBuf<double> surf_cp, surf_d2;
@@ -231,14 +234,22 @@ struct icp_ctx {
 
   void bind() { HIP_OK(hipSetDevice(device)); }
 
-  QueryBuffers query_scratch(size_t K) {
+  // scratch for K queries against a set of n_elems elements (every query may list every element as a candidate)
+  QueryBuffers query_scratch(size_t K, size_t n_elems) {
     if (K > scratch.cap) {
       HIP_OK(hipStreamSynchronize(stream));
       size_t cap = std::max<size_t>(K, 4096);
-      scratch.thr.alloc(cap);
-      scratch.best_d2.alloc(cap);
-      scratch.best_idx.alloc(cap);
+      scratch.thr2.alloc(cap + 8);
+      scratch.qrec.alloc(cap + 8);
+      scratch.thrA.alloc(cap + 8);
+      scratch.cnt.alloc(cap + 8);
       scratch.cap = cap;
+    }
+    const size_t want = std::min(kMaxCandidates, std::max<size_t>((K + 4) * std::max<size_t>(n_elems, 1), 1));
+    if (want > scratch.cand_cap) {
+      HIP_OK(hipStreamSynchronize(stream));
+      scratch.cand.alloc(want);
+      scratch.cand_cap = want;
     }
     return scratch.get();
   }
@@ -323,7 +334,7 @@ void icp_ctx::ensure_surface_prefix(StateSlot& s, int K) {
   if (K > N) fail(ICP_ERR_INVALID_ARG, "model id count exceeds the number of model points");
   if (K <= s.n_surf) return;
   const int k0 = s.n_surf, n = K - k0;
-  QueryBuffers qb = query_scratch(n);
+  QueryBuffers qb = query_scratch(n, target.T);
   launch_surface_query(stream, target.T, target.verts.p, target.tris.p, target.spheres.p, n, s.x.p + 3 * (size_t)k0,
                        hint_surf.p + k0, qb, s.surf_cp.p + 3 * (size_t)k0, s.surf_d2.p + k0, s.surf_tri.p + k0);
   s.n_surf = K;
@@ -334,7 +345,7 @@ void icp_ctx::ensure_nnv_prefix(StateSlot& s, int K) {
   ensure_surface_prefix(s, K);
   if (K <= s.n_nnv) return;
   const int k0 = s.n_nnv, n = K - k0;
-  QueryBuffers qb = query_scratch(n);
+  QueryBuffers qb = query_scratch(n, target.V);
   launch_vertex_query(stream, target.V, target.verts.p, n, s.surf_cp.p + 3 * (size_t)k0, hint_nnv.p + k0, qb, nullptr,
                       s.surf_nnv.p + k0);
   s.n_nnv = K;
@@ -468,7 +479,7 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
   HIP_OK(hipMemsetAsync(status.p + e.status_off, 0, sizeof(int) * 3, c.stream));
   if (prm.direction == ICP_TARGET_SAMPLING) {
     // :117-118 nearest vertex of the current mesh for every decimated-target point
-    QueryBuffers qb = c.query_scratch(K);
+    QueryBuffers qb = c.query_scratch(K, c.N);
     launch_vertex_query(c.stream, c.N, s.x.p, K, target_pts.p, hint_nn.p, qb, nullptr, nn_id.p);
     launch_correspond_target(c.stream, K, s.x.p, target_pts.p, nn_id.p, c.boundary.p, prm.boundary_aware, s.pose, c.ref.p,
                              c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, e.corr());
@@ -549,7 +560,7 @@ void enqueue_eval(icp_evaluator* ev, StateSlot& s, int base) {
   if (t2m) {
     const int Kt = ev->Kt;
     c.ensure_model_spheres(s);
-    QueryBuffers qb = c.query_scratch(Kt);
+    QueryBuffers qb = c.query_scratch(Kt, c.T);
     launch_surface_query(c.stream, c.T, s.x.p, c.tris.p, s.spheres.p, Kt, ev->d_tpts, ev->hint_tri.p, qb, ev->t2m_cp.p,
                          ev->t2m_d2.p, ev->t2m_tri.p);
     if (p.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE) {
@@ -561,7 +572,7 @@ void enqueue_eval(icp_evaluator* ev, StateSlot& s, int base) {
       // TARGET's boundary flags (sic); ids beyond the target's vertex count count as interior.
       const bool flags = c.target.n_boundary > 0;
       if (flags) {
-        QueryBuffers qb2 = c.query_scratch(Kt);
+        QueryBuffers qb2 = c.query_scratch(Kt, c.N);
         launch_vertex_query(c.stream, c.N, s.x.p, Kt, ev->t2m_cp.p, ev->hint_nnv.p, qb2, nullptr, ev->t2m_nnv.p);
       }
       launch_dist_stats(c.stream, Kt, ev->t2m_d2.p, flags ? c.target.boundary.p : nullptr, flags ? ev->t2m_nnv.p : nullptr,
@@ -860,7 +871,7 @@ int icp_vertex_normals(icp_ctx* ctx, const double* theta, double* normals_out) {
 
 namespace {
 // shared body of the four stand-alone search entry points
-void run_search(icp_ctx* ctx, bool surface, int V, int T, const double* verts, const int* tris, const double4* spheres,
+void run_search(icp_ctx* ctx, bool surface, int V, int T, const double* verts, const int* tris, const float4* spheres,
                 int32_t n, const double* queries, double* points_out, int32_t* index_out, double* dist2_out) {
   require(n >= 0 && (queries || n == 0), "bad query array");
   if (n == 0) return;
@@ -870,7 +881,7 @@ void run_search(icp_ctx* ctx, bool surface, int V, int T, const double* verts, c
   cp.alloc(3 * (size_t)n);
   d2.alloc(n);
   idx.alloc(n);
-  QueryBuffers qb = ctx->query_scratch(n);
+  QueryBuffers qb = ctx->query_scratch(n, surface ? T : V);
   if (surface) launch_surface_query(ctx->stream, T, verts, tris, spheres, n, q.p, nullptr, qb, cp.p, d2.p, idx.p);
   else launch_vertex_query(ctx->stream, V, verts, n, q.p, nullptr, qb, d2.p, idx.p);
   if (points_out && surface) HIP_OK(hipMemcpyAsync(points_out, cp.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));

@@ -11,8 +11,8 @@ namespace icp {
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
 // Off by default: when `g_prof` is null the launch wrappers add nothing.
 enum KernelId {
-  KID_INSTANCE = 0, KID_SURFACE_INIT, KID_SURFACE_PASS_A, KID_SURFACE_BOUND, KID_SURFACE_PASS_B, KID_SURFACE_FINAL,
-  KID_VERTEX_INIT, KID_VERTEX_PASS_A, KID_VERTEX_PASS_B, KID_VERTEX_FINAL, KID_TRI_SPHERES, KID_CORRESPOND,
+  KID_INSTANCE = 0, KID_SURFACE_INIT, KID_SURFACE_FILTER, KID_SURFACE_RESOLVE,
+  KID_VERTEX_INIT, KID_VERTEX_FILTER, KID_VERTEX_RESOLVE, KID_TRI_SPHERES, KID_CORRESPOND,
   KID_REGRESSION, KID_FACTOR, KID_TAIL, KID_EIGEN, KID_PROPOSE, KID_REDUCE, KID_COUNT
 };
 extern const char* const kKernelNames[KID_COUNT];
@@ -44,19 +44,22 @@ void launch_instance(hipStream_t st, int N, int r, const double* Qp, const doubl
 void launch_vertex_normals(hipStream_t st, int N, const double* x, const int* tris, const int* adj_off,
                            const int* adj, double* normals);
 
-// bounding sphere (centroid, inflated max corner distance) of every triangle: spheres[t] = {cx,cy,cz,R}
-void launch_tri_spheres(hipStream_t st, int T, const double* verts, const int* tris, double4* spheres);
+// f32 bounding sphere (centroid, conservatively inflated max corner distance) of every triangle: spheres[t] = {cx,cy,cz,R}
+void launch_tri_spheres(hipStream_t st, int T, const double* verts, const int* tris, float4* spheres);
 
 // One brute-force query batch against a triangle mesh or a vertex set.  `hint` carries the previous winner of
 // each query (any valid index gives a valid upper bound; kNoIndex/-1 = none) and receives the new winner.
-struct QueryBuffers {
-  double* thr;                 // [K] pruning bound (surface: inflated distance; vertex: squared distance)
-  unsigned long long* best_d2; // [K] bit pattern of the exact minimum squared distance
-  int* best_idx;               // [K] lowest index attaining it
+struct QueryBuffers {   // scratch of one query batch; per-query arrays hold the batch size rounded up to a multiple of 4
+  double* thr2;          // vertex queries: squared-distance bound
+  float4* qrec;          // surface queries: f32 copy of the point
+  float* thrA;           // surface queries: distance bound (inflated, f32)
+  int* cnt;              // candidates per query
+  int* cand;             // candidate lists, one row of n_elements ints per query
+  size_t cand_capacity;  // ints in `cand`; a batch takes floor(capacity / n_elements) queries
 };
 
 // K4: closest point on surface.  Outputs (any may be null): cp [K*3], d2 [K], tri [K].
-void launch_surface_query(hipStream_t st, int T, const double* verts, const int* tris, const double4* spheres,
+void launch_surface_query(hipStream_t st, int T, const double* verts, const int* tris, const float4* spheres,
                           int K, const double* P, int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);
 
 // K3: nearest vertex.  Outputs (any may be null): d2 [K], idx [K].
