@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -476,7 +477,7 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
   e.stamp = ++clock;
   StateSlot& s = c.state(theta);  // :141 currentMesh
   HIP_OK(hipMemcpyAsync(e.coeffs.p, s.coeffs.p, sizeof(double) * r, hipMemcpyDeviceToDevice, c.stream));
-  HIP_OK(hipMemsetAsync(status.p + e.status_off, 0, sizeof(int) * 3, c.stream));
+  HIP_OK(hipMemsetAsync(status.p + e.status_off, 0, sizeof(int) * 3, c.stream));  // {chol, eigen sweeps (diagnostic), eigen}
   if (prm.direction == ICP_TARGET_SAMPLING) {
     // :117-118 nearest vertex of the current mesh for every decimated-target point
     QueryBuffers qb = c.query_scratch(K, c.N);
@@ -1014,6 +1015,8 @@ int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, 
     sync_proposal_status(p);
     c.finish(r, 0);
     p->check_status(e);
+    static const bool dbg = std::getenv("ICP_DEBUG_EIGEN") != nullptr;
+    if (dbg) std::fprintf(stderr, "eigen sweeps %d\n", p->h_status[e.status_off + 1]);
     std::memcpy(theta_out, theta, sizeof(double) * 10);
     for (int j = 0; j < r; ++j) {
       if (!std::isfinite(c.h_res[j])) fail(ICP_ERR_NOT_FINITE, "proposed coefficients are not finite");

@@ -237,9 +237,9 @@ struct FactorArgs {  // up to 4 posteriors per launch (both ICP directions of on
   double* scratch[4];  // (r+1)·r doubles, used only when the matrix does not fit in LDS
 };
 
-constexpr int kFactorThreads = 1024;
+constexpr int kFactorThreads = 256;
 
-__global__ void __launch_bounds__(kFactorThreads) k_posterior_factor(int r, FactorArgs fa, int use_lds) {
+__global__ void __launch_bounds__(kFactorThreads) k_posterior_factor_generic(int r, FactorArgs fa, int use_lds) {
   __shared__ double s_dinv[512], s_v[512];
   const int tid = threadIdx.x, nt = blockDim.x, n = r + 1, p = blockIdx.x;
   const double* Mpart = fa.Mpart[p];
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(kFactorThreads) k_posterior_factor(int r, Fact
     W[(size_t)i * ld + j] = m;
   }
   __syncthreads();
-  const bool ok = block_cholesky_rootfree(W, r, ld, 1, 5);
+  const bool ok = block_cholesky_rootfree(W, r, ld, 1, 4);
   if (tid == 0) fa.status[p][0] = ok ? 0 : 1;
   if (!ok) return;
   // y = L⁻¹ b sits (unscaled) in row r: y_j = W[r][j]·dinv_j
@@ -290,6 +290,100 @@ __global__ void __launch_bounds__(kFactorThreads) k_posterior_factor(int r, Fact
       __syncthreads();
     }
     for (int i = tid; i < r; i += nt) fa.alpha[p][i] = s_v[i];
+  }
+}
+
+// Fast path (the matrix fits a few elements per thread): every thread OWNS E fixed elements of the lower triangle of
+// [M; bᵀ] and keeps them in registers for the whole root-free factorisation; only the current pivot column is
+// published through a double-buffered LDS vector, so a column costs one reciprocal, ~E fused multiply-adds per thread
+// and ONE barrier.  The finished factor goes to LDS once, for the back substitution.
+template <int E, int NT>
+__global__ void __launch_bounds__(NT) k_posterior_factor_reg(int r, FactorArgs fa) {
+  __shared__ double s_col[2][516], s_dinv[512], s_v[512];
+  const int tid = threadIdx.x, n = r + 1, p = blockIdx.x;
+  const double* Mpart = fa.Mpart[p];
+  const int S = fa.splits[p];
+  double* M = fa.M[p];
+  const int ld = r | 1;
+  double* W = s_dyn;  // (r+1) × ld
+  const int tri = r * (r + 1) / 2, total = tri + r;
+  double v[E];
+  int im[E], km[E];
+#pragma unroll
+  for (int m = 0; m < E; ++m) {
+    const int e = tid + NT * m;
+    int i = r, k = e - tri;
+    if (e < tri) {
+      i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+      while ((i + 1) * (i + 2) / 2 <= e) ++i;
+      while (i * (i + 1) / 2 > e) --i;
+      k = e - i * (i + 1) / 2;
+    }
+    im[m] = i; km[m] = e < total ? k : -1;  // k = -1: slot unused (never > j, never published)
+    double x = 0.0;
+    if (e < total) {
+      for (int s = 0; s < S; ++s) x += Mpart[(size_t)s * n * n + (size_t)i * n + k];
+      if (i < r) {
+        if (i == k) x += 1.0;
+        M[(size_t)i * r + k] = x;
+        M[(size_t)k * r + i] = x;
+      }
+      if (k == 0) s_col[0][i] = x;
+    }
+    v[m] = x;
+  }
+  __syncthreads();
+  for (int j = 0; j < r; ++j) {
+    const double* cur = s_col[j & 1];
+    double* nxt = s_col[(j + 1) & 1];
+    const double ajj = cur[j];
+    if (!(ajj > 0.0)) {  // same value in every thread: uniform exit
+      if (tid == 0) fa.status[p][0] = 1;
+      return;
+    }
+    const double inv = fast_rcp(ajj);
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+      if (km[m] > j) {
+        v[m] = fma(-(cur[im[m]] * inv), cur[km[m]], v[m]);
+        if (km[m] == j + 1) nxt[im[m]] = v[m];  // column j+1 is final now: publish it as the next pivot column
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < E; ++m)
+    if (km[m] >= 0) W[(size_t)im[m] * ld + km[m]] = v[m];
+  __syncthreads();
+  if (tid == 0) fa.status[p][0] = 0;
+  // y = L⁻¹ b sits (unscaled) in row r: y_j = W[r][j]·dinv_j,  L[i][j] = W[i][j]·dinv_j
+  for (int j = tid; j < r; j += NT) {
+    const double d = fast_rsqrt(W[(size_t)j * ld + j]);
+    s_dinv[j] = d;
+    s_v[j] = W[(size_t)r * ld + j] * d;
+  }
+  __syncthreads();
+  if (r <= 64) {
+    if (tid < 64) {  // one wave, registers + cross-lane reads: no barriers on the sequential chain
+      const int i = tid;
+      double x = i < r ? s_v[i] : 0.0;
+      const double di = i < r ? s_dinv[i] : 0.0;
+      for (int j = r - 1; j >= 0; --j) {
+        const double xj = __shfl(x, j, 64) * s_dinv[j];
+        if (i == j) x = xj;
+        else if (i < j) x = fma(-(W[(size_t)j * ld + i] * di), xj, x);
+      }
+      if (i < r) fa.alpha[p][i] = x;
+    }
+  } else {
+    for (int j = r - 1; j >= 0; --j) {
+      if (tid == 0) s_v[j] = s_v[j] * s_dinv[j];
+      __syncthreads();
+      const double xj = s_v[j];
+      for (int i = tid; i < j; i += NT) s_v[i] = fma(-(W[(size_t)j * ld + i] * s_dinv[i]), xj, s_v[i]);
+      __syncthreads();
+    }
+    for (int i = tid; i < r; i += NT) fa.alpha[p][i] = s_v[i];
   }
 }
 
@@ -464,17 +558,74 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen(int r, const double* _
     }
     __syncthreads();
   }
-  const int n2 = (r + 1) & ~1, half = n2 >> 1;
-  const int n_blocks = half * half, n_vitems = r * half;
-  int converged = 0;
+  const int n2 = (r + 1) & ~1, half = n2 >> 1, mm = n2 - 1;
+  // work items of a round: n_blocks 2×2 blocks of A (upper triangle of the pair×pair grid, mirrored) + r·half column
+  // pairs of V.  Item -> thread mapping is fixed, so everything but the pair's current (p,q) is precomputed.
+  const int n_blocks = half * (half + 1) / 2, n_items = n_blocks + r * half;
+  constexpr int kItems = 2;  // items with precomputed descriptors; more (large ranks) go through the generic loop
+  int it_a[kItems], it_b[kItems];  // block item: (P1 <= P2); V item: (k | 0x40000000, P)
+#pragma unroll
+  for (int m = 0; m < kItems; ++m) {
+    const int w = tid + nt * m;
+    it_a[m] = -1; it_b[m] = 0;
+    if (w < n_blocks) {  // unrank the upper triangle row-major: P1 <= P2
+      int P1 = 0, base = 0;
+      while (base + (half - P1) <= w) { base += half - P1; ++P1; }
+      it_a[m] = P1; it_b[m] = P1 + (w - base);
+    } else if (w < n_items) {
+      const int vi = w - n_blocks;
+      it_a[m] = (vi / half) | 0x40000000; it_b[m] = vi % half;
+    }
+  }
+  // round-robin state of the pair this thread computes in phase 1 (slot = tid): incremental, no modulo per round
+  int ra = 0, rb = 0;
+  if (tid < half) {
+    if (tid == 0) { ra = mm; rb = 0; }
+    else { ra = tid % mm; rb = (mm - tid) % mm; }
+  }
+  auto do_block = [&](int P1, int P2) {
+    const int p1 = s_p[P1], q1 = s_q[P1], p2 = s_p[P2], q2 = s_q[P2];
+    const double c1 = s_c[P1], s1 = s_s[P1], c2 = s_c[P2], s2 = s_s[P2];
+    const bool hq1 = q1 < r, hq2 = q2 < r;
+    const int opp = p1 * lda + p2, opq = p1 * lda + q2, oqp = q1 * lda + p2, oqq = q1 * lda + q2;
+    const double bpp = A[opp];
+    const double bpq = hq2 ? A[opq] : 0.0;
+    const double bqp = hq1 ? A[oqp] : 0.0;
+    const double bqq = (hq1 && hq2) ? A[oqq] : 0.0;
+    // rows (pair P1): [p; q] <- [c −s; s c][p; q];  columns (pair P2): [p q] <- [p q][c s; −s c]
+    const double tpp = c1 * bpp - s1 * bqp, tpq = c1 * bpq - s1 * bqq;
+    const double tqp = s1 * bpp + c1 * bqp, tqq = s1 * bpq + c1 * bqq;
+    const double npp = c2 * tpp - s2 * tpq, npq = s2 * tpp + c2 * tpq;
+    const double nqp = c2 * tqp - s2 * tqq, nqq = s2 * tqp + c2 * tqq;
+    A[opp] = npp;
+    if (hq2) A[opq] = npq;
+    if (hq1) A[oqp] = nqp;
+    if (hq1 && hq2) A[oqq] = nqq;
+    if (P1 != P2) {  // mirror block (A stays exactly symmetric)
+      A[p2 * lda + p1] = npp;
+      if (hq2) A[q2 * lda + p1] = npq;
+      if (hq1) A[p2 * lda + q1] = nqp;
+      if (hq1 && hq2) A[q2 * lda + q1] = nqq;
+    }
+  };
+  auto do_vpair = [&](int k, int P) {
+    const int p = s_p[P], q = s_q[P];
+    if (q < r) {
+      const double c = s_c[P], s = s_s[P];
+      const int op = k * ldv + p, oq = k * ldv + q;
+      const double vkp = V[op], vkq = V[oq];
+      V[op] = c * vkp - s * vkq;
+      V[oq] = s * vkp + c * vkq;
+    }
+  };
+  int converged = 0, n_sweeps = 0;
   for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
-    for (int rnd = 0; rnd < n2 - 1; ++rnd) {
+    for (int rnd = 0; rnd < mm; ++rnd) {
       if (tid < half) {
-        int p, q;
-        rr_pair(n2, rnd, tid, &p, &q);
+        const int p = ra < rb ? ra : rb, q = ra < rb ? rb : ra;
         double c = 1.0, s = 0.0;
         if (q < r) {
-          const double apq = A[(size_t)p * lda + q], app = A[(size_t)p * lda + p], aqq = A[(size_t)q * lda + q];
+          const double apq = A[p * lda + q], app = A[p * lda + p], aqq = A[q * lda + q];
           if (fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq)) {
             // t = sgn(a)·b / (|a| + sqrt(a² + b²)),  a = (aqq − app)/2, b = apq  (smaller root of t² + 2τt − 1 = 0)
             const double a = 0.5 * (aqq - app);
@@ -486,36 +637,26 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen(int r, const double* _
           }
         }
         s_p[tid] = (short)p; s_q[tid] = (short)q; s_c[tid] = c; s_s[tid] = s;
+        // next round's pair of this slot (circle method: every player but the fixed one advances by one seat)
+        if (tid == 0) { rb = rb + 1 == mm ? 0 : rb + 1; }
+        else { ra = ra + 1 == mm ? 0 : ra + 1; rb = rb + 1 == mm ? 0 : rb + 1; }
       }
       __syncthreads();
-      for (int w = tid; w < n_blocks + n_vitems; w += nt) {
+#pragma unroll
+      for (int m = 0; m < kItems; ++m) {
+        if (it_a[m] >= 0) {
+          if (it_a[m] & 0x40000000) do_vpair(it_a[m] & 0x3FFFFFFF, it_b[m]);
+          else do_block(it_a[m], it_b[m]);
+        }
+      }
+      for (int w = tid + nt * kItems; w < n_items; w += nt) {  // large ranks only
         if (w < n_blocks) {
-          const int P1 = w / half, P2 = w - P1 * half;
-          const int p1 = s_p[P1], q1 = s_q[P1], p2 = s_p[P2], q2 = s_q[P2];
-          const double c1 = s_c[P1], s1 = s_s[P1], c2 = s_c[P2], s2 = s_s[P2];
-          const bool hq1 = q1 < r, hq2 = q2 < r;
-          double bpp = A[(size_t)p1 * lda + p2];
-          double bpq = hq2 ? A[(size_t)p1 * lda + q2] : 0.0;
-          double bqp = hq1 ? A[(size_t)q1 * lda + p2] : 0.0;
-          double bqq = (hq1 && hq2) ? A[(size_t)q1 * lda + q2] : 0.0;
-          // rows (pair P1):  [p; q] <- [c −s; s c][p; q]
-          const double tpp = c1 * bpp - s1 * bqp, tpq = c1 * bpq - s1 * bqq;
-          const double tqp = s1 * bpp + c1 * bqp, tqq = s1 * bpq + c1 * bqq;
-          // columns (pair P2): [p q] <- [p q][c s; −s c]
-          A[(size_t)p1 * lda + p2] = c2 * tpp - s2 * tpq;
-          if (hq2) A[(size_t)p1 * lda + q2] = s2 * tpp + c2 * tpq;
-          if (hq1) A[(size_t)q1 * lda + p2] = c2 * tqp - s2 * tqq;
-          if (hq1 && hq2) A[(size_t)q1 * lda + q2] = s2 * tqp + c2 * tqq;
+          int P1 = 0, base = 0;
+          while (base + (half - P1) <= w) { base += half - P1; ++P1; }
+          do_block(P1, P1 + (w - base));
         } else {
-          const int v = w - n_blocks;
-          const int k = v / half, P = v - k * half;
-          const int p = s_p[P], q = s_q[P];
-          if (q < r) {
-            const double c = s_c[P], s = s_s[P];
-            const double vkp = V[(size_t)k * ldv + p], vkq = V[(size_t)k * ldv + q];
-            V[(size_t)k * ldv + p] = c * vkp - s * vkq;
-            V[(size_t)k * ldv + q] = s * vkp + c * vkq;
-          }
+          const int vi = w - n_blocks;
+          do_vpair(vi / half, vi % half);
         }
       }
       __syncthreads();
@@ -529,9 +670,10 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen(int r, const double* _
     }
     off = block_sum(off, s_red);
     dg = block_sum(dg, s_red);
-    converged = off <= 1e-29 * dg;
+    converged = off <= 1e-26 * dg;
+    n_sweeps = sweep + 1;
   }
-  if (tid == 0) status[0] = converged ? 0 : 2;
+  if (tid == 0) { status[0] = converged ? 0 : 2; status[-1] = n_sweeps; }
   // eigenvalues of D M⁻¹ D are 1/μ; S descending = μ ascending (ties: lower original index first)
   for (int i = tid; i < r; i += nt) s_mu[i] = A[(size_t)i * lda + i];
   __syncthreads();
@@ -664,6 +806,13 @@ static void set_dyn_lds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+template <int E, int NT>
+static void launch_factor_reg(hipStream_t st, int r, int n_post, const FactorArgs& fa) {
+  const size_t shmem = sizeof(double) * (size_t)(r + 1) * (r | 1);
+  set_dyn_lds((const void*)k_posterior_factor_reg<E, NT>, shmem);
+  hipLaunchKernelGGL((k_posterior_factor_reg<E, NT>), dim3(n_post), dim3(NT), shmem, st, r, fa);
+}
+
 void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io) {
   FactorArgs fa{};
   for (int p = 0; p < n_post; ++p) {
@@ -671,11 +820,19 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
     fa.status[p] = io[p].status; fa.scratch[p] = io[p].scratch;
   }
   const int ld = r | 1;
-  const int use_lds = (size_t)(r + 1) * ld <= (size_t)kLdsDoubles;
-  const size_t shmem = use_lds ? sizeof(double) * (size_t)(r + 1) * ld : 0;
-  set_dyn_lds((const void*)k_posterior_factor, shmem);
-  { ProfScope _ps(st, KID_FACTOR);
-    hipLaunchKernelGGL(k_posterior_factor, dim3(n_post), dim3(kFactorThreads), shmem, st, r, fa, use_lds); }
+  const size_t total = (size_t)r * (r + 1) / 2 + r;
+  const bool w_fits = (size_t)(r + 1) * ld <= (size_t)kLdsDoubles - 2000;  // + the static LDS of the kernel
+  ProfScope _ps(st, KID_FACTOR);
+  if (w_fits && total <= 256 * 6) launch_factor_reg<6, 256>(st, r, n_post, fa);
+  else if (w_fits && total <= 256 * 12) launch_factor_reg<12, 256>(st, r, n_post, fa);
+  else if (w_fits && total <= 1024 * 6) launch_factor_reg<6, 1024>(st, r, n_post, fa);
+  else if (w_fits && total <= 1024 * 12) launch_factor_reg<12, 1024>(st, r, n_post, fa);
+  else {
+    const int use_lds = (size_t)(r + 1) * ld <= (size_t)kLdsDoubles;
+    const size_t shmem = use_lds ? sizeof(double) * (size_t)(r + 1) * ld : 0;
+    set_dyn_lds((const void*)k_posterior_factor_generic, shmem);
+    hipLaunchKernelGGL(k_posterior_factor_generic, dim3(n_post), dim3(kFactorThreads), shmem, st, r, fa, use_lds);
+  }
 }
 
 void launch_transition_tails(hipStream_t st, int r, int n, const TransitionTailIO* io, const double* Ginv, double sigma2) {
