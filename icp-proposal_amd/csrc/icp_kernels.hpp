@@ -13,7 +13,8 @@ namespace icp {
 enum KernelId {
   KID_INSTANCE = 0, KID_SURFACE_INIT, KID_SURFACE_FILTER, KID_SURFACE_RESOLVE,
   KID_VERTEX_INIT, KID_VERTEX_FILTER, KID_VERTEX_RESOLVE, KID_TRI_SPHERES, KID_CORRESPOND,
-  KID_REGRESSION, KID_FACTOR, KID_TAIL, KID_EIGEN, KID_PROPOSE, KID_REDUCE, KID_COUNT
+  KID_REGRESSION, KID_FACTOR, KID_TAIL, KID_EIGEN, KID_PROPOSE, KID_REDUCE,
+  KID_STEP_INSTANCE, KID_STEP_INIT, KID_STEP_FILTER, KID_STEP_RESOLVE, KID_STEP_REGRESSION, KID_STEP_FACTOR, KID_STEP_TAILS, KID_COUNT
 };
 extern const char* const kKernelNames[KID_COUNT];
 
@@ -57,6 +58,10 @@ struct QueryBuffers {   // scratch of one query batch; per-query arrays hold the
   int* cand;             // candidate lists, one row of n_elements ints per query
   size_t cand_capacity;  // ints in `cand`; a batch takes floor(capacity / n_elements) queries
 };
+
+struct SurfaceTask;
+struct VertexTask;
+void split_queries(int n_elem_blocks, int Kpad, int* ksplit, int* kchunk);
 
 // K4: closest point on surface.  Outputs (any may be null): cp [K*3], d2 [K], tri [K].
 void launch_surface_query(hipStream_t st, int T, const double* verts, const int* tris, const float4* spheres,

@@ -1,0 +1,246 @@
+// icp_search.hpp — device-side bodies of the two brute-force searches (K3 point×vertex, K4 point×triangle).
+// Included by kernels_geometry.hip (one kernel per stage) and kernels_step.hip (stages of several query batches merged
+// into one launch per Metropolis–Hastings step).  Design notes: kernels_geometry.hip.
+#pragma once
+#include "icp_device.hpp"
+
+namespace icp {
+
+constexpr int kSearchBlock = 256;
+constexpr double kAbsSlack = 3.0 / 8388608.0;  // 3·2^-23 per unit of |coordinate|: covers rounding a point to f32
+constexpr int kQU = 4;                         // queries per unrolled filter iteration
+
+struct SurfaceTask {  // one batch of closest-point-on-surface queries against one triangle mesh
+  int K, Kpad, T, stride;
+  const double* P;        // [K*3] query points
+  const double* verts;
+  const int* tris;
+  const float4* spheres;  // [T] f32 bounding spheres
+  int* hint;              // [K] previous winner (in/out; may be null)
+  float4* qrec;           // [Kpad] scratch
+  float* thrA;            // [Kpad] scratch
+  int* cnt;               // [Kpad] scratch
+  int* cand;              // [Kpad*stride] scratch
+  double* cp;             // outputs, any may be null
+  double* d2;
+  int* tri;
+  int tblocks, ksplit, kchunk;  // filter decomposition: tblocks × ksplit workgroups
+};
+
+struct VertexTask {  // one batch of nearest-vertex queries against one vertex set
+  int K, Kpad, V, stride;
+  const double* P;
+  const double* verts;
+  int* hint;
+  double* thr2;
+  int* cnt;
+  int* cand;
+  double* d2;  // outputs, any may be null
+  int* idx;
+  int vblocks, ksplit, kchunk;
+};
+
+__device__ __forceinline__ float round_up_f32(double v) { return nextafterf((float)v, __builtin_inff()); }
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// f32 bounding sphere of triangle t: centre = centroid rounded to f32, radius = max corner distance (f64) inflated by
+// the rounding of centre and arithmetic, rounded up
+__device__ __forceinline__ float4 tri_sphere(const double* __restrict__ verts, const int* __restrict__ tris, int t) {
+  d3 a = ld3(verts + 3 * tris[3 * t]), b = ld3(verts + 3 * tris[3 * t + 1]), c = ld3(verts + 3 * tris[3 * t + 2]);
+  d3 m = {(a.x + b.x + c.x) / 3.0, (a.y + b.y + c.y) / 3.0, (a.z + b.z + c.z) / 3.0};
+  d3 da = sub(a, m), db = sub(b, m), dc = sub(c, m);
+  double r2 = fmax(dot(da, da), fmax(dot(db, db), dot(dc, dc)));
+  double R = sqrt(r2) * (1.0 + 2e-6) + kAbsSlack * (fabs(m.x) + fabs(m.y) + fabs(m.z));
+  return make_float4((float)m.x, (float)m.y, (float)m.z, round_up_f32(R));
+}
+
+// append `value` to list[...] for the lanes with `hit`, one atomic per wave; `m` = ballot of hit (non-zero)
+__device__ __forceinline__ void wave_append(unsigned long long m, bool hit, int* __restrict__ counter, int* __restrict__ list, int value) {
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane_id() == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader, 64);
+  if (hit) {
+    const unsigned long long below = m & ((1ull << lane_id()) - 1ull);
+    list[base + __popcll(below)] = value;
+  }
+}
+
+// lexicographic (d², index) minimum across the wave
+__device__ __forceinline__ void wave_lexmin(double& d2, int& idx) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const double od = __shfl_xor(d2, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (od < d2 || (od == d2 && oi < idx)) { d2 = od; idx = oi; }
+  }
+}
+
+// ---------------------------------------------------------------- K4 closest point on surface
+
+// per query: exact distance to the hinted triangle -> filter bound; f32 copy of the query; zero candidate counter.
+// Entries K..Kpad-1 are sentinels (a point at 1e30 with bound 0) so the filter can run unrolled without guards.
+__device__ __forceinline__ void surface_init(const SurfaceTask& q, int k) {
+  if (k >= q.Kpad) return;
+  q.cnt[k] = 0;
+  if (k >= q.K) {
+    q.qrec[k] = make_float4(1e30f, 1e30f, 1e30f, 0.f);
+    q.thrA[k] = 0.f;
+    return;
+  }
+  d3 p = ld3(q.P + 3 * k);
+  int h = q.hint ? q.hint[k] : -1;
+  double d2 = __builtin_inf();
+  if (h >= 0 && h < q.T) d2 = tri_dist2(p, q.verts, q.tris, h, nullptr);
+  if (!(d2 == d2)) d2 = __builtin_inf();  // degenerate hint triangle
+  const double slack = kAbsSlack * (fabs(p.x) + fabs(p.y) + fabs(p.z));
+  q.qrec[k] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f);
+  q.thrA[k] = round_up_f32(sqrt(d2) * (1.0 + 2e-6) + slack);
+}
+
+// workgroup (bx, by) of the tblocks × ksplit filter grid; kSearchBlock threads
+__device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int by) {
+  const int t = bx * kSearchBlock + threadIdx.x;
+  const bool valid = t < q.T;
+  float cx = 3e38f, cy = 3e38f, cz = 3e38f, R = 0.f;  // out-of-range lanes: infinitely far away
+  if (valid) {
+    float4 s = q.spheres[t];
+    cx = s.x; cy = s.y; cz = s.z; R = s.w;
+  }
+  const float4* __restrict__ qrec = q.qrec;
+  const float* __restrict__ thrA = q.thrA;
+  const int k0 = by * q.kchunk;
+  const int k1 = min(q.Kpad, k0 + q.kchunk);
+  for (int k = k0; k < k1; k += kQU) {
+    bool hit[kQU];
+    unsigned long long m[kQU];
+#pragma unroll
+    for (int u = 0; u < kQU; ++u) {  // wave-uniform query records: scalar loads, kQU queries in flight
+      const float4 qq = qrec[k + u];
+      const float tt = thrA[k + u] + R;
+      const float dx = qq.x - cx, dy = qq.y - cy, dz = qq.z - cz;
+      const float dc2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      hit[u] = valid && dc2 <= tt * tt;
+      m[u] = __ballot(hit[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kQU; ++u)
+      if (m[u] != 0ull) wave_append(m[u], hit[u], q.cnt + (k + u), q.cand + (size_t)(k + u) * q.stride, t);  // uniform branch
+  }
+}
+
+// one wave per query.  Returns (all lanes) the winner and its squared distance; lane 0 writes the task's outputs and
+// returns the closest point through *cp_out (valid in lane 0 only).
+__device__ __forceinline__ void surface_resolve(const SurfaceTask& q, int k, double* best_out, int* tri_out, d3* cp_out) {
+  const int n = q.cnt[k];
+  const d3 p = ld3(q.P + 3 * k);
+  const int* list = q.cand + (size_t)k * q.stride;
+  double best = __builtin_inf();
+  int bi = kNoIndex;
+  for (int i = lane_id(); i < n; i += 64) {
+    const int t = list[i];
+    const double d2 = tri_dist2(p, q.verts, q.tris, t, nullptr);
+    if (d2 < best || (d2 == best && t < bi)) { best = d2; bi = t; }  // NaN (degenerate triangle) never wins
+  }
+  wave_lexmin(best, bi);
+  d3 c = {__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
+  if (lane_id() == 0) {
+    if (bi != kNoIndex) tri_dist2(p, q.verts, q.tris, bi, &c);
+    if (q.cp) { q.cp[3 * k] = c.x; q.cp[3 * k + 1] = c.y; q.cp[3 * k + 2] = c.z; }
+    if (q.d2) q.d2[k] = best;
+    if (q.tri) q.tri[k] = bi == kNoIndex ? -1 : bi;
+    if (q.hint) q.hint[k] = bi == kNoIndex ? -1 : bi;
+  }
+  *best_out = best;
+  *tri_out = bi;
+  *cp_out = c;
+}
+
+// ---------------------------------------------------------------- K3 nearest vertex
+
+__device__ __forceinline__ void vertex_init(const VertexTask& q, int k) {
+  if (k >= q.Kpad) return;
+  q.cnt[k] = 0;
+  if (k >= q.K) { q.thr2[k] = -1.0; return; }  // sentinel: nothing passes
+  int h = q.hint ? q.hint[k] : -1;
+  double d2 = __builtin_inf();
+  if (h >= 0 && h < q.V) {
+    d3 d = sub(ld3(q.P + 3 * k), ld3(q.verts + 3 * h));
+    d2 = dot(d, d);
+  }
+  if (!(d2 == d2)) d2 = __builtin_inf();
+  q.thr2[k] = d2;  // squared bound, same expression as the filter -> the hint vertex itself always passes
+}
+
+__device__ __forceinline__ void vertex_filter(const VertexTask& q, int bx, int by) {
+  const int v = bx * kSearchBlock + threadIdx.x;
+  const bool valid = v < q.V;
+  d3 e = {0.0, 0.0, 0.0};
+  if (valid) e = ld3(q.verts + 3 * v);
+  const double* __restrict__ P = q.P;
+  const double* __restrict__ thr2 = q.thr2;
+  const int k0 = by * q.kchunk;
+  const int k1 = min(q.Kpad, k0 + q.kchunk);
+  for (int k = k0; k < k1; k += kQU) {
+    bool hit[kQU];
+    unsigned long long m[kQU];
+#pragma unroll
+    for (int u = 0; u < kQU; ++u) {
+      const int kk = min(k + u, q.K - 1);  // sentinel slots re-read the last real query; their bound is -1
+      d3 p = {P[3 * kk], P[3 * kk + 1], P[3 * kk + 2]};  // wave-uniform
+      d3 d = sub(p, e);
+      const double d2 = dot(d, d);  // (dx·dx + dy·dy) + dz·dz, unfused — the value the argmin is defined on
+      hit[u] = valid && d2 <= thr2[k + u];
+      m[u] = __ballot(hit[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kQU; ++u)
+      if (m[u] != 0ull) wave_append(m[u], hit[u], q.cnt + (k + u), q.cand + (size_t)(k + u) * q.stride, v);
+  }
+}
+
+__device__ __forceinline__ void vertex_resolve(const VertexTask& q, int k, double* best_out, int* idx_out) {
+  const int n = q.cnt[k];
+  const d3 p = ld3(q.P + 3 * k);
+  const int* list = q.cand + (size_t)k * q.stride;
+  double best = __builtin_inf();
+  int bi = kNoIndex;
+  for (int i = lane_id(); i < n; i += 64) {
+    const int v = list[i];
+    d3 d = sub(p, ld3(q.verts + 3 * v));
+    const double d2 = dot(d, d);
+    if (d2 < best || (d2 == best && v < bi)) { best = d2; bi = v; }
+  }
+  wave_lexmin(best, bi);
+  if (lane_id() == 0) {
+    if (q.d2) q.d2[k] = best;
+    if (q.idx) q.idx[k] = bi == kNoIndex ? -1 : bi;
+    if (q.hint) q.hint[k] = bi == kNoIndex ? -1 : bi;
+  }
+  *best_out = best;
+  *idx_out = bi;
+}
+
+// K1: one vertex of x = s(R(x̄ + μ + Q c − ctr) + ctr + t); Qp = scaled basis in planes [(j*3+d)*N + i].
+// Summed in basis order with separately rounded multiply and add (the value every search index is defined on).
+__device__ __forceinline__ void instance_vertex(int i, int N, int r, const double* __restrict__ Qp, const double* __restrict__ ref,
+                                                const double* __restrict__ mean, const Pose& pose, const double* __restrict__ coeffs,
+                                                double* __restrict__ x) {
+  double a0 = mean[3 * i], a1 = mean[3 * i + 1], a2 = mean[3 * i + 2];
+  const double* q = Qp + i;
+  for (int j = 0; j < r; ++j) {
+    double c = coeffs[j];
+    a0 = a0 + q[(size_t)(3 * j) * N] * c;
+    a1 = a1 + q[(size_t)(3 * j + 1) * N] * c;
+    a2 = a2 + q[(size_t)(3 * j + 2) * N] * c;
+  }
+  double u0 = ref[3 * i] + a0, u1 = ref[3 * i + 1] + a1, u2 = ref[3 * i + 2] + a2;
+  double v0 = u0 - pose.ctr[0], v1 = u1 - pose.ctr[1], v2 = u2 - pose.ctr[2];
+  double w0 = (pose.R[0] * v0 + pose.R[1] * v1) + pose.R[2] * v2;
+  double w1 = (pose.R[3] * v0 + pose.R[4] * v1) + pose.R[5] * v2;
+  double w2 = (pose.R[6] * v0 + pose.R[7] * v1) + pose.R[8] * v2;
+  x[3 * i] = pose.s * ((w0 + pose.ctr[0]) + pose.t[0]);
+  x[3 * i + 1] = pose.s * ((w1 + pose.ctr[1]) + pose.t[1]);
+  x[3 * i + 2] = pose.s * ((w2 + pose.ctr[2]) + pose.t[2]);
+}
+
+}  // namespace icp

@@ -8,225 +8,32 @@
 //     (equal to the reference's whitened-coefficient form for ANY square root of D M⁻¹ D; derivation in DESIGN.md)
 // These kernels are latency-bound r×r work (r = 51…201): one workgroup per matrix, data in LDS when it fits.
 #include "icp_kernels.hpp"
+#include "icp_dense.hpp"
 
 namespace icp {
 
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kLdsDoubles = 18432;  // 144 KiB of the 160 KiB LDS for one matrix-sized buffer
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// ---------------------------------------------------------------- correspondences
+// ---------------------------------------------------------------- correspondences (one thread per correspondence)
 
-__device__ __forceinline__ void write_corr(const CorrBuffers& cb, int k, int id, int aux, d3 pt, bool keep, d3 n,
-                                           const Pose& pose, const double* __restrict__ ref, const double* __restrict__ mean) {
-  // inverse RIGID pose (NonRigidIcpProposal.scala:142): Rᵀ((pt − t) − ctr) + ctr, then minus x̄_id (:108) and μ_id
-  double v0 = (pt.x - pose.t[0]) - pose.ctr[0], v1 = (pt.y - pose.t[1]) - pose.ctr[1], v2 = (pt.z - pose.t[2]) - pose.ctr[2];
-  double b0 = ((pose.R[0] * v0 + pose.R[3] * v1) + pose.R[6] * v2) + pose.ctr[0];
-  double b1 = ((pose.R[1] * v0 + pose.R[4] * v1) + pose.R[7] * v2) + pose.ctr[1];
-  double b2 = ((pose.R[2] * v0 + pose.R[5] * v1) + pose.R[8] * v2) + pose.ctr[2];
-  cb.id[k] = id;
-  cb.aux[k] = aux;
-  cb.pt[3 * k] = pt.x; cb.pt[3 * k + 1] = pt.y; cb.pt[3 * k + 2] = pt.z;
-  cb.keep[k] = keep ? 1 : 0;
-  cb.nhat[3 * k] = n.x; cb.nhat[3 * k + 1] = n.y; cb.nhat[3 * k + 2] = n.z;
-  cb.e[3 * k] = (b0 - ref[3 * id]) - mean[3 * id];
-  cb.e[3 * k + 1] = (b1 - ref[3 * id + 1]) - mean[3 * id + 1];
-  cb.e[3 * k + 2] = (b2 - ref[3 * id + 2]) - mean[3 * id + 2];
-}
-
-__global__ void __launch_bounds__(kBlock) k_correspond_model(int K, const double* __restrict__ x, const double* __restrict__ cp,
-                                                              const int* __restrict__ nnv, const unsigned char* __restrict__ tgt_boundary,
-                                                              int boundary_aware, Pose pose, const double* __restrict__ ref,
-                                                              const double* __restrict__ mean, const int* __restrict__ tris,
-                                                              const int* __restrict__ adj_off, const int* __restrict__ adj, CorrBuffers cb) {
+__global__ void __launch_bounds__(kBlock) k_correspond_model(CorrTask c, const double* __restrict__ cp) {
   int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k >= K) return;
-  int aux = nnv ? nnv[k] : -1;
-  bool on_boundary = (nnv && aux >= 0) ? tgt_boundary[aux] != 0 : false;  // :98-99
-  d3 n = vertex_normal(x, tris, adj_off, adj, k);                          // :100
-  write_corr(cb, k, k, aux, ld3(cp + 3 * k), boundary_aware ? !on_boundary : true, n, pose, ref, mean);
+  if (k < c.K) correspond_model_one(c, k, ld3(cp + 3 * k));
 }
 
-__global__ void __launch_bounds__(kBlock) k_correspond_target(int K, const double* __restrict__ x, const double* __restrict__ tpts,
-                                                               const int* __restrict__ nn_id, const unsigned char* __restrict__ model_boundary,
-                                                               int boundary_aware, Pose pose, const double* __restrict__ ref,
-                                                               const double* __restrict__ mean, const int* __restrict__ tris,
-                                                               const int* __restrict__ adj_off, const int* __restrict__ adj, CorrBuffers cb) {
+__global__ void __launch_bounds__(kBlock) k_correspond_target(CorrTask c, const int* __restrict__ nn_id) {
   int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k >= K) return;
-  int id = nn_id[k];                                   // :118
-  bool on_boundary = model_boundary[id] != 0;          // :119
-  d3 n = vertex_normal(x, tris, adj_off, adj, id);     // :120
-  write_corr(cb, k, id, -1, ld3(tpts + 3 * k), boundary_aware ? !on_boundary : true, n, pose, ref, mean);
-}
-
-// ---------------------------------------------------------------- K5a regression assembly on the f64 matrix cores
-// Maug = Σ_i X_iᵀ W_i X_i with X_i = the 4×(r+1) block of correspondence i: rows 0-2 = [Q_i | e_i] (the three
-// coordinate rows, weight w_t), row 3 = n̂_iᵀ[Q_i | e_i] (weight κ).  The contraction length per correspondence is
-// exactly the K = 4 of v_mfma_f64_16x16x4_f64: one MFMA per correspondence per 16×16 output tile.
-// Operand maps (cdna_hip_programming.md §3): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
-// result register g of lane l is D[row = (l>>4) + 4g][col = l&15].
-// grid = (tiles, splits); block = one wave; partial sums per split are reduced by the factor kernel (deterministic).
-// The correspondence loop is unrolled ×4 so that the 24 gathered basis values of four correspondences are in flight
-// together (the loop is L2-latency bound, not bandwidth bound).
-
-typedef double d4_t __attribute__((ext_vector_type(4)));
-
-struct RegOperands { double A, B; };
-
-__device__ __forceinline__ void regression_load(int k, int r, const double* __restrict__ Q, const CorrBuffers& cb, int ca, int cbi,
-                                                double ma, double mb, double ea, double eb, double* a, double* b) {
-  const double* q = Q + (size_t)3 * cb.id[k] * r;
-  const double e0 = cb.e[3 * k], e1 = cb.e[3 * k + 1], e2 = cb.e[3 * k + 2];
-  a[0] = fma(ma, q[ca], ea * e0); a[1] = fma(ma, q[r + ca], ea * e1); a[2] = fma(ma, q[2 * r + ca], ea * e2);
-  b[0] = fma(mb, q[cbi], eb * e0); b[1] = fma(mb, q[r + cbi], eb * e1); b[2] = fma(mb, q[2 * r + cbi], eb * e2);
-}
-
-__device__ __forceinline__ d4_t regression_mac(int k, const CorrBuffers& cb, const double* a, const double* b, int kk, double wt,
-                                               double kappa, d4_t acc) {
-  const double on = cb.keep[k] ? 1.0 : 0.0;  // boundary-filtered correspondences contribute weight 0
-  const double n0 = cb.nhat[3 * k], n1 = cb.nhat[3 * k + 1], n2 = cb.nhat[3 * k + 2];
-  const double va = fma(a[2], n2, fma(a[1], n1, a[0] * n0));
-  const double vb = fma(b[2], n2, fma(b[1], n1, b[0] * n0));
-  const double A_op = kk == 0 ? a[0] : kk == 1 ? a[1] : kk == 2 ? a[2] : va;
-  const double B_op = (kk == 0 ? b[0] : kk == 1 ? b[1] : kk == 2 ? b[2] : vb) * (kk == 3 ? kappa : wt) * on;
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(A_op, B_op, acc, 0, 0, 0);
+  if (k < c.K) correspond_target_one(c, k, nn_id[k]);
 }
 
 __global__ void __launch_bounds__(64) k_regression_mfma(int K, int kchunk, int r, const double* __restrict__ Q, CorrBuffers cb,
                                                          double wt, double kappa, double* __restrict__ Mpart) {
-  const int n = r + 1, nt = (n + 15) >> 4;
-  const int ti = blockIdx.x / nt, tj = blockIdx.x - ti * nt;
-  const int l = threadIdx.x, i16 = l & 15, kk = l >> 4;
-  const int a = 16 * ti + i16, b = 16 * tj + i16;
-  const int ca = a < r ? a : 0, cbi = b < r ? b : 0;
-  const double ma = a < r ? 1.0 : 0.0, mb = b < r ? 1.0 : 0.0;      // basis column?
-  const double ea = a == r ? 1.0 : 0.0, eb = b == r ? 1.0 : 0.0;    // the appended observation column?
-  const int k0 = blockIdx.y * kchunk, k1 = min(K, k0 + kchunk);
-  d4_t acc = {0.0, 0.0, 0.0, 0.0};
-  int k = k0;
-  for (; k + 4 <= k1; k += 4) {
-    double xa[4][3], xb[4][3];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) regression_load(k + u, r, Q, cb, ca, cbi, ma, mb, ea, eb, xa[u], xb[u]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc = regression_mac(k + u, cb, xa[u], xb[u], kk, wt, kappa, acc);
-  }
-  for (; k < k1; ++k) {
-    double xa[3], xb[3];
-    regression_load(k, r, Q, cb, ca, cbi, ma, mb, ea, eb, xa, xb);
-    acc = regression_mac(k, cb, xa, xb, kk, wt, kappa, acc);
-  }
-  double* out = Mpart + (size_t)blockIdx.y * n * n;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int row = 16 * ti + kk + 4 * g, col = 16 * tj + i16;
-    if (row < n && col < n) out[(size_t)row * n + col] = acc[g];
-  }
+  regression_tile(blockIdx.x, blockIdx.y, K, kchunk, r, Q, cb, wt, kappa, Mpart);
 }
-
-// ---------------------------------------------------------------- dense helpers (one workgroup, matrix behind a generic pointer)
-
-__device__ double block_sum(double v, double* s_red) {
-  const int tid = threadIdx.x;
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  __syncthreads();
-  if ((tid & 63) == 0) s_red[tid >> 6] = v;
-  __syncthreads();
-  double t = 0.0;
-  for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) t += s_red[w];
-  return t;
-}
-__device__ double block_max(double v, double* s_red) {
-  const int tid = threadIdx.x;
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-  __syncthreads();
-  if ((tid & 63) == 0) s_red[tid >> 6] = v;
-  __syncthreads();
-  double t = s_red[0];
-  for (int w = 1; w < (int)((blockDim.x + 63) >> 6); ++w) t = fmax(t, s_red[w]);
-  return t;
-}
-
-// hardware reciprocal / reciprocal square root seeds + two Newton steps (≈ 1 ulp); the dependent chains of these small
-// factorisations are latency bound, and the IEEE division / sqrt expansions are 3-5× longer
-__device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-x, y, 1.0);
-  return fma(y, e, y);
-}
-__device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  const double h = 0.5 * x;
-  double e = fma(-h * y, y, 0.5);
-  y = fma(y, e, y);
-  e = fma(-h * y, y, 0.5);
-  return fma(y, e, y);
-}
-
-// y = A x for a row-major r×r matrix A (leading dimension lda; LDS or global), x and y in LDS.  2^tpr_log2 threads share
-// a row (their partial sums meet through wave shuffles), blockDim/2^tpr_log2 rows per pass.  Ends with a barrier.
-__device__ void block_matvec(int r, const double* A, int lda, const double* x, double* y, int tpr_log2) {
-  const int tid = threadIdx.x, tpr = 1 << tpr_log2, sub = tid & (tpr - 1);
-  const int rows_per_pass = blockDim.x >> tpr_log2;
-  for (int row0 = 0; row0 < r; row0 += rows_per_pass) {  // uniform trip count: every lane reaches the shuffles
-    const int row = row0 + (tid >> tpr_log2);
-    double acc = 0.0;
-    if (row < r) {
-      const double* a = A + (size_t)row * lda;
-#pragma unroll 8
-      for (int j = sub; j < r; j += tpr) acc = fma(a[j], x[j], acc);
-    }
-    for (int o = tpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (row < r && sub == 0) y[row] = acc;
-  }
-  __syncthreads();
-}
-
-// threads per row for block_matvec: enough rows in flight to occupy the block, at least ~8 terms per thread
-inline int matvec_tpr_log2(int r, int block) {
-  int t = 0;
-  while (t < 6 && (r << (t + 1)) <= block && (r >> (t + 1)) >= 8) ++t;
-  return t;
-}
-
-// copy a row-major r×r matrix into LDS with leading dimension ld
-__device__ void stage_matrix(int r, const double* __restrict__ src, double* dst, int ld) {
-  for (int e = threadIdx.x; e < r * r; e += blockDim.x) {
-    const int i = e / r, j = e - i * r;
-    dst[(size_t)i * ld + j] = src[e];
-  }
-}
-
-// Root-free right-looking Cholesky of the leading n×n block of W (leading dimension ld), in place, carrying `extra`
-// more rows below it through the same eliminations.  Column j is left UNSCALED (U[i][j] = L[i][j]·l_jj) and the
-// trailing update uses U[i][j]·U[k][j]/U[j][j], so each column costs ONE reciprocal and ONE barrier.
-// Afterwards L[i][j] = W[i][j]·dinv[j] with dinv[j] = 1/sqrt(W[j][j]).  2-D thread grid of tw×tw (tw² = blockDim).
-__device__ bool block_cholesky_rootfree(double* W, int n, int ld, int extra, int tw_log2) {
-  const int tid = threadIdx.x, tw = 1 << tw_log2, ty = tid >> tw_log2, tx = tid & (tw - 1);
-  const int rows = n + extra;
-  for (int j = 0; j < n; ++j) {
-    const double ajj = W[(size_t)j * ld + j];
-    if (!(ajj > 0.0)) return false;  // same value in every thread: uniform exit
-    const double inv = fast_rcp(ajj);
-    for (int i = j + 1 + ty; i < rows; i += tw) {
-      const double uij = W[(size_t)i * ld + j] * inv;
-      const int kmax = i < n ? i : n - 1;
-      for (int k = j + 1 + tx; k <= kmax; k += tw) W[(size_t)i * ld + k] = fma(-uij, W[(size_t)k * ld + j], W[(size_t)i * ld + k]);
-    }
-    __syncthreads();
-  }
-  return true;
-}
-
-// ---------------------------------------------------------------- K5b: M = I + Σ partials, chol(M), α = M⁻¹ b
-
-extern __shared__ double s_dyn[];
 
 struct FactorArgs {  // up to 4 posteriors per launch (both ICP directions of one or two states)
   const double* Mpart[4];
@@ -293,104 +100,11 @@ __global__ void __launch_bounds__(kFactorThreads) k_posterior_factor_generic(int
   }
 }
 
-// Fast path (the matrix fits a few elements per thread): every thread OWNS E fixed elements of the lower triangle of
-// [M; bᵀ] and keeps them in registers for the whole root-free factorisation; only the current pivot column is
-// published through a double-buffered LDS vector, so a column costs one reciprocal, ~E fused multiply-adds per thread
-// and ONE barrier.  The finished factor goes to LDS once, for the back substitution.
 template <int E, int NT>
 __global__ void __launch_bounds__(NT) k_posterior_factor_reg(int r, FactorArgs fa) {
-  __shared__ double s_col[2][516], s_dinv[512], s_v[512];
-  const int tid = threadIdx.x, n = r + 1, p = blockIdx.x;
-  const double* Mpart = fa.Mpart[p];
-  const int S = fa.splits[p];
-  double* M = fa.M[p];
-  const int ld = r | 1;
-  double* W = s_dyn;  // (r+1) × ld
-  const int tri = r * (r + 1) / 2, total = tri + r;
-  double v[E];
-  int im[E], km[E];
-#pragma unroll
-  for (int m = 0; m < E; ++m) {
-    const int e = tid + NT * m;
-    int i = r, k = e - tri;
-    if (e < tri) {
-      i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-      while ((i + 1) * (i + 2) / 2 <= e) ++i;
-      while (i * (i + 1) / 2 > e) --i;
-      k = e - i * (i + 1) / 2;
-    }
-    im[m] = i; km[m] = e < total ? k : -1;  // k = -1: slot unused (never > j, never published)
-    double x = 0.0;
-    if (e < total) {
-      for (int s = 0; s < S; ++s) x += Mpart[(size_t)s * n * n + (size_t)i * n + k];
-      if (i < r) {
-        if (i == k) x += 1.0;
-        M[(size_t)i * r + k] = x;
-        M[(size_t)k * r + i] = x;
-      }
-      if (k == 0) s_col[0][i] = x;
-    }
-    v[m] = x;
-  }
-  __syncthreads();
-  for (int j = 0; j < r; ++j) {
-    const double* cur = s_col[j & 1];
-    double* nxt = s_col[(j + 1) & 1];
-    const double ajj = cur[j];
-    if (!(ajj > 0.0)) {  // same value in every thread: uniform exit
-      if (tid == 0) fa.status[p][0] = 1;
-      return;
-    }
-    const double inv = fast_rcp(ajj);
-#pragma unroll
-    for (int m = 0; m < E; ++m) {
-      if (km[m] > j) {
-        v[m] = fma(-(cur[im[m]] * inv), cur[km[m]], v[m]);
-        if (km[m] == j + 1) nxt[im[m]] = v[m];  // column j+1 is final now: publish it as the next pivot column
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int m = 0; m < E; ++m)
-    if (km[m] >= 0) W[(size_t)im[m] * ld + km[m]] = v[m];
-  __syncthreads();
-  if (tid == 0) fa.status[p][0] = 0;
-  // y = L⁻¹ b sits (unscaled) in row r: y_j = W[r][j]·dinv_j,  L[i][j] = W[i][j]·dinv_j
-  for (int j = tid; j < r; j += NT) {
-    const double d = fast_rsqrt(W[(size_t)j * ld + j]);
-    s_dinv[j] = d;
-    s_v[j] = W[(size_t)r * ld + j] * d;
-  }
-  __syncthreads();
-  if (r <= 64) {
-    if (tid < 64) {  // one wave, registers + cross-lane reads: no barriers on the sequential chain
-      const int i = tid;
-      double x = i < r ? s_v[i] : 0.0;
-      const double di = i < r ? s_dinv[i] : 0.0;
-      for (int j = r - 1; j >= 0; --j) {
-        const double xj = __shfl(x, j, 64) * s_dinv[j];
-        if (i == j) x = xj;
-        else if (i < j) x = fma(-(W[(size_t)j * ld + i] * di), xj, x);
-      }
-      if (i < r) fa.alpha[p][i] = x;
-    }
-  } else {
-    for (int j = r - 1; j >= 0; --j) {
-      if (tid == 0) s_v[j] = s_v[j] * s_dinv[j];
-      __syncthreads();
-      const double xj = s_v[j];
-      for (int i = tid; i < j; i += NT) s_v[i] = fma(-(W[(size_t)j * ld + i] * s_dinv[i]), xj, s_v[i]);
-      __syncthreads();
-    }
-    for (int i = tid; i < r; i += NT) fa.alpha[p][i] = s_v[i];
-  }
+  const int p = blockIdx.x;
+  factor_reg_body<E, NT>(r, fa.Mpart[p], fa.splits[p], fa.M[p], fa.alpha[p], fa.status[p]);
 }
-
-// ---------------------------------------------------------------- a9 transition tails (batched, one workgroup each)
-// (G + σ²M) γ = G d  ⇔  γ = d − σ² G⁻¹ M γ : fixed-point iteration with contraction factor ρ(σ² G⁻¹ M) (≈ 4e-8 for the
-// femur model), run to machine precision; status != 0 if it does not contract, and the host then uses the direct
-// (Cholesky) kernel below.  M and G⁻¹ are staged in LDS when they fit.
 
 struct TailArgs {
   int n;
@@ -405,47 +119,10 @@ struct TailArgs {
 
 __global__ void __launch_bounds__(256) k_transition_tails(int r, TailArgs ta, const double* __restrict__ Ginv, double sigma2,
                                                            int n_lds, int tpr_log2) {
-  __shared__ double s_d[512], s_g[512], s_t[512], s_u[512], s_red[16];
-  const int tid = threadIdx.x, nt = blockDim.x, t = blockIdx.x;
-  const int ld = r | 1;
-  const double* M = ta.M[t];
-  const double* Gi = Ginv;
-  int ldm = r, ldg = r;
-  if (n_lds >= 1) { stage_matrix(r, ta.M[t], s_dyn, ld); M = s_dyn; ldm = ld; }
-  if (n_lds >= 2) { stage_matrix(r, Ginv, s_dyn + (size_t)r * ld, ld); Gi = s_dyn + (size_t)r * ld; ldg = ld; }
-  for (int i = tid; i < r; i += nt) {
-    const double d = (ta.c_from[t][i] + (ta.c_to[t][i] - ta.c_from[t][i]) / ta.step[t]) - ta.alpha[t][i];  // :79 minus posterior mean
-    s_d[i] = d;
-    s_g[i] = d;
-  }
-  __syncthreads();
-  int converged = 0;
-  for (int it = 0; it < 12 && !converged; ++it) {
-    block_matvec(r, M, ldm, s_g, s_t, tpr_log2);
-    block_matvec(r, Gi, ldg, s_t, s_u, tpr_log2);
-    double delta = 0.0, gmax = 0.0;
-    for (int i = tid; i < r; i += nt) {
-      const double gn = fma(-sigma2, s_u[i], s_d[i]);
-      delta = fmax(delta, fabs(gn - s_g[i]));
-      gmax = fmax(gmax, fabs(gn));
-      s_g[i] = gn;
-    }
-    delta = block_max(delta, s_red);
-    gmax = block_max(gmax, s_red);
-    converged = delta <= 1e-15 * gmax || gmax == 0.0;
-    __syncthreads();
-  }
-  block_matvec(r, M, ldm, s_g, s_t, tpr_log2);
-  double part = 0.0;
-  for (int i = tid; i < r; i += nt) part = fma(s_g[i], s_t[i], part);
-  const double q = block_sum(part, s_red);
-  if (tid == 0) {
-    ta.out[t][0] = -0.5 * q - 0.5 * (double)r * 1.8378770664093453;  // ln(2π); no log-det term
-    ta.status[t][0] = converged ? 0 : 3;
-  }
+  const int t = blockIdx.x;
+  tail_body(r, ta.alpha[t], ta.M[t], ta.c_from[t], ta.c_to[t], ta.step[t], ta.out[t], ta.status[t], Ginv, sigma2, n_lds, tpr_log2);
 }
 
-// direct version: factor G + σ²M, solve, quadratic form.  Used only if the iteration above reports non-contraction.
 __global__ void __launch_bounds__(1024) k_transition_tail_direct(int r, const double* __restrict__ alpha, const double* __restrict__ M,
                                                                   const double* __restrict__ G, double sigma2,
                                                                   const double* __restrict__ c_from, const double* __restrict__ c_to,
@@ -730,15 +407,7 @@ __global__ void __launch_bounds__(256) k_propose(int r, const double* __restrict
 
 __global__ void __launch_bounds__(kBlock) k_sum_gauss_logpdf(int K, const double* __restrict__ d2, double mean, double sigma,
                                                               double* __restrict__ out) {
-  __shared__ double s_red[16];
-  const double lognorm = log(sqrt(2.0 * 3.14159265358979323846)) + log(sigma);  // Breeze Gaussian.logNormalizer
-  double part = 0.0;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    double d = (sqrt(d2[k]) - mean) / sigma;
-    part += -d * d / 2.0 - lognorm;
-  }
-  double t = block_sum(part, s_red);
-  if (threadIdx.x == 0) out[0] = t;
+  sum_gauss_logpdf_body(K, d2, mean, sigma, out);
 }
 
 __global__ void __launch_bounds__(kBlock) k_dist_stats(int K, const double* __restrict__ d2, const unsigned char* __restrict__ flags,
@@ -771,9 +440,9 @@ void launch_correspond_model(hipStream_t st, int K, const double* x, const doubl
                              const double* ref, const double* mean, const int* tris, const int* adj_off,
                              const int* adj, const CorrBuffers& cb) {
   if (K <= 0) return;
-  { ProfScope _ps(st, KID_CORRESPOND);
-    hipLaunchKernelGGL(k_correspond_model, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, K, x, cp, nnv, tgt_boundary,
-                     boundary_aware, pose, ref, mean, tris, adj_off, adj, cb); }
+  CorrTask c{K, cb, x, nullptr, tgt_boundary, nnv, boundary_aware, pose, ref, mean, tris, adj_off, adj};
+  ProfScope _ps(st, KID_CORRESPOND);
+  hipLaunchKernelGGL(k_correspond_model, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, c, cp);
 }
 
 void launch_correspond_target(hipStream_t st, int K, const double* x, const double* tpts, const int* nn_id,
@@ -781,9 +450,9 @@ void launch_correspond_target(hipStream_t st, int K, const double* x, const doub
                               const double* ref, const double* mean, const int* tris, const int* adj_off,
                               const int* adj, const CorrBuffers& cb) {
   if (K <= 0) return;
-  { ProfScope _ps(st, KID_CORRESPOND);
-    hipLaunchKernelGGL(k_correspond_target, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, K, x, tpts, nn_id, model_boundary,
-                     boundary_aware, pose, ref, mean, tris, adj_off, adj, cb); }
+  CorrTask c{K, cb, x, tpts, model_boundary, nullptr, boundary_aware, pose, ref, mean, tris, adj_off, adj};
+  ProfScope _ps(st, KID_CORRESPOND);
+  hipLaunchKernelGGL(k_correspond_target, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, c, nn_id);
 }
 
 int regression_splits(int K) {
