@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
-DOMINANT = "k_surface_filter"
+DOMINANT = "k_step_filter"
 
 
 def main():
@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=300, help="steps of the HIP-event roofline leg (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=16, help="steps of the CPU-oracle baseline leg (0 = skip)")
     ap.add_argument("--subdiv", type=int, default=6, help="edge subdivision of the synthetic target (6 -> 58,322 vertices)")
-    ap.add_argument("--no-fused", action="store_true", help="per-method calls only (no icp_chain_eval_step prefetch)")
+    ap.add_argument("--fused", type=int, default=2, choices=[0, 1, 2],
+                    help="host<->device call pattern per step: 0 per-method calls, 1 propose + icp_chain_eval_step, 2 one icp_chain_step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -67,7 +68,7 @@ def main():
     model, target = pkg.data.synthetic_femur_target(n_subdiv=args.subdiv)
     r = model.rank
     ctx = pkg.IcpContext(model, target, device=local_rank)
-    setup = pkg.femur_icp_proposal_registration(model, target, fused=not args.no_fused)
+    setup = pkg.femur_icp_proposal_registration(model, target, fused=args.fused)
     theta0 = pkg.initial_parameters(model)
     if rank > 0:  # apps/femur/RandomSamplesFromModel.scala:28-35: chain i > 0 starts from c ~ N(0, 0.1·I)
         theta0[10:] = np.random.default_rng(1024 + rank).normal(size=r) * np.sqrt(0.1)
@@ -126,7 +127,7 @@ def main():
                         "1 chain per GPU; 0.9 ICP(Target+Model sampling, K=%d) + 0.1 random walk; prior x independent Gaussian(0,2) on %d points"
                         % (model.n_points, r, target.n_points, target.n_cells, 2 * r, 4 * r),
             "chains_per_gpu": 1,
-            "fused_step_call": not args.no_fused,
+            "calls_per_step": {0: "per-method", 1: "propose + icp_chain_eval_step", 2: "icp_chain_step"}[args.fused],
             "accepted": n_acc,
             "icp_proposals": n_icp,
         },
@@ -145,6 +146,8 @@ def main():
                 n_queries = setup.eval["n_model_ids"]  # ids 0..4r-1 (the proposal's 0..2r-1 are a subset, shared)
                 # algorithmic bytes per launch: target vertices 3·M·8 + target triangles 3·Tt·4 + queries K·3·8
                 alg_bytes = 3 * target.n_points * 8 + 3 * target.n_cells * 4 + n_queries * 24
+                if DOMINANT == "k_step_filter":  # the merged launch also holds the TargetSampling search: model vertices + its queries
+                    alg_bytes += 3 * model.n_points * 8 + 2 * r * 24
                 avg_s = k["avg_us"] * 1e-6
                 achieved = alg_bytes / avg_s / 1e9
                 traffic = None

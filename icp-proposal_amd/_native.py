@@ -76,6 +76,8 @@ SIGNATURES = {
     "icp_ctx_profile_stop": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),
     "icp_chain_eval_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_double_p]),
+    "icp_chain_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, c_double_p, c_double_p, c_double_p,
+                                 c_double_p, c_double_p, c_double_p]),
 }
 
 _LIB = None

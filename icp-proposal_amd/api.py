@@ -323,3 +323,23 @@ def chain_eval_step(evaluator: _Evaluator, proposals, theta_cur, theta_prop):
     nat.check(nat.lib().icp_chain_eval_step(evaluator.h, n, arr, _d(a), _d(b), C.byref(val), _d(fwd), _d(bwd)),
               "icp_chain_eval_step")
     return val.value, fwd[:n], bwd[:n]
+
+
+def chain_step(evaluator: _Evaluator, proposals, theta_cur, generator: int = -1, z=None, theta_prop=None):
+    """icp_chain_step: propose from proposals[generator] (or take theta_prop as given when generator < 0) AND evaluate the
+    proposal — likelihood + forward/backward transition log-densities of every proposal — in one device submission.
+    Returns (theta_prop, log_value, fwd, bwd)."""
+    a = _theta(theta_cur)
+    n = len(proposals)
+    arr = (C.c_void_p * max(n, 1))(*[p.h for p in proposals])
+    if generator >= 0:
+        zz = np.ascontiguousarray(z, dtype=np.float64)
+        b = np.zeros_like(a)
+    else:
+        zz = np.zeros(1)
+        b = _theta(theta_prop).copy()
+    val = C.c_double()
+    fwd, bwd = np.zeros(max(n, 1)), np.zeros(max(n, 1))
+    nat.check(nat.lib().icp_chain_step(evaluator.h, n, arr, int(generator), _d(a), _d(zz), _d(b), C.byref(val), _d(fwd), _d(bwd)),
+              "icp_chain_step")
+    return b, val.value, fwd[:n], bwd[:n]

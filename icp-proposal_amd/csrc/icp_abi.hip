@@ -221,6 +221,7 @@ struct icp_ctx {
   StateSlot slots[kStateSlots];
   uint64_t clock = 0;
   QueryScratch scratch;
+  QueryScratch scratch_v;  // second scratch: the merged step launches run a surface and a vertex search side by side
   // staging for small host<->device transfers of one API call
   double* h_stage = nullptr;  // pinned
   DBuf<double> d_stage;
@@ -236,7 +237,8 @@ struct icp_ctx {
   void bind() { HIP_OK(hipSetDevice(device)); }
 
   // scratch for K queries against a set of n_elems elements (every query may list every element as a candidate)
-  QueryBuffers query_scratch(size_t K, size_t n_elems) {
+  QueryBuffers query_scratch(size_t K, size_t n_elems, bool second = false) {
+    QueryScratch& scratch = second ? scratch_v : this->scratch;
     if (K > scratch.cap) {
       HIP_OK(hipStreamSynchronize(stream));
       size_t cap = std::max<size_t>(K, 4096);
@@ -274,6 +276,8 @@ struct icp_ctx {
   }
 
   StateSlot& state(const double* theta);
+  StateSlot* find_state(const double* theta);
+  StateSlot& fresh_state();
   void ensure_model_spheres(StateSlot& s);
   void ensure_surface_prefix(StateSlot& s, int K);
   void ensure_nnv_prefix(StateSlot& s, int K);
@@ -289,14 +293,17 @@ struct Bound {  // selects the context's device and (if enabled) its profiler fo
 };
 }  // namespace
 
-StateSlot& icp_ctx::state(const double* theta) {
+StateSlot* icp_ctx::find_state(const double* theta) {
   const size_t P = 10 + (size_t)r;
+  for (auto& s : slots)
+    if (s.valid && std::memcmp(s.theta.data(), theta, sizeof(double) * P) == 0) return &s;
+  return nullptr;
+}
+
+// least recently used slot, emptied (buffers allocated on first use); the caller fills it and sets `valid`
+StateSlot& icp_ctx::fresh_state() {
   StateSlot* lru = &slots[0];
   for (auto& s : slots) {
-    if (s.valid && std::memcmp(s.theta.data(), theta, sizeof(double) * P) == 0) {
-      s.stamp = ++clock;
-      return s;
-    }
     if (!s.valid) { if (lru->valid) lru = &s; }
     else if (lru->valid && s.stamp < lru->stamp) lru = &s;
   }
@@ -310,13 +317,24 @@ StateSlot& icp_ctx::state(const double* theta) {
     s.surf_tri.alloc(N);
     s.surf_nnv.alloc(N);
   }
+  s.valid = false;
+  s.spheres_valid = false;
+  s.n_surf = 0;
+  s.n_nnv = 0;
+  return s;
+}
+
+StateSlot& icp_ctx::state(const double* theta) {
+  const size_t P = 10 + (size_t)r;
+  if (StateSlot* hit = find_state(theta)) {
+    hit->stamp = ++clock;
+    return *hit;
+  }
+  StateSlot& s = fresh_state();
   s.theta.assign(theta, theta + P);
   s.valid = true;
   s.stamp = ++clock;
   s.pose = pose_from_theta(theta);
-  s.spheres_valid = false;
-  s.n_surf = 0;
-  s.n_nnv = 0;
   const double* dc = stage(theta + 10, r);
   HIP_OK(hipMemcpyAsync(s.coeffs.p, dc, sizeof(double) * r, hipMemcpyDeviceToDevice, stream));
   launch_instance(stream, N, r, Qp.p, ref.p, mean.p, s.pose, s.coeffs.p, s.x.p);  // ModelFittingParameters.scala:108-110
@@ -378,7 +396,7 @@ struct icp_proposal {
   DBuf<double> work;      // r*r scratch of the eigen / direct-tail kernels
   DBuf<double> Mpart;     // split-K partial normal matrices of the regression kernel
   DBuf<double> fscratch;  // (r+1)·r factorisation scratch (ranks too large for LDS)
-  DBuf<double> warmV;     // eigenvectors of the most recent posterior: warm start of the next eigen-decomposition
+  const double* warm_ptr = nullptr;  // eigenvectors of the most recent posterior (inside its memo entry): warm start of the next
   bool warm_valid = false;
   DBuf<int> status;       // 3 ints per memo entry: {chol(M), chol(G+σ²M), eigen}
   std::vector<int> h_status;
@@ -386,6 +404,8 @@ struct icp_proposal {
   uint64_t clock = 0;
 
   PosteriorEntry& posterior(const double* theta, bool want_aux);
+  PosteriorEntry* find_entry(const double* theta);
+  PosteriorEntry& fresh_entry();
   void ensure_eigen(PosteriorEntry& e);
   void check_status(PosteriorEntry& e);
 };
@@ -442,23 +462,19 @@ void check_theta_finite(const icp_ctx* ctx, const double* theta) {
 
 // ===================================================================== posterior (NonRigidIcpProposal.scala:88-153)
 
-PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
-  icp_ctx& c = *ctx;
-  const int r = c.r;
-  const size_t P = 10 + (size_t)r;
+PosteriorEntry* icp_proposal::find_entry(const double* theta) {
+  const size_t P = 10 + (size_t)ctx->r;
+  for (int i = 0; i < kPosteriorMemo; ++i)
+    if (memo[i].valid && std::memcmp(memo[i].theta.data(), theta, sizeof(double) * P) == 0) return &memo[i];
+  return nullptr;
+}
+
+// least recently used memo entry, emptied; the caller fills it and sets `valid`
+PosteriorEntry& icp_proposal::fresh_entry() {
+  const int r = ctx->r;
   PosteriorEntry* lru = &memo[0];
   for (int i = 0; i < kPosteriorMemo; ++i) {
     PosteriorEntry& e = memo[i];
-    if (e.valid && std::memcmp(e.theta.data(), theta, sizeof(double) * P) == 0) {
-      e.stamp = ++clock;
-      if (want_aux && prm.direction == ICP_MODEL_SAMPLING) {
-        // diagnostic request for corr_aux on a cached entry: recompute the nearest-vertex ids into it
-        StateSlot& s = c.state(theta);
-        c.ensure_nnv_prefix(s, K);
-        HIP_OK(hipMemcpyAsync(e.aux.p, s.surf_nnv.p, sizeof(int) * K, hipMemcpyDeviceToDevice, c.stream));
-      }
-      return e;
-    }
     if (!e.valid) { if (lru->valid) lru = &e; }
     else if (lru->valid && e.stamp < lru->stamp) lru = &e;
   }
@@ -471,9 +487,29 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
     e.alpha.alloc(r); e.V.alloc((size_t)r * r); e.Vt.alloc((size_t)r * r); e.S.alloc(r);
     e.status_off = 3 * (int)(&e - &memo[0]);
   }
+  e.valid = false;
+  e.eig_valid = false;
+  return e;
+}
+
+PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
+  icp_ctx& c = *ctx;
+  const int r = c.r;
+  const size_t P = 10 + (size_t)r;
+  if (PosteriorEntry* hit = find_entry(theta)) {
+    PosteriorEntry& e = *hit;
+    e.stamp = ++clock;
+    if (want_aux && prm.direction == ICP_MODEL_SAMPLING) {
+      // diagnostic request for corr_aux on a cached entry: recompute the nearest-vertex ids into it
+      StateSlot& s = c.state(theta);
+      c.ensure_nnv_prefix(s, K);
+      HIP_OK(hipMemcpyAsync(e.aux.p, s.surf_nnv.p, sizeof(int) * K, hipMemcpyDeviceToDevice, c.stream));
+    }
+    return e;
+  }
+  PosteriorEntry& e = fresh_entry();
   e.theta.assign(theta, theta + P);
   e.valid = true;
-  e.eig_valid = false;
   e.stamp = ++clock;
   StateSlot& s = c.state(theta);  // :141 currentMesh
   HIP_OK(hipMemcpyAsync(e.coeffs.p, s.coeffs.p, sizeof(double) * r, hipMemcpyDeviceToDevice, c.stream));
@@ -506,9 +542,10 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
 void icp_proposal::ensure_eigen(PosteriorEntry& e) {
   if (e.eig_valid) return;
   icp_ctx& c = *ctx;
-  launch_posterior_eigen(c.stream, c.r, e.M.p, c.sqrt_lambda.p, warm_valid ? warmV.p : nullptr, e.V.p, e.Vt.p, e.S.p, work.p,
+  // the kernel reads all of Vwarm before it writes V, so the two may be the same buffer (a reused memo entry)
+  launch_posterior_eigen(c.stream, c.r, e.M.p, c.sqrt_lambda.p, warm_valid ? warm_ptr : nullptr, e.V.p, e.Vt.p, e.S.p, work.p,
                          status.p + e.status_off + 2);
-  HIP_OK(hipMemcpyAsync(warmV.p, e.V.p, sizeof(double) * c.r * c.r, hipMemcpyDeviceToDevice, c.stream));
+  warm_ptr = e.V.p;
   warm_valid = true;
   e.eig_valid = true;
 }
@@ -532,6 +569,10 @@ namespace {
 void sync_proposal_status(icp_proposal* p) {
   icp_ctx& c = *p->ctx;
   HIP_OK(hipMemcpyAsync(p->h_status.data(), p->status.p, sizeof(int) * 3 * kPosteriorMemo, hipMemcpyDeviceToHost, c.stream));
+}
+
+void sync_proposal_status_if(icp_proposal* p, bool needed) {
+  if (needed) sync_proposal_status(p);
 }
 
 // ===================================================================== evaluators
@@ -968,7 +1009,6 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     p->work.alloc((size_t)ctx->r * ctx->r);
     p->Mpart.alloc((size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1));
     p->fscratch.alloc((size_t)(ctx->r + 1) * ctx->r);
-    p->warmV.alloc((size_t)ctx->r * ctx->r);
     p->status.alloc(3 * kPosteriorMemo);
     p->status.fill_bytes(0);
     p->h_status.assign(3 * kPosteriorMemo, 0);
@@ -1242,6 +1282,255 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
     }
   });
   return rc != ICP_OK ? rc : status;
+}
+
+// --------------------------------------------------------------------- one Metropolis–Hastings step, one submission
+
+namespace {
+
+// the merged-launch pipeline covers the configurations of the reference's experiments that run on closed targets
+// (apps/femur/*): one proposal per ICP direction, model-to-target likelihood; everything else takes the per-stage path
+bool step_pipeline_covers(icp_evaluator* e, int n_props, icp_proposal* const* props) {
+  icp_ctx& c = *e->ctx;
+  if (n_props < 1 || n_props > 2) return false;
+  const icp_evaluator_params& ep = e->prm;
+  if (ep.mode != ICP_MODEL_TO_TARGET || ep.n_model_ids < 1) return false;
+  if (ep.kind == ICP_EVAL_HAUSDORFF) return false;
+  if (ep.kind == ICP_EVAL_COLLECTIVE_AVG_HAUSDORFF_BOUNDARY_AWARE && c.target.n_boundary > 0) return false;
+  int n_model = 0, n_target = 0, ksurf = ep.n_model_ids;
+  for (int i = 0; i < n_props; ++i) {
+    const icp_proposal* p = props[i];
+    if (p->K < 1) return false;
+    if (p->prm.direction == ICP_MODEL_SAMPLING) {
+      if (p->prm.boundary_aware && c.target.n_boundary > 0) return false;  // needs the nearest-vertex pass (:98-99)
+      ++n_model;
+      ksurf = std::max(ksurf, p->K);
+    } else {
+      ++n_target;
+    }
+  }
+  if (n_model > 1 || n_target > 1) return false;
+  if (c.target.T < 1 || (size_t)(ksurf + 4) * (size_t)c.target.T > kMaxCandidates) return false;
+  if (n_target && (size_t)(props[0]->K + props[n_props - 1]->K + 8) * (size_t)c.N > kMaxCandidates) return false;
+  return step_finish_supported(c.r);
+}
+
+}  // namespace
+
+int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, int32_t generator, const double* theta_cur,
+                   const double* z, double* theta_prop, double* log_value_prop, double* fwd, double* bwd) {
+  int status = ICP_OK;
+  bool per_stage = false;
+  int rc = guard([&] {
+    require(e && theta_cur && theta_prop && log_value_prop, "null argument");
+    require(n_props >= 0 && n_props <= 8 && (n_props == 0 || (props && fwd && bwd)), "bad proposal list");
+    require(generator < n_props, "generator index out of range");
+    require(generator < 0 || z, "z is null");
+    icp_ctx& c = *e->ctx;
+    for (int i = 0; i < n_props; ++i) require(props[i] && props[i]->ctx == &c, "proposal belongs to another context");
+    check_theta_finite(&c, theta_cur);
+    if (generator < 0) check_theta_finite(&c, theta_prop);
+    else
+      for (int j = 0; j < c.r; ++j)
+        if (!std::isfinite(z[j])) fail(ICP_ERR_NOT_FINITE, "z contains a non-finite value");
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    const int r = c.r;
+    per_stage = !step_pipeline_covers(e, n_props, props);
+    if (!per_stage && generator < 0) {
+      // a state the caches already know (or a pose move, whose ICP transition densities are -inf) has nothing to merge
+      per_stage = !pose_equal(theta_cur, theta_prop) || c.find_state(theta_prop) || eval_lookup(e, theta_prop);
+      for (int i = 0; i < n_props && !per_stage; ++i) per_stage = props[i]->find_entry(theta_prop) != nullptr;
+    }
+    if (per_stage) return;
+    Bound _b(&c);
+
+    // ---- cached side: posterior of the current state for every proposal (+ its KL basis for the generating one)
+    PosteriorEntry* ec[2];
+    PosteriorEntry* ep[2];
+    for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
+    bool eigen_enqueued = false;
+    if (generator >= 0 && !ec[generator]->eig_valid) {
+      props[generator]->ensure_eigen(*ec[generator]);
+      eigen_enqueued = true;
+    }
+
+    // ---- new side: one state slot, one memo entry per proposal
+    StateSlot& s = c.fresh_state();
+    s.pose = pose_from_theta(generator >= 0 ? theta_cur : theta_prop);
+    for (int i = 0; i < n_props; ++i) ep[i] = &props[i]->fresh_entry();
+    const icp_evaluator_params& evp = e->prm;
+    icp_proposal* pm = nullptr;  // ModelSampling proposal
+    icp_proposal* pt = nullptr;  // TargetSampling proposal
+    int im = -1, it = -1;
+    for (int i = 0; i < n_props; ++i) {
+      if (props[i]->prm.direction == ICP_MODEL_SAMPLING) { pm = props[i]; im = i; }
+      else { pt = props[i]; it = i; }
+    }
+    const int Ksurf = std::max(evp.n_model_ids, pm ? pm->K : 0);
+    require(Ksurf <= c.N, "model id count exceeds the number of model points");
+    QueryBuffers qs = c.query_scratch(Ksurf, c.target.T);
+    QueryBuffers qv{};
+    if (pt) qv = c.query_scratch(pt->K, c.N, true);
+    for (int i = 0; i < 16; ++i) c.h_res[i] = 0.0;
+    for (int i = 0; i < 16; ++i) c.h_status[i] = 0;
+
+    SurfaceTask st_surf = make_surface_task(c.target.T, c.target.verts.p, c.target.tris.p, c.target.spheres.p, Ksurf, s.x.p,
+                                            c.hint_surf.p, qs, s.surf_cp.p, s.surf_d2.p, s.surf_tri.p);
+    VertexTask st_vert{};
+    if (pt) st_vert = make_vertex_task(c.N, s.x.p, pt->K, pt->target_pts.p, pt->hint_nn.p, qv, nullptr, pt->nn_id.p);
+
+    // 1: coefficients -> instance -> bounds
+    StepBeginArgs b{};
+    b.N = c.N; b.r = r; b.inst_blocks = (c.N + 255) / 256;
+    b.Qp = c.Qp.p; b.ref = c.ref.p; b.mean = c.mean.p; b.pose = s.pose;
+    b.propose = generator >= 0 ? 1 : 0;
+    const double* src = generator >= 0 ? z : theta_prop + 10;
+    if (r <= kStepInlineZ) std::memcpy(b.zin, src, sizeof(double) * r);
+    else {
+      if ((size_t)r > c.stage_cap) fail(ICP_ERR_INVALID_ARG, "internal: staging area exhausted");
+      std::memcpy(c.h_stage, src, sizeof(double) * r);
+      b.z_ptr = c.h_stage;  // pinned, read by the device in place
+    }
+    if (generator >= 0) {
+      PosteriorEntry& g = *ec[generator];
+      b.prop = ProposeIn{g.alpha.p, g.V.p, g.S.p, c.inv_sqrt_lambda.p, c.P.p, g.coeffs.p, nullptr, kSigma2,
+                         props[generator]->prm.step_length};
+      int t = 0;
+      while (t < 6 && (r << (t + 1)) <= 256 && (r >> (t + 1)) >= 8) ++t;  // = matvec_tpr_log2(r, 256) of k_propose
+      b.tpr_log2 = t;
+    }
+    b.n_out = 0;
+    b.out[b.n_out++] = s.coeffs.p;
+    for (int i = 0; i < n_props; ++i) b.out[b.n_out++] = ep[i]->coeffs.p;
+    b.out[b.n_out++] = c.h_res + 16;
+    b.x = s.x.p;
+    b.has_surf = 1; b.surf = st_surf;
+    b.has_vert = pt ? 1 : 0; b.vert = st_vert;
+    launch_step_begin(c.stream, b);
+
+    // 2 + 3: searches and correspondences
+    StepSearchArgs q{};
+    q.n_surf = 1; q.n_vert = pt ? 1 : 0;
+    q.s[0] = st_surf;
+    q.fstart[0] = 0; q.fstart[1] = st_surf.tblocks * st_surf.ksplit;
+    q.rstart[0] = 0; q.rstart[1] = Ksurf;
+    q.s_corr[0] = q.s_corr[1] = q.v_corr[0] = q.v_corr[1] = -1;
+    int n_corr = 0;
+    if (pm) {
+      q.corr[n_corr] = CorrTask{pm->K, ep[im]->corr(), s.x.p, nullptr, c.target.boundary.p, nullptr, pm->prm.boundary_aware,
+                                s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p};
+      q.s_corr[0] = n_corr++;
+    }
+    if (pt) {
+      q.v[0] = st_vert;
+      q.fstart[2] = q.fstart[1] + st_vert.vblocks * st_vert.ksplit;
+      q.rstart[2] = q.rstart[1] + pt->K;
+      q.corr[n_corr] = CorrTask{pt->K, ep[it]->corr(), s.x.p, pt->target_pts.p, c.boundary.p, nullptr, pt->prm.boundary_aware,
+                                s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p};
+      q.v_corr[0] = n_corr++;
+    }
+    launch_step_filter(c.stream, q);
+    launch_step_resolve(c.stream, q);
+
+    // 4: regressions + likelihood reduction
+    StepRegressionArgs g{};
+    g.n = n_props; g.r = r;
+    const int nt = (r + 1 + 15) / 16;
+    g.ntiles = nt * nt;
+    g.Q = c.Q.p;
+    g.ustart[0] = 0;
+    int splits[2] = {1, 1};
+    for (int i = 0; i < n_props; ++i) {
+      icp_proposal* p = props[i];
+      splits[i] = regression_splits(p->K);
+      g.K[i] = p->K;
+      g.kchunk[i] = std::max(1, (p->K + splits[i] - 1) / splits[i]);
+      g.cb[i] = ep[i]->corr();
+      g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
+      g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];
+      g.Mpart[i] = p->Mpart.p;
+      g.ustart[i + 1] = g.ustart[i] + g.ntiles * splits[i];
+    }
+    if (n_props == 1) g.ustart[2] = g.ustart[1];
+    g.reduce_kind = evp.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE ? 1 : 2;
+    g.Kred = evp.n_model_ids; g.d2 = s.surf_d2.p; g.mean = evp.gauss_mean; g.sigma = evp.gauss_sigma;
+    g.red_out = c.h_res;
+    launch_step_regression(c.stream, g);
+
+    // 5: factorisations + tails (results go straight to pinned host memory)
+    StepFinishArgs f{};
+    f.n = n_props; f.r = r; f.Ginv = c.Ginv.p; f.sigma2 = kSigma2;
+    for (int i = 0; i < n_props; ++i) {
+      icp_proposal* p = props[i];
+      f.Mpart[i] = p->Mpart.p; f.splits[i] = splits[i];
+      f.M[i] = ep[i]->M.p; f.alpha[i] = ep[i]->alpha.p;
+      f.status[i] = p->status.p + ep[i]->status_off;
+      f.host_status[i] = c.h_status + 8 + i;
+      f.fwd[i] = TransitionTailIO{ec[i]->alpha.p, ec[i]->M.p, ec[i]->coeffs.p, ep[i]->coeffs.p, p->prm.step_length,
+                                  c.h_res + 8 + 2 * i, c.h_status + 2 * i};
+      f.bwd[i] = TransitionTailIO{ep[i]->alpha.p, ep[i]->M.p, ep[i]->coeffs.p, ec[i]->coeffs.p, p->prm.step_length,
+                                  c.h_res + 9 + 2 * i, c.h_status + 2 * i + 1};
+    }
+    launch_step_finish(c.stream, f);
+    for (int i = 0; i < n_props; ++i) sync_proposal_status_if(props[i], eigen_enqueued && i == generator);
+    c.finish(0, 0);
+
+    // ---- bookkeeping with the results in hand
+    const size_t P = 10 + (size_t)r;
+    if (generator >= 0) {
+      std::memcpy(theta_prop, theta_cur, sizeof(double) * 10);  // :64-66 only the shape changes
+      for (int j = 0; j < r; ++j) {
+        if (!std::isfinite(c.h_res[16 + j])) fail(ICP_ERR_NOT_FINITE, "proposed coefficients are not finite");
+        theta_prop[10 + j] = c.h_res[16 + j];
+      }
+    }
+    s.theta.assign(theta_prop, theta_prop + P);
+    s.valid = true;
+    s.stamp = ++c.clock;
+    s.n_surf = Ksurf;
+    for (int i = 0; i < n_props; ++i) {
+      icp_proposal* p = props[i];
+      ep[i]->theta.assign(theta_prop, theta_prop + P);
+      ep[i]->valid = true;
+      ep[i]->stamp = ++p->clock;
+      p->h_status[ep[i]->status_off] = c.h_status[8 + i];
+      p->h_status[ep[i]->status_off + 1] = 0;
+      p->h_status[ep[i]->status_off + 2] = 0;
+      p->check_status(*ec[i]);
+      p->check_status(*ep[i]);
+    }
+    for (int t = 0; t < 2 * n_props; ++t)
+      if (c.h_status[t] != 0) {  // rare: the fixed-point tail did not contract -> direct kernel
+        std::vector<double> saved(c.h_res, c.h_res + 16);
+        icp_proposal* p = props[t / 2];
+        TransitionTailIO io = (t % 2 == 0) ? f.fwd[t / 2] : f.bwd[t / 2];
+        io.out = c.d_res.p;
+        io.status = c.d_status.p + 32;
+        launch_transition_tail_direct(c.stream, r, io, c.G.p, kSigma2, p->work.p);
+        c.finish(1, 64);
+        if (c.h_status[32] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
+        saved[8 + t] = c.h_res[0];
+        std::memcpy(c.h_res, saved.data(), sizeof(double) * saved.size());
+      }
+    icp_evaluator::Memo* m = eval_store(e, theta_prop);
+    m->status = finish_eval(e, c.h_res, &m->value, m->aux);
+    *log_value_prop = m->value;
+    status = m->status;
+    for (int i = 0; i < n_props; ++i) {
+      fwd[i] = c.h_res[8 + 2 * i];
+      bwd[i] = c.h_res[9 + 2 * i];
+      if (std::isnan(fwd[i]) || std::isnan(bwd[i])) fail(ICP_ERR_NOT_FINITE, "NaN transition probability");
+    }
+  });
+  if (rc != ICP_OK) return rc;
+  if (per_stage) {  // same results through the per-stage kernels
+    if (generator >= 0) {
+      rc = icp_proposal_propose(props[generator], theta_cur, z, theta_prop, nullptr);
+      if (rc != ICP_OK) return rc;
+    }
+    return icp_chain_eval_step(e, n_props, props, theta_cur, theta_prop, log_value_prop, fwd, bwd);
+  }
+  return status;
 }
 
 }  // extern "C"

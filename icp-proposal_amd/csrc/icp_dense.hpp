@@ -27,22 +27,6 @@ __device__ __forceinline__ void write_corr(const CorrBuffers& cb, int k, int id,
 }
 
 
-struct CorrTask {  // everything one correspondence needs besides its search result
-  int K;
-  CorrBuffers cb;
-  const double* x;               // current instance
-  const double* tpts;            // TargetSampling: the decimated-target points (else null)
-  const unsigned char* boundary; // ModelSampling: target boundary flags (indexed by nnv); TargetSampling: model boundary flags
-  const int* nnv;                // ModelSampling: nearest target vertex of the surface point (null = not needed)
-  int boundary_aware;
-  Pose pose;
-  const double* ref;
-  const double* mean;
-  const int* tris;
-  const int* adj_off;
-  const int* adj;
-};
-
 // NonRigidIcpProposal.scala:94-109 for model id k with surface point cp
 __device__ __forceinline__ void correspond_model_one(const CorrTask& c, int k, d3 cp) {
   int aux = c.nnv ? c.nnv[k] : -1;
@@ -56,6 +40,35 @@ __device__ __forceinline__ void correspond_target_one(const CorrTask& c, int k, 
   bool on_boundary = c.boundary[id] != 0;                 // :119
   d3 n = vertex_normal(c.x, c.tris, c.adj_off, c.adj, id); // :120
   write_corr(c.cb, k, id, -1, ld3(c.tpts + 3 * k), c.boundary_aware ? !on_boundary : true, n, c.pose, c.ref, c.mean);
+}
+
+// wave-cooperative versions (all 64 lanes call; the adjacent cell normals are computed one per lane, then summed by
+// every lane in ascending triangle id exactly like vertex_normal) — used where one wave owns one correspondence
+__device__ __forceinline__ d3 vertex_normal_wave(const double* __restrict__ x, const int* __restrict__ tris,
+                                                 const int* __restrict__ adj_off, const int* __restrict__ adj, int v) {
+  const int l = threadIdx.x & 63;
+  const int k0 = adj_off[v], k1 = adj_off[v + 1];
+  d3 n = {0.0, 0.0, 0.0};
+  for (int base = k0; base < k1; base += 64) {
+    const int cnt = min(64, k1 - base);
+    d3 cn = {0.0, 0.0, 0.0};
+    if (l < cnt) cn = cell_normal(x, tris, adj[base + l]);
+    for (int j = 0; j < cnt; ++j) {
+      n.x += __shfl(cn.x, j, 64); n.y += __shfl(cn.y, j, 64); n.z += __shfl(cn.z, j, 64);
+    }
+  }
+  return normalized(n);
+}
+__device__ __forceinline__ void correspond_model_wave(const CorrTask& c, int k, d3 cp) {
+  int aux = c.nnv ? c.nnv[k] : -1;
+  bool on_boundary = (c.nnv && aux >= 0) ? c.boundary[aux] != 0 : false;
+  d3 n = vertex_normal_wave(c.x, c.tris, c.adj_off, c.adj, k);
+  if ((threadIdx.x & 63) == 0) write_corr(c.cb, k, k, aux, cp, c.boundary_aware ? !on_boundary : true, n, c.pose, c.ref, c.mean);
+}
+__device__ __forceinline__ void correspond_target_wave(const CorrTask& c, int k, int id) {
+  bool on_boundary = c.boundary[id] != 0;
+  d3 n = vertex_normal_wave(c.x, c.tris, c.adj_off, c.adj, id);
+  if ((threadIdx.x & 63) == 0) write_corr(c.cb, k, id, -1, ld3(c.tpts + 3 * k), c.boundary_aware ? !on_boundary : true, n, c.pose, c.ref, c.mean);
 }
 
 // ---------------------------------------------------------------- K5a regression assembly on the f64 matrix cores
@@ -229,7 +242,7 @@ extern __shared__ double s_dyn[];
 // published through a double-buffered LDS vector, so a column costs one reciprocal, ~E fused multiply-adds per thread
 // and ONE barrier.  The finished factor goes to LDS once, for the back substitution.
 template <int E, int NT>
-__device__ __forceinline__ void factor_reg_body(int r, const double* __restrict__ Mpart, int S, double* __restrict__ M,
+__device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict__ Mpart, int S, double* __restrict__ M,
                                                 double* __restrict__ alpha_out, int* __restrict__ status) {
   __shared__ double s_col[2][516], s_dinv[512], s_v[512];
   const int tid = threadIdx.x, n = r + 1;
@@ -268,7 +281,7 @@ __device__ __forceinline__ void factor_reg_body(int r, const double* __restrict_
     const double ajj = cur[j];
     if (!(ajj > 0.0)) {  // same value in every thread: uniform exit
       if (tid == 0) status[0] = 1;
-      return;
+      return false;
     }
     const double inv = fast_rcp(ajj);
 #pragma unroll
@@ -314,6 +327,7 @@ __device__ __forceinline__ void factor_reg_body(int r, const double* __restrict_
     }
     for (int i = tid; i < r; i += NT) alpha_out[i] = s_v[i];
   }
+  return true;
 }
 
 // ---------------------------------------------------------------- a9 transition tails (batched, one workgroup each)
@@ -362,6 +376,25 @@ __device__ __forceinline__ void tail_body(int r, const double* __restrict__ alph
     out[0] = -0.5 * q - 0.5 * (double)r * 1.8378770664093453;  // ln(2π); no log-det term
     status[0] = converged ? 0 : 3;
   }
+}
+
+// ---------------------------------------------------------------- a8 propose (one workgroup)
+// c_new = (G + σ²I)⁻¹ G w = w − σ² P w with P = (G + σ²I)⁻¹ precomputed;  w = α + D⁻¹ V (√S ∘ z);  c' = c + step·(c_new − c).
+// c_out may be LDS or global; ends with a barrier.
+__device__ __forceinline__ void propose_body(int r, const ProposeIn& in, double* c_out, int tpr_log2) {
+  __shared__ double s_px[512], s_py[512], s_pw[512];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int j = tid; j < r; j += nt) s_px[j] = sqrt(in.S[j]) * in.z[j];
+  __syncthreads();
+  block_matvec(r, in.V, r, s_px, s_py, tpr_log2);
+  for (int i = tid; i < r; i += nt) s_pw[i] = fma(s_py[i], in.inv_sqrt_lambda[i], in.alpha[i]);
+  __syncthreads();
+  block_matvec(r, in.P, r, s_pw, s_py, tpr_log2);
+  for (int i = tid; i < r; i += nt) {
+    const double cnew = fma(-in.sigma2, s_py[i], s_pw[i]);  // model.coefficients(...) with σ² = 1e-5 (NonRigidIcpProposal.scala:59)
+    c_out[i] = in.c[i] + (cnew - in.c[i]) * in.step;         // :61-62
+  }
+  __syncthreads();
 }
 
 // direct version: factor G + σ²M, solve, quadratic form.  Used only if the iteration above reports non-contraction.

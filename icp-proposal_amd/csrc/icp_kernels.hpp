@@ -14,7 +14,7 @@ enum KernelId {
   KID_INSTANCE = 0, KID_SURFACE_INIT, KID_SURFACE_FILTER, KID_SURFACE_RESOLVE,
   KID_VERTEX_INIT, KID_VERTEX_FILTER, KID_VERTEX_RESOLVE, KID_TRI_SPHERES, KID_CORRESPOND,
   KID_REGRESSION, KID_FACTOR, KID_TAIL, KID_EIGEN, KID_PROPOSE, KID_REDUCE,
-  KID_STEP_INSTANCE, KID_STEP_INIT, KID_STEP_FILTER, KID_STEP_RESOLVE, KID_STEP_REGRESSION, KID_STEP_FACTOR, KID_STEP_TAILS, KID_COUNT
+  KID_STEP_BEGIN, KID_STEP_FILTER, KID_STEP_RESOLVE, KID_STEP_REGRESSION, KID_STEP_FINISH, KID_COUNT
 };
 extern const char* const kKernelNames[KID_COUNT];
 
@@ -59,8 +59,36 @@ struct QueryBuffers {   // scratch of one query batch; per-query arrays hold the
   size_t cand_capacity;  // ints in `cand`; a batch takes floor(capacity / n_elements) queries
 };
 
-struct SurfaceTask;
-struct VertexTask;
+struct SurfaceTask {  // one batch of closest-point-on-surface queries against one triangle mesh
+  int K, Kpad, T, stride;
+  const double* P;        // [K*3] query points
+  const double* verts;
+  const int* tris;
+  const float4* spheres;  // [T] f32 bounding spheres
+  int* hint;              // [K] previous winner (in/out; may be null)
+  float4* qrec;           // [Kpad] scratch
+  float* thrA;            // [Kpad] scratch
+  int* cnt;               // [Kpad] scratch
+  int* cand;              // [Kpad*stride] scratch
+  double* cp;             // outputs, any may be null
+  double* d2;
+  int* tri;
+  int tblocks, ksplit, kchunk;  // filter decomposition: tblocks × ksplit workgroups
+};
+
+struct VertexTask {  // one batch of nearest-vertex queries against one vertex set
+  int K, Kpad, V, stride;
+  const double* P;
+  const double* verts;
+  int* hint;
+  double* thr2;
+  int* cnt;
+  int* cand;
+  double* d2;  // outputs, any may be null
+  int* idx;
+  int vblocks, ksplit, kchunk;
+};
+
 void split_queries(int n_elem_blocks, int Kpad, int* ksplit, int* kchunk);
 
 // K4: closest point on surface.  Outputs (any may be null): cp [K*3], d2 [K], tri [K].
@@ -80,6 +108,22 @@ struct CorrBuffers {   // per-correspondence data of one ICP posterior (device)
   unsigned char* keep; // [K]
   double* nhat;        // [K*3] unit vertex normal at id on the current mesh
   double* e;           // [K*3] observation minus mean: R^T((pt − t) − ctr) + ctr − x̄_id − μ_id
+};
+
+struct CorrTask {  // everything one correspondence needs besides its search result
+  int K;
+  CorrBuffers cb;
+  const double* x;               // current instance
+  const double* tpts;            // TargetSampling: the decimated-target points (else null)
+  const unsigned char* boundary; // ModelSampling: target boundary flags (indexed by nnv); TargetSampling: model boundary flags
+  const int* nnv;                // ModelSampling: nearest target vertex of the surface point (null = not needed)
+  int boundary_aware;
+  Pose pose;
+  const double* ref;
+  const double* mean;
+  const int* tris;
+  const int* adj_off;
+  const int* adj;
 };
 
 // NonRigidIcpProposal.scala:89-110 (ModelSampling): ids 0..K-1, surface points cp, optional nearest-vertex ids
@@ -126,5 +170,78 @@ void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mea
 // (flags may be null; idx (optional) indexes flags: flag = flags[idx[k]] if idx[k] < n_flags else 0)
 void launch_dist_stats(hipStream_t st, int K, const double* d2, const unsigned char* flags, const int* idx,
                        int n_flags, double* out);
+
+// ---- merged launches of one Metropolis–Hastings step (kernels_step.hip): five dependent launches do what the
+// per-stage kernels above do in ~25, with identical arithmetic (same device bodies).
+
+struct ProposeIn {   // a8 inputs (all device pointers; z may also point into kernel arguments)
+  const double* alpha; const double* V; const double* S; const double* inv_sqrt_lambda; const double* P;
+  const double* c; const double* z; double sigma2, step;
+};
+
+constexpr int kStepInlineZ = 128;  // ranks up to this pass the r host-drawn numbers inside the kernel arguments
+constexpr int kStepMaxOut = 6;
+
+struct StepBeginArgs {  // launch 1: [propose] -> coefficients -> instance -> search initialisation
+  int N, r, inst_blocks, tpr_log2;
+  const double* Qp; const double* ref; const double* mean;
+  Pose pose;
+  int propose;              // 1: coefficients = a8 from `prop` (prop.z ignored: see zin/z_ptr); 0: coefficients = zin / z_ptr
+  ProposeIn prop;
+  const double* z_ptr;      // host-visible pointer used when r > kStepInlineZ
+  double zin[kStepInlineZ];
+  int n_out;                // copies of the coefficient vector (state slot, posterior entries, pinned host result)
+  double* out[kStepMaxOut];
+  double* x;                // [N*3] instance
+  int has_surf, has_vert;
+  SurfaceTask surf;         // queries = model ids 0..K-1 of the NEW instance against the target surface
+  VertexTask vert;          // searched set = the NEW instance (TargetSampling)
+};
+
+struct StepSearchArgs {  // launches 2 (filter) and 3 (resolve + correspondences)
+  int n_surf, n_vert;
+  int fstart[5];           // filter: first block of each task (surface tasks first), fstart[n] = grid size
+  int rstart[5];           // resolve: first block (= first query) of each task
+  SurfaceTask s[2];
+  VertexTask v[2];
+  int s_corr[2], v_corr[2];  // index into corr[] of the posterior fed by the task, or -1
+  CorrTask corr[2];
+};
+
+struct StepRegressionArgs {  // launch 4: normal-equation partial sums of every posterior + the likelihood reduction
+  int n, r, ntiles;          // posteriors; tiles per (r+1)x(r+1) matrix
+  int ustart[3];             // first work unit (tile x split) of each posterior; ustart[n] = number of units
+  int K[2], kchunk[2];
+  const double* Q;
+  CorrBuffers cb[2];
+  double wt[2], kappa[2];
+  double* Mpart[2];
+  int reduce_kind;           // 0 none, 1 Σ log N(d; mean, sigma), 2 {Σ d, max d, count}
+  int Kred;
+  const double* d2;
+  double mean, sigma;
+  double* red_out;
+};
+
+struct StepFinishArgs {  // launch 5: per posterior Cholesky + alpha, then the backward tail; forward tails beside them
+  int n, r, n_lds, tpr_log2;
+  const double* Mpart[2]; int splits[2];
+  double* M[2]; double* alpha[2]; int* status[2];      // status: the entry's 3 ints {chol, -, eigen}
+  int* host_status[2];                                  // pinned copy of the Cholesky status
+  TransitionTailIO bwd[2];   // prop -> cur, needs this launch's factorisation
+  TransitionTailIO fwd[2];   // cur -> prop, from the cached posterior of the current state
+  const double* Ginv; double sigma2;
+};
+
+bool step_finish_supported(int r);
+void launch_step_begin(hipStream_t st, const StepBeginArgs& a);
+void launch_step_filter(hipStream_t st, const StepSearchArgs& a);
+void launch_step_resolve(hipStream_t st, const StepSearchArgs& a);
+void launch_step_regression(hipStream_t st, const StepRegressionArgs& a);
+void launch_step_finish(hipStream_t st, const StepFinishArgs& a);
+SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const float4* spheres, int K, const double* P,
+                              int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);
+VertexTask make_vertex_task(int V, const double* verts, int K, const double* P, int* hint, const QueryBuffers& qb, double* d2, int* idx);
+int query_batch(int K, int n_elems, size_t cand_capacity);
 
 }  // namespace icp

@@ -10,36 +10,6 @@ constexpr int kSearchBlock = 256;
 constexpr double kAbsSlack = 3.0 / 8388608.0;  // 3·2^-23 per unit of |coordinate|: covers rounding a point to f32
 constexpr int kQU = 4;                         // queries per unrolled filter iteration
 
-struct SurfaceTask {  // one batch of closest-point-on-surface queries against one triangle mesh
-  int K, Kpad, T, stride;
-  const double* P;        // [K*3] query points
-  const double* verts;
-  const int* tris;
-  const float4* spheres;  // [T] f32 bounding spheres
-  int* hint;              // [K] previous winner (in/out; may be null)
-  float4* qrec;           // [Kpad] scratch
-  float* thrA;            // [Kpad] scratch
-  int* cnt;               // [Kpad] scratch
-  int* cand;              // [Kpad*stride] scratch
-  double* cp;             // outputs, any may be null
-  double* d2;
-  int* tri;
-  int tblocks, ksplit, kchunk;  // filter decomposition: tblocks × ksplit workgroups
-};
-
-struct VertexTask {  // one batch of nearest-vertex queries against one vertex set
-  int K, Kpad, V, stride;
-  const double* P;
-  const double* verts;
-  int* hint;
-  double* thr2;
-  int* cnt;
-  int* cand;
-  double* d2;  // outputs, any may be null
-  int* idx;
-  int vblocks, ksplit, kchunk;
-};
-
 __device__ __forceinline__ float round_up_f32(double v) { return nextafterf((float)v, __builtin_inff()); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
@@ -79,7 +49,9 @@ __device__ __forceinline__ void wave_lexmin(double& d2, int& idx) {
 
 // per query: exact distance to the hinted triangle -> filter bound; f32 copy of the query; zero candidate counter.
 // Entries K..Kpad-1 are sentinels (a point at 1e30 with bound 0) so the filter can run unrolled without guards.
-__device__ __forceinline__ void surface_init(const SurfaceTask& q, int k) {
+// `p` = the query point (q.P[k] for k < K; ignored for sentinel slots), passed in so that a producer kernel can
+// initialise a query from a point it has just computed
+__device__ __forceinline__ void surface_init_at(const SurfaceTask& q, int k, d3 p) {
   if (k >= q.Kpad) return;
   q.cnt[k] = 0;
   if (k >= q.K) {
@@ -87,7 +59,6 @@ __device__ __forceinline__ void surface_init(const SurfaceTask& q, int k) {
     q.thrA[k] = 0.f;
     return;
   }
-  d3 p = ld3(q.P + 3 * k);
   int h = q.hint ? q.hint[k] : -1;
   double d2 = __builtin_inf();
   if (h >= 0 && h < q.T) d2 = tri_dist2(p, q.verts, q.tris, h, nullptr);
@@ -95,6 +66,11 @@ __device__ __forceinline__ void surface_init(const SurfaceTask& q, int k) {
   const double slack = kAbsSlack * (fabs(p.x) + fabs(p.y) + fabs(p.z));
   q.qrec[k] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f);
   q.thrA[k] = round_up_f32(sqrt(d2) * (1.0 + 2e-6) + slack);
+}
+__device__ __forceinline__ void surface_init(const SurfaceTask& q, int k) {
+  d3 p = {0.0, 0.0, 0.0};
+  if (k < q.K) p = ld3(q.P + 3 * k);
+  surface_init_at(q, k, p);
 }
 
 // workgroup (bx, by) of the tblocks × ksplit filter grid; kSearchBlock threads
@@ -157,18 +133,26 @@ __device__ __forceinline__ void surface_resolve(const SurfaceTask& q, int k, dou
 
 // ---------------------------------------------------------------- K3 nearest vertex
 
-__device__ __forceinline__ void vertex_init(const VertexTask& q, int k) {
+// `e` = position of the hinted vertex h (q.verts[h]), `have` = the hint is valid
+__device__ __forceinline__ void vertex_init_at(const VertexTask& q, int k, bool have, d3 e) {
   if (k >= q.Kpad) return;
   q.cnt[k] = 0;
   if (k >= q.K) { q.thr2[k] = -1.0; return; }  // sentinel: nothing passes
-  int h = q.hint ? q.hint[k] : -1;
   double d2 = __builtin_inf();
-  if (h >= 0 && h < q.V) {
-    d3 d = sub(ld3(q.P + 3 * k), ld3(q.verts + 3 * h));
+  if (have) {
+    d3 d = sub(ld3(q.P + 3 * k), e);
     d2 = dot(d, d);
   }
   if (!(d2 == d2)) d2 = __builtin_inf();
   q.thr2[k] = d2;  // squared bound, same expression as the filter -> the hint vertex itself always passes
+}
+__device__ __forceinline__ void vertex_init(const VertexTask& q, int k) {
+  if (k >= q.Kpad) return;
+  int h = (q.hint && k < q.K) ? q.hint[k] : -1;
+  const bool have = h >= 0 && h < q.V;
+  d3 e = {0.0, 0.0, 0.0};
+  if (have) e = ld3(q.verts + 3 * h);
+  vertex_init_at(q, k, have, e);
 }
 
 __device__ __forceinline__ void vertex_filter(const VertexTask& q, int bx, int by) {
@@ -222,9 +206,8 @@ __device__ __forceinline__ void vertex_resolve(const VertexTask& q, int k, doubl
 
 // K1: one vertex of x = s(R(x̄ + μ + Q c − ctr) + ctr + t); Qp = scaled basis in planes [(j*3+d)*N + i].
 // Summed in basis order with separately rounded multiply and add (the value every search index is defined on).
-__device__ __forceinline__ void instance_vertex(int i, int N, int r, const double* __restrict__ Qp, const double* __restrict__ ref,
-                                                const double* __restrict__ mean, const Pose& pose, const double* __restrict__ coeffs,
-                                                double* __restrict__ x) {
+__device__ __forceinline__ d3 instance_point(int i, int N, int r, const double* __restrict__ Qp, const double* __restrict__ ref,
+                                             const double* __restrict__ mean, const Pose& pose, const double* coeffs) {
   double a0 = mean[3 * i], a1 = mean[3 * i + 1], a2 = mean[3 * i + 2];
   const double* q = Qp + i;
   for (int j = 0; j < r; ++j) {
@@ -238,9 +221,13 @@ __device__ __forceinline__ void instance_vertex(int i, int N, int r, const doubl
   double w0 = (pose.R[0] * v0 + pose.R[1] * v1) + pose.R[2] * v2;
   double w1 = (pose.R[3] * v0 + pose.R[4] * v1) + pose.R[5] * v2;
   double w2 = (pose.R[6] * v0 + pose.R[7] * v1) + pose.R[8] * v2;
-  x[3 * i] = pose.s * ((w0 + pose.ctr[0]) + pose.t[0]);
-  x[3 * i + 1] = pose.s * ((w1 + pose.ctr[1]) + pose.t[1]);
-  x[3 * i + 2] = pose.s * ((w2 + pose.ctr[2]) + pose.t[2]);
+  return {pose.s * ((w0 + pose.ctr[0]) + pose.t[0]), pose.s * ((w1 + pose.ctr[1]) + pose.t[1]), pose.s * ((w2 + pose.ctr[2]) + pose.t[2])};
+}
+__device__ __forceinline__ void instance_vertex(int i, int N, int r, const double* __restrict__ Qp, const double* __restrict__ ref,
+                                                const double* __restrict__ mean, const Pose& pose, const double* coeffs,
+                                                double* __restrict__ x) {
+  const d3 p = instance_point(i, N, r, Qp, ref, mean, pose, coeffs);
+  x[3 * i] = p.x; x[3 * i + 1] = p.y; x[3 * i + 2] = p.z;
 }
 
 }  // namespace icp

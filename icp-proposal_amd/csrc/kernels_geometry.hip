@@ -24,7 +24,7 @@ const char* const kKernelNames[KID_COUNT] = {
     "k_instance", "k_surface_init", "k_surface_filter", "k_surface_resolve",
     "k_vertex_init", "k_vertex_filter", "k_vertex_resolve", "k_tri_spheres", "k_correspond",
     "k_regression", "k_posterior_factor", "k_transition_tail", "k_posterior_eigen", "k_propose", "k_reduce",
-    "k_step_instance", "k_step_init", "k_step_filter", "k_step_resolve", "k_step_regression", "k_step_factor", "k_step_tails"};
+    "k_step_begin", "k_step_filter", "k_step_resolve", "k_step_regression", "k_step_finish"};
 
 void Profiler::begin(hipStream_t st, int id) {
   if (used >= pool.size()) { overflow = true; return; }
@@ -95,7 +95,7 @@ void split_queries(int n_elem_blocks, int Kpad, int* ksplit, int* kchunk) {
 }
 
 // queries are processed in batches small enough that every query can list ALL elements as candidates
-static int query_batch(int K, int n_elems, size_t cand_capacity) {
+int query_batch(int K, int n_elems, size_t cand_capacity) {
   size_t kb = cand_capacity / (size_t)(n_elems > 0 ? n_elems : 1);
   if (kb > 4) kb -= 4;  // room for the sentinel slots
   if (kb < 1) kb = 1;

@@ -385,22 +385,8 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen(int r, const double* _
 // ---------------------------------------------------------------- a8 propose
 // c_new = (G + σ²I)⁻¹ G w = w − σ² P w with P = (G + σ²I)⁻¹ precomputed;  w = α + D⁻¹ V (√S ∘ z)
 
-__global__ void __launch_bounds__(256) k_propose(int r, const double* __restrict__ alpha, const double* __restrict__ V,
-                                                  const double* __restrict__ S, const double* __restrict__ inv_sqrt_lambda,
-                                                  const double* __restrict__ P, double sigma2, const double* __restrict__ c,
-                                                  const double* __restrict__ z, double step, double* __restrict__ c_out, int tpr_log2) {
-  __shared__ double s_x[512], s_y[512], s_w[512];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int j = tid; j < r; j += nt) s_x[j] = sqrt(S[j]) * z[j];
-  __syncthreads();
-  block_matvec(r, V, r, s_x, s_y, tpr_log2);
-  for (int i = tid; i < r; i += nt) s_w[i] = fma(s_y[i], inv_sqrt_lambda[i], alpha[i]);
-  __syncthreads();
-  block_matvec(r, P, r, s_w, s_y, tpr_log2);
-  for (int i = tid; i < r; i += nt) {
-    const double cnew = fma(-sigma2, s_y[i], s_w[i]);  // model.coefficients(...) with σ² = 1e-5 (:59)
-    c_out[i] = c[i] + (cnew - c[i]) * step;            // :61-62
-  }
+__global__ void __launch_bounds__(256) k_propose(int r, ProposeIn in, double* __restrict__ c_out, int tpr_log2) {
+  propose_body(r, in, c_out, tpr_log2);
 }
 
 // ---------------------------------------------------------------- evaluator reductions
@@ -548,8 +534,8 @@ void launch_propose(hipStream_t st, int r, const double* alpha, const double* V,
                     const double* inv_sqrt_lambda, const double* P, double sigma2, const double* c,
                     const double* z, double step, double* c_out) {
   { ProfScope _ps(st, KID_PROPOSE);
-    hipLaunchKernelGGL(k_propose, dim3(1), dim3(256), 0, st, r, alpha, V, S, inv_sqrt_lambda, P, sigma2, c, z, step, c_out,
-                       matvec_tpr_log2(r, 256)); }
+    ProposeIn in{alpha, V, S, inv_sqrt_lambda, P, c, z, sigma2, step};
+    hipLaunchKernelGGL(k_propose, dim3(1), dim3(256), 0, st, r, in, c_out, matvec_tpr_log2(r, 256)); }
 }
 
 void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mean, double sigma, double* out) {

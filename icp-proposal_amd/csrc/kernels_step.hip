@@ -1,0 +1,249 @@
+// kernels_step.hip — the device work of ONE Metropolis–Hastings step as five dependent launches (gfx950).
+//
+// A step needs, for a NEW state θ' (SURVEY.md §3.1): the instance, one search per ICP direction + the likelihood
+// queries, the correspondences, one GP regression per direction, and the transition-density tails.  Issued stage by
+// stage that is ~25 small launches plus ~20 staging copies, each a 2.5–5 µs dependent boundary on an otherwise idle
+// chip; the step is bound by those boundaries, not by bandwidth or arithmetic.  Here the stages that do not depend on
+// each other share a launch, inputs arrive as kernel arguments and results are written straight into pinned host
+// memory, so a step is five boundaries and one synchronisation:
+//
+//   1 k_step_begin       [a8 propose: c' from the cached posterior of the current state] -> x(θ') -> per-query bounds
+//   2 k_step_filter      every search of the step: candidate lists (searched sets streamed once)
+//   3 k_step_resolve     exact resolve per query (one wave) -> correspondence record (normal, inverse pose, boundary)
+//   4 k_step_regression  f64-MFMA normal-equation partial sums of every posterior + the likelihood reduction
+//   5 k_step_finish      per posterior: Cholesky + α, then the backward tail; the forward tails run beside them
+//
+// The device bodies are the ones the per-stage kernels use (icp_search.hpp, icp_dense.hpp): results are bit-identical
+// to the per-method entry points.
+#include "icp_kernels.hpp"
+#include "icp_search.hpp"
+#include "icp_dense.hpp"
+
+namespace icp {
+
+namespace {
+
+constexpr int kStepBlock = 256;
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- 1: coefficients -> instance -> query bounds
+
+__global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) {
+  __shared__ double s_c[512];
+  const int tid = threadIdx.x, r = a.r;
+  const double* zsrc = r <= kStepInlineZ ? a.zin : a.z_ptr;
+  if (a.propose) {
+    ProposeIn in = a.prop;
+    in.z = zsrc;
+    propose_body(r, in, s_c, a.tpr_log2);  // NonRigidIcpProposal.scala:53-62 (every workgroup computes its own copy)
+  } else {
+    for (int j = tid; j < r; j += kStepBlock) s_c[j] = zsrc[j];
+    __syncthreads();
+  }
+  if (blockIdx.x == 0)
+    for (int j = tid; j < r; j += kStepBlock) {
+      const double c = s_c[j];
+      for (int o = 0; o < a.n_out; ++o) a.out[o][j] = c;
+    }
+  if ((int)blockIdx.x < a.inst_blocks) {
+    const int i = blockIdx.x * kStepBlock + tid;
+    if (i < a.N) {  // ModelFittingParameters.scala:108-110
+      const d3 p = instance_point(i, a.N, r, a.Qp, a.ref, a.mean, a.pose, s_c);
+      a.x[3 * i] = p.x; a.x[3 * i + 1] = p.y; a.x[3 * i + 2] = p.z;
+      if (a.has_surf && i < a.surf.K) surface_init_at(a.surf, i, p);  // query i = model point i (:96)
+    }
+    if (a.has_surf && blockIdx.x == 0 && tid < kQU) {
+      const int k = a.surf.K + tid;  // sentinel slots
+      if (k < a.surf.Kpad) surface_init_at(a.surf, k, d3{0.0, 0.0, 0.0});
+    }
+  } else if (a.has_vert) {
+    // bound of each TargetSampling query = distance to the previous winner, whose NEW position is recomputed here
+    const int k = (blockIdx.x - a.inst_blocks) * kStepBlock + tid;
+    if (k < a.vert.Kpad) {
+      const int h = (a.vert.hint && k < a.vert.K) ? a.vert.hint[k] : -1;
+      const bool have = h >= 0 && h < a.vert.V;
+      d3 e = {0.0, 0.0, 0.0};
+      if (have) e = instance_point(h, a.N, r, a.Qp, a.ref, a.mean, a.pose, s_c);
+      vertex_init_at(a.vert, k, have, e);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- 2: filters of every search
+
+__global__ void __launch_bounds__(kSearchBlock) k_step_filter(StepSearchArgs a) {
+  const int b = blockIdx.x;
+  if (a.n_surf > 0 && b < a.fstart[1]) {
+    const int l = b - a.fstart[0];
+    surface_filter(a.s[0], l % a.s[0].tblocks, l / a.s[0].tblocks);
+  } else if (a.n_surf > 1 && b < a.fstart[2]) {
+    const int l = b - a.fstart[1];
+    surface_filter(a.s[1], l % a.s[1].tblocks, l / a.s[1].tblocks);
+  } else if (a.n_vert > 0 && b < a.fstart[a.n_surf + 1]) {
+    const int l = b - a.fstart[a.n_surf];
+    vertex_filter(a.v[0], l % a.v[0].vblocks, l / a.v[0].vblocks);
+  } else if (a.n_vert > 1) {
+    const int l = b - a.fstart[a.n_surf + 1];
+    vertex_filter(a.v[1], l % a.v[1].vblocks, l / a.v[1].vblocks);
+  }
+}
+
+// ---------------------------------------------------------------- 3: resolve + correspondence record (one wave per query)
+
+__device__ __forceinline__ void resolve_surface_query(const SurfaceTask& q, int k, int ci, const StepSearchArgs& a) {
+  double best; int tri; d3 cp;
+  surface_resolve(q, k, &best, &tri, &cp);
+  if (ci == 0 && k < a.corr[0].K && tri != kNoIndex) correspond_model_wave(a.corr[0], k, cp);
+  if (ci == 1 && k < a.corr[1].K && tri != kNoIndex) correspond_model_wave(a.corr[1], k, cp);
+}
+__device__ __forceinline__ void resolve_vertex_query(const VertexTask& q, int k, int ci, const StepSearchArgs& a) {
+  double best; int idx;
+  vertex_resolve(q, k, &best, &idx);
+  if (ci == 0 && k < a.corr[0].K && idx != kNoIndex) correspond_target_wave(a.corr[0], k, idx);
+  if (ci == 1 && k < a.corr[1].K && idx != kNoIndex) correspond_target_wave(a.corr[1], k, idx);
+}
+
+__global__ void __launch_bounds__(64) k_step_resolve(StepSearchArgs a) {
+  const int b = blockIdx.x;
+  if (a.n_surf > 0 && b < a.rstart[1]) resolve_surface_query(a.s[0], b - a.rstart[0], a.s_corr[0], a);
+  else if (a.n_surf > 1 && b < a.rstart[2]) resolve_surface_query(a.s[1], b - a.rstart[1], a.s_corr[1], a);
+  else if (a.n_vert > 0 && b < a.rstart[a.n_surf + 1]) resolve_vertex_query(a.v[0], b - a.rstart[a.n_surf], a.v_corr[0], a);
+  else if (a.n_vert > 1) resolve_vertex_query(a.v[1], b - a.rstart[a.n_surf + 1], a.v_corr[1], a);
+}
+
+// ---------------------------------------------------------------- 4: regression partial sums + likelihood reduction
+
+__device__ __forceinline__ void dist_stats_body(int K, const double* __restrict__ d2, double* __restrict__ out) {
+  __shared__ double s_red_d[16];
+  double sum = 0.0, mx = -__builtin_inf(), cnt = 0.0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const double d = sqrt(d2[k]);
+    sum += d;
+    mx = fmax(mx, d);
+    cnt += 1.0;
+  }
+  sum = block_sum(sum, s_red_d);
+  cnt = block_sum(cnt, s_red_d);
+  mx = block_max(mx, s_red_d);
+  if (threadIdx.x == 0) { out[0] = sum; out[1] = mx; out[2] = cnt; }
+}
+
+__global__ void __launch_bounds__(kStepBlock) k_step_regression(StepRegressionArgs a) {
+  const int n_units = a.ustart[a.n];
+  const int n_blocks = (n_units + 3) >> 2;  // one wave per (tile, split) unit, four per workgroup
+  if ((int)blockIdx.x < n_blocks) {
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= n_units) return;
+    if (u < a.ustart[1]) {
+      regression_tile(u % a.ntiles, u / a.ntiles, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0]);
+    } else {
+      const int l = u - a.ustart[1];
+      regression_tile(l % a.ntiles, l / a.ntiles, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1]);
+    }
+    return;
+  }
+  // the last workgroup: likelihood reduction over the surface distances of the evaluator's model ids
+  if (a.reduce_kind == 1) sum_gauss_logpdf_body(a.Kred, a.d2, a.mean, a.sigma, a.red_out);  // IndependentPointDistanceEvaluator.scala:40-46
+  else if (a.reduce_kind == 2) dist_stats_body(a.Kred, a.d2, a.red_out);                      // Collective…Evaluator.scala:43-52 (no boundary)
+}
+
+// ---------------------------------------------------------------- 5: factorisations + transition tails
+
+template <int E, int NT>
+__global__ void __launch_bounds__(NT) k_step_finish(StepFinishArgs a) {
+  const int b = blockIdx.x;
+  if (b < a.n) {
+    const bool ok = factor_reg_body<E, NT>(a.r, a.Mpart[b], a.splits[b], a.M[b], a.alpha[b], a.status[b]);
+    if (threadIdx.x == 0) {
+      a.host_status[b][0] = ok ? 0 : 1;
+      a.status[b][1] = 0;
+      a.status[b][2] = 0;
+    }
+    if (!ok) {  // uniform
+      if (threadIdx.x == 0) { a.bwd[b].out[0] = __builtin_nan(""); a.bwd[b].status[0] = 0; }
+      return;
+    }
+    __syncthreads();  // M and alpha of this posterior are complete (written by this workgroup)
+    const TransitionTailIO& t = a.bwd[b];
+    tail_body(a.r, t.alpha, t.M, t.c_from, t.c_to, t.step, t.out, t.status, a.Ginv, a.sigma2, a.n_lds, a.tpr_log2);
+  } else {
+    const TransitionTailIO& t = a.fwd[b - a.n];
+    tail_body(a.r, t.alpha, t.M, t.c_from, t.c_to, t.step, t.out, t.status, a.Ginv, a.sigma2, a.n_lds, a.tpr_log2);
+  }
+}
+
+static void set_dyn_lds(const void* fn, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+struct FinishPlan { int E, NT, n_lds; size_t shmem; bool ok; };
+
+FinishPlan finish_plan(int r) {
+  FinishPlan p{0, 0, 0, 0, false};
+  const int ld = r | 1;
+  const size_t total = (size_t)r * (r + 1) / 2 + r;
+  const size_t w = (size_t)(r + 1) * ld, one = (size_t)r * ld;
+  const size_t budget = (size_t)kLdsDoubles - 4700;  // static LDS of factor_reg_body + tail_body
+  if (w > budget) return p;
+  if (total <= 256 * 6) { p.E = 6; p.NT = 256; }
+  else if (total <= 256 * 12) { p.E = 12; p.NT = 256; }
+  else if (total <= 1024 * 6) { p.E = 6; p.NT = 1024; }
+  else if (total <= 1024 * 12) { p.E = 12; p.NT = 1024; }
+  else return p;
+  p.n_lds = 2 * one <= budget ? 2 : (one <= budget ? 1 : 0);
+  const size_t tails = one * p.n_lds;
+  p.shmem = sizeof(double) * (w > tails ? w : tails);
+  p.ok = true;
+  return p;
+}
+
+template <int E, int NT>
+void launch_finish(hipStream_t st, const StepFinishArgs& a, size_t shmem) {
+  set_dyn_lds((const void*)k_step_finish<E, NT>, shmem);
+  hipLaunchKernelGGL((k_step_finish<E, NT>), dim3(2 * a.n), dim3(NT), shmem, st, a);
+}
+
+}  // namespace
+
+bool step_finish_supported(int r) { return finish_plan(r).ok; }
+
+void launch_step_begin(hipStream_t st, const StepBeginArgs& a) {
+  const int vblocks = a.has_vert ? cdiv(a.vert.Kpad, kStepBlock) : 0;
+  ProfScope _ps(st, KID_STEP_BEGIN);
+  hipLaunchKernelGGL(k_step_begin, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
+}
+
+void launch_step_filter(hipStream_t st, const StepSearchArgs& a) {
+  const int grid = a.fstart[a.n_surf + a.n_vert];
+  if (grid <= 0) return;
+  ProfScope _ps(st, KID_STEP_FILTER);
+  hipLaunchKernelGGL(k_step_filter, dim3(grid), dim3(kSearchBlock), 0, st, a);
+}
+
+void launch_step_resolve(hipStream_t st, const StepSearchArgs& a) {
+  const int grid = a.rstart[a.n_surf + a.n_vert];
+  if (grid <= 0) return;
+  ProfScope _ps(st, KID_STEP_RESOLVE);
+  hipLaunchKernelGGL(k_step_resolve, dim3(grid), dim3(64), 0, st, a);
+}
+
+void launch_step_regression(hipStream_t st, const StepRegressionArgs& a) {
+  const int blocks = (a.ustart[a.n] + 3) / 4 + (a.reduce_kind ? 1 : 0);
+  if (blocks <= 0) return;
+  ProfScope _ps(st, KID_STEP_REGRESSION);
+  hipLaunchKernelGGL(k_step_regression, dim3(blocks), dim3(kStepBlock), 0, st, a);
+}
+
+void launch_step_finish(hipStream_t st, const StepFinishArgs& a_in) {
+  const FinishPlan p = finish_plan(a_in.r);
+  StepFinishArgs a = a_in;
+  a.n_lds = p.n_lds;
+  a.tpr_log2 = matvec_tpr_log2(a.r, p.NT);
+  ProfScope _ps(st, KID_STEP_FINISH);
+  if (p.E == 6 && p.NT == 256) launch_finish<6, 256>(st, a, p.shmem);
+  else if (p.E == 12 && p.NT == 256) launch_finish<12, 256>(st, a, p.shmem);
+  else if (p.E == 6 && p.NT == 1024) launch_finish<6, 1024>(st, a, p.shmem);
+  else launch_finish<12, 1024>(st, a, p.shmem);
+}
+
+}  // namespace icp

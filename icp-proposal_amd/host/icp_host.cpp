@@ -132,7 +132,10 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
     if (cfg->fused) {
       ch->prefetcher.evaluator = ch->likelihood.get();
       ch->prefetcher.icp = ch->icp;
+      ch->prefetcher.whole_step = cfg->fused >= 2;
       ch->mh->prefetcher = &ch->prefetcher;
+      if (cfg->fused >= 2)
+        for (size_t i = 0; i < ch->icp.size(); ++i) { ch->icp[i]->stepper = &ch->prefetcher; ch->icp[i]->stepperIndex = (int)i; }
     }
     ch->current.allParameters.assign(theta0, theta0 + 10 + ch->r);
     ch->logger.P = 10 + ch->r;

@@ -23,7 +23,8 @@ typedef struct {
   double pose_rot_sigma[3];      /* yaw/pitch/roll stdevs (MixedProposalDistributions.scala:29: 0.01) */
   double pose_trans_sigma[3];    /* x/y/z stdevs (0.1) */
   icp_evaluator_params eval;     /* likelihood; the shape prior is always multiplied in (ProductEvaluators.scala:38-55) */
-  int32_t fused;                 /* 1 = prefetch each step's device work with ONE icp_chain_eval_step call */
+  int32_t fused;                 /* 0 = per-method calls; 1 = icp_chain_eval_step prefetch after propose; 2 = the whole step
+                                    (propose + evaluation) as ONE icp_chain_step submission */
 } icp_host_chain_config;
 
 /* fixed-size per-step record (the layout the multi-GPU log gather ships; mirrors jsonLogFormat,

@@ -147,22 +147,15 @@ struct ProductEvaluator : DistributionEvaluator {  // Scalismo ProductEvaluator:
 
 // ---------------------------------------------------------------- proposals
 
+struct ChainPrefetcher;
+
 struct NonRigidIcpProposal : ProposalGeneratorWithTransition {  // NonRigidIcpProposal.scala:30-41
   NonRigidIcpProposal(icp_ctx* ctx, const icp_proposal_params& prm, std::string generatedBy)
       : generatedBy(std::move(generatedBy)) {
     check(icp_proposal_create(ctx, &prm, &h), "icp_proposal_create");
   }
   ~NonRigidIcpProposal() override { icp_proposal_destroy(h); }
-  ModelFittingParameters propose(const ModelFittingParameters& theta, const StepRandom& rnd, int) override {
-    const int r = theta.rank();
-    std::vector<double> z(r);
-    for (int j = 0; j < r; ++j) z[j] = rnd.normal(j);  // posterior.sample() (:55)
-    ModelFittingParameters out;
-    out.allParameters.resize(theta.allParameters.size());
-    check(icp_proposal_propose(h, theta.data(), z.data(), out.allParameters.data(), nullptr), "icp_proposal_propose");
-    out.generatedBy = generatedBy;  // :66
-    return out;
-  }
+  ModelFittingParameters propose(const ModelFittingParameters& theta, const StepRandom& rnd, int) override;
   double logTransitionProbability(const ModelFittingParameters& from, const ModelFittingParameters& to) override {
     for (auto& pf : prefetched)
       if (pf.valid && pf.from == from && pf.to == to) return pf.value;
@@ -172,6 +165,8 @@ struct NonRigidIcpProposal : ProposalGeneratorWithTransition {  // NonRigidIcpPr
   }
   icp_proposal* h = nullptr;
   std::string generatedBy;
+  ChainPrefetcher* stepper = nullptr;  // set: propose() submits the WHOLE step (icp_chain_step) and parks the other results
+  int stepperIndex = -1;
   struct Prefetched {
     bool valid = false;
     ModelFittingParameters from, to;
@@ -271,13 +266,12 @@ struct AcceptRejectLogger {  // api/sampling/loggers/JSONAcceptRejectLogger.scal
 struct ChainPrefetcher {
   NativeLikelihoodEvaluator* evaluator = nullptr;
   std::vector<NonRigidIcpProposal*> icp;
-  void prefetch(const ModelFittingParameters& cur, const ModelFittingParameters& prop) {
-    std::vector<icp_proposal*> hs;
-    for (auto* p : icp) hs.push_back(p->h);
-    std::vector<double> fwd(icp.size() + 1), bwd(icp.size() + 1);
-    double value;
-    int st = icp_chain_eval_step(evaluator->h, (int)icp.size(), hs.data(), cur.data(), prop.data(), &value, fwd.data(), bwd.data());
-    if (st != ICP_OK && st != ICP_ERR_EMPTY) check(st, "icp_chain_eval_step");
+  bool whole_step = false;  // true: icp_chain_step (propose + evaluation in one submission); false: icp_chain_eval_step
+  bool have = false;        // results of (parked_cur -> parked_prop) are parked
+  ModelFittingParameters parked_cur, parked_prop;
+
+  void park(const ModelFittingParameters& cur, const ModelFittingParameters& prop, int st, double value, const std::vector<double>& fwd,
+            const std::vector<double>& bwd) {
     evaluator->has_prefetch = st == ICP_OK;
     evaluator->prefetched_for = prop;
     evaluator->prefetched_value = value;
@@ -285,8 +279,55 @@ struct ChainPrefetcher {
       icp[i]->prefetched[0] = {true, cur, prop, fwd[i]};
       icp[i]->prefetched[1] = {true, prop, cur, bwd[i]};
     }
+    have = true;
+    parked_cur = cur;
+    parked_prop = prop;
+  }
+  void prefetch(const ModelFittingParameters& cur, const ModelFittingParameters& prop) {
+    if (have && parked_cur == cur && parked_prop == prop) return;  // already submitted by the generating proposal
+    std::vector<icp_proposal*> hs;
+    for (auto* p : icp) hs.push_back(p->h);
+    std::vector<double> fwd(icp.size() + 1), bwd(icp.size() + 1);
+    double value;
+    int st;
+    if (whole_step) {
+      ModelFittingParameters tmp = prop;
+      st = icp_chain_step(evaluator->h, (int)icp.size(), hs.data(), -1, cur.data(), nullptr, tmp.allParameters.data(), &value,
+                          fwd.data(), bwd.data());
+    } else {
+      st = icp_chain_eval_step(evaluator->h, (int)icp.size(), hs.data(), cur.data(), prop.data(), &value, fwd.data(), bwd.data());
+    }
+    if (st != ICP_OK && st != ICP_ERR_EMPTY) check(st, "icp_chain_eval_step");
+    park(cur, prop, st, value, fwd, bwd);
+  }
+  // propose from icp[index] AND evaluate the proposal, one native call
+  ModelFittingParameters step(int index, const ModelFittingParameters& cur, const double* z) {
+    std::vector<icp_proposal*> hs;
+    for (auto* p : icp) hs.push_back(p->h);
+    std::vector<double> fwd(icp.size() + 1), bwd(icp.size() + 1);
+    double value;
+    ModelFittingParameters prop;
+    prop.allParameters.resize(cur.allParameters.size());
+    int st = icp_chain_step(evaluator->h, (int)icp.size(), hs.data(), index, cur.data(), z, prop.allParameters.data(), &value,
+                            fwd.data(), bwd.data());
+    if (st != ICP_OK && st != ICP_ERR_EMPTY) check(st, "icp_chain_step");
+    prop.generatedBy = icp[index]->generatedBy;
+    park(cur, prop, st, value, fwd, bwd);
+    return prop;
   }
 };
+
+inline ModelFittingParameters NonRigidIcpProposal::propose(const ModelFittingParameters& theta, const StepRandom& rnd, int) {
+  const int r = theta.rank();
+  std::vector<double> z(r);
+  for (int j = 0; j < r; ++j) z[j] = rnd.normal(j);  // posterior.sample() (:55)
+  if (stepper) return stepper->step(stepperIndex, theta, z.data());
+  ModelFittingParameters out;
+  out.allParameters.resize(theta.allParameters.size());
+  check(icp_proposal_propose(h, theta.data(), z.data(), out.allParameters.data(), nullptr), "icp_proposal_propose");
+  out.generatedBy = generatedBy;  // :66
+  return out;
+}
 
 // Scalismo MetropolisHastings.next
 struct MetropolisHastings {

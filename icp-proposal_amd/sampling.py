@@ -61,7 +61,7 @@ class ChainSetup:
         self.pose_rot_sigma = (0.01, 0.01, 0.01)
         self.pose_trans_sigma = (0.1, 0.1, 0.1)
         self.eval = dict(kind=0, mode=0, n_model_ids=0, target_pts=np.zeros((0, 3)), gauss_mean=0.0, gauss_sigma=1.0, exp_rate=1.0)
-        self.fused = True
+        self.fused = 2  # 0 per-method calls, 1 icp_chain_eval_step prefetch, 2 whole step in one icp_chain_step submission
 
     def to_c(self):
         cfg = HostChainConfig()
@@ -88,7 +88,7 @@ class ChainSetup:
 
 
 def femur_icp_proposal_registration(model, target, n_icp_points=None, n_eval_points=None, direction="ModelAndTargetSampling",
-                                    eval_mode=0, fused=True) -> ChainSetup:
+                                    eval_mode=0, fused=2) -> ChainSetup:
     """The configuration of apps/femur/IcpProposalRegistration.scala:59-85: K = 2·rank proposal points, 4·rank evaluator
     points, 0.9 ICP(Model+Target, σt=10, σn=5, step 0.1) + 0.1 random walk(0.1), prior × independent Gaussian(0, 2)."""
     r = model.rank

@@ -191,6 +191,19 @@ ICP_API int icp_prior_log_value(int32_t rank, const double *theta, double *out);
 ICP_API int icp_chain_eval_step(icp_evaluator *e, int32_t n_props, icp_proposal *const *props, const double *theta_cur,
                                 const double *theta_prop, double *log_value_prop, double *fwd, double *bwd);
 
+/* One call = propose (if generator >= 0) + icp_chain_eval_step, i.e. ALL device work of one Metropolis–Hastings step
+ *  in one submission of five merged launches with a single synchronisation.
+ *   generator >= 0 : theta_prop (out) = props[generator].propose(theta_cur) with the caller's standard normals z[r]
+ *                    (NonRigidIcpProposal.scala:53-68);
+ *   generator <  0 : theta_prop (in)  = a sample generated on the host (random-walk / pose proposals,
+ *                    RandomShapeUpdateProposal.scala:31-35, PoseProposals.scala:31-90); z is ignored.
+ * Then, as icp_chain_eval_step: log_value_prop = likelihood of theta_prop; fwd[i] / bwd[i] = logT(cur -> prop) /
+ * logT(prop -> cur) of props[i].  Values are identical to the per-method entry points (same device code, same caches);
+ * configurations the merged launches do not cover are routed through the per-stage kernels transparently. */
+ICP_API int icp_chain_step(icp_evaluator *e, int32_t n_props, icp_proposal *const *props, int32_t generator,
+                           const double *theta_cur, const double *z, double *theta_prop, double *log_value_prop, double *fwd,
+                           double *bwd);
+
 /* ---------------------------------------------------------------- instrumentation (bench.py's roofline leg)
  * Between start and stop every kernel the context launches is bracketed by HIP events on the context stream;
  * stop returns one row per kernel name.  Off by default (adds nothing to the launch path). */

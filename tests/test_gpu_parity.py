@@ -227,6 +227,52 @@ def test_chain_eval_step_matches_separate_calls(pkg, ctx50, femur50):
     ev.close()
 
 
+@pytest.mark.parametrize("kind", ["independent", "collective"])
+def test_chain_step_matches_separate_calls(pkg, femur50, kind):
+    """icp_chain_step (five merged launches) == propose + logValue + 4 x logTransitionProbability, bit for bit."""
+    model, target = femur50
+    r = model.rank
+    tp = pkg.data.decimated_point_subset(target, 2 * r)
+    mk_ctx = lambda: pkg.IcpContext(model, target, device=0)
+    def mk(ctx):
+        props = [pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, d, True, decimatedTargetPoints=tp)
+                 for d in ("TargetSampling", "ModelSampling")]
+        if kind == "independent":
+            ev = pkg.IndependentPointDistanceEvaluator(ctx, 0.0, 2.0, 0, 4 * r)
+        else:
+            ev = pkg.CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator(ctx, 0.1, 0.3, 1.0, 0, 4 * r)
+        return props, ev
+    ctx_a, ctx_b = mk_ctx(), mk_ctx()   # separate contexts: separate caches and search hints
+    (props_a, ev_a), (props_b, ev_b) = mk(ctx_a), mk(ctx_b)
+    cur = make_theta(model, 600, pose=False)
+    rng = np.random.default_rng(3)
+    for step in range(6):
+        gen = step % 3 - 1 if step else 0          # 0, 0, 1, -1, 0, 1
+        z = rng.normal(size=r)
+        if gen >= 0:
+            prop_b = props_b[gen].propose(cur, z)
+            prop_a, val, fwd, bwd = pkg.chain_step(ev_a, props_a, cur, generator=gen, z=z)
+        else:
+            prop_b = cur.copy()
+            prop_b[10:] += 0.1 * z
+            prop_a, val, fwd, bwd = pkg.chain_step(ev_a, props_a, cur, generator=-1, theta_prop=prop_b)
+        assert np.array_equal(prop_a, prop_b)
+        assert val == ev_b.logValue(prop_b)
+        for i, p in enumerate(props_b):
+            assert fwd[i] == p.logTransitionProbability(cur, prop_b)
+            assert bwd[i] == p.logTransitionProbability(prop_b, cur)
+        # the caches filled by the merged launches serve the per-method entry points
+        assert ev_a.logValue(prop_a) == val
+        assert props_a[0].logTransitionProbability(cur, prop_a) == fwd[0]
+        pa, pb = props_a[1].icpPosterior(prop_a, with_aux=False), props_b[1].icpPosterior(prop_b, with_aux=False)
+        assert np.array_equal(pa.corr_id, pb.corr_id) and np.array_equal(pa.M, pb.M) and np.array_equal(pa.alpha, pb.alpha)
+        if step % 2 == 0:
+            cur = prop_b   # "accept"
+    for p in props_a + props_b:
+        p.close()
+    ev_a.close(); ev_b.close(); ctx_a.close(); ctx_b.close()
+
+
 def test_error_behaviour(pkg, ctx50, femur50):
     model, _ = femur50
     theta = make_theta(model, 1)
