@@ -1006,7 +1006,8 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
       p->K = params->n_model_ids;
     }
     p->prm.target_points = nullptr;  // caller memory is not retained
-    p->work.alloc((size_t)ctx->r * ctx->r);
+    p->work.alloc(eigen_work_doubles(ctx->r));
+    p->work.fill_bytes(0);  // holds the completion counter of the eigenvector replay kernel
     p->Mpart.alloc((size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1));
     p->fscratch.alloc((size_t)(ctx->r + 1) * ctx->r);
     p->status.alloc(3 * kPosteriorMemo);

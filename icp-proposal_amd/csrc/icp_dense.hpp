@@ -235,7 +235,7 @@ __device__ bool block_cholesky_rootfree(double* W, int n, int ld, int extra, int
 
 // ---------------------------------------------------------------- K5b: M = I + Σ partials, chol(M), α = M⁻¹ b
 
-extern __shared__ double s_dyn[];
+extern __shared__ __attribute__((aligned(16))) double s_dyn[];
 
 // Fast path (the matrix fits a few elements per thread): every thread OWNS E fixed elements of the lower triangle of
 // [M; bᵀ] and keeps them in registers for the whole root-free factorisation; only the current pivot column is

@@ -155,8 +155,9 @@ void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO
 
 // eigen-decomposition of D M^-1 D (posterior KL basis): V columns (and its transpose Vt), S descending, canonical signs
 // Vwarm (optional): eigenvectors of a nearby posterior, used as the starting basis of the Jacobi iteration
+size_t eigen_work_doubles(int r);  // size of `work`
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
-                            double* Vt, double* S, double* work /* r*r */, int* status);
+                            double* Vt, double* S, double* work /* eigen_work_doubles(r) */, int* status);
 
 // a8: c' = c + step·((G+σ²I)^-1 G (α + D^-1 V √S z) − c), with P = (G+σ²I)^-1
 void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,

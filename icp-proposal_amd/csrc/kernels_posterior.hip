@@ -7,14 +7,25 @@
 //   transition: log T = −½ γᵀMγ − (r/2) ln 2π,  (G + σ²M) γ = G (c̃ − α)                           (:71-85)
 //     (equal to the reference's whitened-coefficient form for ANY square root of D M⁻¹ D; derivation in DESIGN.md)
 // These kernels are latency-bound r×r work (r = 51…201): one workgroup per matrix, data in LDS when it fits.
+#include <algorithm>
+#include <cstdlib>
+
 #include "icp_kernels.hpp"
 #include "icp_dense.hpp"
 
 namespace icp {
 
+#ifdef ICP_EIGEN_TIMING  // tools/eigen_bench only: phase stamps (100 MHz) of the last eigen kernel
+__device__ long long g_eigen_stamps[64];
+#define EIG_STAMP(i) do { if (threadIdx.x == 0) g_eigen_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EIG_STAMP(i)
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kEigenMaxSweeps = 40;
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -382,6 +393,428 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen(int r, const double* _
   }
 }
 
+// ---------------------------------------------------------------- posterior KL basis, ranks <= 64: fixed-position Jacobi
+// Same method (cyclic two-sided Jacobi, round-robin pairing, warm start) re-laid for the LDS pipe, which bounds the kernel
+// above: there every round gathers its pair indices and rotation parameters through dependent LDS reads and touches each
+// matrix element with scalar 8-byte accesses.  Here the PAIRING never changes — pair K always sits at positions (2K, 2K+1)
+// — and the matrix itself is permuted by the round-robin rotation while it is written back (Brent–Luk style), so
+//   * every thread reads and writes the SAME addresses every round (all offsets precomputed in registers);
+//   * the two elements of a pair are adjacent: one 16-byte read fetches both;
+//   * A and V are double-buffered (read `cur`, write the permuted result to `nxt`): ONE barrier per round;
+//   * the rotation of a pair of the NEXT round is computed in the same round by a dedicated thread, from the three
+//     transformed entries it needs (evaluated with the expressions the block threads use, so both agree bit for bit).
+// A is kept exactly symmetric (block (J,I) is computed as the transpose of block (I,J) by the same arithmetic).  An odd
+// rank is padded with a dummy index (zero row/column, diagonal 1e300): its rotations are identities.
+
+__device__ __forceinline__ int rr_dst(int pos, int m) {  // where the content of position `pos` goes after a round
+  const int k = pos >> 1;
+  if ((pos & 1) == 0) return k == 0 ? 0 : (k == m - 1 ? 2 * (m - 1) + 1 : 2 * (k + 1));
+  return k == 0 ? 2 : 2 * (k - 1) + 1;
+}
+__device__ __forceinline__ int rr_src(int pos, int m) {  // inverse of rr_dst
+  const int k = pos >> 1;
+  if ((pos & 1) == 0) return k == 0 ? 0 : (k == 1 ? 1 : 2 * (k - 1));
+  return k == m - 1 ? 2 * (m - 1) : 2 * (k + 1) + 1;
+}
+
+struct Rot { double c, s, t; };
+
+// Rotation (nearly) annihilating apq, branch free; the dependent chain is two reciprocal square roots and no division:
+//   a = aqq − app, b = 2·apq (the angle depends on their ratio only), h ≈ sqrt(a² + b²), u = h + |a|:
+//   c = u/sqrt(u² + b²), s = sgn(a)·b/sqrt(u² + b²)          (t = s/c = sgn(a)·b/(|a| + h), the smaller root)
+// c² + s² = 1 holds to rounding for ANY h, so h comes from the bare hardware seed (relative error 5e-8): the rotated
+// off-diagonal entry is then 5e-8·apq instead of 0, which the next sweep removes — the callers store the computed entry,
+// never an assumed zero.
+__device__ __forceinline__ Rot jacobi_rotation(double app, double apq, double aqq) {
+  const double a = aqq - app, b = apq + apq, b2 = b * b;
+  const bool rot = fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq);
+  const double h2 = fma(a, a, b2);
+  const double h = h2 * __builtin_amdgcn_rsq(h2);
+  const double u = h + fabs(a);
+  const double y = fast_rsqrt(fma(u, u, b2));
+  Rot R;
+  R.c = rot ? u * y : 1.0;            // not rotating (negligible or zero entry, dummy index): NaN/inf above are discarded
+  R.s = rot ? (a >= 0.0 ? b : -b) * y : 0.0;
+  R.t = 0.0;
+  return R;
+}
+
+struct B22 { double a00, a01, a10, a11; };
+
+// R1ᵀ·B·R2 with R = [c s; −s c]
+__device__ __forceinline__ B22 rot_block(B22 b, double c1, double s1, double c2, double s2) {
+  const double t00 = fma(c1, b.a00, -(s1 * b.a10)), t01 = fma(c1, b.a01, -(s1 * b.a11));
+  const double t10 = fma(s1, b.a00, c1 * b.a10), t11 = fma(s1, b.a01, c1 * b.a11);
+  return B22{fma(c2, t00, -(s2 * t01)), fma(s2, t00, c2 * t01), fma(c2, t10, -(s2 * t11)), fma(s2, t10, c2 * t11)};
+}
+__device__ __forceinline__ double diag_new(int side, double t, double d00, double d01, double d11) {
+  return side == 0 ? fma(-t, d01, d00) : fma(t, d01, d11);
+}
+
+// entry [ra][ca] of rot_block(b, c1, s1, c2, s2), by the same operations (−(s·x) == (−s)·x exactly)
+__device__ __forceinline__ double rot_block_entry(B22 b, double c1, double s1, double c2, double s2, int ra, int ca) {
+  const double p1 = ra == 0 ? c1 : s1, q1 = ra == 0 ? -s1 : c1;
+  const double p2 = ca == 0 ? c2 : s2, q2 = ca == 0 ? -s2 : c2;
+  const double t0 = fma(p1, b.a00, q1 * b.a10), t1 = fma(p1, b.a01, q1 * b.a11);
+  return fma(p2, t0, q2 * t1);
+}
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dbl2 lds2(const double* p) { return *(const dbl2*)p; }
+
+// Work split of one round (1024 threads launched; ranks <= 64).  Only the upper triangle of A is stored: element {R, C}
+// lives at [min][max], so every element is written once per round and no mirror is kept.
+//   wave 3         lane K prepares the rotation of pair K of the next round — the longest dependent chain of a round; it
+//                  has its SIMD (waves 3, 7, 11, 15) to itself — and appends it to the rotation log in global memory
+//   block waves    (0-2, 4-6, …) one 2×2 block (I <= J) of A per thread: read, rotate, write to the permuted places
+// The rotation table holds R = [c s; −s c] column by column, [c, −s | s, c] per pair, so that a thread that needs column
+// `side` of a pair's rotation reads it with one 16-byte load at a precomputed offset (no selects on the critical chain).
+// V is not touched inside the loop: its 2·r·n2 stores per round cost more than the whole round (measured: ≥ 500 cycles
+// of LDS time per round on one CU in every layout tried, against a ~1000-cycle round).  The rotations are logged instead,
+// and k_eigen_vreplay applies them to V afterwards on many CUs at once (rows of V are independent).
+
+__global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
+                                                              const double* __restrict__ Vwarm, double* __restrict__ Vout,
+                                                              double* __restrict__ Vtout, double* __restrict__ Sout,
+                                                              int* __restrict__ status, int ld, int ldk, double* __restrict__ rotlog,
+                                                              int* __restrict__ meta, int max_sweeps) {
+  __shared__ double s_red[16], s_mu[64];
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int n2 = (r + 1) & ~1, m = n2 >> 1;
+  // buffers are addressed as s_dyn[offset] with integer offsets: a table of pointers would turn every access into a
+  // FLAT instruction (address space lost), several times slower than the DS path
+  const int szA = n2 * ld, szV = n2 * ldk, szC = 4 * m;
+  const int oA = 0, oV = 2 * szA, oT = oV + szV, oC = oT + szV;  // A[2] | Vt (warm start) | T (its transform) | table[2]
+#define LDS_A(b, i) s_dyn[oA + (b) * szA + (i)]
+#define LDS_VT(i) s_dyn[oV + (i)]
+#define LDS_T(i) s_dyn[oT + (i)]
+#define LDS_C(b, i) s_dyn[oC + (b) * szC + (i)]
+  EIG_STAMP(0);
+  // ---- N = D⁻¹ M D⁻¹ (symmetrised), padded; Vt = (warm start or identity)ᵀ, padded with zeros
+  for (int e = tid; e < szV; e += nt) LDS_VT(e) = 0.0;
+  __syncthreads();
+  for (int e = tid; e < n2 * n2; e += nt) {
+    const int i = e / n2, j = e - i * n2;
+    double v = i == j ? 1e300 : 0.0;
+    if (i < r && j < r) v = 0.5 * (M[(size_t)i * r + j] + M[(size_t)j * r + i]) / (sqrt_lambda[i] * sqrt_lambda[j]);
+    LDS_A(0, i * ld + j) = v;
+    if (i < r && j < r) LDS_VT(j * ldk + i) = Vwarm ? Vwarm[(size_t)i * r + j] : (i == j ? 1.0 : 0.0);  // i = coordinate, j = position
+  }
+  __syncthreads();
+  EIG_STAMP(1);
+  if (Vwarm) {  // A <- Vᵀ A V (nearly diagonal when V diagonalised a nearby posterior); 2×2 output tiles per thread,
+    // every inner product runs along contiguous rows (A row · Vt row, Vt row · Tt row); padded entries are zero
+    const int mt = n2 >> 1;
+    for (int e = tid; e < mt * mt; e += nt) {  // Tt[j][i] = (A·V)[i][j]
+      const int ti = e / mt, tj = e - ti * mt, i = 2 * ti, j = 2 * tj;
+      double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+      const bool i1 = i + 1 < r;
+      for (int k = 0; k < n2; k += 2) {
+        const dbl2 a0 = lds2(&LDS_A(0, i * ld + k)), a1 = i1 ? lds2(&LDS_A(0, (i + 1) * ld + k)) : dbl2{0.0, 0.0};
+        const dbl2 v0 = lds2(&LDS_VT(j * ldk + k)), v1 = lds2(&LDS_VT((j + 1) * ldk + k));
+        const double a0y = k + 1 < r ? a0.y : 0.0, a1y = k + 1 < r ? a1.y : 0.0;  // column r of A is the dummy (1e300 on its diagonal)
+        s00 = fma(a0.x, v0.x, s00); s01 = fma(a0.x, v1.x, s01); s10 = fma(a1.x, v0.x, s10); s11 = fma(a1.x, v1.x, s11);
+        s00 = fma(a0y, v0.y, s00); s01 = fma(a0y, v1.y, s01); s10 = fma(a1y, v0.y, s10); s11 = fma(a1y, v1.y, s11);
+      }
+      LDS_T(j * ldk + i) = s00; LDS_T((j + 1) * ldk + i) = s01;
+      LDS_T(j * ldk + i + 1) = i1 ? s10 : 0.0; LDS_T((j + 1) * ldk + i + 1) = i1 ? s11 : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < mt * mt; e += nt) {  // A[i][j] = Σ_k Vt[i][k]·Tt[j][k], upper triangle only
+      const int ti = e / mt, tj = e - ti * mt, i = 2 * ti, j = 2 * tj;
+      if (ti > tj) continue;
+      double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+      for (int k = 0; k < n2; k += 2) {
+        const dbl2 v0 = lds2(&LDS_VT(i * ldk + k)), v1 = lds2(&LDS_VT((i + 1) * ldk + k));
+        const dbl2 t0 = lds2(&LDS_T(j * ldk + k)), t1 = lds2(&LDS_T((j + 1) * ldk + k));
+        s00 = fma(v0.x, t0.x, s00); s01 = fma(v0.x, t1.x, s01); s10 = fma(v1.x, t0.x, s10); s11 = fma(v1.x, t1.x, s11);
+        s00 = fma(v0.y, t0.y, s00); s01 = fma(v0.y, t1.y, s01); s10 = fma(v1.y, t0.y, s10); s11 = fma(v1.y, t1.y, s11);
+      }
+      const bool i1 = i + 1 < r, j1 = j + 1 < r;
+      LDS_A(0, i * ld + j) = s00;
+      if (j1) LDS_A(0, i * ld + j + 1) = s01;
+      if (i1 && j1) LDS_A(0, (i + 1) * ld + j + 1) = s11;
+      if (i1 && ti != tj) LDS_A(0, (i + 1) * ld + j) = s10;
+    }
+    __syncthreads();
+  }
+  EIG_STAMP(2);
+
+  // ---- fixed work of this thread
+  const int nA = m * (m + 1) / 2, nbw = (nA + 63) >> 6;
+  const int widx = (wave & 3) == 3 ? -1 : wave - (wave >> 2);  // index among the waves of SIMDs 0-2 (12 of them)
+  const int bidx = (widx >= 0 && widx < nbw) ? widx * 64 + lane : nA;
+#ifdef ICP_EIGEN_TIMING
+  const bool is_blk = bidx < nA && max_sweeps != 39;  // 39: rotation wave alone (timing experiment, wrong results)
+#else
+  const bool is_blk = bidx < nA;
+#endif
+  int bI = 0, bJ = 0, b_rd = 0, w00 = 0, w01 = 0, w10 = 0, w11 = 0;
+  if (is_blk) {  // unrank the upper triangle row-major
+    int base = 0;
+    while (base + (m - bI) <= bidx) { base += m - bI; ++bI; }
+    bJ = bI + (bidx - base);
+    b_rd = 2 * bI * ld + 2 * bJ;
+    const int R0 = rr_dst(2 * bI, m), R1 = rr_dst(2 * bI + 1, m), C0 = rr_dst(2 * bJ, m), C1 = rr_dst(2 * bJ + 1, m);
+    w00 = min(R0, C0) * ld + max(R0, C0); w01 = min(R0, C1) * ld + max(R0, C1);
+    w10 = min(R1, C0) * ld + max(R1, C0); w11 = min(R1, C1) * ld + max(R1, C1);
+  }
+  const bool is_rot = wave == 3 && lane < m;
+  int rp_dp = 0, rp_dq = 0, rp_ob = 0, rp_cp = 0, rp_cq = 0, rp_cl = 0, rp_ch = 0, rp_k = 0;
+  if (wave == 3) {
+    __builtin_amdgcn_s_setprio(3);
+    rp_k = is_rot ? lane : 0;
+    const int p = rr_src(2 * rp_k, m), q = rr_src(2 * rp_k + 1, m);
+    const int ip = p >> 1, ap = p & 1, iq = q >> 1, aq = q & 1, lo = min(ip, iq), hi = max(ip, iq);
+    const int ra = ip < iq ? ap : aq, ca = ip < iq ? aq : ap;  // (row in pair lo, column in pair hi) of the new off-diagonal entry
+    rp_dp = 2 * ip * ld + 2 * ip; rp_dq = 2 * iq * ld + 2 * iq; rp_ob = 2 * lo * ld + 2 * hi;
+    rp_cp = 4 * ip + 2 * ap; rp_cq = 4 * iq + 2 * aq; rp_cl = 4 * lo + 2 * ra; rp_ch = 4 * hi + 2 * ca;
+    // rotations of the first round, straight from the diagonal blocks
+    const int o = 2 * rp_k * ld + 2 * rp_k;
+    const Rot R = jacobi_rotation(LDS_A(0, o), LDS_A(0, o + 1), LDS_A(0, o + ld + 1));
+    const bool live = is_rot && fabs(R.s) >= 2e-17;
+    const unsigned long long any = __ballot(live);
+    if (is_rot) {
+      LDS_C(0, 4 * rp_k) = R.c; LDS_C(0, 4 * rp_k + 1) = -R.s; LDS_C(0, 4 * rp_k + 2) = R.s; LDS_C(0, 4 * rp_k + 3) = R.c;
+      *(dbl2*)(rotlog + 2 * rp_k) = live ? dbl2{R.c, -R.s} : dbl2{1.0, 0.0};
+    }
+    (void)any;
+  }
+  const size_t lstride = (size_t)2 * m;  // doubles per logged round: (c, −s) of every pair
+  __syncthreads();
+  EIG_STAMP(3);
+
+  int cur = 0, converged = 0, n_sweeps = 0, n_rounds = 0;
+  for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+    for (int rnd = 0; rnd < n2 - 1; ++rnd) {
+      const int ac = oA + cur * szA, an = oA + (cur ^ 1) * szA, cc = oC + cur * szC, cn = oC + (cur ^ 1) * szC;
+#ifdef ICP_EIGEN_TIMING
+      const bool stamp_round = sweep == 1 && rnd == 5;
+      long long tq0 = 0, tq1 = 0;
+      if (stamp_round) tq0 = __builtin_amdgcn_s_memtime();
+#endif
+      if (is_blk) {
+        const dbl2 r0 = lds2(&s_dyn[ac + b_rd]), r1 = lds2(&s_dyn[ac + b_rd + ld]);
+        const dbl2 c1 = lds2(&s_dyn[cc + 4 * bI]), c2 = lds2(&s_dyn[cc + 4 * bJ]);  // (c, −s)
+        const bool dg = bI == bJ;  // diagonal block: its lower entry is not stored
+        const B22 n = rot_block(B22{r0.x, r0.y, dg ? r0.y : r1.x, r1.y}, c1.x, -c1.y, c2.x, -c2.y);
+        // (diagonal block: w01 and w10 are the same address and a01, a10 agree to rounding — either store serves)
+        s_dyn[an + w00] = n.a00; s_dyn[an + w01] = n.a01; s_dyn[an + w10] = n.a10; s_dyn[an + w11] = n.a11;
+      } else if (wave == 3) {
+        // the next round pairs the contents of old positions p (pair ip, side ap) and q (pair iq, side aq); their three
+        // entries after this round's rotations, by the block threads' own expressions
+        const dbl2 dp0 = lds2(&s_dyn[ac + rp_dp]), dp1 = lds2(&s_dyn[ac + rp_dp + ld]);
+        const dbl2 dq0 = lds2(&s_dyn[ac + rp_dq]), dq1 = lds2(&s_dyn[ac + rp_dq + ld]);
+        const dbl2 b0 = lds2(&s_dyn[ac + rp_ob]), b1 = lds2(&s_dyn[ac + rp_ob + ld]);
+        const dbl2 kp = lds2(&s_dyn[cc + rp_cp]), kq = lds2(&s_dyn[cc + rp_cq]);  // rotation column (p, q) of each factor
+        const dbl2 kl = lds2(&s_dyn[cc + rp_cl]), kh = lds2(&s_dyn[cc + rp_ch]);
+#ifdef ICP_EIGEN_TIMING
+        long long tr1 = 0, tr2 = 0, tr3 = 0;
+        if (stamp_round) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr1 = __builtin_amdgcn_s_memtime(); }
+#endif
+        // entry = Σ (rotation entry products)·(block entries), as two independent multiply-add pairs and one add; it
+        // only steers the next angle, so it need not match the block threads' rounding
+        const double app = fma(kp.x * kp.x, dp0.x, (kp.x * kp.y) * dp0.y) + fma(kp.y * kp.x, dp0.y, (kp.y * kp.y) * dp1.y);
+        const double aqq = fma(kq.x * kq.x, dq0.x, (kq.x * kq.y) * dq0.y) + fma(kq.y * kq.x, dq0.y, (kq.y * kq.y) * dq1.y);
+        const double apq = fma(kh.x * kl.x, b0.x, (kh.x * kl.y) * b1.x) + fma(kh.y * kl.x, b0.y, (kh.y * kl.y) * b1.y);
+#ifdef ICP_EIGEN_TIMING
+        if (stamp_round) { asm volatile("v_mov_b32 %0, %0" : "+v"(*(int*)&apq)); tr2 = __builtin_amdgcn_s_memtime(); }
+#endif
+        const Rot R = jacobi_rotation(app, apq, aqq);
+#ifdef ICP_EIGEN_TIMING
+        if (stamp_round) { double tmp = R.c + R.s; asm volatile("v_mov_b32 %0, %0" : "+v"(*(int*)&tmp)); tr3 = __builtin_amdgcn_s_memtime();
+          if (lane == 0) { g_eigen_stamps[50] = tr1 - tq0; g_eigen_stamps[51] = tr2 - tr1; g_eigen_stamps[52] = tr3 - tr2; g_eigen_stamps[53] = tr3; } }
+#endif
+        const bool live = is_rot && fabs(R.s) >= 2e-17;
+        const unsigned long long any = __ballot(live);
+        if (is_rot) {
+          *(dbl2*)&s_dyn[cn + 4 * rp_k] = dbl2{R.c, -R.s};
+          *(dbl2*)&s_dyn[cn + 4 * rp_k + 2] = dbl2{R.s, R.c};
+          double* lg = rotlog + (size_t)(n_rounds + 1) * lstride;
+          *(dbl2*)(lg + 2 * rp_k) = live ? dbl2{R.c, -R.s} : dbl2{1.0, 0.0};
+          (void)any;
+        }
+      }
+#ifdef ICP_EIGEN_TIMING
+      if (stamp_round) { tq1 = __builtin_amdgcn_s_memtime(); if (wave == 3 && lane == 0) g_eigen_stamps[54] = tq1 - g_eigen_stamps[53]; }
+#endif
+      __syncthreads();
+#ifdef ICP_EIGEN_TIMING
+      if (stamp_round && lane == 0) g_eigen_stamps[32 + wave] = ((tq1 - tq0) << 32) | (__builtin_amdgcn_s_memtime() - tq1);
+#endif
+      cur ^= 1;
+      ++n_rounds;
+    }
+    EIG_STAMP(4 + 2 * sweep);
+    double off = 0.0, dg = 0.0;
+    for (int e = tid; e < n2 * n2; e += nt) {
+      const int i = e / n2, j = e - i * n2;
+      const double v = LDS_A(cur, i * ld + j);
+      if (i == j) { if (v < 1e299) dg = fma(v, v, dg); }
+      else if (i < j) off = fma(2.0 * v, v, off);
+    }
+    off = block_sum(off, s_red);
+    dg = block_sum(dg, s_red);
+    converged = off <= 1e-26 * dg;
+    n_sweeps = sweep + 1;
+    EIG_STAMP(5 + 2 * sweep);
+  }
+  if (tid == 0) { status[0] = converged ? 0 : 2; status[-1] = n_sweeps; }
+  EIG_STAMP(62);
+  // ---- eigenvalues of D M⁻¹ D are 1/μ; S descending = μ ascending; the dummy sorts last and is dropped.  The replay
+  // kernel needs the number of logged rounds and, per final position, the rank of its eigenvalue.
+  if (tid < n2) s_mu[tid] = LDS_A(cur, tid * ld + tid);
+  __syncthreads();
+  if (tid < n2) {
+    int rank = 0;
+    const double mi = s_mu[tid];
+    for (int j = 0; j < n2; ++j) rank += (s_mu[j] < mi) || (s_mu[j] == mi && j < tid);
+    meta[2 + tid] = rank;
+    if (rank < r) Sout[rank] = 1.0 / mi;
+  }
+  if (tid == 0) meta[0] = n_rounds;
+  EIG_STAMP(63);
+#undef LDS_A
+#undef LDS_VT
+#undef LDS_T
+#undef LDS_C
+}
+
+// ---------------------------------------------------------------- V <- V·J_0·J_1···  (replay of the rotation log)
+// One wave per four coordinates (rows of V): lane = 4·(pair slot) + coordinate, 16 pairs per pass.  A row is a private
+// 1-D array of n2 positions; one round rotates its pairs and moves them to their next positions (double buffered), with
+// constant per-lane offsets.  Nothing is shared between waves, so no barrier is ever needed; the log streams through
+// LDS in chunks of whole rounds (one chunk in flight).  The last workgroup to finish fixes the signs (largest-|.|
+// component of every eigenvector positive), sorts the columns by the ranks of kernel 1 and writes V and Vᵀ.
+constexpr int kReplayCoords = 4;
+constexpr int kReplayChunk = 1024;  // log entries (16 B) per chunk: 16 per lane
+
+__global__ void __launch_bounds__(64) k_eigen_vreplay(int r, const double* __restrict__ Vwarm, const double* __restrict__ rotlog,
+                                                       int* __restrict__ meta, double* __restrict__ vpos /* [n2][64] */,
+                                                       double* __restrict__ Vout, double* __restrict__ Vtout) {
+  __shared__ __attribute__((aligned(16))) double s_row[2][64 * kReplayCoords];
+  __shared__ __attribute__((aligned(16))) double s_log[2][2 * kReplayChunk];
+  __shared__ int s_last;
+  const int lane = threadIdx.x, n2 = (r + 1) & ~1, m = n2 >> 1;
+#ifdef ICP_EIGEN_TIMING
+  if (blockIdx.x == 0 && lane == 0) g_eigen_stamps[40] = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int n_rounds = meta[0];
+  const int kc = lane & 3, q = lane >> 2, k = kReplayCoords * blockIdx.x + kc;
+  const bool has_a = q < m, has_b = q + 16 < m;
+  const int Ia = has_a ? q : 0, Ib = has_b ? q + 16 : 0;
+  // element (position p, coordinate kc) of the wave's rows lives at s_row[buf][4p + kc]
+  for (int p = q; p < n2; p += 16)
+    s_row[0][4 * p + kc] = (k < r && p < r) ? (Vwarm ? Vwarm[(size_t)k * r + p] : (k == p ? 1.0 : 0.0)) : 0.0;
+  const int rd_a = 8 * Ia + kc, rd_b = 8 * Ib + kc;  // positions 2I, 2I+1 -> offsets 8I + kc, 8I + 4 + kc
+  const int wa0 = 4 * rr_dst(2 * Ia, m) + kc, wa1 = 4 * rr_dst(2 * Ia + 1, m) + kc;
+  const int wb0 = 4 * rr_dst(2 * Ib, m) + kc, wb1 = 4 * rr_dst(2 * Ib + 1, m) + kc;
+  const int rounds_per_chunk = kReplayChunk / m, chunk_entries = rounds_per_chunk * m;
+  const int n_chunks = (n_rounds + rounds_per_chunk - 1) / rounds_per_chunk;
+  constexpr int kPer = kReplayChunk / 64;
+  dbl2 pre[kPer];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int e = lane + 64 * u;
+      const size_t g = (size_t)c * chunk_entries + e;
+      pre[u] = (e < chunk_entries && g < (size_t)n_rounds * m) ? *(const dbl2*)(rotlog + 2 * g) : dbl2{1.0, 0.0};
+    }
+  };
+  auto stash = [&](int b) {
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int e = lane + 64 * u;
+      if (e < chunk_entries) *(dbl2*)&s_log[b][2 * e] = pre[u];
+    }
+  };
+  auto wave_sync = [&]() {  // DS operations of one wave complete in order; this only stops the compiler from reordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  int cur = 0, lb = 0;
+  if (n_chunks > 0) { fetch(0); stash(0); }
+  wave_sync();
+#ifdef ICP_EIGEN_TIMING
+  if (blockIdx.x == 0 && lane == 0) g_eigen_stamps[41] = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int c = 0; c < n_chunks; ++c) {
+    const bool more = c + 1 < n_chunks;
+    if (more) fetch(c + 1);
+    const int t_end = min(n_rounds - c * rounds_per_chunk, rounds_per_chunk);
+    for (int rl = 0; rl < t_end; ++rl) {
+      const double* lg = &s_log[lb][2 * rl * m];
+      const dbl2 ca = *(const dbl2*)(lg + 2 * Ia), cz = *(const dbl2*)(lg + 2 * Ib);
+      const double* src = s_row[cur];
+      double* dst = s_row[cur ^ 1];
+      const double a0 = src[rd_a], a1 = src[rd_a + 4], b0 = src[rd_b], b1 = src[rd_b + 4];
+      if (has_a) { dst[wa0] = fma(ca.x, a0, ca.y * a1); dst[wa1] = fma(-ca.y, a0, ca.x * a1); }
+      if (has_b) { dst[wb0] = fma(cz.x, b0, cz.y * b1); dst[wb1] = fma(-cz.y, b0, cz.x * b1); }
+      wave_sync();
+      cur ^= 1;
+    }
+    if (more) { lb ^= 1; stash(lb); wave_sync(); }
+  }
+#ifdef ICP_EIGEN_TIMING
+  if (blockIdx.x == 0 && lane == 0) g_eigen_stamps[42] = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- publish the rows (position-major), then the last workgroup assembles the output
+  for (int p = q; p < n2; p += 16)
+    if (k < r) vpos[(size_t)p * 64 + k] = s_row[cur][4 * p + kc];
+  __threadfence();
+  if (lane == 0) s_last = atomicAdd(&meta[1], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+#ifdef ICP_EIGEN_TIMING
+  if (lane == 0) g_eigen_stamps[43] = __builtin_amdgcn_s_memrealtime();
+#endif
+  __threadfence();
+  if (lane == 0) meta[1] = 0;  // ready for the next decomposition
+#ifdef ICP_EIGEN_TIMING
+  if (lane == 0) g_eigen_stamps[45] = __builtin_amdgcn_s_memrealtime();
+#endif
+  // Stage the whole position-major V in LDS (coalesced, all loads in flight together; row stride 65: conflict-free
+  // column walks), then lane = position: sign from the largest-|.| component, columns out in rank order.
+  double* s_v = &s_log[0][0];  // 2·2·kReplayChunk doubles >= 64·65
+  for (int p0 = 0; p0 < n2; p0 += 13) {
+    double tmp[13];
+#pragma unroll
+    for (int u = 0; u < 13; ++u) tmp[u] = p0 + u < n2 ? __builtin_nontemporal_load(vpos + (size_t)(p0 + u) * 64 + lane) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 13; ++u)
+      if (p0 + u < n2) s_v[(p0 + u) * 65 + lane] = tmp[u];
+  }
+  __syncthreads();
+#ifdef ICP_EIGEN_TIMING
+  if (lane == 0) g_eigen_stamps[46] = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (lane < n2) {
+    const int rank = meta[2 + lane];
+    if (rank < r) {
+      const double* col = s_v + lane * 65;
+      int best = 0;
+      double bv = fabs(col[0]);
+      for (int kk = 1; kk < r; ++kk) {
+        const double a = fabs(col[kk]);
+        if (a > bv) { bv = a; best = kk; }
+      }
+      const double sgn = col[best] < 0.0 ? -1.0 : 1.0;
+#ifdef ICP_EIGEN_TIMING
+      if (lane == 0) g_eigen_stamps[47] = __builtin_amdgcn_s_memrealtime();
+#endif
+      for (int kk = 0; kk < r; ++kk) {
+        const double v = col[kk] * sgn;
+        Vout[(size_t)kk * r + rank] = v;
+        Vtout[(size_t)rank * r + kk] = v;
+      }
+    }
+  }
+#ifdef ICP_EIGEN_TIMING
+  if (lane == 0) g_eigen_stamps[44] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
 // ---------------------------------------------------------------- a8 propose
 // c_new = (G + σ²I)⁻¹ G w = w − σ² P w with P = (G + σ²I)⁻¹ precomputed;  w = α + D⁻¹ V (√S ∘ z)
 
@@ -516,8 +949,33 @@ void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO
                        io.step, work, io.out, io.status, use_lds); }
 }
 
+size_t eigen_work_doubles(int r) {  // `work` of launch_posterior_eigen: r×r scratch, or the rotation log of the fixed-position variant
+  const size_t n2 = ((size_t)r + 1) & ~(size_t)1;
+  const size_t log = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;  // 2 doubles per pair and round
+  return std::max((size_t)r * r, log + n2 * 64 + 64);               // + position-major V + meta (see launch_posterior_eigen)
+}
+
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
                             double* Vt, double* S, double* work, int* status) {
+  static const bool force_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
+  if (r >= 3 && r <= 64 && !force_generic) {  // fixed-position variant: A, V and the rotation table double-buffered in LDS
+    const int n2 = (r + 1) & ~1, m = n2 >> 1;
+    const int ld = n2 + 2, ldk = 66;  // ldk: 64 coordinates per position row, rows 16 B apart modulo the 256-B bank window
+    const size_t szV = (size_t)n2 * ldk;
+    const size_t shmem = sizeof(double) * (2 * (size_t)n2 * ld + 2 * szV + 8 * (size_t)m);
+    // work = [rotation log | position-major V | meta: n_rounds, done counter, rank per position]
+    const size_t log_doubles = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;
+    double* rotlog = work;
+    double* vpos = work + log_doubles;
+    int* meta = (int*)(vpos + (size_t)n2 * 64);
+    static const int sweeps_cap = std::getenv("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(std::getenv("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
+    set_dyn_lds((const void*)k_posterior_eigen_rr, shmem);
+    ProfScope _ps(st, KID_EIGEN);
+    hipLaunchKernelGGL(k_posterior_eigen_rr, dim3(1), dim3(1024), shmem, st, r, M, sqrt_lambda, Vwarm, V, Vt, S, status, ld, ldk, rotlog,
+                       meta, std::min(sweeps_cap, kEigenMaxSweeps));
+    hipLaunchKernelGGL(k_eigen_vreplay, dim3((r + kReplayCoords - 1) / kReplayCoords), dim3(64), 0, st, r, Vwarm, rotlog, meta, vpos, V, Vt);
+    return;
+  }
   const int ld = r | 1;
   const size_t budget = (size_t)kLdsDoubles - 1800;  // static LDS of the kernel
   const int a_in_lds = (size_t)r * ld <= budget;
