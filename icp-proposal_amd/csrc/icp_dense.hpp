@@ -197,6 +197,26 @@ __device__ void block_matvec(int r, const double* A, int lda, const double* x, d
   __syncthreads();
 }
 
+// same with the matrix in the dynamic LDS segment at s_dyn[offA ...]: indexing s_dyn directly keeps the loads DS
+// instructions (a generic pointer to LDS would make them FLAT, several times slower)
+extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+__device__ void block_matvec_lds(int r, int offA, int lda, const double* x, double* y, int tpr_log2) {
+  const int tid = threadIdx.x, tpr = 1 << tpr_log2, sub = tid & (tpr - 1);
+  const int rows_per_pass = blockDim.x >> tpr_log2;
+  for (int row0 = 0; row0 < r; row0 += rows_per_pass) {
+    const int row = row0 + (tid >> tpr_log2);
+    double acc = 0.0;
+    if (row < r) {
+      const int a = offA + row * lda;
+#pragma unroll 8
+      for (int j = sub; j < r; j += tpr) acc = fma(s_dyn[a + j], x[j], acc);
+    }
+    for (int o = tpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (row < r && sub == 0) y[row] = acc;
+  }
+  __syncthreads();
+}
+
 // threads per row for block_matvec: enough rows in flight to occupy the block, at least ~8 terms per thread
 static inline int matvec_tpr_log2(int r, int block) {
   int t = 0;
@@ -209,6 +229,12 @@ __device__ void stage_matrix(int r, const double* __restrict__ src, double* dst,
   for (int e = threadIdx.x; e < r * r; e += blockDim.x) {
     const int i = e / r, j = e - i * r;
     dst[(size_t)i * ld + j] = src[e];
+  }
+}
+__device__ void stage_matrix_lds(int r, const double* __restrict__ src, int off, int ld) {
+  for (int e = threadIdx.x; e < r * r; e += blockDim.x) {
+    const int i = e / r, j = e - i * r;
+    s_dyn[off + i * ld + j] = src[e];
   }
 }
 
@@ -235,68 +261,133 @@ __device__ bool block_cholesky_rootfree(double* W, int n, int ld, int extra, int
 
 // ---------------------------------------------------------------- K5b: M = I + Σ partials, chol(M), α = M⁻¹ b
 
-extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+// Fast path (the factor fits LDS): every thread OWNS 2×4 tiles of the lower triangle of [M; bᵀ] (rows 2ti, 2ti+1,
+// columns 4tj … 4tj+3) and keeps them in registers for the whole root-free factorisation.  Only the current pivot column
+// is published through a double-buffered LDS vector, so a column step is: three 16-byte loads (the tile's two row entries
+// and four column entries of the pivot column), one reciprocal, 2 + 8 multiply-adds per tile, one barrier.  A tile also
+// covers entries above the diagonal and entries that are already final; those receive throw-away updates instead of
+// predicates (their true values were stored the moment they became final).  The column loop is unrolled four times so
+// that the tile column being published and the pivot-column buffer are compile-time constants.
+#ifdef ICP_EIGEN_TIMING
+extern __device__ long long g_eigen_stamps[64];
+#define FAC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_eigen_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FAC_STAMP(i)
+#endif
 
-// Fast path (the matrix fits a few elements per thread): every thread OWNS E fixed elements of the lower triangle of
-// [M; bᵀ] and keeps them in registers for the whole root-free factorisation; only the current pivot column is
-// published through a double-buffered LDS vector, so a column costs one reciprocal, ~E fused multiply-adds per thread
-// and ONE barrier.  The finished factor goes to LDS once, for the back substitution.
-template <int E, int NT>
+typedef double dense2 __attribute__((ext_vector_type(2)));
+
+// tiles of the lower triangle, row-major over tile rows: tile row ti holds tile columns 0 … ti/2
+static __host__ __device__ inline int factor_tile_count(int r) {
+  const int tr = (r + 2) >> 1;  // tile rows over the r+1 rows (M and bᵀ)
+  int c = 0;
+  for (int t = 0; t < tr; ++t) c += (t >> 1) + 1;
+  return c;
+}
+
+template <int TPT, int NT>
 __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict__ Mpart, int S, double* __restrict__ M,
                                                 double* __restrict__ alpha_out, int* __restrict__ status) {
-  __shared__ double s_col[2][516], s_dinv[512], s_v[512];
+  __shared__ __attribute__((aligned(16))) double s_col[2][520];
+  __shared__ double s_dinv[512], s_v[512];
   const int tid = threadIdx.x, n = r + 1;
   const int ld = r | 1;
-  double* W = s_dyn;  // (r+1) × ld
-  const int tri = r * (r + 1) / 2, total = tri + r;
-  double v[E];
-  int im[E], km[E];
+  double* W = s_dyn;  // (r+1) × ld: the finished (unscaled) factor, row r = forward-eliminated bᵀ
+  FAC_STAMP(16);
+  const int n_tiles = factor_tile_count(r);
+  double v[TPT][2][4];
+  int R0[TPT], C0[TPT];
 #pragma unroll
-  for (int m = 0; m < E; ++m) {
-    const int e = tid + NT * m;
-    int i = r, k = e - tri;
-    if (e < tri) {
-      i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-      while ((i + 1) * (i + 2) / 2 <= e) ++i;
-      while (i * (i + 1) / 2 > e) --i;
-      k = e - i * (i + 1) / 2;
+  for (int t = 0; t < TPT; ++t) {
+    const int e = tid + NT * t;
+    int ti = 0, base = 0;
+    if (e < n_tiles) {
+      while (base + (ti >> 1) + 1 <= e) { base += (ti >> 1) + 1; ++ti; }
     }
-    im[m] = i; km[m] = e < total ? k : -1;  // k = -1: slot unused (never > j, never published)
-    double x = 0.0;
-    if (e < total) {
-      for (int s = 0; s < S; ++s) x += Mpart[(size_t)s * n * n + (size_t)i * n + k];
-      if (i < r) {
-        if (i == k) x += 1.0;
-        M[(size_t)i * r + k] = x;
-        M[(size_t)k * r + i] = x;
+    R0[t] = e < n_tiles ? 2 * ti : -2;            // -2: slot unused
+    C0[t] = e < n_tiles ? 4 * (e - base) : 0;
+    // sum of the split partials: split-major so that the eight loads of a split are in flight together
+    bool live[2][4];
+    size_t off[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = R0[t] + a, k = C0[t] + c;
+        live[a][c] = R0[t] >= 0 && i < n && k < r && k <= i;
+        off[a][c] = live[a][c] ? (size_t)i * n + k : 0;
+        v[t][a][c] = 0.0;
       }
-      if (k == 0) s_col[0][i] = x;
+    for (int sp = 0; sp < S; ++sp) {
+      const double* P = Mpart + (size_t)sp * n * n;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[t][a][c] += P[off[a][c]];
     }
-    v[m] = x;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = R0[t] + a, k = C0[t] + c;
+        double x = live[a][c] ? v[t][a][c] : 0.0;
+        if (live[a][c]) {
+          if (i < r) {
+            if (i == k) x += 1.0;
+            M[(size_t)i * r + k] = x;
+            M[(size_t)k * r + i] = x;
+          }
+          if (k == 0) { s_col[0][i] = x; W[(size_t)i * ld] = x; }
+        }
+        v[t][a][c] = x;
+      }
   }
   __syncthreads();
-  for (int j = 0; j < r; ++j) {
-    const double* cur = s_col[j & 1];
-    double* nxt = s_col[(j + 1) & 1];
-    const double ajj = cur[j];
-    if (!(ajj > 0.0)) {  // same value in every thread: uniform exit
-      if (tid == 0) status[0] = 1;
-      return false;
-    }
-    const double inv = fast_rcp(ajj);
+  FAC_STAMP(17);
+  bool ok = true;
+  for (int j4 = 0; j4 < r && ok; j4 += 4) {
 #pragma unroll
-    for (int m = 0; m < E; ++m) {
-      if (km[m] > j) {
-        v[m] = fma(-(cur[im[m]] * inv), cur[km[m]], v[m]);
-        if (km[m] == j + 1) nxt[im[m]] = v[m];  // column j+1 is final now: publish it as the next pivot column
+    for (int cc = 0; cc < 4; ++cc) {
+      const int j = j4 + cc;
+      if (j >= r) break;                       // uniform
+      const double* cur = s_col[cc & 1];      // j & 1 == cc & 1
+      double* nxt = s_col[(cc + 1) & 1];
+      const double ajj = cur[j];
+      dense2 u[TPT], k01[TPT], k23[TPT];
+#pragma unroll
+      for (int t = 0; t < TPT; ++t) {
+        const int rr = R0[t] < 0 ? 0 : R0[t];
+        u[t] = *(const dense2*)&cur[rr];
+        k01[t] = *(const dense2*)&cur[C0[t]];
+        k23[t] = *(const dense2*)&cur[C0[t] + 2];
       }
-    }
-    __syncthreads();
-  }
+      if (!(ajj > 0.0)) { ok = false; break; }  // same value in every thread: uniform exit
+      const double inv = fast_rcp(ajj);
+      const int kp = j + 1;                      // the column that becomes final in this step
 #pragma unroll
-  for (int m = 0; m < E; ++m)
-    if (km[m] >= 0) W[(size_t)im[m] * ld + km[m]] = v[m];
-  __syncthreads();
+      for (int t = 0; t < TPT; ++t) {
+        const double m0 = -(u[t].x * inv), m1 = -(u[t].y * inv);
+        v[t][0][0] = fma(m0, k01[t].x, v[t][0][0]); v[t][0][1] = fma(m0, k01[t].y, v[t][0][1]);
+        v[t][0][2] = fma(m0, k23[t].x, v[t][0][2]); v[t][0][3] = fma(m0, k23[t].y, v[t][0][3]);
+        v[t][1][0] = fma(m1, k01[t].x, v[t][1][0]); v[t][1][1] = fma(m1, k01[t].y, v[t][1][1]);
+        v[t][1][2] = fma(m1, k23[t].x, v[t][1][2]); v[t][1][3] = fma(m1, k23[t].y, v[t][1][3]);
+        constexpr int cp = 0;  // placeholder to keep the unrolled structure readable
+        (void)cp;
+        if (kp < r && R0[t] >= 0 && C0[t] == (kp & ~3)) {  // this tile holds column kp at tile column (cc+1)&3
+          const double p0 = v[t][0][(cc + 1) & 3], p1 = v[t][1][(cc + 1) & 3];
+          *(dense2*)&nxt[R0[t]] = dense2{p0, p1};
+          if (R0[t] >= kp && R0[t] < n) W[(size_t)R0[t] * ld + kp] = p0;
+          if (R0[t] + 1 >= kp && R0[t] + 1 < n) W[(size_t)(R0[t] + 1) * ld + kp] = p1;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (!ok) {
+    if (tid == 0) status[0] = 1;
+    return false;
+  }
+  FAC_STAMP(18);
   if (tid == 0) status[0] = 0;
   // y = L⁻¹ b sits (unscaled) in row r: y_j = W[r][j]·dinv_j,  L[i][j] = W[i][j]·dinv_j
   for (int j = tid; j < r; j += NT) {
@@ -305,15 +396,35 @@ __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict_
     s_v[j] = W[(size_t)r * ld + j] * d;
   }
   __syncthreads();
+  FAC_STAMP(19);
   if (r <= 64) {
-    if (tid < 64) {  // one wave, registers + cross-lane reads: no barriers on the sequential chain
-      const int i = tid;
-      double x = i < r ? s_v[i] : 0.0;
-      const double di = i < r ? s_dinv[i] : 0.0;
-      for (int j = r - 1; j >= 0; --j) {
-        const double xj = __shfl(x, j, 64) * s_dinv[j];
-        if (i == j) x = xj;
-        else if (i < j) x = fma(-(W[(size_t)j * ld + i] * di), xj, x);
+    if (tid < 64) {  // one wave, registers + cross-lane reads: no barriers on the sequential chain; the rows of L are
+      // fetched (and scaled) four steps ahead, so the chain per step is readlane -> multiply -> fma
+      const int i = tid, ic = i < r ? i : r - 1;  // lanes past r mirror lane r-1 (their result is discarded)
+      double x = s_v[ic];
+      const double di = s_dinv[ic];
+      constexpr int kA = 4;
+      // branch-free: steps with j < 0 (padding of the last group) read row 0 and change nothing
+      double lq[kA], dq[kA];
+#pragma unroll
+      for (int a = 0; a < kA; ++a) {
+        const int jj = max(r - 1 - a, 0);
+        lq[a] = W[(size_t)jj * ld + ic];  // raw: scaled at use, so nothing waits on the load here
+        dq[a] = s_dinv[jj];
+      }
+      for (int j0 = r - 1; j0 >= 0; j0 -= kA) {
+#pragma unroll
+        for (int a = 0; a < kA; ++a) {
+          const int j = j0 - a;
+          const double lij = lq[a] * di, dj = dq[a];
+          const int jn = max(j - kA, 0);
+          lq[a] = W[(size_t)jn * ld + ic];
+          dq[a] = s_dinv[jn];
+          const int lo = __builtin_amdgcn_readlane(__double2loint(x), j & 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), j & 63);
+          const double xj = __hiloint2double(hi, lo) * dj;
+          const double upd = fma(-lij, xj, x);
+          x = i == j ? xj : (i < j ? upd : x);
+        }
       }
       if (i < r) alpha_out[i] = x;
     }
@@ -327,6 +438,7 @@ __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict_
     }
     for (int i = tid; i < r; i += NT) alpha_out[i] = s_v[i];
   }
+  FAC_STAMP(20);
   return true;
 }
 
@@ -341,11 +453,17 @@ __device__ __forceinline__ void tail_body(int r, const double* __restrict__ alph
   __shared__ double s_d[512], s_g[512], s_t[512], s_u[512], s_red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int ld = r | 1;
-  const double* M = Mg;
-  const double* Gi = Ginv;
-  int ldm = r, ldg = r;
-  if (n_lds >= 1) { stage_matrix(r, Mg, s_dyn, ld); M = s_dyn; ldm = ld; }
-  if (n_lds >= 2) { stage_matrix(r, Ginv, s_dyn + (size_t)r * ld, ld); Gi = s_dyn + (size_t)r * ld; ldg = ld; }
+  const int offM = 0, offG = r * ld;
+  if (n_lds >= 1) stage_matrix_lds(r, Mg, offM, ld);
+  if (n_lds >= 2) stage_matrix_lds(r, Ginv, offG, ld);
+  auto mul_M = [&](const double* x, double* y) {
+    if (n_lds >= 1) block_matvec_lds(r, offM, ld, x, y, tpr_log2);
+    else block_matvec(r, Mg, r, x, y, tpr_log2);
+  };
+  auto mul_Ginv = [&](const double* x, double* y) {
+    if (n_lds >= 2) block_matvec_lds(r, offG, ld, x, y, tpr_log2);
+    else block_matvec(r, Ginv, r, x, y, tpr_log2);
+  };
   for (int i = tid; i < r; i += nt) {
     const double d = (c_from[i] + (c_to[i] - c_from[i]) / step) - alpha[i];  // :79 minus posterior mean
     s_d[i] = d;
@@ -354,8 +472,8 @@ __device__ __forceinline__ void tail_body(int r, const double* __restrict__ alph
   __syncthreads();
   int converged = 0;
   for (int it = 0; it < 12 && !converged; ++it) {
-    block_matvec(r, M, ldm, s_g, s_t, tpr_log2);
-    block_matvec(r, Gi, ldg, s_t, s_u, tpr_log2);
+    mul_M(s_g, s_t);
+    mul_Ginv(s_t, s_u);
     double delta = 0.0, gmax = 0.0;
     for (int i = tid; i < r; i += nt) {
       const double gn = fma(-sigma2, s_u[i], s_d[i]);
@@ -368,7 +486,7 @@ __device__ __forceinline__ void tail_body(int r, const double* __restrict__ alph
     converged = delta <= 1e-15 * gmax || gmax == 0.0;
     __syncthreads();
   }
-  block_matvec(r, M, ldm, s_g, s_t, tpr_log2);
+  mul_M(s_g, s_t);
   double part = 0.0;
   for (int i = tid; i < r; i += nt) part = fma(s_g[i], s_t[i], part);
   const double q = block_sum(part, s_red);

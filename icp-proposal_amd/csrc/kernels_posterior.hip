@@ -111,10 +111,10 @@ __global__ void __launch_bounds__(kFactorThreads) k_posterior_factor_generic(int
   }
 }
 
-template <int E, int NT>
+template <int TPT, int NT>
 __global__ void __launch_bounds__(NT) k_posterior_factor_reg(int r, FactorArgs fa) {
   const int p = blockIdx.x;
-  factor_reg_body<E, NT>(r, fa.Mpart[p], fa.splits[p], fa.M[p], fa.alpha[p], fa.status[p]);
+  factor_reg_body<TPT, NT>(r, fa.Mpart[p], fa.splits[p], fa.M[p], fa.alpha[p], fa.status[p]);
 }
 
 struct TailArgs {
@@ -894,11 +894,11 @@ static void set_dyn_lds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int E, int NT>
+template <int TPT, int NT>
 static void launch_factor_reg(hipStream_t st, int r, int n_post, const FactorArgs& fa) {
   const size_t shmem = sizeof(double) * (size_t)(r + 1) * (r | 1);
-  set_dyn_lds((const void*)k_posterior_factor_reg<E, NT>, shmem);
-  hipLaunchKernelGGL((k_posterior_factor_reg<E, NT>), dim3(n_post), dim3(NT), shmem, st, r, fa);
+  set_dyn_lds((const void*)k_posterior_factor_reg<TPT, NT>, shmem);
+  hipLaunchKernelGGL((k_posterior_factor_reg<TPT, NT>), dim3(n_post), dim3(NT), shmem, st, r, fa);
 }
 
 void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io) {
@@ -908,13 +908,12 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
     fa.status[p] = io[p].status; fa.scratch[p] = io[p].scratch;
   }
   const int ld = r | 1;
-  const size_t total = (size_t)r * (r + 1) / 2 + r;
+  const size_t tiles = (size_t)factor_tile_count(r);
   const bool w_fits = (size_t)(r + 1) * ld <= (size_t)kLdsDoubles - 2000;  // + the static LDS of the kernel
   ProfScope _ps(st, KID_FACTOR);
-  if (w_fits && total <= 256 * 6) launch_factor_reg<6, 256>(st, r, n_post, fa);
-  else if (w_fits && total <= 256 * 12) launch_factor_reg<12, 256>(st, r, n_post, fa);
-  else if (w_fits && total <= 1024 * 6) launch_factor_reg<6, 1024>(st, r, n_post, fa);
-  else if (w_fits && total <= 1024 * 12) launch_factor_reg<12, 1024>(st, r, n_post, fa);
+  if (w_fits && tiles <= 256) launch_factor_reg<1, 256>(st, r, n_post, fa);
+  else if (w_fits && tiles <= 1024) launch_factor_reg<1, 1024>(st, r, n_post, fa);
+  else if (w_fits && tiles <= 2048) launch_factor_reg<2, 1024>(st, r, n_post, fa);
   else {
     const int use_lds = (size_t)(r + 1) * ld <= (size_t)kLdsDoubles;
     const size_t shmem = use_lds ? sizeof(double) * (size_t)(r + 1) * ld : 0;

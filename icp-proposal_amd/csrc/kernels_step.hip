@@ -176,19 +176,18 @@ static void set_dyn_lds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-struct FinishPlan { int E, NT, n_lds; size_t shmem; bool ok; };
+struct FinishPlan { int E /* tiles per thread */, NT, n_lds; size_t shmem; bool ok; };
 
 FinishPlan finish_plan(int r) {
   FinishPlan p{0, 0, 0, 0, false};
   const int ld = r | 1;
-  const size_t total = (size_t)r * (r + 1) / 2 + r;
+  const size_t tiles = (size_t)factor_tile_count(r);
   const size_t w = (size_t)(r + 1) * ld, one = (size_t)r * ld;
   const size_t budget = (size_t)kLdsDoubles - 4700;  // static LDS of factor_reg_body + tail_body
   if (w > budget) return p;
-  if (total <= 256 * 6) { p.E = 6; p.NT = 256; }
-  else if (total <= 256 * 12) { p.E = 12; p.NT = 256; }
-  else if (total <= 1024 * 6) { p.E = 6; p.NT = 1024; }
-  else if (total <= 1024 * 12) { p.E = 12; p.NT = 1024; }
+  if (tiles <= 256) { p.E = 1; p.NT = 256; }
+  else if (tiles <= 1024) { p.E = 1; p.NT = 1024; }
+  else if (tiles <= 2048) { p.E = 2; p.NT = 1024; }
   else return p;
   p.n_lds = 2 * one <= budget ? 2 : (one <= budget ? 1 : 0);
   const size_t tails = one * p.n_lds;
@@ -240,10 +239,9 @@ void launch_step_finish(hipStream_t st, const StepFinishArgs& a_in) {
   a.n_lds = p.n_lds;
   a.tpr_log2 = matvec_tpr_log2(a.r, p.NT);
   ProfScope _ps(st, KID_STEP_FINISH);
-  if (p.E == 6 && p.NT == 256) launch_finish<6, 256>(st, a, p.shmem);
-  else if (p.E == 12 && p.NT == 256) launch_finish<12, 256>(st, a, p.shmem);
-  else if (p.E == 6 && p.NT == 1024) launch_finish<6, 1024>(st, a, p.shmem);
-  else launch_finish<12, 1024>(st, a, p.shmem);
+  if (p.E == 1 && p.NT == 256) launch_finish<1, 256>(st, a, p.shmem);
+  else if (p.E == 1 && p.NT == 1024) launch_finish<1, 1024>(st, a, p.shmem);
+  else launch_finish<2, 1024>(st, a, p.shmem);
 }
 
 }  // namespace icp
