@@ -374,13 +374,15 @@ namespace {
 
 struct PosteriorEntry {
   std::vector<double> theta;
-  bool valid = false, eig_valid = false;
+  bool valid = false, eig_valid = false, eig_checked = false;  // eig_checked: its status has reached the host copy
+  hipEvent_t eig_done = nullptr;  // recorded on the proposal's eigen stream behind the entry's decomposition
   uint64_t stamp = 0;
   DBuf<int> id, aux;
   DBuf<double> pt, nhat, e;
   DBuf<uint8_t> keep;
   DBuf<double> coeffs, M, alpha, V, Vt, S;
   int status_off = 0;  // this entry's 3 ints inside the proposal's status buffer
+  ~PosteriorEntry() { if (eig_done) (void)hipEventDestroy(eig_done); }
   CorrBuffers corr() const { return CorrBuffers{id.p, aux.p, pt.p, keep.p, nhat.p, e.p}; }
 };
 
@@ -398,6 +400,11 @@ struct icp_proposal {
   DBuf<double> fscratch;  // (r+1)·r factorisation scratch (ranks too large for LDS)
   const double* warm_ptr = nullptr;  // eigenvectors of the most recent posterior (inside its memo entry): warm start of the next
   bool warm_valid = false;
+  // Every eigen-decomposition of this proposal runs on its own stream (they share `work` and the warm start, so they must
+  // not overlap each other), beside the context stream: the decomposition of a state that is not needed yet — the other
+  // ICP direction of a freshly accepted state — then overlaps the chain's next steps instead of delaying a later one.
+  hipStream_t eig_stream = nullptr;
+  hipEvent_t ev_ready = nullptr;   // context stream -> eigen stream: "M is complete"
   DBuf<int> status;       // 3 ints per memo entry: {chol(M), chol(G+σ²M), eigen}
   std::vector<int> h_status;
   std::unique_ptr<PosteriorEntry[]> memo;
@@ -406,7 +413,8 @@ struct icp_proposal {
   PosteriorEntry& posterior(const double* theta, bool want_aux);
   PosteriorEntry* find_entry(const double* theta);
   PosteriorEntry& fresh_entry();
-  void ensure_eigen(PosteriorEntry& e);
+  void ensure_eigen(PosteriorEntry& e);  // enqueue on eig_stream (no-op if done or in flight)
+  void await_eigen(PosteriorEntry& e);   // make the context stream wait for it
   void check_status(PosteriorEntry& e);
 };
 
@@ -489,6 +497,7 @@ PosteriorEntry& icp_proposal::fresh_entry() {
   }
   e.valid = false;
   e.eig_valid = false;
+  e.eig_checked = false;
   return e;
 }
 
@@ -542,12 +551,20 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
 void icp_proposal::ensure_eigen(PosteriorEntry& e) {
   if (e.eig_valid) return;
   icp_ctx& c = *ctx;
+  if (!e.eig_done) HIP_OK(hipEventCreateWithFlags(&e.eig_done, hipEventDisableTiming));
+  HIP_OK(hipEventRecord(ev_ready, c.stream));  // M of this entry may still be in flight on the context stream
+  HIP_OK(hipStreamWaitEvent(eig_stream, ev_ready, 0));
   // the kernel reads all of Vwarm before it writes V, so the two may be the same buffer (a reused memo entry)
-  launch_posterior_eigen(c.stream, c.r, e.M.p, c.sqrt_lambda.p, warm_valid ? warm_ptr : nullptr, e.V.p, e.Vt.p, e.S.p, work.p,
+  launch_posterior_eigen(eig_stream, c.r, e.M.p, c.sqrt_lambda.p, warm_valid ? warm_ptr : nullptr, e.V.p, e.Vt.p, e.S.p, work.p,
                          status.p + e.status_off + 2);
+  HIP_OK(hipEventRecord(e.eig_done, eig_stream));
   warm_ptr = e.V.p;
   warm_valid = true;
   e.eig_valid = true;
+}
+
+void icp_proposal::await_eigen(PosteriorEntry& e) {
+  if (e.eig_done) HIP_OK(hipStreamWaitEvent(ctx->stream, e.eig_done, 0));
 }
 
 // must be called after a synchronising copy of `status` into h_status
@@ -1006,6 +1023,8 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
       p->K = params->n_model_ids;
     }
     p->prm.target_points = nullptr;  // caller memory is not retained
+    HIP_OK(hipStreamCreateWithFlags(&p->eig_stream, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
     p->work.alloc(eigen_work_doubles(ctx->r));
     p->work.fill_bytes(0);  // holds the completion counter of the eigenvector replay kernel
     p->Mpart.alloc((size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1));
@@ -1026,6 +1045,8 @@ void icp_proposal_destroy(icp_proposal* p) {
     std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->eig_stream) { (void)hipStreamSynchronize(p->eig_stream); (void)hipStreamDestroy(p->eig_stream); }
+    if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
     delete p;
   }
 }
@@ -1042,6 +1063,7 @@ int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, 
     const int r = c.r;
     PosteriorEntry& e = p->posterior(theta, false);  // NonRigidIcpProposal.scala:54
     p->ensure_eigen(e);
+    p->await_eigen(e);
     const double* dz = c.stage(z, r);                 // :55 the caller's standard normals
     launch_propose(c.stream, r, e.alpha.p, e.V.p, e.S.p, c.inv_sqrt_lambda.p, c.P.p, kSigma2, e.coeffs.p, dz,
                    p->prm.step_length, c.d_res.p);
@@ -1108,7 +1130,7 @@ int icp_proposal_posterior(icp_proposal* p, const double* theta, icp_posterior_v
     Bound _b(&c);
     const int r = c.r, K = p->K;
     PosteriorEntry& e = p->posterior(theta, view->corr_aux != nullptr);
-    if (view->V || view->S) p->ensure_eigen(e);
+    if (view->V || view->S) { p->ensure_eigen(e); p->await_eigen(e); }
     view->n_candidates = K;
     auto d2h = [&](void* dst, const void* src, size_t bytes) {
       if (dst && bytes) HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c.stream));
@@ -1349,10 +1371,18 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     PosteriorEntry* ec[2];
     PosteriorEntry* ep[2];
     for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
+    // KL bases of the current state's posteriors: all of them are started now, each on its proposal's own stream (they
+    // run side by side); only the generating one is waited for — the other is ready when a later step draws from it
     bool eigen_enqueued = false;
-    if (generator >= 0 && !ec[generator]->eig_valid) {
-      props[generator]->ensure_eigen(*ec[generator]);
-      eigen_enqueued = true;
+    for (int i = 0; i < n_props; ++i)
+      if (!ec[i]->eig_valid) {
+        props[i]->ensure_eigen(*ec[i]);
+        if (i == generator) eigen_enqueued = true;
+      }
+    if (generator >= 0) {
+      props[generator]->await_eigen(*ec[generator]);
+      eigen_enqueued = !ec[generator]->eig_checked;  // first use (possibly of an earlier prefetch): fetch its status
+      ec[generator]->eig_checked = true;
     }
 
     // ---- new side: one state slot, one memo entry per proposal
