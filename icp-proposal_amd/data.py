@@ -208,3 +208,61 @@ def boundary_vertex_flags(mesh: TriangleMesh) -> np.ndarray:
     flags[b // mesh.n_points] = 1
     flags[b % mesh.n_points] = 1
     return flags
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Synthetic stand-in for the Basel Face Model configurations (BASELINE.json configs[3], configs[4]).
+# The BFM-2017 files are not redistributable and absent from the reference tree (README.md:60-70, .gitignore:26-29);
+# SURVEY.md §8d prescribes a procedural model of the same SIZE: an open height-field "face" patch with smooth
+# low-frequency deformation modes, and a partial target with a hole (the reference crops its scans around the nose,
+# apps/bfm/AlignShapes.scala:90-92).  Nothing here claims to resemble the BFM statistically.
+
+def synthetic_face_model(grid: int = 169, rank: int = 200, seed: int = 2017) -> StatisticalMeshModel:
+    """grid×grid vertices (169 -> N = 28,561, T = 56,448; BFM face12 has 28,588 / 56,572), `rank` deformation modes.
+
+    Geometry: a 150 mm × 200 mm patch with a nose-like bump.  Basis: 2-D cosine modes cos(pi p u)·cos(pi q v) on cell-centred
+    coordinates (exactly orthogonal on the grid), ordered by frequency; every mode deforms along a seeded random unit
+    direction; columns are scaled to squared norm N like Statismo's unscaled eigenfunctions; the variances decay
+    with frequency from 25 down to ~0.05 mm²."""
+    g = int(grid)
+    u = (np.arange(g) + 0.5) / g
+    uu, vv = np.meshgrid(u, u, indexing="ij")
+    x = 150.0 * (uu - 0.5)
+    y = 200.0 * (vv - 0.5)
+    z = 45.0 * np.exp(-((uu - 0.5) ** 2 + (vv - 0.45) ** 2) / 0.012) + 12.0 * np.cos(np.pi * (uu - 0.5)) * np.cos(np.pi * (vv - 0.5))
+    ref = np.stack([x, y, z], axis=-1).reshape(-1, 3)
+    idx = np.arange(g * g).reshape(g, g)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel()
+    cells = np.concatenate([np.stack([a, b, c], axis=1), np.stack([b, d, c], axis=1)], axis=0).astype(np.int32)
+    n = g * g
+    modes = sorted(((p * p + q * q, p, q) for p in range(32) for q in range(32)))[1:rank + 1]   # skip the constant mode
+    rng = np.random.Generator(np.random.PCG64(seed))
+    basis = np.empty((3 * n, rank))
+    var = np.empty(rank)
+    for j, (f2, p, q) in enumerate(modes):
+        phi = (np.cos(np.pi * p * uu) * np.cos(np.pi * q * vv)).reshape(-1)
+        dirn = rng.normal(size=3)
+        dirn /= np.linalg.norm(dirn)
+        col = (phi[:, None] * dirn[None, :]).reshape(-1)
+        basis[:, j] = col * np.sqrt(n / np.dot(col, col))
+        var[j] = 25.0 * np.exp(-f2 / 40.0) + 0.05
+    return StatisticalMeshModel(ref, cells, np.zeros_like(ref), basis, var)
+
+
+def synthetic_partial_target(model: StatisticalMeshModel, seed: int = 7, n_remove: int = 1000, coeff_scale: float = 0.5,
+                             jitter_mm: float = 0.02) -> TriangleMesh:
+    """A model sample (coefficients ~ coeff_scale·N(0, I), seeded) with the `n_remove` vertices nearest to the nose tip cut
+    out (and seeded vertex jitter against exact ties): a target with an inner boundary, as in apps/bfm/BfmFittingPartial.scala."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pts = model.instance(coeff_scale * rng.normal(size=model.rank))
+    pts = pts + rng.normal(0.0, jitter_mm, size=pts.shape)
+    tip = int(np.argmax(model.ref_points[:, 2]))
+    drop = np.zeros(model.n_points, dtype=bool)
+    drop[np.argsort(np.linalg.norm(model.ref_points - model.ref_points[tip], axis=1))[:n_remove]] = True
+    keep_cells = model.cells[~drop[model.cells].any(axis=1)]
+    used = np.zeros(model.n_points, dtype=bool)
+    used[keep_cells.ravel()] = True
+    remap = -np.ones(model.n_points, dtype=np.int64)
+    remap[used] = np.arange(int(used.sum()))
+    return TriangleMesh(pts[used], remap[keep_cells].astype(np.int32))
+

@@ -106,6 +106,50 @@ def femur_icp_proposal_registration(model, target, n_icp_points=None, n_eval_poi
     return s
 
 
+def femur_random_init_comparison(model, target, fused=2) -> ChainSetup:
+    """The ICP chain of apps/femur/RunMHRandomInitComparison.scala:54-61 (BASELINE.json configs[2]): every model point is a
+    sample point of the proposal and of the evaluator (:54-55), ICP mixture with ModelSampling only (:59, no random walk in
+    this chain), prior × independent Gaussian(0, 2) with SymmetricEvaluation (:61)."""
+    n = model.n_points
+    s = ChainSetup()
+    s.icp.append(dict(direction=0, step=0.1, sigma_t=10.0, sigma_n=5.0, boundary_aware=True, n_model_ids=n, weight=0.5))
+    s.w_icp, s.w_rw, s.w_pose = 1.0, 0.0, 0.0
+    s.eval = dict(kind=0, mode=2, n_model_ids=n, target_pts=_data.decimated_point_subset(target, n),
+                  gauss_mean=0.0, gauss_sigma=2.0, exp_rate=1.0)
+    s.fused = fused
+    return s
+
+
+def bfm_fitting_partial(model, target, evaluator: str = "collective", fused=2) -> ChainSetup:
+    """The configuration of apps/bfm/BfmFittingPartial.scala:62-83 (BASELINE.json configs[3], configs[4]): 2·rank ICP points,
+    4·rank evaluator points (:65,78); 0.4 pose + 0.55 ICP(ModelSampling, σt = 6, σn = 3, step 0.1) + 0.05 random walk (:66-70);
+    evaluator: the boundary-aware collective average/Hausdorff likelihood with symmetric evaluation (σ_avg 0.3, rate 1.0,
+    mean 0.1, :80), or the full-mesh Hausdorff evaluator (evaluators/HausdorffDistanceEvaluator.scala, Exponential(1))."""
+    r = model.rank
+    s = ChainSetup()
+    s.icp.append(dict(direction=0, step=0.1, sigma_t=6.0, sigma_n=3.0, boundary_aware=True, n_model_ids=min(2 * r, model.n_points),
+                      weight=0.5))
+    s.w_pose, s.w_icp, s.w_rw = 0.4, 0.55, 0.05
+    s.rw_sigma = 0.1
+    if evaluator == "hausdorff":
+        s.eval = dict(kind=1, mode=2, n_model_ids=0, target_pts=np.zeros((0, 3)), gauss_mean=0.0, gauss_sigma=1.0, exp_rate=1.0)
+    else:
+        s.eval = dict(kind=2, mode=2, n_model_ids=min(4 * r, model.n_points), target_pts=_data.decimated_point_subset(target, 4 * r),
+                      gauss_mean=0.1, gauss_sigma=0.3, exp_rate=1.0)
+    s.fused = fused
+    return s
+
+
+def random_initial_parameters(model, chain_index: int, seed: int = 1024) -> np.ndarray:
+    """Chain i > 0 starts from shape coefficients c ~ N(0, 0.1·I) (apps/femur/RandomSamplesFromModel.scala:26-35 draws the
+    stored start shapes that way); chain 0 from the mean."""
+    from .api import initial_parameters as _init
+    theta = _init(model)
+    if chain_index > 0:
+        theta[10:] = np.random.default_rng(seed + chain_index).normal(size=model.rank) * np.sqrt(0.1)
+    return theta
+
+
 class SamplingRegistration:
     """SamplingRegistration (api/sampling/SamplingRegistration.scala:37-93) over one IcpContext."""
 

@@ -41,3 +41,56 @@ def test_femur50_chain_matches_oracle(pkg, femur50, femur50_oracle, oracle, fuse
     assert n == n_steps and a == acc_o.sum()
     chain.close()
     ctx.close()
+
+
+def test_femur100_all_points_symmetric_matches_oracle(pkg, oracle):
+    """BASELINE.json configs[2] (RunMHRandomInitComparison analogue): femur-100 GPMM (rank 101), every model point a sample
+    point of proposal and evaluator (K = N = 1622), ModelSampling ICP mixture, symmetric evaluation, random initial shape.
+
+    With 1622 correspondences the ICP posterior is so narrow that the reference's transition ratio rejects almost every
+    step (identical on both sides); the step's ingredients are therefore compared one by one as well."""
+    model, target = pkg.data.load_femur_model_and_target(100)
+    assert model.rank == 101
+    r, n = model.rank, model.n_points
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    setup = pkg.femur_random_init_comparison(model, target)
+    theta0 = pkg.random_initial_parameters(model, chain_index=3)
+    ctx = pkg.IcpContext(model, target, device=0)
+    # ---- one step, ingredient by ingredient, through the merged-launch entry point and through the per-method ones
+    pp = oracle.proposal_params(0.1, 10.0, 5.0, oracle.MODEL_SAMPLING, True, n_model_ids=n)
+    e = setup.eval
+    ep = oracle.evaluator_params(e["kind"], e["mode"], n_model_ids=e["n_model_ids"], target_pts=e["target_pts"],
+                                 p0=e["gauss_mean"], p1=e["gauss_sigma"], p2=e["exp_rate"])
+    prop = pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, n, "ModelSampling", True)
+    ev = pkg.IndependentPointDistanceEvaluator(ctx, 0.0, 2.0, 2, n, decimatedTargetPoints=e["target_pts"])
+    rng = np.random.default_rng(5)
+    for trial in range(2):
+        theta = theta0.copy()
+        theta[10:] += 0.2 * rng.normal(size=r)
+        z = rng.normal(size=r)
+        post, po = prop.icpPosterior(theta), oracle.icp_posterior(om, ot, pp, theta)
+        assert np.array_equal(post.corr_id, po.corr_id) and np.array_equal(post.corr_point, po.corr_pt)   # bit-exact
+        assert np.abs(post.alpha - po.alpha).max() <= 1e-9 * np.abs(po.alpha).max()
+        assert np.abs(post.S - po.S).max() <= 1e-9 * np.abs(po.S).max()
+        want = oracle.propose(om, ot, pp, theta, z)
+        got, val, fwd, bwd = pkg.chain_step(ev, [prop], theta, generator=0, z=z)
+        assert np.abs(got - want).max() <= 1e-7 * np.abs(want[10:]).max()
+        lv, rc = oracle.evaluator_log_value(om, ot, ep, want)
+        assert rc == 0 and abs(val - lv) <= 1e-7 * abs(lv)        # the states differ by ~1e-13
+        lf, lb = oracle.log_transition(om, ot, pp, theta, want), oracle.log_transition(om, ot, pp, want, theta)
+        assert abs(fwd[0] - lf) <= 1e-6 * abs(lf) and abs(bwd[0] - lb) <= 1e-6 * abs(lb)
+        assert prop.logTransitionProbability(theta, got) == fwd[0] and ev.logValue(got) == val
+    prop.close()
+    ev.close()
+    # ---- a short chain: identical decisions
+    n_steps, seed = 6, 1031
+    acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), theta0, seed, n_steps)
+    chain = pkg.SamplingRegistration(ctx, setup, theta0, seed)
+    rec = chain.run(n_steps)
+    assert np.array_equal(rec[:, 1].astype(np.uint8), acc_o), "accept/reject sequences differ"
+    assert np.array_equal(rec[:, 2].astype(np.int32), comp_o)
+    scale = np.abs(states_o[:, 10:]).max()
+    assert np.abs(rec[:, 4 + 10:] - states_o[:, 10:]).max() <= 1e-5 * scale
+    assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
+    chain.close()
+    ctx.close()
