@@ -25,7 +25,11 @@ def _worker(rank, world, port, q):
     rec[:, 3] = -100.0 + rank * 10 + np.arange(7)  # rank 1, step 6 is the best sample
     allrec = sharding.gather_records(rec, dist)
     rk, st, best = sharding.best_sample(allrec)
-    q.put((rank, items, allrec.shape, float(allrec[1, 3, 2]), rk, st))
+    # ragged gather: rank 0 holds 3 blocks, rank 1 holds 2 (5 work items over 2 ranks)
+    blocks = [np.full((4, 6), 100.0 * rank + i) for i in range(len(items))]
+    per_rank = sharding.gather_ragged(blocks, dist)
+    ragged_ok = [b.shape for b in per_rank] == [(3, 4, 6), (2, 4, 6)] and per_rank[1][1][0, 0] == 101.0 and per_rank[0][2][3, 5] == 2.0
+    q.put((rank, items, allrec.shape, float(allrec[1, 3, 2]), rk, st, ragged_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,3 +48,4 @@ def test_gather_and_assignment_world2():
     assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
     for r in res:
         assert tuple(r[2]) == (2, 7, 17) and r[3] == 1.0 and (r[4], r[5]) == (1, 6)
+        assert r[6], "ragged gather returned wrong blocks"

@@ -130,3 +130,14 @@ def test_full_face_chain_runs(pkg, full_face, evaluator):
     leaves = set(rec[:, 2].astype(int))
     assert leaves & {3, 4, 5, 6, 7, 8}, "no pose proposal drawn"   # leaf ids 3..8 = the six pose random walks
     chain.close()
+
+
+def test_batch_registration_world1(pkg):
+    """configs[4] plumbing on one GPU: (target, chain) work items, one context per target, records returned in item order."""
+    model = pkg.data.synthetic_face_model(grid=41, rank=40)
+    targets = [pkg.data.synthetic_partial_target(model, seed=s, n_remove=90) for s in (7, 8)]
+    items, recs = pkg.sharding.run_batch(pkg, model, targets, n_chains=2, n_steps=5, make_setup=pkg.bfm_fitting_partial)
+    assert items == [(0, 0), (0, 1), (1, 0), (1, 1)] and len(recs) == 4
+    for k, rec in enumerate(recs):
+        assert rec.shape == (5, 14 + model.rank) and np.all(rec[:, 0] == k) and np.all(np.isfinite(rec[:, 1:]))
+    assert not np.array_equal(recs[0][:, 14:], recs[1][:, 14:])   # different initial shapes / seeds
