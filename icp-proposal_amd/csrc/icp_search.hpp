@@ -73,34 +73,47 @@ __device__ __forceinline__ void surface_init(const SurfaceTask& q, int k) {
   surface_init_at(q, k, p);
 }
 
-// workgroup (bx, by) of the tblocks × ksplit filter grid; kSearchBlock threads
+// workgroup (bx, by) of the tblocks × ksplit filter grid; kSearchBlock threads, TWO spheres per lane so that the whole
+// test runs on packed-f32 instructions (v_pk_add/mul/fma_f32: two sphere tests per issue slot; the wave-uniform query
+// operands come straight from SGPRs with op_sel broadcasts)
+constexpr int kSpheresPerLane = 2;
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int by) {
-  const int t = bx * kSearchBlock + threadIdx.x;
-  const bool valid = t < q.T;
-  float cx = 3e38f, cy = 3e38f, cz = 3e38f, R = 0.f;  // out-of-range lanes: infinitely far away
-  if (valid) {
-    float4 s = q.spheres[t];
-    cx = s.x; cy = s.y; cz = s.z; R = s.w;
-  }
+  const int t0 = (bx * kSearchBlock + threadIdx.x) * kSpheresPerLane;
+  const bool v0 = t0 < q.T, v1 = t0 + 1 < q.T;
+  f2_t cx = {3e38f, 3e38f}, cy = cx, cz = cx, R = {0.f, 0.f};  // out-of-range lanes: infinitely far away
+  if (v0) { const float4 s = q.spheres[t0]; cx.x = s.x; cy.x = s.y; cz.x = s.z; R.x = s.w; }
+  if (v1) { const float4 s = q.spheres[t0 + 1]; cx.y = s.x; cy.y = s.y; cz.y = s.z; R.y = s.w; }
   const float4* __restrict__ qrec = q.qrec;
   const float* __restrict__ thrA = q.thrA;
   const int k0 = by * q.kchunk;
   const int k1 = min(q.Kpad, k0 + q.kchunk);
   for (int k = k0; k < k1; k += kQU) {
-    bool hit[kQU];
-    unsigned long long m[kQU];
+    bool h0[kQU], h1[kQU];
+    unsigned long long m0[kQU], m1[kQU];
 #pragma unroll
     for (int u = 0; u < kQU; ++u) {  // wave-uniform query records: scalar loads, kQU queries in flight
       const float4 qq = qrec[k + u];
-      const float tt = thrA[k + u] + R;
-      const float dx = qq.x - cx, dy = qq.y - cy, dz = qq.z - cz;
-      const float dc2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-      hit[u] = valid && dc2 <= tt * tt;
-      m[u] = __ballot(hit[u]);
+      const float th = thrA[k + u];
+      const f2_t tt = f2_t{th, th} + R;
+      const f2_t dx = f2_t{qq.x, qq.x} - cx, dy = f2_t{qq.y, qq.y} - cy, dz = f2_t{qq.z, qq.z} - cz;
+      const f2_t dc2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      const f2_t t2 = tt * tt;
+      h0[u] = v0 && dc2.x <= t2.x;
+      h1[u] = v1 && dc2.y <= t2.y;
+      m0[u] = __ballot(h0[u]);
+      m1[u] = __ballot(h1[u]);
     }
 #pragma unroll
-    for (int u = 0; u < kQU; ++u)
-      if (m[u] != 0ull) wave_append(m[u], hit[u], q.cnt + (k + u), q.cand + (size_t)(k + u) * q.stride, t);  // uniform branch
+    for (int u = 0; u < kQU; ++u) {
+      if ((m0[u] | m1[u]) != 0ull) {  // uniform branch, rarely taken
+        int* cnt = q.cnt + (k + u);
+        int* list = q.cand + (size_t)(k + u) * q.stride;
+        if (m0[u] != 0ull) wave_append(m0[u], h0[u], cnt, list, t0);
+        if (m1[u] != 0ull) wave_append(m1[u], h1[u], cnt, list, t0 + 1);
+      }
+    }
   }
 }
 

@@ -110,7 +110,7 @@ SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const
   q.P = P; q.verts = verts; q.tris = tris; q.spheres = spheres; q.hint = hint;
   q.qrec = qb.qrec; q.thrA = qb.thrA; q.cnt = qb.cnt; q.cand = qb.cand;
   q.cp = cp; q.d2 = d2; q.tri = tri;
-  q.tblocks = cdiv(T > 0 ? T : 1, kBlock);
+  q.tblocks = cdiv(T > 0 ? T : 1, kBlock * kSpheresPerLane);
   split_queries(q.tblocks, q.Kpad, &q.ksplit, &q.kchunk);
   return q;
 }
