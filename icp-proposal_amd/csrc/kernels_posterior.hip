@@ -681,18 +681,31 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
 }
 
 // ---------------------------------------------------------------- V <- V·J_0·J_1···  (replay of the rotation log)
-// One wave per four coordinates (rows of V): lane = 4·(pair slot) + coordinate, 16 pairs per pass.  A row is a private
-// 1-D array of n2 positions; one round rotates its pairs and moves them to their next positions (double buffered), with
-// constant per-lane offsets.  Nothing is shared between waves, so no barrier is ever needed; the log streams through
-// LDS in chunks of whole rounds (one chunk in flight).  The last workgroup to finish fixes the signs (largest-|.|
-// component of every eigenvector positive), sorts the columns by the ranks of kernel 1 and writes V and Vᵀ.
-constexpr int kReplayCoords = 4;
+// One wave per TWO coordinates (rows of V): lane = pair + 32·coordinate.  A lane keeps its pair's two entries of the row
+// in registers; one round rotates the pair and hands the results to the neighbouring pairs (the round-robin move:
+// first entries travel to pair+1, second entries to pair−1, with the two turn-arounds at the ends): two 64-bit DPP
+// wave shifts per round, no LDS traffic for the data.  Nothing is shared between waves, so no barrier is ever needed;
+// the log streams through LDS in chunks of whole rounds (one chunk in flight, next round's entry prefetched).  The last
+// workgroup to finish fixes the signs (largest-|.| component of every eigenvector positive), sorts the columns by the
+// ranks of kernel 1 and writes V and Vᵀ.
+constexpr int kReplayCoords = 2;
 constexpr int kReplayChunk = 1024;  // log entries (16 B) per chunk: 16 per lane
+
+// whole-wave shifts by one lane on the DPP path of the VALU (gfx9 wave_shr:1 / wave_shl:1): no LDS crossbar trip
+__device__ __forceinline__ double wave_shr1_f64(double v) {  // lane l receives the value of lane l−1 (lane 0 keeps its own)
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1_f64(double v) {  // lane l receives the value of lane l+1 (lane 63 keeps its own)
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 
 __global__ void __launch_bounds__(64) k_eigen_vreplay(int r, const double* __restrict__ Vwarm, const double* __restrict__ rotlog,
                                                        int* __restrict__ meta, double* __restrict__ vpos /* [n2][64] */,
                                                        double* __restrict__ Vout, double* __restrict__ Vtout) {
-  __shared__ __attribute__((aligned(16))) double s_row[2][64 * kReplayCoords];
   __shared__ __attribute__((aligned(16))) double s_log[2][2 * kReplayChunk];
   __shared__ int s_last;
   const int lane = threadIdx.x, n2 = (r + 1) & ~1, m = n2 >> 1;
@@ -700,15 +713,12 @@ __global__ void __launch_bounds__(64) k_eigen_vreplay(int r, const double* __res
   if (blockIdx.x == 0 && lane == 0) g_eigen_stamps[40] = __builtin_amdgcn_s_memrealtime();
 #endif
   const int n_rounds = meta[0];
-  const int kc = lane & 3, q = lane >> 2, k = kReplayCoords * blockIdx.x + kc;
-  const bool has_a = q < m, has_b = q + 16 < m;
-  const int Ia = has_a ? q : 0, Ib = has_b ? q + 16 : 0;
-  // element (position p, coordinate kc) of the wave's rows lives at s_row[buf][4p + kc]
-  for (int p = q; p < n2; p += 16)
-    s_row[0][4 * p + kc] = (k < r && p < r) ? (Vwarm ? Vwarm[(size_t)k * r + p] : (k == p ? 1.0 : 0.0)) : 0.0;
-  const int rd_a = 8 * Ia + kc, rd_b = 8 * Ib + kc;  // positions 2I, 2I+1 -> offsets 8I + kc, 8I + 4 + kc
-  const int wa0 = 4 * rr_dst(2 * Ia, m) + kc, wa1 = 4 * rr_dst(2 * Ia + 1, m) + kc;
-  const int wb0 = 4 * rr_dst(2 * Ib, m) + kc, wb1 = 4 * rr_dst(2 * Ib + 1, m) + kc;
+  const int kc = lane >> 5, q = lane & 31, k = kReplayCoords * blockIdx.x + kc;
+  const bool act = q < m;
+  const int qc = act ? q : 0;
+  // this lane's pair of the row: positions 2q (first) and 2q+1 (second)
+  auto v0_at = [&](int p) { return (k < r && p < r) ? (Vwarm ? Vwarm[(size_t)k * r + p] : (k == p ? 1.0 : 0.0)) : 0.0; };
+  double x0 = act ? v0_at(2 * q) : 0.0, x1 = act ? v0_at(2 * q + 1) : 0.0;
   const int rounds_per_chunk = kReplayChunk / m, chunk_entries = rounds_per_chunk * m;
   const int n_chunks = (n_rounds + rounds_per_chunk - 1) / rounds_per_chunk;
   constexpr int kPer = kReplayChunk / 64;
@@ -733,7 +743,7 @@ __global__ void __launch_bounds__(64) k_eigen_vreplay(int r, const double* __res
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  int cur = 0, lb = 0;
+  int lb = 0;
   if (n_chunks > 0) { fetch(0); stash(0); }
   wave_sync();
 #ifdef ICP_EIGEN_TIMING
@@ -743,16 +753,17 @@ __global__ void __launch_bounds__(64) k_eigen_vreplay(int r, const double* __res
     const bool more = c + 1 < n_chunks;
     if (more) fetch(c + 1);
     const int t_end = min(n_rounds - c * rounds_per_chunk, rounds_per_chunk);
+    dbl2 cs = *(const dbl2*)&s_log[lb][2 * qc];
     for (int rl = 0; rl < t_end; ++rl) {
-      const double* lg = &s_log[lb][2 * rl * m];
-      const dbl2 ca = *(const dbl2*)(lg + 2 * Ia), cz = *(const dbl2*)(lg + 2 * Ib);
-      const double* src = s_row[cur];
-      double* dst = s_row[cur ^ 1];
-      const double a0 = src[rd_a], a1 = src[rd_a + 4], b0 = src[rd_b], b1 = src[rd_b + 4];
-      if (has_a) { dst[wa0] = fma(ca.x, a0, ca.y * a1); dst[wa1] = fma(-ca.y, a0, ca.x * a1); }
-      if (has_b) { dst[wb0] = fma(cz.x, b0, cz.y * b1); dst[wb1] = fma(-cz.y, b0, cz.x * b1); }
-      wave_sync();
-      cur ^= 1;
+      const dbl2 cs_next = *(const dbl2*)&s_log[lb][2 * (min(rl + 1, t_end - 1) * m + qc)];  // independent of the data
+      const double f = fma(cs.x, x0, cs.y * x1), g = fma(-cs.y, x0, cs.x * x1);  // rotated first / second entry of the pair
+      // round-robin move (rr_dst): first entries go one pair up, except pair 0 (stays) and pair m−1 (becomes its own second);
+      // second entries go one pair down, except pair 0 (becomes the first of pair 1)
+      const double from_up = wave_shr1_f64(q == 0 ? g : f);  // what pair q−1 sends up: its first — or pair 0's second
+      const double from_dn = wave_shl1_f64(g);               // what pair q+1 sends down: its second
+      x0 = q == 0 ? f : from_up;
+      x1 = q == m - 1 ? f : from_dn;
+      cs = cs_next;
     }
     if (more) { lb ^= 1; stash(lb); wave_sync(); }
   }
@@ -760,8 +771,7 @@ __global__ void __launch_bounds__(64) k_eigen_vreplay(int r, const double* __res
   if (blockIdx.x == 0 && lane == 0) g_eigen_stamps[42] = __builtin_amdgcn_s_memrealtime();
 #endif
   // ---- publish the rows (position-major), then the last workgroup assembles the output
-  for (int p = q; p < n2; p += 16)
-    if (k < r) vpos[(size_t)p * 64 + k] = s_row[cur][4 * p + kc];
+  if (act && k < r) { vpos[(size_t)(2 * q) * 64 + k] = x0; vpos[(size_t)(2 * q + 1) * 64 + k] = x1; }
   __threadfence();
   if (lane == 0) s_last = atomicAdd(&meta[1], 1) == (int)gridDim.x - 1;
   __syncthreads();
@@ -771,9 +781,6 @@ __global__ void __launch_bounds__(64) k_eigen_vreplay(int r, const double* __res
 #endif
   __threadfence();
   if (lane == 0) meta[1] = 0;  // ready for the next decomposition
-#ifdef ICP_EIGEN_TIMING
-  if (lane == 0) g_eigen_stamps[45] = __builtin_amdgcn_s_memrealtime();
-#endif
   // Stage the whole position-major V in LDS (coalesced, all loads in flight together; row stride 65: conflict-free
   // column walks), then lane = position: sign from the largest-|.| component, columns out in rank order.
   double* s_v = &s_log[0][0];  // 2·2·kReplayChunk doubles >= 64·65
@@ -786,9 +793,6 @@ __global__ void __launch_bounds__(64) k_eigen_vreplay(int r, const double* __res
       if (p0 + u < n2) s_v[(p0 + u) * 65 + lane] = tmp[u];
   }
   __syncthreads();
-#ifdef ICP_EIGEN_TIMING
-  if (lane == 0) g_eigen_stamps[46] = __builtin_amdgcn_s_memrealtime();
-#endif
   if (lane < n2) {
     const int rank = meta[2 + lane];
     if (rank < r) {
@@ -800,9 +804,6 @@ __global__ void __launch_bounds__(64) k_eigen_vreplay(int r, const double* __res
         if (a > bv) { bv = a; best = kk; }
       }
       const double sgn = col[best] < 0.0 ? -1.0 : 1.0;
-#ifdef ICP_EIGEN_TIMING
-      if (lane == 0) g_eigen_stamps[47] = __builtin_amdgcn_s_memrealtime();
-#endif
       for (int kk = 0; kk < r; ++kk) {
         const double v = col[kk] * sgn;
         Vout[(size_t)kk * r + rank] = v;
