@@ -8,6 +8,7 @@
 #include "../../include/icp_proposal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -230,6 +231,9 @@ struct icp_ctx {
   DBuf<double> d_res;
   int* h_status = nullptr;
   DBuf<int> d_status;
+  DBuf<int> d_done;            // completion counter of the step's last launch
+  int* h_flag = nullptr;       // pinned: sequence number of the last finished step
+  int step_seq = 0;
 
   Profiler prof;
   bool profiling = false;
@@ -829,6 +833,10 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->d_res.alloc(res_cap);
     HIP_OK(hipHostMalloc((void**)&ctx->h_status, sizeof(int) * 64, hipHostMallocDefault));
     ctx->d_status.alloc(64);
+    HIP_OK(hipHostMalloc((void**)&ctx->h_flag, sizeof(int) * 16, hipHostMallocDefault));
+    ctx->h_flag[0] = 0;
+    ctx->d_done.alloc(4);
+    ctx->d_done.fill_bytes(0);
     HIP_OK(hipStreamSynchronize(ctx->stream));
     *out = ctx;
   });
@@ -849,6 +857,7 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+  if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
   delete ctx;
 }
 
@@ -1502,9 +1511,23 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       f.bwd[i] = TransitionTailIO{ep[i]->alpha.p, ep[i]->M.p, ep[i]->coeffs.p, ec[i]->coeffs.p, p->prm.step_length,
                                   c.h_res + 9 + 2 * i, c.h_status + 2 * i + 1};
     }
+    f.done_counter = c.d_done.p; f.host_flag = c.h_flag; f.seq = ++c.step_seq;
     launch_step_finish(c.stream, f);
-    for (int i = 0; i < n_props; ++i) sync_proposal_status_if(props[i], eigen_enqueued && i == generator);
-    c.finish(0, 0);
+    if (eigen_enqueued) {
+      sync_proposal_status_if(props[generator], true);
+      c.finish(0, 0);
+    } else {
+      // results and flag are written into pinned memory by the kernels: poll the flag (≈ 4 µs less than a stream
+      // synchronisation); give up after 2 s and let the synchronisation report what went wrong
+      volatile int* flag = c.h_flag;
+      const auto t_start = std::chrono::steady_clock::now();
+      long spins = 0;
+      while (*flag != f.seq) {
+        if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) break;
+      }
+      if (*flag != f.seq) c.finish(0, 0);
+      c.stage_used = 0;
+    }
 
     // ---- bookkeeping with the results in hand
     const size_t P = 10 + (size_t)r;

@@ -318,8 +318,25 @@ __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict_
         off[a][c] = live[a][c] ? (size_t)i * n + k : 0;
         v[t][a][c] = 0.0;
       }
-    for (int sp = 0; sp < S; ++sp) {
-      const double* P = Mpart + (size_t)sp * n * n;
+    const size_t nn = (size_t)n * n;
+    int sp = 0;
+    for (; sp + 4 <= S; sp += 4) {  // four splits (32 loads) in flight; summed in split order
+      double p[4][2][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) p[u][a][c] = Mpart[(size_t)(sp + u) * nn + off[a][c]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[t][a][c] += p[u][a][c];
+    }
+    for (; sp < S; ++sp) {
+      const double* P = Mpart + (size_t)sp * nn;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll

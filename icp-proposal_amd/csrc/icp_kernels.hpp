@@ -232,6 +232,9 @@ struct StepFinishArgs {  // launch 5: per posterior Cholesky + alpha, then the b
   TransitionTailIO bwd[2];   // prop -> cur, needs this launch's factorisation
   TransitionTailIO fwd[2];   // cur -> prop, from the cached posterior of the current state
   const double* Ginv; double sigma2;
+  // completion signal: the last workgroup to finish stores `seq` into pinned host memory (the host polls it instead of
+  // paying a stream synchronisation)
+  int* done_counter; int* host_flag; int seq;
 };
 
 bool step_finish_supported(int r);

@@ -876,7 +876,7 @@ void launch_correspond_target(hipStream_t st, int K, const double* x, const doub
 }
 
 int regression_splits(int K) {
-  int s = (K + 23) / 24;  // ~24 correspondences per wave: short dependent chains, enough waves to overlap the gathers
+  int s = (K + 7) / 8;  // ~8 correspondences per wave: two gather rounds on its dependent chain, many waves to overlap them
   return s < 1 ? 1 : (s > 64 ? 64 : s);
 }
 

@@ -159,16 +159,27 @@ __global__ void __launch_bounds__(NT) k_step_finish(StepFinishArgs a) {
       a.status[b][1] = 0;
       a.status[b][2] = 0;
     }
-    if (!ok) {  // uniform
-      if (threadIdx.x == 0) { a.bwd[b].out[0] = __builtin_nan(""); a.bwd[b].status[0] = 0; }
-      return;
+    if (ok) {  // uniform
+      __syncthreads();  // M and alpha of this posterior are complete (written by this workgroup)
+      const TransitionTailIO& t = a.bwd[b];
+      tail_body(a.r, t.alpha, t.M, t.c_from, t.c_to, t.step, t.out, t.status, a.Ginv, a.sigma2, a.n_lds, a.tpr_log2);
+    } else if (threadIdx.x == 0) {
+      a.bwd[b].out[0] = __builtin_nan("");
+      a.bwd[b].status[0] = 0;
     }
-    __syncthreads();  // M and alpha of this posterior are complete (written by this workgroup)
-    const TransitionTailIO& t = a.bwd[b];
-    tail_body(a.r, t.alpha, t.M, t.c_from, t.c_to, t.step, t.out, t.status, a.Ginv, a.sigma2, a.n_lds, a.tpr_log2);
   } else {
     const TransitionTailIO& t = a.fwd[b - a.n];
     tail_body(a.r, t.alpha, t.M, t.c_from, t.c_to, t.step, t.out, t.status, a.Ginv, a.sigma2, a.n_lds, a.tpr_log2);
+  }
+  // every workgroup's results are in pinned host memory: count in, the last one raises the flag
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    if (atomicAdd(a.done_counter, 1) == (int)gridDim.x - 1) {
+      *a.done_counter = 0;
+      __threadfence_system();
+      *(volatile int*)a.host_flag = a.seq;
+    }
   }
 }
 
