@@ -467,7 +467,7 @@ __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict_
 __device__ __forceinline__ void tail_body(int r, const double* __restrict__ alpha, const double* __restrict__ Mg, const double* __restrict__ c_from,
                                           const double* __restrict__ c_to, double step, double* __restrict__ out, int* __restrict__ status,
                                           const double* __restrict__ Ginv, double sigma2, int n_lds, int tpr_log2) {
-  __shared__ double s_d[512], s_g[512], s_t[512], s_u[512], s_red[16];
+  __shared__ double s_d[512], s_g[512], s_t[512], s_u[512], s_red3[3][16];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int ld = r | 1;
   const int offM = 0, offG = r * ld;
@@ -487,26 +487,38 @@ __device__ __forceinline__ void tail_body(int r, const double* __restrict__ alph
     s_g[i] = d;
   }
   __syncthreads();
+  // Stop on the PREDICTED error of the current iterate: with the contraction factor ρ_k = δ_k/δ_{k-1} observed so far,
+  // ‖γ − g_k‖ <= δ_k·ρ/(1 − ρ).  For the femur models ρ ≈ 4e-8 and the second iterate is exact to rounding.  The quadratic
+  // form uses M·g_{k-1} of the last iteration (it differs from M·g_k by O(δ_k), i.e. by rounding).
   int converged = 0;
+  double delta_prev = 0.0, q = 0.0;
   for (int it = 0; it < 12 && !converged; ++it) {
     mul_M(s_g, s_t);
     mul_Ginv(s_t, s_u);
-    double delta = 0.0, gmax = 0.0;
+    double delta = 0.0, gmax = 0.0, part = 0.0;
     for (int i = tid; i < r; i += nt) {
       const double gn = fma(-sigma2, s_u[i], s_d[i]);
       delta = fmax(delta, fabs(gn - s_g[i]));
       gmax = fmax(gmax, fabs(gn));
+      part = fma(gn, s_t[i], part);
       s_g[i] = gn;
     }
-    delta = block_max(delta, s_red);
-    gmax = block_max(gmax, s_red);
-    converged = delta <= 1e-15 * gmax || gmax == 0.0;
+    // one combined reduction: max, max, sum
+    for (int o = 32; o > 0; o >>= 1) {
+      delta = fmax(delta, __shfl_down(delta, o, 64));
+      gmax = fmax(gmax, __shfl_down(gmax, o, 64));
+      part += __shfl_down(part, o, 64);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { s_red3[0][tid >> 6] = delta; s_red3[1][tid >> 6] = gmax; s_red3[2][tid >> 6] = part; }
+    __syncthreads();
+    delta = s_red3[0][0]; gmax = s_red3[1][0]; q = 0.0;
+    for (int w = 0; w < (int)((nt + 63) >> 6); ++w) { delta = fmax(delta, s_red3[0][w]); gmax = fmax(gmax, s_red3[1][w]); q += s_red3[2][w]; }
+    const double rho = it > 0 && delta_prev > 0.0 ? delta / delta_prev : 1.0;
+    converged = gmax == 0.0 || delta == 0.0 || (it > 0 && rho < 0.5 && delta * rho <= 1e-16 * gmax * (1.0 - rho));
+    delta_prev = delta;
     __syncthreads();
   }
-  mul_M(s_g, s_t);
-  double part = 0.0;
-  for (int i = tid; i < r; i += nt) part = fma(s_g[i], s_t[i], part);
-  const double q = block_sum(part, s_red);
   if (tid == 0) {
     out[0] = -0.5 * q - 0.5 * (double)r * 1.8378770664093453;  // ln(2π); no log-det term
     status[0] = converged ? 0 : 3;

@@ -82,6 +82,21 @@ int main(int argc, char** argv) {
     printf("factor r=%d: %.1f us/call | setup %.1f columns %.1f store %.1f dinv %.1f backsolve %.1f | residual %.2e\n", r, ms * 1000 / 20,
            (s[17] - s[16]) * 0.01, (s[18] - s[17]) * 0.01, (s[19] - s[18]) * 0.01, 0.0, (s[20] - s[19]) * 0.01, res);
   }
+  {  // ---- transition tail on the same matrix (fixed-point form)
+    std::vector<double> G((size_t)r * r, 0.0), Gi((size_t)r * r, 0.0), cf(r), ct(r), al(r);
+    for (int i = 0; i < r; ++i) { G[(size_t)i * r + i] = 1500.0 * sl[i] * sl[i]; Gi[(size_t)i * r + i] = 1.0 / G[(size_t)i * r + i]; cf[i] = nd(rng); ct[i] = cf[i] + 0.1 * nd(rng); al[i] = nd(rng); }
+    double *dGi, *dcf, *dct, *dal, *dout; int* dst3;
+    CK(hipMalloc(&dGi, 8 * r * r)); CK(hipMalloc(&dcf, 8 * r)); CK(hipMalloc(&dct, 8 * r)); CK(hipMalloc(&dal, 8 * r)); CK(hipMalloc(&dout, 64)); CK(hipMalloc(&dst3, 64));
+    CK(hipMemcpy(dGi, Gi.data(), 8 * r * r, hipMemcpyHostToDevice)); CK(hipMemcpy(dcf, cf.data(), 8 * r, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dct, ct.data(), 8 * r, hipMemcpyHostToDevice)); CK(hipMemcpy(dal, al.data(), 8 * r, hipMemcpyHostToDevice));
+    icp::TransitionTailIO io{dal, dM0, dcf, dct, 0.1, dout, dst3};
+    icp::launch_transition_tails(st, r, 1, &io, dGi, 1e-5); hipStreamSynchronize(st);
+    float ms = 0; hipEventRecord(a, st);
+    for (int i = 0; i < 20; ++i) icp::launch_transition_tails(st, r, 1, &io, dGi, 1e-5);
+    hipEventRecord(b, st); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+    int stt; double o; hipMemcpy(&stt, dst3, 4, hipMemcpyDeviceToHost); hipMemcpy(&o, dout, 8, hipMemcpyDeviceToHost);
+    printf("tail r=%d: %.1f us/call (status %d, value %.6g)\n", r, ms * 1000 / 20, stt, o);
+  }
   run("cold", dM0, nullptr, dV0);
   run("warm (3% perturbed)", dM1, dV0, dV1);
   run("warm (same matrix)", dM0, dV0, dV1);
