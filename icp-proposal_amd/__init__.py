@@ -11,3 +11,4 @@ from . import sampling  # noqa: F401
 from .sampling import (SamplingRegistration, ChainSetup, femur_icp_proposal_registration, femur_random_init_comparison,
                        bfm_fitting_partial, random_initial_parameters)  # noqa: F401
 from . import sharding  # noqa: F401
+from . import loggers  # noqa: F401

@@ -14,6 +14,8 @@
 //           lexicographic minimum over (d², index) by wave shuffles, closest point of the winner, hint update.
 // The result is the lexicographic minimum over ALL elements — identical to a sequential scan with `<` — because the
 // true minimiser always survives the filter and the reduction is order independent.
+#include <cstdlib>
+
 #include "icp_kernels.hpp"
 #include "icp_search.hpp"
 
@@ -82,7 +84,8 @@ __global__ void __launch_bounds__(64) k_vertex_resolve(VertexTask q) {
 
 // enough waves to fill 256 CUs, but at least ~8 queries per wave so the element load is amortised; kchunk multiple of kQU
 void split_queries(int n_elem_blocks, int Kpad, int* ksplit, int* kchunk) {
-  int want = cdiv(4096, n_elem_blocks * (kBlock / 64));
+  static const int target_waves = std::getenv("ICP_FILTER_WAVES") ? std::atoi(std::getenv("ICP_FILTER_WAVES")) : 4096;
+  int want = cdiv(target_waves, n_elem_blocks * (kBlock / 64));
   int s = want < 1 ? 1 : want;
   int maxs = cdiv(Kpad, 8);
   if (s > maxs) s = maxs;

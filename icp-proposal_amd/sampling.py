@@ -63,6 +63,16 @@ class ChainSetup:
         self.eval = dict(kind=0, mode=0, n_model_ids=0, target_pts=np.zeros((0, 3)), gauss_mean=0.0, gauss_sigma=1.0, exp_rate=1.0)
         self.fused = 2  # 0 per-method calls, 1 icp_chain_eval_step prefetch, 2 whole step in one icp_chain_step submission
 
+    def leaf_names(self):
+        """generatedBy strings of the leaf proposals, indexed by the leaf id of the per-step records (host/icp_host.cpp)."""
+        names = {}
+        for i, p in enumerate(self.icp):
+            names[i] = "IcpProposal-%s-%.6fStep" % ("TargetSampling" if p["direction"] == 1 else "ModelSampling", p["step"])
+        names[2] = "RandomShape-%.6f" % self.rw_sigma
+        for a, nm in enumerate(("RotationYaw", "RotationPitch", "RotationRoll", "TranslationX", "TranslationY", "TranslationZ")):
+            names[3 + a] = "%s-%.6f" % (nm, self.pose_rot_sigma[a] if a < 3 else self.pose_trans_sigma[a - 3])
+        return names
+
     def to_c(self):
         cfg = HostChainConfig()
         keep = []
