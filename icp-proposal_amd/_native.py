@@ -43,6 +43,11 @@ class PosteriorView(C.Structure):
                 ("keep", c_ubyte_p), ("alpha", c_double_p), ("M", c_double_p), ("V", c_double_p), ("S", c_double_p)]
 
 
+class FitParams(C.Structure):
+    _fields_ = [("direction", C.c_int32), ("n_model_ids", C.c_int32), ("model_ids", c_int_p), ("n_target_points", C.c_int32),
+                ("target_points", c_double_p), ("step_length", C.c_double)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 40), ("calls", C.c_int64), ("total_ms", C.c_double), ("min_ms", C.c_double),
                 ("max_ms", C.c_double)]
@@ -76,6 +81,7 @@ SIGNATURES = {
     "icp_ctx_profile_stop": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),
     "icp_chain_eval_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_double_p]),
+    "icp_fit_deterministic": (C.c_int, [C.c_void_p, C.POINTER(FitParams), c_double_p, C.c_int32, C.c_int32, c_double_p, c_double_p]),
     "icp_chain_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, c_double_p, c_double_p, c_double_p,
                                  c_double_p, c_double_p, c_double_p]),
 }

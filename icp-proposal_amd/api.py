@@ -343,3 +343,26 @@ def chain_step(evaluator: _Evaluator, proposals, theta_cur, generator: int = -1,
     nat.check(nat.lib().icp_chain_step(evaluator.h, n, arr, int(generator), _d(a), _d(zz), _d(b), C.byref(val), _d(fwd), _d(bwd)),
               "icp_chain_step")
     return b, val.value, fwd[:n], bwd[:n]
+
+
+class IcpBasedSurfaceFitting:
+    """api/other/IcpBasedSurfaceFitting.scala:32 — the deterministic non-rigid ICP baseline (posterior MEAN, isotropic noise).
+    `modelPointIds` / `targetPointSamples` stand for the UniformMeshSampler3D draws of :51-53 (made by the caller)."""
+
+    def __init__(self, ctx: IcpContext, stepLength: float = 1.0, projectionDirection=ModelSampling, modelPointIds=None,
+                 targetPointSamples=None):
+        self.ctx, self.step = ctx, float(stepLength)
+        self.direction = 1 if projectionDirection in (TargetSampling, "TargetSampling", 1) else 0
+        self.ids = np.ascontiguousarray(modelPointIds if modelPointIds is not None else np.zeros(0), dtype=np.int32)
+        self.tp = _f64(targetPointSamples if targetPointSamples is not None else np.zeros((0, 3))).reshape(-1, 3)
+
+    def runfitting(self, numIterations: int, iterationSeq=(1.0, 0.1, 0.01), initialModelParameters=None) -> np.ndarray:
+        """:46-126; returns the final parameter vector (the reference returns the corresponding mesh: ctx.transformedMesh)."""
+        th = _theta(initialModelParameters if initialModelParameters is not None else initial_parameters(self.ctx.model))
+        sig = _f64(iterationSeq)
+        out = np.zeros_like(th)
+        fp = nat.FitParams(self.direction, self.ids.shape[0], _i(self.ids), self.tp.shape[0], _d(self.tp), self.step)
+        nat.check(nat.lib().icp_fit_deterministic(self.ctx.h, C.byref(fp), _d(th), int(numIterations), sig.shape[0], _d(sig), _d(out)),
+                  "icp_fit_deterministic")
+        return out
+

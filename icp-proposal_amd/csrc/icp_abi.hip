@@ -1238,6 +1238,80 @@ int icp_prior_log_value(int32_t rank, const double* theta, double* out) {
   });
 }
 
+// --------------------------------------------------------------------- deterministic non-rigid ICP (next row 1)
+
+int icp_fit_deterministic(icp_ctx* ctx, const icp_fit_params* prm, const double* theta_init, int32_t n_iterations, int32_t n_sigma,
+                          const double* sigma2_seq, double* theta_out) {
+  return guard([&] {
+    require(ctx && prm && theta_out && sigma2_seq, "null argument");
+    require(n_iterations >= 0 && n_sigma >= 0, "negative iteration count");
+    require(prm->direction == ICP_MODEL_SAMPLING || prm->direction == ICP_TARGET_SAMPLING, "unknown direction");
+    require(std::isfinite(prm->step_length), "step_length must be finite");
+    icp_ctx& c = *ctx;
+    check_theta_finite(&c, theta_init);
+    const bool model_side = prm->direction == ICP_MODEL_SAMPLING;
+    const int K = model_side ? prm->n_model_ids : prm->n_target_points;
+    require(K >= 0 && (K == 0 || (model_side ? (const void*)prm->model_ids : (const void*)prm->target_points)), "bad sample list");
+    if (model_side)
+      for (int k = 0; k < K; ++k) require(prm->model_ids[k] >= 0 && prm->model_ids[k] < c.N, "model id out of range");
+    for (int i = 0; i < n_sigma; ++i) require(sigma2_seq[i] > 0.0 && std::isfinite(sigma2_seq[i]), "sigma2 must be positive");
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    Bound _b(&c);
+    const int r = c.r, Ka = std::max(K, 1);
+    const Pose pose = pose_from_theta(theta_init);
+    DBuf<double> coeffs, x, P, cp, pts, Mpart, M, alpha, e, nhat, pt;
+    DBuf<int> ids, nn, hint, corr_id, aux, status;
+    DBuf<uint8_t> keep;
+    coeffs.upload(theta_init + 10, r);
+    x.alloc(3 * (size_t)c.N);
+    P.alloc(3 * (size_t)Ka); cp.alloc(3 * (size_t)Ka);
+    hint.alloc(Ka); hint.fill_bytes(0xFF);
+    nn.alloc(Ka); corr_id.alloc(Ka); aux.alloc(Ka); keep.alloc(Ka);
+    e.alloc(3 * (size_t)Ka); nhat.alloc(3 * (size_t)Ka); pt.alloc(3 * (size_t)Ka);
+    if (model_side) ids.upload(prm->model_ids, K);
+    else pts.upload(prm->target_points, 3 * (size_t)K);
+    Mpart.alloc((size_t)regression_splits(Ka) * (r + 1) * (r + 1));
+    M.alloc((size_t)r * r); alpha.alloc(r);
+    DBuf<double> fscratch;
+    fscratch.alloc((size_t)(r + 1) * r);
+    status.alloc(4); status.fill_bytes(0);
+    const CorrBuffers cb{corr_id.p, aux.p, pt.p, keep.p, nhat.p, e.p};
+    for (int si = 0; si < n_sigma; ++si) {
+      const double wt = 1.0 / sigma2_seq[si];                                     // isotropic noise N(0, sigma2·I) (:81)
+      for (int it = 0; it <= n_iterations; ++it) {                                // nbIterations = numIterations .. 0 (:55-104)
+        launch_instance(c.stream, c.N, r, c.Qp.p, c.ref.p, c.mean.p, pose, coeffs.p, x.p);      // :61
+        if (K > 0) {
+          if (model_side) {                                                       // :72-74
+            launch_gather_points(c.stream, K, x.p, ids.p, P.p);
+            QueryBuffers qb = c.query_scratch(K, c.target.T);
+            launch_surface_query(c.stream, c.target.T, c.target.verts.p, c.target.tris.p, c.target.spheres.p, K, P.p, hint.p, qb, cp.p,
+                                 nullptr, nullptr);
+            launch_correspond_plain(c.stream, K, ids.p, cp.p, c.ref.p, c.mean.p, cb);
+          } else {                                                                // :76-78
+            QueryBuffers qb = c.query_scratch(K, c.N);
+            launch_vertex_query(c.stream, c.N, x.p, K, pts.p, hint.p, qb, nullptr, nn.p);
+            launch_correspond_plain(c.stream, K, nn.p, pts.p, c.ref.p, c.mean.p, cb);
+          }
+        }
+        int splits = 1;
+        launch_regression(c.stream, K, r, c.Q.p, cb, wt, 0.0, Mpart.p, &splits);   // model.posterior(corr, sigma2) (:81)
+        PosteriorFactorIO io{Mpart.p, splits, M.p, alpha.p, status.p, fscratch.p};
+        launch_posterior_factor(c.stream, r, 1, &io);                              // posterior.mean (:82)
+        launch_mean_step(c.stream, r, alpha.p, c.P.p, kSigma2, prm->step_length, coeffs.p);   // :84-85
+      }
+    }
+    HIP_OK(hipMemcpyAsync(c.h_res, coeffs.p, sizeof(double) * r, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipMemcpyAsync(c.h_status, status.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    c.finish(0, 0);
+    if (c.h_status[0] != 0) fail(ICP_ERR_NOT_SPD, "regression normal equations are not positive definite");
+    std::memcpy(theta_out, theta_init, sizeof(double) * 10);
+    for (int j = 0; j < r; ++j) {
+      if (!std::isfinite(c.h_res[j])) fail(ICP_ERR_NOT_FINITE, "fitted coefficients are not finite");
+      theta_out[10 + j] = c.h_res[j];
+    }
+  });
+}
+
 // --------------------------------------------------------------------- fused chain step
 
 int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, const double* theta_cur,

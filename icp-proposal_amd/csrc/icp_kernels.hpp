@@ -164,6 +164,15 @@ void launch_propose(hipStream_t st, int r, const double* alpha, const double* V,
                     const double* inv_sqrt_lambda, const double* P, double sigma2, const double* c,
                     const double* z, double step, double* c_out);
 
+// ---- deterministic ICP (api/other/IcpBasedSurfaceFitting.scala:46-126)
+// P[k] = x[ids[k]] (:72)
+void launch_gather_points(hipStream_t st, int K, const double* x, const int* ids, double* P);
+// correspondence records with isotropic noise: id = ids[k] (or nn[k]), e = pt − x̄_id − μ_id in WORLD space (:81), keep = 1, n̂ = 0
+void launch_correspond_plain(hipStream_t st, int K, const int* ids, const double* pts, const double* ref, const double* mean,
+                             const CorrBuffers& cb);
+// c <- c + step·((G+σ²I)⁻¹ G α − c) with P = (G+σ²I)⁻¹ (:84-85)
+void launch_mean_step(hipStream_t st, int r, const double* alpha, const double* P, double sigma2, double step, double* c);
+
 // ---- evaluator reductions (kernels_posterior.hip)
 // out[0] = Σ log N(sqrt(d2_k); mean, sigma)
 void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mean, double sigma, double* out);

@@ -823,6 +823,42 @@ __global__ void __launch_bounds__(256) k_propose(int r, ProposeIn in, double* __
   propose_body(r, in, c_out, tpr_log2);
 }
 
+// ---------------------------------------------------------------- deterministic ICP helpers
+
+__global__ void __launch_bounds__(kBlock) k_gather_points(int K, const double* __restrict__ x, const int* __restrict__ ids,
+                                                           double* __restrict__ P) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= K) return;
+  const int i = ids[k];
+  P[3 * k] = x[3 * i]; P[3 * k + 1] = x[3 * i + 1]; P[3 * k + 2] = x[3 * i + 2];
+}
+
+__global__ void __launch_bounds__(kBlock) k_correspond_plain(int K, const int* __restrict__ ids, const double* __restrict__ pts,
+                                                              const double* __restrict__ ref, const double* __restrict__ mean, CorrBuffers cb) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= K) return;
+  const int id = ids[k];
+  cb.id[k] = id; cb.aux[k] = -1; cb.keep[k] = 1;
+  for (int d = 0; d < 3; ++d) {
+    const double p = pts[3 * k + d];
+    cb.pt[3 * k + d] = p;
+    cb.nhat[3 * k + d] = 0.0;
+    cb.e[3 * k + d] = (p - ref[3 * id + d]) - mean[3 * id + d];  // the regression sees world-space points (IcpBasedSurfaceFitting.scala:81)
+  }
+}
+
+__global__ void __launch_bounds__(256) k_mean_step(int r, const double* __restrict__ alpha, const double* __restrict__ P, double sigma2,
+                                                    double step, double* __restrict__ c, int tpr_log2) {
+  __shared__ double s_a[512], s_y[512];
+  for (int i = threadIdx.x; i < r; i += blockDim.x) s_a[i] = alpha[i];
+  __syncthreads();
+  block_matvec(r, P, r, s_a, s_y, tpr_log2);
+  for (int i = threadIdx.x; i < r; i += blockDim.x) {
+    const double cnew = fma(-sigma2, s_y[i], s_a[i]);   // model.coefficients(posterior.mean) (:84)
+    c[i] = c[i] + (cnew - c[i]) * step;                 // :85
+  }
+}
+
 // ---------------------------------------------------------------- evaluator reductions
 
 __global__ void __launch_bounds__(kBlock) k_sum_gauss_logpdf(int K, const double* __restrict__ d2, double mean, double sigma,
@@ -994,6 +1030,17 @@ void launch_propose(hipStream_t st, int r, const double* alpha, const double* V,
   { ProfScope _ps(st, KID_PROPOSE);
     ProposeIn in{alpha, V, S, inv_sqrt_lambda, P, c, z, sigma2, step};
     hipLaunchKernelGGL(k_propose, dim3(1), dim3(256), 0, st, r, in, c_out, matvec_tpr_log2(r, 256)); }
+}
+
+void launch_gather_points(hipStream_t st, int K, const double* x, const int* ids, double* P) {
+  if (K > 0) hipLaunchKernelGGL(k_gather_points, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, K, x, ids, P);
+}
+void launch_correspond_plain(hipStream_t st, int K, const int* ids, const double* pts, const double* ref, const double* mean,
+                             const CorrBuffers& cb) {
+  if (K > 0) hipLaunchKernelGGL(k_correspond_plain, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, K, ids, pts, ref, mean, cb);
+}
+void launch_mean_step(hipStream_t st, int r, const double* alpha, const double* P, double sigma2, double step, double* c) {
+  hipLaunchKernelGGL(k_mean_step, dim3(1), dim3(256), 0, st, r, alpha, P, sigma2, step, c, matvec_tpr_log2(r, 256));
 }
 
 void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mean, double sigma, double* out) {

@@ -182,6 +182,24 @@ ICP_API int icp_evaluator_log_value(icp_evaluator *e, const double *theta, doubl
 /* ModelPriorEvaluator.logValue (evaluators/ModelPriorEvaluator.scala:24-31): O(r) host arithmetic. */
 ICP_API int icp_prior_log_value(int32_t rank, const double *theta, double *out);
 
+/* ---------------------------------------------------------------- deterministic non-rigid ICP
+ * IcpBasedSurfaceFitting.runfitting (api/other/IcpBasedSurfaceFitting.scala:46-126), the paper's comparison baseline: for every
+ * sigma2 of the sequence (:36-40: 1, 0.1, 0.01) the recursion (:55-104) runs numIterations + 1 times: instance, correspondences
+ * in one direction (:71-79), GP regression with ISOTROPIC noise sigma2 (:81), posterior MEAN (:82), its coefficients (:84), step
+ * (:85).  The sample ids / sample points are drawn by Scalismo's UniformMeshSampler3D in the reference (:51-53) and are inputs
+ * here; so is the per-iteration direction draw of ModelAndTargetSampling (:66-69: call once per iteration instead).  All
+ * iterations run on the device without host round trips.  theta_out = theta_init with the fitted shape coefficients. */
+typedef struct {
+  int32_t direction;             /* icp_direction */
+  int32_t n_model_ids;           /* ModelSampling: pointIds (:53), any ids, repeats allowed */
+  const int32_t *model_ids;
+  int32_t n_target_points;       /* TargetSampling: targetPointSamples (:51) */
+  const double *target_points;
+  double step_length;            /* :32 (default 1.0) */
+} icp_fit_params;
+ICP_API int icp_fit_deterministic(icp_ctx *ctx, const icp_fit_params *params, const double *theta_init, int32_t n_iterations,
+                                  int32_t n_sigma, const double *sigma2_seq, double *theta_out);
+
 /* ---------------------------------------------------------------- fused chain step (measurement harness)
  * One call = all device work one Metropolis–Hastings step needs for a NEW state theta_prop proposed from
  * theta_cur, submitted as one stream sequence with a single synchronisation: the likelihood of theta_prop and,

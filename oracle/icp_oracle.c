@@ -651,6 +651,70 @@ ORC_API int orc_log_transition(const orc_model *m, const orc_mesh *tgt, const or
   return rc;
 }
 
+/* ------------------------------------------------------------------ next row 1: deterministic non-rigid ICP
+ * ref: api/other/IcpBasedSurfaceFitting.scala:46-126.  For every sigma2 of the sequence (:36-40: 1, 0.1, 0.01) the
+ * recursion (:55-104) runs for nbIterations = numIterations .. 0, i.e. numIterations + 1 times:
+ *   instance of the current coefficients (:61), correspondences in ONE direction (:71-79; the random alternation of :66-69 is
+ *   the caller's), model.posterior(correspondences, sigma2) with isotropic noise (:81), its MEAN (:82), model.coefficients of
+ *   that mean (:84), step (:85).  Sample ids / target sample points come from Scalismo's UniformMeshSampler3D (:51-53) and are
+ *   therefore inputs.  The regression works on the UNTRANSFORMED model with the world-space points, as the reference does (:81). */
+typedef struct {
+  int direction;            /* 0 = ModelSampling, 1 = TargetSampling */
+  int n_model_ids;
+  const int *model_ids;     /* pointIds (:53) */
+  int n_target_pts;
+  const double *target_pts; /* targetPointSamples (:51) */
+  double step_length;       /* :32 */
+} orc_fit_params;
+
+ORC_API int orc_fit_deterministic(const orc_model *m, const orc_mesh *tgt, const orc_fit_params *fp, const double *theta_init,
+                                  int n_iterations, int n_sigma, const double *sigma2_seq, double *theta_out) {
+  const int r = m->r, N = m->N, N3 = 3 * N;
+  const int K = fp->direction == 1 ? fp->n_target_pts : fp->n_model_ids;
+  double *theta = theta_out;
+  memcpy(theta, theta_init, sizeof(double) * (10 + r));
+  double *x = (double *)malloc(sizeof(double) * N3), *M = (double *)malloc(sizeof(double) * r * r);
+  double *b = (double *)malloc(sizeof(double) * r), *disp = (double *)malloc(sizeof(double) * N3), *cnew = (double *)malloc(sizeof(double) * r);
+  int rc = 0;
+  for (int si = 0; si < n_sigma && rc == 0; ++si) {
+    const double w = 1.0 / sigma2_seq[si];
+    for (int it = 0; it <= n_iterations && rc == 0; ++it) {
+      orc_instance(m, theta, x);                                                  /* :61 */
+      for (int i = 0; i < r; ++i) { b[i] = 0.0; for (int j = 0; j < r; ++j) M[i * r + j] = (i == j); }
+      for (int k = 0; k < K; ++k) {
+        int id; double tp[3];
+        if (fp->direction == 1) {                                                 /* :76-78 */
+          memcpy(tp, fp->target_pts + 3 * k, sizeof(tp));
+          orc_nearest_vertex(1, tp, N, x, &id, NULL);
+        } else {                                                                  /* :72-74 */
+          id = fp->model_ids[k];
+          orc_closest_point_on_surface(1, x + 3 * id, tgt->pts, tgt->T, tgt->tris, tp, NULL, NULL);
+        }
+        const double *Qi = m->Q + (size_t)3 * id * r;
+        double e[3];
+        for (int d = 0; d < 3; ++d) e[d] = (tp[d] - m->ref[3 * id + d]) - m->mean[3 * id + d];
+        for (int i = 0; i < r; ++i) {
+          for (int j = 0; j < r; ++j) M[i * r + j] += w * ((Qi[i] * Qi[j] + Qi[r + i] * Qi[r + j]) + Qi[2 * r + i] * Qi[2 * r + j]);
+          b[i] += w * ((Qi[i] * e[0] + Qi[r + i] * e[1]) + Qi[2 * r + i] * e[2]);
+        }
+      }
+      rc = cholesky(r, M);
+      if (rc) break;
+      chol_solve(r, M, b);                                                        /* alpha = M^-1 b: posterior mean coefficients */
+      for (int i = 0; i < N3; ++i) {                                              /* posterior.mean − model mean (:82,84) */
+        const double *qi = m->Q + (size_t)i * r;
+        double sacc = 0.0;
+        for (int j = 0; j < r; ++j) sacc += qi[j] * b[j];
+        disp[i] = sacc;
+      }
+      rc = lsq_coefficients(N3, r, m->Q, disp, cnew);                             /* :84 */
+      for (int j = 0; j < r; ++j) theta[10 + j] = theta[10 + j] + (cnew[j] - theta[10 + j]) * fp->step_length;  /* :85 */
+    }
+  }
+  free(x); free(M); free(b); free(disp); free(cnew);
+  return rc;
+}
+
 /* ------------------------------------------------------------------ a11-a14: evaluators */
 
 /* Breeze Gaussian(mu, sigma).logPdf / Exponential(rate).logPdf */

@@ -40,6 +40,11 @@ class EvaluatorParams(C.Structure):
                 ("target_pts", c_double_p), ("p0", C.c_double), ("p1", C.c_double), ("p2", C.c_double)]
 
 
+class FitParams(C.Structure):
+    _fields_ = [("direction", C.c_int), ("n_model_ids", C.c_int), ("model_ids", c_int_p), ("n_target_pts", C.c_int),
+                ("target_pts", c_double_p), ("step_length", C.c_double)]
+
+
 class ChainConfig(C.Structure):
     _fields_ = [("n_icp", C.c_int), ("icp", ProposalParams * 2), ("icp_weight", C.c_double * 2),
                 ("w_icp", C.c_double), ("w_rw", C.c_double), ("rw_sigma", C.c_double), ("eval", EvaluatorParams)]
@@ -87,6 +92,7 @@ def lib():
         L.orc_rng_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_rng_normal.restype = C.c_double
         L.orc_rng_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.orc_fit_deterministic.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(FitParams), c_double_p, C.c_int, C.c_int, c_double_p, c_double_p]
         L.orc_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ChainConfig), c_double_p, C.c_uint64, C.c_int,
                                     c_ubyte_p, c_int_p, c_double_p, c_double_p]
         _LIB = L
@@ -309,3 +315,19 @@ def initial_theta(model_ref_points, rank):
     theta[0] = 1.0
     theta[7:10] = ctr
     return theta
+
+
+def fit_deterministic(model, mesh, theta_init, n_iterations, sigma2_seq=(1.0, 0.1, 0.01), direction=MODEL_SAMPLING, model_ids=None,
+                      target_pts=None, step_length=1.0):
+    """IcpBasedSurfaceFitting.runfitting (api/other/IcpBasedSurfaceFitting.scala:46-126); returns the final parameter vector."""
+    ids = np.ascontiguousarray(model_ids if model_ids is not None else np.zeros(0), dtype=np.int32)
+    tp = _f64(target_pts if target_pts is not None else np.zeros((0, 3))).reshape(-1, 3)
+    fp = FitParams(int(direction), ids.shape[0], _i(ids), tp.shape[0], _d(tp), float(step_length))
+    th = _f64(theta_init)
+    sig = _f64(sigma2_seq)
+    out = np.zeros_like(th)
+    rc = lib().orc_fit_deterministic(model.h, mesh.h, C.byref(fp), _d(th), int(n_iterations), sig.shape[0], _d(sig), _d(out))
+    if rc != 0:
+        raise RuntimeError(f"orc_fit_deterministic failed ({rc})")
+    return out
+

@@ -1,0 +1,39 @@
+"""GPU: deterministic non-rigid ICP (api/other/IcpBasedSurfaceFitting.scala:46-126) against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import make_theta
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("direction", ["ModelSampling", "TargetSampling"])
+def test_deterministic_icp_matches_oracle(pkg, oracle, femur50, femur50_oracle, direction):
+    model, target = femur50
+    om, ot = femur50_oracle
+    rng = np.random.default_rng(17)
+    ids = rng.integers(0, model.n_points, 300).astype(np.int32)            # stand-in for UniformMeshSampler3D + nearest vertex (:51-53)
+    tps = target.points[rng.integers(0, target.n_points, 300)] + rng.normal(size=(300, 3)) * 0.01
+    theta0 = pkg.initial_parameters(model)
+    theta0[10:] = 0.3 * rng.normal(size=model.rank)
+    ctx = pkg.IcpContext(model, target, device=0)
+    fit = pkg.IcpBasedSurfaceFitting(ctx, stepLength=1.0, projectionDirection=direction, modelPointIds=ids, targetPointSamples=tps)
+    n_it, seq = 4, (1.0, 0.1, 0.01)
+    got = fit.runfitting(n_it, seq, theta0)
+    want = oracle.fit_deterministic(om, ot, theta0, n_it, seq, direction=0 if direction == "ModelSampling" else 1, model_ids=ids,
+                                    target_pts=tps, step_length=1.0)
+    assert np.array_equal(got[:10], theta0[:10])
+    assert np.abs(got[10:] - want[10:]).max() <= 1e-7 * np.abs(want[10:]).max()
+    # the fit moved the model onto the target: the mean vertex-to-surface distance drops well below the start's
+    def avg_dist(theta):
+        x = ctx.transformedMesh(theta)
+        _, _, d2 = ctx.closestPointOnTarget(x[::8])
+        return np.sqrt(d2).mean()
+    assert avg_dist(got) < 0.25 * avg_dist(theta0)
+    # step length 0.5, zero extra iterations: one recursion per sigma (numIterations + 1 = 1), still equal to the oracle
+    fit2 = pkg.IcpBasedSurfaceFitting(ctx, stepLength=0.5, projectionDirection=direction, modelPointIds=ids, targetPointSamples=tps)
+    g2 = fit2.runfitting(0, (1.0,), theta0)
+    w2 = oracle.fit_deterministic(om, ot, theta0, 0, (1.0,), direction=0 if direction == "ModelSampling" else 1, model_ids=ids,
+                                  target_pts=tps, step_length=0.5)
+    assert np.abs(g2[10:] - w2[10:]).max() <= 1e-8 * np.abs(w2[10:]).max()
+    ctx.close()
