@@ -366,3 +366,13 @@ class IcpBasedSurfaceFitting:
                   "icp_fit_deterministic")
         return out
 
+
+def posterior_variability(ctx: IcpContext, thetas, mode: int = 0, theta_ref=None) -> np.ndarray:
+    """apps/util/PosteriorVariability.scala:30-73 over logged chain states: per-vertex total variance (mode 0), variance along the
+    normals of theta_ref's mesh (1) or along the mean sample normal (2)."""
+    th = _f64(thetas).reshape(-1, 10 + ctx.rank)
+    ref = _theta(theta_ref if theta_ref is not None else th[0])
+    out = np.zeros(ctx.model.n_points)
+    nat.check(nat.lib().icp_posterior_variability(ctx.h, th.shape[0], _d(th), int(mode), _d(ref), _d(out)), "icp_posterior_variability")
+    return out
+

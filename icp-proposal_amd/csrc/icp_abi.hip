@@ -1312,6 +1312,46 @@ int icp_fit_deterministic(icp_ctx* ctx, const icp_fit_params* prm, const double*
   });
 }
 
+// --------------------------------------------------------------------- posterior variability maps (next row 3)
+
+int icp_posterior_variability(icp_ctx* ctx, int32_t n_samples, const double* thetas, int32_t mode, const double* theta_ref, double* out) {
+  return guard([&] {
+    require(ctx && thetas && out, "null argument");
+    require(n_samples >= 2, "at least two samples are needed");
+    require(mode >= 0 && mode <= 2, "unknown mode");
+    require(mode != 1 || theta_ref, "theta_ref is null");
+    icp_ctx& c = *ctx;
+    const size_t P = 10 + (size_t)c.r, n3 = 3 * (size_t)c.N;
+    for (int s = 0; s < n_samples; ++s) check_theta_finite(&c, thetas + s * P);
+    if (mode == 1) check_theta_finite(&c, theta_ref);
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    Bound _b(&c);
+    DBuf<double> X, coeffs, nrm, tmp, res;
+    X.alloc((size_t)n_samples * n3);
+    std::vector<double> hc((size_t)(n_samples + 1) * c.r);
+    for (int s = 0; s < n_samples; ++s) std::memcpy(&hc[(size_t)s * c.r], thetas + s * P + 10, sizeof(double) * c.r);
+    if (mode == 1) std::memcpy(&hc[(size_t)n_samples * c.r], theta_ref + 10, sizeof(double) * c.r);
+    coeffs.upload(hc.data(), hc.size());
+    nrm.alloc(n3); tmp.alloc(n3); res.alloc(c.N);
+    for (int s = 0; s < n_samples; ++s)   // ModelFittingParameters.transformedMesh of every sample (LogHelper.logSamples2shapes)
+      launch_instance(c.stream, c.N, c.r, c.Qp.p, c.ref.p, c.mean.p, pose_from_theta(thetas + s * P), coeffs.p + (size_t)s * c.r,
+                      X.p + (size_t)s * n3);
+    if (mode == 1) {
+      launch_instance(c.stream, c.N, c.r, c.Qp.p, c.ref.p, c.mean.p, pose_from_theta(theta_ref), coeffs.p + (size_t)n_samples * c.r, tmp.p);
+      launch_vertex_normals(c.stream, c.N, tmp.p, c.tris.p, c.adj_off.p, c.adj.p, nrm.p);
+    } else if (mode == 2) {
+      HIP_OK(hipMemsetAsync(nrm.p, 0, sizeof(double) * n3, c.stream));
+      for (int s = 0; s < n_samples; ++s) {
+        launch_vertex_normals(c.stream, c.N, X.p + (size_t)s * n3, c.tris.p, c.adj_off.p, c.adj.p, tmp.p);
+        launch_accumulate(c.stream, (int)n3, tmp.p, s == n_samples - 1 ? 1.0 / n_samples : 0.0, nrm.p);
+      }
+    }
+    launch_variability(c.stream, c.N, n_samples, X.p, mode, nrm.p, res.p);
+    HIP_OK(hipMemcpyAsync(out, res.p, sizeof(double) * c.N, hipMemcpyDeviceToHost, c.stream));
+    c.finish(0, 0);
+  });
+}
+
 // --------------------------------------------------------------------- fused chain step
 
 int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, const double* theta_cur,

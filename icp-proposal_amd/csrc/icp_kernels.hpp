@@ -173,6 +173,10 @@ void launch_correspond_plain(hipStream_t st, int K, const int* ids, const double
 // c <- c + step·((G+σ²I)⁻¹ G α − c) with P = (G+σ²I)⁻¹ (:84-85)
 void launch_mean_step(hipStream_t st, int r, const double* alpha, const double* P, double sigma2, double step, double* c);
 
+// ---- posterior variability (apps/util/PosteriorVariability.scala:30-73): X = [S][N*3] sample meshes
+void launch_accumulate(hipStream_t st, int n, const double* src, double scale_after /* 0 = none */, double* acc);
+void launch_variability(hipStream_t st, int N, int S, const double* X, int mode, const double* normals, double* out);
+
 // ---- evaluator reductions (kernels_posterior.hip)
 // out[0] = Σ log N(sqrt(d2_k); mean, sigma)
 void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mean, double sigma, double* out);

@@ -859,6 +859,49 @@ __global__ void __launch_bounds__(256) k_mean_step(int r, const double* __restri
   }
 }
 
+// ---------------------------------------------------------------- posterior variability maps
+
+__global__ void __launch_bounds__(kBlock) k_accumulate(int n, const double* __restrict__ src, double scale_after, double* __restrict__ acc) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double v = acc[i] + src[i];
+  if (scale_after != 0.0) v *= scale_after;
+  acc[i] = v;
+}
+
+// lane = vertex; the sample loop runs in the reference's order (mean = (Σ s)·(1/n), then the centred second moments)
+__global__ void __launch_bounds__(kBlock) k_variability(int N, int S, const double* __restrict__ X, int mode,
+                                                         const double* __restrict__ normals, double* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const size_t stride = (size_t)3 * N;
+  double m0 = 0.0, m1 = 0.0, m2 = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const double* x = X + (size_t)s * stride + 3 * i;
+    m0 += x[0]; m1 += x[1]; m2 += x[2];
+  }
+  const double inv_n = 1.0 / S, inv_n1 = 1.0 / (S - 1);
+  m0 *= inv_n; m1 *= inv_n; m2 *= inv_n;
+  if (mode == 0) {
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    for (int s = 0; s < S; ++s) {
+      const double* x = X + (size_t)s * stride + 3 * i;
+      const double v0 = x[0] - m0, v1 = x[1] - m1, v2 = x[2] - m2;
+      c0 += v0 * v0; c1 += v1 * v1; c2 += v2 * v2;
+    }
+    out[i] = (c0 * inv_n1 + c1 * inv_n1) + c2 * inv_n1;   // trace(cov) (:43)
+  } else {
+    const double n0 = normals[3 * i], n1 = normals[3 * i + 1], n2 = normals[3 * i + 2];
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) {
+      const double* x = X + (size_t)s * stride + 3 * i;
+      const double p = (n0 * (x[0] - m0) + n1 * (x[1] - m1)) + n2 * (x[2] - m2);
+      acc += p * p;                                        // :69
+    }
+    out[i] = acc * inv_n1;
+  }
+}
+
 // ---------------------------------------------------------------- evaluator reductions
 
 __global__ void __launch_bounds__(kBlock) k_sum_gauss_logpdf(int K, const double* __restrict__ d2, double mean, double sigma,
@@ -1041,6 +1084,13 @@ void launch_correspond_plain(hipStream_t st, int K, const int* ids, const double
 }
 void launch_mean_step(hipStream_t st, int r, const double* alpha, const double* P, double sigma2, double step, double* c) {
   hipLaunchKernelGGL(k_mean_step, dim3(1), dim3(256), 0, st, r, alpha, P, sigma2, step, c, matvec_tpr_log2(r, 256));
+}
+
+void launch_accumulate(hipStream_t st, int n, const double* src, double scale_after, double* acc) {
+  hipLaunchKernelGGL(k_accumulate, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, n, src, scale_after, acc);
+}
+void launch_variability(hipStream_t st, int N, int S, const double* X, int mode, const double* normals, double* out) {
+  hipLaunchKernelGGL(k_variability, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, st, N, S, X, mode, normals, out);
 }
 
 void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mean, double sigma, double* out) {

@@ -200,6 +200,15 @@ typedef struct {
 ICP_API int icp_fit_deterministic(icp_ctx *ctx, const icp_fit_params *params, const double *theta_init, int32_t n_iterations,
                                   int32_t n_sigma, const double *sigma2_seq, double *theta_out);
 
+/* ---------------------------------------------------------------- posterior variability maps
+ * apps/util/PosteriorVariability.scala:30-73 over n_samples logged chain states (thetas [n_samples*(10+r)]):
+ *   mode 0: trace of the per-vertex sample covariance (computeDistanceMapFromMeshesTotal :30-49);
+ *   mode 1: variance along the unit vertex normals of the mesh of theta_ref (computeDistanceMapFromMeshesNormal, sumNormals = false);
+ *   mode 2: variance along the mean (not renormalised) of the samples' unit vertex normals (sumNormals = true, :63-65).
+ * out [N].  n_samples >= 2. */
+ICP_API int icp_posterior_variability(icp_ctx *ctx, int32_t n_samples, const double *thetas, int32_t mode, const double *theta_ref,
+                                      double *out);
+
 /* ---------------------------------------------------------------- fused chain step (measurement harness)
  * One call = all device work one Metropolis–Hastings step needs for a NEW state theta_prop proposed from
  * theta_cur, submitted as one stream sequence with a single synchronisation: the likelihood of theta_prop and,

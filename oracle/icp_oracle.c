@@ -715,6 +715,57 @@ ORC_API int orc_fit_deterministic(const orc_model *m, const orc_mesh *tgt, const
   return rc;
 }
 
+/* ------------------------------------------------------------------ next row 3: posterior variability maps
+ * ref: apps/util/PosteriorVariability.scala:30-73.  meshes = transformedMesh of every logged sample.
+ *   mode 0 (computeDistanceMapFromMeshesTotal :30-49): trace of the per-vertex sample covariance, mean = (Σ s)·(1/n),
+ *          cov = (Σ (s−mean)(s−mean)ᵀ)·(1/(n−1));
+ *   mode 1 (computeDistanceMapFromMeshesNormal, sumNormals = false :51-72): (Σ (n·(s−mean))²)·(1/(n−1)) with n = unit vertex
+ *          normal of the mesh of theta_ref;
+ *   mode 2 (sumNormals = true): n = (Σ unit vertex normals of the samples)·(1/n), NOT renormalised (:63-65). */
+ORC_API int orc_posterior_variability(const orc_model *m, int n_samples, const double *thetas, int mode, const double *theta_ref,
+                                      double *out) {
+  const int N = m->N, P = 10 + m->r, S = n_samples;
+  if (S < 2) return 1;
+  double *X = (double *)malloc(sizeof(double) * (size_t)S * 3 * N), *nrm = (double *)calloc((size_t)3 * N, sizeof(double));
+  for (int s = 0; s < S; ++s) orc_instance(m, thetas + (size_t)s * P, X + (size_t)s * 3 * N);
+  if (mode == 1) {
+    double *xr = (double *)malloc(sizeof(double) * 3 * N);
+    orc_instance(m, theta_ref, xr);
+    orc_vertex_normals(m, xr, nrm);
+    free(xr);
+  } else if (mode == 2) {
+    double *tmp = (double *)malloc(sizeof(double) * 3 * N);
+    for (int s = 0; s < S; ++s) {
+      orc_vertex_normals(m, X + (size_t)s * 3 * N, tmp);
+      for (int i = 0; i < 3 * N; ++i) nrm[i] += tmp[i];
+    }
+    for (int i = 0; i < 3 * N; ++i) nrm[i] *= 1.0 / S;
+    free(tmp);
+  }
+  for (int i = 0; i < N; ++i) {
+    double mean[3] = {0, 0, 0};
+    for (int s = 0; s < S; ++s)
+      for (int d = 0; d < 3; ++d) mean[d] += X[(size_t)s * 3 * N + 3 * i + d];
+    for (int d = 0; d < 3; ++d) mean[d] *= 1.0 / S;
+    if (mode == 0) {
+      double c[3] = {0, 0, 0};
+      for (int s = 0; s < S; ++s)
+        for (int d = 0; d < 3; ++d) { double v = X[(size_t)s * 3 * N + 3 * i + d] - mean[d]; c[d] += v * v; }
+      out[i] = (c[0] * (1.0 / (S - 1)) + c[1] * (1.0 / (S - 1))) + c[2] * (1.0 / (S - 1));
+    } else {
+      double acc = 0.0;
+      for (int s = 0; s < S; ++s) {
+        const double *x = X + (size_t)s * 3 * N + 3 * i;
+        double p = (nrm[3 * i] * (x[0] - mean[0]) + nrm[3 * i + 1] * (x[1] - mean[1])) + nrm[3 * i + 2] * (x[2] - mean[2]);
+        acc += p * p;
+      }
+      out[i] = acc * (1.0 / (S - 1));
+    }
+  }
+  free(X); free(nrm);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ a11-a14: evaluators */
 
 /* Breeze Gaussian(mu, sigma).logPdf / Exponential(rate).logPdf */

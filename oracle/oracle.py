@@ -93,6 +93,7 @@ def lib():
         L.orc_rng_normal.restype = C.c_double
         L.orc_rng_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_fit_deterministic.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(FitParams), c_double_p, C.c_int, C.c_int, c_double_p, c_double_p]
+        L.orc_posterior_variability.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int, c_double_p, c_double_p]
         L.orc_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ChainConfig), c_double_p, C.c_uint64, C.c_int,
                                     c_ubyte_p, c_int_p, c_double_p, c_double_p]
         _LIB = L
@@ -329,5 +330,16 @@ def fit_deterministic(model, mesh, theta_init, n_iterations, sigma2_seq=(1.0, 0.
     rc = lib().orc_fit_deterministic(model.h, mesh.h, C.byref(fp), _d(th), int(n_iterations), sig.shape[0], _d(sig), _d(out))
     if rc != 0:
         raise RuntimeError(f"orc_fit_deterministic failed ({rc})")
+    return out
+
+
+def posterior_variability(model, thetas, mode=0, theta_ref=None):
+    """apps/util/PosteriorVariability.scala:30-73 (mode 0 total, 1 along the normals of theta_ref's mesh, 2 along the mean sample normal)."""
+    th = _f64(thetas)
+    ref = _f64(theta_ref if theta_ref is not None else th[0])
+    out = np.zeros(model.N)
+    rc = lib().orc_posterior_variability(model.h, th.shape[0], _d(th), int(mode), _d(ref), _d(out))
+    if rc != 0:
+        raise RuntimeError("orc_posterior_variability failed")
     return out
 

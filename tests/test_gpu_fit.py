@@ -37,3 +37,17 @@ def test_deterministic_icp_matches_oracle(pkg, oracle, femur50, femur50_oracle, 
                                   target_pts=tps, step_length=0.5)
     assert np.abs(g2[10:] - w2[10:]).max() <= 1e-8 * np.abs(w2[10:]).max()
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_posterior_variability_matches_oracle(pkg, oracle, femur50, femur50_oracle, mode):
+    """SURVEY.md §8f next row 3 (apps/util/PosteriorVariability.scala:30-73) on 25 chain-like samples."""
+    model, target = femur50
+    om, _ = femur50_oracle
+    thetas = np.stack([make_theta(model, 700 + s, shape_scale=0.3) for s in range(25)])
+    ctx = pkg.IcpContext(model, target, device=0)
+    got = pkg.posterior_variability(ctx, thetas, mode=mode, theta_ref=thetas[3])
+    want = oracle.posterior_variability(om, thetas, mode=mode, theta_ref=thetas[3])
+    assert got.shape == (model.n_points,) and np.all(got >= 0)
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    ctx.close()
