@@ -83,6 +83,7 @@ SIGNATURES = {
                                       c_double_p, c_double_p]),
     "icp_fit_deterministic": (C.c_int, [C.c_void_p, C.POINTER(FitParams), c_double_p, C.c_int32, C.c_int32, c_double_p, c_double_p]),
     "icp_posterior_variability": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, C.c_int32, c_double_p, c_double_p]),
+    "icp_mesh_metrics": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "icp_chain_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, c_double_p, c_double_p, c_double_p,
                                  c_double_p, c_double_p, c_double_p]),
 }

@@ -376,3 +376,11 @@ def posterior_variability(ctx: IcpContext, thetas, mode: int = 0, theta_ref=None
     nat.check(nat.lib().icp_posterior_variability(ctx.h, th.shape[0], _d(th), int(mode), _d(ref), _d(out)), "icp_posterior_variability")
     return out
 
+
+def evaluate_reconstruction_to_ground_truth(ctx: IcpContext, theta) -> dict:
+    """api/other/RegistrationComparison.scala:24-49 for the mesh of theta against the context's target."""
+    out = np.zeros(5)
+    nat.check(nat.lib().icp_mesh_metrics(ctx.h, _d(_theta(theta)), _d(out)), "icp_mesh_metrics")
+    return {"average2surface": out[0], "hausdorff": out[1], "average2surface_boundary_aware": out[2], "max_boundary_aware": out[3],
+            "kept": int(out[4])}
+

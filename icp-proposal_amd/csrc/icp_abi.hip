@@ -1352,6 +1352,43 @@ int icp_posterior_variability(icp_ctx* ctx, int32_t n_samples, const double* the
   });
 }
 
+// --------------------------------------------------------------------- registration metrics (next row 4)
+
+int icp_mesh_metrics(icp_ctx* ctx, const double* theta, double* out) {
+  return guard([&] {
+    require(ctx && out, "null argument");
+    icp_ctx& c = *ctx;
+    check_theta_finite(&c, theta);
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    Bound _b(&c);
+    StateSlot& s = c.state(theta);
+    double* res = c.d_res.p;
+    HIP_OK(hipMemsetAsync(res, 0, sizeof(double) * 16, c.stream));
+    // reconstruction -> target: every model vertex against the target surface (shared with the proposals/evaluators of the state)
+    c.ensure_surface_prefix(s, c.N);
+    launch_dist_stats(c.stream, c.N, s.surf_d2.p, nullptr, nullptr, 0, res + 0);                       // avgDistance, one-sided max
+    const bool flags = c.target.n_boundary > 0;
+    if (flags) c.ensure_nnv_prefix(s, c.N);
+    launch_dist_stats(c.stream, c.N, s.surf_d2.p, flags ? c.target.boundary.p : nullptr, flags ? s.surf_nnv.p : nullptr, c.target.V,
+                      res + 4);                                                                        // boundary-aware (:31-42)
+    // target -> reconstruction: every target vertex against the current model surface (hausdorffDistance is symmetric)
+    DBuf<double> d2;
+    DBuf<int> hint;
+    d2.alloc(c.target.V); hint.alloc(c.target.V); hint.fill_bytes(0xFF);
+    c.ensure_model_spheres(s);
+    QueryBuffers qb = c.query_scratch(c.target.V, c.T);
+    launch_surface_query(c.stream, c.T, s.x.p, c.tris.p, s.spheres.p, c.target.V, c.target.verts.p, hint.p, qb, nullptr, d2.p, nullptr);
+    launch_dist_stats(c.stream, c.target.V, d2.p, nullptr, nullptr, 0, res + 8);
+    c.finish(12, 0);
+    const double* h = c.h_res;
+    out[0] = h[0] / h[2];
+    out[1] = std::max(h[1], h[9]);
+    out[2] = h[6] > 0.0 ? h[4] / h[6] : NAN;
+    out[3] = h[6] > 0.0 ? h[5] : NAN;
+    out[4] = h[6];
+  });
+}
+
 // --------------------------------------------------------------------- fused chain step
 
 int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, const double* theta_cur,

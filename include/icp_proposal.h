@@ -209,6 +209,15 @@ ICP_API int icp_fit_deterministic(icp_ctx *ctx, const icp_fit_params *params, co
 ICP_API int icp_posterior_variability(icp_ctx *ctx, int32_t n_samples, const double *thetas, int32_t mode, const double *theta_ref,
                                       double *out);
 
+/* ---------------------------------------------------------------- registration metrics
+ * api/other/RegistrationComparison.scala:24-49 between the mesh of theta (reconstruction) and the target (ground truth):
+ *   out[0] = MeshMetrics.avgDistance(reconstruction, target)       mean vertex-to-surface distance              (:25)
+ *   out[1] = MeshMetrics.hausdorffDistance(reconstruction, target) max over both directions                     (:27)
+ *   out[2], out[3] = boundary-aware average and maximum: reconstruction vertices whose closest target point's nearest target
+ *                    vertex lies on the target's boundary are dropped                                           (:31-42)
+ *   out[4] = number of vertices kept by that filter. */
+ICP_API int icp_mesh_metrics(icp_ctx *ctx, const double *theta, double *out /* [5] */);
+
 /* ---------------------------------------------------------------- fused chain step (measurement harness)
  * One call = all device work one Metropolis–Hastings step needs for a NEW state theta_prop proposed from
  * theta_cur, submitted as one stream sequence with a single synchronisation: the likelihood of theta_prop and,

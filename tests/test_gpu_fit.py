@@ -51,3 +51,27 @@ def test_posterior_variability_matches_oracle(pkg, oracle, femur50, femur50_orac
     assert got.shape == (model.n_points,) and np.all(got >= 0)
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
     ctx.close()
+
+
+def test_registration_metrics_match_oracle(pkg, oracle, femur50):
+    """SURVEY.md §8f next row 4 (api/other/RegistrationComparison.scala:24-49), on a target WITH a boundary."""
+    from conftest import open_patch_target
+    model, target = femur50
+    pts, cells = open_patch_target(target)
+    tgt = pkg.data.TriangleMesh(pts, cells)
+    ctx = pkg.IcpContext(model, tgt, device=0)
+    om = oracle.OracleModel.from_model(model)
+    theta = make_theta(model, 811)
+    got = pkg.evaluate_reconstruction_to_ground_truth(ctx, theta)
+    x = om.instance(theta)
+    cp, _, d2 = oracle.closest_point_on_surface(x, pts, cells)
+    _, _, d2r = oracle.closest_point_on_surface(pts, x, model.cells)
+    nn, _ = oracle.nearest_vertex(cp, pts)
+    keep = pkg.data.boundary_vertex_flags(tgt)[nn] == 0
+    d = np.sqrt(d2)
+    assert abs(got["average2surface"] - d.sum() / len(d)) <= 1e-12 * d.mean()
+    assert got["hausdorff"] == max(d.max(), np.sqrt(d2r).max())
+    assert got["kept"] == keep.sum() and 0 < keep.sum() < len(d)
+    assert abs(got["average2surface_boundary_aware"] - d[keep].sum() / keep.sum()) <= 1e-12 * d.mean()
+    assert got["max_boundary_aware"] == d[keep].max()
+    ctx.close()
