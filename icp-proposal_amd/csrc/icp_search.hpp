@@ -117,23 +117,33 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
   }
 }
 
-// one wave per query.  Returns (all lanes) the winner and its squared distance; lane 0 writes the task's outputs and
-// returns the closest point through *cp_out (valid in lane 0 only).
+// one wave per query.  Returns (all lanes) the winner, its squared distance and its closest point; lane 0 writes the
+// task's outputs.
 __device__ __forceinline__ void surface_resolve(const SurfaceTask& q, int k, double* best_out, int* tri_out, d3* cp_out) {
   const int n = q.cnt[k];
   const d3 p = ld3(q.P + 3 * k);
   const int* list = q.cand + (size_t)k * q.stride;
   double best = __builtin_inf();
   int bi = kNoIndex;
+  d3 bc = {__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};  // closest point of this lane's best candidate
   for (int i = lane_id(); i < n; i += 64) {
     const int t = list[i];
-    const double d2 = tri_dist2(p, q.verts, q.tris, t, nullptr);
-    if (d2 < best || (d2 == best && t < bi)) { best = d2; bi = t; }  // NaN (degenerate triangle) never wins
+    d3 c;
+    const double d2 = tri_dist2(p, q.verts, q.tris, t, &c);
+    if (d2 < best || (d2 == best && t < bi)) { best = d2; bi = t; bc = c; }  // NaN (degenerate triangle) never wins
   }
+  const double my_best = best;
+  const int my_bi = bi;
   wave_lexmin(best, bi);
+  // the winner's closest point sits in the lane that evaluated it (same triangle, same point: the same value a
+  // re-evaluation would give) — fetch it from there instead of walking triangle -> vertices -> Ericson again
   d3 c = {__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
+  if (bi != kNoIndex) {
+    const unsigned long long owners = __ballot(my_bi == bi && my_best == best);
+    const int src = __ffsll((long long)owners) - 1;
+    c.x = __shfl(bc.x, src, 64); c.y = __shfl(bc.y, src, 64); c.z = __shfl(bc.z, src, 64);
+  }
   if (lane_id() == 0) {
-    if (bi != kNoIndex) tri_dist2(p, q.verts, q.tris, bi, &c);
     if (q.cp) { q.cp[3 * k] = c.x; q.cp[3 * k + 1] = c.y; q.cp[3 * k + 2] = c.z; }
     if (q.d2) q.d2[k] = best;
     if (q.tri) q.tri[k] = bi == kNoIndex ? -1 : bi;
