@@ -417,7 +417,7 @@ __device__ __forceinline__ int rr_src(int pos, int m) {  // inverse of rr_dst
   return k == m - 1 ? 2 * (m - 1) : 2 * (k + 1) + 1;
 }
 
-struct Rot { double c, s, t; };
+struct Rot { double c, s; };
 
 // Rotation (nearly) annihilating apq, branch free; the dependent chain is two reciprocal square roots and no division:
 //   a = aqq − app, b = 2·apq (the angle depends on their ratio only), h ≈ sqrt(a² + b²), u = h + |a|:
@@ -427,15 +427,18 @@ struct Rot { double c, s, t; };
 // never an assumed zero.
 __device__ __forceinline__ Rot jacobi_rotation(double app, double apq, double aqq) {
   const double a = aqq - app, b = apq + apq, b2 = b * b;
-  const bool rot = fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq);
+  const bool rot = apq * apq > 1e-36 * fabs(app * aqq);  // false for zero / underflowing entries and for the dummy index
   const double h2 = fma(a, a, b2);
   const double h = h2 * __builtin_amdgcn_rsq(h2);
   const double u = h + fabs(a);
-  const double y = fast_rsqrt(fma(u, u, b2));
+  const double w = fma(u, u, b2);
+  // 1/sqrt(w): seed (5e-8) and one third-order step, y·(1 + e + 1.5e²) with e = ½ − ½w·y²: error ~e³
+  const double y0 = __builtin_amdgcn_rsq(w);
+  const double e = fma(-(0.5 * w) * y0, y0, 0.5);
+  const double y = fma(y0, e * fma(1.5, e, 1.0), y0);
   Rot R;
   R.c = rot ? u * y : 1.0;            // not rotating (negligible or zero entry, dummy index): NaN/inf above are discarded
   R.s = rot ? (a >= 0.0 ? b : -b) * y : 0.0;
-  R.t = 0.0;
   return R;
 }
 
@@ -447,18 +450,6 @@ __device__ __forceinline__ B22 rot_block(B22 b, double c1, double s1, double c2,
   const double t10 = fma(s1, b.a00, c1 * b.a10), t11 = fma(s1, b.a01, c1 * b.a11);
   return B22{fma(c2, t00, -(s2 * t01)), fma(s2, t00, c2 * t01), fma(c2, t10, -(s2 * t11)), fma(s2, t10, c2 * t11)};
 }
-__device__ __forceinline__ double diag_new(int side, double t, double d00, double d01, double d11) {
-  return side == 0 ? fma(-t, d01, d00) : fma(t, d01, d11);
-}
-
-// entry [ra][ca] of rot_block(b, c1, s1, c2, s2), by the same operations (−(s·x) == (−s)·x exactly)
-__device__ __forceinline__ double rot_block_entry(B22 b, double c1, double s1, double c2, double s2, int ra, int ca) {
-  const double p1 = ra == 0 ? c1 : s1, q1 = ra == 0 ? -s1 : c1;
-  const double p2 = ca == 0 ? c2 : s2, q2 = ca == 0 ? -s2 : c2;
-  const double t0 = fma(p1, b.a00, q1 * b.a10), t1 = fma(p1, b.a01, q1 * b.a11);
-  return fma(p2, t0, q2 * t1);
-}
-
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ dbl2 lds2(const double* p) { return *(const dbl2*)p; }
 
@@ -473,18 +464,26 @@ __device__ __forceinline__ dbl2 lds2(const double* p) { return *(const dbl2*)p; 
 // of LDS time per round on one CU in every layout tried, against a ~1000-cycle round).  The rotations are logged instead,
 // and k_eigen_vreplay applies them to V afterwards on many CUs at once (rows of V are independent).
 
+constexpr int kRrLd = 66;                 // row stride of A (doubles): rows 16 B apart modulo the 256-B bank window
+constexpr int kRrSzA = 64 * kRrLd;        // one buffer of A, sized for rank 64 whatever r is: every offset below is a constant
+constexpr int kRrSzC = 4 * 32;            // one rotation table
+constexpr int kRrOC = 0, kRrOA = 2 * kRrSzC, kRrOV = kRrOA + 2 * kRrSzA;  // table[2] | A[2] | Vt (warm start) | T (its transform)
+constexpr int kRrLogWave = 14;            // never a block wave (at most 9 of those, on waves 0-2, 4-6, 8-10)
+template <int N> struct IntC { static constexpr int value = N; };
+
 __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
                                                               const double* __restrict__ Vwarm, double* __restrict__ Vout,
                                                               double* __restrict__ Vtout, double* __restrict__ Sout,
-                                                              int* __restrict__ status, int ld, int ldk, double* __restrict__ rotlog,
+                                                              int* __restrict__ status, int ldk, double* __restrict__ rotlog,
                                                               int* __restrict__ meta, int max_sweeps) {
   __shared__ double s_red[16], s_mu[64];
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int n2 = (r + 1) & ~1, m = n2 >> 1;
   // buffers are addressed as s_dyn[offset] with integer offsets: a table of pointers would turn every access into a
-  // FLAT instruction (address space lost), several times slower than the DS path
-  const int szA = n2 * ld, szV = n2 * ldk, szC = 4 * m;
-  const int oA = 0, oV = 2 * szA, oT = oV + szV, oC = oT + szV;  // A[2] | Vt (warm start) | T (its transform) | table[2]
+  // FLAT instruction (address space lost), several times slower than the DS path.  The offsets of the round loop are
+  // compile-time constants plus one per-thread register, so they fold into the DS instructions' immediate fields.
+  constexpr int ld = kRrLd, szA = kRrSzA, szC = kRrSzC, oA = kRrOA, oV = kRrOV, oC = kRrOC;
+  const int szV = n2 * ldk, oT = oV + szV;
 #define LDS_A(b, i) s_dyn[oA + (b) * szA + (i)]
 #define LDS_VT(i) s_dyn[oV + (i)]
 #define LDS_T(i) s_dyn[oT + (i)]
@@ -544,11 +543,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
   const int nA = m * (m + 1) / 2, nbw = (nA + 63) >> 6;
   const int widx = (wave & 3) == 3 ? -1 : wave - (wave >> 2);  // index among the waves of SIMDs 0-2 (12 of them)
   const int bidx = (widx >= 0 && widx < nbw) ? widx * 64 + lane : nA;
-#ifdef ICP_EIGEN_TIMING
-  const bool is_blk = bidx < nA && max_sweeps != 39;  // 39: rotation wave alone (timing experiment, wrong results)
-#else
   const bool is_blk = bidx < nA;
-#endif
   int bI = 0, bJ = 0, b_rd = 0, w00 = 0, w01 = 0, w10 = 0, w11 = 0;
   if (is_blk) {  // unrank the upper triangle row-major
     int base = 0;
@@ -572,80 +567,56 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     // rotations of the first round, straight from the diagonal blocks
     const int o = 2 * rp_k * ld + 2 * rp_k;
     const Rot R = jacobi_rotation(LDS_A(0, o), LDS_A(0, o + 1), LDS_A(0, o + ld + 1));
-    const bool live = is_rot && fabs(R.s) >= 2e-17;
-    const unsigned long long any = __ballot(live);
-    if (is_rot) {
-      LDS_C(0, 4 * rp_k) = R.c; LDS_C(0, 4 * rp_k + 1) = -R.s; LDS_C(0, 4 * rp_k + 2) = R.s; LDS_C(0, 4 * rp_k + 3) = R.c;
-      *(dbl2*)(rotlog + 2 * rp_k) = live ? dbl2{R.c, -R.s} : dbl2{1.0, 0.0};
-    }
-    (void)any;
+    if (is_rot) { LDS_C(0, 4 * rp_k) = R.c; LDS_C(0, 4 * rp_k + 1) = -R.s; LDS_C(0, 4 * rp_k + 2) = R.s; LDS_C(0, 4 * rp_k + 3) = R.c; }
   }
+  const bool is_log = wave == kRrLogWave && lane < m;
   const size_t lstride = (size_t)2 * m;  // doubles per logged round: (c, −s) of every pair
   __syncthreads();
   EIG_STAMP(3);
 
-  int cur = 0, converged = 0, n_sweeps = 0, n_rounds = 0;
-  for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
-    for (int rnd = 0; rnd < n2 - 1; ++rnd) {
-      const int ac = oA + cur * szA, an = oA + (cur ^ 1) * szA, cc = oC + cur * szC, cn = oC + (cur ^ 1) * szC;
-#ifdef ICP_EIGEN_TIMING
-      const bool stamp_round = sweep == 1 && rnd == 5;
-      long long tq0 = 0, tq1 = 0;
-      if (stamp_round) tq0 = __builtin_amdgcn_s_memtime();
-#endif
-      if (is_blk) {
-        const dbl2 r0 = lds2(&s_dyn[ac + b_rd]), r1 = lds2(&s_dyn[ac + b_rd + ld]);
-        const dbl2 c1 = lds2(&s_dyn[cc + 4 * bI]), c2 = lds2(&s_dyn[cc + 4 * bJ]);  // (c, −s)
-        const bool dg = bI == bJ;  // diagonal block: its lower entry is not stored
-        const B22 n = rot_block(B22{r0.x, r0.y, dg ? r0.y : r1.x, r1.y}, c1.x, -c1.y, c2.x, -c2.y);
-        // (diagonal block: w01 and w10 are the same address and a01, a10 agree to rounding — either store serves)
-        s_dyn[an + w00] = n.a00; s_dyn[an + w01] = n.a01; s_dyn[an + w10] = n.a10; s_dyn[an + w11] = n.a11;
-      } else if (wave == 3) {
-        // the next round pairs the contents of old positions p (pair ip, side ap) and q (pair iq, side aq); their three
-        // entries after this round's rotations, by the block threads' own expressions
-        const dbl2 dp0 = lds2(&s_dyn[ac + rp_dp]), dp1 = lds2(&s_dyn[ac + rp_dp + ld]);
-        const dbl2 dq0 = lds2(&s_dyn[ac + rp_dq]), dq1 = lds2(&s_dyn[ac + rp_dq + ld]);
-        const dbl2 b0 = lds2(&s_dyn[ac + rp_ob]), b1 = lds2(&s_dyn[ac + rp_ob + ld]);
-        const dbl2 kp = lds2(&s_dyn[cc + rp_cp]), kq = lds2(&s_dyn[cc + rp_cq]);  // rotation column (p, q) of each factor
-        const dbl2 kl = lds2(&s_dyn[cc + rp_cl]), kh = lds2(&s_dyn[cc + rp_ch]);
-#ifdef ICP_EIGEN_TIMING
-        long long tr1 = 0, tr2 = 0, tr3 = 0;
-        if (stamp_round) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr1 = __builtin_amdgcn_s_memtime(); }
-#endif
-        // entry = Σ (rotation entry products)·(block entries), as two independent multiply-add pairs and one add; it
-        // only steers the next angle, so it need not match the block threads' rounding
-        const double app = fma(kp.x * kp.x, dp0.x, (kp.x * kp.y) * dp0.y) + fma(kp.y * kp.x, dp0.y, (kp.y * kp.y) * dp1.y);
-        const double aqq = fma(kq.x * kq.x, dq0.x, (kq.x * kq.y) * dq0.y) + fma(kq.y * kq.x, dq0.y, (kq.y * kq.y) * dq1.y);
-        const double apq = fma(kh.x * kl.x, b0.x, (kh.x * kl.y) * b1.x) + fma(kh.y * kl.x, b0.y, (kh.y * kl.y) * b1.y);
-#ifdef ICP_EIGEN_TIMING
-        if (stamp_round) { asm volatile("v_mov_b32 %0, %0" : "+v"(*(int*)&apq)); tr2 = __builtin_amdgcn_s_memtime(); }
-#endif
-        const Rot R = jacobi_rotation(app, apq, aqq);
-#ifdef ICP_EIGEN_TIMING
-        if (stamp_round) { double tmp = R.c + R.s; asm volatile("v_mov_b32 %0, %0" : "+v"(*(int*)&tmp)); tr3 = __builtin_amdgcn_s_memtime();
-          if (lane == 0) { g_eigen_stamps[50] = tr1 - tq0; g_eigen_stamps[51] = tr2 - tr1; g_eigen_stamps[52] = tr3 - tr2; g_eigen_stamps[53] = tr3; } }
-#endif
-        const bool live = is_rot && fabs(R.s) >= 2e-17;
-        const unsigned long long any = __ballot(live);
-        if (is_rot) {
-          *(dbl2*)&s_dyn[cn + 4 * rp_k] = dbl2{R.c, -R.s};
-          *(dbl2*)&s_dyn[cn + 4 * rp_k + 2] = dbl2{R.s, R.c};
-          double* lg = rotlog + (size_t)(n_rounds + 1) * lstride;
-          *(dbl2*)(lg + 2 * rp_k) = live ? dbl2{R.c, -R.s} : dbl2{1.0, 0.0};
-          (void)any;
-        }
+  // One round: reads buffers `cur`, writes buffers `cur ^ 1`.  `cur` is a template constant (the loop below alternates
+  // the two instantiations), so no address is computed inside the loop at all.
+  int n_rounds = 0;
+  auto round = [&](auto CUR) {
+    constexpr int cur = decltype(CUR)::value;
+    constexpr int ac = oA + cur * szA, an = oA + (cur ^ 1) * szA, cc = oC + cur * szC, cn = oC + (cur ^ 1) * szC;
+    if (is_blk) {
+      const dbl2 r0 = lds2(&s_dyn[ac + b_rd]), r1 = lds2(&s_dyn[ac + b_rd + ld]);
+      const dbl2 c1 = lds2(&s_dyn[cc + 4 * bI]), c2 = lds2(&s_dyn[cc + 4 * bJ]);  // (c, −s)
+      const bool dg = bI == bJ;  // diagonal block: its lower entry is not stored
+      const B22 n = rot_block(B22{r0.x, r0.y, dg ? r0.y : r1.x, r1.y}, c1.x, -c1.y, c2.x, -c2.y);
+      // (diagonal block: w01 and w10 are the same address and a01, a10 agree to rounding — either store serves)
+      s_dyn[an + w00] = n.a00; s_dyn[an + w01] = n.a01; s_dyn[an + w10] = n.a10; s_dyn[an + w11] = n.a11;
+    } else if (wave == 3) {
+      // the next round pairs the contents of old positions p (pair ip, side ap) and q (pair iq, side aq); their three
+      // entries after this round's rotations, by the block threads' own expressions
+      const dbl2 dp0 = lds2(&s_dyn[ac + rp_dp]), dp1 = lds2(&s_dyn[ac + rp_dp + ld]);
+      const dbl2 dq0 = lds2(&s_dyn[ac + rp_dq]), dq1 = lds2(&s_dyn[ac + rp_dq + ld]);
+      const dbl2 b0 = lds2(&s_dyn[ac + rp_ob]), b1 = lds2(&s_dyn[ac + rp_ob + ld]);
+      const dbl2 kp = lds2(&s_dyn[cc + rp_cp]), kq = lds2(&s_dyn[cc + rp_cq]);  // rotation column (p, q) of each factor
+      const dbl2 kl = lds2(&s_dyn[cc + rp_cl]), kh = lds2(&s_dyn[cc + rp_ch]);
+      __builtin_amdgcn_sched_barrier(0);  // all ten reads in flight together: ONE trip of LDS latency on the chain
+      // entry = Σ (rotation entry products)·(block entries), as two independent multiply-add pairs and one add; it
+      // only steers the next angle, so it need not match the block threads' rounding
+      const double app = fma(kp.x * kp.x, dp0.x, (kp.x * kp.y) * dp0.y) + fma(kp.y * kp.x, dp0.y, (kp.y * kp.y) * dp1.y);
+      const double aqq = fma(kq.x * kq.x, dq0.x, (kq.x * kq.y) * dq0.y) + fma(kq.y * kq.x, dq0.y, (kq.y * kq.y) * dq1.y);
+      const double apq = fma(kh.x * kl.x, b0.x, (kh.x * kl.y) * b1.x) + fma(kh.y * kl.x, b0.y, (kh.y * kl.y) * b1.y);
+      const Rot R = jacobi_rotation(app, apq, aqq);
+      if (is_rot) {
+        *(dbl2*)&s_dyn[cn + 4 * rp_k] = dbl2{R.c, -R.s};
+        *(dbl2*)&s_dyn[cn + 4 * rp_k + 2] = dbl2{R.s, R.c};
       }
-#ifdef ICP_EIGEN_TIMING
-      if (stamp_round) { tq1 = __builtin_amdgcn_s_memtime(); if (wave == 3 && lane == 0) g_eigen_stamps[54] = tq1 - g_eigen_stamps[53]; }
-#endif
-      __syncthreads();
-#ifdef ICP_EIGEN_TIMING
-      if (stamp_round && lane == 0) g_eigen_stamps[32 + wave] = ((tq1 - tq0) << 32) | (__builtin_amdgcn_s_memtime() - tq1);
-#endif
-      cur ^= 1;
-      ++n_rounds;
+    } else if (is_log) {  // the rotations this round applies, for the replay kernel (negligible ones as identities)
+      const dbl2 k = lds2(&s_dyn[cc + 4 * lane]);
+      *(dbl2*)(rotlog + (size_t)n_rounds * lstride + 2 * lane) = fabs(k.y) >= 2e-17 ? k : dbl2{1.0, 0.0};
     }
-    EIG_STAMP(4 + 2 * sweep);
+    __syncthreads();
+    ++n_rounds;
+  };
+  int converged = 0, n_sweeps = 0, in_sweep = 0;
+  auto sweep_end = [&](int cur) {  // -> stop?
+    EIG_STAMP(4 + 2 * n_sweeps);
+    in_sweep = 0;
     double off = 0.0, dg = 0.0;
     for (int e = tid; e < n2 * n2; e += nt) {
       const int i = e / n2, j = e - i * n2;
@@ -656,9 +627,18 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     off = block_sum(off, s_red);
     dg = block_sum(dg, s_red);
     converged = off <= 1e-26 * dg;
-    n_sweeps = sweep + 1;
-    EIG_STAMP(5 + 2 * sweep);
-  }
+    ++n_sweeps;
+    EIG_STAMP(3 + 2 * n_sweeps);
+    return converged || n_sweeps >= max_sweeps;
+  };
+  int cur = 0;
+  if (max_sweeps > 0)
+    for (;;) {
+      round(IntC<0>{}); cur = 1;
+      if (++in_sweep == n2 - 1 && sweep_end(cur)) break;
+      round(IntC<1>{}); cur = 0;
+      if (++in_sweep == n2 - 1 && sweep_end(cur)) break;
+    }
   if (tid == 0) { status[0] = converged ? 0 : 2; status[-1] = n_sweeps; }
   EIG_STAMP(62);
   // ---- eigenvalues of D M⁻¹ D are 1/μ; S descending = μ ascending; the dummy sorts last and is dropped.  The replay
@@ -1038,10 +1018,10 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
                             double* Vt, double* S, double* work, int* status) {
   static const bool force_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
   if (r >= 3 && r <= 64 && !force_generic) {  // fixed-position variant: A, V and the rotation table double-buffered in LDS
-    const int n2 = (r + 1) & ~1, m = n2 >> 1;
-    const int ld = n2 + 2, ldk = 66;  // ldk: 64 coordinates per position row, rows 16 B apart modulo the 256-B bank window
+    const int n2 = (r + 1) & ~1;
+    const int ldk = 66;  // ldk: 64 coordinates per position row, rows 16 B apart modulo the 256-B bank window
     const size_t szV = (size_t)n2 * ldk;
-    const size_t shmem = sizeof(double) * (2 * (size_t)n2 * ld + 2 * szV + 8 * (size_t)m);
+    const size_t shmem = sizeof(double) * ((size_t)kRrOV + 2 * szV);
     // work = [rotation log | position-major V | meta: n_rounds, done counter, rank per position]
     const size_t log_doubles = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;
     double* rotlog = work;
@@ -1050,7 +1030,7 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
     static const int sweeps_cap = std::getenv("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(std::getenv("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
     set_dyn_lds((const void*)k_posterior_eigen_rr, shmem);
     ProfScope _ps(st, KID_EIGEN);
-    hipLaunchKernelGGL(k_posterior_eigen_rr, dim3(1), dim3(1024), shmem, st, r, M, sqrt_lambda, Vwarm, V, Vt, S, status, ld, ldk, rotlog,
+    hipLaunchKernelGGL(k_posterior_eigen_rr, dim3(1), dim3(1024), shmem, st, r, M, sqrt_lambda, Vwarm, V, Vt, S, status, ldk, rotlog,
                        meta, std::min(sweeps_cap, kEigenMaxSweeps));
     hipLaunchKernelGGL(k_eigen_vreplay, dim3((r + kReplayCoords - 1) / kReplayCoords), dim3(64), 0, st, r, Vwarm, rotlog, meta, vpos, V, Vt);
     return;
