@@ -231,7 +231,8 @@ struct icp_ctx {
   DBuf<double> d_res;
   int* h_status = nullptr;
   DBuf<int> d_status;
-  DBuf<int> d_done;            // completion counter of the step's last launch
+  DBuf<int> d_done;            // [0] completion counter of the step's last launch; [1] counter and [2] "partials ready" word
+                               // of its regression launch
   int* h_flag = nullptr;       // pinned: sequence number of the last finished step
   int step_seq = 0;
 
@@ -376,6 +377,29 @@ void icp_ctx::ensure_nnv_prefix(StateSlot& s, int K) {
 
 namespace {
 
+// developer aid (ICP_HOST_TIMING=1): where the host side of icp_chain_step spends its time, printed at context destruction
+struct HostTiming {
+  bool on = std::getenv("ICP_HOST_TIMING") != nullptr;
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long n = 0, n_first = 0;
+  std::chrono::steady_clock::time_point last, exit_t;
+  bool have_exit = false;
+  void start() { if (on) { last = std::chrono::steady_clock::now(); if (have_exit) acc[7] += us(exit_t, last); } }
+  void mark(int k) { if (on) { auto t = std::chrono::steady_clock::now(); acc[k] += us(last, t); last = t; } }
+  void mark_wait(bool first_use) { if (on) { auto t = std::chrono::steady_clock::now(); acc[3] += us(last, t); if (first_use) { acc[5] += us(last, t); ++n_first; } last = t; } }
+  void end() { if (on) { exit_t = last; have_exit = true; ++n; } }
+  static double us(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::micro>(b - a).count();
+  }
+  void report() {
+    if (!on || !n) return;
+    std::fprintf(stderr, "[icp host timing] steps %ld | us/step: prepare %.1f  launch K1-K5 %.1f  speculation %.1f  wait %.1f  bookkeeping %.1f  caller %.1f | steps drawing from a new basis %ld: wait %.1f, others: wait %.1f\n",
+                 n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[7] / n, n_first, n_first ? acc[5] / n_first : 0.0,
+                 n > n_first ? (acc[3] - acc[5]) / (n - n_first) : 0.0);
+  }
+};
+HostTiming g_host_timing;
+
 struct PosteriorEntry {
   std::vector<double> theta;
   bool valid = false, eig_valid = false, eig_checked = false;  // eig_checked: its status has reached the host copy
@@ -400,7 +424,12 @@ struct icp_proposal {
   DBuf<int> hint_nn;      // TargetSampling: last nearest model vertex of each target point
   DBuf<int> nn_id;
   DBuf<double> work;      // r*r scratch of the eigen / direct-tail kernels
-  DBuf<double> Mpart;     // split-K partial normal matrices of the regression kernel
+  DBuf<double> Mpart;     // split-K partial normal matrices of the regression kernel, two halves: the merged step alternates
+                          // between them so that a speculative decomposition can still read the previous step's
+  size_t mpart_half_doubles = 0;
+  int mpart_half = 0;
+  hipEvent_t mpart_reader[2] = {nullptr, nullptr};  // completion of the last decomposition that reads the half (not owned)
+  double* mpart_for_write(int half);                // the context stream waits for that reader first
   DBuf<double> fscratch;  // (r+1)·r factorisation scratch (ranks too large for LDS)
   const double* warm_ptr = nullptr;  // eigenvectors of the most recent posterior (inside its memo entry): warm start of the next
   bool warm_valid = false;
@@ -409,6 +438,15 @@ struct icp_proposal {
   // ICP direction of a freshly accepted state — then overlaps the chain's next steps instead of delaying a later one.
   hipStream_t eig_stream = nullptr;
   hipEvent_t ev_ready = nullptr;   // context stream -> eigen stream: "M is complete"
+  // Speculative decomposition (icp_chain_step): the KL basis of the PROPOSED state's posterior is started as soon as its
+  // normal matrix exists, before the caller has decided whether to accept.  The next call tells: its current state is
+  // the proposed one (the basis is already on its way) or not (the decomposition is cancelled through `h_cancel`).
+  int* h_eig = nullptr;            // pinned: eigen status of every memo entry, written by the decomposition itself
+  int* h_cancel = nullptr;         // pinned, 16 slots: the decomposition with sequence number q gives up once slot q%16 holds q
+  int spec_seq = 0;
+  PosteriorEntry* spec_entry = nullptr;
+  void speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, const int* ready, int ready_seq);
+  void resolve_speculation(const double* theta_cur);
   DBuf<int> status;       // 3 ints per memo entry: {chol(M), chol(G+σ²M), eigen}
   std::vector<int> h_status;
   std::unique_ptr<PosteriorEntry[]> memo;
@@ -546,10 +584,19 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
   const double wt = 1.0 / (prm.tangential_noise * prm.tangential_noise);
   const double kappa = 1.0 / (prm.noise_along_normal * prm.noise_along_normal) - wt;
   int splits = 1;
-  launch_regression(c.stream, K, r, c.Q.p, e.corr(), wt, kappa, Mpart.p, &splits);
-  PosteriorFactorIO io{Mpart.p, splits, e.M.p, e.alpha.p, status.p + e.status_off, fscratch.p};
+  double* parts = mpart_for_write(0);
+  launch_regression(c.stream, K, r, c.Q.p, e.corr(), wt, kappa, parts, &splits);
+  PosteriorFactorIO io{parts, splits, e.M.p, e.alpha.p, status.p + e.status_off, fscratch.p};
   launch_posterior_factor(c.stream, r, 1, &io);
   return e;
+}
+
+double* icp_proposal::mpart_for_write(int half) {
+  if (mpart_reader[half]) {
+    HIP_OK(hipStreamWaitEvent(ctx->stream, mpart_reader[half], 0));
+    mpart_reader[half] = nullptr;
+  }
+  return Mpart.p + (size_t)half * mpart_half_doubles;
 }
 
 void icp_proposal::ensure_eigen(PosteriorEntry& e) {
@@ -559,8 +606,9 @@ void icp_proposal::ensure_eigen(PosteriorEntry& e) {
   HIP_OK(hipEventRecord(ev_ready, c.stream));  // M of this entry may still be in flight on the context stream
   HIP_OK(hipStreamWaitEvent(eig_stream, ev_ready, 0));
   // the kernel reads all of Vwarm before it writes V, so the two may be the same buffer (a reused memo entry)
+  h_eig[e.status_off / 3] = 0;
   launch_posterior_eigen(eig_stream, c.r, e.M.p, c.sqrt_lambda.p, warm_valid ? warm_ptr : nullptr, e.V.p, e.Vt.p, e.S.p, work.p,
-                         status.p + e.status_off + 2);
+                         status.p + e.status_off + 2, nullptr, h_eig + e.status_off / 3);
   HIP_OK(hipEventRecord(e.eig_done, eig_stream));
   warm_ptr = e.V.p;
   warm_valid = true;
@@ -569,6 +617,42 @@ void icp_proposal::ensure_eigen(PosteriorEntry& e) {
 
 void icp_proposal::await_eigen(PosteriorEntry& e) {
   if (e.eig_done) HIP_OK(hipStreamWaitEvent(ctx->stream, e.eig_done, 0));
+}
+
+// ready / ready_seq: the word the regression launch that fills the current half of Mpart raises when it is done — the
+// decomposition waits for it on the device (an event between that launch and the next one on the context stream would
+// hold the latter back by several µs)
+void icp_proposal::speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, const int* ready, int ready_seq) {
+  icp_ctx& c = *ctx;
+  if (!e.eig_done) HIP_OK(hipEventCreateWithFlags(&e.eig_done, hipEventDisableTiming));
+  ++spec_seq;
+  const EigenSpec spec{splits, h_cancel + (spec_seq & 15), spec_seq, ready, ready_seq};
+  // warm start: the basis of the current state's posterior (complete, or ahead of this launch on the same stream)
+  const double* warm = cur.eig_valid ? cur.V.p : (warm_valid ? warm_ptr : nullptr);
+  h_eig[e.status_off / 3] = 0;
+  launch_posterior_eigen(eig_stream, c.r, Mpart.p + (size_t)mpart_half * mpart_half_doubles, c.sqrt_lambda.p, warm, e.V.p, e.Vt.p,
+                         e.S.p, work.p, status.p + e.status_off + 2, &spec, h_eig + e.status_off / 3);
+  HIP_OK(hipEventRecord(e.eig_done, eig_stream));
+  mpart_reader[mpart_half] = e.eig_done;
+  e.eig_valid = true;
+  e.eig_checked = false;
+  spec_entry = &e;
+}
+
+// the caller's next current state decides the fate of the decomposition started for the last proposed state
+void icp_proposal::resolve_speculation(const double* theta_cur) {
+  if (!spec_entry) return;
+  PosteriorEntry& e = *spec_entry;
+  spec_entry = nullptr;
+  const size_t P = 10 + (size_t)ctx->r;
+  if (e.valid && e.eig_valid && std::memcmp(e.theta.data(), theta_cur, sizeof(double) * P) == 0) {
+    warm_ptr = e.V.p;  // accepted: this is the basis the next decompositions start from
+    warm_valid = true;
+    return;
+  }
+  __atomic_store_n(h_cancel + (spec_seq & 15), spec_seq, __ATOMIC_RELEASE);  // rejected (or the entry was recycled meanwhile)
+  e.eig_valid = false;
+  e.eig_checked = false;
 }
 
 // must be called after a synchronising copy of `status` into h_status
@@ -853,6 +937,7 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
+  g_host_timing.report();
   for (auto& r : ctx->prof.pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
@@ -1036,8 +1121,13 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     HIP_OK(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
     p->work.alloc(eigen_work_doubles(ctx->r));
     p->work.fill_bytes(0);  // holds the completion counter of the eigenvector replay kernel
-    p->Mpart.alloc((size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1));
+    p->mpart_half_doubles = (size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1);
+    p->Mpart.alloc(2 * p->mpart_half_doubles);
     p->fscratch.alloc((size_t)(ctx->r + 1) * ctx->r);
+    HIP_OK(hipHostMalloc((void**)&p->h_cancel, sizeof(int) * 16, hipHostMallocDefault));
+    for (int i = 0; i < 16; ++i) p->h_cancel[i] = 0;
+    HIP_OK(hipHostMalloc((void**)&p->h_eig, sizeof(int) * kPosteriorMemo, hipHostMallocDefault));
+    for (int i = 0; i < kPosteriorMemo; ++i) p->h_eig[i] = 0;
     p->status.alloc(3 * kPosteriorMemo);
     p->status.fill_bytes(0);
     p->h_status.assign(3 * kPosteriorMemo, 0);
@@ -1056,6 +1146,8 @@ void icp_proposal_destroy(icp_proposal* p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->eig_stream) { (void)hipStreamSynchronize(p->eig_stream); (void)hipStreamDestroy(p->eig_stream); }
     if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
+    if (p->h_cancel) (void)hipHostFree(p->h_cancel);
+    if (p->h_eig) (void)hipHostFree(p->h_eig);
     delete p;
   }
 }
@@ -1503,7 +1595,7 @@ bool step_pipeline_covers(icp_evaluator* e, int n_props, icp_proposal* const* pr
 int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, int32_t generator, const double* theta_cur,
                    const double* z, double* theta_prop, double* log_value_prop, double* fwd, double* bwd) {
   int status = ICP_OK;
-  bool per_stage = false;
+  bool per_stage = false, redo = false;
   int rc = guard([&] {
     require(e && theta_cur && theta_prop && log_value_prop, "null argument");
     require(n_props >= 0 && n_props <= 8 && (n_props == 0 || (props && fwd && bwd)), "bad proposal list");
@@ -1526,24 +1618,26 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     }
     if (per_stage) return;
     Bound _b(&c);
+    g_host_timing.start();
 
+    for (int i = 0; i < n_props; ++i) props[i]->resolve_speculation(theta_cur);
     // ---- cached side: posterior of the current state for every proposal (+ its KL basis for the generating one)
     PosteriorEntry* ec[2];
     PosteriorEntry* ep[2];
     for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
     // KL bases of the current state's posteriors: all of them are started now, each on its proposal's own stream (they
     // run side by side); only the generating one is waited for — the other is ready when a later step draws from it
-    bool eigen_enqueued = false;
     for (int i = 0; i < n_props; ++i)
-      if (!ec[i]->eig_valid) {
-        props[i]->ensure_eigen(*ec[i]);
-        if (i == generator) eigen_enqueued = true;
-      }
+      if (!ec[i]->eig_valid) props[i]->ensure_eigen(*ec[i]);
+    bool eigen_first_use = false;
     if (generator >= 0) {
       props[generator]->await_eigen(*ec[generator]);
-      eigen_enqueued = !ec[generator]->eig_checked;  // first use (possibly of an earlier prefetch): fetch its status
+      eigen_first_use = !ec[generator]->eig_checked;  // (possibly of an earlier prefetch or speculation): fetch its status
       ec[generator]->eig_checked = true;
     }
+    // the decompositions of ranks <= 64 leave their status in pinned memory themselves; the others need a copy
+    const bool eigen_status_pinned = eigen_speculation_supported(r);
+    const bool eigen_enqueued = eigen_first_use && !eigen_status_pinned;
 
     // ---- new side: one state slot, one memo entry per proposal
     StateSlot& s = c.fresh_state();
@@ -1597,6 +1691,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     b.x = s.x.p;
     b.has_surf = 1; b.surf = st_surf;
     b.has_vert = pt ? 1 : 0; b.vert = st_vert;
+    g_host_timing.mark(0);
     launch_step_begin(c.stream, b);
 
     // 2 + 3: searches and correspondences
@@ -1639,13 +1734,20 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       g.cb[i] = ep[i]->corr();
       g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
       g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];
-      g.Mpart[i] = p->Mpart.p;
+      p->mpart_half ^= 1;
+      g.Mpart[i] = p->mpart_for_write(p->mpart_half);
+      g.status[i] = p->status.p + ep[i]->status_off;
       g.ustart[i + 1] = g.ustart[i] + g.ntiles * splits[i];
     }
     if (n_props == 1) g.ustart[2] = g.ustart[1];
     g.reduce_kind = evp.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE ? 1 : 2;
     g.Kred = evp.n_model_ids; g.d2 = s.surf_d2.p; g.mean = evp.gauss_mean; g.sigma = evp.gauss_sigma;
     g.red_out = c.h_res;
+    static const bool no_spec = std::getenv("ICP_NO_SPECULATION") != nullptr;
+    const bool speculate = !no_spec && n_props > 0 && eigen_speculation_supported(r);
+    // test hook: the speculative decompositions wait for a word that never comes, time out and are repeated
+    static const int starve = std::getenv("ICP_TEST_STARVE_SPECULATION") ? (1 << 24) : 0;
+    const int step_seq = ++c.step_seq;
     launch_step_regression(c.stream, g);
 
     // 5: factorisations + tails (results go straight to pinned host memory)
@@ -1653,7 +1755,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     f.n = n_props; f.r = r; f.Ginv = c.Ginv.p; f.sigma2 = kSigma2;
     for (int i = 0; i < n_props; ++i) {
       icp_proposal* p = props[i];
-      f.Mpart[i] = p->Mpart.p; f.splits[i] = splits[i];
+      f.Mpart[i] = g.Mpart[i]; f.splits[i] = splits[i];
       f.M[i] = ep[i]->M.p; f.alpha[i] = ep[i]->alpha.p;
       f.status[i] = p->status.p + ep[i]->status_off;
       f.host_status[i] = c.h_status + 8 + i;
@@ -1662,8 +1764,17 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       f.bwd[i] = TransitionTailIO{ep[i]->alpha.p, ep[i]->M.p, ep[i]->coeffs.p, ec[i]->coeffs.p, p->prm.step_length,
                                   c.h_res + 9 + 2 * i, c.h_status + 2 * i + 1};
     }
-    f.done_counter = c.d_done.p; f.host_flag = c.h_flag; f.seq = ++c.step_seq;
+    f.done_counter = c.d_done.p; f.host_flag = c.h_flag; f.seq = step_seq;
+    f.ready_flag = speculate ? c.d_done.p + 2 : nullptr;
     launch_step_finish(c.stream, f);
+    g_host_timing.mark(1);
+    // KL bases of the proposed state's posteriors, in case it is accepted: they run on the proposals' own streams beside
+    // the factorisations and the host's round trip; the next call keeps or cancels them (resolve_speculation)
+    if (speculate)
+      for (int i = 0; i < n_props; ++i) {
+        props[i]->speculate_eigen(*ep[i], *ec[i], splits[i], c.d_done.p + 2, step_seq + starve);
+      }
+    g_host_timing.mark(2);
     if (eigen_enqueued) {
       sync_proposal_status_if(props[generator], true);
       c.finish(0, 0);
@@ -1681,6 +1792,20 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     }
 
     // ---- bookkeeping with the results in hand
+    g_host_timing.mark_wait(eigen_first_use);
+    if (eigen_first_use && eigen_status_pinned) {  // this step's first launch waited for that decomposition: its status is in
+      icp_proposal* p = props[generator];
+      const int st = p->h_eig[ec[generator]->status_off / 3];
+      if (st == kEigenGaveUp) {  // a speculative decomposition that never saw its input (see k_posterior_eigen_rr): the
+        // step just computed drew from a stale basis — drop it (nothing of it has been recorded) and do it again
+        ec[generator]->eig_valid = false;
+        ec[generator]->eig_checked = false;
+        p->warm_valid = false;  // (it pointed at the basis that was never written)
+        redo = true;
+        return;
+      }
+      p->h_status[ec[generator]->status_off + 2] = st;
+    }
     const size_t P = 10 + (size_t)r;
     if (generator >= 0) {
       std::memcpy(theta_prop, theta_cur, sizeof(double) * 10);  // :64-66 only the shape changes
@@ -1726,8 +1851,11 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       bwd[i] = c.h_res[9 + 2 * i];
       if (std::isnan(fwd[i]) || std::isnan(bwd[i])) fail(ICP_ERR_NOT_FINITE, "NaN transition probability");
     }
+    g_host_timing.mark(4);
+    g_host_timing.end();
   });
   if (rc != ICP_OK) return rc;
+  if (redo) return icp_chain_step(e, n_props, props, generator, theta_cur, z, theta_prop, log_value_prop, fwd, bwd);
   if (per_stage) {  // same results through the per-stage kernels
     if (generator >= 0) {
       rc = icp_proposal_propose(props[generator], theta_cur, z, theta_prop, nullptr);

@@ -156,8 +156,21 @@ void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO
 // eigen-decomposition of D M^-1 D (posterior KL basis): V columns (and its transpose Vt), S descending, canonical signs
 // Vwarm (optional): eigenvectors of a nearby posterior, used as the starting basis of the Jacobi iteration
 size_t eigen_work_doubles(int r);  // size of `work`
+// EigenSpec (optional, ranks <= 64 only): a decomposition started before it is known to be needed.
+//   splits   > 0: `M` points at the split-K partials of the regression launch (splits × (r+1)² row-major; lower triangle
+//            used, identity not yet added) and the kernel sums them itself, in the order the factorisation does — the same
+//            values as the finished r×r M, available one launch earlier
+//   cancel   pinned host word, polled once per sweep: the decomposition gives up (writes nothing) once *cancel == seq
+//            (seq != 0)
+//   ready    device word raised (to ready_seq or beyond) by the regression launch when the partials are complete: the
+//            decomposition is enqueued without a stream dependency on that launch and waits for the word itself
+constexpr int kEigenGaveUp = 3;  // pinned status of a speculative decomposition whose input never arrived
+struct EigenSpec { int splits; const int* cancel; int seq; const int* ready; int ready_seq; };
+bool eigen_speculation_supported(int r);
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
-                            double* Vt, double* S, double* work /* eigen_work_doubles(r) */, int* status);
+                            double* Vt, double* S, double* work /* eigen_work_doubles(r) */, int* status,
+                            const EigenSpec* spec = nullptr, int* host_status = nullptr /* pinned copy of *status; honoured
+                            when eigen_speculation_supported(r) */);
 
 // a8: c' = c + step·((G+σ²I)^-1 G (α + D^-1 V √S z) − c), with P = (G+σ²I)^-1
 void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,
@@ -230,6 +243,8 @@ struct StepRegressionArgs {  // launch 4: normal-equation partial sums of every 
   CorrBuffers cb[2];
   double wt[2], kappa[2];
   double* Mpart[2];
+  int* status[2];            // the new entries' 3 status ints: {-, eigen sweeps, eigen} are cleared here
+
   int reduce_kind;           // 0 none, 1 Σ log N(d; mean, sigma), 2 {Σ d, max d, count}
   int Kred;
   const double* d2;
@@ -248,6 +263,9 @@ struct StepFinishArgs {  // launch 5: per posterior Cholesky + alpha, then the b
   // completion signal: the last workgroup to finish stores `seq` into pinned host memory (the host polls it instead of
   // paying a stream synchronisation)
   int* done_counter; int* host_flag; int seq;
+  // raised (to seq) as soon as this launch starts: everything the regression launch wrote is visible from then on — a
+  // speculative eigen-decomposition enqueued on another stream waits for this word instead of for an event
+  int* ready_flag;
 };
 
 bool step_finish_supported(int r);

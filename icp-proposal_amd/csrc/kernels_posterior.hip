@@ -8,6 +8,7 @@
 //     (equal to the reference's whitened-coefficient form for ANY square root of D M⁻¹ D; derivation in DESIGN.md)
 // These kernels are latency-bound r×r work (r = 51…201): one workgroup per matrix, data in LDS when it fits.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "icp_kernels.hpp"
@@ -464,6 +465,135 @@ __device__ __forceinline__ dbl2 lds2(const double* p) { return *(const dbl2*)p; 
 // of LDS time per round on one CU in every layout tried, against a ~1000-cycle round).  The rotations are logged instead,
 // and k_eigen_vreplay applies them to V afterwards on many CUs at once (rows of V are independent).
 
+// ---- progress word shared by the two roles of k_posterior_eigen_rr (meta[0]); every launch carries its own id so that
+// whatever an earlier launch left there is never mistaken for news
+constexpr int kPwRoundsMask = 0x3FFFF, kPwAbort = 1 << 18, kPwFinished = 1 << 19, kPwIdShift = 20, kPwIdMask = 0x7FF;
+__device__ __forceinline__ void progress_publish(int* meta, int id, int rounds, int flags) {
+  __hip_atomic_store(meta, (id << kPwIdShift) | flags | rounds, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// whole-wave shifts by one lane on the DPP path of the VALU (gfx9 wave_shr:1 / wave_shl:1): no LDS crossbar trip
+__device__ __forceinline__ double wave_shr1_f64(double v) {  // lane l receives the value of lane l−1 (lane 0 keeps its own)
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1_f64(double v) {  // lane l receives the value of lane l+1 (lane 63 keeps its own)
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------- V <- V·J_0·J_1···  (replay of the rotation log)
+// Workgroups 1.. of k_posterior_eigen_rr, running BESIDE the Jacobi workgroup (workgroup 0) on other CUs: they follow its
+// progress word and apply each sweep's rotations to the eigenvector matrix while the next sweep is being computed, so
+// that when the iteration ends only the last sweep's rotations (a few µs) and the final sort are left.
+// One wave per TWO coordinates (rows of V): lane = pair + 32·coordinate.  A lane keeps its pair's two entries of the row
+// in registers; one round rotates the pair and hands the results to the neighbouring pairs (the round-robin move:
+// first entries travel to pair+1, second entries to pair−1, with the two turn-arounds at the ends): two 64-bit DPP
+// wave shifts per round, no LDS traffic for the data.  The rotations of the published rounds are staged in LDS once per
+// workgroup (every row needs all of them).  The last workgroup to finish fixes the signs (largest-|.| component of every
+// eigenvector positive), sorts the columns by the producer's ranks and writes V and Vᵀ.
+constexpr int kReplayStageRounds = 64;   // rounds staged per pass (>= one sweep for ranks <= 64)
+constexpr int kReplayRowsPerBlock = 32;  // 16 waves × 2 coordinates
+
+__device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* rotlog, int* meta,
+                                      double* vpos /* [n2][64] */, double* Vout, double* Vtout,
+                                      int launch_id) {
+  __shared__ int s_pw, s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n2 = (r + 1) & ~1, m = n2 >> 1;
+  double* s_log = s_dyn;  // kReplayStageRounds × m entries of (c, −s)
+  const int kc = lane >> 5, q = lane & 31, k = kReplayRowsPerBlock * ((int)blockIdx.x - 1) + 2 * wave + kc;
+  const bool act = q < m;
+  const int qc = act ? q : 0;
+  // this lane's pair of the row: positions 2q (first) and 2q+1 (second)
+  auto v0_at = [&](int p) { return (k < r && p < r) ? (Vwarm ? Vwarm[(size_t)k * r + p] : (k == p ? 1.0 : 0.0)) : 0.0; };
+  double x0 = act ? v0_at(2 * q) : 0.0, x1 = act ? v0_at(2 * q + 1) : 0.0;
+  int done = 0;
+  bool aborted = false;
+  for (;;) {
+    if (tid == 0) {  // follow the producer
+      int pw;
+      for (;;) {
+        pw = __hip_atomic_load(meta, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (((pw >> kPwIdShift) & kPwIdMask) == launch_id && ((pw & kPwRoundsMask) > done || (pw & (kPwAbort | kPwFinished)))) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+      s_pw = pw;
+    }
+    __syncthreads();
+    const int pw = s_pw;
+    if (pw & kPwAbort) { aborted = true; break; }  // cancelled decomposition: V stays untouched
+    const int avail = pw & kPwRoundsMask;
+    while (done < avail) {
+      const int n = min(avail - done, kReplayStageRounds);
+      __threadfence();  // (acquire side of the progress word for the plain loads below)
+      for (int e = tid; e < n * m; e += blockDim.x) *(dbl2*)&s_log[2 * e] = *(const dbl2*)(rotlog + 2 * ((size_t)done * m + e));
+      __syncthreads();
+      for (int rl = 0; rl < n; rl += 8) {
+        dbl2 cs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cs[u] = *(const dbl2*)&s_log[2 * (min(rl + u, n - 1) * m + qc)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (rl + u < n) {  // uniform
+            const double f = fma(cs[u].x, x0, cs[u].y * x1), g = fma(-cs[u].y, x0, cs[u].x * x1);  // rotated first / second entry
+            // round-robin move (rr_dst): first entries go one pair up, except pair 0 (stays) and pair m−1 (becomes its
+            // own second); second entries go one pair down, except pair 0 (becomes the first of pair 1)
+            const double from_up = wave_shr1_f64(q == 0 ? g : f);  // what pair q−1 sends up: its first — or pair 0's second
+            const double from_dn = wave_shl1_f64(g);               // what pair q+1 sends down: its second
+            x0 = q == 0 ? f : from_up;
+            x1 = q == m - 1 ? f : from_dn;
+          }
+        }
+      }
+      __syncthreads();
+      done += n;
+    }
+    if (pw & kPwFinished) break;
+  }
+  // ---- publish the rows (position-major), then the last workgroup assembles the output
+  if (!aborted && act && k < r) { vpos[(size_t)(2 * q) * 64 + k] = x0; vpos[(size_t)(2 * q + 1) * 64 + k] = x1; }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&meta[1], 1) == (int)gridDim.x - 2;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (tid == 0) {  // ready for the next decomposition (the producer has long finished; nobody reads these any more)
+    meta[1] = 0;
+    __hip_atomic_store(meta, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (aborted) return;
+  // Stage the whole position-major V in LDS (row stride 65: conflict-free column walks); one wave per position finds the
+  // sign (largest-|.| component, the first one among equals, made positive); then the columns go out in rank order.
+  double* s_v = s_dyn;
+  double* s_sgn = s_dyn + 64 * 65;
+  for (int e = tid; e < n2 * 64; e += blockDim.x) s_v[(e >> 6) * 65 + (e & 63)] = __builtin_nontemporal_load(vpos + e);
+  __syncthreads();
+  for (int pos = wave; pos < n2; pos += (int)(blockDim.x >> 6)) {
+    const double v = lane < r ? s_v[pos * 65 + lane] : 0.0;
+    double bv = lane < r ? fabs(v) : -1.0;
+    int bi = lane;
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) s_sgn[pos] = s_v[pos * 65 + bi] < 0.0 ? -1.0 : 1.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < n2 * 64; e += blockDim.x) {
+    const int pos = e >> 6, kk = e & 63, rank = meta[4 + pos];
+    if (kk < r && rank < r) {
+      const double v = s_v[pos * 65 + kk] * s_sgn[pos];
+      Vout[(size_t)kk * r + rank] = v;
+      Vtout[(size_t)rank * r + kk] = v;
+    }
+  }
+}
+
 constexpr int kRrLd = 66;                 // row stride of A (doubles): rows 16 B apart modulo the 256-B bank window
 constexpr int kRrSzA = 64 * kRrLd;        // one buffer of A, sized for rank 64 whatever r is: every offset below is a constant
 constexpr int kRrSzC = 4 * 32;            // one rotation table
@@ -472,11 +602,18 @@ constexpr int kRrLogWave = 14;            // never a block wave (at most 9 of th
 template <int N> struct IntC { static constexpr int value = N; };
 
 __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
-                                                              const double* __restrict__ Vwarm, double* __restrict__ Vout,
-                                                              double* __restrict__ Vtout, double* __restrict__ Sout,
-                                                              int* __restrict__ status, int ldk, double* __restrict__ rotlog,
-                                                              int* __restrict__ meta, int max_sweeps) {
+                                                              const double* Vwarm /* may be Vout */, double* Vout,
+                                                              double* Vtout, double* __restrict__ Sout,
+                                                              int* __restrict__ status, int ldk, double* rotlog,
+                                                              int* meta, double* vpos, int max_sweeps, EigenSpec spec, int launch_id,
+                                                              int* host_status) {
+  if (Vwarm && !(Vwarm[0] == Vwarm[0])) Vwarm = nullptr;  // the basis of a decomposition that gave up (see below): cold start
+  if (blockIdx.x != 0) {
+    eigen_replay_consumer(r, Vwarm, rotlog, meta, vpos, Vout, Vtout, launch_id);
+    return;
+  }
   __shared__ double s_red[16], s_mu[64];
+  __shared__ int s_cancel;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int n2 = (r + 1) & ~1, m = n2 >> 1;
   // buffers are addressed as s_dyn[offset] with integer offsets: a table of pointers would turn every access into a
@@ -489,17 +626,67 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
 #define LDS_T(i) s_dyn[oT + (i)]
 #define LDS_C(b, i) s_dyn[oC + (b) * szC + (i)]
   EIG_STAMP(0);
+  // a speculative decomposition polls its cancel word (pinned host memory: a slow read, so one thread of an otherwise
+  // idle wave fetches it while the others work, and the block looks at the copy at the next convenient barrier)
+  const bool is_poll = spec.cancel != nullptr && tid == 64 * kRrLogWave + 63;
+  if (tid == 0) s_cancel = 0;
   // ---- N = D⁻¹ M D⁻¹ (symmetrised), padded; Vt = (warm start or identity)ᵀ, padded with zeros
   for (int e = tid; e < szV; e += nt) LDS_VT(e) = 0.0;
   __syncthreads();
+  if (spec.ready) {  // enqueued ahead of its input: wait for the launch that announces it (or for the cancellation).
+    // Should that launch not come forward within 5 ms — kernels of different streams forced to run one at a time by a
+    // tool, say — give up and say so in the pinned status: the host then repeats the decomposition the ordinary way.
+    if (is_poll) {
+      const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+      for (;;) {
+        if (__hip_atomic_load(spec.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - spec.ready_seq >= 0) break;
+        if (__hip_atomic_load(spec.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == spec.seq) { s_cancel = 1; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 500000) { s_cancel = 2; break; }
+        __builtin_amdgcn_s_sleep(32);
+      }
+    }
+    __syncthreads();
+    __threadfence();  // (acquire side for the plain loads of the partials below)
+  }
+  if (is_poll && __hip_atomic_load(spec.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == spec.seq) s_cancel = 1;
   for (int e = tid; e < n2 * n2; e += nt) {
     const int i = e / n2, j = e - i * n2;
     double v = i == j ? 1e300 : 0.0;
-    if (i < r && j < r) v = 0.5 * (M[(size_t)i * r + j] + M[(size_t)j * r + i]) / (sqrt_lambda[i] * sqrt_lambda[j]);
+    if (i < r && j < r) {
+      double mij;
+      if (spec.splits > 0) {  // M = I + Σ_s partial_s, lower triangle of the (r+1)² partials, summed in split order from 0.0
+        const size_t o = (size_t)max(i, j) * (r + 1) + min(i, j), nn = (size_t)(r + 1) * (r + 1);
+        mij = 0.0;
+        int sp = 0;
+        for (; sp + 16 <= spec.splits; sp += 16) {
+          double p[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) p[u] = M[(size_t)(sp + u) * nn + o];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) mij += p[u];
+        }
+        for (; sp < spec.splits; ++sp) mij += M[(size_t)sp * nn + o];
+        if (i == j) mij += 1.0;
+      } else {
+        mij = 0.5 * (M[(size_t)i * r + j] + M[(size_t)j * r + i]);
+      }
+      v = mij / (sqrt_lambda[i] * sqrt_lambda[j]);
+    }
     LDS_A(0, i * ld + j) = v;
     if (i < r && j < r) LDS_VT(j * ldk + i) = Vwarm ? Vwarm[(size_t)i * r + j] : (i == j ? 1.0 : 0.0);  // i = coordinate, j = position
   }
   __syncthreads();
+  if (s_cancel) {  // cancelled (or timed out) before it started: nothing is written
+    if (tid == 0) {
+      progress_publish(meta, launch_id, 0, kPwAbort);
+      if (s_cancel == 2) {  // timed out: tell the host, and mark the basis that was never written so that no later
+        // decomposition takes it for a warm start (a NaN in its first entry; a finished decomposition overwrites it)
+        if (host_status) __hip_atomic_store(host_status, kEigenGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        Vout[0] = __builtin_nan("");
+      }
+    }
+    return;
+  }
   EIG_STAMP(1);
   if (Vwarm) {  // A <- Vᵀ A V (nearly diagonal when V diagonalised a nearby posterior); 2×2 output tiles per thread,
     // every inner product runs along contiguous rows (A row · Vt row, Vt row · Tt row); padded entries are zero
@@ -617,6 +804,10 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
   auto sweep_end = [&](int cur) {  // -> stop?
     EIG_STAMP(4 + 2 * n_sweeps);
     in_sweep = 0;
+    // this sweep's rotations are in the log: let the replay workgroups have them while the convergence test runs
+    if (wave == kRrLogWave) __threadfence();
+    __syncthreads();
+    if (tid == 0) progress_publish(meta, launch_id, n_rounds, 0);
     double off = 0.0, dg = 0.0;
     for (int e = tid; e < n2 * n2; e += nt) {
       const int i = e / n2, j = e - i * n2;
@@ -626,20 +817,32 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     }
     off = block_sum(off, s_red);
     dg = block_sum(dg, s_red);
-    converged = off <= 1e-26 * dg;
+    converged = off <= 1e-26 * dg;  // (block_sum's barriers also order the poll thread's s_cancel store before this read)
     ++n_sweeps;
     EIG_STAMP(3 + 2 * n_sweeps);
-    return converged || n_sweeps >= max_sweeps;
+    return converged || n_sweeps >= max_sweeps || s_cancel;
   };
-  int cur = 0;
+  int cur = 0, polled = 0x80000000;
+  const int poll_use = (n2 - 1) >> 2;
   if (max_sweeps > 0)
     for (;;) {
+      // the poll of a sweep is issued at its start and looked at half a sweep later, when the word has long arrived
+      // (waiting for it on the spot would hold every wave at this round's barrier for a microsecond or two)
+      if (is_poll && (in_sweep >> 1) == 0) polled = __hip_atomic_load(spec.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (is_poll && (in_sweep >> 1) == poll_use && polled == spec.seq) s_cancel = 1;
       round(IntC<0>{}); cur = 1;
       if (++in_sweep == n2 - 1 && sweep_end(cur)) break;
       round(IntC<1>{}); cur = 0;
       if (++in_sweep == n2 - 1 && sweep_end(cur)) break;
     }
-  if (tid == 0) { status[0] = converged ? 0 : 2; status[-1] = n_sweeps; }
+  if (s_cancel && !converged) {  // given up: no status, no eigenvalues; the replay workgroups drop what they have
+    if (tid == 0) progress_publish(meta, launch_id, n_rounds, kPwAbort);
+    return;
+  }
+  if (tid == 0) {
+    status[0] = converged ? 0 : 2; status[-1] = n_sweeps;
+    if (host_status) __hip_atomic_store(host_status, converged ? 0 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   EIG_STAMP(62);
   // ---- eigenvalues of D M⁻¹ D are 1/μ; S descending = μ ascending; the dummy sorts last and is dropped.  The replay
   // kernel needs the number of logged rounds and, per final position, the rank of its eigenvalue.
@@ -649,151 +852,17 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     int rank = 0;
     const double mi = s_mu[tid];
     for (int j = 0; j < n2; ++j) rank += (s_mu[j] < mi) || (s_mu[j] == mi && j < tid);
-    meta[2 + tid] = rank;
+    meta[4 + tid] = rank;
     if (rank < r) Sout[rank] = 1.0 / mi;
+    __threadfence();
   }
-  if (tid == 0) meta[0] = n_rounds;
+  __syncthreads();
+  if (tid == 0) progress_publish(meta, launch_id, n_rounds, kPwFinished);  // (max_sweeps == 0: nothing to replay)
   EIG_STAMP(63);
 #undef LDS_A
 #undef LDS_VT
 #undef LDS_T
 #undef LDS_C
-}
-
-// ---------------------------------------------------------------- V <- V·J_0·J_1···  (replay of the rotation log)
-// One wave per TWO coordinates (rows of V): lane = pair + 32·coordinate.  A lane keeps its pair's two entries of the row
-// in registers; one round rotates the pair and hands the results to the neighbouring pairs (the round-robin move:
-// first entries travel to pair+1, second entries to pair−1, with the two turn-arounds at the ends): two 64-bit DPP
-// wave shifts per round, no LDS traffic for the data.  Nothing is shared between waves, so no barrier is ever needed;
-// the log streams through LDS in chunks of whole rounds (one chunk in flight, next round's entry prefetched).  The last
-// workgroup to finish fixes the signs (largest-|.| component of every eigenvector positive), sorts the columns by the
-// ranks of kernel 1 and writes V and Vᵀ.
-constexpr int kReplayCoords = 2;
-constexpr int kReplayChunk = 1024;  // log entries (16 B) per chunk: 16 per lane
-
-// whole-wave shifts by one lane on the DPP path of the VALU (gfx9 wave_shr:1 / wave_shl:1): no LDS crossbar trip
-__device__ __forceinline__ double wave_shr1_f64(double v) {  // lane l receives the value of lane l−1 (lane 0 keeps its own)
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_shl1_f64(double v) {  // lane l receives the value of lane l+1 (lane 63 keeps its own)
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-
-__global__ void __launch_bounds__(64) k_eigen_vreplay(int r, const double* __restrict__ Vwarm, const double* __restrict__ rotlog,
-                                                       int* __restrict__ meta, double* __restrict__ vpos /* [n2][64] */,
-                                                       double* __restrict__ Vout, double* __restrict__ Vtout) {
-  __shared__ __attribute__((aligned(16))) double s_log[2][2 * kReplayChunk];
-  __shared__ int s_last;
-  const int lane = threadIdx.x, n2 = (r + 1) & ~1, m = n2 >> 1;
-#ifdef ICP_EIGEN_TIMING
-  if (blockIdx.x == 0 && lane == 0) g_eigen_stamps[40] = __builtin_amdgcn_s_memrealtime();
-#endif
-  const int n_rounds = meta[0];
-  const int kc = lane >> 5, q = lane & 31, k = kReplayCoords * blockIdx.x + kc;
-  const bool act = q < m;
-  const int qc = act ? q : 0;
-  // this lane's pair of the row: positions 2q (first) and 2q+1 (second)
-  auto v0_at = [&](int p) { return (k < r && p < r) ? (Vwarm ? Vwarm[(size_t)k * r + p] : (k == p ? 1.0 : 0.0)) : 0.0; };
-  double x0 = act ? v0_at(2 * q) : 0.0, x1 = act ? v0_at(2 * q + 1) : 0.0;
-  const int rounds_per_chunk = kReplayChunk / m, chunk_entries = rounds_per_chunk * m;
-  const int n_chunks = (n_rounds + rounds_per_chunk - 1) / rounds_per_chunk;
-  constexpr int kPer = kReplayChunk / 64;
-  dbl2 pre[kPer];
-  auto fetch = [&](int c) {
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      const int e = lane + 64 * u;
-      const size_t g = (size_t)c * chunk_entries + e;
-      pre[u] = (e < chunk_entries && g < (size_t)n_rounds * m) ? *(const dbl2*)(rotlog + 2 * g) : dbl2{1.0, 0.0};
-    }
-  };
-  auto stash = [&](int b) {
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      const int e = lane + 64 * u;
-      if (e < chunk_entries) *(dbl2*)&s_log[b][2 * e] = pre[u];
-    }
-  };
-  auto wave_sync = [&]() {  // DS operations of one wave complete in order; this only stops the compiler from reordering
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  int lb = 0;
-  if (n_chunks > 0) { fetch(0); stash(0); }
-  wave_sync();
-#ifdef ICP_EIGEN_TIMING
-  if (blockIdx.x == 0 && lane == 0) g_eigen_stamps[41] = __builtin_amdgcn_s_memrealtime();
-#endif
-  for (int c = 0; c < n_chunks; ++c) {
-    const bool more = c + 1 < n_chunks;
-    if (more) fetch(c + 1);
-    const int t_end = min(n_rounds - c * rounds_per_chunk, rounds_per_chunk);
-    dbl2 cs = *(const dbl2*)&s_log[lb][2 * qc];
-    for (int rl = 0; rl < t_end; ++rl) {
-      const dbl2 cs_next = *(const dbl2*)&s_log[lb][2 * (min(rl + 1, t_end - 1) * m + qc)];  // independent of the data
-      const double f = fma(cs.x, x0, cs.y * x1), g = fma(-cs.y, x0, cs.x * x1);  // rotated first / second entry of the pair
-      // round-robin move (rr_dst): first entries go one pair up, except pair 0 (stays) and pair m−1 (becomes its own second);
-      // second entries go one pair down, except pair 0 (becomes the first of pair 1)
-      const double from_up = wave_shr1_f64(q == 0 ? g : f);  // what pair q−1 sends up: its first — or pair 0's second
-      const double from_dn = wave_shl1_f64(g);               // what pair q+1 sends down: its second
-      x0 = q == 0 ? f : from_up;
-      x1 = q == m - 1 ? f : from_dn;
-      cs = cs_next;
-    }
-    if (more) { lb ^= 1; stash(lb); wave_sync(); }
-  }
-#ifdef ICP_EIGEN_TIMING
-  if (blockIdx.x == 0 && lane == 0) g_eigen_stamps[42] = __builtin_amdgcn_s_memrealtime();
-#endif
-  // ---- publish the rows (position-major), then the last workgroup assembles the output
-  if (act && k < r) { vpos[(size_t)(2 * q) * 64 + k] = x0; vpos[(size_t)(2 * q + 1) * 64 + k] = x1; }
-  __threadfence();
-  if (lane == 0) s_last = atomicAdd(&meta[1], 1) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (!s_last) return;
-#ifdef ICP_EIGEN_TIMING
-  if (lane == 0) g_eigen_stamps[43] = __builtin_amdgcn_s_memrealtime();
-#endif
-  __threadfence();
-  if (lane == 0) meta[1] = 0;  // ready for the next decomposition
-  // Stage the whole position-major V in LDS (coalesced, all loads in flight together; row stride 65: conflict-free
-  // column walks), then lane = position: sign from the largest-|.| component, columns out in rank order.
-  double* s_v = &s_log[0][0];  // 2·2·kReplayChunk doubles >= 64·65
-  for (int p0 = 0; p0 < n2; p0 += 13) {
-    double tmp[13];
-#pragma unroll
-    for (int u = 0; u < 13; ++u) tmp[u] = p0 + u < n2 ? __builtin_nontemporal_load(vpos + (size_t)(p0 + u) * 64 + lane) : 0.0;
-#pragma unroll
-    for (int u = 0; u < 13; ++u)
-      if (p0 + u < n2) s_v[(p0 + u) * 65 + lane] = tmp[u];
-  }
-  __syncthreads();
-  if (lane < n2) {
-    const int rank = meta[2 + lane];
-    if (rank < r) {
-      const double* col = s_v + lane * 65;
-      int best = 0;
-      double bv = fabs(col[0]);
-      for (int kk = 1; kk < r; ++kk) {
-        const double a = fabs(col[kk]);
-        if (a > bv) { bv = a; best = kk; }
-      }
-      const double sgn = col[best] < 0.0 ? -1.0 : 1.0;
-      for (int kk = 0; kk < r; ++kk) {
-        const double v = col[kk] * sgn;
-        Vout[(size_t)kk * r + rank] = v;
-        Vtout[(size_t)rank * r + kk] = v;
-      }
-    }
-  }
-#ifdef ICP_EIGEN_TIMING
-  if (lane == 0) g_eigen_stamps[44] = __builtin_amdgcn_s_memrealtime();
-#endif
 }
 
 // ---------------------------------------------------------------- a8 propose
@@ -953,6 +1022,12 @@ void launch_regression(hipStream_t st, int K, int r, const double* Q, const Corr
 static void set_dyn_lds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+// the same for a kernel whose largest request is known up front: one runtime call per process instead of one per launch
+static void set_dyn_lds_once(const void* fn, size_t max_bytes, bool* done) {
+  if (*done) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
+  *done = true;
+}
 
 template <int TPT, int NT>
 static void launch_factor_reg(hipStream_t st, int r, int n_post, const FactorArgs& fa) {
@@ -1014,8 +1089,10 @@ size_t eigen_work_doubles(int r) {  // `work` of launch_posterior_eigen: r×r sc
   return std::max((size_t)r * r, log + n2 * 64 + 64);               // + position-major V + meta (see launch_posterior_eigen)
 }
 
+bool eigen_speculation_supported(int r) { return r >= 3 && r <= 64 && std::getenv("ICP_EIGEN_GENERIC") == nullptr; }
+
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
-                            double* Vt, double* S, double* work, int* status) {
+                            double* Vt, double* S, double* work, int* status, const EigenSpec* spec, int* host_status) {
   static const bool force_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
   if (r >= 3 && r <= 64 && !force_generic) {  // fixed-position variant: A, V and the rotation table double-buffered in LDS
     const int n2 = (r + 1) & ~1;
@@ -1028,11 +1105,15 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
     double* vpos = work + log_doubles;
     int* meta = (int*)(vpos + (size_t)n2 * 64);
     static const int sweeps_cap = std::getenv("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(std::getenv("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
-    set_dyn_lds((const void*)k_posterior_eigen_rr, shmem);
+    static bool lds_set = false;
+    set_dyn_lds_once((const void*)k_posterior_eigen_rr, sizeof(double) * ((size_t)kRrOV + 2 * 64 * 66), &lds_set);
+    static std::atomic<int> launch_counter{0};  // (any value the previous launch on this `work` did not use would do)
+    const int launch_id = 1 + (int)((unsigned)(++launch_counter) % kPwIdMask);  // never 0: the idle value of the progress word
     ProfScope _ps(st, KID_EIGEN);
-    hipLaunchKernelGGL(k_posterior_eigen_rr, dim3(1), dim3(1024), shmem, st, r, M, sqrt_lambda, Vwarm, V, Vt, S, status, ldk, rotlog,
-                       meta, std::min(sweeps_cap, kEigenMaxSweeps));
-    hipLaunchKernelGGL(k_eigen_vreplay, dim3((r + kReplayCoords - 1) / kReplayCoords), dim3(64), 0, st, r, Vwarm, rotlog, meta, vpos, V, Vt);
+    // workgroup 0 iterates; the others replay its rotations on V as the sweeps are published (32 coordinates each)
+    const int n_replay = (r + kReplayRowsPerBlock - 1) / kReplayRowsPerBlock;
+    hipLaunchKernelGGL(k_posterior_eigen_rr, dim3(1 + n_replay), dim3(1024), shmem, st, r, M, sqrt_lambda, Vwarm, V, Vt, S, status, ldk,
+                       rotlog, meta, vpos, std::min(sweeps_cap, kEigenMaxSweeps), spec ? *spec : EigenSpec{0, nullptr, 0, nullptr, 0}, launch_id, host_status);
     return;
   }
   const int ld = r | 1;

@@ -133,18 +133,18 @@ __global__ void __launch_bounds__(kStepBlock) k_step_regression(StepRegressionAr
   const int n_blocks = (n_units + 3) >> 2;  // one wave per (tile, split) unit, four per workgroup
   if ((int)blockIdx.x < n_blocks) {
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= n_units) return;
-    if (u < a.ustart[1]) {
-      regression_tile(u % a.ntiles, u / a.ntiles, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0]);
-    } else {
-      const int l = u - a.ustart[1];
-      regression_tile(l % a.ntiles, l / a.ntiles, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1]);
+    if (u < n_units) {
+      const int which = u < a.ustart[1] ? 0 : 1;
+      const int l = u - (which ? a.ustart[1] : 0), tile = l % a.ntiles, split = l / a.ntiles;
+      if (tile == 0 && split == 0 && (threadIdx.x & 63) == 0) { a.status[which][1] = 0; a.status[which][2] = 0; }
+      if (which == 0) regression_tile(tile, split, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0]);
+      else regression_tile(tile, split, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1]);
     }
-    return;
+  } else {
+    // the last workgroup: likelihood reduction over the surface distances of the evaluator's model ids
+    if (a.reduce_kind == 1) sum_gauss_logpdf_body(a.Kred, a.d2, a.mean, a.sigma, a.red_out);  // IndependentPointDistanceEvaluator.scala:40-46
+    else if (a.reduce_kind == 2) dist_stats_body(a.Kred, a.d2, a.red_out);                      // Collective…Evaluator.scala:43-52 (no boundary)
   }
-  // the last workgroup: likelihood reduction over the surface distances of the evaluator's model ids
-  if (a.reduce_kind == 1) sum_gauss_logpdf_body(a.Kred, a.d2, a.mean, a.sigma, a.red_out);  // IndependentPointDistanceEvaluator.scala:40-46
-  else if (a.reduce_kind == 2) dist_stats_body(a.Kred, a.d2, a.red_out);                      // Collective…Evaluator.scala:43-52 (no boundary)
 }
 
 // ---------------------------------------------------------------- 5: factorisations + transition tails
@@ -152,13 +152,10 @@ __global__ void __launch_bounds__(kStepBlock) k_step_regression(StepRegressionAr
 template <int E, int NT>
 __global__ void __launch_bounds__(NT) k_step_finish(StepFinishArgs a) {
   const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0 && a.ready_flag) __hip_atomic_store(a.ready_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (b < a.n) {
     const bool ok = factor_reg_body<E, NT>(a.r, a.Mpart[b], a.splits[b], a.M[b], a.alpha[b], a.status[b]);
-    if (threadIdx.x == 0) {
-      a.host_status[b][0] = ok ? 0 : 1;
-      a.status[b][1] = 0;
-      a.status[b][2] = 0;
-    }
+    if (threadIdx.x == 0) a.host_status[b][0] = ok ? 0 : 1;
     if (ok) {  // uniform
       __syncthreads();  // M and alpha of this posterior are complete (written by this workgroup)
       const TransitionTailIO& t = a.bwd[b];

@@ -94,3 +94,41 @@ def test_femur100_all_points_symmetric_matches_oracle(pkg, oracle):
     assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
     chain.close()
     ctx.close()
+
+
+_SPECULATION_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import __graft_entry__ as graft
+pkg = graft.load_package()
+model, target = pkg.data.load_femur_model_and_target(50)
+setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+ctx = pkg.IcpContext(model, target, device=0)
+chain = pkg.SamplingRegistration(ctx, setup, pkg.initial_parameters(model), 1024)
+np.save({out!r}, chain.run(60))
+chain.close(); ctx.close()
+"""
+
+
+@pytest.mark.parametrize("env", [{"ICP_NO_SPECULATION": "1"}, {"ICP_TEST_STARVE_SPECULATION": "1"}], ids=["off", "starved"])
+def test_speculative_decomposition_fallbacks(pkg, femur50, femur50_oracle, oracle, env, tmp_path):
+    """icp_chain_step starts the KL basis of the proposed state before the caller decides (icp_abi.hip, speculate_eigen).
+    Two ways around it must give the same chain: switched off, and starved — the decomposition never sees its input, gives
+    up after its time-out, and the step that drew from it is repeated with an ordinary decomposition."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    model, target = femur50
+    om, ot = femur50_oracle
+    setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+    acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), pkg.initial_parameters(model), 1024, 60)
+    out = str(tmp_path / "rec.npy")
+    script = _SPECULATION_SCRIPT.format(root=ROOT, out=out)
+    subprocess.run([sys.executable, "-c", script], check=True, env={**os.environ, **env}, timeout=300)
+    rec = np.load(out)
+    assert np.array_equal(rec[:, 1].astype(np.uint8), acc_o), "accept/reject sequences differ"
+    assert np.array_equal(rec[:, 2].astype(np.int32), comp_o), "mixture components differ"
+    scale = np.abs(states_o[:, 10:]).max()
+    assert np.abs(rec[:, 4 + 10:] - states_o[:, 10:]).max() <= 1e-5 * scale
+    assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
