@@ -495,17 +495,19 @@ __device__ __forceinline__ double wave_shl1_f64(double v) {  // lane l receives 
 // workgroup (every row needs all of them).  The last workgroup to finish fixes the signs (largest-|.| component of every
 // eigenvector positive), sorts the columns by the producer's ranks and writes V and Vᵀ.
 constexpr int kReplayStageRounds = 64;   // rounds staged per pass (>= one sweep for ranks <= 64)
-constexpr int kReplayRowsPerBlock = 32;  // 16 waves × 2 coordinates
+constexpr int kReplayWaves = 8;          // waves of a replay workgroup that carry rows: two per SIMD (more would only queue
+                                         // for the same issue slots; the other waves help with staging only)
+constexpr int kReplayRowsPerBlock = 2 * kReplayWaves;
 
 __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* rotlog, int* meta,
                                       double* vpos /* [n2][64] */, double* Vout, double* Vtout,
                                       int launch_id) {
-  __shared__ int s_pw, s_last;
+  __shared__ int s_pw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n2 = (r + 1) & ~1, m = n2 >> 1;
   double* s_log = s_dyn;  // kReplayStageRounds × m entries of (c, −s)
   const int kc = lane >> 5, q = lane & 31, k = kReplayRowsPerBlock * ((int)blockIdx.x - 1) + 2 * wave + kc;
-  const bool act = q < m;
+  const bool act = q < m && wave < kReplayWaves;
   const int qc = act ? q : 0;
   // this lane's pair of the row: positions 2q (first) and 2q+1 (second)
   auto v0_at = [&](int p) { return (k < r && p < r) ? (Vwarm ? Vwarm[(size_t)k * r + p] : (k == p ? 1.0 : 0.0)) : 0.0; };
@@ -521,6 +523,9 @@ __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* 
         __builtin_amdgcn_s_sleep(16);
       }
       s_pw = pw;
+#ifdef ICP_EIGEN_TIMING
+      if (blockIdx.x == 1 && (pw & kPwFinished)) g_eigen_stamps[40] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
     __syncthreads();
     const int pw = s_pw;
@@ -528,10 +533,11 @@ __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* 
     const int avail = pw & kPwRoundsMask;
     while (done < avail) {
       const int n = min(avail - done, kReplayStageRounds);
-      __threadfence();  // (acquire side of the progress word for the plain loads below)
-      for (int e = tid; e < n * m; e += blockDim.x) *(dbl2*)&s_log[2 * e] = *(const dbl2*)(rotlog + 2 * ((size_t)done * m + e));
+      // (agent-scope loads: the log's addresses are reused by every decomposition, a plain load could hit a stale line)
+      for (int e = tid; e < 2 * n * m; e += blockDim.x)
+        s_log[e] = __hip_atomic_load(rotlog + 2 * (size_t)done * m + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      for (int rl = 0; rl < n; rl += 8) {
+      for (int rl = 0; rl < n && wave < kReplayWaves; rl += 8) {
         dbl2 cs[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) cs[u] = *(const dbl2*)&s_log[2 * (min(rl + u, n - 1) * m + qc)];
@@ -553,44 +559,93 @@ __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* 
     }
     if (pw & kPwFinished) break;
   }
-  // ---- publish the rows (position-major), then the last workgroup assembles the output
-  if (!aborted && act && k < r) { vpos[(size_t)(2 * q) * 64 + k] = x0; vpos[(size_t)(2 * q + 1) * 64 + k] = x1; }
-  __threadfence();
+#ifdef ICP_EIGEN_TIMING
+  if (blockIdx.x == 1 && tid == 0) g_eigen_stamps[41] = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- signs and output.  The largest-|.| component of every eigenvector (column of V), the first among equals, is made
+  // positive; the columns go out in the rank order of the producer.  Every workgroup finds the candidates of its own rows
+  // (wave -> workgroup through LDS), the workgroups exchange them through `xchg` (one small message each), and every lane
+  // writes its own entries — V never travels.
+  const int nb = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
+  double* s_pv = s_dyn;                    // [waves][64 positions] candidate value (signed)
+  int* s_pk = (int*)(s_dyn + 16 * 64);     // … and its row
+  double* s_bv = s_dyn + 16 * 64 + 8 * 64; // [64] workgroup's (then the global) candidate
+  int* s_bk = (int*)(s_bv + 64);
+  int* s_rank = s_bk + 64;
+  if (!aborted) {
+    // candidates of this wave's two rows, per position; a lane holds positions 2q (x0) and 2q+1 (x1) of row k
+    const bool mine = act && k < r;
+    double c0 = x0, c1 = x1, a0 = mine ? fabs(x0) : -1.0, a1 = mine ? fabs(x1) : -1.0;
+    int k0 = k, k1 = k;
+    {
+      const double o0 = __shfl_xor(a0, 32, 64), o1 = __shfl_xor(a1, 32, 64), v0 = __shfl_xor(c0, 32, 64), v1 = __shfl_xor(c1, 32, 64);
+      const int ok = __shfl_xor(k, 32, 64);
+      if (o0 > a0 || (o0 == a0 && ok < k0)) { a0 = o0; c0 = v0; k0 = ok; }
+      if (o1 > a1 || (o1 == a1 && ok < k1)) { a1 = o1; c1 = v1; k1 = ok; }
+    }
+    if (lane < 32 && act) {
+      s_pv[wave * 64 + 2 * q] = a0 < 0.0 ? 0.0 : c0; s_pk[wave * 64 + 2 * q] = a0 < 0.0 ? 0x7fffffff : k0;
+      s_pv[wave * 64 + 2 * q + 1] = a1 < 0.0 ? 0.0 : c1; s_pk[wave * 64 + 2 * q + 1] = a1 < 0.0 ? 0x7fffffff : k1;
+    }
+    __syncthreads();
+    double* xv = vpos + (size_t)me * 128;  // this workgroup's message: 64 values, 64 rows
+    if (tid < n2) {
+      double bv = s_pv[tid];
+      int bk = s_pk[tid];
+      for (int w = 1; w < kReplayWaves; ++w) {
+        const double v = s_pv[w * 64 + tid];
+        const int kk = s_pk[w * 64 + tid];
+        if (kk != 0x7fffffff && (bk == 0x7fffffff || fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && kk < bk))) { bv = v; bk = kk; }
+      }
+      s_bv[tid] = bv; s_bk[tid] = bk;
+      s_rank[tid] = meta[8 + tid];
+      if (nb > 1) {
+        __hip_atomic_store(xv + tid, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(xv + 64 + tid, (double)bk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (nb > 1) {
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_store(meta + 2 + me, launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        for (int o = 0; o < nb; ++o)
+          while (__hip_atomic_load(meta + 2 + o, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != launch_id) __builtin_amdgcn_s_sleep(8);
+      }
+      __syncthreads();
+      if (tid < n2) {
+        double bv = s_bv[tid];
+        int bk = s_bk[tid];
+        for (int o = 0; o < nb; ++o) {
+          if (o == me) continue;
+          const double v = __hip_atomic_load(vpos + (size_t)o * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int kk = (int)__hip_atomic_load(vpos + (size_t)o * 128 + 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (kk != 0x7fffffff && (bk == 0x7fffffff || fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && kk < bk))) { bv = v; bk = kk; }
+        }
+        s_bv[tid] = bv;
+      }
+    }
+    __syncthreads();
+    if (mine) {
+      const int p0 = 2 * q, p1 = 2 * q + 1, r0 = s_rank[p0], r1 = s_rank[p1];
+      if (r0 < r) {
+        const double v = s_bv[p0] < 0.0 ? -x0 : x0;
+        Vout[(size_t)k * r + r0] = v; Vtout[(size_t)r0 * r + k] = v;
+      }
+      if (r1 < r) {
+        const double v = s_bv[p1] < 0.0 ? -x1 : x1;
+        Vout[(size_t)k * r + r1] = v; Vtout[(size_t)r1 * r + k] = v;
+      }
+    }
+  }
+#ifdef ICP_EIGEN_TIMING
+  if (blockIdx.x == 1 && tid == 0) g_eigen_stamps[42] = __builtin_amdgcn_s_memrealtime();
+#endif
+  // the last workgroup out puts the shared words back to idle (the producer has long finished; nobody reads them any more)
   __syncthreads();
-  if (tid == 0) s_last = atomicAdd(&meta[1], 1) == (int)gridDim.x - 2;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  if (tid == 0) {  // ready for the next decomposition (the producer has long finished; nobody reads these any more)
+  if (tid == 0 && atomicAdd(&meta[1], 1) == nb - 1) {
     meta[1] = 0;
     __hip_atomic_store(meta, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (aborted) return;
-  // Stage the whole position-major V in LDS (row stride 65: conflict-free column walks); one wave per position finds the
-  // sign (largest-|.| component, the first one among equals, made positive); then the columns go out in rank order.
-  double* s_v = s_dyn;
-  double* s_sgn = s_dyn + 64 * 65;
-  for (int e = tid; e < n2 * 64; e += blockDim.x) s_v[(e >> 6) * 65 + (e & 63)] = __builtin_nontemporal_load(vpos + e);
-  __syncthreads();
-  for (int pos = wave; pos < n2; pos += (int)(blockDim.x >> 6)) {
-    const double v = lane < r ? s_v[pos * 65 + lane] : 0.0;
-    double bv = lane < r ? fabs(v) : -1.0;
-    int bi = lane;
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) s_sgn[pos] = s_v[pos * 65 + bi] < 0.0 ? -1.0 : 1.0;
-  }
-  __syncthreads();
-  for (int e = tid; e < n2 * 64; e += blockDim.x) {
-    const int pos = e >> 6, kk = e & 63, rank = meta[4 + pos];
-    if (kk < r && rank < r) {
-      const double v = s_v[pos * 65 + kk] * s_sgn[pos];
-      Vout[(size_t)kk * r + rank] = v;
-      Vtout[(size_t)rank * r + kk] = v;
-    }
+    for (int o = 0; o < nb; ++o) __hip_atomic_store(meta + 2 + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -612,7 +667,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     eigen_replay_consumer(r, Vwarm, rotlog, meta, vpos, Vout, Vtout, launch_id);
     return;
   }
-  __shared__ double s_red[16], s_mu[64];
+  __shared__ double s_red[16], s_red2[16], s_mu[64];
   __shared__ int s_cancel;
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int n2 = (r + 1) & ~1, m = n2 >> 1;
@@ -804,23 +859,36 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
   auto sweep_end = [&](int cur) {  // -> stop?
     EIG_STAMP(4 + 2 * n_sweeps);
     in_sweep = 0;
-    // this sweep's rotations are in the log: let the replay workgroups have them while the convergence test runs
+    // this sweep's rotations are in the log: the replay workgroups may have them (published behind the barrier below)
     if (wave == kRrLogWave) __threadfence();
+    // convergence: off(A)² <= 1e-26·Σ diag².  Thread (row, 4 columns) over the stored upper triangle; one barrier.
+    double off = 0.0, dg = 0.0;
+    {
+      const int i = tid >> 4, j0 = (tid & 15) << 2;
+      if (i < n2 && j0 + 3 >= i && j0 < n2) {
+        const dbl2 u = lds2(&LDS_A(cur, i * ld + j0)), w = lds2(&LDS_A(cur, i * ld + j0 + 2));
+        const double v[4] = {u.x, u.y, w.x, w.y};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int j = j0 + c;
+          if (j < n2) {
+            if (j == i) { if (v[c] < 1e299) dg = fma(v[c], v[c], dg); }
+            else if (j > i) off = fma(2.0 * v[c], v[c], off);
+          }
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
+    if (lane == 0) { s_red[wave] = off; s_red2[wave] = dg; }
     __syncthreads();
     if (tid == 0) progress_publish(meta, launch_id, n_rounds, 0);
-    double off = 0.0, dg = 0.0;
-    for (int e = tid; e < n2 * n2; e += nt) {
-      const int i = e / n2, j = e - i * n2;
-      const double v = LDS_A(cur, i * ld + j);
-      if (i == j) { if (v < 1e299) dg = fma(v, v, dg); }
-      else if (i < j) off = fma(2.0 * v, v, off);
-    }
-    off = block_sum(off, s_red);
-    dg = block_sum(dg, s_red);
-    converged = off <= 1e-26 * dg;  // (block_sum's barriers also order the poll thread's s_cancel store before this read)
+    off = 0.0; dg = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { off += s_red[w]; dg += s_red2[w]; }
+    converged = off <= 1e-26 * dg;
     ++n_sweeps;
     EIG_STAMP(3 + 2 * n_sweeps);
-    return converged || n_sweeps >= max_sweeps || s_cancel;
+    return converged || n_sweeps >= max_sweeps || s_cancel;  // (s_cancel: stored by the poll thread rounds ago)
   };
   int cur = 0, polled = 0x80000000;
   const int poll_use = (n2 - 1) >> 2;
@@ -852,7 +920,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     int rank = 0;
     const double mi = s_mu[tid];
     for (int j = 0; j < n2; ++j) rank += (s_mu[j] < mi) || (s_mu[j] == mi && j < tid);
-    meta[4 + tid] = rank;
+    meta[8 + tid] = rank;
     if (rank < r) Sout[rank] = 1.0 / mi;
     __threadfence();
   }

@@ -54,7 +54,8 @@ int main(int argc, char** argv) {
     printf("%-22s r=%d: %.1f us/call, sweeps %d, status %d | init %.1f warm %.1f setup %.1f", name, r, ms * 1000 / reps, stat[0], stat[1],
            (s[1] - s[0]) * 0.01, (s[2] - s[1]) * 0.01, (s[3] - s[2]) * 0.01);
     for (int w = 0; w < stat[0] && w < 12; ++w) printf(" | sweep%d %.1f chk %.1f", w, (s[4 + 2 * w] - (w ? s[3 + 2 * w] : s[3])) * 0.01, (s[5 + 2 * w] - s[4 + 2 * w]) * 0.01);
-    printf(" | final %.1f\n", (s[63] - s[62]) * 0.01);
+    printf(" | final %.1f || replay after the producer's end: sees it %.1f, rounds done %.1f, output written %.1f\n", (s[63] - s[62]) * 0.01,
+           (s[40] - s[63]) * 0.01, (s[41] - s[63]) * 0.01, (s[42] - s[63]) * 0.01);
 
   };
   {  // ---- posterior factorisation (Cholesky + solve) on the same matrix: Mpart = [M − I, b; bᵀ, 0], one split
