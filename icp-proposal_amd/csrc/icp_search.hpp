@@ -24,16 +24,33 @@ __device__ __forceinline__ float4 tri_sphere(const double* __restrict__ verts, c
   return make_float4((float)m.x, (float)m.y, (float)m.z, round_up_f32(R));
 }
 
-// append `value` to list[...] for the lanes with `hit`, one atomic per wave; `m` = ballot of hit (non-zero)
-__device__ __forceinline__ void wave_append(unsigned long long m, bool hit, int* __restrict__ counter, int* __restrict__ list, int value) {
-  const int leader = __ffsll((long long)m) - 1;
-  int base = 0;
-  if (lane_id() == leader) base = atomicAdd(counter, __popcll(m));
-  base = __shfl(base, leader, 64);
-  if (hit) {
-    const unsigned long long below = m & ((1ull << lane_id()) - 1ull);
-    list[base + __popcll(below)] = value;
+// Candidate lists of the filter loops.  A hit costs an atomic round trip to L2 before its list entries can
+// be stored; taken one query after the other, the few waves whose elements lie near many queries spend most of a filter
+// launch waiting for those round trips.  Instead the wave parks each (query, hit mask) event in the registers of ONE
+// lane — lane e keeps event e — and carries on; at the end (or when 64 events are parked) every lane settles its own
+// event: one atomic per event, all of them in flight together, then the lane writes the entries of its mask itself (the
+// element behind bit b of a mask is known from the wave's position).  The order of a list's entries is irrelevant — the
+// resolve step takes the lexicographic (distance, index) minimum — and its counter ends at the number of entries.
+struct ParkedHits {
+  int n = 0;                       // wave-uniform
+  int k = 0;                       // per lane: the event this lane holds
+  unsigned long long m0 = 0, m1 = 0;
+};
+__device__ __forceinline__ void park_hits(ParkedHits& ph, int k, unsigned long long m0, unsigned long long m1) {
+  if (lane_id() == ph.n) { ph.k = k; ph.m0 = m0; ph.m1 = m1; }
+  ++ph.n;
+}
+// element behind bit b of mask w (w = 0, 1): first + b·step + w
+__device__ __forceinline__ void settle_hits(ParkedHits& ph, int* __restrict__ cnt, int* __restrict__ cand, size_t stride, int first, int step) {
+  if (lane_id() < ph.n) {
+    const int n0 = __popcll(ph.m0), n1 = __popcll(ph.m1);
+    int* list = cand + (size_t)ph.k * stride + atomicAdd(cnt + ph.k, n0 + n1);
+    unsigned long long m = ph.m0;
+    while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; *list++ = first + b * step; }
+    m = ph.m1;
+    while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; *list++ = first + b * step + 1; }
   }
+  ph.n = 0;
 }
 
 // lexicographic (d², index) minimum across the wave
@@ -79,42 +96,52 @@ __device__ __forceinline__ void surface_init(const SurfaceTask& q, int k) {
 constexpr int kSpheresPerLane = 2;
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
+constexpr int kFilterTile = 128;  // queries staged in LDS at a time
+
 __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int by) {
+  __shared__ float4 s_q[kFilterTile];
+  __shared__ float s_thr[kFilterTile];
   const int t0 = (bx * kSearchBlock + threadIdx.x) * kSpheresPerLane;
   const bool v0 = t0 < q.T, v1 = t0 + 1 < q.T;
-  f2_t cx = {3e38f, 3e38f}, cy = cx, cz = cx, R = {0.f, 0.f};  // out-of-range lanes: infinitely far away
+  // out-of-range lanes: centre NaN — their squared distance is NaN and passes no threshold, not even an infinite one
+  // (a query without a usable hint has bound +inf: everything in range is a candidate)
+  f2_t cx = {__builtin_nanf(""), __builtin_nanf("")}, cy = cx, cz = cx, R = {0.f, 0.f};
   if (v0) { const float4 s = q.spheres[t0]; cx.x = s.x; cy.x = s.y; cz.x = s.z; R.x = s.w; }
   if (v1) { const float4 s = q.spheres[t0 + 1]; cx.y = s.x; cy.y = s.y; cz.y = s.z; R.y = s.w; }
-  const float4* __restrict__ qrec = q.qrec;
-  const float* __restrict__ thrA = q.thrA;
   const int k0 = by * q.kchunk;
   const int k1 = min(q.Kpad, k0 + q.kchunk);
-  for (int k = k0; k < k1; k += kQU) {
-    bool h0[kQU], h1[kQU];
-    unsigned long long m0[kQU], m1[kQU];
+  ParkedHits ph;
+  const int first = (bx * kSearchBlock + (threadIdx.x & ~63)) * kSpheresPerLane;  // triangle of lane 0's first sphere
+  for (int kt = k0; kt < k1; kt += kFilterTile) {
+    // this workgroup's queries go through LDS: one coalesced read per tile, then every lane reads the same record
+    // (broadcast, conflict free) — the loop below never waits for global memory
+    const int nq = min(kFilterTile, k1 - kt);  // multiple of kQU
+    if (kt != k0) __syncthreads();
+    if ((int)threadIdx.x < nq) { s_q[threadIdx.x] = q.qrec[kt + threadIdx.x]; s_thr[threadIdx.x] = q.thrA[kt + threadIdx.x]; }
+    __syncthreads();
+    for (int k = 0; k < nq; k += kQU) {
+      unsigned long long m0[kQU], m1[kQU];
 #pragma unroll
-    for (int u = 0; u < kQU; ++u) {  // wave-uniform query records: scalar loads, kQU queries in flight
-      const float4 qq = qrec[k + u];
-      const float th = thrA[k + u];
-      const f2_t tt = f2_t{th, th} + R;
-      const f2_t dx = f2_t{qq.x, qq.x} - cx, dy = f2_t{qq.y, qq.y} - cy, dz = f2_t{qq.z, qq.z} - cz;
-      const f2_t dc2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-      const f2_t t2 = tt * tt;
-      h0[u] = v0 && dc2.x <= t2.x;
-      h1[u] = v1 && dc2.y <= t2.y;
-      m0[u] = __ballot(h0[u]);
-      m1[u] = __ballot(h1[u]);
-    }
+      for (int u = 0; u < kQU; ++u) {
+        const float4 qq = s_q[k + u];
+        const float th = s_thr[k + u];
+        const f2_t tt = f2_t{th, th} + R;
+        const f2_t dx = f2_t{qq.x, qq.x} - cx, dy = f2_t{qq.y, qq.y} - cy, dz = f2_t{qq.z, qq.z} - cz;
+        const f2_t dc2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        const f2_t t2 = tt * tt;
+        m0[u] = __ballot(dc2.x <= t2.x);
+        m1[u] = __ballot(dc2.y <= t2.y);
+      }
 #pragma unroll
-    for (int u = 0; u < kQU; ++u) {
-      if ((m0[u] | m1[u]) != 0ull) {  // uniform branch, rarely taken
-        int* cnt = q.cnt + (k + u);
-        int* list = q.cand + (size_t)(k + u) * q.stride;
-        if (m0[u] != 0ull) wave_append(m0[u], h0[u], cnt, list, t0);
-        if (m1[u] != 0ull) wave_append(m1[u], h1[u], cnt, list, t0 + 1);
+      for (int u = 0; u < kQU; ++u) {
+        if ((m0[u] | m1[u]) != 0ull) {  // uniform branch, rarely taken
+          park_hits(ph, kt + k + u, m0[u], m1[u]);
+          if (ph.n == 64) settle_hits(ph, q.cnt, q.cand, q.stride, first, kSpheresPerLane);
+        }
       }
     }
   }
+  settle_hits(ph, q.cnt, q.cand, q.stride, first, kSpheresPerLane);
 }
 
 // one wave per query.  Returns (all lanes) the winner, its squared distance and its closest point; lane 0 writes the
@@ -187,8 +214,9 @@ __device__ __forceinline__ void vertex_filter(const VertexTask& q, int bx, int b
   const double* __restrict__ thr2 = q.thr2;
   const int k0 = by * q.kchunk;
   const int k1 = min(q.Kpad, k0 + q.kchunk);
+  ParkedHits ph;
+  const int first = bx * kSearchBlock + (threadIdx.x & ~63);
   for (int k = k0; k < k1; k += kQU) {
-    bool hit[kQU];
     unsigned long long m[kQU];
 #pragma unroll
     for (int u = 0; u < kQU; ++u) {
@@ -196,13 +224,16 @@ __device__ __forceinline__ void vertex_filter(const VertexTask& q, int bx, int b
       d3 p = {P[3 * kk], P[3 * kk + 1], P[3 * kk + 2]};  // wave-uniform
       d3 d = sub(p, e);
       const double d2 = dot(d, d);  // (dx·dx + dy·dy) + dz·dz, unfused — the value the argmin is defined on
-      hit[u] = valid && d2 <= thr2[k + u];
-      m[u] = __ballot(hit[u]);
+      m[u] = __ballot(valid && d2 <= thr2[k + u]);
     }
 #pragma unroll
     for (int u = 0; u < kQU; ++u)
-      if (m[u] != 0ull) wave_append(m[u], hit[u], q.cnt + (k + u), q.cand + (size_t)(k + u) * q.stride, v);
+      if (m[u] != 0ull) {
+        park_hits(ph, k + u, m[u], 0ull);
+        if (ph.n == 64) settle_hits(ph, q.cnt, q.cand, q.stride, first, 1);
+      }
   }
+  settle_hits(ph, q.cnt, q.cand, q.stride, first, 1);
 }
 
 __device__ __forceinline__ void vertex_resolve(const VertexTask& q, int k, double* best_out, int* idx_out) {
