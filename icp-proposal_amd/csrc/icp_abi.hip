@@ -1663,6 +1663,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
                                             c.hint_surf.p, qs, s.surf_cp.p, s.surf_d2.p, s.surf_tri.p);
     VertexTask st_vert{};
     if (pt) st_vert = make_vertex_task(c.N, s.x.p, pt->K, pt->target_pts.p, pt->hint_nn.p, qv, nullptr, pt->nn_id.p);
+    st_vert.thr2 = nullptr;  // bounds are computed by the filter launch itself (see vertex_filter)
 
     // 1: coefficients -> instance -> bounds
     StepBeginArgs b{};

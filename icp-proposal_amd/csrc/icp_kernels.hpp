@@ -206,6 +206,9 @@ struct ProposeIn {   // a8 inputs (all device pointers; z may also point into ke
   const double* c; const double* z; double sigma2, step;
 };
 
+constexpr int kStepBeginPoints = 128;  // model points per workgroup of the first launch (256 threads; half of them carry a point:
+                                       // the instance streams 24·r bytes per point through ONE CU's L2 port, so the points are
+                                       // spread over twice as many CUs as threads alone would need)
 constexpr int kStepInlineZ = 128;  // ranks up to this pass the r host-drawn numbers inside the kernel arguments
 constexpr int kStepMaxOut = 6;
 

@@ -68,7 +68,20 @@ __device__ __forceinline__ void wave_lexmin(double& d2, int& idx) {
 // Entries K..Kpad-1 are sentinels (a point at 1e30 with bound 0) so the filter can run unrolled without guards.
 // `p` = the query point (q.P[k] for k < K; ignored for sentinel slots), passed in so that a producer kernel can
 // initialise a query from a point it has just computed
-__device__ __forceinline__ void surface_init_at(const SurfaceTask& q, int k, d3 p) {
+// (the hinted triangle's corners are fetched by the caller — a producer kernel does that ahead of the point itself)
+struct HintTriangle { bool have; d3 a, b, c; };
+__device__ __forceinline__ HintTriangle load_hint_triangle(const SurfaceTask& q, int k) {
+  HintTriangle ht{false, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  if (k >= q.K) return ht;
+  const int h = q.hint ? q.hint[k] : -1;
+  if (h >= 0 && h < q.T) {
+    const int ia = q.tris[3 * h], ib = q.tris[3 * h + 1], ic = q.tris[3 * h + 2];
+    ht.have = true;
+    ht.a = ld3(q.verts + 3 * ia); ht.b = ld3(q.verts + 3 * ib); ht.c = ld3(q.verts + 3 * ic);
+  }
+  return ht;
+}
+__device__ __forceinline__ void surface_init_with(const SurfaceTask& q, int k, d3 p, const HintTriangle& ht) {
   if (k >= q.Kpad) return;
   q.cnt[k] = 0;
   if (k >= q.K) {
@@ -76,13 +89,18 @@ __device__ __forceinline__ void surface_init_at(const SurfaceTask& q, int k, d3 
     q.thrA[k] = 0.f;
     return;
   }
-  int h = q.hint ? q.hint[k] : -1;
   double d2 = __builtin_inf();
-  if (h >= 0 && h < q.T) d2 = tri_dist2(p, q.verts, q.tris, h, nullptr);
+  if (ht.have) {  // = tri_dist2 of the hinted triangle
+    const d3 d = sub(p, closest_point_triangle(p, ht.a, ht.b, ht.c));
+    d2 = dot(d, d);
+  }
   if (!(d2 == d2)) d2 = __builtin_inf();  // degenerate hint triangle
   const double slack = kAbsSlack * (fabs(p.x) + fabs(p.y) + fabs(p.z));
   q.qrec[k] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f);
   q.thrA[k] = round_up_f32(sqrt(d2) * (1.0 + 2e-6) + slack);
+}
+__device__ __forceinline__ void surface_init_at(const SurfaceTask& q, int k, d3 p) {
+  surface_init_with(q, k, p, load_hint_triangle(q, k));
 }
 __device__ __forceinline__ void surface_init(const SurfaceTask& q, int k) {
   d3 p = {0.0, 0.0, 0.0};
@@ -205,33 +223,58 @@ __device__ __forceinline__ void vertex_init(const VertexTask& q, int k) {
   vertex_init_at(q, k, have, e);
 }
 
+// bound of query k, as vertex_init_at stores it: squared distance to the previous winner (−1 for a sentinel slot)
+__device__ __forceinline__ double vertex_bound(const VertexTask& q, int k) {
+  if (k >= q.K) return -1.0;
+  const int h = q.hint ? q.hint[k] : -1;
+  double d2 = __builtin_inf();
+  if (h >= 0 && h < q.V) {
+    d3 d = sub(ld3(q.P + 3 * k), ld3(q.verts + 3 * h));
+    d2 = dot(d, d);
+  }
+  if (!(d2 == d2)) d2 = __builtin_inf();
+  return d2;
+}
+
+// The workgroup's query chunk goes through LDS (point + bound per query, every lane then reads the same record).  With
+// q.thr2 == nullptr the bounds are computed here from the hints instead of being read — the merged step does that: the
+// searched vertices (the new instance) are complete when this launch starts, whereas its first launch would have to
+// compute every hinted vertex a second time.
 __device__ __forceinline__ void vertex_filter(const VertexTask& q, int bx, int by) {
+  __shared__ double s_vq[kFilterTile][4];
   const int v = bx * kSearchBlock + threadIdx.x;
   const bool valid = v < q.V;
   d3 e = {0.0, 0.0, 0.0};
   if (valid) e = ld3(q.verts + 3 * v);
-  const double* __restrict__ P = q.P;
-  const double* __restrict__ thr2 = q.thr2;
   const int k0 = by * q.kchunk;
   const int k1 = min(q.Kpad, k0 + q.kchunk);
   ParkedHits ph;
   const int first = bx * kSearchBlock + (threadIdx.x & ~63);
-  for (int k = k0; k < k1; k += kQU) {
-    unsigned long long m[kQU];
-#pragma unroll
-    for (int u = 0; u < kQU; ++u) {
-      const int kk = min(k + u, q.K - 1);  // sentinel slots re-read the last real query; their bound is -1
-      d3 p = {P[3 * kk], P[3 * kk + 1], P[3 * kk + 2]};  // wave-uniform
-      d3 d = sub(p, e);
-      const double d2 = dot(d, d);  // (dx·dx + dy·dy) + dz·dz, unfused — the value the argmin is defined on
-      m[u] = __ballot(valid && d2 <= thr2[k + u]);
+  for (int kt = k0; kt < k1; kt += kFilterTile) {
+    const int nq = min(kFilterTile, k1 - kt);  // multiple of kQU
+    if (kt != k0) __syncthreads();
+    if ((int)threadIdx.x < nq) {
+      const int k = kt + threadIdx.x, kk = min(k, q.K - 1);  // sentinel slots re-read the last real query; their bound is -1
+      s_vq[threadIdx.x][0] = q.P[3 * kk]; s_vq[threadIdx.x][1] = q.P[3 * kk + 1]; s_vq[threadIdx.x][2] = q.P[3 * kk + 2];
+      s_vq[threadIdx.x][3] = q.thr2 ? q.thr2[k] : vertex_bound(q, k);
     }
+    __syncthreads();
+    for (int k = 0; k < nq; k += kQU) {
+      unsigned long long m[kQU];
 #pragma unroll
-    for (int u = 0; u < kQU; ++u)
-      if (m[u] != 0ull) {
-        park_hits(ph, k + u, m[u], 0ull);
-        if (ph.n == 64) settle_hits(ph, q.cnt, q.cand, q.stride, first, 1);
+      for (int u = 0; u < kQU; ++u) {
+        const d3 p = {s_vq[k + u][0], s_vq[k + u][1], s_vq[k + u][2]};
+        d3 d = sub(p, e);
+        const double d2 = dot(d, d);  // (dx·dx + dy·dy) + dz·dz, unfused — the value the argmin is defined on
+        m[u] = __ballot(valid && d2 <= s_vq[k + u][3]);
       }
+#pragma unroll
+      for (int u = 0; u < kQU; ++u)
+        if (m[u] != 0ull) {
+          park_hits(ph, kt + k + u, m[u], 0ull);
+          if (ph.n == 64) settle_hits(ph, q.cnt, q.cand, q.stride, first, 1);
+        }
+    }
   }
   settle_hits(ph, q.cnt, q.cand, q.stride, first, 1);
 }
@@ -260,22 +303,47 @@ __device__ __forceinline__ void vertex_resolve(const VertexTask& q, int k, doubl
 
 // K1: one vertex of x = s(R(x̄ + μ + Q c − ctr) + ctr + t); Qp = scaled basis in planes [(j*3+d)*N + i].
 // Summed in basis order with separately rounded multiply and add (the value every search index is defined on).
-__device__ __forceinline__ d3 instance_point(int i, int N, int r, const double* __restrict__ Qp, const double* __restrict__ ref,
-                                             const double* __restrict__ mean, const Pose& pose, const double* coeffs) {
-  double a0 = mean[3 * i], a1 = mean[3 * i + 1], a2 = mean[3 * i + 2];
-  const double* q = Qp + i;
-  for (int j = 0; j < r; ++j) {
-    double c = coeffs[j];
-    a0 = a0 + q[(size_t)(3 * j) * N] * c;
-    a1 = a1 + q[(size_t)(3 * j + 1) * N] * c;
-    a2 = a2 + q[(size_t)(3 * j + 2) * N] * c;
+template <int kU>
+__device__ __forceinline__ void instance_batch(const double* __restrict__ q, int N, int r, const double* coeffs, int& j, double& a0,
+                                               double& a1, double& a2) {
+  for (; j + kU <= r; j += kU) {
+    double v[3 * kU];
+#pragma unroll
+    for (int u = 0; u < 3 * kU; ++u) v[u] = q[(size_t)(3 * j + u) * N];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const double c = coeffs[j + u];
+      a0 = a0 + v[3 * u] * c;
+      a1 = a1 + v[3 * u + 1] * c;
+      a2 = a2 + v[3 * u + 2] * c;
+    }
   }
+}
+// the rigid part of instance_point: x̄ + deformation -> posed point
+__device__ __forceinline__ d3 instance_pose(int i, const double* __restrict__ ref, const Pose& pose, double a0, double a1, double a2) {
   double u0 = ref[3 * i] + a0, u1 = ref[3 * i + 1] + a1, u2 = ref[3 * i + 2] + a2;
   double v0 = u0 - pose.ctr[0], v1 = u1 - pose.ctr[1], v2 = u2 - pose.ctr[2];
   double w0 = (pose.R[0] * v0 + pose.R[1] * v1) + pose.R[2] * v2;
   double w1 = (pose.R[3] * v0 + pose.R[4] * v1) + pose.R[5] * v2;
   double w2 = (pose.R[6] * v0 + pose.R[7] * v1) + pose.R[8] * v2;
   return {pose.s * ((w0 + pose.ctr[0]) + pose.t[0]), pose.s * ((w1 + pose.ctr[1]) + pose.t[1]), pose.s * ((w2 + pose.ctr[2]) + pose.t[2])};
+}
+__device__ __forceinline__ d3 instance_point(int i, int N, int r, const double* __restrict__ Qp, const double* __restrict__ ref,
+                                             const double* __restrict__ mean, const Pose& pose, const double* coeffs) {
+  double a0 = mean[3 * i], a1 = mean[3 * i + 1], a2 = mean[3 * i + 2];
+  const double* q = Qp + i;
+  int j = 0;
+  // the loop is bound by the latency of its loads (rows of Qp, 8·N bytes apart): 75, then 30 of them in flight per batch;
+  // the sums keep their order
+  instance_batch<25>(q, N, r, coeffs, j, a0, a1, a2);
+  instance_batch<10>(q, N, r, coeffs, j, a0, a1, a2);
+  for (; j < r; ++j) {
+    double c = coeffs[j];
+    a0 = a0 + q[(size_t)(3 * j) * N] * c;
+    a1 = a1 + q[(size_t)(3 * j + 1) * N] * c;
+    a2 = a2 + q[(size_t)(3 * j + 2) * N] * c;
+  }
+  return instance_pose(i, ref, pose, a0, a1, a2);
 }
 __device__ __forceinline__ void instance_vertex(int i, int N, int r, const double* __restrict__ Qp, const double* __restrict__ ref,
                                                 const double* __restrict__ mean, const Pose& pose, const double* coeffs,

@@ -32,6 +32,14 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) {
   __shared__ double s_c[512];
   const int tid = threadIdx.x, r = a.r;
   const double* zsrc = r <= kStepInlineZ ? a.zin : a.z_ptr;
+  const bool inst = (int)blockIdx.x < a.inst_blocks;
+  const int i = blockIdx.x * kStepBeginPoints + tid;
+  const bool my_point = inst && tid < kStepBeginPoints && i < a.N;
+  // what does not depend on the new coefficients is fetched first, so that its latency runs beside the proposal
+  // arithmetic: the corners of the triangle that bounds this thread's query
+  HintTriangle ht{false, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  const bool my_query = my_point && a.has_surf && i < a.surf.K;
+  if (my_query) ht = load_hint_triangle(a.surf, i);
   if (a.propose) {
     ProposeIn in = a.prop;
     in.z = zsrc;
@@ -45,27 +53,21 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) {
       const double c = s_c[j];
       for (int o = 0; o < a.n_out; ++o) a.out[o][j] = c;
     }
-  if ((int)blockIdx.x < a.inst_blocks) {
-    const int i = blockIdx.x * kStepBlock + tid;
-    if (i < a.N) {  // ModelFittingParameters.scala:108-110
+  if (inst) {
+    if (my_point) {  // ModelFittingParameters.scala:108-110
       const d3 p = instance_point(i, a.N, r, a.Qp, a.ref, a.mean, a.pose, s_c);
       a.x[3 * i] = p.x; a.x[3 * i + 1] = p.y; a.x[3 * i + 2] = p.z;
-      if (a.has_surf && i < a.surf.K) surface_init_at(a.surf, i, p);  // query i = model point i (:96)
+      if (my_query) surface_init_with(a.surf, i, p, ht);  // query i = model point i (:96)
     }
     if (a.has_surf && blockIdx.x == 0 && tid < kQU) {
       const int k = a.surf.K + tid;  // sentinel slots
       if (k < a.surf.Kpad) surface_init_at(a.surf, k, d3{0.0, 0.0, 0.0});
     }
   } else if (a.has_vert) {
-    // bound of each TargetSampling query = distance to the previous winner, whose NEW position is recomputed here
+    // TargetSampling queries: only the candidate counters are reset here; their bounds (distance to the previous winner at
+    // its NEW position) are taken by the filter launch, when the new instance is complete (vert.thr2 == nullptr)
     const int k = (blockIdx.x - a.inst_blocks) * kStepBlock + tid;
-    if (k < a.vert.Kpad) {
-      const int h = (a.vert.hint && k < a.vert.K) ? a.vert.hint[k] : -1;
-      const bool have = h >= 0 && h < a.vert.V;
-      d3 e = {0.0, 0.0, 0.0};
-      if (have) e = instance_point(h, a.N, r, a.Qp, a.ref, a.mean, a.pose, s_c);
-      vertex_init_at(a.vert, k, have, e);
-    }
+    if (k < a.vert.Kpad) a.vert.cnt[k] = 0;
   }
 }
 
@@ -214,7 +216,9 @@ void launch_finish(hipStream_t st, const StepFinishArgs& a, size_t shmem) {
 
 bool step_finish_supported(int r) { return finish_plan(r).ok; }
 
-void launch_step_begin(hipStream_t st, const StepBeginArgs& a) {
+void launch_step_begin(hipStream_t st, const StepBeginArgs& a_in) {
+  StepBeginArgs a = a_in;
+  a.inst_blocks = cdiv(a.N, kStepBeginPoints);
   const int vblocks = a.has_vert ? cdiv(a.vert.Kpad, kStepBlock) : 0;
   ProfScope _ps(st, KID_STEP_BEGIN);
   hipLaunchKernelGGL(k_step_begin, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
