@@ -1699,7 +1699,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     StepSearchArgs q{};
     q.n_surf = 1; q.n_vert = pt ? 1 : 0;
     q.s[0] = st_surf;
-    q.fstart[0] = 0; q.fstart[1] = st_surf.tblocks * st_surf.ksplit;
+    q.fstart[0] = 0; q.fstart[1] = filter_grid_blocks(st_surf.tblocks, st_surf.ksplit);
     q.rstart[0] = 0; q.rstart[1] = Ksurf;
     q.s_corr[0] = q.s_corr[1] = q.v_corr[0] = q.v_corr[1] = -1;
     int n_corr = 0;
@@ -1710,7 +1710,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     }
     if (pt) {
       q.v[0] = st_vert;
-      q.fstart[2] = q.fstart[1] + st_vert.vblocks * st_vert.ksplit;
+      q.fstart[2] = q.fstart[1] + filter_grid_blocks(st_vert.vblocks, st_vert.ksplit);
       q.rstart[2] = q.rstart[1] + pt->K;
       q.corr[n_corr] = CorrTask{pt->K, ep[it]->corr(), s.x.p, pt->target_pts.p, c.boundary.p, nullptr, pt->prm.boundary_aware,
                                 s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p};

@@ -228,6 +228,12 @@ struct StepBeginArgs {  // launch 1: [propose] -> coefficients -> instance -> se
   VertexTask vert;          // searched set = the NEW instance (TargetSampling)
 };
 
+// Filter grid of one task, XCD-aware: the `ksplit` workgroups that stream the SAME block of elements (one per query
+// chunk) get indices that are equal modulo 8, i.e. the same XCD under round-robin dispatch, so that the block is
+// fetched from HBM once and served to the others by that XCD's L2 (first-block index of the task must be a multiple of 8).
+//   index l  ->  element block (l / (8·ksplit))·8 + l % 8,  query chunk (l % (8·ksplit)) / 8
+inline int filter_grid_blocks(int elem_blocks, int ksplit) { return (elem_blocks + 7) / 8 * 8 * ksplit; }
+
 struct StepSearchArgs {  // launches 2 (filter) and 3 (resolve + correspondences)
   int n_surf, n_vert;
   int fstart[5];           // filter: first block of each task (surface tasks first), fstart[n] = grid size

@@ -75,18 +75,15 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) {
 
 __global__ void __launch_bounds__(kSearchBlock) k_step_filter(StepSearchArgs a) {
   const int b = blockIdx.x;
-  if (a.n_surf > 0 && b < a.fstart[1]) {
-    const int l = b - a.fstart[0];
-    surface_filter(a.s[0], l % a.s[0].tblocks, l / a.s[0].tblocks);
-  } else if (a.n_surf > 1 && b < a.fstart[2]) {
-    const int l = b - a.fstart[1];
-    surface_filter(a.s[1], l % a.s[1].tblocks, l / a.s[1].tblocks);
-  } else if (a.n_vert > 0 && b < a.fstart[a.n_surf + 1]) {
-    const int l = b - a.fstart[a.n_surf];
-    vertex_filter(a.v[0], l % a.v[0].vblocks, l / a.v[0].vblocks);
-  } else if (a.n_vert > 1) {
-    const int l = b - a.fstart[a.n_surf + 1];
-    vertex_filter(a.v[1], l % a.v[1].vblocks, l / a.v[1].vblocks);
+  int task = 0;
+  while (task + 1 < a.n_surf + a.n_vert && b >= a.fstart[task + 1]) ++task;
+  const int l = b - a.fstart[task];
+  const int ksplit = task < a.n_surf ? a.s[task].ksplit : a.v[task - a.n_surf].ksplit;
+  const int bx = l / (8 * ksplit) * 8 + (l & 7), by = (l % (8 * ksplit)) >> 3;  // see filter_grid_blocks
+  if (task < a.n_surf) {
+    if (bx < a.s[task].tblocks) surface_filter(a.s[task], bx, by);
+  } else {
+    if (bx < a.v[task - a.n_surf].vblocks) vertex_filter(a.v[task - a.n_surf], bx, by);
   }
 }
 
