@@ -286,14 +286,27 @@ static __host__ __device__ inline int factor_tile_count(int r) {
 }
 
 template <int TPT, int NT>
+// tail_base >= 0: the caller runs a transition tail on this posterior right afterwards — the assembled M is ALSO written
+// to s_dyn[tail_base + i·ld + j] and G⁻¹ (tail_Ginv) to s_dyn[tail_base + r·ld + …] (layout of tail_body), its loads
+// issued beside the partial sums', so that the tail finds both matrices in LDS instead of fetching them again.
 __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict__ Mpart, int S, double* __restrict__ M,
-                                                double* __restrict__ alpha_out, int* __restrict__ status) {
+                                                double* __restrict__ alpha_out, int* __restrict__ status, int tail_base = -1,
+                                                const double* __restrict__ tail_Ginv = nullptr) {
   __shared__ __attribute__((aligned(16))) double s_col[2][520];
   __shared__ double s_dinv[512], s_v[512];
   const int tid = threadIdx.x, n = r + 1;
   const int ld = r | 1;
   double* W = s_dyn;  // (r+1) × ld: the finished (unscaled) factor, row r = forward-eliminated bᵀ
   FAC_STAMP(16);
+  constexpr int kGinvPer = 16;  // elements of G⁻¹ per thread held in flight (covers r² <= 16·NT; the rest goes the slow way)
+  double ginv[kGinvPer];
+  if (tail_base >= 0) {
+#pragma unroll
+    for (int u = 0; u < kGinvPer; ++u) {
+      const int e = tid + u * NT;
+      ginv[u] = e < r * r ? tail_Ginv[e] : 0.0;
+    }
+  }
   const int n_tiles = factor_tile_count(r);
   double v[TPT][2][4];
   int R0[TPT], C0[TPT];
@@ -353,11 +366,21 @@ __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict_
             if (i == k) x += 1.0;
             M[(size_t)i * r + k] = x;
             M[(size_t)k * r + i] = x;
+            if (tail_base >= 0) { s_dyn[tail_base + i * ld + k] = x; s_dyn[tail_base + k * ld + i] = x; }
           }
           if (k == 0) { s_col[0][i] = x; W[(size_t)i * ld] = x; }
         }
         v[t][a][c] = x;
       }
+  }
+  if (tail_base >= 0) {
+    const int offG = tail_base + r * ld;
+#pragma unroll
+    for (int u = 0; u < kGinvPer; ++u) {
+      const int e = tid + u * NT;
+      if (e < r * r) { const int i = e / r; s_dyn[offG + i * ld + (e - i * r)] = ginv[u]; }
+    }
+    for (int e = tid + kGinvPer * NT; e < r * r; e += NT) { const int i = e / r; s_dyn[offG + i * ld + (e - i * r)] = tail_Ginv[e]; }
   }
   __syncthreads();
   FAC_STAMP(17);
@@ -466,13 +489,16 @@ __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict_
 
 __device__ __forceinline__ void tail_body(int r, const double* __restrict__ alpha, const double* __restrict__ Mg, const double* __restrict__ c_from,
                                           const double* __restrict__ c_to, double step, double* __restrict__ out, int* __restrict__ status,
-                                          const double* __restrict__ Ginv, double sigma2, int n_lds, int tpr_log2) {
+                                          const double* __restrict__ Ginv, double sigma2, int n_lds, int tpr_log2,
+                                          int lds_base = 0, bool prestaged = false) {
   __shared__ double s_d[512], s_g[512], s_t[512], s_u[512], s_red3[3][16];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int ld = r | 1;
-  const int offM = 0, offG = r * ld;
-  if (n_lds >= 1) stage_matrix_lds(r, Mg, offM, ld);
-  if (n_lds >= 2) stage_matrix_lds(r, Ginv, offG, ld);
+  const int offM = lds_base, offG = lds_base + r * ld;
+  if (!prestaged) {
+    if (n_lds >= 1) stage_matrix_lds(r, Mg, offM, ld);
+    if (n_lds >= 2) stage_matrix_lds(r, Ginv, offG, ld);
+  }
   auto mul_M = [&](const double* x, double* y) {
     if (n_lds >= 1) block_matvec_lds(r, offM, ld, x, y, tpr_log2);
     else block_matvec(r, Mg, r, x, y, tpr_log2);

@@ -263,6 +263,7 @@ struct StepRegressionArgs {  // launch 4: normal-equation partial sums of every 
 
 struct StepFinishArgs {  // launch 5: per posterior Cholesky + alpha, then the backward tail; forward tails beside them
   int n, r, n_lds, tpr_log2;
+  int tail_base;             // >= 0: LDS offset (doubles) where the factor workgroups stage M and G⁻¹ for their tail (set by the launcher)
   const double* Mpart[2]; int splits[2];
   double* M[2]; double* alpha[2]; int* status[2];      // status: the entry's 3 ints {chol, -, eigen}
   int* host_status[2];                                  // pinned copy of the Cholesky status

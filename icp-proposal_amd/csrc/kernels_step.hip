@@ -153,12 +153,14 @@ __global__ void __launch_bounds__(NT) k_step_finish(StepFinishArgs a) {
   const int b = blockIdx.x;
   if (b == 0 && threadIdx.x == 0 && a.ready_flag) __hip_atomic_store(a.ready_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (b < a.n) {
-    const bool ok = factor_reg_body<E, NT>(a.r, a.Mpart[b], a.splits[b], a.M[b], a.alpha[b], a.status[b]);
+    // (the matrices of the backward tail are put into LDS on the way, behind the factor's own region: a.tail_base)
+    const bool ok = factor_reg_body<E, NT>(a.r, a.Mpart[b], a.splits[b], a.M[b], a.alpha[b], a.status[b], a.tail_base, a.Ginv);
     if (threadIdx.x == 0) a.host_status[b][0] = ok ? 0 : 1;
     if (ok) {  // uniform
       __syncthreads();  // M and alpha of this posterior are complete (written by this workgroup)
       const TransitionTailIO& t = a.bwd[b];
-      tail_body(a.r, t.alpha, t.M, t.c_from, t.c_to, t.step, t.out, t.status, a.Ginv, a.sigma2, a.n_lds, a.tpr_log2);
+      tail_body(a.r, t.alpha, t.M, t.c_from, t.c_to, t.step, t.out, t.status, a.Ginv, a.sigma2, a.n_lds, a.tpr_log2,
+                a.tail_base >= 0 ? a.tail_base : 0, a.tail_base >= 0);
     } else if (threadIdx.x == 0) {
       a.bwd[b].out[0] = __builtin_nan("");
       a.bwd[b].status[0] = 0;
@@ -183,10 +185,10 @@ static void set_dyn_lds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-struct FinishPlan { int E /* tiles per thread */, NT, n_lds; size_t shmem; bool ok; };
+struct FinishPlan { int E /* tiles per thread */, NT, n_lds, tail_base; size_t shmem; bool ok; };
 
 FinishPlan finish_plan(int r) {
-  FinishPlan p{0, 0, 0, 0, false};
+  FinishPlan p{0, 0, 0, -1, 0, false};
   const int ld = r | 1;
   const size_t tiles = (size_t)factor_tile_count(r);
   const size_t w = (size_t)(r + 1) * ld, one = (size_t)r * ld;
@@ -198,7 +200,9 @@ FinishPlan finish_plan(int r) {
   else return p;
   p.n_lds = 2 * one <= budget ? 2 : (one <= budget ? 1 : 0);
   const size_t tails = one * p.n_lds;
-  p.shmem = sizeof(double) * (w > tails ? w : tails);
+  // the backward tail's matrices behind the factor's region when both fit (then the factor stages them on its way)
+  if (p.n_lds == 2 && w + tails <= budget) { p.tail_base = (int)w; p.shmem = sizeof(double) * (w + tails); }
+  else p.shmem = sizeof(double) * (w > tails ? w : tails);
   p.ok = true;
   return p;
 }
@@ -246,6 +250,7 @@ void launch_step_finish(hipStream_t st, const StepFinishArgs& a_in) {
   const FinishPlan p = finish_plan(a_in.r);
   StepFinishArgs a = a_in;
   a.n_lds = p.n_lds;
+  a.tail_base = p.tail_base;
   a.tpr_log2 = matvec_tpr_log2(a.r, p.NT);
   ProfScope _ps(st, KID_STEP_FINISH);
   if (p.E == 1 && p.NT == 256) launch_finish<1, 256>(st, a, p.shmem);
