@@ -8,6 +8,7 @@
 #include "../../include/icp_proposal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -235,6 +236,8 @@ struct icp_ctx {
                                // of its regression launch
   int* h_flag = nullptr;       // pinned: sequence number of the last finished step
   int step_seq = 0;
+  bool counted = false;          // included in g_live_contexts
+  bool speculation_off = false;  // a speculative decomposition timed out once (see resolve_speculation): not tried again
 
   Profiler prof;
   bool profiling = false;
@@ -399,6 +402,11 @@ struct HostTiming {
   }
 };
 HostTiming g_host_timing;
+
+// Contexts alive in this process.  The speculative decompositions of icp_chain_step keep a few workgroups waiting on the
+// device and put three streams per context to work; the runtime multiplexes streams onto four hardware queues, and beyond
+// two contexts (measured: tools/multichain.py) the waiting kernels cost the other chains more than they gain.
+std::atomic<int> g_live_contexts{0};
 
 struct PosteriorEntry {
   std::vector<double> theta;
@@ -644,6 +652,10 @@ void icp_proposal::resolve_speculation(const double* theta_cur) {
   if (!spec_entry) return;
   PosteriorEntry& e = *spec_entry;
   spec_entry = nullptr;
+  // A decomposition that gave up waiting for its input (k_posterior_eigen_rr) has said so in its pinned status.  That
+  // happens when the runtime puts its stream on a hardware queue ahead of the launch it waits for — many streams in one
+  // process, or a tool that serialises kernels — and each occurrence stalls the step for the time-out: once is enough.
+  if (h_eig[e.status_off / 3] == kEigenGaveUp) ctx->speculation_off = true;
   const size_t P = 10 + (size_t)ctx->r;
   if (e.valid && e.eig_valid && std::memcmp(e.theta.data(), theta_cur, sizeof(double) * P) == 0) {
     warm_ptr = e.V.p;  // accepted: this is the basis the next decompositions start from
@@ -922,6 +934,8 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->d_done.alloc(4);
     ctx->d_done.fill_bytes(0);
     HIP_OK(hipStreamSynchronize(ctx->stream));
+    ++g_live_contexts;
+    ctx->counted = true;
     *out = ctx;
   });
   if (rc != ICP_OK && ctx) {
@@ -943,6 +957,7 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+  if (ctx->counted) --g_live_contexts;
   delete ctx;
 }
 
@@ -1145,6 +1160,7 @@ void icp_proposal_destroy(icp_proposal* p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->eig_stream) { (void)hipStreamSynchronize(p->eig_stream); (void)hipStreamDestroy(p->eig_stream); }
+    if (g_host_timing.on && eigen_speculation_supported(p->ctx->r)) eigen_debug_dump(p->work.p, p->ctx->r);
     if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
     if (p->h_cancel) (void)hipHostFree(p->h_cancel);
     if (p->h_eig) (void)hipHostFree(p->h_eig);
@@ -1745,7 +1761,8 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     g.Kred = evp.n_model_ids; g.d2 = s.surf_d2.p; g.mean = evp.gauss_mean; g.sigma = evp.gauss_sigma;
     g.red_out = c.h_res;
     static const bool no_spec = std::getenv("ICP_NO_SPECULATION") != nullptr;
-    const bool speculate = !no_spec && n_props > 0 && eigen_speculation_supported(r);
+    const bool speculate = !no_spec && !c.speculation_off && g_live_contexts.load(std::memory_order_relaxed) <= 2 && n_props > 0 &&
+                           eigen_speculation_supported(r);
     // test hook: the speculative decompositions wait for a word that never comes, time out and are repeated
     static const int starve = std::getenv("ICP_TEST_STARVE_SPECULATION") ? (1 << 24) : 0;
     const int step_seq = ++c.step_seq;

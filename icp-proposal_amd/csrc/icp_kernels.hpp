@@ -167,6 +167,7 @@ size_t eigen_work_doubles(int r);  // size of `work`
 constexpr int kEigenGaveUp = 3;  // pinned status of a speculative decomposition whose input never arrived
 struct EigenSpec { int splits; const int* cancel; int seq; const int* ready; int ready_seq; };
 bool eigen_speculation_supported(int r);
+void eigen_debug_dump(const double* work, int r);
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
                             double* Vt, double* S, double* work /* eigen_work_doubles(r) */, int* status,
                             const EigenSpec* spec = nullptr, int* host_status = nullptr /* pinned copy of *status; honoured

@@ -9,6 +9,7 @@
 // These kernels are latency-bound r×r work (r = 51…201): one workgroup per matrix, data in LDS when it fits.
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 #include "icp_kernels.hpp"
@@ -886,6 +887,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
 #pragma unroll
     for (int w = 0; w < 16; ++w) { off += s_red[w]; dg += s_red2[w]; }
     converged = off <= 1e-26 * dg;
+    if (tid == 0 && n_sweeps < 8) ((double*)(meta + 80))[n_sweeps] = off / dg;  // diagnostic: off(A)²/Σdiag² after each sweep
     ++n_sweeps;
     EIG_STAMP(3 + 2 * n_sweeps);
     return converged || n_sweeps >= max_sweeps || s_cancel;  // (s_cancel: stored by the poll thread rounds ago)
@@ -908,6 +910,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     return;
   }
   if (tid == 0) {
+    ++meta[100 + min(n_sweeps, 15)];  // diagnostic: histogram of sweep counts on this work buffer
     status[0] = converged ? 0 : 2; status[-1] = n_sweeps;
     if (host_status) __hip_atomic_store(host_status, converged ? 0 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -1155,6 +1158,17 @@ size_t eigen_work_doubles(int r) {  // `work` of launch_posterior_eigen: r×r sc
   const size_t n2 = ((size_t)r + 1) & ~(size_t)1;
   const size_t log = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;  // 2 doubles per pair and round
   return std::max((size_t)r * r, log + n2 * 64 + 64);               // + position-major V + meta (see launch_posterior_eigen)
+}
+
+void eigen_debug_dump(const double* work, int r) {  // developer aid: convergence trace of the last decomposition on `work`
+  const size_t n2 = ((size_t)r + 1) & ~(size_t)1;
+  const size_t log_doubles = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;
+  double tr[8];
+  (void)hipMemcpy(tr, (const char*)(work + log_doubles + n2 * 64) + 80 * sizeof(int), sizeof(tr), hipMemcpyDeviceToHost);
+  std::fprintf(stderr, "[icp eigen] off^2/diag^2 after sweeps 1..: %.2e %.2e %.2e %.2e %.2e\n", tr[0], tr[1], tr[2], tr[3], tr[4]);
+  int hist[16];
+  (void)hipMemcpy(hist, (const char*)(work + log_doubles + n2 * 64) + 100 * sizeof(int), sizeof(hist), hipMemcpyDeviceToHost);
+  std::fprintf(stderr, "[icp eigen] decompositions by sweep count 1..8: %d %d %d %d %d %d %d %d\n", hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
 }
 
 bool eigen_speculation_supported(int r) { return r >= 3 && r <= 64 && std::getenv("ICP_EIGEN_GENERIC") == nullptr; }
