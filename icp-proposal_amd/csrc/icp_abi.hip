@@ -438,7 +438,7 @@ struct icp_proposal {
   int mpart_half = 0;
   hipEvent_t mpart_reader[2] = {nullptr, nullptr};  // completion of the last decomposition that reads the half (not owned)
   double* mpart_for_write(int half);                // the context stream waits for that reader first
-  DBuf<double> fscratch;  // (r+1)·r factorisation scratch (ranks too large for LDS)
+  DBuf<double> fscratch;  // (r+1)·r + 8 factorisation scratch (ranks too large for LDS)
   const double* warm_ptr = nullptr;  // eigenvectors of the most recent posterior (inside its memo entry): warm start of the next
   bool warm_valid = false;
   // Every eigen-decomposition of this proposal runs on its own stream (they share `work` and the warm start, so they must
@@ -1138,7 +1138,7 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     p->work.fill_bytes(0);  // holds the completion counter of the eigenvector replay kernel
     p->mpart_half_doubles = (size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1);
     p->Mpart.alloc(2 * p->mpart_half_doubles);
-    p->fscratch.alloc((size_t)(ctx->r + 1) * ctx->r);
+    p->fscratch.alloc((size_t)(ctx->r + 1) * ctx->r + 8);
     HIP_OK(hipHostMalloc((void**)&p->h_cancel, sizeof(int) * 16, hipHostMallocDefault));
     for (int i = 0; i < 16; ++i) p->h_cancel[i] = 0;
     HIP_OK(hipHostMalloc((void**)&p->h_eig, sizeof(int) * kPosteriorMemo, hipHostMallocDefault));
@@ -1381,7 +1381,7 @@ int icp_fit_deterministic(icp_ctx* ctx, const icp_fit_params* prm, const double*
     Mpart.alloc((size_t)regression_splits(Ka) * (r + 1) * (r + 1));
     M.alloc((size_t)r * r); alpha.alloc(r);
     DBuf<double> fscratch;
-    fscratch.alloc((size_t)(r + 1) * r);
+    fscratch.alloc((size_t)(r + 1) * r + 8);
     status.alloc(4); status.fill_bytes(0);
     const CorrBuffers cb{corr_id.p, aux.p, pt.p, keep.p, nhat.p, e.p};
     for (int si = 0; si < n_sigma; ++si) {

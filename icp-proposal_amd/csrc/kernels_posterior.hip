@@ -12,6 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <mutex>
+
+#include <rocsolver/rocsolver.h>
+
 #include "icp_kernels.hpp"
 #include "icp_dense.hpp"
 
@@ -193,15 +197,6 @@ __global__ void __launch_bounds__(1024) k_transition_tail_direct(int r, const do
 // Warm start: if `Vwarm` is given, the iteration starts from Vwarmᵀ N Vwarm (nearly diagonal when Vwarm diagonalised a
 // nearby posterior) with V = Vwarm, which cuts the number of sweeps roughly in half; the result is the same
 // eigen-decomposition (to rounding) either way.
-
-__device__ __forceinline__ void rr_pair(int n2, int rnd, int slot, int* p, int* q) {
-  const int m = n2 - 1;
-  int a, b;
-  if (slot == 0) { a = m; b = rnd % m; }
-  else { a = (rnd + slot) % m; b = (rnd - slot + m) % m; }
-  *p = a < b ? a : b;
-  *q = a < b ? b : a;
-}
 
 __global__ void __launch_bounds__(1024) k_posterior_eigen(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
                                                            const double* __restrict__ Vwarm, double* __restrict__ Vout,
@@ -1107,6 +1102,54 @@ static void launch_factor_reg(hipStream_t st, int r, int n_post, const FactorArg
   hipLaunchKernelGGL((k_posterior_factor_reg<TPT, NT>), dim3(n_post), dim3(NT), shmem, st, r, fa);
 }
 
+// ---------------------------------------------------------------- ranks whose factor does not fit one CU's LDS (r > 127)
+// Same framing as the eigensolver above: the assembly (split sums in split order, + I) and the status are ours, the
+// Cholesky factorisation and the two triangular solves are rocsolver_dpotrf / dpotrs (3.3 ms -> 0.3 ms at rank 200).
+// scratch: r² (factor) | r (right-hand side -> α) | 1 int (info)
+__global__ void __launch_bounds__(256) k_factor_lib_prepare(int r, const double* __restrict__ Mpart, int S, double* __restrict__ M,
+                                                            double* __restrict__ W, double* __restrict__ b) {
+  const int n = r + 1, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * r) return;
+  const int i = e / r, j = e - i * r;  // i == r: the appended row bᵀ = Maug[r][0..r-1]
+  const int hi = i < r ? max(i, j) : r, lo = i < r ? min(i, j) : j;  // the factor kernels read the lower triangle of the partials
+  double m = 0.0;
+  for (int s = 0; s < S; ++s) m += Mpart[(size_t)s * n * n + (size_t)hi * n + lo];
+  if (i < r) {
+    m += i == j ? 1.0 : 0.0;
+    M[e] = m;
+    W[e] = m;  // symmetric: row- = column-major
+  } else {
+    b[j] = m;
+  }
+}
+__global__ void __launch_bounds__(256) k_factor_lib_finish(int r, const double* __restrict__ b, const int* __restrict__ info,
+                                                           double* __restrict__ alpha, int* __restrict__ status) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < r) alpha[i] = b[i];
+  if (i == 0) status[0] = info[0] == 0 ? 0 : 1;
+}
+static rocblas_handle library_handle(hipStream_t st) {  // callers hold g_library_mutex
+  static rocblas_handle handle = nullptr;
+  if (!handle && rocblas_create_handle(&handle) != rocblas_status_success) handle = nullptr;
+  if (handle && rocblas_set_stream(handle, st) != rocblas_status_success) return nullptr;
+  return handle;
+}
+static std::mutex g_library_mutex;  // (the handle carries the stream; calls only enqueue)
+
+static bool launch_factor_library(hipStream_t st, int r, const PosteriorFactorIO& io) {
+  std::lock_guard<std::mutex> lk(g_library_mutex);
+  rocblas_handle handle = library_handle(st);
+  if (!handle) return false;
+  double* W = io.scratch;
+  double* b = W + (size_t)r * r;
+  int* info = (int*)(b + r);
+  hipLaunchKernelGGL(k_factor_lib_prepare, dim3(((r + 1) * r + 255) / 256), dim3(256), 0, st, r, io.Mpart, io.splits, io.M, W, b);
+  if (rocsolver_dpotrf(handle, rocblas_fill_lower, r, W, r, info) != rocblas_status_success) return false;
+  if (rocsolver_dpotrs(handle, rocblas_fill_lower, r, 1, W, r, b, r) != rocblas_status_success) return false;
+  hipLaunchKernelGGL(k_factor_lib_finish, dim3((r + 255) / 256), dim3(256), 0, st, r, b, info, io.alpha, io.status);
+  return true;
+}
+
 void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io) {
   FactorArgs fa{};
   for (int p = 0; p < n_post; ++p) {
@@ -1121,6 +1164,12 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
   else if (w_fits && tiles <= 1024) launch_factor_reg<1, 1024>(st, r, n_post, fa);
   else if (w_fits && tiles <= 2048) launch_factor_reg<2, 1024>(st, r, n_post, fa);
   else {
+    static const bool own_generic = std::getenv("ICP_FACTOR_GENERIC") != nullptr;
+    if (!own_generic) {
+      bool ok = true;
+      for (int p = 0; p < n_post && ok; ++p) ok = launch_factor_library(st, r, io[p]);
+      if (ok) return;
+    }
     const int use_lds = (size_t)(r + 1) * ld <= (size_t)kLdsDoubles;
     const size_t shmem = use_lds ? sizeof(double) * (size_t)(r + 1) * ld : 0;
     set_dyn_lds((const void*)k_posterior_factor_generic, shmem);
@@ -1157,7 +1206,68 @@ void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO
 size_t eigen_work_doubles(int r) {  // `work` of launch_posterior_eigen: r×r scratch, or the rotation log of the fixed-position variant
   const size_t n2 = ((size_t)r + 1) & ~(size_t)1;
   const size_t log = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;  // 2 doubles per pair and round
-  return std::max((size_t)r * r, log + n2 * 64 + 64);               // + position-major V + meta (see launch_posterior_eigen)
+  return std::max((size_t)r * r + 2 * (size_t)r + 8, log + n2 * 64 + 64);  // library path: matrix, eigenvalues, scratch, info |
+                                                                              // log + sign exchange + meta (see launch_posterior_eigen)
+}
+
+// ---------------------------------------------------------------- ranks > 64: library eigensolver between two small kernels
+// The fixed-position Jacobi kernel keeps the matrix in ONE CU's LDS, which ends at rank 64; the generic kernel further up
+// runs out of that CU's L2 port (68 ms at rank 200).  The ranks of the face configurations therefore go through
+// rocsolver_dsyevd (tridiagonalisation + divide & conquer, 4.3 ms at rank 200, 1.6 ms at 101 — tools/syevd_probe) — a
+// library call on a path the headline configuration never takes — framed by the same conventions as the kernels above:
+// N = D⁻¹MD⁻¹ in, S = 1/μ descending, eigenvector signs by their largest-|.| component.
+__global__ void __launch_bounds__(256) k_eigen_lib_prepare(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
+                                                           double* __restrict__ A) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= r * r) return;
+  const int i = e / r, j = e - i * r;
+  A[e] = 0.5 * (M[(size_t)i * r + j] + M[(size_t)j * r + i]) / (sqrt_lambda[i] * sqrt_lambda[j]);  // symmetric: row- = column-major
+}
+// one wave per eigenvector (column `c` of the column-major result, eigenvalues ascending => rank = c)
+__global__ void __launch_bounds__(64) k_eigen_lib_finalize(int r, const double* __restrict__ Z, const double* __restrict__ mu,
+                                                           const int* __restrict__ info, double* __restrict__ Vout,
+                                                           double* __restrict__ Vtout, double* __restrict__ Sout, int* __restrict__ status,
+                                                           int* __restrict__ host_status) {
+  const int c = blockIdx.x, l = threadIdx.x;
+  const double* z = Z + (size_t)c * r;
+  double bv = -1.0;
+  int bi = 0x7fffffff;
+  for (int k = l; k < r; k += 64) {
+    const double a = fabs(z[k]);
+    if (a > bv) { bv = a; bi = k; }  // (ascending k within a lane: the first among equals stays)
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  const double sgn = z[bi] < 0.0 ? -1.0 : 1.0;
+  for (int k = l; k < r; k += 64) {
+    const double v = z[k] * sgn;
+    Vout[(size_t)k * r + c] = v;
+    Vtout[(size_t)c * r + k] = v;
+  }
+  if (l == 0) Sout[c] = 1.0 / mu[c];
+  if (c == 0 && l == 0) {
+    const int st = info[0] == 0 ? 0 : 2;
+    status[0] = st; status[-1] = 0;
+    if (host_status) __hip_atomic_store(host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+static bool launch_eigen_library(hipStream_t st, int r, const double* M, const double* sqrt_lambda, double* V, double* Vt, double* S,
+                                 double* work, int* status, int* host_status) {
+  std::lock_guard<std::mutex> lk(g_library_mutex);
+  rocblas_handle handle = library_handle(st);
+  if (!handle) return false;
+  double* A = work;                       // r² : N in, eigenvectors (columns) out
+  double* D = work + (size_t)r * r;       // r  : eigenvalues, ascending
+  double* E = D + r;                      // r  : scratch of the tridiagonal form
+  int* info = (int*)(E + r);
+  hipLaunchKernelGGL(k_eigen_lib_prepare, dim3((r * r + 255) / 256), dim3(256), 0, st, r, M, sqrt_lambda, A);
+  if (rocsolver_dsyevd(handle, rocblas_evect_original, rocblas_fill_upper, r, A, r, D, E, info) != rocblas_status_success) return false;
+  hipLaunchKernelGGL(k_eigen_lib_finalize, dim3(r), dim3(64), 0, st, r, A, D, info, V, Vt, S, status, host_status);
+  return true;
 }
 
 void eigen_debug_dump(const double* work, int r) {  // developer aid: convergence trace of the last decomposition on `work`
@@ -1197,6 +1307,11 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
     hipLaunchKernelGGL(k_posterior_eigen_rr, dim3(1 + n_replay), dim3(1024), shmem, st, r, M, sqrt_lambda, Vwarm, V, Vt, S, status, ldk,
                        rotlog, meta, vpos, std::min(sweeps_cap, kEigenMaxSweeps), spec ? *spec : EigenSpec{0, nullptr, 0, nullptr, 0}, launch_id, host_status);
     return;
+  }
+  static const bool own_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
+  if (!own_generic && r > 64) {
+    ProfScope _ps(st, KID_EIGEN);
+    if (launch_eigen_library(st, r, M, sqrt_lambda, V, Vt, S, work, status, host_status)) return;
   }
   const int ld = r | 1;
   const size_t budget = (size_t)kLdsDoubles - 1800;  // static LDS of the kernel
