@@ -684,6 +684,37 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
   // ---- N = D⁻¹ M D⁻¹ (symmetrised), padded; Vt = (warm start or identity)ᵀ, padded with zeros
   for (int e = tid; e < szV; e += nt) LDS_VT(e) = 0.0;
   __syncthreads();
+  // ---- fixed work of this thread (indices only: nothing here depends on the matrix, so a speculative launch does it —
+  // and the staging of the warm-start basis — while it still waits for its input)
+  const int nA = m * (m + 1) / 2, nbw = (nA + 63) >> 6;
+  const int widx = (wave & 3) == 3 ? -1 : wave - (wave >> 2);  // index among the waves of SIMDs 0-2 (12 of them)
+  const int bidx = (widx >= 0 && widx < nbw) ? widx * 64 + lane : nA;
+  const bool is_blk = bidx < nA;
+  int bI = 0, bJ = 0, b_rd = 0, w00 = 0, w01 = 0, w10 = 0, w11 = 0;
+  if (is_blk) {  // unrank the upper triangle row-major
+    int base = 0;
+    while (base + (m - bI) <= bidx) { base += m - bI; ++bI; }
+    bJ = bI + (bidx - base);
+    b_rd = 2 * bI * ld + 2 * bJ;
+    const int R0 = rr_dst(2 * bI, m), R1 = rr_dst(2 * bI + 1, m), C0 = rr_dst(2 * bJ, m), C1 = rr_dst(2 * bJ + 1, m);
+    w00 = min(R0, C0) * ld + max(R0, C0); w01 = min(R0, C1) * ld + max(R0, C1);
+    w10 = min(R1, C0) * ld + max(R1, C0); w11 = min(R1, C1) * ld + max(R1, C1);
+  }
+  const bool is_rot = wave == 3 && lane < m;
+  int rp_dp = 0, rp_dq = 0, rp_ob = 0, rp_cp = 0, rp_cq = 0, rp_cl = 0, rp_ch = 0, rp_k = 0;
+  if (wave == 3) {
+    __builtin_amdgcn_s_setprio(3);
+    rp_k = is_rot ? lane : 0;
+    const int p = rr_src(2 * rp_k, m), q = rr_src(2 * rp_k + 1, m);
+    const int ip = p >> 1, ap = p & 1, iq = q >> 1, aq = q & 1, lo = min(ip, iq), hi = max(ip, iq);
+    const int ra = ip < iq ? ap : aq, ca = ip < iq ? aq : ap;  // (row in pair lo, column in pair hi) of the new off-diagonal entry
+    rp_dp = 2 * ip * ld + 2 * ip; rp_dq = 2 * iq * ld + 2 * iq; rp_ob = 2 * lo * ld + 2 * hi;
+    rp_cp = 4 * ip + 2 * ap; rp_cq = 4 * iq + 2 * aq; rp_cl = 4 * lo + 2 * ra; rp_ch = 4 * hi + 2 * ca;
+  }
+  for (int e = tid; e < r * r; e += nt) {  // i = coordinate, j = position
+    const int i = e / r, j = e - i * r;
+    LDS_VT(j * ldk + i) = Vwarm ? Vwarm[e] : (i == j ? 1.0 : 0.0);
+  }
   if (spec.ready) {  // enqueued ahead of its input: wait for the launch that announces it (or for the cancellation).
     // Should that launch not come forward within 5 ms — kernels of different streams forced to run one at a time by a
     // tool, say — give up and say so in the pinned status: the host then repeats the decomposition the ordinary way.
@@ -724,7 +755,6 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
       v = mij / (sqrt_lambda[i] * sqrt_lambda[j]);
     }
     LDS_A(0, i * ld + j) = v;
-    if (i < r && j < r) LDS_VT(j * ldk + i) = Vwarm ? Vwarm[(size_t)i * r + j] : (i == j ? 1.0 : 0.0);  // i = coordinate, j = position
   }
   __syncthreads();
   if (s_cancel) {  // cancelled (or timed out) before it started: nothing is written
@@ -777,31 +807,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
   }
   EIG_STAMP(2);
 
-  // ---- fixed work of this thread
-  const int nA = m * (m + 1) / 2, nbw = (nA + 63) >> 6;
-  const int widx = (wave & 3) == 3 ? -1 : wave - (wave >> 2);  // index among the waves of SIMDs 0-2 (12 of them)
-  const int bidx = (widx >= 0 && widx < nbw) ? widx * 64 + lane : nA;
-  const bool is_blk = bidx < nA;
-  int bI = 0, bJ = 0, b_rd = 0, w00 = 0, w01 = 0, w10 = 0, w11 = 0;
-  if (is_blk) {  // unrank the upper triangle row-major
-    int base = 0;
-    while (base + (m - bI) <= bidx) { base += m - bI; ++bI; }
-    bJ = bI + (bidx - base);
-    b_rd = 2 * bI * ld + 2 * bJ;
-    const int R0 = rr_dst(2 * bI, m), R1 = rr_dst(2 * bI + 1, m), C0 = rr_dst(2 * bJ, m), C1 = rr_dst(2 * bJ + 1, m);
-    w00 = min(R0, C0) * ld + max(R0, C0); w01 = min(R0, C1) * ld + max(R0, C1);
-    w10 = min(R1, C0) * ld + max(R1, C0); w11 = min(R1, C1) * ld + max(R1, C1);
-  }
-  const bool is_rot = wave == 3 && lane < m;
-  int rp_dp = 0, rp_dq = 0, rp_ob = 0, rp_cp = 0, rp_cq = 0, rp_cl = 0, rp_ch = 0, rp_k = 0;
   if (wave == 3) {
-    __builtin_amdgcn_s_setprio(3);
-    rp_k = is_rot ? lane : 0;
-    const int p = rr_src(2 * rp_k, m), q = rr_src(2 * rp_k + 1, m);
-    const int ip = p >> 1, ap = p & 1, iq = q >> 1, aq = q & 1, lo = min(ip, iq), hi = max(ip, iq);
-    const int ra = ip < iq ? ap : aq, ca = ip < iq ? aq : ap;  // (row in pair lo, column in pair hi) of the new off-diagonal entry
-    rp_dp = 2 * ip * ld + 2 * ip; rp_dq = 2 * iq * ld + 2 * iq; rp_ob = 2 * lo * ld + 2 * hi;
-    rp_cp = 4 * ip + 2 * ap; rp_cq = 4 * iq + 2 * aq; rp_cl = 4 * lo + 2 * ra; rp_ch = 4 * hi + 2 * ca;
     // rotations of the first round, straight from the diagonal blocks
     const int o = 2 * rp_k * ld + 2 * rp_k;
     const Rot R = jacobi_rotation(LDS_A(0, o), LDS_A(0, o + 1), LDS_A(0, o + ld + 1));
