@@ -236,6 +236,8 @@ struct icp_ctx {
                                // of its regression launch
   int* h_flag = nullptr;       // pinned: sequence number of the last finished step
   int step_seq = 0;
+  icp_idle_fn idle_fn = nullptr;  // icp_ctx_set_idle_hook
+  void* idle_arg = nullptr;
   bool counted = false;          // included in g_live_contexts
   bool speculation_off = false;  // a speculative decomposition timed out once (see resolve_speculation): not tried again
 
@@ -959,6 +961,14 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
   if (ctx->counted) --g_live_contexts;
   delete ctx;
+}
+
+int icp_ctx_set_idle_hook(icp_ctx* ctx, icp_idle_fn fn, void* arg) {
+  if (!ctx) return ICP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  ctx->idle_fn = fn;
+  ctx->idle_arg = fn ? arg : nullptr;
+  return ICP_OK;
 }
 
 int icp_ctx_profile_start(icp_ctx* ctx, int32_t max_launches) {
@@ -1792,6 +1802,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       for (int i = 0; i < n_props; ++i) {
         props[i]->speculate_eigen(*ep[i], *ec[i], splits[i], c.d_done.p + 2, step_seq + starve);
       }
+    if (c.idle_fn) c.idle_fn(c.idle_arg);  // the caller's outcome-independent host work runs beside the device
     g_host_timing.mark(2);
     if (eigen_enqueued) {
       sync_proposal_status_if(props[generator], true);

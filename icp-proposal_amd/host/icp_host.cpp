@@ -3,6 +3,7 @@
 
 #include <memory>
 #include <string>
+#include <thread>
 
 #include "icp_host.hpp"
 
@@ -51,6 +52,20 @@ struct icp_host_chain {
   ModelFittingParameters current;
   RecordLogger logger;
   double current_p = 0.0;
+  // the standard normals of step `ahead_step`, drawn by the idle hook of the native library while the step before it is
+  // on the device (counter-based RNG: a pure function of (seed, step, lane), so drawing early changes nothing)
+  std::vector<double> ahead;
+  uint64_t ahead_step = ~0ull;
+  std::thread::id runner;  // the thread inside icp_host_chain_run (chains that share a context share its hook slot)
+  static void draw_ahead(void* self) {
+    icp_host_chain* ch = static_cast<icp_host_chain*>(self);
+    if (std::this_thread::get_id() != ch->runner) return;  // another chain's step on a shared context: not our turn
+    const uint64_t next = (uint64_t)ch->logger.index + 1;
+    if (ch->ahead_step == next) return;
+    StepRandom rnd{ch->seed, next};
+    for (size_t j = 0; j < ch->ahead.size(); ++j) ch->ahead[j] = rnd.normal(j);
+    ch->ahead_step = next;
+  }
 };
 
 template <class F>
@@ -137,6 +152,8 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
       if (cfg->fused >= 2)
         for (size_t i = 0; i < ch->icp.size(); ++i) { ch->icp[i]->stepper = &ch->prefetcher; ch->icp[i]->stepperIndex = (int)i; }
     }
+    ch->ahead.assign(ch->r, 0.0);
+    if (cfg->fused >= 2) check(icp_ctx_set_idle_hook(ctx, &icp_host_chain::draw_ahead, ch), "icp_ctx_set_idle_hook");
     ch->current.allParameters.assign(theta0, theta0 + 10 + ch->r);
     ch->logger.P = 10 + ch->r;
     ch->current_p = ch->product.logValue(ch->current);
@@ -150,8 +167,10 @@ int icp_host_chain_run(icp_host_chain* ch, int32_t n_steps, double* records) {
   return host_guard([&] {
     if (!ch || n_steps < 0) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chain_run");
     ch->logger.out = records;
+    ch->runner = std::this_thread::get_id();
     for (int s = 0; s < n_steps; ++s) {  // SamplingRegistration.scala:58-85: chain.iterator(...).take(n)
       StepRandom rnd{ch->seed, (uint64_t)ch->logger.index};
+      if (ch->ahead_step == rnd.step) { rnd.ahead = ch->ahead.data(); rnd.n_ahead = (int)ch->ahead.size(); }
       ch->current = ch->mh->next(ch->current, rnd, &ch->logger);
       ch->current_p = ch->mh->cached_current_p;
     }
@@ -168,6 +187,9 @@ int icp_host_chain_state(icp_host_chain* ch, double* theta_out, double* logp_out
   return ICP_OK;
 }
 
-void icp_host_chain_destroy(icp_host_chain* ch) { delete ch; }
+void icp_host_chain_destroy(icp_host_chain* ch) {
+  if (ch && ch->ctx) (void)icp_ctx_set_idle_hook(ch->ctx, nullptr, nullptr);  // (several chains may share a context: last one wins)
+  delete ch;
+}
 
 }  // extern "C"

@@ -43,11 +43,15 @@ inline uint64_t splitmix64(uint64_t x) {
 
 struct StepRandom {  // the random numbers of ONE Metropolis–Hastings step
   uint64_t seed = 0, step = 0;
+  // standard normals 0..n_ahead-1 of this step drawn ahead of time (icp_host.cpp: while the previous step was on the device)
+  const double* ahead = nullptr;
+  int n_ahead = 0;
   double uniform(uint64_t lane) const {
     uint64_t h = splitmix64(splitmix64(splitmix64(seed) ^ (step * 0xD1342543DE82EF95ull)) ^ (lane * 0x2545F4914F6CDD1Dull));
     return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
   }
   double normal(uint64_t lane) const {
+    if (lane < (uint64_t)n_ahead) return ahead[lane];
     double u1 = uniform(2 * lane + 1000), u2 = uniform(2 * lane + 1001);
     return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
   }

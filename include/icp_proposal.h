@@ -251,6 +251,14 @@ typedef struct {
 ICP_API int icp_ctx_profile_start(icp_ctx *ctx, int32_t max_launches);
 ICP_API int icp_ctx_profile_stop(icp_ctx *ctx, icp_kernel_stat *stats, int32_t capacity /* >= 32 */, int32_t *n_out);
 
+/* ---- idle hook (optional).  icp_chain_step spends most of a step waiting for the device.  A caller that has host
+ * work which does not depend on the step's outcome — drawing the random numbers of the NEXT step, say — registers it
+ * here: `fn(arg)` is called once per icp_chain_step, on the calling thread, after the step's launches have been issued
+ * and before the wait.  It must not call back into this library.  fn == NULL removes the hook.  Nothing in the
+ * reference corresponds to it (its Breeze RNG is sequential); the C++ harness uses it with its counter-based RNG. */
+typedef void (*icp_idle_fn)(void *arg);
+ICP_API int icp_ctx_set_idle_hook(icp_ctx *ctx, icp_idle_fn fn, void *arg);
+
 #ifdef __cplusplus
 }
 #endif
