@@ -79,6 +79,7 @@ SIGNATURES = {
     "icp_prior_log_value": (C.c_int, [C.c_int32, c_double_p, c_double_p]),
     "icp_ctx_profile_start": (C.c_int, [C.c_void_p, C.c_int32]),
     "icp_ctx_set_idle_hook": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "icp_chain_step_prelaunch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "icp_ctx_profile_stop": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),
     "icp_chain_eval_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_double_p]),

@@ -194,6 +194,7 @@ constexpr size_t kMaxCandidates = (size_t)256 << 20;  // ints (1 GiB): larger qu
 struct StateSlot {
   std::vector<double> theta;
   bool valid = false;
+  bool reserved = false;  // handed out to a step whose launches are in flight: not to be recycled
   uint64_t stamp = 0;
   Pose pose;
   DBuf<double> coeffs, x;
@@ -312,11 +313,14 @@ StateSlot* icp_ctx::find_state(const double* theta) {
 
 // least recently used slot, emptied (buffers allocated on first use); the caller fills it and sets `valid`
 StateSlot& icp_ctx::fresh_state() {
-  StateSlot* lru = &slots[0];
+  StateSlot* lru = nullptr;
   for (auto& s : slots) {
+    if (s.reserved) continue;
+    if (!lru) { lru = &s; continue; }
     if (!s.valid) { if (lru->valid) lru = &s; }
     else if (lru->valid && s.stamp < lru->stamp) lru = &s;
   }
+  if (!lru) fail(ICP_ERR_DEVICE, "internal: every state slot is reserved");
   StateSlot& s = *lru;
   if (!s.x.p) {
     s.coeffs.alloc(r);
@@ -413,6 +417,7 @@ std::atomic<int> g_live_contexts{0};
 struct PosteriorEntry {
   std::vector<double> theta;
   bool valid = false, eig_valid = false, eig_checked = false;  // eig_checked: its status has reached the host copy
+  bool reserved = false;  // handed out to a step whose launches are in flight: not to be recycled
   hipEvent_t eig_done = nullptr;  // recorded on the proposal's eigen stream behind the entry's decomposition
   uint64_t stamp = 0;
   DBuf<int> id, aux;
@@ -470,9 +475,29 @@ struct icp_proposal {
   void check_status(PosteriorEntry& e);
 };
 
+namespace {
+// Launches 1-3 of a merged step (proposal -> instance -> searches -> correspondences), enqueued.  icp_chain_step issues
+// them itself, or finds them already issued by icp_chain_step_prelaunch for exactly its arguments.
+struct StepFront {
+  bool valid = false;
+  int n_props = 0, generator = -1;
+  icp_proposal* props[2] = {nullptr, nullptr};
+  std::vector<double> theta_cur, key;  // key: z (generator >= 0) or the proposed state (generator < 0)
+  PosteriorEntry* ec[2] = {nullptr, nullptr};
+  PosteriorEntry* ep[2] = {nullptr, nullptr};
+  StateSlot* s = nullptr;
+  bool eigen_first_use = false;
+  int parity = 0;  // which half of the pinned coefficient area its first launch writes
+  int Ksurf = 0;
+};
+constexpr int kCoeffArea = 512;  // doubles per half of that area (>= kMaxRank)
+}  // namespace
+
 struct icp_evaluator {
   icp_ctx* ctx = nullptr;
   icp_evaluator_params prm{};
+  StepFront front;  // pre-launched first half of the next step, if any
+  int front_parity = 0;
   DBuf<double> target_pts;
   // target-side queries against the CURRENT model surface
   int Kt = 0;              // number of target-side query points (decimated target, or all target vertices for Hausdorff)
@@ -532,12 +557,15 @@ PosteriorEntry* icp_proposal::find_entry(const double* theta) {
 // least recently used memo entry, emptied; the caller fills it and sets `valid`
 PosteriorEntry& icp_proposal::fresh_entry() {
   const int r = ctx->r;
-  PosteriorEntry* lru = &memo[0];
+  PosteriorEntry* lru = nullptr;
   for (int i = 0; i < kPosteriorMemo; ++i) {
     PosteriorEntry& e = memo[i];
+    if (e.reserved) continue;
+    if (!lru) { lru = &e; continue; }
     if (!e.valid) { if (lru->valid) lru = &e; }
     else if (lru->valid && e.stamp < lru->stamp) lru = &e;
   }
+  if (!lru) fail(ICP_ERR_DEVICE, "internal: every posterior entry is reserved");
   PosteriorEntry& e = *lru;
   const int Ka = std::max(K, 1);
   if (!e.M.p) {
@@ -926,7 +954,7 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->stage_cap = 64 * (size_t)(10 + r) + 4096;
     HIP_OK(hipHostMalloc((void**)&ctx->h_stage, sizeof(double) * ctx->stage_cap, hipHostMallocDefault));
     ctx->d_stage.alloc(ctx->stage_cap);
-    const size_t res_cap = std::max<size_t>(1024, 3 * (size_t)N + 64);
+    const size_t res_cap = std::max<size_t>(2048, 3 * (size_t)N + 64);
     HIP_OK(hipHostMalloc((void**)&ctx->h_res, sizeof(double) * res_cap, hipHostMallocDefault));
     ctx->d_res.alloc(res_cap);
     HIP_OK(hipHostMalloc((void**)&ctx->h_status, sizeof(int) * 64, hipHostMallocDefault));
@@ -1618,6 +1646,186 @@ bool step_pipeline_covers(icp_evaluator* e, int n_props, icp_proposal* const* pr
 
 }  // namespace
 
+}  // extern "C"
+
+namespace {
+
+// give back what a front holds without recording anything (its launches, if any, are harmless: they wrote to a state
+// slot and memo entries that nobody refers to, to the search scratch and to the hints, which may be stale by design)
+void release_front(StepFront& F) {
+  if (F.s) F.s->reserved = false;
+  for (int i = 0; i < F.n_props; ++i)
+    if (F.ep[i]) F.ep[i]->reserved = false;
+  if (F.valid && F.eigen_first_use && F.generator >= 0 && F.ec[F.generator]) F.ec[F.generator]->eig_checked = false;
+  F = StepFront{};
+}
+
+// launches 1-3 of the step (theta_cur --generator/key--> proposal); `key` = z or the proposed state (see StepFront)
+void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, int generator, const double* theta_cur,
+                   const double* key, StepFront& F) {
+  icp_ctx& c = *e->ctx;
+  const int r = c.r;
+  F = StepFront{};
+  F.n_props = n_props; F.generator = generator;
+  for (int i = 0; i < n_props; ++i) F.props[i] = props[i];
+  F.theta_cur.assign(theta_cur, theta_cur + 10 + r);
+  F.key.assign(key, key + (generator >= 0 ? r : 10 + r));
+  F.parity = (e->front_parity ^= 1);
+  // ---- cached side: posterior of the current state for every proposal (+ its KL basis for the generating one)
+  PosteriorEntry** ec = F.ec;
+  PosteriorEntry** ep = F.ep;
+  for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
+  // KL bases of the current state's posteriors: all of them are started now, each on its proposal's own stream (they
+  // run side by side); only the generating one is waited for — the other is ready when a later step draws from it
+  for (int i = 0; i < n_props; ++i)
+    if (!ec[i]->eig_valid) props[i]->ensure_eigen(*ec[i]);
+  bool eigen_first_use = false;
+  if (generator >= 0) {
+    props[generator]->await_eigen(*ec[generator]);
+    eigen_first_use = !ec[generator]->eig_checked;  // (possibly of an earlier prefetch or speculation): fetch its status
+    ec[generator]->eig_checked = true;
+  }
+  F.eigen_first_use = eigen_first_use;
+
+  // ---- new side: one state slot, one memo entry per proposal
+  StateSlot& s = c.fresh_state();
+  s.reserved = true;
+  F.s = &s;
+  s.pose = pose_from_theta(generator >= 0 ? theta_cur : key);
+  for (int i = 0; i < n_props; ++i) { ep[i] = &props[i]->fresh_entry(); ep[i]->reserved = true; }
+  const icp_evaluator_params& evp = e->prm;
+  icp_proposal* pm = nullptr;  // ModelSampling proposal
+  icp_proposal* pt = nullptr;  // TargetSampling proposal
+  int im = -1, it = -1;
+  for (int i = 0; i < n_props; ++i) {
+    if (props[i]->prm.direction == ICP_MODEL_SAMPLING) { pm = props[i]; im = i; }
+    else { pt = props[i]; it = i; }
+  }
+  const int Ksurf = std::max(evp.n_model_ids, pm ? pm->K : 0);
+  F.Ksurf = Ksurf;
+  require(Ksurf <= c.N, "model id count exceeds the number of model points");
+  QueryBuffers qs = c.query_scratch(Ksurf, c.target.T);
+  QueryBuffers qv{};
+  if (pt) qv = c.query_scratch(pt->K, c.N, true);
+
+  SurfaceTask st_surf = make_surface_task(c.target.T, c.target.verts.p, c.target.tris.p, c.target.spheres.p, Ksurf, s.x.p,
+                                          c.hint_surf.p, qs, s.surf_cp.p, s.surf_d2.p, s.surf_tri.p);
+  VertexTask st_vert{};
+  if (pt) st_vert = make_vertex_task(c.N, s.x.p, pt->K, pt->target_pts.p, pt->hint_nn.p, qv, nullptr, pt->nn_id.p);
+  st_vert.thr2 = nullptr;  // bounds are computed by the filter launch itself (see vertex_filter)
+
+  // 1: coefficients -> instance -> bounds
+  StepBeginArgs b{};
+  b.N = c.N; b.r = r; b.inst_blocks = (c.N + 255) / 256;
+  b.Qp = c.Qp.p; b.ref = c.ref.p; b.mean = c.mean.p; b.pose = s.pose;
+  b.propose = generator >= 0 ? 1 : 0;
+  const double* src = generator >= 0 ? key : key + 10;
+  if (r <= kStepInlineZ) std::memcpy(b.zin, src, sizeof(double) * r);
+  else {
+    if ((size_t)r > c.stage_cap) fail(ICP_ERR_INVALID_ARG, "internal: staging area exhausted");
+    std::memcpy(c.h_stage, src, sizeof(double) * r);
+    b.z_ptr = c.h_stage;  // pinned, read by the device in place
+  }
+  if (generator >= 0) {
+    PosteriorEntry& g = *ec[generator];
+    b.prop = ProposeIn{g.alpha.p, g.V.p, g.S.p, c.inv_sqrt_lambda.p, c.P.p, g.coeffs.p, nullptr, kSigma2,
+                       props[generator]->prm.step_length};
+    int t = 0;
+    while (t < 6 && (r << (t + 1)) <= 256 && (r >> (t + 1)) >= 8) ++t;  // = matvec_tpr_log2(r, 256) of k_propose
+    b.tpr_log2 = t;
+  }
+  b.n_out = 0;
+  b.out[b.n_out++] = s.coeffs.p;
+  for (int i = 0; i < n_props; ++i) b.out[b.n_out++] = ep[i]->coeffs.p;
+  b.out[b.n_out++] = c.h_res + 16 + F.parity * kCoeffArea;
+  b.x = s.x.p;
+  b.has_surf = 1; b.surf = st_surf;
+  b.has_vert = pt ? 1 : 0; b.vert = st_vert;
+  launch_step_begin(c.stream, b);
+
+  // 2 + 3: searches and correspondences
+  StepSearchArgs q{};
+  q.n_surf = 1; q.n_vert = pt ? 1 : 0;
+  q.s[0] = st_surf;
+  q.fstart[0] = 0; q.fstart[1] = filter_grid_blocks(st_surf.tblocks, st_surf.ksplit);
+  q.rstart[0] = 0; q.rstart[1] = Ksurf;
+  q.s_corr[0] = q.s_corr[1] = q.v_corr[0] = q.v_corr[1] = -1;
+  int n_corr = 0;
+  if (pm) {
+    q.corr[n_corr] = CorrTask{pm->K, ep[im]->corr(), s.x.p, nullptr, c.target.boundary.p, nullptr, pm->prm.boundary_aware,
+                              s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p};
+    q.s_corr[0] = n_corr++;
+  }
+  if (pt) {
+    q.v[0] = st_vert;
+    q.fstart[2] = q.fstart[1] + filter_grid_blocks(st_vert.vblocks, st_vert.ksplit);
+    q.rstart[2] = q.rstart[1] + pt->K;
+    q.corr[n_corr] = CorrTask{pt->K, ep[it]->corr(), s.x.p, pt->target_pts.p, c.boundary.p, nullptr, pt->prm.boundary_aware,
+                              s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p};
+    q.v_corr[0] = n_corr++;
+  }
+  launch_step_filter(c.stream, q);
+  launch_step_resolve(c.stream, q);
+
+  F.valid = true;
+}
+
+bool front_matches(const StepFront& F, int n_props, icp_proposal* const* props, int generator, const double* theta_cur,
+                   const double* key, int r) {
+  if (!F.valid || F.n_props != n_props || F.generator != generator) return false;
+  for (int i = 0; i < n_props; ++i)
+    if (F.props[i] != props[i]) return false;
+  return std::memcmp(F.theta_cur.data(), theta_cur, sizeof(double) * (10 + r)) == 0 &&
+         std::memcmp(F.key.data(), key, sizeof(double) * F.key.size()) == 0;
+}
+
+// shared argument checks of icp_chain_step and icp_chain_step_prelaunch; -> the merged launches cover this call
+bool chain_step_covered(icp_evaluator* e, int n_props, icp_proposal* const* props, int generator, const double* theta_cur,
+                        const double* theta_prop_in) {
+  icp_ctx& c = *e->ctx;
+  bool per_stage = !step_pipeline_covers(e, n_props, props);
+  if (!per_stage && generator < 0) {
+    // a state the caches already know (or a pose move, whose ICP transition densities are -inf) has nothing to merge
+    per_stage = !pose_equal(theta_cur, theta_prop_in) || c.find_state(theta_prop_in) || eval_lookup(e, theta_prop_in);
+    for (int i = 0; i < n_props && !per_stage; ++i) per_stage = props[i]->find_entry(theta_prop_in) != nullptr;
+  }
+  return !per_stage;
+}
+
+}  // namespace
+
+extern "C" {
+
+int icp_chain_step_prelaunch(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, int32_t generator, const double* theta_cur,
+                             const double* z_or_theta_prop) {
+  return guard([&] {
+    require(e && theta_cur && z_or_theta_prop, "null argument");
+    require(n_props >= 1 && n_props <= 2 && props, "bad proposal list");
+    require(generator < n_props, "generator index out of range");
+    icp_ctx& c = *e->ctx;
+    for (int i = 0; i < n_props; ++i) require(props[i] && props[i]->ctx == &c, "proposal belongs to another context");
+    check_theta_finite(&c, theta_cur);
+    if (generator < 0) check_theta_finite(&c, z_or_theta_prop);
+    else
+      for (int j = 0; j < c.r; ++j)
+        if (!std::isfinite(z_or_theta_prop[j])) fail(ICP_ERR_NOT_FINITE, "z contains a non-finite value");
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    if (e->front.valid) release_front(e->front);
+    if (c.r > kStepInlineZ) return;  // (larger ranks stage z in one pinned area: not double-buffered)
+    if (!chain_step_covered(e, n_props, props, generator, theta_cur, z_or_theta_prop)) return;  // nothing to pre-launch
+    // every posterior of the assumed current state must be on record already (the step in flight computed them)
+    for (int i = 0; i < n_props; ++i)
+      if (!props[i]->find_entry(theta_cur)) return;
+    Bound _b(&c);
+    try {
+      enqueue_front(e, n_props, props, generator, theta_cur, z_or_theta_prop, e->front);
+    } catch (...) {
+      release_front(e->front);
+      throw;
+    }
+  });
+}
+
 int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, int32_t generator, const double* theta_cur,
                    const double* z, double* theta_prop, double* log_value_prop, double* fwd, double* bwd) {
   int status = ICP_OK;
@@ -1636,114 +1844,35 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
         if (!std::isfinite(z[j])) fail(ICP_ERR_NOT_FINITE, "z contains a non-finite value");
     std::lock_guard<std::recursive_mutex> lk(c.mu);
     const int r = c.r;
-    per_stage = !step_pipeline_covers(e, n_props, props);
-    if (!per_stage && generator < 0) {
-      // a state the caches already know (or a pose move, whose ICP transition densities are -inf) has nothing to merge
-      per_stage = !pose_equal(theta_cur, theta_prop) || c.find_state(theta_prop) || eval_lookup(e, theta_prop);
-      for (int i = 0; i < n_props && !per_stage; ++i) per_stage = props[i]->find_entry(theta_prop) != nullptr;
-    }
+    const double* key = generator >= 0 ? z : theta_prop;
+    const bool reuse = n_props <= 2 && front_matches(e->front, n_props, props, generator, theta_cur, key, r);
+    if (e->front.valid && !reuse) release_front(e->front);  // pre-launched for another outcome: dropped
+    per_stage = !reuse && !chain_step_covered(e, n_props, props, generator, theta_cur, theta_prop);
     if (per_stage) return;
     Bound _b(&c);
     g_host_timing.start();
 
     for (int i = 0; i < n_props; ++i) props[i]->resolve_speculation(theta_cur);
-    // ---- cached side: posterior of the current state for every proposal (+ its KL basis for the generating one)
-    PosteriorEntry* ec[2];
-    PosteriorEntry* ep[2];
-    for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
-    // KL bases of the current state's posteriors: all of them are started now, each on its proposal's own stream (they
-    // run side by side); only the generating one is waited for — the other is ready when a later step draws from it
-    for (int i = 0; i < n_props; ++i)
-      if (!ec[i]->eig_valid) props[i]->ensure_eigen(*ec[i]);
-    bool eigen_first_use = false;
-    if (generator >= 0) {
-      props[generator]->await_eigen(*ec[generator]);
-      eigen_first_use = !ec[generator]->eig_checked;  // (possibly of an earlier prefetch or speculation): fetch its status
-      ec[generator]->eig_checked = true;
-    }
+    StepFront F;
+    struct FrontGuard {  // whatever happens below, the slots of this step are not left reserved
+      StepFront* f;
+      ~FrontGuard() { if (f) release_front(*f); }
+    } front_guard{&F};
+    if (reuse) { F = e->front; e->front = StepFront{}; }
+    else enqueue_front(e, n_props, props, generator, theta_cur, key, F);
+    g_host_timing.mark(0);
+    PosteriorEntry** ec = F.ec;
+    PosteriorEntry** ep = F.ep;
+    StateSlot& s = *F.s;
+    const int Ksurf = F.Ksurf;
+    const bool eigen_first_use = F.eigen_first_use;
+    const icp_evaluator_params& evp = e->prm;
     // the decompositions of ranks <= 64 leave their status in pinned memory themselves; the others need a copy
     const bool eigen_status_pinned = eigen_speculation_supported(r);
     const bool eigen_enqueued = eigen_first_use && !eigen_status_pinned;
-
-    // ---- new side: one state slot, one memo entry per proposal
-    StateSlot& s = c.fresh_state();
-    s.pose = pose_from_theta(generator >= 0 ? theta_cur : theta_prop);
-    for (int i = 0; i < n_props; ++i) ep[i] = &props[i]->fresh_entry();
-    const icp_evaluator_params& evp = e->prm;
-    icp_proposal* pm = nullptr;  // ModelSampling proposal
-    icp_proposal* pt = nullptr;  // TargetSampling proposal
-    int im = -1, it = -1;
-    for (int i = 0; i < n_props; ++i) {
-      if (props[i]->prm.direction == ICP_MODEL_SAMPLING) { pm = props[i]; im = i; }
-      else { pt = props[i]; it = i; }
-    }
-    const int Ksurf = std::max(evp.n_model_ids, pm ? pm->K : 0);
-    require(Ksurf <= c.N, "model id count exceeds the number of model points");
-    QueryBuffers qs = c.query_scratch(Ksurf, c.target.T);
-    QueryBuffers qv{};
-    if (pt) qv = c.query_scratch(pt->K, c.N, true);
+    const double* h_coeffs = c.h_res + 16 + F.parity * kCoeffArea;
     for (int i = 0; i < 16; ++i) c.h_res[i] = 0.0;
     for (int i = 0; i < 16; ++i) c.h_status[i] = 0;
-
-    SurfaceTask st_surf = make_surface_task(c.target.T, c.target.verts.p, c.target.tris.p, c.target.spheres.p, Ksurf, s.x.p,
-                                            c.hint_surf.p, qs, s.surf_cp.p, s.surf_d2.p, s.surf_tri.p);
-    VertexTask st_vert{};
-    if (pt) st_vert = make_vertex_task(c.N, s.x.p, pt->K, pt->target_pts.p, pt->hint_nn.p, qv, nullptr, pt->nn_id.p);
-    st_vert.thr2 = nullptr;  // bounds are computed by the filter launch itself (see vertex_filter)
-
-    // 1: coefficients -> instance -> bounds
-    StepBeginArgs b{};
-    b.N = c.N; b.r = r; b.inst_blocks = (c.N + 255) / 256;
-    b.Qp = c.Qp.p; b.ref = c.ref.p; b.mean = c.mean.p; b.pose = s.pose;
-    b.propose = generator >= 0 ? 1 : 0;
-    const double* src = generator >= 0 ? z : theta_prop + 10;
-    if (r <= kStepInlineZ) std::memcpy(b.zin, src, sizeof(double) * r);
-    else {
-      if ((size_t)r > c.stage_cap) fail(ICP_ERR_INVALID_ARG, "internal: staging area exhausted");
-      std::memcpy(c.h_stage, src, sizeof(double) * r);
-      b.z_ptr = c.h_stage;  // pinned, read by the device in place
-    }
-    if (generator >= 0) {
-      PosteriorEntry& g = *ec[generator];
-      b.prop = ProposeIn{g.alpha.p, g.V.p, g.S.p, c.inv_sqrt_lambda.p, c.P.p, g.coeffs.p, nullptr, kSigma2,
-                         props[generator]->prm.step_length};
-      int t = 0;
-      while (t < 6 && (r << (t + 1)) <= 256 && (r >> (t + 1)) >= 8) ++t;  // = matvec_tpr_log2(r, 256) of k_propose
-      b.tpr_log2 = t;
-    }
-    b.n_out = 0;
-    b.out[b.n_out++] = s.coeffs.p;
-    for (int i = 0; i < n_props; ++i) b.out[b.n_out++] = ep[i]->coeffs.p;
-    b.out[b.n_out++] = c.h_res + 16;
-    b.x = s.x.p;
-    b.has_surf = 1; b.surf = st_surf;
-    b.has_vert = pt ? 1 : 0; b.vert = st_vert;
-    g_host_timing.mark(0);
-    launch_step_begin(c.stream, b);
-
-    // 2 + 3: searches and correspondences
-    StepSearchArgs q{};
-    q.n_surf = 1; q.n_vert = pt ? 1 : 0;
-    q.s[0] = st_surf;
-    q.fstart[0] = 0; q.fstart[1] = filter_grid_blocks(st_surf.tblocks, st_surf.ksplit);
-    q.rstart[0] = 0; q.rstart[1] = Ksurf;
-    q.s_corr[0] = q.s_corr[1] = q.v_corr[0] = q.v_corr[1] = -1;
-    int n_corr = 0;
-    if (pm) {
-      q.corr[n_corr] = CorrTask{pm->K, ep[im]->corr(), s.x.p, nullptr, c.target.boundary.p, nullptr, pm->prm.boundary_aware,
-                                s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p};
-      q.s_corr[0] = n_corr++;
-    }
-    if (pt) {
-      q.v[0] = st_vert;
-      q.fstart[2] = q.fstart[1] + filter_grid_blocks(st_vert.vblocks, st_vert.ksplit);
-      q.rstart[2] = q.rstart[1] + pt->K;
-      q.corr[n_corr] = CorrTask{pt->K, ep[it]->corr(), s.x.p, pt->target_pts.p, c.boundary.p, nullptr, pt->prm.boundary_aware,
-                                s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p};
-      q.v_corr[0] = n_corr++;
-    }
-    launch_step_filter(c.stream, q);
-    launch_step_resolve(c.stream, q);
 
     // 4: regressions + likelihood reduction
     StepRegressionArgs g{};
@@ -1839,8 +1968,8 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     if (generator >= 0) {
       std::memcpy(theta_prop, theta_cur, sizeof(double) * 10);  // :64-66 only the shape changes
       for (int j = 0; j < r; ++j) {
-        if (!std::isfinite(c.h_res[16 + j])) fail(ICP_ERR_NOT_FINITE, "proposed coefficients are not finite");
-        theta_prop[10 + j] = c.h_res[16 + j];
+        if (!std::isfinite(h_coeffs[j])) fail(ICP_ERR_NOT_FINITE, "proposed coefficients are not finite");
+        theta_prop[10 + j] = h_coeffs[j];
       }
     }
     s.theta.assign(theta_prop, theta_prop + P);
@@ -1880,6 +2009,9 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       bwd[i] = c.h_res[9 + 2 * i];
       if (std::isnan(fwd[i]) || std::isnan(bwd[i])) fail(ICP_ERR_NOT_FINITE, "NaN transition probability");
     }
+    s.reserved = false;
+    for (int i = 0; i < n_props; ++i) ep[i]->reserved = false;
+    front_guard.f = nullptr;
     g_host_timing.mark(4);
     g_host_timing.end();
   });

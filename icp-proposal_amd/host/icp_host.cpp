@@ -65,6 +65,21 @@ struct icp_host_chain {
     StepRandom rnd{ch->seed, next};
     for (size_t j = 0; j < ch->ahead.size(); ++j) ch->ahead[j] = rnd.normal(j);
     ch->ahead_step = next;
+    // Two steps out of three are rejected: the next step then starts from the SAME state, and its proposal is a pure
+    // function of that state and of the numbers just drawn.  Its first launches are issued now, behind the step in
+    // flight, so the device does not idle through the host's turn-around; if this step is accepted instead they are
+    // dropped (icp_chain_step_prelaunch).
+    if (!ch->prefetcher.whole_step || ch->icp.empty() || ch->icp.size() > 2) return;
+    rnd.ahead = ch->ahead.data(); rnd.n_ahead = (int)ch->ahead.size();
+    ProposalGeneratorWithTransition* leaf = ch->root->peek(rnd, 0);
+    icp_proposal* hs[2] = {nullptr, nullptr};
+    for (size_t i = 0; i < ch->icp.size(); ++i) hs[i] = ch->icp[i]->h;
+    if (auto* ip = dynamic_cast<NonRigidIcpProposal*>(leaf)) {
+      if (ip->stepper) (void)icp_chain_step_prelaunch(ch->likelihood->h, (int)ch->icp.size(), hs, ip->stepperIndex, ch->current.data(), ch->ahead.data());
+    } else if (auto* rw = dynamic_cast<RandomShapeUpdateProposal*>(leaf)) {
+      const ModelFittingParameters prop = rw->propose(ch->current, rnd, 0);
+      (void)icp_chain_step_prelaunch(ch->likelihood->h, (int)ch->icp.size(), hs, -1, ch->current.data(), prop.data());
+    }
   }
 };
 

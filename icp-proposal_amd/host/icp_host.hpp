@@ -105,6 +105,8 @@ struct ProposalGeneratorWithTransition {
     if (std::isinf(fw) && fw < 0 && std::isinf(bw) && bw < 0) return 0.0;
     return fw - bw;
   }
+  // the leaf proposal that propose(·, rnd, depth) would draw from, without drawing (mixtures descend; leaves are themselves)
+  virtual ProposalGeneratorWithTransition* peek(const StepRandom&, int) { return this; }
   // index of the leaf proposal that generated the last sample (for logs)
   virtual int lastLeaf() const { return leafId; }
   int leafId = -1;
@@ -222,16 +224,22 @@ struct GaussianAxisPoseProposal : ProposalGeneratorWithTransition {
 // transition density = log-sum-exp over ALL components.
 struct MixtureProposal : ProposalGeneratorWithTransition {
   void add(double weight, ProposalGeneratorWithTransition* g) { weights.push_back(weight); generators.push_back(g); }
-  ModelFittingParameters propose(const ModelFittingParameters& current, const StepRandom& rnd, int depth) override {
+  size_t pick_component(const StepRandom& rnd, int depth) const {
     double wsum = 0.0;
     for (double w : weights) wsum += w;
     const double u = rnd.uniform(StepRandom::mixture_lane(depth));
-    size_t pick = generators.size() - 1;
     double acc = 0.0;
     for (size_t i = 0; i < generators.size(); ++i) {
       acc += weights[i] / wsum;
-      if (acc >= u) { pick = i; break; }
+      if (acc >= u) return i;
     }
+    return generators.size() - 1;
+  }
+  ProposalGeneratorWithTransition* peek(const StepRandom& rnd, int depth) override {
+    return generators[pick_component(rnd, depth)]->peek(rnd, depth + 1);
+  }
+  ModelFittingParameters propose(const ModelFittingParameters& current, const StepRandom& rnd, int depth) override {
+    const size_t pick = pick_component(rnd, depth);
     ModelFittingParameters out = generators[pick]->propose(current, rnd, depth + 1);
     last = generators[pick];
     return out;

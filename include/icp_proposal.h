@@ -240,6 +240,15 @@ ICP_API int icp_chain_step(icp_evaluator *e, int32_t n_props, icp_proposal *cons
                            const double *theta_cur, const double *z, double *theta_prop, double *log_value_prop, double *fwd,
                            double *bwd);
 
+/* Optional companion of icp_chain_step: issue the first launches (proposal, instance, searches, correspondences) of the
+ * step  theta_cur --generator, z--> proposal  (generator < 0: z_or_theta_prop is the proposed state itself) ahead of the
+ * call that asks for it.  Meant to be called from the idle hook (below) with the NEXT step's arguments under the
+ * assumption that the step in flight is rejected: an icp_chain_step with exactly these arguments then finds its first
+ * half already on the device; any other call drops it.  Never changes results.  Does nothing when the posteriors of
+ * theta_cur are not on record or the configuration is not covered by the merged launches. */
+ICP_API int icp_chain_step_prelaunch(icp_evaluator *e, int32_t n_props, icp_proposal *const *props, int32_t generator,
+                                     const double *theta_cur, const double *z_or_theta_prop);
+
 /* ---------------------------------------------------------------- instrumentation (bench.py's roofline leg)
  * Between start and stop every kernel the context launches is bracketed by HIP events on the context stream;
  * stop returns one row per kernel name.  Off by default (adds nothing to the launch path). */
@@ -254,7 +263,7 @@ ICP_API int icp_ctx_profile_stop(icp_ctx *ctx, icp_kernel_stat *stats, int32_t c
 /* ---- idle hook (optional).  icp_chain_step spends most of a step waiting for the device.  A caller that has host
  * work which does not depend on the step's outcome — drawing the random numbers of the NEXT step, say — registers it
  * here: `fn(arg)` is called once per icp_chain_step, on the calling thread, after the step's launches have been issued
- * and before the wait.  It must not call back into this library.  fn == NULL removes the hook.  Nothing in the
+ * and before the wait.  It may call icp_chain_step_prelaunch and nothing else of this library.  fn == NULL removes the hook.  Nothing in the
  * reference corresponds to it (its Breeze RNG is sequential); the C++ harness uses it with its counter-based RNG. */
 typedef void (*icp_idle_fn)(void *arg);
 ICP_API int icp_ctx_set_idle_hook(icp_ctx *ctx, icp_idle_fn fn, void *arg);
