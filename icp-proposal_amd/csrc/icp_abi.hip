@@ -1343,11 +1343,16 @@ int icp_evaluator_create(icp_ctx* ctx, const icp_evaluator_params* params, icp_e
   return rc;
 }
 
+namespace { void release_front(StepFront& F); }
+
 void icp_evaluator_destroy(icp_evaluator* e) {
   if (!e) return;
   std::lock_guard<std::recursive_mutex> lk(e->ctx->mu);
   (void)hipSetDevice(e->ctx->device);
   (void)hipStreamSynchronize(e->ctx->stream);
+  // a pre-launched half step holds a state slot of the context and memo entries of its proposals: an evaluator with one
+  // pending must be destroyed before those proposals (the harness does; nobody else pre-launches)
+  if (e->front.valid) release_front(e->front);
   delete e;
 }
 
@@ -1812,6 +1817,9 @@ int icp_chain_step_prelaunch(icp_evaluator* e, int32_t n_props, icp_proposal* co
     std::lock_guard<std::recursive_mutex> lk(c.mu);
     if (e->front.valid) release_front(e->front);
     if (c.r > kStepInlineZ) return;  // (larger ranks stage z in one pinned area: not double-buffered)
+    // with several chains in the process the device is not idle during one chain's turn-around, and the launches of a
+    // dropped half step cost the others host time (tools/multichain.py)
+    if (g_live_contexts.load(std::memory_order_relaxed) > 1) return;
     if (!chain_step_covered(e, n_props, props, generator, theta_cur, z_or_theta_prop)) return;  // nothing to pre-launch
     // every posterior of the assumed current state must be on record already (the step in flight computed them)
     for (int i = 0; i < n_props; ++i)
