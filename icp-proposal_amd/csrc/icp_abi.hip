@@ -212,6 +212,19 @@ struct StateSlot {
 struct icp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // icp_chain_step splits a step over two streams: launches 1-3 (`front`) here, launches 4-5 on `stream`; a front waits on the
+  // device for the finish launch of the step before it (StepBeginArgs::wait_flag), the back half for its front's event
+  hipStream_t front_stream = nullptr;
+  // every eigen-decomposition of the context runs on this stream, beside the chain (launch order = execution order, so the
+  // decompositions of one proposal never overlap each other; the two directions of a step share ONE launch)
+  hipStream_t eig_stream = nullptr;
+  hipEvent_t ev_ready = nullptr;                 // stream -> eig_stream: "M is complete"
+  hipEvent_t ev_front[2] = {nullptr, nullptr};   // recorded behind launch 3 of the front with that parity
+  hipEvent_t ev_join = nullptr;                  // stream -> front_stream, when another entry point has used `stream`
+  hipEvent_t front_last = nullptr;               // the most recent front event (not owned): other entry points wait for it
+  bool stream_used_elsewhere = false;            // an entry point other than the chain step has enqueued on `stream`
+  int last_back_seq = 0;                         // sequence number of the last finish launch
+  int* h_wait_error = nullptr;                   // pinned: a front gave up waiting (never expected)
   std::recursive_mutex mu;
   int N = 0, T = 0, r = 0;
   DBuf<double> ref, mean, Q, Qp, sqrt_lambda, inv_sqrt_lambda, G, Ginv, P;  // P = (G + σ²I)⁻¹
@@ -296,9 +309,15 @@ struct icp_ctx {
 
 namespace {
 struct Bound {  // selects the context's device and (if enabled) its profiler for the calling thread
-  explicit Bound(icp_ctx* c) {
+  // chain_path: the caller is the merged chain step, which orders its two streams itself.  Every other entry point works
+  // on `stream` alone and shares scratch with the fronts: it first lets `stream` wait for the last front in flight.
+  explicit Bound(icp_ctx* c, bool chain_path = false) {
     c->bind();
     g_prof = c->profiling ? &c->prof : nullptr;
+    if (!chain_path) {
+      if (c->front_last) { (void)hipStreamWaitEvent(c->stream, c->front_last, 0); c->front_last = nullptr; }
+      c->stream_used_elsewhere = true;
+    }
   }
   ~Bound() { g_prof = nullptr; }
 };
@@ -418,7 +437,8 @@ struct PosteriorEntry {
   std::vector<double> theta;
   bool valid = false, eig_valid = false, eig_checked = false;  // eig_checked: its status has reached the host copy
   bool reserved = false;  // handed out to a step whose launches are in flight: not to be recycled
-  hipEvent_t eig_done = nullptr;  // recorded on the proposal's eigen stream behind the entry's decomposition
+  hipEvent_t eig_done = nullptr;  // recorded on the eigen stream behind the launch that holds the entry's decomposition
+  int done_value = 0;             // … and what the entry's word in icp_proposal::eig_words holds once it is complete (0: none)
   uint64_t stamp = 0;
   DBuf<int> id, aux;
   DBuf<double> pt, nhat, e;
@@ -451,16 +471,19 @@ struct icp_proposal {
   // Every eigen-decomposition of this proposal runs on its own stream (they share `work` and the warm start, so they must
   // not overlap each other), beside the context stream: the decomposition of a state that is not needed yet — the other
   // ICP direction of a freshly accepted state — then overlaps the chain's next steps instead of delaying a later one.
-  hipStream_t eig_stream = nullptr;
-  hipEvent_t ev_ready = nullptr;   // context stream -> eigen stream: "M is complete"
   // Speculative decomposition (icp_chain_step): the KL basis of the PROPOSED state's posterior is started as soon as its
   // normal matrix exists, before the caller has decided whether to accept.  The next call tells: its current state is
   // the proposed one (the basis is already on its way) or not (the decomposition is cancelled through `h_cancel`).
   int* h_eig = nullptr;            // pinned: eigen status of every memo entry, written by the decomposition itself
+  DBuf<int> eig_words;             // per memo entry: sequence number of its last finished decomposition (EigenRequest::done_word)
+  int eig_seq = 0;
   int* h_cancel = nullptr;         // pinned, 16 slots: the decomposition with sequence number q gives up once slot q%16 holds q
   int spec_seq = 0;
   PosteriorEntry* spec_entry = nullptr;
-  void speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, const int* ready, int ready_seq);
+  // fills the request of a speculative decomposition of `e` (the caller launches it, possibly together with another
+  // proposal's, on the context's eigen stream and records e.eig_done behind it)
+  void speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, const int* ready, int ready_seq, EigenSpec* spec_out,
+                       EigenRequest* rq_out);
   void resolve_speculation(const double* theta_cur);
   DBuf<int> status;       // 3 ints per memo entry: {chol(M), chol(G+σ²M), eigen}
   std::vector<int> h_status;
@@ -470,7 +493,8 @@ struct icp_proposal {
   PosteriorEntry& posterior(const double* theta, bool want_aux);
   PosteriorEntry* find_entry(const double* theta);
   PosteriorEntry& fresh_entry();
-  void ensure_eigen(PosteriorEntry& e);  // enqueue on eig_stream (no-op if done or in flight)
+  void prepare_eigen(PosteriorEntry& e, EigenRequest* rq);
+  void ensure_eigen(PosteriorEntry& e);  // enqueue on the context's eigen stream (no-op if done or in flight)
   void await_eigen(PosteriorEntry& e);   // make the context stream wait for it
   void check_status(PosteriorEntry& e);
 };
@@ -637,20 +661,32 @@ double* icp_proposal::mpart_for_write(int half) {
   return Mpart.p + (size_t)half * mpart_half_doubles;
 }
 
-void icp_proposal::ensure_eigen(PosteriorEntry& e) {
-  if (e.eig_valid) return;
-  icp_ctx& c = *ctx;
+// the request of the (ordinary) decomposition of `e`; the caller launches it on the context's eigen stream behind an
+// ev_ready wait and records e.eig_done
+void icp_proposal::prepare_eigen(PosteriorEntry& e, EigenRequest* rq) {
   if (!e.eig_done) HIP_OK(hipEventCreateWithFlags(&e.eig_done, hipEventDisableTiming));
-  HIP_OK(hipEventRecord(ev_ready, c.stream));  // M of this entry may still be in flight on the context stream
-  HIP_OK(hipStreamWaitEvent(eig_stream, ev_ready, 0));
   // the kernel reads all of Vwarm before it writes V, so the two may be the same buffer (a reused memo entry)
   h_eig[e.status_off / 3] = 0;
-  launch_posterior_eigen(eig_stream, c.r, e.M.p, c.sqrt_lambda.p, warm_valid ? warm_ptr : nullptr, e.V.p, e.Vt.p, e.S.p, work.p,
-                         status.p + e.status_off + 2, nullptr, h_eig + e.status_off / 3);
-  HIP_OK(hipEventRecord(e.eig_done, eig_stream));
+  e.done_value = ++eig_seq;
+  *rq = EigenRequest{e.M.p, warm_valid ? warm_ptr : nullptr, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2, nullptr,
+                     h_eig + e.status_off / 3, eig_words.p + e.status_off / 3, e.done_value};
   warm_ptr = e.V.p;
   warm_valid = true;
   e.eig_valid = true;
+}
+
+void icp_proposal::ensure_eigen(PosteriorEntry& e) {
+  if (e.eig_valid) return;
+  icp_ctx& c = *ctx;
+  EigenRequest rq;
+  prepare_eigen(e, &rq);
+  HIP_OK(hipEventRecord(c.ev_ready, c.stream));  // M of this entry may still be in flight on the context stream
+  HIP_OK(hipStreamWaitEvent(c.eig_stream, c.ev_ready, 0));
+  if (!launch_posterior_eigen_pair(c.eig_stream, c.r, c.sqrt_lambda.p, 1, &rq)) {  // ranks > 64: no completion word
+    e.done_value = 0;
+    launch_posterior_eigen(c.eig_stream, c.r, rq.M, c.sqrt_lambda.p, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.work, rq.status, nullptr, rq.host_status);
+  }
+  HIP_OK(hipEventRecord(e.eig_done, c.eig_stream));
 }
 
 void icp_proposal::await_eigen(PosteriorEntry& e) {
@@ -660,17 +696,17 @@ void icp_proposal::await_eigen(PosteriorEntry& e) {
 // ready / ready_seq: the word the regression launch that fills the current half of Mpart raises when it is done — the
 // decomposition waits for it on the device (an event between that launch and the next one on the context stream would
 // hold the latter back by several µs)
-void icp_proposal::speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, const int* ready, int ready_seq) {
-  icp_ctx& c = *ctx;
+void icp_proposal::speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, const int* ready, int ready_seq,
+                                   EigenSpec* spec_out, EigenRequest* rq_out) {
   if (!e.eig_done) HIP_OK(hipEventCreateWithFlags(&e.eig_done, hipEventDisableTiming));
   ++spec_seq;
-  const EigenSpec spec{splits, h_cancel + (spec_seq & 15), spec_seq, ready, ready_seq};
+  *spec_out = EigenSpec{splits, h_cancel + (spec_seq & 15), spec_seq, ready, ready_seq};
   // warm start: the basis of the current state's posterior (complete, or ahead of this launch on the same stream)
   const double* warm = cur.eig_valid ? cur.V.p : (warm_valid ? warm_ptr : nullptr);
   h_eig[e.status_off / 3] = 0;
-  launch_posterior_eigen(eig_stream, c.r, Mpart.p + (size_t)mpart_half * mpart_half_doubles, c.sqrt_lambda.p, warm, e.V.p, e.Vt.p,
-                         e.S.p, work.p, status.p + e.status_off + 2, &spec, h_eig + e.status_off / 3);
-  HIP_OK(hipEventRecord(e.eig_done, eig_stream));
+  e.done_value = ++eig_seq;
+  *rq_out = EigenRequest{Mpart.p + (size_t)mpart_half * mpart_half_doubles, warm, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2,
+                         spec_out, h_eig + e.status_off / 3, eig_words.p + e.status_off / 3, e.done_value};
   mpart_reader[mpart_half] = e.eig_done;
   e.eig_valid = true;
   e.eig_checked = false;
@@ -889,6 +925,13 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->N = N; ctx->T = T; ctx->r = r;
     ctx->bind();
     HIP_OK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&ctx->front_stream, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&ctx->eig_stream, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&ctx->ev_front[i], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    HIP_OK(hipHostMalloc((void**)&ctx->h_wait_error, sizeof(int) * 16, hipHostMallocDefault));
+    ctx->h_wait_error[0] = 0;
 
     // ---- model: Q = Φ·diag(√λ) in two layouts, Gram matrix G = QᵀQ and chol(G + σ²I) (one-off host work)
     std::vector<double> Q((size_t)3 * N * r), Qp((size_t)3 * N * r), sl(r), isl(r);
@@ -977,10 +1020,22 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
 void icp_ctx_destroy(icp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->eig_stream) {
+    (void)hipStreamSynchronize(ctx->eig_stream);
+    (void)hipStreamDestroy(ctx->eig_stream);
+  }
+  if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
+  if (ctx->front_stream) {
+    (void)hipStreamSynchronize(ctx->front_stream);
+    (void)hipStreamDestroy(ctx->front_stream);
+  }
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
+  for (int i = 0; i < 2; ++i) if (ctx->ev_front[i]) (void)hipEventDestroy(ctx->ev_front[i]);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->h_wait_error) (void)hipHostFree(ctx->h_wait_error);
   g_host_timing.report();
   for (auto& r : ctx->prof.pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -1170,8 +1225,6 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
       p->K = params->n_model_ids;
     }
     p->prm.target_points = nullptr;  // caller memory is not retained
-    HIP_OK(hipStreamCreateWithFlags(&p->eig_stream, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
     p->work.alloc(eigen_work_doubles(ctx->r));
     p->work.fill_bytes(0);  // holds the completion counter of the eigenvector replay kernel
     p->mpart_half_doubles = (size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1);
@@ -1183,6 +1236,8 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     for (int i = 0; i < kPosteriorMemo; ++i) p->h_eig[i] = 0;
     p->status.alloc(3 * kPosteriorMemo);
     p->status.fill_bytes(0);
+    p->eig_words.alloc(kPosteriorMemo);
+    p->eig_words.fill_bytes(0);
     p->h_status.assign(3 * kPosteriorMemo, 0);
     p->memo.reset(new PosteriorEntry[kPosteriorMemo]);
     *out = p;
@@ -1197,9 +1252,8 @@ void icp_proposal_destroy(icp_proposal* p) {
     std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    if (p->eig_stream) { (void)hipStreamSynchronize(p->eig_stream); (void)hipStreamDestroy(p->eig_stream); }
+    (void)hipStreamSynchronize(p->ctx->eig_stream);
     if (g_host_timing.on && eigen_speculation_supported(p->ctx->r)) eigen_debug_dump(p->work.p, p->ctx->r);
-    if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
     if (p->h_cancel) (void)hipHostFree(p->h_cancel);
     if (p->h_eig) (void)hipHostFree(p->h_eig);
     delete p;
@@ -1676,17 +1730,49 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   F.theta_cur.assign(theta_cur, theta_cur + 10 + r);
   F.key.assign(key, key + (generator >= 0 ? r : 10 + r));
   F.parity = (e->front_parity ^= 1);
+  if (c.stream_used_elsewhere) {  // another entry point has work on `stream` that the front may depend on: join once
+    HIP_OK(hipEventRecord(c.ev_join, c.stream));
+    HIP_OK(hipStreamWaitEvent(c.front_stream, c.ev_join, 0));
+    c.stream_used_elsewhere = false;
+  }
   // ---- cached side: posterior of the current state for every proposal (+ its KL basis for the generating one)
   PosteriorEntry** ec = F.ec;
   PosteriorEntry** ep = F.ep;
+  bool missing = false;
+  for (int i = 0; i < n_props; ++i) missing = missing || !props[i]->find_entry(theta_cur);
+  if (missing && c.front_last) {  // the posteriors are computed on `stream` with the scratch a front in flight may still use
+    HIP_OK(hipStreamWaitEvent(c.stream, c.front_last, 0));
+    c.front_last = nullptr;
+  }
   for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
+  if (missing) {  // … and this front reads them
+    HIP_OK(hipEventRecord(c.ev_join, c.stream));
+    HIP_OK(hipStreamWaitEvent(c.front_stream, c.ev_join, 0));
+  }
   // KL bases of the current state's posteriors: all of them are started now, each on its proposal's own stream (they
   // run side by side); only the generating one is waited for — the other is ready when a later step draws from it
-  for (int i = 0; i < n_props; ++i)
-    if (!ec[i]->eig_valid) props[i]->ensure_eigen(*ec[i]);
+  {
+    EigenRequest rqs[2];
+    PosteriorEntry* need[2];
+    int nn = 0;
+    for (int i = 0; i < n_props; ++i)
+      if (!ec[i]->eig_valid) { props[i]->prepare_eigen(*ec[i], &rqs[nn]); need[nn++] = ec[i]; }
+    if (nn > 0) {
+      HIP_OK(hipEventRecord(c.ev_ready, c.stream));  // M of these entries may still be in flight on the context stream
+      HIP_OK(hipStreamWaitEvent(c.eig_stream, c.ev_ready, 0));
+      if (!launch_posterior_eigen_pair(c.eig_stream, r, c.sqrt_lambda.p, nn, rqs))  // (ranks > 64: one after the other)
+        for (int i = 0; i < nn; ++i) {
+          need[i]->done_value = 0;
+          launch_posterior_eigen(c.eig_stream, r, rqs[i].M, c.sqrt_lambda.p, rqs[i].Vwarm, rqs[i].V, rqs[i].Vt, rqs[i].S, rqs[i].work, rqs[i].status,
+                                 nullptr, rqs[i].host_status);
+        }
+      for (int i = 0; i < nn; ++i) HIP_OK(hipEventRecord(need[i]->eig_done, c.eig_stream));
+    }
+  }
   bool eigen_first_use = false;
   if (generator >= 0) {
-    props[generator]->await_eigen(*ec[generator]);
+    // (await_eigen on the front's stream: through the decomposition's own completion word when it has one — see launch 1)
+    if (ec[generator]->done_value == 0 && ec[generator]->eig_done) HIP_OK(hipStreamWaitEvent(c.front_stream, ec[generator]->eig_done, 0));
     eigen_first_use = !ec[generator]->eig_checked;  // (possibly of an earlier prefetch or speculation): fetch its status
     ec[generator]->eig_checked = true;
   }
@@ -1746,7 +1832,14 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   b.x = s.x.p;
   b.has_surf = 1; b.surf = st_surf;
   b.has_vert = pt ? 1 : 0; b.vert = st_vert;
-  launch_step_begin(c.stream, b);
+  b.wait_flag = c.last_back_seq > 0 ? c.d_done.p + 2 : nullptr;  // (nothing to wait for before the first finish launch)
+  b.wait_seq = c.last_back_seq;
+  b.wait_error = c.h_wait_error;
+  if (generator >= 0 && ec[generator]->done_value != 0) {
+    b.wait2_flag = props[generator]->eig_words.p + ec[generator]->status_off / 3;
+    b.wait2_seq = ec[generator]->done_value;
+  }
+  launch_step_begin(c.front_stream, b);
 
   // 2 + 3: searches and correspondences
   StepSearchArgs q{};
@@ -1769,8 +1862,10 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
                               s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p};
     q.v_corr[0] = n_corr++;
   }
-  launch_step_filter(c.stream, q);
-  launch_step_resolve(c.stream, q);
+  launch_step_filter(c.front_stream, q);
+  launch_step_resolve(c.front_stream, q);
+  HIP_OK(hipEventRecord(c.ev_front[F.parity], c.front_stream));
+  c.front_last = c.ev_front[F.parity];
 
   F.valid = true;
 }
@@ -1824,7 +1919,7 @@ int icp_chain_step_prelaunch(icp_evaluator* e, int32_t n_props, icp_proposal* co
     // every posterior of the assumed current state must be on record already (the step in flight computed them)
     for (int i = 0; i < n_props; ++i)
       if (!props[i]->find_entry(theta_cur)) return;
-    Bound _b(&c);
+    Bound _b(&c, true);
     try {
       enqueue_front(e, n_props, props, generator, theta_cur, z_or_theta_prop, e->front);
     } catch (...) {
@@ -1857,7 +1952,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     if (e->front.valid && !reuse) release_front(e->front);  // pre-launched for another outcome: dropped
     per_stage = !reuse && !chain_step_covered(e, n_props, props, generator, theta_cur, theta_prop);
     if (per_stage) return;
-    Bound _b(&c);
+    Bound _b(&c, true);
     g_host_timing.start();
 
     for (int i = 0; i < n_props; ++i) props[i]->resolve_speculation(theta_cur);
@@ -1913,6 +2008,8 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     // test hook: the speculative decompositions wait for a word that never comes, time out and are repeated
     static const int starve = std::getenv("ICP_TEST_STARVE_SPECULATION") ? (1 << 24) : 0;
     const int step_seq = ++c.step_seq;
+    HIP_OK(hipStreamWaitEvent(c.stream, c.ev_front[F.parity], 0));  // launches 1-3 of this step (other stream)
+    if (c.front_last == c.ev_front[F.parity]) c.front_last = nullptr;  // (`stream` now follows it anyway)
     launch_step_regression(c.stream, g);
 
     // 5: factorisations + tails (results go straight to pinned host memory)
@@ -1930,15 +2027,19 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
                                   c.h_res + 9 + 2 * i, c.h_status + 2 * i + 1};
     }
     f.done_counter = c.d_done.p; f.host_flag = c.h_flag; f.seq = step_seq;
-    f.ready_flag = speculate ? c.d_done.p + 2 : nullptr;
+    f.ready_flag = c.d_done.p + 2;  // (speculative decompositions and the next step's first launches wait for it)
+    c.last_back_seq = step_seq;
     launch_step_finish(c.stream, f);
     g_host_timing.mark(1);
     // KL bases of the proposed state's posteriors, in case it is accepted: they run on the proposals' own streams beside
     // the factorisations and the host's round trip; the next call keeps or cancels them (resolve_speculation)
-    if (speculate)
-      for (int i = 0; i < n_props; ++i) {
-        props[i]->speculate_eigen(*ep[i], *ec[i], splits[i], c.d_done.p + 2, step_seq + starve);
-      }
+    if (speculate) {  // both directions in one launch: they run side by side
+      EigenSpec specs[2];
+      EigenRequest rqs[2];
+      for (int i = 0; i < n_props; ++i) props[i]->speculate_eigen(*ep[i], *ec[i], splits[i], c.d_done.p + 2, step_seq + starve, &specs[i], &rqs[i]);
+      launch_posterior_eigen_pair(c.eig_stream, r, c.sqrt_lambda.p, n_props, rqs);
+      for (int i = 0; i < n_props; ++i) HIP_OK(hipEventRecord(ep[i]->eig_done, c.eig_stream));
+    }
     if (c.idle_fn) c.idle_fn(c.idle_arg);  // the caller's outcome-independent host work runs beside the device
     g_host_timing.mark(2);
     if (eigen_enqueued) {
@@ -1959,6 +2060,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
 
     // ---- bookkeeping with the results in hand
     g_host_timing.mark_wait(eigen_first_use);
+    if (c.h_wait_error[0]) { c.h_wait_error[0] = 0; fail(ICP_ERR_DEVICE, "internal: a step's first launches timed out waiting for the step before them"); }
     if (eigen_first_use && eigen_status_pinned) {  // this step's first launch waited for that decomposition: its status is in
       icp_proposal* p = props[generator];
       const int st = p->h_eig[ec[generator]->status_off / 3];

@@ -167,6 +167,12 @@ size_t eigen_work_doubles(int r);  // size of `work`
 constexpr int kEigenGaveUp = 3;  // pinned status of a speculative decomposition whose input never arrived
 struct EigenSpec { int splits; const int* cancel; int seq; const int* ready; int ready_seq; };
 bool eigen_speculation_supported(int r);
+// up to two decompositions of the same rank in ONE launch (they run side by side); false: not available for this rank
+// done_word (optional): set to done_value (release, agent scope) when THIS decomposition's outputs are complete — or when it
+// gave up — so that a consumer on another stream can wait for one of the two without waiting for the whole launch
+struct EigenRequest { const double* M; const double* Vwarm; double* V; double* Vt; double* S; double* work; int* status;
+                      const EigenSpec* spec; int* host_status; int* done_word; int done_value; };
+bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq);
 void eigen_debug_dump(const double* work, int r);
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
                             double* Vt, double* S, double* work /* eigen_work_doubles(r) */, int* status,
@@ -215,6 +221,12 @@ constexpr int kStepMaxOut = 6;
 
 struct StepBeginArgs {  // launch 1: [propose] -> coefficients -> instance -> search initialisation
   int N, r, inst_blocks, tpr_log2;
+  // The first three launches run on their own stream, beside the last launch of the step BEFORE them (which they do not
+  // depend on).  What they must not overtake is that step's searches — same scratch, same hints — so the launch waits, on
+  // the device, for the word the finish launch of that step raises when it starts (*wait_flag - wait_seq >= 0); an event
+  // there would hold that step's own launches back.  *wait_error (pinned) is set if the word does not come within 50 ms.
+  const int* wait_flag; int wait_seq; int* wait_error;
+  const int* wait2_flag; int wait2_seq;  // likewise: the word of the eigen-decomposition the proposal draws from (EigenRequest::done_word)
   const double* Qp; const double* ref; const double* mean;
   Pose pose;
   int propose;              // 1: coefficients = a8 from `prop` (prop.z ignored: see zin/z_ptr); 0: coefficients = zin / z_ptr

@@ -497,12 +497,13 @@ constexpr int kReplayRowsPerBlock = 2 * kReplayWaves;
 
 __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* rotlog, int* meta,
                                       double* vpos /* [n2][64] */, double* Vout, double* Vtout,
-                                      int launch_id) {
+                                      int launch_id, int me /* 0-based replay workgroup of this problem */, int nb /* their number */,
+                                      int* done_word, int done_value) {
   __shared__ int s_pw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n2 = (r + 1) & ~1, m = n2 >> 1;
   double* s_log = s_dyn;  // kReplayStageRounds × m entries of (c, −s)
-  const int kc = lane >> 5, q = lane & 31, k = kReplayRowsPerBlock * ((int)blockIdx.x - 1) + 2 * wave + kc;
+  const int kc = lane >> 5, q = lane & 31, k = kReplayRowsPerBlock * me + 2 * wave + kc;
   const bool act = q < m && wave < kReplayWaves;
   const int qc = act ? q : 0;
   // this lane's pair of the row: positions 2q (first) and 2q+1 (second)
@@ -520,7 +521,7 @@ __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* 
       }
       s_pw = pw;
 #ifdef ICP_EIGEN_TIMING
-      if (blockIdx.x == 1 && (pw & kPwFinished)) g_eigen_stamps[40] = __builtin_amdgcn_s_memrealtime();
+      if (me == 0 && (pw & kPwFinished)) g_eigen_stamps[40] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
     __syncthreads();
@@ -556,13 +557,12 @@ __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* 
     if (pw & kPwFinished) break;
   }
 #ifdef ICP_EIGEN_TIMING
-  if (blockIdx.x == 1 && tid == 0) g_eigen_stamps[41] = __builtin_amdgcn_s_memrealtime();
+  if (me == 0 && tid == 0) g_eigen_stamps[41] = __builtin_amdgcn_s_memrealtime();
 #endif
   // ---- signs and output.  The largest-|.| component of every eigenvector (column of V), the first among equals, is made
   // positive; the columns go out in the rank order of the producer.  Every workgroup finds the candidates of its own rows
   // (wave -> workgroup through LDS), the workgroups exchange them through `xchg` (one small message each), and every lane
   // writes its own entries — V never travels.
-  const int nb = (int)gridDim.x - 1, me = (int)blockIdx.x - 1;
   double* s_pv = s_dyn;                    // [waves][64 positions] candidate value (signed)
   int* s_pk = (int*)(s_dyn + 16 * 64);     // … and its row
   double* s_bv = s_dyn + 16 * 64 + 8 * 64; // [64] workgroup's (then the global) candidate
@@ -634,14 +634,19 @@ __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* 
     }
   }
 #ifdef ICP_EIGEN_TIMING
-  if (blockIdx.x == 1 && tid == 0) g_eigen_stamps[42] = __builtin_amdgcn_s_memrealtime();
+  if (me == 0 && tid == 0) g_eigen_stamps[42] = __builtin_amdgcn_s_memrealtime();
 #endif
   // the last workgroup out puts the shared words back to idle (the producer has long finished; nobody reads them any more)
   __syncthreads();
-  if (tid == 0 && atomicAdd(&meta[1], 1) == nb - 1) {
-    meta[1] = 0;
-    __hip_atomic_store(meta, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int o = 0; o < nb; ++o) __hip_atomic_store(meta + 2 + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    __threadfence();  // this workgroup's rows of V and Vᵀ, before it is counted out
+    if (atomicAdd(&meta[1], 1) == nb - 1) {
+      meta[1] = 0;
+      __hip_atomic_store(meta, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int o = 0; o < nb; ++o) __hip_atomic_store(meta + 2 + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // this decomposition is complete (or dropped): whoever waits for it alone need not wait for the rest of the launch
+      if (done_word) __hip_atomic_store(done_word, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -652,15 +657,33 @@ constexpr int kRrOC = 0, kRrOA = 2 * kRrSzC, kRrOV = kRrOA + 2 * kRrSzA;  // tab
 constexpr int kRrLogWave = 14;            // never a block wave (at most 9 of those, on waves 0-2, 4-6, 8-10)
 template <int N> struct IntC { static constexpr int value = N; };
 
-__global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
-                                                              const double* Vwarm /* may be Vout */, double* Vout,
-                                                              double* Vtout, double* __restrict__ Sout,
-                                                              int* __restrict__ status, int ldk, double* rotlog,
-                                                              int* meta, double* vpos, int max_sweeps, EigenSpec spec, int launch_id,
-                                                              int* host_status) {
+// One launch decomposes up to two posteriors side by side (the two ICP directions of a chain step): problem p owns the
+// workgroups [p·per, (p+1)·per), the first of which iterates while the others replay.
+struct EigenProblem {
+  const double* M; const double* Vwarm /* may be Vout */; double* Vout; double* Vtout; double* Sout; int* status;
+  double* rotlog; int* meta; double* vpos; EigenSpec spec; int launch_id; int* host_status; int* done_word; int done_value;
+};
+struct EigenBatch { int n; EigenProblem p[2]; };
+
+__global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double* __restrict__ sqrt_lambda, int ldk, int max_sweeps,
+                                                              int per /* workgroups per problem */, EigenBatch batch) {
+  const int which = (int)blockIdx.x / per, local = (int)blockIdx.x - which * per;
+  const EigenProblem& pb = batch.p[which];
+  const double* __restrict__ M = pb.M;
+  const double* Vwarm = pb.Vwarm;
+  double* Vout = pb.Vout;
+  double* Vtout = pb.Vtout;
+  double* __restrict__ Sout = pb.Sout;
+  int* __restrict__ status = pb.status;
+  double* rotlog = pb.rotlog;
+  int* meta = pb.meta;
+  double* vpos = pb.vpos;
+  const EigenSpec spec = pb.spec;
+  const int launch_id = pb.launch_id;
+  int* host_status = pb.host_status;
   if (Vwarm && !(Vwarm[0] == Vwarm[0])) Vwarm = nullptr;  // the basis of a decomposition that gave up (see below): cold start
-  if (blockIdx.x != 0) {
-    eigen_replay_consumer(r, Vwarm, rotlog, meta, vpos, Vout, Vtout, launch_id);
+  if (local != 0) {
+    eigen_replay_consumer(r, Vwarm, rotlog, meta, vpos, Vout, Vtout, launch_id, local - 1, per - 1, pb.done_word, pb.done_value);
     return;
   }
   __shared__ double s_red[16], s_red2[16], s_mu[64];
@@ -1289,30 +1312,42 @@ void eigen_debug_dump(const double* work, int r) {  // developer aid: convergenc
 
 bool eigen_speculation_supported(int r) { return r >= 3 && r <= 64 && std::getenv("ICP_EIGEN_GENERIC") == nullptr; }
 
+bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq) {
+  static const bool force_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
+  if (!(r >= 3 && r <= 64 && !force_generic) || n < 1 || n > 2) return false;
+  // fixed-position variant: A, V and the rotation table double-buffered in LDS
+  const int n2 = (r + 1) & ~1;
+  const int ldk = 66;  // ldk: 64 coordinates per position row, rows 16 B apart modulo the 256-B bank window
+  const size_t szV = (size_t)n2 * ldk;
+  const size_t shmem = sizeof(double) * ((size_t)kRrOV + 2 * szV);
+  // work = [rotation log | sign exchange | meta: progress word, counters, rank per position]
+  const size_t log_doubles = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;
+  static const int sweeps_cap = std::getenv("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(std::getenv("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
+  static bool lds_set = false;
+  set_dyn_lds_once((const void*)k_posterior_eigen_rr, sizeof(double) * ((size_t)kRrOV + 2 * 64 * 66), &lds_set);
+  static std::atomic<int> launch_counter{0};  // (any value the previous launch on this `work` did not use would do)
+  EigenBatch batch{};
+  batch.n = n;
+  for (int i = 0; i < n; ++i) {
+    double* vpos = rq[i].work + log_doubles;
+    const int launch_id = 1 + (int)((unsigned)(++launch_counter) % kPwIdMask);  // never 0: the idle value of the progress word
+    batch.p[i] = EigenProblem{rq[i].M, rq[i].Vwarm, rq[i].V, rq[i].Vt, rq[i].S, rq[i].status, rq[i].work, (int*)(vpos + (size_t)n2 * 64), vpos,
+                              rq[i].spec ? *rq[i].spec : EigenSpec{0, nullptr, 0, nullptr, 0}, launch_id, rq[i].host_status, rq[i].done_word,
+                              rq[i].done_value};
+  }
+  ProfScope _ps(st, KID_EIGEN);
+  // per problem: workgroup 0 iterates; the others replay its rotations on V as the sweeps are published
+  const int per = 1 + (r + kReplayRowsPerBlock - 1) / kReplayRowsPerBlock;
+  hipLaunchKernelGGL(k_posterior_eigen_rr, dim3(n * per), dim3(1024), shmem, st, r, sqrt_lambda, ldk, std::min(sweeps_cap, kEigenMaxSweeps), per,
+                     batch);
+  return true;
+}
+
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
                             double* Vt, double* S, double* work, int* status, const EigenSpec* spec, int* host_status) {
-  static const bool force_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
-  if (r >= 3 && r <= 64 && !force_generic) {  // fixed-position variant: A, V and the rotation table double-buffered in LDS
-    const int n2 = (r + 1) & ~1;
-    const int ldk = 66;  // ldk: 64 coordinates per position row, rows 16 B apart modulo the 256-B bank window
-    const size_t szV = (size_t)n2 * ldk;
-    const size_t shmem = sizeof(double) * ((size_t)kRrOV + 2 * szV);
-    // work = [rotation log | position-major V | meta: n_rounds, done counter, rank per position]
-    const size_t log_doubles = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;
-    double* rotlog = work;
-    double* vpos = work + log_doubles;
-    int* meta = (int*)(vpos + (size_t)n2 * 64);
-    static const int sweeps_cap = std::getenv("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(std::getenv("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
-    static bool lds_set = false;
-    set_dyn_lds_once((const void*)k_posterior_eigen_rr, sizeof(double) * ((size_t)kRrOV + 2 * 64 * 66), &lds_set);
-    static std::atomic<int> launch_counter{0};  // (any value the previous launch on this `work` did not use would do)
-    const int launch_id = 1 + (int)((unsigned)(++launch_counter) % kPwIdMask);  // never 0: the idle value of the progress word
-    ProfScope _ps(st, KID_EIGEN);
-    // workgroup 0 iterates; the others replay its rotations on V as the sweeps are published (32 coordinates each)
-    const int n_replay = (r + kReplayRowsPerBlock - 1) / kReplayRowsPerBlock;
-    hipLaunchKernelGGL(k_posterior_eigen_rr, dim3(1 + n_replay), dim3(1024), shmem, st, r, M, sqrt_lambda, Vwarm, V, Vt, S, status, ldk,
-                       rotlog, meta, vpos, std::min(sweeps_cap, kEigenMaxSweeps), spec ? *spec : EigenSpec{0, nullptr, 0, nullptr, 0}, launch_id, host_status);
-    return;
+  {
+    const EigenRequest rq{M, Vwarm, V, Vt, S, work, status, spec, host_status, nullptr, 0};
+    if (launch_posterior_eigen_pair(st, r, sqrt_lambda, 1, &rq)) return;
   }
   static const bool own_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
   if (!own_generic && r > 64) {

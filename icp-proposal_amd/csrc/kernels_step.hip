@@ -32,6 +32,23 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) {
   __shared__ double s_c[512];
   const int tid = threadIdx.x, r = a.r;
   const double* zsrc = r <= kStepInlineZ ? a.zin : a.z_ptr;
+  if (a.wait_flag || a.wait2_flag) {  // see StepBeginArgs
+    if (tid == 0) {
+      const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+      for (;;) {
+        const bool ok1 = !a.wait_flag || __hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - a.wait_seq >= 0;
+        const bool ok2 = !a.wait2_flag || __hip_atomic_load(a.wait2_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - a.wait2_seq >= 0;
+        if (ok1 && ok2) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000) {
+          __hip_atomic_store(a.wait_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    __threadfence();
+  }
   const bool inst = (int)blockIdx.x < a.inst_blocks;
   const int i = blockIdx.x * kStepBeginPoints + tid;
   const bool my_point = inst && tid < kStepBeginPoints && i < a.N;
