@@ -212,16 +212,17 @@ struct StateSlot {
 struct icp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  // icp_chain_step splits a step over two streams: launches 1-3 (`front`) here, launches 4-5 on `stream`; a front waits on the
-  // device for the finish launch of the step before it (StepBeginArgs::wait_flag), the back half for its front's event
-  hipStream_t front_stream = nullptr;
+  // icp_chain_step alternates between two streams: the five launches of a step go to one of them in order, the next step's
+  // to the other.  Launches 1-3 of a step do not depend on the finish launch of the step before it and run beside it; what
+  // they must not overtake is that step's searches (same scratch, same hints), so launch 1 waits on the device for the word
+  // the finish launch of that step raises when it starts (StepBeginArgs::wait_flag).  No event crosses the two streams.
+  hipStream_t front_stream = nullptr;            // the second of the two (`stream` is the first, and everybody else's)
   // every eigen-decomposition of the context runs on this stream, beside the chain (launch order = execution order, so the
   // decompositions of one proposal never overlap each other; the two directions of a step share ONE launch)
   hipStream_t eig_stream = nullptr;
   hipEvent_t ev_ready = nullptr;                 // stream -> eig_stream: "M is complete"
-  hipEvent_t ev_front[2] = {nullptr, nullptr};   // recorded behind launch 3 of the front with that parity
   hipEvent_t ev_join = nullptr;                  // stream -> front_stream, when another entry point has used `stream`
-  hipEvent_t front_last = nullptr;               // the most recent front event (not owned): other entry points wait for it
+  bool front_stream_used = false;                // a step is (or may still be) on front_stream: other entry points drain it first
   bool stream_used_elsewhere = false;            // an entry point other than the chain step has enqueued on `stream`
   int last_back_seq = 0;                         // sequence number of the last finish launch
   int* h_wait_error = nullptr;                   // pinned: a front gave up waiting (never expected)
@@ -315,7 +316,7 @@ struct Bound {  // selects the context's device and (if enabled) its profiler fo
     c->bind();
     g_prof = c->profiling ? &c->prof : nullptr;
     if (!chain_path) {
-      if (c->front_last) { (void)hipStreamWaitEvent(c->stream, c->front_last, 0); c->front_last = nullptr; }
+      if (c->front_stream_used) { (void)hipStreamSynchronize(c->front_stream); c->front_stream_used = false; }
       c->stream_used_elsewhere = true;
     }
   }
@@ -511,7 +512,8 @@ struct StepFront {
   PosteriorEntry* ep[2] = {nullptr, nullptr};
   StateSlot* s = nullptr;
   bool eigen_first_use = false;
-  int parity = 0;  // which half of the pinned coefficient area its first launch writes
+  int parity = 0;  // which half of the pinned coefficient area its first launch writes, and which of the two streams the step uses
+  hipStream_t stream = nullptr;
   int Ksurf = 0;
 };
 constexpr int kCoeffArea = 512;  // doubles per half of that area (>= kMaxRank)
@@ -928,7 +930,6 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     HIP_OK(hipStreamCreateWithFlags(&ctx->front_stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&ctx->eig_stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&ctx->ev_front[i], hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     HIP_OK(hipHostMalloc((void**)&ctx->h_wait_error, sizeof(int) * 16, hipHostMallocDefault));
     ctx->h_wait_error[0] = 0;
@@ -1033,7 +1034,6 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
-  for (int i = 0; i < 2; ++i) if (ctx->ev_front[i]) (void)hipEventDestroy(ctx->ev_front[i]);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->h_wait_error) (void)hipHostFree(ctx->h_wait_error);
   g_host_timing.report();
@@ -1730,25 +1730,26 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   F.theta_cur.assign(theta_cur, theta_cur + 10 + r);
   F.key.assign(key, key + (generator >= 0 ? r : 10 + r));
   F.parity = (e->front_parity ^= 1);
-  if (c.stream_used_elsewhere) {  // another entry point has work on `stream` that the front may depend on: join once
-    HIP_OK(hipEventRecord(c.ev_join, c.stream));
-    HIP_OK(hipStreamWaitEvent(c.front_stream, c.ev_join, 0));
-    c.stream_used_elsewhere = false;
-  }
   // ---- cached side: posterior of the current state for every proposal (+ its KL basis for the generating one)
   PosteriorEntry** ec = F.ec;
   PosteriorEntry** ep = F.ep;
   bool missing = false;
   for (int i = 0; i < n_props; ++i) missing = missing || !props[i]->find_entry(theta_cur);
-  if (missing && c.front_last) {  // the posteriors are computed on `stream` with the scratch a front in flight may still use
-    HIP_OK(hipStreamWaitEvent(c.stream, c.front_last, 0));
-    c.front_last = nullptr;
+  if (missing && c.front_stream_used) {  // the posteriors are computed on `stream` with the scratch a step in flight may still use
+    HIP_OK(hipStreamSynchronize(c.front_stream));
+    c.front_stream_used = false;
   }
   for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
-  if (missing) {  // … and this front reads them
-    HIP_OK(hipEventRecord(c.ev_join, c.stream));
-    HIP_OK(hipStreamWaitEvent(c.front_stream, c.ev_join, 0));
+  if (missing) c.stream_used_elsewhere = true;  // … and this step reads them
+  F.stream = F.parity ? c.front_stream : c.stream;
+  if (F.parity) {
+    if (c.stream_used_elsewhere) {  // another entry point has work on `stream` that this step may depend on: join once
+      HIP_OK(hipEventRecord(c.ev_join, c.stream));
+      HIP_OK(hipStreamWaitEvent(c.front_stream, c.ev_join, 0));
+    }
+    c.front_stream_used = true;
   }
+  c.stream_used_elsewhere = false;
   // KL bases of the current state's posteriors: all of them are started now, each on its proposal's own stream (they
   // run side by side); only the generating one is waited for — the other is ready when a later step draws from it
   {
@@ -1772,7 +1773,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   bool eigen_first_use = false;
   if (generator >= 0) {
     // (await_eigen on the front's stream: through the decomposition's own completion word when it has one — see launch 1)
-    if (ec[generator]->done_value == 0 && ec[generator]->eig_done) HIP_OK(hipStreamWaitEvent(c.front_stream, ec[generator]->eig_done, 0));
+    if (ec[generator]->done_value == 0 && ec[generator]->eig_done) HIP_OK(hipStreamWaitEvent(F.stream, ec[generator]->eig_done, 0));
     eigen_first_use = !ec[generator]->eig_checked;  // (possibly of an earlier prefetch or speculation): fetch its status
     ec[generator]->eig_checked = true;
   }
@@ -1839,7 +1840,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
     b.wait2_flag = props[generator]->eig_words.p + ec[generator]->status_off / 3;
     b.wait2_seq = ec[generator]->done_value;
   }
-  launch_step_begin(c.front_stream, b);
+  launch_step_begin(F.stream, b);
 
   // 2 + 3: searches and correspondences
   StepSearchArgs q{};
@@ -1862,10 +1863,8 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
                               s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p};
     q.v_corr[0] = n_corr++;
   }
-  launch_step_filter(c.front_stream, q);
-  launch_step_resolve(c.front_stream, q);
-  HIP_OK(hipEventRecord(c.ev_front[F.parity], c.front_stream));
-  c.front_last = c.ev_front[F.parity];
+  launch_step_filter(F.stream, q);
+  launch_step_resolve(F.stream, q);
 
   F.valid = true;
 }
@@ -2008,9 +2007,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     // test hook: the speculative decompositions wait for a word that never comes, time out and are repeated
     static const int starve = std::getenv("ICP_TEST_STARVE_SPECULATION") ? (1 << 24) : 0;
     const int step_seq = ++c.step_seq;
-    HIP_OK(hipStreamWaitEvent(c.stream, c.ev_front[F.parity], 0));  // launches 1-3 of this step (other stream)
-    if (c.front_last == c.ev_front[F.parity]) c.front_last = nullptr;  // (`stream` now follows it anyway)
-    launch_step_regression(c.stream, g);
+    launch_step_regression(F.stream, g);  // (behind launches 1-3 of this step, same stream)
 
     // 5: factorisations + tails (results go straight to pinned host memory)
     StepFinishArgs f{};
@@ -2029,7 +2026,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     f.done_counter = c.d_done.p; f.host_flag = c.h_flag; f.seq = step_seq;
     f.ready_flag = c.d_done.p + 2;  // (speculative decompositions and the next step's first launches wait for it)
     c.last_back_seq = step_seq;
-    launch_step_finish(c.stream, f);
+    launch_step_finish(F.stream, f);
     g_host_timing.mark(1);
     // KL bases of the proposed state's posteriors, in case it is accepted: they run on the proposals' own streams beside
     // the factorisations and the host's round trip; the next call keeps or cancels them (resolve_speculation)
@@ -2043,6 +2040,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     if (c.idle_fn) c.idle_fn(c.idle_arg);  // the caller's outcome-independent host work runs beside the device
     g_host_timing.mark(2);
     if (eigen_enqueued) {
+      if (F.stream != c.stream) HIP_OK(hipStreamSynchronize(F.stream));
       sync_proposal_status_if(props[generator], true);
       c.finish(0, 0);
     } else {
@@ -2054,7 +2052,10 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       while (*flag != f.seq) {
         if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) break;
       }
-      if (*flag != f.seq) c.finish(0, 0);
+      if (*flag != f.seq) {
+        if (F.stream != c.stream) HIP_OK(hipStreamSynchronize(F.stream));
+        c.finish(0, 0);
+      }
       c.stage_used = 0;
     }
 
