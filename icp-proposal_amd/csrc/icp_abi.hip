@@ -439,6 +439,7 @@ struct PosteriorEntry {
   bool valid = false, eig_valid = false, eig_checked = false;  // eig_checked: its status has reached the host copy
   bool reserved = false;  // handed out to a step whose launches are in flight: not to be recycled
   hipEvent_t eig_done = nullptr;  // recorded on the eigen stream behind the launch that holds the entry's decomposition
+  hipEvent_t eig_done_shared = nullptr;  // … or, not owned, the event of the entry it shared that launch with
   int done_value = 0;             // … and what the entry's word in icp_proposal::eig_words holds once it is complete (0: none)
   uint64_t stamp = 0;
   DBuf<int> id, aux;
@@ -447,6 +448,7 @@ struct PosteriorEntry {
   DBuf<double> coeffs, M, alpha, V, Vt, S;
   int status_off = 0;  // this entry's 3 ints inside the proposal's status buffer
   ~PosteriorEntry() { if (eig_done) (void)hipEventDestroy(eig_done); }
+  hipEvent_t eigen_event() const { return eig_done_shared ? eig_done_shared : eig_done; }
   CorrBuffers corr() const { return CorrBuffers{id.p, aux.p, pt.p, keep.p, nhat.p, e.p}; }
 };
 
@@ -464,8 +466,8 @@ struct icp_proposal {
                           // between them so that a speculative decomposition can still read the previous step's
   size_t mpart_half_doubles = 0;
   int mpart_half = 0;
-  hipEvent_t mpart_reader[2] = {nullptr, nullptr};  // completion of the last decomposition that reads the half (not owned)
-  double* mpart_for_write(int half);                // the context stream waits for that reader first
+  PosteriorEntry* mpart_reader[2] = {nullptr, nullptr};  // the entry whose decomposition reads the half (its event is waited for)
+  double* mpart_for_write(int half, hipStream_t st);  // `st` (where the writer runs) waits for that reader first, if it is still at work
   DBuf<double> fscratch;  // (r+1)·r + 8 factorisation scratch (ranks too large for LDS)
   const double* warm_ptr = nullptr;  // eigenvectors of the most recent posterior (inside its memo entry): warm start of the next
   bool warm_valid = false;
@@ -648,16 +650,19 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
   const double wt = 1.0 / (prm.tangential_noise * prm.tangential_noise);
   const double kappa = 1.0 / (prm.noise_along_normal * prm.noise_along_normal) - wt;
   int splits = 1;
-  double* parts = mpart_for_write(0);
+  double* parts = mpart_for_write(0, c.stream);
   launch_regression(c.stream, K, r, c.Q.p, e.corr(), wt, kappa, parts, &splits);
   PosteriorFactorIO io{parts, splits, e.M.p, e.alpha.p, status.p + e.status_off, fscratch.p};
   launch_posterior_factor(c.stream, r, 1, &io);
   return e;
 }
 
-double* icp_proposal::mpart_for_write(int half) {
-  if (mpart_reader[half]) {
-    HIP_OK(hipStreamWaitEvent(ctx->stream, mpart_reader[half], 0));
+double* icp_proposal::mpart_for_write(int half, hipStream_t st) {
+  if (PosteriorEntry* rd = mpart_reader[half]) {
+    // a cancelled reader (eig_valid withdrawn) may read anything; a finished one has left its status in pinned memory
+    // (-1 while in flight): the wait — an API call per step otherwise — is only enqueued for a kept one still at work
+    const bool at_work = rd->eig_valid && *(volatile int*)(h_eig + rd->status_off / 3) == -1;
+    if (at_work && rd->eigen_event()) HIP_OK(hipStreamWaitEvent(st, rd->eigen_event(), 0));
     mpart_reader[half] = nullptr;
   }
   return Mpart.p + (size_t)half * mpart_half_doubles;
@@ -668,7 +673,7 @@ double* icp_proposal::mpart_for_write(int half) {
 void icp_proposal::prepare_eigen(PosteriorEntry& e, EigenRequest* rq) {
   if (!e.eig_done) HIP_OK(hipEventCreateWithFlags(&e.eig_done, hipEventDisableTiming));
   // the kernel reads all of Vwarm before it writes V, so the two may be the same buffer (a reused memo entry)
-  h_eig[e.status_off / 3] = 0;
+  h_eig[e.status_off / 3] = -1;  // in flight; the decomposition stores its status here when it ends
   e.done_value = ++eig_seq;
   *rq = EigenRequest{e.M.p, warm_valid ? warm_ptr : nullptr, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2, nullptr,
                      h_eig + e.status_off / 3, eig_words.p + e.status_off / 3, e.done_value};
@@ -689,10 +694,11 @@ void icp_proposal::ensure_eigen(PosteriorEntry& e) {
     launch_posterior_eigen(c.eig_stream, c.r, rq.M, c.sqrt_lambda.p, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.work, rq.status, nullptr, rq.host_status);
   }
   HIP_OK(hipEventRecord(e.eig_done, c.eig_stream));
+  e.eig_done_shared = nullptr;
 }
 
 void icp_proposal::await_eigen(PosteriorEntry& e) {
-  if (e.eig_done) HIP_OK(hipStreamWaitEvent(ctx->stream, e.eig_done, 0));
+  if (e.eigen_event()) HIP_OK(hipStreamWaitEvent(ctx->stream, e.eigen_event(), 0));
 }
 
 // ready / ready_seq: the word the regression launch that fills the current half of Mpart raises when it is done — the
@@ -705,11 +711,11 @@ void icp_proposal::speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur,
   *spec_out = EigenSpec{splits, h_cancel + (spec_seq & 15), spec_seq, ready, ready_seq};
   // warm start: the basis of the current state's posterior (complete, or ahead of this launch on the same stream)
   const double* warm = cur.eig_valid ? cur.V.p : (warm_valid ? warm_ptr : nullptr);
-  h_eig[e.status_off / 3] = 0;
+  h_eig[e.status_off / 3] = -1;  // in flight
   e.done_value = ++eig_seq;
   *rq_out = EigenRequest{Mpart.p + (size_t)mpart_half * mpart_half_doubles, warm, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2,
                          spec_out, h_eig + e.status_off / 3, eig_words.p + e.status_off / 3, e.done_value};
-  mpart_reader[mpart_half] = e.eig_done;
+  mpart_reader[mpart_half] = &e;
   e.eig_valid = true;
   e.eig_checked = false;
   spec_entry = &e;
@@ -1767,13 +1773,13 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
           launch_posterior_eigen(c.eig_stream, r, rqs[i].M, c.sqrt_lambda.p, rqs[i].Vwarm, rqs[i].V, rqs[i].Vt, rqs[i].S, rqs[i].work, rqs[i].status,
                                  nullptr, rqs[i].host_status);
         }
-      for (int i = 0; i < nn; ++i) HIP_OK(hipEventRecord(need[i]->eig_done, c.eig_stream));
+      for (int i = 0; i < nn; ++i) { HIP_OK(hipEventRecord(need[i]->eig_done, c.eig_stream)); need[i]->eig_done_shared = nullptr; }
     }
   }
   bool eigen_first_use = false;
   if (generator >= 0) {
     // (await_eigen on the front's stream: through the decomposition's own completion word when it has one — see launch 1)
-    if (ec[generator]->done_value == 0 && ec[generator]->eig_done) HIP_OK(hipStreamWaitEvent(F.stream, ec[generator]->eig_done, 0));
+    if (ec[generator]->done_value == 0 && ec[generator]->eigen_event()) HIP_OK(hipStreamWaitEvent(F.stream, ec[generator]->eigen_event(), 0));
     eigen_first_use = !ec[generator]->eig_checked;  // (possibly of an earlier prefetch or speculation): fetch its status
     ec[generator]->eig_checked = true;
   }
@@ -1993,7 +1999,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
       g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];
       p->mpart_half ^= 1;
-      g.Mpart[i] = p->mpart_for_write(p->mpart_half);
+      g.Mpart[i] = p->mpart_for_write(p->mpart_half, F.stream);
       g.status[i] = p->status.p + ep[i]->status_off;
       g.ustart[i + 1] = g.ustart[i] + g.ntiles * splits[i];
     }
@@ -2035,7 +2041,9 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       EigenRequest rqs[2];
       for (int i = 0; i < n_props; ++i) props[i]->speculate_eigen(*ep[i], *ec[i], splits[i], c.d_done.p + 2, step_seq + starve, &specs[i], &rqs[i]);
       launch_posterior_eigen_pair(c.eig_stream, r, c.sqrt_lambda.p, n_props, rqs);
-      for (int i = 0; i < n_props; ++i) HIP_OK(hipEventRecord(ep[i]->eig_done, c.eig_stream));
+      HIP_OK(hipEventRecord(ep[0]->eig_done, c.eig_stream));  // one launch, one event
+      ep[0]->eig_done_shared = nullptr;
+      for (int i = 1; i < n_props; ++i) ep[i]->eig_done_shared = ep[0]->eig_done;
     }
     if (c.idle_fn) c.idle_fn(c.idle_arg);  // the caller's outcome-independent host work runs beside the device
     g_host_timing.mark(2);

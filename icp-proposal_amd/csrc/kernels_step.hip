@@ -226,7 +226,8 @@ FinishPlan finish_plan(int r) {
 
 template <int E, int NT>
 void launch_finish(hipStream_t st, const StepFinishArgs& a, size_t shmem) {
-  set_dyn_lds((const void*)k_step_finish<E, NT>, shmem);
+  static size_t lds_granted = 0;  // (one runtime call per process and size class instead of one per launch)
+  if (shmem > lds_granted) { set_dyn_lds((const void*)k_step_finish<E, NT>, shmem); lds_granted = shmem; }
   hipLaunchKernelGGL((k_step_finish<E, NT>), dim3(2 * a.n), dim3(NT), shmem, st, a);
 }
 
