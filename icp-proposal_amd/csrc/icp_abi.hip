@@ -485,8 +485,8 @@ struct icp_proposal {
   PosteriorEntry* spec_entry = nullptr;
   // fills the request of a speculative decomposition of `e` (the caller launches it, possibly together with another
   // proposal's, on the context's eigen stream and records e.eig_done behind it)
-  void speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, const int* ready, int ready_seq, EigenSpec* spec_out,
-                       EigenRequest* rq_out);
+  void speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, int half /* of Mpart: the step's partials */,
+                       const int* ready, int ready_seq, EigenSpec* spec_out, EigenRequest* rq_out);
   void resolve_speculation(const double* theta_cur);
   DBuf<int> status;       // 3 ints per memo entry: {chol(M), chol(G+σ²M), eigen}
   std::vector<int> h_status;
@@ -516,9 +516,13 @@ struct StepFront {
   bool eigen_first_use = false;
   int parity = 0;  // which half of the pinned coefficient area its first launch writes, and which of the two streams the step uses
   hipStream_t stream = nullptr;
+  int splits[2] = {1, 1};                  // launch 4: split count and partial-sum buffers of every posterior
+  double* mpart[2] = {nullptr, nullptr};
+  int mpart_half[2] = {0, 0};
   int Ksurf = 0;
 };
 constexpr int kCoeffArea = 512;  // doubles per half of that area (>= kMaxRank)
+constexpr int kReduceArea = 16 + 2 * kCoeffArea;  // pinned result of launch 4's likelihood reduction: 8 doubles per parity
 }  // namespace
 
 struct icp_evaluator {
@@ -704,7 +708,7 @@ void icp_proposal::await_eigen(PosteriorEntry& e) {
 // ready / ready_seq: the word the regression launch that fills the current half of Mpart raises when it is done — the
 // decomposition waits for it on the device (an event between that launch and the next one on the context stream would
 // hold the latter back by several µs)
-void icp_proposal::speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, const int* ready, int ready_seq,
+void icp_proposal::speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, int half, const int* ready, int ready_seq,
                                    EigenSpec* spec_out, EigenRequest* rq_out) {
   if (!e.eig_done) HIP_OK(hipEventCreateWithFlags(&e.eig_done, hipEventDisableTiming));
   ++spec_seq;
@@ -713,9 +717,9 @@ void icp_proposal::speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur,
   const double* warm = cur.eig_valid ? cur.V.p : (warm_valid ? warm_ptr : nullptr);
   h_eig[e.status_off / 3] = -1;  // in flight
   e.done_value = ++eig_seq;
-  *rq_out = EigenRequest{Mpart.p + (size_t)mpart_half * mpart_half_doubles, warm, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2,
+  *rq_out = EigenRequest{Mpart.p + (size_t)half * mpart_half_doubles, warm, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2,
                          spec_out, h_eig + e.status_off / 3, eig_words.p + e.status_off / 3, e.done_value};
-  mpart_reader[mpart_half] = &e;
+  mpart_reader[half] = &e;
   e.eig_valid = true;
   e.eig_checked = false;
   spec_entry = &e;
@@ -1872,6 +1876,34 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   launch_step_filter(F.stream, q);
   launch_step_resolve(F.stream, q);
 
+  // 4: regressions + likelihood reduction
+  StepRegressionArgs g{};
+  g.n = n_props; g.r = r;
+  const int nt = (r + 1 + 15) / 16;
+  g.ntiles = nt * nt;
+  g.Q = c.Q.p;
+  g.ustart[0] = 0;
+  int* splits = F.splits;
+  for (int i = 0; i < n_props; ++i) {
+    icp_proposal* p = props[i];
+    splits[i] = regression_splits(p->K);
+    g.K[i] = p->K;
+    g.kchunk[i] = std::max(1, (p->K + splits[i] - 1) / splits[i]);
+    g.cb[i] = ep[i]->corr();
+    g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
+    g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];
+    p->mpart_half ^= 1;
+    g.Mpart[i] = p->mpart_for_write(p->mpart_half, F.stream);
+    g.status[i] = p->status.p + ep[i]->status_off;
+    g.ustart[i + 1] = g.ustart[i] + g.ntiles * splits[i];
+  }
+  if (n_props == 1) g.ustart[2] = g.ustart[1];
+  g.reduce_kind = evp.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE ? 1 : 2;
+  g.Kred = evp.n_model_ids; g.d2 = s.surf_d2.p; g.mean = evp.gauss_mean; g.sigma = evp.gauss_sigma;
+  g.red_out = c.h_res + kReduceArea + F.parity * 8;  // (its own half: the host may still be reading the previous step's)
+  for (int i = 0; i < n_props; ++i) { F.mpart[i] = g.Mpart[i]; F.mpart_half[i] = props[i]->mpart_half; }
+  launch_step_regression(F.stream, g);
+
   F.valid = true;
 }
 
@@ -1982,45 +2014,19 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     for (int i = 0; i < 16; ++i) c.h_res[i] = 0.0;
     for (int i = 0; i < 16; ++i) c.h_status[i] = 0;
 
-    // 4: regressions + likelihood reduction
-    StepRegressionArgs g{};
-    g.n = n_props; g.r = r;
-    const int nt = (r + 1 + 15) / 16;
-    g.ntiles = nt * nt;
-    g.Q = c.Q.p;
-    g.ustart[0] = 0;
-    int splits[2] = {1, 1};
-    for (int i = 0; i < n_props; ++i) {
-      icp_proposal* p = props[i];
-      splits[i] = regression_splits(p->K);
-      g.K[i] = p->K;
-      g.kchunk[i] = std::max(1, (p->K + splits[i] - 1) / splits[i]);
-      g.cb[i] = ep[i]->corr();
-      g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
-      g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];
-      p->mpart_half ^= 1;
-      g.Mpart[i] = p->mpart_for_write(p->mpart_half, F.stream);
-      g.status[i] = p->status.p + ep[i]->status_off;
-      g.ustart[i + 1] = g.ustart[i] + g.ntiles * splits[i];
-    }
-    if (n_props == 1) g.ustart[2] = g.ustart[1];
-    g.reduce_kind = evp.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE ? 1 : 2;
-    g.Kred = evp.n_model_ids; g.d2 = s.surf_d2.p; g.mean = evp.gauss_mean; g.sigma = evp.gauss_sigma;
-    g.red_out = c.h_res;
     static const bool no_spec = std::getenv("ICP_NO_SPECULATION") != nullptr;
     const bool speculate = !no_spec && !c.speculation_off && g_live_contexts.load(std::memory_order_relaxed) <= 2 && n_props > 0 &&
                            eigen_speculation_supported(r);
     // test hook: the speculative decompositions wait for a word that never comes, time out and are repeated
     static const int starve = std::getenv("ICP_TEST_STARVE_SPECULATION") ? (1 << 24) : 0;
     const int step_seq = ++c.step_seq;
-    launch_step_regression(F.stream, g);  // (behind launches 1-3 of this step, same stream)
 
     // 5: factorisations + tails (results go straight to pinned host memory)
     StepFinishArgs f{};
     f.n = n_props; f.r = r; f.Ginv = c.Ginv.p; f.sigma2 = kSigma2;
     for (int i = 0; i < n_props; ++i) {
       icp_proposal* p = props[i];
-      f.Mpart[i] = g.Mpart[i]; f.splits[i] = splits[i];
+      f.Mpart[i] = F.mpart[i]; f.splits[i] = F.splits[i];
       f.M[i] = ep[i]->M.p; f.alpha[i] = ep[i]->alpha.p;
       f.status[i] = p->status.p + ep[i]->status_off;
       f.host_status[i] = c.h_status + 8 + i;
@@ -2034,18 +2040,22 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     c.last_back_seq = step_seq;
     launch_step_finish(F.stream, f);
     g_host_timing.mark(1);
+    // the caller's outcome-independent host work runs beside the device — first of all the pre-launch of the next step's
+    // first half, which the device can start as soon as the finish launch above has
+    static const bool hook_late = std::getenv("ICP_HOOK_LATE") != nullptr;  // (A/B switch: hook behind the speculative launches)
+    if (c.idle_fn && !hook_late) c.idle_fn(c.idle_arg);
     // KL bases of the proposed state's posteriors, in case it is accepted: they run on the proposals' own streams beside
     // the factorisations and the host's round trip; the next call keeps or cancels them (resolve_speculation)
     if (speculate) {  // both directions in one launch: they run side by side
       EigenSpec specs[2];
       EigenRequest rqs[2];
-      for (int i = 0; i < n_props; ++i) props[i]->speculate_eigen(*ep[i], *ec[i], splits[i], c.d_done.p + 2, step_seq + starve, &specs[i], &rqs[i]);
+      for (int i = 0; i < n_props; ++i) props[i]->speculate_eigen(*ep[i], *ec[i], F.splits[i], F.mpart_half[i], c.d_done.p + 2, step_seq + starve, &specs[i], &rqs[i]);
       launch_posterior_eigen_pair(c.eig_stream, r, c.sqrt_lambda.p, n_props, rqs);
       HIP_OK(hipEventRecord(ep[0]->eig_done, c.eig_stream));  // one launch, one event
       ep[0]->eig_done_shared = nullptr;
       for (int i = 1; i < n_props; ++i) ep[i]->eig_done_shared = ep[0]->eig_done;
     }
-    if (c.idle_fn) c.idle_fn(c.idle_arg);  // the caller's outcome-independent host work runs beside the device
+    if (c.idle_fn && hook_late) c.idle_fn(c.idle_arg);
     g_host_timing.mark(2);
     if (eigen_enqueued) {
       if (F.stream != c.stream) HIP_OK(hipStreamSynchronize(F.stream));
@@ -2119,6 +2129,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
         saved[8 + t] = c.h_res[0];
         std::memcpy(c.h_res, saved.data(), sizeof(double) * saved.size());
       }
+    for (int i = 0; i < 4; ++i) c.h_res[i] = c.h_res[kReduceArea + F.parity * 8 + i];  // launch 4's reduction, where finish_eval looks
     icp_evaluator::Memo* m = eval_store(e, theta_prop);
     m->status = finish_eval(e, c.h_res, &m->value, m->aux);
     *log_value_prop = m->value;

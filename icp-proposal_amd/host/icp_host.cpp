@@ -54,32 +54,41 @@ struct icp_host_chain {
   double current_p = 0.0;
   // the standard normals of step `ahead_step`, drawn by the idle hook of the native library while the step before it is
   // on the device (counter-based RNG: a pure function of (seed, step, lane), so drawing early changes nothing)
-  std::vector<double> ahead;
-  uint64_t ahead_step = ~0ull;
+  std::vector<double> ahead, ahead2;  // … and of the step after that
+  uint64_t ahead_step = ~0ull, ahead2_step = ~0ull;
   std::thread::id runner;  // the thread inside icp_host_chain_run (chains that share a context share its hook slot)
+  void draw_normals(uint64_t step, std::vector<double>& out) const {
+    StepRandom rnd{seed, step};
+    for (size_t j = 0; j < out.size(); ++j) out[j] = rnd.normal(j);
+  }
   static void draw_ahead(void* self) {
     icp_host_chain* ch = static_cast<icp_host_chain*>(self);
     if (std::this_thread::get_id() != ch->runner) return;  // another chain's step on a shared context: not our turn
     const uint64_t next = (uint64_t)ch->logger.index + 1;
-    if (ch->ahead_step == next) return;
-    StepRandom rnd{ch->seed, next};
-    for (size_t j = 0; j < ch->ahead.size(); ++j) ch->ahead[j] = rnd.normal(j);
-    ch->ahead_step = next;
-    // Two steps out of three are rejected: the next step then starts from the SAME state, and its proposal is a pure
-    // function of that state and of the numbers just drawn.  Its first launches are issued now, behind the step in
-    // flight, so the device does not idle through the host's turn-around; if this step is accepted instead they are
-    // dropped (icp_chain_step_prelaunch).
-    if (!ch->prefetcher.whole_step || ch->icp.empty() || ch->icp.size() > 2) return;
-    rnd.ahead = ch->ahead.data(); rnd.n_ahead = (int)ch->ahead.size();
-    ProposalGeneratorWithTransition* leaf = ch->root->peek(rnd, 0);
-    icp_proposal* hs[2] = {nullptr, nullptr};
-    for (size_t i = 0; i < ch->icp.size(); ++i) hs[i] = ch->icp[i]->h;
-    if (auto* ip = dynamic_cast<NonRigidIcpProposal*>(leaf)) {
-      if (ip->stepper) (void)icp_chain_step_prelaunch(ch->likelihood->h, (int)ch->icp.size(), hs, ip->stepperIndex, ch->current.data(), ch->ahead.data());
-    } else if (auto* rw = dynamic_cast<RandomShapeUpdateProposal*>(leaf)) {
-      const ModelFittingParameters prop = rw->propose(ch->current, rnd, 0);
-      (void)icp_chain_step_prelaunch(ch->likelihood->h, (int)ch->icp.size(), hs, -1, ch->current.data(), prop.data());
+    // the normals of step `next` were drawn one step earlier (below), so that the pre-launch can go out at once
+    if (ch->ahead_step != next) {
+      if (ch->ahead2_step == next) { ch->ahead.swap(ch->ahead2); ch->ahead2_step = ~0ull; }
+      else ch->draw_normals(next, ch->ahead);
+      ch->ahead_step = next;
+      // Two steps out of three are rejected: the next step then starts from the SAME state, and its proposal is a pure
+      // function of that state and of the numbers just drawn.  Its first launches are issued now, behind the step in
+      // flight, so the device does not idle through the host's turn-around; if this step is accepted instead they are
+      // dropped (icp_chain_step_prelaunch).
+      if (ch->prefetcher.whole_step && !ch->icp.empty() && ch->icp.size() <= 2) {
+        StepRandom rnd{ch->seed, next};
+        rnd.ahead = ch->ahead.data(); rnd.n_ahead = (int)ch->ahead.size();
+        ProposalGeneratorWithTransition* leaf = ch->root->peek(rnd, 0);
+        icp_proposal* hs[2] = {nullptr, nullptr};
+        for (size_t i = 0; i < ch->icp.size(); ++i) hs[i] = ch->icp[i]->h;
+        if (auto* ip = dynamic_cast<NonRigidIcpProposal*>(leaf)) {
+          if (ip->stepper) (void)icp_chain_step_prelaunch(ch->likelihood->h, (int)ch->icp.size(), hs, ip->stepperIndex, ch->current.data(), ch->ahead.data());
+        } else if (auto* rw = dynamic_cast<RandomShapeUpdateProposal*>(leaf)) {
+          const ModelFittingParameters prop = rw->propose(ch->current, rnd, 0);
+          (void)icp_chain_step_prelaunch(ch->likelihood->h, (int)ch->icp.size(), hs, -1, ch->current.data(), prop.data());
+        }
+      }
     }
+    if (ch->ahead2_step != next + 1) { ch->draw_normals(next + 1, ch->ahead2); ch->ahead2_step = next + 1; }
   }
 };
 
@@ -168,6 +177,7 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
         for (size_t i = 0; i < ch->icp.size(); ++i) { ch->icp[i]->stepper = &ch->prefetcher; ch->icp[i]->stepperIndex = (int)i; }
     }
     ch->ahead.assign(ch->r, 0.0);
+    ch->ahead2.assign(ch->r, 0.0);
     if (cfg->fused >= 2) check(icp_ctx_set_idle_hook(ctx, &icp_host_chain::draw_ahead, ch), "icp_ctx_set_idle_hook");
     ch->current.allParameters.assign(theta0, theta0 + 10 + ch->r);
     ch->logger.P = 10 + ch->r;
