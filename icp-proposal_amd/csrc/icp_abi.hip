@@ -1089,6 +1089,8 @@ int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity,
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     ctx->bind();
     HIP_OK(hipStreamSynchronize(ctx->stream));
+    HIP_OK(hipStreamSynchronize(ctx->front_stream));
+    HIP_OK(hipStreamSynchronize(ctx->eig_stream));
     ctx->profiling = false;
     std::vector<icp_kernel_stat> acc(KID_COUNT);
     for (int i = 0; i < KID_COUNT; ++i) {
@@ -1936,7 +1938,13 @@ extern "C" {
 int icp_chain_step_prelaunch(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, int32_t generator, const double* theta_cur,
                              const double* z_or_theta_prop) {
   return guard([&] {
-    require(e && theta_cur && z_or_theta_prop, "null argument");
+    require(e != nullptr, "null argument");
+    if (n_props == 0) {  // "nothing further": drop a pending half step
+      std::lock_guard<std::recursive_mutex> lk0(e->ctx->mu);
+      if (e->front.valid) release_front(e->front);
+      return;
+    }
+    require(theta_cur && z_or_theta_prop, "null argument");
     require(n_props >= 1 && n_props <= 2 && props, "bad proposal list");
     require(generator < n_props, "generator index out of range");
     icp_ctx& c = *e->ctx;
@@ -2014,7 +2022,9 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     for (int i = 0; i < 16; ++i) c.h_res[i] = 0.0;
     for (int i = 0; i < 16; ++i) c.h_status[i] = 0;
 
-    static const bool no_spec = std::getenv("ICP_NO_SPECULATION") != nullptr;
+    // Off unless ICP_SPECULATION=1: since the steps are pipelined over two streams (a rejected step costs ≈ 45 µs), starting two
+    // decompositions per step costs the rejected two thirds more (host calls, CUs) than it saves the accepted third.
+    static const bool no_spec = std::getenv("ICP_SPECULATION") == nullptr || std::getenv("ICP_NO_SPECULATION") != nullptr;
     const bool speculate = !no_spec && !c.speculation_off && g_live_contexts.load(std::memory_order_relaxed) <= 2 && n_props > 0 &&
                            eigen_speculation_supported(r);
     // test hook: the speculative decompositions wait for a word that never comes, time out and are repeated

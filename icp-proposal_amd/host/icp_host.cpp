@@ -200,6 +200,8 @@ int icp_host_chain_run(icp_host_chain* ch, int32_t n_steps, double* records) {
       ch->current_p = ch->mh->cached_current_p;
     }
     ch->logger.out = nullptr;
+    // no further step for now: whatever was launched ahead for it is dropped
+    if (ch->prefetcher.whole_step && ch->likelihood) (void)icp_chain_step_prelaunch(ch->likelihood->h, 0, nullptr, -1, nullptr, nullptr);
   });
 }
 

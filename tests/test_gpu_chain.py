@@ -110,11 +110,11 @@ chain.close(); ctx.close()
 """
 
 
-@pytest.mark.parametrize("env", [{"ICP_NO_SPECULATION": "1"}, {"ICP_TEST_STARVE_SPECULATION": "1"}], ids=["off", "starved"])
+@pytest.mark.parametrize("env", [{"ICP_SPECULATION": "1"}, {"ICP_SPECULATION": "1", "ICP_TEST_STARVE_SPECULATION": "1"}], ids=["on", "starved"])
 def test_speculative_decomposition_fallbacks(pkg, femur50, femur50_oracle, oracle, env, tmp_path):
-    """icp_chain_step starts the KL basis of the proposed state before the caller decides (icp_abi.hip, speculate_eigen).
-    Two ways around it must give the same chain: switched off, and starved — the decomposition never sees its input, gives
-    up after its time-out, and the step that drew from it is repeated with an ordinary decomposition."""
+    """With ICP_SPECULATION=1 icp_chain_step starts the KL basis of the proposed state before the caller decides (icp_abi.hip,
+    speculate_eigen; off by default).  It must give the same chain switched on, and starved — the decomposition never
+    sees its input, gives up after its time-out, and the step that drew from it is repeated with an ordinary one."""
     import os
     import subprocess
     import sys
