@@ -1753,6 +1753,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   }
   for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
   if (missing) c.stream_used_elsewhere = true;  // … and this step reads them
+  const bool m_in_flight = c.stream_used_elsewhere;  // `stream` may still be writing what the decompositions below read
   F.stream = F.parity ? c.front_stream : c.stream;
   if (F.parity) {
     if (c.stream_used_elsewhere) {  // another entry point has work on `stream` that this step may depend on: join once
@@ -1771,15 +1772,21 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
     for (int i = 0; i < n_props; ++i)
       if (!ec[i]->eig_valid) { props[i]->prepare_eigen(*ec[i], &rqs[nn]); need[nn++] = ec[i]; }
     if (nn > 0) {
-      HIP_OK(hipEventRecord(c.ev_ready, c.stream));  // M of these entries may still be in flight on the context stream
-      HIP_OK(hipStreamWaitEvent(c.eig_stream, c.ev_ready, 0));
+      // M of these entries is complete when they were recorded by a finished chain step (the host has seen its results);
+      // only work another entry point has put on `stream` may still be writing them
+      if (m_in_flight) {
+        HIP_OK(hipEventRecord(c.ev_ready, c.stream));
+        HIP_OK(hipStreamWaitEvent(c.eig_stream, c.ev_ready, 0));
+      }
       if (!launch_posterior_eigen_pair(c.eig_stream, r, c.sqrt_lambda.p, nn, rqs))  // (ranks > 64: one after the other)
         for (int i = 0; i < nn; ++i) {
           need[i]->done_value = 0;
           launch_posterior_eigen(c.eig_stream, r, rqs[i].M, c.sqrt_lambda.p, rqs[i].Vwarm, rqs[i].V, rqs[i].Vt, rqs[i].S, rqs[i].work, rqs[i].status,
                                  nullptr, rqs[i].host_status);
         }
-      for (int i = 0; i < nn; ++i) { HIP_OK(hipEventRecord(need[i]->eig_done, c.eig_stream)); need[i]->eig_done_shared = nullptr; }
+      HIP_OK(hipEventRecord(need[0]->eig_done, c.eig_stream));  // (one event for what was one launch — or two in a row)
+      need[0]->eig_done_shared = nullptr;
+      for (int i = 1; i < nn; ++i) need[i]->eig_done_shared = need[0]->eig_done;
     }
   }
   bool eigen_first_use = false;
