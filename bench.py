@@ -159,9 +159,9 @@ def main():
                                     "avg_launch_us": k["avg_us"], "launches": k["calls"], "algorithmic_bytes": alg_bytes,
                                     "note": "brute-force search is VALU-bound by construction (SURVEY.md §8d); HBM fraction reported as north_star asks"}
                 line["kernel_us_per_step"] = {name: round(s["total_ms"] * 1e3 / args.profile_steps, 2) for name, s in stats.items()}
-                line["kernel_us_per_step_note"] = ("HIP events around each launch (these add ~3 us per launch); k_posterior_eigen runs on side "
-                                                   "streams, two speculative launches per step, and its figure includes their wait for the step's "
-                                                   "regression output")
+                line["kernel_us_per_step_note"] = ("HIP events around each launch (these add ~3 us per launch); a step's launches alternate between two "
+                                                   "streams and overlap the previous step's finish launch; k_step_begin includes the time it waits ON THE "
+                                                   "DEVICE for that launch to start or for the eigen-decomposition it draws from (k_posterior_eigen, side stream)")
         # ---- CPU baseline: the oracle's chain (same math, brute force, 1 thread) on a bounded sample
         if args.cpu_steps > 0:
             from oracle import oracle as O
