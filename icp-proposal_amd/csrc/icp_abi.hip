@@ -223,6 +223,9 @@ struct icp_ctx {
   hipEvent_t ev_ready = nullptr;                 // stream -> eig_stream: "M is complete"
   hipEvent_t ev_join = nullptr;                  // stream -> front_stream, when another entry point has used `stream`
   bool front_stream_used = false;                // a step is (or may still be) on front_stream: other entry points drain it first
+  // ICP_NO_PIPELINE=1, or a first launch once timed out on its word (a tool that lets one kernel run at a time, in an order
+  // of its own): every step on `stream`, nothing launched ahead, no device-side waits
+  bool pipeline_off = std::getenv("ICP_NO_PIPELINE") != nullptr;
   bool stream_used_elsewhere = false;            // an entry point other than the chain step has enqueued on `stream`
   int last_back_seq = 0;                         // sequence number of the last finish launch
   int* h_wait_error = nullptr;                   // pinned: a front gave up waiting (never expected)
@@ -1754,8 +1757,8 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
   if (missing) c.stream_used_elsewhere = true;  // … and this step reads them
   const bool m_in_flight = c.stream_used_elsewhere;  // `stream` may still be writing what the decompositions below read
-  F.stream = F.parity ? c.front_stream : c.stream;
-  if (F.parity) {
+  F.stream = (F.parity && !c.pipeline_off) ? c.front_stream : c.stream;
+  if (F.stream == c.front_stream) {
     if (c.stream_used_elsewhere) {  // another entry point has work on `stream` that this step may depend on: join once
       HIP_OK(hipEventRecord(c.ev_join, c.stream));
       HIP_OK(hipStreamWaitEvent(c.front_stream, c.ev_join, 0));
@@ -1852,8 +1855,11 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   b.x = s.x.p;
   b.has_surf = 1; b.surf = st_surf;
   b.has_vert = pt ? 1 : 0; b.vert = st_vert;
-  b.wait_flag = c.last_back_seq > 0 ? c.d_done.p + 2 : nullptr;  // (nothing to wait for before the first finish launch)
-  b.wait_seq = c.last_back_seq;
+  // (nothing to wait for before the first finish launch, nor when every step is on one stream)
+  b.wait_flag = (c.last_back_seq > 0 && !c.pipeline_off) ? c.d_done.p + 2 : nullptr;
+  // test hook: the first launch waits for a word that never comes, times out, and the step is repeated unpipelined
+  static const int starve_pipeline = std::getenv("ICP_TEST_STARVE_PIPELINE") ? (1 << 24) : 0;
+  b.wait_seq = c.last_back_seq + starve_pipeline;
   b.wait_error = c.h_wait_error;
   if (generator >= 0 && ec[generator]->done_value != 0) {
     b.wait2_flag = props[generator]->eig_words.p + ec[generator]->status_off / 3;
@@ -1963,6 +1969,7 @@ int icp_chain_step_prelaunch(icp_evaluator* e, int32_t n_props, icp_proposal* co
         if (!std::isfinite(z_or_theta_prop[j])) fail(ICP_ERR_NOT_FINITE, "z contains a non-finite value");
     std::lock_guard<std::recursive_mutex> lk(c.mu);
     if (e->front.valid) release_front(e->front);
+    if (c.pipeline_off) return;
     if (c.r > kStepInlineZ) return;  // (larger ranks stage z in one pinned area: not double-buffered)
     // with several chains in the process the device is not idle during one chain's turn-around, and the launches of a
     // dropped half step cost the others host time (tools/multichain.py)
@@ -2096,7 +2103,20 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
 
     // ---- bookkeeping with the results in hand
     g_host_timing.mark_wait(eigen_first_use);
-    if (c.h_wait_error[0]) { c.h_wait_error[0] = 0; fail(ICP_ERR_DEVICE, "internal: a step's first launches timed out waiting for the step before them"); }
+    if (c.h_wait_error[0]) {
+      // A first launch did not see the word it waits for within 50 ms and went ahead unordered.  That is what a tool does
+      // that lets one kernel run at a time in an order of its own (rocprofv3 --pmc): drain everything, switch the pipelining
+      // off for this context, and do the step again — nothing of it has been recorded.
+      HIP_OK(hipStreamSynchronize(c.stream));
+      HIP_OK(hipStreamSynchronize(c.front_stream));  // (a half step launched ahead may time out here, too)
+      HIP_OK(hipStreamSynchronize(c.eig_stream));
+      c.h_wait_error[0] = 0;
+      if (c.pipeline_off) fail(ICP_ERR_DEVICE, "internal: a step's first launch timed out on its word");
+      c.pipeline_off = true;
+      if (e->front.valid) release_front(e->front);
+      redo = true;
+      return;
+    }
     if (eigen_first_use && eigen_status_pinned) {  // this step's first launch waited for that decomposition: its status is in
       icp_proposal* p = props[generator];
       const int st = p->h_eig[ec[generator]->status_off / 3];

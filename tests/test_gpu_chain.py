@@ -110,11 +110,15 @@ chain.close(); ctx.close()
 """
 
 
-@pytest.mark.parametrize("env", [{"ICP_SPECULATION": "1"}, {"ICP_SPECULATION": "1", "ICP_TEST_STARVE_SPECULATION": "1"}], ids=["on", "starved"])
+@pytest.mark.parametrize("env", [{"ICP_SPECULATION": "1"}, {"ICP_SPECULATION": "1", "ICP_TEST_STARVE_SPECULATION": "1"},
+                                 {"ICP_NO_PIPELINE": "1"}, {"ICP_TEST_STARVE_PIPELINE": "1"}],
+                         ids=["speculation-on", "speculation-starved", "pipeline-off", "pipeline-starved"])
 def test_speculative_decomposition_fallbacks(pkg, femur50, femur50_oracle, oracle, env, tmp_path):
     """With ICP_SPECULATION=1 icp_chain_step starts the KL basis of the proposed state before the caller decides (icp_abi.hip,
     speculate_eigen; off by default).  It must give the same chain switched on, and starved — the decomposition never
-    sees its input, gives up after its time-out, and the step that drew from it is repeated with an ordinary one."""
+    sees its input, gives up after its time-out, and the step that drew from it is repeated with an ordinary one.
+    Likewise the two-stream step pipeline (on by default): switched off, and starved — a first launch times out on the
+    word it waits for, and the context falls back to unpipelined steps."""
     import os
     import subprocess
     import sys
