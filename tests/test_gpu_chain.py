@@ -136,3 +136,36 @@ def test_speculative_decomposition_fallbacks(pkg, femur50, femur50_oracle, oracl
     scale = np.abs(states_o[:, 10:]).max()
     assert np.abs(rec[:, 4 + 10:] - states_o[:, 10:]).max() <= 1e-5 * scale
     assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
+
+
+_PIPELINE_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import __graft_entry__ as graft
+pkg = graft.load_package()
+model, target = pkg.data.synthetic_femur_target()
+setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+ctx = pkg.IcpContext(model, target, device=0)
+chain = pkg.SamplingRegistration(ctx, setup, pkg.initial_parameters(model), 1024)
+np.save({out!r}, np.concatenate([chain.run(n) for n in (300, 1, 2, 297)]))
+chain.close(); ctx.close()
+"""
+
+
+def test_pipelined_steps_are_bit_identical_to_unpipelined(tmp_path):
+    """BASELINE.json configs[1] (the metric configuration), 600 steps in four runs: the default chain step — steps
+    alternating between two streams, the next step's first four launches issued ahead under the rejection assumption and
+    dropped on acceptance, decompositions in pairs on a third stream — must reproduce the records of the
+    unpipelined one (ICP_NO_PIPELINE=1) bit for bit: any ordering hazard between the streams would show here."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    recs = []
+    for tag, env in (("pipelined", {}), ("plain", {"ICP_NO_PIPELINE": "1"})):
+        out = str(tmp_path / (tag + ".npy"))
+        subprocess.run([sys.executable, "-c", _PIPELINE_SCRIPT.format(root=ROOT, out=out)], check=True,
+                       env={**os.environ, **env}, timeout=300)
+        recs.append(np.load(out))
+    assert recs[0].shape == (600, recs[0].shape[1]) and recs[0][:, 1].sum() > 100
+    assert np.array_equal(recs[0], recs[1])
