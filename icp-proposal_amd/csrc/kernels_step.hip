@@ -189,11 +189,12 @@ __global__ void __launch_bounds__(NT) k_step_finish(StepFinishArgs a) {
   // every workgroup's results are in pinned host memory: count in, the last one raises the flag
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence_system();
+    __threadfence_system();  // this workgroup's results, before it is counted in
     if (atomicAdd(a.done_counter, 1) == (int)gridDim.x - 1) {
+      // (everybody else's results became visible before their increments, which this one has observed: the flag needs no
+      // fence of its own — a second system-scope fence here cost ≈ 1.5 µs at the very end of every step)
       *a.done_counter = 0;
-      __threadfence_system();
-      *(volatile int*)a.host_flag = a.seq;
+      __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
