@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
       }
     }
     __syncthreads();
-    __threadfence();  // (acquire side for the plain loads of the partials below)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (acquire side for the plain loads of the partials below)
   }
   if (is_poll && __hip_atomic_load(spec.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == spec.seq) s_cancel = 1;
   for (int e = tid; e < n2 * n2; e += nt) {
@@ -885,7 +885,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     EIG_STAMP(4 + 2 * n_sweeps);
     in_sweep = 0;
     // this sweep's rotations are in the log: the replay workgroups may have them (published behind the barrier below)
-    if (wave == kRrLogWave) __threadfence();
+    if (wave == kRrLogWave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (write back only)
     // convergence: off(A)² <= 1e-26·Σ diag².  Thread (row, 4 columns) over the stored upper triangle; one barrier.
     double off = 0.0, dg = 0.0;
     {

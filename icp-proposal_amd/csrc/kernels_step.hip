@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) {
       }
     }
     __syncthreads();
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (invalidate only: nothing of ours to write back)
   }
   const bool inst = (int)blockIdx.x < a.inst_blocks;
   const int i = blockIdx.x * kStepBeginPoints + tid;
