@@ -169,3 +169,26 @@ def test_pipelined_steps_are_bit_identical_to_unpipelined(tmp_path):
         recs.append(np.load(out))
     assert recs[0].shape == (600, recs[0].shape[1]) and recs[0][:, 1].sum() > 100
     assert np.array_equal(recs[0], recs[1])
+
+
+def test_metric_configuration_chain_matches_oracle(pkg, oracle):
+    """BASELINE.json configs[1] — the configuration bench.py times (femur-50 model against the 58,322-vertex synthetic
+    target, pipelined chain step): accept/reject sequence and mixture components identical to the oracle's chain, states
+    within 1e-5 relative, over 48 steps (the oracle's brute-force scan of 116,640 triangles runs at ~4 steps/s)."""
+    model, target = pkg.data.synthetic_femur_target()
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    n_steps, seed = 48, 1024
+    setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+    theta0 = pkg.initial_parameters(model)
+    acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), theta0, seed, n_steps)
+    ctx = pkg.IcpContext(model, target, device=0)
+    chain = pkg.SamplingRegistration(ctx, setup, theta0, seed)
+    rec = np.concatenate([chain.run(20), chain.run(28)])
+    assert np.array_equal(rec[:, 1].astype(np.uint8), acc_o), "accept/reject sequences differ"
+    assert np.array_equal(rec[:, 2].astype(np.int32), comp_o), "mixture components differ"
+    assert acc_o.sum() > 5
+    scale = np.abs(states_o[:, 10:]).max()
+    assert np.abs(rec[:, 4 + 10:] - states_o[:, 10:]).max() <= 1e-5 * scale
+    assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
+    chain.close()
+    ctx.close()
