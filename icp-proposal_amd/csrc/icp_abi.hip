@@ -1336,6 +1336,7 @@ int icp_proposal_log_transition(icp_proposal* p, const double* theta_from, const
     if (c.h_status[0] != 0) {  // the fixed-point form did not contract for this model/noise: direct factorisation
       const double* dto2 = c.stage(theta_to + 10, c.r);
       io.c_to = dto2;
+      HIP_OK(hipStreamSynchronize(c.eig_stream));  // (the direct form borrows the eigen work buffer)
       launch_transition_tail_direct(c.stream, c.r, io, c.G.p, kSigma2, p->work.p);
       c.finish(1, 1);
       if (c.h_status[0] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
@@ -1663,6 +1664,7 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         io.c_to = c.stage((t % 2 == 0 ? theta_prop : theta_cur) + 10, r);
         io.out = c.d_res.p;
         io.status = c.d_status.p + 32;
+        HIP_OK(hipStreamSynchronize(c.eig_stream));  // (the direct form borrows the eigen work buffer)
         launch_transition_tail_direct(c.stream, r, io, c.G.p, kSigma2, p->work.p);
         c.finish(1, 64);
         if (c.h_status[32] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
@@ -2160,6 +2162,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
         TransitionTailIO io = (t % 2 == 0) ? f.fwd[t / 2] : f.bwd[t / 2];
         io.out = c.d_res.p;
         io.status = c.d_status.p + 32;
+        HIP_OK(hipStreamSynchronize(c.eig_stream));  // (the direct form borrows the eigen work buffer)
         launch_transition_tail_direct(c.stream, r, io, c.G.p, kSigma2, p->work.p);
         c.finish(1, 64);
         if (c.h_status[32] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
