@@ -345,6 +345,20 @@ def chain_step(evaluator: _Evaluator, proposals, theta_cur, generator: int = -1,
     return b, val.value, fwd[:n], bwd[:n]
 
 
+def chain_step_prelaunch(evaluator: _Evaluator, proposals, theta_cur, generator: int = -1, z=None, theta_prop=None):
+    """icp_chain_step_prelaunch: issue the first launches of the step that a later chain_step with exactly these arguments
+    will ask for (typically: the next step under the assumption that the step in flight is rejected).  Never changes
+    results; proposals == [] drops a pending half step."""
+    n = len(proposals)
+    if n == 0:
+        nat.check(nat.lib().icp_chain_step_prelaunch(evaluator.h, 0, None, -1, None, None), "icp_chain_step_prelaunch")
+        return
+    a = _theta(theta_cur)
+    arr = (C.c_void_p * n)(*[p.h for p in proposals])
+    key = np.ascontiguousarray(z, dtype=np.float64) if generator >= 0 else _theta(theta_prop)
+    nat.check(nat.lib().icp_chain_step_prelaunch(evaluator.h, n, arr, int(generator), _d(a), _d(key)), "icp_chain_step_prelaunch")
+
+
 class IcpBasedSurfaceFitting:
     """api/other/IcpBasedSurfaceFitting.scala:32 — the deterministic non-rigid ICP baseline (posterior MEAN, isotropic noise).
     `modelPointIds` / `targetPointSamples` stand for the UniformMeshSampler3D draws of :51-53 (made by the caller)."""

@@ -254,6 +254,7 @@ struct icp_ctx {
                                // of its regression launch
   int* h_flag = nullptr;       // pinned: sequence number of the last finished step
   int step_seq = 0;
+  std::vector<struct icp_evaluator*> evaluators;  // live evaluators (a proposal being destroyed drops their pending half steps)
   icp_idle_fn idle_fn = nullptr;  // icp_ctx_set_idle_hook
   void* idle_arg = nullptr;
   bool counted = false;          // included in g_live_contexts
@@ -1261,13 +1262,18 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
   return rc;
 }
 
+namespace { void release_front(StepFront& F); }
+
 void icp_proposal_destroy(icp_proposal* p) {
   if (!p) return;
   {
     std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
+    (void)hipStreamSynchronize(p->ctx->front_stream);
     (void)hipStreamSynchronize(p->ctx->eig_stream);
+    for (icp_evaluator* ev : p->ctx->evaluators)  // a half step launched ahead with this proposal holds entries of it
+      if (ev->front.valid && (ev->front.props[0] == p || ev->front.props[1] == p)) release_front(ev->front);
     if (g_host_timing.on && eigen_speculation_supported(p->ctx->r)) eigen_debug_dump(p->work.p, p->ctx->r);
     if (p->h_cancel) (void)hipHostFree(p->h_cancel);
     if (p->h_eig) (void)hipHostFree(p->h_eig);
@@ -1407,22 +1413,22 @@ int icp_evaluator_create(icp_ctx* ctx, const icp_evaluator_params* params, icp_e
     ev->hint_nnv.alloc(Ka); ev->hint_nnv.fill_bytes(0xFF);
     ev->t2m_tri.alloc(Ka); ev->t2m_nnv.alloc(Ka);
     ev->t2m_cp.alloc(3 * Ka); ev->t2m_d2.alloc(Ka);
+    ctx->evaluators.push_back(ev);
     *out = ev;
   });
   if (rc != ICP_OK && ev) delete ev;
   return rc;
 }
 
-namespace { void release_front(StepFront& F); }
-
 void icp_evaluator_destroy(icp_evaluator* e) {
   if (!e) return;
   std::lock_guard<std::recursive_mutex> lk(e->ctx->mu);
   (void)hipSetDevice(e->ctx->device);
   (void)hipStreamSynchronize(e->ctx->stream);
-  // a pre-launched half step holds a state slot of the context and memo entries of its proposals: an evaluator with one
-  // pending must be destroyed before those proposals (the harness does; nobody else pre-launches)
+  // a pre-launched half step holds a state slot of the context and memo entries of its proposals
   if (e->front.valid) release_front(e->front);
+  auto& evs = e->ctx->evaluators;
+  evs.erase(std::remove(evs.begin(), evs.end(), e), evs.end());
   delete e;
 }
 
@@ -2030,7 +2036,6 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     StateSlot& s = *F.s;
     const int Ksurf = F.Ksurf;
     const bool eigen_first_use = F.eigen_first_use;
-    const icp_evaluator_params& evp = e->prm;
     // the decompositions of ranks <= 64 leave their status in pinned memory themselves; the others need a copy
     const bool eigen_status_pinned = eigen_speculation_supported(r);
     const bool eigen_enqueued = eigen_first_use && !eigen_status_pinned;

@@ -247,8 +247,7 @@ ICP_API int icp_chain_step(icp_evaluator *e, int32_t n_props, icp_proposal *cons
  * half already on the device; any other call drops it.  Never changes results.  Does nothing when the posteriors of
  * theta_cur are not on record or the configuration is not covered by the merged launches.  n_props == 0 drops a
  * pending half step (a caller that stops stepping for a while should: the speculative work attached to it would
- * otherwise wait for its time-out).  An evaluator with a
- * pre-launched half step pending must be destroyed before the proposals it was given. */
+ * otherwise wait for its time-out). */
 ICP_API int icp_chain_step_prelaunch(icp_evaluator *e, int32_t n_props, icp_proposal *const *props, int32_t generator,
                                      const double *theta_cur, const double *z_or_theta_prop);
 

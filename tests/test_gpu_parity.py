@@ -295,3 +295,43 @@ def test_error_behaviour(pkg, ctx50, femur50):
     with pytest.raises(pkg._native.IcpNativeError) as e:
         pkg.NonRigidIcpProposal(ctx50, 0.1, -1.0, 5.0, 10, "ModelSampling")
     assert e.value.status == -1
+
+
+def test_prelaunched_half_step_never_changes_results(pkg, femur50):
+    """icp_chain_step_prelaunch issues launches 1-4 of a step ahead of the icp_chain_step that asks for it.  Whether that
+    call then finds them (same arguments), finds others (different arguments: dropped), or none: bit-identical outputs —
+    two contexts run the same sequence of steps, one with pre-launches (matching, mismatching, dropped), one without."""
+    model, target = femur50
+    r = model.rank
+    tp = pkg.data.decimated_point_subset(target, 2 * r)
+    def mk():
+        ctx = pkg.IcpContext(model, target, device=0)
+        props = [pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, d, True, decimatedTargetPoints=tp)
+                 for d in ("TargetSampling", "ModelSampling")]
+        return ctx, props, pkg.IndependentPointDistanceEvaluator(ctx, 0.0, 2.0, 0, 4 * r)
+    (ctx_a, props_a, ev_a), (ctx_b, props_b, ev_b) = mk(), mk()
+    cur = make_theta(model, 601, pose=False)
+    rng = np.random.default_rng(11)
+    zs = rng.normal(size=(8, r))
+    # warm both sides up identically (posterior of `cur` on record, one basis computed)
+    first_a = pkg.chain_step(ev_a, props_a, cur, generator=0, z=zs[0])
+    first_b = pkg.chain_step(ev_b, props_b, cur, generator=0, z=zs[0])
+    assert all(np.array_equal(x, y) for x, y in zip(first_a, first_b))
+    for step in range(1, 8):
+        gen = step % 2
+        kind = step % 4
+        if kind == 1:
+            pkg.chain_step_prelaunch(ev_a, props_a, cur, generator=gen, z=zs[step])          # matches the call below
+        elif kind == 2:
+            pkg.chain_step_prelaunch(ev_a, props_a, cur, generator=gen, z=zs[step] + 1.0)    # does not: dropped
+        elif kind == 3:
+            pkg.chain_step_prelaunch(ev_a, props_a, cur, generator=1 - gen, z=zs[step])
+            pkg.chain_step_prelaunch(ev_a, [], cur)                                          # dropped explicitly
+        out_a = pkg.chain_step(ev_a, props_a, cur, generator=gen, z=zs[step])
+        out_b = pkg.chain_step(ev_b, props_b, cur, generator=gen, z=zs[step])
+        for x, y in zip(out_a, out_b):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), "step %d" % step
+        if step % 3 == 0:   # "accept": continue from the proposed state on both sides
+            cur = np.asarray(out_a[0]).copy()
+    for o in props_a + props_b + [ev_a, ev_b, ctx_a, ctx_b]:
+        o.close()
