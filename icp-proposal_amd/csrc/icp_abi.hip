@@ -475,10 +475,11 @@ struct icp_proposal {
   DBuf<double> fscratch;  // (r+1)·r + 8 factorisation scratch (ranks too large for LDS)
   const double* warm_ptr = nullptr;  // eigenvectors of the most recent posterior (inside its memo entry): warm start of the next
   bool warm_valid = false;
-  // Every eigen-decomposition of this proposal runs on its own stream (they share `work` and the warm start, so they must
-  // not overlap each other), beside the context stream: the decomposition of a state that is not needed yet — the other
-  // ICP direction of a freshly accepted state — then overlaps the chain's next steps instead of delaying a later one.
-  // Speculative decomposition (icp_chain_step): the KL basis of the PROPOSED state's posterior is started as soon as its
+  // The eigen-decompositions of this proposal run on the context's eigen stream (icp_ctx::eig_stream) in launch order — they
+  // share `work` and the warm start, so they must not overlap each other — beside the chain's own streams: the decomposition
+  // of a state that is not needed yet — the other ICP direction of a freshly accepted state — overlaps the chain's next
+  // steps instead of delaying a later one.
+  // Speculative decomposition (icp_chain_step, ICP_SPECULATION=1): the KL basis of the PROPOSED state's posterior is started as soon as its
   // normal matrix exists, before the caller has decided whether to accept.  The next call tells: its current state is
   // the proposed one (the basis is already on its way) or not (the decomposition is cancelled through `h_cancel`).
   int* h_eig = nullptr;            // pinned: eigen status of every memo entry, written by the decomposition itself
@@ -1774,8 +1775,9 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
     c.front_stream_used = true;
   }
   c.stream_used_elsewhere = false;
-  // KL bases of the current state's posteriors: all of them are started now, each on its proposal's own stream (they
-  // run side by side); only the generating one is waited for — the other is ready when a later step draws from it
+  // KL bases of the current state's posteriors: all of them are started now, in ONE launch on the eigen stream (they run
+  // side by side); only the generating one is waited for (through its completion word) — the other is ready when a later
+  // step draws from it
   {
     EigenRequest rqs[2];
     PosteriorEntry* need[2];
@@ -2075,7 +2077,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     // first half, which the device can start as soon as the finish launch above has
     static const bool hook_late = std::getenv("ICP_HOOK_LATE") != nullptr;  // (A/B switch: hook behind the speculative launches)
     if (c.idle_fn && !hook_late) c.idle_fn(c.idle_arg);
-    // KL bases of the proposed state's posteriors, in case it is accepted: they run on the proposals' own streams beside
+    // KL bases of the proposed state's posteriors, in case it is accepted (opt-in): they run on the eigen stream beside
     // the factorisations and the host's round trip; the next call keeps or cancels them (resolve_speculation)
     if (speculate) {  // both directions in one launch: they run side by side
       EigenSpec specs[2];

@@ -221,8 +221,8 @@ constexpr int kStepMaxOut = 6;
 
 struct StepBeginArgs {  // launch 1: [propose] -> coefficients -> instance -> search initialisation
   int N, r, inst_blocks, tpr_log2;
-  // The first three launches run on their own stream, beside the last launch of the step BEFORE them (which they do not
-  // depend on).  What they must not overtake is that step's searches — same scratch, same hints — so the launch waits, on
+  // Consecutive steps alternate between two streams, so the first four launches of a step run beside the last launch of
+  // the step BEFORE them (which they do not depend on).  What they must not overtake is that step's searches — same scratch, same hints — so the launch waits, on
   // the device, for the word the finish launch of that step raises when it starts (*wait_flag - wait_seq >= 0); an event
   // there would hold that step's own launches back.  *wait_error (pinned) is set if the word does not come within 50 ms.
   const int* wait_flag; int wait_seq; int* wait_error;

@@ -15,6 +15,12 @@
 //
 // The device bodies are the ones the per-stage kernels use (icp_search.hpp, icp_dense.hpp): results are bit-identical
 // to the per-method entry points.
+//
+// Launches 1-4 of a step do not depend on launch 5 of the step before it: the host side (icp_abi.hip, enqueue_front)
+// alternates steps between two streams and issues 1-4 of the next step ahead, under the assumption that the step in
+// flight is rejected.  The cross-stream order is taken on the device: launch 1 waits for a word that launch 5 of the
+// previous step raises when it starts (StepBeginArgs::wait_flag), and for the completion word of the eigen-decomposition
+// it draws from.
 #include "icp_kernels.hpp"
 #include "icp_search.hpp"
 #include "icp_dense.hpp"
