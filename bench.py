@@ -55,7 +55,7 @@ def main():
         args.gpus = world
 
     dist = torch = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run the RCCL path is taken even with one rank
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
         torch.cuda.set_device(local_rank)
@@ -99,7 +99,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     rec = chain.run(args.steps)
+    t_chain = time.perf_counter() - t0
     gather_logs(rec)
+    t_gather = time.perf_counter() - t0 - t_chain
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -128,6 +130,8 @@ def main():
                         % (model.n_points, r, target.n_points, target.n_cells, 2 * r, 4 * r),
             "chains_per_gpu": 1,
             "calls_per_step": {0: "per-method", 1: "propose + icp_chain_eval_step", 2: "icp_chain_step"}[args.fused],
+            "chain_ms": 1e3 * t_chain,
+            "log_gather_ms": 1e3 * t_gather,
             "accepted": n_acc,
             "icp_proposals": n_icp,
         },

@@ -941,9 +941,16 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->device = device;
     ctx->N = N; ctx->T = T; ctx->r = r;
     ctx->bind();
-    HIP_OK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&ctx->front_stream, hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&ctx->eig_stream, hipStreamNonBlocking));
+    // The runtime multiplexes streams onto a small pool of hardware queues PER PRIORITY (four by default), and two
+    // streams on one hardware queue run one kernel at a time: with other streams alive in the process (torch's,
+    // RCCL's: normal priority) the two step streams ended up sharing a queue and a step cost 15 % more (measured under
+    // torch.distributed.run).  The context's three streams are therefore created at the greatest priority: a pool of
+    // their own.
+    int prio_least = 0, prio_greatest = 0;
+    HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIP_OK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest));
+    HIP_OK(hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest));
+    HIP_OK(hipStreamCreateWithPriority(&ctx->eig_stream, hipStreamNonBlocking, prio_greatest));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     HIP_OK(hipHostMalloc((void**)&ctx->h_wait_error, sizeof(int) * 16, hipHostMallocDefault));
