@@ -943,11 +943,17 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->bind();
     // The runtime multiplexes streams onto a small pool of hardware queues PER PRIORITY (four by default), and two
     // streams on one hardware queue run one kernel at a time: with other streams alive in the process (torch's,
-    // RCCL's: normal priority) the two step streams ended up sharing a queue and a step cost 15 % more (measured under
-    // torch.distributed.run).  The context's three streams are therefore created at the greatest priority: a pool of
-    // their own.
+    // RCCL's: default priority) the two step streams ended up sharing a queue and a step cost 15 % more (measured under
+    // torch.distributed.run).  The streams of the first context of a process — the one-chain-per-GPU layout — are
+    // therefore created at the greatest priority: a pool of their own.  Further contexts (several chains on one GPU
+    // from one process) take the default priority: with every stream in the greatest-priority pool their aggregate
+    // rate fell from 22k to 15k it/s (tools/multichain.py, 4-16 contexts).
     int prio_least = 0, prio_greatest = 0;
     HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    if (g_live_contexts.load(std::memory_order_relaxed) > 0) prio_greatest = 0;
+    if (const char* sp = std::getenv("ICP_STREAM_PRIORITY")) {  // A/B switch: 0 = default priority everywhere
+      if (std::atoi(sp) == 0) prio_greatest = 0;
+    }
     HIP_OK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest));
     HIP_OK(hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest));
     HIP_OK(hipStreamCreateWithPriority(&ctx->eig_stream, hipStreamNonBlocking, prio_greatest));
