@@ -88,6 +88,9 @@ SIGNATURES = {
     "icp_mesh_metrics": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "icp_chain_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, c_double_p, c_double_p, c_double_p,
                                  c_double_p, c_double_p, c_double_p]),
+    "icp_chain_step_batched": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                         C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p), c_double_p, c_double_p,
+                                         c_double_p, C.POINTER(C.c_int32)]),
 }
 
 _LIB = None

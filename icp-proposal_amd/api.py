@@ -345,6 +345,36 @@ def chain_step(evaluator: _Evaluator, proposals, theta_cur, generator: int = -1,
     return b, val.value, fwd[:n], bwd[:n]
 
 
+def chain_step_batched(evaluators, proposals, theta_cur, generator, z=None, theta_prop=None):
+    """icp_chain_step_batched: chain_step for B independent chains (one context each) in one sequence of launches.
+    evaluators[b], proposals[b] (list of n_props), theta_cur[b], generator[b]; z[b] where generator[b] >= 0, theta_prop[b]
+    where generator[b] < 0.  Returns (theta_prop [B, 10+r], log_value [B], fwd [B, n], bwd [B, n], status [B])."""
+    B = len(evaluators)
+    n = len(proposals[0])
+    cur = [_theta(t) for t in theta_cur]
+    P = cur[0].shape[0]
+    out = np.zeros((B, P))
+    zs = []
+    for b in range(B):
+        if generator[b] >= 0:
+            zs.append(np.ascontiguousarray(z[b], dtype=np.float64))
+        else:
+            zs.append(np.zeros(1))
+            out[b] = _theta(theta_prop[b])
+    ev = (C.c_void_p * B)(*[e.h for e in evaluators])
+    pr = (C.c_void_p * max(B * n, 1))(*[p.h for ps in proposals for p in ps])
+    gen = (C.c_int32 * B)(*[int(g) for g in generator])
+    dp = nat.c_double_p
+    curp = (dp * B)(*[_d(t) for t in cur])
+    zp = (dp * B)(*[_d(t) for t in zs])
+    outp = (dp * B)(*[_d(out[b]) for b in range(B)])
+    val, fwd, bwd = np.zeros(B), np.zeros((B, max(n, 1))), np.zeros((B, max(n, 1)))
+    status = (C.c_int32 * B)()
+    rc = nat.lib().icp_chain_step_batched(B, ev, n, pr, gen, curp, zp, outp, _d(val), _d(fwd), _d(bwd), status)
+    nat.check(rc, "icp_chain_step_batched")
+    return out, val, fwd[:, :n], bwd[:, :n], np.array(list(status), dtype=np.int32)
+
+
 def chain_step_prelaunch(evaluator: _Evaluator, proposals, theta_cur, generator: int = -1, z=None, theta_prop=None):
     """icp_chain_step_prelaunch: issue the first launches of the step that a later chain_step with exactly these arguments
     will ask for (typically: the next step under the assumption that the step in flight is rejected).  Never changes

@@ -17,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <set>
 #include <vector>
 
 #include "icp_kernels.hpp"
@@ -220,6 +221,8 @@ struct icp_ctx {
   // every eigen-decomposition of the context runs on this stream, beside the chain (launch order = execution order, so the
   // decompositions of one proposal never overlap each other; the two directions of a step share ONE launch)
   hipStream_t eig_stream = nullptr;
+  hipStream_t eig_last = nullptr;  // where this context's latest decompositions were launched: eig_stream, or the eigen stream
+                                   // of the first context of a batch (see eigen_stream_for)
   hipEvent_t ev_ready = nullptr;                 // stream -> eig_stream: "M is complete"
   hipEvent_t ev_join = nullptr;                  // stream -> front_stream, when another entry point has used `stream`
   bool front_stream_used = false;                // a step is (or may still be) on front_stream: other entry points drain it first
@@ -262,6 +265,10 @@ struct icp_ctx {
 
   Profiler prof;
   bool profiling = false;
+  // argument arrays of the icp_chain_step_batched launches led by this context: pinned copy, device copy
+  void* batch_pinned = nullptr;
+  DBuf<unsigned char> batch_device;
+  size_t batch_bytes = 0;
 
   void bind() { HIP_OK(hipSetDevice(device)); }
 
@@ -433,10 +440,34 @@ struct HostTiming {
 };
 HostTiming g_host_timing;
 
+struct BatchTiming {  // ICP_HOST_TIMING: where a batched step's host time goes (reported with the above)
+  bool on = std::getenv("ICP_HOST_TIMING") != nullptr;
+  double acc[4] = {0, 0, 0, 0};
+  long calls = 0, chains = 0;
+  std::chrono::steady_clock::time_point last;
+  void start() { if (on) last = std::chrono::steady_clock::now(); }
+  void mark(int k) { if (on) { auto t = std::chrono::steady_clock::now(); acc[k] += HostTiming::us(last, t); last = t; } }
+  void report() {
+    if (!on || !calls) return;
+    std::fprintf(stderr, "[icp batch timing] calls %ld, %.1f chains each | us/call: prepare %.1f  launch %.1f  wait for first chain %.1f  record %.1f\n",
+                 calls, (double)chains / calls, acc[0] / calls, acc[1] / calls, acc[2] / calls, acc[3] / calls);
+    calls = 0;
+  }
+};
+BatchTiming g_batch_timing;
+
 // Contexts alive in this process.  The speculative decompositions of icp_chain_step keep a few workgroups waiting on the
 // device and put three streams per context to work; the runtime multiplexes streams onto four hardware queues, and beyond
 // two contexts (measured: tools/multichain.py) the waiting kernels cost the other chains more than they gain.
 std::atomic<int> g_live_contexts{0};
+
+// Eigen streams of the live contexts.  The decompositions of one proposal share its work buffer and its warm-start chain, so
+// they must run one after the other: they do, in launch order, as long as they are launched on ONE stream.  Ordinarily
+// that is the context's own eigen stream; the chains of icp_chain_step_batched have theirs launched together on the eigen
+// stream of the batch's first context.  A context whose decompositions move from one stream to another first waits, on the
+// host, for those on the old one (a transition between single and batched stepping: rare) — if that stream still exists.
+std::mutex g_eig_streams_mu;
+std::set<hipStream_t> g_eig_streams;
 
 struct PosteriorEntry {
   std::vector<double> theta;
@@ -685,10 +716,25 @@ void icp_proposal::prepare_eigen(PosteriorEntry& e, EigenRequest* rq) {
   h_eig[e.status_off / 3] = -1;  // in flight; the decomposition stores its status here when it ends
   e.done_value = ++eig_seq;
   *rq = EigenRequest{e.M.p, warm_valid ? warm_ptr : nullptr, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2, nullptr,
-                     h_eig + e.status_off / 3, eig_words.p + e.status_off / 3, e.done_value};
+                     h_eig + e.status_off / 3, eig_words.p + e.status_off / 3, e.done_value, ctx->sqrt_lambda.p};
   warm_ptr = e.V.p;
   warm_valid = true;
   e.eig_valid = true;
+}
+
+// waits for every decomposition of this context that may still be running
+void sync_eigen(icp_ctx& c) {
+  if (c.eig_last && c.eig_last != c.eig_stream) {
+    std::lock_guard<std::mutex> lk(g_eig_streams_mu);
+    if (g_eig_streams.count(c.eig_last)) HIP_OK(hipStreamSynchronize(c.eig_last));
+  }
+  HIP_OK(hipStreamSynchronize(c.eig_stream));
+}
+// the stream the next decompositions of this context go to (see g_eig_streams)
+hipStream_t eigen_stream_for(icp_ctx& c, hipStream_t want) {
+  if (c.eig_last && c.eig_last != want) sync_eigen(c);
+  c.eig_last = want;
+  return want;
 }
 
 void icp_proposal::ensure_eigen(PosteriorEntry& e) {
@@ -697,12 +743,13 @@ void icp_proposal::ensure_eigen(PosteriorEntry& e) {
   EigenRequest rq;
   prepare_eigen(e, &rq);
   HIP_OK(hipEventRecord(c.ev_ready, c.stream));  // M of this entry may still be in flight on the context stream
-  HIP_OK(hipStreamWaitEvent(c.eig_stream, c.ev_ready, 0));
-  if (!launch_posterior_eigen_pair(c.eig_stream, c.r, c.sqrt_lambda.p, 1, &rq)) {  // ranks > 64: no completion word
+  const hipStream_t es = eigen_stream_for(c, c.eig_stream);
+  HIP_OK(hipStreamWaitEvent(es, c.ev_ready, 0));
+  if (!launch_posterior_eigen_pair(es, c.r, c.sqrt_lambda.p, 1, &rq)) {  // ranks > 64: no completion word
     e.done_value = 0;
-    launch_posterior_eigen(c.eig_stream, c.r, rq.M, c.sqrt_lambda.p, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.work, rq.status, nullptr, rq.host_status);
+    launch_posterior_eigen(es, c.r, rq.M, c.sqrt_lambda.p, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.work, rq.status, nullptr, rq.host_status);
   }
-  HIP_OK(hipEventRecord(e.eig_done, c.eig_stream));
+  HIP_OK(hipEventRecord(e.eig_done, es));
   e.eig_done_shared = nullptr;
 }
 
@@ -957,6 +1004,7 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     HIP_OK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest));
     HIP_OK(hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest));
     HIP_OK(hipStreamCreateWithPriority(&ctx->eig_stream, hipStreamNonBlocking, prio_greatest));
+    { std::lock_guard<std::mutex> lk(g_eig_streams_mu); g_eig_streams.insert(ctx->eig_stream); }
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     HIP_OK(hipHostMalloc((void**)&ctx->h_wait_error, sizeof(int) * 16, hipHostMallocDefault));
@@ -1049,7 +1097,13 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
 void icp_ctx_destroy(icp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->eig_last && ctx->eig_last != ctx->eig_stream) {  // decompositions of this context on a batch's stream
+    std::lock_guard<std::mutex> lk(g_eig_streams_mu);
+    if (g_eig_streams.count(ctx->eig_last)) (void)hipStreamSynchronize(ctx->eig_last);
+  }
   if (ctx->eig_stream) {
+    std::lock_guard<std::mutex> lk(g_eig_streams_mu);
+    g_eig_streams.erase(ctx->eig_stream);
     (void)hipStreamSynchronize(ctx->eig_stream);
     (void)hipStreamDestroy(ctx->eig_stream);
   }
@@ -1065,11 +1119,13 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->h_wait_error) (void)hipHostFree(ctx->h_wait_error);
   g_host_timing.report();
+  g_batch_timing.report();
   for (auto& r : ctx->prof.pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+  if (ctx->batch_pinned) (void)hipHostFree(ctx->batch_pinned);
   if (ctx->counted) --g_live_contexts;
   delete ctx;
 }
@@ -1108,7 +1164,7 @@ int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity,
     ctx->bind();
     HIP_OK(hipStreamSynchronize(ctx->stream));
     HIP_OK(hipStreamSynchronize(ctx->front_stream));
-    HIP_OK(hipStreamSynchronize(ctx->eig_stream));
+    sync_eigen(*ctx);
     ctx->profiling = false;
     std::vector<icp_kernel_stat> acc(KID_COUNT);
     for (int i = 0; i < KID_COUNT; ++i) {
@@ -1285,7 +1341,7 @@ void icp_proposal_destroy(icp_proposal* p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     (void)hipStreamSynchronize(p->ctx->front_stream);
-    (void)hipStreamSynchronize(p->ctx->eig_stream);
+    try { sync_eigen(*p->ctx); } catch (...) {}
     for (icp_evaluator* ev : p->ctx->evaluators)  // a half step launched ahead with this proposal holds entries of it
       if (ev->front.valid && (ev->front.props[0] == p || ev->front.props[1] == p)) release_front(ev->front);
     if (g_host_timing.on && eigen_speculation_supported(p->ctx->r)) eigen_debug_dump(p->work.p, p->ctx->r);
@@ -1356,7 +1412,7 @@ int icp_proposal_log_transition(icp_proposal* p, const double* theta_from, const
     if (c.h_status[0] != 0) {  // the fixed-point form did not contract for this model/noise: direct factorisation
       const double* dto2 = c.stage(theta_to + 10, c.r);
       io.c_to = dto2;
-      HIP_OK(hipStreamSynchronize(c.eig_stream));  // (the direct form borrows the eigen work buffer)
+      sync_eigen(c);  // (the direct form borrows the eigen work buffer)
       launch_transition_tail_direct(c.stream, c.r, io, c.G.p, kSigma2, p->work.p);
       c.finish(1, 1);
       if (c.h_status[0] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
@@ -1684,7 +1740,7 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         io.c_to = c.stage((t % 2 == 0 ? theta_prop : theta_cur) + 10, r);
         io.out = c.d_res.p;
         io.status = c.d_status.p + 32;
-        HIP_OK(hipStreamSynchronize(c.eig_stream));  // (the direct form borrows the eigen work buffer)
+        sync_eigen(c);  // (the direct form borrows the eigen work buffer)
         launch_transition_tail_direct(c.stream, r, io, c.G.p, kSigma2, p->work.p);
         c.finish(1, 64);
         if (c.h_status[32] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
@@ -1756,9 +1812,53 @@ void release_front(StepFront& F) {
   F = StepFront{};
 }
 
+// KL bases of a state's posteriors `ec` that are not on record yet: all of them are started now, in ONE launch on the eigen
+// stream (they run side by side); a step waits for the one it draws from only (through its completion word) — the other
+// is ready when a later step draws from it.  m_in_flight: `stream` may still be writing what they read.
+struct EigenCollect {  // the decompositions of a batch of chains, launched together (icp_chain_step_batched)
+  hipStream_t stream;                  // the eigen stream of the batch's first context
+  std::vector<EigenRequest> rq;
+  std::vector<PosteriorEntry*> first;  // per chain with requests: the entry whose event stands for the chain's
+};
+void start_decompositions(icp_ctx& c, int n_props, icp_proposal* const* props, PosteriorEntry* const* ec, bool m_in_flight,
+                          EigenCollect* collect = nullptr) {
+  const int r = c.r;
+  EigenRequest rqs[2];
+  PosteriorEntry* need[2];
+  int nn = 0;
+  for (int i = 0; i < n_props; ++i)
+    if (!ec[i]->eig_valid) { props[i]->prepare_eigen(*ec[i], &rqs[nn]); need[nn++] = ec[i]; }
+  if (nn == 0) return;
+  need[0]->eig_done_shared = nullptr;
+  for (int i = 1; i < nn; ++i) need[i]->eig_done_shared = need[0]->eig_done;
+  if (collect) {
+    if (m_in_flight) HIP_OK(hipStreamSynchronize(c.stream));
+    (void)eigen_stream_for(c, collect->stream);
+    for (int i = 0; i < nn; ++i) collect->rq.push_back(rqs[i]);
+    collect->first.push_back(need[0]);
+    return;
+  }
+  const hipStream_t es = eigen_stream_for(c, c.eig_stream);
+  // M of these entries is complete when they were recorded by a finished chain step (the host has seen its results);
+  // only work another entry point has put on `stream` may still be writing them
+  if (m_in_flight) {
+    HIP_OK(hipEventRecord(c.ev_ready, c.stream));
+    HIP_OK(hipStreamWaitEvent(es, c.ev_ready, 0));
+  }
+  if (!launch_posterior_eigen_pair(es, r, c.sqrt_lambda.p, nn, rqs))  // (ranks > 64: one after the other)
+    for (int i = 0; i < nn; ++i) {
+      need[i]->done_value = 0;
+      launch_posterior_eigen(es, r, rqs[i].M, c.sqrt_lambda.p, rqs[i].Vwarm, rqs[i].V, rqs[i].Vt, rqs[i].S, rqs[i].work, rqs[i].status,
+                             nullptr, rqs[i].host_status);
+    }
+  HIP_OK(hipEventRecord(need[0]->eig_done, es));  // (one event for what was one launch — or two in a row)
+}
+
 // launches 1-3 of the step (theta_cur --generator/key--> proposal); `key` = z or the proposed state (see StepFront)
+// (batched: the launches are being captured for icp_chain_step_batched — one stream, nothing to wait for on the device
+// but the decomposition)
 void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, int generator, const double* theta_cur,
-                   const double* key, StepFront& F) {
+                   const double* key, StepFront& F, bool batched = false) {
   icp_ctx& c = *e->ctx;
   const int r = c.r;
   F = StepFront{};
@@ -1779,7 +1879,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
   if (missing) c.stream_used_elsewhere = true;  // … and this step reads them
   const bool m_in_flight = c.stream_used_elsewhere;  // `stream` may still be writing what the decompositions below read
-  F.stream = (F.parity && !c.pipeline_off) ? c.front_stream : c.stream;
+  F.stream = (F.parity && !c.pipeline_off && !batched) ? c.front_stream : c.stream;
   if (F.stream == c.front_stream) {
     if (c.stream_used_elsewhere) {  // another entry point has work on `stream` that this step may depend on: join once
       HIP_OK(hipEventRecord(c.ev_join, c.stream));
@@ -1788,33 +1888,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
     c.front_stream_used = true;
   }
   c.stream_used_elsewhere = false;
-  // KL bases of the current state's posteriors: all of them are started now, in ONE launch on the eigen stream (they run
-  // side by side); only the generating one is waited for (through its completion word) — the other is ready when a later
-  // step draws from it
-  {
-    EigenRequest rqs[2];
-    PosteriorEntry* need[2];
-    int nn = 0;
-    for (int i = 0; i < n_props; ++i)
-      if (!ec[i]->eig_valid) { props[i]->prepare_eigen(*ec[i], &rqs[nn]); need[nn++] = ec[i]; }
-    if (nn > 0) {
-      // M of these entries is complete when they were recorded by a finished chain step (the host has seen its results);
-      // only work another entry point has put on `stream` may still be writing them
-      if (m_in_flight) {
-        HIP_OK(hipEventRecord(c.ev_ready, c.stream));
-        HIP_OK(hipStreamWaitEvent(c.eig_stream, c.ev_ready, 0));
-      }
-      if (!launch_posterior_eigen_pair(c.eig_stream, r, c.sqrt_lambda.p, nn, rqs))  // (ranks > 64: one after the other)
-        for (int i = 0; i < nn; ++i) {
-          need[i]->done_value = 0;
-          launch_posterior_eigen(c.eig_stream, r, rqs[i].M, c.sqrt_lambda.p, rqs[i].Vwarm, rqs[i].V, rqs[i].Vt, rqs[i].S, rqs[i].work, rqs[i].status,
-                                 nullptr, rqs[i].host_status);
-        }
-      HIP_OK(hipEventRecord(need[0]->eig_done, c.eig_stream));  // (one event for what was one launch — or two in a row)
-      need[0]->eig_done_shared = nullptr;
-      for (int i = 1; i < nn; ++i) need[i]->eig_done_shared = need[0]->eig_done;
-    }
-  }
+  start_decompositions(c, n_props, props, ec, m_in_flight);
   bool eigen_first_use = false;
   if (generator >= 0) {
     // (await_eigen on the front's stream: through the decomposition's own completion word when it has one — see launch 1)
@@ -1879,7 +1953,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   b.has_surf = 1; b.surf = st_surf;
   b.has_vert = pt ? 1 : 0; b.vert = st_vert;
   // (nothing to wait for before the first finish launch, nor when every step is on one stream)
-  b.wait_flag = (c.last_back_seq > 0 && !c.pipeline_off) ? c.d_done.p + 2 : nullptr;
+  b.wait_flag = (c.last_back_seq > 0 && !c.pipeline_off && !batched) ? c.d_done.p + 2 : nullptr;
   // test hook: the first launch waits for a word that never comes, times out, and the step is repeated unpipelined
   static const int starve_pipeline = std::getenv("ICP_TEST_STARVE_PIPELINE") ? (1 << 24) : 0;
   b.wait_seq = c.last_back_seq + starve_pipeline;
@@ -1943,6 +2017,82 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   launch_step_regression(F.stream, g);
 
   F.valid = true;
+}
+
+// Host side of a merged step whose results have arrived in the context's pinned memory: status of the decomposition it
+// drew from, the proposed state, the memo entries, the rare direct transition tail, likelihood and densities.
+// -> false: the step has to be done again (nothing of it has been recorded)
+bool chain_step_record(icp_evaluator* e, int n_props, icp_proposal* const* props, int generator, const double* theta_cur, StepFront& F,
+                       const StepFinishArgs& f, double* theta_prop, double* log_value_prop, double* fwd, double* bwd, int* status) {
+  icp_ctx& c = *e->ctx;
+  const int r = c.r;
+  PosteriorEntry** ec = F.ec;
+  PosteriorEntry** ep = F.ep;
+  StateSlot& s = *F.s;
+  const int Ksurf = F.Ksurf;
+  const bool eigen_first_use = F.eigen_first_use;
+  const bool eigen_status_pinned = eigen_speculation_supported(r);
+  const double* h_coeffs = c.h_res + 16 + F.parity * kCoeffArea;
+  if (eigen_first_use && eigen_status_pinned) {  // this step's first launch waited for that decomposition: its status is in
+    icp_proposal* p = props[generator];
+    const int st = p->h_eig[ec[generator]->status_off / 3];
+    if (st == kEigenGaveUp) {  // a speculative decomposition that never saw its input (see k_posterior_eigen_rr): the
+      // step just computed drew from a stale basis — drop it (nothing of it has been recorded) and do it again
+      ec[generator]->eig_valid = false;
+      ec[generator]->eig_checked = false;
+      p->warm_valid = false;  // (it pointed at the basis that was never written)
+      return false;
+    }
+    p->h_status[ec[generator]->status_off + 2] = st;
+  }
+  const size_t P = 10 + (size_t)r;
+  if (generator >= 0) {
+    std::memcpy(theta_prop, theta_cur, sizeof(double) * 10);  // :64-66 only the shape changes
+    for (int j = 0; j < r; ++j) {
+      if (!std::isfinite(h_coeffs[j])) fail(ICP_ERR_NOT_FINITE, "proposed coefficients are not finite");
+      theta_prop[10 + j] = h_coeffs[j];
+    }
+  }
+  s.theta.assign(theta_prop, theta_prop + P);
+  s.valid = true;
+  s.stamp = ++c.clock;
+  s.n_surf = Ksurf;
+  for (int i = 0; i < n_props; ++i) {
+    icp_proposal* p = props[i];
+    ep[i]->theta.assign(theta_prop, theta_prop + P);
+    ep[i]->valid = true;
+    ep[i]->stamp = ++p->clock;
+    p->h_status[ep[i]->status_off] = c.h_status[8 + i];
+    p->h_status[ep[i]->status_off + 1] = 0;
+    p->h_status[ep[i]->status_off + 2] = 0;
+    p->check_status(*ec[i]);
+    p->check_status(*ep[i]);
+  }
+  for (int t = 0; t < 2 * n_props; ++t)
+    if (c.h_status[t] != 0) {  // rare: the fixed-point tail did not contract -> direct kernel
+      std::vector<double> saved(c.h_res, c.h_res + 16);
+      icp_proposal* p = props[t / 2];
+      TransitionTailIO io = (t % 2 == 0) ? f.fwd[t / 2] : f.bwd[t / 2];
+      io.out = c.d_res.p;
+      io.status = c.d_status.p + 32;
+      sync_eigen(c);  // (the direct form borrows the eigen work buffer)
+      launch_transition_tail_direct(c.stream, r, io, c.G.p, kSigma2, p->work.p);
+      c.finish(1, 64);
+      if (c.h_status[32] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
+      saved[8 + t] = c.h_res[0];
+      std::memcpy(c.h_res, saved.data(), sizeof(double) * saved.size());
+    }
+  for (int i = 0; i < 4; ++i) c.h_res[i] = c.h_res[kReduceArea + F.parity * 8 + i];  // launch 4's reduction, where finish_eval looks
+  icp_evaluator::Memo* m = eval_store(e, theta_prop);
+  m->status = finish_eval(e, c.h_res, &m->value, m->aux);
+  *log_value_prop = m->value;
+  *status = m->status;
+  for (int i = 0; i < n_props; ++i) {
+    fwd[i] = c.h_res[8 + 2 * i];
+    bwd[i] = c.h_res[9 + 2 * i];
+    if (std::isnan(fwd[i]) || std::isnan(bwd[i])) fail(ICP_ERR_NOT_FINITE, "NaN transition probability");
+  }
+  return true;
 }
 
 bool front_matches(const StepFront& F, int n_props, icp_proposal* const* props, int generator, const double* theta_cur,
@@ -2049,12 +2199,10 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     PosteriorEntry** ec = F.ec;
     PosteriorEntry** ep = F.ep;
     StateSlot& s = *F.s;
-    const int Ksurf = F.Ksurf;
     const bool eigen_first_use = F.eigen_first_use;
     // the decompositions of ranks <= 64 leave their status in pinned memory themselves; the others need a copy
     const bool eigen_status_pinned = eigen_speculation_supported(r);
     const bool eigen_enqueued = eigen_first_use && !eigen_status_pinned;
-    const double* h_coeffs = c.h_res + 16 + F.parity * kCoeffArea;
     for (int i = 0; i < 16; ++i) c.h_res[i] = 0.0;
     for (int i = 0; i < 16; ++i) c.h_status[i] = 0;
 
@@ -2096,8 +2244,9 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       EigenSpec specs[2];
       EigenRequest rqs[2];
       for (int i = 0; i < n_props; ++i) props[i]->speculate_eigen(*ep[i], *ec[i], F.splits[i], F.mpart_half[i], c.d_done.p + 2, step_seq + starve, &specs[i], &rqs[i]);
-      launch_posterior_eigen_pair(c.eig_stream, r, c.sqrt_lambda.p, n_props, rqs);
-      HIP_OK(hipEventRecord(ep[0]->eig_done, c.eig_stream));  // one launch, one event
+      const hipStream_t es = eigen_stream_for(c, c.eig_stream);
+      launch_posterior_eigen_pair(es, r, c.sqrt_lambda.p, n_props, rqs);
+      HIP_OK(hipEventRecord(ep[0]->eig_done, es));  // one launch, one event
       ep[0]->eig_done_shared = nullptr;
       for (int i = 1; i < n_props; ++i) ep[i]->eig_done_shared = ep[0]->eig_done;
     }
@@ -2131,7 +2280,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       // off for this context, and do the step again — nothing of it has been recorded.
       HIP_OK(hipStreamSynchronize(c.stream));
       HIP_OK(hipStreamSynchronize(c.front_stream));  // (a half step launched ahead may time out here, too)
-      HIP_OK(hipStreamSynchronize(c.eig_stream));
+      sync_eigen(c);
       c.h_wait_error[0] = 0;
       if (c.pipeline_off) fail(ICP_ERR_DEVICE, "internal: a step's first launch timed out on its word");
       c.pipeline_off = true;
@@ -2139,65 +2288,9 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       redo = true;
       return;
     }
-    if (eigen_first_use && eigen_status_pinned) {  // this step's first launch waited for that decomposition: its status is in
-      icp_proposal* p = props[generator];
-      const int st = p->h_eig[ec[generator]->status_off / 3];
-      if (st == kEigenGaveUp) {  // a speculative decomposition that never saw its input (see k_posterior_eigen_rr): the
-        // step just computed drew from a stale basis — drop it (nothing of it has been recorded) and do it again
-        ec[generator]->eig_valid = false;
-        ec[generator]->eig_checked = false;
-        p->warm_valid = false;  // (it pointed at the basis that was never written)
-        redo = true;
-        return;
-      }
-      p->h_status[ec[generator]->status_off + 2] = st;
-    }
-    const size_t P = 10 + (size_t)r;
-    if (generator >= 0) {
-      std::memcpy(theta_prop, theta_cur, sizeof(double) * 10);  // :64-66 only the shape changes
-      for (int j = 0; j < r; ++j) {
-        if (!std::isfinite(h_coeffs[j])) fail(ICP_ERR_NOT_FINITE, "proposed coefficients are not finite");
-        theta_prop[10 + j] = h_coeffs[j];
-      }
-    }
-    s.theta.assign(theta_prop, theta_prop + P);
-    s.valid = true;
-    s.stamp = ++c.clock;
-    s.n_surf = Ksurf;
-    for (int i = 0; i < n_props; ++i) {
-      icp_proposal* p = props[i];
-      ep[i]->theta.assign(theta_prop, theta_prop + P);
-      ep[i]->valid = true;
-      ep[i]->stamp = ++p->clock;
-      p->h_status[ep[i]->status_off] = c.h_status[8 + i];
-      p->h_status[ep[i]->status_off + 1] = 0;
-      p->h_status[ep[i]->status_off + 2] = 0;
-      p->check_status(*ec[i]);
-      p->check_status(*ep[i]);
-    }
-    for (int t = 0; t < 2 * n_props; ++t)
-      if (c.h_status[t] != 0) {  // rare: the fixed-point tail did not contract -> direct kernel
-        std::vector<double> saved(c.h_res, c.h_res + 16);
-        icp_proposal* p = props[t / 2];
-        TransitionTailIO io = (t % 2 == 0) ? f.fwd[t / 2] : f.bwd[t / 2];
-        io.out = c.d_res.p;
-        io.status = c.d_status.p + 32;
-        HIP_OK(hipStreamSynchronize(c.eig_stream));  // (the direct form borrows the eigen work buffer)
-        launch_transition_tail_direct(c.stream, r, io, c.G.p, kSigma2, p->work.p);
-        c.finish(1, 64);
-        if (c.h_status[32] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
-        saved[8 + t] = c.h_res[0];
-        std::memcpy(c.h_res, saved.data(), sizeof(double) * saved.size());
-      }
-    for (int i = 0; i < 4; ++i) c.h_res[i] = c.h_res[kReduceArea + F.parity * 8 + i];  // launch 4's reduction, where finish_eval looks
-    icp_evaluator::Memo* m = eval_store(e, theta_prop);
-    m->status = finish_eval(e, c.h_res, &m->value, m->aux);
-    *log_value_prop = m->value;
-    status = m->status;
-    for (int i = 0; i < n_props; ++i) {
-      fwd[i] = c.h_res[8 + 2 * i];
-      bwd[i] = c.h_res[9 + 2 * i];
-      if (std::isnan(fwd[i]) || std::isnan(bwd[i])) fail(ICP_ERR_NOT_FINITE, "NaN transition probability");
+    if (!chain_step_record(e, n_props, props, generator, theta_cur, F, f, theta_prop, log_value_prop, fwd, bwd, &status)) {
+      redo = true;
+      return;
     }
     s.reserved = false;
     for (int i = 0; i < n_props; ++i) ep[i]->reserved = false;
@@ -2216,5 +2309,213 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
   }
   return status;
 }
+
+// B chains per launch.  Every chain takes the merged step of icp_chain_step with its own context's buffers; the five
+// launches are recorded per chain (StepCapture) and issued ONCE for all of them on the first chain's stream, the
+// decompositions of chains that moved run on their own contexts' eigen streams beside it (launch 1 waits for each on the
+// device, as in the single-chain step).  Chains this does not cover (another device or rank than the first chain's, a
+// context that already has a chain in the batch, a configuration the merged launches do not cover, ranks > 64) take
+// icp_chain_step one after the other, behind the batch.
+int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props,
+                           const int32_t* generator, const double* const* theta_cur, const double* const* z,
+                           double* const* theta_prop, double* log_value_prop, double* fwd, double* bwd, int32_t* status) {
+  struct Item {
+    icp_evaluator* e = nullptr;
+    icp_proposal* const* props = nullptr;
+    int generator = -1;
+    const double* key = nullptr;
+    bool batched = false, issued = false, redo = false;
+    StepFront F;
+    StepFinishArgs f{};
+    std::unique_lock<std::recursive_mutex> lk;
+  };
+  std::vector<Item> items;
+  std::vector<StepCapture> caps;
+  int rc = guard([&] {
+    require(n_chains >= 1 && evaluators && generator && theta_cur && theta_prop && log_value_prop && status, "null argument");
+    require(n_props >= 0 && n_props <= 8 && (n_props == 0 || (props && fwd && bwd)), "bad proposal list");
+    items.resize(n_chains);
+    for (int b = 0; b < n_chains; ++b) {
+      Item& it = items[b];
+      it.e = evaluators[b];
+      it.props = props + (size_t)b * n_props;
+      it.generator = generator[b];
+      require(it.e && theta_cur[b] && theta_prop[b], "null argument");
+      require(it.generator < n_props, "generator index out of range");
+      require(it.generator < 0 || (z && z[b]), "z is null");
+      icp_ctx& c = *it.e->ctx;
+      for (int i = 0; i < n_props; ++i) require(it.props[i] && it.props[i]->ctx == &c, "proposal belongs to another context");
+      check_theta_finite(&c, theta_cur[b]);
+      if (it.generator < 0) check_theta_finite(&c, theta_prop[b]);
+      else
+        for (int j = 0; j < c.r; ++j)
+          if (!std::isfinite(z[b][j])) fail(ICP_ERR_NOT_FINITE, "z contains a non-finite value");
+      it.key = it.generator >= 0 ? z[b] : theta_prop[b];
+      status[b] = ICP_OK;
+    }
+    icp_ctx& lead = *items[0].e->ctx;
+    // ---- which chains share the launches
+    int n_batched = 0;
+    for (int b = 0; b < n_chains; ++b) {
+      Item& it = items[b];
+      icp_ctx& c = *it.e->ctx;
+      bool ok = n_props >= 1 && n_props <= 2 && c.device == lead.device && c.r == lead.r && eigen_speculation_supported(c.r) &&
+                c.r <= kStepInlineZ;
+      for (int a = 0; a < b && ok; ++a) ok = !(items[a].batched && items[a].e->ctx == &c);
+      if (!ok) continue;
+      it.lk = std::unique_lock<std::recursive_mutex>(c.mu);
+      if (it.e->front.valid || c.front_stream_used) {  // half steps launched ahead by the pipelined entry points: drained
+        if (it.e->front.valid) release_front(it.e->front);
+        c.bind();
+        HIP_OK(hipStreamSynchronize(c.stream));
+        HIP_OK(hipStreamSynchronize(c.front_stream));
+        c.front_stream_used = false;
+      }
+      if (!chain_step_covered(it.e, n_props, it.props, it.generator, theta_cur[b], theta_prop[b])) { it.lk.unlock(); continue; }
+      it.batched = true;
+      ++n_batched;
+    }
+    // ---- per chain: host side of the step, launches captured
+    g_batch_timing.start();
+    caps.resize(n_batched > 0 ? n_batched : 1);
+    // the decompositions of the chains that moved go out first, together, so that they run while the host prepares the
+    // launches (a chain whose posteriors are not on record yet starts its own in enqueue_front)
+    EigenCollect eigens{lead.eig_stream, {}, {}};
+    for (int b = 0; b < n_chains; ++b) {
+      Item& it = items[b];
+      if (!it.batched) continue;
+      icp_ctx& c = *it.e->ctx;
+      PosteriorEntry* ec[2] = {nullptr, nullptr};
+      bool all = true;
+      for (int i = 0; i < n_props; ++i) { ec[i] = it.props[i]->find_entry(theta_cur[b]); all = all && ec[i]; }
+      if (!all) continue;
+      Bound _b(&c, true);
+      for (int i = 0; i < n_props; ++i) it.props[i]->resolve_speculation(theta_cur[b]);
+      start_decompositions(c, n_props, it.props, ec, c.stream_used_elsewhere, &eigens);
+    }
+    if (!eigens.rq.empty()) {  // … in one launch (per 24), on the first chain's eigen stream
+      Bound _b(&lead, true);
+      (void)eigen_stream_for(lead, lead.eig_stream);
+      launch_posterior_eigen_many(lead.eig_stream, lead.r, (int)eigens.rq.size(), eigens.rq.data());
+      for (PosteriorEntry* e0 : eigens.first) HIP_OK(hipEventRecord(e0->eig_done, lead.eig_stream));
+    }
+    int nb = 0;
+    for (int b = 0; b < n_chains; ++b) {
+      Item& it = items[b];
+      if (!it.batched) continue;
+      icp_ctx& c = *it.e->ctx;
+      const int r = c.r;
+      Bound _b(&c, true);
+      for (int i = 0; i < n_props; ++i) it.props[i]->resolve_speculation(theta_cur[b]);
+      bool other_work = c.stream_used_elsewhere;  // another entry point may still be busy on `stream` …
+      for (int i = 0; i < n_props; ++i) other_work = other_work || !it.props[i]->find_entry(theta_cur[b]);  // … or is about to be
+      StepCapture& cap = caps[nb];
+      std::memset(cap.grid, 0, sizeof(cap.grid));
+      struct CaptureScope { CaptureScope(StepCapture* c) { step_capture(c); } ~CaptureScope() { step_capture(nullptr); } } scope(&cap);
+      enqueue_front(it.e, n_props, it.props, it.generator, theta_cur[b], it.key, it.F, true);
+      it.issued = true;
+      StepFront& F = it.F;
+      // the batch runs on the first chain's stream: what it needs from this chain's own streams is awaited here
+      if (other_work) HIP_OK(hipStreamSynchronize(c.stream));
+      if (it.generator >= 0 && F.ec[it.generator]->done_value == 0) sync_eigen(c);
+      for (int i = 0; i < 16; ++i) c.h_res[i] = 0.0;
+      for (int i = 0; i < 16; ++i) c.h_status[i] = 0;
+      const int step_seq = ++c.step_seq;
+      StepFinishArgs& f = it.f;
+      f.n = n_props; f.r = r; f.Ginv = c.Ginv.p; f.sigma2 = kSigma2;
+      for (int i = 0; i < n_props; ++i) {
+        icp_proposal* p = it.props[i];
+        f.Mpart[i] = F.mpart[i]; f.splits[i] = F.splits[i];
+        f.M[i] = F.ep[i]->M.p; f.alpha[i] = F.ep[i]->alpha.p;
+        f.status[i] = p->status.p + F.ep[i]->status_off;
+        f.host_status[i] = c.h_status + 8 + i;
+        f.fwd[i] = TransitionTailIO{F.ec[i]->alpha.p, F.ec[i]->M.p, F.ec[i]->coeffs.p, F.ep[i]->coeffs.p, p->prm.step_length,
+                                    c.h_res + 8 + 2 * i, c.h_status + 2 * i};
+        f.bwd[i] = TransitionTailIO{F.ep[i]->alpha.p, F.ep[i]->M.p, F.ep[i]->coeffs.p, F.ec[i]->coeffs.p, p->prm.step_length,
+                                    c.h_res + 9 + 2 * i, c.h_status + 2 * i + 1};
+      }
+      f.done_counter = c.d_done.p; f.host_flag = c.h_flag; f.seq = step_seq;
+      f.ready_flag = c.d_done.p + 2;
+      c.last_back_seq = step_seq;
+      launch_step_finish(c.stream, f);  // (captured)
+      it.f = cap.finish;                // as finalised by the launcher
+      ++nb;
+    }
+    // ---- one sequence of launches for all of them
+    g_batch_timing.mark(0);
+    if (nb > 0) {
+      Bound _b(&lead, true);
+      const size_t bytes = step_batch_bytes(nb);
+      if (bytes > lead.batch_bytes) {
+        HIP_OK(hipStreamSynchronize(lead.stream));
+        if (lead.batch_pinned) { HIP_OK(hipHostFree(lead.batch_pinned)); lead.batch_pinned = nullptr; }
+        const size_t cap_bytes = std::max(bytes, step_batch_bytes(16));
+        HIP_OK(hipHostMalloc(&lead.batch_pinned, cap_bytes, hipHostMallocDefault));
+        lead.batch_device.alloc(cap_bytes);
+        lead.batch_bytes = cap_bytes;
+      }
+      launch_step_batch(lead.stream, nb, caps.data(), lead.batch_pinned, lead.batch_device.p);
+    }
+    // ---- results, chain by chain
+    g_batch_timing.mark(1);
+    bool first_wait = true;
+    for (int b = 0; b < n_chains; ++b) {
+      Item& it = items[b];
+      if (!it.batched) continue;
+      icp_ctx& c = *it.e->ctx;
+      Bound _b(&c, true);
+      volatile int* flag = c.h_flag;
+      const auto t_start = std::chrono::steady_clock::now();
+      long spins = 0;
+      while (*flag != it.f.seq) {
+        if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) break;
+      }
+      if (*flag != it.f.seq) HIP_OK(hipStreamSynchronize(lead.stream));
+      if (first_wait) { g_batch_timing.mark(2); first_wait = false; }
+      c.stage_used = 0;
+      if (c.h_wait_error[0]) {  // the decomposition this chain draws from did not finish in time (a tool that serialises kernels)
+        HIP_OK(hipStreamSynchronize(lead.stream));
+        sync_eigen(c);
+        c.h_wait_error[0] = 0;
+        it.redo = true;
+      } else {
+        int st = ICP_OK;
+        it.redo = !chain_step_record(it.e, n_props, it.props, it.generator, theta_cur[b], it.F, it.f, theta_prop[b], log_value_prop + b,
+                                     fwd + (size_t)b * n_props, bwd + (size_t)b * n_props, &st);
+        status[b] = st;
+      }
+      if (it.redo) release_front(it.F);
+      else {
+        it.F.s->reserved = false;
+        for (int i = 0; i < n_props; ++i) it.F.ep[i]->reserved = false;
+      }
+      it.issued = false;
+    }
+    g_batch_timing.mark(3);
+    if (g_batch_timing.on) { ++g_batch_timing.calls; g_batch_timing.chains += nb; }
+  });
+  // whatever happened, nothing stays reserved or locked; a failed batch leaves its launches to drain
+  for (auto& it : items) {
+    if (it.issued) {
+      (void)hipStreamSynchronize(items[0].e->ctx->stream);
+      release_front(it.F);
+    }
+    if (it.lk.owns_lock()) it.lk.unlock();
+  }
+  if (rc != ICP_OK) return rc;
+  // ---- the others, and whatever has to be done again, one after the other
+  int first_bad = ICP_OK;
+  for (int b = 0; b < n_chains; ++b) {
+    Item& it = items[b];
+    if (it.batched && !it.redo) continue;
+    const int st = icp_chain_step(it.e, n_props, it.props, it.generator, theta_cur[b], it.generator >= 0 ? z[b] : nullptr, theta_prop[b],
+                                  log_value_prop + b, fwd + (size_t)b * n_props, bwd + (size_t)b * n_props);
+    status[b] = st;
+  }
+  for (int b = 0; b < n_chains; ++b)
+    if (status[b] != ICP_OK && status[b] != ICP_ERR_EMPTY && first_bad == ICP_OK) first_bad = status[b];
+  return first_bad;
+}
+
 
 }  // extern "C"

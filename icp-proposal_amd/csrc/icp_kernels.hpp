@@ -171,8 +171,12 @@ bool eigen_speculation_supported(int r);
 // done_word (optional): set to done_value (release, agent scope) when THIS decomposition's outputs are complete — or when it
 // gave up — so that a consumer on another stream can wait for one of the two without waiting for the whole launch
 struct EigenRequest { const double* M; const double* Vwarm; double* V; double* Vt; double* S; double* work; int* status;
-                      const EigenSpec* spec; int* host_status; int* done_word; int done_value; };
+                      const EigenSpec* spec; int* host_status; int* done_word; int done_value;
+                      const double* sqrt_lambda = nullptr; /* of the request's own model; launch_posterior_eigen_many needs it */ };
 bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq);
+// any number of decompositions of one rank (the chains of icp_chain_step_batched) in as few launches as the kernel argument
+// segment allows (24 each); every request carries its model's sqrt_lambda
+bool launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest* rq);
 void eigen_debug_dump(const double* work, int r);
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
                             double* Vt, double* S, double* work /* eigen_work_doubles(r) */, int* status,
@@ -297,6 +301,18 @@ void launch_step_filter(hipStream_t st, const StepSearchArgs& a);
 void launch_step_resolve(hipStream_t st, const StepSearchArgs& a);
 void launch_step_regression(hipStream_t st, const StepRegressionArgs& a);
 void launch_step_finish(hipStream_t st, const StepFinishArgs& a);
+
+// B chains per launch (icp_chain_step_batched).  While a capture is set for the calling thread, the five launchers above
+// record their (finalised) arguments and grid sizes in it instead of launching; launch_step_batch then issues ONE
+// sequence for all captured chains: blockIdx.y = chain, arguments from an array in device memory that the first kernel of
+// the sequence copies out of `pinned` (step_batch_bytes(B) bytes each, 16-byte aligned).  All chains must have one rank.
+struct StepCapture {
+  StepBeginArgs begin; StepSearchArgs search; StepRegressionArgs regression; StepFinishArgs finish;
+  int grid[5];
+};
+void step_capture(StepCapture* c);  // nullptr: launch as usual
+size_t step_batch_bytes(int B);
+void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pinned, void* device);
 SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const float4* spheres, int K, const double* P,
                               int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);
 VertexTask make_vertex_task(int V, const double* verts, int K, const double* P, int* hint, const QueryBuffers& qb, double* d2, int* idx);

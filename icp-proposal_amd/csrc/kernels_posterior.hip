@@ -662,13 +662,20 @@ template <int N> struct IntC { static constexpr int value = N; };
 struct EigenProblem {
   const double* M; const double* Vwarm /* may be Vout */; double* Vout; double* Vtout; double* Sout; int* status;
   double* rotlog; int* meta; double* vpos; EigenSpec spec; int launch_id; int* host_status; int* done_word; int done_value;
+  const double* sqrt_lambda;  // of this problem's model (nullptr: the launch's)
 };
-struct EigenBatch { int n; EigenProblem p[2]; };
+// CAP = 2: the two directions of one chain step; CAP = kEigenBatchMax: the decompositions of a batch of chains
+// (icp_chain_step_batched) — the record travels as a kernel argument (4 KB at most)
+template <int CAP> struct EigenBatch { int n; EigenProblem p[CAP]; };
+constexpr int kEigenBatchMax = 24;
+static_assert(sizeof(EigenBatch<kEigenBatchMax>) + 64 <= 4096, "the batch record must fit the kernel argument segment");
 
-__global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double* __restrict__ sqrt_lambda, int ldk, int max_sweeps,
-                                                              int per /* workgroups per problem */, EigenBatch batch) {
+template <int CAP>
+__global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double* __restrict__ sqrt_lambda_launch, int ldk, int max_sweeps,
+                                                              int per /* workgroups per problem */, EigenBatch<CAP> batch) {
   const int which = (int)blockIdx.x / per, local = (int)blockIdx.x - which * per;
   const EigenProblem& pb = batch.p[which];
+  const double* __restrict__ sqrt_lambda = pb.sqrt_lambda ? pb.sqrt_lambda : sqrt_lambda_launch;
   const double* __restrict__ M = pb.M;
   const double* Vwarm = pb.Vwarm;
   double* Vout = pb.Vout;
@@ -1312,9 +1319,9 @@ void eigen_debug_dump(const double* work, int r) {  // developer aid: convergenc
 
 bool eigen_speculation_supported(int r) { return r >= 3 && r <= 64 && std::getenv("ICP_EIGEN_GENERIC") == nullptr; }
 
-bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq) {
-  static const bool force_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
-  if (!(r >= 3 && r <= 64 && !force_generic) || n < 1 || n > 2) return false;
+namespace {
+template <int CAP>
+void launch_eigen_rr(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq) {
   // fixed-position variant: A, V and the rotation table double-buffered in LDS
   const int n2 = (r + 1) & ~1;
   const int ldk = 66;  // ldk: 64 coordinates per position row, rows 16 B apart modulo the 256-B bank window
@@ -1324,22 +1331,40 @@ bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambd
   const size_t log_doubles = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;
   static const int sweeps_cap = std::getenv("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(std::getenv("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
   static bool lds_set = false;
-  set_dyn_lds_once((const void*)k_posterior_eigen_rr, sizeof(double) * ((size_t)kRrOV + 2 * 64 * 66), &lds_set);
+  set_dyn_lds_once((const void*)k_posterior_eigen_rr<CAP>, sizeof(double) * ((size_t)kRrOV + 2 * 64 * 66), &lds_set);
   static std::atomic<int> launch_counter{0};  // (any value the previous launch on this `work` did not use would do)
-  EigenBatch batch{};
+  EigenBatch<CAP> batch{};
   batch.n = n;
   for (int i = 0; i < n; ++i) {
     double* vpos = rq[i].work + log_doubles;
     const int launch_id = 1 + (int)((unsigned)(++launch_counter) % kPwIdMask);  // never 0: the idle value of the progress word
     batch.p[i] = EigenProblem{rq[i].M, rq[i].Vwarm, rq[i].V, rq[i].Vt, rq[i].S, rq[i].status, rq[i].work, (int*)(vpos + (size_t)n2 * 64), vpos,
                               rq[i].spec ? *rq[i].spec : EigenSpec{0, nullptr, 0, nullptr, 0}, launch_id, rq[i].host_status, rq[i].done_word,
-                              rq[i].done_value};
+                              rq[i].done_value, rq[i].sqrt_lambda};
   }
   ProfScope _ps(st, KID_EIGEN);
   // per problem: workgroup 0 iterates; the others replay its rotations on V as the sweeps are published
   const int per = 1 + (r + kReplayRowsPerBlock - 1) / kReplayRowsPerBlock;
-  hipLaunchKernelGGL(k_posterior_eigen_rr, dim3(n * per), dim3(1024), shmem, st, r, sqrt_lambda, ldk, std::min(sweeps_cap, kEigenMaxSweeps), per,
+  hipLaunchKernelGGL(k_posterior_eigen_rr<CAP>, dim3(n * per), dim3(1024), shmem, st, r, sqrt_lambda, ldk, std::min(sweeps_cap, kEigenMaxSweeps), per,
                      batch);
+}
+}  // namespace
+
+bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq) {
+  static const bool force_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
+  if (!(r >= 3 && r <= 64 && !force_generic) || n < 1 || n > 2) return false;
+  launch_eigen_rr<2>(st, r, sqrt_lambda, n, rq);
+  return true;
+}
+
+bool launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest* rq) {
+  static const bool force_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
+  if (!(r >= 3 && r <= 64 && !force_generic) || n < 1) return false;
+  for (int i = 0; i < n; i += kEigenBatchMax) {
+    const int m = std::min(kEigenBatchMax, n - i);
+    if (m <= 2) launch_eigen_rr<2>(st, r, nullptr, m, rq + i);
+    else launch_eigen_rr<kEigenBatchMax>(st, r, nullptr, m, rq + i);
+  }
   return true;
 }
 

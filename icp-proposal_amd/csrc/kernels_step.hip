@@ -34,7 +34,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------- 1: coefficients -> instance -> query bounds
 
-__global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) {
+__device__ __forceinline__ void step_begin_body(const StepBeginArgs& a, const int bx) {
   __shared__ double s_c[512];
   const int tid = threadIdx.x, r = a.r;
   const double* zsrc = r <= kStepInlineZ ? a.zin : a.z_ptr;
@@ -55,8 +55,8 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) {
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (invalidate only: nothing of ours to write back)
   }
-  const bool inst = (int)blockIdx.x < a.inst_blocks;
-  const int i = blockIdx.x * kStepBeginPoints + tid;
+  const bool inst = bx < a.inst_blocks;
+  const int i = bx * kStepBeginPoints + tid;
   const bool my_point = inst && tid < kStepBeginPoints && i < a.N;
   // what does not depend on the new coefficients is fetched first, so that its latency runs beside the proposal
   // arithmetic: the corners of the triangle that bounds this thread's query
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) {
     for (int j = tid; j < r; j += kStepBlock) s_c[j] = zsrc[j];
     __syncthreads();
   }
-  if (blockIdx.x == 0)
+  if (bx == 0)
     for (int j = tid; j < r; j += kStepBlock) {
       const double c = s_c[j];
       for (int o = 0; o < a.n_out; ++o) a.out[o][j] = c;
@@ -82,22 +82,26 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) {
       a.x[3 * i] = p.x; a.x[3 * i + 1] = p.y; a.x[3 * i + 2] = p.z;
       if (my_query) surface_init_with(a.surf, i, p, ht);  // query i = model point i (:96)
     }
-    if (a.has_surf && blockIdx.x == 0 && tid < kQU) {
+    if (a.has_surf && bx == 0 && tid < kQU) {
       const int k = a.surf.K + tid;  // sentinel slots
       if (k < a.surf.Kpad) surface_init_at(a.surf, k, d3{0.0, 0.0, 0.0});
     }
   } else if (a.has_vert) {
     // TargetSampling queries: only the candidate counters are reset here; their bounds (distance to the previous winner at
     // its NEW position) are taken by the filter launch, when the new instance is complete (vert.thr2 == nullptr)
-    const int k = (blockIdx.x - a.inst_blocks) * kStepBlock + tid;
+    const int k = (bx - a.inst_blocks) * kStepBlock + tid;
     if (k < a.vert.Kpad) a.vert.cnt[k] = 0;
   }
 }
+__device__ __forceinline__ int step_begin_grid(const StepBeginArgs& a) {
+  return a.inst_blocks + (a.has_vert ? (a.vert.Kpad + kStepBlock - 1) / kStepBlock : 0);
+}
+
+__global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) { step_begin_body(a, blockIdx.x); }
 
 // ---------------------------------------------------------------- 2: filters of every search
 
-__global__ void __launch_bounds__(kSearchBlock) k_step_filter(StepSearchArgs a) {
-  const int b = blockIdx.x;
+__device__ __forceinline__ void step_filter_body(const StepSearchArgs& a, const int b) {
   int task = 0;
   while (task + 1 < a.n_surf + a.n_vert && b >= a.fstart[task + 1]) ++task;
   const int l = b - a.fstart[task];
@@ -109,6 +113,8 @@ __global__ void __launch_bounds__(kSearchBlock) k_step_filter(StepSearchArgs a) 
     if (bx < a.v[task - a.n_surf].vblocks) vertex_filter(a.v[task - a.n_surf], bx, by);
   }
 }
+
+__global__ void __launch_bounds__(kSearchBlock) k_step_filter(StepSearchArgs a) { step_filter_body(a, blockIdx.x); }
 
 // ---------------------------------------------------------------- 3: resolve + correspondence record (one wave per query)
 
@@ -125,13 +131,14 @@ __device__ __forceinline__ void resolve_vertex_query(const VertexTask& q, int k,
   if (ci == 1 && k < a.corr[1].K && idx != kNoIndex) correspond_target_wave(a.corr[1], k, idx);
 }
 
-__global__ void __launch_bounds__(64) k_step_resolve(StepSearchArgs a) {
-  const int b = blockIdx.x;
+__device__ __forceinline__ void step_resolve_body(const StepSearchArgs& a, const int b) {
   if (a.n_surf > 0 && b < a.rstart[1]) resolve_surface_query(a.s[0], b - a.rstart[0], a.s_corr[0], a);
   else if (a.n_surf > 1 && b < a.rstart[2]) resolve_surface_query(a.s[1], b - a.rstart[1], a.s_corr[1], a);
   else if (a.n_vert > 0 && b < a.rstart[a.n_surf + 1]) resolve_vertex_query(a.v[0], b - a.rstart[a.n_surf], a.v_corr[0], a);
   else if (a.n_vert > 1) resolve_vertex_query(a.v[1], b - a.rstart[a.n_surf + 1], a.v_corr[1], a);
 }
+
+__global__ void __launch_bounds__(64) k_step_resolve(StepSearchArgs a) { step_resolve_body(a, blockIdx.x); }
 
 // ---------------------------------------------------------------- 4: regression partial sums + likelihood reduction
 
@@ -150,11 +157,11 @@ __device__ __forceinline__ void dist_stats_body(int K, const double* __restrict_
   if (threadIdx.x == 0) { out[0] = sum; out[1] = mx; out[2] = cnt; }
 }
 
-__global__ void __launch_bounds__(kStepBlock) k_step_regression(StepRegressionArgs a) {
+__device__ __forceinline__ void step_regression_body(const StepRegressionArgs& a, const int bx) {
   const int n_units = a.ustart[a.n];
   const int n_blocks = (n_units + 3) >> 2;  // one wave per (tile, split) unit, four per workgroup
-  if ((int)blockIdx.x < n_blocks) {
-    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bx < n_blocks) {
+    const int u = bx * 4 + (threadIdx.x >> 6);
     if (u < n_units) {
       const int which = u < a.ustart[1] ? 0 : 1;
       const int l = u - (which ? a.ustart[1] : 0), tile = l % a.ntiles, split = l / a.ntiles;
@@ -168,12 +175,16 @@ __global__ void __launch_bounds__(kStepBlock) k_step_regression(StepRegressionAr
     else if (a.reduce_kind == 2) dist_stats_body(a.Kred, a.d2, a.red_out);                      // Collective…Evaluator.scala:43-52 (no boundary)
   }
 }
+__device__ __forceinline__ int step_regression_grid(const StepRegressionArgs& a) {
+  return (a.ustart[a.n] + 3) / 4 + (a.reduce_kind ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(kStepBlock) k_step_regression(StepRegressionArgs a) { step_regression_body(a, blockIdx.x); }
 
 // ---------------------------------------------------------------- 5: factorisations + transition tails
 
 template <int E, int NT>
-__global__ void __launch_bounds__(NT) k_step_finish(StepFinishArgs a) {
-  const int b = blockIdx.x;
+__device__ __forceinline__ void step_finish_body(const StepFinishArgs& a, const int b) {
   if (b == 0 && threadIdx.x == 0 && a.ready_flag) __hip_atomic_store(a.ready_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (b < a.n) {
     // (the matrices of the backward tail are put into LDS on the way, behind the factor's own region: a.tail_base)
@@ -196,7 +207,7 @@ __global__ void __launch_bounds__(NT) k_step_finish(StepFinishArgs a) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence_system();  // this workgroup's results, before it is counted in
-    if (atomicAdd(a.done_counter, 1) == (int)gridDim.x - 1) {
+    if (atomicAdd(a.done_counter, 1) == 2 * a.n - 1) {
       // (everybody else's results became visible before their increments, which this one has observed: the flag needs no
       // fence of its own — a second system-scope fence here cost ≈ 1.5 µs at the very end of every step)
       *a.done_counter = 0;
@@ -204,6 +215,50 @@ __global__ void __launch_bounds__(NT) k_step_finish(StepFinishArgs a) {
     }
   }
 }
+
+template <int E, int NT>
+__global__ void __launch_bounds__(NT) k_step_finish(StepFinishArgs a) { step_finish_body<E, NT>(a, blockIdx.x); }
+
+// ---------------------------------------------------------------- the same five launches for B chains at once
+//
+// icp_chain_step_batched: blockIdx.y = chain, arguments of chain y = batch[y] in device memory (brought there by
+// k_step_batch_args at the head of the sequence); a chain whose grid is smaller than the launch's leaves its surplus
+// workgroups idle.  (The record is read in place: a private copy of it lands in scratch, its arrays being indexed at run
+// time.)
+
+__global__ void __launch_bounds__(256) k_step_batch_args(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];  // src: pinned host memory, read in place
+}
+
+__global__ void __launch_bounds__(kStepBlock) k_step_begin_batch(const StepBeginArgs* __restrict__ batch) {
+  const StepBeginArgs& a = batch[blockIdx.y];
+  if ((int)blockIdx.x >= step_begin_grid(a)) return;
+  step_begin_body(a, blockIdx.x);
+}
+__global__ void __launch_bounds__(kSearchBlock) k_step_filter_batch(const StepSearchArgs* __restrict__ batch) {
+  const StepSearchArgs& a = batch[blockIdx.y];
+  if ((int)blockIdx.x >= a.fstart[a.n_surf + a.n_vert]) return;
+  step_filter_body(a, blockIdx.x);
+}
+__global__ void __launch_bounds__(64) k_step_resolve_batch(const StepSearchArgs* __restrict__ batch) {
+  const StepSearchArgs& a = batch[blockIdx.y];
+  if ((int)blockIdx.x >= a.rstart[a.n_surf + a.n_vert]) return;
+  step_resolve_body(a, blockIdx.x);
+}
+__global__ void __launch_bounds__(kStepBlock) k_step_regression_batch(const StepRegressionArgs* __restrict__ batch) {
+  const StepRegressionArgs& a = batch[blockIdx.y];
+  if ((int)blockIdx.x >= step_regression_grid(a)) return;
+  step_regression_body(a, blockIdx.x);
+}
+template <int E, int NT>
+__global__ void __launch_bounds__(NT) k_step_finish_batch(const StepFinishArgs* __restrict__ batch) {
+  const StepFinishArgs& a = batch[blockIdx.y];
+  if ((int)blockIdx.x >= 2 * a.n) return;
+  step_finish_body<E, NT>(a, blockIdx.x);
+}
+
+thread_local StepCapture* t_capture = nullptr;
 
 static void set_dyn_lds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -246,12 +301,14 @@ void launch_step_begin(hipStream_t st, const StepBeginArgs& a_in) {
   StepBeginArgs a = a_in;
   a.inst_blocks = cdiv(a.N, kStepBeginPoints);
   const int vblocks = a.has_vert ? cdiv(a.vert.Kpad, kStepBlock) : 0;
+  if (t_capture) { t_capture->begin = a; t_capture->grid[0] = a.inst_blocks + vblocks; return; }
   ProfScope _ps(st, KID_STEP_BEGIN);
   hipLaunchKernelGGL(k_step_begin, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
 }
 
 void launch_step_filter(hipStream_t st, const StepSearchArgs& a) {
   const int grid = a.fstart[a.n_surf + a.n_vert];
+  if (t_capture) { t_capture->search = a; t_capture->grid[1] = grid; return; }
   if (grid <= 0) return;
   ProfScope _ps(st, KID_STEP_FILTER);
   hipLaunchKernelGGL(k_step_filter, dim3(grid), dim3(kSearchBlock), 0, st, a);
@@ -259,6 +316,7 @@ void launch_step_filter(hipStream_t st, const StepSearchArgs& a) {
 
 void launch_step_resolve(hipStream_t st, const StepSearchArgs& a) {
   const int grid = a.rstart[a.n_surf + a.n_vert];
+  if (t_capture) { t_capture->grid[2] = grid; return; }  // (same arguments as the filter launch)
   if (grid <= 0) return;
   ProfScope _ps(st, KID_STEP_RESOLVE);
   hipLaunchKernelGGL(k_step_resolve, dim3(grid), dim3(64), 0, st, a);
@@ -266,6 +324,7 @@ void launch_step_resolve(hipStream_t st, const StepSearchArgs& a) {
 
 void launch_step_regression(hipStream_t st, const StepRegressionArgs& a) {
   const int blocks = (a.ustart[a.n] + 3) / 4 + (a.reduce_kind ? 1 : 0);
+  if (t_capture) { t_capture->regression = a; t_capture->grid[3] = blocks; return; }
   if (blocks <= 0) return;
   ProfScope _ps(st, KID_STEP_REGRESSION);
   hipLaunchKernelGGL(k_step_regression, dim3(blocks), dim3(kStepBlock), 0, st, a);
@@ -277,10 +336,59 @@ void launch_step_finish(hipStream_t st, const StepFinishArgs& a_in) {
   a.n_lds = p.n_lds;
   a.tail_base = p.tail_base;
   a.tpr_log2 = matvec_tpr_log2(a.r, p.NT);
+  if (t_capture) { t_capture->finish = a; t_capture->grid[4] = 2 * a.n; return; }
   ProfScope _ps(st, KID_STEP_FINISH);
   if (p.E == 1 && p.NT == 256) launch_finish<1, 256>(st, a, p.shmem);
   else if (p.E == 1 && p.NT == 1024) launch_finish<1, 1024>(st, a, p.shmem);
   else launch_finish<2, 1024>(st, a, p.shmem);
+}
+
+
+void step_capture(StepCapture* c) { t_capture = c; }
+
+namespace {
+template <int E, int NT>
+void launch_finish_batch(hipStream_t st, const StepFinishArgs* batch, int gx, int B, size_t shmem) {
+  static size_t lds_granted = 0;
+  if (shmem > lds_granted) { set_dyn_lds((const void*)k_step_finish_batch<E, NT>, shmem); lds_granted = shmem; }
+  hipLaunchKernelGGL((k_step_finish_batch<E, NT>), dim3(gx, B), dim3(NT), shmem, st, batch);
+}
+inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
+}  // namespace
+
+size_t step_batch_bytes(int B) {
+  return up16(sizeof(StepBeginArgs) * B) + up16(sizeof(StepSearchArgs) * B) + up16(sizeof(StepRegressionArgs) * B) +
+         up16(sizeof(StepFinishArgs) * B);
+}
+
+void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pinned, void* device) {
+  if (B <= 0) return;
+  const size_t o1 = up16(sizeof(StepBeginArgs) * B), o2 = o1 + up16(sizeof(StepSearchArgs) * B),
+               o3 = o2 + up16(sizeof(StepRegressionArgs) * B), total = step_batch_bytes(B);
+  char* h = (char*)pinned;
+  char* d = (char*)device;
+  int gx[5] = {0, 0, 0, 0, 0};
+  for (int b = 0; b < B; ++b) {
+    ((StepBeginArgs*)h)[b] = caps[b].begin;
+    ((StepSearchArgs*)(h + o1))[b] = caps[b].search;
+    ((StepRegressionArgs*)(h + o2))[b] = caps[b].regression;
+    ((StepFinishArgs*)(h + o3))[b] = caps[b].finish;
+    for (int k = 0; k < 5; ++k) gx[k] = caps[b].grid[k] > gx[k] ? caps[b].grid[k] : gx[k];
+  }
+  const int n16 = (int)(total / 16);
+  hipLaunchKernelGGL(k_step_batch_args, dim3(cdiv(n16, 256)), dim3(256), 0, st, (const uint4*)h, (uint4*)d, n16);
+  if (gx[0] > 0) { ProfScope _ps(st, KID_STEP_BEGIN); hipLaunchKernelGGL(k_step_begin_batch, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d); }
+  if (gx[1] > 0) { ProfScope _ps(st, KID_STEP_FILTER); hipLaunchKernelGGL(k_step_filter_batch, dim3(gx[1], B), dim3(kSearchBlock), 0, st, (const StepSearchArgs*)(d + o1)); }
+  if (gx[2] > 0) { ProfScope _ps(st, KID_STEP_RESOLVE); hipLaunchKernelGGL(k_step_resolve_batch, dim3(gx[2], B), dim3(64), 0, st, (const StepSearchArgs*)(d + o1)); }
+  if (gx[3] > 0) { ProfScope _ps(st, KID_STEP_REGRESSION); hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, (const StepRegressionArgs*)(d + o2)); }
+  if (gx[4] > 0) {
+    const FinishPlan p = finish_plan(caps[0].finish.r);  // (one rank per batch: checked by the caller)
+    ProfScope _ps(st, KID_STEP_FINISH);
+    const StepFinishArgs* fb = (const StepFinishArgs*)(d + o3);
+    if (p.E == 1 && p.NT == 256) launch_finish_batch<1, 256>(st, fb, gx[4], B, p.shmem);
+    else if (p.E == 1 && p.NT == 1024) launch_finish_batch<1, 1024>(st, fb, gx[4], B, p.shmem);
+    else launch_finish_batch<2, 1024>(st, fb, gx[4], B, p.shmem);
+  }
 }
 
 }  // namespace icp

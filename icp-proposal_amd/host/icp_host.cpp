@@ -205,6 +205,81 @@ int icp_host_chain_run(icp_host_chain* ch, int32_t n_steps, double* records) {
   });
 }
 
+int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains, int32_t n_steps, double* const* records) {
+  return host_guard([&] {
+    if (!chains || n_chains < 1 || n_steps < 0) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chains_run_batched");
+    const size_t n_icp = chains[0] ? chains[0]->icp.size() : 0;
+    for (int b = 0; b < n_chains; ++b) {
+      icp_host_chain* ch = chains[b];
+      if (!ch || !ch->prefetcher.whole_step || ch->icp.size() != n_icp || ch->r != chains[0]->r)
+        throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chains_run_batched: chains must share one configuration with fused = 2");
+      ch->logger.out = records ? records[b] : nullptr;
+      ch->runner = std::this_thread::get_id();
+    }
+    const int B = n_chains, r = chains[0]->r, P = 10 + r;
+    std::vector<StepRandom> rnd(B);
+    std::vector<std::vector<double>> z(B, std::vector<double>(r)), prop(B, std::vector<double>(P));
+    std::vector<int> member;  // chains of this step's submission
+    std::vector<icp_evaluator*> ev;
+    std::vector<icp_proposal*> props;
+    std::vector<int32_t> gen, status;
+    std::vector<const double*> cur_p, z_p;
+    std::vector<double*> prop_p;
+    std::vector<double> value, fwd, bwd;
+    for (int s = 0; s < n_steps; ++s) {
+      member.clear(); ev.clear(); props.clear(); gen.clear(); cur_p.clear(); z_p.clear(); prop_p.clear();
+      for (int b = 0; b < B; ++b) {
+        icp_host_chain* ch = chains[b];
+        rnd[b] = StepRandom{ch->seed, (uint64_t)ch->logger.index};
+        ch->prefetcher.submitted_index = -1;
+        ProposalGeneratorWithTransition* leaf = ch->root->peek(rnd[b], 0);
+        int g = -2;
+        if (auto* ip = dynamic_cast<NonRigidIcpProposal*>(leaf)) {
+          if (ip->stepper) {
+            g = ip->stepperIndex;
+            for (int j = 0; j < r; ++j) z[b][j] = rnd[b].normal(j);  // posterior.sample() (NonRigidIcpProposal.scala:55)
+          }
+        } else if (auto* rw = dynamic_cast<RandomShapeUpdateProposal*>(leaf)) {
+          g = -1;
+          prop[b] = rw->propose(ch->current, rnd[b], 0).allParameters;
+        }
+        if (g == -2 || n_icp == 0) continue;  // pose proposals: MetropolisHastings::next submits them itself
+        member.push_back(b);
+        ev.push_back(ch->likelihood->h);
+        for (auto* p : ch->icp) props.push_back(p->h);
+        gen.push_back(g);
+        cur_p.push_back(ch->current.data());
+        z_p.push_back(z[b].data());
+        prop_p.push_back(prop[b].data());
+      }
+      const int nb = (int)member.size();
+      if (nb > 0) {
+        value.assign(nb, 0.0); fwd.assign((size_t)nb * n_icp + 1, 0.0); bwd.assign((size_t)nb * n_icp + 1, 0.0); status.assign(nb, 0);
+        const int st = icp_chain_step_batched(nb, ev.data(), (int)n_icp, props.data(), gen.data(), cur_p.data(), z_p.data(), prop_p.data(),
+                                              value.data(), fwd.data(), bwd.data(), status.data());
+        if (st != ICP_OK) check(st, "icp_chain_step_batched");
+        for (int k = 0; k < nb; ++k) {
+          icp_host_chain* ch = chains[member[k]];
+          ModelFittingParameters pr;
+          pr.allParameters = prop[member[k]];
+          if (gen[k] >= 0) pr.generatedBy = ch->icp[gen[k]]->generatedBy;
+          else pr.generatedBy = static_cast<RandomShapeUpdateProposal*>(ch->root->peek(rnd[member[k]], 0))->generatedBy;
+          const std::vector<double> f(fwd.begin() + (size_t)k * n_icp, fwd.begin() + (size_t)(k + 1) * n_icp);
+          const std::vector<double> w(bwd.begin() + (size_t)k * n_icp, bwd.begin() + (size_t)(k + 1) * n_icp);
+          ch->prefetcher.park(ch->current, pr, status[k], value[k], f, w);
+          if (gen[k] >= 0) { ch->prefetcher.submitted_index = gen[k]; ch->prefetcher.submitted_z = z[member[k]]; }
+        }
+      }
+      for (int b = 0; b < B; ++b) {  // SamplingRegistration.scala:58-85, every chain with what was parked for it
+        icp_host_chain* ch = chains[b];
+        ch->current = ch->mh->next(ch->current, rnd[b], &ch->logger);
+        ch->current_p = ch->mh->cached_current_p;
+      }
+    }
+    for (int b = 0; b < B; ++b) chains[b]->logger.out = nullptr;
+  });
+}
+
 int icp_host_chain_state(icp_host_chain* ch, double* theta_out, double* logp_out, int64_t* steps_done, int64_t* accepted) {
   if (!ch) return ICP_ERR_INVALID_ARG;
   if (theta_out) std::memcpy(theta_out, ch->current.data(), sizeof(double) * (10 + ch->r));

@@ -36,6 +36,12 @@ ICP_API int icp_host_chain_create(icp_ctx *ctx, const icp_host_chain_config *cfg
                                   icp_host_chain **out);
 /* runs n_steps more steps; records [n_steps * (4 + 10 + r)] may be NULL */
 ICP_API int icp_host_chain_run(icp_host_chain *chain, int32_t n_steps, double *records);
+/* n_steps more steps of n_chains chains in lockstep: per step ONE icp_chain_step_batched submission for all chains
+ * whose proposal is an ICP or a random-walk shape proposal (the others step on their own), then every chain's
+ * MetropolisHastings.next with those results.  Chain by chain the records are those of icp_host_chain_run.  Every chain
+ * needs its own context and fused = 2.  records[b] may be NULL. */
+ICP_API int icp_host_chains_run_batched(icp_host_chain *const *chains, int32_t n_chains, int32_t n_steps,
+                                        double *const *records);
 ICP_API int icp_host_chain_state(icp_host_chain *chain, double *theta_out, double *logp_out, int64_t *steps_done,
                                  int64_t *accepted);
 ICP_API void icp_host_chain_destroy(icp_host_chain *chain);

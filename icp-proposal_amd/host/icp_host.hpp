@@ -281,6 +281,10 @@ struct ChainPrefetcher {
   bool whole_step = false;  // true: icp_chain_step (propose + evaluation in one submission); false: icp_chain_eval_step
   bool have = false;        // results of (parked_cur -> parked_prop) are parked
   ModelFittingParameters parked_cur, parked_prop;
+  // a whole step submitted ahead of MetropolisHastings::next by the batched runner (icp_host_chains_run_batched): step()
+  // hands its proposal out when asked for exactly that step
+  int submitted_index = -1;
+  std::vector<double> submitted_z;
 
   void park(const ModelFittingParameters& cur, const ModelFittingParameters& prop, int st, double value, const std::vector<double>& fwd,
             const std::vector<double>& bwd) {
@@ -314,6 +318,12 @@ struct ChainPrefetcher {
   }
   // propose from icp[index] AND evaluate the proposal, one native call
   ModelFittingParameters step(int index, const ModelFittingParameters& cur, const double* z) {
+    if (have && submitted_index == index && parked_cur == cur && !submitted_z.empty() &&
+        std::memcmp(submitted_z.data(), z, sizeof(double) * submitted_z.size()) == 0) {
+      submitted_index = -1;
+      return parked_prop;
+    }
+    submitted_index = -1;
     std::vector<icp_proposal*> hs;
     for (auto* p : icp) hs.push_back(p->h);
     std::vector<double> fwd(icp.size() + 1), bwd(icp.size() + 1);

@@ -38,6 +38,8 @@ def host_lib():
         L.icp_host_chain_create.argtypes = [C.c_void_p, C.POINTER(HostChainConfig), nat.c_double_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.icp_host_chain_run.restype = C.c_int
         L.icp_host_chain_run.argtypes = [C.c_void_p, C.c_int32, nat.c_double_p]
+        L.icp_host_chains_run_batched.restype = C.c_int
+        L.icp_host_chains_run_batched.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.POINTER(nat.c_double_p)]
         L.icp_host_chain_state.restype = C.c_int
         L.icp_host_chain_state.argtypes = [C.c_void_p, nat.c_double_p, nat.c_double_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.icp_host_chain_destroy.restype = None
@@ -197,3 +199,17 @@ class SamplingRegistration:
         n, a = C.c_int64(), C.c_int64()
         host_lib().icp_host_chain_state(self.h, _dp(theta), C.byref(logp), C.byref(n), C.byref(a))
         return theta, logp.value, n.value, a.value
+
+
+def run_chains_batched(chains, n_steps: int, want_records: bool = True):
+    """n_steps more steps of several SamplingRegistration chains (one IcpContext each, same setup) in lockstep: every
+    step is ONE icp_chain_step_batched submission for all of them (icp_host_chains_run_batched).  Returns the list of the
+    chains' record arrays — chain by chain what chain.run(n_steps) returns."""
+    B = len(chains)
+    recs = [np.zeros((n_steps, RECORD_HEADER + c.P)) for c in chains] if want_records else None
+    hs = (C.c_void_p * B)(*[c.h for c in chains])
+    rp = (nat.c_double_p * B)(*[_dp(r) for r in recs]) if want_records else None
+    st = host_lib().icp_host_chains_run_batched(hs, B, n_steps, rp)
+    if st != 0:
+        raise nat.IcpNativeError(st, "icp_host_chains_run_batched", (host_lib().icp_host_last_error() or b"").decode())
+    return recs

@@ -251,6 +251,22 @@ ICP_API int icp_chain_step(icp_evaluator *e, int32_t n_props, icp_proposal *cons
 ICP_API int icp_chain_step_prelaunch(icp_evaluator *e, int32_t n_props, icp_proposal *const *props, int32_t generator,
                                      const double *theta_cur, const double *z_or_theta_prop);
 
+/* B chains per launch (SURVEY.md §8b "*_batched variants", §8e "within a GPU, batch B chains per launch"; the
+ * reference runs its chains from a ForkJoin pool, apps/femur/RunMHRandomInitComparison.scala:66): icp_chain_step for
+ * n_chains independent chains in ONE sequence of five launches (chain = second grid dimension), the decompositions of
+ * the chains that moved beside it.  Chain b = evaluators[b] with props[b*n_props .. b*n_props + n_props), generator[b],
+ * theta_cur[b], z[b] (may be NULL where generator[b] < 0), theta_prop[b] (in or out as in icp_chain_step);
+ * log_value_prop[b], fwd/bwd[b*n_props + i] and status[b] (ICP_OK / ICP_ERR_EMPTY / error of that chain) are written
+ * per chain.  Every chain needs a context of its own (contexts hold the per-chain scratch; model and target are simply
+ * given to each); chains on another device or of another rank than chain 0, a second chain on one context, and
+ * configurations or ranks the merged launches do not cover take icp_chain_step one after the other.  Values are
+ * bit-identical to icp_chain_step chain by chain.  Returns ICP_OK or the first failing chain's code.  Calls from
+ * several threads must use disjoint sets of contexts. */
+ICP_API int icp_chain_step_batched(int32_t n_chains, icp_evaluator *const *evaluators, int32_t n_props,
+                                   icp_proposal *const *props, const int32_t *generator, const double *const *theta_cur,
+                                   const double *const *z, double *const *theta_prop, double *log_value_prop, double *fwd,
+                                   double *bwd, int32_t *status);
+
 /* ---------------------------------------------------------------- instrumentation (bench.py's roofline leg)
  * Between start and stop every kernel the context launches is bracketed by HIP events on the context stream;
  * stop returns one row per kernel name.  Off by default (adds nothing to the launch path). */

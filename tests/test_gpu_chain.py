@@ -192,3 +192,89 @@ def test_metric_configuration_chain_matches_oracle(pkg, oracle):
     assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
     chain.close()
     ctx.close()
+
+
+def test_batched_chains_are_bit_identical_to_single_chains(pkg, femur50):
+    """icp_chain_step_batched (B chains per launch): chains stepped in lockstep through ONE sequence of
+    launches per step give, chain by chain, exactly the records of the same chains run on their own — including a chain
+    with pose proposals (those steps leave the batch) and a batch whose members differ in their proposal kind per step."""
+    model, target = femur50
+    n_steps, B = 50, 4
+    setups = [pkg.femur_icp_proposal_registration(model, target, fused=2) for _ in range(B)]
+    inits = [pkg.initial_parameters(model)] + [pkg.random_initial_parameters(model, chain_index=i) for i in range(1, B)]
+
+    def make():
+        ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
+        return ctxs, [pkg.SamplingRegistration(ctxs[i], setups[i], inits[i], seed=1024 + i) for i in range(B)]
+
+    ctxs, chains = make()
+    single = [c.run(n_steps) for c in chains]
+    [c.close() for c in chains]; [c.close() for c in ctxs]
+    ctxs, chains = make()
+    first = pkg.run_chains_batched(chains, 20)
+    second = pkg.run_chains_batched(chains, n_steps - 20)  # (a second call continues the chains)
+    for b in range(B):
+        got = np.vstack([first[b], second[b]])
+        assert np.array_equal(got, single[b]), f"chain {b} differs"
+        assert single[b][:, 1].sum() > 3
+    # a batch of one, and a chain that alternates between batched and single stepping
+    more_b = pkg.run_chains_batched(chains[:1], 5)[0]
+    more_s = chains[0].run(5)
+    [c.close() for c in chains]; [c.close() for c in ctxs]
+    ctx = pkg.IcpContext(model, target, device=0)
+    ref = pkg.SamplingRegistration(ctx, setups[0], inits[0], seed=1024)
+    want = ref.run(n_steps + 10)
+    assert np.array_equal(np.vstack([more_b, more_s]), want[n_steps:])
+    ref.close(); ctx.close()
+
+
+def test_chain_step_batched_entry_point(pkg, femur50):
+    """The C entry point itself: per chain the values of icp_chain_step; a second chain on the same context and a chain
+    with a generator-less (host-made) proposal are accepted and give the same values."""
+    model, target = femur50
+    r = model.rank
+    rng = np.random.default_rng(5)
+    tp = pkg.data.decimated_point_subset(target, 2 * r)
+    B = 3
+    ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
+
+    def objects(ctx):
+        props = [pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, pkg.TargetSampling, True, decimatedTargetPoints=tp),
+                 pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, pkg.ModelSampling, True, decimatedTargetPoints=tp)]
+        ev = pkg.IndependentPointDistanceEvaluator(ctx, 0.0, 2.0, pkg.ModelToTargetEvaluation, 4 * r, decimatedTargetPoints=tp)
+        return ev, props
+
+    objs = [objects(c) for c in ctxs]
+    thetas = []
+    for b in range(B):
+        t = pkg.initial_parameters(model)
+        t[10:] = 0.3 * rng.normal(size=r)
+        thetas.append(t)
+    zs = [rng.normal(size=r) for _ in range(B)]
+    rw = thetas[2].copy()
+    rw[10:] += 0.1 * rng.normal(size=r)
+    gens = [0, 1, -1]
+    # reference values: one chain at a time on fresh objects
+    want = []
+    ref_ctx = pkg.IcpContext(model, target, device=0)
+    for b in range(B):
+        ev, props = objects(ref_ctx)
+        want.append(pkg.chain_step(ev, props, thetas[b], gens[b], z=zs[b], theta_prop=rw if gens[b] < 0 else None))
+        ev.close(); [p.close() for p in props]
+    ref_ctx.close()
+    out, val, fwd, bwd, status = pkg.chain_step_batched([o[0] for o in objs], [o[1] for o in objs], thetas, gens, z=zs,
+                                                        theta_prop=[None, None, rw])
+    assert list(status) == [0, 0, 0]
+    for b in range(B):
+        assert np.array_equal(out[b], want[b][0]) and val[b] == want[b][1]
+        assert np.array_equal(fwd[b], want[b][2]) and np.array_equal(bwd[b], want[b][3])
+    # the same step again, now with chain 1 given the context of chain 0: it is stepped behind the batch, same values
+    ev1, props1 = objects(ctxs[0])
+    out2, val2, fwd2, bwd2, status2 = pkg.chain_step_batched([objs[0][0], ev1, objs[2][0]], [objs[0][1], props1, objs[2][1]], thetas, gens,
+                                                             z=zs, theta_prop=[None, None, rw])
+    assert list(status2) == [0, 0, 0]
+    assert np.array_equal(out2, out) and np.array_equal(val2, val) and np.array_equal(fwd2, fwd) and np.array_equal(bwd2, bwd)
+    ev1.close(); [p.close() for p in props1]
+    for ev, props in objs:
+        ev.close(); [p.close() for p in props]
+    [c.close() for c in ctxs]
