@@ -1105,15 +1105,18 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     g_eig_streams.erase(ctx->eig_stream);
     (void)hipStreamSynchronize(ctx->eig_stream);
+    library_release_stream(ctx->eig_stream);
     (void)hipStreamDestroy(ctx->eig_stream);
   }
   if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
   if (ctx->front_stream) {
     (void)hipStreamSynchronize(ctx->front_stream);
+    library_release_stream(ctx->front_stream);
     (void)hipStreamDestroy(ctx->front_stream);
   }
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
+    library_release_stream(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -2314,8 +2317,8 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
 // launches are recorded per chain (StepCapture) and issued ONCE for all of them on the first chain's stream, the
 // decompositions of chains that moved run on their own contexts' eigen streams beside it (launch 1 waits for each on the
 // device, as in the single-chain step).  Chains this does not cover (another device or rank than the first chain's, a
-// context that already has a chain in the batch, a configuration the merged launches do not cover, ranks > 64) take
-// icp_chain_step one after the other, behind the batch.
+// context that already has a chain in the batch, a configuration the merged launches do not cover) take icp_chain_step
+// one after the other, behind the batch.
 int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props,
                            const int32_t* generator, const double* const* theta_cur, const double* const* z,
                            double* const* theta_prop, double* log_value_prop, double* fwd, double* bwd, int32_t* status) {
@@ -2359,8 +2362,7 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
     for (int b = 0; b < n_chains; ++b) {
       Item& it = items[b];
       icp_ctx& c = *it.e->ctx;
-      bool ok = n_props >= 1 && n_props <= 2 && c.device == lead.device && c.r == lead.r && eigen_speculation_supported(c.r) &&
-                c.r <= kStepInlineZ;
+      bool ok = n_props >= 1 && n_props <= 2 && c.device == lead.device && c.r == lead.r;
       for (int a = 0; a < b && ok; ++a) ok = !(items[a].batched && items[a].e->ctx == &c);
       if (!ok) continue;
       it.lk = std::unique_lock<std::recursive_mutex>(c.mu);
@@ -2391,7 +2393,8 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
       if (!all) continue;
       Bound _b(&c, true);
       for (int i = 0; i < n_props; ++i) it.props[i]->resolve_speculation(theta_cur[b]);
-      start_decompositions(c, n_props, it.props, ec, c.stream_used_elsewhere, &eigens);
+      // (ranks > 64 decompose through the library, each chain on its own eigen stream, and are awaited on the host below)
+      start_decompositions(c, n_props, it.props, ec, c.stream_used_elsewhere, eigen_speculation_supported(c.r) ? &eigens : nullptr);
     }
     if (!eigens.rq.empty()) {  // … in one launch (per 24), on the first chain's eigen stream
       Bound _b(&lead, true);
@@ -2472,6 +2475,10 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
       }
       if (*flag != it.f.seq) HIP_OK(hipStreamSynchronize(lead.stream));
       if (first_wait) { g_batch_timing.mark(2); first_wait = false; }
+      if (it.F.eigen_first_use && !eigen_speculation_supported(c.r)) {  // (its status is not written to pinned memory)
+        sync_proposal_status_if(it.props[it.generator], true);
+        c.finish(0, 0);
+      }
       c.stage_used = 0;
       if (c.h_wait_error[0]) {  // the decomposition this chain draws from did not finish in time (a tool that serialises kernels)
         HIP_OK(hipStreamSynchronize(lead.stream));

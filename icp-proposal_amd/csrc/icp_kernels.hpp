@@ -178,6 +178,7 @@ bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambd
 // segment allows (24 each); every request carries its model's sqrt_lambda
 bool launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest* rq);
 void eigen_debug_dump(const double* work, int r);
+void library_release_stream(hipStream_t st);  // drops the library handle kept for `st` (ranks > 64), before the stream is destroyed
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
                             double* Vt, double* S, double* work /* eigen_work_doubles(r) */, int* status,
                             const EigenSpec* spec = nullptr, int* host_status = nullptr /* pinned copy of *status; honoured

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <map>
 #include <mutex>
 
 #include <rocsolver/rocsolver.h>
@@ -1164,13 +1165,28 @@ __global__ void __launch_bounds__(256) k_factor_lib_finish(int r, const double* 
   if (i < r) alpha[i] = b[i];
   if (i == 0) status[0] = info[0] == 0 ? 0 : 1;
 }
+// One handle per stream: a handle owns the device workspace its calls use, in the order of ITS stream — one handle moved
+// from stream to stream let the decompositions of two chains (each on its own context's eigen stream) share that
+// workspace while both were in flight (memory fault with two rank-101 chains in one batch).
+static std::map<hipStream_t, rocblas_handle> g_library_handles;
 static rocblas_handle library_handle(hipStream_t st) {  // callers hold g_library_mutex
-  static rocblas_handle handle = nullptr;
-  if (!handle && rocblas_create_handle(&handle) != rocblas_status_success) handle = nullptr;
-  if (handle && rocblas_set_stream(handle, st) != rocblas_status_success) return nullptr;
+  std::map<hipStream_t, rocblas_handle>& handles = g_library_handles;
+  auto it = handles.find(st);
+  if (it != handles.end()) return it->second;
+  rocblas_handle handle = nullptr;
+  if (rocblas_create_handle(&handle) != rocblas_status_success) return nullptr;
+  if (rocblas_set_stream(handle, st) != rocblas_status_success) { (void)rocblas_destroy_handle(handle); return nullptr; }
+  handles[st] = handle;
   return handle;
 }
 static std::mutex g_library_mutex;  // (the handle carries the stream; calls only enqueue)
+void library_release_stream(hipStream_t st) {  // the stream is about to be destroyed (and has been synchronised)
+  std::lock_guard<std::mutex> lk(g_library_mutex);
+  auto it = g_library_handles.find(st);
+  if (it == g_library_handles.end()) return;
+  (void)rocblas_destroy_handle(it->second);
+  g_library_handles.erase(it);
+}
 
 static bool launch_factor_library(hipStream_t st, int r, const PosteriorFactorIO& io) {
   std::lock_guard<std::mutex> lk(g_library_mutex);

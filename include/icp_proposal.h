@@ -259,7 +259,7 @@ ICP_API int icp_chain_step_prelaunch(icp_evaluator *e, int32_t n_props, icp_prop
  * log_value_prop[b], fwd/bwd[b*n_props + i] and status[b] (ICP_OK / ICP_ERR_EMPTY / error of that chain) are written
  * per chain.  Every chain needs a context of its own (contexts hold the per-chain scratch; model and target are simply
  * given to each); chains on another device or of another rank than chain 0, a second chain on one context, and
- * configurations or ranks the merged launches do not cover take icp_chain_step one after the other.  Values are
+ * configurations the merged launches do not cover take icp_chain_step one after the other.  Values are
  * bit-identical to icp_chain_step chain by chain.  Returns ICP_OK or the first failing chain's code.  Calls from
  * several threads must use disjoint sets of contexts. */
 ICP_API int icp_chain_step_batched(int32_t n_chains, icp_evaluator *const *evaluators, int32_t n_props,

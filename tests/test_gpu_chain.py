@@ -278,3 +278,25 @@ def test_chain_step_batched_entry_point(pkg, femur50):
     for ev, props in objs:
         ev.close(); [p.close() for p in props]
     [c.close() for c in ctxs]
+
+
+def test_batched_chains_rank_101(pkg):
+    """Ranks above 64 decompose through the library on each chain's own stream; the batch waits for them on the host."""
+    model, target = pkg.data.load_femur_model_and_target(100)
+    n_steps, B = 12, 3
+    setups = [pkg.femur_icp_proposal_registration(model, target, fused=2) for _ in range(B)]
+    inits = [pkg.random_initial_parameters(model, chain_index=i) for i in range(B)]
+
+    def make():
+        ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
+        return ctxs, [pkg.SamplingRegistration(ctxs[i], setups[i], inits[i], seed=7 + i) for i in range(B)]
+
+    ctxs, chains = make()
+    single = [c.run(n_steps) for c in chains]
+    [c.close() for c in chains]; [c.close() for c in ctxs]
+    ctxs, chains = make()
+    got = pkg.run_chains_batched(chains, n_steps)
+    for b in range(B):
+        assert np.array_equal(got[b], single[b]), f"chain {b} differs"
+    assert sum(s[:, 1].sum() for s in single) > 3
+    [c.close() for c in chains]; [c.close() for c in ctxs]
