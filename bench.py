@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=300, help="steps of the HIP-event roofline leg (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=16, help="steps of the CPU-oracle baseline leg (0 = skip)")
     ap.add_argument("--subdiv", type=int, default=6, help="edge subdivision of the synthetic target (6 -> 58,322 vertices)")
+    ap.add_argument("--chains-per-gpu", type=int, default=1,
+                    help="independent chains per GPU, stepped in lockstep through icp_chain_step_batched (default 1 = the BASELINE.json "
+                         "configuration; more is the RunMHRandomInitComparison-style many-chains job on fewer GPUs)")
     ap.add_argument("--fused", type=int, default=2, choices=[0, 1, 2],
                     help="host<->device call pattern per step: 0 per-method calls, 1 propose + icp_chain_eval_step, 2 one icp_chain_step")
     args = ap.parse_args()
@@ -67,13 +70,26 @@ def main():
     # ---- workload (identical on every rank; synthetic target built from the bundled femur data)
     model, target = pkg.data.synthetic_femur_target(n_subdiv=args.subdiv)
     r = model.rank
-    ctx = pkg.IcpContext(model, target, device=local_rank)
+    B = max(1, args.chains_per_gpu)
+    ctxs = [pkg.IcpContext(model, target, device=local_rank) for _ in range(B)]  # (a context holds one chain's scratch)
+    ctx = ctxs[0]
     setup = pkg.femur_icp_proposal_registration(model, target, fused=args.fused)
     theta0 = pkg.initial_parameters(model)
-    if rank > 0:  # apps/femur/RandomSamplesFromModel.scala:28-35: chain i > 0 starts from c ~ N(0, 0.1·I)
-        theta0[10:] = np.random.default_rng(1024 + rank).normal(size=r) * np.sqrt(0.1)
-    chain = pkg.SamplingRegistration(ctx, setup, theta0, seed=1024 + rank)
+    chains = []
+    for i in range(B):
+        gid = rank * B + i  # chain id within the job
+        th = theta0.copy()
+        if gid > 0:  # apps/femur/RandomSamplesFromModel.scala:28-35: chain i > 0 starts from c ~ N(0, 0.1·I)
+            th[10:] = np.random.default_rng(1024 + gid).normal(size=r) * np.sqrt(0.1)
+        chains.append(pkg.SamplingRegistration(ctxs[i], setup, th, seed=1024 + gid))
+    chain = chains[0]
     rec_len = 4 + 10 + r
+
+    def run_chains(n):
+        """n steps of every chain of this rank -> records [B * n, rec_len]"""
+        if B == 1:
+            return chain.run(n)
+        return np.concatenate(pkg.run_chains_batched(chains, n))
 
     def barrier():
         if dist is not None:
@@ -92,13 +108,13 @@ def main():
         return out
 
     # ---- warmup (also builds the RCCL communicator)
-    w = chain.run(max(args.warmup, 1))
+    w = run_chains(max(args.warmup, 1))
     gather_logs(w)
 
     # ---- timed region: exactly K steps per rank + the log gather
     barrier()
     t0 = time.perf_counter()
-    rec = chain.run(args.steps)
+    rec = run_chains(args.steps)
     t_chain = time.perf_counter() - t0
     gather_logs(rec)
     t_gather = time.perf_counter() - t0 - t_chain
@@ -113,7 +129,7 @@ def main():
 
     line = {
         "metric": "ICP-proposal MH iterations/sec (femur GPMM r=50, ~50k-vtx target)",
-        "value": world * args.steps / dt,
+        "value": world * B * args.steps / dt,
         "unit": "iterations/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -126,10 +142,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "BASELINE.json configs[1]: femur 50-basis GPMM (N=%d, rank %d) vs synthetic target M=%d vertices / %d triangles; "
-                        "1 chain per GPU; 0.9 ICP(Target+Model sampling, K=%d) + 0.1 random walk; prior x independent Gaussian(0,2) on %d points"
-                        % (model.n_points, r, target.n_points, target.n_cells, 2 * r, 4 * r),
-            "chains_per_gpu": 1,
-            "calls_per_step": {0: "per-method", 1: "propose + icp_chain_eval_step", 2: "icp_chain_step"}[args.fused],
+                        "%d chain%s per GPU; 0.9 ICP(Target+Model sampling, K=%d) + 0.1 random walk; prior x independent Gaussian(0,2) on %d points"
+                        % (model.n_points, r, target.n_points, target.n_cells, B, "" if B == 1 else "s (lockstep, icp_chain_step_batched)", 2 * r, 4 * r),
+            "chains_per_gpu": B,
+            "calls_per_step": {0: "per-method", 1: "propose + icp_chain_eval_step", 2: "icp_chain_step"}[args.fused] if B == 1 else "icp_chain_step_batched",
             "chain_ms": 1e3 * t_chain,
             "log_gather_ms": 1e3 * t_gather,
             "accepted": n_acc,
@@ -139,7 +155,7 @@ def main():
         "cpu_baseline": None,
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and B == 1:
         # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on (the library's stream)
         if args.profile_steps > 0:
             ctx.profile_start(max_launches=64 * args.profile_steps + 1024)
@@ -192,8 +208,10 @@ def main():
                                     "gpu_matches_oracle_on_sample": same}
     if rank == 0:
         print(json.dumps(line))
-    chain.close()
-    ctx.close()
+    for ch in chains:
+        ch.close()
+    for cx in ctxs:
+        cx.close()
     if dist is not None:
         dist.destroy_process_group()
 

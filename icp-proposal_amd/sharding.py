@@ -61,18 +61,37 @@ def gather_ragged(blocks, dist=None, device=None):
     return [g[1:1 + int(g[0, 0, 0])] for g in gathered]
 
 
-def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist=None, device_index: int = 0, base_seed: int = 1024):
+def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist=None, device_index: int = 0, base_seed: int = 1024,
+              chains_per_launch: int = 1):
     """Batch registration (BASELINE.json configs[4]; reference: the 10-way target pool × per-target chain loop of
     apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala:106-163): work items = (target, chain) pairs, dealt round-robin
     over the ranks; a rank keeps ONE context per target it meets; chains never communicate; the per-step records of all items
     are exchanged with a single all_gather at the end.  Returns (items, records): items[k] = (target index, chain index) and
-    records[k] = [n_steps, 14 + rank] for every item of the whole job, in item order, on every rank."""
+    records[k] = [n_steps, 14 + rank] for every item of the whole job, in item order, on every rank.
+    chains_per_launch > 1: the rank steps that many of its chains in lockstep through icp_chain_step_batched (one context per
+    chain; SURVEY.md §8e "within a GPU, batch B chains per launch") — same records, chain by chain."""
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
     items = [(t, c) for t in range(len(targets)) for c in range(n_chains)]
     mine = assign_work_items(len(items), world)[rank]
     blocks, ctx, ctx_target = [], None, -1
-    for k in sorted(mine, key=lambda k: items[k][0]):          # target-major: one context per target
+    order = sorted(mine, key=lambda k: items[k][0])
+    if chains_per_launch > 1:
+        for g0 in range(0, len(order), chains_per_launch):
+            group = order[g0:g0 + chains_per_launch]
+            ctxs = [pkg.IcpContext(model, targets[items[k][0]], device=device_index) for k in group]
+            chains = [pkg.SamplingRegistration(cx, make_setup(model, targets[items[k][0]]),
+                                               pkg.random_initial_parameters(model, items[k][1], base_seed),
+                                               seed=base_seed + 1000 * items[k][0] + items[k][1]) for cx, k in zip(ctxs, group)]
+            for k, rec in zip(group, pkg.run_chains_batched(chains, n_steps)):
+                rec[:, 0] = k
+                blocks.append(rec)
+            for ch in chains:
+                ch.close()
+            for cx in ctxs:
+                cx.close()
+        order = []
+    for k in order:                                            # target-major: one context per target
         t, c = items[k]
         if t != ctx_target:
             if ctx is not None:

@@ -141,3 +141,16 @@ def test_batch_registration_world1(pkg):
     for k, rec in enumerate(recs):
         assert rec.shape == (5, 14 + model.rank) and np.all(rec[:, 0] == k) and np.all(np.isfinite(rec[:, 1:]))
     assert not np.array_equal(recs[0][:, 14:], recs[1][:, 14:])   # different initial shapes / seeds
+    # the same job with the rank's chains stepped in lockstep, three per submission: identical records
+    items3, recs3 = pkg.sharding.run_batch(pkg, model, targets, n_chains=2, n_steps=5, make_setup=pkg.bfm_fitting_partial, chains_per_launch=3)
+    assert items3 == items and all(np.array_equal(a, b) for a, b in zip(recs, recs3))
+
+
+def test_batch_registration_lockstep_femur(pkg, femur50):
+    """Closed target: the lockstep chains really share their launches (icp_chain_step_batched); records as one by one."""
+    model, target = femur50
+    setup = lambda m, t: pkg.femur_icp_proposal_registration(m, t, fused=2)
+    items, recs = pkg.sharding.run_batch(pkg, model, [target], n_chains=5, n_steps=25, make_setup=setup)
+    items4, recs4 = pkg.sharding.run_batch(pkg, model, [target], n_chains=5, n_steps=25, make_setup=setup, chains_per_launch=4)
+    assert items4 == items and all(np.array_equal(a, b) for a, b in zip(recs, recs4))
+    assert sum(r[:, 1].sum() for r in recs) > 10
