@@ -206,6 +206,8 @@ int icp_host_chain_run(icp_host_chain* ch, int32_t n_steps, double* records) {
 }
 
 int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains, int32_t n_steps, double* const* records) {
+  // a lone chain is better off with the pipelined single-chain step (launches of the next step issued ahead)
+  if (chains && n_chains == 1 && chains[0]) return icp_host_chain_run(chains[0], n_steps, records ? records[0] : nullptr);
   return host_guard([&] {
     if (!chains || n_chains < 1 || n_steps < 0) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chains_run_batched");
     const size_t n_icp = chains[0] ? chains[0]->icp.size() : 0;
