@@ -266,9 +266,18 @@ struct icp_ctx {
   Profiler prof;
   bool profiling = false;
   // argument arrays of the icp_chain_step_batched launches led by this context: pinned copy, device copy
-  void* batch_pinned = nullptr;
-  DBuf<unsigned char> batch_device;
-  size_t batch_bytes = 0;
+  // (kBatchRing of each, used in turn: a caller may keep that many batches in flight on this context's stream)
+  static constexpr int kBatchRing = 4;
+  void* batch_pinned[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
+  DBuf<unsigned char> batch_device[kBatchRing];
+  size_t batch_bytes[kBatchRing] = {0, 0, 0, 0};
+  int batch_turn = 0;
+  // eigen streams of the batches this context carries, one per batch in flight (keyed by the batch's first chain): created
+  // together, so that the runtime spreads them over different hardware queues — the member contexts' own eigen streams
+  // collide on one queue for some batch sizes (24 chains in three groups: 49k instead of 70k it/s)
+  hipStream_t batch_eig[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
+  const void* batch_eig_owner[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
+  int batch_eig_evict = 0;
 
   void bind() { HIP_OK(hipSetDevice(device)); }
 
@@ -722,6 +731,24 @@ void icp_proposal::prepare_eigen(PosteriorEntry& e, EigenRequest* rq) {
   e.eig_valid = true;
 }
 
+// the eigen stream of the batch whose first chain lives on `owner`, out of the launch context's pool
+hipStream_t batch_eigen_stream(icp_ctx& lead, const void* owner) {
+  if (!lead.batch_eig[0]) {
+    std::lock_guard<std::mutex> lk(g_eig_streams_mu);
+    for (int k = 0; k < icp_ctx::kBatchRing; ++k) {
+      HIP_OK(hipStreamCreateWithFlags(&lead.batch_eig[k], hipStreamNonBlocking));
+      g_eig_streams.insert(lead.batch_eig[k]);
+    }
+  }
+  for (int k = 0; k < icp_ctx::kBatchRing; ++k)
+    if (lead.batch_eig_owner[k] == owner) return lead.batch_eig[k];
+  for (int k = 0; k < icp_ctx::kBatchRing; ++k)
+    if (!lead.batch_eig_owner[k]) { lead.batch_eig_owner[k] = owner; return lead.batch_eig[k]; }
+  const int k = (lead.batch_eig_evict = (lead.batch_eig_evict + 1) % icp_ctx::kBatchRing);  // (more than four batches: shared)
+  lead.batch_eig_owner[k] = owner;
+  return lead.batch_eig[k];
+}
+
 // waits for every decomposition of this context that may still be running
 void sync_eigen(icp_ctx& c) {
   if (c.eig_last && c.eig_last != c.eig_stream) {
@@ -1101,6 +1128,14 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     if (g_eig_streams.count(ctx->eig_last)) (void)hipStreamSynchronize(ctx->eig_last);
   }
+  for (hipStream_t& bs : ctx->batch_eig)
+    if (bs) {
+      std::lock_guard<std::mutex> lk(g_eig_streams_mu);
+      g_eig_streams.erase(bs);
+      (void)hipStreamSynchronize(bs);
+      (void)hipStreamDestroy(bs);
+      bs = nullptr;
+    }
   if (ctx->eig_stream) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     g_eig_streams.erase(ctx->eig_stream);
@@ -1128,7 +1163,8 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
-  if (ctx->batch_pinned) (void)hipHostFree(ctx->batch_pinned);
+  for (void* bp : ctx->batch_pinned)
+    if (bp) (void)hipHostFree(bp);
   if (ctx->counted) --g_live_contexts;
   delete ctx;
 }
@@ -2319,29 +2355,83 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
 // device, as in the single-chain step).  Chains this does not cover (another device or rank than the first chain's, a
 // context that already has a chain in the batch, a configuration the merged launches do not cover) take icp_chain_step
 // one after the other, behind the batch.
-int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props,
-                           const int32_t* generator, const double* const* theta_cur, const double* const* z,
-                           double* const* theta_prop, double* log_value_prop, double* fwd, double* bwd, int32_t* status) {
-  struct Item {
-    icp_evaluator* e = nullptr;
-    icp_proposal* const* props = nullptr;
-    int generator = -1;
-    const double* key = nullptr;
-    bool batched = false, issued = false, redo = false;
-    StepFront F;
-    StepFinishArgs f{};
-    std::unique_lock<std::recursive_mutex> lk;
-  };
-  std::vector<Item> items;
+// The work is split in two so that a caller can keep two batches in flight (the decompositions of one run beside the
+// launches of the other): _issue ends when everything is on the device, _collect waits and records.
+} // extern "C" (helpers)
+
+struct BatchItem {
+  icp_evaluator* e = nullptr;
+  icp_proposal* const* props = nullptr;
+  int generator = -1;
+  const double* key = nullptr;
+  bool batched = false, issued = false, redo = false;
+  StepFront F;
+  StepFinishArgs f{};
+  std::unique_lock<std::recursive_mutex> lk;
+};
+
+struct icp_step_ticket {
+  int n_chains = 0, n_props = 0, nb = 0;
+  icp_ctx* lead = nullptr;
+  hipStream_t finish_stream = nullptr;  // where the batch's last launch went, if not lead->stream
+  std::vector<BatchItem> items;
   std::vector<StepCapture> caps;
+  std::vector<icp_proposal*> props;
+  std::vector<const double*> theta_cur, z;
+  std::vector<double*> theta_prop;
+  double* log_value_prop = nullptr;
+  double* fwd = nullptr;
+  double* bwd = nullptr;
+  int32_t* status = nullptr;
+};
+
+namespace {
+// whatever happened, nothing stays reserved or locked; a failed batch leaves its launches to drain
+void batch_release(icp_step_ticket& t) {
+  for (auto& it : t.items) {
+    if (it.issued) {
+      if (t.lead) (void)hipStreamSynchronize(t.lead->stream);
+      if (t.finish_stream) (void)hipStreamSynchronize(t.finish_stream);
+      release_front(it.F);
+      it.issued = false;
+    }
+    if (it.lk.owns_lock()) it.lk.unlock();
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props,
+                                 const int32_t* generator, const double* const* theta_cur_in, const double* const* z_in,
+                                 double* const* theta_prop_in, double* log_value_prop, double* fwd, double* bwd, int32_t* status,
+                                 icp_ctx* launch_ctx, icp_step_ticket** out) {
+  if (out) *out = nullptr;
+  icp_step_ticket* tk = nullptr;
   int rc = guard([&] {
-    require(n_chains >= 1 && evaluators && generator && theta_cur && theta_prop && log_value_prop && status, "null argument");
+    require(out != nullptr, "null argument");
+    require(n_chains >= 1 && evaluators && generator && theta_cur_in && theta_prop_in && log_value_prop && status, "null argument");
+    tk = new icp_step_ticket();
+    icp_step_ticket& t = *tk;
+    t.n_chains = n_chains; t.n_props = n_props;
+    t.theta_cur.assign(theta_cur_in, theta_cur_in + n_chains);
+    t.theta_prop.assign(theta_prop_in, theta_prop_in + n_chains);
+    t.z.assign(n_chains, nullptr);
+    if (z_in) t.z.assign(z_in, z_in + n_chains);
+    t.log_value_prop = log_value_prop; t.fwd = fwd; t.bwd = bwd; t.status = status;
+    std::vector<BatchItem>& items = t.items;
+    std::vector<StepCapture>& caps = t.caps;
+    const double* const* theta_cur = t.theta_cur.data();
+    const double* const* z = z_in ? t.z.data() : nullptr;
+    double* const* theta_prop = t.theta_prop.data();
+    typedef BatchItem Item;
     require(n_props >= 0 && n_props <= 8 && (n_props == 0 || (props && fwd && bwd)), "bad proposal list");
+    t.props.assign(props, props + (size_t)n_chains * n_props);
     items.resize(n_chains);
     for (int b = 0; b < n_chains; ++b) {
       Item& it = items[b];
       it.e = evaluators[b];
-      it.props = props + (size_t)b * n_props;
+      it.props = t.props.data() + (size_t)b * n_props;
       it.generator = generator[b];
       require(it.e && theta_cur[b] && theta_prop[b], "null argument");
       require(it.generator < n_props, "generator index out of range");
@@ -2356,13 +2446,17 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
       it.key = it.generator >= 0 ? z[b] : theta_prop[b];
       status[b] = ICP_OK;
     }
-    icp_ctx& lead = *items[0].e->ctx;
+    // `lead` carries the launches (its stream, its argument buffers); the decompositions go to the first chain's eigen stream
+    icp_ctx& elead = *items[0].e->ctx;
+    icp_ctx& lead = launch_ctx ? *launch_ctx : elead;
+    require(lead.device == elead.device, "launch context on another device");
+    t.lead = &lead;
     // ---- which chains share the launches
     int n_batched = 0;
     for (int b = 0; b < n_chains; ++b) {
       Item& it = items[b];
       icp_ctx& c = *it.e->ctx;
-      bool ok = n_props >= 1 && n_props <= 2 && c.device == lead.device && c.r == lead.r;
+      bool ok = n_props >= 1 && n_props <= 2 && c.device == elead.device && c.r == elead.r;
       for (int a = 0; a < b && ok; ++a) ok = !(items[a].batched && items[a].e->ctx == &c);
       if (!ok) continue;
       it.lk = std::unique_lock<std::recursive_mutex>(c.mu);
@@ -2382,7 +2476,7 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
     caps.resize(n_batched > 0 ? n_batched : 1);
     // the decompositions of the chains that moved go out first, together, so that they run while the host prepares the
     // launches (a chain whose posteriors are not on record yet starts its own in enqueue_front)
-    EigenCollect eigens{lead.eig_stream, {}, {}};
+    EigenCollect eigens{batch_eigen_stream(lead, &elead), {}, {}};
     for (int b = 0; b < n_chains; ++b) {
       Item& it = items[b];
       if (!it.batched) continue;
@@ -2396,11 +2490,10 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
       // (ranks > 64 decompose through the library, each chain on its own eigen stream, and are awaited on the host below)
       start_decompositions(c, n_props, it.props, ec, c.stream_used_elsewhere, eigen_speculation_supported(c.r) ? &eigens : nullptr);
     }
-    if (!eigens.rq.empty()) {  // … in one launch (per 24), on the first chain's eigen stream
-      Bound _b(&lead, true);
-      (void)eigen_stream_for(lead, lead.eig_stream);
-      launch_posterior_eigen_many(lead.eig_stream, lead.r, (int)eigens.rq.size(), eigens.rq.data());
-      for (PosteriorEntry* e0 : eigens.first) HIP_OK(hipEventRecord(e0->eig_done, lead.eig_stream));
+    if (!eigens.rq.empty()) {  // … in one launch (per 24), on the batch's eigen stream
+      Bound _b(&elead, true);
+      launch_posterior_eigen_many(eigens.stream, elead.r, (int)eigens.rq.size(), eigens.rq.data());
+      for (PosteriorEntry* e0 : eigens.first) HIP_OK(hipEventRecord(e0->eig_done, eigens.stream));
     }
     int nb = 0;
     for (int b = 0; b < n_chains; ++b) {
@@ -2449,18 +2542,49 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
     if (nb > 0) {
       Bound _b(&lead, true);
       const size_t bytes = step_batch_bytes(nb);
-      if (bytes > lead.batch_bytes) {
+      const int turn = (lead.batch_turn = (lead.batch_turn + 1) % icp_ctx::kBatchRing);
+      if (bytes > lead.batch_bytes[turn]) {
         HIP_OK(hipStreamSynchronize(lead.stream));
-        if (lead.batch_pinned) { HIP_OK(hipHostFree(lead.batch_pinned)); lead.batch_pinned = nullptr; }
+        if (lead.batch_pinned[turn]) { HIP_OK(hipHostFree(lead.batch_pinned[turn])); lead.batch_pinned[turn] = nullptr; }
         const size_t cap_bytes = std::max(bytes, step_batch_bytes(16));
-        HIP_OK(hipHostMalloc(&lead.batch_pinned, cap_bytes, hipHostMallocDefault));
-        lead.batch_device.alloc(cap_bytes);
-        lead.batch_bytes = cap_bytes;
+        HIP_OK(hipHostMalloc(&lead.batch_pinned[turn], cap_bytes, hipHostMallocDefault));
+        lead.batch_device[turn].alloc(cap_bytes);
+        lead.batch_bytes[turn] = cap_bytes;
       }
-      launch_step_batch(lead.stream, nb, caps.data(), lead.batch_pinned, lead.batch_device.p);
+      static const bool finish_aside = std::getenv("ICP_BATCH_FINISH_INLINE") == nullptr;  // (A/B switch)
+      launch_step_batch(lead.stream, nb, caps.data(), lead.batch_pinned[turn], lead.batch_device[turn].p,
+                        finish_aside ? lead.front_stream : nullptr, lead.ev_join);
+      if (finish_aside) t.finish_stream = lead.front_stream;
     }
-    // ---- results, chain by chain
+    t.nb = nb;
+    t.lead = &lead;
     g_batch_timing.mark(1);
+  });
+  if (rc != ICP_OK) {
+    if (tk) { batch_release(*tk); delete tk; }
+    return rc;
+  }
+  *out = tk;
+  return ICP_OK;
+}
+
+int icp_chain_step_batched_collect(icp_step_ticket* tk) {
+  if (!tk) return ICP_ERR_INVALID_ARG;
+  icp_step_ticket& t = *tk;
+  const int n_chains = t.n_chains, n_props = t.n_props, nb = t.nb;
+  std::vector<BatchItem>& items = t.items;
+  const double* const* theta_cur = t.theta_cur.data();
+  const double* const* z = t.z.data();
+  double* const* theta_prop = t.theta_prop.data();
+  double* log_value_prop = t.log_value_prop;
+  double* fwd = t.fwd;
+  double* bwd = t.bwd;
+  int32_t* status = t.status;
+  typedef BatchItem Item;
+  int rc = guard([&] {
+    icp_ctx& lead = *t.lead;
+    g_batch_timing.start();
+    // ---- results, chain by chain
     bool first_wait = true;
     for (int b = 0; b < n_chains; ++b) {
       Item& it = items[b];
@@ -2473,7 +2597,10 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
       while (*flag != it.f.seq) {
         if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) break;
       }
-      if (*flag != it.f.seq) HIP_OK(hipStreamSynchronize(lead.stream));
+      if (*flag != it.f.seq) {
+        HIP_OK(hipStreamSynchronize(lead.stream));
+        if (t.finish_stream) HIP_OK(hipStreamSynchronize(t.finish_stream));
+      }
       if (first_wait) { g_batch_timing.mark(2); first_wait = false; }
       if (it.F.eigen_first_use && !eigen_speculation_supported(c.r)) {  // (its status is not written to pinned memory)
         sync_proposal_status_if(it.props[it.generator], true);
@@ -2482,6 +2609,7 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
       c.stage_used = 0;
       if (c.h_wait_error[0]) {  // the decomposition this chain draws from did not finish in time (a tool that serialises kernels)
         HIP_OK(hipStreamSynchronize(lead.stream));
+        if (t.finish_stream) HIP_OK(hipStreamSynchronize(t.finish_stream));
         sync_eigen(c);
         c.h_wait_error[0] = 0;
         it.redo = true;
@@ -2501,15 +2629,8 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
     g_batch_timing.mark(3);
     if (g_batch_timing.on) { ++g_batch_timing.calls; g_batch_timing.chains += nb; }
   });
-  // whatever happened, nothing stays reserved or locked; a failed batch leaves its launches to drain
-  for (auto& it : items) {
-    if (it.issued) {
-      (void)hipStreamSynchronize(items[0].e->ctx->stream);
-      release_front(it.F);
-    }
-    if (it.lk.owns_lock()) it.lk.unlock();
-  }
-  if (rc != ICP_OK) return rc;
+  batch_release(t);
+  if (rc != ICP_OK) { delete tk; return rc; }
   // ---- the others, and whatever has to be done again, one after the other
   int first_bad = ICP_OK;
   for (int b = 0; b < n_chains; ++b) {
@@ -2521,8 +2642,20 @@ int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, i
   }
   for (int b = 0; b < n_chains; ++b)
     if (status[b] != ICP_OK && status[b] != ICP_ERR_EMPTY && first_bad == ICP_OK) first_bad = status[b];
+  delete tk;
   return first_bad;
 }
+
+int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props,
+                           const int32_t* generator, const double* const* theta_cur, const double* const* z,
+                           double* const* theta_prop, double* log_value_prop, double* fwd, double* bwd, int32_t* status) {
+  icp_step_ticket* tk = nullptr;
+  const int rc = icp_chain_step_batched_issue(n_chains, evaluators, n_props, props, generator, theta_cur, z, theta_prop, log_value_prop, fwd,
+                                              bwd, status, nullptr, &tk);
+  if (rc != ICP_OK) return rc;
+  return icp_chain_step_batched_collect(tk);
+}
+
 
 
 }  // extern "C"

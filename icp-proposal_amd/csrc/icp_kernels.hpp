@@ -313,7 +313,9 @@ struct StepCapture {
 };
 void step_capture(StepCapture* c);  // nullptr: launch as usual
 size_t step_batch_bytes(int B);
-void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pinned, void* device);
+// st_finish/ev (optional): the fifth launch goes to st_finish behind an event recorded on st
+void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pinned, void* device, hipStream_t st_finish = nullptr,
+                       hipEvent_t ev = nullptr);
 SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const float4* spheres, int K, const double* P,
                               int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);
 VertexTask make_vertex_task(int V, const double* verts, int K, const double* P, int* hint, const QueryBuffers& qb, double* d2, int* idx);

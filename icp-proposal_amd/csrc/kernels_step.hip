@@ -361,7 +361,7 @@ size_t step_batch_bytes(int B) {
          up16(sizeof(StepFinishArgs) * B);
 }
 
-void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pinned, void* device) {
+void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pinned, void* device, hipStream_t st_finish, hipEvent_t ev) {
   if (B <= 0) return;
   const size_t o1 = up16(sizeof(StepBeginArgs) * B), o2 = o1 + up16(sizeof(StepSearchArgs) * B),
                o3 = o2 + up16(sizeof(StepRegressionArgs) * B), total = step_batch_bytes(B);
@@ -383,6 +383,13 @@ void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pin
   if (gx[3] > 0) { ProfScope _ps(st, KID_STEP_REGRESSION); hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, (const StepRegressionArgs*)(d + o2)); }
   if (gx[4] > 0) {
     const FinishPlan p = finish_plan(caps[0].finish.r);  // (one rank per batch: checked by the caller)
+    // launch 5 keeps four CUs per chain busy for 30 µs whatever the batch: on a stream of its own it runs beside the first
+    // launches of the NEXT batch on `st` (other chains: nothing of theirs depends on it)
+    if (st_finish && st_finish != st && ev) {
+      (void)hipEventRecord(ev, st);
+      (void)hipStreamWaitEvent(st_finish, ev, 0);
+      st = st_finish;
+    }
     ProfScope _ps(st, KID_STEP_FINISH);
     const StepFinishArgs* fb = (const StepFinishArgs*)(d + o3);
     if (p.E == 1 && p.NT == 256) launch_finish_batch<1, 256>(st, fb, gx[4], B, p.shmem);

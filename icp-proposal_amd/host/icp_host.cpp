@@ -205,81 +205,139 @@ int icp_host_chain_run(icp_host_chain* ch, int32_t n_steps, double* records) {
   });
 }
 
+namespace {
+// A set of chains stepped in lockstep: per step ONE icp_chain_step_batched submission for all members whose proposal is an
+// ICP or a random-walk shape proposal, then every member's MetropolisHastings.next with the results parked for it.
+struct LockstepGroup {
+  std::vector<icp_host_chain*> chains;
+  size_t n_icp = 0;
+  int r = 0;
+  std::vector<StepRandom> rnd;
+  std::vector<std::vector<double>> z, prop;
+  std::vector<int> member;  // chains of the submission in flight
+  std::vector<icp_evaluator*> ev;
+  std::vector<icp_proposal*> props;
+  std::vector<int32_t> gen, status;
+  std::vector<const double*> cur_p, z_p;
+  std::vector<double*> prop_p;
+  std::vector<double> value, fwd, bwd;
+  icp_step_ticket* ticket = nullptr;
+  icp_ctx* launch_ctx = nullptr;  // whose stream carries the group's launches (nullptr: the first member's)
+
+  void init() {
+    const size_t B = chains.size();
+    n_icp = chains[0]->icp.size();
+    r = chains[0]->r;
+    rnd.resize(B);
+    z.assign(B, std::vector<double>(r));
+    prop.assign(B, std::vector<double>(10 + r));
+  }
+  // the next step of every member: random numbers, proposal kind, arguments; submission of those that share launches
+  void issue() {
+    member.clear(); ev.clear(); props.clear(); gen.clear(); cur_p.clear(); z_p.clear(); prop_p.clear();
+    for (size_t b = 0; b < chains.size(); ++b) {
+      icp_host_chain* ch = chains[b];
+      rnd[b] = StepRandom{ch->seed, (uint64_t)ch->logger.index};
+      ch->prefetcher.submitted_index = -1;
+      ProposalGeneratorWithTransition* leaf = ch->root->peek(rnd[b], 0);
+      int g = -2;
+      if (auto* ip = dynamic_cast<NonRigidIcpProposal*>(leaf)) {
+        if (ip->stepper) {
+          g = ip->stepperIndex;
+          for (int j = 0; j < r; ++j) z[b][j] = rnd[b].normal(j);  // posterior.sample() (NonRigidIcpProposal.scala:55)
+        }
+      } else if (auto* rw = dynamic_cast<RandomShapeUpdateProposal*>(leaf)) {
+        g = -1;
+        prop[b] = rw->propose(ch->current, rnd[b], 0).allParameters;
+      }
+      if (g == -2 || n_icp == 0) continue;  // pose proposals: MetropolisHastings::next submits them itself
+      member.push_back((int)b);
+      ev.push_back(ch->likelihood->h);
+      for (auto* p : ch->icp) props.push_back(p->h);
+      gen.push_back(g);
+      cur_p.push_back(ch->current.data());
+      z_p.push_back(z[b].data());
+      prop_p.push_back(prop[b].data());
+    }
+    const int nb = (int)member.size();
+    ticket = nullptr;
+    if (nb == 0) return;
+    value.assign(nb, 0.0); fwd.assign((size_t)nb * n_icp + 1, 0.0); bwd.assign((size_t)nb * n_icp + 1, 0.0); status.assign(nb, 0);
+    check(icp_chain_step_batched_issue(nb, ev.data(), (int)n_icp, props.data(), gen.data(), cur_p.data(), z_p.data(), prop_p.data(),
+                                       value.data(), fwd.data(), bwd.data(), status.data(), launch_ctx, &ticket),
+          "icp_chain_step_batched_issue");
+  }
+  // results of the submission in flight, then SamplingRegistration.scala:58-85 for every member
+  void finish() {
+    if (ticket) {
+      icp_step_ticket* t = ticket;
+      ticket = nullptr;
+      const int st = icp_chain_step_batched_collect(t);
+      if (st != ICP_OK) check(st, "icp_chain_step_batched_collect");
+      for (size_t k = 0; k < member.size(); ++k) {
+        icp_host_chain* ch = chains[member[k]];
+        ModelFittingParameters pr;
+        pr.allParameters = prop[member[k]];
+        if (gen[k] >= 0) pr.generatedBy = ch->icp[gen[k]]->generatedBy;
+        else pr.generatedBy = static_cast<RandomShapeUpdateProposal*>(ch->root->peek(rnd[member[k]], 0))->generatedBy;
+        const std::vector<double> f(fwd.begin() + k * n_icp, fwd.begin() + (k + 1) * n_icp);
+        const std::vector<double> w(bwd.begin() + k * n_icp, bwd.begin() + (k + 1) * n_icp);
+        ch->prefetcher.park(ch->current, pr, status[k], value[k], f, w);
+        if (gen[k] >= 0) { ch->prefetcher.submitted_index = gen[k]; ch->prefetcher.submitted_z = z[member[k]]; }
+      }
+    }
+    for (size_t b = 0; b < chains.size(); ++b) {
+      icp_host_chain* ch = chains[b];
+      ch->current = ch->mh->next(ch->current, rnd[b], &ch->logger);
+      ch->current_p = ch->mh->cached_current_p;
+    }
+  }
+  void abandon() {  // after a failure elsewhere: the submission in flight is waited for and dropped
+    if (ticket) { (void)icp_chain_step_batched_collect(ticket); ticket = nullptr; }
+  }
+};
+}  // namespace
+
 int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains, int32_t n_steps, double* const* records) {
   // a lone chain is better off with the pipelined single-chain step (launches of the next step issued ahead)
   if (chains && n_chains == 1 && chains[0]) return icp_host_chain_run(chains[0], n_steps, records ? records[0] : nullptr);
-  return host_guard([&] {
+  constexpr int kMaxGroups = 4;
+  LockstepGroup groups[kMaxGroups];
+  int rc = host_guard([&] {
     if (!chains || n_chains < 1 || n_steps < 0) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chains_run_batched");
-    const size_t n_icp = chains[0] ? chains[0]->icp.size() : 0;
     for (int b = 0; b < n_chains; ++b) {
       icp_host_chain* ch = chains[b];
-      if (!ch || !ch->prefetcher.whole_step || ch->icp.size() != n_icp || ch->r != chains[0]->r)
+      if (!ch || !ch->prefetcher.whole_step || ch->icp.size() != chains[0]->icp.size() || ch->r != chains[0]->r)
         throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chains_run_batched: chains must share one configuration with fused = 2");
       ch->logger.out = records ? records[b] : nullptr;
       ch->runner = std::this_thread::get_id();
     }
-    const int B = n_chains, r = chains[0]->r, P = 10 + r;
-    std::vector<StepRandom> rnd(B);
-    std::vector<std::vector<double>> z(B, std::vector<double>(r)), prop(B, std::vector<double>(P));
-    std::vector<int> member;  // chains of this step's submission
-    std::vector<icp_evaluator*> ev;
-    std::vector<icp_proposal*> props;
-    std::vector<int32_t> gen, status;
-    std::vector<const double*> cur_p, z_p;
-    std::vector<double*> prop_p;
-    std::vector<double> value, fwd, bwd;
-    for (int s = 0; s < n_steps; ++s) {
-      member.clear(); ev.clear(); props.clear(); gen.clear(); cur_p.clear(); z_p.clear(); prop_p.clear();
-      for (int b = 0; b < B; ++b) {
-        icp_host_chain* ch = chains[b];
-        rnd[b] = StepRandom{ch->seed, (uint64_t)ch->logger.index};
-        ch->prefetcher.submitted_index = -1;
-        ProposalGeneratorWithTransition* leaf = ch->root->peek(rnd[b], 0);
-        int g = -2;
-        if (auto* ip = dynamic_cast<NonRigidIcpProposal*>(leaf)) {
-          if (ip->stepper) {
-            g = ip->stepperIndex;
-            for (int j = 0; j < r; ++j) z[b][j] = rnd[b].normal(j);  // posterior.sample() (NonRigidIcpProposal.scala:55)
-          }
-        } else if (auto* rw = dynamic_cast<RandomShapeUpdateProposal*>(leaf)) {
-          g = -1;
-          prop[b] = rw->propose(ch->current, rnd[b], 0).allParameters;
-        }
-        if (g == -2 || n_icp == 0) continue;  // pose proposals: MetropolisHastings::next submits them itself
-        member.push_back(b);
-        ev.push_back(ch->likelihood->h);
-        for (auto* p : ch->icp) props.push_back(p->h);
-        gen.push_back(g);
-        cur_p.push_back(ch->current.data());
-        z_p.push_back(z[b].data());
-        prop_p.push_back(prop[b].data());
+    // Several groups a fraction of a step apart: while one group's launches run, the other groups' decompositions do, and
+    // the host prepares their submissions (a step's first launch waits ≈ 100 µs for the decompositions of the chains that
+    // moved).  Few chains stay in one group: the launches of a part of them would not fill the device.
+    static const int forced = std::getenv("ICP_LOCKSTEP_GROUPS") ? std::atoi(std::getenv("ICP_LOCKSTEP_GROUPS")) : 0;
+    int n_groups = forced > 0 ? forced : (n_chains >= 24 ? 3 : n_chains >= 8 ? 2 : 1);  // (measured: tools/ab_batch.sh)
+    n_groups = std::max(1, std::min(std::min(n_groups, kMaxGroups), n_chains));
+    for (int b = 0; b < n_chains; ++b) groups[(size_t)b * n_groups / n_chains].chains.push_back(chains[b]);
+    for (int g = 0; g < n_groups; ++g) groups[g].init();
+    // all groups' launches on ONE stream, one group behind the other: side by side the big launches of two groups slow each
+    // other down more than the overlap gains (regression 18 -> 80 µs beside the other group's filter); the decompositions
+    // keep their own streams
+    for (int g = 1; g < n_groups; ++g) groups[g].launch_ctx = groups[0].chains[0]->ctx;
+    // steady state: every group has a submission in flight; they are collected and renewed in turn
+    if (n_steps > 0)
+      for (int g = 0; g < n_groups; ++g) groups[g].issue();
+    for (int s = 0; s < n_steps; ++s)
+      for (int g = 0; g < n_groups; ++g) {
+        groups[g].finish();
+        if (s + 1 < n_steps) groups[g].issue();
       }
-      const int nb = (int)member.size();
-      if (nb > 0) {
-        value.assign(nb, 0.0); fwd.assign((size_t)nb * n_icp + 1, 0.0); bwd.assign((size_t)nb * n_icp + 1, 0.0); status.assign(nb, 0);
-        const int st = icp_chain_step_batched(nb, ev.data(), (int)n_icp, props.data(), gen.data(), cur_p.data(), z_p.data(), prop_p.data(),
-                                              value.data(), fwd.data(), bwd.data(), status.data());
-        if (st != ICP_OK) check(st, "icp_chain_step_batched");
-        for (int k = 0; k < nb; ++k) {
-          icp_host_chain* ch = chains[member[k]];
-          ModelFittingParameters pr;
-          pr.allParameters = prop[member[k]];
-          if (gen[k] >= 0) pr.generatedBy = ch->icp[gen[k]]->generatedBy;
-          else pr.generatedBy = static_cast<RandomShapeUpdateProposal*>(ch->root->peek(rnd[member[k]], 0))->generatedBy;
-          const std::vector<double> f(fwd.begin() + (size_t)k * n_icp, fwd.begin() + (size_t)(k + 1) * n_icp);
-          const std::vector<double> w(bwd.begin() + (size_t)k * n_icp, bwd.begin() + (size_t)(k + 1) * n_icp);
-          ch->prefetcher.park(ch->current, pr, status[k], value[k], f, w);
-          if (gen[k] >= 0) { ch->prefetcher.submitted_index = gen[k]; ch->prefetcher.submitted_z = z[member[k]]; }
-        }
-      }
-      for (int b = 0; b < B; ++b) {  // SamplingRegistration.scala:58-85, every chain with what was parked for it
-        icp_host_chain* ch = chains[b];
-        ch->current = ch->mh->next(ch->current, rnd[b], &ch->logger);
-        ch->current_p = ch->mh->cached_current_p;
-      }
-    }
-    for (int b = 0; b < B; ++b) chains[b]->logger.out = nullptr;
   });
+  for (auto& g : groups) g.abandon();
+  if (chains)
+    for (int b = 0; b < n_chains; ++b)
+      if (chains[b]) chains[b]->logger.out = nullptr;
+  return rc;
 }
 
 int icp_host_chain_state(icp_host_chain* ch, double* theta_out, double* logp_out, int64_t* steps_done, int64_t* accepted) {

@@ -39,7 +39,9 @@ ICP_API int icp_host_chain_run(icp_host_chain *chain, int32_t n_steps, double *r
 /* n_steps more steps of n_chains chains in lockstep: per step ONE icp_chain_step_batched submission for all chains
  * whose proposal is an ICP or a random-walk shape proposal (the others step on their own), then every chain's
  * MetropolisHastings.next with those results.  Chain by chain the records are those of icp_host_chain_run.  Every chain
- * needs its own context and fused = 2.  records[b] may be NULL. */
+ * needs its own context and fused = 2.  records[b] may be NULL.  From 8 chains on they form two groups (from 24:
+ * three) a fraction of a step apart (ICP_LOCKSTEP_GROUPS = 1..4 overrides), so that one group's decompositions run beside
+ * the other's launches. */
 ICP_API int icp_host_chains_run_batched(icp_host_chain *const *chains, int32_t n_chains, int32_t n_steps,
                                         double *const *records);
 ICP_API int icp_host_chain_state(icp_host_chain *chain, double *theta_out, double *logp_out, int64_t *steps_done,

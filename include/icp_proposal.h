@@ -267,6 +267,22 @@ ICP_API int icp_chain_step_batched(int32_t n_chains, icp_evaluator *const *evalu
                                    const double *const *z, double *const *theta_prop, double *log_value_prop, double *fwd,
                                    double *bwd, int32_t *status);
 
+/* The same in two halves, for a caller that keeps two batches in flight (the decompositions of one run beside the
+ * launches of the other; the C++ harness does): _issue returns when the batch's work is on the device, _collect waits for
+ * it and writes the outputs named at _issue.  Everything passed to _issue by pointer (states, z, outputs) must stay valid
+ * until _collect; the pointer ARRAYS themselves are copied.  Both calls of a ticket come from one thread; a ticket is
+ * consumed by _collect, and the contexts of its chains accept no other call in between.  launch_ctx (may be NULL: the
+ * first chain's context) names the context whose stream carries the launches: two batches given the SAME launch_ctx run
+ * their launches one behind the other while the decompositions of the second run beside the launches of the first — at
+ * most four tickets per launch_ctx at a time, collected in the order they were issued. */
+typedef struct icp_step_ticket icp_step_ticket;
+ICP_API int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator *const *evaluators, int32_t n_props,
+                                         icp_proposal *const *props, const int32_t *generator,
+                                         const double *const *theta_cur, const double *const *z, double *const *theta_prop,
+                                         double *log_value_prop, double *fwd, double *bwd, int32_t *status,
+                                         icp_ctx *launch_ctx, icp_step_ticket **ticket);
+ICP_API int icp_chain_step_batched_collect(icp_step_ticket *ticket);
+
 /* ---------------------------------------------------------------- instrumentation (bench.py's roofline leg)
  * Between start and stop every kernel the context launches is bracketed by HIP events on the context stream;
  * stop returns one row per kernel name.  Off by default (adds nothing to the launch path). */
