@@ -88,6 +88,10 @@ SIGNATURES = {
     "icp_mesh_metrics": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "icp_chain_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, c_double_p, c_double_p, c_double_p,
                                  c_double_p, c_double_p, c_double_p]),
+    "icp_chain_step_batched_issue": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                               C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p), c_double_p,
+                                               c_double_p, c_double_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "icp_chain_step_batched_collect": (C.c_int, [C.c_void_p]),
     "icp_chain_step_batched": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                          C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p), c_double_p, c_double_p,
                                          c_double_p, C.POINTER(C.c_int32)]),
