@@ -452,14 +452,14 @@ HostTiming g_host_timing;
 struct BatchTiming {  // ICP_HOST_TIMING: where a batched step's host time goes (reported with the above)
   bool on = std::getenv("ICP_HOST_TIMING") != nullptr;
   double acc[4] = {0, 0, 0, 0};
-  long calls = 0, chains = 0;
+  long calls = 0, chains = 0, stepped_alone = 0;
   std::chrono::steady_clock::time_point last;
   void start() { if (on) last = std::chrono::steady_clock::now(); }
   void mark(int k) { if (on) { auto t = std::chrono::steady_clock::now(); acc[k] += HostTiming::us(last, t); last = t; } }
   void report() {
     if (!on || !calls) return;
-    std::fprintf(stderr, "[icp batch timing] calls %ld, %.1f chains each | us/call: prepare %.1f  launch %.1f  wait for first chain %.1f  record %.1f\n",
-                 calls, (double)chains / calls, acc[0] / calls, acc[1] / calls, acc[2] / calls, acc[3] / calls);
+    std::fprintf(stderr, "[icp batch timing] calls %ld, %.1f chains each (%ld chain steps taken one by one) | us/call: prepare %.1f  launch %.1f  wait for first chain %.1f  record %.1f\n",
+                 calls, (double)chains / calls, stepped_alone, acc[0] / calls, acc[1] / calls, acc[2] / calls, acc[3] / calls);
     calls = 0;
   }
 };
@@ -2636,6 +2636,7 @@ int icp_chain_step_batched_collect(icp_step_ticket* tk) {
   for (int b = 0; b < n_chains; ++b) {
     Item& it = items[b];
     if (it.batched && !it.redo) continue;
+    if (g_batch_timing.on) ++g_batch_timing.stepped_alone;
     const int st = icp_chain_step(it.e, n_props, it.props, it.generator, theta_cur[b], it.generator >= 0 ? z[b] : nullptr, theta_prop[b],
                                   log_value_prop + b, fwd + (size_t)b * n_props, bwd + (size_t)b * n_props);
     status[b] = st;
