@@ -155,11 +155,14 @@ def main():
         "cpu_baseline": None,
     }
 
-    if rank == 0 and world == 1 and B == 1:
+    if rank == 0 and world == 1:
         # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on (the library's stream)
         if args.profile_steps > 0:
-            ctx.profile_start(max_launches=64 * args.profile_steps + 1024)
-            chain.run(args.profile_steps, want_records=False)
+            ctx.profile_start(max_launches=64 * args.profile_steps + 1024)   # (a batch's launches go out on the first chain's context)
+            if B == 1:
+                chain.run(args.profile_steps, want_records=False)
+            else:
+                pkg.run_chains_batched(chains, args.profile_steps, want_records=False)
             stats = ctx.profile_stop()
             if DOMINANT in stats:
                 k = stats[DOMINANT]
@@ -168,22 +171,27 @@ def main():
                 alg_bytes = 3 * target.n_points * 8 + 3 * target.n_cells * 4 + n_queries * 24
                 if DOMINANT == "k_step_filter":  # the merged launch also holds the TargetSampling search: model vertices + its queries
                     alg_bytes += 3 * model.n_points * 8 + 2 * r * 24
+                chains_per_launch = 1.0
+                if B > 1:  # one launch holds the searches of a group of chains: units per launch = chain steps / launches
+                    chains_per_launch = B * args.profile_steps / max(k["calls"], 1)
+                    alg_bytes = int(alg_bytes * chains_per_launch)
                 avg_s = k["avg_us"] * 1e-6
                 achieved = alg_bytes / avg_s / 1e9
                 traffic = None
                 tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-                if os.path.exists(tfile):
+                if os.path.exists(tfile) and B == 1:
                     traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
                 line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": DOMINANT,
                                     "avg_launch_us": k["avg_us"], "launches": k["calls"], "algorithmic_bytes": alg_bytes,
+                                    "chains_per_launch": chains_per_launch,
                                     "note": "brute-force search is VALU-bound by construction (SURVEY.md §8d); HBM fraction reported as north_star asks"}
                 line["kernel_us_per_step"] = {name: round(s["total_ms"] * 1e3 / args.profile_steps, 2) for name, s in stats.items()}
                 line["kernel_us_per_step_note"] = ("HIP events around each launch (these add ~3 us per launch); a step's launches alternate between two "
                                                    "streams and overlap the previous step's finish launch; k_step_begin includes the time it waits ON THE "
                                                    "DEVICE for that launch to start or for the eigen-decomposition it draws from (k_posterior_eigen, side stream)")
         # ---- CPU baseline: the oracle's chain (same math, brute force, 1 thread) on a bounded sample
-        if args.cpu_steps > 0:
+        if args.cpu_steps > 0 and B == 1:
             from oracle import oracle as O
             om, ot = O.OracleModel.from_model(model), O.OracleMesh(target.points, target.cells)
             icp = [O.proposal_params(p["step"], p["sigma_t"], p["sigma_n"], p["direction"], p.get("boundary_aware", True),

@@ -1204,6 +1204,8 @@ int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity,
     HIP_OK(hipStreamSynchronize(ctx->stream));
     HIP_OK(hipStreamSynchronize(ctx->front_stream));
     sync_eigen(*ctx);
+    for (hipStream_t bs : ctx->batch_eig)
+      if (bs) HIP_OK(hipStreamSynchronize(bs));  // (decompositions of batches this context carried)
     ctx->profiling = false;
     std::vector<icp_kernel_stat> acc(KID_COUNT);
     for (int i = 0; i < KID_COUNT; ++i) {
