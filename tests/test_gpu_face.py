@@ -154,3 +154,16 @@ def test_batch_registration_lockstep_femur(pkg, femur50):
     items4, recs4 = pkg.sharding.run_batch(pkg, model, [target], n_chains=5, n_steps=25, make_setup=setup, chains_per_launch=4)
     assert items4 == items and all(np.array_equal(a, b) for a, b in zip(recs, recs4))
     assert sum(r[:, 1].sum() for r in recs) > 10
+
+
+def test_batch_registration_lockstep_mixed_targets(pkg, femur50):
+    """Chains of one submission may face targets of different sizes (their launches differ in grid size: the batch takes the
+    largest and the smaller chains leave their surplus workgroups idle)."""
+    model, target = femur50
+    _, finer = pkg.data.synthetic_femur_target(n_subdiv=2)
+    assert finer.n_points > 3 * target.n_points
+    setup = lambda m, t: pkg.femur_icp_proposal_registration(m, t, fused=2)
+    items, recs = pkg.sharding.run_batch(pkg, model, [target, finer], n_chains=3, n_steps=20, make_setup=setup)
+    items6, recs6 = pkg.sharding.run_batch(pkg, model, [target, finer], n_chains=3, n_steps=20, make_setup=setup, chains_per_launch=6)
+    assert items6 == items and all(np.array_equal(a, b) for a, b in zip(recs, recs6))
+    assert sum(r[:, 1].sum() for r in recs) > 10
