@@ -300,3 +300,31 @@ def test_batched_chains_rank_101(pkg):
         assert np.array_equal(got[b], single[b]), f"chain {b} differs"
     assert sum(s[:, 1].sum() for s in single) > 3
     [c.close() for c in chains]; [c.close() for c in ctxs]
+
+
+def test_batched_chains_with_pose_proposals_and_one_icp_direction(pkg, femur50):
+    """A mixture with pose proposals (those steps leave the submission and step on their own), ONE ICP direction and the
+    collective evaluator, model-to-target, on the closed target: the merged launches cover it with one posterior per chain."""
+    model, target = femur50
+    n_steps, B = 40, 5
+    def setup():
+        s = pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2)
+        s.eval["mode"] = 0   # ModelToTargetEvaluation: the configuration the merged launches cover
+        return s
+    inits = [pkg.random_initial_parameters(model, chain_index=i) for i in range(B)]
+
+    def make():
+        ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
+        return ctxs, [pkg.SamplingRegistration(ctxs[i], setup(), inits[i], seed=77 + i) for i in range(B)]
+
+    ctxs, chains = make()
+    single = [c.run(n_steps) for c in chains]
+    [c.close() for c in chains]; [c.close() for c in ctxs]
+    ctxs, chains = make()
+    got = pkg.run_chains_batched(chains, n_steps)
+    leaves = set()
+    for b in range(B):
+        assert np.array_equal(got[b], single[b]), f"chain {b} differs"
+        leaves |= set(single[b][:, 2].astype(int))
+    assert leaves & {3, 4, 5, 6, 7, 8} and 0 in leaves and 2 in leaves   # pose walks, the ICP proposal, the shape walk
+    [c.close() for c in chains]; [c.close() for c in ctxs]
