@@ -185,7 +185,8 @@ def main():
                                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": DOMINANT,
                                     "avg_launch_us": k["avg_us"], "launches": k["calls"], "algorithmic_bytes": alg_bytes,
                                     "chains_per_launch": chains_per_launch,
-                                    "note": "brute-force search is VALU-bound by construction (SURVEY.md §8d); HBM fraction reported as north_star asks"}
+                                    "note": "one chain per launch: the filter is a chain of latencies (spheres + queries in, patch test, sphere tests, hits out), "
+                                            "not a stream; HBM fraction reported as north_star asks (more chains per launch: --chains-per-gpu)"}
                 line["kernel_us_per_step"] = {name: round(s["total_ms"] * 1e3 / args.profile_steps, 2) for name, s in stats.items()}
                 line["kernel_us_per_step_note"] = ("HIP events around each launch (these add ~3 us per launch); a step's launches alternate between two "
                                                    "streams and overlap the previous step's finish launch; k_step_begin includes the time it waits ON THE "

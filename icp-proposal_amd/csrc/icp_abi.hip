@@ -177,7 +177,8 @@ struct DeviceMesh {
   int V = 0, T = 0, n_boundary = 0;
   DBuf<double> verts;
   DBuf<int> tris;
-  DBuf<float4> spheres;
+  DBuf<int> tri_order;       // position in the sphere list -> triangle (coherent_triangle_order)
+  DBuf<float4> spheres;      // sphere_floats4(T): spheres in that order, then the triangle ids
   DBuf<uint8_t> boundary;
 };
 
@@ -236,6 +237,7 @@ struct icp_ctx {
   int N = 0, T = 0, r = 0;
   DBuf<double> ref, mean, Q, Qp, sqrt_lambda, inv_sqrt_lambda, G, Ginv, P;  // P = (G + σ²I)⁻¹
   DBuf<int> tris, adj_off, adj;
+  DBuf<int> tri_order;  // sphere-list order of the model's triangles (from the reference shape; patches stay patches under the model's deformations)
   DBuf<uint8_t> boundary;
   int n_boundary = 0;
   DeviceMesh target;
@@ -365,7 +367,7 @@ StateSlot& icp_ctx::fresh_state() {
   if (!s.x.p) {
     s.coeffs.alloc(r);
     s.x.alloc(3 * (size_t)N);
-    s.spheres.alloc(T);
+    s.spheres.alloc(sphere_floats4(T));
     s.surf_cp.alloc(3 * (size_t)N);
     s.surf_d2.alloc(N);
     s.surf_tri.alloc(N);
@@ -397,7 +399,7 @@ StateSlot& icp_ctx::state(const double* theta) {
 
 void icp_ctx::ensure_model_spheres(StateSlot& s) {
   if (s.spheres_valid) return;
-  launch_tri_spheres(stream, T, s.x.p, tris.p, s.spheres.p);
+  launch_tri_spheres(stream, T, s.x.p, tris.p, tri_order.p, s.spheres.p);
   s.spheres_valid = true;
 }
 
@@ -1080,6 +1082,10 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->Ginv.upload(Ginv.data(), Ginv.size());
     ctx->P.upload(Pinv.data(), Pinv.size());
     ctx->tris.upload(model->triangles, (size_t)3 * T);
+    {
+      const std::vector<int> order = coherent_triangle_order(N, T, model->ref_points, model->triangles);
+      ctx->tri_order.upload(order.data(), order.size());
+    }
     ctx->adj_off.upload(off.data(), off.size());
     ctx->adj.upload(adj.data(), adj.size());
     ctx->boundary.upload(mb.data(), mb.size());
@@ -1093,8 +1099,12 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     tg.verts.upload(target->points, (size_t)3 * tg.V);
     tg.tris.upload(target->triangles, (size_t)3 * tg.T);
     tg.boundary.upload(tb.data(), tb.size());
-    tg.spheres.alloc(tg.T);
-    launch_tri_spheres(ctx->stream, tg.T, tg.verts.p, tg.tris.p, tg.spheres.p);
+    tg.spheres.alloc(sphere_floats4(tg.T));
+    {
+      const std::vector<int> order = coherent_triangle_order(tg.V, tg.T, target->points, target->triangles);
+      tg.tri_order.upload(order.data(), order.size());
+    }
+    launch_tri_spheres(ctx->stream, tg.T, tg.verts.p, tg.tris.p, tg.tri_order.p, tg.spheres.p);
 
     ctx->hint_surf.alloc(N); ctx->hint_surf.fill_bytes(0xFF);
     ctx->hint_nnv.alloc(N); ctx->hint_nnv.fill_bytes(0xFF);

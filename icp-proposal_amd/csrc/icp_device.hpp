@@ -95,6 +95,10 @@ __device__ __forceinline__ d3 vertex_normal(const double* __restrict__ x, const 
 __device__ __forceinline__ unsigned long long d2bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 __device__ __forceinline__ double bits2d(unsigned long long b) { return __longlong_as_double((long long)b); }
 
+// the triangle ids behind a sphere list of T entries (they follow the spheres in the same buffer: launch_tri_spheres)
+__host__ __device__ __forceinline__ int* sphere_triangles(float4* spheres, int T) { return (int*)(spheres + T); }
+__host__ __device__ __forceinline__ const int* sphere_triangles(const float4* spheres, int T) { return (const int*)(spheres + T); }
+
 constexpr unsigned long long kInfBits = 0x7FF0000000000000ull;
 constexpr int kNoIndex = 0x7FFFFFFF;
 

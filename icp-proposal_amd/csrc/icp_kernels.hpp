@@ -46,7 +46,11 @@ void launch_vertex_normals(hipStream_t st, int N, const double* x, const int* tr
                            const int* adj, double* normals);
 
 // f32 bounding sphere (centroid, conservatively inflated max corner distance) of every triangle: spheres[t] = {cx,cy,cz,R}
-void launch_tri_spheres(hipStream_t st, int T, const double* verts, const int* tris, float4* spheres);
+// `spheres` holds sphere_floats4(T) float4: the T spheres, then the T triangle ids they belong to (position -> triangle)
+void launch_tri_spheres(hipStream_t st, int T, const double* verts, const int* tris, const int* order /* device, or nullptr */,
+                        float4* spheres);
+inline size_t sphere_floats4(int T) { return (size_t)(T > 0 ? T : 0) + ((size_t)(T > 0 ? T : 0) + 3) / 4 + 1; }
+std::vector<int> coherent_triangle_order(int V, int T, const double* verts /* host */, const int* tris /* host */);
 
 // One brute-force query batch against a triangle mesh or a vertex set.  `hint` carries the previous winner of
 // each query (any valid index gives a valid upper bound; kNoIndex/-1 = none) and receives the new winner.

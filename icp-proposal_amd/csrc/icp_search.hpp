@@ -40,7 +40,7 @@ __device__ __forceinline__ void park_hits(ParkedHits& ph, int k, unsigned long l
   if (lane_id() == ph.n) { ph.k = k; ph.m0 = m0; ph.m1 = m1; }
   ++ph.n;
 }
-// element behind bit b of mask w (w = 0, 1): first + b·step + w
+// element behind bit b of mask w (w = 0, 1): position first + b·step + w of the streamed list
 __device__ __forceinline__ void settle_hits(ParkedHits& ph, int* __restrict__ cnt, int* __restrict__ cand, size_t stride, int first, int step) {
   if (lane_id() < ph.n) {
     const int n0 = __popcll(ph.m0), n1 = __popcll(ph.m1);
@@ -114,11 +114,22 @@ __device__ __forceinline__ void surface_init(const SurfaceTask& q, int k) {
 constexpr int kSpheresPerLane = 2;
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
-constexpr int kFilterTile = 128;  // queries staged in LDS at a time
+constexpr int kFilterTile = 128;   // queries staged in LDS at a time (vertex filter)
+constexpr int kSurfaceTile = 512;  // … surface filter: a whole chunk (split_surface_queries), so that a workgroup's query
+                                   // records arrive in one go beside its spheres — the kernel is a chain of latencies, not of arithmetic
 
+// Two levels.  A wave holds 128 CONSECUTIVE triangles, i.e. a patch of the surface (mesh files list neighbouring triangles
+// together; a synthetic subdivision lists the children of a triangle together): their spheres fit a ball of a few mm
+// — centre C = mean of the centres, radius Rw = max(|c_i − C| + R_i), taken once per wave by shuffles — and a query can
+// only have a candidate in the wave if |q − C| <= bound + Rw (triangle inequality; Rw carries slack for the f32
+// rounding of both tests, so whatever passes the sphere test below passes this one).  That test is made for 64 queries
+// at a time, one per lane; the sphere test — every lane its two spheres against ONE query — runs only for the queries
+// that survive: 2 % of the (wave, query) pairs on the 58k-vertex target.  Every pair is still decided, the set of
+// candidates is the one the plain double loop gives; a wave whose triangles are scattered over the surface just keeps
+// (almost) all queries.
 __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int by) {
-  __shared__ float4 s_q[kFilterTile];
-  __shared__ float s_thr[kFilterTile];
+  __shared__ float4 s_q[kSurfaceTile];
+  __shared__ float s_thr[kSurfaceTile];
   const int t0 = (bx * kSearchBlock + threadIdx.x) * kSpheresPerLane;
   const bool v0 = t0 < q.T, v1 = t0 + 1 < q.T;
   // out-of-range lanes: centre NaN — their squared distance is NaN and passes no threshold, not even an infinite one
@@ -126,34 +137,55 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
   f2_t cx = {__builtin_nanf(""), __builtin_nanf("")}, cy = cx, cz = cx, R = {0.f, 0.f};
   if (v0) { const float4 s = q.spheres[t0]; cx.x = s.x; cy.x = s.y; cz.x = s.z; R.x = s.w; }
   if (v1) { const float4 s = q.spheres[t0 + 1]; cx.y = s.x; cy.y = s.y; cz.y = s.z; R.y = s.w; }
+  // ---- the wave's ball
+  float sx = (v0 ? cx.x : 0.f) + (v1 ? cx.y : 0.f), sy = (v0 ? cy.x : 0.f) + (v1 ? cy.y : 0.f), sz = (v0 ? cz.x : 0.f) + (v1 ? cz.y : 0.f);
+  float sn = (v0 ? 1.f : 0.f) + (v1 ? 1.f : 0.f);
+  for (int o = 32; o > 0; o >>= 1) {
+    sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); sz += __shfl_xor(sz, o, 64); sn += __shfl_xor(sn, o, 64);
+  }
+  const bool wave_live = sn > 0.f;  // (uniform; a wave past the end of the list has nothing to offer)
+  const float inv_n = wave_live ? 1.f / sn : 0.f;
+  const float Cx = sx * inv_n, Cy = sy * inv_n, Cz = sz * inv_n;
+  float rad = 0.f;
+  if (v0) { const float dx = cx.x - Cx, dy = cy.x - Cy, dz = cz.x - Cz; rad = fmaxf(rad, sqrtf(dx * dx + dy * dy + dz * dz) + R.x); }
+  if (v1) { const float dx = cx.y - Cx, dy = cy.y - Cy, dz = cz.y - Cz; rad = fmaxf(rad, sqrtf(dx * dx + dy * dy + dz * dz) + R.y); }
+  for (int o = 32; o > 0; o >>= 1) rad = fmaxf(rad, __shfl_xor(rad, o, 64));
+  // slack: a few hundred ulps of the largest magnitudes involved (the tests' own rounding errors are a few ulps)
+  const float Rw = rad * 1.00002f + 2e-5f * (fabsf(Cx) + fabsf(Cy) + fabsf(Cz) + rad);
   const int k0 = by * q.kchunk;
   const int k1 = min(q.Kpad, k0 + q.kchunk);
   ParkedHits ph;
-  const int first = (bx * kSearchBlock + (threadIdx.x & ~63)) * kSpheresPerLane;  // triangle of lane 0's first sphere
-  for (int kt = k0; kt < k1; kt += kFilterTile) {
-    // this workgroup's queries go through LDS: one coalesced read per tile, then every lane reads the same record
-    // (broadcast, conflict free) — the loop below never waits for global memory
-    const int nq = min(kFilterTile, k1 - kt);  // multiple of kQU
+  const int first = (bx * kSearchBlock + (threadIdx.x & ~63)) * kSpheresPerLane;  // list position of lane 0's first sphere
+                                                                                  // (candidates are named by position: see surface_resolve)
+  const int lane = threadIdx.x & 63;
+  for (int kt = k0; kt < k1; kt += kSurfaceTile) {
+    // this workgroup's queries go through LDS: one coalesced read per tile; the loops below never wait for global memory
+    const int nq = min(kSurfaceTile, k1 - kt);
     if (kt != k0) __syncthreads();
-    if ((int)threadIdx.x < nq) { s_q[threadIdx.x] = q.qrec[kt + threadIdx.x]; s_thr[threadIdx.x] = q.thrA[kt + threadIdx.x]; }
+    for (int i = threadIdx.x; i < nq; i += kSearchBlock) { s_q[i] = q.qrec[kt + i]; s_thr[i] = q.thrA[kt + i]; }
     __syncthreads();
-    for (int k = 0; k < nq; k += kQU) {
-      unsigned long long m0[kQU], m1[kQU];
-#pragma unroll
-      for (int u = 0; u < kQU; ++u) {
-        const float4 qq = s_q[k + u];
-        const float th = s_thr[k + u];
+    if (!wave_live) continue;
+    for (int g = 0; g < nq; g += 64) {
+      bool near = false;
+      if (g + lane < nq) {  // lane l: query g + l against the wave's ball
+        const float4 qq = s_q[g + lane];
+        const float dx = qq.x - Cx, dy = qq.y - Cy, dz = qq.z - Cz;
+        const float lim = s_thr[g + lane] + Rw + 2e-5f * (fabsf(qq.x) + fabsf(qq.y) + fabsf(qq.z));
+        near = dx * dx + dy * dy + dz * dz <= lim * lim;  // (sentinel slots sit at 1e30 with bound 0: never; bound +inf: always)
+      }
+      unsigned long long todo = __ballot(near);
+      while (todo) {  // wave-uniform: the surviving queries, each against the lanes' spheres
+        const int j = g + __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const float4 qq = s_q[j];
+        const float th = s_thr[j];
         const f2_t tt = f2_t{th, th} + R;
         const f2_t dx = f2_t{qq.x, qq.x} - cx, dy = f2_t{qq.y, qq.y} - cy, dz = f2_t{qq.z, qq.z} - cz;
         const f2_t dc2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
         const f2_t t2 = tt * tt;
-        m0[u] = __ballot(dc2.x <= t2.x);
-        m1[u] = __ballot(dc2.y <= t2.y);
-      }
-#pragma unroll
-      for (int u = 0; u < kQU; ++u) {
-        if ((m0[u] | m1[u]) != 0ull) {  // uniform branch, rarely taken
-          park_hits(ph, kt + k + u, m0[u], m1[u]);
+        const unsigned long long m0 = __ballot(dc2.x <= t2.x), m1 = __ballot(dc2.y <= t2.y);
+        if ((m0 | m1) != 0ull) {
+          park_hits(ph, kt + j, m0, m1);
           if (ph.n == 64) settle_hits(ph, q.cnt, q.cand, q.stride, first, kSpheresPerLane);
         }
       }
@@ -171,8 +203,9 @@ __device__ __forceinline__ void surface_resolve(const SurfaceTask& q, int k, dou
   double best = __builtin_inf();
   int bi = kNoIndex;
   d3 bc = {__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};  // closest point of this lane's best candidate
+  const int* tri_of = sphere_triangles(q.spheres, q.T);  // the filter names its candidates by their position in the sphere list
   for (int i = lane_id(); i < n; i += 64) {
-    const int t = list[i];
+    const int t = tri_of[list[i]];
     d3 c;
     const double d2 = tri_dist2(p, q.verts, q.tris, t, &c);
     if (d2 < best || (d2 == best && t < bi)) { best = d2; bi = t; bc = c; }  // NaN (degenerate triangle) never wins

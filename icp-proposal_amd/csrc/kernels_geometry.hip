@@ -16,6 +16,7 @@
 // true minimiser always survives the filter and the reduction is order independent.
 #include <cstdlib>
 
+#include <algorithm>
 #include "icp_kernels.hpp"
 #include "icp_search.hpp"
 
@@ -61,10 +62,15 @@ __global__ void __launch_bounds__(kBlock) k_vertex_normals(int N, const double* 
   normals[3 * v] = n.x; normals[3 * v + 1] = n.y; normals[3 * v + 2] = n.z;
 }
 
+// position pos of the list holds triangle order[pos] (nullptr: the identity); the triangle ids follow the T spheres in the
+// same buffer (sphere_triangles), for the filter to name its candidates
 __global__ void __launch_bounds__(kBlock) k_tri_spheres(int T, const double* __restrict__ verts, const int* __restrict__ tris,
-                                                         float4* __restrict__ spheres) {
-  int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t < T) spheres[t] = tri_sphere(verts, tris, t);
+                                                         const int* __restrict__ order, float4* __restrict__ spheres) {
+  const int pos = blockIdx.x * kBlock + threadIdx.x;
+  if (pos >= T) return;
+  const int t = order ? order[pos] : pos;
+  spheres[pos] = tri_sphere(verts, tris, t);
+  sphere_triangles(spheres, T)[pos] = t;
 }
 
 __global__ void __launch_bounds__(kBlock) k_surface_init(SurfaceTask q) { surface_init(q, blockIdx.x * kBlock + threadIdx.x); }
@@ -97,6 +103,19 @@ void split_queries(int n_elem_blocks, int Kpad, int* ksplit, int* kchunk) {
   *ksplit = cdiv(Kpad, kc);
 }
 
+// Surface filter: its two-level test makes the arithmetic per query negligible, what is left is a chain of latencies per
+// workgroup (spheres + queries in, ball, tests, hits out) whatever the number of queries it takes (tools/ab_chunk.sh: 64
+// to 512 queries per workgroup measure the same for one chain) — so few workgroups: a batch of chains launches B times as
+// many.  256 queries per workgroup: two workgroups per block of spheres for the 308 queries of the femur step.
+void split_surface_queries(int Kpad, int* ksplit, int* kchunk) {
+  static const int tile = std::getenv("ICP_SURFACE_CHUNK") ? std::atoi(std::getenv("ICP_SURFACE_CHUNK")) : 256;  // (A/B: <= 512)
+  int kc = Kpad < tile ? Kpad : tile;
+  kc = (kc + kQU - 1) / kQU * kQU;
+  if (kc < kQU) kc = kQU;
+  *kchunk = kc;
+  *ksplit = cdiv(Kpad, kc);
+}
+
 // queries are processed in batches small enough that every query can list ALL elements as candidates
 int query_batch(int K, int n_elems, size_t cand_capacity) {
   size_t kb = cand_capacity / (size_t)(n_elems > 0 ? n_elems : 1);
@@ -114,7 +133,7 @@ SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const
   q.qrec = qb.qrec; q.thrA = qb.thrA; q.cnt = qb.cnt; q.cand = qb.cand;
   q.cp = cp; q.d2 = d2; q.tri = tri;
   q.tblocks = cdiv(T > 0 ? T : 1, kBlock * kSpheresPerLane);
-  split_queries(q.tblocks, q.Kpad, &q.ksplit, &q.kchunk);
+  split_surface_queries(q.Kpad, &q.ksplit, &q.kchunk);
   return q;
 }
 
@@ -138,10 +157,57 @@ void launch_vertex_normals(hipStream_t st, int N, const double* x, const int* tr
   hipLaunchKernelGGL(k_vertex_normals, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, st, N, x, tris, adj_off, adj, normals);
 }
 
-void launch_tri_spheres(hipStream_t st, int T, const double* verts, const int* tris, float4* spheres) {
+void launch_tri_spheres(hipStream_t st, int T, const double* verts, const int* tris, const int* order, float4* spheres) {
   if (T <= 0) return;
   ProfScope _ps(st, KID_TRI_SPHERES);
-  hipLaunchKernelGGL(k_tri_spheres, dim3(cdiv(T, kBlock)), dim3(kBlock), 0, st, T, verts, tris, spheres);
+  hipLaunchKernelGGL(k_tri_spheres, dim3(cdiv(T, kBlock)), dim3(kBlock), 0, st, T, verts, tris, order, spheres);
+}
+
+// Order of the triangles in the sphere list: a k-d split of the centroids (longest box axis, cut at a multiple of 128
+// positions) down to runs of 128 — the 128 spheres a wave of the surface filter holds then always form ONE compact patch.
+// In file order most runs are patches, too, but the few that are not (a run that ends one strip of the surface and begins
+// another) keep every query in the filter's second level and set the duration of the whole launch.
+namespace {
+void kd_runs(int* idx, int lo, int hi, const float* c) {
+  const int n = hi - lo;
+  if (n <= 128) return;
+  float mn[3] = {c[3 * idx[lo]], c[3 * idx[lo] + 1], c[3 * idx[lo] + 2]}, mx[3] = {mn[0], mn[1], mn[2]};
+  for (int i = lo + 1; i < hi; ++i)
+    for (int d = 0; d < 3; ++d) {
+      const float v = c[3 * idx[i] + d];
+      mn[d] = v < mn[d] ? v : mn[d];
+      mx[d] = v > mx[d] ? v : mx[d];
+    }
+  int ax = 0;
+  for (int d = 1; d < 3; ++d)
+    if (mx[d] - mn[d] > mx[ax] - mn[ax]) ax = d;
+  int half = (n / 2 + 64) / 128 * 128;
+  if (half < 128) half = 128;
+  if (half >= n) half = (n - 1) / 128 * 128;
+  std::nth_element(idx + lo, idx + lo + half, idx + hi, [&](int a, int b) {
+    const float va = c[3 * a + ax], vb = c[3 * b + ax];
+    return va < vb || (va == vb && a < b);
+  });
+  kd_runs(idx, lo, lo + half, c);
+  kd_runs(idx, lo + half, hi, c);
+}
+}  // namespace
+std::vector<int> coherent_triangle_order(int V, int T, const double* verts, const int* tris) {
+  std::vector<int> idx(T > 0 ? T : 0);
+  std::vector<float> c((size_t)3 * (T > 0 ? T : 0));
+  for (int t = 0; t < T; ++t) {
+    idx[t] = t;
+    for (int d = 0; d < 3; ++d) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        const int v = tris[3 * t + k];
+        s += (v >= 0 && v < V) ? verts[3 * (size_t)v + d] : 0.0;
+      }
+      c[3 * (size_t)t + d] = (float)(s / 3.0);
+    }
+  }
+  if (T > 128) kd_runs(idx.data(), 0, T, c.data());
+  return idx;
 }
 
 void launch_surface_query(hipStream_t st, int T, const double* verts, const int* tris, const float4* spheres,
