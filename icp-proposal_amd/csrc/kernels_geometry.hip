@@ -203,7 +203,8 @@ std::vector<int> coherent_triangle_order(int V, int T, const double* verts, cons
         const int v = tris[3 * t + k];
         s += (v >= 0 && v < V) ? verts[3 * (size_t)v + d] : 0.0;
       }
-      c[3 * (size_t)t + d] = (float)(s / 3.0);
+      const float m = (float)(s / 3.0);
+      c[3 * (size_t)t + d] = m == m && m - m == 0.f ? m : 0.f;  // (a non-finite vertex must not break the ordering's comparisons)
     }
   }
   if (T > 128) kd_runs(idx.data(), 0, T, c.data());
