@@ -137,9 +137,12 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
   f2_t cx = {__builtin_nanf(""), __builtin_nanf("")}, cy = cx, cz = cx, R = {0.f, 0.f};
   if (v0) { const float4 s = q.spheres[t0]; cx.x = s.x; cy.x = s.y; cz.x = s.z; R.x = s.w; }
   if (v1) { const float4 s = q.spheres[t0 + 1]; cx.y = s.x; cy.y = s.y; cz.y = s.z; R.y = s.w; }
-  // ---- the wave's ball
-  float sx = (v0 ? cx.x : 0.f) + (v1 ? cx.y : 0.f), sy = (v0 ? cy.x : 0.f) + (v1 ? cy.y : 0.f), sz = (v0 ? cz.x : 0.f) + (v1 ? cz.y : 0.f);
-  float sn = (v0 ? 1.f : 0.f) + (v1 ? 1.f : 0.f);
+  // ---- the wave's ball (a sphere that is not finite — a triangle with a non-finite corner — passes no test by itself
+  // and must not spoil the ball of its neighbours)
+  auto finite4 = [](float a, float b, float c, float d) { return fabsf(a) + fabsf(b) + fabsf(c) + fabsf(d) <= 3.0e38f; };
+  const bool b0 = v0 && finite4(cx.x, cy.x, cz.x, R.x), b1 = v1 && finite4(cx.y, cy.y, cz.y, R.y);
+  float sx = (b0 ? cx.x : 0.f) + (b1 ? cx.y : 0.f), sy = (b0 ? cy.x : 0.f) + (b1 ? cy.y : 0.f), sz = (b0 ? cz.x : 0.f) + (b1 ? cz.y : 0.f);
+  float sn = (b0 ? 1.f : 0.f) + (b1 ? 1.f : 0.f);
   for (int o = 32; o > 0; o >>= 1) {
     sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); sz += __shfl_xor(sz, o, 64); sn += __shfl_xor(sn, o, 64);
   }
@@ -147,8 +150,8 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
   const float inv_n = wave_live ? 1.f / sn : 0.f;
   const float Cx = sx * inv_n, Cy = sy * inv_n, Cz = sz * inv_n;
   float rad = 0.f;
-  if (v0) { const float dx = cx.x - Cx, dy = cy.x - Cy, dz = cz.x - Cz; rad = fmaxf(rad, sqrtf(dx * dx + dy * dy + dz * dz) + R.x); }
-  if (v1) { const float dx = cx.y - Cx, dy = cy.y - Cy, dz = cz.y - Cz; rad = fmaxf(rad, sqrtf(dx * dx + dy * dy + dz * dz) + R.y); }
+  if (b0) { const float dx = cx.x - Cx, dy = cy.x - Cy, dz = cz.x - Cz; rad = fmaxf(rad, sqrtf(dx * dx + dy * dy + dz * dz) + R.x); }
+  if (b1) { const float dx = cx.y - Cx, dy = cy.y - Cy, dz = cz.y - Cz; rad = fmaxf(rad, sqrtf(dx * dx + dy * dy + dz * dz) + R.y); }
   for (int o = 32; o > 0; o >>= 1) rad = fmaxf(rad, __shfl_xor(rad, o, 64));
   // slack: a few hundred ulps of the largest magnitudes involved (the tests' own rounding errors are a few ulps)
   const float Rw = rad * 1.00002f + 2e-5f * (fabsf(Cx) + fabsf(Cy) + fabsf(Cz) + rad);
