@@ -335,3 +335,35 @@ def test_prelaunched_half_step_never_changes_results(pkg, femur50):
             cur = np.asarray(out_a[0]).copy()
     for o in props_a + props_b + [ev_a, ev_b, ctx_a, ctx_b]:
         o.close()
+
+
+def test_hinted_searches_on_a_shuffled_distant_target(pkg, femur50, oracle):
+    """The triangle filter's patch test (two levels) under conditions that are hard on it: triangles listed in
+    random order (the sphere list is re-ordered inside the library: candidates must come back under their own ids), the
+    whole scene 5 m from the origin (f32 spacing there: 0.5 µm — the slack of the patch test has to cover it), and a
+    sequence of states so that the searches run with tight bounds from the previous winners.  Correspondence ids bit-exact,
+    likelihood to 1e-9."""
+    model, target = femur50
+    rng = np.random.default_rng(21)
+    shift = np.array([5000.0, -3000.0, 4000.0])
+    cells = target.cells[rng.permutation(target.n_cells)]
+    far = type(target)(target.points + shift, cells)
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(far.points, far.cells)
+    ctx = pkg.IcpContext(model, far, device=0)
+    r = model.rank
+    tp = pkg.data.decimated_point_subset(far, 2 * r)
+    prop = pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, pkg.ModelSampling, True, decimatedTargetPoints=tp)
+    pp = oracle.proposal_params(0.1, 10.0, 5.0, oracle.MODEL_SAMPLING, True, n_model_ids=2 * r)
+    ev = pkg.IndependentPointDistanceEvaluator(ctx, 0.0, 2.0, pkg.ModelToTargetEvaluation, 4 * r, decimatedTargetPoints=tp)
+    ep = oracle.evaluator_params(oracle.EVAL_INDEPENDENT, oracle.MODEL_TO_TARGET, n_model_ids=4 * r, target_pts=tp, p0=0.0, p1=2.0)
+    theta = make_theta(model, 3, shape_scale=0.3, pose=False)
+    theta[1:4] = shift
+    for step in range(5):
+        post = oracle.icp_posterior(om, ot, pp, theta)
+        got, corr = prop.propose(theta, rng.normal(size=r), return_correspondences=True)
+        assert np.array_equal(corr, np.where(post.keep == 1, post.corr_id, -1)), f"step {step}: correspondence ids differ"
+        lv, (lvo, _) = ev.logValue(theta), oracle.evaluator_log_value(om, ot, ep, theta)
+        assert abs(lv - lvo) <= 1e-9 * abs(lvo), (step, lv, lvo)
+        theta = theta.copy()
+        theta[10:] += 0.05 * rng.normal(size=r)   # a nearby state: the next searches start from this one's winners
+    prop.close(); ev.close(); ctx.close()
