@@ -2042,8 +2042,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   // 4: regressions + likelihood reduction
   StepRegressionArgs g{};
   g.n = n_props; g.r = r;
-  const int nt = (r + 1 + 15) / 16;
-  g.ntiles = nt * nt;
+  g.ntiles = regression_tiles(r);
   g.Q = c.Q.p;
   g.ustart[0] = 0;
   int* splits = F.splits;

@@ -104,11 +104,15 @@ __device__ __forceinline__ d4_t regression_mac(int k, const CorrBuffers& cb, con
   return __builtin_amdgcn_mfma_f64_16x16x4f64(A_op, B_op, acc, 0, 0, 0);
 }
 
-// tile = index into the nt×nt grid of 16×16 output tiles, split = which slice of the correspondence list; one wave
+// tile = index into the LOWER triangle (tile row ti >= tile column tj, row-major: regression_tiles(r) of them) of the grid of
+// 16×16 output tiles — the matrix is symmetric and every reader of the partial sums takes entries (i, k <= i) —
+// split = which slice of the correspondence list; one wave
 __device__ __forceinline__ void regression_tile(int tile, int split, int K, int kchunk, int r, const double* __restrict__ Q,
                                                 const CorrBuffers& cb, double wt, double kappa, double* __restrict__ Mpart) {
-  const int n = r + 1, nt = (n + 15) >> 4;
-  const int ti = tile / nt, tj = tile - ti * nt;
+  const int n = r + 1;
+  int ti = 0;
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
   const int l = threadIdx.x & 63, i16 = l & 15, kk = l >> 4;
   const int a = 16 * ti + i16, b = 16 * tj + i16;
   const int ca = a < r ? a : 0, cbi = b < r ? b : 0;

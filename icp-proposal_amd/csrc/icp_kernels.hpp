@@ -266,6 +266,9 @@ struct StepSearchArgs {  // launches 2 (filter) and 3 (resolve + correspondences
   CorrTask corr[2];
 };
 
+// 16×16 output tiles of the lower triangle of the (r+1)×(r+1) normal matrix (see regression_tile)
+__host__ __device__ inline int regression_tiles(int r) { const int nt = (r + 1 + 15) >> 4; return nt * (nt + 1) / 2; }
+
 struct StepRegressionArgs {  // launch 4: normal-equation partial sums of every posterior + the likelihood reduction
   int n, r, ntiles;          // posteriors; tiles per (r+1)x(r+1) matrix
   int ustart[3];             // first work unit (tile x split) of each posterior; ustart[n] = number of units

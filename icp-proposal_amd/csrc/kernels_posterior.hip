@@ -75,7 +75,8 @@ __global__ void __launch_bounds__(kFactorThreads) k_posterior_factor_generic(int
   for (int e = tid; e < n * r; e += nt) {
     const int i = e / r, j = e - i * r;   // i == r: the appended row bᵀ = Maug[r][0..r-1]
     double m = 0.0;
-    for (int s = 0; s < S; ++s) m += Mpart[(size_t)s * n * n + (size_t)i * n + j];
+    const int hi = i < r ? max(i, j) : r, lo = i < r ? min(i, j) : j;  // (only the lower triangle of the partials is computed)
+    for (int s = 0; s < S; ++s) m += Mpart[(size_t)s * n * n + (size_t)hi * n + lo];
     if (i < r) {
       m += i == j ? 1.0 : 0.0;
       M[e] = m;
@@ -1113,13 +1114,12 @@ int regression_splits(int K) {
 
 void launch_regression(hipStream_t st, int K, int r, const double* Q, const CorrBuffers& cb, double w_tangent,
                        double kappa, double* Mpart, int* splits_out) {
-  const int n = r + 1, nt = (n + 15) / 16;
   const int S = regression_splits(K);
   int kchunk = (K + S - 1) / S;
   if (kchunk < 1) kchunk = 1;
   *splits_out = S;
   { ProfScope _ps(st, KID_REGRESSION);
-    hipLaunchKernelGGL(k_regression_mfma, dim3(nt * nt, S), dim3(64), 0, st, K, kchunk, r, Q, cb, w_tangent, kappa, Mpart); }
+    hipLaunchKernelGGL(k_regression_mfma, dim3(regression_tiles(r), S), dim3(64), 0, st, K, kchunk, r, Q, cb, w_tangent, kappa, Mpart); }
 }
 
 static void set_dyn_lds(const void* fn, size_t bytes) {
