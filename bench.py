@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="independent chains per GPU, stepped in lockstep through icp_chain_step_batched (default 1 = the BASELINE.json "
                          "configuration; more is the RunMHRandomInitComparison-style many-chains job on fewer GPUs)")
+    ap.add_argument("--many-chains", type=int, default=32,
+                    help="extra leg after the timed region (1 GPU, 1 chain per GPU only): aggregate rate of this many chains on the GPU "
+                         "stepped through icp_chain_step_batched, reported as `many_chains` (0 = skip)")
     ap.add_argument("--fused", type=int, default=2, choices=[0, 1, 2],
                     help="host<->device call pattern per step: 0 per-method calls, 1 propose + icp_chain_eval_step, 2 one icp_chain_step")
     args = ap.parse_args()
@@ -215,12 +218,34 @@ def main():
                                               "posterior/likelihood of the current state carried over like the reference's Memoize); "
                                               "host has %d logical cores" % (args.cpu_steps, os.cpu_count()),
                                     "gpu_matches_oracle_on_sample": same}
-    if rank == 0:
-        print(json.dumps(line))
     for ch in chains:
         ch.close()
     for cx in ctxs:
         cx.close()
+    if rank == 0 and world == 1 and B == 1 and args.many_chains > 1:
+        # ---- not the headline: the same workload with many independent chains on the one GPU (SURVEY.md §8e "within a GPU,
+        # batch B chains per launch"; RunMHRandomInitComparison-style jobs), one context per chain, lockstep submissions
+        nB = args.many_chains
+        mctx = [pkg.IcpContext(model, target, device=local_rank) for _ in range(nB)]
+        mch = []
+        for i in range(nB):
+            th = theta0.copy()
+            if i > 0:
+                th[10:] = np.random.default_rng(1024 + i).normal(size=r) * np.sqrt(0.1)
+            mch.append(pkg.SamplingRegistration(mctx[i], setup, th, seed=1024 + i))
+        pkg.run_chains_batched(mch, 40, want_records=False)
+        n_m = 300
+        t1 = time.perf_counter()
+        pkg.run_chains_batched(mch, n_m, want_records=False)
+        mdt = time.perf_counter() - t1
+        line["many_chains"] = {"chains_per_gpu": nB, "value": nB * n_m / mdt, "unit": "iterations/s", "steps_per_chain": n_m,
+                               "entry_point": "icp_chain_step_batched"}
+        for ch in mch:
+            ch.close()
+        for cx in mctx:
+            cx.close()
+    if rank == 0:
+        print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 
