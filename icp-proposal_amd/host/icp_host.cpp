@@ -222,6 +222,7 @@ struct LockstepGroup {
   std::vector<double*> prop_p;
   std::vector<double> value, fwd, bwd;
   icp_step_ticket* ticket = nullptr;
+  ModelFittingParameters scratch_prop;
   icp_ctx* launch_ctx = nullptr;  // whose stream carries the group's launches (nullptr: the first member's)
 
   void init() {
@@ -276,13 +277,11 @@ struct LockstepGroup {
       if (st != ICP_OK) check(st, "icp_chain_step_batched_collect");
       for (size_t k = 0; k < member.size(); ++k) {
         icp_host_chain* ch = chains[member[k]];
-        ModelFittingParameters pr;
+        ModelFittingParameters& pr = scratch_prop;  // (keeps its storage from chain to chain)
         pr.allParameters = prop[member[k]];
         if (gen[k] >= 0) pr.generatedBy = ch->icp[gen[k]]->generatedBy;
         else pr.generatedBy = static_cast<RandomShapeUpdateProposal*>(ch->root->peek(rnd[member[k]], 0))->generatedBy;
-        const std::vector<double> f(fwd.begin() + k * n_icp, fwd.begin() + (k + 1) * n_icp);
-        const std::vector<double> w(bwd.begin() + k * n_icp, bwd.begin() + (k + 1) * n_icp);
-        ch->prefetcher.park(ch->current, pr, status[k], value[k], f, w);
+        ch->prefetcher.park(ch->current, pr, status[k], value[k], fwd.data() + k * n_icp, bwd.data() + k * n_icp);
         if (gen[k] >= 0) { ch->prefetcher.submitted_index = gen[k]; ch->prefetcher.submitted_z = z[member[k]]; }
       }
     }

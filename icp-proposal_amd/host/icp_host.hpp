@@ -178,6 +178,7 @@ struct NonRigidIcpProposal : ProposalGeneratorWithTransition {  // NonRigidIcpPr
     ModelFittingParameters from, to;
     double value = 0.0;
   } prefetched[2];
+  std::vector<double> z_scratch;  // the standard normals of the sample being drawn (one chain = one thread)
 };
 
 struct RandomShapeUpdateProposal : ProposalGeneratorWithTransition {  // RandomShapeUpdateProposal.scala:25-46
@@ -247,7 +248,10 @@ struct MixtureProposal : ProposalGeneratorWithTransition {
   double logTransitionProbability(const ModelFittingParameters& from, const ModelFittingParameters& to) override {
     double wsum = 0.0, mx = -std::numeric_limits<double>::infinity();
     for (double w : weights) wsum += w;
-    std::vector<double> t(generators.size());
+    double t_small[8];
+    std::vector<double> t_big;
+    if (generators.size() > 8) t_big.resize(generators.size());
+    double* t = generators.size() > 8 ? t_big.data() : t_small;
     for (size_t i = 0; i < generators.size(); ++i) {
       t[i] = generators[i]->logTransitionProbability(from, to);
       if (std::isnan(t[i])) throw std::runtime_error("NaN transition probability encountered!");
@@ -288,12 +292,18 @@ struct ChainPrefetcher {
 
   void park(const ModelFittingParameters& cur, const ModelFittingParameters& prop, int st, double value, const std::vector<double>& fwd,
             const std::vector<double>& bwd) {
+    park(cur, prop, st, value, fwd.data(), bwd.data());
+  }
+  // (field by field: the parked copies keep their storage from step to step)
+  void park(const ModelFittingParameters& cur, const ModelFittingParameters& prop, int st, double value, const double* fwd, const double* bwd) {
     evaluator->has_prefetch = st == ICP_OK;
     evaluator->prefetched_for = prop;
     evaluator->prefetched_value = value;
     for (size_t i = 0; i < icp.size(); ++i) {
-      icp[i]->prefetched[0] = {true, cur, prop, fwd[i]};
-      icp[i]->prefetched[1] = {true, prop, cur, bwd[i]};
+      NonRigidIcpProposal::Prefetched& f = icp[i]->prefetched[0];
+      f.valid = true; f.from = cur; f.to = prop; f.value = fwd[i];
+      NonRigidIcpProposal::Prefetched& b = icp[i]->prefetched[1];
+      b.valid = true; b.from = prop; b.to = cur; b.value = bwd[i];
     }
     have = true;
     parked_cur = cur;
@@ -341,7 +351,8 @@ struct ChainPrefetcher {
 
 inline ModelFittingParameters NonRigidIcpProposal::propose(const ModelFittingParameters& theta, const StepRandom& rnd, int) {
   const int r = theta.rank();
-  std::vector<double> z(r);
+  std::vector<double>& z = z_scratch;
+  z.resize(r);
   for (int j = 0; j < r; ++j) z[j] = rnd.normal(j);  // posterior.sample() (:55)
   if (stepper) return stepper->step(stepperIndex, theta, z.data());
   ModelFittingParameters out;
