@@ -82,6 +82,21 @@ def test_invalid_arguments_rejected_before_device(pkg, femur50):
     assert b"out of range" in lib.icp_last_error()
 
 
+def test_batched_step_rejects_bad_arguments_before_device(pkg):
+    """icp_chain_step_batched / _issue / _collect: null and empty argument lists are refused with ICP_ERR_INVALID_ARG and leave
+    no ticket behind (no device is touched: this runs without a GPU)."""
+    lib = pkg._native.lib()
+    assert lib.icp_chain_step_batched(0, None, 0, None, None, None, None, None, None, None, None, None) == -1
+    assert b"null argument" in lib.icp_last_error()
+    status = (ctypes.c_int32 * 1)()
+    assert lib.icp_chain_step_batched(1, None, 0, None, None, None, None, None, None, None, None, status) == -1
+    ticket = ctypes.c_void_p(1234)
+    assert lib.icp_chain_step_batched_issue(1, None, 0, None, None, None, None, None, None, None, None, status, None,
+                                            ctypes.byref(ticket)) == -1
+    assert ticket.value is None
+    assert lib.icp_chain_step_batched_collect(None) == -1
+
+
 def test_synthetic_target_sizes(pkg):
     """BASELINE.json configs[1]: 6-way subdivision of the femur target -> 58,322 vertices / 116,640 triangles."""
     _, big = pkg.data.synthetic_femur_target()
