@@ -467,7 +467,9 @@ __device__ __forceinline__ dbl2 lds2(const double* p) { return *(const dbl2*)p; 
 // whatever an earlier launch left there is never mistaken for news
 constexpr int kPwRoundsMask = 0x3FFFF, kPwAbort = 1 << 18, kPwFinished = 1 << 19, kPwIdShift = 20, kPwIdMask = 0x7FF;
 __device__ __forceinline__ void progress_publish(int* meta, int id, int rounds, int flags) {
-  __hip_atomic_store(meta, (id << kPwIdShift) | flags | rounds, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // no fence: everything the word announces (rotation log, final diagonal, correction) is written with write-through
+  // stores that the storing waves have waited for (s_waitcnt vmcnt(0), then the workgroup's barrier) before this store
+  __hip_atomic_store(meta, (id << kPwIdShift) | flags | rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // whole-wave shifts by one lane on the DPP path of the VALU (gfx9 wave_shr:1 / wave_shl:1): no LDS crossbar trip
@@ -483,43 +485,53 @@ __device__ __forceinline__ double wave_shl1_f64(double v) {  // lane l receives 
 }
 
 // ---------------------------------------------------------------- V <- V·J_0·J_1···  (replay of the rotation log)
-// Workgroups 1.. of k_posterior_eigen_rr, running BESIDE the Jacobi workgroup (workgroup 0) on other CUs: they follow its
-// progress word and apply each sweep's rotations to the eigenvector matrix while the next sweep is being computed, so
-// that when the iteration ends only the last sweep's rotations (a few µs) and the final sort are left.
-// One wave per TWO coordinates (rows of V): lane = pair + 32·coordinate.  A lane keeps its pair's two entries of the row
-// in registers; one round rotates the pair and hands the results to the neighbouring pairs (the round-robin move:
-// first entries travel to pair+1, second entries to pair−1, with the two turn-arounds at the ends): two 64-bit DPP
-// wave shifts per round, no LDS traffic for the data.  The rotations of the published rounds are staged in LDS once per
-// workgroup (every row needs all of them).  The last workgroup to finish fixes the signs (largest-|.| component of every
-// eigenvector positive), sorts the columns by the producer's ranks and writes V and Vᵀ.
+// Workgroups 1.. of a problem of k_posterior_eigen_rr (one per 32 rows of V), running BESIDE its Jacobi workgroup
+// (workgroup 0) on other CUs: they follow the progress word — the producer's log wave advances it every round, a few
+// rounds behind its write-through stores — and apply the rotations to the eigenvector matrix while the iteration goes on,
+// so that when it ends only a handful of rounds, the first-order correction and the final sort are left.
+// One wave per FOUR coordinates (rows of V): lane = pair + 32·(row pair), two rows per lane, 8 row-carrying waves per
+// workgroup (one CU cannot keep pace with the iteration for all 64 rows: ≈ 60 cycles per row and round).  A lane keeps its
+// pair's two entries of each row in registers; one round rotates the pair and hands the results to the neighbouring pairs
+// (the round-robin move: first entries travel to pair+1, second entries to pair−1, with the two turn-arounds at the
+// ends): two 64-bit DPP wave shifts per row and round, no LDS traffic for the data.  The rotations of the published
+// rounds are staged in LDS once per pass.  At the end every workgroup applies the correction V <- V·(I + X) (see
+// k_posterior_eigen_rr) to its rows, ranks the eigenvalues, and the two workgroups exchange, per column, their
+// largest-|.| candidate (one 1-KB message each, write-through stores and a flag) to fix the signs — largest-|.| component
+// of every eigenvector positive, the first among equals — before every lane writes its own entries of V and Vᵀ.
 constexpr int kReplayStageRounds = 64;   // rounds staged per pass (>= one sweep for ranks <= 64)
-constexpr int kReplayWaves = 8;          // waves of a replay workgroup that carry rows: two per SIMD (more would only queue
-                                         // for the same issue slots; the other waves help with staging only)
-constexpr int kReplayRowsPerBlock = 2 * kReplayWaves;
+constexpr int kReplayWaves = 8;          // waves of a replay workgroup that carry rows (the others help with staging)
+constexpr int kReplayRows = 4 * kReplayWaves;  // rows of V per replay workgroup
+constexpr int kEigMetaCorr = 7;          // meta word: the producer left a first-order correction X in `xcorr`
+constexpr int kEigMetaMu = 64;           // (double*)meta + this: the final diagonal, by position
+constexpr int kEigMetaXchg = 128;        // (double*)meta + this: [2 workgroups][64 values | 64 rows] sign candidates
 
-__device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* rotlog, int* meta,
-                                      double* vpos /* [n2][64] */, double* Vout, double* Vtout,
-                                      int launch_id, int me /* 0-based replay workgroup of this problem */, int nb /* their number */,
-                                      int* done_word, int done_value) {
+__device__ __forceinline__ void sc1_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double sc1_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* rotlog, int* meta, const double* xcorr /* [n2][n2] */,
+                                      double* Vout, double* Vtout, double* Sout, int launch_id, int me, int nb, int* done_word,
+                                      int done_value) {
   __shared__ int s_pw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n2 = (r + 1) & ~1, m = n2 >> 1;
   double* s_log = s_dyn;  // kReplayStageRounds × m entries of (c, −s)
-  const int kc = lane >> 5, q = lane & 31, k = kReplayRowsPerBlock * me + 2 * wave + kc;
-  const bool act = q < m && wave < kReplayWaves;
-  const int qc = act ? q : 0;
-  // this lane's pair of the row: positions 2q (first) and 2q+1 (second)
-  auto v0_at = [&](int p) { return (k < r && p < r) ? (Vwarm ? Vwarm[(size_t)k * r + p] : (k == p ? 1.0 : 0.0)) : 0.0; };
-  double x0 = act ? v0_at(2 * q) : 0.0, x1 = act ? v0_at(2 * q + 1) : 0.0;
+  const int kc = lane >> 5, q = lane & 31, ka = kReplayRows * me + 4 * wave + 2 * kc, kb = ka + 1;
+  const bool carry = wave < kReplayWaves && kReplayRows * me + 4 * wave < r;  // (uniform) this wave holds rows of V
+  const bool act = q < m && carry;
+  const int qc = q < m ? q : 0;
+  // this lane's pair of each of its two rows: positions 2q (first) and 2q+1 (second)
+  auto v0_at = [&](int k, int p) { return (k < r && p < r) ? (Vwarm ? Vwarm[(size_t)k * r + p] : (k == p ? 1.0 : 0.0)) : 0.0; };
+  double a0 = act ? v0_at(ka, 2 * q) : 0.0, a1 = act ? v0_at(ka, 2 * q + 1) : 0.0;
+  double b0 = act ? v0_at(kb, 2 * q) : 0.0, b1 = act ? v0_at(kb, 2 * q + 1) : 0.0;
   int done = 0;
   bool aborted = false;
   for (;;) {
-    if (tid == 0) {  // follow the producer
+    if (tid == 0) {  // follow the producer (relaxed polls: an acquiring load would invalidate this CU's L1 every time round)
       int pw;
       for (;;) {
-        pw = __hip_atomic_load(meta, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        pw = __hip_atomic_load(meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (((pw >> kPwIdShift) & kPwIdMask) == launch_id && ((pw & kPwRoundsMask) > done || (pw & (kPwAbort | kPwFinished)))) break;
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(2);
       }
       s_pw = pw;
 #ifdef ICP_EIGEN_TIMING
@@ -532,24 +544,28 @@ __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* 
     const int avail = pw & kPwRoundsMask;
     while (done < avail) {
       const int n = min(avail - done, kReplayStageRounds);
-      // (agent-scope loads: the log's addresses are reused by every decomposition, a plain load could hit a stale line)
-      for (int e = tid; e < 2 * n * m; e += blockDim.x)
-        s_log[e] = __hip_atomic_load(rotlog + 2 * (size_t)done * m + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (the log is written with write-through stores and read with loads served by L2: its addresses are reused by every
+      // decomposition, a plain load could hit a stale line of this CU's L1; the word is advanced behind the stores' return)
+      for (int e = tid; e < 2 * n * m; e += blockDim.x) s_log[e] = sc1_load(rotlog + 2 * (size_t)done * m + e);
       __syncthreads();
-      for (int rl = 0; rl < n && wave < kReplayWaves; rl += 8) {
-        dbl2 cs[8];
+      if (carry) {
+        for (int rl = 0; rl < n; rl += 8) {
+          dbl2 cs[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cs[u] = *(const dbl2*)&s_log[2 * (min(rl + u, n - 1) * m + qc)];
+          for (int u = 0; u < 8; ++u) cs[u] = *(const dbl2*)&s_log[2 * (min(rl + u, n - 1) * m + qc)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (rl + u < n) {  // uniform
-            const double f = fma(cs[u].x, x0, cs[u].y * x1), g = fma(-cs[u].y, x0, cs[u].x * x1);  // rotated first / second entry
-            // round-robin move (rr_dst): first entries go one pair up, except pair 0 (stays) and pair m−1 (becomes its
-            // own second); second entries go one pair down, except pair 0 (becomes the first of pair 1)
-            const double from_up = wave_shr1_f64(q == 0 ? g : f);  // what pair q−1 sends up: its first — or pair 0's second
-            const double from_dn = wave_shl1_f64(g);               // what pair q+1 sends down: its second
-            x0 = q == 0 ? f : from_up;
-            x1 = q == m - 1 ? f : from_dn;
+          for (int u = 0; u < 8; ++u) {
+            if (rl + u < n) {  // uniform
+              // rotated first / second entry of both rows
+              const double fa = fma(cs[u].x, a0, cs[u].y * a1), ga = fma(-cs[u].y, a0, cs[u].x * a1);
+              const double fb = fma(cs[u].x, b0, cs[u].y * b1), gb = fma(-cs[u].y, b0, cs[u].x * b1);
+              // round-robin move (rr_dst): first entries go one pair up, except pair 0 (stays) and pair m−1 (becomes its
+              // own second); second entries go one pair down, except pair 0 (becomes the first of pair 1)
+              const double ua = wave_shr1_f64(q == 0 ? ga : fa), da = wave_shl1_f64(ga);
+              const double ub = wave_shr1_f64(q == 0 ? gb : fb), db = wave_shl1_f64(gb);
+              a0 = q == 0 ? fa : ua; a1 = q == m - 1 ? fa : da;
+              b0 = q == 0 ? fb : ub; b1 = q == m - 1 ? fb : db;
+            }
           }
         }
       }
@@ -561,32 +577,59 @@ __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* 
 #ifdef ICP_EIGEN_TIMING
   if (me == 0 && tid == 0) g_eigen_stamps[41] = __builtin_amdgcn_s_memrealtime();
 #endif
-  // ---- signs and output.  The largest-|.| component of every eigenvector (column of V), the first among equals, is made
-  // positive; the columns go out in the rank order of the producer.  Every workgroup finds the candidates of its own rows
-  // (wave -> workgroup through LDS), the workgroups exchange them through `xchg` (one small message each), and every lane
-  // writes its own entries — V never travels.
-  double* s_pv = s_dyn;                    // [waves][64 positions] candidate value (signed)
-  int* s_pk = (int*)(s_dyn + 16 * 64);     // … and its row
-  double* s_bv = s_dyn + 16 * 64 + 8 * 64; // [64] workgroup's (then the global) candidate
-  int* s_bk = (int*)(s_bv + 64);
-  int* s_rank = s_bk + 64;
+  // ---- correction, ranks, signs, output
+  double* s_x = s_dyn;                       // [n2][n2] first-order correction (the log's region: every wave is past it)
+  double* s_mu = s_dyn + 4096;               // [64] final diagonal by position
+  int* s_rank = (int*)(s_dyn + 4096 + 64);   // [64]
+  double* s_bv = s_dyn + 4096 + 128;         // [64] signed winner per position
+  int* s_bk = (int*)(s_dyn + 4096 + 192);    // [64] … and its row
+  double* s_pv = s_dyn + 4096 + 256;         // [8 waves][64 positions] candidate value (signed)
+  int* s_pk = (int*)(s_dyn + 4096 + 256 + kReplayWaves * 64);  // … and its row
+  // s_dyn[5632 …): [32 rows][64 positions] the workgroup's rows, for the correction
+  double* xchg = (double*)meta + kEigMetaXchg;
   if (!aborted) {
-    // candidates of this wave's two rows, per position; a lane holds positions 2q (x0) and 2q+1 (x1) of row k
-    const bool mine = act && k < r;
-    double c0 = x0, c1 = x1, a0 = mine ? fabs(x0) : -1.0, a1 = mine ? fabs(x1) : -1.0;
-    int k0 = k, k1 = k;
-    {
-      const double o0 = __shfl_xor(a0, 32, 64), o1 = __shfl_xor(a1, 32, 64), v0 = __shfl_xor(c0, 32, 64), v1 = __shfl_xor(c1, 32, 64);
-      const int ok = __shfl_xor(k, 32, 64);
-      if (o0 > a0 || (o0 == a0 && ok < k0)) { a0 = o0; c0 = v0; k0 = ok; }
-      if (o1 > a1 || (o1 == a1 && ok < k1)) { a1 = o1; c1 = v1; k1 = ok; }
+    const int has_corr = __hip_atomic_load(meta + kEigMetaCorr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < n2) s_mu[tid] = sc1_load((const double*)meta + kEigMetaMu + tid);
+    if (has_corr)
+      for (int e = tid; e < n2 * n2; e += blockDim.x) s_x[e] = sc1_load(xcorr + e);
+    __syncthreads();
+    if (has_corr) {  // row·(I + X): entry p of a row gains Σ_i row[i]·X[i][p].  The rows go through LDS (every lane then reads
+      // the SAME two entries of its row — a broadcast — beside its own two columns of X): a quarter of the LDS cycles of
+      // fetching the entries from their lanes by shuffles, which is what this step is bound by
+      if (act) {
+        *(dbl2*)&s_dyn[5632 + (4 * wave + 2 * kc) * 64 + 2 * q] = dbl2{a0, a1};
+        *(dbl2*)&s_dyn[5632 + (4 * wave + 2 * kc + 1) * 64 + 2 * q] = dbl2{b0, b1};
+      }
+      __syncthreads();
+      if (carry) {
+        double ca0 = 0.0, ca1 = 0.0, cb0 = 0.0, cb1 = 0.0;
+        const int ra = 5632 + (4 * wave + 2 * kc) * 64, rb = ra + 64;
+        for (int i = 0; i < n2; i += 2) {
+          const dbl2 va = *(const dbl2*)&s_dyn[ra + i], vb = *(const dbl2*)&s_dyn[rb + i];
+          const dbl2 xe = *(const dbl2*)&s_dyn[i * n2 + 2 * qc], xo = *(const dbl2*)&s_dyn[(i + 1) * n2 + 2 * qc];
+          ca0 = fma(va.x, xe.x, ca0); ca1 = fma(va.x, xe.y, ca1); cb0 = fma(vb.x, xe.x, cb0); cb1 = fma(vb.x, xe.y, cb1);
+          ca0 = fma(va.y, xo.x, ca0); ca1 = fma(va.y, xo.y, ca1); cb0 = fma(vb.y, xo.x, cb0); cb1 = fma(vb.y, xo.y, cb1);
+        }
+        if (act) { a0 += ca0; a1 += ca1; b0 += cb0; b1 += cb1; }
+      }
     }
-    if (lane < 32 && act) {
-      s_pv[wave * 64 + 2 * q] = a0 < 0.0 ? 0.0 : c0; s_pk[wave * 64 + 2 * q] = a0 < 0.0 ? 0x7fffffff : k0;
-      s_pv[wave * 64 + 2 * q + 1] = a1 < 0.0 ? 0.0 : c1; s_pk[wave * 64 + 2 * q + 1] = a1 < 0.0 ? 0x7fffffff : k1;
+    // sign candidates per position: largest |.| over the rows, the lowest row among equals
+    if (wave < kReplayWaves) {
+      const bool va = act && ka < r, vb = act && kb < r;
+      double m0 = va ? fabs(a0) : -1.0, m1 = va ? fabs(a1) : -1.0, c0 = a0, c1 = a1;
+      int k0 = ka, k1 = ka;
+      if (vb && fabs(b0) > m0) { m0 = fabs(b0); c0 = b0; k0 = kb; }
+      if (vb && fabs(b1) > m1) { m1 = fabs(b1); c1 = b1; k1 = kb; }
+      const double o0 = __shfl_xor(m0, 32, 64), o1 = __shfl_xor(m1, 32, 64), w0 = __shfl_xor(c0, 32, 64), w1 = __shfl_xor(c1, 32, 64);
+      const int ok0 = __shfl_xor(k0, 32, 64), ok1 = __shfl_xor(k1, 32, 64);
+      if (o0 > m0 || (o0 == m0 && ok0 < k0)) { m0 = o0; c0 = w0; k0 = ok0; }
+      if (o1 > m1 || (o1 == m1 && ok1 < k1)) { m1 = o1; c1 = w1; k1 = ok1; }
+      if (lane < 32 && q < m) {
+        s_pv[wave * 64 + 2 * q] = m0 < 0.0 ? 0.0 : c0; s_pk[wave * 64 + 2 * q] = m0 < 0.0 ? 0x7fffffff : k0;
+        s_pv[wave * 64 + 2 * q + 1] = m1 < 0.0 ? 0.0 : c1; s_pk[wave * 64 + 2 * q + 1] = m1 < 0.0 ? 0x7fffffff : k1;
+      }
     }
     __syncthreads();
-    double* xv = vpos + (size_t)me * 128;  // this workgroup's message: 64 values, 64 rows
     if (tid < n2) {
       double bv = s_pv[tid];
       int bk = s_pk[tid];
@@ -596,58 +639,60 @@ __device__ void eigen_replay_consumer(int r, const double* Vwarm, const double* 
         if (kk != 0x7fffffff && (bk == 0x7fffffff || fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && kk < bk))) { bv = v; bk = kk; }
       }
       s_bv[tid] = bv; s_bk[tid] = bk;
-      s_rank[tid] = meta[8 + tid];
-      if (nb > 1) {
-        __hip_atomic_store(xv + tid, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(xv + 64 + tid, (double)bk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (nb > 1) { sc1_store(xchg + me * 128 + tid, bv); sc1_store(xchg + me * 128 + 64 + tid, (double)bk); }
+      // eigenvalues of D M⁻¹ D are 1/μ; S descending = μ ascending (ties: lower position first); the dummy sorts last
+      int rank = 0;
+      const double mi = s_mu[tid];
+      for (int j = 0; j < n2; ++j) rank += (s_mu[j] < mi) || (s_mu[j] == mi && j < tid);
+      s_rank[tid] = rank;
+      if (me == 0 && rank < r) sc1_store(Sout + rank, 1.0 / mi);
     }
-    if (nb > 1) {
+    if (nb > 1) {  // exchange with the other workgroup: message out (write-through, drained), flag up; its flag, its message
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      const int o = 1 - me;
       if (tid == 0) {
-        __hip_atomic_store(meta + 2 + me, launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        for (int o = 0; o < nb; ++o)
-          while (__hip_atomic_load(meta + 2 + o, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != launch_id) __builtin_amdgcn_s_sleep(8);
+        __hip_atomic_store(meta + 2 + me, launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(meta + 2 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != launch_id) __builtin_amdgcn_s_sleep(1);
       }
       __syncthreads();
       if (tid < n2) {
+        const double v = sc1_load(xchg + o * 128 + tid);
+        const int kk = (int)sc1_load(xchg + o * 128 + 64 + tid);
         double bv = s_bv[tid];
-        int bk = s_bk[tid];
-        for (int o = 0; o < nb; ++o) {
-          if (o == me) continue;
-          const double v = __hip_atomic_load(vpos + (size_t)o * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int kk = (int)__hip_atomic_load(vpos + (size_t)o * 128 + 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (kk != 0x7fffffff && (bk == 0x7fffffff || fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && kk < bk))) { bv = v; bk = kk; }
-        }
+        const int bk = s_bk[tid];
+        if (kk != 0x7fffffff && (bk == 0x7fffffff || fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && kk < bk))) bv = v;
         s_bv[tid] = bv;
       }
+      if (tid == 0) __hip_atomic_store(meta + 2 + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read: back to idle (ids repeat after 2047 launches)
     }
     __syncthreads();
-    if (mine) {
+    if (act) {  // (write-through stores: nothing to write back before the completion word)
       const int p0 = 2 * q, p1 = 2 * q + 1, r0 = s_rank[p0], r1 = s_rank[p1];
-      if (r0 < r) {
-        const double v = s_bv[p0] < 0.0 ? -x0 : x0;
-        Vout[(size_t)k * r + r0] = v; Vtout[(size_t)r0 * r + k] = v;
+      const bool n0 = s_bv[p0] < 0.0, n1 = s_bv[p1] < 0.0;
+      if (ka < r) {
+        if (r0 < r) { const double v = n0 ? -a0 : a0; sc1_store(Vout + (size_t)ka * r + r0, v); sc1_store(Vtout + (size_t)r0 * r + ka, v); }
+        if (r1 < r) { const double v = n1 ? -a1 : a1; sc1_store(Vout + (size_t)ka * r + r1, v); sc1_store(Vtout + (size_t)r1 * r + ka, v); }
       }
-      if (r1 < r) {
-        const double v = s_bv[p1] < 0.0 ? -x1 : x1;
-        Vout[(size_t)k * r + r1] = v; Vtout[(size_t)r1 * r + k] = v;
+      if (kb < r) {
+        if (r0 < r) { const double v = n0 ? -b0 : b0; sc1_store(Vout + (size_t)kb * r + r0, v); sc1_store(Vtout + (size_t)r0 * r + kb, v); }
+        if (r1 < r) { const double v = n1 ? -b1 : b1; sc1_store(Vout + (size_t)kb * r + r1, v); sc1_store(Vtout + (size_t)r1 * r + kb, v); }
       }
     }
   }
 #ifdef ICP_EIGEN_TIMING
   if (me == 0 && tid == 0) g_eigen_stamps[42] = __builtin_amdgcn_s_memrealtime();
 #endif
-  // the last workgroup out puts the shared words back to idle (the producer has long finished; nobody reads them any more)
+  // every wave's (write-through) stores have left before the workgroup is counted out; the last workgroup out puts the
+  // shared words back to idle and raises the completion word
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __threadfence();  // this workgroup's rows of V and Vᵀ, before it is counted out
-    if (atomicAdd(&meta[1], 1) == nb - 1) {
-      meta[1] = 0;
-      __hip_atomic_store(meta, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int o = 0; o < nb; ++o) __hip_atomic_store(meta + 2 + o, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nb == 1 || __hip_atomic_fetch_add(meta + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1) {
+      __hip_atomic_store(meta + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(meta, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the producer has long finished; nobody reads it any more)
       // this decomposition is complete (or dropped): whoever waits for it alone need not wait for the rest of the launch
-      if (done_word) __hip_atomic_store(done_word, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (done_word) __hip_atomic_store(done_word, done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -657,6 +702,9 @@ constexpr int kRrSzA = 64 * kRrLd;        // one buffer of A, sized for rank 64 
 constexpr int kRrSzC = 4 * 32;            // one rotation table
 constexpr int kRrOC = 0, kRrOA = 2 * kRrSzC, kRrOV = kRrOA + 2 * kRrSzA;  // table[2] | A[2] | Vt (warm start) | T (its transform)
 constexpr int kRrLogWave = 14;            // never a block wave (at most 9 of those, on waves 0-2, 4-6, 8-10)
+constexpr int kRrPollWave = 13;           // … nor this one: a speculative decomposition's cancel word is polled here (a slow read of
+                                          // pinned memory, which must not sit in the log wave's memory queue: it counts its stores)
+constexpr int kRrLogLag = 8;              // the progress word trails the log wave's write-through stores by this many rounds
 template <int N> struct IntC { static constexpr int value = N; };
 
 // One launch decomposes up to two posteriors side by side (the two ICP directions of a chain step): problem p owns the
@@ -674,7 +722,8 @@ static_assert(sizeof(EigenBatch<kEigenBatchMax>) + 64 <= 4096, "the batch record
 
 template <int CAP>
 __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double* __restrict__ sqrt_lambda_launch, int ldk, int max_sweeps,
-                                                              int per /* workgroups per problem */, EigenBatch<CAP> batch) {
+                                                              int no_corr /* 1: sweep to the strict test (A/B, tests) */, EigenBatch<CAP> batch) {
+  const int per = 1 + (r + kReplayRows - 1) / kReplayRows;  // workgroups per problem: the iteration + the replay (32 rows each)
   const int which = (int)blockIdx.x / per, local = (int)blockIdx.x - which * per;
   const EigenProblem& pb = batch.p[which];
   const double* __restrict__ sqrt_lambda = pb.sqrt_lambda ? pb.sqrt_lambda : sqrt_lambda_launch;
@@ -692,11 +741,11 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
   int* host_status = pb.host_status;
   if (Vwarm && !(Vwarm[0] == Vwarm[0])) Vwarm = nullptr;  // the basis of a decomposition that gave up (see below): cold start
   if (local != 0) {
-    eigen_replay_consumer(r, Vwarm, rotlog, meta, vpos, Vout, Vtout, launch_id, local - 1, per - 1, pb.done_word, pb.done_value);
+    eigen_replay_consumer(r, Vwarm, rotlog, meta, vpos, Vout, Vtout, Sout, launch_id, local - 1, per - 1, pb.done_word, pb.done_value);
     return;
   }
-  __shared__ double s_red[16], s_red2[16], s_mu[64];
-  __shared__ int s_cancel;
+  __shared__ double s_red[16], s_red2[16];
+  __shared__ int s_cancel, s_bad[16];
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int n2 = (r + 1) & ~1, m = n2 >> 1;
   // buffers are addressed as s_dyn[offset] with integer offsets: a table of pointers would turn every access into a
@@ -711,7 +760,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
   EIG_STAMP(0);
   // a speculative decomposition polls its cancel word (pinned host memory: a slow read, so one thread of an otherwise
   // idle wave fetches it while the others work, and the block looks at the copy at the next convenient barrier)
-  const bool is_poll = spec.cancel != nullptr && tid == 64 * kRrLogWave + 63;
+  const bool is_poll = spec.cancel != nullptr && tid == 64 * kRrPollWave + 63;
   if (tid == 0) s_cancel = 0;
   // ---- N = D⁻¹ M D⁻¹ (symmetrised), padded; Vt = (warm start or identity)ᵀ, padded with zeros
   for (int e = tid; e < szV; e += nt) LDS_VT(e) = 0.0;
@@ -801,39 +850,69 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     return;
   }
   EIG_STAMP(1);
-  if (Vwarm) {  // A <- Vᵀ A V (nearly diagonal when V diagonalised a nearby posterior); 2×2 output tiles per thread,
-    // every inner product runs along contiguous rows (A row · Vt row, Vt row · Tt row); padded entries are zero
-    const int mt = n2 >> 1;
-    for (int e = tid; e < mt * mt; e += nt) {  // Tt[j][i] = (A·V)[i][j]
-      const int ti = e / mt, tj = e - ti * mt, i = 2 * ti, j = 2 * tj;
-      double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
-      const bool i1 = i + 1 < r;
-      for (int k = 0; k < n2; k += 2) {
-        const dbl2 a0 = lds2(&LDS_A(0, i * ld + k)), a1 = i1 ? lds2(&LDS_A(0, (i + 1) * ld + k)) : dbl2{0.0, 0.0};
-        const dbl2 v0 = lds2(&LDS_VT(j * ldk + k)), v1 = lds2(&LDS_VT((j + 1) * ldk + k));
-        const double a0y = k + 1 < r ? a0.y : 0.0, a1y = k + 1 < r ? a1.y : 0.0;  // column r of A is the dummy (1e300 on its diagonal)
-        s00 = fma(a0.x, v0.x, s00); s01 = fma(a0.x, v1.x, s01); s10 = fma(a1.x, v0.x, s10); s11 = fma(a1.x, v1.x, s11);
-        s00 = fma(a0y, v0.y, s00); s01 = fma(a0y, v1.y, s01); s10 = fma(a1y, v0.y, s10); s11 = fma(a1y, v1.y, s11);
+  if (Vwarm) {  // A <- Vᵀ A V (nearly diagonal when V diagonalised a nearby posterior) on the f64 matrix cores: one 16×16
+    // output tile per wave, the contraction in steps of 4 (v_mfma_f64_16x16x4_f64: lane l supplies A[l&15][l>>4] and
+    // B[l>>4][l&15], result register g is D[(l>>4) + 4g][l&15]).  Both products read their operands along rows of LDS
+    // images (row = l&15, k = l>>4: rows are 16 B apart modulo the 256-B bank window, conflict free); indices >= r (the
+    // dummy of an odd rank, the padding of the tiles) enter as zeros.
+    const int tI = wave >> 2, tJ = wave & 3, nT = (n2 + 15) >> 4, l15 = lane & 15, l4 = lane >> 4;
+    {  // Tt[j][i] = Σ_k Vt[j][k]·A[k][i]   (tile rows j, tile columns i)
+      const int j = 16 * tI + l15, i = 16 * tJ + l15;
+      const bool vj = j < r, vi = i < r;
+      const int jc = vj ? j : 0, ic = vi ? i : 0;
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      if (tI < nT && tJ < nT) {
+        // eight steps' operands at a time (one trip of LDS latency), then their MFMAs back to back
+#pragma unroll
+        for (int h = 0; h < 16; h += 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          const int k = 4 * (h + st) + l4;
+          const bool vk = k < r;
+          const int kk = vk ? k : 0;
+          const double a = LDS_VT(jc * ldk + kk), b = LDS_A(0, kk * ld + ic);
+          av[st] = (vj && vk) ? a : 0.0; bv[st] = (vi && vk) ? b : 0.0;
+        }
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+          if (4 * (h + st) < n2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], bv[st], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * tI + l4 + 4 * g;
+          if (row < n2 && i < n2) LDS_T(row * ldk + i) = acc[g];
+        }
       }
-      LDS_T(j * ldk + i) = s00; LDS_T((j + 1) * ldk + i) = s01;
-      LDS_T(j * ldk + i + 1) = i1 ? s10 : 0.0; LDS_T((j + 1) * ldk + i + 1) = i1 ? s11 : 0.0;
     }
     __syncthreads();
-    for (int e = tid; e < mt * mt; e += nt) {  // A[i][j] = Σ_k Vt[i][k]·Tt[j][k], upper triangle only
-      const int ti = e / mt, tj = e - ti * mt, i = 2 * ti, j = 2 * tj;
-      if (ti > tj) continue;
-      double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
-      for (int k = 0; k < n2; k += 2) {
-        const dbl2 v0 = lds2(&LDS_VT(i * ldk + k)), v1 = lds2(&LDS_VT((i + 1) * ldk + k));
-        const dbl2 t0 = lds2(&LDS_T(j * ldk + k)), t1 = lds2(&LDS_T((j + 1) * ldk + k));
-        s00 = fma(v0.x, t0.x, s00); s01 = fma(v0.x, t1.x, s01); s10 = fma(v1.x, t0.x, s10); s11 = fma(v1.x, t1.x, s11);
-        s00 = fma(v0.y, t0.y, s00); s01 = fma(v0.y, t1.y, s01); s10 = fma(v1.y, t0.y, s10); s11 = fma(v1.y, t1.y, s11);
+    {  // A[i][j] = Σ_k Vt[i][k]·Tt[j][k], tiles of the upper triangle only
+      const int i = 16 * tI + l15, j = 16 * tJ + l15;
+      const bool vi = i < r, vj = j < r;
+      const int ic = vi ? i : 0, jc = vj ? j : 0;
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      if (tI <= tJ && tJ < nT) {
+#pragma unroll
+        for (int h = 0; h < 16; h += 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          const int k = 4 * (h + st) + l4;
+          const bool vk = k < r;
+          const int kk = vk ? k : 0;
+          const double a = LDS_VT(ic * ldk + kk), b = LDS_T(jc * ldk + kk);
+          av[st] = (vi && vk) ? a : 0.0; bv[st] = (vj && vk) ? b : 0.0;
+        }
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+          if (4 * (h + st) < n2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], bv[st], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * tI + l4 + 4 * g;
+          if (row <= j && j < r) LDS_A(0, row * ld + j) = acc[g];
+        }
       }
-      const bool i1 = i + 1 < r, j1 = j + 1 < r;
-      LDS_A(0, i * ld + j) = s00;
-      if (j1) LDS_A(0, i * ld + j + 1) = s01;
-      if (i1 && j1) LDS_A(0, (i + 1) * ld + j + 1) = s11;
-      if (i1 && ti != tj) LDS_A(0, (i + 1) * ld + j) = s10;
     }
     __syncthreads();
   }
@@ -852,7 +931,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
 
   // One round: reads buffers `cur`, writes buffers `cur ^ 1`.  `cur` is a template constant (the loop below alternates
   // the two instantiations), so no address is computed inside the loop at all.
-  int n_rounds = 0;
+  int n_rounds = 0, pub_floor = 0;
   auto round = [&](auto CUR) {
     constexpr int cur = decltype(CUR)::value;
     constexpr int ac = oA + cur * szA, an = oA + (cur ^ 1) * szA, cc = oC + cur * szC, cn = oC + (cur ^ 1) * szC;
@@ -882,44 +961,81 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
         *(dbl2*)&s_dyn[cn + 4 * rp_k] = dbl2{R.c, -R.s};
         *(dbl2*)&s_dyn[cn + 4 * rp_k + 2] = dbl2{R.s, R.c};
       }
-    } else if (is_log) {  // the rotations this round applies, for the replay kernel (negligible ones as identities)
-      const dbl2 k = lds2(&s_dyn[cc + 4 * lane]);
-      *(dbl2*)(rotlog + (size_t)n_rounds * lstride + 2 * lane) = fabs(k.y) >= 2e-17 ? k : dbl2{1.0, 0.0};
+    } else if (wave == kRrLogWave) {  // the rotations this round applies, for the replay workgroups (negligible ones as
+      // identities): two write-through stores per pair; every fourth round the progress word is advanced to kRrLogLag rounds
+      // behind — 2 + ¼ memory operations per round in this wave's queue, so all but the youngest 2·lag + lag/4 − 1 of them
+      // being done means the rounds up to n_rounds − lag have arrived
+      if (is_log) {
+        const dbl2 k = lds2(&s_dyn[cc + 4 * lane]);
+        const dbl2 w = fabs(k.y) >= 2e-17 ? k : dbl2{1.0, 0.0};
+        double* dst = rotlog + (size_t)n_rounds * lstride + 2 * lane;
+        sc1_store(dst, w.x); sc1_store(dst + 1, w.y);
+      }
+      if ((n_rounds & 3) == 3) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kRrLogLag + kRrLogLag / 4 - 1) : "memory");
+        const int upto = n_rounds + 1 - kRrLogLag;
+        if (lane == 0 && upto > pub_floor) __hip_atomic_store(meta, (launch_id << kPwIdShift) | upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     __syncthreads();
     ++n_rounds;
   };
-  int converged = 0, n_sweeps = 0, in_sweep = 0;
-  auto sweep_end = [&](int cur) {  // -> stop?
+  int converged = 0, n_sweeps = 0, in_sweep = 0, use_corr = 0;
+  // (a warm-started iteration has never met either test after one sweep, a cold one never before its third: those passes
+  // — two barriers and a reduction each — are skipped; were the matrix diagonal already, one more sweep would be harmless)
+  const int first_test = Vwarm ? 1 : 2;
+  auto sweep_end = [&](int cur) -> bool {  // -> stop?
     EIG_STAMP(4 + 2 * n_sweeps);
     in_sweep = 0;
-    // this sweep's rotations are in the log: the replay workgroups may have them (published behind the barrier below)
-    if (wave == kRrLogWave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (write back only)
-    // convergence: off(A)² <= 1e-26·Σ diag².  Thread (row, 4 columns) over the stored upper triangle; one barrier.
+    if (n_sweeps < first_test && n_sweeps + 1 < max_sweeps) {
+      ++n_sweeps;
+      EIG_STAMP(3 + 2 * n_sweeps);
+      return s_cancel != 0;
+    }
+    // this sweep's rotations are in the log (written through; the log wave's own progress stores have landed, too): the
+    // replay workgroups may have all of them (published behind the barrier below)
+    if (wave == kRrLogWave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pub_floor = n_rounds;
+    // Two ways to be done, both from one pass over the stored upper triangle (thread = row, 4 columns; one barrier):
+    //   strict  off(A)² <= 1e-26·Σ diag²: nothing left to do;
+    //   loose   every |A_ij| <= 1e-6·|A_jj − A_ii|: what one more sweep would do to the eigenvectors is, to first order,
+    //           V <- V·(I + X) with X_ij = A_ij/(A_jj − A_ii) (antisymmetric), all |X_ij| <= 1e-6 — the replay workgroup
+    //           applies that instead (error of the correction ~ X²: 1e-12, against 19 µs for the sweep).  The Jacobi sweeps
+    //           converge quadratically, so the sweep before the last is the one that meets this test.
     double off = 0.0, dg = 0.0;
+    bool bad = false;
     {
       const int i = tid >> 4, j0 = (tid & 15) << 2;
       if (i < n2 && j0 + 3 >= i && j0 < n2) {
         const dbl2 u = lds2(&LDS_A(cur, i * ld + j0)), w = lds2(&LDS_A(cur, i * ld + j0 + 2));
+        const double dii = LDS_A(cur, i * ld + i);
         const double v[4] = {u.x, u.y, w.x, w.y};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int j = j0 + c;
           if (j < n2) {
             if (j == i) { if (v[c] < 1e299) dg = fma(v[c], v[c], dg); }
-            else if (j > i) off = fma(2.0 * v[c], v[c], off);
+            else if (j > i) {
+              off = fma(2.0 * v[c], v[c], off);
+              bad = bad || fabs(v[c]) > 1e-6 * fabs(LDS_A(cur, j * ld + j) - dii);
+            }
           }
         }
       }
     }
     for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
-    if (lane == 0) { s_red[wave] = off; s_red2[wave] = dg; }
+    const bool wave_bad = __any(bad);
+    if (lane == 0) { s_red[wave] = off; s_red2[wave] = dg; s_bad[wave] = wave_bad ? 1 : 0; }
     __syncthreads();
     if (tid == 0) progress_publish(meta, launch_id, n_rounds, 0);
     off = 0.0; dg = 0.0;
+    int any_bad = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) { off += s_red[w]; dg += s_red2[w]; }
-    converged = off <= 1e-26 * dg;
+    for (int w = 0; w < 16; ++w) { off += s_red[w]; dg += s_red2[w]; any_bad |= s_bad[w]; }
+    const int strict = off <= 1e-26 * dg;
+    const int loose = !any_bad && off <= dg;  // (off <= dg: false for NaN)
+    converged = strict || (loose && !no_corr);
+    use_corr = converged && !strict;
     if (tid == 0 && n_sweeps < 8) ((double*)(meta + 80))[n_sweeps] = off / dg;  // diagnostic: off(A)²/Σdiag² after each sweep
     ++n_sweeps;
     EIG_STAMP(3 + 2 * n_sweeps);
@@ -948,18 +1064,29 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     if (host_status) __hip_atomic_store(host_status, converged ? 0 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   EIG_STAMP(62);
-  // ---- eigenvalues of D M⁻¹ D are 1/μ; S descending = μ ascending; the dummy sorts last and is dropped.  The replay
-  // kernel needs the number of logged rounds and, per final position, the rank of its eigenvalue.
-  if (tid < n2) s_mu[tid] = LDS_A(cur, tid * ld + tid);
-  __syncthreads();
-  if (tid < n2) {
-    int rank = 0;
-    const double mi = s_mu[tid];
-    for (int j = 0; j < n2; ++j) rank += (s_mu[j] < mi) || (s_mu[j] == mi && j < tid);
-    meta[8 + tid] = rank;
-    if (rank < r) Sout[rank] = 1.0 / mi;
-    __threadfence();
+  // ---- hand-over to the replay workgroup: the final diagonal by position (it ranks the eigenvalues: those of D M⁻¹ D are
+  // 1/μ, S descending = μ ascending, the dummy sorts last and is dropped) and, when the iteration stopped on the loose
+  // test, the first-order correction X
+  double* xg = vpos;
+  if (tid < n2) sc1_store((double*)meta + kEigMetaMu + tid, LDS_A(cur, tid * ld + tid));
+  if (use_corr) {
+    const int i = tid >> 4, j0 = (tid & 15) << 2;
+    if (i < n2 && j0 + 3 >= i && j0 < n2) {
+      const double dii = LDS_A(cur, i * ld + i);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = j0 + c;
+        if (j < n2 && j >= i) {
+          const double a = LDS_A(cur, i * ld + j);
+          const double x = (j == i || a == 0.0) ? 0.0 : a / (LDS_A(cur, j * ld + j) - dii);
+          sc1_store(xg + i * n2 + j, x);
+          if (j != i) sc1_store(xg + j * n2 + i, -x);
+        }
+      }
+    }
   }
+  if (tid == 0) __hip_atomic_store(meta + kEigMetaCorr, use_corr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's stores, before the barrier behind which they are released
   __syncthreads();
   if (tid == 0) progress_publish(meta, launch_id, n_rounds, kPwFinished);  // (max_sweeps == 0: nothing to replay)
   EIG_STAMP(63);
@@ -1258,7 +1385,7 @@ void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO
 size_t eigen_work_doubles(int r) {  // `work` of launch_posterior_eigen: r×r scratch, or the rotation log of the fixed-position variant
   const size_t n2 = ((size_t)r + 1) & ~(size_t)1;
   const size_t log = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;  // 2 doubles per pair and round
-  return std::max((size_t)r * r + 2 * (size_t)r + 8, log + n2 * 64 + 64);  // library path: matrix, eigenvalues, scratch, info |
+  return std::max((size_t)r * r + 2 * (size_t)r + 8, log + n2 * 64 + 128 + 256);  // library path: matrix, eigenvalues, scratch, info |
                                                                               // log + sign exchange + meta (see launch_posterior_eigen)
 }
 
@@ -1359,9 +1486,9 @@ void launch_eigen_rr(hipStream_t st, int r, const double* sqrt_lambda, int n, co
                               rq[i].done_value, rq[i].sqrt_lambda};
   }
   ProfScope _ps(st, KID_EIGEN);
-  // per problem: workgroup 0 iterates; the others replay its rotations on V as the sweeps are published
-  const int per = 1 + (r + kReplayRowsPerBlock - 1) / kReplayRowsPerBlock;
-  hipLaunchKernelGGL(k_posterior_eigen_rr<CAP>, dim3(n * per), dim3(1024), shmem, st, r, sqrt_lambda, ldk, std::min(sweeps_cap, kEigenMaxSweeps), per,
+  // per problem: workgroup 0 iterates, workgroup 1 replays its rotations on V as the sweeps are published
+  static const int no_corr = std::getenv("ICP_EIGEN_NO_CORRECTION") != nullptr;
+  hipLaunchKernelGGL(k_posterior_eigen_rr<CAP>, dim3(n * (1 + (r + kReplayRows - 1) / kReplayRows)), dim3(1024), shmem, st, r, sqrt_lambda, ldk, std::min(sweeps_cap, kEigenMaxSweeps), no_corr,
                      batch);
 }
 }  // namespace
