@@ -21,6 +21,8 @@
 // flight is rejected.  The cross-stream order is taken on the device: launch 1 waits for a word that launch 5 of the
 // previous step raises when it starts (StepBeginArgs::wait_flag), and for the completion word of the eigen-decomposition
 // it draws from.
+#include <cstdlib>
+
 #include "icp_kernels.hpp"
 #include "icp_search.hpp"
 #include "icp_dense.hpp"
@@ -93,11 +95,124 @@ __device__ __forceinline__ void step_begin_body(const StepBeginArgs& a, const in
     if (k < a.vert.Kpad) a.vert.cnt[k] = 0;
   }
 }
+// The same for ranks 32..RMAX with everything the step does NOT depend on held in registers before the wait: the point's
+// 3·r basis values (the instance is bound by the latency of those loads, 24·r bytes per point through one CU's L2 port),
+// the thread's share of P = (G + σ²I)⁻¹ and the posterior mean.  What is left behind the wait — for the word of the
+// decomposition the proposal draws from, on the accepted path — is the product with the fresh basis V, two reductions and
+// arithmetic on registers: ≈ 3 µs instead of ≈ 10.  Same operations in the same order as propose_body / instance_point
+// (for these ranks block_matvec runs with four threads per row and one pass): bit-identical results.
+template <int RMAX>
+__device__ __forceinline__ void step_begin_body_reg(const StepBeginArgs& a, const int bx) {
+  __shared__ double s_c[64], s_px[64], s_py[64], s_pw[64];
+  const int tid = threadIdx.x, r = a.r;
+  const double* zsrc = a.zin;  // (r <= kStepInlineZ)
+  const bool inst = bx < a.inst_blocks;
+  const int i = bx * kStepBeginPoints + tid;
+  const bool my_point = inst && tid < kStepBeginPoints && i < a.N;
+  const int row = tid >> 2, sub = tid & 3;
+  const ProposeIn& in = a.prop;
+  // ---- before the wait: immutable model data
+  double qv[3 * RMAX];
+  double m0 = 0.0, m1 = 0.0, m2 = 0.0;
+  if (my_point) {
+    const double* q = a.Qp + i;
+#pragma unroll
+    for (int u = 0; u < 3 * RMAX; ++u) qv[u] = u < 3 * r ? q[(size_t)u * a.N] : 0.0;
+    m0 = a.mean[3 * i]; m1 = a.mean[3 * i + 1]; m2 = a.mean[3 * i + 2];
+  }
+  double pv[16], al = 0.0, isl = 0.0;
+  if (a.propose) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { const int j = sub + 4 * t; pv[t] = (row < r && j < r) ? in.P[(size_t)row * r + j] : 0.0; }
+    if (tid < r) { al = in.alpha[tid]; isl = in.inv_sqrt_lambda[tid]; }
+  }
+  if (a.wait_flag || a.wait2_flag) {  // see StepBeginArgs
+    if (tid == 0) {
+      const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+      for (;;) {
+        const bool ok1 = !a.wait_flag || __hip_atomic_load(a.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.wait_seq >= 0;
+        const bool ok2 = !a.wait2_flag || __hip_atomic_load(a.wait2_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.wait2_seq >= 0;
+        if (ok1 && ok2) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000) {
+          __hip_atomic_store(a.wait_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (invalidate only: nothing of ours to write back)
+  }
+  HintTriangle ht{false, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  const bool my_query = my_point && a.has_surf && i < a.surf.K;
+  if (my_query) ht = load_hint_triangle(a.surf, i);
+  if (a.propose) {  // NonRigidIcpProposal.scala:53-62 (every workgroup computes its own copy)
+    double vv[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { const int j = sub + 4 * t; vv[t] = (row < r && j < r) ? in.V[(size_t)row * r + j] : 0.0; }
+    if (tid < r) s_px[tid] = sqrt(in.S[tid]) * zsrc[tid];
+    __syncthreads();
+    {
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { const int j = sub + 4 * t; if (j < r) acc = fma(vv[t], s_px[j], acc); }
+      acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64);
+      if (row < r && sub == 0) s_py[row] = acc;
+    }
+    __syncthreads();
+    if (tid < r) s_pw[tid] = fma(s_py[tid], isl, al);
+    __syncthreads();
+    {
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { const int j = sub + 4 * t; if (j < r) acc = fma(pv[t], s_pw[j], acc); }
+      acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64);
+      if (row < r && sub == 0) s_py[row] = acc;
+    }
+    __syncthreads();
+    if (tid < r) {
+      const double cnew = fma(-in.sigma2, s_py[tid], s_pw[tid]);  // model.coefficients(...) with σ² = 1e-5 (:59)
+      const double c0 = in.c[tid];
+      s_c[tid] = c0 + (cnew - c0) * in.step;                       // :61-62
+    }
+    __syncthreads();
+  } else {
+    if (tid < r) s_c[tid] = zsrc[tid];
+    __syncthreads();
+  }
+  if (bx == 0 && tid < r) {
+    const double c = s_c[tid];
+    for (int o = 0; o < a.n_out; ++o) a.out[o][tid] = c;
+  }
+  if (inst) {
+    if (my_point) {  // ModelFittingParameters.scala:108-110, summed in basis order with separately rounded multiply and add
+      double a0 = m0, a1 = m1, a2 = m2;
+#pragma unroll
+      for (int j = 0; j < RMAX; ++j)
+        if (j < r) {
+          const double c = s_c[j];
+          a0 = a0 + qv[3 * j] * c; a1 = a1 + qv[3 * j + 1] * c; a2 = a2 + qv[3 * j + 2] * c;
+        }
+      const d3 p = instance_pose(i, a.ref, a.pose, a0, a1, a2);
+      a.x[3 * i] = p.x; a.x[3 * i + 1] = p.y; a.x[3 * i + 2] = p.z;
+      if (my_query) surface_init_with(a.surf, i, p, ht);  // query i = model point i (:96)
+    }
+    if (a.has_surf && bx == 0 && tid < kQU) {
+      const int k = a.surf.K + tid;  // sentinel slots
+      if (k < a.surf.Kpad) surface_init_at(a.surf, k, d3{0.0, 0.0, 0.0});
+    }
+  } else if (a.has_vert) {
+    const int k = (bx - a.inst_blocks) * kStepBlock + tid;
+    if (k < a.vert.Kpad) a.vert.cnt[k] = 0;
+  }
+}
 __device__ __forceinline__ int step_begin_grid(const StepBeginArgs& a) {
   return a.inst_blocks + (a.has_vert ? (a.vert.Kpad + kStepBlock - 1) / kStepBlock : 0);
 }
 
 __global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) { step_begin_body(a, blockIdx.x); }
+template <int RMAX>
+__global__ void __launch_bounds__(kStepBlock) k_step_begin_reg(StepBeginArgs a) { step_begin_body_reg<RMAX>(a, blockIdx.x); }
 
 // ---------------------------------------------------------------- 2: filters of every search
 
@@ -236,6 +351,12 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin_batch(const StepBegin
   if ((int)blockIdx.x >= step_begin_grid(a)) return;
   step_begin_body(a, blockIdx.x);
 }
+template <int RMAX>
+__global__ void __launch_bounds__(kStepBlock) k_step_begin_batch_reg(const StepBeginArgs* __restrict__ batch) {
+  const StepBeginArgs& a = batch[blockIdx.y];
+  if ((int)blockIdx.x >= step_begin_grid(a)) return;
+  step_begin_body_reg<RMAX>(a, blockIdx.x);
+}
 __global__ void __launch_bounds__(kSearchBlock) k_step_filter_batch(const StepSearchArgs* __restrict__ batch) {
   const StepSearchArgs& a = batch[blockIdx.y];
   if ((int)blockIdx.x >= a.fstart[a.n_surf + a.n_vert]) return;
@@ -303,7 +424,10 @@ void launch_step_begin(hipStream_t st, const StepBeginArgs& a_in) {
   const int vblocks = a.has_vert ? cdiv(a.vert.Kpad, kStepBlock) : 0;
   if (t_capture) { t_capture->begin = a; t_capture->grid[0] = a.inst_blocks + vblocks; return; }
   ProfScope _ps(st, KID_STEP_BEGIN);
-  hipLaunchKernelGGL(k_step_begin, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
+  static const bool no_reg = std::getenv("ICP_BEGIN_STREAMED") != nullptr;  // (A/B switch)
+  if (a.r >= 32 && a.r <= 52 && !no_reg) hipLaunchKernelGGL(k_step_begin_reg<52>, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
+  else if (a.r >= 32 && a.r <= 64 && !no_reg) hipLaunchKernelGGL(k_step_begin_reg<64>, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
+  else hipLaunchKernelGGL(k_step_begin, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
 }
 
 void launch_step_filter(hipStream_t st, const StepSearchArgs& a) {
@@ -377,7 +501,14 @@ void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pin
   }
   const int n16 = (int)(total / 16);
   hipLaunchKernelGGL(k_step_batch_args, dim3(cdiv(n16, 256)), dim3(256), 0, st, (const uint4*)h, (uint4*)d, n16);
-  if (gx[0] > 0) { ProfScope _ps(st, KID_STEP_BEGIN); hipLaunchKernelGGL(k_step_begin_batch, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d); }
+  if (gx[0] > 0) {
+    ProfScope _ps(st, KID_STEP_BEGIN);
+    static const bool no_reg = std::getenv("ICP_BEGIN_STREAMED") != nullptr;  // (A/B switch)
+    const int r = caps[0].begin.r;  // (one rank per batch: checked by the caller)
+    if (r >= 32 && r <= 52 && !no_reg) hipLaunchKernelGGL(k_step_begin_batch_reg<52>, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d);
+    else if (r >= 32 && r <= 64 && !no_reg) hipLaunchKernelGGL(k_step_begin_batch_reg<64>, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d);
+    else hipLaunchKernelGGL(k_step_begin_batch, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d);
+  }
   if (gx[1] > 0) { ProfScope _ps(st, KID_STEP_FILTER); hipLaunchKernelGGL(k_step_filter_batch, dim3(gx[1], B), dim3(kSearchBlock), 0, st, (const StepSearchArgs*)(d + o1)); }
   if (gx[2] > 0) { ProfScope _ps(st, KID_STEP_RESOLVE); hipLaunchKernelGGL(k_step_resolve_batch, dim3(gx[2], B), dim3(64), 0, st, (const StepSearchArgs*)(d + o1)); }
   if (gx[3] > 0) { ProfScope _ps(st, KID_STEP_REGRESSION); hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, (const StepRegressionArgs*)(d + o2)); }
