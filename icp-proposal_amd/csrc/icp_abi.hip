@@ -325,6 +325,7 @@ struct icp_ctx {
   StateSlot& state(const double* theta);
   StateSlot* find_state(const double* theta);
   StateSlot& fresh_state();
+  void alloc_slot(StateSlot& s);
   void ensure_model_spheres(StateSlot& s);
   void ensure_surface_prefix(StateSlot& s, int K);
   void ensure_nnv_prefix(StateSlot& s, int K);
@@ -354,6 +355,19 @@ StateSlot* icp_ctx::find_state(const double* theta) {
 }
 
 // least recently used slot, emptied (buffers allocated on first use); the caller fills it and sets `valid`
+// device buffers of a state slot (all slots at context creation: an allocation is a synchronising runtime call of 50-100 µs,
+// which a chain's first steps would otherwise pay one slot at a time)
+void icp_ctx::alloc_slot(StateSlot& s) {
+  if (s.x.p) return;
+  s.coeffs.alloc(r);
+  s.x.alloc(3 * (size_t)N);
+  s.spheres.alloc(sphere_floats4(T));
+  s.surf_cp.alloc(3 * (size_t)N);
+  s.surf_d2.alloc(N);
+  s.surf_tri.alloc(N);
+  s.surf_nnv.alloc(N);
+}
+
 StateSlot& icp_ctx::fresh_state() {
   StateSlot* lru = nullptr;
   for (auto& s : slots) {
@@ -364,15 +378,7 @@ StateSlot& icp_ctx::fresh_state() {
   }
   if (!lru) fail(ICP_ERR_DEVICE, "internal: every state slot is reserved");
   StateSlot& s = *lru;
-  if (!s.x.p) {
-    s.coeffs.alloc(r);
-    s.x.alloc(3 * (size_t)N);
-    s.spheres.alloc(sphere_floats4(T));
-    s.surf_cp.alloc(3 * (size_t)N);
-    s.surf_d2.alloc(N);
-    s.surf_tri.alloc(N);
-    s.surf_nnv.alloc(N);
-  }
+  alloc_slot(s);
   s.valid = false;
   s.spheres_valid = false;
   s.n_surf = 0;
@@ -486,6 +492,9 @@ struct PosteriorEntry {
   bool reserved = false;  // handed out to a step whose launches are in flight: not to be recycled
   hipEvent_t eig_done = nullptr;  // recorded on the eigen stream behind the launch that holds the entry's decomposition
   hipEvent_t eig_done_shared = nullptr;  // … or, not owned, the event of the entry it shared that launch with
+  bool eig_event_valid = false;   // an event stands for the latest decomposition of this entry (the chain step's own launches
+                                  // of ranks <= 64 record none: their consumers wait for the completion word on the device, and
+                                  // an event record is 2-3 µs of host time on the accepted path)
   int done_value = 0;             // … and what the entry's word in icp_proposal::eig_words holds once it is complete (0: none)
   uint64_t stamp = 0;
   DBuf<int> id, aux;
@@ -494,7 +503,7 @@ struct PosteriorEntry {
   DBuf<double> coeffs, M, alpha, V, Vt, S;
   int status_off = 0;  // this entry's 3 ints inside the proposal's status buffer
   ~PosteriorEntry() { if (eig_done) (void)hipEventDestroy(eig_done); }
-  hipEvent_t eigen_event() const { return eig_done_shared ? eig_done_shared : eig_done; }
+  hipEvent_t eigen_event() const { return !eig_event_valid ? nullptr : (eig_done_shared ? eig_done_shared : eig_done); }
   CorrBuffers corr() const { return CorrBuffers{id.p, aux.p, pt.p, keep.p, nhat.p, e.p}; }
 };
 
@@ -512,7 +521,9 @@ struct icp_proposal {
                           // between them so that a speculative decomposition can still read the previous step's
   size_t mpart_half_doubles = 0;
   int mpart_half = 0;
-  PosteriorEntry* mpart_reader[2] = {nullptr, nullptr};  // the entry whose decomposition reads the half (its event is waited for)
+  static constexpr int kMpartRing = 4;  // (a speculative decomposition reads the partials of the step that started it: with four
+                                        // buffers used in turn the writer of a buffer practically never finds its reader still at work)
+  PosteriorEntry* mpart_reader[kMpartRing] = {nullptr, nullptr, nullptr, nullptr};  // the entry whose decomposition reads the buffer
   double* mpart_for_write(int half, hipStream_t st);  // `st` (where the writer runs) waits for that reader first, if it is still at work
   DBuf<double> fscratch;  // (r+1)·r + 8 factorisation scratch (ranks too large for LDS)
   const double* warm_ptr = nullptr;  // eigenvectors of the most recent posterior (inside its memo entry): warm start of the next
@@ -543,6 +554,7 @@ struct icp_proposal {
   PosteriorEntry& posterior(const double* theta, bool want_aux);
   PosteriorEntry* find_entry(const double* theta);
   PosteriorEntry& fresh_entry();
+  void alloc_entry(PosteriorEntry& e);
   void prepare_eigen(PosteriorEntry& e, EigenRequest* rq);
   void ensure_eigen(PosteriorEntry& e);  // enqueue on the context's eigen stream (no-op if done or in flight)
   void await_eigen(PosteriorEntry& e);   // make the context stream wait for it
@@ -577,6 +589,10 @@ struct icp_evaluator {
   icp_evaluator_params prm{};
   StepFront front;  // pre-launched first half of the next step, if any
   int front_parity = 0;
+  // Acceptance estimate of the chain stepped through this evaluator (icp_chain_step): the decomposition of the PROPOSED
+  // state is started speculatively unless next to nothing is being accepted.
+  std::vector<double> last_prop;  // the state the previous merged step proposed
+  double acc_ema = 0.5;
   DBuf<double> target_pts;
   // target-side queries against the CURRENT model surface
   int Kt = 0;              // number of target-side query points (decimated target, or all target vertices for Hausdorff)
@@ -634,8 +650,19 @@ PosteriorEntry* icp_proposal::find_entry(const double* theta) {
 }
 
 // least recently used memo entry, emptied; the caller fills it and sets `valid`
+// device buffers of a memo entry (all entries at proposal creation, see icp_ctx::alloc_slot)
+void icp_proposal::alloc_entry(PosteriorEntry& e) {
+  if (e.M.p) return;
+  const int r = ctx->r, Ka = std::max(K, 1);
+  e.id.alloc(Ka); e.aux.alloc(Ka); e.pt.alloc(3 * (size_t)Ka); e.nhat.alloc(3 * (size_t)Ka); e.e.alloc(3 * (size_t)Ka);
+  e.keep.alloc(Ka);
+  e.coeffs.alloc(r); e.M.alloc((size_t)r * r);
+  e.alpha.alloc(r); e.V.alloc((size_t)r * r); e.Vt.alloc((size_t)r * r); e.S.alloc(r);
+  e.status_off = 3 * (int)(&e - &memo[0]);
+  HIP_OK(hipEventCreateWithFlags(&e.eig_done, hipEventDisableTiming));
+}
+
 PosteriorEntry& icp_proposal::fresh_entry() {
-  const int r = ctx->r;
   PosteriorEntry* lru = nullptr;
   for (int i = 0; i < kPosteriorMemo; ++i) {
     PosteriorEntry& e = memo[i];
@@ -646,14 +673,7 @@ PosteriorEntry& icp_proposal::fresh_entry() {
   }
   if (!lru) fail(ICP_ERR_DEVICE, "internal: every posterior entry is reserved");
   PosteriorEntry& e = *lru;
-  const int Ka = std::max(K, 1);
-  if (!e.M.p) {
-    e.id.alloc(Ka); e.aux.alloc(Ka); e.pt.alloc(3 * (size_t)Ka); e.nhat.alloc(3 * (size_t)Ka); e.e.alloc(3 * (size_t)Ka);
-    e.keep.alloc(Ka);
-    e.coeffs.alloc(r); e.M.alloc((size_t)r * r);
-    e.alpha.alloc(r); e.V.alloc((size_t)r * r); e.Vt.alloc((size_t)r * r); e.S.alloc(r);
-    e.status_off = 3 * (int)(&e - &memo[0]);
-  }
+  alloc_entry(e);
   e.valid = false;
   e.eig_valid = false;
   e.eig_checked = false;
@@ -708,12 +728,17 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
   return e;
 }
 
+void sync_eigen(icp_ctx& c);
+
 double* icp_proposal::mpart_for_write(int half, hipStream_t st) {
   if (PosteriorEntry* rd = mpart_reader[half]) {
     // a cancelled reader (eig_valid withdrawn) may read anything; a finished one has left its status in pinned memory
     // (-1 while in flight): the wait — an API call per step otherwise — is only enqueued for a kept one still at work
     const bool at_work = rd->eig_valid && *(volatile int*)(h_eig + rd->status_off / 3) == -1;
-    if (at_work && rd->eigen_event()) HIP_OK(hipStreamWaitEvent(st, rd->eigen_event(), 0));
+    if (at_work) {
+      if (rd->eigen_event()) HIP_OK(hipStreamWaitEvent(st, rd->eigen_event(), 0));
+      else sync_eigen(*ctx);  // (no event on record: wait on the host — four steps behind, never seen in practice)
+    }
     mpart_reader[half] = nullptr;
   }
   return Mpart.p + (size_t)half * mpart_half_doubles;
@@ -726,6 +751,9 @@ void icp_proposal::prepare_eigen(PosteriorEntry& e, EigenRequest* rq) {
   // the kernel reads all of Vwarm before it writes V, so the two may be the same buffer (a reused memo entry)
   h_eig[e.status_off / 3] = -1;  // in flight; the decomposition stores its status here when it ends
   e.done_value = ++eig_seq;
+  // Every decomposition inherits the (tiny) deviation from orthogonality of the basis it starts from and adds that of its own
+  // first-order correction (<= 1e-11): every 128th starts cold, from the identity, which puts an end to the accumulation.
+  if (((eig_seq + 1) & 127) == 0) warm_valid = false;
   *rq = EigenRequest{e.M.p, warm_valid ? warm_ptr : nullptr, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2, nullptr,
                      h_eig + e.status_off / 3, eig_words.p + e.status_off / 3, e.done_value, ctx->sqrt_lambda.p};
   warm_ptr = e.V.p;
@@ -780,10 +808,12 @@ void icp_proposal::ensure_eigen(PosteriorEntry& e) {
   }
   HIP_OK(hipEventRecord(e.eig_done, es));
   e.eig_done_shared = nullptr;
+  e.eig_event_valid = true;
 }
 
 void icp_proposal::await_eigen(PosteriorEntry& e) {
   if (e.eigen_event()) HIP_OK(hipStreamWaitEvent(ctx->stream, e.eigen_event(), 0));
+  else if (e.eig_valid) sync_eigen(*ctx);  // started by a chain step without an event: wait on the host
 }
 
 // ready / ready_seq: the word the regression launch that fills the current half of Mpart raises when it is done — the
@@ -791,11 +821,11 @@ void icp_proposal::await_eigen(PosteriorEntry& e) {
 // hold the latter back by several µs)
 void icp_proposal::speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur, int splits, int half, const int* ready, int ready_seq,
                                    EigenSpec* spec_out, EigenRequest* rq_out) {
-  if (!e.eig_done) HIP_OK(hipEventCreateWithFlags(&e.eig_done, hipEventDisableTiming));
+  e.eig_event_valid = false;
   ++spec_seq;
   *spec_out = EigenSpec{splits, h_cancel + (spec_seq & 15), spec_seq, ready, ready_seq};
   // warm start: the basis of the current state's posterior (complete, or ahead of this launch on the same stream)
-  const double* warm = cur.eig_valid ? cur.V.p : (warm_valid ? warm_ptr : nullptr);
+  const double* warm = (eig_seq & 127) == 127 ? nullptr : (cur.eig_valid ? cur.V.p : (warm_valid ? warm_ptr : nullptr));  // (see prepare_eigen)
   h_eig[e.status_off / 3] = -1;  // in flight
   e.done_value = ++eig_seq;
   *rq_out = EigenRequest{Mpart.p + (size_t)half * mpart_half_doubles, warm, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2,
@@ -1120,6 +1150,7 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->h_flag[0] = 0;
     ctx->d_done.alloc(4);
     ctx->d_done.fill_bytes(0);
+    for (auto& sl : ctx->slots) ctx->alloc_slot(sl);
     HIP_OK(hipStreamSynchronize(ctx->stream));
     ++g_live_contexts;
     ctx->counted = true;
@@ -1365,7 +1396,7 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     p->work.alloc(eigen_work_doubles(ctx->r));
     p->work.fill_bytes(0);  // holds the completion counter of the eigenvector replay kernel
     p->mpart_half_doubles = (size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1);
-    p->Mpart.alloc(2 * p->mpart_half_doubles);
+    p->Mpart.alloc(icp_proposal::kMpartRing * p->mpart_half_doubles);
     p->fscratch.alloc((size_t)(ctx->r + 1) * ctx->r + 8);
     HIP_OK(hipHostMalloc((void**)&p->h_cancel, sizeof(int) * 16, hipHostMallocDefault));
     for (int i = 0; i < 16; ++i) p->h_cancel[i] = 0;
@@ -1377,6 +1408,7 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     p->eig_words.fill_bytes(0);
     p->h_status.assign(3 * kPosteriorMemo, 0);
     p->memo.reset(new PosteriorEntry[kPosteriorMemo]);
+    for (int i = 0; i < kPosteriorMemo; ++i) p->alloc_entry(p->memo[i]);
     *out = p;
   });
   if (rc != ICP_OK && p) delete p;
@@ -1855,6 +1887,17 @@ namespace {
 
 // give back what a front holds without recording anything (its launches, if any, are harmless: they wrote to a state
 // slot and memo entries that nobody refers to, to the search scratch and to the hints, which may be stale by design)
+void release_front(StepFront& F);
+// A half step launched ahead for an outcome that did not happen.  Its launches may still be running — they write the search
+// scratch, the hints, a state slot and memo entries that the replacement is about to be given — so the step that replaces it
+// must be ordered behind it: it takes the dropped front's own stream (enqueue_front toggles the parity back), where stream
+// order does that, instead of the other one, where nothing would.
+void drop_front(icp_evaluator* e) {
+  if (!e->front.valid) return;
+  const int parity = e->front.parity;
+  release_front(e->front);
+  e->front_parity = parity ^ 1;
+}
 void release_front(StepFront& F) {
   if (F.s) F.s->reserved = false;
   for (int i = 0; i < F.n_props; ++i)
@@ -1884,6 +1927,7 @@ void start_decompositions(icp_ctx& c, int n_props, icp_proposal* const* props, P
   for (int i = 1; i < nn; ++i) need[i]->eig_done_shared = need[0]->eig_done;
   if (collect) {
     if (m_in_flight) HIP_OK(hipStreamSynchronize(c.stream));
+    for (int i = 0; i < nn; ++i) need[i]->eig_event_valid = true;  // (recorded by the caller behind the batch's launch)
     (void)eigen_stream_for(c, collect->stream);
     for (int i = 0; i < nn; ++i) collect->rq.push_back(rqs[i]);
     collect->first.push_back(need[0]);
@@ -1896,13 +1940,19 @@ void start_decompositions(icp_ctx& c, int n_props, icp_proposal* const* props, P
     HIP_OK(hipEventRecord(c.ev_ready, c.stream));
     HIP_OK(hipStreamWaitEvent(es, c.ev_ready, 0));
   }
-  if (!launch_posterior_eigen_pair(es, r, c.sqrt_lambda.p, nn, rqs))  // (ranks > 64: one after the other)
-    for (int i = 0; i < nn; ++i) {
-      need[i]->done_value = 0;
-      launch_posterior_eigen(es, r, rqs[i].M, c.sqrt_lambda.p, rqs[i].Vwarm, rqs[i].V, rqs[i].Vt, rqs[i].S, rqs[i].work, rqs[i].status,
-                             nullptr, rqs[i].host_status);
-    }
-  HIP_OK(hipEventRecord(need[0]->eig_done, es));  // (one event for what was one launch — or two in a row)
+  if (launch_posterior_eigen_pair(es, r, c.sqrt_lambda.p, nn, rqs)) {
+    // completion words: the step's first launch waits for the one it draws from on the device; no event (host time on the
+    // accepted path) — whoever else needs the basis waits for the eigen stream on the host (await_eigen)
+    for (int i = 0; i < nn; ++i) need[i]->eig_event_valid = false;
+    return;
+  }
+  for (int i = 0; i < nn; ++i) {  // (ranks > 64: one after the other)
+    need[i]->done_value = 0;
+    launch_posterior_eigen(es, r, rqs[i].M, c.sqrt_lambda.p, rqs[i].Vwarm, rqs[i].V, rqs[i].Vt, rqs[i].S, rqs[i].work, rqs[i].status,
+                           nullptr, rqs[i].host_status);
+  }
+  HIP_OK(hipEventRecord(need[0]->eig_done, es));  // (one event for two launches in a row)
+  for (int i = 0; i < nn; ++i) need[i]->eig_event_valid = true;
 }
 
 // launches 1-3 of the step (theta_cur --generator/key--> proposal); `key` = z or the proposed state (see StepFront)
@@ -2012,6 +2062,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   if (generator >= 0 && ec[generator]->done_value != 0) {
     b.wait2_flag = props[generator]->eig_words.p + ec[generator]->status_off / 3;
     b.wait2_seq = ec[generator]->done_value;
+    b.hold_regs = *(volatile int*)(props[generator]->h_eig + ec[generator]->status_off / 3) == -1;  // still in flight
   }
   launch_step_begin(F.stream, b);
 
@@ -2054,7 +2105,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
     g.cb[i] = ep[i]->corr();
     g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
     g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];
-    p->mpart_half ^= 1;
+    p->mpart_half = (p->mpart_half + 1) % icp_proposal::kMpartRing;
     g.Mpart[i] = p->mpart_for_write(p->mpart_half, F.stream);
     g.status[i] = p->status.p + ep[i]->status_off;
     g.ustart[i + 1] = g.ustart[i] + g.ntiles * splits[i];
@@ -2145,6 +2196,16 @@ bool chain_step_record(icp_evaluator* e, int n_props, icp_proposal* const* props
   return true;
 }
 
+// ICP_SPECULATION: 0 never, 1 always, unset = adaptive (2): while the chain's running acceptance rate is high
+int speculation_mode() {
+  static const int mode = [] {
+    if (std::getenv("ICP_NO_SPECULATION")) return 0;
+    const char* v = std::getenv("ICP_SPECULATION");
+    return v ? (std::atoi(v) != 0 ? 1 : 0) : 2;
+  }();
+  return mode;
+}
+
 bool front_matches(const StepFront& F, int n_props, icp_proposal* const* props, int generator, const double* theta_cur,
                    const double* key, int r) {
   if (!F.valid || F.n_props != n_props || F.generator != generator) return false;
@@ -2177,7 +2238,7 @@ int icp_chain_step_prelaunch(icp_evaluator* e, int32_t n_props, icp_proposal* co
     require(e != nullptr, "null argument");
     if (n_props == 0) {  // "nothing further": drop a pending half step
       std::lock_guard<std::recursive_mutex> lk0(e->ctx->mu);
-      if (e->front.valid) release_front(e->front);
+      drop_front(e);
       return;
     }
     require(theta_cur && z_or_theta_prop, "null argument");
@@ -2191,7 +2252,7 @@ int icp_chain_step_prelaunch(icp_evaluator* e, int32_t n_props, icp_proposal* co
       for (int j = 0; j < c.r; ++j)
         if (!std::isfinite(z_or_theta_prop[j])) fail(ICP_ERR_NOT_FINITE, "z contains a non-finite value");
     std::lock_guard<std::recursive_mutex> lk(c.mu);
-    if (e->front.valid) release_front(e->front);
+    drop_front(e);
     if (c.pipeline_off) return;
     if (c.r > kStepInlineZ) return;  // (larger ranks stage z in one pinned area: not double-buffered)
     // with several chains in the process the device is not idle during one chain's turn-around, and the launches of a
@@ -2231,13 +2292,17 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     const int r = c.r;
     const double* key = generator >= 0 ? z : theta_prop;
     const bool reuse = n_props <= 2 && front_matches(e->front, n_props, props, generator, theta_cur, key, r);
-    if (e->front.valid && !reuse) release_front(e->front);  // pre-launched for another outcome: dropped
+    if (e->front.valid && !reuse) drop_front(e);  // pre-launched for another outcome: dropped
     per_stage = !reuse && !chain_step_covered(e, n_props, props, generator, theta_cur, theta_prop);
     if (per_stage) return;
     Bound _b(&c, true);
     g_host_timing.start();
 
     for (int i = 0; i < n_props; ++i) props[i]->resolve_speculation(theta_cur);
+    if (!e->last_prop.empty()) {  // did the caller keep the state the previous step proposed?
+      const bool accepted = std::memcmp(e->last_prop.data(), theta_cur, sizeof(double) * (10 + (size_t)r)) == 0;
+      e->acc_ema = 0.9 * e->acc_ema + (accepted ? 0.1 : 0.0);
+    }
     StepFront F;
     struct FrontGuard {  // whatever happens below, the slots of this step are not left reserved
       StepFront* f;
@@ -2256,11 +2321,12 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     for (int i = 0; i < 16; ++i) c.h_res[i] = 0.0;
     for (int i = 0; i < 16; ++i) c.h_status[i] = 0;
 
-    // Off unless ICP_SPECULATION=1: since the steps are pipelined over two streams (a rejected step costs ≈ 45 µs), starting two
-    // decompositions per step costs the rejected two thirds more (host calls, CUs) than it saves the accepted third.
-    static const bool no_spec = std::getenv("ICP_SPECULATION") == nullptr || std::getenv("ICP_NO_SPECULATION") != nullptr;
-    const bool speculate = !no_spec && !c.speculation_off && g_live_contexts.load(std::memory_order_relaxed) <= 2 && n_props > 0 &&
-                           eigen_speculation_supported(r);
+    // Adaptive (speculation_mode): an accepted step finds its basis ≈ 50 µs earlier; a rejected one has paid one launch
+    // (≈ 3 µs of host time, a few CUs for at most one sweep) for nothing — worth it unless next to nothing is accepted
+    // (measured: 8.3k against 7.4k it/s over a chain's first 20 steps, 13.6k against 13.7k at one acceptance in three).
+    const int spec_mode = speculation_mode();
+    const bool speculate = (spec_mode == 1 || (spec_mode == 2 && e->acc_ema >= 0.1)) && !c.speculation_off &&
+                           g_live_contexts.load(std::memory_order_relaxed) <= 2 && n_props > 0 && eigen_speculation_supported(r);
     // test hook: the speculative decompositions wait for a word that never comes, time out and are repeated
     static const int starve = std::getenv("ICP_TEST_STARVE_SPECULATION") ? (1 << 24) : 0;
     const int step_seq = ++c.step_seq;
@@ -2286,21 +2352,19 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     g_host_timing.mark(1);
     // the caller's outcome-independent host work runs beside the device — first of all the pre-launch of the next step's
     // first half, which the device can start as soon as the finish launch above has
-    static const bool hook_late = std::getenv("ICP_HOOK_LATE") != nullptr;  // (A/B switch: hook behind the speculative launches)
-    if (c.idle_fn && !hook_late) c.idle_fn(c.idle_arg);
-    // KL bases of the proposed state's posteriors, in case it is accepted (opt-in): they run on the eigen stream beside
-    // the factorisations and the host's round trip; the next call keeps or cancels them (resolve_speculation)
-    if (speculate) {  // both directions in one launch: they run side by side
+    // KL bases of the proposed state's posteriors, in case it is accepted: they run on the eigen stream beside the
+    // factorisations and the host's round trip; the next call keeps or cancels them (resolve_speculation).  One launch (both
+    // directions side by side), issued BEFORE the caller's hook: the accepted path waits for nothing else.
+    if (speculate) {
       EigenSpec specs[2];
       EigenRequest rqs[2];
       for (int i = 0; i < n_props; ++i) props[i]->speculate_eigen(*ep[i], *ec[i], F.splits[i], F.mpart_half[i], c.d_done.p + 2, step_seq + starve, &specs[i], &rqs[i]);
       const hipStream_t es = eigen_stream_for(c, c.eig_stream);
-      launch_posterior_eigen_pair(es, r, c.sqrt_lambda.p, n_props, rqs);
-      HIP_OK(hipEventRecord(ep[0]->eig_done, es));  // one launch, one event
-      ep[0]->eig_done_shared = nullptr;
-      for (int i = 1; i < n_props; ++i) ep[i]->eig_done_shared = ep[0]->eig_done;
+      launch_posterior_eigen_pair(es, r, c.sqrt_lambda.p, n_props, rqs);  // (no event: completion words, see start_decompositions)
     }
-    if (c.idle_fn && hook_late) c.idle_fn(c.idle_arg);
+    // the caller's outcome-independent host work runs beside the device — first of all the pre-launch of the next step's
+    // first half (under the rejection assumption), which the device can start as soon as the finish launch above has
+    if (c.idle_fn) c.idle_fn(c.idle_arg);
     g_host_timing.mark(2);
     if (eigen_enqueued) {
       if (F.stream != c.stream) HIP_OK(hipStreamSynchronize(F.stream));
@@ -2345,6 +2409,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     s.reserved = false;
     for (int i = 0; i < n_props; ++i) ep[i]->reserved = false;
     front_guard.f = nullptr;
+    e->last_prop.assign(theta_prop, theta_prop + 10 + r);
     g_host_timing.mark(4);
     g_host_timing.end();
   });
@@ -2505,6 +2570,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       Bound _b(&elead, true);
       launch_posterior_eigen_many(eigens.stream, elead.r, (int)eigens.rq.size(), eigens.rq.data());
       for (PosteriorEntry* e0 : eigens.first) HIP_OK(hipEventRecord(e0->eig_done, eigens.stream));
+      // (entries that share e0's event carry eig_done_shared; eig_event_valid is set where the requests were collected)
     }
     int nb = 0;
     for (int b = 0; b < n_chains; ++b) {

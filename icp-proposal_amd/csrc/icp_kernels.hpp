@@ -236,6 +236,8 @@ struct StepBeginArgs {  // launch 1: [propose] -> coefficients -> instance -> se
   // there would hold that step's own launches back.  *wait_error (pinned) is set if the word does not come within 50 ms.
   const int* wait_flag; int wait_seq; int* wait_error;
   const int* wait2_flag; int wait2_seq;  // likewise: the word of the eigen-decomposition the proposal draws from (EigenRequest::done_word)
+  int hold_regs;  // the decomposition is still in flight: use the launch variant that holds the model data in registers across the wait
+                  // (k_step_begin_reg: ≈ 3 µs slower by itself, ≈ 6 µs less behind the wait)
   const double* Qp; const double* ref; const double* mean;
   Pose pose;
   int propose;              // 1: coefficients = a8 from `prop` (prop.z ignored: see zin/z_ptr); 0: coefficients = zin / z_ptr

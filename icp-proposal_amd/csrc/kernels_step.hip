@@ -425,8 +425,8 @@ void launch_step_begin(hipStream_t st, const StepBeginArgs& a_in) {
   if (t_capture) { t_capture->begin = a; t_capture->grid[0] = a.inst_blocks + vblocks; return; }
   ProfScope _ps(st, KID_STEP_BEGIN);
   static const bool no_reg = std::getenv("ICP_BEGIN_STREAMED") != nullptr;  // (A/B switch)
-  if (a.r >= 32 && a.r <= 52 && !no_reg) hipLaunchKernelGGL(k_step_begin_reg<52>, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
-  else if (a.r >= 32 && a.r <= 64 && !no_reg) hipLaunchKernelGGL(k_step_begin_reg<64>, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
+  if (a.hold_regs && a.r >= 32 && a.r <= 52 && !no_reg) hipLaunchKernelGGL(k_step_begin_reg<52>, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
+  else if (a.hold_regs && a.r >= 32 && a.r <= 64 && !no_reg) hipLaunchKernelGGL(k_step_begin_reg<64>, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
   else hipLaunchKernelGGL(k_step_begin, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
 }
 
@@ -505,8 +505,10 @@ void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pin
     ProfScope _ps(st, KID_STEP_BEGIN);
     static const bool no_reg = std::getenv("ICP_BEGIN_STREAMED") != nullptr;  // (A/B switch)
     const int r = caps[0].begin.r;  // (one rank per batch: checked by the caller)
-    if (r >= 32 && r <= 52 && !no_reg) hipLaunchKernelGGL(k_step_begin_batch_reg<52>, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d);
-    else if (r >= 32 && r <= 64 && !no_reg) hipLaunchKernelGGL(k_step_begin_batch_reg<64>, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d);
+    bool hold = false;  // any chain of the batch still waiting for its decomposition
+    for (int b = 0; b < B; ++b) hold = hold || caps[b].begin.hold_regs != 0;
+    if (hold && r >= 32 && r <= 52 && !no_reg) hipLaunchKernelGGL(k_step_begin_batch_reg<52>, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d);
+    else if (hold && r >= 32 && r <= 64 && !no_reg) hipLaunchKernelGGL(k_step_begin_batch_reg<64>, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d);
     else hipLaunchKernelGGL(k_step_begin_batch, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d);
   }
   if (gx[1] > 0) { ProfScope _ps(st, KID_STEP_FILTER); hipLaunchKernelGGL(k_step_filter_batch, dim3(gx[1], B), dim3(kSearchBlock), 0, st, (const StepSearchArgs*)(d + o1)); }
