@@ -796,6 +796,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     const int i = e / r, j = e - i * r;
     LDS_VT(j * ldk + i) = Vwarm ? Vwarm[e] : (i == j ? 1.0 : 0.0);
   }
+  EIG_STAMP(50);
   if (spec.ready) {  // enqueued ahead of its input: wait for the launch that announces it (or for the cancellation).
     // Should that launch not come forward within 5 ms — kernels of different streams forced to run one at a time by a
     // tool, say — give up and say so in the pinned status: the host then repeats the decomposition the ordinary way.
@@ -811,31 +812,73 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (acquire side for the plain loads of the partials below)
   }
-  if (is_poll && __hip_atomic_load(spec.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == spec.seq) s_cancel = 1;
-  for (int e = tid; e < n2 * n2; e += nt) {
-    const int i = e / n2, j = e - i * n2;
-    double v = i == j ? 1e300 : 0.0;
-    if (i < r && j < r) {
-      double mij;
-      if (spec.splits > 0) {  // M = I + Σ_s partial_s, lower triangle of the (r+1)² partials, summed in split order from 0.0
-        const size_t o = (size_t)max(i, j) * (r + 1) + min(i, j), nn = (size_t)(r + 1) * (r + 1);
-        mij = 0.0;
-        int sp = 0;
-        for (; sp + 16 <= spec.splits; sp += 16) {
-          double p[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) p[u] = M[(size_t)(sp + u) * nn + o];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) mij += p[u];
-        }
-        for (; sp < spec.splits; ++sp) mij += M[(size_t)sp * nn + o];
-        if (i == j) mij += 1.0;
-      } else {
-        mij = 0.5 * (M[(size_t)i * r + j] + M[(size_t)j * r + i]);
-      }
-      v = mij / (sqrt_lambda[i] * sqrt_lambda[j]);
+  EIG_STAMP(51);
+  if (is_poll && !spec.ready && __hip_atomic_load(spec.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == spec.seq) s_cancel = 1;
+  if (spec.splits > 0) {
+    // M = I + Σ_s partial_s from the split-K partials of the regression launch (lower triangle of (r+1)² matrices, summed in
+    // split order from 0.0 like the factorisation does).  One 16-byte piece (row i, columns 2jp, 2jp+1) per thread and row
+    // half, every split's load in flight at once: the partials sit in other CUs' L2 slices, and this CU's share of them
+    // (13 × 21 KB at rank 51) is what the step costs — dependent loads took 8-10 µs here, this takes ≈ 2.
+    for (int e = tid; e < n2 * n2; e += nt) {
+      const int i = e / n2, j = e - i * n2;
+      LDS_A(0, i * ld + j) = (i == j && i >= r) ? 1e300 : 0.0;
     }
-    LDS_A(0, i * ld + j) = v;
+    __syncthreads();
+    const size_t nn = (size_t)(r + 1) * (r + 1);
+    const int jp = tid & 31, j0 = 2 * jp;
+    dbl2 acc[2] = {dbl2{0.0, 0.0}, dbl2{0.0, 0.0}};
+    bool live[2];
+    size_t off[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = (tid >> 5) + 32 * h;
+      live[h] = i < r && j0 <= i;
+      off[h] = live[h] ? (size_t)i * (r + 1) + j0 : 0;  // (r + 1 even or odd: the piece is read as two 8-byte halves when unaligned)
+    }
+    const bool aligned = ((r + 1) & 1) == 0;
+    int sp = 0;
+    for (; sp + 8 <= spec.splits; sp += 8) {
+      dbl2 p[8][2];
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double* src = M + (size_t)(sp + q8) * nn + off[h];
+          p[q8][h] = aligned ? *(const dbl2*)src : dbl2{src[0], src[1]};
+        }
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[h] += p[q8][h];
+    }
+    for (; sp < spec.splits; ++sp) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double* src = M + (size_t)sp * nn + off[h];
+        acc[h] += aligned ? *(const dbl2*)src : dbl2{src[0], src[1]};
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (live[h]) {
+        const int i = (tid >> 5) + 32 * h;
+        const double si = sqrt_lambda[i];
+        double v0 = acc[h].x + (i == j0 ? 1.0 : 0.0);
+        v0 = v0 / (si * sqrt_lambda[j0]);
+        LDS_A(0, i * ld + j0) = v0; LDS_A(0, j0 * ld + i) = v0;
+        if (j0 + 1 <= i) {
+          double v1 = acc[h].y + (i == j0 + 1 ? 1.0 : 0.0);
+          v1 = v1 / (si * sqrt_lambda[j0 + 1]);
+          LDS_A(0, i * ld + j0 + 1) = v1; LDS_A(0, (j0 + 1) * ld + i) = v1;
+        }
+      }
+  } else {
+    for (int e = tid; e < n2 * n2; e += nt) {
+      const int i = e / n2, j = e - i * n2;
+      double v = i == j ? 1e300 : 0.0;
+      if (i < r && j < r) v = 0.5 * (M[(size_t)i * r + j] + M[(size_t)j * r + i]) / (sqrt_lambda[i] * sqrt_lambda[j]);
+      LDS_A(0, i * ld + j) = v;
+    }
   }
   __syncthreads();
   if (s_cancel) {  // cancelled (or timed out) before it started: nothing is written

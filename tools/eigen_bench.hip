@@ -93,6 +93,31 @@ int main(int argc, char** argv) {
     int stt; double o; hipMemcpy(&stt, dst3, 4, hipMemcpyDeviceToHost); hipMemcpy(&o, dout, 8, hipMemcpyDeviceToHost);
     printf("tail r=%d: %.1f us/call (status %d, value %.6g)\n", r, ms * 1000 / 20, stt, o);
   }
+  {  // ---- the speculative form: input = split-K partials of the regression launch, ready word already raised, cancel word in pinned memory
+    const int n = r + 1, S = 13;
+    std::vector<double> Mp((size_t)S * n * n, 0.0);
+    for (int sp = 0; sp < S; ++sp)
+      for (int i = 0; i < r; ++i) for (int j = 0; j <= i; ++j) Mp[(size_t)sp * n * n + (size_t)i * n + j] = (M1[(size_t)i * r + j] - (i == j ? 1.0 : 0.0)) / S;
+    double* dMp; int *dready, *hcancel, *hstat;
+    CK(hipMalloc(&dMp, 8 * Mp.size())); CK(hipMemcpy(dMp, Mp.data(), 8 * Mp.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&dready, 64)); CK(hipMemset(dready, 0x01, 64));
+    CK(hipHostMalloc((void**)&hcancel, 64, hipHostMallocDefault)); CK(hipHostMalloc((void**)&hstat, 64, hipHostMallocDefault));
+    hcancel[0] = 0;
+    icp::launch_posterior_eigen(st, r, dM0, dsl, nullptr, dV0, dVt, dS, dwork, dstat + 1); hipStreamSynchronize(st);
+    icp::EigenSpec spec{S, hcancel, 7, dready, 1};
+    float ms = 0; const int reps = 20;
+    icp::launch_posterior_eigen(st, r, dMp, dsl, dV0, dV1, dVt, dS, dwork, dstat + 1, &spec, hstat); hipStreamSynchronize(st);
+    hipEventRecord(a, st);
+    for (int i = 0; i < reps; ++i) icp::launch_posterior_eigen(st, r, dMp, dsl, dV0, dV1, dVt, dS, dwork, dstat + 1, &spec, hstat);
+    hipEventRecord(b, st); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+    int stat[2]; hipMemcpy(stat, dstat, 8, hipMemcpyDeviceToHost);
+    long long s[64]; hipMemcpyFromSymbol(s, HIP_SYMBOL(icp::g_eigen_stamps), sizeof(s));
+    printf("speculative (partials)  r=%d: %.1f us/call, sweeps %d, status %d | staging %.1f wait %.1f assembly %.1f warm %.1f setup %.1f", r, ms * 1000 / reps, stat[0], stat[1],
+           (s[50] - s[0]) * 0.01, (s[51] - s[50]) * 0.01, (s[1] - s[51]) * 0.01, (s[2] - s[1]) * 0.01, (s[3] - s[2]) * 0.01);
+    for (int w = 0; w < stat[0] && w < 12; ++w) printf(" | sweep%d %.1f chk %.1f", w, (s[4 + 2 * w] - (w ? s[3 + 2 * w] : s[3])) * 0.01, (s[5 + 2 * w] - s[4 + 2 * w]) * 0.01);
+    printf(" | final %.1f || replay after the producer's end: sees it %.1f, rounds done %.1f, output written %.1f\n", (s[63] - s[62]) * 0.01,
+           (s[40] - s[63]) * 0.01, (s[41] - s[63]) * 0.01, (s[42] - s[63]) * 0.01);
+  }
   run("cold", dM0, nullptr, dV0);
   run("warm (3% perturbed)", dM1, dV0, dV1);
   run("warm (same matrix)", dM0, dV0, dV1);
