@@ -92,6 +92,7 @@ SIGNATURES = {
                                                C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p), c_double_p,
                                                c_double_p, c_double_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_void_p)]),
     "icp_chain_step_batched_collect": (C.c_int, [C.c_void_p]),
+    "icp_chain_step_batched_abandon": (C.c_int, [C.c_void_p]),
     "icp_chain_step_batched": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                          C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p), c_double_p, c_double_p,
                                          c_double_p, C.POINTER(C.c_int32)]),

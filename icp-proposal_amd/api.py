@@ -375,6 +375,49 @@ def chain_step_batched(evaluators, proposals, theta_cur, generator, z=None, thet
     return out, val, fwd[:, :n], bwd[:, :n], np.array(list(status), dtype=np.int32)
 
 
+class BatchedStepTicket:
+    """icp_chain_step_batched_issue: a batch in flight.  collect() waits for it and returns what chain_step_batched returns;
+    abandon() waits for its launches and drops the step.  Until then the member contexts refuse every other call (ICP_ERR_BUSY)."""
+
+    def __init__(self, evaluators, proposals, theta_cur, generator, z=None, theta_prop=None, launch_ctx=None):
+        B = len(evaluators)
+        n = len(proposals[0])
+        self._n = n
+        self._keep = cur = [_theta(t) for t in theta_cur]
+        self.out = np.zeros((B, cur[0].shape[0]))
+        zs = []
+        for b in range(B):
+            if generator[b] >= 0:
+                zs.append(np.ascontiguousarray(z[b], dtype=np.float64))
+            else:
+                zs.append(np.zeros(1))
+                self.out[b] = _theta(theta_prop[b])
+        self._zs = zs
+        ev = (C.c_void_p * B)(*[e.h for e in evaluators])
+        pr = (C.c_void_p * max(B * n, 1))(*[p.h for ps in proposals for p in ps])
+        gen = (C.c_int32 * B)(*[int(g) for g in generator])
+        dp = nat.c_double_p
+        curp = (dp * B)(*[_d(t) for t in cur])
+        zp = (dp * B)(*[_d(t) for t in zs])
+        outp = (dp * B)(*[_d(self.out[b]) for b in range(B)])
+        self.val, self.fwd, self.bwd = np.zeros(B), np.zeros((B, max(n, 1))), np.zeros((B, max(n, 1)))
+        self.status = (C.c_int32 * B)()
+        self._h = C.c_void_p()
+        rc = nat.lib().icp_chain_step_batched_issue(B, ev, n, pr, gen, curp, zp, outp, _d(self.val), _d(self.fwd), _d(self.bwd), self.status,
+                                                    launch_ctx.h if launch_ctx is not None else None, C.byref(self._h))
+        nat.check(rc, "icp_chain_step_batched_issue")
+
+    def collect(self):
+        h, self._h = self._h, None
+        nat.check(nat.lib().icp_chain_step_batched_collect(h), "icp_chain_step_batched_collect")
+        return self.out, self.val, self.fwd[:, :self._n], self.bwd[:, :self._n], np.array(list(self.status), dtype=np.int32)
+
+    def abandon(self):
+        h, self._h = self._h, None
+        if h:
+            nat.check(nat.lib().icp_chain_step_batched_abandon(h), "icp_chain_step_batched_abandon")
+
+
 def chain_step_prelaunch(evaluator: _Evaluator, proposals, theta_cur, generator: int = -1, z=None, theta_prop=None):
     """icp_chain_step_prelaunch: issue the first launches of the step that a later chain_step with exactly these arguments
     will ask for (typically: the next step under the assumption that the step in flight is rejected).  Never changes

@@ -264,6 +264,9 @@ struct icp_ctx {
   void* idle_arg = nullptr;
   bool counted = false;          // included in g_live_contexts
   bool speculation_off = false;  // a speculative decomposition timed out once (see resolve_speculation): not tried again
+  // member of a batch between icp_chain_step_batched_issue and _collect / _abandon (set and cleared under `mu`, which is NOT
+  // held in between): every other entry point on this context fails with ICP_ERR_BUSY meanwhile
+  bool batch_busy = false;
 
   Profiler prof;
   bool profiling = false;
@@ -335,7 +338,8 @@ namespace {
 struct Bound {  // selects the context's device and (if enabled) its profiler for the calling thread
   // chain_path: the caller is the merged chain step, which orders its two streams itself.  Every other entry point works
   // on `stream` alone and shares scratch with the fronts: it first lets `stream` wait for the last front in flight.
-  explicit Bound(icp_ctx* c, bool chain_path = false) {
+  explicit Bound(icp_ctx* c, bool chain_path = false, bool batch_owner = false) {
+    if (c->batch_busy && !batch_owner) throw IcpError{ICP_ERR_BUSY, "the context belongs to a batch in flight (icp_chain_step_batched_issue): collect or abandon it first"};
     c->bind();
     g_prof = c->profiling ? &c->prof : nullptr;
     if (!chain_path) {
@@ -1007,6 +1011,7 @@ const char* icp_status_string(int status) {
     case ICP_ERR_NOT_FINITE: return "non-finite result";
     case ICP_ERR_NOT_SPD: return "matrix not positive definite";
     case ICP_ERR_EMPTY: return "no points left after the boundary filter";
+    case ICP_ERR_BUSY: return "context busy: part of a batch in flight";
     default: return "unknown status";
   }
 }
@@ -2465,13 +2470,18 @@ namespace {
 // whatever happened, nothing stays reserved or locked; a failed batch leaves its launches to drain
 void batch_release(icp_step_ticket& t) {
   for (auto& it : t.items) {
+    if (!it.batched || !it.e) continue;
+    icp_ctx& c = *it.e->ctx;
+    if (!it.lk.owns_lock()) it.lk = std::unique_lock<std::recursive_mutex>(c.mu);
     if (it.issued) {
+      (void)hipSetDevice(c.device);
       if (t.lead) (void)hipStreamSynchronize(t.lead->stream);
       if (t.finish_stream) (void)hipStreamSynchronize(t.finish_stream);
       release_front(it.F);
       it.issued = false;
     }
-    if (it.lk.owns_lock()) it.lk.unlock();
+    c.batch_busy = false;
+    it.lk.unlock();
   }
 }
 }  // namespace
@@ -2536,6 +2546,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       for (int a = 0; a < b && ok; ++a) ok = !(items[a].batched && items[a].e->ctx == &c);
       if (!ok) continue;
       it.lk = std::unique_lock<std::recursive_mutex>(c.mu);
+      if (c.batch_busy) fail(ICP_ERR_BUSY, "a chain's context already belongs to a batch in flight");
       if (it.e->front.valid || c.front_stream_used) {  // half steps launched ahead by the pipelined entry points: drained
         if (it.e->front.valid) release_front(it.e->front);
         c.bind();
@@ -2552,7 +2563,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
     caps.resize(n_batched > 0 ? n_batched : 1);
     // the decompositions of the chains that moved go out first, together, so that they run while the host prepares the
     // launches (a chain whose posteriors are not on record yet starts its own in enqueue_front)
-    EigenCollect eigens{batch_eigen_stream(lead, &elead), {}, {}};
+    EigenCollect eigens{[&] { std::lock_guard<std::recursive_mutex> lead_lk(lead.mu); return batch_eigen_stream(lead, &elead); }(), {}, {}};
     for (int b = 0; b < n_chains; ++b) {
       Item& it = items[b];
       if (!it.batched) continue;
@@ -2617,7 +2628,10 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
     // ---- one sequence of launches for all of them
     g_batch_timing.mark(0);
     if (nb > 0) {
-      Bound _b(&lead, true);
+      // (the launch context may itself be busy — a member of an earlier batch on the same stream — but its stream and its
+      // argument ring are used under its lock)
+      std::lock_guard<std::recursive_mutex> lead_lk(lead.mu);
+      Bound _b(&lead, true, true);
       const size_t bytes = step_batch_bytes(nb);
       const int turn = (lead.batch_turn = (lead.batch_turn + 1) % icp_ctx::kBatchRing);
       if (bytes > lead.batch_bytes[turn]) {
@@ -2636,6 +2650,10 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
     t.nb = nb;
     t.lead = &lead;
     g_batch_timing.mark(1);
+    // no mutex is held across the API boundary: the member contexts are marked busy instead (other entry points fail with
+    // ICP_ERR_BUSY until the ticket is collected or abandoned — by any thread)
+    for (auto& it : items)
+      if (it.lk.owns_lock()) { it.e->ctx->batch_busy = true; it.lk.unlock(); }
   });
   if (rc != ICP_OK) {
     if (tk) { batch_release(*tk); delete tk; }
@@ -2667,7 +2685,8 @@ int icp_chain_step_batched_collect(icp_step_ticket* tk) {
       Item& it = items[b];
       if (!it.batched) continue;
       icp_ctx& c = *it.e->ctx;
-      Bound _b(&c, true);
+      it.lk = std::unique_lock<std::recursive_mutex>(c.mu);
+      Bound _b(&c, true, true);
       volatile int* flag = c.h_flag;
       const auto t_start = std::chrono::steady_clock::now();
       long spins = 0;
@@ -2702,6 +2721,8 @@ int icp_chain_step_batched_collect(icp_step_ticket* tk) {
         for (int i = 0; i < n_props; ++i) it.F.ep[i]->reserved = false;
       }
       it.issued = false;
+      c.batch_busy = false;
+      it.lk.unlock();
     }
     g_batch_timing.mark(3);
     if (g_batch_timing.on) { ++g_batch_timing.calls; g_batch_timing.chains += nb; }
@@ -2722,6 +2743,13 @@ int icp_chain_step_batched_collect(icp_step_ticket* tk) {
     if (status[b] != ICP_OK && status[b] != ICP_ERR_EMPTY && first_bad == ICP_OK) first_bad = status[b];
   delete tk;
   return first_bad;
+}
+
+int icp_chain_step_batched_abandon(icp_step_ticket* tk) {
+  if (!tk) return ICP_ERR_INVALID_ARG;
+  batch_release(*tk);  // waits for the batch's launches, gives back what they hold; nothing of the step is recorded
+  delete tk;
+  return ICP_OK;
 }
 
 int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props,

@@ -46,7 +46,8 @@ typedef enum {
   ICP_ERR_DEVICE = -2,      /* HIP runtime / no device / out of memory (icp_last_error() has the HIP string) */
   ICP_ERR_NOT_FINITE = -3,  /* a result is NaN (the Scalismo chain throws on NaN transition probabilities) */
   ICP_ERR_NOT_SPD = -4,     /* a normal-equation matrix failed to factor */
-  ICP_ERR_EMPTY = -5        /* boundary-aware evaluator dropped every point (reference: empty .max throws) */
+  ICP_ERR_EMPTY = -5,       /* boundary-aware evaluator dropped every point (reference: empty .max throws) */
+  ICP_ERR_BUSY = -6         /* the context is part of a batch between icp_chain_step_batched_issue and _collect / _abandon */
 } icp_status;
 
 /* api/other/IcpProjectionDirection.scala:19-25.  ModelAndTargetSampling is not a proposal direction: the
@@ -270,8 +271,9 @@ ICP_API int icp_chain_step_batched(int32_t n_chains, icp_evaluator *const *evalu
 /* The same in two halves, for a caller that keeps two batches in flight (the decompositions of one run beside the
  * launches of the other; the C++ harness does): _issue returns when the batch's work is on the device, _collect waits for
  * it and writes the outputs named at _issue.  Everything passed to _issue by pointer (states, z, outputs) must stay valid
- * until _collect; the pointer ARRAYS themselves are copied.  Both calls of a ticket come from one thread; a ticket is
- * consumed by _collect, and the contexts of its chains accept no other call in between.  launch_ctx (may be NULL: the
+ * until _collect; the pointer ARRAYS themselves are copied.  A ticket is consumed by _collect or by _abandon (either may
+ * come from any thread; no lock is held in between); until then every other entry point on a member context fails with
+ * ICP_ERR_BUSY.  _abandon waits for the batch's launches and drops the step (nothing of it is recorded).  launch_ctx (may be NULL: the
  * first chain's context) names the context whose stream carries the launches: two batches given the SAME launch_ctx run
  * their launches one behind the other while the decompositions of the second run beside the launches of the first — at
  * most four tickets per launch_ctx at a time, collected in the order they were issued. */
@@ -282,6 +284,7 @@ ICP_API int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator *const 
                                          double *log_value_prop, double *fwd, double *bwd, int32_t *status,
                                          icp_ctx *launch_ctx, icp_step_ticket **ticket);
 ICP_API int icp_chain_step_batched_collect(icp_step_ticket *ticket);
+ICP_API int icp_chain_step_batched_abandon(icp_step_ticket *ticket);
 
 /* ---------------------------------------------------------------- instrumentation (bench.py's roofline leg)
  * Between start and stop every kernel the context launches is bracketed by HIP events on the context stream;

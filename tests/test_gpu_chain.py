@@ -328,3 +328,93 @@ def test_batched_chains_with_pose_proposals_and_one_icp_direction(pkg, femur50):
         leaves |= set(single[b][:, 2].astype(int))
     assert leaves & {3, 4, 5, 6, 7, 8} and 0 in leaves and 2 in leaves   # pose walks, the ICP proposal, the shape walk
     [c.close() for c in chains]; [c.close() for c in ctxs]
+
+
+def _chain_objects(pkg, ctx, r, tp):
+    props = [pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, pkg.TargetSampling, True, decimatedTargetPoints=tp),
+             pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, pkg.ModelSampling, True, decimatedTargetPoints=tp)]
+    ev = pkg.IndependentPointDistanceEvaluator(ctx, 0.0, 2.0, pkg.ModelToTargetEvaluation, 4 * r, decimatedTargetPoints=tp)
+    return ev, props
+
+
+def test_batched_ticket_marks_contexts_busy_and_can_be_abandoned(pkg, femur50):
+    """Between icp_chain_step_batched_issue and _collect / _abandon no mutex is held: the member contexts answer every other
+    entry point with ICP_ERR_BUSY; an abandoned ticket leaves them usable and records nothing (the same step, issued again
+    and collected, gives the values of a fresh context)."""
+    model, target = femur50
+    r = model.rank
+    rng = np.random.default_rng(11)
+    tp = pkg.data.decimated_point_subset(target, 2 * r)
+    B = 2
+    ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
+    objs = [_chain_objects(pkg, c, r, tp) for c in ctxs]
+    thetas = []
+    for b in range(B):
+        t = pkg.initial_parameters(model)
+        t[10:] = 0.3 * rng.normal(size=r)
+        thetas.append(t)
+    zs = [rng.normal(size=r) for _ in range(B)]
+    gens = [0, 1]
+    ref_ctx = pkg.IcpContext(model, target, device=0)
+    want = []
+    for b in range(B):
+        ev, props = _chain_objects(pkg, ref_ctx, r, tp)
+        want.append(pkg.chain_step(ev, props, thetas[b], gens[b], z=zs[b]))
+        ev.close(); [p.close() for p in props]
+    ref_ctx.close()
+    tk = pkg.BatchedStepTicket([o[0] for o in objs], [o[1] for o in objs], thetas, gens, z=zs)
+    for c in ctxs:
+        with pytest.raises(pkg._native.IcpNativeError) as ei:
+            c.transformedMesh(thetas[0])
+        assert ei.value.status == -6
+    with pytest.raises(pkg._native.IcpNativeError) as ei:  # a second batch over a busy context is refused, too
+        pkg.BatchedStepTicket([objs[0][0]], [objs[0][1]], [thetas[0]], [0], z=[zs[0]])
+    assert ei.value.status == -6
+    tk.abandon()
+    assert ctxs[0].transformedMesh(thetas[0]).shape == (model.n_points, 3)
+    out, val, fwd, bwd, status = pkg.BatchedStepTicket([o[0] for o in objs], [o[1] for o in objs], thetas, gens, z=zs).collect()
+    assert list(status) == [0, 0]
+    for b in range(B):
+        assert np.abs(out[b] - want[b][0]).max() <= 1e-9 and abs(val[b] - want[b][1]) <= 1e-9 * abs(want[b][1])
+        assert np.allclose(fwd[b], want[b][2], rtol=1e-9, atol=0) and np.allclose(bwd[b], want[b][3], rtol=1e-9, atol=0)
+    for ev, props in objs:
+        ev.close(); [p.close() for p in props]
+    for c in ctxs:
+        c.close()
+
+
+def test_dropped_half_step_is_ordered_before_its_replacement(pkg):
+    """A half step launched ahead for an outcome that does not happen (icp_chain_step_prelaunch with a wrong guess) writes the
+    same scratch, hints, state slot and memo entries as the step that replaces it.  The replacement must run BEHIND it — also
+    when it waits for no decomposition (a random-walk proposal, generator < 0) and the dropped launches are long (58k-vertex
+    target): every value must equal what a context that never saw the dropped half step computes."""
+    model, target = pkg.data.synthetic_femur_target()  # the metric workload: 58,322 vertices
+    r = model.rank
+    rng = np.random.default_rng(23)
+    tp = pkg.data.decimated_point_subset(target, 2 * r)
+    ctx, ref_ctx = pkg.IcpContext(model, target, device=0), pkg.IcpContext(model, target, device=0)
+    ev, props = _chain_objects(pkg, ctx, r, tp)
+    rev, rprops = _chain_objects(pkg, ref_ctx, r, tp)
+    cur = pkg.initial_parameters(model)
+    cur[10:] = 0.2 * rng.normal(size=r)
+    for it in range(12):
+        z = rng.normal(size=r)
+        gen = it % 2
+        got = pkg.chain_step(ev, props, cur, gen, z=z)
+        want = pkg.chain_step(rev, rprops, cur, gen, z=z)
+        assert np.array_equal(got[0], want[0]) and got[1] == want[1]
+        # the caller "expects a rejection" and launches the next ICP half step ahead …
+        pkg.chain_step_prelaunch(ev, props, cur, 1 - gen, z=rng.normal(size=r))
+        # … but the step is accepted and the next proposal is a random walk from the NEW state: the half step is dropped
+        cur = got[0].copy()
+        rw = cur.copy()
+        rw[10:] += 0.05 * rng.normal(size=r)
+        got = pkg.chain_step(ev, props, cur, -1, theta_prop=rw)
+        want = pkg.chain_step(rev, rprops, cur, -1, theta_prop=rw)
+        assert got[1] == want[1], (it, got[1], want[1])
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+        pm, pw = props[1].icpPosterior(rw, with_aux=False), rprops[1].icpPosterior(rw, with_aux=False)
+        assert np.array_equal(pm.corr_id, pw.corr_id) and np.array_equal(pm.corr_point, pw.corr_point)
+    for e_, ps in ((ev, props), (rev, rprops)):
+        e_.close(); [p.close() for p in ps]
+    ctx.close(); ref_ctx.close()
