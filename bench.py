@@ -1,27 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — MH iterations/s of the closest-point-proposal path on MI355X (BASELINE.json metric).
 
-One "step" = one Metropolis–Hastings step of the femur configuration of the reference's
-apps/femur/IcpProposalRegistration.scala:59-85 (0.9 ICP mixture [TargetSampling + ModelSampling, K = 2·rank,
-σt = 10, σn = 5, step 0.1] + 0.1 random walk; prior × independent Gaussian(0, 2) likelihood on 4·rank points)
-against the synthetic ~50k-vertex target of BASELINE.json configs[1] (the bundled femur target
-subdivided 6-way per edge, 58,322 vertices / 116,640 triangles, seeded 0.05 mm jitter).  Model, target and all
-chain state are resident in HBM before the timed region starts; the per-step host<->device traffic is the
-(10 + r)-double state vector in and a handful of doubles out.
+One "step" = one Metropolis–Hastings step of the reference's experiment configuration named by --config:
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): every rank runs an independent chain on its own GPU
-(weak scaling, no data-path collective); the fixed-size per-step log records are gathered ONCE with an RCCL
-all_gather at log-write time, inside the timed region.
+  1 (default, the configuration BASELINE.json's metric is quoted on)  apps/femur/IcpProposalRegistration.scala:59-85:
+      femur 50-basis GPMM, 0.9 ICP mixture [TargetSampling + ModelSampling, K = 2·rank, σt = 10, σn = 5, step 0.1] + 0.1 random
+      walk; prior × independent Gaussian(0, 2) likelihood on 4·rank points; synthetic ~50k-vertex target (the
+      bundled femur target subdivided 6-way per edge, 58,322 vertices / 116,640 triangles, seeded 0.05 mm jitter)
+  2  apps/femur/RunMHRandomInitComparison.scala:54-61: femur 100-basis GPMM, every model point a sample point (K = N = 1622),
+      ICP(ModelSampling), SymmetricEvaluation; same 58k target; chain i > 0 starts from c ~ N(0, 0.1·I)
+  3  apps/bfm/BfmFittingPartial.scala:62-83 on the BFM-sized synthetic stand-in (N = 28,561, rank 200, partial target with a
+      boundary): 0.4 pose + 0.55 ICP(ModelSampling, K = 400) + 0.05 random walk, full-mesh Hausdorff evaluator
 
-Prints ONE JSON line (rank 0).  Extra legs after the timed region (rank 0, N = 1 only): the roofline of the
-dominant kernel measured with HIP events on the library's stream, and the CPU baseline (oracle/, "port", 1 core)
-on a bounded sample of the same workload.
+Model, target and all chain state are resident in HBM before the timed region starts; the per-step host<->device traffic is
+the (10 + r)-double state vector in and a handful of doubles out.
+
+Multi-GPU (--gpus N): every rank runs an independent chain on its own GPU (weak scaling, no data-path collective); the
+fixed-size per-step log records are gathered ONCE with an RCCL all_gather at log-write time, inside the timed region.  Launched
+by `python -m torch.distributed.run` the ranks are taken from the environment; launched plainly (`python bench.py --gpus N`) this
+process — which never touches a GPU — starts the N rank processes itself and relays rank 0's line.
+
+Prints ONE JSON line (rank 0).  Extra legs after the timed region (rank 0, N = 1 only): per-kernel time with HIP events on the
+library's streams -> `roofline` of the time-dominant kernel (+ the whole step and the distance kernel against both rooflines),
+and the CPU baselines B1 / B2 of BASELINE.md §3 (oracle/, bounded samples).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,38 +39,186 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
-DOMINANT = "k_step_filter"
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+F32_VECTOR_TFLOPS = 157.3  # same guide: peak FP32 vector (the filters run on packed f32; the exact resolves in f64)
+F64_VECTOR_TFLOPS = 78.6   # AMD's public MI355X figure for vector FP64 (not in the local guide; SURVEY.md §8d uses it)
+METRIC = "ICP-proposal MH iterations/sec (femur GPMM r=50, ~50k-vtx target)"
 
 
+# ---------------------------------------------------------------------------------------------- launcher
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: N child processes, one per GPU, over 127.0.0.1.
+    This parent makes no GPU call (it only spawns, waits and relays)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rk in range(args.gpus):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rk == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(rk, rc) for rk, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit("rank processes failed: " + ", ".join(f"rank {rk} -> exit {rc}" for rk, rc in bad))
+
+
+def selftest_launcher_rank():
+    """Body of a rank under --selftest-launcher (CPU, gloo): exercises the launcher's environment, the barrier-bracketed timing
+    and the gather; prints the same kind of line from rank 0.  Used by tests/test_bench_launcher_cpu.py (no GPU there)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec = np.full((5, 8), float(rank))
+    dist.barrier()
+    t0 = time.perf_counter()
+    t = torch.from_numpy(rec)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ok = all(float(o[0, 0]) == float(k) for k, o in enumerate(out))
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "gather_ok": ok, "max_s": float(dt.item())}))
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
+# ---------------------------------------------------------------------------------------------- workloads
+def build_workload(pkg, config, subdiv, fused):
+    """-> dict(model, target, setup, name, init(gid))"""
+    if config == 1:
+        model, target = pkg.data.synthetic_femur_target(n_subdiv=subdiv)
+        setup = pkg.femur_icp_proposal_registration(model, target, fused=fused)
+        name = ("BASELINE.json configs[1]: femur 50-basis GPMM (N=%d, rank %d) vs synthetic target M=%d vertices / %d triangles; "
+                "0.9 ICP(Target+Model sampling, K=%d) + 0.1 random walk; prior x independent Gaussian(0,2) on %d points"
+                % (model.n_points, model.rank, target.n_points, target.n_cells, 2 * model.rank, 4 * model.rank))
+    elif config == 2:
+        model, target = pkg.data.synthetic_femur_target(n_subdiv=subdiv, n_components=100)
+        setup = pkg.femur_random_init_comparison(model, target, fused=fused)
+        name = ("BASELINE.json configs[2] (one chain per GPU): femur 100-basis GPMM (N=%d, rank %d) vs synthetic target M=%d vertices / %d "
+                "triangles; ICP(ModelSampling, K = N = %d); prior x independent Gaussian(0,2), SymmetricEvaluation on all %d points"
+                % (model.n_points, model.rank, target.n_points, target.n_cells, model.n_points, model.n_points))
+    elif config == 3:
+        model = pkg.data.synthetic_face_model()
+        target = pkg.data.synthetic_partial_target(model, seed=7)
+        setup = pkg.bfm_fitting_partial(model, target, evaluator="hausdorff", fused=fused)
+        name = ("BASELINE.json configs[3]: BFM-face12-sized synthetic stand-in (N=%d, T=%d, rank %d) vs partial target M=%d vertices / %d "
+                "triangles (with boundary); 0.4 pose + 0.55 ICP(ModelSampling, K=%d) + 0.05 random walk; prior x full-mesh Hausdorff "
+                "evaluator" % (model.n_points, model.n_cells, model.rank, target.n_points, target.n_cells, 2 * model.rank))
+    else:
+        raise SystemExit("--config must be 1, 2 or 3")
+
+    def init(gid):
+        if config == 2:  # every chain of the random-init comparison starts from a random shape (chain 0 from the mean)
+            return pkg.random_initial_parameters(model, gid)
+        th = pkg.initial_parameters(model)
+        if gid > 0:  # apps/femur/RandomSamplesFromModel.scala:28-35: chain i > 0 starts from c ~ N(0, 0.1·I)
+            th[10:] = np.random.default_rng(1024 + gid).normal(size=model.rank) * np.sqrt(0.1)
+        return th
+    return dict(model=model, target=target, setup=setup, name=name, init=init)
+
+
+def algorithmic_step(model, target, setup, target_has_boundary):
+    """ALGORITHMIC bytes and flops of one MH step whose proposal came from the ICP mixture (brute-force
+    definition: every operand read once per step; w = 8)."""
+    N, T, r = model.n_points, model.n_cells, model.rank
+    M, Tt = target.n_points, target.n_cells
+    dirs = len(setup.icp)
+    K = max([p.get("n_model_ids", 0) or np.asarray(p.get("target_pts", np.zeros((0, 3)))).reshape(-1, 3).shape[0] for p in setup.icp] + [0])
+    e = setup.eval
+    b = 3 * N * r * 8 + 3 * N * 8 * 2 + 3 * T * 4 + 3 * Tt * 4 + 3 * M * 8 + dirs * K * 3 * r * 8 + 3 * r * r * 8
+    f = 2 * 3 * N * r + 30 * T + 12 * N
+    for p in setup.icp:
+        if p["direction"] == 1:
+            f += 8 * np.asarray(p["target_pts"]).reshape(-1, 3).shape[0] * N
+        else:
+            f += 60 * p["n_model_ids"] * Tt + (8 * p["n_model_ids"] * M if target_has_boundary else 0)
+    f += dirs * (2 * 3 * K * r * r + 18 * K * r) + dirs * (r ** 3 / 3 + 10 * r ** 3)
+    if e["kind"] == 1:
+        f += 60 * (N * Tt + M * T)
+    else:
+        if e["mode"] in (0, 2):
+            f += 60 * e["n_model_ids"] * Tt
+        if e["mode"] in (1, 2):
+            f += 60 * np.asarray(e["target_pts"]).reshape(-1, 3).shape[0] * T
+    return float(b), float(f)
+
+
+def kernel_algorithmic_bytes(name, model, target, setup):
+    """Algorithmic bytes of ONE launch of the named kernel (what it has to read and write at least once)."""
+    N, T, r = model.n_points, model.n_cells, model.rank
+    M, Tt = target.n_points, target.n_cells
+    dirs = len(setup.icp)
+    Km = max([p.get("n_model_ids", 0) for p in setup.icp] + [0])
+    Kt = max([np.asarray(p.get("target_pts", np.zeros((0, 3)))).reshape(-1, 3).shape[0] for p in setup.icp if p["direction"] == 1] + [0])
+    e = setup.eval
+    Ke = e["n_model_ids"]
+    Ksurf = max(Km, Ke)
+    splits = lambda k: min(64, max(1, (k + 7) // 8))
+    n1 = (r + 1) * (r + 1)
+    if name == "k_step_filter":      # target vertices + triangle ids + surface queries; the TargetSampling search: model vertices + its queries
+        return 3 * M * 8 + 3 * Tt * 4 + Ksurf * 24 + (3 * N * 8 + Kt * 24 if Kt else 0)
+    if name == "k_step_begin":       # scaled basis + reference + mean in, instance out, V and P of the proposal, query records
+        return 3 * N * r * 8 + 3 * N * 8 * 3 + 2 * r * r * 8 + Ksurf * 24
+    if name == "k_step_resolve":     # query points, winners' triangles (3 corners), correspondence records out
+        return (Ksurf + Kt) * (24 + 72) + (Km + Kt) * 100
+    if name == "k_step_regression":  # gathered basis rows + correspondence records in, split-K partials out (lower-triangle tiles)
+        return sum((Km if p["direction"] == 0 else Kt) * (3 * r * 8 + 56) + splits(Km if p["direction"] == 0 else Kt) * n1 * 8 * 0.625 for p in setup.icp)
+    if name == "k_step_finish":      # partials in (lower triangle), M out, M + G^-1 for the two tails of every posterior
+        return sum(splits(Km if p["direction"] == 0 else Kt) * n1 * 8 * 0.5 + r * r * 8 * 2 for p in setup.icp) + 2 * r * r * 8
+    if name.startswith("k_posterior_eigen"):  # per launch (both directions): M, warm basis in, V, Vt, S out, rotation log out and in
+        return dirs * (r * r * 8 * 4 + 3 * 51 * (r + 1) * 8 * 2)
+    if name == "k_surface_filter":
+        return 3 * M * 8 + 3 * Tt * 4 + Ksurf * 24
+    if name == "k_vertex_filter":
+        return 3 * M * 8 + Ksurf * 24
+    return None
+
+
+# ---------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[i] that fits one GPU per rank: 1 (metric configuration), 2, 3")
     ap.add_argument("--profile-steps", type=int, default=300, help="steps of the HIP-event roofline leg (0 = skip)")
-    ap.add_argument("--cpu-steps", type=int, default=16, help="steps of the CPU-oracle baseline leg (0 = skip)")
-    ap.add_argument("--subdiv", type=int, default=6, help="edge subdivision of the synthetic target (6 -> 58,322 vertices)")
+    ap.add_argument("--cpu-steps", type=int, default=16, help="steps of the B2 leg of the CPU baseline (B1 runs 4x as many; 0 = skip)")
+    ap.add_argument("--subdiv", type=int, default=6, help="edge subdivision of the synthetic femur target (6 -> 58,322 vertices)")
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="independent chains per GPU, stepped in lockstep through icp_chain_step_batched (default 1 = the BASELINE.json "
                          "configuration; more is the RunMHRandomInitComparison-style many-chains job on fewer GPUs)")
     ap.add_argument("--many-chains", type=int, default=32,
-                    help="extra leg after the timed region (1 GPU, 1 chain per GPU only): aggregate rate of this many chains on the GPU "
+                    help="extra leg after the timed region (1 GPU, 1 chain per GPU, config 1 only): aggregate rate of this many chains on the GPU "
                          "stepped through icp_chain_step_batched, reported as `many_chains` (0 = skip)")
     ap.add_argument("--fused", type=int, default=2, choices=[0, 1, 2],
                     help="host<->device call pattern per step: 0 per-method calls, 1 propose + icp_chain_eval_step, 2 one icp_chain_step")
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_launcher and args.gpus > 1:
+        launch_ranks(args, sys.argv[1:])
+        return
+    if args.selftest_launcher:
+        selftest_launcher_rank()
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
 
     dist = torch = None
-    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run the RCCL path is taken even with one rank
+    if under_launcher:  # under a launcher the RCCL path is taken even with one rank
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
         torch.cuda.set_device(local_rank)
@@ -70,29 +227,25 @@ def main():
     import __graft_entry__ as graft
     pkg = graft.load_package()
 
-    # ---- workload (identical on every rank; synthetic target built from the bundled femur data)
-    model, target = pkg.data.synthetic_femur_target(n_subdiv=args.subdiv)
+    # ---- workload (identical on every rank; synthetic, built from the bundled femur data or procedurally)
+    wl = build_workload(pkg, args.config, args.subdiv, args.fused)
+    model, target, setup = wl["model"], wl["target"], wl["setup"]
     r = model.rank
     B = max(1, args.chains_per_gpu)
     ctxs = [pkg.IcpContext(model, target, device=local_rank) for _ in range(B)]  # (a context holds one chain's scratch)
     ctx = ctxs[0]
-    setup = pkg.femur_icp_proposal_registration(model, target, fused=args.fused)
-    theta0 = pkg.initial_parameters(model)
     chains = []
     for i in range(B):
         gid = rank * B + i  # chain id within the job
-        th = theta0.copy()
-        if gid > 0:  # apps/femur/RandomSamplesFromModel.scala:28-35: chain i > 0 starts from c ~ N(0, 0.1·I)
-            th[10:] = np.random.default_rng(1024 + gid).normal(size=r) * np.sqrt(0.1)
-        chains.append(pkg.SamplingRegistration(ctxs[i], setup, th, seed=1024 + gid))
+        chains.append(pkg.SamplingRegistration(ctxs[i], setup, wl["init"](gid), seed=1024 + gid))
     chain = chains[0]
-    rec_len = 4 + 10 + r
 
-    def run_chains(n):
+    def run_chains(n, want_records=True):
         """n steps of every chain of this rank -> records [B * n, rec_len]"""
         if B == 1:
-            return chain.run(n)
-        return np.concatenate(pkg.run_chains_batched(chains, n))
+            return chain.run(n, want_records=want_records)
+        rec = pkg.run_chains_batched(chains, n, want_records=want_records)
+        return np.concatenate(rec) if want_records else None
 
     def barrier():
         if dist is not None:
@@ -129,10 +282,11 @@ def main():
         dt = float(tt.item())
     n_acc = int(rec[:, 1].sum())
     n_icp = int((rec[:, 2] < 2).sum())
+    rate = world * B * args.steps / dt
 
     line = {
-        "metric": "ICP-proposal MH iterations/sec (femur GPMM r=50, ~50k-vtx target)",
-        "value": world * B * args.steps / dt,
+        "metric": METRIC,
+        "value": rate,
         "unit": "iterations/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -144,9 +298,8 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE.json configs[1]: femur 50-basis GPMM (N=%d, rank %d) vs synthetic target M=%d vertices / %d triangles; "
-                        "%d chain%s per GPU; 0.9 ICP(Target+Model sampling, K=%d) + 0.1 random walk; prior x independent Gaussian(0,2) on %d points"
-                        % (model.n_points, r, target.n_points, target.n_cells, B, "" if B == 1 else "s (lockstep, icp_chain_step_batched)", 2 * r, 4 * r),
+            "workload": wl["name"] + "; %d chain%s per GPU" % (B, "" if B == 1 else "s (lockstep, icp_chain_step_batched)"),
+            "baseline_config_index": args.config,
             "chains_per_gpu": B,
             "calls_per_step": {0: "per-method", 1: "propose + icp_chain_eval_step", 2: "icp_chain_step"}[args.fused] if B == 1 else "icp_chain_step_batched",
             "chain_ms": 1e3 * t_chain,
@@ -159,81 +312,29 @@ def main():
     }
 
     if rank == 0 and world == 1:
-        # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on (the library's stream)
+        # ---- per-kernel time: HIP events on the streams the kernels run on (the library's streams) -> roofline block
         if args.profile_steps > 0:
-            ctx.profile_start(max_launches=64 * args.profile_steps + 1024)   # (a batch's launches go out on the first chain's context)
-            if B == 1:
-                chain.run(args.profile_steps, want_records=False)
-            else:
-                pkg.run_chains_batched(chains, args.profile_steps, want_records=False)
-            stats = ctx.profile_stop()
-            if DOMINANT in stats:
-                k = stats[DOMINANT]
-                n_queries = setup.eval["n_model_ids"]  # ids 0..4r-1 (the proposal's 0..2r-1 are a subset, shared)
-                # algorithmic bytes per launch: target vertices 3·M·8 + target triangles 3·Tt·4 + queries K·3·8
-                alg_bytes = 3 * target.n_points * 8 + 3 * target.n_cells * 4 + n_queries * 24
-                if DOMINANT == "k_step_filter":  # the merged launch also holds the TargetSampling search: model vertices + its queries
-                    alg_bytes += 3 * model.n_points * 8 + 2 * r * 24
-                chains_per_launch = 1.0
-                if B > 1:  # one launch holds the searches of a group of chains: units per launch = chain steps / launches
-                    chains_per_launch = B * args.profile_steps / max(k["calls"], 1)
-                    alg_bytes = int(alg_bytes * chains_per_launch)
-                avg_s = k["avg_us"] * 1e-6
-                achieved = alg_bytes / avg_s / 1e9
-                traffic = None
-                tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-                if os.path.exists(tfile) and B == 1:
-                    traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-                line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": DOMINANT,
-                                    "avg_launch_us": k["avg_us"], "launches": k["calls"], "algorithmic_bytes": alg_bytes,
-                                    "chains_per_launch": chains_per_launch,
-                                    "note": "one chain per launch: the filter is a chain of latencies (spheres + queries in, patch test, sphere tests, hits out), "
-                                            "not a stream; HBM fraction reported as north_star asks (more chains per launch: --chains-per-gpu)"}
-                line["kernel_us_per_step"] = {name: round(s["total_ms"] * 1e3 / args.profile_steps, 2) for name, s in stats.items()}
-                line["kernel_us_per_step_note"] = ("HIP events around each launch (these add ~3 us per launch); a step's launches alternate between two "
-                                                   "streams and overlap the previous step's finish launch; k_step_begin includes the time it waits ON THE "
-                                                   "DEVICE for that launch to start or for the eigen-decomposition it draws from (k_posterior_eigen, side stream)")
-        # ---- CPU baseline: the oracle's chain (same math, brute force, 1 thread) on a bounded sample
+            try:
+                line["roofline"] = roofline_leg(pkg, args, wl, ctx, chains, B, rate, line)
+            except Exception as e:  # the headline line is printed whatever happens in the extra legs
+                line["roofline_error"] = str(e)[:300]
+        # ---- CPU baselines B1 / B2 on bounded samples of the same workload
         if args.cpu_steps > 0 and B == 1:
-            from oracle import oracle as O
-            om, ot = O.OracleModel.from_model(model), O.OracleMesh(target.points, target.cells)
-            icp = [O.proposal_params(p["step"], p["sigma_t"], p["sigma_n"], p["direction"], p.get("boundary_aware", True),
-                                     n_model_ids=p.get("n_model_ids", 0), target_pts=p.get("target_pts")) for p in setup.icp]
-            e = setup.eval
-            ep = O.evaluator_params(e["kind"], e["mode"], n_model_ids=e["n_model_ids"], target_pts=e["target_pts"],
-                                    p0=e["gauss_mean"], p1=e["gauss_sigma"], p2=e["exp_rate"])
-            cfg = O.chain_config(icp, [p.get("weight", 0.5) for p in setup.icp], setup.w_icp, setup.w_rw, setup.rw_sigma, ep)
-            t1 = time.perf_counter()
-            acc_o, comp_o, _, states_o = O.run_chain(om, ot, cfg, theta0, 1024, args.cpu_steps)
-            cdt = time.perf_counter() - t1
-            # the first cpu_steps records of a fresh GPU chain must reproduce the oracle's decisions
-            chk = pkg.SamplingRegistration(ctx, setup, theta0, seed=1024)
-            crec = chk.run(args.cpu_steps)
-            same = bool(np.array_equal(crec[:, 1].astype(np.uint8), acc_o)) and \
-                float(np.abs(crec[:, 14:] - states_o[:, 10:]).max()) <= 1e-5 * max(float(np.abs(states_o[:, 10:]).max()), 1e-30)
-            chk.close()
-            line["cpu_baseline"] = {"value": args.cpu_steps / cdt, "unit": "iterations/s", "cores": 1, "kind": "port",
-                                    "sample": "%d MH steps of the same workload, oracle/icp_oracle.c (brute-force f64, single thread, "
-                                              "posterior/likelihood of the current state carried over like the reference's Memoize); "
-                                              "host has %d logical cores" % (args.cpu_steps, os.cpu_count()),
-                                    "gpu_matches_oracle_on_sample": same}
+            try:
+                line["cpu_baseline"] = cpu_baseline_leg(pkg, args, wl, ctx)
+            except Exception as e:
+                line["cpu_baseline_error"] = str(e)[:300]
     for ch in chains:
         ch.close()
     for cx in ctxs:
         cx.close()
-    if rank == 0 and world == 1 and B == 1 and args.many_chains > 1:
+    if rank == 0 and world == 1 and B == 1 and args.many_chains > 1 and args.config == 1:
         # ---- not the headline: the same workload with many independent chains on the one GPU (SURVEY.md §8e "within a GPU,
         # batch B chains per launch"; RunMHRandomInitComparison-style jobs), one context per chain, lockstep submissions
         try:
             nB = args.many_chains
             mctx = [pkg.IcpContext(model, target, device=local_rank) for _ in range(nB)]
-            mch = []
-            for i in range(nB):
-                th = theta0.copy()
-                if i > 0:
-                    th[10:] = np.random.default_rng(1024 + i).normal(size=r) * np.sqrt(0.1)
-                mch.append(pkg.SamplingRegistration(mctx[i], setup, th, seed=1024 + i))
+            mch = [pkg.SamplingRegistration(mctx[i], setup, wl["init"](i), seed=1024 + i) for i in range(nB)]
             pkg.run_chains_batched(mch, 40, want_records=False)
             n_m = 300
             t1 = time.perf_counter()
@@ -245,12 +346,142 @@ def main():
                 ch.close()
             for cx in mctx:
                 cx.close()
-        except Exception as e:  # the headline line is printed whatever happens in this extra leg
+        except Exception as e:
             line["many_chains"] = {"error": str(e)[:200]}
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def roofline_leg(pkg, args, wl, ctx, chains, B, rate, line):
+    model, target, setup = wl["model"], wl["target"], wl["setup"]
+    ctx.profile_start(max_launches=80 * args.profile_steps + 2048)   # (a batch's launches go out on the first chain's context)
+    if B == 1:
+        chains[0].run(args.profile_steps, want_records=False)
+    else:
+        pkg.run_chains_batched(chains, args.profile_steps, want_records=False)
+    stats = ctx.profile_stop()
+    wait = stats.pop("k_step_begin.device_wait", None)
+    busy = {}
+    for name, s in stats.items():
+        t = s["total_ms"]
+        if name == "k_step_begin" and wait is not None:  # its launches include the time they WAIT on the device for another stream
+            t = max(t - wait["total_ms"], 0.0)
+        busy[name] = t
+    if not busy:
+        return None
+    dominant = max(busy, key=busy.get)
+    k = stats[dominant]
+    avg_us = 1e3 * busy[dominant] / max(k["calls"], 1)
+    chains_per_launch = 1.0
+    alg = kernel_algorithmic_bytes(dominant, model, target, setup)
+    if B > 1:
+        chains_per_launch = B * args.profile_steps / max(k["calls"], 1)
+        alg = alg * chains_per_launch if alg is not None else None
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if os.path.exists(tfile) and B == 1:
+        traffic = json.load(open(tfile)).get("config%d" % args.config, {}).get(dominant, {}).get("hbm_bytes_per_launch")
+    has_boundary = bool(pkg.data.boundary_vertex_flags(target).any())
+    bytes_step, flops_step = algorithmic_step(model, target, setup, has_boundary)
+    icp_share = line["config"]["icp_proposals"] / max(args.steps * B, 1)
+    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
+            "kernel": dominant, "avg_launch_us": avg_us, "launches": k["calls"], "algorithmic_bytes": alg,
+            "chains_per_launch": chains_per_launch,
+            "selection": "time-dominant kernel of this run: largest sum of launch durations (HIP events on the launch streams; "
+                         "k_step_begin without the time it waits on the device for its words)"}
+    if alg is not None:
+        roof["achieved"] = alg / (avg_us * 1e-6) / 1e9
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+    # the whole step against both rooflines: which one binds
+    hbm_frac = bytes_step * rate / (HBM_PEAK_GBS * 1e9)
+    f32_frac = flops_step * rate / (F32_VECTOR_TFLOPS * 1e12)
+    f64_frac = flops_step * rate / (F64_VECTOR_TFLOPS * 1e12)
+    roof["whole_step"] = {"algorithmic_bytes_per_step": bytes_step, "algorithmic_flops_per_step": flops_step, "iterations_per_s": rate,
+                          "hbm_frac": hbm_frac, "flops_frac_f32_vector_peak": f32_frac, "flops_frac_f64_vector_peak": f64_frac,
+                          "binding": "flops" if f32_frac > hbm_frac else "hbm",
+                          "note": "brute-force algorithmic figures (SURVEY.md §8d) x measured rate; steps whose proposal is a random walk or a pose move "
+                                  "(%.0f %% here) do less.  Either fraction is small by construction at this size: a step is a chain of dependent "
+                                  "launches (DESIGN.md §5), not a stream" % (100 * (1 - icp_share))}
+    # the distance kernel (north_star: HBM GB/s of the N x M search), whichever kernel dominates
+    for dk in ("k_step_filter", "k_surface_filter"):
+        if dk in stats:
+            dalg = kernel_algorithmic_bytes(dk, model, target, setup)
+            davg = stats[dk]["avg_us"]
+            if B > 1:
+                dalg *= B * args.profile_steps / max(stats[dk]["calls"], 1)
+            roof["distance_kernel"] = {"kernel": dk, "avg_launch_us": davg, "launches": stats[dk]["calls"], "algorithmic_bytes": dalg,
+                                       "achieved_GBs": dalg / (davg * 1e-6) / 1e9, "frac_hbm": dalg / (davg * 1e-6) / 1e9 / HBM_PEAK_GBS}
+            break
+    line["kernel_us_per_step"] = {name: round(s["total_ms"] * 1e3 / args.profile_steps, 2) for name, s in stats.items()}
+    if wait is not None:
+        line["kernel_us_per_step"]["k_step_begin.device_wait"] = round(wait["total_ms"] * 1e3 / args.profile_steps, 2)
+    line["kernel_us_per_step_note"] = ("HIP events around each launch (these add ~2-3 us per launch: quote fractions from profiles/*.md where both exist); a step's "
+                                       "launches alternate between two streams and overlap the previous step's finish launch; k_step_begin.device_wait is "
+                                       "the part of k_step_begin spent waiting ON THE DEVICE for that launch to start or for the eigen-decomposition it draws from")
+    return roof
+
+
+def cpu_baseline_leg(pkg, args, wl, ctx):
+    """BASELINE.md §3.  B1 "reference-shaped": the oracle's chain (oracle/icp_oracle.c: sequential, long-form N-point regressions
+    as Scalismo does them, posterior/likelihood of the current state carried over like the reference's Memoize) with a KD-tree for
+    findClosestPoint and a bounding-volume hierarchy for closestPointOnSurface, the structures of the current model instance rebuilt
+    for every new state, ONE thread.  B2: the same chain with brute-force scans over ALL host cores (OpenMP).  Identical results
+    (tests/test_oracle.py::test_chain_identical_under_every_search_backend); the first GPU records are checked against B1 here."""
+    from oracle import oracle as O
+    model, target, setup = wl["model"], wl["target"], wl["setup"]
+    if setup.w_pose > 0:  # the oracle's chain has no pose proposals: run the ICP + random-walk part of the mixture (it is the costly part)
+        note_pose = "; pose proposals left out of the CPU chain (no closest-point work in them)"
+    else:
+        note_pose = ""
+    om, ot = O.OracleModel.from_model(model), O.OracleMesh(target.points, target.cells)
+    icp = [O.proposal_params(p["step"], p["sigma_t"], p["sigma_n"], p["direction"], p.get("boundary_aware", True),
+                             n_model_ids=p.get("n_model_ids", 0), target_pts=p.get("target_pts")) for p in setup.icp]
+    e = setup.eval
+    ep = O.evaluator_params(e["kind"], e["mode"], n_model_ids=e["n_model_ids"], target_pts=e["target_pts"],
+                            p0=e["gauss_mean"] if e["kind"] != 1 else e["exp_rate"], p1=e["gauss_sigma"], p2=e["exp_rate"])
+    wsum = setup.w_icp + setup.w_rw
+    cfg = O.chain_config(icp, [p.get("weight", 0.5) for p in setup.icp], setup.w_icp / wsum, setup.w_rw / wsum, setup.rw_sigma, ep)
+    theta0 = wl["init"](0)
+    cores = os.cpu_count()
+    out = {}
+    def timed(n):
+        t = time.perf_counter()
+        res = O.run_chain(om, ot, cfg, theta0, 1024, n)
+        return res, time.perf_counter() - t
+
+    try:
+        # sample sizes: bounded by --cpu-steps AND by time (a first step of each variant is timed as a probe: at BFM size one CPU
+        # step takes seconds), so that the default run stays within minutes
+        O.set_search_backend(O.SEARCH_TREES)
+        _, probe = timed(1)  # (also builds the static target's structures, as the reference does once)
+        n1 = int(min(4 * args.cpu_steps, max(1, 15.0 / max(probe, 1e-6))))
+        (acc_o, comp_o, _, states_o), d1 = timed(n1)
+        kd, bvh = O.search_stats()
+        out["B1"] = {"value": n1 / d1, "unit": "iterations/s", "cores": 1,
+                     "what": "reference-shaped: sequential chain, KD-tree + bounding-volume hierarchy rebuilt per new state (%d + %d builds so "
+                             "far), long-form regressions, Memoize-like carry-over; oracle/icp_oracle.c + icp_spatial.c" % (kd, bvh),
+                     "sample": "%d MH steps" % n1}
+        O.set_search_backend(O.SEARCH_BRUTE_OMP, 0)
+        _, probe = timed(1)
+        n2 = int(min(args.cpu_steps, max(1, 10.0 / max(probe, 1e-6))))
+        _, d2 = timed(n2)
+        out["B2"] = {"value": n2 / d2, "unit": "iterations/s", "cores": cores,
+                     "what": "the same chain, brute-force scans spread over all host cores with OpenMP", "sample": "%d MH steps" % n2}
+    finally:
+        O.set_search_backend(O.SEARCH_BRUTE)
+    same = None
+    if setup.w_pose == 0:  # the first records of a fresh GPU chain must reproduce the oracle's decisions
+        chk = pkg.SamplingRegistration(ctx, setup, theta0, seed=1024)
+        crec = chk.run(n1)
+        same = bool(np.array_equal(crec[:, 1].astype(np.uint8), acc_o)) and \
+            float(np.abs(crec[:, 14:] - states_o[:, 10:]).max()) <= 1e-5 * max(float(np.abs(states_o[:, 10:]).max()), 1e-30)
+        chk.close()
+    return {"value": out["B1"]["value"], "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": "B1 of BASELINE.md §3 (the baseline the >= 50x target is defined on): %s of the same workload, one thread; host has %d logical cores%s"
+                      % (out["B1"]["sample"], cores, note_pose),
+            "B1": out["B1"], "B2": out["B2"], "gpu_matches_oracle_on_sample": same}
 
 
 if __name__ == "__main__":

@@ -270,6 +270,7 @@ struct icp_ctx {
 
   Profiler prof;
   bool profiling = false;
+  DBuf<long long> d_wait_ticks;  // profiling: time the steps' first launches spent waiting on the device (StepBeginArgs::wait_ticks)
   // argument arrays of the icp_chain_step_batched launches led by this context: pinned copy, device copy
   // (kBatchRing of each, used in turn: a caller may keep that many batches in flight on this context's stream)
   static constexpr int kBatchRing = 4;
@@ -1155,6 +1156,8 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->h_flag[0] = 0;
     ctx->d_done.alloc(4);
     ctx->d_done.fill_bytes(0);
+    ctx->d_wait_ticks.alloc(2);
+    ctx->d_wait_ticks.fill_bytes(0);
     for (auto& sl : ctx->slots) ctx->alloc_slot(sl);
     HIP_OK(hipStreamSynchronize(ctx->stream));
     ++g_live_contexts;
@@ -1238,6 +1241,7 @@ int icp_ctx_profile_start(icp_ctx* ctx, int32_t max_launches) {
     }
     ctx->prof.used = 0;
     ctx->prof.overflow = false;
+    ctx->d_wait_ticks.fill_bytes(0);
     ctx->profiling = true;
   });
 }
@@ -1271,6 +1275,18 @@ int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity,
     int n = 0;
     for (int i = 0; i < KID_COUNT; ++i)
       if (acc[i].calls > 0) stats[n++] = acc[i];
+    {  // how much of k_step_begin's time was spent waiting ON THE DEVICE for the previous step / the decomposition it draws from
+      long long ticks = 0;
+      HIP_OK(hipMemcpy(&ticks, ctx->d_wait_ticks.p, sizeof(ticks), hipMemcpyDeviceToHost));
+      if (ticks > 0 && n < capacity) {
+        icp_kernel_stat w;
+        std::memset(&w, 0, sizeof(w));
+        std::strncpy(w.name, "k_step_begin.device_wait", sizeof(w.name) - 1);
+        w.calls = acc[KID_STEP_BEGIN].calls;
+        w.total_ms = (double)ticks * 1e-5;  // 100 MHz ticks
+        stats[n++] = w;
+      }
+    }
     *n_out = n;
     if (ctx->prof.overflow) fail(ICP_ERR_INVALID_ARG, "profiler event pool too small: raise max_launches");
   });
@@ -2064,6 +2080,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   static const int starve_pipeline = std::getenv("ICP_TEST_STARVE_PIPELINE") ? (1 << 24) : 0;
   b.wait_seq = c.last_back_seq + starve_pipeline;
   b.wait_error = c.h_wait_error;
+  b.wait_ticks = c.profiling ? c.d_wait_ticks.p : nullptr;
   if (generator >= 0 && ec[generator]->done_value != 0) {
     b.wait2_flag = props[generator]->eig_words.p + ec[generator]->status_off / 3;
     b.wait2_seq = ec[generator]->done_value;

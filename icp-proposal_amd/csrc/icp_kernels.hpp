@@ -236,6 +236,7 @@ struct StepBeginArgs {  // launch 1: [propose] -> coefficients -> instance -> se
   // there would hold that step's own launches back.  *wait_error (pinned) is set if the word does not come within 50 ms.
   const int* wait_flag; int wait_seq; int* wait_error;
   const int* wait2_flag; int wait2_seq;  // likewise: the word of the eigen-decomposition the proposal draws from (EigenRequest::done_word)
+  long long* wait_ticks;  // profiling (may be null): workgroup 0 adds the 100 MHz ticks it spent waiting for the two words
   int hold_regs;  // the decomposition is still in flight: use the launch variant that holds the model data in registers across the wait
                   // (k_step_begin_reg: ≈ 3 µs slower by itself, ≈ 6 µs less behind the wait)
   const double* Qp; const double* ref; const double* mean;

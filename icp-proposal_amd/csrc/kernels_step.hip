@@ -53,6 +53,7 @@ __device__ __forceinline__ void step_begin_body(const StepBeginArgs& a, const in
         }
         __builtin_amdgcn_s_sleep(8);
       }
+      if (a.wait_ticks && bx == 0) atomicAdd((unsigned long long*)a.wait_ticks, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - t0));
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (invalidate only: nothing of ours to write back)
@@ -139,6 +140,7 @@ __device__ __forceinline__ void step_begin_body_reg(const StepBeginArgs& a, cons
         }
         __builtin_amdgcn_s_sleep(2);
       }
+      if (a.wait_ticks && bx == 0) atomicAdd((unsigned long long*)a.wait_ticks, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - t0));
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (invalidate only: nothing of ours to write back)

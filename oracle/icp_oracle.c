@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "icp_spatial.h"
+
 #define ORC_API __attribute__((visibility("default")))
 
 /* ------------------------------------------------------------------ small helpers */
@@ -233,6 +235,15 @@ ORC_API void orc_vertex_normals(const orc_model *m, const double *x, double *nor
 /* Scalismo UnstructuredPoints.findClosestPoint: exact NN; here brute force, lowest index wins ties.
  * d² evaluated as (dx·dx + dy·dy) + dz·dz. */
 ORC_API void orc_nearest_vertex(int K, const double *q, int M, const double *pts, int *idx, double *d2) {
+  const int backend = orc_get_search_backend();  /* icp_spatial.h: the CPU-baseline variants B1 / B2, same results */
+  if (backend != ORC_SEARCH_BRUTE) {
+    for (int k = 0; k < K; ++k) {
+      double dd;
+      idx[k] = backend == ORC_SEARCH_TREES ? spatial_nearest_vertex(q + 3 * k, M, pts, &dd) : spatial_nearest_vertex_omp(q + 3 * k, M, pts, &dd);
+      if (d2) d2[k] = dd;
+    }
+    return;
+  }
   for (int k = 0; k < K; ++k) {
     double best = INFINITY;
     int bi = -1;
@@ -286,6 +297,17 @@ static void closest_point_triangle(const double *p, const double *a, const doubl
 /* mesh.operations.closestPointOnSurface(p).point: brute force over all triangles, lowest (d², triangle id) wins */
 ORC_API void orc_closest_point_on_surface(int K, const double *q, const double *pts, int T, const int *tris,
                                           double *cp, int *tri_idx, double *d2) {
+  const int backend = orc_get_search_backend();  /* icp_spatial.h */
+  if (backend != ORC_SEARCH_BRUTE) {
+    for (int k = 0; k < K; ++k) {
+      double dd;
+      const int bi = backend == ORC_SEARCH_TREES ? spatial_closest_on_surface(q + 3 * k, pts, T, tris, closest_point_triangle, cp + 3 * k, &dd)
+                                                 : spatial_closest_on_surface_omp(q + 3 * k, pts, T, tris, closest_point_triangle, cp + 3 * k, &dd);
+      if (tri_idx) tri_idx[k] = bi;
+      if (d2) d2[k] = dd;
+    }
+    return;
+  }
   for (int k = 0; k < K; ++k) {
     double best = INFINITY, bp[3] = {0, 0, 0};
     int bi = -1;

@@ -53,7 +53,8 @@ class ChainConfig(C.Structure):
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libicp_oracle.so")
     src = os.path.join(_HERE, "icp_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("icp_oracle.c", "icp_spatial.c", "icp_spatial.h"))
+    if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
         subprocess.run(["make", "-C", _HERE, "-B", "libicp_oracle.so"], check=True, stdout=subprocess.DEVNULL)
     return so
 
@@ -176,6 +177,27 @@ def rotation_matrix(phi, theta, psi):
     R = np.empty((3, 3))
     lib().orc_rotation_matrix(phi, theta, psi, _d(R))
     return R
+
+
+SEARCH_BRUTE, SEARCH_TREES, SEARCH_BRUTE_OMP = 0, 1, 2
+
+
+def set_search_backend(backend: int, n_threads: int = 0):
+    """CPU-baseline variants of BASELINE.md §3 (icp_spatial.h): 0 the restatement's single-thread scans, 1 = B1 (KD-tree +
+    bounding-volume hierarchy, rebuilt for every new mesh), 2 = B2 (the scans over n_threads cores, 0 = all).  Same results."""
+    L = lib()
+    L.orc_set_search_backend.argtypes = [C.c_int, C.c_int]
+    L.orc_set_search_backend.restype = None
+    L.orc_set_search_backend(int(backend), int(n_threads))
+
+
+def search_stats():
+    L = lib()
+    kd, bvh = C.c_long(), C.c_long()
+    L.orc_search_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    L.orc_search_stats.restype = None
+    L.orc_search_stats(C.byref(kd), C.byref(bvh))
+    return kd.value, bvh.value
 
 
 def nearest_vertex(q, pts):

@@ -272,3 +272,63 @@ def test_golden_chain_prefix(oracle, femur50, femur50_oracle, pkg):
     acc, comp, logp, states = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), pkg.initial_parameters(model), 1024, 25)
     assert np.array_equal(acc, GOLD["chain_accepted"][:25]) and np.array_equal(comp, GOLD["chain_component"][:25])
     assert np.allclose(states, GOLD["chain_states"][:25], rtol=1e-9, atol=1e-11)
+
+
+def test_search_backends_agree(oracle, pkg):
+    """the CPU baselines B1 (KD-tree + bounding-volume hierarchy) and B2 (OpenMP scans) are the restatement
+    with another search back end (oracle/icp_spatial.c).  They must return what the single-thread scans return, bit for bit:
+    indices (ties to the lowest index), squared distances and closest points — on the femur meshes, on a subdivided target
+    with exactly coplanar/duplicated distances, and on queries that sit ON vertices and edges (ties by construction)."""
+    model, target = pkg.data.load_femur_model_and_target(50)
+    big = pkg.data.subdivide(target, 3)  # no jitter: shared edges and coplanar children give exact ties
+    rng = np.random.default_rng(3)
+    q = np.concatenate([model.ref_points[:200] + rng.normal(0, 2.0, size=(200, 3)),
+                        big.points[:100],                                              # on vertices: several triangles at distance 0
+                        0.5 * (big.points[big.cells[:50, 0]] + big.points[big.cells[:50, 1]]),  # on edges
+                        rng.normal(0, 300.0, size=(20, 3))])                            # far away
+    try:
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)
+        idx0, d0 = oracle.nearest_vertex(q, big.points)
+        cp0, tri0, s0 = oracle.closest_point_on_surface(q, big.points, big.cells)
+        for backend in (oracle.SEARCH_TREES, oracle.SEARCH_BRUTE_OMP):
+            oracle.set_search_backend(backend, 4)
+            idx, d = oracle.nearest_vertex(q, big.points)
+            cp, tri, s = oracle.closest_point_on_surface(q, big.points, big.cells)
+            assert np.array_equal(idx, idx0) and np.array_equal(d, d0)
+            assert np.array_equal(tri, tri0) and np.array_equal(s, s0) and np.array_equal(cp, cp0)
+        # a changed mesh at the same address is a new mesh (B1 rebuilds its structures per state)
+        oracle.set_search_backend(oracle.SEARCH_TREES)
+        pts = np.ascontiguousarray(model.ref_points.copy())
+        kd0, bvh0 = oracle.search_stats()
+        a, _ = oracle.nearest_vertex(q[:50], pts)
+        pts += 1.5
+        b, _ = oracle.nearest_vertex(q[:50], pts)
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)
+        b0, _ = oracle.nearest_vertex(q[:50], pts)
+        assert np.array_equal(b, b0)
+    finally:
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)
+
+
+def test_chain_identical_under_every_search_backend(oracle, pkg):
+    """The whole chain (accept/reject sequence, components, states) is bit-identical under B1 and B2."""
+    model, target = pkg.data.load_femur_model_and_target(50)
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    setup = pkg.femur_icp_proposal_registration(model, target)
+    icp = [oracle.proposal_params(p["step"], p["sigma_t"], p["sigma_n"], p["direction"], p.get("boundary_aware", True),
+                                  n_model_ids=p.get("n_model_ids", 0), target_pts=p.get("target_pts")) for p in setup.icp]
+    e = setup.eval
+    ep = oracle.evaluator_params(e["kind"], 2, n_model_ids=e["n_model_ids"], target_pts=e["target_pts"], p0=e["gauss_mean"], p1=e["gauss_sigma"],
+                                 p2=e["exp_rate"])  # symmetric: the current model surface is searched, too
+    cfg = oracle.chain_config(icp, [0.5, 0.5], setup.w_icp, setup.w_rw, setup.rw_sigma, ep)
+    theta0 = pkg.initial_parameters(model)
+    try:
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)
+        ref = oracle.run_chain(om, ot, cfg, theta0, 7, 6)
+        for backend in (oracle.SEARCH_TREES, oracle.SEARCH_BRUTE_OMP):
+            oracle.set_search_backend(backend, 4)
+            got = oracle.run_chain(om, ot, cfg, theta0, 7, 6)
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b)
+    finally:
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)
