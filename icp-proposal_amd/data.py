@@ -71,6 +71,10 @@ class StatisticalMeshModel:
         return self.ref_points.shape[0]
 
     @property
+    def n_cells(self):
+        return self.cells.shape[0]
+
+    @property
     def reference_mesh(self):
         return TriangleMesh(self.ref_points, self.cells)
 
