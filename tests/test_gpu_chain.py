@@ -418,3 +418,41 @@ def test_dropped_half_step_is_ordered_before_its_replacement(pkg):
     for e_, ps in ((ev, props), (rev, rprops)):
         e_.close(); [p.close() for p in ps]
     ctx.close(); ref_ctx.close()
+
+
+def test_femur100_all_points_symmetric_58k_target_matches_oracle(pkg, oracle):
+    """configs[2] on the target SURVEY.md §8d assigns to it (58,322 vertices / 116,640 triangles): femur-100, every model point a
+    sample point of the proposal and of the symmetric evaluator, random-init chains.  Two chains of a few steps against the
+    oracle's chain (tree back end: bit-identical to its scans): identical decisions, states within 1e-5, and the correspondence
+    indices of the final states bit for bit."""
+    model, target = pkg.data.synthetic_femur_target(n_components=100)
+    assert target.n_points == 58322 and model.rank == 101
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    setup = pkg.femur_random_init_comparison(model, target)
+    cfg = oracle_chain_config(oracle, setup)
+    ctx = pkg.IcpContext(model, target, device=0)
+    n_steps = 5
+    try:
+        oracle.set_search_backend(oracle.SEARCH_TREES)
+        for trial in (1, 2):
+            theta0 = pkg.random_initial_parameters(model, chain_index=trial)
+            seed = 1024 + trial
+            acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, cfg, theta0, seed, n_steps)
+            chain = pkg.SamplingRegistration(ctx, setup, theta0, seed)
+            rec = chain.run(n_steps)
+            assert np.array_equal(rec[:, 1].astype(np.uint8), acc_o), "accept/reject sequences differ"
+            assert np.array_equal(rec[:, 2].astype(np.int32), comp_o)
+            scale = np.abs(states_o[:, 10:]).max()
+            assert np.abs(rec[:, 14:] - states_o[:, 10:]).max() <= 1e-5 * scale
+            assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
+            chain.close()
+            # correspondences of all 1622 model points against the 116,640 triangles, at the chain's last state
+            theta = rec[-1, 4:].copy()
+            pp = oracle.proposal_params(0.1, 10.0, 5.0, oracle.MODEL_SAMPLING, True, n_model_ids=model.n_points)
+            prop = pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, model.n_points, "ModelSampling", True)
+            post, po = prop.icpPosterior(theta, with_aux=False), oracle.icp_posterior(om, ot, pp, theta)
+            assert np.array_equal(post.corr_id, po.corr_id) and np.array_equal(post.corr_point, po.corr_pt) and np.array_equal(post.keep, po.keep)
+            prop.close()
+    finally:
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)
+    ctx.close()

@@ -167,3 +167,60 @@ def test_batch_registration_lockstep_mixed_targets(pkg, femur50):
     items6, recs6 = pkg.sharding.run_batch(pkg, model, [target, finer], n_chains=3, n_steps=20, make_setup=setup, chains_per_launch=6)
     assert items6 == items and all(np.array_equal(a, b) for a, b in zip(recs, recs6))
     assert sum(r[:, 1].sum() for r in recs) > 10
+
+
+def test_full_face_hausdorff_matches_oracle(pkg, oracle, full_face):
+    """configs[3]: the full-mesh Hausdorff evaluator (28,561 x 54,324 + 27,561 x 56,448 point-triangle pairs) against the oracle at
+    FULL size — affordable with the oracle's tree back end (B1 of BASELINE.md §3; bit-identical to its brute-force scans,
+    tests/test_oracle.py::test_search_backends_agree)."""
+    model, target, ctx = full_face
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    ep = oracle.evaluator_params(oracle.EVAL_HAUSDORFF, 2, p0=1.0)
+    hd = pkg.HausdorffDistanceEvaluator(ctx, 1.0)
+    try:
+        oracle.set_search_backend(oracle.SEARCH_TREES)
+        for seed in (21, 22):
+            theta = face_theta(model, seed)
+            want, rc = oracle.evaluator_log_value(om, ot, ep, theta)
+            got, aux = hd.logValue(theta, return_aux=True)
+            assert rc == 0 and abs(got - want) <= 1e-12 * abs(want), (got, want)
+    finally:
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)
+    hd.close()
+
+
+def test_batch_registration_full_face_matches_oracle(pkg, oracle):
+    """configs[4] at FULL BFM size through the batch runner: 3 targets x 3 random-init chains (work items dealt as over 8 ranks,
+    here world 1), a few steps each.  For every chain's final state the correspondence indices / points / boundary filter of the
+    proposal and the collective likelihood are compared with the oracle (tree back end), and so is the decision sequence of one
+    chain's first steps whose proposals were ICP or random-walk moves."""
+    model = pkg.data.synthetic_face_model()
+    r = model.rank
+    targets = [pkg.data.synthetic_partial_target(model, seed=s) for s in (7, 8, 9)]
+    n_steps = 6
+    items, recs = pkg.sharding.run_batch(pkg, model, targets, n_chains=3, n_steps=n_steps, make_setup=pkg.bfm_fitting_partial)
+    assert items == [(t, c) for t in range(3) for c in range(3)] and len(recs) == 9
+    om = oracle.OracleModel.from_model(model)
+    pp = oracle.proposal_params(0.1, 6.0, 3.0, oracle.MODEL_SAMPLING, True, n_model_ids=2 * r)
+    try:
+        oracle.set_search_backend(oracle.SEARCH_TREES)
+        for t in range(3):
+            ot = oracle.OracleMesh(targets[t].points, targets[t].cells)
+            ctx = pkg.IcpContext(model, targets[t], device=0)
+            prop = pkg.NonRigidIcpProposal(ctx, 0.1, 6.0, 3.0, 2 * r, "ModelSampling", True)
+            tp = pkg.data.decimated_point_subset(targets[t], 4 * r)
+            ev = pkg.CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator(ctx, 0.1, 0.3, 1.0, 2, 4 * r, decimatedTargetPoints=tp)
+            ep = oracle.evaluator_params(oracle.EVAL_COLLECTIVE, 2, n_model_ids=4 * r, target_pts=tp, p0=0.1, p1=0.3, p2=1.0)
+            for c in range(3):
+                rec = recs[3 * t + c]
+                assert rec.shape == (n_steps, 14 + r) and np.all(np.isfinite(rec[:, 1:]))
+                theta = rec[-1, 4:].copy()
+                post, po = prop.icpPosterior(theta), oracle.icp_posterior(om, ot, pp, theta)
+                assert np.array_equal(post.corr_id, po.corr_id) and np.array_equal(post.corr_aux, po.corr_aux)
+                assert np.array_equal(post.keep, po.keep) and np.array_equal(post.corr_point, po.corr_pt)
+                want, rc = oracle.evaluator_log_value(om, ot, ep, theta)
+                got = ev.logValue(theta)
+                assert rc == 0 and abs(got - want) <= 1e-10 * abs(want)
+            ev.close(); prop.close(); ctx.close()
+    finally:
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)
