@@ -15,8 +15,6 @@
 #include <map>
 #include <mutex>
 
-#include <rocsolver/rocsolver.h>
-
 #include "icp_kernels.hpp"
 #include "icp_dense.hpp"
 
@@ -123,6 +121,177 @@ template <int TPT, int NT>
 __global__ void __launch_bounds__(NT) k_posterior_factor_reg(int r, FactorArgs fa) {
   const int p = blockIdx.x;
   factor_reg_body<TPT, NT>(r, fa.Mpart[p], fa.splits[p], fa.M[p], fa.alpha[p], fa.status[p]);
+}
+
+// ---------------------------------------------------------------- K5b for ranks whose factor does not fit one CU's LDS (128..256)
+// Right-looking blocked Cholesky of [M; bᵀ] in ONE launch, one workgroup per posterior: the matrix sits in `scratch` (global,
+// L2-resident: 320 KB at rank 200), block columns of 64 go through LDS —
+//   1 the 64×64 diagonal block is factored in LDS (two barriers per column);
+//   2 every row below it (the appended row bᵀ included: forward substitution for free) is solved against that factor, one
+//     thread per row, and kept in LDS as the panel P;
+//   3 the trailing lower triangle takes −P·Pᵀ (operands from LDS, the matrix itself read and written in place).
+// Then the blocked back substitution Lᵀα = y.  ≈ 0.15 ms at rank 200 (the generic kernel further up, every entry behind L2:
+// 3.3 ms).
+constexpr int kCholNB = 64;
+constexpr int kCholMaxRank = 256;
+
+__global__ void __launch_bounds__(1024) k_posterior_factor_blocked(int r, FactorArgs fa) {
+  __shared__ double s_y[512], s_dinv[kCholNB];
+  __shared__ int s_fail;
+  const int tid = threadIdx.x, nt = blockDim.x, n = r + 1, p = blockIdx.x;
+  const double* __restrict__ Mpart = fa.Mpart[p];
+  const int S = fa.splits[p];
+  double* __restrict__ W = fa.scratch[p];  // rows 0..r-1: lower triangle of M -> L; row r: bᵀ -> y = L⁻¹b  (row-major, ld = r)
+  double* __restrict__ M = fa.M[p];
+  double* D = s_dyn;                       // [kCholNB][kCholNB + 1] diagonal block
+  double* P = s_dyn + kCholNB * (kCholNB + 1);  // [rows below][kCholNB (+1: rows one bank apart)] panel
+  constexpr int ldd = kCholNB + 1, ldp = kCholNB + 1;
+#ifdef ICP_EIGEN_TIMING
+  long long t_acc[4] = {0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memrealtime();
+#define CHOL_T(i) do { const long long t_now = __builtin_amdgcn_s_memrealtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define CHOL_T(i)
+#endif
+  if (tid == 0) s_fail = 0;
+  // ---- M = I + Σ partials (lower triangle of the partials, split order), bᵀ = row r
+  for (int e = tid; e < n * r; e += nt) {
+    const int i = e / r, j = e - i * r;
+    if (j > i) continue;
+    double m = 0.0;
+    const double* src = Mpart + (size_t)i * n + j;
+    for (int s0 = 0; s0 < S; s0 += 8) {  // eight splits in flight (a loop of dependent loads took 0.4 ms here); summed in split order
+      double q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = src[(size_t)min(s0 + u, S - 1) * n * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (s0 + u < S) m += q[u];
+    }
+    if (i < r) {
+      if (i == j) m += 1.0;
+      M[(size_t)i * r + j] = m;
+      M[(size_t)j * r + i] = m;
+    }
+    W[(size_t)i * r + j] = m;
+  }
+  __syncthreads();
+  CHOL_T(0);
+  for (int kb = 0; kb < r; kb += kCholNB) {
+    const int nbk = min(kCholNB, r - kb), below0 = kb + nbk, n_below = n - below0;
+    // 1: diagonal block
+    for (int e = tid; e < nbk * nbk; e += nt) {
+      const int i = e / nbk, j = e - i * nbk;
+      if (j <= i) D[i * ldd + j] = W[(size_t)(kb + i) * r + kb + j];
+    }
+    __syncthreads();
+    // root-free right-looking elimination (one reciprocal and ONE barrier per column), then the columns are scaled once:
+    // L[i][j] = U[i][j]·rsqrt(U[j][j])
+    if (!block_cholesky_rootfree(D, nbk, ldd, 0, 5)) { if (tid == 0) s_fail = 1; }
+    __syncthreads();
+    if (!s_fail) {
+      const int ty = tid >> 5, tx = tid & 31;
+      for (int j = tx; j < nbk; j += 32) {
+        const double dinv = fast_rsqrt(D[j * ldd + j]);
+        for (int i = j + 1 + ty; i < nbk; i += 32) D[i * ldd + j] *= dinv;
+      }
+      __syncthreads();
+      for (int j = tid; j < nbk; j += nt) { const double u = D[j * ldd + j], ri = fast_rsqrt(u); D[j * ldd + j] = u * ri; s_dinv[j] = ri; }
+      __syncthreads();
+    }
+    if (s_fail) break;
+    for (int e = tid; e < nbk * nbk; e += nt) {
+      const int i = e / nbk, j = e - i * nbk;
+      if (j <= i) W[(size_t)(kb + i) * r + kb + j] = D[i * ldd + j];
+    }
+    CHOL_T(1);
+    // 2: panel — row `below0 + t` solved against the block's factor: x_j = (a_j − Σ_{k<j} x_k·l_jk) / l_jj
+    // (the rows' segments come into LDS first, all loads in flight, and go back when solved: a load per step of the
+    // substitution — which the stores of the step before it pin in place — cost one trip to L2 per column)
+    for (int e = tid; e < n_below * nbk; e += nt) {
+      const int t = e / nbk, j = e - t * nbk;
+      P[(size_t)t * ldp + j] = W[(size_t)(below0 + t) * r + kb + j];
+    }
+    __syncthreads();
+    for (int t = tid; t < n_below; t += nt) {
+      double* x = P + (size_t)t * ldp;
+      for (int j = 0; j < nbk; ++j) {
+        double a = x[j];
+        const double* lj = D + j * ldd;
+        int k = 0;
+        for (; k + 8 <= j; k += 8) {  // eight operand pairs in flight (three waves carry rows: nothing else hides the LDS latency)
+          double xv[8], lv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { xv[u] = x[k + u]; lv[u] = lj[k + u]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a = fma(-xv[u], lv[u], a);
+        }
+        for (; k < j; ++k) a = fma(-x[k], lj[k], a);
+        x[j] = a * s_dinv[j];
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < n_below * nbk; e += nt) {
+      const int t = e / nbk, j = e - t * nbk;
+      W[(size_t)(below0 + t) * r + kb + j] = P[(size_t)t * ldp + j];
+    }
+    CHOL_T(2);
+    // 3: trailing update of the rows below (lower triangle; the appended row r has every column < r)
+    for (int ti = tid >> 5; ti < n_below; ti += 32)
+      for (int tj = tid & 31; tj <= ti; tj += 32) {
+        const int gi = below0 + ti, gj = below0 + tj;
+        if (gj >= r) continue;
+        const double* xi = P + (size_t)ti * ldp;
+        const double* xj = P + (size_t)tj * ldp;
+        double acc = 0.0;
+        for (int k = 0; k < nbk; ++k) acc = fma(xi[k], xj[k], acc);
+        W[(size_t)gi * r + gj] -= acc;
+      }
+    __syncthreads();
+    CHOL_T(3);
+  }
+#ifdef ICP_EIGEN_TIMING
+  if (tid == 0 && blockIdx.x == 0) { for (int i = 0; i < 4; ++i) g_eigen_stamps[24 + i] = t_acc[i]; g_eigen_stamps[28] = t_last; }
+#endif
+  if (s_fail) {
+    if (tid == 0) fa.status[p][0] = 1;
+    return;
+  }
+  // ---- back substitution Lᵀ α = y (y = row r of W), block by block from the end
+  for (int j = tid; j < r; j += nt) s_y[j] = W[(size_t)r * r + j];
+  __syncthreads();
+  const int last_kb = ((r - 1) / kCholNB) * kCholNB;
+  for (int kb = last_kb; kb >= 0; kb -= kCholNB) {
+    const int nbk = min(kCholNB, r - kb);
+    for (int e = tid; e < nbk * nbk; e += nt) {
+      const int i = e / nbk, j = e - i * nbk;
+      if (j <= i) D[i * ldd + j] = W[(size_t)(kb + i) * r + kb + j];
+    }
+    __syncthreads();
+    if (tid < nbk) s_dinv[tid] = fast_rcp(D[tid * ldd + tid]);
+    __syncthreads();
+    if (tid < 64) {  // one wave: α_j = (y_j − Σ_{i>j} l_ij α_i) / l_jj, from the block's last unknown to its first
+      const int i = tid;
+      double v = i < nbk ? s_y[kb + i] : 0.0;
+      const double* dd = s_dinv;
+      for (int j = nbk - 1; j >= 0; --j) {
+        const double aj = __shfl(v, j, 64) * dd[j];
+        if (i == j) v = aj;
+        else if (i < j) v = fma(-D[j * ldd + i], aj, v);
+      }
+      if (i < nbk) s_y[kb + i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < kb; i += nt) {  // the unknowns further up lose this block's contribution
+      double acc = 0.0;
+      for (int j = 0; j < nbk; ++j) acc = fma(W[(size_t)(kb + j) * r + i], s_y[kb + j], acc);
+      s_y[i] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int j = tid; j < r; j += nt) fa.alpha[p][j] = s_y[j];
+  if (tid == 0) fa.status[p][0] = 0;
+#ifdef ICP_EIGEN_TIMING
+  if (tid == 0 && blockIdx.x == 0) g_eigen_stamps[29] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 struct TailArgs {
@@ -1139,6 +1308,304 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
 #undef LDS_C
 }
 
+// ---------------------------------------------------------------- posterior KL basis, ranks 65..200: in-place parallel Jacobi
+// One CU's LDS cannot hold these matrices twice (the fixed-position kernel above reads one copy and writes the permuted
+// other), but it holds the strict upper triangle ONCE, packed, beside the diagonal (rank 200: 159 KB + 1.6 KB): the classical
+// parallel-order Jacobi iteration updates it in place — pair P of a round rotates (p, q) of the round-robin tournament, block
+// (P1, P2) owns the four entries A[{p1,q1}][{p2,q2}] and nobody else touches them in that round.
+//   workgroup 0      phase 1: one thread per pair computes (c, s) from three entries and logs it; barrier;
+//                    phase 2: every thread transforms its (up to five) 2×2 blocks, R1ᵀ·B·R2, in place; barrier.
+//                    ≈ 2.3 µs per round at rank 200 (LDS cycles: 5,050 blocks × 8 accesses), 199 rounds per sweep.
+//   workgroups 1..   64 coordinates (rows of V) each, the slab in LDS: they follow the published sweeps and apply every
+//                    round's rotations to their rows (the tournament's pairs are recomputed, only (c, s) is read from the log).
+// Warm start: the launcher transforms N by the basis of a nearby posterior first (k_eigen_big_warm, two plain GEMM passes on
+// many CUs), the slabs start from that basis.  Sort, signs and the two output layouts are taken by k_eigen_big_finish (one
+// wave per eigenvector) behind this launch.  Ranks above 200 take the generic kernel further up.
+constexpr int kBigBlocksPerThread = 5;   // 1024 threads × 5 >= 100·101/2 blocks (rank 200)
+constexpr int kBigMaxRank = 200;
+constexpr int kBigSlabRows = 64;
+constexpr int kBigStageRounds = 16;      // rounds of (c, s) staged per pass by a replay workgroup
+
+__device__ __forceinline__ int big_idx(int i, int j, int n) {  // packed strict upper triangle, i < j
+  return i * (2 * n - i - 1) / 2 + (j - i - 1);
+}
+// round-robin tournament (circle method) on n2 players: slot 0 holds (mm, 0) in round 0 and keeps its first player; every
+// other seat advances by one per round.  State (ra, rb) of a slot; the pair is (min, max)
+__device__ __forceinline__ void rr_init(int slot, int mm, int& ra, int& rb) {
+  if (slot == 0) { ra = mm; rb = 0; }
+  else { ra = slot % mm; rb = (mm - slot) % mm; }
+}
+__device__ __forceinline__ void rr_advance(int slot, int mm, int& ra, int& rb) {
+  if (slot == 0) { rb = rb + 1 == mm ? 0 : rb + 1; }
+  else { ra = ra + 1 == mm ? 0 : ra + 1; rb = rb + 1 == mm ? 0 : rb + 1; }
+}
+
+// SQUARE: the upper triangle inside a full n × ld image (ranks <= 140: it fits, and an entry's address is i·ld + j); otherwise the
+// packed triangle, row bases carried along with the tournament's players
+template <bool SQUARE>
+__global__ void __launch_bounds__(1024) k_eigen_big(int r, const double* __restrict__ A0 /* r×r, symmetric */, const double* __restrict__ Vwarm,
+                                                     double* __restrict__ Vwork /* [coordinate][index] eigenvectors, unsorted */,
+                                                     double* __restrict__ mu_out, double* rotlog, double* xcorr /* r×r */, int* meta,
+                                                     int max_sweeps, int no_corr, int launch_id, int* __restrict__ status) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n = r, n2 = (r + 1) & ~1, half = n2 >> 1, mm = n2 - 1;
+  __shared__ short s_p[128], s_q[128];
+  __shared__ double s_red[16], s_red2[16];
+  __shared__ int s_pw, s_bad[16];
+  if (blockIdx.x != 0) {
+    // ---------------- replay: rows [row0, row0 + rows) of V in LDS, rotated as the sweeps are published
+    const int row0 = ((int)blockIdx.x - 1) * kBigSlabRows, rows = min(kBigSlabRows, r - row0);
+    double* s_cs = s_dyn + kBigSlabRows * n;  // kBigStageRounds × half × (c, s); later: 16 columns of the correction
+    for (int e = tid; e < rows * n; e += nt) {
+      const int k = e / n, p = e - k * n;
+      s_dyn[e] = Vwarm ? Vwarm[(size_t)(row0 + k) * r + p] : (row0 + k == p ? 1.0 : 0.0);
+    }
+    int ra = 0, rb = 0;
+    if (tid < half) rr_init(tid, mm, ra, rb);
+    // items of a round: (row k, pair P); the same ones every round
+    constexpr int kItems = 7;  // 64 rows × 100 pairs / 1024 threads
+    int itk[kItems], itP[kItems];
+#pragma unroll
+    for (int m = 0; m < kItems; ++m) {
+      const int it = tid + m * nt;
+      itk[m] = it < rows * half ? it / half : -1;
+      itP[m] = it < rows * half ? it - itk[m] * half : 0;
+    }
+    int done = 0;
+    for (;;) {
+      if (tid == 0) {
+        int pw;
+        for (;;) {
+          pw = __hip_atomic_load(meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (((pw >> kPwIdShift) & kPwIdMask) == launch_id && ((pw & kPwRoundsMask) > done || (pw & (kPwAbort | kPwFinished)))) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+        s_pw = pw;
+      }
+      __syncthreads();
+      const int pw = s_pw;
+      const int avail = pw & kPwRoundsMask;
+      while (done < avail) {
+        const int nr = min(avail - done, kBigStageRounds);
+        for (int e = tid; e < 2 * nr * half; e += nt) s_cs[e] = sc1_load(rotlog + 2 * (size_t)done * half + e);
+        __syncthreads();
+        for (int rl = 0; rl < nr; ++rl) {
+          if (tid < half) {
+            const int p = ra < rb ? ra : rb, q = ra < rb ? rb : ra;
+            s_p[tid] = (short)p; s_q[tid] = (short)q;
+            rr_advance(tid, mm, ra, rb);
+          }
+          __syncthreads();
+#pragma unroll
+          for (int m = 0; m < kItems; ++m) {
+            if (itk[m] < 0) continue;
+            const int k = itk[m], P = itP[m];
+            const int p = s_p[P], q = s_q[P];
+            if (q < r) {
+              const dbl2 cs = *(const dbl2*)&s_cs[2 * (rl * half + P)];
+              const double vp = s_dyn[k * n + p], vq = s_dyn[k * n + q];
+              s_dyn[k * n + p] = fma(cs.x, vp, -(cs.y * vq));   // columns: [p q] <- [p q]·[c s; −s c]
+              s_dyn[k * n + q] = fma(cs.y, vp, cs.x * vq);
+            }
+          }
+          __syncthreads();
+        }
+        done += nr;
+      }
+      if (pw & (kPwFinished | kPwAbort)) break;
+    }
+    if (__hip_atomic_load(meta + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == launch_id) {
+      // the iteration stopped on the loose test: rows·(I + X), sixteen columns of X through LDS at a time (k_posterior_eigen_rr)
+      for (int j0 = 0; j0 < n; j0 += 16) {
+        __syncthreads();
+        for (int e = tid; e < n * 16; e += nt) {
+          const int i = e >> 4, j = j0 + (e & 15);
+          s_cs[e] = j < n ? sc1_load(xcorr + (size_t)i * n + j) : 0.0;
+        }
+        __syncthreads();
+        const int k = tid >> 4, j = j0 + (tid & 15);
+        if (k < rows && j < n) {
+          double acc = 0.0;
+          for (int i = 0; i < n; ++i) acc = fma(s_dyn[k * n + i], s_cs[i * 16 + (tid & 15)], acc);
+          Vwork[(size_t)(row0 + k) * r + j] = s_dyn[k * n + j] + acc;
+        }
+      }
+    } else {
+      for (int e = tid; e < rows * n; e += nt) Vwork[(size_t)row0 * r + e] = s_dyn[e];
+    }
+    return;
+  }
+  // ---------------- the iteration
+  const int ld = SQUARE ? (n | 1) : 0;
+  const int n_off = SQUARE ? n * ld : n * (n - 1) / 2;
+  double* s_diag = s_dyn + n_off;
+  double* s_cs = s_diag + n;  // [half] (c, s) of the round's pairs
+  auto at = [&](int i, int j) { return SQUARE ? i * ld + j : big_idx(i, j, n); };  // i < j
+  for (int e = tid; e < n * n; e += nt) {
+    const int i = e / n, j = e - i * n;
+    if (i < j) s_dyn[at(i, j)] = 0.5 * (A0[e] + A0[(size_t)j * n + i]);
+    else if (i == j) s_diag[i] = A0[e];
+  }
+  const int n_blocks = half * (half + 1) / 2;
+  // this thread's blocks (P1 <= P2) and the players sitting at their four seats, advanced round by round in registers
+  int bP1[kBigBlocksPerThread], bP2[kBigBlocksPerThread], a1[kBigBlocksPerThread], b1[kBigBlocksPerThread], a2[kBigBlocksPerThread],
+      b2[kBigBlocksPerThread];
+#pragma unroll
+  for (int m = 0; m < kBigBlocksPerThread; ++m) {
+    const int w = tid + nt * m;
+    bP1[m] = -1; bP2[m] = 0; a1[m] = b1[m] = a2[m] = b2[m] = 0;
+    if (w < n_blocks) {  // unrank the upper triangle of the pair × pair grid, row-major
+      int P1 = 0, base = 0;
+      while (base + (half - P1) <= w) { base += half - P1; ++P1; }
+      bP1[m] = P1; bP2[m] = P1 + (w - base);
+      rr_init(bP1[m], mm, a1[m], b1[m]);
+      rr_init(bP2[m], mm, a2[m], b2[m]);
+    }
+  }
+  int ra = 0, rb = 0;
+  if (tid < half) rr_init(tid, mm, ra, rb);
+  __syncthreads();
+  int converged = 0, use_corr = 0, n_sweeps = 0, n_rounds = 0;
+  for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+    for (int rnd = 0; rnd < mm; ++rnd) {
+      if (tid < half) {
+        const int p = ra < rb ? ra : rb, q = ra < rb ? rb : ra;
+        Rot R{1.0, 0.0};
+        if (q < r) R = jacobi_rotation(s_diag[p], s_dyn[at(p, q)], s_diag[q]);
+        *(dbl2*)&s_cs[2 * tid] = dbl2{R.c, R.s};
+        *(dbl2*)(rotlog + 2 * ((size_t)n_rounds * half + tid)) = dbl2{R.c, R.s};
+        rr_advance(tid, mm, ra, rb);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < kBigBlocksPerThread; ++m) {
+        if (bP1[m] < 0) continue;
+        const int P1 = bP1[m], P2 = bP2[m];
+        const int p1 = min(a1[m], b1[m]), q1 = max(a1[m], b1[m]), p2 = min(a2[m], b2[m]), q2 = max(a2[m], b2[m]);
+        rr_advance(P1, mm, a1[m], b1[m]);
+        rr_advance(P2, mm, a2[m], b2[m]);
+        const dbl2 r1 = *(const dbl2*)&s_cs[2 * P1], r2 = *(const dbl2*)&s_cs[2 * P2];
+        if (P1 == P2) {
+          if (q1 < r) {
+            const int o = at(p1, q1);
+            const double apq = s_dyn[o];
+            const B22 nb = rot_block(B22{s_diag[p1], apq, apq, s_diag[q1]}, r1.x, r1.y, r1.x, r1.y);
+            s_diag[p1] = nb.a00; s_diag[q1] = nb.a11; s_dyn[o] = nb.a01;
+          }
+        } else {
+          // entries A[x][y], x in {p1, q1}, y in {p2, q2}; a bye (q >= r) has no row / column and an identity rotation
+          // (taken block by block: holding all five blocks' entries at once — one trip of LDS latency for the lot — needs
+          // more than the 128 registers a 1024-thread workgroup has, and the spills cost more than the latency: 648 -> 899 µs at rank 101)
+          const bool h1 = q1 < r, h2 = q2 < r;
+          const int opp = p1 < p2 ? at(p1, p2) : at(p2, p1);
+          const int opq = h2 ? (p1 < q2 ? at(p1, q2) : at(q2, p1)) : 0;
+          const int oqp = h1 ? (q1 < p2 ? at(q1, p2) : at(p2, q1)) : 0;
+          const int oqq = (h1 && h2) ? (q1 < q2 ? at(q1, q2) : at(q2, q1)) : 0;
+          B22 b{s_dyn[opp], h2 ? s_dyn[opq] : 0.0, h1 ? s_dyn[oqp] : 0.0, (h1 && h2) ? s_dyn[oqq] : 0.0};
+          const B22 nb = rot_block(b, r1.x, r1.y, r2.x, r2.y);
+          s_dyn[opp] = nb.a00;
+          if (h2) s_dyn[opq] = nb.a01;
+          if (h1) s_dyn[oqp] = nb.a10;
+          if (h1 && h2) s_dyn[oqq] = nb.a11;
+        }
+      }
+      __syncthreads();
+      ++n_rounds;
+    }
+    // convergence (thread = row of the triangle): strict off(A)² <= 1e-26·Σ diag², or loose — every |A_ij| <= 4e-6·|A_jj − A_ii|:
+    // the replay workgroups then apply V <- V·(I + X), X_ij = A_ij/(A_jj − A_ii), in place of one more sweep (see k_posterior_eigen_rr)
+    double off = 0.0, dg = 0.0;
+    bool bad = false;
+    if (tid < n) {
+      const double dii = s_diag[tid];
+      for (int j = tid + 1; j < n; ++j) {
+        const double v = s_dyn[at(tid, j)];
+        off = fma(2.0 * v, v, off);
+        bad = bad || fabs(v) > 4e-6 * fabs(s_diag[j] - dii);
+      }
+      dg = dii * dii;
+    }
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
+    const bool wave_bad = __any(bad);
+    if ((tid & 63) == 0) { s_red[tid >> 6] = off; s_red2[tid >> 6] = dg; s_bad[tid >> 6] = wave_bad ? 1 : 0; }
+    __syncthreads();
+    off = 0.0; dg = 0.0;
+    int any_bad = 0;
+    for (int w = 0; w < 16; ++w) { off += s_red[w]; dg += s_red2[w]; any_bad |= s_bad[w]; }
+    const int strict = off <= 1e-26 * dg;
+    converged = strict || (!any_bad && off <= dg && !no_corr);
+    use_corr = converged && !strict;
+    n_sweeps = sweep + 1;
+    const bool last = converged || sweep + 1 >= max_sweeps;
+    if (last && use_corr && tid < n) {
+      const double dii = s_diag[tid];
+      sc1_store(xcorr + (size_t)tid * n + tid, 0.0);
+      for (int j = tid + 1; j < n; ++j) {
+        const double a = s_dyn[at(tid, j)];
+        const double x = a == 0.0 ? 0.0 : a / (s_diag[j] - dii);
+        sc1_store(xcorr + (size_t)tid * n + j, x);
+        sc1_store(xcorr + (size_t)j * n + tid, -x);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // this sweep's rotations are in the log (plain stores, every storing wave past the barrier above): released, then announced
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (last) __hip_atomic_store(meta + 1, use_corr ? launch_id : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(meta, (launch_id << kPwIdShift) | (last ? kPwFinished : 0) | n_rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+  if (tid < n) mu_out[tid] = s_diag[tid];
+  if (tid == 0) { status[0] = converged ? 0 : 2; status[-1] = n_sweeps; }
+}
+
+// T = A·V (pass 0) or A' = Vᵀ·T (pass 1): plain one-thread-per-entry products (r <= 200: 8 MFLOP, spread over the chip)
+__global__ void __launch_bounds__(256) k_eigen_big_warm(int r, const double* __restrict__ X, const double* __restrict__ V, double* __restrict__ out,
+                                                         int pass) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= r * r) return;
+  const int i = e / r, j = e - i * r;
+  double s = 0.0;
+  if (pass == 0) { for (int k = 0; k < r; ++k) s = fma(X[(size_t)i * r + k], V[(size_t)k * r + j], s); }
+  else { for (int k = 0; k < r; ++k) s = fma(V[(size_t)k * r + i], X[(size_t)k * r + j], s); }
+  out[e] = s;
+}
+
+// one wave per index p: rank of its eigenvalue (S descending = mu ascending, ties: lower index first), sign by the
+// largest-|.| component (the first among equals), the two output layouts
+__global__ void __launch_bounds__(64) k_eigen_big_finish(int r, const double* __restrict__ Vwork, const double* __restrict__ mu,
+                                                          double* __restrict__ Vout, double* __restrict__ Vtout, double* __restrict__ Sout,
+                                                          const int* __restrict__ status, int* __restrict__ host_status) {
+  const int p = blockIdx.x, l = threadIdx.x;
+  const double mp = mu[p];
+  int cnt = 0;
+  for (int j = l; j < r; j += 64) { const double mj = mu[j]; cnt += (mj < mp) || (mj == mp && j < p); }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  const int rank = cnt;
+  double bv = -1.0;
+  int bi = 0x7fffffff;
+  for (int k = l; k < r; k += 64) {
+    const double a = fabs(Vwork[(size_t)k * r + p]);
+    if (a > bv) { bv = a; bi = k; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  const double sgn = Vwork[(size_t)bi * r + p] < 0.0 ? -1.0 : 1.0;
+  for (int k = l; k < r; k += 64) {
+    const double v = Vwork[(size_t)k * r + p] * sgn;
+    Vout[(size_t)k * r + rank] = v;
+    Vtout[(size_t)rank * r + k] = v;
+  }
+  if (l == 0) Sout[rank] = 1.0 / mp;
+  if (p == 0 && l == 0 && host_status) __hip_atomic_store(host_status, status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------- a8 propose
 // c_new = (G + σ²I)⁻¹ G w = w − σ² P w with P = (G + σ²I)⁻¹ precomputed;  w = α + D⁻¹ V (√S ∘ z)
 
@@ -1309,68 +1776,7 @@ static void launch_factor_reg(hipStream_t st, int r, int n_post, const FactorArg
   hipLaunchKernelGGL((k_posterior_factor_reg<TPT, NT>), dim3(n_post), dim3(NT), shmem, st, r, fa);
 }
 
-// ---------------------------------------------------------------- ranks whose factor does not fit one CU's LDS (r > 127)
-// Same framing as the eigensolver above: the assembly (split sums in split order, + I) and the status are ours, the
-// Cholesky factorisation and the two triangular solves are rocsolver_dpotrf / dpotrs (3.3 ms -> 0.3 ms at rank 200).
-// scratch: r² (factor) | r (right-hand side -> α) | 1 int (info)
-__global__ void __launch_bounds__(256) k_factor_lib_prepare(int r, const double* __restrict__ Mpart, int S, double* __restrict__ M,
-                                                            double* __restrict__ W, double* __restrict__ b) {
-  const int n = r + 1, e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n * r) return;
-  const int i = e / r, j = e - i * r;  // i == r: the appended row bᵀ = Maug[r][0..r-1]
-  const int hi = i < r ? max(i, j) : r, lo = i < r ? min(i, j) : j;  // the factor kernels read the lower triangle of the partials
-  double m = 0.0;
-  for (int s = 0; s < S; ++s) m += Mpart[(size_t)s * n * n + (size_t)hi * n + lo];
-  if (i < r) {
-    m += i == j ? 1.0 : 0.0;
-    M[e] = m;
-    W[e] = m;  // symmetric: row- = column-major
-  } else {
-    b[j] = m;
-  }
-}
-__global__ void __launch_bounds__(256) k_factor_lib_finish(int r, const double* __restrict__ b, const int* __restrict__ info,
-                                                           double* __restrict__ alpha, int* __restrict__ status) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < r) alpha[i] = b[i];
-  if (i == 0) status[0] = info[0] == 0 ? 0 : 1;
-}
-// One handle per stream: a handle owns the device workspace its calls use, in the order of ITS stream — one handle moved
-// from stream to stream let the decompositions of two chains (each on its own context's eigen stream) share that
-// workspace while both were in flight (memory fault with two rank-101 chains in one batch).
-static std::map<hipStream_t, rocblas_handle> g_library_handles;
-static rocblas_handle library_handle(hipStream_t st) {  // callers hold g_library_mutex
-  std::map<hipStream_t, rocblas_handle>& handles = g_library_handles;
-  auto it = handles.find(st);
-  if (it != handles.end()) return it->second;
-  rocblas_handle handle = nullptr;
-  if (rocblas_create_handle(&handle) != rocblas_status_success) return nullptr;
-  if (rocblas_set_stream(handle, st) != rocblas_status_success) { (void)rocblas_destroy_handle(handle); return nullptr; }
-  handles[st] = handle;
-  return handle;
-}
-static std::mutex g_library_mutex;  // (the handle carries the stream; calls only enqueue)
-void library_release_stream(hipStream_t st) {  // the stream is about to be destroyed (and has been synchronised)
-  std::lock_guard<std::mutex> lk(g_library_mutex);
-  auto it = g_library_handles.find(st);
-  if (it == g_library_handles.end()) return;
-  (void)rocblas_destroy_handle(it->second);
-  g_library_handles.erase(it);
-}
-
-static bool launch_factor_library(hipStream_t st, int r, const PosteriorFactorIO& io) {
-  std::lock_guard<std::mutex> lk(g_library_mutex);
-  rocblas_handle handle = library_handle(st);
-  if (!handle) return false;
-  double* W = io.scratch;
-  double* b = W + (size_t)r * r;
-  int* info = (int*)(b + r);
-  hipLaunchKernelGGL(k_factor_lib_prepare, dim3(((r + 1) * r + 255) / 256), dim3(256), 0, st, r, io.Mpart, io.splits, io.M, W, b);
-  if (rocsolver_dpotrf(handle, rocblas_fill_lower, r, W, r, info) != rocblas_status_success) return false;
-  if (rocsolver_dpotrs(handle, rocblas_fill_lower, r, 1, W, r, b, r) != rocblas_status_success) return false;
-  hipLaunchKernelGGL(k_factor_lib_finish, dim3((r + 255) / 256), dim3(256), 0, st, r, b, info, io.alpha, io.status);
-  return true;
-}
+void library_release_stream(hipStream_t) {}  // (no library handles any more: kept for the callers' stream teardown)
 
 void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io) {
   FactorArgs fa{};
@@ -1385,13 +1791,12 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
   if (w_fits && tiles <= 256) launch_factor_reg<1, 256>(st, r, n_post, fa);
   else if (w_fits && tiles <= 1024) launch_factor_reg<1, 1024>(st, r, n_post, fa);
   else if (w_fits && tiles <= 2048) launch_factor_reg<2, 1024>(st, r, n_post, fa);
-  else {
-    static const bool own_generic = std::getenv("ICP_FACTOR_GENERIC") != nullptr;
-    if (!own_generic) {
-      bool ok = true;
-      for (int p = 0; p < n_post && ok; ++p) ok = launch_factor_library(st, r, io[p]);
-      if (ok) return;
-    }
+  else if (r <= kCholMaxRank) {  // blocked, matrix in `scratch`, block columns through LDS
+    const size_t shmem = sizeof(double) * ((size_t)kCholNB * (kCholNB + 1) + (size_t)(r + 1) * (kCholNB + 1));
+    static size_t lds_granted = 0;
+    if (shmem > lds_granted) { set_dyn_lds((const void*)k_posterior_factor_blocked, shmem); lds_granted = shmem; }
+    hipLaunchKernelGGL(k_posterior_factor_blocked, dim3(n_post), dim3(1024), shmem, st, r, fa);
+  } else {
     const int use_lds = (size_t)(r + 1) * ld <= (size_t)kLdsDoubles;
     const size_t shmem = use_lds ? sizeof(double) * (size_t)(r + 1) * ld : 0;
     set_dyn_lds((const void*)k_posterior_factor_generic, shmem);
@@ -1425,71 +1830,64 @@ void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO
                        io.step, work, io.out, io.status, use_lds); }
 }
 
-size_t eigen_work_doubles(int r) {  // `work` of launch_posterior_eigen: r×r scratch, or the rotation log of the fixed-position variant
+size_t eigen_work_doubles(int r) {  // `work` of launch_posterior_eigen
   const size_t n2 = ((size_t)r + 1) & ~(size_t)1;
+  if (r > 64) {  // in-place Jacobi (k_eigen_big): A0 | T | Vwork | mu | rotation log of every sweep | meta — or the generic kernel's r×r scratch
+    const size_t log = (size_t)kEigenMaxSweeps * (n2 - 1) * n2;  // (c, s) per pair and round
+    return 3 * (size_t)r * r + n2 + log + 64;
+  }
   const size_t log = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;  // 2 doubles per pair and round
-  return std::max((size_t)r * r + 2 * (size_t)r + 8, log + n2 * 64 + 128 + 256);  // library path: matrix, eigenvalues, scratch, info |
-                                                                              // log + sign exchange + meta (see launch_posterior_eigen)
+  return log + n2 * 64 + 128 + 256;  // fixed-position variant: log + correction + meta (see launch_eigen_rr)
 }
 
-// ---------------------------------------------------------------- ranks > 64: library eigensolver between two small kernels
-// The fixed-position Jacobi kernel keeps the matrix in ONE CU's LDS, which ends at rank 64; the generic kernel further up
-// runs out of that CU's L2 port (68 ms at rank 200).  The ranks of the face configurations therefore go through
-// rocsolver_dsyevd (tridiagonalisation + divide & conquer, 4.3 ms at rank 200, 1.6 ms at 101 — tools/syevd_probe) — a
-// library call on a path the headline configuration never takes — framed by the same conventions as the kernels above:
-// N = D⁻¹MD⁻¹ in, S = 1/μ descending, eigenvector signs by their largest-|.| component.
-__global__ void __launch_bounds__(256) k_eigen_lib_prepare(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
+// N = D⁻¹ M D⁻¹ (symmetrised) for the in-place kernel
+__global__ void __launch_bounds__(256) k_eigen_big_prepare(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
                                                            double* __restrict__ A) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= r * r) return;
   const int i = e / r, j = e - i * r;
-  A[e] = 0.5 * (M[(size_t)i * r + j] + M[(size_t)j * r + i]) / (sqrt_lambda[i] * sqrt_lambda[j]);  // symmetric: row- = column-major
-}
-// one wave per eigenvector (column `c` of the column-major result, eigenvalues ascending => rank = c)
-__global__ void __launch_bounds__(64) k_eigen_lib_finalize(int r, const double* __restrict__ Z, const double* __restrict__ mu,
-                                                           const int* __restrict__ info, double* __restrict__ Vout,
-                                                           double* __restrict__ Vtout, double* __restrict__ Sout, int* __restrict__ status,
-                                                           int* __restrict__ host_status) {
-  const int c = blockIdx.x, l = threadIdx.x;
-  const double* z = Z + (size_t)c * r;
-  double bv = -1.0;
-  int bi = 0x7fffffff;
-  for (int k = l; k < r; k += 64) {
-    const double a = fabs(z[k]);
-    if (a > bv) { bv = a; bi = k; }  // (ascending k within a lane: the first among equals stays)
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    const double ov = __shfl_xor(bv, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-  }
-  const double sgn = z[bi] < 0.0 ? -1.0 : 1.0;
-  for (int k = l; k < r; k += 64) {
-    const double v = z[k] * sgn;
-    Vout[(size_t)k * r + c] = v;
-    Vtout[(size_t)c * r + k] = v;
-  }
-  if (l == 0) Sout[c] = 1.0 / mu[c];
-  if (c == 0 && l == 0) {
-    const int st = info[0] == 0 ? 0 : 2;
-    status[0] = st; status[-1] = 0;
-    if (host_status) __hip_atomic_store(host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  A[e] = 0.5 * (M[(size_t)i * r + j] + M[(size_t)j * r + i]) / (sqrt_lambda[i] * sqrt_lambda[j]);
 }
 
-static bool launch_eigen_library(hipStream_t st, int r, const double* M, const double* sqrt_lambda, double* V, double* Vt, double* S,
-                                 double* work, int* status, int* host_status) {
-  std::lock_guard<std::mutex> lk(g_library_mutex);
-  rocblas_handle handle = library_handle(st);
-  if (!handle) return false;
-  double* A = work;                       // r² : N in, eigenvectors (columns) out
-  double* D = work + (size_t)r * r;       // r  : eigenvalues, ascending
-  double* E = D + r;                      // r  : scratch of the tridiagonal form
-  int* info = (int*)(E + r);
-  hipLaunchKernelGGL(k_eigen_lib_prepare, dim3((r * r + 255) / 256), dim3(256), 0, st, r, M, sqrt_lambda, A);
-  if (rocsolver_dsyevd(handle, rocblas_evect_original, rocblas_fill_upper, r, A, r, D, E, info) != rocblas_status_success) return false;
-  hipLaunchKernelGGL(k_eigen_lib_finalize, dim3(r), dim3(64), 0, st, r, A, D, info, V, Vt, S, status, host_status);
-  return true;
+static void launch_eigen_big(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V, double* Vt,
+                             double* S, double* work, int* status, int* host_status) {
+  const size_t n2 = ((size_t)r + 1) & ~(size_t)1, rr = (size_t)r * r;
+  double* A0 = work;
+  double* T = work + rr;
+  double* Vwork = work + 2 * rr;
+  double* mu = work + 3 * rr;
+  double* rotlog = mu + n2;
+  int* meta = (int*)(rotlog + (size_t)kEigenMaxSweeps * (n2 - 1) * n2);
+  const int eb = (int)((rr + 255) / 256);
+  hipLaunchKernelGGL(k_eigen_big_prepare, dim3(eb), dim3(256), 0, st, r, M, sqrt_lambda, A0);
+  if (Vwarm) {  // A0 <- Vwarmᵀ·A0·Vwarm
+    hipLaunchKernelGGL(k_eigen_big_warm, dim3(eb), dim3(256), 0, st, r, (const double*)A0, Vwarm, T, 0);
+    hipLaunchKernelGGL(k_eigen_big_warm, dim3(eb), dim3(256), 0, st, r, (const double*)T, Vwarm, A0, 1);
+  }
+  const size_t half = n2 / 2;
+  const bool square = r <= 140;  // the full n × (n|1) image fits one CU's LDS
+  const size_t lds_iter = sizeof(double) * ((square ? (size_t)r * (r | 1) : (size_t)r * (r - 1) / 2) + r + 2 * half);
+  const size_t lds_replay = sizeof(double) * ((size_t)kBigSlabRows * r + std::max(2 * (size_t)kBigStageRounds * half, (size_t)16 * r));
+  const size_t shmem = std::max(lds_iter, lds_replay);
+  static size_t lds_granted[2] = {0, 0};
+  if (shmem > lds_granted[square]) {
+    if (square) set_dyn_lds((const void*)k_eigen_big<true>, shmem); else set_dyn_lds((const void*)k_eigen_big<false>, shmem);
+    lds_granted[square] = shmem;
+  }
+  static std::atomic<int> launch_counter{0};
+  const int launch_id = 1 + (int)((unsigned)(++launch_counter) % kPwIdMask);
+  static const int sweeps_cap = std::getenv("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(std::getenv("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
+  static const int no_corr = std::getenv("ICP_EIGEN_NO_CORRECTION") != nullptr;
+  const int nb = (r + kBigSlabRows - 1) / kBigSlabRows;
+  double* xcorr = T;  // (the warm transform's scratch is free once the iteration starts)
+  if (square)
+    hipLaunchKernelGGL(k_eigen_big<true>, dim3(1 + nb), dim3(1024), shmem, st, r, (const double*)A0, Vwarm, Vwork, mu, rotlog, xcorr, meta,
+                       std::min(sweeps_cap, kEigenMaxSweeps), no_corr, launch_id, status);
+  else
+    hipLaunchKernelGGL(k_eigen_big<false>, dim3(1 + nb), dim3(1024), shmem, st, r, (const double*)A0, Vwarm, Vwork, mu, rotlog, xcorr, meta,
+                       std::min(sweeps_cap, kEigenMaxSweeps), no_corr, launch_id, status);
+  hipLaunchKernelGGL(k_eigen_big_finish, dim3(r), dim3(64), 0, st, r, (const double*)Vwork, (const double*)mu, V, Vt, S, (const int*)status,
+                     host_status);
 }
 
 void eigen_debug_dump(const double* work, int r) {  // developer aid: convergence trace of the last decomposition on `work`
@@ -1560,11 +1958,12 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
     const EigenRequest rq{M, Vwarm, V, Vt, S, work, status, spec, host_status, nullptr, 0};
     if (launch_posterior_eigen_pair(st, r, sqrt_lambda, 1, &rq)) return;
   }
-  static const bool own_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
-  if (!own_generic && r > 64) {
+  if (r > 64 && r <= kBigMaxRank) {  // in-place parallel Jacobi, packed triangle in one CU's LDS + replay workgroups
     ProfScope _ps(st, KID_EIGEN);
-    if (launch_eigen_library(st, r, M, sqrt_lambda, V, Vt, S, work, status, host_status)) return;
+    launch_eigen_big(st, r, M, sqrt_lambda, Vwarm, V, Vt, S, work, status, host_status);
+    return;
   }
+  // ranks above 200: the generic single-workgroup kernel (matrix behind L2)
   const int ld = r | 1;
   const size_t budget = (size_t)kLdsDoubles - 1800;  // static LDS of the kernel
   const int a_in_lds = (size_t)r * ld <= budget;

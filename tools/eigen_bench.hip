@@ -75,6 +75,8 @@ int main(int argc, char** argv) {
     std::vector<double> al(r); hipMemcpy(al.data(), dal, 8 * r, hipMemcpyDeviceToHost);
     double res = 0;
     for (int i = 0; i < r; ++i) { double t = -Mp[(size_t)r * n + i]; for (int j = 0; j < r; ++j) t += M0[(size_t)i * r + j] * al[j]; res = std::fmax(res, std::fabs(t)); }
+    if (r > 127) printf("blocked factor r=%d: assembly %.1f diagonal blocks %.1f panels %.1f trailing %.1f back substitution %.1f us\n", r, s[24] * 0.01, s[25] * 0.01,
+                        s[26] * 0.01, s[27] * 0.01, (s[29] - s[28]) * 0.01);
     printf("factor r=%d: %.1f us/call | setup %.1f columns %.1f store %.1f dinv %.1f backsolve %.1f | residual %.2e\n", r, ms * 1000 / 20,
            (s[17] - s[16]) * 0.01, (s[18] - s[17]) * 0.01, (s[19] - s[18]) * 0.01, 0.0, (s[20] - s[19]) * 0.01, res);
   }
