@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libicp_proposal_amd.so")
+# ICP_LIBRARY_PATH: a test process may ask for the build with the test hooks compiled in (libicp_proposal_amd_testhooks.so)
+LIB_PATH = os.environ.get("ICP_LIBRARY_PATH") or os.path.join(_HERE, "libicp_proposal_amd.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int32)
@@ -93,6 +94,7 @@ SIGNATURES = {
                                                c_double_p, c_double_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_void_p)]),
     "icp_chain_step_batched_collect": (C.c_int, [C.c_void_p]),
     "icp_chain_step_batched_abandon": (C.c_int, [C.c_void_p]),
+    "icp_ctx_set_rotation": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "icp_chain_step_batched": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                          C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p), c_double_p, c_double_p,
                                          c_double_p, C.POINTER(C.c_int32)]),

@@ -95,9 +95,21 @@ class IcpContext:
         nat.check(L.icp_ctx_create(C.byref(md), C.byref(td), device, C.byref(h)), "icp_ctx_create")
         self.h = h
         self.rank, self.N = model.rank, model.n_points
+        self._children = []  # weak references to the proposals / evaluators / chains created on this context
+
+    def _adopt(self, child):
+        import weakref
+        self._children.append(weakref.ref(child))
 
     def close(self):
+        """Destroys the context — after every proposal, evaluator and chain that still lives on it (their native objects hold
+        device buffers, pinned memory and events of this context: closing the context first would leak them)."""
         if getattr(self, "h", None):
+            for ref in reversed(getattr(self, "_children", [])):
+                child = ref()
+                if child is not None and getattr(child, "h", None):
+                    child.close()
+            self._children = []
             nat.lib().icp_ctx_destroy(self.h)
             self.h = None
 
@@ -118,6 +130,13 @@ class IcpContext:
             out[s.name.decode()] = dict(calls=s.calls, total_ms=s.total_ms, avg_us=1e3 * s.total_ms / s.calls,
                                         min_us=1e3 * s.min_ms, max_us=1e3 * s.max_ms)
         return out
+
+    def setRotation(self, angles, R=None):
+        """icp_ctx_set_rotation: use the caller's rotation matrix (row-major 3x3, e.g. Scalismo's Rotation(phi, theta, psi)) for every
+        theta whose Euler angles equal `angles`; R=None withdraws it."""
+        a = _f64(angles).reshape(3)
+        m = _f64(R).reshape(9) if R is not None else None
+        nat.check(nat.lib().icp_ctx_set_rotation(self.h, _d(a), _d(m) if m is not None else None), "icp_ctx_set_rotation")
 
     def transformedMesh(self, theta) -> np.ndarray:
         """ModelFittingParameters.transformedMesh (ModelFittingParameters.scala:108-110) -> points [N,3]."""
@@ -197,6 +216,7 @@ class NonRigidIcpProposal:
         nat.check(nat.lib().icp_proposal_create(ctx.h, C.byref(prm), C.byref(h)), "icp_proposal_create")
         self.h = h
         self.K = nat.lib().icp_proposal_num_candidates(h)
+        ctx._adopt(self)
 
     def close(self):
         if getattr(self, "h", None) and getattr(self.ctx, "h", None):
@@ -248,6 +268,7 @@ class _Evaluator:
         h = C.c_void_p()
         nat.check(nat.lib().icp_evaluator_create(ctx.h, C.byref(prm), C.byref(h)), "icp_evaluator_create")
         self.h = h
+        ctx._adopt(self)
 
     def close(self):
         if getattr(self, "h", None) and getattr(self.ctx, "h", None):

@@ -326,6 +326,16 @@ struct icp_ctx {
     stage_used = 0;
   }
 
+  // Rotation matrices supplied by the caller for given Euler triples (icp_ctx_set_rotation): the reference delegates
+  // Rotation(phi, theta, psi, centre) to Scalismo (ModelFittingParameters.scala:79-86), whose convention cannot be verified in
+  // this image — a host that passes Scalismo's own matrix keeps that convention its own; without an entry for a triple the
+  // library's Rz·Ry·Rx is used.  Small LRU table, exact comparison of the three angles.
+  struct RotationEntry { double angles[3]; double R[9]; uint64_t stamp; bool valid = false; };
+  static constexpr int kRotationEntries = 32;
+  RotationEntry rotations[kRotationEntries];
+  uint64_t rotation_clock = 0;
+  Pose pose_of(const double* theta);
+
   StateSlot& state(const double* theta);
   StateSlot* find_state(const double* theta);
   StateSlot& fresh_state();
@@ -351,6 +361,17 @@ struct Bound {  // selects the context's device and (if enabled) its profiler fo
   ~Bound() { g_prof = nullptr; }
 };
 }  // namespace
+
+Pose icp_ctx::pose_of(const double* theta) {
+  Pose p = pose_from_theta(theta);
+  for (auto& e : rotations)
+    if (e.valid && e.angles[0] == theta[4] && e.angles[1] == theta[5] && e.angles[2] == theta[6]) {
+      for (int k = 0; k < 9; ++k) p.R[k] = e.R[k];
+      e.stamp = ++rotation_clock;
+      break;
+    }
+  return p;
+}
 
 StateSlot* icp_ctx::find_state(const double* theta) {
   const size_t P = 10 + (size_t)r;
@@ -401,7 +422,7 @@ StateSlot& icp_ctx::state(const double* theta) {
   s.theta.assign(theta, theta + P);
   s.valid = true;
   s.stamp = ++clock;
-  s.pose = pose_from_theta(theta);
+  s.pose = pose_of(theta);
   const double* dc = stage(theta + 10, r);
   HIP_OK(hipMemcpyAsync(s.coeffs.p, dc, sizeof(double) * r, hipMemcpyDeviceToDevice, stream));
   launch_instance(stream, N, r, Qp.p, ref.p, mean.p, s.pose, s.coeffs.p, s.x.p);  // ModelFittingParameters.scala:108-110
@@ -1063,7 +1084,7 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     int prio_least = 0, prio_greatest = 0;
     HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     if (g_live_contexts.load(std::memory_order_relaxed) > 0) prio_greatest = 0;
-    if (const char* sp = std::getenv("ICP_STREAM_PRIORITY")) {  // A/B switch: 0 = default priority everywhere
+    if (const char* sp = dev_env("ICP_STREAM_PRIORITY")) {  // A/B switch: 0 = default priority everywhere
       if (std::atoi(sp) == 0) prio_greatest = 0;
     }
     HIP_OK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest));
@@ -1216,6 +1237,44 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     if (bp) (void)hipHostFree(bp);
   if (ctx->counted) --g_live_contexts;
   delete ctx;
+}
+
+int icp_ctx_set_rotation(icp_ctx* ctx, const double* angles, const double* R) {
+  return guard([&] {
+    require(ctx && angles, "null argument");
+    for (int k = 0; k < 3; ++k) require(std::isfinite(angles[k]), "angles must be finite");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    icp_ctx::RotationEntry* slot = nullptr;
+    for (auto& e : ctx->rotations)
+      if (e.valid && e.angles[0] == angles[0] && e.angles[1] == angles[1] && e.angles[2] == angles[2]) { slot = &e; break; }
+    if (!R) {  // withdraw the entry
+      if (slot) slot->valid = false;
+      return;
+    }
+    // the matrix must be a rotation (orthonormal to 1e-9, determinant +1): a wrong layout would otherwise pass silently
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        double d = 0.0;
+        for (int k = 0; k < 3; ++k) d += R[3 * a + k] * R[3 * b + k];
+        require(std::fabs(d - (a == b ? 1.0 : 0.0)) <= 1e-9, "R is not orthonormal (row-major 3x3 rotation expected)");
+      }
+    const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+    require(det > 0.0, "R is a reflection, not a rotation");
+    if (!slot) {
+      slot = &ctx->rotations[0];
+      for (auto& e : ctx->rotations) {
+        if (!e.valid) { slot = &e; break; }
+        if (e.stamp < slot->stamp) slot = &e;
+      }
+      // states cached under the same angles were posed with another matrix: forget them (and what hangs on them is keyed by theta, too)
+      for (auto& sl : ctx->slots)
+        if (sl.valid && sl.theta[4] == angles[0] && sl.theta[5] == angles[1] && sl.theta[6] == angles[2]) sl.valid = false;
+    }
+    for (int k = 0; k < 3; ++k) slot->angles[k] = angles[k];
+    for (int k = 0; k < 9; ++k) slot->R[k] = R[k];
+    slot->valid = true;
+    slot->stamp = ++ctx->rotation_clock;
+  });
 }
 
 int icp_ctx_set_idle_hook(icp_ctx* ctx, icp_idle_fn fn, void* arg) {
@@ -1482,7 +1541,7 @@ int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, 
     sync_proposal_status(p);
     c.finish(r, 0);
     p->check_status(e);
-    static const bool dbg = std::getenv("ICP_DEBUG_EIGEN") != nullptr;
+    static const bool dbg = dev_env("ICP_DEBUG_EIGEN") != nullptr;
     if (dbg) std::fprintf(stderr, "eigen sweeps %d\n", p->h_status[e.status_off + 1]);
     std::memcpy(theta_out, theta, sizeof(double) * 10);
     for (int j = 0; j < r; ++j) {
@@ -1659,7 +1718,7 @@ int icp_fit_deterministic(icp_ctx* ctx, const icp_fit_params* prm, const double*
     std::lock_guard<std::recursive_mutex> lk(c.mu);
     Bound _b(&c);
     const int r = c.r, Ka = std::max(K, 1);
-    const Pose pose = pose_from_theta(theta_init);
+    const Pose pose = c.pose_of(theta_init);
     DBuf<double> coeffs, x, P, cp, pts, Mpart, M, alpha, e, nhat, pt;
     DBuf<int> ids, nn, hint, corr_id, aux, status;
     DBuf<uint8_t> keep;
@@ -1735,10 +1794,10 @@ int icp_posterior_variability(icp_ctx* ctx, int32_t n_samples, const double* the
     coeffs.upload(hc.data(), hc.size());
     nrm.alloc(n3); tmp.alloc(n3); res.alloc(c.N);
     for (int s = 0; s < n_samples; ++s)   // ModelFittingParameters.transformedMesh of every sample (LogHelper.logSamples2shapes)
-      launch_instance(c.stream, c.N, c.r, c.Qp.p, c.ref.p, c.mean.p, pose_from_theta(thetas + s * P), coeffs.p + (size_t)s * c.r,
+      launch_instance(c.stream, c.N, c.r, c.Qp.p, c.ref.p, c.mean.p, c.pose_of(thetas + s * P), coeffs.p + (size_t)s * c.r,
                       X.p + (size_t)s * n3);
     if (mode == 1) {
-      launch_instance(c.stream, c.N, c.r, c.Qp.p, c.ref.p, c.mean.p, pose_from_theta(theta_ref), coeffs.p + (size_t)n_samples * c.r, tmp.p);
+      launch_instance(c.stream, c.N, c.r, c.Qp.p, c.ref.p, c.mean.p, c.pose_of(theta_ref), coeffs.p + (size_t)n_samples * c.r, tmp.p);
       launch_vertex_normals(c.stream, c.N, tmp.p, c.tris.p, c.adj_off.p, c.adj.p, nrm.p);
     } else if (mode == 2) {
       HIP_OK(hipMemsetAsync(nrm.p, 0, sizeof(double) * n3, c.stream));
@@ -2024,7 +2083,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   StateSlot& s = c.fresh_state();
   s.reserved = true;
   F.s = &s;
-  s.pose = pose_from_theta(generator >= 0 ? theta_cur : key);
+  s.pose = c.pose_of(generator >= 0 ? theta_cur : key);
   for (int i = 0; i < n_props; ++i) { ep[i] = &props[i]->fresh_entry(); ep[i]->reserved = true; }
   const icp_evaluator_params& evp = e->prm;
   icp_proposal* pm = nullptr;  // ModelSampling proposal
@@ -2053,12 +2112,10 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   b.Qp = c.Qp.p; b.ref = c.ref.p; b.mean = c.mean.p; b.pose = s.pose;
   b.propose = generator >= 0 ? 1 : 0;
   const double* src = generator >= 0 ? key : key + 10;
-  if (r <= kStepInlineZ) std::memcpy(b.zin, src, sizeof(double) * r);
-  else {
-    if ((size_t)r > c.stage_cap) fail(ICP_ERR_INVALID_ARG, "internal: staging area exhausted");
-    std::memcpy(c.h_stage, src, sizeof(double) * r);
-    b.z_ptr = c.h_stage;  // pinned, read by the device in place
-  }
+  // (the merged launches cover ranks whose factor fits LDS — step_finish_supported, about 116 — so the r host-drawn numbers
+  // always travel inside the kernel arguments)
+  require(r <= kStepInlineZ, "internal: merged step at a rank above the inline-argument limit");
+  std::memcpy(b.zin, src, sizeof(double) * r);
   if (generator >= 0) {
     PosteriorEntry& g = *ec[generator];
     b.prop = ProposeIn{g.alpha.p, g.V.p, g.S.p, c.inv_sqrt_lambda.p, c.P.p, g.coeffs.p, nullptr, kSigma2,
@@ -2077,7 +2134,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   // (nothing to wait for before the first finish launch, nor when every step is on one stream)
   b.wait_flag = (c.last_back_seq > 0 && !c.pipeline_off && !batched) ? c.d_done.p + 2 : nullptr;
   // test hook: the first launch waits for a word that never comes, times out, and the step is repeated unpipelined
-  static const int starve_pipeline = std::getenv("ICP_TEST_STARVE_PIPELINE") ? (1 << 24) : 0;
+  static const int starve_pipeline = dev_env("ICP_TEST_STARVE_PIPELINE") ? (1 << 24) : 0;
   b.wait_seq = c.last_back_seq + starve_pipeline;
   b.wait_error = c.h_wait_error;
   b.wait_ticks = c.profiling ? c.d_wait_ticks.p : nullptr;
@@ -2276,7 +2333,6 @@ int icp_chain_step_prelaunch(icp_evaluator* e, int32_t n_props, icp_proposal* co
     std::lock_guard<std::recursive_mutex> lk(c.mu);
     drop_front(e);
     if (c.pipeline_off) return;
-    if (c.r > kStepInlineZ) return;  // (larger ranks stage z in one pinned area: not double-buffered)
     // with several chains in the process the device is not idle during one chain's turn-around, and the launches of a
     // dropped half step cost the others host time (tools/multichain.py)
     if (g_live_contexts.load(std::memory_order_relaxed) > 1) return;
@@ -2350,7 +2406,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     const bool speculate = (spec_mode == 1 || (spec_mode == 2 && e->acc_ema >= 0.1)) && !c.speculation_off &&
                            g_live_contexts.load(std::memory_order_relaxed) <= 2 && n_props > 0 && eigen_speculation_supported(r);
     // test hook: the speculative decompositions wait for a word that never comes, time out and are repeated
-    static const int starve = std::getenv("ICP_TEST_STARVE_SPECULATION") ? (1 << 24) : 0;
+    static const int starve = dev_env("ICP_TEST_STARVE_SPECULATION") ? (1 << 24) : 0;
     const int step_seq = ++c.step_seq;
 
     // 5: factorisations + tails (results go straight to pinned host memory)
@@ -2659,7 +2715,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
         lead.batch_device[turn].alloc(cap_bytes);
         lead.batch_bytes[turn] = cap_bytes;
       }
-      static const bool finish_aside = std::getenv("ICP_BATCH_FINISH_INLINE") == nullptr;  // (A/B switch)
+      static const bool finish_aside = dev_env("ICP_BATCH_FINISH_INLINE") == nullptr;  // (A/B switch)
       launch_step_batch(lead.stream, nb, caps.data(), lead.batch_pinned[turn], lead.batch_device[turn].p,
                         finish_aside ? lead.front_stream : nullptr, lead.ev_join);
       if (finish_aside) t.finish_stream = lead.front_stream;

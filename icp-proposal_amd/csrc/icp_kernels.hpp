@@ -4,9 +4,22 @@
 #include <stdint.h>
 #include "icp_device.hpp"
 
+#include <cstdlib>
 #include <vector>
 
 namespace icp {
+
+// Developer A/B switches and test hooks read the environment ONLY in builds made for that purpose (-DICP_DEV_SWITCHES for the
+// tools/, -DICP_TEST_HOOKS for libicp_proposal_amd_testhooks.so, which tests/ load through ICP_LIBRARY_PATH); the shipped
+// library answers nullptr.  Operational switches (ICP_NO_PIPELINE, ICP_SPECULATION, ICP_HOST_TIMING) use getenv directly.
+inline const char* dev_env(const char* name) {
+#if defined(ICP_DEV_SWITCHES) || defined(ICP_TEST_HOOKS)
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
 // Off by default: when `g_prof` is null the launch wrappers add nothing.

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(64) k_vertex_resolve(VertexTask q) {
 
 // enough waves to fill 256 CUs, but at least ~8 queries per wave so the element load is amortised; kchunk multiple of kQU
 void split_queries(int n_elem_blocks, int Kpad, int* ksplit, int* kchunk) {
-  static const int target_waves = std::getenv("ICP_FILTER_WAVES") ? std::atoi(std::getenv("ICP_FILTER_WAVES")) : 4096;
+  static const int target_waves = dev_env("ICP_FILTER_WAVES") ? std::atoi(dev_env("ICP_FILTER_WAVES")) : 4096;
   int want = cdiv(target_waves, n_elem_blocks * (kBlock / 64));
   int s = want < 1 ? 1 : want;
   int maxs = cdiv(Kpad, 8);
@@ -108,7 +108,7 @@ void split_queries(int n_elem_blocks, int Kpad, int* ksplit, int* kchunk) {
 // to 512 queries per workgroup measure the same for one chain) — so few workgroups: a batch of chains launches B times as
 // many.  256 queries per workgroup: two workgroups per block of spheres for the 308 queries of the femur step.
 void split_surface_queries(int Kpad, int* ksplit, int* kchunk) {
-  static const int tile = std::getenv("ICP_SURFACE_CHUNK") ? std::atoi(std::getenv("ICP_SURFACE_CHUNK")) : 256;  // (A/B: <= 512)
+  static const int tile = dev_env("ICP_SURFACE_CHUNK") ? std::atoi(dev_env("ICP_SURFACE_CHUNK")) : 256;  // (A/B: <= 512)
   int kc = Kpad < tile ? Kpad : tile;
   kc = (kc + kQU - 1) / kQU * kQU;
   if (kc < kQU) kc = kQU;

@@ -1876,8 +1876,8 @@ static void launch_eigen_big(hipStream_t st, int r, const double* M, const doubl
   }
   static std::atomic<int> launch_counter{0};
   const int launch_id = 1 + (int)((unsigned)(++launch_counter) % kPwIdMask);
-  static const int sweeps_cap = std::getenv("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(std::getenv("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
-  static const int no_corr = std::getenv("ICP_EIGEN_NO_CORRECTION") != nullptr;
+  static const int sweeps_cap = dev_env("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(dev_env("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
+  static const int no_corr = dev_env("ICP_EIGEN_NO_CORRECTION") != nullptr;
   const int nb = (r + kBigSlabRows - 1) / kBigSlabRows;
   double* xcorr = T;  // (the warm transform's scratch is free once the iteration starts)
   if (square)
@@ -1901,7 +1901,7 @@ void eigen_debug_dump(const double* work, int r) {  // developer aid: convergenc
   std::fprintf(stderr, "[icp eigen] decompositions by sweep count 1..8: %d %d %d %d %d %d %d %d\n", hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
 }
 
-bool eigen_speculation_supported(int r) { return r >= 3 && r <= 64 && std::getenv("ICP_EIGEN_GENERIC") == nullptr; }
+bool eigen_speculation_supported(int r) { return r >= 3 && r <= 64 && dev_env("ICP_EIGEN_GENERIC") == nullptr; }
 
 namespace {
 template <int CAP>
@@ -1913,7 +1913,7 @@ void launch_eigen_rr(hipStream_t st, int r, const double* sqrt_lambda, int n, co
   const size_t shmem = sizeof(double) * ((size_t)kRrOV + 2 * szV);
   // work = [rotation log | sign exchange | meta: progress word, counters, rank per position]
   const size_t log_doubles = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;
-  static const int sweeps_cap = std::getenv("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(std::getenv("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
+  static const int sweeps_cap = dev_env("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(dev_env("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
   static bool lds_set = false;
   set_dyn_lds_once((const void*)k_posterior_eigen_rr<CAP>, sizeof(double) * ((size_t)kRrOV + 2 * 64 * 66), &lds_set);
   static std::atomic<int> launch_counter{0};  // (any value the previous launch on this `work` did not use would do)
@@ -1928,21 +1928,21 @@ void launch_eigen_rr(hipStream_t st, int r, const double* sqrt_lambda, int n, co
   }
   ProfScope _ps(st, KID_EIGEN);
   // per problem: workgroup 0 iterates, workgroup 1 replays its rotations on V as the sweeps are published
-  static const int no_corr = std::getenv("ICP_EIGEN_NO_CORRECTION") != nullptr;
+  static const int no_corr = dev_env("ICP_EIGEN_NO_CORRECTION") != nullptr;
   hipLaunchKernelGGL(k_posterior_eigen_rr<CAP>, dim3(n * (1 + (r + kReplayRows - 1) / kReplayRows)), dim3(1024), shmem, st, r, sqrt_lambda, ldk, std::min(sweeps_cap, kEigenMaxSweeps), no_corr,
                      batch);
 }
 }  // namespace
 
 bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq) {
-  static const bool force_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
+  static const bool force_generic = dev_env("ICP_EIGEN_GENERIC") != nullptr;
   if (!(r >= 3 && r <= 64 && !force_generic) || n < 1 || n > 2) return false;
   launch_eigen_rr<2>(st, r, sqrt_lambda, n, rq);
   return true;
 }
 
 bool launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest* rq) {
-  static const bool force_generic = std::getenv("ICP_EIGEN_GENERIC") != nullptr;
+  static const bool force_generic = dev_env("ICP_EIGEN_GENERIC") != nullptr;
   if (!(r >= 3 && r <= 64 && !force_generic) || n < 1) return false;
   for (int i = 0; i < n; i += kEigenBatchMax) {
     const int m = std::min(kEigenBatchMax, n - i);

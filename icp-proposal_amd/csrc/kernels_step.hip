@@ -426,7 +426,7 @@ void launch_step_begin(hipStream_t st, const StepBeginArgs& a_in) {
   const int vblocks = a.has_vert ? cdiv(a.vert.Kpad, kStepBlock) : 0;
   if (t_capture) { t_capture->begin = a; t_capture->grid[0] = a.inst_blocks + vblocks; return; }
   ProfScope _ps(st, KID_STEP_BEGIN);
-  static const bool no_reg = std::getenv("ICP_BEGIN_STREAMED") != nullptr;  // (A/B switch)
+  static const bool no_reg = dev_env("ICP_BEGIN_STREAMED") != nullptr;  // (A/B switch)
   if (a.hold_regs && a.r >= 32 && a.r <= 52 && !no_reg) hipLaunchKernelGGL(k_step_begin_reg<52>, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
   else if (a.hold_regs && a.r >= 32 && a.r <= 64 && !no_reg) hipLaunchKernelGGL(k_step_begin_reg<64>, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
   else hipLaunchKernelGGL(k_step_begin, dim3(a.inst_blocks + vblocks), dim3(kStepBlock), 0, st, a);
@@ -505,7 +505,7 @@ void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pin
   hipLaunchKernelGGL(k_step_batch_args, dim3(cdiv(n16, 256)), dim3(256), 0, st, (const uint4*)h, (uint4*)d, n16);
   if (gx[0] > 0) {
     ProfScope _ps(st, KID_STEP_BEGIN);
-    static const bool no_reg = std::getenv("ICP_BEGIN_STREAMED") != nullptr;  // (A/B switch)
+    static const bool no_reg = dev_env("ICP_BEGIN_STREAMED") != nullptr;  // (A/B switch)
     const int r = caps[0].begin.r;  // (one rank per batch: checked by the caller)
     bool hold = false;  // any chain of the batch still waiting for its decomposition
     for (int b = 0; b < B; ++b) hold = hold || caps[b].begin.hold_regs != 0;

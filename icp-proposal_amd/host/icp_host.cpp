@@ -1,11 +1,50 @@
 // icp_host.cpp — SamplingRegistration.runfitting mirrored over the C ABI (see icp_host.hpp / icp_host.h).
 #include "icp_host.h"
 
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <thread>
 
 #include "icp_host.hpp"
+
+// java.lang.Double.toString for the magnitudes proposal names are made of (api/sampling/MixedProposalDistributions.scala:31-54
+// interpolates Scala Doubles: "RandomShape-0.1", "RotationYaw-0.01"): the shortest decimal that round-trips, with a
+// fractional part; computerised scientific notation below 1e-3 and from 1e7 ("1.0E-4")
+static std::string scala_double(double x) {
+  if (x != x) return "NaN";
+  if (x == 0.0) return std::signbit(x) ? "-0.0" : "0.0";
+  if (std::isinf(x)) return x > 0 ? "Infinity" : "-Infinity";
+  char buf[64];
+  int prec = 1;
+  for (; prec <= 17; ++prec) {  // shortest mantissa that reproduces x
+    std::snprintf(buf, sizeof(buf), "%.*e", prec - 1, x);
+    if (std::strtod(buf, nullptr) == x) break;
+  }
+  std::string m(buf);
+  const size_t epos = m.find('e');
+  const int ex = std::atoi(m.c_str() + epos + 1);
+  m = m.substr(0, epos);
+  if (m.find('.') == std::string::npos) m += ".0";
+  const double ax = std::fabs(x);
+  if (ax >= 1e-3 && ax < 1e7) {
+    std::string digits;
+    bool neg = false;
+    for (char c : m) { if (c == '-') neg = true; else if (c != '.') digits += c; }
+    std::string out;
+    if (ex >= 0) {
+      while ((int)digits.size() < ex + 2) digits += '0';
+      out = digits.substr(0, ex + 1) + "." + digits.substr(ex + 1);
+    } else {
+      out = "0." + std::string(-ex - 1, '0') + digits;
+    }
+    while (out.size() > 1 && out.back() == '0' && out[out.size() - 2] != '.') out.pop_back();
+    return (neg ? "-" : "") + out;
+  }
+  return m + "E" + std::to_string(ex);
+}
 
 using namespace icphost;
 
@@ -127,7 +166,7 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
       icpMix = static_cast<MixtureProposal*>(own(new MixtureProposal()));
       for (int i = 0; i < cfg->n_icp; ++i) {
         const char* dir = cfg->icp[i].direction == ICP_TARGET_SAMPLING ? "TargetSampling" : "ModelSampling";
-        auto* p = new NonRigidIcpProposal(ctx, cfg->icp[i], std::string("IcpProposal-") + dir + "-" + std::to_string(cfg->icp[i].step_length) + "Step");
+        auto* p = new NonRigidIcpProposal(ctx, cfg->icp[i], std::string("IcpProposal-") + dir + "-" + scala_double(cfg->icp[i].step_length) + "Step");
         p->leafId = i;
         own(p);
         ch->icp.push_back(p);
@@ -138,7 +177,7 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
     MixtureProposal* rwMix = nullptr;
     if (cfg->w_rw > 0) {
       rwMix = static_cast<MixtureProposal*>(own(new MixtureProposal()));
-      auto* p = new RandomShapeUpdateProposal(cfg->rw_sigma, "RandomShape-" + std::to_string(cfg->rw_sigma));
+      auto* p = new RandomShapeUpdateProposal(cfg->rw_sigma, "RandomShape-" + scala_double(cfg->rw_sigma));
       p->leafId = 2;
       own(p);
       rwMix->add(0.5, p);
@@ -151,7 +190,7 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
       for (int a = 0; a < 6; ++a) {
         const double sd = a < 3 ? cfg->pose_rot_sigma[a] : cfg->pose_trans_sigma[a - 3];
         // YawAxis/PitchAxis/RollAxis perturb phi/theta/psi (PoseProposals.scala:40-48) = theta[4..6]; translations theta[1..3]
-        auto* p = new GaussianAxisPoseProposal(a < 3 ? 4 + a : 1 + (a - 3), sd, std::string(names[a]) + "-" + std::to_string(sd));
+        auto* p = new GaussianAxisPoseProposal(a < 3 ? 4 + a : 1 + (a - 3), sd, std::string(names[a]) + "-" + scala_double(sd));
         p->leafId = 3 + a;
         own(p);
         poseMix->add(0.5, p);
@@ -314,7 +353,11 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
     // Several groups a fraction of a step apart: while one group's launches run, the other groups' decompositions do, and
     // the host prepares their submissions (a step's first launch waits ≈ 100 µs for the decompositions of the chains that
     // moved).  Few chains stay in one group: the launches of a part of them would not fill the device.
+    #ifdef ICP_DEV_SWITCHES
     static const int forced = std::getenv("ICP_LOCKSTEP_GROUPS") ? std::atoi(std::getenv("ICP_LOCKSTEP_GROUPS")) : 0;
+#else
+    static const int forced = 0;  // (developer A/B switch: -DICP_DEV_SWITCHES)
+#endif
     int n_groups = forced > 0 ? forced : (n_chains >= 24 ? 3 : n_chains >= 8 ? 2 : 1);  // (measured: tools/ab_batch.sh)
     n_groups = std::max(1, std::min(std::min(n_groups, kMaxGroups), n_chains));
     for (int b = 0; b < n_chains; ++b) groups[(size_t)b * n_groups / n_chains].chains.push_back(chains[b]);

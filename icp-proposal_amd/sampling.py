@@ -65,14 +65,39 @@ class ChainSetup:
         self.eval = dict(kind=0, mode=0, n_model_ids=0, target_pts=np.zeros((0, 3)), gauss_mean=0.0, gauss_sigma=1.0, exp_rate=1.0)
         self.fused = 2  # 0 per-method calls, 1 icp_chain_eval_step prefetch, 2 whole step in one icp_chain_step submission
 
+    @staticmethod
+    def scala_double(x: float) -> str:
+        """java.lang.Double.toString, which Scala's string interpolation uses for the proposal names
+        (api/sampling/MixedProposalDistributions.scala:31-54: s"RandomShape-$sd" -> "RandomShape-0.1"): the shortest decimal that
+        round-trips, always with a fractional part, computerised scientific notation below 1e-3 and from 1e7 ("1.0E-4")."""
+        x = float(x)
+        if x != x:
+            return "NaN"
+        if x in (float("inf"), float("-inf")):
+            return "Infinity" if x > 0 else "-Infinity"
+        if x == 0.0:
+            return "-0.0" if str(x).startswith("-") else "0.0"
+        if 1e-3 <= abs(x) < 1e7:
+            s = repr(x)
+            if "e" in s or "E" in s:  # repr switches to exponents earlier than Java for some magnitudes
+                s = ("%.17f" % x).rstrip("0")
+                if s.endswith("."):
+                    s += "0"
+            return s if "." in s else s + ".0"
+        m, e = ("%r" % x).lower().split("e") if "e" in repr(x).lower() else ("%.16e" % x).split("e")
+        m = m.rstrip("0") if "." in m else m + ".0"
+        if m.endswith("."):
+            m += "0"
+        return "%sE%d" % (m, int(e))
+
     def leaf_names(self):
         """generatedBy strings of the leaf proposals, indexed by the leaf id of the per-step records (host/icp_host.cpp)."""
         names = {}
         for i, p in enumerate(self.icp):
-            names[i] = "IcpProposal-%s-%.6fStep" % ("TargetSampling" if p["direction"] == 1 else "ModelSampling", p["step"])
-        names[2] = "RandomShape-%.6f" % self.rw_sigma
+            names[i] = "IcpProposal-%s-%sStep" % ("TargetSampling" if p["direction"] == 1 else "ModelSampling", self.scala_double(p["step"]))
+        names[2] = "RandomShape-%s" % self.scala_double(self.rw_sigma)
         for a, nm in enumerate(("RotationYaw", "RotationPitch", "RotationRoll", "TranslationX", "TranslationY", "TranslationZ")):
-            names[3 + a] = "%s-%.6f" % (nm, self.pose_rot_sigma[a] if a < 3 else self.pose_trans_sigma[a - 3])
+            names[3 + a] = "%s-%s" % (nm, self.scala_double(self.pose_rot_sigma[a] if a < 3 else self.pose_trans_sigma[a - 3]))
         return names
 
     def to_c(self):
@@ -176,6 +201,8 @@ class SamplingRegistration:
         if st != 0:
             raise nat.IcpNativeError(st, "icp_host_chain_create", (host_lib().icp_host_last_error() or b"").decode())
         self.h = h
+        if hasattr(ctx, "_adopt"):
+            ctx._adopt(self)  # (IcpContext.close() closes the chain — it owns proposals and an evaluator of the context — first)
 
     def close(self):
         if getattr(self, "h", None) and getattr(self.ctx, "h", None):

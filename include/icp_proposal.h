@@ -133,6 +133,14 @@ ICP_API const char *icp_last_error(void); /* thread-local detail of the last fai
 ICP_API int icp_ctx_rank(const icp_ctx *ctx);
 ICP_API int icp_ctx_device(const icp_ctx *ctx);
 
+/* Pose across the boundary.  theta carries the three Euler angles; the reference turns them into a rotation with
+ * Scalismo's Rotation(phi, theta, psi, centre) (ModelFittingParameters.scala:79-86).  A caller that wants Scalismo's OWN matrix
+ * used — whatever its convention — registers it for the triple before passing a theta with these angles: R = row-major 3x3 rotation
+ * (checked: orthonormal, determinant +1); R == NULL withdraws the entry.  Up to 32 triples are remembered (least recently used
+ * out); a theta whose angles have no entry is posed with the library's Rz(phi)·Ry(theta)·Rx(psi).  Register BEFORE the first
+ * call with such a theta: results already memoised under it are not recomputed. */
+ICP_API int icp_ctx_set_rotation(icp_ctx *ctx, const double angles[3], const double R[9]);
+
 /* ModelFittingParameters.transformedMesh (ModelFittingParameters.scala:108-110): points_out [N*3]. */
 ICP_API int icp_transformed_mesh(icp_ctx *ctx, const double *theta, double *points_out);
 /* vertex normals of that mesh (Scalismo vertexNormals, used at NonRigidIcpProposal.scala:100,120): [N*3]. */

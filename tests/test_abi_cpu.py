@@ -95,6 +95,8 @@ def test_batched_step_rejects_bad_arguments_before_device(pkg):
                                             ctypes.byref(ticket)) == -1
     assert ticket.value is None
     assert lib.icp_chain_step_batched_collect(None) == -1
+    assert lib.icp_chain_step_batched_abandon(None) == -1
+    assert lib.icp_ctx_set_rotation(None, None, None) == -1
 
 
 def test_synthetic_target_sizes(pkg):

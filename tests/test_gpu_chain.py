@@ -114,8 +114,8 @@ chain.close(); ctx.close()
                                  {"ICP_NO_PIPELINE": "1"}, {"ICP_TEST_STARVE_PIPELINE": "1"}],
                          ids=["speculation-on", "speculation-starved", "pipeline-off", "pipeline-starved"])
 def test_speculative_decomposition_fallbacks(pkg, femur50, femur50_oracle, oracle, env, tmp_path):
-    """With ICP_SPECULATION=1 icp_chain_step starts the KL basis of the proposed state before the caller decides (icp_abi.hip,
-    speculate_eigen; off by default).  It must give the same chain switched on, and starved — the decomposition never
+    """icp_chain_step starts the KL basis of the proposed state before the caller decides (icp_abi.hip, speculate_eigen;
+    ICP_SPECULATION=1: always, unset: adaptive).  It must give the same chain switched on, and starved — the decomposition never
     sees its input, gives up after its time-out, and the step that drew from it is repeated with an ordinary one.
     Likewise the two-stream step pipeline (on by default): switched off, and starved — a first launch times out on the
     word it waits for, and the context falls back to unpipelined steps."""
@@ -129,6 +129,12 @@ def test_speculative_decomposition_fallbacks(pkg, femur50, femur50_oracle, oracl
     acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), pkg.initial_parameters(model), 1024, 60)
     out = str(tmp_path / "rec.npy")
     script = _SPECULATION_SCRIPT.format(root=ROOT, out=out)
+    if any(k.startswith("ICP_TEST_") for k in env):
+        # the starvation hooks exist only in the test-hooks build of the library (csrc/Makefile: -DICP_TEST_HOOKS); the shipped
+        # library does not read these variables
+        hooks = os.path.join(ROOT, "icp-proposal_amd", "libicp_proposal_amd_testhooks.so")
+        assert os.path.exists(hooks), "build the test-hooks library (python -c 'import __graft_entry__ as g; g.build()')"
+        env = {**env, "ICP_LIBRARY_PATH": hooks}
     subprocess.run([sys.executable, "-c", script], check=True, env={**os.environ, **env}, timeout=300)
     rec = np.load(out)
     assert np.array_equal(rec[:, 1].astype(np.uint8), acc_o), "accept/reject sequences differ"

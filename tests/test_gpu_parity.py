@@ -367,3 +367,50 @@ def test_hinted_searches_on_a_shuffled_distant_target(pkg, femur50, oracle):
         theta = theta.copy()
         theta[10:] += 0.05 * rng.normal(size=r)   # a nearby state: the next searches start from this one's winners
     prop.close(); ev.close(); ctx.close()
+
+
+def test_caller_supplied_rotation_convention(pkg, femur50):
+    """SURVEY.md §8b "pose across the boundary": the host may hand over Scalismo's own rotation matrix for a theta's Euler angles
+    (icp_ctx_set_rotation), so the convention of Rotation(phi, theta, psi, centre) stays Scalismo's.  With the library's own
+    Rz·Ry·Rx registered nothing changes; with another convention the mesh is the one that matrix gives, and the proposal's
+    inverse pose (NonRigidIcpProposal.scala:142) uses the same matrix (z = 0 proposal moves towards the posterior mean)."""
+    model, target = femur50
+    ctx = pkg.IcpContext(model, target, device=0)
+    theta = make_theta(model, 5, pose=True)
+    theta[4:7] = [0.3, -0.2, 0.15]
+    phi, th, psi = theta[4:7]
+    c, s = np.cos, np.sin
+    Rx = np.array([[1, 0, 0], [0, c(psi), -s(psi)], [0, s(psi), c(psi)]])
+    Ry = np.array([[c(th), 0, s(th)], [0, 1, 0], [-s(th), 0, c(th)]])
+    Rz = np.array([[c(phi), -s(phi), 0], [s(phi), c(phi), 0], [0, 0, 1]])
+    x_native = ctx.transformedMesh(theta)
+    ctx.close()
+
+    def posed(R):
+        shape = model.instance(theta[10:])
+        ctr = theta[7:10]
+        return theta[0] * ((shape - ctr) @ R.T + ctr + theta[1:4])
+
+    assert np.abs(x_native - posed(Rz @ Ry @ Rx)).max() < 1e-10   # the library's documented convention
+    for R, differs in ((Rz @ Ry @ Rx, False), (Rx @ Ry @ Rz, True)):
+        ctx = pkg.IcpContext(model, target, device=0)
+        ctx.setRotation(theta[4:7], R)
+        x = ctx.transformedMesh(theta)
+        assert np.abs(x - posed(R)).max() < 1e-10
+        assert (np.abs(x - x_native).max() > 1.0) == differs
+        other = theta.copy(); other[4] += 0.01       # a triple without an entry: native convention
+        xo = ctx.transformedMesh(other)
+        assert np.all(np.isfinite(xo))
+        prop = pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * model.rank, "ModelSampling", True)
+        post = prop.icpPosterior(theta, with_aux=False)
+        got = prop.propose(theta, np.zeros(model.rank))
+        assert np.abs(got[10:] - (theta[10:] + 0.1 * (post.alpha - theta[10:]))).max() < 1e-6 * max(1.0, np.abs(post.alpha).max())
+        # the correspondences' observations are the target points taken back through THIS rotation: R^T((q - t) - ctr) + ctr
+        q = post.corr_point[0]
+        back = ((q / 1.0 - theta[1:4]) - theta[7:10]) @ R + theta[7:10]
+        assert np.all(np.isfinite(back))
+        prop.close()
+        ctx.setRotation(theta[4:7], None)
+        with pytest.raises(pkg._native.IcpNativeError):
+            ctx.setRotation(theta[4:7], 2.0 * R)     # not a rotation
+        ctx.close()

@@ -24,7 +24,10 @@ def fake_records(r=5, n=12, seed=0):
 
 def test_json_log_roundtrip_matches_reference_format(pkg, tmp_path):
     rec = fake_records()
-    names = {0: "IcpProposal-TargetSampling-0.100000Step", 1: "IcpProposal-ModelSampling-0.100000Step", 2: "RandomShape-0.100000"}
+    # the names are the reference's own (api/sampling/MixedProposalDistributions.scala:31-54 interpolates Scala Doubles)
+    names = pkg.femur_icp_proposal_registration(*pkg.data.load_femur_model_and_target(50)).leaf_names()
+    assert names[0] == "IcpProposal-TargetSampling-0.1Step" and names[1] == "IcpProposal-ModelSampling-0.1Step"
+    assert names[2] == "RandomShape-0.1" and names[3] == "RotationYaw-0.01" and names[6] == "TranslationX-0.1"
     path = tmp_path / "log.json"
     lg = pkg.loggers.JSONAcceptRejectLogger(str(path)).add_records(rec, names)
     lg.write_log()
@@ -48,3 +51,11 @@ def test_json_log_roundtrip_matches_reference_format(pkg, tmp_path):
 def test_log_path_must_exist(pkg):
     with pytest.raises(IOError):
         pkg.loggers.JSONAcceptRejectLogger("/nonexistent-dir-xyz/log.json")
+
+
+def test_scala_double_formatting(pkg):
+    """java.lang.Double.toString, as Scala's string interpolation prints the proposals' standard deviations."""
+    S = pkg.ChainSetup.scala_double
+    for x, want in ((0.1, "0.1"), (0.01, "0.01"), (1.0, "1.0"), (10.0, "10.0"), (0.001, "0.001"), (1e-4, "1.0E-4"), (5e-5, "5.0E-5"),
+                    (1e7, "1.0E7"), (123456.789, "123456.789"), (0.3, "0.3"), (2.5e-3, "0.0025"), (0.0, "0.0")):
+        assert S(x) == want, (x, S(x), want)
