@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -45,14 +46,22 @@ template <class T>
 struct DBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool owned = true;  // false: a view of a buffer another object owns (immutable model / target data shared between contexts)
   DBuf() = default;
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
   ~DBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    owned = true;
+  }
+  void alias(const DBuf& o) {
+    release();
+    p = o.p;
+    n = o.n;
+    owned = false;
   }
   void alloc(size_t count) {
     release();
@@ -182,6 +191,46 @@ struct DeviceMesh {
   DBuf<uint8_t> boundary;
 };
 
+// Immutable device data of one statistical model / one target mesh, shared by every context of a device that was created from
+// the same arrays (64 chains on one GPU have 64 contexts — per-chain scratch, caches, streams — but ONE copy of the basis and of
+// the target; the BFM-sized model is 2 x 137 MB).  Contexts hold them through shared_ptr and address them through aliasing DBufs.
+struct SharedModel {
+  DBuf<double> ref, mean, Q, Qp, sqrt_lambda, inv_sqrt_lambda, G, Ginv, P;
+  DBuf<int> tris, adj_off, adj, tri_order;
+  DBuf<uint8_t> boundary;
+  int n_boundary = 0;
+};
+struct SharedTarget {
+  DeviceMesh mesh;
+};
+struct SharedKey {
+  int device, a, b, c;
+  uint64_t hash;
+  bool operator<(const SharedKey& o) const {
+    if (device != o.device) return device < o.device;
+    if (a != o.a) return a < o.a;
+    if (b != o.b) return b < o.b;
+    if (c != o.c) return c < o.c;
+    return hash < o.hash;
+  }
+};
+std::mutex g_shared_mu;
+std::map<SharedKey, std::weak_ptr<SharedModel>> g_shared_models;
+std::map<SharedKey, std::weak_ptr<SharedTarget>> g_shared_targets;
+
+uint64_t hash_words(uint64_t h, const void* data, size_t bytes) {  // word-wise multiply-xor (identity of the arrays, not security)
+  const unsigned char* p = (const unsigned char*)data;
+  size_t i = 0;
+  for (; i + 8 <= bytes; i += 8) {
+    uint64_t w;
+    std::memcpy(&w, p + i, 8);
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+  }
+  for (; i < bytes; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+  return h;
+}
+
 struct QueryScratch {
   DBuf<double> thr2;
   DBuf<float4> qrec;
@@ -191,7 +240,7 @@ struct QueryScratch {
   QueryBuffers get() const { return QueryBuffers{thr2.p, qrec.p, thrA.p, cnt.p, cand.p, cand_cap}; }
 };
 
-constexpr size_t kMaxCandidates = (size_t)256 << 20;  // ints (1 GiB): larger query×element products are batched
+constexpr size_t kMaxCandidates = (size_t)64 << 20;  // ints (256 MiB of candidate lists, 512 per query): more queries than that are batched
 
 struct StateSlot {
   std::vector<double> theta;
@@ -241,6 +290,8 @@ struct icp_ctx {
   DBuf<uint8_t> boundary;
   int n_boundary = 0;
   DeviceMesh target;
+  std::shared_ptr<SharedModel> shared_model;    // owners of what the members above alias (ref … boundary; target.*)
+  std::shared_ptr<SharedTarget> shared_target;
   DBuf<int> hint_surf;  // [N] last target triangle of model id i
   DBuf<int> hint_nnv;   // [N] last nearest target vertex of that surface point
   StateSlot slots[kStateSlots];
@@ -299,7 +350,7 @@ struct icp_ctx {
       scratch.cnt.alloc(cap + 8);
       scratch.cap = cap;
     }
-    const size_t want = std::min(kMaxCandidates, std::max<size_t>((K + 4) * std::max<size_t>(n_elems, 1), 1));
+    const size_t want = std::min(kMaxCandidates, std::max<size_t>((K + 4) * (size_t)cand_stride((int)std::min<size_t>(n_elems, 1u << 30)), 1));
     if (want > scratch.cand_cap) {
       HIP_OK(hipStreamSynchronize(stream));
       scratch.cand.alloc(want);
@@ -1096,72 +1147,107 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     HIP_OK(hipHostMalloc((void**)&ctx->h_wait_error, sizeof(int) * 16, hipHostMallocDefault));
     ctx->h_wait_error[0] = 0;
 
-    // ---- model: Q = Φ·diag(√λ) in two layouts, Gram matrix G = QᵀQ and chol(G + σ²I) (one-off host work)
-    std::vector<double> Q((size_t)3 * N * r), Qp((size_t)3 * N * r), sl(r), isl(r);
-    for (int j = 0; j < r; ++j) { sl[j] = std::sqrt(model->variance[j]); isl[j] = 1.0 / sl[j]; }
-    for (size_t row = 0; row < (size_t)3 * N; ++row)
-      for (int j = 0; j < r; ++j) {
-        double q = model->basis[row * r + j] * sl[j];
-        Q[row * r + j] = q;
-        size_t i = row / 3, d = row % 3;
-        Qp[((size_t)j * 3 + d) * N + i] = q;
+    // ---- model and target: the immutable device data is shared between the contexts of a device made from the same arrays
+    std::lock_guard<std::mutex> shared_lk(g_shared_mu);
+    uint64_t mh = hash_words(0x1234, model->ref_points, sizeof(double) * 3 * N);
+    mh = hash_words(mh, model->basis, sizeof(double) * 3 * N * r);
+    mh = hash_words(mh, model->variance, sizeof(double) * r);
+    if (model->mean_deformation) mh = hash_words(mh, model->mean_deformation, sizeof(double) * 3 * N);
+    mh = hash_words(mh, model->triangles, sizeof(int32_t) * 3 * T);
+    const SharedKey mkey{device, N, T, r, mh};
+    std::shared_ptr<SharedModel> sm = g_shared_models[mkey].lock();
+    if (!sm) {
+      sm = std::make_shared<SharedModel>();
+      // Q = Φ·diag(√λ) in two layouts, Gram matrix G = QᵀQ and chol(G + σ²I) (one-off host work)
+      std::vector<double> Q((size_t)3 * N * r), Qp((size_t)3 * N * r), sl(r), isl(r);
+      for (int j = 0; j < r; ++j) { sl[j] = std::sqrt(model->variance[j]); isl[j] = 1.0 / sl[j]; }
+      for (size_t row = 0; row < (size_t)3 * N; ++row)
+        for (int j = 0; j < r; ++j) {
+          double q = model->basis[row * r + j] * sl[j];
+          Q[row * r + j] = q;
+          size_t i = row / 3, d = row % 3;
+          Qp[((size_t)j * 3 + d) * N + i] = q;
+        }
+      std::vector<double> G((size_t)r * r, 0.0);
+      for (size_t row = 0; row < (size_t)3 * N; ++row) {
+        const double* q = &Q[row * r];
+        for (int a = 0; a < r; ++a) {
+          double qa = q[a];
+          double* g = &G[(size_t)a * r];
+          for (int b = 0; b <= a; ++b) g[b] += qa * q[b];
+        }
       }
-    std::vector<double> G((size_t)r * r, 0.0);
-    for (size_t row = 0; row < (size_t)3 * N; ++row) {
-      const double* q = &Q[row * r];
-      for (int a = 0; a < r; ++a) {
-        double qa = q[a];
-        double* g = &G[(size_t)a * r];
-        for (int b = 0; b <= a; ++b) g[b] += qa * q[b];
+      for (int a = 0; a < r; ++a)
+        for (int b = a + 1; b < r; ++b) G[(size_t)a * r + b] = G[(size_t)b * r + a];
+      std::vector<double> Gs = G, Ginv, Pinv;
+      for (int a = 0; a < r; ++a) Gs[(size_t)a * r + a] += kSigma2;
+      if (!host_spd_inverse(r, Gs, Pinv)) fail(ICP_ERR_NOT_SPD, "Q^T Q + sigma^2 I is not positive definite");
+      if (!host_spd_inverse(r, G, Ginv)) fail(ICP_ERR_NOT_SPD, "Q^T Q is not positive definite (linearly dependent basis functions)");
+      std::vector<double> mean((size_t)3 * N, 0.0);
+      if (model->mean_deformation) std::memcpy(mean.data(), model->mean_deformation, sizeof(double) * 3 * N);
+      std::vector<uint8_t> mb;
+      boundary_flags(N, T, model->triangles, mb);
+      std::vector<int> off, adj;
+      vertex_adjacency(N, T, model->triangles, off, adj);
+      sm->n_boundary = (int)std::count(mb.begin(), mb.end(), (uint8_t)1);
+      sm->ref.upload(model->ref_points, (size_t)3 * N);
+      sm->mean.upload(mean.data(), mean.size());
+      sm->Q.upload(Q.data(), Q.size());
+      sm->Qp.upload(Qp.data(), Qp.size());
+      sm->sqrt_lambda.upload(sl.data(), r);
+      sm->inv_sqrt_lambda.upload(isl.data(), r);
+      sm->G.upload(G.data(), G.size());
+      sm->Ginv.upload(Ginv.data(), Ginv.size());
+      sm->P.upload(Pinv.data(), Pinv.size());
+      sm->tris.upload(model->triangles, (size_t)3 * T);
+      {
+        const std::vector<int> order = coherent_triangle_order(N, T, model->ref_points, model->triangles);
+        sm->tri_order.upload(order.data(), order.size());
       }
+      sm->adj_off.upload(off.data(), off.size());
+      sm->adj.upload(adj.data(), adj.size());
+      sm->boundary.upload(mb.data(), mb.size());
+      g_shared_models[mkey] = sm;
     }
-    for (int a = 0; a < r; ++a)
-      for (int b = a + 1; b < r; ++b) G[(size_t)a * r + b] = G[(size_t)b * r + a];
-    std::vector<double> Gs = G, Ginv, Pinv;
-    for (int a = 0; a < r; ++a) Gs[(size_t)a * r + a] += kSigma2;
-    if (!host_spd_inverse(r, Gs, Pinv)) fail(ICP_ERR_NOT_SPD, "Q^T Q + sigma^2 I is not positive definite");
-    if (!host_spd_inverse(r, G, Ginv)) fail(ICP_ERR_NOT_SPD, "Q^T Q is not positive definite (linearly dependent basis functions)");
-    std::vector<double> mean((size_t)3 * N, 0.0);
-    if (model->mean_deformation) std::memcpy(mean.data(), model->mean_deformation, sizeof(double) * 3 * N);
-    std::vector<uint8_t> mb;
-    boundary_flags(N, T, model->triangles, mb);
-    std::vector<int> off, adj;
-    vertex_adjacency(N, T, model->triangles, off, adj);
-    ctx->n_boundary = (int)std::count(mb.begin(), mb.end(), (uint8_t)1);
-
-    ctx->ref.upload(model->ref_points, (size_t)3 * N);
-    ctx->mean.upload(mean.data(), mean.size());
-    ctx->Q.upload(Q.data(), Q.size());
-    ctx->Qp.upload(Qp.data(), Qp.size());
-    ctx->sqrt_lambda.upload(sl.data(), r);
-    ctx->inv_sqrt_lambda.upload(isl.data(), r);
-    ctx->G.upload(G.data(), G.size());
-    ctx->Ginv.upload(Ginv.data(), Ginv.size());
-    ctx->P.upload(Pinv.data(), Pinv.size());
-    ctx->tris.upload(model->triangles, (size_t)3 * T);
-    {
-      const std::vector<int> order = coherent_triangle_order(N, T, model->ref_points, model->triangles);
-      ctx->tri_order.upload(order.data(), order.size());
-    }
-    ctx->adj_off.upload(off.data(), off.size());
-    ctx->adj.upload(adj.data(), adj.size());
-    ctx->boundary.upload(mb.data(), mb.size());
+    ctx->shared_model = sm;
+    ctx->n_boundary = sm->n_boundary;
+    ctx->ref.alias(sm->ref); ctx->mean.alias(sm->mean); ctx->Q.alias(sm->Q); ctx->Qp.alias(sm->Qp);
+    ctx->sqrt_lambda.alias(sm->sqrt_lambda); ctx->inv_sqrt_lambda.alias(sm->inv_sqrt_lambda);
+    ctx->G.alias(sm->G); ctx->Ginv.alias(sm->Ginv); ctx->P.alias(sm->P);
+    ctx->tris.alias(sm->tris); ctx->tri_order.alias(sm->tri_order); ctx->adj_off.alias(sm->adj_off); ctx->adj.alias(sm->adj);
+    ctx->boundary.alias(sm->boundary);
 
     // ---- target (static): vertices, triangles, boundary flags, bounding spheres
-    DeviceMesh& tg = ctx->target;
-    tg.V = target->n_points; tg.T = target->n_triangles;
-    std::vector<uint8_t> tb;
-    boundary_flags(tg.V, tg.T, target->triangles, tb);
-    tg.n_boundary = (int)std::count(tb.begin(), tb.end(), (uint8_t)1);
-    tg.verts.upload(target->points, (size_t)3 * tg.V);
-    tg.tris.upload(target->triangles, (size_t)3 * tg.T);
-    tg.boundary.upload(tb.data(), tb.size());
-    tg.spheres.alloc(sphere_floats4(tg.T));
-    {
-      const std::vector<int> order = coherent_triangle_order(tg.V, tg.T, target->points, target->triangles);
-      tg.tri_order.upload(order.data(), order.size());
+    uint64_t th = hash_words(0x5678, target->points, sizeof(double) * 3 * (size_t)target->n_points);
+    th = hash_words(th, target->triangles, sizeof(int32_t) * 3 * (size_t)target->n_triangles);
+    const SharedKey tkey{device, target->n_points, target->n_triangles, 0, th};
+    std::shared_ptr<SharedTarget> stg = g_shared_targets[tkey].lock();
+    if (!stg) {
+      stg = std::make_shared<SharedTarget>();
+      DeviceMesh& tg = stg->mesh;
+      tg.V = target->n_points; tg.T = target->n_triangles;
+      std::vector<uint8_t> tb;
+      boundary_flags(tg.V, tg.T, target->triangles, tb);
+      tg.n_boundary = (int)std::count(tb.begin(), tb.end(), (uint8_t)1);
+      tg.verts.upload(target->points, (size_t)3 * tg.V);
+      tg.tris.upload(target->triangles, (size_t)3 * tg.T);
+      tg.boundary.upload(tb.data(), tb.size());
+      tg.spheres.alloc(sphere_floats4(tg.T));
+      {
+        const std::vector<int> order = coherent_triangle_order(tg.V, tg.T, target->points, target->triangles);
+        tg.tri_order.upload(order.data(), order.size());
+      }
+      launch_tri_spheres(ctx->stream, tg.T, tg.verts.p, tg.tris.p, tg.tri_order.p, tg.spheres.p);
+      HIP_OK(hipStreamSynchronize(ctx->stream));  // (complete before another context may find it)
+      g_shared_targets[tkey] = stg;
     }
-    launch_tri_spheres(ctx->stream, tg.T, tg.verts.p, tg.tris.p, tg.tri_order.p, tg.spheres.p);
+    ctx->shared_target = stg;
+    {
+      DeviceMesh& tg = ctx->target;
+      const DeviceMesh& o = stg->mesh;
+      tg.V = o.V; tg.T = o.T; tg.n_boundary = o.n_boundary;
+      tg.verts.alias(o.verts); tg.tris.alias(o.tris); tg.tri_order.alias(o.tri_order); tg.spheres.alias(o.spheres); tg.boundary.alias(o.boundary);
+    }
 
     ctx->hint_surf.alloc(N); ctx->hint_surf.fill_bytes(0xFF);
     ctx->hint_nnv.alloc(N); ctx->hint_nnv.fill_bytes(0xFF);
@@ -1954,8 +2040,8 @@ bool step_pipeline_covers(icp_evaluator* e, int n_props, icp_proposal* const* pr
     }
   }
   if (n_model > 1 || n_target > 1) return false;
-  if (c.target.T < 1 || (size_t)(ksurf + 4) * (size_t)c.target.T > kMaxCandidates) return false;
-  if (n_target && (size_t)(props[0]->K + props[n_props - 1]->K + 8) * (size_t)c.N > kMaxCandidates) return false;
+  if (c.target.T < 1 || (size_t)(ksurf + 4) * (size_t)cand_stride(c.target.T) > kMaxCandidates) return false;
+  if (n_target && (size_t)(props[0]->K + props[n_props - 1]->K + 8) * (size_t)cand_stride(c.N) > kMaxCandidates) return false;
   return step_finish_supported(c.r);
 }
 

@@ -72,9 +72,16 @@ struct QueryBuffers {   // scratch of one query batch; per-query arrays hold the
   float4* qrec;          // surface queries: f32 copy of the point
   float* thrA;           // surface queries: distance bound (inflated, f32)
   int* cnt;              // candidates per query
-  int* cand;             // candidate lists, one row of n_elements ints per query
-  size_t cand_capacity;  // ints in `cand`; a batch takes floor(capacity / n_elements) queries
+  int* cand;             // candidate lists, one row of cand_stride(n_elements) ints per query
+  size_t cand_capacity;  // ints in `cand`; a batch takes floor(capacity / stride) queries
 };
+
+// Candidate lists hold at most this many entries per query.  With a hint (the previous winner) a query lists a few dozen; a list
+// that overflows — a first search without hints — keeps COUNTING, and the resolve stage, seeing a count above the capacity,
+// scans the whole searched set for that query instead (same lexicographic minimum, exact either way).  Lists sized for the worst
+// case (every element a candidate of every query) were 97 MB per chain at the metric size and 1 GiB for a full-mesh Hausdorff pass.
+constexpr int kCandStride = 512;
+inline int cand_stride(int n_elems) { return n_elems < kCandStride ? (n_elems > 0 ? n_elems : 1) : kCandStride; }
 
 struct SurfaceTask {  // one batch of closest-point-on-surface queries against one triangle mesh
   int K, Kpad, T, stride;

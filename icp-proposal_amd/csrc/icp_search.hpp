@@ -44,11 +44,13 @@ __device__ __forceinline__ void park_hits(ParkedHits& ph, int k, unsigned long l
 __device__ __forceinline__ void settle_hits(ParkedHits& ph, int* __restrict__ cnt, int* __restrict__ cand, size_t stride, int first, int step) {
   if (lane_id() < ph.n) {
     const int n0 = __popcll(ph.m0), n1 = __popcll(ph.m1);
-    int* list = cand + (size_t)ph.k * stride + atomicAdd(cnt + ph.k, n0 + n1);
+    int pos = atomicAdd(cnt + ph.k, n0 + n1);  // (the counter keeps counting past the capacity: that is how the resolve stage knows)
+    int* list = cand + (size_t)ph.k * stride;
+    const int cap = (int)stride;
     unsigned long long m = ph.m0;
-    while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; *list++ = first + b * step; }
+    while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; if (pos < cap) list[pos] = first + b * step; ++pos; }
     m = ph.m1;
-    while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; *list++ = first + b * step + 1; }
+    while (m) { const int b = __ffsll((long long)m) - 1; m &= m - 1; if (pos < cap) list[pos] = first + b * step + 1; ++pos; }
   }
   ph.n = 0;
 }
@@ -207,8 +209,9 @@ __device__ __forceinline__ void surface_resolve(const SurfaceTask& q, int k, dou
   int bi = kNoIndex;
   d3 bc = {__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};  // closest point of this lane's best candidate
   const int* tri_of = sphere_triangles(q.spheres, q.T);  // the filter names its candidates by their position in the sphere list
-  for (int i = lane_id(); i < n; i += 64) {
-    const int t = tri_of[list[i]];
+  const bool listed = n <= q.stride;  // (uniform) otherwise the list overflowed: every triangle is looked at
+  for (int i = lane_id(); i < (listed ? n : q.T); i += 64) {
+    const int t = listed ? tri_of[list[i]] : i;
     d3 c;
     const double d2 = tri_dist2(p, q.verts, q.tris, t, &c);
     if (d2 < best || (d2 == best && t < bi)) { best = d2; bi = t; bc = c; }  // NaN (degenerate triangle) never wins
@@ -321,8 +324,9 @@ __device__ __forceinline__ void vertex_resolve(const VertexTask& q, int k, doubl
   const int* list = q.cand + (size_t)k * q.stride;
   double best = __builtin_inf();
   int bi = kNoIndex;
-  for (int i = lane_id(); i < n; i += 64) {
-    const int v = list[i];
+  const bool listed = n <= q.stride;  // (uniform) otherwise the list overflowed: every vertex is looked at
+  for (int i = lane_id(); i < (listed ? n : q.V); i += 64) {
+    const int v = listed ? list[i] : i;
     d3 d = sub(p, ld3(q.verts + 3 * v));
     const double d2 = dot(d, d);
     if (d2 < best || (d2 == best && v < bi)) { best = d2; bi = v; }

@@ -462,3 +462,32 @@ def test_femur100_all_points_symmetric_58k_target_matches_oracle(pkg, oracle):
     finally:
         oracle.set_search_backend(oracle.SEARCH_BRUTE)
     ctx.close()
+
+
+def test_contexts_share_model_and_target_memory(pkg):
+    """one context per chain must not duplicate the immutable model / target data nor hold worst-case candidate
+    lists: at the metric size (58,322-vertex target) a further context with its chain costs < 16 MB of HBM (64 chains < 1 GB),
+    and chains on such contexts still give the values of a chain on a context of its own."""
+    import torch
+    model, target = pkg.data.synthetic_femur_target()
+    setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+    first = pkg.IcpContext(model, target, device=0)
+    ch0 = pkg.SamplingRegistration(first, setup, pkg.initial_parameters(model), seed=1024)
+    want = ch0.run(30)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    n = 16
+    ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(n)]
+    chains = [pkg.SamplingRegistration(c, setup, pkg.initial_parameters(model), seed=1024) for c in ctxs]
+    recs = pkg.run_chains_batched(chains, 30)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    per_ctx = (free0 - free1) / n
+    assert per_ctx < 16e6, f"{per_ctx / 1e6:.1f} MB per further context"
+    for rec in recs:
+        assert np.array_equal(rec[:, 1:3], want[:, 1:3])
+        assert np.abs(rec[:, 14:] - want[:, 14:]).max() <= 1e-9 * np.abs(want[:, 14:]).max()
+    for ch in chains + [ch0]:
+        ch.close()
+    for c in ctxs + [first]:
+        c.close()
