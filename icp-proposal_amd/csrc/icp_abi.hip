@@ -350,7 +350,7 @@ struct icp_ctx {
       scratch.cnt.alloc(cap + 8);
       scratch.cap = cap;
     }
-    const size_t want = std::min(kMaxCandidates, std::max<size_t>((K + 4) * (size_t)cand_stride((int)std::min<size_t>(n_elems, 1u << 30)), 1));
+    const size_t want = std::min(kMaxCandidates, std::max<size_t>((K + 4) * std::min<size_t>(std::max<size_t>(n_elems, 1), (size_t)kCandStrideMax), 1));
     if (want > scratch.cand_cap) {
       HIP_OK(hipStreamSynchronize(stream));
       scratch.cand.alloc(want);

@@ -80,8 +80,18 @@ struct QueryBuffers {   // scratch of one query batch; per-query arrays hold the
 // that overflows — a first search without hints — keeps COUNTING, and the resolve stage, seeing a count above the capacity,
 // scans the whole searched set for that query instead (same lexicographic minimum, exact either way).  Lists sized for the worst
 // case (every element a candidate of every query) were 97 MB per chain at the metric size and 1 GiB for a full-mesh Hausdorff pass.
-constexpr int kCandStride = 512;
+constexpr int kCandStride = 512;      // at least (fewer elements than that: all of them)
+constexpr int kCandStrideMax = 4096;  // at most, where the scratch has room: a query far from the searched surface (a partial target's
+                                      // hole) has thousands of triangles within its bound
 inline int cand_stride(int n_elems) { return n_elems < kCandStride ? (n_elems > 0 ? n_elems : 1) : kCandStride; }
+// entries per query of a batch of K queries given `capacity` ints of scratch
+inline int cand_stride_for(int n_elems, int K, size_t capacity) {
+  size_t s = capacity / (size_t)(K + 4 > 0 ? K + 4 : 1);
+  if (s > (size_t)kCandStrideMax) s = kCandStrideMax;
+  if (s < (size_t)kCandStride) s = kCandStride;
+  if (s > (size_t)(n_elems > 0 ? n_elems : 1)) s = n_elems > 0 ? n_elems : 1;
+  return (int)s;
+}
 
 struct SurfaceTask {  // one batch of closest-point-on-surface queries against one triangle mesh
   int K, Kpad, T, stride;

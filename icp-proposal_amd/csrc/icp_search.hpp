@@ -209,12 +209,32 @@ __device__ __forceinline__ void surface_resolve(const SurfaceTask& q, int k, dou
   int bi = kNoIndex;
   d3 bc = {__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};  // closest point of this lane's best candidate
   const int* tri_of = sphere_triangles(q.spheres, q.T);  // the filter names its candidates by their position in the sphere list
-  const bool listed = n <= q.stride;  // (uniform) otherwise the list overflowed: every triangle is looked at
-  for (int i = lane_id(); i < (listed ? n : q.T); i += 64) {
-    const int t = listed ? tri_of[list[i]] : i;
-    d3 c;
-    const double d2 = tri_dist2(p, q.verts, q.tris, t, &c);
-    if (d2 < best || (d2 == best && t < bi)) { best = d2; bi = t; bc = c; }  // NaN (degenerate triangle) never wins
+  const bool listed = n <= q.stride;  // (uniform) otherwise the list overflowed (a query far from the surface, or without a hint)
+  if (listed) {
+    for (int i = lane_id(); i < n; i += 64) {
+      const int t = tri_of[list[i]];
+      d3 c;
+      const double d2 = tri_dist2(p, q.verts, q.tris, t, &c);
+      if (d2 < best || (d2 == best && t < bi)) { best = d2; bi = t; bc = c; }  // NaN (degenerate triangle) never wins
+    }
+  } else {
+    // every triangle is considered, through its bounding sphere first: a triangle can only win (or tie) if
+    // |p − centre| − R <= the smaller of the query's bound and the best distance this lane has seen — the spheres contain
+    // their triangles with room to spare (tri_sphere), the comparison is relaxed by 1e-6 relative on top, so what is skipped
+    // is strictly farther than the winner: the same lexicographic minimum as a scan of all exact distances
+    const double thr = (double)q.thrA[k];  // (inflated distance to the hinted triangle; +inf without a hint)
+    double lim2 = thr * thr;
+    for (int pos = lane_id(); pos < q.T; pos += 64) {
+      const float4 s = q.spheres[pos];
+      const double dx = p.x - (double)s.x, dy = p.y - (double)s.y, dz = p.z - (double)s.z;
+      const double dc = sqrt(dx * dx + dy * dy + dz * dz) - (double)s.w;
+      const double lb = dc > 0.0 ? dc * dc * (1.0 - 1e-6) : 0.0;
+      if (lb > lim2) continue;  // (NaN spheres fall through to the exact evaluation)
+      const int t = tri_of[pos];
+      d3 c;
+      const double d2 = tri_dist2(p, q.verts, q.tris, t, &c);
+      if (d2 < best || (d2 == best && t < bi)) { best = d2; bi = t; bc = c; if (d2 < lim2) lim2 = d2; }
+    }
   }
   const double my_best = best;
   const int my_bi = bi;

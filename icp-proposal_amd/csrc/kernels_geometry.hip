@@ -128,7 +128,7 @@ int query_batch(int K, int n_elems, size_t cand_capacity) {
 SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const float4* spheres, int K, const double* P,
                               int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri) {
   SurfaceTask q{};
-  q.K = K; q.Kpad = (K + kQU - 1) / kQU * kQU; q.T = T; q.stride = cand_stride(T);
+  q.K = K; q.Kpad = (K + kQU - 1) / kQU * kQU; q.T = T; q.stride = cand_stride_for(T, K, qb.cand_capacity);
   q.P = P; q.verts = verts; q.tris = tris; q.spheres = spheres; q.hint = hint;
   q.qrec = qb.qrec; q.thrA = qb.thrA; q.cnt = qb.cnt; q.cand = qb.cand;
   q.cp = cp; q.d2 = d2; q.tri = tri;
@@ -139,7 +139,7 @@ SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const
 
 VertexTask make_vertex_task(int V, const double* verts, int K, const double* P, int* hint, const QueryBuffers& qb, double* d2, int* idx) {
   VertexTask q{};
-  q.K = K; q.Kpad = (K + kQU - 1) / kQU * kQU; q.V = V; q.stride = cand_stride(V);
+  q.K = K; q.Kpad = (K + kQU - 1) / kQU * kQU; q.V = V; q.stride = cand_stride_for(V, K, qb.cand_capacity);
   q.P = P; q.verts = verts; q.hint = hint; q.thr2 = qb.thr2; q.cnt = qb.cnt; q.cand = qb.cand; q.d2 = d2; q.idx = idx;
   q.vblocks = cdiv(V > 0 ? V : 1, kBlock);
   split_queries(q.vblocks, q.Kpad, &q.ksplit, &q.kchunk);
