@@ -298,6 +298,7 @@ struct icp_ctx {
   uint64_t clock = 0;
   QueryScratch scratch;
   QueryScratch scratch_v;  // second scratch: the merged step launches run a surface and a vertex search side by side
+  QueryScratch scratch_t;  // third: … and the evaluator's target -> model surface search
   // staging for small host<->device transfers of one API call
   double* h_stage = nullptr;  // pinned
   DBuf<double> d_stage;
@@ -339,8 +340,8 @@ struct icp_ctx {
   void bind() { HIP_OK(hipSetDevice(device)); }
 
   // scratch for K queries against a set of n_elems elements (every query may list every element as a candidate)
-  QueryBuffers query_scratch(size_t K, size_t n_elems, bool second = false) {
-    QueryScratch& scratch = second ? scratch_v : this->scratch;
+  QueryBuffers query_scratch(size_t K, size_t n_elems, int which = 0) {
+    QueryScratch& scratch = which == 1 ? scratch_v : (which == 2 ? scratch_t : this->scratch);
     if (K > scratch.cap) {
       HIP_OK(hipStreamSynchronize(stream));
       size_t cap = std::max<size_t>(K, 4096);
@@ -2024,10 +2025,13 @@ bool step_pipeline_covers(icp_evaluator* e, int n_props, icp_proposal* const* pr
   icp_ctx& c = *e->ctx;
   if (n_props < 1 || n_props > 2) return false;
   const icp_evaluator_params& ep = e->prm;
-  if (ep.mode != ICP_MODEL_TO_TARGET || ep.n_model_ids < 1) return false;
   if (ep.kind == ICP_EVAL_HAUSDORFF) return false;
+  // (the boundary-aware collective evaluator on a target WITH boundary needs the nearest-vertex pass behind the searches)
   if (ep.kind == ICP_EVAL_COLLECTIVE_AVG_HAUSDORFF_BOUNDARY_AWARE && c.target.n_boundary > 0) return false;
-  int n_model = 0, n_target = 0, ksurf = ep.n_model_ids;
+  const bool m2t = ep.mode != ICP_TARGET_TO_MODEL, t2m = ep.mode != ICP_MODEL_TO_TARGET;
+  if (m2t && ep.n_model_ids < 1) return false;
+  if (t2m && (e->Kt < 1 || c.T < 1 || (size_t)(e->Kt + 4) * (size_t)cand_stride(c.T) > kMaxCandidates)) return false;
+  int n_model = 0, n_target = 0, ksurf = m2t ? ep.n_model_ids : 0;
   for (int i = 0; i < n_props; ++i) {
     const icp_proposal* p = props[i];
     if (p->K < 1) return false;
@@ -2040,6 +2044,7 @@ bool step_pipeline_covers(icp_evaluator* e, int n_props, icp_proposal* const* pr
     }
   }
   if (n_model > 1 || n_target > 1) return false;
+  if (ksurf < 1) return false;  // (a TargetToModel evaluator beside a TargetSampling proposal alone: no model-side surface query at all)
   if (c.target.T < 1 || (size_t)(ksurf + 4) * (size_t)cand_stride(c.target.T) > kMaxCandidates) return false;
   if (n_target && (size_t)(props[0]->K + props[n_props - 1]->K + 8) * (size_t)cand_stride(c.N) > kMaxCandidates) return false;
   return step_finish_supported(c.r);
@@ -2179,18 +2184,28 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
     if (props[i]->prm.direction == ICP_MODEL_SAMPLING) { pm = props[i]; im = i; }
     else { pt = props[i]; it = i; }
   }
-  const int Ksurf = std::max(evp.n_model_ids, pm ? pm->K : 0);
+  const bool ev_m2t = evp.mode != ICP_TARGET_TO_MODEL, ev_t2m = evp.mode != ICP_MODEL_TO_TARGET;
+  const int Ksurf = std::max(ev_m2t ? evp.n_model_ids : 0, pm ? pm->K : 0);
   F.Ksurf = Ksurf;
   require(Ksurf <= c.N, "model id count exceeds the number of model points");
   QueryBuffers qs = c.query_scratch(Ksurf, c.target.T);
   QueryBuffers qv{};
-  if (pt) qv = c.query_scratch(pt->K, c.N, true);
+  if (pt) qv = c.query_scratch(pt->K, c.N, 1);
 
   SurfaceTask st_surf = make_surface_task(c.target.T, c.target.verts.p, c.target.tris.p, c.target.spheres.p, Ksurf, s.x.p,
                                           c.hint_surf.p, qs, s.surf_cp.p, s.surf_d2.p, s.surf_tri.p);
   VertexTask st_vert{};
   if (pt) st_vert = make_vertex_task(c.N, s.x.p, pt->K, pt->target_pts.p, pt->hint_nn.p, qv, nullptr, pt->nn_id.p);
   st_vert.thr2 = nullptr;  // bounds are computed by the filter launch itself (see vertex_filter)
+  // the evaluator's reverse direction (IndependentPointDistanceEvaluator.scala:49-54, Collective…Evaluator.scala:55-64): its
+  // decimated-target points against the surface of the NEW instance — spheres and bounds are taken by the filter launch itself
+  SurfaceTask st_t2m{};
+  if (ev_t2m) {
+    QueryBuffers qt = c.query_scratch(e->Kt, c.T, 2);
+    st_t2m = make_surface_task(c.T, s.x.p, c.tris.p, nullptr, e->Kt, e->d_tpts, e->hint_tri.p, qt, e->t2m_cp.p, e->t2m_d2.p, e->t2m_tri.p);
+    st_t2m.order = c.tri_order.p;
+    st_t2m.thrA = nullptr;
+  }
 
   // 1: coefficients -> instance -> bounds
   StepBeginArgs b{};
@@ -2217,6 +2232,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   b.x = s.x.p;
   b.has_surf = 1; b.surf = st_surf;
   b.has_vert = pt ? 1 : 0; b.vert = st_vert;
+  b.zero2 = ev_t2m ? st_t2m.cnt : nullptr; b.n_zero2 = ev_t2m ? st_t2m.Kpad : 0;
   // (nothing to wait for before the first finish launch, nor when every step is on one stream)
   b.wait_flag = (c.last_back_seq > 0 && !c.pipeline_off && !batched) ? c.d_done.p + 2 : nullptr;
   // test hook: the first launch waits for a word that never comes, times out, and the step is repeated unpipelined
@@ -2233,10 +2249,17 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
 
   // 2 + 3: searches and correspondences
   StepSearchArgs q{};
-  q.n_surf = 1; q.n_vert = pt ? 1 : 0;
+  q.n_surf = ev_t2m ? 2 : 1; q.n_vert = pt ? 1 : 0;
   q.s[0] = st_surf;
   q.fstart[0] = 0; q.fstart[1] = filter_grid_blocks(st_surf.tblocks, st_surf.ksplit);
   q.rstart[0] = 0; q.rstart[1] = Ksurf;
+  int nt = 1;  // tasks so far (surface tasks first)
+  if (ev_t2m) {
+    q.s[1] = st_t2m;
+    q.fstart[2] = q.fstart[1] + filter_grid_blocks(st_t2m.tblocks, st_t2m.ksplit);
+    q.rstart[2] = q.rstart[1] + e->Kt;
+    nt = 2;
+  }
   q.s_corr[0] = q.s_corr[1] = q.v_corr[0] = q.v_corr[1] = -1;
   int n_corr = 0;
   if (pm) {
@@ -2246,8 +2269,8 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   }
   if (pt) {
     q.v[0] = st_vert;
-    q.fstart[2] = q.fstart[1] + filter_grid_blocks(st_vert.vblocks, st_vert.ksplit);
-    q.rstart[2] = q.rstart[1] + pt->K;
+    q.fstart[nt + 1] = q.fstart[nt] + filter_grid_blocks(st_vert.vblocks, st_vert.ksplit);
+    q.rstart[nt + 1] = q.rstart[nt] + pt->K;
     q.corr[n_corr] = CorrTask{pt->K, ep[it]->corr(), s.x.p, pt->target_pts.p, c.boundary.p, nullptr, pt->prm.boundary_aware,
                               s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p};
     q.v_corr[0] = n_corr++;
@@ -2277,7 +2300,8 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   }
   if (n_props == 1) g.ustart[2] = g.ustart[1];
   g.reduce_kind = evp.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE ? 1 : 2;
-  g.Kred = evp.n_model_ids; g.d2 = s.surf_d2.p; g.mean = evp.gauss_mean; g.sigma = evp.gauss_sigma;
+  g.Kred = ev_m2t ? evp.n_model_ids : 0; g.d2 = s.surf_d2.p; g.mean = evp.gauss_mean; g.sigma = evp.gauss_sigma;
+  g.Kred2 = ev_t2m ? e->Kt : 0; g.d2b = e->t2m_d2.p;
   g.red_out = c.h_res + kReduceArea + F.parity * 8;  // (its own half: the host may still be reading the previous step's)
   for (int i = 0; i < n_props; ++i) { F.mpart[i] = g.Mpart[i]; F.mpart_half[i] = props[i]->mpart_half; }
   launch_step_regression(F.stream, g);
@@ -2348,7 +2372,7 @@ bool chain_step_record(icp_evaluator* e, int n_props, icp_proposal* const* props
       saved[8 + t] = c.h_res[0];
       std::memcpy(c.h_res, saved.data(), sizeof(double) * saved.size());
     }
-  for (int i = 0; i < 4; ++i) c.h_res[i] = c.h_res[kReduceArea + F.parity * 8 + i];  // launch 4's reduction, where finish_eval looks
+  for (int i = 0; i < 8; ++i) c.h_res[i] = c.h_res[kReduceArea + F.parity * 8 + i];  // launch 4's reductions, where finish_eval looks
   icp_evaluator::Memo* m = eval_store(e, theta_prop);
   m->status = finish_eval(e, c.h_res, &m->value, m->aux);
   *log_value_prop = m->value;

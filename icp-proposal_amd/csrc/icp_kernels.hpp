@@ -98,10 +98,14 @@ struct SurfaceTask {  // one batch of closest-point-on-surface queries against o
   const double* P;        // [K*3] query points
   const double* verts;
   const int* tris;
-  const float4* spheres;  // [T] f32 bounding spheres
+  const float4* spheres;  // [T] f32 bounding spheres, followed by the triangle id of every list position; nullptr: the searched
+                          // mesh has just been made (the current model instance inside a merged step) — the filter computes the spheres
+                          // itself, in the order given by `order`
+  const int* order;       // position in the sphere list -> triangle (used when spheres == nullptr)
   int* hint;              // [K] previous winner (in/out; may be null)
   float4* qrec;           // [Kpad] scratch
-  float* thrA;            // [Kpad] scratch
+  float* thrA;            // [Kpad] scratch; nullptr: the bounds (distance to the hinted triangle) are taken by the filter itself,
+                          // when the searched mesh is complete
   int* cnt;               // [Kpad] scratch
   int* cand;              // [Kpad*stride] scratch
   double* cp;             // outputs, any may be null
@@ -281,6 +285,7 @@ struct StepBeginArgs {  // launch 1: [propose] -> coefficients -> instance -> se
   int has_surf, has_vert;
   SurfaceTask surf;         // queries = model ids 0..K-1 of the NEW instance against the target surface
   VertexTask vert;          // searched set = the NEW instance (TargetSampling)
+  int* zero2; int n_zero2;  // a second list of candidate counters to reset (the evaluator's target -> model queries)
 };
 
 // Filter grid of one task, XCD-aware: the `ksplit` workgroups that stream the SAME block of elements (one per query
@@ -313,8 +318,10 @@ struct StepRegressionArgs {  // launch 4: normal-equation partial sums of every 
   int* status[2];            // the new entries' 3 status ints: {-, eigen sweeps, eigen} are cleared here
 
   int reduce_kind;           // 0 none, 1 Σ log N(d; mean, sigma), 2 {Σ d, max d, count}
-  int Kred;
+  int Kred;                  // model -> target distances (0: that direction is not evaluated)
   const double* d2;
+  int Kred2;                 // target -> model distances of a TargetToModel / Symmetric evaluator (0: none); results at red_out + 4
+  const double* d2b;
   double mean, sigma;
   double* red_out;
 };

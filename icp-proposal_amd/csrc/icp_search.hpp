@@ -83,6 +83,18 @@ __device__ __forceinline__ HintTriangle load_hint_triangle(const SurfaceTask& q,
   }
   return ht;
 }
+// f32 record and inflated bound of one real query (k < K)
+__device__ __forceinline__ void surface_bound(d3 p, const HintTriangle& ht, float4* rec, float* thr) {
+  double d2 = __builtin_inf();
+  if (ht.have) {  // = tri_dist2 of the hinted triangle
+    const d3 d = sub(p, closest_point_triangle(p, ht.a, ht.b, ht.c));
+    d2 = dot(d, d);
+  }
+  if (!(d2 == d2)) d2 = __builtin_inf();  // degenerate hint triangle
+  const double slack = kAbsSlack * (fabs(p.x) + fabs(p.y) + fabs(p.z));
+  *rec = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f);
+  *thr = round_up_f32(sqrt(d2) * (1.0 + 2e-6) + slack);
+}
 __device__ __forceinline__ void surface_init_with(const SurfaceTask& q, int k, d3 p, const HintTriangle& ht) {
   if (k >= q.Kpad) return;
   q.cnt[k] = 0;
@@ -91,15 +103,10 @@ __device__ __forceinline__ void surface_init_with(const SurfaceTask& q, int k, d
     q.thrA[k] = 0.f;
     return;
   }
-  double d2 = __builtin_inf();
-  if (ht.have) {  // = tri_dist2 of the hinted triangle
-    const d3 d = sub(p, closest_point_triangle(p, ht.a, ht.b, ht.c));
-    d2 = dot(d, d);
-  }
-  if (!(d2 == d2)) d2 = __builtin_inf();  // degenerate hint triangle
-  const double slack = kAbsSlack * (fabs(p.x) + fabs(p.y) + fabs(p.z));
-  q.qrec[k] = make_float4((float)p.x, (float)p.y, (float)p.z, 0.f);
-  q.thrA[k] = round_up_f32(sqrt(d2) * (1.0 + 2e-6) + slack);
+  float4 rec; float thr;
+  surface_bound(p, ht, &rec, &thr);
+  q.qrec[k] = rec;
+  q.thrA[k] = thr;
 }
 __device__ __forceinline__ void surface_init_at(const SurfaceTask& q, int k, d3 p) {
   surface_init_with(q, k, p, load_hint_triangle(q, k));
@@ -137,8 +144,8 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
   // out-of-range lanes: centre NaN — their squared distance is NaN and passes no threshold, not even an infinite one
   // (a query without a usable hint has bound +inf: everything in range is a candidate)
   f2_t cx = {__builtin_nanf(""), __builtin_nanf("")}, cy = cx, cz = cx, R = {0.f, 0.f};
-  if (v0) { const float4 s = q.spheres[t0]; cx.x = s.x; cy.x = s.y; cz.x = s.z; R.x = s.w; }
-  if (v1) { const float4 s = q.spheres[t0 + 1]; cx.y = s.x; cy.y = s.y; cz.y = s.z; R.y = s.w; }
+  if (v0) { const float4 s = q.spheres ? q.spheres[t0] : tri_sphere(q.verts, q.tris, q.order[t0]); cx.x = s.x; cy.x = s.y; cz.x = s.z; R.x = s.w; }
+  if (v1) { const float4 s = q.spheres ? q.spheres[t0 + 1] : tri_sphere(q.verts, q.tris, q.order[t0 + 1]); cx.y = s.x; cy.y = s.y; cz.y = s.z; R.y = s.w; }
   // ---- the wave's ball (a sphere that is not finite — a triangle with a non-finite corner — passes no test by itself
   // and must not spoil the ball of its neighbours)
   auto finite4 = [](float a, float b, float c, float d) { return fabsf(a) + fabsf(b) + fabsf(c) + fabsf(d) <= 3.0e38f; };
@@ -167,7 +174,17 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
     // this workgroup's queries go through LDS: one coalesced read per tile; the loops below never wait for global memory
     const int nq = min(kSurfaceTile, k1 - kt);
     if (kt != k0) __syncthreads();
-    for (int i = threadIdx.x; i < nq; i += kSearchBlock) { s_q[i] = q.qrec[kt + i]; s_thr[i] = q.thrA[kt + i]; }
+    if (q.thrA) {
+      for (int i = threadIdx.x; i < nq; i += kSearchBlock) { s_q[i] = q.qrec[kt + i]; s_thr[i] = q.thrA[kt + i]; }
+    } else {  // the bounds are taken here (the searched mesh was not complete when the step's first launch ran)
+      for (int i = threadIdx.x; i < nq; i += kSearchBlock) {
+        const int k = kt + i;
+        float4 rec = make_float4(1e30f, 1e30f, 1e30f, 0.f);
+        float thr = 0.f;
+        if (k < q.K) surface_bound(ld3(q.P + 3 * k), load_hint_triangle(q, k), &rec, &thr);
+        s_q[i] = rec; s_thr[i] = thr;
+      }
+    }
     __syncthreads();
     if (!wave_live) continue;
     for (int g = 0; g < nq; g += 64) {
@@ -208,7 +225,7 @@ __device__ __forceinline__ void surface_resolve(const SurfaceTask& q, int k, dou
   double best = __builtin_inf();
   int bi = kNoIndex;
   d3 bc = {__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};  // closest point of this lane's best candidate
-  const int* tri_of = sphere_triangles(q.spheres, q.T);  // the filter names its candidates by their position in the sphere list
+  const int* tri_of = q.spheres ? sphere_triangles(q.spheres, q.T) : q.order;  // the filter names its candidates by their position in the sphere list
   const bool listed = n <= q.stride;  // (uniform) otherwise the list overflowed (a query far from the surface, or without a hint)
   if (listed) {
     for (int i = lane_id(); i < n; i += 64) {
@@ -222,10 +239,10 @@ __device__ __forceinline__ void surface_resolve(const SurfaceTask& q, int k, dou
     // |p − centre| − R <= the smaller of the query's bound and the best distance this lane has seen — the spheres contain
     // their triangles with room to spare (tri_sphere), the comparison is relaxed by 1e-6 relative on top, so what is skipped
     // is strictly farther than the winner: the same lexicographic minimum as a scan of all exact distances
-    const double thr = (double)q.thrA[k];  // (inflated distance to the hinted triangle; +inf without a hint)
+    const double thr = q.thrA ? (double)q.thrA[k] : __builtin_inf();  // (inflated distance to the hinted triangle; +inf without a hint)
     double lim2 = thr * thr;
     for (int pos = lane_id(); pos < q.T; pos += 64) {
-      const float4 s = q.spheres[pos];
+      const float4 s = q.spheres ? q.spheres[pos] : tri_sphere(q.verts, q.tris, q.order[pos]);
       const double dx = p.x - (double)s.x, dy = p.y - (double)s.y, dz = p.z - (double)s.z;
       const double dc = sqrt(dx * dx + dy * dy + dz * dz) - (double)s.w;
       const double lb = dc > 0.0 ? dc * dc * (1.0 - 1e-6) : 0.0;

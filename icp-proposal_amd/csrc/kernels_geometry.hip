@@ -129,7 +129,7 @@ SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const
                               int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri) {
   SurfaceTask q{};
   q.K = K; q.Kpad = (K + kQU - 1) / kQU * kQU; q.T = T; q.stride = cand_stride_for(T, K, qb.cand_capacity);
-  q.P = P; q.verts = verts; q.tris = tris; q.spheres = spheres; q.hint = hint;
+  q.P = P; q.verts = verts; q.tris = tris; q.spheres = spheres; q.order = nullptr; q.hint = hint;
   q.qrec = qb.qrec; q.thrA = qb.thrA; q.cnt = qb.cnt; q.cand = qb.cand;
   q.cp = cp; q.d2 = d2; q.tri = tri;
   q.tblocks = cdiv(T > 0 ? T : 1, kBlock * kSpheresPerLane);

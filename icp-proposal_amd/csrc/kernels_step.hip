@@ -21,6 +21,7 @@
 // flight is rejected.  The cross-stream order is taken on the device: launch 1 waits for a word that launch 5 of the
 // previous step raises when it starts (StepBeginArgs::wait_flag), and for the completion word of the eigen-decomposition
 // it draws from.
+#include <algorithm>
 #include <cstdlib>
 
 #include "icp_kernels.hpp"
@@ -89,11 +90,12 @@ __device__ __forceinline__ void step_begin_body(const StepBeginArgs& a, const in
       const int k = a.surf.K + tid;  // sentinel slots
       if (k < a.surf.Kpad) surface_init_at(a.surf, k, d3{0.0, 0.0, 0.0});
     }
-  } else if (a.has_vert) {
-    // TargetSampling queries: only the candidate counters are reset here; their bounds (distance to the previous winner at
-    // its NEW position) are taken by the filter launch, when the new instance is complete (vert.thr2 == nullptr)
+  } else {
+    // TargetSampling queries, the evaluator's target -> model queries: only the candidate counters are reset here; their bounds
+    // (distance to the previous winner at its NEW position) are taken by the filter launch, when the new instance is complete
     const int k = (bx - a.inst_blocks) * kStepBlock + tid;
-    if (k < a.vert.Kpad) a.vert.cnt[k] = 0;
+    if (a.has_vert && k < a.vert.Kpad) a.vert.cnt[k] = 0;
+    if (k < a.n_zero2) a.zero2[k] = 0;
   }
 }
 // The same for ranks 32..RMAX with everything the step does NOT depend on held in registers before the wait: the point's
@@ -203,13 +205,15 @@ __device__ __forceinline__ void step_begin_body_reg(const StepBeginArgs& a, cons
       const int k = a.surf.K + tid;  // sentinel slots
       if (k < a.surf.Kpad) surface_init_at(a.surf, k, d3{0.0, 0.0, 0.0});
     }
-  } else if (a.has_vert) {
+  } else {
     const int k = (bx - a.inst_blocks) * kStepBlock + tid;
-    if (k < a.vert.Kpad) a.vert.cnt[k] = 0;
+    if (a.has_vert && k < a.vert.Kpad) a.vert.cnt[k] = 0;
+    if (k < a.n_zero2) a.zero2[k] = 0;
   }
 }
 __device__ __forceinline__ int step_begin_grid(const StepBeginArgs& a) {
-  return a.inst_blocks + (a.has_vert ? (a.vert.Kpad + kStepBlock - 1) / kStepBlock : 0);
+  const int nz = max(a.has_vert ? a.vert.Kpad : 0, a.n_zero2);
+  return a.inst_blocks + (nz + kStepBlock - 1) / kStepBlock;
 }
 
 __global__ void __launch_bounds__(kStepBlock) k_step_begin(StepBeginArgs a) { step_begin_body(a, blockIdx.x); }
@@ -287,9 +291,15 @@ __device__ __forceinline__ void step_regression_body(const StepRegressionArgs& a
       else regression_tile(tile, split, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1]);
     }
   } else {
-    // the last workgroup: likelihood reduction over the surface distances of the evaluator's model ids
-    if (a.reduce_kind == 1) sum_gauss_logpdf_body(a.Kred, a.d2, a.mean, a.sigma, a.red_out);  // IndependentPointDistanceEvaluator.scala:40-46
-    else if (a.reduce_kind == 2) dist_stats_body(a.Kred, a.d2, a.red_out);                      // Collective…Evaluator.scala:43-52 (no boundary)
+    // the last workgroup: likelihood reduction over the surface distances of the evaluator's model ids (results 0-3) and, for a
+    // TargetToModel / Symmetric evaluator, of its target points against the new model surface (results 4-7)
+    if (a.reduce_kind == 1) {
+      if (a.Kred > 0) sum_gauss_logpdf_body(a.Kred, a.d2, a.mean, a.sigma, a.red_out);  // IndependentPointDistanceEvaluator.scala:40-46
+      if (a.Kred2 > 0) { __syncthreads(); sum_gauss_logpdf_body(a.Kred2, a.d2b, a.mean, a.sigma, a.red_out + 4); }  // :49-54
+    } else if (a.reduce_kind == 2) {
+      if (a.Kred > 0) dist_stats_body(a.Kred, a.d2, a.red_out);                                    // Collective…Evaluator.scala:43-52 (no boundary)
+      if (a.Kred2 > 0) { __syncthreads(); dist_stats_body(a.Kred2, a.d2b, a.red_out + 4); }        // :55-64
+    }
   }
 }
 __device__ __forceinline__ int step_regression_grid(const StepRegressionArgs& a) {
@@ -423,7 +433,7 @@ bool step_finish_supported(int r) { return finish_plan(r).ok; }
 void launch_step_begin(hipStream_t st, const StepBeginArgs& a_in) {
   StepBeginArgs a = a_in;
   a.inst_blocks = cdiv(a.N, kStepBeginPoints);
-  const int vblocks = a.has_vert ? cdiv(a.vert.Kpad, kStepBlock) : 0;
+  const int vblocks = cdiv(std::max(a.has_vert ? a.vert.Kpad : 0, a.n_zero2), kStepBlock);
   if (t_capture) { t_capture->begin = a; t_capture->grid[0] = a.inst_blocks + vblocks; return; }
   ProfScope _ps(st, KID_STEP_BEGIN);
   static const bool no_reg = dev_env("ICP_BEGIN_STREAMED") != nullptr;  // (A/B switch)
