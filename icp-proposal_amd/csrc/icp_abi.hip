@@ -2305,6 +2305,16 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   g.red_out = c.h_res + kReduceArea + F.parity * 8;  // (its own half: the host may still be reading the previous step's)
   for (int i = 0; i < n_props; ++i) { F.mpart[i] = g.Mpart[i]; F.mpart_half[i] = props[i]->mpart_half; }
   launch_step_regression(F.stream, g);
+  if (!batched) {  // 4b: many partials are summed by many CUs before the one-workgroup factorisation (see launch_step_reduce)
+    bool many = false;
+    for (int i = 0; i < n_props; ++i) many = many || splits[i] >= kStepReduceSplits;
+    if (many) {
+      StepReduceArgs ra{};
+      ra.n = n_props; ra.nn = (r + 1) * (r + 1);
+      for (int i = 0; i < n_props; ++i) { ra.Mpart[i] = g.Mpart[i]; ra.splits[i] = splits[i]; splits[i] = 1; }
+      launch_step_reduce(F.stream, ra);
+    }
+  }
 
   F.valid = true;
 }

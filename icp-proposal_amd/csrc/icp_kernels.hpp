@@ -343,6 +343,13 @@ struct StepFinishArgs {  // launch 5: per posterior Cholesky + alpha, then the b
   int* ready_flag;
 };
 
+// launch 4b (only where a posterior has many split-K partials — every model point a correspondence, configs[2]: 64 × 83 KB): the
+// partials are summed, in split order, by as many threads as the matrix has entries, into the first one; the finish launch — ONE
+// workgroup per posterior — then reads 83 KB instead of 5.3 MB (100 µs at one CU's fetch rate).  Same bits: the factorisation
+// sums the splits in the same order from 0.0.
+constexpr int kStepReduceSplits = 32;  // from this many splits on
+struct StepReduceArgs { int n; int nn; double* Mpart[2]; int splits[2]; };
+void launch_step_reduce(hipStream_t st, const StepReduceArgs& a);
 bool step_finish_supported(int r);
 void launch_step_begin(hipStream_t st, const StepBeginArgs& a);
 void launch_step_filter(hipStream_t st, const StepSearchArgs& a);

@@ -308,6 +308,22 @@ __device__ __forceinline__ int step_regression_grid(const StepRegressionArgs& a)
 
 __global__ void __launch_bounds__(kStepBlock) k_step_regression(StepRegressionArgs a) { step_regression_body(a, blockIdx.x); }
 
+__global__ void __launch_bounds__(256) k_step_reduce(StepReduceArgs a) {
+  const int which = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (which >= a.n || e >= a.nn) return;
+  double* P = a.Mpart[which];
+  const int S = a.splits[which];
+  double acc = 0.0;
+  for (int s0 = 0; s0 < S; s0 += 8) {  // eight splits in flight, summed in split order
+    double q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = P[(size_t)min(s0 + u, S - 1) * a.nn + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (s0 + u < S) acc += q[u];
+  }
+  P[e] = acc;
+}
+
 // ---------------------------------------------------------------- 5: factorisations + transition tails
 
 template <int E, int NT>
@@ -464,6 +480,12 @@ void launch_step_regression(hipStream_t st, const StepRegressionArgs& a) {
   if (blocks <= 0) return;
   ProfScope _ps(st, KID_STEP_REGRESSION);
   hipLaunchKernelGGL(k_step_regression, dim3(blocks), dim3(kStepBlock), 0, st, a);
+}
+
+void launch_step_reduce(hipStream_t st, const StepReduceArgs& a) {
+  if (t_capture) return;  // (B chains per launch: the finish launch sums the partials itself)
+  ProfScope _ps(st, KID_STEP_REGRESSION);
+  hipLaunchKernelGGL(k_step_reduce, dim3(cdiv(a.nn, 256), a.n), dim3(256), 0, st, a);
 }
 
 void launch_step_finish(hipStream_t st, const StepFinishArgs& a_in) {
