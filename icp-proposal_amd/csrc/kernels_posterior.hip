@@ -31,6 +31,10 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kEigenMaxSweeps = 40;
+#ifndef ICP_LOOSE_TAU
+#define ICP_LOOSE_TAU 4e-6
+#endif
+constexpr double kLooseTau = ICP_LOOSE_TAU;  // loose stopping test of the Jacobi kernels (see k_posterior_eigen_rr)
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -1229,7 +1233,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
             if (j == i) { if (v[c] < 1e299) dg = fma(v[c], v[c], dg); }
             else if (j > i) {
               off = fma(2.0 * v[c], v[c], off);
-              bad = bad || fabs(v[c]) > 4e-6 * fabs(LDS_A(cur, j * ld + j) - dii);
+              bad = bad || fabs(v[c]) > kLooseTau * fabs(LDS_A(cur, j * ld + j) - dii);
             }
           }
         }
