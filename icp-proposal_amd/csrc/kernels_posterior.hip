@@ -26,6 +26,9 @@ __device__ long long g_eigen_stamps[64];
 #else
 #define EIG_STAMP(i)
 #endif
+}  // namespace icp
+#include "icp_tridiag.hpp"
+namespace icp {
 
 namespace {
 
@@ -1834,7 +1837,7 @@ void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO
                        io.step, work, io.out, io.status, use_lds); }
 }
 
-size_t eigen_work_doubles(int r) {  // `work` of launch_posterior_eigen
+static size_t jacobi_work_doubles(int r) {
   const size_t n2 = ((size_t)r + 1) & ~(size_t)1;
   if (r > 64) {  // in-place Jacobi (k_eigen_big): A0 | T | Vwork | mu | rotation log of every sweep | meta — or the generic kernel's r×r scratch
     const size_t log = (size_t)kEigenMaxSweeps * (n2 - 1) * n2;  // (c, s) per pair and round
@@ -1842,6 +1845,37 @@ size_t eigen_work_doubles(int r) {  // `work` of launch_posterior_eigen
   }
   const size_t log = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;  // 2 doubles per pair and round
   return log + n2 * 64 + 128 + 256;  // fixed-position variant: log + correction + meta (see launch_eigen_rr)
+}
+// the tridiagonal route's part of `work`, behind the Jacobi kernels': d | e | beta | mu | sync words | reflectors
+constexpr int kTriMaxRank = 200;
+static size_t tri_work_doubles(int r) { return r <= kTriMaxRank ? 4 * (size_t)tri::kTriMaxN + 8 + (size_t)r * 256 : 0; }
+size_t eigen_work_doubles(int r) { return jacobi_work_doubles(r) + tri_work_doubles(r); }  // `work` of launch_posterior_eigen
+
+// Householder tridiagonalisation on one workgroup, then one wave per eigenpair (icp_tridiag.hpp)
+static bool tridiag_route(int r) {
+  static const int forced = dev_env("ICP_EIGEN_TRIDIAG") ? std::atoi(dev_env("ICP_EIGEN_TRIDIAG")) : -1;
+  if (r < 3 || r > kTriMaxRank) return false;
+  return forced >= 0 ? forced != 0 : r > 64;
+}
+static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const double* sqrt_lambda, double* V, double* Vt, double* S, double* work,
+                                 int* status, int* host_status, int* done_word, int done_value) {
+  double* base = work + jacobi_work_doubles(r);
+  double *d = base, *e = base + tri::kTriMaxN, *beta = base + 2 * tri::kTriMaxN, *mu = base + 3 * tri::kTriMaxN;
+  int* sync = (int*)(base + 4 * tri::kTriMaxN);
+  double* Hv = base + 4 * tri::kTriMaxN + 8;
+  tri::TridiagIO ti{r, M, sqrt_lambda, d, e, beta, Hv};
+  tri::TriSolveIO so{r, d, e, beta, Hv, V, Vt, S, mu, sync, status, host_status, done_word, done_value};
+  const int nwg = (r + 3) / 4;
+  if (r <= 64) {
+    hipLaunchKernelGGL((tri::k_tridiag<4, 1, 16>), dim3(1), dim3(256), 0, st, ti);
+    hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), 0, st, so);
+  } else if (r <= 128) {
+    hipLaunchKernelGGL((tri::k_tridiag<8, 2, 16>), dim3(1), dim3(512), 0, st, ti);
+    hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), 0, st, so);
+  } else {
+    hipLaunchKernelGGL((tri::k_tridiag<8, 4, 25>), dim3(1), dim3(512), 0, st, ti);
+    hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), 0, st, so);
+  }
 }
 
 // N = D⁻¹ M D⁻¹ (symmetrised) for the in-place kernel
@@ -1958,9 +1992,14 @@ bool launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenReques
 
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
                             double* Vt, double* S, double* work, int* status, const EigenSpec* spec, int* host_status) {
-  {
+  if (!(tridiag_route(r) && spec == nullptr)) {
     const EigenRequest rq{M, Vwarm, V, Vt, S, work, status, spec, host_status, nullptr, 0};
     if (launch_posterior_eigen_pair(st, r, sqrt_lambda, 1, &rq)) return;
+  }
+  if (tridiag_route(r)) {
+    ProfScope _ps(st, KID_EIGEN);
+    launch_eigen_tridiag(st, r, M, sqrt_lambda, V, Vt, S, work, status, host_status, nullptr, 0);
+    return;
   }
   if (r > 64 && r <= kBigMaxRank) {  // in-place parallel Jacobi, packed triangle in one CU's LDS + replay workgroups
     ProfScope _ps(st, KID_EIGEN);

@@ -1,0 +1,106 @@
+// tri_bench.hip — accuracy and timing of the posterior eigen-decomposition against a host Jacobi iteration (dev tool, not product).
+// usage: tri_bench <rank> ; route chosen by ICP_EIGEN_TRIDIAG=0|1 (dev switch of kernels_posterior.hip)
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "../icp-proposal_amd/csrc/icp_kernels.hpp"
+
+namespace icp { extern __device__ long long g_eigen_stamps[64]; }
+#define CK(x) do{hipError_t e_=(x); if(e_!=hipSuccess){printf("err %s line %d\n", hipGetErrorString(e_), __LINE__); return 1;}}while(0)
+
+static void host_jacobi(int n, std::vector<double> a, std::vector<double>& w, std::vector<double>& V) {
+  V.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < n; ++i) { diag += a[(size_t)i * n + i] * a[(size_t)i * n + i]; for (int j = i + 1; j < n; ++j) off += a[(size_t)i * n + j] * a[(size_t)i * n + j]; }
+    if (off <= 1e-60 * diag) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = a[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double tau = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
+        for (int k = 0; k < n; ++k) { const double x = a[(size_t)k * n + p], y = a[(size_t)k * n + q]; a[(size_t)k * n + p] = c * x - s * y; a[(size_t)k * n + q] = s * x + c * y; }
+        for (int k = 0; k < n; ++k) { const double x = a[(size_t)p * n + k], y = a[(size_t)q * n + k]; a[(size_t)p * n + k] = c * x - s * y; a[(size_t)q * n + k] = s * x + c * y; }
+        for (int k = 0; k < n; ++k) { const double x = V[(size_t)k * n + p], y = V[(size_t)k * n + q]; V[(size_t)k * n + p] = c * x - s * y; V[(size_t)k * n + q] = s * x + c * y; }
+      }
+  }
+  w.resize(n);
+  for (int i = 0; i < n; ++i) w[i] = a[(size_t)i * n + i];
+}
+
+int main(int argc, char** argv) {
+  const int r = argc > 1 ? atoi(argv[1]) : 200;
+  std::mt19937_64 rng(7);
+  std::normal_distribution<double> nd;
+  const int K = 6 * r;
+  std::vector<double> sl(r), B((size_t)K * r), M((size_t)r * r, 0.0);
+  for (int j = 0; j < r; ++j) sl[j] = std::sqrt(28.0 * std::pow(0.182 / 28.0, (double)j / (r - 1)));
+  for (auto& b : B) b = nd(rng);
+  for (int k = 0; k < K; ++k) for (int j = 0; j < r; ++j) B[(size_t)k * r + j] *= sl[j];
+  for (int i = 0; i < r; ++i) M[(size_t)i * r + i] = 1.0;
+  for (int k = 0; k < K; ++k) for (int i = 0; i < r; ++i) for (int j = 0; j < r; ++j) M[(size_t)i * r + j] += 0.02 * B[(size_t)k * r + i] * B[(size_t)k * r + j];
+  std::vector<double> N((size_t)r * r), mu, Vh;
+  for (int i = 0; i < r; ++i) for (int j = 0; j < r; ++j) N[(size_t)i * r + j] = 0.5 * (M[(size_t)i * r + j] + M[(size_t)j * r + i]) / (sl[i] * sl[j]);
+  host_jacobi(r, N, mu, Vh);
+  // order by mu ascending (S descending), canonical signs
+  std::vector<int> ord(r);
+  for (int i = 0; i < r; ++i) ord[i] = i;
+  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return mu[a] < mu[b]; });
+  std::vector<double> Vref((size_t)r * r), Sref(r);
+  double mingap = 1e300;
+  for (int c = 0; c < r; ++c) {
+    const int p = ord[c];
+    int bi = 0; double bv = -1;
+    for (int k = 0; k < r; ++k) if (std::fabs(Vh[(size_t)k * r + p]) > bv) { bv = std::fabs(Vh[(size_t)k * r + p]); bi = k; }
+    const double sg = Vh[(size_t)bi * r + p] < 0 ? -1.0 : 1.0;
+    for (int k = 0; k < r; ++k) Vref[(size_t)k * r + c] = sg * Vh[(size_t)k * r + p];
+    Sref[c] = 1.0 / mu[p];
+    if (c) mingap = std::fmin(mingap, mu[p] - mu[ord[c - 1]]);
+  }
+  printf("rank %d: mu in [%.4g, %.4g], smallest gap %.3e (%.2e of the norm)\n", r, mu[ord[0]], mu[ord[r - 1]], mingap, mingap / mu[ord[r - 1]]);
+
+  double *dM, *dsl, *dV, *dVt, *dS, *dwork; int* dstat;
+  CK(hipMalloc(&dM, 8 * r * r)); CK(hipMalloc(&dsl, 8 * r)); CK(hipMalloc(&dV, 8 * r * r)); CK(hipMalloc(&dVt, 8 * r * r)); CK(hipMalloc(&dS, 8 * r));
+  CK(hipMalloc(&dwork, 8 * icp::eigen_work_doubles(r))); CK(hipMemset(dwork, 0, 8 * icp::eigen_work_doubles(r))); CK(hipMalloc(&dstat, 64));
+  CK(hipMemcpy(dM, M.data(), 8 * r * r, hipMemcpyHostToDevice)); CK(hipMemcpy(dsl, sl.data(), 8 * r, hipMemcpyHostToDevice));
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  CK(hipMemset(dV, 0, 8 * r * r)); CK(hipMemset(dS, 0, 8 * r));
+  icp::launch_posterior_eigen(st, r, dM, dsl, nullptr, dV, dVt, dS, dwork, dstat + 1);
+  CK(hipStreamSynchronize(st));
+  std::vector<double> V((size_t)r * r), Vt((size_t)r * r), S(r);
+  CK(hipMemcpy(V.data(), dV, 8 * r * r, hipMemcpyDeviceToHost)); CK(hipMemcpy(Vt.data(), dVt, 8 * r * r, hipMemcpyDeviceToHost)); CK(hipMemcpy(S.data(), dS, 8 * r, hipMemcpyDeviceToHost));
+  int stat[2]; CK(hipMemcpy(stat, dstat, 8, hipMemcpyDeviceToHost));
+  double dv = 0, dsr = 0, res = 0, orth = 0, dvt = 0;
+  for (size_t i = 0; i < V.size(); ++i) dv = std::fmax(dv, std::fabs(V[i] - Vref[i]));
+  for (int i = 0; i < r; ++i) for (int j = 0; j < r; ++j) dvt = std::fmax(dvt, std::fabs(V[(size_t)i * r + j] - Vt[(size_t)j * r + i]));
+  for (int i = 0; i < r; ++i) dsr = std::fmax(dsr, std::fabs(S[i] - Sref[i]) / Sref[i]);
+  for (int c = 0; c < r; ++c) {
+    for (int i = 0; i < r; ++i) {
+      double t = 0;
+      for (int j = 0; j < r; ++j) t += N[(size_t)i * r + j] * V[(size_t)j * r + c];
+      res = std::fmax(res, std::fabs(t - V[(size_t)i * r + c] / S[c]));
+    }
+    for (int c2 = 0; c2 < r; ++c2) {
+      double t = 0;
+      for (int i = 0; i < r; ++i) t += V[(size_t)i * r + c] * V[(size_t)i * r + c2];
+      orth = std::fmax(orth, std::fabs(t - (c == c2)));
+    }
+  }
+  printf("status %d (sweeps %d) | vs host Jacobi: max|dV| %.3e, max rel dS %.3e | residual %.3e, orthogonality %.3e, V vs Vt %.1e\n", stat[1], stat[0], dv, dsr, res,
+         orth, dvt);
+  float ms = 0; const int reps = 20;
+  hipEventRecord(a, st);
+  for (int i = 0; i < reps; ++i) icp::launch_posterior_eigen(st, r, dM, dsl, nullptr, dV, dVt, dS, dwork, dstat + 1);
+  hipEventRecord(b, st); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+  long long s[64]; hipMemcpyFromSymbol(s, HIP_SYMBOL(icp::g_eigen_stamps), sizeof(s));
+  printf("%.1f us per decomposition (cold) | stamps: reduction %.1f | solve: setup %.1f multisection %.1f vectors %.1f back-transformation %.1f output %.1f\n", ms * 1000 / reps,
+         (s[1] - s[0]) * 0.01, (s[9] - s[8]) * 0.01, (s[10] - s[9]) * 0.01, (s[11] - s[10]) * 0.01, (s[12] - s[11]) * 0.01, (s[13] - s[12]) * 0.01);
+  return 0;
+}
