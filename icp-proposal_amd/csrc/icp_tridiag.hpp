@@ -19,13 +19,24 @@ namespace tri {
 #else
 #define TRI_STAMP(i)
 #endif
+#ifdef ICP_TRI_CYCLES  // developer aid: shader-clock cycles per part of a reduction step, summed over the steps (wave 0)
+#define TRI_CYC(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); cyc[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define TRI_CYC(i)
+#endif
 
 template <int N> struct Tag { static constexpr int value = N; };
 
-template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
+template <int CTRL, int ROWMASK = 0xf> __device__ __forceinline__ double dpp_f64(double v) {
+  if constexpr (ROWMASK == 0xf) {  // every lane receives a value: no "old" operand to set up
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  } else {  // lanes of the masked rows receive zero
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+  }
 }
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
@@ -33,28 +44,55 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // sum over the 64 lanes, the same value (bit for bit) in every lane and in every wave that sums the same numbers: four DPP
 // exchanges inside the rows of 16 (xor 1, xor 2, half mirror, mirror), then the four row totals through scalar registers.
 // Call with all lanes active.
+// square root and reciprocal to a few ulp from the hardware seeds (v_rsq_f64 / v_rcp_f64) and Newton steps: the reflector's
+// norm and 2/vᵀv need no correct rounding, and the library sequences are three times as long.  Arguments well inside the range.
+__device__ __forceinline__ double fast_sqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  const double g = x * y;
+  return fma(0.5 * y, fma(-g, g, x), g);
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(y, fma(-x, y, 1.0), y);
+  y = fma(y, fma(-x, y, 1.0), y);
+  return y;
+}
 // LDS written by some lanes of a wave and read by others of the same wave (the LDS queue keeps a wave's accesses in order)
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// workgroup barrier for data exchanged through LDS only: does not wait for the global stores in flight (the reflectors on their
+// way to memory are read by the next launch)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141>(v);  // row_half_mirror
-  v += dpp_f64<0x140>(v);  // row_mirror
-  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+  v += dpp_f64<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);       // row_half_mirror
+  v += dpp_f64<0x140>(v);       // row_mirror: every lane of a row of 16 holds the row's total
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3 (bound_ctrl: the other rows add zero)
+  v += dpp_f64<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return readlane_f64(v, 63);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Tridiagonalisation.  NW waves; lane l of wave w holds A[i][j] for i = l + 64·s (s < SI), j = w + NW·t (t < NT), the FULL
-// symmetric matrix: the product A·v then accumulates inside a thread over its wave's columns, and the NW partial sums per row
-// meet in LDS.  Every wave carries the Householder vector v and w = β(Av) − K·v redundantly, one row slot per lane, so a
-// wave's own columns' entries v_j, w_j come out of its own registers (v_readlane) — no second exchange.  The column that is
-// eliminated next travels through LDS one step ahead, before this step's update, and every wave applies the update to it
-// itself.  One barrier per step (two where the partial sums are reduced in two stages: NW·SI > 8).
-// Finished rows and columns are skipped by whole slots (compile-time bounds per phase of NW steps).
+// symmetric matrix: a product A·x accumulates inside a thread over its wave's columns, and the NW partial sums per row meet
+// in LDS.  Every wave carries the Householder vector v, w = β(Av) − K·v and the next column x redundantly, one row slot per
+// lane; the entries at its own columns (v_j, w_j, x_j) come back as LDS broadcast reads from a wave-private copy — the VALU
+// does the multiply-adds only.
+//
+// One pass over the registers per step: A ← A − v wᵀ − w vᵀ and, entry by entry, the NEXT step's product A·x.  That works because
+// (i) the column eliminated next travels through LDS one step ahead, before the update, and every wave updates it itself
+// (x' = c − v w_{k+1} − w v_{k+1}); (ii) A·v = A·x − α·A e_{k+1} and vᵀAv = xᵀAx − 2α(Ax)_{k+1} + α²A_{k+1,k+1}: the products are
+// formed with x, before the reflector (norm, square root, reciprocal — computed beside the pass) is known.
+// Per step: one barrier (two where the partial sums are reduced in two stages, SI >= 2), one wave-private LDS round trip, one
+// wave reduction (xᵀAx) on the critical path.  Finished rows and columns are skipped by whole slots (compile-time bounds per
+// phase of NW steps).
 struct TridiagIO {
   int n;
   const double* M;            // n×n, row-major; symmetrised on load
@@ -63,182 +101,325 @@ struct TridiagIO {
   double* e;                  // [n−1] sub-diagonal
   double* beta;               // [n] H_k = I − beta_k v_k v_kᵀ, k = 0..n−3
   double* Hv;                 // [n][64·SI] v_k, zero outside rows k+1..n−1
+  double* Nout;               // [n][n] (optional) the matrix itself, for the refinement step
 };
 
-template <int NW, int SI, int NT>
-__device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[SI][NT], double* part, double* psum, double* colbuf) {
-  constexpr int LD = 64 * SI;
-  constexpr bool TWO = NW * SI > 8;
-  static_assert(64 % NW == 0, "a wave's columns must map to fixed lanes");
-  const int n = a.n;
+template <int NW, int SI> struct TridiagLds {
+  static constexpr int LD = 64 * SI;
+  static constexpr bool TWO = SI >= 2;
+  static constexpr int oPart = 0;                                 // [TWO ? 1 : 2][NW][LD] partial sums of A·x
+  static constexpr int oPsum = oPart + (TWO ? 1 : 2) * NW * LD;   // [LD] their total (two-stage form)
+  static constexpr int oCol = oPsum + LD;                         // [2][LD] the column eliminated next, before the update
+  static constexpr int oScal = oCol + 2 * LD;                     // [2][NW] per-wave parts of xᵀAx
+  static constexpr int oPriv = oScal + 2 * NW;                    // [NW][3][LD] wave-private: x/v (two parities), w
+  static constexpr int doubles = oPriv + NW * 3 * LD;
+};
+
+// Index space: the matrix occupies the LAST n of the LD = 64·SI row/column positions (position = index + off, off = LD − n),
+// so that the partly filled row slot is the one eliminated — and dropped from the passes — first.  TOFF = column slots that
+// are empty for every n of the configuration (they get no registers).
+template <int NW, int SI, int NT, int TOFF>
+__device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[SI][NT], const double (&col0)[SI], double d0, double* lds) {
+  using L = TridiagLds<NW, SI>;
+  constexpr int LD = L::LD;
+  constexpr bool TWO = L::TWO;
+  static_assert(NW * (NT + TOFF) == LD, "column slots must cover the index space");
+  double* part = lds + L::oPart;
+  double* psum = lds + L::oPsum;
+  double* colbuf = lds + L::oCol;
+  double* scal = lds + L::oScal;
+  const int n = a.n, off = LD - n;
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double xs[SI];
-  // column 0 to everyone
-  if (w == 0) {
+  double* vb = lds + L::oPriv + w * 3 * LD;  // vb[par·LD + i]: x of step k (v once its entry k+1 is fixed), k & 1 = par
+  double* wb = vb + 2 * LD;
+
+#ifdef ICP_TRI_CYCLES
+  long long cyc[10] = {}, tprev = 0;
+#endif
+  // Per step the lane-form vectors (one row slot per lane) are: x, the column eliminated now (rows > k); v; w; x', the next column.
+  // They stay in registers from one step to the next — except in the largest configuration (SI = 4: no registers to spare),
+  // where they live in the wave-private LDS arrays vb (x / x' by step parity) and wb.
+  constexpr bool VLDS = SI >= 4;
+  double xs[SI];    // x (registers form)
+  double x0, sig2;  // its first entry x_{k+1}; Σ_{i>k+1} x_i²
+  // ---- the pass over the registers: optional rank-2 update, then acc = A·x'; publishes the partial sums, this wave's part of
+  // x'ᵀAx' and column `cnext` of the updated matrix.  Row slots below S0 are finished (compile time); columns are taken four at a
+  // time — their entries of v, w, x' come from the lanes that hold those positions as rows (v_readlane), fetched together ahead
+  // of the multiply-adds — and a group whose columns are all <= kdone is skipped (uniform branch).
+  auto pass = [&](auto s0tag, auto updtag, int vpar, int xpar, int cnext, int kdone, const double (&vr)[SI], const double (&wr)[SI],
+                  const double (&xr)[SI]) {
+    constexpr int S0 = decltype(s0tag)::value;
+    constexpr bool UPD = decltype(updtag)::value != 0;
+    constexpr int CH = 4;
+    double acc[SI], vs[SI], ws[SI], xl[SI];
 #pragma unroll
-    for (int s = 0; s < SI; ++s) colbuf[LD + l + 64 * s] = A[s][0];
-  }
-  __syncthreads();
+    for (int s = 0; s < SI; ++s) {
+      acc[s] = 0.0;
+      if constexpr (VLDS) {
+        vs[s] = UPD && s >= S0 ? vb[vpar * LD + l + 64 * s] : 0.0;
+        ws[s] = UPD && s >= S0 ? wb[l + 64 * s] : 0.0;
+        xl[s] = s >= S0 ? vb[xpar * LD + l + 64 * s] : 0.0;
+      } else {
+        vs[s] = vr[s]; ws[s] = wr[s]; xl[s] = xr[s];
+      }
+    }
+    const bool owner = w == (cnext & (NW - 1));
+    const int tc = cnext / NW - TOFF;
 #pragma unroll
-  for (int s = 0; s < SI; ++s) {
-    const int i = l + 64 * s;
-    const double cb = colbuf[LD + i];
-    xs[s] = i > 0 ? cb : 0.0;
-    if (w == 0 && i == 0) a.d[0] = cb;
+    for (int c0 = 0; c0 < NT; c0 += CH) {
+      if (SI == 1 || NW * (c0 + CH + TOFF) > kdone + 1) {
+        double vj[CH], wj[CH], xj[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          const int t = c0 + q < NT ? c0 + q : NT - 1;
+          const int sj = (NW * (t + TOFF)) >> 6;  // where column j = w + NW·(t + TOFF) sits as a row (constants once unrolled)
+          const int lj = ((NW * (t + TOFF)) & 63) + w;
+          xj[q] = readlane_f64(xl[sj], lj);
+          if constexpr (UPD) { vj[q] = readlane_f64(vs[sj], lj); wj[q] = readlane_f64(ws[sj], lj); }
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          const int t = c0 + q;
+          if (t < NT) {
+            if constexpr (UPD) {
+#pragma unroll
+              for (int s = S0; s < SI; ++s) A[s][t] = fma(-vs[s], wj[q], fma(-ws[s], vj[q], A[s][t]));
+            }
+#pragma unroll
+            for (int s = S0; s < SI; ++s) acc[s] = fma(A[s][t], xj[q], acc[s]);
+          }
+        }
+      }
+    }
+    if constexpr (UPD) TRI_CYC(5);
+    // the column eliminated after this one leaves the registers of the wave that holds it: a binary search over the column
+    // slots (uniform branches), so that every store names its register
+    if (owner) {
+      auto publish = [&](auto self, auto lotag, auto hitag) -> void {
+        constexpr int lo = decltype(lotag)::value, hi = decltype(hitag)::value;
+        if constexpr (hi - lo == 1) {
+#pragma unroll
+          for (int s = S0; s < SI; ++s) {
+            double val = A[s][lo];
+            asm volatile("" : "+v"(val));  // (keeps the leaves apart: merged, they become an indexed copy of A in scratch memory)
+            colbuf[xpar * LD + l + 64 * s] = val;
+          }
+        } else {
+          constexpr int mid = (lo + hi) / 2;
+          if (tc < mid) self(self, lotag, Tag<mid>{}); else self(self, Tag<mid>{}, hitag);
+        }
+      };
+      publish(publish, Tag<0>{}, Tag<NT>{});
+    }
+    double* mypart = part + (TWO ? 0 : xpar * NW * LD) + w * LD;
+    double q = 0.0;
+#pragma unroll
+    for (int s = S0; s < SI; ++s) {
+      mypart[l + 64 * s] = acc[s];
+      q = fma(xl[s], acc[s], q);
+    }
+    q = wave_sum(q);
+    if (l == 0) scal[xpar * NW + w] = q;
+    if constexpr (UPD) TRI_CYC(6);
+  };
+
+  // ---- the first column (position off < 64; handed in by the caller, one row slot per lane, with its diagonal entry) and its product
+  {
+    double loc = 0.0;
+#pragma unroll
+    for (int s = 0; s < SI; ++s) {
+      const int i = l + 64 * s;
+      const double cb = col0[s];
+      xs[s] = i > off ? cb : 0.0;
+      if constexpr (VLDS) vb[(off & 1) * LD + i] = xs[s];
+      loc = i > off + 1 ? fma(cb, cb, loc) : loc;
+    }
+    if constexpr (VLDS) wave_lds_sync();
+    if (w == 0 && l == 0) a.d[0] = d0;
+    {
+      double t = xs[0];
+#pragma unroll
+      for (int s = 1; s < SI; ++s) t = ((off + 1) >> 6) == s ? xs[s] : t;
+      x0 = readlane_f64(t, (off + 1) & 63);
+    }
+    sig2 = wave_sum(loc);
+    const double zero[SI] = {};
+    pass(Tag<0>{}, Tag<0>{}, 0, off & 1, off + 1, off - 1, zero, zero, xs);
   }
 
-  auto phase = [&](auto t0tag) {
-    constexpr int T0 = decltype(t0tag)::value;
-    constexpr int S0 = (NW * T0) / 64;
-    constexpr int T1 = T0 + 1 < NT ? T0 + 1 : NT - 1;
-    const int kend = min(NW * (T0 + 1), n - 2);
-    for (int k = NW * T0; k < kend; ++k) {
-      const int par = k & 1;
-      const int k1 = k + 1;
-      // ---- the reflector of column k
-      double loc = 0.0;
-#pragma unroll
-      for (int s = S0; s < SI; ++s) loc = (l + 64 * s > k1) ? fma(xs[s], xs[s], loc) : loc;
-      const double sig2 = wave_sum(loc);
-      double xk1 = xs[S0];
-#pragma unroll
-      for (int s = S0 + 1; s < SI; ++s) xk1 = ((k1 >> 6) == s) ? xs[s] : xk1;
-      const double x0 = readlane_f64(xk1, k1 & 63);
+  auto phase = [&](auto s0tag) {
+    constexpr int S0 = decltype(s0tag)::value;
+    const int kbeg = max(64 * S0, off), kend = min(64 * (S0 + 1), off + n - 2);
+    for (int k = kbeg; k < kend; ++k) {  // (positions: the step eliminates column k, index k − off)
+      const int par = k & 1, k1 = k + 1;
+#ifdef ICP_TRI_CYCLES
+      tprev = (long long)__builtin_amdgcn_s_memtime();
+#endif
+      // ---- the reflector of column k: alpha = ∓‖x‖, v = x − alpha e_{k+1}, beta = 2/vᵀv
       double alpha = x0, beta = 0.0;
       if (sig2 != 0.0) {
-        const double nrm = sqrt(fma(x0, x0, sig2));
+        const double s2 = fma(x0, x0, sig2);
+        const double nrm = fast_sqrt(s2);
         alpha = x0 >= 0.0 ? -nrm : nrm;
-        beta = 1.0 / (alpha * (alpha - x0));
+        beta = fast_rcp(fma(nrm, fabs(x0), s2));
       }
-      double vs[SI], ws[SI];
+      const double vk1 = x0 - alpha;
+      TRI_CYC(0);
+      lds_barrier();
+      TRI_CYC(1);
+      if constexpr (TWO) {
+        constexpr int CHR = LD / NW;  // rows summed by one wave
+        if (l < CHR) {
+          const int i = w * CHR + l;
+          double tq[NW];
+#pragma unroll
+          for (int ww = 0; ww < NW; ++ww) tq[ww] = part[ww * LD + i];
+#pragma unroll
+          for (int h = NW / 2; h > 0; h >>= 1)
+#pragma unroll
+            for (int ww = 0; ww < h; ++ww) tq[ww] += tq[ww + h];
+          psum[i] = tq[0];
+        }
+        lds_barrier();
+      }
+      double Axk1;
+      if constexpr (TWO) {
+        Axk1 = psum[k1];
+      } else {
+        const double* pp = part + par * NW * LD + k1;
+        double tq[NW];
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) tq[ww] = pp[ww * LD];
+#pragma unroll
+        for (int h = NW / 2; h > 0; h >>= 1)
+#pragma unroll
+          for (int ww = 0; ww < h; ++ww) tq[ww] += tq[ww + h];
+        Axk1 = tq[0];
+      }
+      double xAx;
+      {
+        double tq[NW];
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) tq[ww] = scal[par * NW + ww];
+#pragma unroll
+        for (int h = NW / 2; h > 0; h >>= 1)
+#pragma unroll
+          for (int ww = 0; ww < h; ++ww) tq[ww] += tq[ww + h];
+        xAx = tq[0];
+      }
+      const double ck1 = colbuf[par * LD + k1];
+      // ---- w = beta·A v − K v with A v = A x − alpha·c, K = beta²·vᵀA v / 2; the next column x' = c − v w_{k+1} − w v_{k+1}
+      const double vAv = fma(alpha * alpha, ck1, fma(-2.0 * alpha, Axk1, xAx));
+      const double K = 0.5 * beta * beta * vAv;
+      const double wk1 = fma(-K, vk1, beta * fma(-alpha, ck1, Axk1));
+      TRI_CYC(2);
+      const bool keeper = w == (k & (NW - 1));  // the wave that files this step's reflector
+      double* hv = a.Hv + (size_t)(k - off) * LD;
+      double vs[SI], ws[SI], xnew[SI];
+      double loc = 0.0;
 #pragma unroll
       for (int s = 0; s < SI; ++s) {
         const int i = l + 64 * s;
-        vs[s] = s < S0 ? 0.0 : (i > k1 ? xs[s] : (i == k1 ? x0 - alpha : 0.0));
-      }
-      if (w == (k & (NW - 1))) {
-#pragma unroll
-        for (int s = 0; s < SI; ++s) a.Hv[(size_t)k * LD + l + 64 * s] = vs[s];
-        if (l == 0) { a.beta[k] = beta; a.e[k] = alpha; }
-      }
-      // ---- partial sums of A·v over this wave's columns; the next column to everyone
-      double vj[NT];
-#pragma unroll
-      for (int t = T0; t < NT; ++t) vj[t] = readlane_f64(vs[(NW * t) >> 6], ((NW * t) & 63) + w);
-      double* mypart = part + (TWO ? 0 : par * NW * LD) + w * LD;
-#pragma unroll
-      for (int s = S0; s < SI; ++s) {
-        double acc = 0.0;
-#pragma unroll
-        for (int t = T0; t < NT; ++t) acc = fma(A[s][t], vj[t], acc);
-        mypart[l + 64 * s] = acc;
-      }
-      if (w == (k1 & (NW - 1))) {
-        const bool first = (k1 / NW) == T0;
-#pragma unroll
-        for (int s = S0; s < SI; ++s) colbuf[par * LD + l + 64 * s] = first ? A[s][T0] : A[s][T1];
-      }
-      __syncthreads();
-      double p[SI];
-      if constexpr (TWO) {
-        constexpr int CH = LD / NW;  // rows summed by one wave
-        if (l < CH) {
-          const int i = w * CH + l;
-          double sum = part[i];
-#pragma unroll
-          for (int ww = 1; ww < NW; ++ww) sum += part[ww * LD + i];
-          psum[i] = sum;
+        vs[s] = 0.0; ws[s] = 0.0; xnew[s] = 0.0;
+        if (s < S0) {
+          if (keeper) hv[i] = 0.0;
+          continue;
         }
-        __syncthreads();
+        double sm;
+        if constexpr (TWO) {
+          sm = psum[i];
+        } else {
+          const double* pp = part + par * NW * LD + i;
+          double tq[NW];
 #pragma unroll
-        for (int s = S0; s < SI; ++s) p[s] = beta * psum[l + 64 * s];
-      } else {
-        const double* pp = part + par * NW * LD;
+          for (int ww = 0; ww < NW; ++ww) tq[ww] = pp[ww * LD];
 #pragma unroll
-        for (int s = S0; s < SI; ++s) {
-          double sum = pp[l + 64 * s];
+          for (int h = NW / 2; h > 0; h >>= 1)
 #pragma unroll
-          for (int ww = 1; ww < NW; ++ww) sum += pp[ww * LD + l + 64 * s];
-          p[s] = beta * sum;
+            for (int ww = 0; ww < h; ++ww) tq[ww] += tq[ww + h];
+          sm = tq[0];
         }
+        const double c = colbuf[par * LD + i];
+        double xi;
+        if constexpr (VLDS) xi = vb[par * LD + i]; else xi = xs[s];
+        const double vi = i == k1 ? vk1 : xi;
+        const double wi = i > k ? fma(-K, vi, beta * fma(-alpha, c, sm)) : 0.0;
+        const double xw = i > k1 ? fma(-vi, wk1, fma(-wi, vk1, c)) : 0.0;
+        loc = i > k1 + 1 ? fma(xw, xw, loc) : loc;
+        if constexpr (VLDS) {
+          wb[i] = wi;
+          vb[(par ^ 1) * LD + i] = xw;
+          if (i == k1) vb[par * LD + i] = vk1;
+        }
+        vs[s] = vi; ws[s] = wi; xnew[s] = xw;
+        if (keeper) hv[i] = vi;
       }
-      // ---- w = p − K v, rows above the active block frozen
-      double pv = 0.0;
-#pragma unroll
-      for (int s = S0; s < SI; ++s) pv = fma(p[s], vs[s], pv);
-      const double K = 0.5 * beta * wave_sum(pv);
-#pragma unroll
-      for (int s = 0; s < SI; ++s) ws[s] = (s >= S0 && l + 64 * s > k) ? fma(-K, vs[s], p[s]) : 0.0;
-      // ---- A ← A − v wᵀ − w vᵀ on the slots still alive
-#pragma unroll
-      for (int t = T0; t < NT; ++t) {
-        const double wj = readlane_f64(ws[(NW * t) >> 6], ((NW * t) & 63) + w);
-#pragma unroll
-        for (int s = S0; s < SI; ++s) A[s][t] = fma(-vs[s], wj, fma(-ws[s], vj[t], A[s][t]));
+      if (keeper && l == 0) {
+        a.beta[k - off] = beta;
+        a.e[k - off] = alpha;
+        a.d[k1 - off] = fma(-vk1, wk1, fma(-wk1, vk1, ck1));
       }
-      // ---- column k+1 after the update: the next x, and d[k+1]
-      double vk1 = vs[S0], wk1 = ws[S0];
+      if constexpr (VLDS) wave_lds_sync();
+      TRI_CYC(3);
+      {
+        double t = xnew[S0];
 #pragma unroll
-      for (int s = S0 + 1; s < SI; ++s) { const bool here = (k1 >> 6) == s; vk1 = here ? vs[s] : vk1; wk1 = here ? ws[s] : wk1; }
-      vk1 = readlane_f64(vk1, k1 & 63);
-      wk1 = readlane_f64(wk1, k1 & 63);
-#pragma unroll
-      for (int s = S0; s < SI; ++s) {
-        const int i = l + 64 * s;
-        const double cn = fma(-vs[s], wk1, fma(-ws[s], vk1, colbuf[par * LD + i]));
-        xs[s] = i > k1 ? cn : 0.0;
-        if (w == 0 && i == k1) a.d[k1] = cn;
+        for (int s = S0 + 1; s < SI; ++s) t = ((k1 + 1) >> 6) == s ? xnew[s] : t;
+        x0 = readlane_f64(t, (k1 + 1) & 63);
       }
+      sig2 = wave_sum(loc);
+      TRI_CYC(4);
+      pass(s0tag, Tag<1>{}, par, par ^ 1, k1 + 1, k, vs, ws, xnew);
+#pragma unroll
+      for (int s = 0; s < SI; ++s) xs[s] = xnew[s];
+      TRI_CYC(7);
     }
   };
-  // phases T0 = 0 .. NT−1, each with its own compile-time bounds (stops where the matrix ends)
-  auto run = [&](auto self, auto t0tag) -> void {
-    constexpr int T0 = decltype(t0tag)::value;
-    if (NW * T0 < n - 2) {
-      phase(t0tag);
-      if constexpr (T0 + 1 < NT) self(self, Tag<T0 + 1>{});
-    }
+  // one phase per row slot: rows of the slots before it are finished
+  auto run = [&](auto self, auto s0tag) -> void {
+    constexpr int S0 = decltype(s0tag)::value;
+    phase(s0tag);
+    if constexpr (S0 + 1 < SI) self(self, Tag<S0 + 1>{});
   };
   run(run, Tag<0>{});
-  // what is left: e[n−2] = A[n−1][n−2] (the last x), d[n−1]
-  if (w == 0) {
-#pragma unroll
-    for (int s = 0; s < SI; ++s)
-      if (l + 64 * s == n - 1) a.e[n - 2] = xs[s];
+#ifdef ICP_TRI_CYCLES
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 8; ++i) g_eigen_stamps[16 + i] = cyc[i];
+#endif
+  // what is left: e[n−2] = A[n−1][n−2] (the last x), d[n−1] (the last column published)
+  lds_barrier();
+  if (w == 0 && l == 0) {
+    a.e[n - 2] = x0;
+    a.d[n - 1] = colbuf[(((off + n - 3) & 1) ^ 1) * LD + LD - 1];
   }
-#pragma unroll
-  for (int s = 0; s < SI; ++s)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-      if (l + 64 * s == n - 1 && w + NW * t == n - 1) a.d[n - 1] = A[s][t];
 }
 
-template <int NW, int SI, int NT>
+template <int NW, int SI, int NT, int TOFF>
 __global__ void __launch_bounds__(NW * 64) k_tridiag(TridiagIO a) {
   constexpr int LD = 64 * SI;
-  constexpr bool TWO = NW * SI > 8;
-  __shared__ double part[(TWO ? 1 : 2) * NW * LD];
-  __shared__ double psum[LD];
-  __shared__ double colbuf[2 * LD];
-  const int n = a.n;
+  __shared__ double lds[TridiagLds<NW, SI>::doubles];
+  const int n = a.n, off = LD - n;
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double A[SI][NT];
+  auto entry = [&](int i, int j) {  // N_ij, by index
+    return 0.5 * (a.M[(size_t)j * n + i] + a.M[(size_t)i * n + j]) / (a.sqrt_lambda[i] * a.sqrt_lambda[j]);
+  };
+  double A[SI][NT], col0[SI];
 #pragma unroll
   for (int s = 0; s < SI; ++s) {
-    const int i = l + 64 * s;
-    const double sli = i < n ? a.sqrt_lambda[i] : 1.0;
+    const int i = l + 64 * s - off;
+    col0[s] = i >= 0 ? entry(i, 0) : 0.0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int j = w + NW * t;
-      double v = 0.0;
-      if (i < n && j < n) v = 0.5 * (a.M[(size_t)j * n + i] + a.M[(size_t)i * n + j]) / (sli * a.sqrt_lambda[j]);
-      A[s][t] = v;
+      const int j = w + NW * (t + TOFF) - off;
+      A[s][t] = i >= 0 && j >= 0 ? entry(i, j) : 0.0;
+      if (a.Nout && i >= 0 && j >= 0) a.Nout[(size_t)j * n + i] = A[s][t];
     }
   }
+  const double d0 = entry(0, 0);
   EIG_STAMP(0);
-  tridiagonalise<NW, SI, NT>(a, A, part, psum, colbuf);
+  tridiagonalise<NW, SI, NT, TOFF>(a, A, col0, d0, lds);
   EIG_STAMP(1);
 }
 
@@ -249,16 +430,13 @@ struct TriSolveIO {
   const double* d;
   const double* e;
   const double* beta;
-  const double* Hv;   // [n][64·SI]
+  const double* Hv;   // [n][64·SI], by position (index + 64·SI − n)
   double* V;          // n×n: column `rank` = eigenvector
   double* Vt;         // n×n: row `rank`
   double* S;          // [n] = 1/mu, descending
   double* mu;         // [n] scratch: the eigenvalues, ascending (the last wave checks the gaps)
   int* sync;          // [2] {waves finished, trouble flags}: zero between launches
   int* status;        // status[0]: 0 ok, 2 = not trustworthy (gaps below resolution / non-finite); status[-1]: 0
-  int* host_status;   // optional pinned copy
-  int* done_word;     // optional completion word (agent scope)
-  int done_value;
 };
 
 constexpr int kTriPasses = 5;       // multisection passes of 64 points: the bracket shrinks 65× per pass
@@ -289,6 +467,7 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const 
 template <int SI>
 __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
   constexpr int LD = 64 * SI;
+  const int off = LD - a.n;  // position of index 0 (see tridiagonalise)
   __shared__ double ds[kTriMaxN], es[kTriMaxN], e2[kTriMaxN], bet[kTriMaxN];
   __shared__ double scr[4][4 * kTriMaxN];
   __shared__ double red[8];
@@ -406,7 +585,7 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
   {
     const double sc = 1.0 / sqrt(znorm2);
 #pragma unroll
-    for (int s = 0; s < SI; ++s) zs[s] = l + 64 * s < n ? zb[l + 64 * s] * sc : 0.0;
+    for (int s = 0; s < SI; ++s) zs[s] = l + 64 * s >= off ? zb[l + 64 * s - off] * sc : 0.0;
   }
   {
     constexpr int PF = 4;
@@ -446,7 +625,7 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
   for (int s = 0; s < SI; ++s) {
     const int i = l + 64 * s;
     const double av = fabs(zs[s]);
-    if (i < n && av > bv) { bv = av; bi = i; }
+    if (i >= off && av > bv) { bv = av; bi = i; }
   }
   for (int o = 32; o > 0; o >>= 1) {
     const double ov = __shfl_xor(bv, o, 64);
@@ -462,8 +641,8 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
   if (!(bv >= 0.0) || !(muj > 0.0)) trouble = true;
 #pragma unroll
   for (int s = 0; s < SI; ++s) {
-    const int i = l + 64 * s;
-    if (i < n) {
+    const int i = l + 64 * s - off;
+    if (i >= 0) {
       const double v = zs[s] * sgn;
       a.V[(size_t)i * n + j] = v;
       a.Vt[(size_t)j * n + i] = v;
@@ -495,9 +674,75 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
     a.status[-1] = 0;
     a.sync[0] = 0;
     a.sync[1] = 0;
-    if (a.host_status) __hip_atomic_store(a.host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (a.done_word) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One refinement step (Ogita & Aishima 2018) on the eigenvector matrix X of the step before: eigenvectors of close eigenvalues
+// come out of the twisted factorisations accurate to eps/gap each but not orthogonal to each other beyond that (1e-9 for the
+// face posteriors); with R = I − XᵀX, S = XᵀNX, mu_i = S_ii/(1 − R_ii), E_ij = (S_ij + mu_j R_ij)/(mu_j − mu_i), E_ii = R_ii/2,
+// X' = X + X·E converges quadratically — one step takes orthogonality and residual to working precision.  Four small products
+// on the f64 matrix cores (one 16×16 tile per wave, operands straight from L2: lane l supplies P[k = l>>4][i = l&15] and
+// Q[k][j = l&15], result register g is C[(l>>4) + 4g][l&15]) and one elementwise launch.
+typedef double tri_d4 __attribute__((ext_vector_type(4)));
+struct TriGemm {
+  const double* P;   // [n][n] row-major: C = PᵀQ (+ mode)
+  const double* Q;
+  double* C;
+  int mode;          // 0: C = PᵀQ; 1: C = I − PᵀQ; 2: C = X + PᵀQ, and Ct = Cᵀ
+  const double* X;
+  double* Ct;
+};
+__global__ void __launch_bounds__(64) k_tri_gemm(int n, TriGemm g0, TriGemm g1) {
+  const TriGemm g = blockIdx.z ? g1 : g0;
+  const int l = threadIdx.x, l15 = l & 15, l4 = l >> 4;
+  const int i0 = 16 * blockIdx.y, j0 = 16 * blockIdx.x;
+  const bool vi = i0 + l15 < n, vj = j0 + l15 < n;
+  const double* p = g.P + i0 + l15;
+  const double* q = g.Q + j0 + l15;
+  tri_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < n; k0 += 32) {
+    double a[8], b[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int k = k0 + 4 * st + l4;
+      a[st] = vi && k < n ? p[(size_t)k * n] : 0.0;
+      b[st] = vj && k < n ? q[(size_t)k * n] : 0.0;
+    }
+#pragma unroll
+    for (int st = 0; st < 8; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[st], b[st], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const int i = i0 + l4 + 4 * r4, j = j0 + l15;
+    if (i < n && j < n) {
+      double v = acc[r4];
+      if (g.mode == 1) v = (i == j ? 1.0 : 0.0) - v;
+      if (g.mode == 2) { v += g.X[(size_t)i * n + j]; g.Ct[(size_t)j * n + i] = v; }
+      g.C[(size_t)i * n + j] = v;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_tri_correction(int n, const double* __restrict__ S, const double* __restrict__ R, double* __restrict__ E,
+                                                        double* __restrict__ Sout) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * n) return;
+  const int i = e / n, j = e - i * n;
+  const double rii = R[(size_t)i * n + i], rjj = R[(size_t)j * n + j];
+  const double mi = S[(size_t)i * n + i] / (1.0 - rii), mj = S[(size_t)j * n + j] / (1.0 - rjj);
+  double v;
+  if (i == j) {
+    v = 0.5 * rii;
+    Sout[i] = 1.0 / mi;
+  } else {
+    const double den = mj - mi;
+    v = fabs(den) > 1e-11 * (fabs(mi) + fabs(mj)) ? fma(mj, R[e], S[e]) / den : 0.5 * R[e];
+  }
+  E[e] = v;
+}
+__global__ void k_tri_done(const int* status, int* host_status, int* done_word, int done_value) {
+  if (host_status) __hip_atomic_store(host_status, status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (done_word) __hip_atomic_store(done_word, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace tri

@@ -1863,19 +1863,34 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   double *d = base, *e = base + tri::kTriMaxN, *beta = base + 2 * tri::kTriMaxN, *mu = base + 3 * tri::kTriMaxN;
   int* sync = (int*)(base + 4 * tri::kTriMaxN);
   double* Hv = base + 4 * tri::kTriMaxN + 8;
-  tri::TridiagIO ti{r, M, sqrt_lambda, d, e, beta, Hv};
-  tri::TriSolveIO so{r, d, e, beta, Hv, V, Vt, S, mu, sync, status, host_status, done_word, done_value};
+  // the refinement step's matrices live where the Jacobi kernels' log would be (this route replaces them): N | X | Xt | T | S | R
+  const size_t rr = (size_t)r * r;
+  double *Nm = work, *X = work + rr, *Xt = work + 2 * rr, *T = work + 3 * rr, *Sm = work + 4 * rr, *R = work + 5 * rr;
+  tri::TridiagIO ti{r, M, sqrt_lambda, d, e, beta, Hv, Nm};
+  tri::TriSolveIO so{r, d, e, beta, Hv, X, Xt, S, mu, sync, status};
   const int nwg = (r + 3) / 4;
   if (r <= 64) {
-    hipLaunchKernelGGL((tri::k_tridiag<4, 1, 16>), dim3(1), dim3(256), 0, st, ti);
+    hipLaunchKernelGGL((tri::k_tridiag<4, 1, 16, 0>), dim3(1), dim3(256), 0, st, ti);
     hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), 0, st, so);
   } else if (r <= 128) {
-    hipLaunchKernelGGL((tri::k_tridiag<8, 2, 16>), dim3(1), dim3(512), 0, st, ti);
+    hipLaunchKernelGGL((tri::k_tridiag<4, 2, 32, 0>), dim3(1), dim3(256), 0, st, ti);
     hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), 0, st, so);
+  } else if (r <= 192) {
+    hipLaunchKernelGGL((tri::k_tridiag<8, 3, 24, 0>), dim3(1), dim3(512), 0, st, ti);
+    hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg), dim3(256), 0, st, so);
   } else {
-    hipLaunchKernelGGL((tri::k_tridiag<8, 4, 25>), dim3(1), dim3(512), 0, st, ti);
+    hipLaunchKernelGGL((tri::k_tridiag<8, 4, 25, 7>), dim3(1), dim3(512), 0, st, ti);
     hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), 0, st, so);
   }
+  // one refinement step: T = N·X and R = I − XᵀX, S = XᵀT, E, then V = X + X·E (and Vt)
+  const int nt = (r + 15) / 16;
+  const tri::TriGemm gT{Nm, X, T, 0, nullptr, nullptr}, gR{X, X, R, 1, nullptr, nullptr}, gS{X, T, Sm, 0, nullptr, nullptr};
+  hipLaunchKernelGGL(tri::k_tri_gemm, dim3(nt, nt, 2), dim3(64), 0, st, r, gT, gR);
+  hipLaunchKernelGGL(tri::k_tri_gemm, dim3(nt, nt, 1), dim3(64), 0, st, r, gS, gS);
+  hipLaunchKernelGGL(tri::k_tri_correction, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, st, r, (const double*)Sm, (const double*)R, T, S);
+  const tri::TriGemm gV{Xt, T, V, 2, X, Vt};
+  hipLaunchKernelGGL(tri::k_tri_gemm, dim3(nt, nt, 1), dim3(64), 0, st, r, gV, gV);
+  if (host_status || done_word) hipLaunchKernelGGL(tri::k_tri_done, dim3(1), dim3(1), 0, st, (const int*)status, host_status, done_word, done_value);
 }
 
 // N = D⁻¹ M D⁻¹ (symmetrised) for the in-place kernel

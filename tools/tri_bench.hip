@@ -102,5 +102,10 @@ int main(int argc, char** argv) {
   long long s[64]; hipMemcpyFromSymbol(s, HIP_SYMBOL(icp::g_eigen_stamps), sizeof(s));
   printf("%.1f us per decomposition (cold) | stamps: reduction %.1f | solve: setup %.1f multisection %.1f vectors %.1f back-transformation %.1f output %.1f\n", ms * 1000 / reps,
          (s[1] - s[0]) * 0.01, (s[9] - s[8]) * 0.01, (s[10] - s[9]) * 0.01, (s[11] - s[10]) * 0.01, (s[12] - s[11]) * 0.01, (s[13] - s[12]) * 0.01);
+  if (r >= 3) {
+    const double st_ = r - 2;
+    printf("reduction, shader cycles per step: reflector %.0f | barrier %.0f | scalars %.0f | rows + private LDS %.0f | norm %.0f | pass %.0f | publish + xAx %.0f | (tail %.0f)\n", s[16] / st_,
+           s[17] / st_, s[18] / st_, s[19] / st_, s[20] / st_, s[21] / st_, s[22] / st_, s[23] / st_);
+  }
   return 0;
 }
