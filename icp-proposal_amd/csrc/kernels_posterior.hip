@@ -218,21 +218,39 @@ __global__ void __launch_bounds__(1024) k_posterior_factor_blocked(int r, Factor
       P[(size_t)t * ldp + j] = W[(size_t)(below0 + t) * r + kb + j];
     }
     __syncthreads();
-    for (int t = tid; t < n_below; t += nt) {
-      double* x = P + (size_t)t * ldp;
-      for (int j = 0; j < nbk; ++j) {
-        double a = x[j];
-        const double* lj = D + j * ldd;
-        int k = 0;
-        for (; k + 8 <= j; k += 8) {  // eight operand pairs in flight (three waves carry rows: nothing else hides the LDS latency)
-          double xv[8], lv[8];
+    // eight lanes per row, entry k of the row with lane k mod 8: a step's dot product is at most eight multiply-adds per lane
+    // and three DPP exchanges inside the group; the lane that owns x_j is the only one that needs it (128 rows per pass)
+    for (int row0 = 0; row0 < n_below; row0 += 128) {
+      const int t = row0 + (tid >> 3), u = tid & 7;
+      const bool act = t < n_below;
+      double* xrow = P + (size_t)(act ? t : 0) * ldp;
+      double x[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { xv[u] = x[k + u]; lv[u] = lj[k + u]; }
+      for (int q = 0; q < 8; ++q) x[q] = act && u + 8 * q < nbk ? xrow[u + 8 * q] : 0.0;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) a = fma(-xv[u], lv[u], a);
+      for (int jj = 0; jj < 8; ++jj) {
+        if (8 * jj < nbk) {
+#pragma unroll
+          for (int uu = 0; uu < 8; ++uu) {
+            const int j = 8 * jj + uu;
+            if (j < nbk) {
+              const double* lj = D + j * ldd + u;
+              double part = 0.0;
+#pragma unroll
+              for (int q = 0; q < jj; ++q) part = fma(x[q], lj[8 * q], part);
+              part = u < uu ? fma(x[jj], lj[8 * jj], part) : part;
+              part += tri::dpp_f64<0xB1>(part);
+              part += tri::dpp_f64<0x4E>(part);
+              part += tri::dpp_f64<0x141>(part);
+              const double xj = (x[jj] - part) * s_dinv[j];
+              x[jj] = u == uu ? xj : x[jj];
+            }
+          }
         }
-        for (; k < j; ++k) a = fma(-x[k], lj[k], a);
-        x[j] = a * s_dinv[j];
+      }
+      if (act) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (u + 8 * q < nbk) xrow[u + 8 * q] = x[q];
       }
     }
     __syncthreads();
@@ -242,16 +260,45 @@ __global__ void __launch_bounds__(1024) k_posterior_factor_blocked(int r, Factor
     }
     CHOL_T(2);
     // 3: trailing update of the rows below (lower triangle; the appended row r has every column < r)
-    for (int ti = tid >> 5; ti < n_below; ti += 32)
-      for (int tj = tid & 31; tj <= ti; tj += 32) {
-        const int gi = below0 + ti, gj = below0 + tj;
-        if (gj >= r) continue;
-        const double* xi = P + (size_t)ti * ldp;
-        const double* xj = P + (size_t)tj * ldp;
-        double acc = 0.0;
-        for (int k = 0; k < nbk; ++k) acc = fma(xi[k], xj[k], acc);
-        W[(size_t)gi * r + gj] -= acc;
+    // (4×4 outputs per thread: eight LDS reads per sixteen multiply-adds instead of two per one)
+    {
+      const int nt4 = (n_below + 3) >> 2, ntiles = nt4 * (nt4 + 1) / 2;
+      for (int tile = tid; tile < ntiles; tile += nt) {
+        int bi = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+        while (bi * (bi + 1) / 2 > tile) --bi;
+        while ((bi + 1) * (bi + 2) / 2 <= tile) ++bi;
+        const int bj = tile - bi * (bi + 1) / 2;
+        const double* xi[4];
+        const double* xj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          xi[a] = P + (size_t)min(4 * bi + a, n_below - 1) * ldp;
+          xj[a] = P + (size_t)min(4 * bj + a, n_below - 1) * ldp;
+        }
+        double acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+        for (int k = 0; k < nbk; ++k) {
+          double va[4], vb[4];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) { va[a] = xi[a][k]; vb[a] = xj[a][k]; }
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = fma(va[a], vb[b], acc[a][b]);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int ti = 4 * bi + a, tj = 4 * bj + b;
+            const int gi = below0 + ti, gj = below0 + tj;
+            if (ti < n_below && tj <= ti && gj < r) W[(size_t)gi * r + gj] -= acc[a][b];
+          }
       }
+    }
     __syncthreads();
     CHOL_T(3);
   }
@@ -1794,6 +1841,23 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
   const int ld = r | 1;
   const size_t tiles = (size_t)factor_tile_count(r);
   const bool w_fits = (size_t)(r + 1) * ld <= (size_t)kLdsDoubles - 2000;  // + the static LDS of the kernel
+  const bool blocked = !(w_fits && tiles <= 2048) && r <= kCholMaxRank;
+  if (blocked) {
+    // the split-K partials are summed by a launch of their own, on many CUs, into the first one (same order of summation as the
+    // kernel's own loop, which one workgroup's share of the memory system made 44 us of at rank 200)
+    for (int p0 = 0; p0 < n_post; p0 += 2) {
+      StepReduceArgs ra{};
+      ra.nn = (r + 1) * (r + 1);
+      for (int p = p0; p < std::min(n_post, p0 + 2); ++p)
+        if (fa.splits[p] > 1) {
+          ra.Mpart[ra.n] = const_cast<double*>(fa.Mpart[p]);
+          ra.splits[ra.n] = fa.splits[p];
+          ++ra.n;
+          fa.splits[p] = 1;
+        }
+      if (ra.n) launch_step_reduce(st, ra);
+    }
+  }
   ProfScope _ps(st, KID_FACTOR);
   if (w_fits && tiles <= 256) launch_factor_reg<1, 256>(st, r, n_post, fa);
   else if (w_fits && tiles <= 1024) launch_factor_reg<1, 1024>(st, r, n_post, fa);
