@@ -447,19 +447,29 @@ constexpr int kTriMaxN = 256;
 // three-term recurrence (one dependent fma per row), rescaled every eighth row
 __device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const double* __restrict__ e2, int n, double x) {
   double p0 = 1.0, p1 = ds[0] - x;
-  if (p1 == 0.0) p1 = -1e-300;
   int cnt = (unsigned)__double2hiint(p1) >> 31;
-  for (int i = 1; i < n; ++i) {
-    double p2 = fma(ds[i] - x, p1, -(e2[i - 1] * p0));
-    if (p2 == 0.0) p2 = p1 < 0.0 ? 1e-300 : -1e-300;
-    cnt += (unsigned)(__double2hiint(p2) ^ __double2hiint(p1)) >> 31;
-    p0 = p1;
-    p1 = p2;
-    if ((i & 7) == 0) {
-      const int ex = max(__builtin_amdgcn_frexp_exp(p0), __builtin_amdgcn_frexp_exp(p1));
-      p0 = ldexp(p0, -ex);
-      p1 = ldexp(p1, -ex);
+  for (int i0 = 1; i0 < n; i0 += 8) {  // eight rows' coefficients fetched together: the recurrence itself is one dependent fma per row
+    double dd[8], ee[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + u, n - 1);
+      dd[u] = ds[i] - x;
+      ee[u] = e2[i - 1];
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i0 + u < n) {
+        // (an exact zero needs no care: by its sign bit it counts as positive, and its successor −e²·p0 has the sign opposite
+        // to its predecessor's — one change across the three, whichever way round)
+        const double p2 = fma(dd[u], p1, -(ee[u] * p0));
+        cnt += (unsigned)(__double2hiint(p2) ^ __double2hiint(p1)) >> 31;
+        p0 = p1;
+        p1 = p2;
+      }
+    }
+    const int ex = max(__builtin_amdgcn_frexp_exp(p0), __builtin_amdgcn_frexp_exp(p1));
+    p0 = ldexp(p0, -ex);
+    p1 = ldexp(p1, -ex);
   }
   return cnt;
 }
@@ -531,15 +541,17 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
       const int st = dir ? -1 : 1;
       double D = ds[i] - lam;
       Dq[dir * n + i] = D;
+      double ee = es[dir ? i - 1 : i], dn = ds[i + st] - lam;  // the next step's coefficients are fetched a step ahead
       for (int k = 0; k < n - 1; ++k) {
         const int ie = dir ? i - 1 : i;
-        if (fabs(D) < 1e-150) D = D < 0.0 ? -1e-150 : 1e-150;
-        const double ee = es[ie];
-        const double L = ee / D;
-        Lq[dir * n + ie] = L;
+        D = copysign(fmax(fabs(D), 1e-150), D);
+        const double L = ee * fast_rcp(D);
+        const double Dn = fma(-L, ee, dn);
         i += st;
-        D = (ds[i] - lam) - L * ee;
-        Dq[dir * n + i] = D;
+        if (k + 1 < n - 1) { ee = es[dir ? i - 1 : i]; dn = ds[i + st] - lam; }
+        Lq[dir * n + ie] = L;
+        Dq[dir * n + i] = Dn;
+        D = Dn;
       }
     }
     wave_lds_sync();
@@ -562,11 +574,16 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
       const int cnt = dir ? n - 1 - rt : rt;
       double zc = 1.0;
       int idx = rt;
+      const int stp = dir ? 1 : -1;
+      const double* lq = Lq + dir * n + (dir ? 0 : -1);  // the multiplier of the step from idx: lq[idx]
+      double l0 = cnt > 0 ? lq[idx] : 0.0, l1 = cnt > 1 ? lq[idx + stp] : 0.0;  // fetched two steps ahead
       for (int k = 0; k < cnt; ++k) {
-        const int ie = dir ? idx : idx - 1;
-        zc = -(Lq[dir * n + ie] * zc);
-        idx += dir ? 1 : -1;
+        const double l2 = k + 2 < cnt ? lq[idx + 2 * stp] : 0.0;
+        zc = -(l0 * zc);
+        idx += stp;
         zb[idx] = zc;
+        l0 = l1;
+        l1 = l2;
       }
       if (dir == 0) zb[rt] = 1.0;
     }

@@ -139,6 +139,25 @@ __global__ void __launch_bounds__(NT) k_posterior_factor_reg(int r, FactorArgs f
 //   3 the trailing lower triangle takes −P·Pᵀ (operands from LDS, the matrix itself read and written in place).
 // Then the blocked back substitution Lᵀα = y.  ≈ 0.15 ms at rank 200 (the generic kernel further up, every entry behind L2:
 // 3.3 ms).
+// Σ of the split-K partials of up to two posteriors into their first partial, on many CUs, in split order (the order of the
+// factor kernels' own loops)
+struct PartialSumArgs { int n; int nn; double* Mpart[2]; int splits[2]; };
+__global__ void __launch_bounds__(256) k_sum_partials(PartialSumArgs a) {
+  const int which = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (which >= a.n || e >= a.nn) return;
+  double* P = a.Mpart[which];
+  const int S = a.splits[which];
+  double acc = 0.0;
+  for (int s0 = 0; s0 < S; s0 += 8) {  // eight splits in flight
+    double q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = P[(size_t)min(s0 + u, S - 1) * a.nn + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (s0 + u < S) acc += q[u];
+  }
+  P[e] = acc;
+}
+
 constexpr int kCholNB = 64;
 constexpr int kCholMaxRank = 256;
 
@@ -1753,7 +1772,7 @@ __global__ void __launch_bounds__(kBlock) k_sum_gauss_logpdf(int K, const double
   sum_gauss_logpdf_body(K, d2, mean, sigma, out);
 }
 
-__global__ void __launch_bounds__(kBlock) k_dist_stats(int K, const double* __restrict__ d2, const unsigned char* __restrict__ flags,
+__global__ void __launch_bounds__(1024) k_dist_stats(int K, const double* __restrict__ d2, const unsigned char* __restrict__ flags,
                                                         const int* __restrict__ idx, int n_flags, double* __restrict__ out) {
   __shared__ double s_red[16];
   double sum = 0.0, mx = -__builtin_inf(), cnt = 0.0;
@@ -1846,7 +1865,7 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
     // the split-K partials are summed by a launch of their own, on many CUs, into the first one (same order of summation as the
     // kernel's own loop, which one workgroup's share of the memory system made 44 us of at rank 200)
     for (int p0 = 0; p0 < n_post; p0 += 2) {
-      StepReduceArgs ra{};
+      PartialSumArgs ra{};
       ra.nn = (r + 1) * (r + 1);
       for (int p = p0; p < std::min(n_post, p0 + 2); ++p)
         if (fa.splits[p] > 1) {
@@ -1855,7 +1874,7 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
           ++ra.n;
           fa.splits[p] = 1;
         }
-      if (ra.n) launch_step_reduce(st, ra);
+      if (ra.n) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(ra.nn, 256), ra.n), dim3(256), 0, st, ra);
     }
   }
   ProfScope _ps(st, KID_FACTOR);
@@ -2132,7 +2151,8 @@ void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mea
 void launch_dist_stats(hipStream_t st, int K, const double* d2, const unsigned char* flags, const int* idx,
                        int n_flags, double* out) {
   { ProfScope _ps(st, KID_REDUCE);
-    hipLaunchKernelGGL(k_dist_stats, dim3(1), dim3(kBlock), 0, st, K, d2, flags, idx, n_flags, out); }
+    // (one workgroup: the sum has one fixed order; four times the threads where the list is a whole mesh — 40 us per call at 28k points)
+    hipLaunchKernelGGL(k_dist_stats, dim3(1), dim3(K > 4096 ? 1024 : kBlock), 0, st, K, d2, flags, idx, n_flags, out); }
 }
 
 }  // namespace icp
