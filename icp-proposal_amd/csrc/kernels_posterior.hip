@@ -1419,7 +1419,9 @@ template <bool SQUARE>
 __global__ void __launch_bounds__(1024) k_eigen_big(int r, const double* __restrict__ A0 /* r×r, symmetric */, const double* __restrict__ Vwarm,
                                                      double* __restrict__ Vwork /* [coordinate][index] eigenvectors, unsorted */,
                                                      double* __restrict__ mu_out, double* rotlog, double* xcorr /* r×r */, int* meta,
-                                                     int max_sweeps, int no_corr, int launch_id, int* __restrict__ status) {
+                                                     int max_sweeps, int no_corr, int launch_id, int* __restrict__ status,
+                                                     const int* __restrict__ gate /* optional: run only if *gate == 2 */) {
+  if (gate && gate[0] != 2) return;  // (the fall-back of the tridiagonal route: its eigenvalues were told apart)
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n = r, n2 = (r + 1) & ~1, half = n2 >> 1, mm = n2 - 1;
   __shared__ short s_p[128], s_q[128];
@@ -1651,7 +1653,9 @@ __global__ void __launch_bounds__(256) k_eigen_big_warm(int r, const double* __r
 // largest-|.| component (the first among equals), the two output layouts
 __global__ void __launch_bounds__(64) k_eigen_big_finish(int r, const double* __restrict__ Vwork, const double* __restrict__ mu,
                                                           double* __restrict__ Vout, double* __restrict__ Vtout, double* __restrict__ Sout,
-                                                          const int* __restrict__ status, int* __restrict__ host_status) {
+                                                          const int* __restrict__ status, int* __restrict__ host_status,
+                                                          const int* __restrict__ gate, int gate_value) {
+  if (gate && ((gate[0] >> kPwIdShift) & kPwIdMask) != gate_value) return;  // (gate = the iteration's progress word: did THIS launch's run?)
   const int p = blockIdx.x, l = threadIdx.x;
   const double mp = mu[p];
   int cnt = 0;
@@ -1940,6 +1944,8 @@ static bool tridiag_route(int r) {
   if (r < 3 || r > kTriMaxRank) return false;
   return forced >= 0 ? forced != 0 : r > 64;
 }
+static void launch_eigen_big(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V, double* Vt,
+                             double* S, double* work, int* status, int* host_status, const int* gate);
 static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const double* sqrt_lambda, double* V, double* Vt, double* S, double* work,
                                  int* status, int* host_status, int* done_word, int done_value) {
   double* base = work + jacobi_work_doubles(r);
@@ -1973,12 +1979,17 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   hipLaunchKernelGGL(tri::k_tri_correction, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, st, r, (const double*)Sm, (const double*)R, T, S);
   const tri::TriGemm gV{Xt, T, V, 2, X, Vt};
   hipLaunchKernelGGL(tri::k_tri_gemm, dim3(nt, nt, 1), dim3(64), 0, st, r, gV, gV);
+  // eigenvalues that multisection could not tell apart (status 2: a spectrum with (near-)multiple eigenvalues, e.g. a posterior without
+  // correspondences over a model with equal variances): the Jacobi iteration takes over, cold, in the same stream — its launches
+  // return at once otherwise
+  if (r > 64) launch_eigen_big(st, r, M, sqrt_lambda, nullptr, V, Vt, S, work, status, nullptr, status);
   if (host_status || done_word) hipLaunchKernelGGL(tri::k_tri_done, dim3(1), dim3(1), 0, st, (const int*)status, host_status, done_word, done_value);
 }
 
 // N = D⁻¹ M D⁻¹ (symmetrised) for the in-place kernel
 __global__ void __launch_bounds__(256) k_eigen_big_prepare(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
-                                                           double* __restrict__ A) {
+                                                           double* __restrict__ A, const int* __restrict__ gate) {
+  if (gate && gate[0] != 2) return;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= r * r) return;
   const int i = e / r, j = e - i * r;
@@ -1986,7 +1997,7 @@ __global__ void __launch_bounds__(256) k_eigen_big_prepare(int r, const double* 
 }
 
 static void launch_eigen_big(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V, double* Vt,
-                             double* S, double* work, int* status, int* host_status) {
+                             double* S, double* work, int* status, int* host_status, const int* gate) {
   const size_t n2 = ((size_t)r + 1) & ~(size_t)1, rr = (size_t)r * r;
   double* A0 = work;
   double* T = work + rr;
@@ -1995,7 +2006,7 @@ static void launch_eigen_big(hipStream_t st, int r, const double* M, const doubl
   double* rotlog = mu + n2;
   int* meta = (int*)(rotlog + (size_t)kEigenMaxSweeps * (n2 - 1) * n2);
   const int eb = (int)((rr + 255) / 256);
-  hipLaunchKernelGGL(k_eigen_big_prepare, dim3(eb), dim3(256), 0, st, r, M, sqrt_lambda, A0);
+  hipLaunchKernelGGL(k_eigen_big_prepare, dim3(eb), dim3(256), 0, st, r, M, sqrt_lambda, A0, gate);
   if (Vwarm) {  // A0 <- Vwarmᵀ·A0·Vwarm
     hipLaunchKernelGGL(k_eigen_big_warm, dim3(eb), dim3(256), 0, st, r, (const double*)A0, Vwarm, T, 0);
     hipLaunchKernelGGL(k_eigen_big_warm, dim3(eb), dim3(256), 0, st, r, (const double*)T, Vwarm, A0, 1);
@@ -2018,12 +2029,13 @@ static void launch_eigen_big(hipStream_t st, int r, const double* M, const doubl
   double* xcorr = T;  // (the warm transform's scratch is free once the iteration starts)
   if (square)
     hipLaunchKernelGGL(k_eigen_big<true>, dim3(1 + nb), dim3(1024), shmem, st, r, (const double*)A0, Vwarm, Vwork, mu, rotlog, xcorr, meta,
-                       std::min(sweeps_cap, kEigenMaxSweeps), no_corr, launch_id, status);
+                       std::min(sweeps_cap, kEigenMaxSweeps), no_corr, launch_id, status, gate);
   else
     hipLaunchKernelGGL(k_eigen_big<false>, dim3(1 + nb), dim3(1024), shmem, st, r, (const double*)A0, Vwarm, Vwork, mu, rotlog, xcorr, meta,
-                       std::min(sweeps_cap, kEigenMaxSweeps), no_corr, launch_id, status);
+                       std::min(sweeps_cap, kEigenMaxSweeps), no_corr, launch_id, status, gate);
+  // (as a fall-back the sort runs only if the iteration did: its progress word carries this launch's id then)
   hipLaunchKernelGGL(k_eigen_big_finish, dim3(r), dim3(64), 0, st, r, (const double*)Vwork, (const double*)mu, V, Vt, S, (const int*)status,
-                     host_status);
+                     host_status, gate ? (const int*)meta : nullptr, launch_id);
 }
 
 void eigen_debug_dump(const double* work, int r) {  // developer aid: convergence trace of the last decomposition on `work`
@@ -2101,7 +2113,7 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
   }
   if (r > 64 && r <= kBigMaxRank) {  // in-place parallel Jacobi, packed triangle in one CU's LDS + replay workgroups
     ProfScope _ps(st, KID_EIGEN);
-    launch_eigen_big(st, r, M, sqrt_lambda, Vwarm, V, Vt, S, work, status, host_status);
+    launch_eigen_big(st, r, M, sqrt_lambda, Vwarm, V, Vt, S, work, status, host_status, nullptr);
     return;
   }
   // ranks above 200: the generic single-workgroup kernel (matrix behind L2)

@@ -68,6 +68,28 @@ def test_small_face_evaluators_match_oracle(pkg, oracle, small, kind):
     ev.close()
 
 
+def test_multiple_eigenvalues_take_the_jacobi_fall_back(pkg, oracle):
+    """Ranks above 64 are decomposed by tridiagonalisation + multisection + twisted factorisation, which needs eigenvalues it can
+    tell apart.  The stand-in's variances come in equal pairs (modes (p, q) and (q, p)): without correspondences — and with a
+    single one, a rank-3 change — the posterior's spectrum has exact multiples, the route reports them on the device and the Jacobi
+    iteration takes over in the same stream; with the usual 2r correspondences it does not.  All three against the oracle."""
+    model = pkg.data.synthetic_face_model(grid=41, rank=72)
+    assert (np.diff(np.sort(model.variance)) == 0).sum() >= 30
+    target = pkg.data.synthetic_partial_target(model, n_remove=90)
+    ctx = pkg.IcpContext(model, target, device=0)
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    theta = face_theta(model, 3)
+    for K in (0, 1, 144):
+        pp = oracle.proposal_params(0.1, 6.0, 3.0, oracle.MODEL_SAMPLING, True, n_model_ids=K)
+        prop = pkg.NonRigidIcpProposal(ctx, 0.1, 6.0, 3.0, K, "ModelSampling", True)
+        post, po = prop.icpPosterior(theta), oracle.icp_posterior(om, ot, pp, theta)
+        assert np.abs(post.S - po.S).max() <= 1e-12 * np.abs(po.S).max()
+        assert np.abs(post.V.T @ post.V - np.eye(72)).max() <= 1e-10
+        assert np.abs(post.V - po.V).max() <= 1e-9
+        prop.close()
+    ctx.close()
+
+
 @pytest.fixture(scope="module")
 def full_face(pkg):
     model = pkg.data.synthetic_face_model()          # N = 28,561, T = 56,448, rank 200
