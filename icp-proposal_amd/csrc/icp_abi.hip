@@ -774,6 +774,10 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
     return e;
   }
   PosteriorEntry& e = fresh_entry();
+  if (e.eig_event_valid && e.eigen_event()) {  // a decomposition that may still read this entry's M (started ahead, its state not kept)
+    HIP_OK(hipStreamWaitEvent(c.stream, e.eigen_event(), 0));
+    e.eig_event_valid = false;
+  }
   e.theta.assign(theta, theta + P);
   e.valid = true;
   e.stamp = ++clock;
@@ -1938,6 +1942,19 @@ int icp_mesh_metrics(icp_ctx* ctx, const double* theta, double* out) {
 
 // --------------------------------------------------------------------- fused chain step
 
+} // extern "C" (helper)
+namespace {
+// 0: never, 1: always, 2: adaptive (ICP_SPECULATION / ICP_NO_SPECULATION)
+int speculation_mode() {
+  static const int mode = [] {
+    if (std::getenv("ICP_NO_SPECULATION")) return 0;
+    const char* v = std::getenv("ICP_SPECULATION");
+    return v ? (std::atoi(v) != 0 ? 1 : 0) : 2;
+  }();
+  return mode;
+}
+}  // namespace
+extern "C" {
 int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, const double* theta_cur,
                         const double* theta_prop, double* log_value_prop, double* fwd, double* bwd) {
   int status = ICP_OK;
@@ -1953,11 +1970,22 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
     const int r = c.r;
     icp_evaluator::Memo* m = eval_lookup(e, theta_prop);
     const bool need_eval = m == nullptr;
-    if (need_eval) {
+    const bool shape_only = pose_equal(theta_cur, theta_prop);
+    // Ranks above 64 (one workgroup factors, one reduces to tridiagonal form: 0.2 + 0.7 ms at rank 200 with most of the chip idle):
+    // the posteriors go first and the proposed state's decomposition starts at once on the eigen stream, BESIDE the evaluator's
+    // searches on this one — if the state is accepted, the next proposal finds its basis done or under way; if not, the work
+    // was done on CUs nobody needed.  (Acceptance tracked as in the merged step; not worth it when next to nothing is accepted.)
+    if (!e->last_prop.empty()) {
+      const bool accepted = std::memcmp(e->last_prop.data(), theta_cur, sizeof(double) * (10 + (size_t)r)) == 0;
+      e->acc_ema = 0.9 * e->acc_ema + (accepted ? 0.1 : 0.0);
+    }
+    const int spec_mode = speculation_mode();
+    const bool spec_big = r > 64 && shape_only && n_props == 1 && need_eval && !c.speculation_off &&
+                          (spec_mode == 1 || (spec_mode == 2 && e->acc_ema >= 0.1));
+    if (need_eval && !spec_big) {
       StateSlot& s = c.state(theta_prop);
       enqueue_eval(e, s, 0);
     }
-    const bool shape_only = pose_equal(theta_cur, theta_prop);
     PosteriorEntry* ec[8];
     PosteriorEntry* ep[8];
     TransitionTailIO tails[16];
@@ -1977,9 +2005,15 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         ++n_tails;
         sync_proposal_status(p);
       }
+      if (spec_big) props[0]->ensure_eigen(*ep[0]);  // (no-op if this entry's basis exists or is under way)
       for (int t0 = 0; t0 < n_tails; t0 += 8)
         launch_transition_tails(c.stream, r, std::min(8, n_tails - t0), tails + t0, c.Ginv.p, kSigma2);
     }
+    if (need_eval && spec_big) {
+      StateSlot& s = c.state(theta_prop);
+      enqueue_eval(e, s, 0);
+    }
+    e->last_prop.assign(theta_prop, theta_prop + 10 + r);
     c.finish(8 + (size_t)n_tails, (size_t)n_tails);
     for (int t = 0; t < n_tails; ++t)
       if (c.h_status[t] != 0) {  // rare: fixed-point tail did not contract -> direct kernel, one at a time
@@ -2396,14 +2430,6 @@ bool chain_step_record(icp_evaluator* e, int n_props, icp_proposal* const* props
 }
 
 // ICP_SPECULATION: 0 never, 1 always, unset = adaptive (2): while the chain's running acceptance rate is high
-int speculation_mode() {
-  static const int mode = [] {
-    if (std::getenv("ICP_NO_SPECULATION")) return 0;
-    const char* v = std::getenv("ICP_SPECULATION");
-    return v ? (std::atoi(v) != 0 ? 1 : 0) : 2;
-  }();
-  return mode;
-}
 
 bool front_matches(const StepFront& F, int n_props, icp_proposal* const* props, int generator, const double* theta_cur,
                    const double* key, int r) {

@@ -470,7 +470,11 @@ def test_contexts_share_model_and_target_memory(pkg):
     about 10 MB are the runtime's own per-stream allocations — 64 chains: 1.8 GB, against 7 GB with per-context copies and worst-case
     lists), and chains on such contexts still give the values of a chain on a context of its own."""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")  # (the runtime the library itself uses: free memory as the process sees it)
+    # the HIP runtime the library itself is linked to (the very file this process has mapped: another copy would be another runtime)
+    with open("/proc/self/maps") as f:
+        paths = {line.split()[-1] for line in f if "libamdhip64" in line}
+    assert len(paths) >= 1
+    hip = ctypes.CDLL(sorted(paths)[0])
 
     def free_bytes():
         free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
