@@ -274,6 +274,9 @@ struct icp_ctx {
   hipStream_t eig_last = nullptr;  // where this context's latest decompositions were launched: eig_stream, or the eigen stream
                                    // of the first context of a batch (see eigen_stream_for)
   hipEvent_t ev_ready = nullptr;                 // stream -> eig_stream: "M is complete"
+  hipEvent_t ev_side = nullptr;                  // front_stream -> stream: factorisations / tails that went to the side stream are done
+  hipEvent_t ev_sum = nullptr;                   // front_stream -> eig_stream: the partials of the latest posterior are summed
+  hipEvent_t ev_asm = nullptr;                   // eig_stream -> stream: … and read (the next regression may overwrite them)
   hipEvent_t ev_join = nullptr;                  // stream -> front_stream, when another entry point has used `stream`
   bool front_stream_used = false;                // a step is (or may still be) on front_stream: other entry points drain it first
   // ICP_NO_PIPELINE=1, or a first launch once timed out on its word (a tool that lets one kernel run at a time, in an order
@@ -629,7 +632,12 @@ struct icp_proposal {
   std::unique_ptr<PosteriorEntry[]> memo;
   uint64_t clock = 0;
 
-  PosteriorEntry& posterior(const double* theta, bool want_aux);
+  // side: (optional) the stream the factorisation goes to, behind the regression on the context stream (see icp_chain_eval_step)
+  PosteriorEntry& posterior(const double* theta, bool want_aux, hipStream_t side = nullptr);
+  bool side_factor_pending = false;  // a factorisation on the side stream may still read Mpart / write fscratch
+  bool side_asm_pending = false;     // … and a decomposition's first launch on the eigen stream the summed partials
+  double* side_parts = nullptr;      // the summed partials of the latest posterior(…, side), until the next regression …
+  const PosteriorEntry* side_parts_entry = nullptr;  // … and the entry they belong to
   PosteriorEntry* find_entry(const double* theta);
   PosteriorEntry& fresh_entry();
   void alloc_entry(PosteriorEntry& e);
@@ -758,7 +766,7 @@ PosteriorEntry& icp_proposal::fresh_entry() {
   return e;
 }
 
-PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
+PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipStream_t side) {
   icp_ctx& c = *ctx;
   const int r = c.r;
   const size_t P = 10 + (size_t)r;
@@ -803,10 +811,33 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux) {
   const double wt = 1.0 / (prm.tangential_noise * prm.tangential_noise);
   const double kappa = 1.0 / (prm.noise_along_normal * prm.noise_along_normal) - wt;
   int splits = 1;
+  if (side_factor_pending) {  // the partials and the factor scratch are still being read / written over there
+    HIP_OK(hipStreamWaitEvent(c.stream, c.ev_side, 0));
+    side_factor_pending = false;
+  }
+  if (side_asm_pending) {
+    HIP_OK(hipStreamWaitEvent(c.stream, c.ev_asm, 0));
+    side_asm_pending = false;
+  }
+  side_parts = nullptr;
+  side_parts_entry = nullptr;
   double* parts = mpart_for_write(0, c.stream);
   launch_regression(c.stream, K, r, c.Q.p, e.corr(), wt, kappa, parts, &splits);
   PosteriorFactorIO io{parts, splits, e.M.p, e.alpha.p, status.p + e.status_off, fscratch.p};
-  launch_posterior_factor(c.stream, r, 1, &io);
+  if (side) {
+    HIP_OK(hipEventRecord(c.ev_ready, c.stream));
+    HIP_OK(hipStreamWaitEvent(side, c.ev_ready, 0));
+    launch_sum_partials(side, r, parts, splits);
+    io.splits = 1;
+    HIP_OK(hipEventRecord(c.ev_sum, side));
+    side_parts = parts;
+    side_parts_entry = &e;
+    launch_posterior_factor(side, r, 1, &io);
+    HIP_OK(hipEventRecord(c.ev_side, side));
+    side_factor_pending = true;
+  } else {
+    launch_posterior_factor(c.stream, r, 1, &io);
+  }
   return e;
 }
 
@@ -1148,6 +1179,9 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     HIP_OK(hipStreamCreateWithPriority(&ctx->eig_stream, hipStreamNonBlocking, prio_greatest));
     { std::lock_guard<std::mutex> lk(g_eig_streams_mu); g_eig_streams.insert(ctx->eig_stream); }
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ctx->ev_sum, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     HIP_OK(hipHostMalloc((void**)&ctx->h_wait_error, sizeof(int) * 16, hipHostMallocDefault));
     ctx->h_wait_error[0] = 0;
@@ -1305,6 +1339,9 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     (void)hipStreamDestroy(ctx->eig_stream);
   }
   if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
+  if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
+  if (ctx->ev_sum) (void)hipEventDestroy(ctx->ev_sum);
+  if (ctx->ev_asm) (void)hipEventDestroy(ctx->ev_asm);
   if (ctx->front_stream) {
     (void)hipStreamSynchronize(ctx->front_stream);
     library_release_stream(ctx->front_stream);
@@ -1990,28 +2027,58 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
     PosteriorEntry* ep[8];
     TransitionTailIO tails[16];
     int n_tails = 0;
+    // (… and so do the one-workgroup factorisations and the tails: they go to a stream of their own, behind the regression; the
+    // decomposition follows them on the eigen stream; this stream goes on with the searches and waits for the tails before the
+    // results are copied)
+    const hipStream_t side = spec_big ? c.front_stream : nullptr;  // (the merged step's second stream: idle on this path)
     if (shape_only && n_props > 0) {
       const double* d_cur = c.stage(theta_cur + 10, r);
       const double* d_prop = c.stage(theta_prop + 10, r);
       for (int i = 0; i < n_props; ++i) {
         icp_proposal* p = props[i];
-        ec[i] = &p->posterior(theta_cur, false);
-        ep[i] = &p->posterior(theta_prop, false);
+        ec[i] = &p->posterior(theta_cur, false, side);
+        ep[i] = &p->posterior(theta_prop, false, side);
         tails[n_tails] = TransitionTailIO{ec[i]->alpha.p, ec[i]->M.p, d_cur, d_prop, p->prm.step_length, c.d_res.p + 8 + n_tails,
                                           c.d_status.p + n_tails};
         ++n_tails;
         tails[n_tails] = TransitionTailIO{ep[i]->alpha.p, ep[i]->M.p, d_prop, d_cur, p->prm.step_length, c.d_res.p + 8 + n_tails,
                                           c.d_status.p + n_tails};
         ++n_tails;
-        sync_proposal_status(p);
+        if (!side) sync_proposal_status(p);
       }
-      if (spec_big) props[0]->ensure_eigen(*ep[0]);  // (no-op if this entry's basis exists or is under way)
+      if (side) {  // (the staged coefficients and — for entries found in the memo — everything else the tails read: all behind ev_ready)
+        HIP_OK(hipEventRecord(c.ev_ready, c.stream));
+        HIP_OK(hipStreamWaitEvent(side, c.ev_ready, 0));
+      }
       for (int t0 = 0; t0 < n_tails; t0 += 8)
-        launch_transition_tails(c.stream, r, std::min(8, n_tails - t0), tails + t0, c.Ginv.p, kSigma2);
+        launch_transition_tails(side ? side : c.stream, r, std::min(8, n_tails - t0), tails + t0, c.Ginv.p, kSigma2);
+      if (side) {
+        HIP_OK(hipEventRecord(c.ev_side, side));
+        props[0]->side_factor_pending = false;  // (this stream waits for ev_side below)
+        if (!ep[0]->eig_valid) {
+          // the decomposition of the proposed state: behind its factorisation — or, if its posterior was computed just now,
+          // beside it: M = I + the summed partials is written by a launch at the head of the decomposition as well (the same
+          // values the factorisation's assembly writes)
+          const hipStream_t es = eigen_stream_for(c, c.eig_stream);
+          if (props[0]->side_parts && props[0]->side_parts_entry == ep[0]) {
+            HIP_OK(hipStreamWaitEvent(es, c.ev_sum, 0));
+            launch_assemble_posterior_matrix(es, r, props[0]->side_parts, ep[0]->M.p);
+            HIP_OK(hipEventRecord(c.ev_asm, es));
+            props[0]->side_asm_pending = true;
+          } else {
+            HIP_OK(hipStreamWaitEvent(es, c.ev_side, 0));
+          }
+          props[0]->ensure_eigen(*ep[0]);
+        }
+      }
     }
     if (need_eval && spec_big) {
       StateSlot& s = c.state(theta_prop);
       enqueue_eval(e, s, 0);
+    }
+    if (side && shape_only && n_props > 0) {
+      HIP_OK(hipStreamWaitEvent(c.stream, c.ev_side, 0));
+      sync_proposal_status(props[0]);
     }
     e->last_prop.assign(theta_prop, theta_prop + 10 + r);
     c.finish(8 + (size_t)n_tails, (size_t)n_tails);

@@ -184,6 +184,11 @@ void launch_regression(hipStream_t st, int K, int r, const double* Q, const Corr
 // K5b, up to 4 posteriors per launch: M = I + Σ partials, alpha = M^-1 b (Cholesky); status[0] != 0 if M is not SPD.
 struct PosteriorFactorIO { const double* Mpart; int splits; double* M; double* alpha; int* status; double* scratch /* (r+1)·r, large ranks only */; };
 void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io);
+// Σ of one posterior's split-K partials into its first partial, on many CUs (what the factor kernels do themselves otherwise; with
+// it done, they take splits = 1), and M = I + that sum, both triangles, from the summed partial — the start of a decomposition
+// that does not wait for the factorisation (icp_chain_eval_step)
+void launch_sum_partials(hipStream_t st, int r, double* Mpart, int splits);
+void launch_assemble_posterior_matrix(hipStream_t st, int r, const double* Mpart_summed, double* M);
 
 // a9 tails, up to 8 per launch: out = −½ γ^T M γ − (r/2) ln 2π with (G + σ²M) γ = G (c_from + (c_to − c_from)/step − α).
 // Iterative (needs Ginv = G^-1); status[0] != 0 = did not contract -> use the direct kernel.

@@ -1855,6 +1855,27 @@ static void launch_factor_reg(hipStream_t st, int r, int n_post, const FactorArg
 
 void library_release_stream(hipStream_t) {}  // (no library handles any more: kept for the callers' stream teardown)
 
+__global__ void __launch_bounds__(256) k_assemble_posterior_matrix(int r, const double* __restrict__ P, double* __restrict__ M) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= r * r) return;
+  const int i = e / r, j = e - i * r;
+  const int hi = max(i, j), lo = min(i, j);
+  M[e] = P[(size_t)hi * (r + 1) + lo] + (i == j ? 1.0 : 0.0);  // (the values the factor kernels' own assembly writes)
+}
+
+void launch_sum_partials(hipStream_t st, int r, double* Mpart, int splits) {
+  if (splits <= 1) return;
+  PartialSumArgs ra{};
+  ra.nn = (r + 1) * (r + 1);
+  ra.n = 1;
+  ra.Mpart[0] = Mpart;
+  ra.splits[0] = splits;
+  hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(ra.nn, 256), 1), dim3(256), 0, st, ra);
+}
+void launch_assemble_posterior_matrix(hipStream_t st, int r, const double* Mpart_summed, double* M) {
+  hipLaunchKernelGGL(k_assemble_posterior_matrix, dim3(cdiv(r * r, 256)), dim3(256), 0, st, r, Mpart_summed, M);
+}
+
 void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io) {
   FactorArgs fa{};
   for (int p = 0; p < n_post; ++p) {
