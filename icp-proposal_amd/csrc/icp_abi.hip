@@ -271,6 +271,7 @@ struct icp_ctx {
   // every eigen-decomposition of the context runs on this stream, beside the chain (launch order = execution order, so the
   // decompositions of one proposal never overlap each other; the two directions of a step share ONE launch)
   hipStream_t eig_stream = nullptr;
+  hipStream_t eig_stream2 = nullptr;  // ranks above 64: decompositions started ahead alternate between the two (each with a work buffer of its own)
   hipStream_t eig_last = nullptr;  // where this context's latest decompositions were launched: eig_stream, or the eigen stream
                                    // of the first context of a batch (see eigen_stream_for)
   hipEvent_t ev_ready = nullptr;                 // stream -> eig_stream: "M is complete"
@@ -643,6 +644,10 @@ struct icp_proposal {
   void alloc_entry(PosteriorEntry& e);
   void prepare_eigen(PosteriorEntry& e, EigenRequest* rq);
   void ensure_eigen(PosteriorEntry& e);  // enqueue on the context's eigen stream (no-op if done or in flight)
+  // … or on `es` (eig_stream / eig_stream2) with that stream's work buffer; the caller has made `es` wait for the entry's M
+  void ensure_eigen_on(PosteriorEntry& e, hipStream_t es);
+  DBuf<double> work2;  // eig_stream2's (ranks above 64)
+  unsigned eig_flip = 0;
   void await_eigen(PosteriorEntry& e);   // make the context stream wait for it
   void check_status(PosteriorEntry& e);
 };
@@ -899,6 +904,7 @@ void sync_eigen(icp_ctx& c) {
     if (g_eig_streams.count(c.eig_last)) HIP_OK(hipStreamSynchronize(c.eig_last));
   }
   HIP_OK(hipStreamSynchronize(c.eig_stream));
+  if (c.eig_stream2) HIP_OK(hipStreamSynchronize(c.eig_stream2));
 }
 // the stream the next decompositions of this context go to (see g_eig_streams)
 hipStream_t eigen_stream_for(icp_ctx& c, hipStream_t want) {
@@ -919,6 +925,22 @@ void icp_proposal::ensure_eigen(PosteriorEntry& e) {
     e.done_value = 0;
     launch_posterior_eigen(es, c.r, rq.M, c.sqrt_lambda.p, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.work, rq.status, nullptr, rq.host_status);
   }
+  HIP_OK(hipEventRecord(e.eig_done, es));
+  e.eig_done_shared = nullptr;
+  e.eig_event_valid = true;
+}
+
+void icp_proposal::ensure_eigen_on(PosteriorEntry& e, hipStream_t es) {
+  if (e.eig_valid) return;
+  icp_ctx& c = *ctx;
+  EigenRequest rq;
+  prepare_eigen(e, &rq);
+  if (es == c.eig_stream2) {
+    if (!work2.p) { work2.alloc(eigen_work_doubles(c.r)); work2.fill_bytes(0); }
+    rq.work = work2.p;
+  }
+  e.done_value = 0;
+  launch_posterior_eigen(es, c.r, rq.M, c.sqrt_lambda.p, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.work, rq.status, nullptr, rq.host_status);
   HIP_OK(hipEventRecord(e.eig_done, es));
   e.eig_done_shared = nullptr;
   e.eig_event_valid = true;
@@ -1331,6 +1353,10 @@ void icp_ctx_destroy(icp_ctx* ctx) {
       (void)hipStreamDestroy(bs);
       bs = nullptr;
     }
+  if (ctx->eig_stream2) {
+    (void)hipStreamSynchronize(ctx->eig_stream2);
+    (void)hipStreamDestroy(ctx->eig_stream2);
+  }
   if (ctx->eig_stream) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     g_eig_streams.erase(ctx->eig_stream);
@@ -2017,9 +2043,15 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
       e->acc_ema = 0.9 * e->acc_ema + (accepted ? 0.1 : 0.0);
     }
     const int spec_mode = speculation_mode();
-    const bool spec_big = r > 64 && shape_only && n_props == 1 && need_eval && !c.speculation_off &&
-                          (spec_mode == 1 || (spec_mode == 2 && e->acc_ema >= 0.1));
-    if (need_eval && !spec_big) {
+    const bool spec_ok = r > 64 && n_props == 1 && need_eval && !c.speculation_off &&
+                         (spec_mode == 1 || (spec_mode == 2 && e->acc_ema >= 0.1));
+    const bool spec_big = spec_ok && shape_only;
+    // a pose move changes the state too: if it is kept, the next ICP proposal draws from the posterior at the NEW state — which
+    // nothing on this path computes (the transition probabilities across a pose change are zero).  Started here, ahead, it is
+    // done or under way by then: search (the evaluator's own, for a model-sampling proposal), regression, factorisation and
+    // decomposition, all beside the evaluator.
+    const bool spec_pose = spec_ok && !shape_only;
+    if (need_eval && !spec_big && !spec_pose) {
       StateSlot& s = c.state(theta_prop);
       enqueue_eval(e, s, 0);
     }
@@ -2030,7 +2062,36 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
     // (… and so do the one-workgroup factorisations and the tails: they go to a stream of their own, behind the regression; the
     // decomposition follows them on the eigen stream; this stream goes on with the searches and waits for the tails before the
     // results are copied)
-    const hipStream_t side = spec_big ? c.front_stream : nullptr;  // (the merged step's second stream: idle on this path)
+    const hipStream_t side = spec_big || spec_pose ? c.front_stream : nullptr;  // (the merged step's second stream: idle on this path)
+    // the decomposition of a posterior whose factorisation has just gone to the side stream: behind that — or, if the posterior was
+    // computed just now, beside it: M = I + the summed partials is written by a launch at the head of the decomposition as well
+    // (the same values the factorisation's assembly writes)
+    auto decompose_ahead = [&](icp_proposal* p, PosteriorEntry& en) {
+      if (en.eig_valid) return;
+      if (c.eig_last && c.eig_last != c.eig_stream) (void)eigen_stream_for(c, c.eig_stream);  // (a batch's stream was in use: drained)
+      c.eig_last = c.eig_stream;
+      if (!c.eig_stream2) {  // (created on first use: a stream costs a few MB of the runtime's own memory, see the memory test)
+        int prio_least = 0, prio_greatest = 0;
+        HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIP_OK(hipStreamCreateWithPriority(&c.eig_stream2, hipStreamNonBlocking, prio_greatest));
+      }
+      const hipStream_t es = (p->eig_flip++ & 1) ? c.eig_stream2 : c.eig_stream;  // two under way at a time
+      HIP_OK(hipEventRecord(c.ev_ready, c.stream));  // (whatever of this entry is still in flight on the context stream)
+      HIP_OK(hipStreamWaitEvent(es, c.ev_ready, 0));
+      if (p->side_parts && p->side_parts_entry == &en) {
+        HIP_OK(hipStreamWaitEvent(es, c.ev_sum, 0));
+        launch_assemble_posterior_matrix(es, r, p->side_parts, en.M.p);
+        HIP_OK(hipEventRecord(c.ev_asm, es));
+        p->side_asm_pending = true;
+      } else {
+        HIP_OK(hipStreamWaitEvent(es, c.ev_side, 0));
+      }
+      p->ensure_eigen_on(en, es);
+    };
+    if (spec_pose) {
+      PosteriorEntry& en = props[0]->posterior(theta_prop, false, side);
+      decompose_ahead(props[0], en);
+    }
     if (shape_only && n_props > 0) {
       const double* d_cur = c.stage(theta_cur + 10, r);
       const double* d_prop = c.stage(theta_prop + 10, r);
@@ -2055,24 +2116,10 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
       if (side) {
         HIP_OK(hipEventRecord(c.ev_side, side));
         props[0]->side_factor_pending = false;  // (this stream waits for ev_side below)
-        if (!ep[0]->eig_valid) {
-          // the decomposition of the proposed state: behind its factorisation — or, if its posterior was computed just now,
-          // beside it: M = I + the summed partials is written by a launch at the head of the decomposition as well (the same
-          // values the factorisation's assembly writes)
-          const hipStream_t es = eigen_stream_for(c, c.eig_stream);
-          if (props[0]->side_parts && props[0]->side_parts_entry == ep[0]) {
-            HIP_OK(hipStreamWaitEvent(es, c.ev_sum, 0));
-            launch_assemble_posterior_matrix(es, r, props[0]->side_parts, ep[0]->M.p);
-            HIP_OK(hipEventRecord(c.ev_asm, es));
-            props[0]->side_asm_pending = true;
-          } else {
-            HIP_OK(hipStreamWaitEvent(es, c.ev_side, 0));
-          }
-          props[0]->ensure_eigen(*ep[0]);
-        }
+        decompose_ahead(props[0], *ep[0]);
       }
     }
-    if (need_eval && spec_big) {
+    if (need_eval && (spec_big || spec_pose)) {
       StateSlot& s = c.state(theta_prop);
       enqueue_eval(e, s, 0);
     }
