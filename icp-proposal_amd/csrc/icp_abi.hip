@@ -1199,6 +1199,9 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     HIP_OK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest));
     HIP_OK(hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest));
     HIP_OK(hipStreamCreateWithPriority(&ctx->eig_stream, hipStreamNonBlocking, prio_greatest));
+    // (ranks above 64 only: a stream costs a few MB of the runtime's own memory; created HERE, next to its sibling, and not on first
+    // use: the runtime maps streams to its hardware queues in creation order, and a latecomer shared one with the context stream)
+    if (ctx->r > 64) HIP_OK(hipStreamCreateWithPriority(&ctx->eig_stream2, hipStreamNonBlocking, prio_greatest));
     { std::lock_guard<std::mutex> lk(g_eig_streams_mu); g_eig_streams.insert(ctx->eig_stream); }
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
@@ -2070,12 +2073,7 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
       if (en.eig_valid) return;
       if (c.eig_last && c.eig_last != c.eig_stream) (void)eigen_stream_for(c, c.eig_stream);  // (a batch's stream was in use: drained)
       c.eig_last = c.eig_stream;
-      if (!c.eig_stream2) {  // (created on first use: a stream costs a few MB of the runtime's own memory, see the memory test)
-        int prio_least = 0, prio_greatest = 0;
-        HIP_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        HIP_OK(hipStreamCreateWithPriority(&c.eig_stream2, hipStreamNonBlocking, prio_greatest));
-      }
-      const hipStream_t es = (p->eig_flip++ & 1) ? c.eig_stream2 : c.eig_stream;  // two under way at a time
+      const hipStream_t es = (c.eig_stream2 && (p->eig_flip++ & 1)) ? c.eig_stream2 : c.eig_stream;  // two under way at a time
       HIP_OK(hipEventRecord(c.ev_ready, c.stream));  // (whatever of this entry is still in flight on the context stream)
       HIP_OK(hipStreamWaitEvent(es, c.ev_ready, 0));
       if (p->side_parts && p->side_parts_entry == &en) {
