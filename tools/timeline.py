@@ -9,7 +9,8 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 120
 def short(name):
     for k in ("k_step_begin", "k_step_filter", "k_step_resolve", "k_step_regression", "k_step_finish", "k_posterior_eigen_rr", "k_posterior_eigen"):
         if k in name: return k
-    return name.split("(")[0][-40:]
+    name = name.replace("icp::(anonymous namespace)::", "").replace("icp::tri::", "tri::").replace("icp::", "").replace("void ", "")
+    return name.split("(")[0][:40]
 t0 = int(rows[first]["Start_Timestamp"])
 for r in rows[first:first + n]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
