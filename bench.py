@@ -174,7 +174,10 @@ def kernel_algorithmic_bytes(name, model, target, setup):
         return sum((Km if p["direction"] == 0 else Kt) * (3 * r * 8 + 56) + splits(Km if p["direction"] == 0 else Kt) * n1 * 8 * 0.625 for p in setup.icp)
     if name == "k_step_finish":      # partials in (lower triangle), M out, M + G^-1 for the two tails of every posterior
         return sum(splits(Km if p["direction"] == 0 else Kt) * n1 * 8 * 0.5 + r * r * 8 * 2 for p in setup.icp) + 2 * r * r * 8
-    if name.startswith("k_posterior_eigen"):  # per launch (both directions): M, warm basis in, V, Vt, S out, rotation log out and in
+    if name.startswith("k_posterior_eigen"):
+        if r > 64:  # the tridiagonal route, one posterior per launch sequence: M in, reflectors out and in, V and Vt out (+ S)
+            return r * r * 8 * 5 + r * 8
+        # ranks <= 64, per launch (both directions): M, warm basis in, V, Vt, S out, rotation log out and in
         return dirs * (r * r * 8 * 4 + 3 * 51 * (r + 1) * 8 * 2)
     if name == "k_surface_filter":
         return 3 * M * 8 + 3 * Tt * 4 + Ksurf * 24

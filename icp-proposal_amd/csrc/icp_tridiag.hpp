@@ -131,7 +131,11 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
   const int n = a.n, off = LD - n;
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* vb = lds + L::oPriv + w * 3 * LD;  // vb[par·LD + i]: x of step k (v once its entry k+1 is fixed), k & 1 = par
+  // With eight waves (two per SIMD) the chain of scalars and lane vectors of a step — the same in every wave — would be paid twice per
+  // SIMD: there ONE wave carries it (LEAD), the others wait at a barrier and take v, w, x' from one shared copy in LDS.
+  constexpr bool LEAD = NW == 8;
+  const bool lead = !LEAD || w == 0;
+  double* vb = lds + L::oPriv + (LEAD ? 0 : w * 3 * LD);  // vb[par·LD + i]: x of step k (v once its entry k+1 is fixed), k & 1 = par
   double* wb = vb + 2 * LD;
 
 #ifdef ICP_TRI_CYCLES
@@ -140,7 +144,7 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
   // Per step the lane-form vectors (one row slot per lane) are: x, the column eliminated now (rows > k); v; w; x', the next column.
   // They stay in registers from one step to the next — except in the largest configuration (SI = 4: no registers to spare),
   // where they live in the wave-private LDS arrays vb (x / x' by step parity) and wb.
-  constexpr bool VLDS = SI >= 4;
+  constexpr bool VLDS = LEAD || SI >= 4;
   double xs[SI];    // x (registers form)
   double x0, sig2;  // its first entry x_{k+1}; Σ_{i>k+1} x_i²
   // ---- the pass over the registers: optional rank-2 update, then acc = A·x'; publishes the partial sums, this wave's part of
@@ -175,8 +179,16 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
           const int t = c0 + q < NT ? c0 + q : NT - 1;
           const int sj = (NW * (t + TOFF)) >> 6;  // where column j = w + NW·(t + TOFF) sits as a row (constants once unrolled)
           const int lj = ((NW * (t + TOFF)) & 63) + w;
-          xj[q] = readlane_f64(xl[sj], lj);
-          if constexpr (UPD) { vj[q] = readlane_f64(vs[sj], lj); wj[q] = readlane_f64(ws[sj], lj); }
+          if constexpr (VLDS && SI <= 3) {  // (SI = 4: no registers for the fetched values — the v_readlane results live in SGPRs)
+            // (the vectors are in LDS anyway: broadcast reads — 4 cycles of the CU's LDS pipe each — beside the multiply-adds,
+            // which are what the SIMDs are short of with two waves each; the other wave covers the latency)
+            const int j = w + NW * (t + TOFF);
+            xj[q] = vb[xpar * LD + j];
+            if constexpr (UPD) { vj[q] = vb[vpar * LD + j]; wj[q] = wb[j]; }
+          } else {
+            xj[q] = readlane_f64(xl[sj], lj);
+            if constexpr (UPD) { vj[q] = readlane_f64(vs[sj], lj); wj[q] = readlane_f64(ws[sj], lj); }
+          }
         }
 #pragma unroll
         for (int q = 0; q < CH; ++q) {
@@ -232,10 +244,10 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
       const int i = l + 64 * s;
       const double cb = col0[s];
       xs[s] = i > off ? cb : 0.0;
-      if constexpr (VLDS) vb[(off & 1) * LD + i] = xs[s];
+      if constexpr (VLDS) { if (lead) vb[(off & 1) * LD + i] = xs[s]; }
       loc = i > off + 1 ? fma(cb, cb, loc) : loc;
     }
-    if constexpr (VLDS) wave_lds_sync();
+    if constexpr (LEAD) lds_barrier(); else if constexpr (VLDS) wave_lds_sync();
     if (w == 0 && l == 0) a.d[0] = d0;
     {
       double t = xs[0];
@@ -258,7 +270,7 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
 #endif
       // ---- the reflector of column k: alpha = ∓‖x‖, v = x − alpha e_{k+1}, beta = 2/vᵀv
       double alpha = x0, beta = 0.0;
-      if (sig2 != 0.0) {
+      if (lead && sig2 != 0.0) {
         const double s2 = fma(x0, x0, sig2);
         const double nrm = fast_sqrt(s2);
         alpha = x0 >= 0.0 ? -nrm : nrm;
@@ -283,6 +295,10 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
         }
         lds_barrier();
       }
+      double vs[SI], ws[SI], xnew[SI];
+#pragma unroll
+      for (int s = 0; s < SI; ++s) { vs[s] = 0.0; ws[s] = 0.0; xnew[s] = 0.0; }
+      if (lead) {
       double Axk1;
       if constexpr (TWO) {
         Axk1 = psum[k1];
@@ -314,14 +330,12 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
       const double K = 0.5 * beta * beta * vAv;
       const double wk1 = fma(-K, vk1, beta * fma(-alpha, ck1, Axk1));
       TRI_CYC(2);
-      const bool keeper = w == (k & (NW - 1));  // the wave that files this step's reflector
+      const bool keeper = LEAD || w == (k & (NW - 1));  // the wave that files this step's reflector
       double* hv = a.Hv + (size_t)(k - off) * LD;
-      double vs[SI], ws[SI], xnew[SI];
       double loc = 0.0;
 #pragma unroll
       for (int s = 0; s < SI; ++s) {
         const int i = l + 64 * s;
-        vs[s] = 0.0; ws[s] = 0.0; xnew[s] = 0.0;
         if (s < S0) {
           if (keeper) hv[i] = 0.0;
           continue;
@@ -360,7 +374,7 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
         a.e[k - off] = alpha;
         a.d[k1 - off] = fma(-vk1, wk1, fma(-wk1, vk1, ck1));
       }
-      if constexpr (VLDS) wave_lds_sync();
+      if constexpr (VLDS && !LEAD) wave_lds_sync();
       TRI_CYC(3);
       {
         double t = xnew[S0];
@@ -369,6 +383,8 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
         x0 = readlane_f64(t, (k1 + 1) & 63);
       }
       sig2 = wave_sum(loc);
+      }  // lead
+      if constexpr (LEAD) lds_barrier();  // v, w, x' of this step are in LDS
       TRI_CYC(4);
       pass(s0tag, Tag<1>{}, par, par ^ 1, k1 + 1, k, vs, ws, xnew);
 #pragma unroll
