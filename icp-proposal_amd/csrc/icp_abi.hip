@@ -775,6 +775,12 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipS
   icp_ctx& c = *ctx;
   const int r = c.r;
   const size_t P = 10 + (size_t)r;
+  if (side_factor_pending) {
+    // a factorisation that went to the side stream ahead of its use (icp_chain_eval_step, pose moves) may still be writing the M and
+    // alpha of an entry this call hands out — and it reads the partials and the factor scratch a new posterior would overwrite
+    HIP_OK(hipStreamWaitEvent(c.stream, c.ev_side, 0));
+    side_factor_pending = false;
+  }
   if (PosteriorEntry* hit = find_entry(theta)) {
     PosteriorEntry& e = *hit;
     e.stamp = ++clock;
