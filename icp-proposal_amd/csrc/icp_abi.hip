@@ -2701,6 +2701,12 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       EigenSpec specs[2];
       EigenRequest rqs[2];
       for (int i = 0; i < n_props; ++i) props[i]->speculate_eigen(*ep[i], *ec[i], F.splits[i], F.mpart_half[i], c.d_done.p + 2, step_seq + starve, &specs[i], &rqs[i]);
+      // (developer switch: the tridiagonal route for these decompositions while the running acceptance rate is above a threshold —
+      // its time does not depend on how far the chain has moved, the warm-started iteration's does (124 µs on average over a chain's
+      // first steps against 84 in the steady state); measured: 7.2k against 8.7k it/s over the first 20 steps — from input to
+      // completion word the two launches take ≈ 110 µs, the iteration with its replay beside it ≈ 100 even at four sweeps.)
+      static const double direct_above = dev_env("ICP_DIRECT_ABOVE") ? std::atof(dev_env("ICP_DIRECT_ABOVE")) : 2.0;
+      for (int i = 0; i < n_props; ++i) rqs[i].direct = e->acc_ema >= direct_above;
       const hipStream_t es = eigen_stream_for(c, c.eig_stream);
       launch_posterior_eigen_pair(es, r, c.sqrt_lambda.p, n_props, rqs);  // (no event: completion words, see start_decompositions)
     }

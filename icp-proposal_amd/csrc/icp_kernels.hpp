@@ -215,7 +215,9 @@ bool eigen_speculation_supported(int r);
 // gave up — so that a consumer on another stream can wait for one of the two without waiting for the whole launch
 struct EigenRequest { const double* M; const double* Vwarm; double* V; double* Vt; double* S; double* work; int* status;
                       const EigenSpec* spec; int* host_status; int* done_word; int done_value;
-                      const double* sqrt_lambda = nullptr; /* of the request's own model; launch_posterior_eigen_many needs it */ };
+                      const double* sqrt_lambda = nullptr; /* of the request's own model; launch_posterior_eigen_many needs it */
+                      bool direct = false; /* launch_posterior_eigen_pair: take the tridiagonal route (state-independent time) instead of
+                      the warm-started iteration — worth it while the chain moves fast (burn-in: the iteration needs 4 sweeps) */ };
 bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq);
 // any number of decompositions of one rank (the chains of icp_chain_step_batched) in as few launches as the kernel argument
 // segment allows (24 each); every request carries its model's sqrt_lambda

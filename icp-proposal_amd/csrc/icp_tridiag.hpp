@@ -439,6 +439,115 @@ __global__ void __launch_bounds__(NW * 64) k_tridiag(TridiagIO a) {
   EIG_STAMP(1);
 }
 
+// Ranks <= 64, up to two decompositions per launch (one workgroup each), with the front end of a decomposition that was
+// enqueued ahead of its input (EigenSpec, see k_posterior_eigen_rr): wait on the device for the regression launch's word, give up
+// on cancellation or after 5 ms, sum the split-K partials.
+struct TriSmallProblem {
+  const double* M;            // r×r matrix — or, splits > 0, the partials: splits × (r+1)² row-major, lower triangle, identity not added
+  int splits;
+  const int* ready;           // (optional) device word raised to ready_seq or beyond when the partials are complete
+  int ready_seq;
+  const int* cancel;          // (optional) pinned host word: give up once *cancel == seq
+  int seq;
+  const double* sqrt_lambda;
+  TridiagIO out;              // d, e, beta, Hv (M / sqrt_lambda unused here)
+  int* sync;                  // the solve launch's words: [2] = skip
+};
+struct TriSmallBatch { int r; TriSmallProblem p[2]; };
+
+__global__ void __launch_bounds__(256) k_tridiag_small(TriSmallBatch b) {
+  constexpr int NW = 4, SI = 1, NT = 16;
+  __shared__ double lds[TridiagLds<NW, SI>::doubles];
+  __shared__ int s_cancel;
+  const TriSmallProblem& pb = b.p[blockIdx.x];
+  const int n = b.r, off = 64 - n;
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) s_cancel = 0;
+  __syncthreads();
+  const bool is_poll = pb.cancel != nullptr && tid == 255;
+  if (tid == 255) {
+    if (pb.ready) {
+      const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+      for (;;) {
+        if (__hip_atomic_load(pb.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - pb.ready_seq >= 0) break;
+        if (pb.cancel && __hip_atomic_load(pb.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == pb.seq) { s_cancel = 1; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 500000) { s_cancel = 2; break; }
+        __builtin_amdgcn_s_sleep(32);
+      }
+    } else if (pb.cancel) {
+      if (__hip_atomic_load(pb.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == pb.seq) s_cancel = 1;
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (acquire side for the plain loads of the partials below)
+  if (s_cancel) {
+    if (tid == 0) __hip_atomic_store(pb.sync + 2, s_cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // ---- the matrix into registers: lane l holds row l − off, wave w columns w + 4t − off
+  const double* __restrict__ sl = pb.sqrt_lambda;
+  double A[SI][NT], col0[SI];
+  const int i = l - off;
+  double d0;
+  if (pb.splits > 0) {
+    // Σ over the splits in split order from 0.0, like the factorisation; four splits × seventeen entries in flight
+    const size_t nn = (size_t)(n + 1) * (n + 1);
+    size_t offs[NT + 1];
+    bool live[NT + 1];
+#pragma unroll
+    for (int t = 0; t <= NT; ++t) {
+      const int j = t < NT ? w + NW * t - off : 0;  // (slot NT: column 0, for the first reflector)
+      live[t] = i >= 0 && j >= 0;
+      const int hi = max(i, j), lo = min(i, j);
+      offs[t] = live[t] ? (size_t)hi * (n + 1) + lo : 0;
+    }
+    double acc[NT + 1];
+#pragma unroll
+    for (int t = 0; t <= NT; ++t) acc[t] = 0.0;
+    for (int sp = 0; sp < pb.splits; sp += 4) {
+      double q[4][NT + 1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* src = pb.M + (size_t)min(sp + u, pb.splits - 1) * nn;
+#pragma unroll
+        for (int t = 0; t <= NT; ++t) q[u][t] = src[offs[t]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (sp + u < pb.splits) {
+#pragma unroll
+          for (int t = 0; t <= NT; ++t) acc[t] += q[u][t];
+        }
+    }
+    const double sli = i >= 0 ? sl[i] : 1.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = w + NW * t - off;
+      A[0][t] = live[t] ? (acc[t] + (i == j ? 1.0 : 0.0)) / (sli * sl[j]) : 0.0;
+    }
+    col0[0] = live[NT] ? (acc[NT] + (i == 0 ? 1.0 : 0.0)) / (sli * sl[0]) : 0.0;
+    d0 = readlane_f64(col0[0], off);  // (N_00: lane off of every wave holds row 0)
+  } else {
+    auto entry = [&](int ii, int jj) { return 0.5 * (pb.M[(size_t)jj * n + ii] + pb.M[(size_t)ii * n + jj]) / (sl[ii] * sl[jj]); };
+    col0[0] = i >= 0 ? entry(i, 0) : 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = w + NW * t - off;
+      A[0][t] = i >= 0 && j >= 0 ? entry(i, j) : 0.0;
+    }
+    d0 = entry(0, 0);
+  }
+  TridiagIO a = pb.out;
+  a.n = n;
+  EIG_STAMP(0);
+  tridiagonalise<NW, SI, NT, 0>(a, A, col0, d0, lds);
+  EIG_STAMP(1);
+  // cancelled meanwhile? (the solve launch then only tidies up)
+  if (is_poll && __hip_atomic_load(pb.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == pb.seq)
+    __hip_atomic_store(pb.sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // One wave per eigenpair.
 struct TriSolveIO {
@@ -451,8 +560,12 @@ struct TriSolveIO {
   double* Vt;         // n×n: row `rank`
   double* S;          // [n] = 1/mu, descending
   double* mu;         // [n] scratch: the eigenvalues, ascending (the last wave checks the gaps)
-  int* sync;          // [2] {waves finished, trouble flags}: zero between launches
+  int* sync;          // [3] {waves finished, trouble flags, skip: 1 = cancelled, 2 = its input never came}: zero between launches
   int* status;        // status[0]: 0 ok, 2 = not trustworthy (gaps below resolution / non-finite); status[-1]: 0
+  // (ranks <= 64, where nothing follows this launch) published by the last wave:
+  int* host_status;   // pinned copy of the status (kEigenGaveUp for skip = 2)
+  int* done_word;     // set to done_value when the outputs are complete — or the decomposition was dropped
+  int done_value;
 };
 
 constexpr int kTriPasses = 5;       // multisection passes of 64 points: the bracket shrinks 65× per pass
@@ -464,7 +577,27 @@ constexpr int kTriMaxN = 256;
 __device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const double* __restrict__ e2, int n, double x) {
   double p0 = 1.0, p1 = ds[0] - x;
   int cnt = (unsigned)__double2hiint(p1) >> 31;
-  for (int i0 = 1; i0 < n; i0 += 8) {  // eight rows' coefficients fetched together: the recurrence itself is one dependent fma per row
+  // eight rows' coefficients fetched together: the recurrence itself is one dependent fma per row.  Whole groups of eight run
+  // without a test per row (a taken branch costs more than the row); the remainder is one guarded group.
+  // (An exact zero needs no care: by its sign bit it counts as positive, and its successor −e²·p0 has the sign opposite to its
+  // predecessor's — one change across the three, whichever way round.)
+  int i0 = 1;
+  for (; i0 + 8 <= n; i0 += 8) {
+    double dd[8], ee[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { dd[u] = ds[i0 + u] - x; ee[u] = e2[i0 + u - 1]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double p2 = fma(dd[u], p1, -(ee[u] * p0));
+      cnt += (unsigned)(__double2hiint(p2) ^ __double2hiint(p1)) >> 31;
+      p0 = p1;
+      p1 = p2;
+    }
+    const int ex = max(__builtin_amdgcn_frexp_exp(p0), __builtin_amdgcn_frexp_exp(p1));
+    p0 = ldexp(p0, -ex);
+    p1 = ldexp(p1, -ex);
+  }
+  if (i0 < n) {
     double dd[8], ee[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -475,23 +608,19 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (i0 + u < n) {
-        // (an exact zero needs no care: by its sign bit it counts as positive, and its successor −e²·p0 has the sign opposite
-        // to its predecessor's — one change across the three, whichever way round)
         const double p2 = fma(dd[u], p1, -(ee[u] * p0));
         cnt += (unsigned)(__double2hiint(p2) ^ __double2hiint(p1)) >> 31;
         p0 = p1;
         p1 = p2;
       }
     }
-    const int ex = max(__builtin_amdgcn_frexp_exp(p0), __builtin_amdgcn_frexp_exp(p1));
-    p0 = ldexp(p0, -ex);
-    p1 = ldexp(p1, -ex);
   }
   return cnt;
 }
 
 template <int SI>
-__global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
+__global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1) {
+  const TriSolveIO& a = blockIdx.y ? a1 : a0;  // (up to two decompositions side by side: the two ICP directions of a chain step)
   constexpr int LD = 64 * SI;
   const int off = LD - a.n;  // position of index 0 (see tridiagonalise)
   __shared__ double ds[kTriMaxN], es[kTriMaxN], e2[kTriMaxN], bet[kTriMaxN];
@@ -502,6 +631,23 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = blockIdx.x * 4 + w;  // this wave's eigenvalue (ascending), rank j of the output
   TRI_STAMP(8);
+  // a decomposition that was cancelled or never got its input (the reduction launch says so): nothing is computed, the waves only
+  // count themselves in, the last one tidies up
+  const int skip = __hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (skip) {
+    if (j >= a.n) return;
+    int last = 0;
+    if (l == 0) last = atomicAdd(a.sync, 1) == a.n - 1;
+    if (last) {
+      a.sync[0] = 0; a.sync[1] = 0; a.sync[2] = 0;
+      if (skip == 2) {  // timed out: tell the host, and mark the basis that was never written so that nothing starts from it
+        if (a.host_status) __hip_atomic_store(a.host_status, 3 /* kEigenGaveUp */, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        a.V[0] = __builtin_nan("");
+      }
+      if (a.done_word) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   // ---- the matrix, scaled to norm <= 1 (Gershgorin)
   double glo = 1e300, ghi = -1e300;
   for (int i = tid; i < n; i += 256) {
@@ -557,17 +703,25 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
       const int st = dir ? -1 : 1;
       double D = ds[i] - lam;
       Dq[dir * n + i] = D;
-      double ee = es[dir ? i - 1 : i], dn = ds[i + st] - lam;  // the next step's coefficients are fetched a step ahead
-      for (int k = 0; k < n - 1; ++k) {
+      double ee = es[dir ? i - 1 : i], dnr = ds[i + st];  // the next step's coefficients are fetched a step ahead (used, raw, a step later:
+      for (int k = 0; k < n - 1; ++k) {                    // nothing waits for the fetch where it is issued)
+        const double dn = dnr - lam;
         const int ie = dir ? i - 1 : i;
-        D = copysign(fmax(fabs(D), 1e-150), D);
-        const double L = ee * fast_rcp(D);
+        // (no guard against a vanishing pivot in the chain: an exact zero turns the vector into NaNs, which the norm test below
+        // reports; the reciprocal is the hardware seed and one Newton step — 1e-15, and λ is corrected afterwards anyway)
+        double y = __builtin_amdgcn_rcp(D);
+        y = fma(y, fma(-D, y, 1.0), y);
+        const double L = ee * y;
         const double Dn = fma(-L, ee, dn);
         i += st;
-        if (k + 1 < n - 1) { ee = es[dir ? i - 1 : i]; dn = ds[i + st] - lam; }
+        // (fetched unconditionally: past the ends the arrays are padded, and nothing uses what comes back)
+        const int inext = max(min(i + st, n - 1), 0), ienext = max(dir ? i - 1 : i, 0);
+        const double ee_next = es[ienext];
+        dnr = ds[inext];
         Lq[dir * n + ie] = L;
         Dq[dir * n + i] = Dn;
         D = Dn;
+        ee = ee_next;
       }
     }
     wave_lds_sync();
@@ -707,6 +861,8 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a) {
     a.status[-1] = 0;
     a.sync[0] = 0;
     a.sync[1] = 0;
+    if (a.host_status) __hip_atomic_store(a.host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.done_word) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

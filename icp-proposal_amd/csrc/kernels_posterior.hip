@@ -1977,20 +1977,20 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   const size_t rr = (size_t)r * r;
   double *Nm = work, *X = work + rr, *Xt = work + 2 * rr, *T = work + 3 * rr, *Sm = work + 4 * rr, *R = work + 5 * rr;
   tri::TridiagIO ti{r, M, sqrt_lambda, d, e, beta, Hv, Nm};
-  tri::TriSolveIO so{r, d, e, beta, Hv, X, Xt, S, mu, sync, status};
+  tri::TriSolveIO so{r, d, e, beta, Hv, X, Xt, S, mu, sync, status, nullptr, nullptr, 0};
   const int nwg = (r + 3) / 4;
   if (r <= 64) {
     hipLaunchKernelGGL((tri::k_tridiag<4, 1, 16, 0>), dim3(1), dim3(256), 0, st, ti);
-    hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), 0, st, so);
+    hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), 0, st, so, so);
   } else if (r <= 128) {
     hipLaunchKernelGGL((tri::k_tridiag<4, 2, 32, 0>), dim3(1), dim3(256), 0, st, ti);
-    hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), 0, st, so);
+    hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), 0, st, so, so);
   } else if (r <= 192) {
     hipLaunchKernelGGL((tri::k_tridiag<8, 3, 24, 0>), dim3(1), dim3(512), 0, st, ti);
-    hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg), dim3(256), 0, st, so);
+    hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg), dim3(256), 0, st, so, so);
   } else {
     hipLaunchKernelGGL((tri::k_tridiag<8, 4, 25, 7>), dim3(1), dim3(512), 0, st, ti);
-    hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), 0, st, so);
+    hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), 0, st, so, so);
   }
   // one refinement step: T = N·X and R = I − XᵀX, S = XᵀT, E, then V = X + X·E (and Vt)
   const int nt = (r + 15) / 16;
@@ -2103,10 +2103,51 @@ void launch_eigen_rr(hipStream_t st, int r, const double* sqrt_lambda, int n, co
 }
 }  // namespace
 
+// ranks <= 64 by the tridiagonal route: one launch reduces (a workgroup per decomposition, with the front end of a decomposition
+// enqueued ahead of its input), one solves (a wave per eigenpair); no refinement step (gaps at these ranks leave the vectors
+// orthogonal to 1e-13), completion words from the solve launch's last wave
+static void launch_eigen_tridiag_small(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq) {
+  tri::TriSmallBatch b{};
+  b.r = r;
+  tri::TriSolveIO so[2] = {};
+  for (int i = 0; i < n; ++i) {
+    double* base = rq[i].work + jacobi_work_doubles(r);
+    double *d = base, *e = base + tri::kTriMaxN, *beta = base + 2 * tri::kTriMaxN, *mu = base + 3 * tri::kTriMaxN;
+    int* sync = (int*)(base + 4 * tri::kTriMaxN);
+    double* Hv = base + 4 * tri::kTriMaxN + 8;
+    const EigenSpec* sp = rq[i].spec;
+    tri::TriSmallProblem& p = b.p[i];
+    p.M = rq[i].M;
+    p.splits = sp ? sp->splits : 0;
+    p.ready = sp ? sp->ready : nullptr;
+    p.ready_seq = sp ? sp->ready_seq : 0;
+    p.cancel = sp ? sp->cancel : nullptr;
+    p.seq = sp ? sp->seq : 0;
+    p.sqrt_lambda = rq[i].sqrt_lambda ? rq[i].sqrt_lambda : sqrt_lambda;
+    p.out = tri::TridiagIO{r, nullptr, nullptr, d, e, beta, Hv, nullptr};
+    p.sync = sync;
+    so[i] = tri::TriSolveIO{r, d, e, beta, Hv, rq[i].V, rq[i].Vt, rq[i].S, mu, sync, rq[i].status, rq[i].host_status, rq[i].done_word,
+                            rq[i].done_value};
+  }
+  if (n == 1) { b.p[1] = b.p[0]; so[1] = so[0]; }
+  ProfScope _ps(st, KID_EIGEN);
+  hipLaunchKernelGGL(tri::k_tridiag_small, dim3(n), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3((r + 3) / 4, n), dim3(256), 0, st, so[0], so[1]);
+}
+
 bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq) {
   static const bool force_generic = dev_env("ICP_EIGEN_GENERIC") != nullptr;
   if (!(r >= 3 && r <= 64 && !force_generic) || n < 1 || n > 2) return false;
-  launch_eigen_rr<2>(st, r, sqrt_lambda, n, rq);
+  // The direct route at these ranks is a measured alternative, not the default: from input to completion word its two
+  // launches take ≈ 110 µs whatever the state, the warm-started iteration ≈ 100 even at four sweeps (70 at two); and without the
+  // refinement step its eigenvectors of close eigenvalues are a little further from the oracle's than the iteration's (femur-50
+  // golden proposals: 1.4e-7 against a tolerance of 1.2e-7).  Requests ask for it (EigenRequest::direct) under developer switches only.
+  static const int forced = dev_env("ICP_EIGEN_TRIDIAG") ? std::atoi(dev_env("ICP_EIGEN_TRIDIAG")) : -1;
+  bool direct = false;
+  for (int i = 0; i < n; ++i) direct = direct || rq[i].direct;
+  if (forced >= 0) direct = forced != 0;
+  if (direct) launch_eigen_tridiag_small(st, r, sqrt_lambda, n, rq);
+  else launch_eigen_rr<2>(st, r, sqrt_lambda, n, rq);
   return true;
 }
 

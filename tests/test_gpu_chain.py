@@ -79,7 +79,9 @@ def test_femur100_all_points_symmetric_matches_oracle(pkg, oracle):
         assert rc == 0 and abs(val - lv) <= 1e-7 * abs(lv)        # the states differ by ~1e-13
         lf, lb = oracle.log_transition(om, ot, pp, theta, want), oracle.log_transition(om, ot, pp, want, theta)
         assert abs(fwd[0] - lf) <= 1e-6 * abs(lf) and abs(bwd[0] - lb) <= 1e-6 * abs(lb)
-        assert prop.logTransitionProbability(theta, got) == fwd[0] and ev.logValue(got) == val
+        # (the merged launch and the per-method kernel sum the tail's products over 1,024 and over 256 threads at this rank: the same
+        # value to the last bit or two, not always to the last)
+        assert abs(prop.logTransitionProbability(theta, got) - fwd[0]) <= 1e-13 * abs(fwd[0]) and ev.logValue(got) == val
     prop.close()
     ev.close()
     # ---- a short chain: identical decisions

@@ -102,6 +102,39 @@ int main(int argc, char** argv) {
   long long s[64]; hipMemcpyFromSymbol(s, HIP_SYMBOL(icp::g_eigen_stamps), sizeof(s));
   printf("%.1f us per decomposition (cold) | stamps: reduction %.1f | solve: setup %.1f multisection %.1f vectors %.1f back-transformation %.1f output %.1f\n", ms * 1000 / reps,
          (s[1] - s[0]) * 0.01, (s[9] - s[8]) * 0.01, (s[10] - s[9]) * 0.01, (s[11] - s[10]) * 0.01, (s[12] - s[11]) * 0.01, (s[13] - s[12]) * 0.01);
+  if (r <= 64) {  // the speculative form of the same decomposition: split-K partials, ready word raised, cancel word in pinned memory
+    const int n1 = r + 1, SP = 13;
+    std::vector<double> Mp((size_t)SP * n1 * n1, 0.0);
+    for (int sp = 0; sp < SP; ++sp)
+      for (int i = 0; i < r; ++i) for (int j = 0; j <= i; ++j) Mp[(size_t)sp * n1 * n1 + (size_t)i * n1 + j] = (M[(size_t)i * r + j] - (i == j ? 1.0 : 0.0)) / SP;
+    double* dMp; int *dready, *hcancel, *hstat, *ddone;
+    CK(hipMalloc(&dMp, 8 * Mp.size())); CK(hipMemcpy(dMp, Mp.data(), 8 * Mp.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&dready, 64)); CK(hipMemset(dready, 0x01, 64)); CK(hipMalloc(&ddone, 64)); CK(hipMemset(ddone, 0, 64));
+    CK(hipHostMalloc((void**)&hcancel, 64, hipHostMallocDefault)); CK(hipHostMalloc((void**)&hstat, 64, hipHostMallocDefault));
+    hcancel[0] = 0; hstat[0] = -1;
+    icp::EigenSpec spec{SP, hcancel, 7, dready, 1};
+    CK(hipMemset(dV, 0, 8 * r * r));
+    icp::EigenRequest rq{dMp, nullptr, dV, dVt, dS, dwork, dstat + 1, &spec, hstat, ddone, 41, dsl};
+    rq.direct = true;
+    icp::launch_posterior_eigen_pair(st, r, dsl, 1, &rq);
+    CK(hipStreamSynchronize(st));
+    std::vector<double> V2((size_t)r * r);
+    CK(hipMemcpy(V2.data(), dV, 8 * r * r, hipMemcpyDeviceToHost));
+    int done = 0; CK(hipMemcpy(&done, ddone, 4, hipMemcpyDeviceToHost));
+    double dv2 = 0;
+    for (size_t i = 0; i < V2.size(); ++i) dv2 = std::fmax(dv2, std::fabs(V2[i] - Vref[i]));
+    float ms2 = 0;
+    hipEventRecord(a, st);
+    for (int i = 0; i < reps; ++i) icp::launch_posterior_eigen_pair(st, r, dsl, 1, &rq);
+    hipEventRecord(b, st); hipEventSynchronize(b); hipEventElapsedTime(&ms2, a, b);
+    // cancelled before it starts: nothing written, the completion word still set
+    hcancel[0] = 7; CK(hipMemset(ddone, 0, 64)); rq.done_value = 42; CK(hipMemset(dV, 0, 8 * r * r));
+    icp::launch_posterior_eigen_pair(st, r, dsl, 1, &rq); CK(hipStreamSynchronize(st));
+    int done2 = 0; CK(hipMemcpy(&done2, ddone, 4, hipMemcpyDeviceToHost));
+    double v00 = 1; CK(hipMemcpy(&v00, dV, 8, hipMemcpyDeviceToHost));
+    printf("speculative form (13 partials): max|dV| %.3e vs host Jacobi, pinned status %d, completion word %d; %.1f us per decomposition | cancelled: completion word %d, V untouched %d\n",
+           dv2, hstat[0], done, ms2 * 1000 / reps, done2, v00 == 0.0);
+  }
   if (r >= 3) {
     const double st_ = r - 2;
     printf("reduction, shader cycles per step: reflector %.0f | barrier %.0f | scalars %.0f | rows + private LDS %.0f | norm %.0f | pass %.0f | publish + xAx %.0f | (tail %.0f)\n", s[16] / st_,
