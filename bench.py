@@ -194,7 +194,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[i] that fits one GPU per rank: 1 (metric configuration), 2, 3")
     ap.add_argument("--profile-steps", type=int, default=300, help="steps of the HIP-event roofline leg (0 = skip)")
-    ap.add_argument("--cpu-steps", type=int, default=16, help="steps of the B2 leg of the CPU baseline (B1 runs 4x as many; 0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=96, help="steps of the B2 leg of the CPU baseline (B1 runs 4x as many; 0 = skip)")
     ap.add_argument("--subdiv", type=int, default=6, help="edge subdivision of the synthetic femur target (6 -> 58,322 vertices)")
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="independent chains per GPU, stepped in lockstep through icp_chain_step_batched (default 1 = the BASELINE.json "
