@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=1,
                     help="independent chains per GPU, stepped in lockstep through icp_chain_step_batched (default 1 = the BASELINE.json "
                          "configuration; more is the RunMHRandomInitComparison-style many-chains job on fewer GPUs)")
-    ap.add_argument("--many-chains", type=int, default=32,
+    ap.add_argument("--many-chains", type=int, default=64,
                     help="extra leg after the timed region (1 GPU, 1 chain per GPU, config 1 only): aggregate rate of this many chains on the GPU "
                          "stepped through icp_chain_step_batched, reported as `many_chains` (0 = skip)")
     ap.add_argument("--fused", type=int, default=2, choices=[0, 1, 2],
