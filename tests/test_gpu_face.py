@@ -68,6 +68,34 @@ def test_small_face_evaluators_match_oracle(pkg, oracle, small, kind):
     ev.close()
 
 
+@pytest.mark.parametrize("rank", [100, 150, 193])
+def test_tridiagonal_route_configurations_match_oracle(pkg, oracle, rank):
+    """Ranks 65..200 are decomposed by Householder tridiagonalisation + multisection + twisted factorisation + one refinement step
+    (icp_tridiag.hpp), in one of three register layouts: up to 128 (four waves), up to 192 (eight waves, three row slots), up to 200
+    (four row slots, the first partly filled).  One posterior per layout against the oracle's Jacobi iteration (the full-size face
+    tests and the femur-100 tests cover ranks 200 and 101 in the chain)."""
+    model = pkg.data.synthetic_face_model(grid=41, rank=rank)
+    target = pkg.data.synthetic_partial_target(model, n_remove=90)
+    ctx = pkg.IcpContext(model, target, device=0)
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    pp = oracle.proposal_params(0.1, 6.0, 3.0, oracle.MODEL_SAMPLING, True, n_model_ids=2 * rank)
+    prop = pkg.NonRigidIcpProposal(ctx, 0.1, 6.0, 3.0, 2 * rank, "ModelSampling", True)
+    rng = np.random.default_rng(rank)
+    for seed in (5, 6):
+        theta = face_theta(model, seed)
+        post, po = prop.icpPosterior(theta), oracle.icp_posterior(om, ot, pp, theta)
+        assert np.array_equal(post.corr_id, po.corr_id) and np.array_equal(post.keep, po.keep)
+        assert np.abs(post.alpha - po.alpha).max() <= 1e-9 * np.abs(po.alpha).max()
+        assert np.abs(post.S - po.S).max() <= 1e-11 * np.abs(po.S).max()
+        assert np.abs(post.V.T @ post.V - np.eye(rank)).max() <= 1e-11
+        assert np.abs(post.V - po.V).max() <= 1e-8
+        z = rng.normal(size=rank)
+        got, want = prop.propose(theta, z), oracle.propose(om, ot, pp, theta, z)
+        assert np.abs(got - want).max() <= 1e-7 * np.abs(want[10:]).max()
+    prop.close()
+    ctx.close()
+
+
 def test_multiple_eigenvalues_take_the_jacobi_fall_back(pkg, oracle):
     """Ranks above 64 are decomposed by tridiagonalisation + multisection + twisted factorisation, which needs eigenvalues it can
     tell apart.  The stand-in's variances come in equal pairs (modes (p, q) and (q, p)): without correspondences — and with a
