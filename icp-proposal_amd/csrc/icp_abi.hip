@@ -941,10 +941,7 @@ void icp_proposal::ensure_eigen_on(PosteriorEntry& e, hipStream_t es) {
   icp_ctx& c = *ctx;
   EigenRequest rq;
   prepare_eigen(e, &rq);
-  if (es == c.eig_stream2) {
-    if (!work2.p) { work2.alloc(eigen_work_doubles(c.r)); work2.fill_bytes(0); }
-    rq.work = work2.p;
-  }
+  if (es == c.eig_stream2) rq.work = work2.p;  // (allocated and zeroed with the proposal: a memset issued here could land in the kernels)
   e.done_value = 0;
   launch_posterior_eigen(es, c.r, rq.M, c.sqrt_lambda.p, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.work, rq.status, nullptr, rq.host_status);
   HIP_OK(hipEventRecord(e.eig_done, es));
@@ -1638,6 +1635,10 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     p->prm.target_points = nullptr;  // caller memory is not retained
     p->work.alloc(eigen_work_doubles(ctx->r));
     p->work.fill_bytes(0);  // holds the completion counter of the eigenvector replay kernel
+    if (ctx->eig_stream2) {  // ranks above 64: the second eigen stream's work area
+      p->work2.alloc(eigen_work_doubles(ctx->r));
+      p->work2.fill_bytes(0);
+    }
     p->mpart_half_doubles = (size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1);
     p->Mpart.alloc(icp_proposal::kMpartRing * p->mpart_half_doubles);
     p->fscratch.alloc((size_t)(ctx->r + 1) * ctx->r + 8);

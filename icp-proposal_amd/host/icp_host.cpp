@@ -358,7 +358,9 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
 #else
     static const int forced = 0;  // (developer A/B switch: -DICP_DEV_SWITCHES)
 #endif
-    int n_groups = forced > 0 ? forced : (n_chains >= 24 ? 3 : n_chains >= 8 ? 2 : 1);  // (measured: tools/ab_batch.sh)
+    // (measured, tools/ab_groups64.sh: two groups from 8 chains to 64 — 16 chains: 70k against 56k it/s with one or three, 32: 108k against
+    // 90k with three, 64: 134k against 117k; beyond that groups of about 32: 96 chains 135k, 128 chains 142k with four)
+    int n_groups = forced > 0 ? forced : (n_chains > 80 ? (n_chains + 31) / 32 : n_chains >= 8 ? 2 : 1);
     n_groups = std::max(1, std::min(std::min(n_groups, kMaxGroups), n_chains));
     for (int b = 0; b < n_chains; ++b) groups[(size_t)b * n_groups / n_chains].chains.push_back(chains[b]);
     for (int g = 0; g < n_groups; ++g) groups[g].init();
