@@ -368,7 +368,10 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
     // other down more than the overlap gains (regression 18 -> 80 µs beside the other group's filter); the decompositions
     // keep their own streams
     for (int g = 1; g < n_groups; ++g) groups[g].launch_ctx = groups[0].chains[0]->ctx;
-    // steady state: every group has a submission in flight; they are collected and renewed in turn
+    // steady state: every group has a submission in flight; they are collected and renewed in turn.  (A host thread per group
+    // was tried — the kernel trace shows the launch stream idle a third of the time at 64 chains: sequences of 152 µs every 236 µs,
+    // the host needs ≈ 7 µs per chain and step — and measured slower at every size, 16 chains 58k against 71k it/s, 64 chains 126k
+    // against 129k: the threads' launches and their waits meet in the runtime.)
     if (n_steps > 0)
       for (int g = 0; g < n_groups; ++g) groups[g].issue();
     for (int s = 0; s < n_steps; ++s)

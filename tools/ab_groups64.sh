@@ -1,6 +1,6 @@
 #!/bin/bash
 # developer A/B: lockstep groups x chains per GPU (builds the host harness with its developer switches, restores it afterwards)
-cd icp-proposal_amd/host && g++ -O2 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -DICP_DEV_SWITCHES -shared -o ../libicp_host.so icp_host.cpp -L.. -licp_proposal_amd -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib && cd ../..
+cd icp-proposal_amd/host && g++ -O2 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -pthread -DICP_DEV_SWITCHES -shared -o ../libicp_host.so icp_host.cpp -L.. -licp_proposal_amd -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib && cd ../..
 for B in ${CHAINS:-32 48 96 128}; do
 for g in ${GROUPS_:-2 3 4}; do
   for k in 1 2; do
