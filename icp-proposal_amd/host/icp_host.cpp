@@ -6,6 +6,9 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "icp_host.hpp"
@@ -247,8 +250,57 @@ int icp_host_chain_run(icp_host_chain* ch, int32_t n_steps, double* records) {
 namespace {
 // A set of chains stepped in lockstep: per step ONE icp_chain_step_batched submission for all members whose proposal is an
 // ICP or a random-walk shape proposal, then every member's MetropolisHastings.next with the results parked for it.
+// The standard normals of the chains' NEXT step (posterior.sample(), 2·r uniforms, r logarithms, square roots and cosines per
+// chain: 2-3 µs of the ≈ 7 µs of host time a chain's step costs in a batch), drawn by a helper thread while the calling thread
+// submits and records: they depend on (seed, step) only.  The same StepRandom::normal calls: the same values.
+struct NormalsAhead {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool stop = false, pending = false;
+  std::atomic<bool> done{true};
+  int r = 0;
+  std::vector<uint64_t> seed, step;      // the job: per chain
+  std::vector<std::vector<double>> z;    // its result
+  std::vector<uint64_t> z_step;          // the step z[b] belongs to (~0: none)
+  void start(size_t B, int rank) {
+    r = rank;
+    seed.assign(B, 0); step.assign(B, 0); z.assign(B, std::vector<double>(rank)); z_step.assign(B, ~0ull);
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(mu);
+      for (;;) {
+        cv.wait(lk, [this] { return stop || pending; });
+        if (stop) return;
+        pending = false;
+        lk.unlock();
+        for (size_t b = 0; b < z.size(); ++b) {
+          const StepRandom rn{seed[b], step[b]};
+          for (int j = 0; j < r; ++j) z[b][j] = rn.normal(j);
+          z_step[b] = step[b];
+        }
+        done.store(true, std::memory_order_release);
+        lk.lock();
+      }
+    });
+  }
+  void request() {  // (seed / step filled in by the caller, who has seen done == true)
+    done.store(false, std::memory_order_relaxed);
+    { std::lock_guard<std::mutex> lk(mu); pending = true; }
+    cv.notify_one();
+  }
+  bool ready() const { return done.load(std::memory_order_acquire); }
+  ~NormalsAhead() {
+    if (th.joinable()) {
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      cv.notify_one();
+      th.join();
+    }
+  }
+};
+
 struct LockstepGroup {
   std::vector<icp_host_chain*> chains;
+  NormalsAhead ahead;
   size_t n_icp = 0;
   int r = 0;
   std::vector<StepRandom> rnd;
@@ -271,6 +323,12 @@ struct LockstepGroup {
     rnd.resize(B);
     z.assign(B, std::vector<double>(r));
     prop.assign(B, std::vector<double>(10 + r));
+#ifdef ICP_DEV_SWITCHES
+    static const bool no_ahead = std::getenv("ICP_NO_NORMALS_AHEAD") != nullptr;  // (developer A/B)
+#else
+    static const bool no_ahead = false;
+#endif
+    if (B >= 8 && n_icp > 0 && !no_ahead) ahead.start(B, r);
   }
   // the next step of every member: random numbers, proposal kind, arguments; submission of those that share launches
   void issue() {
@@ -284,7 +342,9 @@ struct LockstepGroup {
       if (auto* ip = dynamic_cast<NonRigidIcpProposal*>(leaf)) {
         if (ip->stepper) {
           g = ip->stepperIndex;
-          for (int j = 0; j < r; ++j) z[b][j] = rnd[b].normal(j);  // posterior.sample() (NonRigidIcpProposal.scala:55)
+          // posterior.sample() (NonRigidIcpProposal.scala:55): drawn ahead by the helper thread if it got that far
+          if (ahead.th.joinable() && ahead.ready() && ahead.z_step[b] == rnd[b].step) z[b] = ahead.z[b];
+          else for (int j = 0; j < r; ++j) z[b][j] = rnd[b].normal(j);
         }
       } else if (auto* rw = dynamic_cast<RandomShapeUpdateProposal*>(leaf)) {
         g = -1;
@@ -301,11 +361,18 @@ struct LockstepGroup {
     }
     const int nb = (int)member.size();
     ticket = nullptr;
-    if (nb == 0) return;
+    if (nb == 0) { draw_ahead(); return; }
     value.assign(nb, 0.0); fwd.assign((size_t)nb * n_icp + 1, 0.0); bwd.assign((size_t)nb * n_icp + 1, 0.0); status.assign(nb, 0);
     check(icp_chain_step_batched_issue(nb, ev.data(), (int)n_icp, props.data(), gen.data(), cur_p.data(), z_p.data(), prop_p.data(),
                                        value.data(), fwd.data(), bwd.data(), status.data(), launch_ctx, &ticket),
           "icp_chain_step_batched_issue");
+    draw_ahead();
+  }
+  // the normals of every member's next step, while this one is on the device
+  void draw_ahead() {
+    if (!ahead.th.joinable() || !ahead.ready()) return;
+    for (size_t b = 0; b < chains.size(); ++b) { ahead.seed[b] = chains[b]->seed; ahead.step[b] = (uint64_t)chains[b]->logger.index + 1; }
+    ahead.request();
   }
   // results of the submission in flight, then SamplingRegistration.scala:58-85 for every member
   void finish() {
