@@ -735,8 +735,16 @@ void check_theta_finite(const icp_ctx* ctx, const double* theta) {
 
 PosteriorEntry* icp_proposal::find_entry(const double* theta) {
   const size_t P = 10 + (size_t)ctx->r;
-  for (int i = 0; i < kPosteriorMemo; ++i)
-    if (memo[i].valid && std::memcmp(memo[i].theta.data(), theta, sizeof(double) * P) == 0) return &memo[i];
+  // (two states of a chain share their first ten numbers — the pose — more often than not: the last coefficient tells most entries
+  // apart before the comparison of the whole vector; compared as bits, like memcmp does)
+  uint64_t last;
+  std::memcpy(&last, theta + P - 1, sizeof last);
+  for (int i = 0; i < kPosteriorMemo; ++i) {
+    if (!memo[i].valid) continue;
+    uint64_t mine;
+    std::memcpy(&mine, memo[i].theta.data() + P - 1, sizeof mine);
+    if (mine == last && std::memcmp(memo[i].theta.data(), theta, sizeof(double) * P) == 0) return &memo[i];
+  }
   return nullptr;
 }
 
