@@ -274,3 +274,41 @@ def test_batch_registration_full_face_matches_oracle(pkg, oracle):
             ev.close(); prop.close(); ctx.close()
     finally:
         oracle.set_search_backend(oracle.SEARCH_BRUTE)
+
+
+_SCHEDULE_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import __graft_entry__ as graft
+pkg = graft.load_package()
+model = pkg.data.synthetic_face_model(grid=41, rank={rank})
+target = pkg.data.synthetic_partial_target(model, n_remove=90)
+setup = pkg.bfm_fitting_partial(model, target, evaluator={evaluator!r})
+ctx = pkg.IcpContext(model, target, device=0)
+chain = pkg.SamplingRegistration(ctx, setup, pkg.initial_parameters(model), 77)
+np.save({out!r}, chain.run({n_steps}))
+chain.close(); ctx.close()
+"""
+
+
+@pytest.mark.parametrize("rank,evaluator", [(72, "hausdorff"), (150, "collective")])
+def test_step_schedule_at_large_ranks_does_not_change_the_chain(rank, evaluator, tmp_path):
+    """Above rank 64 a chain step spreads over four streams (icp_chain_eval_step): factorisation and tails beside the evaluator's
+    searches, the proposed state's decomposition — and the posterior of a proposed pose move — started ahead, on two eigen streams.
+    With ICP_SPECULATION=0 the same step runs on one stream with nothing ahead.  Same seed, same records, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    recs = []
+    for spec in (None, "0"):
+        env = dict(os.environ)
+        env.pop("ICP_SPECULATION", None)
+        if spec is not None:
+            env["ICP_SPECULATION"] = spec
+        out = str(tmp_path / f"rec_{spec}.npy")
+        script = _SCHEDULE_SCRIPT.format(root=ROOT, rank=rank, evaluator=evaluator, out=out, n_steps=150)
+        subprocess.run([sys.executable, "-c", script], check=True, env=env, timeout=300)
+        recs.append(np.load(out))
+    a, b = recs
+    assert a[:, 1].sum() > 20 and np.array_equal(a, b)
