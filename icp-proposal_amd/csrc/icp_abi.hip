@@ -1043,7 +1043,7 @@ void enqueue_eval(icp_evaluator* ev, StateSlot& s, int base) {
     if (p.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE) {
       launch_sum_gauss_logpdf(c.stream, Km, s.surf_d2.p, p.gauss_mean, p.gauss_sigma, out + 0);  // IndependentPointDistanceEvaluator.scala:40-46
     } else if (p.kind == ICP_EVAL_HAUSDORFF) {
-      launch_dist_stats(c.stream, Km, s.surf_d2.p, nullptr, nullptr, 0, out + 0);
+      launch_dist_max(c.stream, Km, s.surf_d2.p, out + 1);  // (finish_eval reads the maxima only: res[1], res[5])
     } else {
       const bool flags = c.target.n_boundary > 0;  // Collective…Evaluator.scala:44-48
       if (flags) c.ensure_nnv_prefix(s, Km);
@@ -1060,7 +1060,7 @@ void enqueue_eval(icp_evaluator* ev, StateSlot& s, int base) {
     if (p.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE) {
       launch_sum_gauss_logpdf(c.stream, Kt, ev->t2m_d2.p, p.gauss_mean, p.gauss_sigma, out + 4);  // :49-54
     } else if (p.kind == ICP_EVAL_HAUSDORFF) {
-      launch_dist_stats(c.stream, Kt, ev->t2m_d2.p, nullptr, nullptr, 0, out + 4);
+      launch_dist_max(c.stream, Kt, ev->t2m_d2.p, out + 5);
     } else {
       // Collective…Evaluator.scala:56-60: nearest MODEL-sample vertex of the surface point, tested against the
       // TARGET's boundary flags (sic); ids beyond the target's vertex count count as interior.

@@ -252,6 +252,8 @@ void launch_variability(hipStream_t st, int N, int S, const double* X, int mode,
 void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mean, double sigma, double* out);
 // out[0] = Σ kept distances, out[1] = max kept distance, out[2] = number kept;  flag[k] != 0 drops the point
 // (flags may be null; idx (optional) indexes flags: flag = flags[idx[k]] if idx[k] < n_flags else 0)
+// out_max (zero or a distance beforehand) = max(out_max, max_k sqrt(d2[k])): many workgroups, exact (the Hausdorff evaluator's reduction)
+void launch_dist_max(hipStream_t st, int K, const double* d2, double* out_max);
 void launch_dist_stats(hipStream_t st, int K, const double* d2, const unsigned char* flags, const int* idx,
                        int n_flags, double* out);
 

@@ -1799,6 +1799,16 @@ __global__ void __launch_bounds__(1024) k_dist_stats(int K, const double* __rest
   if (threadIdx.x == 0) { out[0] = sum; out[1] = mx; out[2] = cnt; }
 }
 
+// the maximum alone (the Hausdorff evaluator needs nothing else of the list): any number of workgroups, the non-negative doubles'
+// bit patterns through a 64-bit atomic maximum — order-independent, so exact; `out_max` must be zero (or a distance) beforehand
+__global__ void __launch_bounds__(1024) k_dist_max(int K, const double* __restrict__ d2, double* __restrict__ out_max) {
+  __shared__ double s_red[16];
+  const int k = blockIdx.x * 1024 + threadIdx.x;
+  double mx = k < K ? d2[k] : 0.0;
+  mx = block_max(mx, s_red);
+  if (threadIdx.x == 0) atomicMax((unsigned long long*)out_max, d2bits(sqrt(mx)));
+}
+
 }  // namespace
 
 void launch_correspond_model(hipStream_t st, int K, const double* x, const double* cp, const int* nnv,
@@ -2220,6 +2230,12 @@ void launch_variability(hipStream_t st, int N, int S, const double* X, int mode,
 void launch_sum_gauss_logpdf(hipStream_t st, int K, const double* d2, double mean, double sigma, double* out) {
   { ProfScope _ps(st, KID_REDUCE);
     hipLaunchKernelGGL(k_sum_gauss_logpdf, dim3(1), dim3(kBlock), 0, st, K, d2, mean, sigma, out); }
+}
+
+void launch_dist_max(hipStream_t st, int K, const double* d2, double* out_max) {
+  if (K <= 0) return;  // (an empty list leaves the zero in place: distances are non-negative)
+  ProfScope _ps(st, KID_REDUCE);
+  hipLaunchKernelGGL(k_dist_max, dim3((K + 1023) / 1024), dim3(1024), 0, st, K, d2, out_max);
 }
 
 void launch_dist_stats(hipStream_t st, int K, const double* d2, const unsigned char* flags, const int* idx,
