@@ -79,6 +79,25 @@ struct RecordLogger : AcceptRejectLogger {
 };
 }  // namespace
 
+// MixedProposalDistributions.mixedRandomPoseProposal (api/sampling/MixedProposalDistributions.scala:29-39): six walks of weight 0.5
+// in the reference's order.  rot_sigma = (rotYaw, rotPitch, rotRoll), trans_sigma = (transX, transY, transZ) — the argument
+// order of :29.  YawAxis perturbs rotation._3 = theta[6], PitchAxis _2 = theta[5], RollAxis _1 = theta[4]
+// (api/sampling/proposals/PoseProposals.scala:39-41).  Leaf ids 3..8 in this order.
+template <class Own>
+static MixtureProposal* mixed_random_pose_proposal(Own&& own, const double rot_sigma[3], const double trans_sigma[3]) {
+  MixtureProposal* poseMix = static_cast<MixtureProposal*>(own(new MixtureProposal()));
+  static const char* names[6] = {"RotationYaw", "RotationPitch", "RotationRoll", "TranslationX", "TranslationY", "TranslationZ"};
+  static const int param_index[6] = {6, 5, 4, 1, 2, 3};
+  for (int a = 0; a < 6; ++a) {
+    const double sd = a < 3 ? rot_sigma[a] : trans_sigma[a - 3];
+    auto* p = new GaussianAxisPoseProposal(param_index[a], sd, std::string(names[a]) + "-" + scala_double(sd));
+    p->leafId = 3 + a;
+    own(p);
+    poseMix->add(0.5, p);
+  }
+  return poseMix;
+}
+
 struct icp_host_chain {
   icp_ctx* ctx = nullptr;
   int r = 0;
@@ -187,18 +206,7 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
     }
     // MixedProposalDistributions.mixedRandomPoseProposal (:29-39): six equally weighted 1-D walks
     MixtureProposal* poseMix = nullptr;
-    if (cfg->w_pose > 0) {
-      poseMix = static_cast<MixtureProposal*>(own(new MixtureProposal()));
-      static const char* names[6] = {"RotationYaw", "RotationPitch", "RotationRoll", "TranslationX", "TranslationY", "TranslationZ"};
-      for (int a = 0; a < 6; ++a) {
-        const double sd = a < 3 ? cfg->pose_rot_sigma[a] : cfg->pose_trans_sigma[a - 3];
-        // YawAxis/PitchAxis/RollAxis perturb phi/theta/psi (PoseProposals.scala:40-48) = theta[4..6]; translations theta[1..3]
-        auto* p = new GaussianAxisPoseProposal(a < 3 ? 4 + a : 1 + (a - 3), sd, std::string(names[a]) + "-" + scala_double(sd));
-        p->leafId = 3 + a;
-        own(p);
-        poseMix->add(0.5, p);
-      }
-    }
+    if (cfg->w_pose > 0) poseMix = mixed_random_pose_proposal(own, cfg->pose_rot_sigma, cfg->pose_trans_sigma);
     // outer mixture (IcpProposalRegistration.scala:72 / BfmFittingPartial.scala:70)
     ch->root = static_cast<MixtureProposal*>(own(new MixtureProposal()));
     if (poseMix) ch->root->add(cfg->w_pose, poseMix);
@@ -452,6 +460,53 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
     for (int b = 0; b < n_chains; ++b)
       if (chains[b]) chains[b]->logger.out = nullptr;
   return rc;
+}
+
+int icp_host_chain_log_transition(icp_host_chain* ch, const double* theta_from, const double* theta_to, double* out) {
+  return host_guard([&] {
+    if (!ch || !theta_from || !theta_to || !out) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chain_log_transition");
+    ModelFittingParameters a, b;
+    a.allParameters.assign(theta_from, theta_from + 10 + ch->r);
+    b.allParameters.assign(theta_to, theta_to + 10 + ch->r);
+    *out = ch->root->logTransitionProbability(a, b);
+  });
+}
+
+int icp_host_pose_mixture_log_transition(int32_t n_params, const double* rot_sigma, const double* trans_sigma, const double* theta_from,
+                                         const double* theta_to, double* out) {
+  return host_guard([&] {
+    if (n_params < 10 || !rot_sigma || !trans_sigma || !theta_from || !theta_to || !out)
+      throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_pose_mixture_log_transition");
+    std::vector<std::unique_ptr<ProposalGeneratorWithTransition>> owned;
+    MixtureProposal* mix = mixed_random_pose_proposal([&](ProposalGeneratorWithTransition* p) { owned.emplace_back(p); return p; }, rot_sigma, trans_sigma);
+    ModelFittingParameters a, b;
+    a.allParameters.assign(theta_from, theta_from + n_params);
+    b.allParameters.assign(theta_to, theta_to + n_params);
+    *out = mix->logTransitionProbability(a, b);
+  });
+}
+
+int icp_host_pose_mixture_propose(int32_t n_params, const double* rot_sigma, const double* trans_sigma, const double* theta, uint64_t seed,
+                                  uint64_t step, double* theta_out, int32_t* leaf_out, char* name_out, int32_t name_len) {
+  return host_guard([&] {
+    if (n_params < 10 || !rot_sigma || !trans_sigma || !theta || !theta_out)
+      throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_pose_mixture_propose");
+    std::vector<std::unique_ptr<ProposalGeneratorWithTransition>> owned;
+    MixtureProposal* mix = mixed_random_pose_proposal([&](ProposalGeneratorWithTransition* p) { owned.emplace_back(p); return p; }, rot_sigma, trans_sigma);
+    ModelFittingParameters cur;
+    cur.allParameters.assign(theta, theta + n_params);
+    const StepRandom rnd{seed, step};
+    const ModelFittingParameters prop = mix->propose(cur, rnd, 1);  // depth 1: the pose mixture sits inside the chain's outer mixture
+    std::memcpy(theta_out, prop.data(), sizeof(double) * n_params);
+    if (leaf_out) *leaf_out = mix->lastLeaf();
+    if (name_out && name_len > 0) std::snprintf(name_out, (size_t)name_len, "%s", prop.generatedBy.c_str());
+  });
+}
+
+int icp_host_scala_double(double x, char* out, int32_t out_len) {
+  if (!out || out_len <= 0) return ICP_ERR_INVALID_ARG;
+  std::snprintf(out, (size_t)out_len, "%s", scala_double(x).c_str());
+  return ICP_OK;
 }
 
 int icp_host_chain_state(icp_host_chain* ch, double* theta_out, double* logp_out, int64_t* steps_done, int64_t* accepted) {

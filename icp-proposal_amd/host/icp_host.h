@@ -20,7 +20,8 @@ typedef struct {
   double w_rw;                   /*                random shape walk       (0.10) */
   double w_pose;                 /*                6-component pose walk   (BfmFittingPartial.scala:70: 0.55; 0 = none) */
   double rw_sigma;               /* RandomShapeUpdateProposal stdev (0.1) */
-  double pose_rot_sigma[3];      /* yaw/pitch/roll stdevs (MixedProposalDistributions.scala:29: 0.01) */
+  double pose_rot_sigma[3];      /* rotYaw, rotPitch, rotRoll (MixedProposalDistributions.scala:29: 0.01): the walks on
+                                    rotation._3 = theta[6], _2 = theta[5], _1 = theta[4] (PoseProposals.scala:39-41) */
   double pose_trans_sigma[3];    /* x/y/z stdevs (0.1) */
   icp_evaluator_params eval;     /* likelihood; the shape prior is always multiplied in (ProductEvaluators.scala:38-55) */
   int32_t fused;                 /* 0 = per-method calls; 1 = icp_chain_eval_step prefetch after propose; 2 = the whole step
@@ -46,6 +47,18 @@ ICP_API int icp_host_chains_run_batched(icp_host_chain *const *chains, int32_t n
                                         double *const *records);
 ICP_API int icp_host_chain_state(icp_host_chain *chain, double *theta_out, double *logp_out, int64_t *steps_done,
                                  int64_t *accepted);
+/* the chain's whole proposal mixture: MixtureProposal.logTransitionProbability(from, to) = log-sum-exp over every leaf */
+ICP_API int icp_host_chain_log_transition(icp_host_chain *chain, const double *theta_from, const double *theta_to, double *out);
+/* MixedProposalDistributions.mixedRandomPoseProposal (MixedProposalDistributions.scala:29-39) by itself — host arithmetic only, no
+ * context: its logTransitionProbability, and one propose() with the random numbers of (seed, step) as the chain would draw them
+ * (mixture draw on lane 1, perturbation = sigma * normal(0)); leaf_out = 3..8 (Yaw, Pitch, Roll, X, Y, Z), name_out = generatedBy */
+ICP_API int icp_host_pose_mixture_log_transition(int32_t n_params, const double *rot_sigma, const double *trans_sigma,
+                                                 const double *theta_from, const double *theta_to, double *out);
+ICP_API int icp_host_pose_mixture_propose(int32_t n_params, const double *rot_sigma, const double *trans_sigma, const double *theta,
+                                          uint64_t seed, uint64_t step, double *theta_out, int32_t *leaf_out, char *name_out,
+                                          int32_t name_len);
+/* java.lang.Double.toString, as the proposal names interpolate their parameters ("RotationYaw-0.01", "RandomShape-1.0E-4") */
+ICP_API int icp_host_scala_double(double x, char *out, int32_t out_len);
 ICP_API void icp_host_chain_destroy(icp_host_chain *chain);
 ICP_API const char *icp_host_last_error(void);
 

@@ -200,23 +200,31 @@ struct RandomShapeUpdateProposal : ProposalGeneratorWithTransition {  // RandomS
   std::string generatedBy;
 };
 
-// PoseProposals.scala:31-62 (rotation about one Euler axis) and :64-90 (translation along one axis): 1-D Gaussian walks
+// PoseProposals.scala:31-62 (rotation about one Euler axis) and :64-90 (translation along one axis): 1-D Gaussian walks.
+// allParameters = [s | t(3) | rotation._1, _2, _3 | centre(3) | c] (ModelFittingParameters.scala:28-36,64); RollAxis perturbs
+// rotation._1 = theta[4], PitchAxis _2 = theta[5], YawAxis _3 = theta[6] (PoseProposals.scala:39-41); translation axis a theta[1 + a].
 struct GaussianAxisPoseProposal : ProposalGeneratorWithTransition {
   GaussianAxisPoseProposal(int param_index, double stdev, std::string generatedBy)
-      : index(param_index), stdev(stdev), generatedBy(std::move(generatedBy)) {}
+      : index(param_index), group_begin(param_index >= 4 ? 4 : 1), stdev(stdev), generatedBy(std::move(generatedBy)) {}
   ModelFittingParameters propose(const ModelFittingParameters& theta, const StepRandom& rnd, int) override {
     ModelFittingParameters out = theta;
-    out.allParameters[index] = theta.allParameters[index] + stdev * rnd.normal(0);
+    out.allParameters[index] = theta.allParameters[index] + stdev * rnd.normal(0);  // :39-41, :72-74
     out.generatedBy = generatedBy;
     return out;
   }
+  // :46-60 / :77-88.  The reference resets the WHOLE rotation triple (:47) or the WHOLE translation (:78) of `to` to `from`'s before
+  // it compares the parameter vectors: -inf only when something OUTSIDE the proposal's own group differs.  Inside the group
+  // only this proposal's axis enters the residual — the Yaw walk evaluated on a Roll move returns logPdf(0), finite, and
+  // takes part in the mixture's log-sum-exp.
   double logTransitionProbability(const ModelFittingParameters& from, const ModelFittingParameters& to) override {
     for (size_t i = 0; i < from.allParameters.size(); ++i)
-      if ((int)i != index && from.allParameters[i] != to.allParameters[i]) return -std::numeric_limits<double>::infinity();
+      if (((int)i < group_begin || (int)i >= group_begin + 3) && from.allParameters[i] != to.allParameters[i])
+        return -std::numeric_limits<double>::infinity();
     double d = (to.allParameters[index] - from.allParameters[index]) / stdev;  // breeze Gaussian(0, σ).logPdf(residual)
     return -d * d / 2.0 - (std::log(std::sqrt(2.0 * M_PI)) + std::log(stdev));
   }
-  int index;  // 1..3 translation x/y/z, 4..6 rotation phi/theta/psi
+  int index;        // 1..3 translation x/y/z, 4..6 rotation._1/_2/_3 (roll / pitch / yaw)
+  int group_begin;  // first parameter of the group the reference resets before comparing (1: translation, 4: rotation)
   double stdev;
   std::string generatedBy;
 };

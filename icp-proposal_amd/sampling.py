@@ -45,12 +45,58 @@ def host_lib():
         L.icp_host_chain_destroy.restype = None
         L.icp_host_chain_destroy.argtypes = [C.c_void_p]
         L.icp_host_last_error.restype = C.c_char_p
+        L.icp_host_chain_log_transition.restype = C.c_int
+        L.icp_host_chain_log_transition.argtypes = [C.c_void_p, nat.c_double_p, nat.c_double_p, nat.c_double_p]
+        L.icp_host_pose_mixture_log_transition.restype = C.c_int
+        L.icp_host_pose_mixture_log_transition.argtypes = [C.c_int32, nat.c_double_p, nat.c_double_p, nat.c_double_p, nat.c_double_p,
+                                                           nat.c_double_p]
+        L.icp_host_pose_mixture_propose.restype = C.c_int
+        L.icp_host_pose_mixture_propose.argtypes = [C.c_int32, nat.c_double_p, nat.c_double_p, nat.c_double_p, C.c_uint64, C.c_uint64,
+                                                    nat.c_double_p, C.POINTER(C.c_int32), C.c_char_p, C.c_int32]
+        L.icp_host_scala_double.restype = C.c_int
+        L.icp_host_scala_double.argtypes = [C.c_double, C.c_char_p, C.c_int32]
         _HOST = L
     return _HOST
 
 
 def _dp(a):
     return a.ctypes.data_as(nat.c_double_p)
+
+
+# leaf id of a pose walk -> index of the parameter it perturbs in allParameters = [s | t(3) | rotation._1,_2,_3 | centre(3) | c]
+POSE_LEAF_PARAMETER = {3: 6, 4: 5, 5: 4, 6: 1, 7: 2, 8: 3}
+
+
+def scala_double_native(x: float) -> str:
+    """The C++ harness' java.lang.Double.toString (what the native chain writes into generatedBy)."""
+    buf = C.create_string_buffer(64)
+    host_lib().icp_host_scala_double(float(x), buf, 64)
+    return buf.value.decode()
+
+
+def pose_mixture_log_transition(rot_sigma, trans_sigma, theta_from, theta_to) -> float:
+    """mixedRandomPoseProposal(...).logTransitionProbability(from, to) (MixedProposalDistributions.scala:29-39) — host arithmetic."""
+    a = np.ascontiguousarray(theta_from, dtype=np.float64)
+    b = np.ascontiguousarray(theta_to, dtype=np.float64)
+    rs, ts = np.ascontiguousarray(rot_sigma, dtype=np.float64), np.ascontiguousarray(trans_sigma, dtype=np.float64)
+    out = C.c_double()
+    st = host_lib().icp_host_pose_mixture_log_transition(a.shape[0], _dp(rs), _dp(ts), _dp(a), _dp(b), C.byref(out))
+    if st != 0:
+        raise nat.IcpNativeError(st, "icp_host_pose_mixture_log_transition", (host_lib().icp_host_last_error() or b"").decode())
+    return out.value
+
+
+def pose_mixture_propose(rot_sigma, trans_sigma, theta, seed: int, step: int):
+    """One propose() of mixedRandomPoseProposal with the chain's random numbers of (seed, step): (theta', leaf id, generatedBy)."""
+    a = np.ascontiguousarray(theta, dtype=np.float64)
+    rs, ts = np.ascontiguousarray(rot_sigma, dtype=np.float64), np.ascontiguousarray(trans_sigma, dtype=np.float64)
+    out = np.zeros_like(a)
+    leaf = C.c_int32()
+    name = C.create_string_buffer(96)
+    st = host_lib().icp_host_pose_mixture_propose(a.shape[0], _dp(rs), _dp(ts), _dp(a), seed, step, _dp(out), C.byref(leaf), name, 96)
+    if st != 0:
+        raise nat.IcpNativeError(st, "icp_host_pose_mixture_propose", (host_lib().icp_host_last_error() or b"").decode())
+    return out, leaf.value, name.value.decode()
 
 
 class ChainSetup:
@@ -77,21 +123,28 @@ class ChainSetup:
             return "Infinity" if x > 0 else "-Infinity"
         if x == 0.0:
             return "-0.0" if str(x).startswith("-") else "0.0"
+        # repr() gives the shortest digits that round-trip (what Double.toString prints); only the layout differs
+        import decimal
+        sign, digits, exp10 = decimal.Decimal(repr(x)).as_tuple()
+        digits = list(digits)
+        while len(digits) > 1 and digits[-1] == 0:
+            digits.pop()
+            exp10 += 1
+        ex = exp10 + len(digits) - 1          # decimal exponent of the first digit
+        ds = "".join(str(d) for d in digits)
+        neg = "-" if sign else ""
         if 1e-3 <= abs(x) < 1e7:
-            s = repr(x)
-            if "e" in s or "E" in s:  # repr switches to exponents earlier than Java for some magnitudes
-                s = ("%.17f" % x).rstrip("0")
-                if s.endswith("."):
-                    s += "0"
-            return s if "." in s else s + ".0"
-        m, e = ("%r" % x).lower().split("e") if "e" in repr(x).lower() else ("%.16e" % x).split("e")
-        m = m.rstrip("0") if "." in m else m + ".0"
-        if m.endswith("."):
-            m += "0"
-        return "%sE%d" % (m, int(e))
+            if ex >= 0:
+                ds = ds.ljust(ex + 2, "0")
+                return neg + ds[:ex + 1] + "." + ds[ex + 1:]
+            return neg + "0." + "0" * (-ex - 1) + ds
+        return "%s%s.%sE%d" % (neg, ds[0], ds[1:] or "0", ex)
 
     def leaf_names(self):
-        """generatedBy strings of the leaf proposals, indexed by the leaf id of the per-step records (host/icp_host.cpp)."""
+        """generatedBy strings of the leaf proposals, indexed by the leaf id of the per-step records (host/icp_host.cpp).
+        Leaves 3..8 are the pose walks in the order of MixedProposalDistributions.scala:31-36 — Yaw, Pitch, Roll, X, Y, Z — with
+        pose_rot_sigma = (rotYaw, rotPitch, rotRoll); the parameter each one perturbs is POSE_LEAF_PARAMETER[leaf]
+        (YawAxis -> rotation._3 = theta[6], PitchAxis -> theta[5], RollAxis -> theta[4]: PoseProposals.scala:39-41)."""
         names = {}
         for i, p in enumerate(self.icp):
             names[i] = "IcpProposal-%s-%sStep" % ("TargetSampling" if p["direction"] == 1 else "ModelSampling", self.scala_double(p["step"]))
@@ -219,6 +272,16 @@ class SamplingRegistration:
         if st != 0:
             raise nat.IcpNativeError(st, "icp_host_chain_run", (host_lib().icp_host_last_error() or b"").decode())
         return rec
+
+    def logTransitionProbability(self, theta_from, theta_to) -> float:
+        """The chain's whole proposal mixture (Scalismo MixtureProposal.logTransitionProbability: log-sum-exp over all leaves)."""
+        a = np.ascontiguousarray(theta_from, dtype=np.float64)
+        b = np.ascontiguousarray(theta_to, dtype=np.float64)
+        out = C.c_double()
+        st = host_lib().icp_host_chain_log_transition(self.h, _dp(a), _dp(b), C.byref(out))
+        if st != 0:
+            raise nat.IcpNativeError(st, "icp_host_chain_log_transition", (host_lib().icp_host_last_error() or b"").decode())
+        return out.value
 
     def state(self):
         theta = np.zeros(self.P)

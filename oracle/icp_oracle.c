@@ -927,6 +927,12 @@ typedef struct {
   double w_icp, w_rw;              /* outer mixture (0.9/0.1, ref: IcpProposalRegistration.scala:72) */
   double rw_sigma;                 /* RandomShapeUpdateProposal stdev (ref: RandomShapeUpdateProposal.scala:25-35) */
   orc_evaluator_params eval;       /* likelihood; the prior evaluator is always multiplied in (ProductEvaluators.scala:38-55) */
+  /* mixedRandomPoseProposal (ref: MixedProposalDistributions.scala:29-39): six equally weighted one-dimensional Gaussian walks,
+   * in the reference's order Yaw, Pitch, Roll, X, Y, Z; the outer mixture is then (pose, ICP, shape walk) as in ref:
+   * apps/bfm/BfmFittingPartial.scala:70 (0.4 / 0.55 / 0.05).  w_pose = 0: no pose proposals. */
+  double w_pose;
+  double pose_rot_sigma[3];        /* rotYaw, rotPitch, rotRoll */
+  double pose_trans_sigma[3];      /* transX, transY, transZ */
 } orc_chain_config;
 
 static double logsumexp_mix(int n, const double *w, const double *t) {
@@ -948,37 +954,106 @@ static double rw_log_transition(int r, double sigma, const double *from, const d
   return -0.5 * nn / (sigma * sigma) - 0.5 * (r * log(2.0 * M_PI) + r * log(sigma * sigma));
 }
 
+/* The pose walks of ref: api/sampling/proposals/PoseProposals.scala:31-90 in the order of
+ * ref: MixedProposalDistributions.scala:31-36: Yaw, Pitch, Roll, X, Y, Z.  allParameters = [s | t(3) | rotation._1, _2, _3 |
+ * centre(3) | c] (ref: ModelFittingParameters.scala:28-36,64), and RollAxis -> _1, PitchAxis -> _2, YawAxis -> _3
+ * (ref: PoseProposals.scala:39-41): component a perturbs theta[pose_param_index[a]]. */
+static const int pose_param_index[6] = {6, 5, 4, 1, 2, 3};
+
+/* ref: PoseProposals.scala:46-60 (rotation), :77-88 (translation).  -inf only when a parameter OUTSIDE the proposal's own
+ * group differs: the comparison of :47 / :78 is made after the WHOLE rotation triple / translation vector of `to` has been reset to
+ * `from`'s.  Inside the group only the component's own axis enters the residual, so e.g. the Yaw component evaluated on a Roll
+ * move returns logPdf(0), finite.  breeze Gaussian(0, sd).logPdf(x) = -(x/sd)^2/2 - (log sqrt(2 pi) + log sd). */
+ORC_API double orc_pose_log_transition(int P, int component, double sd, const double *from, const double *to) {
+  const int idx = pose_param_index[component];
+  const int g0 = component < 3 ? 4 : 1, g1 = g0 + 3;
+  for (int i = 0; i < P; ++i)
+    if ((i < g0 || i >= g1) && from[i] != to[i]) return -INFINITY;
+  const double d = (to[idx] - from[idx]) / sd;
+  return -d * d / 2.0 - (log(sqrt(2.0 * M_PI)) + log(sd));
+}
+
+/* MixtureProposal.logTransitionProbability of mixedRandomPoseProposal: six components of weight 0.5 each (normalised: 1/6) */
+ORC_API double orc_pose_mixture_log_transition(int P, const double rot_sigma[3], const double trans_sigma[3], const double *from,
+                                               const double *to) {
+  double t[6], w[6], ws = 0.0;
+  for (int a = 0; a < 6; ++a) t[a] = orc_pose_log_transition(P, a, a < 3 ? rot_sigma[a] : trans_sigma[a - 3], from, to);
+  for (int a = 0; a < 6; ++a) ws += 0.5;
+  for (int a = 0; a < 6; ++a) w[a] = 0.5 / ws;
+  return logsumexp_mix(6, w, t);
+}
+
+/* the outer mixture's components in the order the reference builds them (pose, ICP, shape walk; absent ones skipped) with their
+ * normalised weights; returns their number.  kind: 0 pose, 1 ICP, 2 shape walk */
+static int chain_outer_components(const orc_chain_config *cfg, int *kind, double *w) {
+  int n = 0;
+  double raw[3], wsum = 0.0;
+  if (cfg->w_pose > 0) { kind[n] = 0; raw[n++] = cfg->w_pose; }
+  if (cfg->n_icp > 0 && cfg->w_icp > 0) { kind[n] = 1; raw[n++] = cfg->w_icp; }
+  if (cfg->w_rw > 0) { kind[n] = 2; raw[n++] = cfg->w_rw; }
+  for (int i = 0; i < n; ++i) wsum += raw[i];
+  for (int i = 0; i < n; ++i) w[i] = raw[i] / wsum;
+  return n;
+}
+
 /* log-sum-exp over ALL mixture components of the transition density from -> to, given the ICP posteriors of
  * `from` (Scalismo MixtureProposal.logTransitionProbability) */
 static int chain_log_transition(const orc_model *m, const orc_chain_config *cfg, const orc_posterior *post_from,
                                 const double *from, const double *to, double *out) {
-  double outer_t[2], outer_w[2];
-  int n_outer = 0, rc = 0;
-  double wsum = cfg->w_icp + cfg->w_rw;
-  if (cfg->n_icp > 0 && cfg->w_icp > 0) {
-    double t[2], w[2], ws = 0;
-    for (int i = 0; i < cfg->n_icp; ++i) ws += cfg->icp_weight[i];
-    for (int i = 0; i < cfg->n_icp; ++i) {
-      w[i] = cfg->icp_weight[i] / ws;
-      rc |= orc_log_transition_from_posterior(m, &cfg->icp[i], &post_from[i], from, to, &t[i]);
+  double outer_t[3], outer_w[3];
+  int kind[3], rc = 0;
+  const int n_outer = chain_outer_components(cfg, kind, outer_w);
+  for (int o = 0; o < n_outer; ++o) {
+    if (kind[o] == 0) {
+      outer_t[o] = orc_pose_mixture_log_transition(10 + m->r, cfg->pose_rot_sigma, cfg->pose_trans_sigma, from, to);
+    } else if (kind[o] == 1) {
+      double t[2], w[2], ws = 0;
+      for (int i = 0; i < cfg->n_icp; ++i) ws += cfg->icp_weight[i];
+      for (int i = 0; i < cfg->n_icp; ++i) {
+        w[i] = cfg->icp_weight[i] / ws;
+        rc |= orc_log_transition_from_posterior(m, &cfg->icp[i], &post_from[i], from, to, &t[i]);
+      }
+      outer_t[o] = logsumexp_mix(cfg->n_icp, w, t);
+    } else {
+      /* mixedRandomShapeProposal is itself a 1-component mixture (weight normalised to 1) */
+      outer_t[o] = rw_log_transition(m->r, cfg->rw_sigma, from, to);
     }
-    outer_t[n_outer] = logsumexp_mix(cfg->n_icp, w, t);
-    outer_w[n_outer++] = cfg->w_icp / wsum;
-  }
-  if (cfg->w_rw > 0) {
-    /* mixedRandomShapeProposal is itself a 1-component mixture (weight normalised to 1) */
-    outer_t[n_outer] = rw_log_transition(m->r, cfg->rw_sigma, from, to);
-    outer_w[n_outer++] = cfg->w_rw / wsum;
   }
   *out = logsumexp_mix(n_outer, outer_w, outer_t);
   return rc;
 }
 
+/* the whole chain mixture's transition density from -> to (posteriors of `from` computed here): for tests of the harness */
+ORC_API int orc_chain_log_transition(const orc_model *m, const orc_mesh *tgt, const orc_chain_config *cfg, const double *from,
+                                     const double *to, double *out) {
+  orc_posterior pf[2];
+  int rc = 0;
+  for (int i = 0; i < cfg->n_icp; ++i) {
+    pf[i] = posterior_alloc(proposal_K(&cfg->icp[i]), m->r);
+    rc |= orc_icp_posterior(m, tgt, &cfg->icp[i], from, &pf[i]);
+  }
+  if (rc == 0) rc = chain_log_transition(m, cfg, pf, from, to, out);
+  for (int i = 0; i < cfg->n_icp; ++i) posterior_free(&pf[i]);
+  return rc;
+}
+
+/* first component whose cumulative normalised weight reaches u (Scalismo MixtureProposal) */
+static int mixture_pick(int n, const double *w_normalised, double u) {
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) {
+    acc += w_normalised[i];
+    if (acc >= u) return i;
+  }
+  return n - 1;
+}
+
 /* Runs n_steps MH steps from theta0.  Outputs per step: accepted flag, component index (0/1 = ICP component,
- * 2 = random walk), log posterior value of the state after the step, and the state itself.
+ * 2 = random walk, 3..8 = the pose walks Yaw, Pitch, Roll, X, Y, Z), log posterior value of the state after the step, and the
+ * state itself.
  * The ICP posteriors and the likelihood of the CURRENT state are carried over between steps, which is what the
  * reference's Memoize caches achieve (ref: NonRigidIcpProposal.scala:49, evaluators/EvaluationCaching.scala:32).
- * RNG lanes per step: uniform lane 0 outer mixture draw, 1 inner mixture draw, 2 accept draw; normal lane j = z_j. */
+ * RNG lanes per step: uniform lane 0 outer mixture draw, 1 inner mixture draw, 2 accept draw; normal lane j = z_j (a pose walk
+ * perturbs its parameter by sigma * z_0). */
 ORC_API int orc_run_chain(const orc_model *m, const orc_mesh *tgt, const orc_chain_config *cfg, const double *theta0,
                           uint64_t seed, int n_steps, unsigned char *accepted, int *component, double *logp,
                           double *states /* [n_steps*(10+r)] */) {
@@ -995,24 +1070,32 @@ ORC_API int orc_run_chain(const orc_model *m, const orc_mesh *tgt, const orc_cha
     pp[i] = posterior_alloc(proposal_K(&cfg->icp[i]), r);
     rc |= orc_icp_posterior(m, tgt, &cfg->icp[i], cur, &pc[i]);
   }
+  int kind[3];
+  double outer_w[3];
+  const int n_outer = chain_outer_components(cfg, kind, outer_w);
   for (int s = 0; s < n_steps && rc == 0; ++s) {
-    double wsum = cfg->w_icp + cfg->w_rw;
-    double u = orc_rng_uniform(seed, (uint64_t)s, 0);
+    const double u = orc_rng_uniform(seed, (uint64_t)s, 0);
     int comp;
     for (int j = 0; j < r; ++j) z[j] = orc_rng_normal(seed, (uint64_t)s, (uint64_t)j);
-    if (cfg->n_icp > 0 && u <= cfg->w_icp / wsum) { /* first cumulative weight >= u */
-      double ws = 0, acc = 0, u2 = orc_rng_uniform(seed, (uint64_t)s, 1);
+    const int outer = kind[mixture_pick(n_outer, outer_w, u)];
+    if (outer == 1) {
+      double w[2], ws = 0, u2 = orc_rng_uniform(seed, (uint64_t)s, 1);
       for (int i = 0; i < cfg->n_icp; ++i) ws += cfg->icp_weight[i];
-      comp = cfg->n_icp - 1;
-      for (int i = 0; i < cfg->n_icp; ++i) {
-        acc += cfg->icp_weight[i] / ws;
-        if (acc >= u2) { comp = i; break; }
-      }
+      for (int i = 0; i < cfg->n_icp; ++i) w[i] = cfg->icp_weight[i] / ws;
+      comp = mixture_pick(cfg->n_icp, w, u2);
       rc |= orc_propose_from_posterior(m, &cfg->icp[comp], &pc[comp], cur, z, prop);
-    } else {
+    } else if (outer == 2) {
       comp = 2;
       memcpy(prop, cur, sizeof(double) * P);
       for (int j = 0; j < r; ++j) prop[10 + j] = cur[10 + j] + cfg->rw_sigma * z[j];
+    } else { /* ref: PoseProposals.scala:36-44, :71-76 */
+      double w[6], ws = 0, u2 = orc_rng_uniform(seed, (uint64_t)s, 1);
+      for (int a = 0; a < 6; ++a) ws += 0.5;
+      for (int a = 0; a < 6; ++a) w[a] = 0.5 / ws;
+      const int a = mixture_pick(6, w, u2);
+      comp = 3 + a;
+      memcpy(prop, cur, sizeof(double) * P);
+      prop[pose_param_index[a]] = cur[pose_param_index[a]] + (a < 3 ? cfg->pose_rot_sigma[a] : cfg->pose_trans_sigma[a - 3]) * z[0];
     }
     double prop_like, fw, bw;
     rc |= orc_evaluator_log_value(m, tgt, &cfg->eval, prop, &prop_like);

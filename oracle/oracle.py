@@ -47,7 +47,8 @@ class FitParams(C.Structure):
 
 class ChainConfig(C.Structure):
     _fields_ = [("n_icp", C.c_int), ("icp", ProposalParams * 2), ("icp_weight", C.c_double * 2),
-                ("w_icp", C.c_double), ("w_rw", C.c_double), ("rw_sigma", C.c_double), ("eval", EvaluatorParams)]
+                ("w_icp", C.c_double), ("w_rw", C.c_double), ("rw_sigma", C.c_double), ("eval", EvaluatorParams),
+                ("w_pose", C.c_double), ("pose_rot_sigma", C.c_double * 3), ("pose_trans_sigma", C.c_double * 3)]
 
 
 def build(force: bool = False) -> str:
@@ -97,6 +98,11 @@ def lib():
         L.orc_posterior_variability.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int, c_double_p, c_double_p]
         L.orc_run_chain.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ChainConfig), c_double_p, C.c_uint64, C.c_int,
                                     c_ubyte_p, c_int_p, c_double_p, c_double_p]
+        L.orc_pose_log_transition.restype = C.c_double
+        L.orc_pose_log_transition.argtypes = [C.c_int, C.c_int, C.c_double, c_double_p, c_double_p]
+        L.orc_pose_mixture_log_transition.restype = C.c_double
+        L.orc_pose_mixture_log_transition.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
+        L.orc_chain_log_transition.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ChainConfig), c_double_p, c_double_p, c_double_p]
         _LIB = L
     return _LIB
 
@@ -307,15 +313,49 @@ def evaluator_log_value(model, target, ep, theta):
     return out.value, rc
 
 
-def chain_config(icp_params, icp_weights, w_icp, w_rw, rw_sigma, ep):
+def chain_config(icp_params, icp_weights, w_icp, w_rw, rw_sigma, ep, w_pose=0.0, pose_rot_sigma=(0.01, 0.01, 0.01),
+                 pose_trans_sigma=(0.1, 0.1, 0.1)):
+    """Outer mixture (pose, ICP, shape walk) as apps/bfm/BfmFittingPartial.scala:70 builds it; w_pose = 0 leaves the pose walks
+    out (apps/femur/IcpProposalRegistration.scala:72).  pose_rot_sigma = (rotYaw, rotPitch, rotRoll), pose_trans_sigma = (x, y, z):
+    the argument order of MixedProposalDistributions.mixedRandomPoseProposal (:29)."""
     cfg = ChainConfig()
     cfg.n_icp = len(icp_params)
     for i, p in enumerate(icp_params):
         cfg.icp[i] = p
         cfg.icp_weight[i] = icp_weights[i]
     cfg.w_icp, cfg.w_rw, cfg.rw_sigma, cfg.eval = w_icp, w_rw, rw_sigma, ep
+    cfg.w_pose = w_pose
+    for a in range(3):
+        cfg.pose_rot_sigma[a] = pose_rot_sigma[a]
+        cfg.pose_trans_sigma[a] = pose_trans_sigma[a]
     cfg._keep = (icp_params, ep)
     return cfg
+
+
+POSE_PARAM_INDEX = (6, 5, 4, 1, 2, 3)  # Yaw, Pitch, Roll, X, Y, Z -> index into allParameters (PoseProposals.scala:39-41)
+
+
+def pose_log_transition(component, sd, theta_from, theta_to):
+    """GaussianAxisRotationProposal / GaussianAxisTranslationProposal.logTransitionProbability (PoseProposals.scala:46-60, :77-88);
+    component 0..5 = Yaw, Pitch, Roll, X, Y, Z."""
+    a, b = _f64(theta_from), _f64(theta_to)
+    return lib().orc_pose_log_transition(a.shape[0], int(component), float(sd), _d(a), _d(b))
+
+
+def pose_mixture_log_transition(rot_sigma, trans_sigma, theta_from, theta_to):
+    a, b = _f64(theta_from), _f64(theta_to)
+    rs, ts = _f64(rot_sigma), _f64(trans_sigma)
+    return lib().orc_pose_mixture_log_transition(a.shape[0], _d(rs), _d(ts), _d(a), _d(b))
+
+
+def chain_log_transition(model, target, cfg, theta_from, theta_to):
+    """The whole proposal mixture's logTransitionProbability(from, to) (Scalismo MixtureProposal: log-sum-exp over all leaves)."""
+    a, b = _f64(theta_from), _f64(theta_to)
+    out = C.c_double()
+    rc = lib().orc_chain_log_transition(model.h, target.h, C.byref(cfg), _d(a), _d(b), C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"orc_chain_log_transition rc={rc}")
+    return out.value
 
 
 def run_chain(model, target, cfg, theta0, seed, n_steps):

@@ -16,7 +16,8 @@ def oracle_chain_config(oracle, setup):
     e = setup.eval
     ep = oracle.evaluator_params(e["kind"], e["mode"], n_model_ids=e["n_model_ids"], target_pts=e["target_pts"],
                                  p0=e["gauss_mean"] if e["kind"] != 1 else e["exp_rate"], p1=e["gauss_sigma"], p2=e["exp_rate"])
-    return oracle.chain_config(icp, [p.get("weight", 0.5) for p in setup.icp], setup.w_icp, setup.w_rw, setup.rw_sigma, ep)
+    return oracle.chain_config(icp, [p.get("weight", 0.5) for p in setup.icp], setup.w_icp, setup.w_rw, setup.rw_sigma, ep,
+                               w_pose=setup.w_pose, pose_rot_sigma=setup.pose_rot_sigma, pose_trans_sigma=setup.pose_trans_sigma)
 
 
 @pytest.mark.parametrize("fused", [2, 1, 0])

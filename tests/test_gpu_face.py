@@ -182,6 +182,86 @@ def test_full_face_chain_runs(pkg, full_face, evaluator):
     chain.close()
 
 
+def compare_chain_with_oracle(rec, acc_o, comp_o, logp_o, states_o):
+    """Identical accept/reject and mixture-component sequences, states within 1e-5 relative."""
+    n = rec.shape[0]
+    assert np.array_equal(rec[:, 0], np.arange(n))
+    assert np.array_equal(rec[:, 1].astype(np.uint8), acc_o), "accept/reject sequences differ"
+    assert np.array_equal(rec[:, 2].astype(np.int32), comp_o), "mixture components differ"
+    scale = max(np.abs(states_o[:, 10:]).max(), 1e-3)
+    assert np.abs(rec[:, 4 + 10:] - states_o[:, 10:]).max() <= 1e-5 * scale
+    assert np.abs(rec[:, 4 + 1:4 + 7] - states_o[:, 1:7]).max() <= 1e-12       # pose parameters: host arithmetic on both sides
+    assert np.array_equal(rec[:, 4 + 7:4 + 10], states_o[:, 7:10]) and np.array_equal(rec[:, 4], states_o[:, 0])
+    assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
+
+
+@pytest.mark.parametrize("evaluator", ["collective", "hausdorff"])
+def test_small_face_pose_chain_matches_oracle(pkg, oracle, small, evaluator):
+    """apps/bfm/BfmFittingPartial.scala:62-83 at reduced size: 0.4 pose + 0.55 ICP(ModelSampling) + 0.05 shape walk, on a target
+    WITH boundary, 150 steps, decision for decision against the oracle's chain (which has the six pose walks of
+    api/sampling/proposals/PoseProposals.scala:31-90 since round 3) — with UNEQUAL pose sigmas, so that a wrong pairing of name,
+    sigma and parameter (round 2: Yaw and Roll swapped) changes the chain."""
+    from test_gpu_chain import oracle_chain_config
+    model, target, ctx, om, ot = small
+    setup = pkg.bfm_fitting_partial(model, target, evaluator=evaluator)
+    setup.pose_rot_sigma, setup.pose_trans_sigma = (0.02, 0.01, 0.004), (0.2, 0.1, 0.05)
+    theta0, seed, n = pkg.initial_parameters(model), 77, 150
+    try:
+        oracle.set_search_backend(oracle.SEARCH_TREES)
+        acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), theta0, seed, n)
+    finally:
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)
+    chain = pkg.SamplingRegistration(ctx, setup, theta0, seed)
+    rec = chain.run(n)
+    compare_chain_with_oracle(rec, acc_o, comp_o, logp_o, states_o)
+    assert 20 < acc_o.sum() < n and (comp_o == 0).sum() > 40 and (comp_o == 2).sum() > 0
+    assert all((comp_o == k).sum() > 0 for k in range(3, 9)), "not every pose walk was drawn"
+    # accepted moves of all six pose walks: each changed exactly the parameter the reference's axis names
+    moved = set()
+    prev = theta0
+    for s in range(n):
+        if acc_o[s] and comp_o[s] >= 3:
+            assert list(np.flatnonzero(rec[s, 4:] != prev)) == [pkg.sampling.POSE_LEAF_PARAMETER[int(comp_o[s])]]
+            moved.add(int(comp_o[s]))
+        prev = rec[s, 4:]
+    assert len(moved) >= 4
+    # the whole mixture's transition density of a pose move (the Yaw walk evaluated on a Roll move is FINITE and enters the
+    # log-sum-exp: PoseProposals.scala:47-49) and of a shape move, harness against oracle
+    cfg = oracle_chain_config(oracle, setup)
+    k = next(s for s in range(1, n) if acc_o[s] and comp_o[s] == 5)             # an accepted Roll move
+    a, b = rec[k - 1, 4:].copy(), rec[k, 4:].copy()
+    got, want = chain.logTransitionProbability(a, b), oracle.chain_log_transition(om, ot, cfg, a, b)
+    hand = np.log(0.4) + np.log(sum(np.exp(-0.5 * (d / sd) ** 2) / (np.sqrt(2 * np.pi) * sd)
+                                    for d, sd in ((0.0, 0.02), (0.0, 0.01), (b[4] - a[4], 0.004))) / 6.0)
+    assert abs(got - want) <= 1e-13 * abs(want) and abs(got - hand) <= 1e-12 * abs(hand)
+    k = next(s for s in range(1, n) if acc_o[s] and comp_o[s] == 0)             # an accepted ICP move
+    a, b = rec[k - 1, 4:].copy(), rec[k, 4:].copy()
+    got, want = chain.logTransitionProbability(a, b), oracle.chain_log_transition(om, ot, cfg, a, b)
+    assert np.isfinite(want) and abs(got - want) <= 1e-6 * abs(want)
+    chain.close()
+
+
+@pytest.mark.parametrize("evaluator", ["collective", "hausdorff"])
+def test_full_face_pose_chain_matches_oracle(pkg, oracle, full_face, evaluator):
+    """configs[3] at FULL size (N = 28,561, rank 200, K = 400, K_e = 800 / the full-mesh Hausdorff evaluator): the first 12 steps of
+    the BfmFittingPartial chain, decision for decision against the oracle's chain (tree back end, bit-identical to its scans)."""
+    from test_gpu_chain import oracle_chain_config
+    model, target, ctx = full_face
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    setup = pkg.bfm_fitting_partial(model, target, evaluator=evaluator)
+    theta0, seed, n = pkg.initial_parameters(model), 5, 12
+    try:
+        oracle.set_search_backend(oracle.SEARCH_TREES)
+        acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), theta0, seed, n)
+    finally:
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)
+    chain = pkg.SamplingRegistration(ctx, setup, theta0, seed)
+    rec = chain.run(n)
+    compare_chain_with_oracle(rec, acc_o, comp_o, logp_o, states_o)
+    assert (comp_o == 0).sum() > 0 and (comp_o >= 3).sum() > 0 and acc_o.sum() > 0
+    chain.close()
+
+
 def test_batch_registration_world1(pkg):
     """configs[4] plumbing on one GPU: (target, chain) work items, one context per target, records returned in item order."""
     model = pkg.data.synthetic_face_model(grid=41, rank=40)
@@ -272,6 +352,16 @@ def test_batch_registration_full_face_matches_oracle(pkg, oracle):
                 got = ev.logValue(theta)
                 assert rc == 0 and abs(got - want) <= 1e-10 * abs(want)
             ev.close(); prop.close(); ctx.close()
+        # the decision sequence of one work item — (target 0, chain 1): random initial shape, seed as run_batch deals it — against
+        # the oracle's chain (pose walks included)
+        from test_gpu_chain import oracle_chain_config
+        ot = oracle.OracleMesh(targets[0].points, targets[0].cells)
+        setup = pkg.bfm_fitting_partial(model, targets[0])
+        acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup),
+                                                            pkg.random_initial_parameters(model, 1, 1024), 1024 + 1, n_steps)
+        rec = recs[1].copy()
+        rec[:, 0] = np.arange(n_steps)        # (run_batch stores the item id in the index field)
+        compare_chain_with_oracle(rec, acc_o, comp_o, logp_o, states_o)
     finally:
         oracle.set_search_backend(oracle.SEARCH_BRUTE)
 
