@@ -54,6 +54,11 @@ class KernelStat(C.Structure):
                 ("max_ms", C.c_double)]
 
 
+class RuntimeStats(C.Structure):
+    _fields_ = [("wait_timeouts", C.c_int64), ("speculation_giveups", C.c_int64), ("pipeline_fallbacks", C.c_int64),
+                ("step_redos", C.c_int64), ("gate_timeouts", C.c_int64), ("reserved", C.c_int64 * 3)]
+
+
 # every symbol include/icp_proposal.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "icp_ctx_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(MeshDesc), C.c_int, C.POINTER(C.c_void_p)]),
@@ -95,6 +100,7 @@ SIGNATURES = {
     "icp_chain_step_batched_collect": (C.c_int, [C.c_void_p]),
     "icp_chain_step_batched_abandon": (C.c_int, [C.c_void_p]),
     "icp_ctx_set_rotation": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "icp_ctx_runtime_stats": (C.c_int, [C.c_void_p, C.POINTER(RuntimeStats)]),
     "icp_chain_step_batched": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                          C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p), c_double_p, c_double_p,
                                          c_double_p, C.POINTER(C.c_int32)]),
@@ -130,3 +136,11 @@ def check(status, where):
         L = lib()
         detail = (L.icp_last_error() or b"").decode() or (L.icp_status_string(status) or b"").decode()
         raise IcpNativeError(status, where, detail)
+
+
+def runtime_stats(ctx_handle=None) -> dict:
+    """icp_ctx_runtime_stats: fall-back counters of one context (its handle) or, with None, of the whole process.  A normal run
+    shows zero everywhere."""
+    st = RuntimeStats()
+    check(lib().icp_ctx_runtime_stats(ctx_handle, C.byref(st)), "icp_ctx_runtime_stats")
+    return {k: int(getattr(st, k)) for k, _ in RuntimeStats._fields_ if k != "reserved"}

@@ -116,6 +116,10 @@ class IcpContext:
     def __del__(self):
         self.close()
 
+    def runtime_stats(self) -> dict:
+        """Fall-back counters of this context (icp_ctx_runtime_stats): all zero in a normal run."""
+        return nat.runtime_stats(self.h)
+
     def profile_start(self, max_launches: int = 200000):
         nat.check(nat.lib().icp_ctx_profile_start(self.h, max_launches), "icp_ctx_profile_start")
 

@@ -260,8 +260,15 @@ struct StateSlot {
 
 }  // namespace
 
+// icp_runtime_stats (include/icp_proposal.h): per context and for the process
+struct RuntimeStats {
+  std::atomic<int64_t> wait_timeouts{0}, speculation_giveups{0}, pipeline_fallbacks{0}, step_redos{0}, gate_timeouts{0};
+};
+RuntimeStats g_runtime_stats;
+
 struct icp_ctx {
   int device = 0;
+  RuntimeStats stats;
   hipStream_t stream = nullptr;
   // icp_chain_step alternates between two streams: the five launches of a step go to one of them in order, the next step's
   // to the other.  Launches 1-3 of a step do not depend on the finish launch of the step before it and run beside it; what
@@ -334,6 +341,15 @@ struct icp_ctx {
   DBuf<unsigned char> batch_device[kBatchRing];
   size_t batch_bytes[kBatchRing] = {0, 0, 0, 0};
   int batch_turn = 0;
+  // … and of their decompositions: the records of launch_posterior_eigen_many (pinned, read in place by the kernel), the counter
+  // its workgroups announce themselves in and what it will hold once every workgroup launched so far has started (the gate of
+  // launch_step_batch) and the gate's pinned error word
+  void* batch_eig_rec[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
+  size_t batch_eig_rec_bytes[kBatchRing] = {0, 0, 0, 0};
+  int batch_eig_turn = 0;
+  DBuf<int> batch_gate;
+  int batch_gate_expected = 0;
+  int* h_gate_error = nullptr;
   // eigen streams of the batches this context carries, one per batch in flight (keyed by the batch's first chain): created
   // together, so that the runtime spreads them over different hardware queues — the member contexts' own eigen streams
   // collide on one queue for some batch sizes (24 chains in three groups: 49k instead of 70k it/s)
@@ -574,6 +590,13 @@ struct PosteriorEntry {
   bool reserved = false;  // handed out to a step whose launches are in flight: not to be recycled
   hipEvent_t eig_done = nullptr;  // recorded on the eigen stream behind the launch that holds the entry's decomposition
   hipEvent_t eig_done_shared = nullptr;  // … or, not owned, the event of the entry it shared that launch with
+  // a shared event out of the device's ring (next_batch_event, icp_chain_step_batched): the slot's generation counter (static
+  // storage) and its value when the event was recorded for this entry — a slot recorded again since stands for LATER work on
+  // possibly another stream, which orders nothing of this entry's: such a waiter synchronises with the eigen streams on the host
+  // instead (eigen_event() returns nullptr then; await_eigen / mpart_for_write fall back to sync_eigen)
+  const uint64_t* eig_shared_gen = nullptr;
+  uint64_t eig_shared_gen_value = 0;
+  bool eigen_event_stale() const { return eig_event_valid && eig_done_shared && eig_shared_gen && *eig_shared_gen != eig_shared_gen_value; }
   bool eig_event_valid = false;   // an event stands for the latest decomposition of this entry (the chain step's own launches
                                   // of ranks <= 64 record none: their consumers wait for the completion word on the device, and
                                   // an event record is 2-3 µs of host time on the accepted path)
@@ -585,7 +608,7 @@ struct PosteriorEntry {
   DBuf<double> coeffs, M, alpha, V, Vt, S;
   int status_off = 0;  // this entry's 3 ints inside the proposal's status buffer
   ~PosteriorEntry() { if (eig_done) (void)hipEventDestroy(eig_done); }
-  hipEvent_t eigen_event() const { return !eig_event_valid ? nullptr : (eig_done_shared ? eig_done_shared : eig_done); }
+  hipEvent_t eigen_event() const { return (!eig_event_valid || eigen_event_stale()) ? nullptr : (eig_done_shared ? eig_done_shared : eig_done); }
   CorrBuffers corr() const { return CorrBuffers{id.p, aux.p, pt.p, keep.p, nhat.p, e.p}; }
 };
 
@@ -941,6 +964,7 @@ void icp_proposal::ensure_eigen(PosteriorEntry& e) {
   }
   HIP_OK(hipEventRecord(e.eig_done, es));
   e.eig_done_shared = nullptr;
+  e.eig_shared_gen = nullptr;
   e.eig_event_valid = true;
 }
 
@@ -954,6 +978,7 @@ void icp_proposal::ensure_eigen_on(PosteriorEntry& e, hipStream_t es) {
   launch_posterior_eigen(es, c.r, rq.M, c.sqrt_lambda.p, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.work, rq.status, nullptr, rq.host_status);
   HIP_OK(hipEventRecord(e.eig_done, es));
   e.eig_done_shared = nullptr;
+  e.eig_shared_gen = nullptr;
   e.eig_event_valid = true;
 }
 
@@ -990,7 +1015,10 @@ void icp_proposal::resolve_speculation(const double* theta_cur) {
   // A decomposition that gave up waiting for its input (k_posterior_eigen_rr) has said so in its pinned status.  That
   // happens when the runtime puts its stream on a hardware queue ahead of the launch it waits for — many streams in one
   // process, or a tool that serialises kernels — and each occurrence stalls the step for the time-out: once is enough.
-  if (h_eig[e.status_off / 3] == kEigenGaveUp) ctx->speculation_off = true;
+  if (h_eig[e.status_off / 3] == kEigenGaveUp && !ctx->speculation_off) {
+    ctx->speculation_off = true;
+    ++ctx->stats.speculation_giveups; ++g_runtime_stats.speculation_giveups;
+  }
   const size_t P = 10 + (size_t)ctx->r;
   if (e.valid && e.eig_valid && std::memcmp(e.theta.data(), theta_cur, sizeof(double) * P) == 0) {
     warm_ptr = e.V.p;  // accepted: this is the basis the next decompositions start from
@@ -1394,6 +1422,9 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   }
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->h_wait_error) (void)hipHostFree(ctx->h_wait_error);
+  if (ctx->h_gate_error) (void)hipHostFree(ctx->h_gate_error);
+  for (void* bp : ctx->batch_eig_rec)
+    if (bp) (void)hipHostFree(bp);
   g_host_timing.report();
   g_batch_timing.report();
   for (auto& r : ctx->prof.pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1443,6 +1474,18 @@ int icp_ctx_set_rotation(icp_ctx* ctx, const double* angles, const double* R) {
     slot->valid = true;
     slot->stamp = ++ctx->rotation_clock;
   });
+}
+
+int icp_ctx_runtime_stats(const icp_ctx* ctx, icp_runtime_stats* out) {
+  if (!out) return ICP_ERR_INVALID_ARG;
+  const RuntimeStats& s = ctx ? ctx->stats : g_runtime_stats;
+  std::memset(out, 0, sizeof(*out));
+  out->wait_timeouts = s.wait_timeouts.load();
+  out->speculation_giveups = s.speculation_giveups.load();
+  out->pipeline_fallbacks = s.pipeline_fallbacks.load();
+  out->step_redos = s.step_redos.load();
+  out->gate_timeouts = s.gate_timeouts.load();
+  return ICP_OK;
 }
 
 int icp_ctx_set_idle_hook(icp_ctx* ctx, icp_idle_fn fn, void* arg) {
@@ -2247,18 +2290,32 @@ struct EigenCollect {  // the decompositions of a batch of chains, launched toge
   std::vector<PosteriorEntry*> all;    // every entry with a request: ONE event, recorded behind the launch, stands for them all
 };
 
-// Events for the decompositions of whole batches: a ring that lives as long as the process (the entries of many chains — many
-// proposals, many contexts, destroyed in any order — point at one of them; a slot that has been recorded again since only makes a
-// late waiter wait for later work).  One record per batch instead of one per chain that moved: ≈ 2.3 µs of host time each.
-hipEvent_t next_batch_event() {
+// Events for the decompositions of whole batches: one ring PER DEVICE (an event belongs to the device that was current when it
+// was created) that lives as long as the process — the entries of many chains, many proposals, many contexts, destroyed in any
+// order, point at its slots.  A slot is handed out again after 64 batches; the entries of the earlier batch notice by the slot's
+// generation counter (PosteriorEntry::eigen_event_stale) and wait on the host instead of on an event that now stands for other work.
+// One record per batch instead of one per chain that moved: ≈ 2.3 µs of host time each.
+struct BatchEventSlot { hipEvent_t ev = nullptr; uint64_t gen = 0; };
+BatchEventSlot& next_batch_event(int device) {
+  constexpr int kMaxDevices = 64, kRing = 64;
   static std::mutex mu;
-  static hipEvent_t ring[64] = {};
-  static unsigned turn = 0;
+  static BatchEventSlot ring[kMaxDevices][kRing];
+  static unsigned turn[kMaxDevices] = {};
+  require(device >= 0 && device < kMaxDevices, "device ordinal out of range");
   std::lock_guard<std::mutex> lk(mu);
-  hipEvent_t& e = ring[turn++ & 63];
-  if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  BatchEventSlot& e = ring[device][turn[device]++ % kRing];
+  if (!e.ev) HIP_OK(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));  // (the caller has bound `device`)
+  ++e.gen;
   return e;
 }
+// A launch that waits ON THE DEVICE for a word another stream's launch raises is safe as long as the waiting workgroups cannot keep
+// the launch they wait for from becoming resident.  One chain's step cannot (its first launch is 14 workgroups, a decomposition
+// six), two chains' neither; the batched step orders its chip-wide first launch behind the residency of its decompositions
+// explicitly (StepBatchGate).  MANY contexts stepped one by one from many threads could, together, fill the chip with spinning first
+// launches (round 2 saw the batched form of this: a 50 ms time-out): from three live contexts on, the single-chain
+// step therefore takes its cross-stream order from events and stream order — no device-side wait at all.
+bool device_side_waits_allowed() { return g_live_contexts.load(std::memory_order_relaxed) <= 2; }
+
 void start_decompositions(icp_ctx& c, int n_props, icp_proposal* const* props, PosteriorEntry* const* ec, bool m_in_flight,
                           EigenCollect* collect = nullptr) {
   const int r = c.r;
@@ -2270,6 +2327,7 @@ void start_decompositions(icp_ctx& c, int n_props, icp_proposal* const* props, P
   if (nn == 0) return;
   need[0]->eig_done_shared = nullptr;
   for (int i = 1; i < nn; ++i) need[i]->eig_done_shared = need[0]->eig_done;
+  for (int i = 0; i < nn; ++i) need[i]->eig_shared_gen = nullptr;
   if (collect) {
     if (m_in_flight) HIP_OK(hipStreamSynchronize(c.stream));
     for (int i = 0; i < nn; ++i) need[i]->eig_event_valid = true;  // (recorded by the caller behind the batch's launch)
@@ -2286,6 +2344,12 @@ void start_decompositions(icp_ctx& c, int n_props, icp_proposal* const* props, P
     HIP_OK(hipStreamWaitEvent(es, c.ev_ready, 0));
   }
   if (launch_posterior_eigen_pair(es, r, c.sqrt_lambda.p, nn, rqs)) {
+    if (!device_side_waits_allowed()) {
+      // many contexts in the process: an event instead of the completion word (see device_side_waits_allowed)
+      HIP_OK(hipEventRecord(need[0]->eig_done, es));
+      for (int i = 0; i < nn; ++i) { need[i]->eig_event_valid = true; need[i]->done_value = 0; }
+      return;
+    }
     // completion words: the step's first launch waits for the one it draws from on the device; no event (host time on the
     // accepted path) — whoever else needs the basis waits for the eigen stream on the host (await_eigen)
     for (int i = 0; i < nn; ++i) need[i]->eig_event_valid = false;
@@ -2325,7 +2389,8 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
   if (missing) c.stream_used_elsewhere = true;  // … and this step reads them
   const bool m_in_flight = c.stream_used_elsewhere;  // `stream` may still be writing what the decompositions below read
-  F.stream = (F.parity && !c.pipeline_off && !batched) ? c.front_stream : c.stream;
+  const bool two_streams = !c.pipeline_off && !batched && device_side_waits_allowed();
+  F.stream = (F.parity && two_streams) ? c.front_stream : c.stream;
   if (F.stream == c.front_stream) {
     if (c.stream_used_elsewhere) {  // another entry point has work on `stream` that this step may depend on: join once
       HIP_OK(hipEventRecord(c.ev_join, c.stream));
@@ -2408,7 +2473,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   b.has_vert = pt ? 1 : 0; b.vert = st_vert;
   b.zero2 = ev_t2m ? st_t2m.cnt : nullptr; b.n_zero2 = ev_t2m ? st_t2m.Kpad : 0;
   // (nothing to wait for before the first finish launch, nor when every step is on one stream)
-  b.wait_flag = (c.last_back_seq > 0 && !c.pipeline_off && !batched) ? c.d_done.p + 2 : nullptr;
+  b.wait_flag = (c.last_back_seq > 0 && two_streams) ? c.d_done.p + 2 : nullptr;
   // test hook: the first launch waits for a word that never comes, times out, and the step is repeated unpipelined
   static const int starve_pipeline = dev_env("ICP_TEST_STARVE_PIPELINE") ? (1 << 24) : 0;
   b.wait_seq = c.last_back_seq + starve_pipeline;
@@ -2512,6 +2577,7 @@ bool chain_step_record(icp_evaluator* e, int n_props, icp_proposal* const* props
     const int st = p->h_eig[ec[generator]->status_off / 3];
     if (st == kEigenGaveUp) {  // a speculative decomposition that never saw its input (see k_posterior_eigen_rr): the
       // step just computed drew from a stale basis — drop it (nothing of it has been recorded) and do it again
+      ++c.stats.speculation_giveups; ++g_runtime_stats.speculation_giveups;
       ec[generator]->eig_valid = false;
       ec[generator]->eig_checked = false;
       p->warm_valid = false;  // (it pointed at the basis that was never written)
@@ -2766,13 +2832,17 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       HIP_OK(hipStreamSynchronize(c.front_stream));  // (a half step launched ahead may time out here, too)
       sync_eigen(c);
       c.h_wait_error[0] = 0;
+      ++c.stats.wait_timeouts; ++g_runtime_stats.wait_timeouts;
       if (c.pipeline_off) fail(ICP_ERR_DEVICE, "internal: a step's first launch timed out on its word");
       c.pipeline_off = true;
+      ++c.stats.pipeline_fallbacks; ++g_runtime_stats.pipeline_fallbacks;
+      ++c.stats.step_redos; ++g_runtime_stats.step_redos;
       if (e->front.valid) release_front(e->front);
       redo = true;
       return;
     }
     if (!chain_step_record(e, n_props, props, generator, theta_cur, F, f, theta_prop, log_value_prop, fwd, bwd, &status)) {
+      ++c.stats.step_redos; ++g_runtime_stats.step_redos;
       redo = true;
       return;
     }
@@ -2942,15 +3012,40 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       // (ranks > 64 decompose through the library, each chain on its own eigen stream, and are awaited on the host below)
       start_decompositions(c, n_props, it.props, ec, c.stream_used_elsewhere, eigen_speculation_supported(c.r) ? &eigens : nullptr);
     }
-    if (!eigens.rq.empty()) {  // … in one launch (per 24), on the batch's eigen stream
+    StepBatchGate gate{};
+    if (!eigens.rq.empty()) {  // … in ONE launch, on the batch's eigen stream
+      std::lock_guard<std::recursive_mutex> lead_lk(lead.mu);  // (the record ring and the gate counter are the launch context's)
       Bound _b(&elead, true);
-      launch_posterior_eigen_many(eigens.stream, elead.r, (int)eigens.rq.size(), eigens.rq.data());
+      const int turn = (lead.batch_eig_turn = (lead.batch_eig_turn + 1) % icp_ctx::kBatchRing);
+      const size_t bytes = eigen_many_record_bytes((int)eigens.rq.size());
+      if (bytes > lead.batch_eig_rec_bytes[turn]) {
+        // (the slot's previous reader was the batch four tickets ago: collected, its launches finished)
+        if (lead.batch_eig_rec[turn]) { HIP_OK(hipHostFree(lead.batch_eig_rec[turn])); lead.batch_eig_rec[turn] = nullptr; }
+        const size_t cap_bytes = std::max(bytes, eigen_many_record_bytes(128));
+        HIP_OK(hipHostMalloc(&lead.batch_eig_rec[turn], cap_bytes, hipHostMallocDefault));
+        lead.batch_eig_rec_bytes[turn] = cap_bytes;
+      }
+      if (!lead.batch_gate.p) {
+        lead.batch_gate.alloc(16);
+        HIP_OK(hipMemset(lead.batch_gate.p, 0, sizeof(int) * 16));
+        HIP_OK(hipHostMalloc((void**)&lead.h_gate_error, sizeof(int) * 16, hipHostMallocDefault));
+        lead.h_gate_error[0] = 0;
+        lead.batch_gate_expected = 0;
+      }
+      const int wgs = launch_posterior_eigen_many(eigens.stream, elead.r, (int)eigens.rq.size(), eigens.rq.data(), lead.batch_eig_rec[turn],
+                                                  lead.batch_gate.p);
+      require(wgs > 0, "internal: batched decompositions at a rank the kernel does not cover");
+      lead.batch_gate_expected = (int)((unsigned)lead.batch_gate_expected + (unsigned)wgs);  // (wraps with the counter)
+      gate = StepBatchGate{lead.batch_gate.p, lead.batch_gate_expected, lead.h_gate_error};
       g_batch_timing.mark(4);
-      const hipEvent_t done = next_batch_event();
-      HIP_OK(hipEventRecord(done, eigens.stream));
-      for (PosteriorEntry* en : eigens.all) en->eig_done_shared = done;  // (eig_event_valid is set where the requests were collected)
+      BatchEventSlot& done = next_batch_event(elead.device);
+      HIP_OK(hipEventRecord(done.ev, eigens.stream));
+      for (PosteriorEntry* en : eigens.all) {  // (eig_event_valid is set where the requests were collected)
+        en->eig_done_shared = done.ev;
+        en->eig_shared_gen = &done.gen;
+        en->eig_shared_gen_value = done.gen;
+      }
       g_batch_timing.mark(5);
-      // (entries that share e0's event carry eig_done_shared; eig_event_valid is set where the requests were collected)
     }
     int nb = 0;
     for (int b = 0; b < n_chains; ++b) {
@@ -3013,7 +3108,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       }
       static const bool finish_aside = dev_env("ICP_BATCH_FINISH_INLINE") == nullptr;  // (A/B switch)
       launch_step_batch(lead.stream, nb, caps.data(), lead.batch_pinned[turn], lead.batch_device[turn].p,
-                        finish_aside ? lead.front_stream : nullptr, lead.ev_join);
+                        finish_aside ? lead.front_stream : nullptr, lead.ev_join, gate);
       if (finish_aside) t.finish_stream = lead.front_stream;
     }
     t.nb = nb;
@@ -3048,6 +3143,10 @@ int icp_chain_step_batched_collect(icp_step_ticket* tk) {
   int rc = guard([&] {
     icp_ctx& lead = *t.lead;
     g_batch_timing.start();
+    if (lead.h_gate_error && lead.h_gate_error[0]) {  // (counted; the launches went ahead and their own time-outs take it from there)
+      lead.h_gate_error[0] = 0;
+      ++lead.stats.gate_timeouts; ++g_runtime_stats.gate_timeouts;
+    }
     // ---- results, chain by chain
     bool first_wait = true;
     for (int b = 0; b < n_chains; ++b) {
@@ -3077,6 +3176,7 @@ int icp_chain_step_batched_collect(icp_step_ticket* tk) {
         if (t.finish_stream) HIP_OK(hipStreamSynchronize(t.finish_stream));
         sync_eigen(c);
         c.h_wait_error[0] = 0;
+        ++c.stats.wait_timeouts; ++g_runtime_stats.wait_timeouts;
         it.redo = true;
       } else {
         int st = ICP_OK;
@@ -3084,6 +3184,7 @@ int icp_chain_step_batched_collect(icp_step_ticket* tk) {
                                      fwd + (size_t)b * n_props, bwd + (size_t)b * n_props, &st);
         status[b] = st;
       }
+      if (it.redo) { ++c.stats.step_redos; ++g_runtime_stats.step_redos; }
       if (it.redo) release_front(it.F);
       else {
         it.F.s->reserved = false;

@@ -219,9 +219,13 @@ struct EigenRequest { const double* M; const double* Vwarm; double* V; double* V
                       bool direct = false; /* launch_posterior_eigen_pair: take the tridiagonal route (state-independent time) instead of
                       the warm-started iteration — worth it while the chain moves fast (burn-in: the iteration needs 4 sweeps) */ };
 bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq);
-// any number of decompositions of one rank (the chains of icp_chain_step_batched) in as few launches as the kernel argument
-// segment allows (24 each); every request carries its model's sqrt_lambda
-bool launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest* rq);
+// any number of decompositions of one rank (the chains of icp_chain_step_batched) in ONE launch (up to 80; more: a second launch on
+// the same stream); every request carries its model's sqrt_lambda.  pinned_records: eigen_many_record_bytes(n) bytes of pinned host
+// memory that stay untouched until the launch has finished (the kernel reads its records there); arrive (may be null): a device
+// counter every workgroup of the launch increments when it starts.  Returns the number of workgroups launched, -1 if the rank is
+// not covered (nothing launched).
+size_t eigen_many_record_bytes(int n);
+int launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest* rq, void* pinned_records, int* arrive);
 void eigen_debug_dump(const double* work, int r);
 void library_release_stream(hipStream_t st);  // drops the library handle kept for `st` (ranks > 64), before the stream is destroyed
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
@@ -376,9 +380,15 @@ struct StepCapture {
 };
 void step_capture(StepCapture* c);  // nullptr: launch as usual
 size_t step_batch_bytes(int B);
-// st_finish/ev (optional): the fifth launch goes to st_finish behind an event recorded on st
+// st_finish/ev (optional): the fifth launch goes to st_finish behind an event recorded on st.
+// gate (optional): the sequence's first kernel (one workgroup's worth of copying) does not end before the device counter
+// gate.counter has reached gate.expected — i.e. before every workgroup of the decompositions this batch waits for ON THE DEVICE
+// has started (launch_posterior_eigen_many's `arrive`).  The launch behind it fills the chip with workgroups that spin on those
+// decompositions' completion words; ordered like this they can never keep them from becoming resident.  After 2 s the gate opens
+// anyway and says so in gate.error (pinned).
+struct StepBatchGate { const int* counter = nullptr; int expected = 0; int* error = nullptr; };
 void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pinned, void* device, hipStream_t st_finish = nullptr,
-                       hipEvent_t ev = nullptr);
+                       hipEvent_t ev = nullptr, StepBatchGate gate = StepBatchGate{});
 SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const float4* spheres, int K, const double* P,
                               int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);
 VertexTask make_vertex_task(int V, const double* verts, int K, const double* P, int* hint, const QueryBuffers& qb, double* d2, int* idx);

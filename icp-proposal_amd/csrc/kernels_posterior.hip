@@ -956,18 +956,30 @@ struct EigenProblem {
   double* rotlog; int* meta; double* vpos; EigenSpec spec; int launch_id; int* host_status; int* done_word; int done_value;
   const double* sqrt_lambda;  // of this problem's model (nullptr: the launch's)
 };
-// CAP = 2: the two directions of one chain step; CAP = kEigenBatchMax: the decompositions of a batch of chains
-// (icp_chain_step_batched) — the record travels as a kernel argument (4 KB at most)
-template <int CAP> struct EigenBatch { int n; EigenProblem p[CAP]; };
-constexpr int kEigenBatchMax = 24;
-static_assert(sizeof(EigenBatch<kEigenBatchMax>) + 64 <= 4096, "the batch record must fit the kernel argument segment");
+// The batch record.  EigenBatch<2>: the two directions of one chain step, by value in the kernel arguments.  EigenBatchMem: the
+// decompositions of a batch of chains (icp_chain_step_batched) — any number of them in ONE launch, the records read in place from
+// pinned host memory (136 bytes per workgroup, once); every workgroup announces itself in `arrive` when it starts, so that the
+// batch's launch sequence can be held back until all of them are resident (k_step_batch_args: its first launch fills the chip with
+// workgroups that spin on these decompositions' completion words, and must not get there first).
+template <int CAP> struct EigenBatch {
+  int n; EigenProblem p[CAP];
+  __device__ __forceinline__ void announce() const {}
+};
+struct EigenBatchMem {
+  int n; const EigenProblem* p; int* arrive;
+  __device__ __forceinline__ void announce() const {
+    if (arrive && threadIdx.x == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+static_assert(sizeof(EigenBatch<2>) + 64 <= 4096, "the batch record must fit the kernel argument segment");
 
-template <int CAP>
+template <class Batch>
 __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double* __restrict__ sqrt_lambda_launch, int ldk, int max_sweeps,
-                                                              int no_corr /* 1: sweep to the strict test (A/B, tests) */, EigenBatch<CAP> batch) {
+                                                              int no_corr /* 1: sweep to the strict test (A/B, tests) */, Batch batch) {
+  batch.announce();
   const int per = 1 + (r + kReplayRows - 1) / kReplayRows;  // workgroups per problem: the iteration + the replay (32 rows each)
   const int which = (int)blockIdx.x / per, local = (int)blockIdx.x - which * per;
-  const EigenProblem& pb = batch.p[which];
+  const EigenProblem pb = batch.p[which];
   const double* __restrict__ sqrt_lambda = pb.sqrt_lambda ? pb.sqrt_lambda : sqrt_lambda_launch;
   const double* __restrict__ M = pb.M;
   const double* Vwarm = pb.Vwarm;
@@ -2083,33 +2095,41 @@ void eigen_debug_dump(const double* work, int r) {  // developer aid: convergenc
 bool eigen_speculation_supported(int r) { return r >= 3 && r <= 64 && dev_env("ICP_EIGEN_GENERIC") == nullptr; }
 
 namespace {
-template <int CAP>
-void launch_eigen_rr(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq) {
+// workgroups per problem: the iteration + the replay (32 rows each)
+inline int eigen_rr_per(int r) { return 1 + (r + kReplayRows - 1) / kReplayRows; }
+inline EigenProblem eigen_rr_problem(int r, const EigenRequest& rq) {
+  const int n2 = (r + 1) & ~1;
+  // work = [rotation log | sign exchange | meta: progress word, counters, rank per position]
+  const size_t log_doubles = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;
+  static std::atomic<int> launch_counter{0};  // (any value the previous launch on this `work` did not use would do)
+  double* vpos = rq.work + log_doubles;
+  const int launch_id = 1 + (int)((unsigned)(++launch_counter) % kPwIdMask);  // never 0: the idle value of the progress word
+  return EigenProblem{rq.M, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.status, rq.work, (int*)(vpos + (size_t)n2 * 64), vpos,
+                      rq.spec ? *rq.spec : EigenSpec{0, nullptr, 0, nullptr, 0}, launch_id, rq.host_status, rq.done_word,
+                      rq.done_value, rq.sqrt_lambda};
+}
+template <class Batch>
+void launch_eigen_rr_batch(hipStream_t st, int r, const double* sqrt_lambda, int n, const Batch& batch) {
   // fixed-position variant: A, V and the rotation table double-buffered in LDS
   const int n2 = (r + 1) & ~1;
   const int ldk = 66;  // ldk: 64 coordinates per position row, rows 16 B apart modulo the 256-B bank window
   const size_t szV = (size_t)n2 * ldk;
   const size_t shmem = sizeof(double) * ((size_t)kRrOV + 2 * szV);
-  // work = [rotation log | sign exchange | meta: progress word, counters, rank per position]
-  const size_t log_doubles = ((size_t)kEigenMaxSweeps * (n2 - 1) + 2) * n2;
   static const int sweeps_cap = dev_env("ICP_EIGEN_MAX_SWEEPS") ? std::atoi(dev_env("ICP_EIGEN_MAX_SWEEPS")) : kEigenMaxSweeps;
   static bool lds_set = false;
-  set_dyn_lds_once((const void*)k_posterior_eigen_rr<CAP>, sizeof(double) * ((size_t)kRrOV + 2 * 64 * 66), &lds_set);
-  static std::atomic<int> launch_counter{0};  // (any value the previous launch on this `work` did not use would do)
-  EigenBatch<CAP> batch{};
-  batch.n = n;
-  for (int i = 0; i < n; ++i) {
-    double* vpos = rq[i].work + log_doubles;
-    const int launch_id = 1 + (int)((unsigned)(++launch_counter) % kPwIdMask);  // never 0: the idle value of the progress word
-    batch.p[i] = EigenProblem{rq[i].M, rq[i].Vwarm, rq[i].V, rq[i].Vt, rq[i].S, rq[i].status, rq[i].work, (int*)(vpos + (size_t)n2 * 64), vpos,
-                              rq[i].spec ? *rq[i].spec : EigenSpec{0, nullptr, 0, nullptr, 0}, launch_id, rq[i].host_status, rq[i].done_word,
-                              rq[i].done_value, rq[i].sqrt_lambda};
-  }
+  set_dyn_lds_once((const void*)k_posterior_eigen_rr<Batch>, sizeof(double) * ((size_t)kRrOV + 2 * 64 * 66), &lds_set);
   ProfScope _ps(st, KID_EIGEN);
   // per problem: workgroup 0 iterates, workgroup 1 replays its rotations on V as the sweeps are published
   static const int no_corr = dev_env("ICP_EIGEN_NO_CORRECTION") != nullptr;
-  hipLaunchKernelGGL(k_posterior_eigen_rr<CAP>, dim3(n * (1 + (r + kReplayRows - 1) / kReplayRows)), dim3(1024), shmem, st, r, sqrt_lambda, ldk, std::min(sweeps_cap, kEigenMaxSweeps), no_corr,
-                     batch);
+  hipLaunchKernelGGL(k_posterior_eigen_rr<Batch>, dim3(n * eigen_rr_per(r)), dim3(1024), shmem, st, r, sqrt_lambda, ldk,
+                     std::min(sweeps_cap, kEigenMaxSweeps), no_corr, batch);
+}
+template <int CAP>
+void launch_eigen_rr(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq) {
+  EigenBatch<CAP> batch{};
+  batch.n = n;
+  for (int i = 0; i < n; ++i) batch.p[i] = eigen_rr_problem(r, rq[i]);
+  launch_eigen_rr_batch(st, r, sqrt_lambda, n, batch);
 }
 }  // namespace
 
@@ -2161,15 +2181,21 @@ bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambd
   return true;
 }
 
-bool launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest* rq) {
+size_t eigen_many_record_bytes(int n) { return sizeof(EigenProblem) * (size_t)n; }
+
+int launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest* rq, void* pinned_records, int* arrive) {
   static const bool force_generic = dev_env("ICP_EIGEN_GENERIC") != nullptr;
-  if (!(r >= 3 && r <= 64 && !force_generic) || n < 1) return false;
-  for (int i = 0; i < n; i += kEigenBatchMax) {
-    const int m = std::min(kEigenBatchMax, n - i);
-    if (m <= 2) launch_eigen_rr<2>(st, r, nullptr, m, rq + i);
-    else launch_eigen_rr<kEigenBatchMax>(st, r, nullptr, m, rq + i);
+  if (!(r >= 3 && r <= 64 && !force_generic) || n < 1) return -1;
+  // ONE launch while all of its workgroups can be resident together on an otherwise idle chip (a replay workgroup waits for its
+  // neighbour at the sign exchange): 240 workgroups; more problems than that follow in a second launch on the same stream
+  const int per = eigen_rr_per(r), chunk = 240 / per;
+  EigenProblem* rec = (EigenProblem*)pinned_records;
+  for (int i = 0; i < n; ++i) rec[i] = eigen_rr_problem(r, rq[i]);
+  for (int i = 0; i < n; i += chunk) {
+    const int m = std::min(chunk, n - i);
+    launch_eigen_rr_batch(st, r, nullptr, m, EigenBatchMem{m, rec + i, arrive});
   }
-  return true;
+  return n * per;
 }
 
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,

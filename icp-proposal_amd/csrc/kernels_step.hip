@@ -369,9 +369,21 @@ __global__ void __launch_bounds__(NT) k_step_finish(StepFinishArgs a) { step_fin
 // workgroups idle.  (The record is read in place: a private copy of it lands in scratch, its arrays being indexed at run
 // time.)
 
-__global__ void __launch_bounds__(256) k_step_batch_args(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16) {
+__global__ void __launch_bounds__(256) k_step_batch_args(const uint4* __restrict__ src, uint4* __restrict__ dst, int n16, StepBatchGate gate) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n16) dst[i] = src[i];  // src: pinned host memory, read in place
+  // the gate (see StepBatchGate): ONE thread of the sequence's first kernel waits — a single wave on a single CU keeps nothing
+  // from becoming resident — for every workgroup of the batch's decompositions to have started
+  if (gate.counter && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    while (__hip_atomic_load(gate.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gate.expected < 0) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ll) {
+        __hip_atomic_store(gate.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
 }
 
 __global__ void __launch_bounds__(kStepBlock) k_step_begin_batch(const StepBeginArgs* __restrict__ batch) {
@@ -519,7 +531,8 @@ size_t step_batch_bytes(int B) {
          up16(sizeof(StepFinishArgs) * B);
 }
 
-void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pinned, void* device, hipStream_t st_finish, hipEvent_t ev) {
+void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pinned, void* device, hipStream_t st_finish, hipEvent_t ev,
+                       StepBatchGate gate) {
   if (B <= 0) return;
   const size_t o1 = up16(sizeof(StepBeginArgs) * B), o2 = o1 + up16(sizeof(StepSearchArgs) * B),
                o3 = o2 + up16(sizeof(StepRegressionArgs) * B), total = step_batch_bytes(B);
@@ -534,7 +547,7 @@ void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pin
     for (int k = 0; k < 5; ++k) gx[k] = caps[b].grid[k] > gx[k] ? caps[b].grid[k] : gx[k];
   }
   const int n16 = (int)(total / 16);
-  hipLaunchKernelGGL(k_step_batch_args, dim3(cdiv(n16, 256)), dim3(256), 0, st, (const uint4*)h, (uint4*)d, n16);
+  hipLaunchKernelGGL(k_step_batch_args, dim3(cdiv(n16, 256)), dim3(256), 0, st, (const uint4*)h, (uint4*)d, n16, gate);
   if (gx[0] > 0) {
     ProfScope _ps(st, KID_STEP_BEGIN);
     static const bool no_reg = dev_env("ICP_BEGIN_STREAMED") != nullptr;  // (A/B switch)

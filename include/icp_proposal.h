@@ -305,6 +305,21 @@ typedef struct {
 ICP_API int icp_ctx_profile_start(icp_ctx *ctx, int32_t max_launches);
 ICP_API int icp_ctx_profile_stop(icp_ctx *ctx, icp_kernel_stat *stats, int32_t capacity /* >= 32 */, int32_t *n_out);
 
+/* ---- fall-back counters.  The step schedules above take their cross-stream order on the device (a launch waits for a word another
+ * stream's launch raises) with time-outs behind them; every time-out ends in a slower but equivalent schedule, so a normal run must
+ * show ZERO everywhere — anything else is a performance bug (or a tool that lets one kernel run at a time: rocprofv3 --pmc).
+ * ctx == NULL: totals of the process since it started. */
+typedef struct {
+  int64_t wait_timeouts;        /* a step's first launch gave up waiting for its word (50 ms on the device) */
+  int64_t speculation_giveups;  /* a KL basis started ahead never saw its input (5 ms) and the step that drew from it was repeated */
+  int64_t pipeline_fallbacks;   /* contexts switched to the one-stream schedule for good after a time-out */
+  int64_t step_redos;           /* steps computed twice because of any of the above */
+  int64_t gate_timeouts;        /* batched steps: the launch sequence was not released because the batch's decompositions did not
+                                   become resident in time (2 s) */
+  int64_t reserved[3];
+} icp_runtime_stats;
+ICP_API int icp_ctx_runtime_stats(const icp_ctx *ctx, icp_runtime_stats *out);
+
 /* ---- idle hook (optional).  icp_chain_step spends most of a step waiting for the device.  A caller that has host
  * work which does not depend on the step's outcome — drawing the random numbers of the NEXT step, say — registers it
  * here: `fn(arg)` is called once per icp_chain_step, on the calling thread, after the step's launches have been issued

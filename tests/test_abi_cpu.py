@@ -37,6 +37,15 @@ def test_struct_layouts_match_header(pkg):
     assert ctypes.sizeof(nat.ModelDesc) == 56 and ctypes.sizeof(nat.MeshDesc) == 24
     assert ctypes.sizeof(nat.ProposalParams) == 48 and ctypes.sizeof(nat.EvaluatorParams) == 48
     assert ctypes.sizeof(nat.PosteriorView) == 72 and ctypes.sizeof(nat.KernelStat) == 72
+    assert ctypes.sizeof(nat.RuntimeStats) == 64
+
+
+def test_runtime_stats_start_at_zero(pkg):
+    """icp_ctx_runtime_stats(NULL): the process-wide fall-back counters (no device needed)."""
+    st = pkg._native.runtime_stats()
+    assert set(st) == {"wait_timeouts", "speculation_giveups", "pipeline_fallbacks", "step_redos", "gate_timeouts"}
+    assert all(v == 0 for v in st.values())
+    assert pkg._native.lib().icp_ctx_runtime_stats(None, None) == -1
 
 
 def test_prior_is_host_arithmetic(pkg, femur50):

@@ -504,3 +504,31 @@ def test_contexts_share_model_and_target_memory(pkg):
         ch.close()
     for c in ctxs + [first]:
         c.close()
+
+
+def test_no_fallback_in_normal_runs(pkg, femur50):
+    """The step schedules take their cross-stream order on the device, with time-outs behind them (icp_ctx_runtime_stats).  A normal
+    run must never need one: the metric chain over 3,000 steps (pipelined single-chain step, speculative decompositions) and 64 chains
+    x 300 steps through the batched step, burn-in included — where round 2's profile showed a 50 ms time-out (more than 24
+    decompositions per batch went out as several launches on one stream, and the chip-wide first launch of the step, spinning on
+    THEIR completion words, kept the later ones from becoming resident) — leave every counter at zero."""
+    model, _ = femur50
+    _, target = pkg.data.synthetic_femur_target()
+    before = pkg._native.runtime_stats()
+    setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+    ctx = pkg.IcpContext(model, target, device=0)
+    chain = pkg.SamplingRegistration(ctx, setup, pkg.initial_parameters(model), seed=1024)
+    rec = chain.run(3000)
+    assert 500 < rec[:, 1].sum() < 2000
+    assert all(v == 0 for v in ctx.runtime_stats().values()), ctx.runtime_stats()
+    chain.close(); ctx.close()
+    B = 64
+    ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
+    chains = [pkg.SamplingRegistration(ctxs[i], setup, pkg.random_initial_parameters(model, chain_index=i), seed=2000 + i) for i in range(B)]
+    recs = pkg.run_chains_batched(chains, 300)
+    assert sum(r[:, 1].sum() for r in recs) > 64 * 60          # burn-in: most early steps are accepted
+    per_ctx = [c.runtime_stats() for c in ctxs]
+    assert all(v == 0 for st in per_ctx for v in st.values()), [st for st in per_ctx if any(st.values())]
+    [c.close() for c in chains]; [c.close() for c in ctxs]
+    after = pkg._native.runtime_stats()
+    assert after == before, (before, after)
