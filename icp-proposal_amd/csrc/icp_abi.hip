@@ -334,6 +334,7 @@ struct icp_ctx {
   Profiler prof;
   bool profiling = false;
   DBuf<long long> d_wait_ticks;  // profiling: time the steps' first launches spent waiting on the device (StepBeginArgs::wait_ticks)
+  DBuf<unsigned long long> d_search_counters;  // profiling: executed tests of the searches (SurfaceTask::stats)
   // argument arrays of the icp_chain_step_batched launches led by this context: pinned copy, device copy
   // (kBatchRing of each, used in turn: a caller may keep that many batches in flight on this context's stream)
   static constexpr int kBatchRing = 4;
@@ -994,7 +995,7 @@ void icp_proposal::speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur,
                                    EigenSpec* spec_out, EigenRequest* rq_out) {
   e.eig_event_valid = false;
   ++spec_seq;
-  *spec_out = EigenSpec{splits, h_cancel + (spec_seq & 15), spec_seq, ready, ready_seq};
+  *spec_out = EigenSpec{splits, h_cancel + (spec_seq & 15), spec_seq, ready, ready_seq, ctx->profiling ? ctx->d_wait_ticks.p + 1 : nullptr};
   // warm start: the basis of the current state's posterior (complete, or ahead of this launch on the same stream)
   const double* warm = (eig_seq & 127) == 127 ? nullptr : (cur.eig_valid ? cur.V.p : (warm_valid ? warm_ptr : nullptr));  // (see prepare_eigen)
   h_eig[e.status_off / 3] = -1;  // in flight
@@ -1512,6 +1513,9 @@ int icp_ctx_profile_start(icp_ctx* ctx, int32_t max_launches) {
     ctx->prof.used = 0;
     ctx->prof.overflow = false;
     ctx->d_wait_ticks.fill_bytes(0);
+    if (!ctx->d_search_counters.p) ctx->d_search_counters.alloc(kSearchCounters);
+    ctx->d_search_counters.fill_bytes(0);
+    ctx->prof.counters = ctx->d_search_counters.p;
     ctx->profiling = true;
   });
 }
@@ -1546,8 +1550,17 @@ int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity,
     for (int i = 0; i < KID_COUNT; ++i)
       if (acc[i].calls > 0) stats[n++] = acc[i];
     {  // how much of k_step_begin's time was spent waiting ON THE DEVICE for the previous step / the decomposition it draws from
-      long long ticks = 0;
-      HIP_OK(hipMemcpy(&ticks, ctx->d_wait_ticks.p, sizeof(ticks), hipMemcpyDeviceToHost));
+      long long both[2] = {0, 0};
+      HIP_OK(hipMemcpy(both, ctx->d_wait_ticks.p, sizeof(both), hipMemcpyDeviceToHost));
+      const long long ticks = both[0];
+      if (both[1] > 0 && n < capacity) {  // … and of the speculative decompositions' time waiting for their input (EigenSpec::wait_ticks)
+        icp_kernel_stat w;
+        std::memset(&w, 0, sizeof(w));
+        std::strncpy(w.name, "k_posterior_eigen.device_wait", sizeof(w.name) - 1);
+        w.calls = acc[KID_EIGEN].calls;
+        w.total_ms = (double)both[1] * 1e-5;
+        stats[n++] = w;
+      }
       if (ticks > 0 && n < capacity) {
         icp_kernel_stat w;
         std::memset(&w, 0, sizeof(w));
@@ -1556,6 +1569,20 @@ int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity,
         w.total_ms = (double)ticks * 1e-5;  // 100 MHz ticks
         stats[n++] = w;
       }
+    }
+    {  // executed tests of the searches (counted per wave while profiling): rows "count.*", the number in `calls`
+      unsigned long long cnt[kSearchCounters] = {};
+      if (ctx->d_search_counters.p) HIP_OK(hipMemcpy(cnt, ctx->d_search_counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+      static const char* names[5] = {"count.surface_ball_tests", "count.surface_sphere_tests", "count.surface_exact_tests",
+                                     "count.vertex_filter_tests", "count.vertex_exact_tests"};
+      for (int k = 0; k < 5; ++k)
+        if (cnt[k] > 0 && n < capacity) {
+          icp_kernel_stat w;
+          std::memset(&w, 0, sizeof(w));
+          std::strncpy(w.name, names[k], sizeof(w.name) - 1);
+          w.calls = (int64_t)cnt[k];
+          stats[n++] = w;
+        }
     }
     *n_out = n;
     if (ctx->prof.overflow) fail(ICP_ERR_INVALID_ARG, "profiler event pool too small: raise max_launches");
@@ -3037,6 +3064,9 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       require(wgs > 0, "internal: batched decompositions at a rank the kernel does not cover");
       lead.batch_gate_expected = (int)((unsigned)lead.batch_gate_expected + (unsigned)wgs);  // (wraps with the counter)
       gate = StepBatchGate{lead.batch_gate.p, lead.batch_gate_expected, lead.h_gate_error};
+      // test hook (tools/r3_timeout_repro.py: round 2's schedule, for the record): the launch sequence is not held back
+      static const bool no_gate = dev_env("ICP_TEST_NO_GATE") != nullptr;
+      if (no_gate) gate = StepBatchGate{};
       g_batch_timing.mark(4);
       BatchEventSlot& done = next_batch_event(elead.device);
       HIP_OK(hipEventRecord(done.ev, eigens.stream));

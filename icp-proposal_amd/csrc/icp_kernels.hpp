@@ -31,11 +31,13 @@ enum KernelId {
 };
 extern const char* const kKernelNames[KID_COUNT];
 
+constexpr int kSearchCounters = 8;
 struct Profiler {
   struct Rec { hipEvent_t a, b; int id; };
   std::vector<Rec> pool;
   size_t used = 0;
   bool overflow = false;
+  unsigned long long* counters = nullptr;  // device, kSearchCounters: executed tests of the searches (SurfaceTask::stats)
   void begin(hipStream_t st, int id);
   void end(hipStream_t st);
 };
@@ -112,6 +114,9 @@ struct SurfaceTask {  // one batch of closest-point-on-surface queries against o
   double* d2;
   int* tri;
   int tblocks, ksplit, kchunk;  // filter decomposition: tblocks × ksplit workgroups
+  // profiling only (nullptr otherwise): executed tests, counted per wave — [0] ball tests (one query against a wave's patch),
+  // [1] sphere tests (one query against one triangle's bounding sphere), [2] exact point–triangle evaluations of the resolve stage
+  unsigned long long* stats;
 };
 
 struct VertexTask {  // one batch of nearest-vertex queries against one vertex set
@@ -125,6 +130,7 @@ struct VertexTask {  // one batch of nearest-vertex queries against one vertex s
   double* d2;  // outputs, any may be null
   int* idx;
   int vblocks, ksplit, kchunk;
+  unsigned long long* stats;  // profiling only: [3] exact point–vertex distances of the filter (every pair), [4] of the resolve stage
 };
 
 void split_queries(int n_elem_blocks, int Kpad, int* ksplit, int* kchunk);
@@ -208,7 +214,8 @@ size_t eigen_work_doubles(int r);  // size of `work`
 //   ready    device word raised (to ready_seq or beyond) by the regression launch when the partials are complete: the
 //            decomposition is enqueued without a stream dependency on that launch and waits for the word itself
 constexpr int kEigenGaveUp = 3;  // pinned status of a speculative decomposition whose input never arrived
-struct EigenSpec { int splits; const int* cancel; int seq; const int* ready; int ready_seq; };
+struct EigenSpec { int splits; const int* cancel; int seq; const int* ready; int ready_seq;
+                   long long* wait_ticks = nullptr; /* profiling: 100 MHz ticks spent waiting for `ready` are added here */ };
 bool eigen_speculation_supported(int r);
 // up to two decompositions of the same rank in ONE launch (they run side by side); false: not available for this rank
 // done_word (optional): set to done_value (release, agent scope) when THIS decomposition's outputs are complete — or when it

@@ -170,6 +170,7 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
   const int first = (bx * kSearchBlock + (threadIdx.x & ~63)) * kSpheresPerLane;  // list position of lane 0's first sphere
                                                                                   // (candidates are named by position: see surface_resolve)
   const int lane = threadIdx.x & 63;
+  unsigned n_ball = 0, n_sphere = 0;  // (wave-uniform; reported only when profiling)
   for (int kt = k0; kt < k1; kt += kSurfaceTile) {
     // this workgroup's queries go through LDS: one coalesced read per tile; the loops below never wait for global memory
     const int nq = min(kSurfaceTile, k1 - kt);
@@ -196,6 +197,8 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
         near = dx * dx + dy * dy + dz * dz <= lim * lim;  // (sentinel slots sit at 1e30 with bound 0: never; bound +inf: always)
       }
       unsigned long long todo = __ballot(near);
+      n_ball += (unsigned)min(64, nq - g);
+      n_sphere += (unsigned)__popcll(todo);
       while (todo) {  // wave-uniform: the surviving queries, each against the lanes' spheres
         const int j = g + __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -214,6 +217,10 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
     }
   }
   settle_hits(ph, q.cnt, q.cand, q.stride, first, kSpheresPerLane);
+  if (q.stats && lane == 0) {
+    atomicAdd(q.stats + 0, (unsigned long long)n_ball);
+    atomicAdd(q.stats + 1, (unsigned long long)n_sphere * 64ull * kSpheresPerLane);
+  }
 }
 
 // one wave per query.  Returns (all lanes) the winner, its squared distance and its closest point; lane 0 writes the
@@ -269,6 +276,7 @@ __device__ __forceinline__ void surface_resolve(const SurfaceTask& q, int k, dou
     if (q.d2) q.d2[k] = best;
     if (q.tri) q.tri[k] = bi == kNoIndex ? -1 : bi;
     if (q.hint) q.hint[k] = bi == kNoIndex ? -1 : bi;
+    if (q.stats) atomicAdd(q.stats + 2, (unsigned long long)(listed ? n : q.T));  // (an overflowed list: at most T, through the spheres)
   }
   *best_out = best;
   *tri_out = bi;
@@ -353,6 +361,7 @@ __device__ __forceinline__ void vertex_filter(const VertexTask& q, int bx, int b
     }
   }
   settle_hits(ph, q.cnt, q.cand, q.stride, first, 1);
+  if (q.stats && (threadIdx.x & 63) == 0) atomicAdd(q.stats + 3, 64ull * (unsigned long long)(k1 > k0 ? k1 - k0 : 0));
 }
 
 __device__ __forceinline__ void vertex_resolve(const VertexTask& q, int k, double* best_out, int* idx_out) {
@@ -373,6 +382,7 @@ __device__ __forceinline__ void vertex_resolve(const VertexTask& q, int k, doubl
     if (q.d2) q.d2[k] = best;
     if (q.idx) q.idx[k] = bi == kNoIndex ? -1 : bi;
     if (q.hint) q.hint[k] = bi == kNoIndex ? -1 : bi;
+    if (q.stats) atomicAdd(q.stats + 4, (unsigned long long)(listed ? n : q.V));
   }
   *best_out = best;
   *idx_out = bi;

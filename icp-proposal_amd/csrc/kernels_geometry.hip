@@ -132,6 +132,7 @@ SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const
   q.P = P; q.verts = verts; q.tris = tris; q.spheres = spheres; q.order = nullptr; q.hint = hint;
   q.qrec = qb.qrec; q.thrA = qb.thrA; q.cnt = qb.cnt; q.cand = qb.cand;
   q.cp = cp; q.d2 = d2; q.tri = tri;
+  q.stats = g_prof ? g_prof->counters : nullptr;
   q.tblocks = cdiv(T > 0 ? T : 1, kBlock * kSpheresPerLane);
   split_surface_queries(q.Kpad, &q.ksplit, &q.kchunk);
   return q;
@@ -141,6 +142,7 @@ VertexTask make_vertex_task(int V, const double* verts, int K, const double* P, 
   VertexTask q{};
   q.K = K; q.Kpad = (K + kQU - 1) / kQU * kQU; q.V = V; q.stride = cand_stride_for(V, K, qb.cand_capacity);
   q.P = P; q.verts = verts; q.hint = hint; q.thr2 = qb.thr2; q.cnt = qb.cnt; q.cand = qb.cand; q.d2 = d2; q.idx = idx;
+  q.stats = g_prof ? g_prof->counters : nullptr;
   q.vblocks = cdiv(V > 0 ? V : 1, kBlock);
   split_queries(q.vblocks, q.Kpad, &q.ksplit, &q.kchunk);
   return q;

@@ -1062,6 +1062,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
         if (__builtin_amdgcn_s_memrealtime() - t0 > 500000) { s_cancel = 2; break; }
         __builtin_amdgcn_s_sleep(32);
       }
+      if (spec.wait_ticks) atomicAdd((unsigned long long*)spec.wait_ticks, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - t0));
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (acquire side for the plain loads of the partials below)
@@ -2105,7 +2106,7 @@ inline EigenProblem eigen_rr_problem(int r, const EigenRequest& rq) {
   double* vpos = rq.work + log_doubles;
   const int launch_id = 1 + (int)((unsigned)(++launch_counter) % kPwIdMask);  // never 0: the idle value of the progress word
   return EigenProblem{rq.M, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.status, rq.work, (int*)(vpos + (size_t)n2 * 64), vpos,
-                      rq.spec ? *rq.spec : EigenSpec{0, nullptr, 0, nullptr, 0}, launch_id, rq.host_status, rq.done_word,
+                      rq.spec ? *rq.spec : EigenSpec{0, nullptr, 0, nullptr, 0, nullptr}, launch_id, rq.host_status, rq.done_word,
                       rq.done_value, rq.sqrt_lambda};
 }
 template <class Batch>
@@ -2188,7 +2189,9 @@ int launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest
   if (!(r >= 3 && r <= 64 && !force_generic) || n < 1) return -1;
   // ONE launch while all of its workgroups can be resident together on an otherwise idle chip (a replay workgroup waits for its
   // neighbour at the sign exchange): 240 workgroups; more problems than that follow in a second launch on the same stream
-  const int per = eigen_rr_per(r), chunk = 240 / per;
+  // (test hook ICP_TEST_EIGEN_CHUNK: round 2's 24 per launch, for tools/r3_timeout_repro.py)
+  static const int chunk_hook = dev_env("ICP_TEST_EIGEN_CHUNK") ? std::atoi(dev_env("ICP_TEST_EIGEN_CHUNK")) : 0;
+  const int per = eigen_rr_per(r), chunk = chunk_hook > 0 ? chunk_hook : 240 / per;
   EigenProblem* rec = (EigenProblem*)pinned_records;
   for (int i = 0; i < n; ++i) rec[i] = eigen_rr_problem(r, rq[i]);
   for (int i = 0; i < n; i += chunk) {

@@ -10,8 +10,58 @@ import numpy as np
 
 
 def assign_work_items(n_items: int, world_size: int):
-    """Round-robin: item i -> rank i % world_size.  Returns a list (per rank) of item indices; sizes differ by <= 1."""
+    """Round-robin: item i -> rank i % world_size.  Returns a list (per rank) of item indices; sizes differ by <= 1.
+    (Independent chains on ONE target: RunMHRandomInitComparison-style jobs.  Batch registration uses assign_target_major.)"""
     return [list(range(rk, n_items, world_size)) for rk in range(world_size)]
+
+
+def assign_target_major(n_targets: int, n_chains: int, world_size: int):
+    """(target, chain) work items of a batch registration (item k = target k // n_chains, chain k % n_chains) over the ranks,
+    TARGET-MAJOR: loads differ by at most one item, and a rank meets as few targets as that allows — every target a rank meets costs
+    it a context (the target's upload, its sphere hierarchy, cold first searches of 0.6-3.4 ms), and chains of one target on one
+    rank can share launches.  Round-robin made every rank meet every target (10 targets x 10 chains over 8 ranks: 10 contexts per
+    rank instead of 2).
+
+    1. quotas: n_items // world (+1 for the first n_items % world ranks);
+    2. whole targets go to the rank with the largest remaining quota while one fits (longest-processing-time order);
+    3. a target that fits nowhere whole is cut into pieces that FILL ranks' remaining quotas exactly where a subset of them adds up to
+       n_chains (subset sum over <= world numbers), else dealt to the largest remaining quotas in turn.
+    Returns a list (per rank) of item indices in target-major order."""
+    n_items = n_targets * n_chains
+    quota = [n_items // world_size + (1 if rk < n_items % world_size else 0) for rk in range(world_size)]
+    out = [[] for _ in range(world_size)]
+    split = []
+    for t in range(n_targets):
+        rk = max(range(world_size), key=lambda k: (quota[k], -k))
+        if quota[rk] >= n_chains:
+            out[rk] += list(range(t * n_chains, (t + 1) * n_chains))
+            quota[rk] -= n_chains
+        else:
+            split.append(t)
+    for t in split:
+        chains = list(range(t * n_chains, (t + 1) * n_chains))
+        # subset of ranks whose remaining quotas add up to exactly n_chains (prefer few, large pieces)
+        order = sorted((k for k in range(world_size) if quota[k] > 0), key=lambda k: (-quota[k], k))
+        reach = {0: []}
+        for k in order:
+            for tot, used in sorted(reach.items(), reverse=True):
+                nt = tot + quota[k]
+                if nt <= n_chains and nt not in reach:
+                    reach[nt] = used + [k]
+        ranks = reach.get(n_chains)
+        if ranks is None:  # no exact fill: largest remaining quotas in turn
+            ranks = order
+        for k in ranks:
+            take = min(quota[k], len(chains))
+            out[k] += chains[:take]
+            chains = chains[take:]
+            quota[k] -= take
+            if not chains:
+                break
+        assert not chains, "internal: work items left unassigned"
+    for o in out:
+        o.sort()
+    return out
 
 
 def gather_records(records: np.ndarray, dist=None, device=None):
@@ -62,55 +112,63 @@ def gather_ragged(blocks, dist=None, device=None):
 
 
 def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist=None, device_index: int = 0, base_seed: int = 1024,
-              chains_per_launch: int = 1):
+              chains_per_launch: int = 1, return_stats: bool = False):
     """Batch registration (BASELINE.json configs[4]; reference: the 10-way target pool × per-target chain loop of
-    apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala:106-163): work items = (target, chain) pairs, dealt round-robin
-    over the ranks; a rank keeps ONE context per target it meets; chains never communicate; the per-step records of all items
-    are exchanged with a single all_gather at the end.  Returns (items, records): items[k] = (target index, chain index) and
-    records[k] = [n_steps, 14 + rank] for every item of the whole job, in item order, on every rank.
-    chains_per_launch > 1: the rank steps that many of its chains in lockstep through icp_chain_step_batched (one context per
-    chain; SURVEY.md §8e "within a GPU, batch B chains per launch") — same records, chain by chain."""
+    apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala:106-163): work items = (target, chain) pairs, dealt target-major
+    over the ranks (assign_target_major); a rank keeps ONE context per target it meets; chains never communicate; the per-step
+    records of all items are exchanged with a single all_gather at the end.  Returns (items, records): items[k] = (target index,
+    chain index) and records[k] = [n_steps, 14 + rank] for every item of the whole job, in item order, on every rank.
+    chains_per_launch > 1: the rank steps that many of its chains OF ONE TARGET in lockstep through icp_chain_step_batched (one
+    context per chain — model and target are shared between them on the device; SURVEY.md §8e "within a GPU, batch B chains per
+    launch") — same records, chain by chain.
+    return_stats: a third value, this rank's {items, contexts_built, targets_met, chain_ms, gather_ms}."""
+    import time
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
     items = [(t, c) for t in range(len(targets)) for c in range(n_chains)]
-    mine = assign_work_items(len(items), world)[rank]
-    blocks, ctx, ctx_target = [], None, -1
-    order = sorted(mine, key=lambda k: items[k][0])
-    if chains_per_launch > 1:
-        for g0 in range(0, len(order), chains_per_launch):
-            group = order[g0:g0 + chains_per_launch]
-            ctxs = [pkg.IcpContext(model, targets[items[k][0]], device=device_index) for k in group]
-            chains = [pkg.SamplingRegistration(cx, make_setup(model, targets[items[k][0]]),
-                                               pkg.random_initial_parameters(model, items[k][1], base_seed),
-                                               seed=base_seed + 1000 * items[k][0] + items[k][1]) for cx, k in zip(ctxs, group)]
-            for k, rec in zip(group, pkg.run_chains_batched(chains, n_steps)):
+    mine = assign_target_major(len(targets), n_chains, world)[rank]
+    blocks = []
+    contexts_built = 0
+    t_start = time.perf_counter()
+    my_targets = sorted(set(items[k][0] for k in mine))
+    for t in my_targets:
+        ks = [k for k in mine if items[k][0] == t]
+        setup = make_setup(model, targets[t])
+        theta0 = lambda k: pkg.random_initial_parameters(model, items[k][1], base_seed)
+        seed = lambda k: base_seed + 1000 * t + items[k][1]
+        if chains_per_launch > 1:
+            for g0 in range(0, len(ks), chains_per_launch):
+                group = ks[g0:g0 + chains_per_launch]
+                ctxs = [pkg.IcpContext(model, targets[t], device=device_index) for _ in group]
+                contexts_built += len(ctxs)
+                chains = [pkg.SamplingRegistration(cx, setup, theta0(k), seed=seed(k)) for cx, k in zip(ctxs, group)]
+                for k, rec in zip(group, pkg.run_chains_batched(chains, n_steps)):
+                    rec[:, 0] = k                              # the record's index field carries the item id across the gather
+                    blocks.append(rec)
+                for ch in chains:
+                    ch.close()
+                for cx in ctxs:
+                    cx.close()
+        else:                                                  # one context per target, its chains one after the other
+            ctx = pkg.IcpContext(model, targets[t], device=device_index)
+            contexts_built += 1
+            for k in ks:
+                chain = pkg.SamplingRegistration(ctx, setup, theta0(k), seed=seed(k))
+                rec = chain.run(n_steps)
                 rec[:, 0] = k
                 blocks.append(rec)
-            for ch in chains:
-                ch.close()
-            for cx in ctxs:
-                cx.close()
-        order = []
-    for k in order:                                            # target-major: one context per target
-        t, c = items[k]
-        if t != ctx_target:
-            if ctx is not None:
-                ctx.close()
-            ctx, ctx_target = pkg.IcpContext(model, targets[t], device=device_index), t
-        chain = pkg.SamplingRegistration(ctx, make_setup(model, targets[t]), pkg.random_initial_parameters(model, c, base_seed),
-                                         seed=base_seed + 1000 * t + c)
-        rec = chain.run(n_steps)
-        rec[:, 0] = k                                          # the record's index field carries the item id across the gather
-        blocks.append(rec)
-        chain.close()
-    if ctx is not None:
-        ctx.close()
+                chain.close()
+            ctx.close()
+    t_chains = time.perf_counter()
     import torch
     dev = torch.device("cuda", device_index) if (dist is not None and dist.is_initialized() and dist.get_backend() == "nccl") else None
     per_rank = gather_ragged(blocks, dist, dev)
+    t_gather = time.perf_counter()
     out = [None] * len(items)
     for blocks_r in per_rank:
         for b in blocks_r:
             out[int(b[0, 0])] = b
+    if return_stats:
+        return items, out, dict(items=len(mine), contexts_built=contexts_built, targets_met=len(my_targets),
+                                chain_ms=1e3 * (t_chains - t_start), gather_ms=1e3 * (t_gather - t_chains))
     return items, out
-

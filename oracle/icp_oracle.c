@@ -24,6 +24,11 @@
 #include <string.h>
 
 #include "icp_spatial.h"
+#ifdef _OPENMP
+#include <omp.h>
+#else
+static inline int omp_get_max_threads(void) { return 1; }
+#endif
 
 #define ORC_API __attribute__((visibility("default")))
 
@@ -234,28 +239,39 @@ ORC_API void orc_vertex_normals(const orc_model *m, const double *x, double *nor
 
 /* Scalismo UnstructuredPoints.findClosestPoint: exact NN; here brute force, lowest index wins ties.
  * d² evaluated as (dx·dx + dy·dy) + dz·dz. */
+static void nearest_vertex_scan(const double *q, int M, const double *pts, int *idx, double *d2) {
+  double best = INFINITY;
+  int bi = -1;
+  for (int i = 0; i < M; ++i) {
+    double d[3];
+    sub3(q, pts + 3 * i, d);
+    double dd = dot3(d, d);
+    if (dd < best) { best = dd; bi = i; }
+  }
+  *idx = bi;
+  if (d2) *d2 = best;
+}
+
 ORC_API void orc_nearest_vertex(int K, const double *q, int M, const double *pts, int *idx, double *d2) {
   const int backend = orc_get_search_backend();  /* icp_spatial.h: the CPU-baseline variants B1 / B2, same results */
-  if (backend != ORC_SEARCH_BRUTE) {
+  if (backend == ORC_SEARCH_TREES) {
     for (int k = 0; k < K; ++k) {
       double dd;
-      idx[k] = backend == ORC_SEARCH_TREES ? spatial_nearest_vertex(q + 3 * k, M, pts, &dd) : spatial_nearest_vertex_omp(q + 3 * k, M, pts, &dd);
+      idx[k] = spatial_nearest_vertex(q + 3 * k, M, pts, &dd);
       if (d2) d2[k] = dd;
     }
     return;
   }
-  for (int k = 0; k < K; ++k) {
-    double best = INFINITY;
-    int bi = -1;
-    for (int i = 0; i < M; ++i) {
-      double d[3];
-      sub3(q + 3 * k, pts + 3 * i, d);
-      double dd = dot3(d, d);
-      if (dd < best) { best = dd; bi = i; }
-    }
-    idx[k] = bi;
-    if (d2) d2[k] = best;
+  if (backend == ORC_SEARCH_BRUTE_OMP && K > 1) {
+    /* B2: the K independent queries of a batch over the host cores, every query the sequential scan below (same result, same
+     * tie-break: lowest index).  (Round 2 split the scan of ONE query over the threads with a critical section at the end:
+     * 32 threads were slower than one.) */
+    const int nt = orc_get_search_threads();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nt > 0 ? nt : omp_get_max_threads())
+    for (int k = 0; k < K; ++k) nearest_vertex_scan(q + 3 * k, M, pts, idx + k, d2 ? d2 + k : NULL);
+    return;
   }
+  for (int k = 0; k < K; ++k) nearest_vertex_scan(q + 3 * k, M, pts, idx + k, d2 ? d2 + k : NULL);
 }
 
 /* Closest point on triangle (a,b,c) to p — Voronoi-region method (Ericson, Real-Time Collision Detection §5.1.5).
@@ -295,33 +311,40 @@ static void closest_point_triangle(const double *p, const double *a, const doubl
 }
 
 /* mesh.operations.closestPointOnSurface(p).point: brute force over all triangles, lowest (d², triangle id) wins */
+static void closest_on_surface_scan(const double *q, const double *pts, int T, const int *tris, double *cp, int *tri_idx, double *d2) {
+  double best = INFINITY, bp[3] = {0, 0, 0};
+  int bi = -1;
+  for (int t = 0; t < T; ++t) {
+    double o[3], d[3];
+    closest_point_triangle(q, pts + 3 * tris[3 * t], pts + 3 * tris[3 * t + 1], pts + 3 * tris[3 * t + 2], o);
+    sub3(q, o, d);
+    double dd = dot3(d, d);
+    if (dd < best) { best = dd; bi = t; bp[0] = o[0]; bp[1] = o[1]; bp[2] = o[2]; }
+  }
+  cp[0] = bp[0]; cp[1] = bp[1]; cp[2] = bp[2];
+  if (tri_idx) *tri_idx = bi;
+  if (d2) *d2 = best;
+}
+
 ORC_API void orc_closest_point_on_surface(int K, const double *q, const double *pts, int T, const int *tris,
                                           double *cp, int *tri_idx, double *d2) {
   const int backend = orc_get_search_backend();  /* icp_spatial.h */
-  if (backend != ORC_SEARCH_BRUTE) {
+  if (backend == ORC_SEARCH_TREES) {
     for (int k = 0; k < K; ++k) {
       double dd;
-      const int bi = backend == ORC_SEARCH_TREES ? spatial_closest_on_surface(q + 3 * k, pts, T, tris, closest_point_triangle, cp + 3 * k, &dd)
-                                                 : spatial_closest_on_surface_omp(q + 3 * k, pts, T, tris, closest_point_triangle, cp + 3 * k, &dd);
+      const int bi = spatial_closest_on_surface(q + 3 * k, pts, T, tris, closest_point_triangle, cp + 3 * k, &dd);
       if (tri_idx) tri_idx[k] = bi;
       if (d2) d2[k] = dd;
     }
     return;
   }
-  for (int k = 0; k < K; ++k) {
-    double best = INFINITY, bp[3] = {0, 0, 0};
-    int bi = -1;
-    for (int t = 0; t < T; ++t) {
-      double o[3], d[3];
-      closest_point_triangle(q + 3 * k, pts + 3 * tris[3 * t], pts + 3 * tris[3 * t + 1], pts + 3 * tris[3 * t + 2], o);
-      sub3(q + 3 * k, o, d);
-      double dd = dot3(d, d);
-      if (dd < best) { best = dd; bi = t; bp[0] = o[0]; bp[1] = o[1]; bp[2] = o[2]; }
-    }
-    cp[3 * k] = bp[0]; cp[3 * k + 1] = bp[1]; cp[3 * k + 2] = bp[2];
-    if (tri_idx) tri_idx[k] = bi;
-    if (d2) d2[k] = best;
+  if (backend == ORC_SEARCH_BRUTE_OMP && K > 1) { /* B2: queries over the cores (see orc_nearest_vertex) */
+    const int nt = orc_get_search_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt > 0 ? nt : omp_get_max_threads())
+    for (int k = 0; k < K; ++k) closest_on_surface_scan(q + 3 * k, pts, T, tris, cp + 3 * k, tri_idx ? tri_idx + k : NULL, d2 ? d2 + k : NULL);
+    return;
   }
+  for (int k = 0; k < K; ++k) closest_on_surface_scan(q + 3 * k, pts, T, tris, cp + 3 * k, tri_idx ? tri_idx + k : NULL, d2 ? d2 + k : NULL);
 }
 
 /* ------------------------------------------------------------------ a6: surface-normal dependent noise
@@ -492,23 +515,26 @@ ORC_API int orc_icp_posterior(const orc_model *m, const orc_mesh *tgt, const orc
   out->K = K;
   double *obs = (double *)malloc(sizeof(double) * 3 * (K > 0 ? K : 1));   /* y_i */
   double *Linv = (double *)malloc(sizeof(double) * 9 * (K > 0 ? K : 1));  /* Σ_i^-1 */
+  /* the K searches first, as ONE batch of independent queries (the CPU-baseline back ends may spread them over cores; per query
+   * the result is the same scan), then the per-correspondence arithmetic in the reference's order */
+  int *ids = (int *)malloc(sizeof(int) * (K > 0 ? K : 1)), *tids = (int *)malloc(sizeof(int) * (K > 0 ? K : 1));
+  double *tps = (double *)malloc(sizeof(double) * 3 * (K > 0 ? K : 1));
+  if (pp->direction == 1) { /* targetBasedClosestPointsEstimation :112-131 */
+    orc_nearest_vertex(K, pp->target_pts, N, x, ids, NULL);         /* :118 */
+    memcpy(tps, pp->target_pts, sizeof(double) * 3 * K);            /* :117 */
+    for (int k = 0; k < K; ++k) tids[k] = -1;
+  } else { /* modelBasedClosestPointsEstimation :89-110 */
+    for (int k = 0; k < K; ++k) ids[k] = k;                         /* :94 ids 0 until K_m index the FULL mesh (:96) */
+    orc_closest_point_on_surface(K, x, tgt->pts, tgt->T, tgt->tris, tps, NULL, NULL); /* :97 (x + 3·id, id = k) */
+    orc_nearest_vertex(K, tps, tgt->M, tgt->pts, tids, NULL);       /* :98 */
+  }
   for (int k = 0; k < K; ++k) {
-    int id, on_boundary;
-    double tp[3], nrm[3], cov[9], back[3];
-    if (pp->direction == 1) { /* targetBasedClosestPointsEstimation :112-131 */
-      const double *q = pp->target_pts + 3 * k;                     /* :117 */
-      orc_nearest_vertex(1, q, N, x, &id, NULL);                    /* :118 */
-      on_boundary = m->boundary[id];                                /* :119 currentMesh has the model's triangulation */
-      tp[0] = q[0]; tp[1] = q[1]; tp[2] = q[2];
-      out->corr_aux[k] = -1;
-    } else { /* modelBasedClosestPointsEstimation :89-110 */
-      id = k;                                                       /* :94 ids 0 until K_m index the FULL mesh (:96) */
-      int tid;
-      orc_closest_point_on_surface(1, x + 3 * id, tgt->pts, tgt->T, tgt->tris, tp, NULL, NULL); /* :97 */
-      orc_nearest_vertex(1, tp, tgt->M, tgt->pts, &tid, NULL);      /* :98 */
-      on_boundary = tgt->boundary[tid];                             /* :99 */
-      out->corr_aux[k] = tid;
-    }
+    const int id = ids[k];
+    double nrm[3], cov[9], back[3];
+    const double *tp = tps + 3 * k;
+    /* :119 currentMesh has the model's triangulation / :99 */
+    const int on_boundary = pp->direction == 1 ? m->boundary[id] : tgt->boundary[tids[k]];
+    out->corr_aux[k] = tids[k];
     vertex_normal(x, m->tris, m->adj_off, m->adj, id, nrm);         /* :100 / :120 */
     orc_surface_noise_cov(nrm, pp->noise_along_normal, pp->tangential_noise, cov);
     inv3(cov, Linv + 9 * k);
@@ -518,6 +544,7 @@ ORC_API int orc_icp_posterior(const orc_model *m, const orc_mesh *tgt, const orc
     inverse_pose(theta, tp, back);                                  /* :108 / :129 */
     for (int d = 0; d < 3; ++d) obs[3 * k + d] = back[d] - m->ref[3 * id + d];
   }
+  free(ids); free(tids); free(tps);
   /* regression: M = Q^T L Q + I,  α = Minv (Q^T L)(y − m) */
   double *M = out->M, *b = (double *)calloc((size_t)r, sizeof(double));
   for (int i = 0; i < r; ++i)
@@ -814,12 +841,17 @@ ORC_API double orc_prior_log_value(int r, const double *theta) {
   return -0.5 * nn - 0.5 * r * log(2.0 * M_PI);
 }
 
-static double point_surface_distance(const double *p, const double *pts, int T, const int *tris, double *cp_out) {
-  double cp[3], d[3];
-  orc_closest_point_on_surface(1, p, pts, T, tris, cp, NULL, NULL);
-  sub3(cp, p, d);
-  if (cp_out) { cp_out[0] = cp[0]; cp_out[1] = cp[1]; cp_out[2] = cp[2]; }
-  return sqrt(dot3(d, d));
+/* distances of K points to a surface, the K searches as ONE batch of independent queries (see orc_icp_posterior):
+ * dist[k] = |closestPointOnSurface(p_k) − p_k|, cp (optional) = the closest points */
+static void point_surface_distances(int K, const double *p, const double *pts, int T, const int *tris, double *dist, double *cp_out) {
+  double *cp = cp_out ? cp_out : (double *)malloc(sizeof(double) * 3 * (K > 0 ? K : 1));
+  orc_closest_point_on_surface(K, p, pts, T, tris, cp, NULL, NULL);
+  for (int k = 0; k < K; ++k) {
+    double d[3];
+    sub3(cp + 3 * k, p + 3 * k, d);
+    dist[k] = sqrt(dot3(d, d));
+  }
+  if (!cp_out) free(cp);
 }
 
 ORC_API int orc_evaluator_log_value(const orc_model *m, const orc_mesh *tgt, const orc_evaluator_params *ep,
@@ -828,72 +860,72 @@ ORC_API int orc_evaluator_log_value(const orc_model *m, const orc_mesh *tgt, con
   double *x = (double *)malloc(sizeof(double) * 3 * N);
   orc_instance(m, theta, x);
   int rc = 0;
+  const int Kmax = ep->kind == 1 ? (N > tgt->M ? N : tgt->M) : (ep->n_model_ids > ep->n_target_pts ? ep->n_model_ids : ep->n_target_pts);
+  double *dist = (double *)malloc(sizeof(double) * (Kmax > 0 ? Kmax : 1));
   if (ep->kind == 0) {
     /* ref: evaluators/IndependentPointDistanceEvaluator.scala:40-66 */
     double m2t = 0.0, t2m = 0.0;
-    if (ep->mode == 0 || ep->mode == 2)
-      for (int k = 0; k < ep->n_model_ids; ++k)                  /* :41 ids 0 until K_e of the full sample mesh */
-        m2t += gauss_logpdf(point_surface_distance(x + 3 * k, tgt->pts, tgt->T, tgt->tris, NULL), ep->p0, ep->p1); /* :43 */
-    if (ep->mode == 1 || ep->mode == 2)
-      for (int k = 0; k < ep->n_target_pts; ++k)                 /* :50-52 */
-        t2m += gauss_logpdf(point_surface_distance(ep->target_pts + 3 * k, x, m->T, m->tris, NULL), ep->p0, ep->p1);
+    if (ep->mode == 0 || ep->mode == 2) {
+      point_surface_distances(ep->n_model_ids, x, tgt->pts, tgt->T, tgt->tris, dist, NULL); /* :41 ids 0 until K_e of the full sample mesh, :43 */
+      for (int k = 0; k < ep->n_model_ids; ++k) m2t += gauss_logpdf(dist[k], ep->p0, ep->p1);
+    }
+    if (ep->mode == 1 || ep->mode == 2) {
+      point_surface_distances(ep->n_target_pts, ep->target_pts, x, m->T, m->tris, dist, NULL); /* :50-52 */
+      for (int k = 0; k < ep->n_target_pts; ++k) t2m += gauss_logpdf(dist[k], ep->p0, ep->p1);
+    }
     *out = ep->mode == 0 ? m2t : ep->mode == 1 ? t2m : 0.5 * m2t + 0.5 * t2m; /* :60-64 */
   } else if (ep->kind == 1) {
     /* ref: evaluators/HausdorffDistanceEvaluator.scala:31-35; MeshMetrics.hausdorffDistance = max over both
      * directions of vertex -> closest-surface-point distance (SURVEY App. B7 [SCALISMO-UNVERIFIED]) */
     double hd = 0.0;
-    for (int i = 0; i < N; ++i) {
-      double d = point_surface_distance(x + 3 * i, tgt->pts, tgt->T, tgt->tris, NULL);
-      if (d > hd) hd = d;
-    }
-    for (int i = 0; i < tgt->M; ++i) {
-      double d = point_surface_distance(tgt->pts + 3 * i, x, m->T, m->tris, NULL);
-      if (d > hd) hd = d;
-    }
+    point_surface_distances(N, x, tgt->pts, tgt->T, tgt->tris, dist, NULL);
+    for (int i = 0; i < N; ++i)
+      if (dist[i] > hd) hd = dist[i];
+    point_surface_distances(tgt->M, tgt->pts, x, m->T, m->tris, dist, NULL);
+    for (int i = 0; i < tgt->M; ++i)
+      if (dist[i] > hd) hd = dist[i];
     *out = expo_logpdf(hd, ep->p0);
   } else {
     /* ref: evaluators/CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:40-78 */
     double avg[2] = {0, 0}, mx[2] = {0, 0};
-    int used[2] = {0, 0};
+    double *cps = (double *)malloc(sizeof(double) * 3 * (Kmax > 0 ? Kmax : 1));
+    int *vids = (int *)malloc(sizeof(int) * (Kmax > 0 ? Kmax : 1));
     if (ep->mode == 0 || ep->mode == 2) {                        /* distModelToTarget :40-52 */
       double sum = 0.0, mxx = -INFINITY;
       int cnt = 0;
+      point_surface_distances(ep->n_model_ids, x, tgt->pts, tgt->T, tgt->tris, dist, cps); /* :45 */
+      orc_nearest_vertex(ep->n_model_ids, cps, tgt->M, tgt->pts, vids, NULL);              /* :46 */
       for (int k = 0; k < ep->n_model_ids; ++k) {
-        double cp[3];
-        int tid;
-        double d = point_surface_distance(x + 3 * k, tgt->pts, tgt->T, tgt->tris, cp); /* :45 */
-        orc_nearest_vertex(1, cp, tgt->M, tgt->pts, &tid, NULL);                       /* :46 */
-        if (tgt->boundary[tid]) continue;                                              /* :47 */
-        sum += d; cnt++;
-        if (d > mxx) mxx = d;
+        if (tgt->boundary[vids[k]]) continue;                                              /* :47 */
+        sum += dist[k]; cnt++;
+        if (dist[k] > mxx) mxx = dist[k];
       }
-      avg[0] = sum / cnt; mx[0] = mxx; used[0] = 1;              /* :51 (empty list: NaN / exception in the reference) */
+      avg[0] = sum / cnt; mx[0] = mxx;                           /* :51 (empty list: NaN / exception in the reference) */
       if (cnt == 0) rc = -2;
     }
     if (ep->mode == 1 || ep->mode == 2) {                        /* distTargetToModel :54-65 */
       double sum = 0.0, mxx = -INFINITY;
       int cnt = 0;
+      point_surface_distances(ep->n_target_pts, ep->target_pts, x, m->T, m->tris, dist, cps); /* :57 */
+      orc_nearest_vertex(ep->n_target_pts, cps, N, x, vids, NULL);                            /* :58 id in modelSample */
       for (int k = 0; k < ep->n_target_pts; ++k) {
-        double cp[3];
-        int vid;
-        double d = point_surface_distance(ep->target_pts + 3 * k, x, m->T, m->tris, cp); /* :57 */
-        orc_nearest_vertex(1, cp, N, x, &vid, NULL);                                      /* :58 id in modelSample */
         /* :59 (sic) tests the TARGET mesh's boundary flag with a model-sample vertex id;
          * an id beyond the target's vertex count is treated as "not on boundary". */
-        if (vid < tgt->M && tgt->boundary[vid]) continue;
-        sum += d; cnt++;
-        if (d > mxx) mxx = d;
+        if (vids[k] < tgt->M && tgt->boundary[vids[k]]) continue;
+        sum += dist[k]; cnt++;
+        if (dist[k] > mxx) mxx = dist[k];
       }
-      avg[1] = sum / cnt; mx[1] = mxx; used[1] = 1;
+      avg[1] = sum / cnt; mx[1] = mxx;
       if (cnt == 0) rc = -2;
     }
     double a, h;
     if (ep->mode == 0) { a = avg[0]; h = mx[0]; }
     else if (ep->mode == 1) { a = avg[1]; h = mx[1]; }
     else { a = 0.5 * avg[0] + 0.5 * avg[1]; h = fmax(mx[0], mx[1]); } /* :71-75 */
-    (void)used;
     *out = gauss_logpdf(a, ep->p0, ep->p1) + expo_logpdf(h, ep->p2);  /* :77 */
+    free(cps); free(vids);
   }
+  free(dist);
   free(x);
   return rc;
 }

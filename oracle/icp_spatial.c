@@ -25,6 +25,7 @@ static __thread long t_kd_builds = 0, t_bvh_builds = 0;
 
 void orc_set_search_backend(int backend, int n_threads) { t_backend = backend; t_threads = n_threads; }
 int orc_get_search_backend(void) { return t_backend; }
+int orc_get_search_threads(void) { return t_threads; }
 void orc_search_stats(long *kd, long *bvh) { if (kd) *kd = t_kd_builds; if (bvh) *bvh = t_bvh_builds; }
 
 static inline double d2_of(const double *a, const double *b) {
@@ -267,59 +268,6 @@ int spatial_closest_on_surface(const double *q, const double *pts, int T, const 
   return bi;
 }
 
-/* ---------------------------------------------------------------- B2: the brute-force scans over all cores */
-int spatial_nearest_vertex_omp(const double *q, int M, const double *pts, double *d2_out) {
-  double best = INFINITY;
-  int bi = -1;
-#ifdef _OPENMP
-  const int nt = t_threads > 0 ? t_threads : omp_get_max_threads();
-#pragma omp parallel num_threads(nt)
-#endif
-  {
-    double lb = INFINITY;
-    int li = -1;
-#ifdef _OPENMP
-#pragma omp for schedule(static) nowait
-#endif
-    for (int i = 0; i < M; ++i) {
-      const double dd = d2_of(q, pts + 3 * i);
-      if (dd < lb) { lb = dd; li = i; }
-    }
-#ifdef _OPENMP
-#pragma omp critical
-#endif
-    if (li >= 0 && (lb < best || (lb == best && li < bi))) { best = lb; bi = li; }
-  }
-  if (d2_out) *d2_out = best;
-  return bi;
-}
-
-int spatial_closest_on_surface_omp(const double *q, const double *pts, int T, const int *tris, orc_tri_kernel kernel, double *cp_out,
-                                   double *d2_out) {
-  double best = INFINITY, bp[3] = {0.0, 0.0, 0.0};
-  int bi = -1;
-#ifdef _OPENMP
-  const int nt = t_threads > 0 ? t_threads : omp_get_max_threads();
-#pragma omp parallel num_threads(nt)
-#endif
-  {
-    double lb = INFINITY, lp[3] = {0.0, 0.0, 0.0};
-    int li = -1;
-#ifdef _OPENMP
-#pragma omp for schedule(static) nowait
-#endif
-    for (int k = 0; k < T; ++k) {
-      double o[3];
-      kernel(q, pts + 3 * tris[3 * k], pts + 3 * tris[3 * k + 1], pts + 3 * tris[3 * k + 2], o);
-      const double dd = d2_of(q, o);
-      if (dd < lb) { lb = dd; li = k; lp[0] = o[0]; lp[1] = o[1]; lp[2] = o[2]; }
-    }
-#ifdef _OPENMP
-#pragma omp critical
-#endif
-    if (li >= 0 && (lb < best || (lb == best && li < bi))) { best = lb; bi = li; bp[0] = lp[0]; bp[1] = lp[1]; bp[2] = lp[2]; }
-  }
-  cp_out[0] = bp[0]; cp_out[1] = bp[1]; cp_out[2] = bp[2];
-  if (d2_out) *d2_out = best;
-  return bi;
-}
+/* ---------------------------------------------------------------- B2: the brute-force scans over all cores
+ * live in icp_oracle.c (orc_nearest_vertex / orc_closest_point_on_surface): the K independent queries of a batch are spread over
+ * the threads, every query the restatement's own sequential scan. */

@@ -29,3 +29,13 @@ def test_self_launch_reports_failing_rank():
     # MASTER settings come from the launcher itself; a rank that cannot run (bad flag) must make the parent exit non-zero
     p = _run(["--gpus", "2", "--selftest-launcher", "--config", "notanumber"])
     assert p.returncode != 0
+
+
+def test_config4_plumbing_two_ranks_gloo():
+    """`python bench.py --config 4 --gpus 2 --selftest-launcher`: BASELINE.json configs[4]'s plumbing without a GPU — the 10 x 10 work
+    items target-major over two self-launched ranks, fabricated records, the ragged gather, reassembly in item order."""
+    p = _run(["--gpus", "2", "--selftest-launcher", "--config", "4"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["selftest"] == "config4" and d["n_gpus"] == 2 and d["gather_ok"] is True
+    assert d["items_per_rank"] == [50, 50] and d["targets_per_rank"] == [5, 5]
