@@ -537,7 +537,15 @@ def roofline_leg(pkg, args, wl, ctx, chains, B, rate, line):
     else:
         pkg.run_chains_batched(chains, args.profile_steps, want_records=False)
     stats = ctx.profile_stop()
-    counts = {k[len("count."):]: int(v["calls"]) for k, v in stats.items() if k.startswith("count.")}
+    # a short leg of its own for the executed-test counts (the counting atomics slow the filter launches down: not for timing)
+    n_count = min(60, args.profile_steps)
+    ctx.profile_start(max_launches=80 * n_count + 2048, count_searches=True)
+    if B == 1:
+        chains[0].run(n_count, want_records=False)
+    else:
+        pkg.run_chains_batched(chains, n_count, want_records=False)
+    cstats = ctx.profile_stop()
+    counts = {k[len("count."):]: int(v["calls"]) for k, v in cstats.items() if k.startswith("count.")}
     stats = {k: v for k, v in stats.items() if not k.startswith("count.")}
     waits = {"k_step_begin": stats.pop("k_step_begin.device_wait", None), "k_posterior_eigen": stats.pop("k_posterior_eigen.device_wait", None)}
     busy = {}
@@ -601,7 +609,7 @@ def roofline_leg(pkg, args, wl, ctx, chains, B, rate, line):
                      % (100 * (1 - icp_share))}
     if counts:
         # executed tests per step, counted on the device during this leg (per wave): what the searches really did
-        n_st = max(args.profile_steps * B, 1)
+        n_st = max(n_count * B, 1)
         ex = {kk: vv / n_st for kk, vv in counts.items()}
         # flops actually executed by the searches: ball test ~11, sphere test ~11 (packed f32), exact point-triangle ~60 (f64),
         # exact point-vertex 8 (f64)

@@ -76,6 +76,7 @@ SIGNATURES = {
     "icp_proposal_create": (C.c_int, [C.c_void_p, C.POINTER(ProposalParams), C.POINTER(C.c_void_p)]),
     "icp_proposal_destroy": (None, [C.c_void_p]),
     "icp_proposal_num_candidates": (C.c_int, [C.c_void_p]),
+    "icp_proposal_set_sampler": (C.c_int, [C.c_void_p, C.c_int32]),
     "icp_proposal_propose": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_int_p]),
     "icp_proposal_log_transition": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "icp_proposal_posterior": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(PosteriorView)]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "icp_evaluator_log_value": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "icp_prior_log_value": (C.c_int, [C.c_int32, c_double_p, c_double_p]),
     "icp_ctx_profile_start": (C.c_int, [C.c_void_p, C.c_int32]),
+    "icp_ctx_profile_search_counters": (C.c_int, [C.c_void_p, C.c_int32]),
     "icp_ctx_set_idle_hook": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "icp_chain_step_prelaunch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "icp_ctx_profile_stop": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int32, C.POINTER(C.c_int32)]),

@@ -120,7 +120,10 @@ class IcpContext:
         """Fall-back counters of this context (icp_ctx_runtime_stats): all zero in a normal run."""
         return nat.runtime_stats(self.h)
 
-    def profile_start(self, max_launches: int = 200000):
+    def profile_start(self, max_launches: int = 200000, count_searches: bool = False):
+        """count_searches: also count the tests the searches execute (rows "count.*" of profile_stop; slows the filter launches
+        down — for a short leg of its own, not for timing)."""
+        nat.check(nat.lib().icp_ctx_profile_search_counters(self.h, int(count_searches)), "icp_ctx_profile_search_counters")
         nat.check(nat.lib().icp_ctx_profile_start(self.h, max_launches), "icp_ctx_profile_start")
 
     def profile_stop(self):
@@ -131,7 +134,7 @@ class IcpContext:
         out = {}
         for i in range(n.value):
             s = stats[i]
-            out[s.name.decode()] = dict(calls=s.calls, total_ms=s.total_ms, avg_us=1e3 * s.total_ms / s.calls,
+            out[s.name.decode()] = dict(calls=s.calls, total_ms=s.total_ms, avg_us=1e3 * s.total_ms / max(s.calls, 1),
                                         min_us=1e3 * s.min_ms, max_us=1e3 * s.max_ms)
         return out
 
@@ -221,6 +224,13 @@ class NonRigidIcpProposal:
         self.h = h
         self.K = nat.lib().icp_proposal_num_candidates(h)
         ctx._adopt(self)
+
+    def setSampler(self, sampler: str = "eigen"):
+        """icp_proposal_set_sampler: "eigen" (default; Scalismo's posterior.sample(), parity with the reference for a given z) or
+        "cholesky-root" (opt-in: the same distribution from W = D·L⁻ᵀ, no eigen-decomposition; ranks <= 64)."""
+        kind = {"eigen": 0, "cholesky-root": 1}[sampler]
+        nat.check(nat.lib().icp_proposal_set_sampler(self.h, kind), "icp_proposal_set_sampler")
+        return self
 
     def close(self):
         if getattr(self, "h", None) and getattr(self.ctx, "h", None):

@@ -323,6 +323,7 @@ struct icp_ctx {
   int* h_flag = nullptr;       // pinned: sequence number of the last finished step
   int step_seq = 0;
   std::vector<struct icp_evaluator*> evaluators;  // live evaluators (a proposal being destroyed drops their pending half steps)
+  std::vector<struct icp_proposal*> proposals;    // live proposals (icp_ctx_set_rotation forgets what they memoised under a triple)
   icp_idle_fn idle_fn = nullptr;  // icp_ctx_set_idle_hook
   void* idle_arg = nullptr;
   bool counted = false;          // included in g_live_contexts
@@ -335,6 +336,7 @@ struct icp_ctx {
   bool profiling = false;
   DBuf<long long> d_wait_ticks;  // profiling: time the steps' first launches spent waiting on the device (StepBeginArgs::wait_ticks)
   DBuf<unsigned long long> d_search_counters;  // profiling: executed tests of the searches (SurfaceTask::stats)
+  bool count_searches = false;                 // icp_ctx_profile_search_counters
   // argument arrays of the icp_chain_step_batched launches led by this context: pinned copy, device copy
   // (kBatchRing of each, used in turn: a caller may keep that many batches in flight on this context's stream)
   static constexpr int kBatchRing = 4;
@@ -641,6 +643,7 @@ struct icp_proposal {
   // Speculative decomposition (icp_chain_step, ICP_SPECULATION=1): the KL basis of the PROPOSED state's posterior is started as soon as its
   // normal matrix exists, before the caller has decided whether to accept.  The next call tells: its current state is
   // the proposed one (the basis is already on its way) or not (the decomposition is cancelled through `h_cancel`).
+  int sampler = ICP_SAMPLER_EIGEN; // icp_proposal_set_sampler: what the "decomposition" of a posterior writes into V / S
   int* h_eig = nullptr;            // pinned: eigen status of every memo entry, written by the decomposition itself
   DBuf<int> eig_words;             // per memo entry: sequence number of its last finished decomposition (EigenRequest::done_word)
   int eig_seq = 0;
@@ -912,6 +915,8 @@ void icp_proposal::prepare_eigen(PosteriorEntry& e, EigenRequest* rq) {
   if (((eig_seq + 1) & 127) == 0) warm_valid = false;
   *rq = EigenRequest{e.M.p, warm_valid ? warm_ptr : nullptr, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2, nullptr,
                      h_eig + e.status_off / 3, eig_words.p + e.status_off / 3, e.done_value, ctx->sqrt_lambda.p};
+  rq->root = sampler == ICP_SAMPLER_CHOLESKY_ROOT;
+  if (rq->root) rq->Vwarm = nullptr;
   warm_ptr = e.V.p;
   warm_valid = true;
   e.eig_valid = true;
@@ -1002,6 +1007,7 @@ void icp_proposal::speculate_eigen(PosteriorEntry& e, const PosteriorEntry& cur,
   e.done_value = ++eig_seq;
   *rq_out = EigenRequest{Mpart.p + (size_t)half * mpart_half_doubles, warm, e.V.p, e.Vt.p, e.S.p, work.p, status.p + e.status_off + 2,
                          spec_out, h_eig + e.status_off / 3, eig_words.p + e.status_off / 3, e.done_value};
+  rq_out->root = sampler == ICP_SAMPLER_CHOLESKY_ROOT;
   mpart_reader[half] = &e;
   e.eig_valid = true;
   e.eig_checked = false;
@@ -1439,6 +1445,8 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   delete ctx;
 }
 
+namespace { void release_front(StepFront& F); }
+
 int icp_ctx_set_rotation(icp_ctx* ctx, const double* angles, const double* R) {
   return guard([&] {
     require(ctx && angles, "null argument");
@@ -1447,8 +1455,44 @@ int icp_ctx_set_rotation(icp_ctx* ctx, const double* angles, const double* R) {
     icp_ctx::RotationEntry* slot = nullptr;
     for (auto& e : ctx->rotations)
       if (e.valid && e.angles[0] == angles[0] && e.angles[1] == angles[1] && e.angles[2] == angles[2]) { slot = &e; break; }
+    // Everything cached under a theta with these angles was posed with the matrix in force so far: whenever that changes — a first
+    // registration (the library's own convention until now), a replacement, a withdrawal, an eviction — the state slots, the
+    // posterior memo entries of every proposal and the evaluators' memoised values of such thetas are dropped.  (Pending half steps
+    // and decompositions in flight are drained first: they hold such entries.)
+    auto forget = [&](const double* a) {
+      auto same = [&](const std::vector<double>& th) { return th.size() >= 7 && th[4] == a[0] && th[5] == a[1] && th[6] == a[2]; };
+      bool any = false;
+      for (auto& sl : ctx->slots) any = any || (sl.valid && same(sl.theta));
+      for (icp_proposal* p : ctx->proposals)
+        for (int i = 0; i < kPosteriorMemo; ++i) any = any || (p->memo[i].valid && same(p->memo[i].theta));
+      for (icp_evaluator* ev : ctx->evaluators) {
+        for (auto& m : ev->memo) any = any || (m.valid && same(m.theta));
+        any = any || (ev->front.valid && same(ev->front.theta_cur));
+      }
+      if (!any) return;
+      if (ctx->batch_busy) throw IcpError{ICP_ERR_BUSY, "the context belongs to a batch in flight"};
+      ctx->bind();
+      HIP_OK(hipStreamSynchronize(ctx->stream));
+      HIP_OK(hipStreamSynchronize(ctx->front_stream));
+      sync_eigen(*ctx);
+      for (icp_evaluator* ev : ctx->evaluators) {
+        if (ev->front.valid) release_front(ev->front);
+        for (auto& m : ev->memo)
+          if (m.valid && same(m.theta)) m.valid = false;
+        ev->last_prop.clear();
+      }
+      for (auto& sl : ctx->slots)
+        if (sl.valid && same(sl.theta)) sl.valid = false;
+      for (icp_proposal* p : ctx->proposals) {
+        for (int i = 0; i < kPosteriorMemo; ++i) {
+          PosteriorEntry& en = p->memo[i];
+          if (en.valid && same(en.theta)) { en.valid = false; en.eig_valid = false; en.eig_checked = false; }
+        }
+        p->spec_entry = nullptr;
+      }
+    };
     if (!R) {  // withdraw the entry
-      if (slot) slot->valid = false;
+      if (slot) { slot->valid = false; forget(angles); }
       return;
     }
     // the matrix must be a rotation (orthonormal to 1e-9, determinant +1): a wrong layout would otherwise pass silently
@@ -1460,15 +1504,18 @@ int icp_ctx_set_rotation(icp_ctx* ctx, const double* angles, const double* R) {
       }
     const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
     require(det > 0.0, "R is a reflection, not a rotation");
-    if (!slot) {
+    if (slot) {  // replacement: only if the matrix really differs
+      bool differs = false;
+      for (int k = 0; k < 9; ++k) differs = differs || slot->R[k] != R[k];
+      if (differs) forget(angles);
+    } else {
       slot = &ctx->rotations[0];
       for (auto& e : ctx->rotations) {
         if (!e.valid) { slot = &e; break; }
         if (e.stamp < slot->stamp) slot = &e;
       }
-      // states cached under the same angles were posed with another matrix: forget them (and what hangs on them is keyed by theta, too)
-      for (auto& sl : ctx->slots)
-        if (sl.valid && sl.theta[4] == angles[0] && sl.theta[5] == angles[1] && sl.theta[6] == angles[2]) sl.valid = false;
+      if (slot->valid) forget(slot->angles);  // eviction: that triple falls back to the library's convention
+      forget(angles);
     }
     for (int k = 0; k < 3; ++k) slot->angles[k] = angles[k];
     for (int k = 0; k < 9; ++k) slot->R[k] = R[k];
@@ -1515,9 +1562,16 @@ int icp_ctx_profile_start(icp_ctx* ctx, int32_t max_launches) {
     ctx->d_wait_ticks.fill_bytes(0);
     if (!ctx->d_search_counters.p) ctx->d_search_counters.alloc(kSearchCounters);
     ctx->d_search_counters.fill_bytes(0);
-    ctx->prof.counters = ctx->d_search_counters.p;
+    ctx->prof.counters = ctx->count_searches ? ctx->d_search_counters.p : nullptr;
     ctx->profiling = true;
   });
+}
+
+int icp_ctx_profile_search_counters(icp_ctx* ctx, int32_t on) {
+  if (!ctx) return ICP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  ctx->count_searches = on != 0;
+  return ICP_OK;
 }
 
 int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity, int32_t* n_out) {
@@ -1572,7 +1626,7 @@ int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity,
     }
     {  // executed tests of the searches (counted per wave while profiling): rows "count.*", the number in `calls`
       unsigned long long cnt[kSearchCounters] = {};
-      if (ctx->d_search_counters.p) HIP_OK(hipMemcpy(cnt, ctx->d_search_counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+      if (ctx->d_search_counters.p && ctx->prof.counters) HIP_OK(hipMemcpy(cnt, ctx->d_search_counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
       static const char* names[5] = {"count.surface_ball_tests", "count.surface_sphere_tests", "count.surface_exact_tests",
                                      "count.vertex_filter_tests", "count.vertex_exact_tests"};
       for (int k = 0; k < 5; ++k)
@@ -1731,6 +1785,7 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     p->h_status.assign(3 * kPosteriorMemo, 0);
     p->memo.reset(new PosteriorEntry[kPosteriorMemo]);
     for (int i = 0; i < kPosteriorMemo; ++i) p->alloc_entry(p->memo[i]);
+    ctx->proposals.push_back(p);
     *out = p;
   });
   if (rc != ICP_OK && p) delete p;
@@ -1752,11 +1807,34 @@ void icp_proposal_destroy(icp_proposal* p) {
     if (g_host_timing.on && eigen_speculation_supported(p->ctx->r)) eigen_debug_dump(p->work.p, p->ctx->r);
     if (p->h_cancel) (void)hipHostFree(p->h_cancel);
     if (p->h_eig) (void)hipHostFree(p->h_eig);
+    auto& live = p->ctx->proposals;
+    live.erase(std::remove(live.begin(), live.end(), p), live.end());
     delete p;
   }
 }
 
 int icp_proposal_num_candidates(const icp_proposal* p) { return p ? p->K : ICP_ERR_INVALID_ARG; }
+
+int icp_proposal_set_sampler(icp_proposal* p, int32_t sampler) {
+  return guard([&] {
+    require(p != nullptr, "null argument");
+    require(sampler == ICP_SAMPLER_EIGEN || sampler == ICP_SAMPLER_CHOLESKY_ROOT, "unknown sampler");
+    icp_ctx& c = *p->ctx;
+    require(sampler == ICP_SAMPLER_EIGEN || eigen_speculation_supported(c.r), "the Cholesky-root sampler covers ranks 3..64");
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    if (p->sampler == sampler) return;
+    Bound _b(&c);
+    // whatever was decomposed (or is being decomposed) the other way is dropped: its V / S mean something else
+    HIP_OK(hipStreamSynchronize(c.stream));
+    sync_eigen(c);
+    for (icp_evaluator* ev : c.evaluators)
+      if (ev->front.valid && (ev->front.props[0] == p || ev->front.props[1] == p)) release_front(ev->front);
+    for (int i = 0; i < kPosteriorMemo; ++i) { p->memo[i].eig_valid = false; p->memo[i].eig_checked = false; }
+    p->spec_entry = nullptr;
+    p->warm_valid = false;
+    p->sampler = sampler;
+  });
+}
 
 int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, double* theta_out, int32_t* corr_id_out) {
   return guard([&] {

@@ -224,7 +224,9 @@ struct EigenRequest { const double* M; const double* Vwarm; double* V; double* V
                       const EigenSpec* spec; int* host_status; int* done_word; int done_value;
                       const double* sqrt_lambda = nullptr; /* of the request's own model; launch_posterior_eigen_many needs it */
                       bool direct = false; /* launch_posterior_eigen_pair: take the tridiagonal route (state-independent time) instead of
-                      the warm-started iteration — worth it while the chain moves fast (burn-in: the iteration needs 4 sweeps) */ };
+                      the warm-started iteration — worth it while the chain moves fast (burn-in: the iteration needs 4 sweeps) */
+                      bool root = false; /* write V := D·L⁻ᵀ (M = L·Lᵀ), S := 1 instead of the eigen-decomposition: the opt-in
+                      Cholesky-root sampler (kernels_posterior.hip: k_posterior_root; ranks <= 64) */ };
 bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq);
 // any number of decompositions of one rank (the chains of icp_chain_step_batched) in ONE launch (up to 80; more: a second launch on
 // the same stream); every request carries its model's sqrt_lambda.  pinned_records: eigen_many_record_bytes(n) bytes of pinned host

@@ -2134,6 +2134,147 @@ void launch_eigen_rr(hipStream_t st, int r, const double* sqrt_lambda, int n, co
 }
 }  // namespace
 
+// ---------------------------------------------------------------- opt-in: the Cholesky-root sampler (ranks <= 64)
+// The reference draws posterior.sample() in the eigenbasis of the posterior covariance (D M⁻¹ D = V S Vᵀ: the numbers z multiply
+// the columns of V√S) — that is what the kernels above are for, and what parity with the reference needs.  ANY square root W of
+// D M⁻¹ D gives a sample of the same distribution, and the transition density does not depend on the root: with
+// M = L Lᵀ, W = D L⁻ᵀ.  This kernel writes V := D L⁻ᵀ and S := 1 where the decomposition would write V and S — same buffers,
+// same completion protocol, same front end for a launch enqueued ahead of its input — so everything downstream (the proposal of
+// launch 1) is unchanged.  One workgroup per posterior: the normal matrix in LDS, a root-free right-looking elimination (one
+// barrier per column), then the inverse of the triangular factor, one column per lane group.  No iteration, no warm start, no
+// state from one posterior to the next: ≈ 15 µs at rank 51 against 70-110 µs for the warm-started decomposition.
+// (icp_proposal_set_sampler; NOT the default: the chain it produces is a different realisation of the same Markov kernel.)
+struct RootBatch2 {
+  int n; EigenProblem p[2];
+  __device__ __forceinline__ void announce() const {}
+};
+typedef EigenBatchMem RootBatchMem;
+
+template <class Batch>
+__global__ void __launch_bounds__(256) k_posterior_root(int r, const double* __restrict__ sqrt_lambda_launch, Batch batch) {
+  batch.announce();
+  const EigenProblem pb = batch.p[blockIdx.x];
+  const double* __restrict__ sl = pb.sqrt_lambda ? pb.sqrt_lambda : sqrt_lambda_launch;
+  constexpr int ld = 65;
+  __shared__ double sA[64 * ld], sX[64 * ld], s_d[64];
+  __shared__ int s_cancel, s_bad;
+  const int tid = threadIdx.x;
+  const EigenSpec spec = pb.spec;
+  if (tid == 0) { s_cancel = 0; s_bad = 0; }
+  __syncthreads();
+  if (tid == 255) {  // (the protocol of k_posterior_eigen_rr: wait for the input, or for the cancellation, or give up after 5 ms)
+    if (spec.ready) {
+      const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+      for (;;) {
+        if (__hip_atomic_load(spec.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - spec.ready_seq >= 0) break;
+        if (spec.cancel && __hip_atomic_load(spec.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == spec.seq) { s_cancel = 1; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 500000) { s_cancel = 2; break; }
+        __builtin_amdgcn_s_sleep(32);
+      }
+      if (spec.wait_ticks) atomicAdd((unsigned long long*)spec.wait_ticks, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - t0));
+    } else if (spec.cancel) {
+      if (__hip_atomic_load(spec.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == spec.seq) s_cancel = 1;
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (acquire side for the plain loads of the partials below)
+  if (s_cancel) {
+    if (tid == 0) {
+      if (s_cancel == 2) {
+        if (pb.host_status) __hip_atomic_store(pb.host_status, kEigenGaveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        pb.Vout[0] = __builtin_nan("");
+      }
+      __threadfence();
+      if (pb.done_word) __hip_atomic_store(pb.done_word, pb.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  // ---- M (lower triangle) into LDS: I + Σ_s partial_s in split order from 0.0 like the factorisation, or the stored matrix
+  if (spec.splits > 0) {
+    const size_t nn = (size_t)(r + 1) * (r + 1);
+    for (int e = tid; e < r * r; e += 256) {
+      const int i = e / r, j = e - i * r;
+      if (j > i) continue;
+      double acc = 0.0;
+      const double* src = pb.M + (size_t)i * (r + 1) + j;
+      for (int sp = 0; sp < spec.splits; ++sp) acc += src[(size_t)sp * nn];
+      sA[i * ld + j] = acc + (i == j ? 1.0 : 0.0);
+    }
+  } else {
+    for (int e = tid; e < r * r; e += 256) {
+      const int i = e / r, j = e - i * r;
+      if (j <= i) sA[i * ld + j] = 0.5 * (pb.M[(size_t)i * r + j] + pb.M[(size_t)j * r + i]);
+    }
+  }
+  __syncthreads();
+  // ---- root-free elimination: after step k, column k holds l_ik·d_k (i > k) and the diagonal d_k; M = L̃ D̃ L̃ᵀ
+  for (int k = 0; k < r - 1; ++k) {
+    const double dk = sA[k * ld + k];
+    if (!(dk > 0.0)) { if (tid == 0) s_bad = 1; }
+    const double inv = 1.0 / dk;
+    const int m = r - 1 - k;
+    for (int e = tid; e < m * m; e += 256) {
+      const int a = e / m, b = e - a * m;
+      if (b > a) continue;
+      const int i = k + 1 + a, j = k + 1 + b;
+      sA[i * ld + j] -= sA[i * ld + k] * sA[j * ld + k] * inv;
+    }
+    __syncthreads();
+  }
+  if (tid < r) {
+    const double d = sA[tid * ld + tid];
+    if (!(d > 0.0)) s_bad = 1;
+    s_d[tid] = d;
+  }
+  __syncthreads();
+  // ---- L = L̃ D̃^{1/2} in place: L_ik = (l_ik d_k)/sqrt(d_k), L_kk = sqrt(d_k)
+  for (int e = tid; e < r * r; e += 256) {
+    const int i = e / r, k = e - i * r;
+    if (k <= i) sA[i * ld + k] = (k == i) ? sqrt(s_d[k]) : sA[i * ld + k] / sqrt(s_d[k]);
+  }
+  __syncthreads();
+  // ---- X = L⁻¹ (lower triangular), column j by four lanes: lane q of the group takes the terms k ≡ j + q (mod 4) of every row's
+  // sum; rows in order, one barrier per row (x_i of a column is read by the other lanes of its group in the next rows)
+  {
+    const int j = tid >> 2, q = tid & 3;
+    if (j < r && q == 0) sX[j * ld + j] = 1.0 / sA[j * ld + j];
+    __syncthreads();
+    for (int i = 1; i < r; ++i) {  // (uniform trip count: every lane takes part in the shuffles and the barrier)
+      double part = 0.0;
+      const bool live = j < r && i > j;
+      if (live)
+        for (int k = j + q; k < i; k += 4) part += sA[i * ld + k] * sX[k * ld + j];
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      if (live && q == 0) sX[i * ld + j] = -part / sA[i * ld + i];
+      __syncthreads();
+    }
+  }
+  // ---- outputs: V = D L⁻ᵀ (V[i][k] = sl_i X[k][i], k >= i), Vt, S = 1
+  for (int e = tid; e < r * r; e += 256) {
+    const int i = e / r, k = e - i * r;
+    const double v = k >= i ? sl[i] * sX[k * ld + i] : 0.0;
+    pb.Vout[(size_t)i * r + k] = v;
+    pb.Vtout[(size_t)k * r + i] = v;
+  }
+  if (tid < r) pb.Sout[tid] = 1.0;
+  if (tid == 0) {
+    pb.status[0] = s_bad ? 2 : 0; pb.status[-1] = 0;
+    if (pb.host_status) __hip_atomic_store(pb.host_status, s_bad ? 2 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0 && pb.done_word) __hip_atomic_store(pb.done_word, pb.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+namespace {
+template <class Batch>
+void launch_root_batch(hipStream_t st, int r, const double* sqrt_lambda, int n, const Batch& batch) {
+  ProfScope _ps(st, KID_EIGEN);
+  hipLaunchKernelGGL(k_posterior_root<Batch>, dim3(n), dim3(256), 0, st, r, sqrt_lambda, batch);
+}
+}  // namespace
+
 // ranks <= 64 by the tridiagonal route: one launch reduces (a workgroup per decomposition, with the front end of a decomposition
 // enqueued ahead of its input), one solves (a wave per eigenpair); no refinement step (gaps at these ranks leave the vectors
 // orthogonal to 1e-13), completion words from the solve launch's last wave
@@ -2174,6 +2315,13 @@ bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambd
   // refinement step its eigenvectors of close eigenvalues are a little further from the oracle's than the iteration's (femur-50
   // golden proposals: 1.4e-7 against a tolerance of 1.2e-7).  Requests ask for it (EigenRequest::direct) under developer switches only.
   static const int forced = dev_env("ICP_EIGEN_TRIDIAG") ? std::atoi(dev_env("ICP_EIGEN_TRIDIAG")) : -1;
+  if (rq[0].root) {  // the Cholesky-root sampler (icp_proposal_set_sampler): no decomposition at all
+    RootBatch2 b{};
+    b.n = n;
+    for (int i = 0; i < n; ++i) b.p[i] = eigen_rr_problem(r, rq[i]);
+    launch_root_batch(st, r, sqrt_lambda, n, b);
+    return true;
+  }
   bool direct = false;
   for (int i = 0; i < n; ++i) direct = direct || rq[i].direct;
   if (forced >= 0) direct = forced != 0;
@@ -2194,6 +2342,10 @@ int launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest
   const int per = eigen_rr_per(r), chunk = chunk_hook > 0 ? chunk_hook : 240 / per;
   EigenProblem* rec = (EigenProblem*)pinned_records;
   for (int i = 0; i < n; ++i) rec[i] = eigen_rr_problem(r, rq[i]);
+  if (rq[0].root) {  // (all requests of a batch share the sampler: checked by the caller)
+    launch_root_batch(st, r, nullptr, n, RootBatchMem{n, rec, arrive});
+    return n;
+  }
   for (int i = 0; i < n; i += chunk) {
     const int m = std::min(chunk, n - i);
     launch_eigen_rr_batch(st, r, nullptr, m, EigenBatchMem{m, rec + i, arrive});

@@ -191,6 +191,7 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
         auto* p = new NonRigidIcpProposal(ctx, cfg->icp[i], std::string("IcpProposal-") + dir + "-" + scala_double(cfg->icp[i].step_length) + "Step");
         p->leafId = i;
         own(p);
+        if (cfg->sampler != 0) check(icp_proposal_set_sampler(p->h, cfg->sampler), "icp_proposal_set_sampler");
         ch->icp.push_back(p);
         icpMix->add(cfg->icp_weight[i], p);
       }

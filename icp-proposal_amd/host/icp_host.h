@@ -18,7 +18,7 @@ typedef struct {
   double icp_weight[2];          /* inner mixture weights (0.5 / 0.5) */
   double w_icp;                  /* outer mixture: ICP mixture            (IcpProposalRegistration.scala:72: 0.90) */
   double w_rw;                   /*                random shape walk       (0.10) */
-  double w_pose;                 /*                6-component pose walk   (BfmFittingPartial.scala:70: 0.55; 0 = none) */
+  double w_pose;                 /*                6-component pose walk   (BfmFittingPartial.scala:70: 0.4; 0 = none) */
   double rw_sigma;               /* RandomShapeUpdateProposal stdev (0.1) */
   double pose_rot_sigma[3];      /* rotYaw, rotPitch, rotRoll (MixedProposalDistributions.scala:29: 0.01): the walks on
                                     rotation._3 = theta[6], _2 = theta[5], _1 = theta[4] (PoseProposals.scala:39-41) */
@@ -26,6 +26,8 @@ typedef struct {
   icp_evaluator_params eval;     /* likelihood; the shape prior is always multiplied in (ProductEvaluators.scala:38-55) */
   int32_t fused;                 /* 0 = per-method calls; 1 = icp_chain_eval_step prefetch after propose; 2 = the whole step
                                     (propose + evaluation) as ONE icp_chain_step submission */
+  int32_t sampler;               /* icp_sampler of the ICP proposals: 0 = eigen (the reference's posterior.sample()), 1 = opt-in
+                                    Cholesky root (same distribution, no eigen-decomposition; NOT the reference's arithmetic) */
 } icp_host_chain_config;
 
 /* fixed-size per-step record (the layout the multi-GPU log gather ships; mirrors jsonLogFormat,

@@ -24,7 +24,7 @@ class HostChainConfig(C.Structure):
     _fields_ = [("n_icp", C.c_int32), ("icp", nat.ProposalParams * 2), ("icp_weight", C.c_double * 2),
                 ("w_icp", C.c_double), ("w_rw", C.c_double), ("w_pose", C.c_double), ("rw_sigma", C.c_double),
                 ("pose_rot_sigma", C.c_double * 3), ("pose_trans_sigma", C.c_double * 3),
-                ("eval", nat.EvaluatorParams), ("fused", C.c_int32)]
+                ("eval", nat.EvaluatorParams), ("fused", C.c_int32), ("sampler", C.c_int32)]
 
 
 def host_lib():
@@ -110,6 +110,7 @@ class ChainSetup:
         self.pose_trans_sigma = (0.1, 0.1, 0.1)
         self.eval = dict(kind=0, mode=0, n_model_ids=0, target_pts=np.zeros((0, 3)), gauss_mean=0.0, gauss_sigma=1.0, exp_rate=1.0)
         self.fused = 2  # 0 per-method calls, 1 icp_chain_eval_step prefetch, 2 whole step in one icp_chain_step submission
+        self.sampler = "eigen"  # or "cholesky-root" (opt-in, not the reference's arithmetic: NonRigidIcpProposal.setSampler)
 
     @staticmethod
     def scala_double(x: float) -> str:
@@ -173,6 +174,7 @@ class ChainSetup:
         cfg.eval = nat.EvaluatorParams(e["kind"], e["mode"], int(e["n_model_ids"]), tp.shape[0], _dp(tp), e["gauss_mean"],
                                        e["gauss_sigma"], e["exp_rate"])
         cfg.fused = int(self.fused)
+        cfg.sampler = {"eigen": 0, "cholesky-root": 1}[self.sampler]
         cfg._keep = keep
         return cfg
 

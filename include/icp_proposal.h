@@ -137,8 +137,10 @@ ICP_API int icp_ctx_device(const icp_ctx *ctx);
  * Scalismo's Rotation(phi, theta, psi, centre) (ModelFittingParameters.scala:79-86).  A caller that wants Scalismo's OWN matrix
  * used — whatever its convention — registers it for the triple before passing a theta with these angles: R = row-major 3x3 rotation
  * (checked: orthonormal, determinant +1); R == NULL withdraws the entry.  Up to 32 triples are remembered (least recently used
- * out); a theta whose angles have no entry is posed with the library's Rz(phi)·Ry(theta)·Rx(psi).  Register BEFORE the first
- * call with such a theta: results already memoised under it are not recomputed. */
+ * out); a theta whose angles have no entry is posed with the library's Rz(phi)·Ry(theta)·Rx(psi).  Whenever the matrix in force
+ * for a triple changes — first registration, replacement by a different matrix, withdrawal, eviction — everything the context has
+ * cached under thetas with these angles (instances, posteriors of every proposal, memoised likelihood values) is dropped, so a
+ * later call recomputes it with the new matrix; registering before the first use of a triple costs nothing. */
 ICP_API int icp_ctx_set_rotation(icp_ctx *ctx, const double angles[3], const double R[9]);
 
 /* ModelFittingParameters.transformedMesh (ModelFittingParameters.scala:108-110): points_out [N*3]. */
@@ -173,6 +175,18 @@ ICP_API int icp_proposal_propose(icp_proposal *p, const double *theta, const dou
 
 /* logTransitionProbability(from, to) (NonRigidIcpProposal.scala:71-85). */
 ICP_API int icp_proposal_log_transition(icp_proposal *p, const double *theta_from, const double *theta_to, double *out);
+
+/* Opt-in, NOT the reference's arithmetic: how propose() turns the caller's standard normals z into a sample of the posterior.
+ *   ICP_SAMPLER_EIGEN (default)   z multiplies the posterior's KL basis, D M^-1 D = V S V^T (what Scalismo's posterior.sample() does,
+ *                                 NonRigidIcpProposal.scala:55): parity with the reference for a given z; needs the eigen-decomposition
+ *                                 of every accepted state's posterior, the longest link of an accepted step.
+ *   ICP_SAMPLER_CHOLESKY_ROOT     z multiplies W = D L^-T (M = L L^T): W W^T = D M^-1 D as well, so the sample has the SAME distribution
+ *                                 and logTransitionProbability (which does not depend on the root) is unchanged — the chain
+ *                                 is a different realisation of the same Markov kernel.  No eigen-decomposition at all.  The diagnostic
+ *                                 view then returns V = W, S = 1.  Ranks <= 64.
+ * Call before the proposal's first use, or any time: posteriors already decomposed the other way are decomposed again. */
+typedef enum { ICP_SAMPLER_EIGEN = 0, ICP_SAMPLER_CHOLESKY_ROOT = 1 } icp_sampler;
+ICP_API int icp_proposal_set_sampler(icp_proposal *p, int32_t sampler);
 
 /* icpPosterior(theta) (NonRigidIcpProposal.scala:88-153), diagnostic. */
 ICP_API int icp_proposal_posterior(icp_proposal *p, const double *theta, icp_posterior_view *view);
@@ -303,6 +317,11 @@ typedef struct {
   double total_ms, min_ms, max_ms;
 } icp_kernel_stat;
 ICP_API int icp_ctx_profile_start(icp_ctx *ctx, int32_t max_launches);
+/* on != 0: the NEXT profile_start .. profile_stop interval also counts the tests the searches execute (per wave, with atomics on
+ * a handful of device words — they slow the filter launches down, so this is for a short leg of its own, not for timing);
+ * profile_stop then returns extra rows "count.surface_ball_tests", "count.surface_sphere_tests", "count.surface_exact_tests",
+ * "count.vertex_filter_tests", "count.vertex_exact_tests" with the number in `calls`. */
+ICP_API int icp_ctx_profile_search_counters(icp_ctx *ctx, int32_t on);
 ICP_API int icp_ctx_profile_stop(icp_ctx *ctx, icp_kernel_stat *stats, int32_t capacity /* >= 32 */, int32_t *n_out);
 
 /* ---- fall-back counters.  The step schedules above take their cross-stream order on the device (a launch waits for a word another

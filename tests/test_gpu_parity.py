@@ -414,3 +414,135 @@ def test_caller_supplied_rotation_convention(pkg, femur50):
         with pytest.raises(pkg._native.IcpNativeError):
             ctx.setRotation(theta[4:7], 2.0 * R)     # not a rotation
         ctx.close()
+
+
+def test_rotation_change_drops_what_was_cached_under_the_old_matrix(pkg, femur50):
+    """icp_ctx_set_rotation on a triple that is already in use — replacement, withdrawal — must not leave instances, posteriors or
+    likelihood values computed with the previous matrix behind: a second context that only ever saw the final matrix
+    gives the reference values."""
+    model, target = femur50
+    r = model.rank
+    theta = make_theta(model, 9, pose=True)
+    theta[4:7] = [0.25, -0.1, 0.2]
+    phi, th, psi = theta[4:7]
+    c, s = np.cos, np.sin
+    Rx = np.array([[1, 0, 0], [0, c(psi), -s(psi)], [0, s(psi), c(psi)]])
+    Ry = np.array([[c(th), 0, s(th)], [0, 1, 0], [-s(th), 0, c(th)]])
+    Rz = np.array([[c(phi), -s(phi), 0], [s(phi), c(phi), 0], [0, 0, 1]])
+    R1, R2 = Rx @ Ry @ Rz, Ry @ Rx @ Rz
+    tp = pkg.data.decimated_point_subset(target, 4 * r)
+
+    def values(ctx, prop, ev):
+        post = prop.icpPosterior(theta, with_aux=False)
+        return ctx.transformedMesh(theta), post.alpha.copy(), post.corr_point.copy(), ev.logValue(theta)
+
+    def fresh(R):
+        ctx = pkg.IcpContext(model, target, device=0)
+        if R is not None:
+            ctx.setRotation(theta[4:7], R)
+        prop = pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, "ModelSampling", True)
+        ev = pkg.IndependentPointDistanceEvaluator(ctx, 0.0, 2.0, 0, 4 * r, decimatedTargetPoints=tp)
+        out = values(ctx, prop, ev)
+        prop.close(); ev.close(); ctx.close()
+        return out
+
+    want1, want2, want_native = fresh(R1), fresh(R2), fresh(None)
+    assert np.abs(want1[0] - want2[0]).max() > 1.0 and abs(want1[3] - want2[3]) > 1e-3
+    ctx = pkg.IcpContext(model, target, device=0)
+    prop = pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, "ModelSampling", True)
+    ev = pkg.IndependentPointDistanceEvaluator(ctx, 0.0, 2.0, 0, 4 * r, decimatedTargetPoints=tp)
+    for R, want in ((None, want_native), (R1, want1), (R2, want2), (R1, want1), (None, want_native)):   # first use, insert, replace, replace, withdraw
+        if R is not None or want is want_native:
+            ctx.setRotation(theta[4:7], R)
+        got = values(ctx, prop, ev)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+        assert np.array_equal(got[1], want[1]) and got[3] == want[3]
+    prop.close(); ev.close(); ctx.close()
+
+
+def test_cholesky_root_sampler_has_the_posterior_covariance(pkg, femur50):
+    """Opt-in sampler (icp_proposal_set_sampler, NOT the reference's arithmetic): z multiplies W = D·L⁻ᵀ (M = L·Lᵀ) instead of the KL
+    basis V√S.  W·Wᵀ must equal V·S·Vᵀ (= D·M⁻¹·D) to 1e-12 — same proposal distribution —, the proposal must be the closed form
+    with that root, and logTransitionProbability, which does not depend on the root, must not change at all."""
+    model, target = femur50
+    r = model.rank
+    ctx = pkg.IcpContext(model, target, device=0)
+    tp = pkg.data.decimated_point_subset(target, 2 * r)
+    rng = np.random.default_rng(3)
+    Q = model.basis * np.sqrt(model.variance)[None, :]
+    G = Q.T @ Q
+    sigma2 = 1e-5
+    P = np.linalg.inv(G + sigma2 * np.eye(r))
+    sl = np.sqrt(model.variance)
+    for direction in ("ModelSampling", "TargetSampling"):
+        pe = pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, direction, True, decimatedTargetPoints=tp)
+        pr = pkg.NonRigidIcpProposal(ctx, 0.1, 10.0, 5.0, 2 * r, direction, True, decimatedTargetPoints=tp).setSampler("cholesky-root")
+        for seed in (1, 2):
+            theta = make_theta(model, seed, pose=True)
+            a, b = pe.icpPosterior(theta), pr.icpPosterior(theta)
+            assert np.array_equal(a.corr_id, b.corr_id) and np.array_equal(a.alpha, b.alpha) and np.array_equal(a.M, b.M)
+            cov_e = (a.V * a.S[None, :]) @ a.V.T
+            cov_r = (b.V * b.S[None, :]) @ b.V.T
+            assert np.all(b.S == 1.0) and np.allclose(np.triu(b.V, 0), b.V)          # W = D·L⁻ᵀ is upper triangular
+            assert np.abs(cov_r - cov_e).max() <= 1e-12 * np.abs(cov_e).max()
+            want_cov = (sl[:, None] * np.linalg.inv(a.M)) * sl[None, :]
+            assert np.abs(cov_r - want_cov).max() <= 1e-12 * np.abs(want_cov).max()
+            z = rng.normal(size=r)
+            got = pr.propose(theta, z)
+            L = np.linalg.cholesky(0.5 * (a.M + a.M.T))
+            w = a.alpha + np.linalg.solve(L.T, z)
+            cnew = w - sigma2 * (P @ w)
+            want = theta[10:] + 0.1 * (cnew - theta[10:])
+            assert np.abs(got[10:] - want).max() <= 1e-9 * np.abs(want).max()
+            assert np.array_equal(got[:10], theta[:10])
+            # root-free transition density: bit-identical under both samplers, and finite for a root-sampled proposal
+            other = pe.propose(theta, z)
+            for to in (got, other):
+                assert pe.logTransitionProbability(theta, to) == pr.logTransitionProbability(theta, to)
+            assert np.isfinite(pr.logTransitionProbability(theta, got))
+        # switching back: the eigen form again, the same values as the proposal that never switched
+        pr.setSampler("eigen")
+        c = pr.icpPosterior(theta)
+        assert np.abs(c.S - a.S).max() <= 1e-10 * a.S.max() and np.abs(c.V - a.V).max() <= 1e-7
+        pe.close(); pr.close()
+    ctx.close()
+
+
+def test_cholesky_root_sampler_chain(pkg, femur50):
+    """The metric chain with the opt-in sampler: a valid Metropolis–Hastings chain (same acceptance behaviour as the eigen form on
+    average, different realisation), identical step by step through the merged step, the per-method calls and the batched step."""
+    model, target = femur50
+    n = 300
+    recs = {}
+    for fused in (2, 0):
+        setup = pkg.femur_icp_proposal_registration(model, target, fused=fused)
+        setup.sampler = "cholesky-root"
+        ctx = pkg.IcpContext(model, target, device=0)
+        chain = pkg.SamplingRegistration(ctx, setup, pkg.initial_parameters(model), seed=1024)
+        recs[fused] = chain.run(n)
+        assert all(v == 0 for v in ctx.runtime_stats().values())
+        chain.close(); ctx.close()
+    assert np.array_equal(recs[2][:, :3], recs[0][:, :3])
+    assert np.abs(recs[2][:, 14:] - recs[0][:, 14:]).max() <= 1e-9 * np.abs(recs[0][:, 14:]).max()
+    setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+    ctx = pkg.IcpContext(model, target, device=0)
+    ref = pkg.SamplingRegistration(ctx, setup, pkg.initial_parameters(model), seed=1024).run(n)
+    ctx.close()
+    acc_root, acc_eig = recs[2][:, 1].mean(), ref[:, 1].mean()
+    assert 0.15 < acc_root < 0.9 and abs(acc_root - acc_eig) < 0.15
+    assert recs[2][-1, 3] > recs[2][0, 3] + 100.0          # the chain climbs like the eigen form does
+    assert abs(recs[2][-50:, 3].mean() - ref[-50:, 3].mean()) < 0.05 * abs(ref[-50:, 3].mean())
+    # batched: chain by chain the records of the single chains
+    setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+    setup.sampler = "cholesky-root"
+    B = 9
+    def make():
+        ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
+        return ctxs, [pkg.SamplingRegistration(ctxs[i], setup, pkg.random_initial_parameters(model, i), seed=50 + i) for i in range(B)]
+    ctxs, chains = make()
+    single = [c.run(40) for c in chains]
+    [c.close() for c in chains]; [c.close() for c in ctxs]
+    ctxs, chains = make()
+    got = pkg.run_chains_batched(chains, 40)
+    assert all(np.array_equal(a, b) for a, b in zip(got, single))
+    [c.close() for c in chains]; [c.close() for c in ctxs]
