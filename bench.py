@@ -259,6 +259,8 @@ def main():
                          "stepped through icp_chain_step_batched, reported as `many_chains` (0 = skip)")
     ap.add_argument("--fused", type=int, default=2, choices=[0, 1, 2],
                     help="host<->device call pattern per step: 0 per-method calls, 1 propose + icp_chain_eval_step, 2 one icp_chain_step")
+    ap.add_argument("--root-sampler-leg", type=int, default=1,
+                    help="default run (N = 1, config 1): extra leg with the opt-in Cholesky-root sampler, reported as `cholesky_root_sampler` (0 = skip)")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -400,6 +402,30 @@ def main():
                 line["extra_configs"]["config%d" % cfg_i] = extra_config_leg(pkg, args, cfg_i, local_rank)
             except Exception as e:
                 line["extra_configs"]["config%d" % cfg_i] = {"error": str(e)[:200]}
+    if rank == 0 and world == 1 and B == 1 and args.config == 1 and args.root_sampler_leg:
+        # ---- not the headline and NOT the reference's arithmetic: the same chain with the opt-in Cholesky-root sampler
+        # (icp_proposal_set_sampler) — what the accepted path costs when the reference's SVD convention for posterior.sample() is not required
+        try:
+            import copy
+            rs = copy.copy(setup)
+            rs.sampler = "cholesky-root"
+            out = {"sampler": "cholesky-root", "unit": "iterations/s",
+                   "note": "opt-in: z multiplies W = D L^-T (M = L L^T) instead of the KL basis V sqrt(S): same proposal distribution, same transition "
+                           "density, no eigen-decomposition; a different realisation of the same Markov kernel, so NOT comparable decision for decision "
+                           "with the reference (tests/test_gpu_parity.py::test_cholesky_root_sampler_*)"}
+            for key, n_w, n in (("first_20_steps", 5, 20), ("value", 200, 3000)):
+                rctx = pkg.IcpContext(model, target, device=local_rank)
+                rch = pkg.SamplingRegistration(rctx, rs, wl["init"](0), seed=1024)
+                rch.run(n_w, want_records=False)
+                t1 = time.perf_counter()
+                rrec = rch.run(n)
+                out[key] = n / (time.perf_counter() - t1)
+                out[key + "_accepted"] = int(rrec[:, 1].sum())
+                out["runtime_stats"] = rctx.runtime_stats()
+                rch.close(); rctx.close()
+            line["cholesky_root_sampler"] = out
+        except Exception as e:
+            line["cholesky_root_sampler"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and B == 1 and args.many_chains > 1 and args.config == 1:
         # ---- not the headline: the same workload with many independent chains on the one GPU (SURVEY.md §8e "within a GPU,
         # batch B chains per launch"; RunMHRandomInitComparison-style jobs), one context per chain, lockstep submissions

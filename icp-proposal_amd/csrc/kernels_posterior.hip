@@ -2156,11 +2156,25 @@ __global__ void __launch_bounds__(256) k_posterior_root(int r, const double* __r
   const EigenProblem pb = batch.p[blockIdx.x];
   const double* __restrict__ sl = pb.sqrt_lambda ? pb.sqrt_lambda : sqrt_lambda_launch;
   constexpr int ld = 65;
-  __shared__ double sA[64 * ld], sX[64 * ld], s_d[64];
+  constexpr int kOwn = 9;  // entries of the lower triangle per thread: 64·65/2 = 2080 <= 9·256
+  __shared__ double sW[64 * ld];                                 // the finished factor, column by column (unscaled: l_ik·d_k; diagonal d_k)
+  __shared__ __attribute__((aligned(16))) double s_col[2][64];   // the pivot column of the current step (double-buffered: one barrier per column)
+  __shared__ double s_isd[64];                                   // 1/sqrt(d_k)
   __shared__ int s_cancel, s_bad;
   const int tid = threadIdx.x;
   const EigenSpec spec = pb.spec;
   if (tid == 0) { s_cancel = 0; s_bad = 0; }
+  // ---- this thread's entries (i >= j) of the lower triangle, row-major rank e = tid + 256·u (nothing here depends on the input)
+  int ei[kOwn], ej[kOwn];
+#pragma unroll
+  for (int u = 0; u < kOwn; ++u) {
+    const int e = tid + 256 * u;
+    int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    while (i * (i + 1) / 2 > e) --i;
+    ei[u] = i < r ? i : -1;
+    ej[u] = e - i * (i + 1) / 2;
+  }
   __syncthreads();
   if (tid == 255) {  // (the protocol of k_posterior_eigen_rr: wait for the input, or for the cancellation, or give up after 5 ms)
     if (spec.ready) {
@@ -2189,73 +2203,91 @@ __global__ void __launch_bounds__(256) k_posterior_root(int r, const double* __r
     }
     return;
   }
-  // ---- M (lower triangle) into LDS: I + Σ_s partial_s in split order from 0.0 like the factorisation, or the stored matrix
+  // ---- M into registers: I + Σ_s partial_s (split order from 0.0, like the factorisation; four splits in flight), or the stored matrix
+  double v[kOwn];
   if (spec.splits > 0) {
     const size_t nn = (size_t)(r + 1) * (r + 1);
-    for (int e = tid; e < r * r; e += 256) {
-      const int i = e / r, j = e - i * r;
-      if (j > i) continue;
-      double acc = 0.0;
-      const double* src = pb.M + (size_t)i * (r + 1) + j;
-      for (int sp = 0; sp < spec.splits; ++sp) acc += src[(size_t)sp * nn];
-      sA[i * ld + j] = acc + (i == j ? 1.0 : 0.0);
+    size_t off[kOwn];
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u) { off[u] = ei[u] >= 0 ? (size_t)ei[u] * (r + 1) + ej[u] : 0; v[u] = 0.0; }
+    int sp = 0;
+    for (; sp + 4 <= spec.splits; sp += 4) {
+      double q[4][kOwn];
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int u = 0; u < kOwn; ++u) q[w][u] = pb.M[(size_t)(sp + w) * nn + off[u]];
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int u = 0; u < kOwn; ++u) v[u] += q[w][u];
     }
+    for (; sp < spec.splits; ++sp)
+#pragma unroll
+      for (int u = 0; u < kOwn; ++u) v[u] += pb.M[(size_t)sp * nn + off[u]];
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u) v[u] = ei[u] >= 0 ? v[u] + (ei[u] == ej[u] ? 1.0 : 0.0) : 0.0;
   } else {
-    for (int e = tid; e < r * r; e += 256) {
-      const int i = e / r, j = e - i * r;
-      if (j <= i) sA[i * ld + j] = 0.5 * (pb.M[(size_t)i * r + j] + pb.M[(size_t)j * r + i]);
-    }
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u)
+      v[u] = ei[u] >= 0 ? 0.5 * (pb.M[(size_t)ei[u] * r + ej[u]] + pb.M[(size_t)ej[u] * r + ei[u]]) : 0.0;
   }
+  // ---- root-free right-looking elimination in registers: step k needs the pivot column only, published through s_col (column k+1
+  // right after step k has made it final: one barrier per column); finished columns are kept in sW
+#pragma unroll
+  for (int u = 0; u < kOwn; ++u)
+    if (ei[u] >= 0 && ej[u] == 0) { s_col[0][ei[u]] = v[u]; sW[ei[u] * ld] = v[u]; }
   __syncthreads();
-  // ---- root-free elimination: after step k, column k holds l_ik·d_k (i > k) and the diagonal d_k; M = L̃ D̃ L̃ᵀ
   for (int k = 0; k < r - 1; ++k) {
-    const double dk = sA[k * ld + k];
+    const double* cur = s_col[k & 1];
+    double* nxt = s_col[(k + 1) & 1];
+    const double dk = cur[k];
     if (!(dk > 0.0)) { if (tid == 0) s_bad = 1; }
     const double inv = 1.0 / dk;
-    const int m = r - 1 - k;
-    for (int e = tid; e < m * m; e += 256) {
-      const int a = e / m, b = e - a * m;
-      if (b > a) continue;
-      const int i = k + 1 + a, j = k + 1 + b;
-      sA[i * ld + j] -= sA[i * ld + k] * sA[j * ld + k] * inv;
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u) {
+      if (ei[u] >= 0 && ej[u] > k) {
+        v[u] -= cur[ei[u]] * cur[ej[u]] * inv;
+        if (ej[u] == k + 1) { nxt[ei[u]] = v[u]; sW[ei[u] * ld + k + 1] = v[u]; }
+      }
     }
     __syncthreads();
   }
   if (tid < r) {
-    const double d = sA[tid * ld + tid];
+    const double d = sW[tid * ld + tid];
     if (!(d > 0.0)) s_bad = 1;
-    s_d[tid] = d;
+    s_isd[tid] = 1.0 / sqrt(d);
   }
   __syncthreads();
-  // ---- L = L̃ D̃^{1/2} in place: L_ik = (l_ik d_k)/sqrt(d_k), L_kk = sqrt(d_k)
-  for (int e = tid; e < r * r; e += 256) {
-    const int i = e / r, k = e - i * r;
-    if (k <= i) sA[i * ld + k] = (k == i) ? sqrt(s_d[k]) : sA[i * ld + k] / sqrt(s_d[k]);
-  }
-  __syncthreads();
-  // ---- X = L⁻¹ (lower triangular), column j by four lanes: lane q of the group takes the terms k ≡ j + q (mod 4) of every row's
-  // sum; rows in order, one barrier per row (x_i of a column is read by the other lanes of its group in the next rows)
+  // ---- X = L⁻¹ with L_ik = sW[i][k]·isd_k (L_kk = sqrt(d_k) = 1/isd_k), column j by the four lanes of a group, lane q the rows
+  // m ≡ q (mod 4): x_i = (δ_ij − s_i)·isd_i, then s_m += L_mi·x_i for the rows behind it — all inside one wave, no barrier.
+  // V = D·L⁻ᵀ goes out as it is produced: V[j][i] = sl_j·X[i][j].
   {
     const int j = tid >> 2, q = tid & 3;
-    if (j < r && q == 0) sX[j * ld + j] = 1.0 / sA[j * ld + j];
-    __syncthreads();
-    for (int i = 1; i < r; ++i) {  // (uniform trip count: every lane takes part in the shuffles and the barrier)
-      double part = 0.0;
-      const bool live = j < r && i > j;
-      if (live)
-        for (int k = j + q; k < i; k += 4) part += sA[i * ld + k] * sX[k * ld + j];
-      part += __shfl_xor(part, 1, 64);
-      part += __shfl_xor(part, 2, 64);
-      if (live && q == 0) sX[i * ld + j] = -part / sA[i * ld + i];
-      __syncthreads();
+    double sm[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sm[t] = 0.0;
+    const double slj = j < r ? sl[j] : 0.0;
+    for (int i = 0; i < r; ++i) {
+      // the owner lane of row i holds s_i: i = q' + 4t
+      double si = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) si = (i >> 2) == t ? sm[t] : si;
+      si = __shfl(si, (tid & 60) | (i & 3), 64);
+      const double isd_i = s_isd[i];
+      const double xi = (i < j || j >= r) ? 0.0 : ((i == j ? 1.0 : 0.0) - si) * isd_i;
+      if (q == 0 && j < r) {
+        const double vji = slj * xi;
+        pb.Vout[(size_t)j * r + i] = vji;
+        pb.Vtout[(size_t)i * r + j] = vji;
+      }
+      const double xs = xi * isd_i;  // L_mi·x_i = sW[m][i]·isd_i·x_i
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int m = q + 4 * t;
+        if (m > i && m < r) sm[t] = fma(sW[m * ld + i], xs, sm[t]);
+      }
     }
-  }
-  // ---- outputs: V = D L⁻ᵀ (V[i][k] = sl_i X[k][i], k >= i), Vt, S = 1
-  for (int e = tid; e < r * r; e += 256) {
-    const int i = e / r, k = e - i * r;
-    const double v = k >= i ? sl[i] * sX[k * ld + i] : 0.0;
-    pb.Vout[(size_t)i * r + k] = v;
-    pb.Vtout[(size_t)k * r + i] = v;
   }
   if (tid < r) pb.Sout[tid] = 1.0;
   if (tid == 0) {
