@@ -1849,7 +1849,7 @@ int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, 
     p->await_eigen(e);
     const double* dz = c.stage(z, r);                 // :55 the caller's standard normals
     launch_propose(c.stream, r, e.alpha.p, e.V.p, e.S.p, c.inv_sqrt_lambda.p, c.P.p, kSigma2, e.coeffs.p, dz,
-                   p->prm.step_length, c.d_res.p);
+                   p->prm.step_length, c.d_res.p, p->sampler == ICP_SAMPLER_CHOLESKY_ROOT);
     std::vector<int> ids;
     std::vector<uint8_t> keep;
     if (corr_id_out && p->K > 0) {
@@ -2564,7 +2564,7 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   if (generator >= 0) {
     PosteriorEntry& g = *ec[generator];
     b.prop = ProposeIn{g.alpha.p, g.V.p, g.S.p, c.inv_sqrt_lambda.p, c.P.p, g.coeffs.p, nullptr, kSigma2,
-                       props[generator]->prm.step_length};
+                       props[generator]->prm.step_length, props[generator]->sampler == ICP_SAMPLER_CHOLESKY_ROOT};
     int t = 0;
     while (t < 6 && (r << (t + 1)) <= 256 && (r >> (t + 1)) >= 8) ++t;  // = matvec_tpr_log2(r, 256) of k_propose
     b.tpr_log2 = t;
@@ -2587,7 +2587,8 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   if (generator >= 0 && ec[generator]->done_value != 0) {
     b.wait2_flag = props[generator]->eig_words.p + ec[generator]->status_off / 3;
     b.wait2_seq = ec[generator]->done_value;
-    b.hold_regs = *(volatile int*)(props[generator]->h_eig + ec[generator]->status_off / 3) == -1;  // still in flight
+    // still in flight (the register-holding variant of launch 1 multiplies with the KL basis: not for the Cholesky-root sampler)
+    b.hold_regs = *(volatile int*)(props[generator]->h_eig + ec[generator]->status_off / 3) == -1 && !b.prop.root;
   }
   launch_step_begin(F.stream, b);
 

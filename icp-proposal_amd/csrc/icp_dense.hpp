@@ -293,9 +293,12 @@ template <int TPT, int NT>
 // tail_base >= 0: the caller runs a transition tail on this posterior right afterwards — the assembled M is ALSO written
 // to s_dyn[tail_base + i·ld + j] and G⁻¹ (tail_Ginv) to s_dyn[tail_base + r·ld + …] (layout of tail_body), its loads
 // issued beside the partial sums', so that the tail finds both matrices in LDS instead of fetching them again.
+// Mplain != nullptr: the matrix comes assembled (row-major r × r, symmetric, the identity already in it) instead of as split-K
+// partials — nothing is written to M, the appended row is zero and no α is solved (alpha_out unused): k_posterior_root.
 __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict__ Mpart, int S, double* __restrict__ M,
                                                 double* __restrict__ alpha_out, int* __restrict__ status, int tail_base = -1,
-                                                const double* __restrict__ tail_Ginv = nullptr) {
+                                                const double* __restrict__ tail_Ginv = nullptr, const double* __restrict__ Mplain = nullptr,
+                                                bool solve = true) {
   __shared__ __attribute__((aligned(16))) double s_col[2][520];
   __shared__ double s_dinv[512], s_v[512];
   const int tid = threadIdx.x, n = r + 1;
@@ -337,6 +340,16 @@ __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict_
       }
     const size_t nn = (size_t)n * n;
     int sp = 0;
+    if (Mplain) {  // (uniform) the assembled matrix: one load per entry, the mirrored pair averaged like the decompositions do
+      sp = S;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = R0[t] + a, k = C0[t] + c;
+          if (live[a][c] && i < r) v[t][a][c] = 0.5 * (Mplain[(size_t)i * r + k] + Mplain[(size_t)k * r + i]);
+        }
+    }
     for (; sp + 4 <= S; sp += 4) {  // four splits (32 loads) in flight; summed in split order
       double p[4][2][4];
 #pragma unroll
@@ -366,7 +379,7 @@ __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict_
         const int i = R0[t] + a, k = C0[t] + c;
         double x = live[a][c] ? v[t][a][c] : 0.0;
         if (live[a][c]) {
-          if (i < r) {
+          if (i < r && !Mplain) {
             if (i == k) x += 1.0;
             M[(size_t)i * r + k] = x;
             M[(size_t)k * r + i] = x;
@@ -433,6 +446,7 @@ __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict_
   }
   FAC_STAMP(18);
   if (tid == 0) status[0] = 0;
+  if (!solve) return true;  // (uniform)
   // y = L⁻¹ b sits (unscaled) in row r: y_j = W[r][j]·dinv_j,  L[i][j] = W[i][j]·dinv_j
   for (int j = tid; j < r; j += NT) {
     const double d = fast_rsqrt(W[(size_t)j * ld + j]);
@@ -561,11 +575,45 @@ __device__ __forceinline__ void tail_body(int r, const double* __restrict__ alph
 __device__ __forceinline__ void propose_body(int r, const ProposeIn& in, double* c_out, int tpr_log2) {
   __shared__ double s_px[512], s_py[512], s_pw[512];
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int j = tid; j < r; j += nt) s_px[j] = sqrt(in.S[j]) * in.z[j];
-  __syncthreads();
-  block_matvec(r, in.V, r, s_px, s_py, tpr_log2);
-  for (int i = tid; i < r; i += nt) s_pw[i] = fma(s_py[i], in.inv_sqrt_lambda[i], in.alpha[i]);
-  __syncthreads();
+  if (in.root) {
+    // Cholesky-root sampler (ranks <= 64): u = L⁻ᵀ z by ONE wave — lane i carries u_i, rows of L (in.V, row-major) arrive four
+    // steps ahead, the chain per step is readlane -> multiply -> fma (the back substitution of factor_reg_body, with z as the
+    // right-hand side); w = α + u
+    if (tid < 64) {
+      const int i = tid, ic = i < r ? i : r - 1;  // lanes past r mirror lane r-1 (their result is discarded)
+      double x = in.z[ic];
+      constexpr int kA = 4;
+      double lq[kA], dq[kA];
+#pragma unroll
+      for (int a = 0; a < kA; ++a) {
+        const int jj = max(r - 1 - a, 0);
+        lq[a] = in.V[(size_t)jj * r + ic];
+        dq[a] = in.S[jj];
+      }
+      for (int j0 = r - 1; j0 >= 0; j0 -= kA) {
+#pragma unroll
+        for (int a = 0; a < kA; ++a) {
+          const int j = j0 - a;                       // (steps with j < 0, the padding of the last group, change nothing)
+          const double lij = lq[a], dj = dq[a];
+          const int jn = max(j - kA, 0);
+          lq[a] = in.V[(size_t)jn * r + ic];
+          dq[a] = in.S[jn];
+          const int lo = __builtin_amdgcn_readlane(__double2loint(x), j & 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), j & 63);
+          const double xj = __hiloint2double(hi, lo) * dj;
+          const double upd = fma(-lij, xj, x);
+          x = j < 0 ? x : (i == j ? xj : (i < j ? upd : x));
+        }
+      }
+      if (i < r) s_pw[i] = x + in.alpha[i];
+    }
+    __syncthreads();
+  } else {
+    for (int j = tid; j < r; j += nt) s_px[j] = sqrt(in.S[j]) * in.z[j];
+    __syncthreads();
+    block_matvec(r, in.V, r, s_px, s_py, tpr_log2);
+    for (int i = tid; i < r; i += nt) s_pw[i] = fma(s_py[i], in.inv_sqrt_lambda[i], in.alpha[i]);
+    __syncthreads();
+  }
   block_matvec(r, in.P, r, s_pw, s_py, tpr_log2);
   for (int i = tid; i < r; i += nt) {
     const double cnew = fma(-in.sigma2, s_py[i], s_pw[i]);  // model.coefficients(...) with σ² = 1e-5 (NonRigidIcpProposal.scala:59)

@@ -245,7 +245,7 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
 // a8: c' = c + step·((G+σ²I)^-1 G (α + D^-1 V √S z) − c), with P = (G+σ²I)^-1
 void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,
                     const double* inv_sqrt_lambda, const double* P, double sigma2, const double* c,
-                    const double* z, double step, double* c_out);
+                    const double* z, double step, double* c_out, int root = 0);
 
 // ---- deterministic ICP (api/other/IcpBasedSurfaceFitting.scala:46-126)
 // P[k] = x[ids[k]] (:72)
@@ -276,6 +276,8 @@ void launch_dist_stats(hipStream_t st, int K, const double* d2, const unsigned c
 struct ProposeIn {   // a8 inputs (all device pointers; z may also point into kernel arguments)
   const double* alpha; const double* V; const double* S; const double* inv_sqrt_lambda; const double* P;
   const double* c; const double* z; double sigma2, step;
+  int root = 0;  // 1: the opt-in Cholesky-root sampler — V holds L (M = L·Lᵀ, row-major lower triangle), S holds 1/diag(L), and
+                 // D⁻¹·W·z = L⁻ᵀ·z is ONE back substitution instead of the product with the KL basis (k_posterior_root)
 };
 
 constexpr int kStepBeginPoints = 128;  // model points per workgroup of the first launch (256 threads; half of them carry a point:

@@ -2138,11 +2138,12 @@ void launch_eigen_rr(hipStream_t st, int r, const double* sqrt_lambda, int n, co
 // The reference draws posterior.sample() in the eigenbasis of the posterior covariance (D M⁻¹ D = V S Vᵀ: the numbers z multiply
 // the columns of V√S) — that is what the kernels above are for, and what parity with the reference needs.  ANY square root W of
 // D M⁻¹ D gives a sample of the same distribution, and the transition density does not depend on the root: with
-// M = L Lᵀ, W = D L⁻ᵀ.  This kernel writes V := D L⁻ᵀ and S := 1 where the decomposition would write V and S — same buffers,
-// same completion protocol, same front end for a launch enqueued ahead of its input — so everything downstream (the proposal of
-// launch 1) is unchanged.  One workgroup per posterior: the normal matrix in LDS, a root-free right-looking elimination (one
-// barrier per column), then the inverse of the triangular factor, one column per lane group.  No iteration, no warm start, no
-// state from one posterior to the next: ≈ 15 µs at rank 51 against 70-110 µs for the warm-started decomposition.
+// M = L Lᵀ, W = D L⁻ᵀ, i.e. D⁻¹ W z = L⁻ᵀ z — ONE back substitution per proposal (propose_body), no decomposition, no inverse.
+// This kernel writes the factor where the decomposition would write its basis — V := L (lower triangular, row-major), S := 1/diag(L)
+// — with the same completion protocol and the same front end for a launch enqueued ahead of its input, so the machinery around
+// it (speculation, completion words, batches) is unchanged.  One workgroup per posterior; the factorisation is the chain step's own
+// (factor_reg_body: 2×4 register tiles, one barrier per column).  No iteration, no warm start, no state from one posterior to the
+// next: ≈ 15 µs at rank 51 against 70-110 µs for the warm-started decomposition.
 // (icp_proposal_set_sampler; NOT the default: the chain it produces is a different realisation of the same Markov kernel.)
 struct RootBatch2 {
   int n; EigenProblem p[2];
@@ -2150,33 +2151,17 @@ struct RootBatch2 {
 };
 typedef EigenBatchMem RootBatchMem;
 
-template <class Batch>
-__global__ void __launch_bounds__(256) k_posterior_root(int r, const double* __restrict__ sqrt_lambda_launch, Batch batch) {
+template <class Batch, int NT>
+__global__ void __launch_bounds__(NT) k_posterior_root(int r, Batch batch) {
   batch.announce();
   const EigenProblem pb = batch.p[blockIdx.x];
-  const double* __restrict__ sl = pb.sqrt_lambda ? pb.sqrt_lambda : sqrt_lambda_launch;
-  constexpr int ld = 65;
-  constexpr int kOwn = 9;  // entries of the lower triangle per thread: 64·65/2 = 2080 <= 9·256
-  __shared__ double sW[64 * ld];                                 // the finished factor, column by column (unscaled: l_ik·d_k; diagonal d_k)
-  __shared__ __attribute__((aligned(16))) double s_col[2][64];   // the pivot column of the current step (double-buffered: one barrier per column)
-  __shared__ double s_isd[64];                                   // 1/sqrt(d_k)
-  __shared__ int s_cancel, s_bad;
+  __shared__ int s_cancel;
   const int tid = threadIdx.x;
   const EigenSpec spec = pb.spec;
-  if (tid == 0) { s_cancel = 0; s_bad = 0; }
-  // ---- this thread's entries (i >= j) of the lower triangle, row-major rank e = tid + 256·u (nothing here depends on the input)
-  int ei[kOwn], ej[kOwn];
-#pragma unroll
-  for (int u = 0; u < kOwn; ++u) {
-    const int e = tid + 256 * u;
-    int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= e) ++i;
-    while (i * (i + 1) / 2 > e) --i;
-    ei[u] = i < r ? i : -1;
-    ej[u] = e - i * (i + 1) / 2;
-  }
+  EIG_STAMP(0);
+  if (tid == 0) s_cancel = 0;
   __syncthreads();
-  if (tid == 255) {  // (the protocol of k_posterior_eigen_rr: wait for the input, or for the cancellation, or give up after 5 ms)
+  if (tid == NT - 1) {  // (the protocol of k_posterior_eigen_rr: wait for the input, or for the cancellation, or give up after 5 ms)
     if (spec.ready) {
       const long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
       for (;;) {
@@ -2203,107 +2188,47 @@ __global__ void __launch_bounds__(256) k_posterior_root(int r, const double* __r
     }
     return;
   }
-  // ---- M into registers: I + Σ_s partial_s (split order from 0.0, like the factorisation; four splits in flight), or the stored matrix
-  double v[kOwn];
-  if (spec.splits > 0) {
-    const size_t nn = (size_t)(r + 1) * (r + 1);
-    size_t off[kOwn];
-#pragma unroll
-    for (int u = 0; u < kOwn; ++u) { off[u] = ei[u] >= 0 ? (size_t)ei[u] * (r + 1) + ej[u] : 0; v[u] = 0.0; }
-    int sp = 0;
-    for (; sp + 4 <= spec.splits; sp += 4) {
-      double q[4][kOwn];
-#pragma unroll
-      for (int w = 0; w < 4; ++w)
-#pragma unroll
-        for (int u = 0; u < kOwn; ++u) q[w][u] = pb.M[(size_t)(sp + w) * nn + off[u]];
-#pragma unroll
-      for (int w = 0; w < 4; ++w)
-#pragma unroll
-        for (int u = 0; u < kOwn; ++u) v[u] += q[w][u];
+  EIG_STAMP(1);
+  // the factor kernel's own body; its by-products (assembled M, α) go to this problem's scratch (`rotlog` = the proposal's work buffer)
+  double* scratch = pb.rotlog;
+  const bool ok = factor_reg_body<1, NT>(r, pb.M, spec.splits, scratch, scratch + (size_t)r * r, (int*)(scratch + (size_t)r * r + r),
+                                         -1, nullptr, spec.splits > 0 ? nullptr : pb.M, false);
+  EIG_STAMP(3);
+  // ---- V := L = L̃·D̃^{1/2} (L_ik = w_ik / sqrt(d_k), L_kk = sqrt(d_k)), Vt := Lᵀ, S := 1 / L_kk
+  const int ld = r | 1;
+  const double* W = s_dyn;
+  if (ok) {
+    for (int e = tid; e < r * r; e += NT) {
+      const int i = e / r, k = e - i * r;
+      const double v = k <= i ? W[(size_t)i * ld + k] * fast_rsqrt(W[(size_t)k * ld + k]) : 0.0;
+      pb.Vout[(size_t)i * r + k] = v;
+      pb.Vtout[(size_t)k * r + i] = v;
     }
-    for (; sp < spec.splits; ++sp)
-#pragma unroll
-      for (int u = 0; u < kOwn; ++u) v[u] += pb.M[(size_t)sp * nn + off[u]];
-#pragma unroll
-    for (int u = 0; u < kOwn; ++u) v[u] = ei[u] >= 0 ? v[u] + (ei[u] == ej[u] ? 1.0 : 0.0) : 0.0;
-  } else {
-#pragma unroll
-    for (int u = 0; u < kOwn; ++u)
-      v[u] = ei[u] >= 0 ? 0.5 * (pb.M[(size_t)ei[u] * r + ej[u]] + pb.M[(size_t)ej[u] * r + ei[u]]) : 0.0;
+    if (tid < r) pb.Sout[tid] = fast_rsqrt(W[(size_t)tid * ld + tid]);
   }
-  // ---- root-free right-looking elimination in registers: step k needs the pivot column only, published through s_col (column k+1
-  // right after step k has made it final: one barrier per column); finished columns are kept in sW
-#pragma unroll
-  for (int u = 0; u < kOwn; ++u)
-    if (ei[u] >= 0 && ej[u] == 0) { s_col[0][ei[u]] = v[u]; sW[ei[u] * ld] = v[u]; }
-  __syncthreads();
-  for (int k = 0; k < r - 1; ++k) {
-    const double* cur = s_col[k & 1];
-    double* nxt = s_col[(k + 1) & 1];
-    const double dk = cur[k];
-    if (!(dk > 0.0)) { if (tid == 0) s_bad = 1; }
-    const double inv = 1.0 / dk;
-#pragma unroll
-    for (int u = 0; u < kOwn; ++u) {
-      if (ei[u] >= 0 && ej[u] > k) {
-        v[u] -= cur[ei[u]] * cur[ej[u]] * inv;
-        if (ej[u] == k + 1) { nxt[ei[u]] = v[u]; sW[ei[u] * ld + k + 1] = v[u]; }
-      }
-    }
-    __syncthreads();
-  }
-  if (tid < r) {
-    const double d = sW[tid * ld + tid];
-    if (!(d > 0.0)) s_bad = 1;
-    s_isd[tid] = 1.0 / sqrt(d);
-  }
-  __syncthreads();
-  // ---- X = L⁻¹ with L_ik = sW[i][k]·isd_k (L_kk = sqrt(d_k) = 1/isd_k), column j by the four lanes of a group, lane q the rows
-  // m ≡ q (mod 4): x_i = (δ_ij − s_i)·isd_i, then s_m += L_mi·x_i for the rows behind it — all inside one wave, no barrier.
-  // V = D·L⁻ᵀ goes out as it is produced: V[j][i] = sl_j·X[i][j].
-  {
-    const int j = tid >> 2, q = tid & 3;
-    double sm[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) sm[t] = 0.0;
-    const double slj = j < r ? sl[j] : 0.0;
-    for (int i = 0; i < r; ++i) {
-      // the owner lane of row i holds s_i: i = q' + 4t
-      double si = 0.0;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) si = (i >> 2) == t ? sm[t] : si;
-      si = __shfl(si, (tid & 60) | (i & 3), 64);
-      const double isd_i = s_isd[i];
-      const double xi = (i < j || j >= r) ? 0.0 : ((i == j ? 1.0 : 0.0) - si) * isd_i;
-      if (q == 0 && j < r) {
-        const double vji = slj * xi;
-        pb.Vout[(size_t)j * r + i] = vji;
-        pb.Vtout[(size_t)i * r + j] = vji;
-      }
-      const double xs = xi * isd_i;  // L_mi·x_i = sW[m][i]·isd_i·x_i
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int m = q + 4 * t;
-        if (m > i && m < r) sm[t] = fma(sW[m * ld + i], xs, sm[t]);
-      }
-    }
-  }
-  if (tid < r) pb.Sout[tid] = 1.0;
+  EIG_STAMP(4);
   if (tid == 0) {
-    pb.status[0] = s_bad ? 2 : 0; pb.status[-1] = 0;
-    if (pb.host_status) __hip_atomic_store(pb.host_status, s_bad ? 2 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    pb.status[0] = ok ? 0 : 2; pb.status[-1] = 0;
+    if (pb.host_status) __hip_atomic_store(pb.host_status, ok ? 0 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __threadfence();
   __syncthreads();
   if (tid == 0 && pb.done_word) __hip_atomic_store(pb.done_word, pb.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  EIG_STAMP(5);
 }
 
 namespace {
 template <class Batch>
-void launch_root_batch(hipStream_t st, int r, const double* sqrt_lambda, int n, const Batch& batch) {
+void launch_root_batch(hipStream_t st, int r, int n, const Batch& batch) {
   ProfScope _ps(st, KID_EIGEN);
-  hipLaunchKernelGGL(k_posterior_root<Batch>, dim3(n), dim3(256), 0, st, r, sqrt_lambda, batch);
+  const size_t shmem = sizeof(double) * (size_t)(r + 1) * (r | 1);
+  if (factor_tile_count(r) <= 256) {
+    set_dyn_lds((const void*)k_posterior_root<Batch, 256>, shmem);
+    hipLaunchKernelGGL((k_posterior_root<Batch, 256>), dim3(n), dim3(256), shmem, st, r, batch);
+  } else {
+    set_dyn_lds((const void*)k_posterior_root<Batch, 1024>, shmem);
+    hipLaunchKernelGGL((k_posterior_root<Batch, 1024>), dim3(n), dim3(1024), shmem, st, r, batch);
+  }
 }
 }  // namespace
 
@@ -2351,7 +2276,7 @@ bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambd
     RootBatch2 b{};
     b.n = n;
     for (int i = 0; i < n; ++i) b.p[i] = eigen_rr_problem(r, rq[i]);
-    launch_root_batch(st, r, sqrt_lambda, n, b);
+    launch_root_batch(st, r, n, b);
     return true;
   }
   bool direct = false;
@@ -2375,7 +2300,7 @@ int launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest
   EigenProblem* rec = (EigenProblem*)pinned_records;
   for (int i = 0; i < n; ++i) rec[i] = eigen_rr_problem(r, rq[i]);
   if (rq[0].root) {  // (all requests of a batch share the sampler: checked by the caller)
-    launch_root_batch(st, r, nullptr, n, RootBatchMem{n, rec, arrive});
+    launch_root_batch(st, r, n, RootBatchMem{n, rec, arrive});
     return n;
   }
   for (int i = 0; i < n; i += chunk) {
@@ -2416,9 +2341,9 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
 
 void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,
                     const double* inv_sqrt_lambda, const double* P, double sigma2, const double* c,
-                    const double* z, double step, double* c_out) {
+                    const double* z, double step, double* c_out, int root) {
   { ProfScope _ps(st, KID_PROPOSE);
-    ProposeIn in{alpha, V, S, inv_sqrt_lambda, P, c, z, sigma2, step};
+    ProposeIn in{alpha, V, S, inv_sqrt_lambda, P, c, z, sigma2, step, root};
     hipLaunchKernelGGL(k_propose, dim3(1), dim3(256), 0, st, r, in, c_out, matvec_tpr_log2(r, 256)); }
 }
 

@@ -182,8 +182,9 @@ ICP_API int icp_proposal_log_transition(icp_proposal *p, const double *theta_fro
  *                                 of every accepted state's posterior, the longest link of an accepted step.
  *   ICP_SAMPLER_CHOLESKY_ROOT     z multiplies W = D L^-T (M = L L^T): W W^T = D M^-1 D as well, so the sample has the SAME distribution
  *                                 and logTransitionProbability (which does not depend on the root) is unchanged — the chain
- *                                 is a different realisation of the same Markov kernel.  No eigen-decomposition at all.  The diagnostic
- *                                 view then returns V = W, S = 1.  Ranks <= 64.
+ *                                 is a different realisation of the same Markov kernel.  No eigen-decomposition at all: D^-1 W z = L^-T z
+ *                                 is one back substitution per proposal.  The diagnostic view then returns V = L (row-major lower
+ *                                 triangle) and S = 1 / diag(L).  Ranks <= 64.
  * Call before the proposal's first use, or any time: posteriors already decomposed the other way are decomposed again. */
 typedef enum { ICP_SAMPLER_EIGEN = 0, ICP_SAMPLER_CHOLESKY_ROOT = 1 } icp_sampler;
 ICP_API int icp_proposal_set_sampler(icp_proposal *p, int32_t sampler);

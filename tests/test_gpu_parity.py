@@ -482,8 +482,12 @@ def test_cholesky_root_sampler_has_the_posterior_covariance(pkg, femur50):
             a, b = pe.icpPosterior(theta), pr.icpPosterior(theta)
             assert np.array_equal(a.corr_id, b.corr_id) and np.array_equal(a.alpha, b.alpha) and np.array_equal(a.M, b.M)
             cov_e = (a.V * a.S[None, :]) @ a.V.T
-            cov_r = (b.V * b.S[None, :]) @ b.V.T
-            assert np.all(b.S == 1.0) and np.allclose(np.triu(b.V, 0), b.V)          # W = D·L⁻ᵀ is upper triangular
+            # root mode: the view returns the factor itself, V = L (M = L·Lᵀ, lower triangular) and S = 1/diag(L); W = D·L⁻ᵀ
+            Lg = b.V
+            assert np.allclose(np.tril(Lg), Lg) and np.abs(b.S * np.diag(Lg) - 1.0).max() <= 1e-14
+            assert np.abs(Lg @ Lg.T - a.M).max() <= 1e-13 * np.abs(a.M).max()
+            W = sl[:, None] * np.linalg.inv(Lg).T
+            cov_r = W @ W.T
             assert np.abs(cov_r - cov_e).max() <= 1e-12 * np.abs(cov_e).max()
             want_cov = (sl[:, None] * np.linalg.inv(a.M)) * sl[None, :]
             assert np.abs(cov_r - want_cov).max() <= 1e-12 * np.abs(want_cov).max()
