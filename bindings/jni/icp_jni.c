@@ -24,9 +24,21 @@
 #include "icp_proposal.h"
 
 static void throw_status(JNIEnv *env, int st) {
-  if (st == ICP_OK || st == ICP_ERR_EMPTY) return; /* ICP_ERR_EMPTY: the Scala side maps it like the reference's empty .max */
+  if (st == ICP_OK) return;
+  if (st == ICP_ERR_EMPTY) {
+    /* no point survived the boundary filter: the reference's evaluator takes `.max` of an empty list there
+     * (evaluators/CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:49-51, :61-63) and throws — so does the binding */
+    jclass ecls = (*env)->FindClass(env, "java/lang/UnsupportedOperationException");
+    if (ecls) (*env)->ThrowNew(env, ecls, "empty.max");
+    return;
+  }
   jclass cls = (*env)->FindClass(env, "java/lang/RuntimeException");
   if (cls) (*env)->ThrowNew(env, cls, icp_last_error());
+}
+/* Get*ArrayElements returns NULL when the JVM is out of memory (an OutOfMemoryError is then pending): never dereferenced */
+static int oom(JNIEnv *env, const void *p) {
+  (void)env;
+  return p == 0;
 }
 #define PTR(T, h) ((T *)(intptr_t)(h))
 
@@ -38,17 +50,23 @@ JNIEXPORT jlong JNICALL Java_api_gpu_NativeIcp_00024_ctxCreate(JNIEnv *env, jobj
   jdouble *a_basis = (*env)->GetDoubleArrayElements(env, basis, 0), *a_var = (*env)->GetDoubleArrayElements(env, variance, 0);
   jint *a_tris = (*env)->GetIntArrayElements(env, tris, 0), *a_ttris = (*env)->GetIntArrayElements(env, ttris, 0);
   jdouble *a_tpts = (*env)->GetDoubleArrayElements(env, tpts, 0);
-  icp_model_desc md = {n, t, r, a_ref, a_mean, a_basis, a_var, (const int32_t *)a_tris};
-  icp_mesh_desc td = {m, tt, a_tpts, (const int32_t *)a_ttris};
   icp_ctx *ctx = 0;
-  int st = icp_ctx_create(&md, &td, device, &ctx); /* copies everything to HBM; keeps no JVM pointer */
-  (*env)->ReleaseDoubleArrayElements(env, ref, a_ref, JNI_ABORT);
-  if (mean) (*env)->ReleaseDoubleArrayElements(env, mean, a_mean, JNI_ABORT);
-  (*env)->ReleaseDoubleArrayElements(env, basis, a_basis, JNI_ABORT);
-  (*env)->ReleaseDoubleArrayElements(env, variance, a_var, JNI_ABORT);
-  (*env)->ReleaseIntArrayElements(env, tris, a_tris, JNI_ABORT);
-  (*env)->ReleaseDoubleArrayElements(env, tpts, a_tpts, JNI_ABORT);
-  (*env)->ReleaseIntArrayElements(env, ttris, a_ttris, JNI_ABORT);
+  int st = ICP_OK;
+  const int failed = oom(env, a_ref) || (mean && oom(env, a_mean)) || oom(env, a_basis) || oom(env, a_var) || oom(env, a_tris) ||
+                     oom(env, a_ttris) || oom(env, a_tpts);
+  if (!failed) {
+    icp_model_desc md = {n, t, r, a_ref, a_mean, a_basis, a_var, (const int32_t *)a_tris};
+    icp_mesh_desc td = {m, tt, a_tpts, (const int32_t *)a_ttris};
+    st = icp_ctx_create(&md, &td, device, &ctx); /* copies everything to HBM; keeps no JVM pointer */
+  }
+  if (a_ref) (*env)->ReleaseDoubleArrayElements(env, ref, a_ref, JNI_ABORT);
+  if (mean && a_mean) (*env)->ReleaseDoubleArrayElements(env, mean, a_mean, JNI_ABORT);
+  if (a_basis) (*env)->ReleaseDoubleArrayElements(env, basis, a_basis, JNI_ABORT);
+  if (a_var) (*env)->ReleaseDoubleArrayElements(env, variance, a_var, JNI_ABORT);
+  if (a_tris) (*env)->ReleaseIntArrayElements(env, tris, a_tris, JNI_ABORT);
+  if (a_tpts) (*env)->ReleaseDoubleArrayElements(env, tpts, a_tpts, JNI_ABORT);
+  if (a_ttris) (*env)->ReleaseIntArrayElements(env, ttris, a_ttris, JNI_ABORT);
+  if (failed) return 0; /* (the pending OutOfMemoryError surfaces in the caller) */
   throw_status(env, st);
   return (jlong)(intptr_t)ctx;
 }
@@ -62,9 +80,11 @@ JNIEXPORT void JNICALL Java_api_gpu_NativeIcp_00024_ctxDestroy(JNIEnv *env, jobj
 JNIEXPORT void JNICALL Java_api_gpu_NativeIcp_00024_setRotation(JNIEnv *env, jobject self, jlong ctx, jdoubleArray angles, jdoubleArray rot) {
   (void)self;
   jdouble *a = (*env)->GetDoubleArrayElements(env, angles, 0), *r = rot ? (*env)->GetDoubleArrayElements(env, rot, 0) : 0;
-  int st = icp_ctx_set_rotation(PTR(icp_ctx, ctx), a, r);
-  (*env)->ReleaseDoubleArrayElements(env, angles, a, JNI_ABORT);
-  if (rot) (*env)->ReleaseDoubleArrayElements(env, rot, r, JNI_ABORT);
+  const int failed = oom(env, a) || (rot && oom(env, r));
+  int st = failed ? ICP_OK : icp_ctx_set_rotation(PTR(icp_ctx, ctx), a, r);
+  if (a) (*env)->ReleaseDoubleArrayElements(env, angles, a, JNI_ABORT);
+  if (rot && r) (*env)->ReleaseDoubleArrayElements(env, rot, r, JNI_ABORT);
+  if (failed) return;
   throw_status(env, st);
 }
 
@@ -74,6 +94,7 @@ JNIEXPORT jlong JNICALL Java_api_gpu_NativeIcp_00024_proposalCreate(JNIEnv *env,
   (void)self;
   jsize nt = target_pts ? (*env)->GetArrayLength(env, target_pts) / 3 : 0;
   jdouble *tp = target_pts ? (*env)->GetDoubleArrayElements(env, target_pts, 0) : 0;
+  if (target_pts && oom(env, tp)) return 0;
   icp_proposal_params prm = {step, sigma_t, sigma_n, direction, boundary_aware ? 1 : 0, n_model_ids, (int32_t)nt, tp};
   icp_proposal *p = 0;
   int st = icp_proposal_create(PTR(icp_ctx, ctx), &prm, &p);
