@@ -54,6 +54,10 @@ class KernelStat(C.Structure):
                 ("max_ms", C.c_double)]
 
 
+class MhMixture(C.Structure):
+    _fields_ = [("icp_weight", C.c_double * 2), ("w_icp", C.c_double), ("w_rw", C.c_double), ("rw_sigma", C.c_double)]
+
+
 class RuntimeStats(C.Structure):
     _fields_ = [("wait_timeouts", C.c_int64), ("speculation_giveups", C.c_int64), ("pipeline_fallbacks", C.c_int64),
                 ("step_redos", C.c_int64), ("gate_timeouts", C.c_int64), ("reserved", C.c_int64 * 3)]
@@ -103,6 +107,9 @@ SIGNATURES = {
     "icp_chain_step_batched_abandon": (C.c_int, [C.c_void_p]),
     "icp_ctx_set_rotation": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "icp_ctx_runtime_stats": (C.c_int, [C.c_void_p, C.POINTER(RuntimeStats)]),
+    "icp_chains_run_on_device": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(MhMixture),
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(c_double_p), c_double_p, C.c_int32,
+                                           C.POINTER(c_double_p), C.POINTER(C.c_int64)]),
     "icp_chain_step_batched": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                          C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p), c_double_p, c_double_p,
                                          c_double_p, C.POINTER(C.c_int32)]),

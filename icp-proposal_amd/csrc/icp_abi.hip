@@ -2469,6 +2469,9 @@ void start_decompositions(icp_ctx& c, int n_props, icp_proposal* const* props, P
   for (int i = 0; i < nn; ++i) need[i]->eig_event_valid = true;
 }
 
+void front_launches(icp_evaluator* e, int n_props, icp_proposal* const* props, int generator, const double* key, StepFront& F, bool batched,
+                    bool two_streams);
+
 // launches 1-3 of the step (theta_cur --generator/key--> proposal); `key` = z or the proposed state (see StepFront)
 // (batched: the launches are being captured for icp_chain_step_batched — one stream, nothing to wait for on the device
 // but the decomposition)
@@ -2520,6 +2523,20 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   F.s = &s;
   s.pose = c.pose_of(generator >= 0 ? theta_cur : key);
   for (int i = 0; i < n_props; ++i) { ep[i] = &props[i]->fresh_entry(); ep[i]->reserved = true; }
+  front_launches(e, n_props, props, generator, key, F, batched, two_streams);
+  F.valid = true;
+}
+
+// launches 1-4 of a merged step with every choice made: F.ec / F.ep (the posterior entries of the current and of the proposed state),
+// F.s (the proposed state's slot, its pose set), F.parity, F.stream.  enqueue_front above makes those choices from the memo; the
+// on-device chain loop (icp_chains_run_on_device) fixes them once per chain and captures the arguments.
+void front_launches(icp_evaluator* e, int n_props, icp_proposal* const* props, int generator, const double* key, StepFront& F, bool batched,
+                    bool two_streams) {
+  icp_ctx& c = *e->ctx;
+  const int r = c.r;
+  PosteriorEntry** ec = F.ec;
+  PosteriorEntry** ep = F.ep;
+  StateSlot& s = *F.s;
   const icp_evaluator_params& evp = e->prm;
   icp_proposal* pm = nullptr;  // ModelSampling proposal
   icp_proposal* pt = nullptr;  // TargetSampling proposal
@@ -2660,8 +2677,6 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
       launch_step_reduce(F.stream, ra);
     }
   }
-
-  F.valid = true;
 }
 
 // Host side of a merged step whose results have arrived in the context's pinned memory: status of the decomposition it
@@ -2980,6 +2995,22 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
 // The work is split in two so that a caller can keep two batches in flight (the decompositions of one run beside the
 // launches of the other): _issue ends when everything is on the device, _collect waits and records.
 } // extern "C" (helpers)
+
+// StepRandom::normal of the C++ harness (host/icp_host.hpp; = orc_rng_normal of the oracle): Box–Muller over the counter-based uniforms
+static inline uint64_t harness_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+static inline double harness_uniform(uint64_t seed, uint64_t step, uint64_t lane) {
+  const uint64_t h = harness_splitmix64(harness_splitmix64(harness_splitmix64(seed) ^ (step * 0xD1342543DE82EF95ull)) ^ (lane * 0x2545F4914F6CDD1Dull));
+  return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+static inline double harness_normal(uint64_t seed, uint64_t step, uint64_t lane) {
+  const double u1 = harness_uniform(seed, step, 2 * lane + 1000), u2 = harness_uniform(seed, step, 2 * lane + 1001);
+  return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
+}
 
 struct BatchItem {
   icp_evaluator* e = nullptr;
@@ -3329,6 +3360,357 @@ int icp_chain_step_batched_abandon(icp_step_ticket* tk) {
   batch_release(*tk);  // waits for the batch's launches, gives back what they hold; nothing of the step is recorded
   delete tk;
   return ICP_OK;
+}
+
+// --------------------------------------------------------------------- the whole MH loop on the device (MhChain, kernels_step.hip)
+int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props_in,
+                             const icp_mh_mixture* mix, const uint64_t* seeds, const int64_t* first_step, double* const* theta,
+                             double* log_value, int32_t n_steps, double* const* records, int64_t* accepted) {
+  struct Chain {
+    icp_evaluator* e = nullptr;
+    icp_proposal* props[2] = {nullptr, nullptr};
+    PosteriorEntry* set[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [sel][proposal]
+    StateSlot* slot = nullptr;
+    std::unique_lock<std::recursive_mutex> lk;
+    bool busy = false;
+  };
+  std::vector<Chain> chains;
+  auto release = [&]() {
+    for (auto& ch : chains) {
+      if (!ch.e) continue;
+      icp_ctx& c = *ch.e->ctx;
+      if (!ch.lk.owns_lock()) ch.lk = std::unique_lock<std::recursive_mutex>(c.mu);
+      for (int sel = 0; sel < 2; ++sel)
+        for (int i = 0; i < 2; ++i)
+          if (ch.set[sel][i]) ch.set[sel][i]->reserved = false;
+      if (ch.slot) ch.slot->reserved = false;
+      if (ch.busy) c.batch_busy = false;
+      ch.lk.unlock();
+    }
+  };
+  int rc = guard([&] {
+    require(n_chains >= 1 && evaluators && props_in && mix && seeds && first_step && theta && log_value && n_steps >= 0, "null argument");
+    require(n_props >= 1 && n_props <= 2, "the on-device loop takes one or two ICP proposals per chain");
+    require(mix->w_icp > 0.0 && mix->w_rw >= 0.0 && mix->rw_sigma > 0.0, "bad mixture");
+    chains.resize(n_chains);
+    icp_ctx& lead = *evaluators[0]->ctx;
+    const int r = lead.r, P = 10 + r;
+    require(eigen_speculation_supported(r), "the on-device loop covers ranks 3..64");
+    // ---- claim the chains' contexts, fix their posterior entries and state slot
+    for (int b = 0; b < n_chains; ++b) {
+      Chain& ch = chains[b];
+      require(evaluators[b] && theta[b], "null argument");
+      icp_ctx& c = *evaluators[b]->ctx;
+      require(c.device == lead.device && c.r == r, "chains of one run share a device and a rank");
+      for (int a = 0; a < b; ++a) require(chains[a].e->ctx != &c, "every chain needs a context of its own");
+      ch.e = evaluators[b];
+      for (int i = 0; i < n_props; ++i) {
+        ch.props[i] = props_in[(size_t)b * n_props + i];
+        require(ch.props[i] && ch.props[i]->ctx == &c, "proposal belongs to another context");
+        require(ch.props[i]->sampler == ch.props[0]->sampler && ch.props[i]->sampler == chains[0].props[0]->sampler, "one sampler per run");
+      }
+      check_theta_finite(&c, theta[b]);
+      ch.lk = std::unique_lock<std::recursive_mutex>(c.mu);
+      if (c.batch_busy) fail(ICP_ERR_BUSY, "a chain's context already belongs to a batch in flight");
+      require(step_pipeline_covers(ch.e, n_props, ch.props), "configuration not covered by the merged launches");
+      Bound _b(&c);
+      if (ch.e->front.valid) release_front(ch.e->front);
+      for (int i = 0; i < n_props; ++i) {
+        icp_proposal* p = ch.props[i];
+        p->resolve_speculation(theta[b]);
+        PosteriorEntry& cur = p->posterior(theta[b], false);  // the current state's posterior and its basis, the ordinary way
+        p->ensure_eigen(cur);
+        cur.reserved = true;
+        ch.set[0][i] = &cur;
+        PosteriorEntry& other = p->fresh_entry();
+        other.reserved = true;
+        ch.set[1][i] = &other;
+      }
+      HIP_OK(hipStreamSynchronize(c.stream));
+      HIP_OK(hipStreamSynchronize(c.front_stream));
+      sync_eigen(c);
+      for (int i = 0; i < n_props; ++i) {
+        sync_proposal_status(ch.props[i]);
+        ch.props[i]->check_status(*ch.set[0][i]);
+        if (ch.props[i]->h_eig[ch.set[0][i]->status_off / 3] != 0) fail(ICP_ERR_NOT_FINITE, "posterior eigen-decomposition did not converge");
+      }
+      StateSlot& s = c.fresh_state();
+      s.reserved = true;
+      s.pose = c.pose_of(theta[b]);
+      ch.slot = &s;
+      c.batch_busy = true;
+      ch.busy = true;
+      ch.lk.unlock();
+    }
+    // ---- groups: each its own stream, everything of a group in order on it; two groups overlap each other's small launches
+    const int n_groups = n_chains >= 16 ? 2 : 1;
+    struct Group {
+      int b0 = 0, B = 0;
+      hipStream_t st = nullptr;
+      int grid[5] = {0, 0, 0, 0, 0};
+      DBuf<StepBeginArgs> begin_alt, begin_live;
+      DBuf<StepSearchArgs> search_alt, search_live;
+      DBuf<StepRegressionArgs> regression_alt, regression_live;
+      DBuf<StepFinishArgs> finish_alt, finish_live;
+      DBuf<MhChain> mh;
+      DBuf<EigenProblem> eig_live;
+      DBuf<int> eig_skip;
+      DBuf<double> normals[2], theta, rec;
+      double* h_normals[2] = {nullptr, nullptr};
+      hipEvent_t ev_copy[2] = {nullptr, nullptr};
+    };
+    std::vector<Group> groups(n_groups);
+    constexpr int kChunk = 64;  // steps per block of standard normals
+    const int root = chains[0].props[0]->sampler == ICP_SAMPLER_CHOLESKY_ROOT;
+    struct GroupGuard {
+      std::vector<Group>& g;
+      ~GroupGuard() {
+        for (auto& gr : g) {
+          for (int k = 0; k < 2; ++k) {
+            if (gr.h_normals[k]) (void)hipHostFree(gr.h_normals[k]);
+            if (gr.ev_copy[k]) (void)hipEventDestroy(gr.ev_copy[k]);
+          }
+        }
+      }
+    } group_guard{groups};
+    lead.bind();
+    std::vector<double> zero_key(P, 0.0);
+    for (int g = 0; g < n_groups; ++g) {
+      Group& gr = groups[g];
+      gr.b0 = (int)((long long)g * n_chains / n_groups);
+      gr.B = (int)((long long)(g + 1) * n_chains / n_groups) - gr.b0;
+      gr.st = chains[gr.b0].e->ctx->stream;  // the group's first context's stream (every chain has a context, hence a stream, of its own)
+      const int B = gr.B;
+      gr.begin_alt.alloc(2 * B); gr.begin_live.alloc(B);
+      gr.search_alt.alloc(2 * B); gr.search_live.alloc(B);
+      gr.regression_alt.alloc(2 * B); gr.regression_live.alloc(B);
+      gr.finish_alt.alloc(2 * B); gr.finish_live.alloc(B);
+      gr.mh.alloc(B);
+      gr.eig_live.alloc((size_t)B * n_props);
+      gr.eig_skip.alloc((size_t)B * n_props);
+      gr.theta.alloc((size_t)B * P);
+      gr.rec.alloc(records ? (size_t)B * std::max(n_steps, 1) * (4 + P) : 1);
+      for (int k = 0; k < 2; ++k) {
+        gr.normals[k].alloc((size_t)B * kChunk * r);
+        HIP_OK(hipHostMalloc((void**)&gr.h_normals[k], sizeof(double) * (size_t)B * kChunk * r, hipHostMallocDefault));
+        HIP_OK(hipEventCreateWithFlags(&gr.ev_copy[k], hipEventDisableTiming));
+      }
+      std::vector<StepBeginArgs> hb(2 * B);
+      std::vector<StepSearchArgs> hs(2 * B);
+      std::vector<StepRegressionArgs> hr(2 * B);
+      std::vector<StepFinishArgs> hf(2 * B);
+      std::vector<MhChain> hm(B);
+      std::vector<int> hskip((size_t)B * n_props, 1);
+      std::vector<double> hth((size_t)B * P);
+      for (int k = 0; k < B; ++k) {
+        Chain& ch = chains[gr.b0 + k];
+        icp_ctx& c = *ch.e->ctx;
+        std::lock_guard<std::recursive_mutex> lk(c.mu);
+        Bound _b(&c, true, true);
+        MhChain& m = hm[k];
+        std::memset(&m, 0, sizeof(m));
+        for (int sel = 0; sel < 2; ++sel) {
+          // the step's launches with the current state in set `sel` and the proposed one in the other, captured
+          StepCapture cap;
+          std::memset(cap.grid, 0, sizeof(cap.grid));
+          StepFront F;
+          F.n_props = n_props; F.generator = -1; F.parity = 0; F.stream = c.stream; F.s = ch.slot;
+          for (int i = 0; i < n_props; ++i) { F.props[i] = ch.props[i]; F.ec[i] = ch.set[sel][i]; F.ep[i] = ch.set[1 - sel][i]; }
+          {
+            struct CaptureScope { CaptureScope(StepCapture* cp) { step_capture(cp); } ~CaptureScope() { step_capture(nullptr); } } scope(&cap);
+            front_launches(ch.e, n_props, ch.props, -1, zero_key.data(), F, true, false);
+            StepFinishArgs f{};
+            f.n = n_props; f.r = r; f.Ginv = c.Ginv.p; f.sigma2 = kSigma2;
+            for (int i = 0; i < n_props; ++i) {
+              icp_proposal* p = ch.props[i];
+              f.Mpart[i] = F.mpart[i]; f.splits[i] = F.splits[i];
+              f.M[i] = F.ep[i]->M.p; f.alpha[i] = F.ep[i]->alpha.p;
+              f.status[i] = p->status.p + F.ep[i]->status_off;
+              f.host_status[i] = c.h_status + 8 + i;
+              f.fwd[i] = TransitionTailIO{F.ec[i]->alpha.p, F.ec[i]->M.p, F.ec[i]->coeffs.p, F.ep[i]->coeffs.p, p->prm.step_length,
+                                          c.h_res + 8 + 2 * i, c.h_status + 2 * i};
+              f.bwd[i] = TransitionTailIO{F.ep[i]->alpha.p, F.ep[i]->M.p, F.ep[i]->coeffs.p, F.ec[i]->coeffs.p, p->prm.step_length,
+                                          c.h_res + 9 + 2 * i, c.h_status + 2 * i + 1};
+            }
+            f.done_counter = c.d_done.p; f.host_flag = c.h_flag; f.seq = 0;
+            f.ready_flag = nullptr;
+            launch_step_finish(c.stream, f);  // (captured; finalised by the launcher)
+          }
+          cap.begin.wait_flag = nullptr; cap.begin.wait2_flag = nullptr; cap.begin.wait_ticks = nullptr; cap.begin.hold_regs = 0;
+          {  // (launch 1's matvec layout: set by enqueue_front only when it knows the generator)
+            int t = 0;
+            while (t < 6 && (r << (t + 1)) <= 256 && (r >> (t + 1)) >= 8) ++t;
+            cap.begin.tpr_log2 = t;
+          }
+          hb[(size_t)sel * B + k] = cap.begin; hs[(size_t)sel * B + k] = cap.search; hr[(size_t)sel * B + k] = cap.regression;
+          hf[(size_t)sel * B + k] = cap.finish;
+          for (int q = 0; q < 5; ++q) gr.grid[q] = std::max(gr.grid[q], cap.grid[q]);
+          m.begin_alt[sel] = gr.begin_alt.p + (size_t)sel * B + k;
+          m.search_alt[sel] = gr.search_alt.p + (size_t)sel * B + k;
+          m.regression_alt[sel] = gr.regression_alt.p + (size_t)sel * B + k;
+          m.finish_alt[sel] = gr.finish_alt.p + (size_t)sel * B + k;
+          for (int i = 0; i < n_props; ++i) {
+            icp_proposal* p = ch.props[i];
+            PosteriorEntry& cur = *ch.set[sel][i];
+            m.prop_alt[sel][i] = ProposeIn{cur.alpha.p, cur.V.p, cur.S.p, c.inv_sqrt_lambda.p, c.P.p, cur.coeffs.p, nullptr, kSigma2,
+                                           p->prm.step_length, root};
+            // the decomposition of set `sel`'s posterior (an accepted state arrives there), warm-started from the other set's basis
+            PosteriorEntry& other = *ch.set[1 - sel][i];
+            EigenRequest rq{cur.M.p, root ? nullptr : other.V.p, cur.V.p, cur.Vt.p, cur.S.p, p->work.p, p->status.p + cur.status_off + 2, nullptr,
+                            p->h_eig + cur.status_off / 3, p->eig_words.p + cur.status_off / 3, 0, c.sqrt_lambda.p};
+            rq.root = root != 0;
+            m.eig_alt[sel][i] = eigen_problem_of(r, rq);
+          }
+        }
+        m.begin_live = gr.begin_live.p + k; m.search_live = gr.search_live.p + k;
+        m.regression_live = gr.regression_live.p + k; m.finish_live = gr.finish_live.p + k;
+        m.eig_live = gr.eig_live.p + (size_t)k * n_props;
+        m.eig_skip = gr.eig_skip.p + (size_t)k * n_props;
+        m.pw_id_mask = 2046;
+        m.seed = seeds[gr.b0 + k];
+        m.r = r; m.n_icp = n_props;
+        {  // MixtureProposal weights, normalised as the harness normalises them (host/icp_host.hpp: pick_component)
+          double ws = 0.0;
+          for (int i = 0; i < n_props; ++i) ws += mix->icp_weight[i];
+          for (int i = 0; i < n_props; ++i) m.icp_w[i] = mix->icp_weight[i] / ws;
+          double raw[2];
+          int no = 0;
+          m.outer_kind[no] = 1; raw[no++] = mix->w_icp;
+          if (mix->w_rw > 0.0) { m.outer_kind[no] = 2; raw[no++] = mix->w_rw; }
+          double wsum = 0.0;
+          for (int o = 0; o < no; ++o) wsum += raw[o];
+          for (int o = 0; o < no; ++o) m.outer_w[o] = raw[o] / wsum;
+          m.n_outer = no;
+        }
+        m.rw_sigma = mix->rw_sigma;
+        m.rw_logc = 0.5 * (r * std::log(2.0 * M_PI) + r * std::log(mix->rw_sigma * mix->rw_sigma));
+        m.prior_c = 0.5 * r * std::log(2.0 * M_PI);
+        const icp_evaluator_params& ep = ch.e->prm;
+        m.eval_kind = ep.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE ? 0 : 2;
+        m.eval_mode = ep.mode;
+        m.gauss_mean = ep.gauss_mean; m.gauss_sigma = ep.gauss_sigma;
+        m.gauss_logn = std::log(std::sqrt(2.0 * M_PI)) + std::log(ep.gauss_sigma);
+        m.exp_rate = ep.exp_rate; m.exp_lograte = std::log(ep.exp_rate);
+        m.coeff_prop = ch.slot->coeffs.p;
+        m.red = c.h_res + kReduceArea;  // (parity 0)
+        m.tails = c.h_res + 8;
+        m.tail_status = c.h_status;
+        m.chol_status = c.h_status + 8;
+        m.normals = nullptr; m.normals_first = 0;
+        m.records = records && records[gr.b0 + k] ? gr.rec.p + (size_t)k * n_steps * (4 + P) : nullptr;
+        m.rec_first = first_step[gr.b0 + k];
+        m.theta = gr.theta.p + (size_t)k * P;
+        m.cur_p = log_value[gr.b0 + k];
+        m.step = first_step[gr.b0 + k];
+        m.accepted = 0; m.cur_sel = 0; m.gen = -1; m.leaf = -1; m.error = 0;
+        for (int i = 0; i < n_props; ++i) m.eig_seq[i] = ch.props[i]->eig_seq;
+        std::memcpy(hth.data() + (size_t)k * P, theta[gr.b0 + k], sizeof(double) * P);
+        for (int i = 0; i < 16; ++i) { c.h_res[i] = 0.0; c.h_status[i] = 0; }
+      }
+      HIP_OK(hipMemcpy(gr.begin_alt.p, hb.data(), sizeof(StepBeginArgs) * hb.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(gr.search_alt.p, hs.data(), sizeof(StepSearchArgs) * hs.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(gr.regression_alt.p, hr.data(), sizeof(StepRegressionArgs) * hr.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(gr.finish_alt.p, hf.data(), sizeof(StepFinishArgs) * hf.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(gr.eig_skip.p, hskip.data(), sizeof(int) * hskip.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(gr.theta.p, hth.data(), sizeof(double) * hth.size(), hipMemcpyHostToDevice));
+      // (normals: the two buffers are addressed through MhChain::normals / normals_first, re-pointed per block of steps below)
+      HIP_OK(hipMemcpy(gr.mh.p, hm.data(), sizeof(MhChain) * hm.size(), hipMemcpyHostToDevice));
+    }
+    // ---- the loop: per block of kChunk steps the chains' standard normals (the harness' own expression, drawn here on the host
+    // while the device works on the block before), then per step and group eight launches, nothing waited for
+    auto draw_block = [&](Group& gr, int blk, int buf) {
+      const int s0 = blk * kChunk, ns = std::min(kChunk, n_steps - s0);
+      double* out = gr.h_normals[buf];
+      for (int k = 0; k < gr.B; ++k) {
+        const uint64_t seed = seeds[gr.b0 + k];
+        const uint64_t f0 = (uint64_t)first_step[gr.b0 + k] + (uint64_t)s0;
+        for (int s_ = 0; s_ < ns; ++s_)
+          for (int j = 0; j < r; ++j) out[((size_t)k * kChunk + s_) * r + j] = harness_normal(seed, f0 + (uint64_t)s_, (uint64_t)j);
+      }
+    };
+    const int n_blocks = (n_steps + kChunk - 1) / kChunk;
+    for (int blk = 0; blk < n_blocks; ++blk) {
+      const int buf = blk & 1, s0 = blk * kChunk, ns = std::min(kChunk, n_steps - s0);
+      for (auto& gr : groups) {
+        HIP_OK(hipEventSynchronize(gr.ev_copy[buf]));  // (the staging buffer's previous upload has left it)
+        draw_block(gr, blk, buf);
+        HIP_OK(hipMemcpyAsync(gr.normals[buf].p, gr.h_normals[buf], sizeof(double) * (size_t)gr.B * kChunk * r, hipMemcpyHostToDevice, gr.st));
+        HIP_OK(hipEventRecord(gr.ev_copy[buf], gr.st));
+        launch_mh_set_normals(gr.st, gr.B, gr.mh.p, gr.normals[buf].p, kChunk * r, s0);
+      }
+      for (int s_ = 0; s_ < ns; ++s_)
+        for (auto& gr : groups) {
+          launch_mh_front(gr.st, gr.B, gr.mh.p);
+          launch_step_batch_resident(gr.st, gr.B, gr.grid, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p);
+          launch_mh_decide(gr.st, gr.B, gr.mh.p);
+          launch_posterior_eigen_resident(gr.st, r, gr.B * n_props, gr.eig_live.p, gr.eig_skip.p, root);
+        }
+    }
+    // ---- results: nothing is handed out unless every chain came through
+    std::vector<std::vector<MhChain>> hms(n_groups);
+    int first_error = 0;
+    for (int g = 0; g < n_groups; ++g) {
+      Group& gr = groups[g];
+      HIP_OK(hipStreamSynchronize(gr.st));
+      hms[g].resize(gr.B);
+      HIP_OK(hipMemcpy(hms[g].data(), gr.mh.p, sizeof(MhChain) * hms[g].size(), hipMemcpyDeviceToHost));
+      for (const MhChain& m : hms[g])
+        if (m.error != 0 && first_error == 0) first_error = m.error;
+    }
+    if (first_error != 0) {
+      for (auto& ch : chains) {  // whatever the sets hold now belongs to no state on record
+        std::lock_guard<std::recursive_mutex> lk(ch.e->ctx->mu);
+        for (int i = 0; i < n_props; ++i) {
+          for (int sel = 0; sel < 2; ++sel) { ch.set[sel][i]->valid = false; ch.set[sel][i]->eig_valid = false; ch.set[sel][i]->eig_checked = false; }
+          ch.props[i]->warm_valid = false;
+          ch.props[i]->spec_entry = nullptr;
+        }
+        ch.slot->valid = false;
+      }
+      fail(first_error == 3 ? ICP_ERR_NOT_SPD : first_error == 5 ? ICP_ERR_EMPTY : ICP_ERR_NOT_FINITE,
+           first_error == 2 ? "on-device loop: a transition tail did not contract (step these chains through icp_chain_step_batched)"
+                            : "on-device loop: a chain stopped on a non-finite, empty or non-positive-definite result");
+    }
+    for (int g = 0; g < n_groups; ++g) {
+      Group& gr = groups[g];
+      std::vector<double> hth((size_t)gr.B * P);
+      HIP_OK(hipMemcpy(hth.data(), gr.theta.p, sizeof(double) * hth.size(), hipMemcpyDeviceToHost));
+      for (int k = 0; k < gr.B; ++k) {
+        const int b = gr.b0 + k;
+        Chain& ch = chains[b];
+        icp_ctx& c = *ch.e->ctx;
+        const MhChain& m = hms[g][k];
+        std::memcpy(theta[b], hth.data() + (size_t)k * P, sizeof(double) * P);
+        log_value[b] = m.cur_p;
+        if (accepted) accepted[b] = m.accepted;
+        if (records && records[b] && n_steps > 0)
+          HIP_OK(hipMemcpy(records[b], gr.rec.p + (size_t)k * n_steps * (4 + P), sizeof(double) * (size_t)n_steps * (4 + P), hipMemcpyDeviceToHost));
+        // the contexts' own bookkeeping: the set that holds the current state is on record again, decomposed
+        std::lock_guard<std::recursive_mutex> lk(c.mu);
+        for (int i = 0; i < n_props; ++i) {
+          icp_proposal* p = ch.props[i];
+          for (int sel = 0; sel < 2; ++sel) {
+            PosteriorEntry& en = *ch.set[sel][i];
+            const bool cur = sel == m.cur_sel;
+            en.valid = cur; en.eig_valid = cur; en.eig_checked = cur; en.eig_event_valid = false; en.done_value = 0;
+            if (cur) {
+              en.theta.assign(theta[b], theta[b] + P);
+              en.stamp = ++p->clock;
+              p->h_eig[en.status_off / 3] = 0;
+              p->warm_ptr = en.V.p;
+              p->warm_valid = true;
+            }
+          }
+          p->eig_seq = m.eig_seq[i];
+          p->spec_entry = nullptr;
+        }
+        ch.slot->valid = false;
+        ch.e->last_prop.clear();
+      }
+    }
+  });
+  release();
+  return rc;
 }
 
 int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props,

@@ -228,6 +228,16 @@ struct EigenRequest { const double* M; const double* Vwarm; double* V; double* V
                       bool root = false; /* write V := D·L⁻ᵀ (M = L·Lᵀ), S := 1 instead of the eigen-decomposition: the opt-in
                       Cholesky-root sampler (kernels_posterior.hip: k_posterior_root; ranks <= 64) */ };
 bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq);
+// one decomposition as the rank <= 64 kernels see it (EigenRequest resolved into the kernel's own pointers)
+struct EigenProblem {
+  const double* M; const double* Vwarm /* may be Vout */; double* Vout; double* Vtout; double* Sout; int* status;
+  double* rotlog; int* meta; double* vpos; EigenSpec spec; int launch_id; int* host_status; int* done_word; int done_value;
+  const double* sqrt_lambda;  // of this problem's model (nullptr: the launch's)
+};
+EigenProblem eigen_problem_of(int r, const EigenRequest& rq);
+// decompositions (root != 0: Cholesky factors, k_posterior_root) of n records that LIVE IN DEVICE MEMORY, skip[i] != 0 leaving record i
+// out: the on-device chain loop's launch (its decide kernel writes records and skip flags)
+void launch_posterior_eigen_resident(hipStream_t st, int r, int n, const EigenProblem* records, const int* skip, int root);
 // any number of decompositions of one rank (the chains of icp_chain_step_batched) in ONE launch (up to 80; more: a second launch on
 // the same stream); every request carries its model's sqrt_lambda.  pinned_records: eigen_many_record_bytes(n) bytes of pinned host
 // memory that stay untouched until the launch has finished (the kernel reads its records there); arrive (may be null): a device
@@ -400,6 +410,59 @@ size_t step_batch_bytes(int B);
 struct StepBatchGate { const int* counter = nullptr; int expected = 0; int* error = nullptr; };
 void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pinned, void* device, hipStream_t st_finish = nullptr,
                        hipEvent_t ev = nullptr, StepBatchGate gate = StepBatchGate{});
+// ---- the on-device Metropolis–Hastings loop (kernels_step.hip: k_mh_front / k_mh_decide; icp_abi.hip:
+// icp_chains_run_on_device).  One record per chain in device memory.  The five merged launches read their per-chain arguments from
+// device-resident arrays (as in icp_chain_step_batched); the arguments exist in TWO alternatives per chain — which of a proposal's two
+// posterior entries holds the CURRENT state — and k_mh_front copies the right one into the live array at the head of every step and
+// fills in what changes from step to step (which proposal generates, its standard normals or the random-walk sample).  k_mh_decide,
+// behind launch 5, is Scalismo's MetropolisHastings.next for the step (prior, product value, mixture transition ratio by log-sum-exp over
+// ALL leaves, accept/reject with the step's uniform draw, record) and, for an accepted state, writes the decomposition records of its
+// posteriors.  Random numbers: the harness' counter-based generator (host/icp_host.hpp: splitmix64 over (seed, step, lane)) — the
+// uniforms are integer arithmetic and are drawn on the device, bit for bit the host's; the standard normals need log / cos and are
+// drawn on the host with the harness' own expression and streamed in ahead of the steps that use them.
+struct MhChain {
+  // -- fixed for the run
+  unsigned long long seed;
+  int r, n_icp;
+  int n_outer, outer_kind[2];            // outer mixture in the reference's order; kind 1 = the ICP mixture, 2 = the shape random walk
+  double outer_w[2];                     // normalised weights
+  double icp_w[2];                       // normalised inner weights of the ICP mixture
+  double rw_sigma, rw_logc;              // rw_logc = 0.5·(r·log 2π + r·log σ²)
+  double prior_c;                        // 0.5·r·log 2π
+  int eval_kind, eval_mode;              // icp_eval_kind / icp_eval_mode
+  double gauss_mean, gauss_sigma, gauss_logn /* log sqrt(2π) + log σ */, exp_rate, exp_lograte;
+  const StepBeginArgs* begin_alt[2]; StepBeginArgs* begin_live;
+  const StepSearchArgs* search_alt[2]; StepSearchArgs* search_live;
+  const StepRegressionArgs* regression_alt[2]; StepRegressionArgs* regression_live;
+  const StepFinishArgs* finish_alt[2]; StepFinishArgs* finish_live;
+  ProposeIn prop_alt[2][2];              // [cur_sel][ICP proposal]: the proposal from the current state's posterior
+  EigenProblem eig_alt[2][2];            // [new cur_sel][ICP proposal]: decomposition of the accepted state's posterior, warm start = the other set's basis
+  EigenProblem* eig_live;                // [n_icp] this chain's records in the launch's array
+  int* eig_skip;                         // [n_icp]
+  int pw_id_mask;                        // launch ids of the decompositions: 1 + q % mask
+  const double* coeff_prop;              // proposed coefficients as launch 1 wrote them (the state slot's copy)
+  const double* red;                     // launch 4's likelihood reductions [8]
+  const double* tails;                   // fwd_i = tails[2i], bwd_i = tails[2i + 1]
+  const int* tail_status;                // [2·n_icp] (fixed-point tail did not contract: the host's direct kernel would be needed)
+  const int* chol_status;                // [n_icp]
+  const double* normals;                 // [steps][r] standard normals of this chain, row = step − normals_first
+  long long normals_first;
+  double* records;                       // [steps][4 + 10 + r], row = step − rec_first
+  long long rec_first;
+  // -- chain state
+  double* theta;                         // [10 + r] current state
+  double cur_p;                          // its log product value (prior × likelihood)
+  long long step, accepted;
+  int cur_sel, gen, leaf, error;         // error != 0: the chain needs the host (non-contracting tail, non-finite value, …) and stands still
+  int eig_seq[2];                        // decompositions of proposal i so far (cold every 128th, as the host path)
+};
+void launch_mh_set_normals(hipStream_t st, int B, MhChain* chains, const double* base, int stride, int offset);
+void launch_mh_front(hipStream_t st, int B, MhChain* chains);
+void launch_mh_decide(hipStream_t st, int B, MhChain* chains);
+// the five merged launches for B chains from DEVICE-RESIDENT argument arrays (no copy kernel, no gate: one stream, in order)
+void launch_step_batch_resident(hipStream_t st, int B, const int grid[5], int r, const StepBeginArgs* begin, const StepSearchArgs* search,
+                                const StepRegressionArgs* regression, const StepFinishArgs* finish);
+
 SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const float4* spheres, int K, const double* P,
                               int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);
 VertexTask make_vertex_task(int V, const double* verts, int K, const double* P, int* hint, const QueryBuffers& qb, double* d2, int* idx);

@@ -951,11 +951,7 @@ template <int N> struct IntC { static constexpr int value = N; };
 
 // One launch decomposes up to two posteriors side by side (the two ICP directions of a chain step): problem p owns the
 // workgroups [p·per, (p+1)·per), the first of which iterates while the others replay.
-struct EigenProblem {
-  const double* M; const double* Vwarm /* may be Vout */; double* Vout; double* Vtout; double* Sout; int* status;
-  double* rotlog; int* meta; double* vpos; EigenSpec spec; int launch_id; int* host_status; int* done_word; int done_value;
-  const double* sqrt_lambda;  // of this problem's model (nullptr: the launch's)
-};
+// (struct EigenProblem: icp_kernels.hpp — the on-device chain loop patches these records in device memory)
 // The batch record.  EigenBatch<2>: the two directions of one chain step, by value in the kernel arguments.  EigenBatchMem: the
 // decompositions of a batch of chains (icp_chain_step_batched) — any number of them in ONE launch, the records read in place from
 // pinned host memory (136 bytes per workgroup, once); every workgroup announces itself in `arrive` when it starts, so that the
@@ -964,12 +960,16 @@ struct EigenProblem {
 template <int CAP> struct EigenBatch {
   int n; EigenProblem p[CAP];
   __device__ __forceinline__ void announce() const {}
+  __device__ __forceinline__ bool skipped(int) const { return false; }
 };
 struct EigenBatchMem {
   int n; const EigenProblem* p; int* arrive;
+  const int* skip = nullptr;  // (optional) skip[problem] != 0: nothing to decompose this time (the on-device chain loop launches the
+                              // decompositions of every chain every step; only the chains that moved have one)
   __device__ __forceinline__ void announce() const {
     if (arrive && threadIdx.x == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __device__ __forceinline__ bool skipped(int which) const { return skip != nullptr && skip[which] != 0; }
 };
 static_assert(sizeof(EigenBatch<2>) + 64 <= 4096, "the batch record must fit the kernel argument segment");
 
@@ -979,6 +979,7 @@ __global__ void __launch_bounds__(1024) k_posterior_eigen_rr(int r, const double
   batch.announce();
   const int per = 1 + (r + kReplayRows - 1) / kReplayRows;  // workgroups per problem: the iteration + the replay (32 rows each)
   const int which = (int)blockIdx.x / per, local = (int)blockIdx.x - which * per;
+  if (batch.skipped(which)) return;  // (uniform per workgroup)
   const EigenProblem pb = batch.p[which];
   const double* __restrict__ sqrt_lambda = pb.sqrt_lambda ? pb.sqrt_lambda : sqrt_lambda_launch;
   const double* __restrict__ M = pb.M;
@@ -2148,12 +2149,14 @@ void launch_eigen_rr(hipStream_t st, int r, const double* sqrt_lambda, int n, co
 struct RootBatch2 {
   int n; EigenProblem p[2];
   __device__ __forceinline__ void announce() const {}
+  __device__ __forceinline__ bool skipped(int) const { return false; }
 };
 typedef EigenBatchMem RootBatchMem;
 
 template <class Batch, int NT>
 __global__ void __launch_bounds__(NT) k_posterior_root(int r, Batch batch) {
   batch.announce();
+  if (batch.skipped(blockIdx.x)) return;
   const EigenProblem pb = batch.p[blockIdx.x];
   __shared__ int s_cancel;
   const int tid = threadIdx.x;
@@ -2288,6 +2291,16 @@ bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambd
 }
 
 size_t eigen_many_record_bytes(int n) { return sizeof(EigenProblem) * (size_t)n; }
+
+EigenProblem eigen_problem_of(int r, const EigenRequest& rq) { return eigen_rr_problem(r, rq); }
+
+void launch_posterior_eigen_resident(hipStream_t st, int r, int n, const EigenProblem* records, const int* skip, int root) {
+  if (n < 1) return;
+  EigenBatchMem b{n, records, nullptr};
+  b.skip = skip;
+  if (root) launch_root_batch(st, r, n, b);
+  else launch_eigen_rr_batch(st, r, nullptr, n, b);
+}
 
 int launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest* rq, void* pinned_records, int* arrive) {
   static const bool force_generic = dev_env("ICP_EIGEN_GENERIC") != nullptr;

@@ -526,6 +526,204 @@ void launch_finish_batch(hipStream_t st, const StepFinishArgs* batch, int gx, in
 inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 }  // namespace
 
+void launch_step_batch_resident(hipStream_t st, int B, const int gx[5], int r, const StepBeginArgs* begin, const StepSearchArgs* search,
+                                const StepRegressionArgs* regression, const StepFinishArgs* finish) {
+  if (B <= 0) return;
+  if (gx[0] > 0) hipLaunchKernelGGL(k_step_begin_batch, dim3(gx[0], B), dim3(kStepBlock), 0, st, begin);
+  if (gx[1] > 0) hipLaunchKernelGGL(k_step_filter_batch, dim3(gx[1], B), dim3(kSearchBlock), 0, st, search);
+  if (gx[2] > 0) hipLaunchKernelGGL(k_step_resolve_batch, dim3(gx[2], B), dim3(64), 0, st, search);
+  if (gx[3] > 0) hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, regression);
+  if (gx[4] > 0) {
+    const FinishPlan p = finish_plan(r);
+    if (p.E == 1 && p.NT == 256) launch_finish_batch<1, 256>(st, finish, gx[4], B, p.shmem);
+    else if (p.E == 1 && p.NT == 1024) launch_finish_batch<1, 1024>(st, finish, gx[4], B, p.shmem);
+    else launch_finish_batch<2, 1024>(st, finish, gx[4], B, p.shmem);
+  }
+}
+
+// ---------------------------------------------------------------- the on-device Metropolis–Hastings loop (see MhChain)
+
+namespace {
+__device__ __forceinline__ unsigned long long mh_splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// StepRandom::uniform (host/icp_host.hpp) = orc_rng_uniform (the oracle): integer hash -> (0, 1), exact in double
+__device__ __forceinline__ double mh_uniform(unsigned long long seed, unsigned long long step, unsigned long long lane) {
+  const unsigned long long h = mh_splitmix64(mh_splitmix64(mh_splitmix64(seed) ^ (step * 0xD1342543DE82EF95ull)) ^ (lane * 0x2545F4914F6CDD1Dull));
+  return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+// first component whose cumulative normalised weight reaches u (Scalismo MixtureProposal; icp_host.hpp: pick_component)
+__device__ __forceinline__ int mh_pick(int n, const double* w, double u) {
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) {
+    acc += w[i];
+    if (acc >= u) return i;
+  }
+  return n - 1;
+}
+// Scalismo MixtureProposal.logTransitionProbability: log-sum-exp over the components (icp_host.hpp)
+__device__ __forceinline__ double mh_lse(int n, const double* w, const double* t) {
+  double mx = -__builtin_inf();
+  for (int i = 0; i < n; ++i)
+    if (t[i] > mx) mx = t[i];
+  if (mx == -__builtin_inf()) return mx;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += w[i] * exp(t[i] - mx);
+  return log(s) + mx;
+}
+template <class T>
+__device__ __forceinline__ void mh_copy(T* dst, const T* src, int tid, int nt) {
+  static_assert(sizeof(T) % 8 == 0, "argument records are copied in 8-byte words");
+  const unsigned long long* s = (const unsigned long long*)src;
+  unsigned long long* d = (unsigned long long*)dst;
+  for (int i = tid; i < (int)(sizeof(T) / 8); i += nt) d[i] = s[i];
+}
+}  // namespace
+
+// head of a step: mixture draw (MixtureProposal.propose: outer draw on lane 0, inner on lane 1), the step's arguments
+__global__ void __launch_bounds__(64) k_mh_front(MhChain* __restrict__ chains) {
+  MhChain& c = chains[blockIdx.x];
+  if (c.error) return;
+  const int tid = threadIdx.x, r = c.r;
+  __shared__ int s_gen;
+  if (tid == 0) {
+    const unsigned long long step = (unsigned long long)c.step;
+    const int o = mh_pick(c.n_outer, c.outer_w, mh_uniform(c.seed, step, 0));
+    int gen = -1, leaf = 2;  // the shape random walk (RandomShapeUpdateProposal) = leaf 2
+    if (c.outer_kind[o] == 1) {
+      gen = mh_pick(c.n_icp, c.icp_w, mh_uniform(c.seed, step, 1));
+      leaf = gen;
+    }
+    c.gen = gen; c.leaf = leaf;
+    s_gen = gen;
+  }
+  const int sel = c.cur_sel;
+  mh_copy(c.begin_live, c.begin_alt[sel], tid, 64);
+  mh_copy(c.search_live, c.search_alt[sel], tid, 64);
+  mh_copy(c.regression_live, c.regression_alt[sel], tid, 64);
+  mh_copy(c.finish_live, c.finish_alt[sel], tid, 64);
+  __threadfence_block();
+  __syncthreads();
+  const int gen = s_gen;
+  const double* z = c.normals + (size_t)(c.step - c.normals_first) * r;
+  StepBeginArgs& b = *c.begin_live;
+  if (tid == 0) {
+    b.propose = gen >= 0 ? 1 : 0;
+    if (gen >= 0) b.prop = c.prop_alt[sel][gen];
+  }
+  if (tid < r) {
+    // ICP: posterior.sample()'s standard normals (NonRigidIcpProposal.scala:55); shape walk: the sample itself, c + σ·z
+    // (RandomShapeUpdateProposal.scala:31-35)
+    b.zin[tid] = gen >= 0 ? z[tid] : c.theta[10 + tid] + c.rw_sigma * z[tid];
+  }
+}
+
+// tail of a step: MetropolisHastings.next with the device results (one lane per chain: O(r) sequential sums in the host's order)
+__global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) {
+  MhChain& c = chains[blockIdx.x];
+  if (threadIdx.x != 0 || c.error) return;
+  const int r = c.r, P = 10 + r, n_icp = c.n_icp;
+  const double* cp = c.coeff_prop;
+  const double ninf = -__builtin_inf();
+  for (int i = 0; i < n_icp; ++i) {
+    if (c.chol_status[i] != 0) { c.error = 3; return; }
+    if (c.tail_status[2 * i] != 0 || c.tail_status[2 * i + 1] != 0) { c.error = 2; return; }
+  }
+  // ---- evaluators: ModelPriorEvaluator (:24-31), the likelihood from launch 4's reductions (finish_eval), ProductEvaluator
+  double nn = 0.0;
+  for (int j = 0; j < r; ++j) nn += cp[j] * cp[j];
+  const double prior = -0.5 * nn - c.prior_c;
+  const double* res = c.red;
+  double lik;
+  if (c.eval_kind == 0) {  // IndependentPointDistanceEvaluator.scala:60-64
+    const double m2t = res[0], t2m = res[4];
+    lik = c.eval_mode == 0 ? m2t : c.eval_mode == 1 ? t2m : 0.5 * m2t + 0.5 * t2m;
+  } else {                 // CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:66-78 (closed target)
+    const double a0 = res[0] / res[2], h0 = res[1], a1 = res[4] / res[6], h1 = res[5];
+    double a, h;
+    bool empty;
+    if (c.eval_mode == 0) { a = a0; h = h0; empty = res[2] == 0.0; }
+    else if (c.eval_mode == 1) { a = a1; h = h1; empty = res[6] == 0.0; }
+    else { a = 0.5 * a0 + 0.5 * a1; h = h0 > h1 ? h0 : h1; empty = res[2] == 0.0 || res[6] == 0.0; }
+    if (empty) { c.error = 5; return; }
+    const double d = (a - c.gauss_mean) / c.gauss_sigma;
+    lik = (-d * d / 2.0 - c.gauss_logn) + (-c.exp_rate * h + c.exp_lograte);
+  }
+  if (!(lik == lik)) { c.error = 4; return; }
+  double prop_p = 0.0;
+  prop_p += prior;
+  prop_p += lik;
+  // ---- transition ratio: every leaf's density both ways, log-sum-exp through the mixture tree
+  double fw_i[2], bw_i[2];
+  for (int i = 0; i < n_icp; ++i) {
+    fw_i[i] = c.tails[2 * i]; bw_i[i] = c.tails[2 * i + 1];
+    if (!(fw_i[i] == fw_i[i]) || !(bw_i[i] == bw_i[i])) { c.error = 4; return; }
+  }
+  double dd = 0.0;  // RandomShapeUpdateProposal.scala:37-45: MVN(0, σ²I).logpdf(to − from), the same number both ways
+  for (int j = 0; j < r; ++j) { const double d = cp[j] - c.theta[10 + j]; dd += d * d; }
+  const double rw_t = -0.5 * dd / (c.rw_sigma * c.rw_sigma) - c.rw_logc;
+  double dd_b = 0.0;
+  for (int j = 0; j < r; ++j) { const double d = c.theta[10 + j] - cp[j]; dd_b += d * d; }
+  const double rw_tb = -0.5 * dd_b / (c.rw_sigma * c.rw_sigma) - c.rw_logc;
+  double of[2], ob[2];
+  for (int o = 0; o < c.n_outer; ++o) {
+    if (c.outer_kind[o] == 1) { of[o] = mh_lse(n_icp, c.icp_w, fw_i); ob[o] = mh_lse(n_icp, c.icp_w, bw_i); }
+    else {  // mixedRandomShapeProposal: a one-component mixture (weight 0.5 / 0.5 = 1)
+      const double one = 1.0;
+      of[o] = mh_lse(1, &one, &rw_t); ob[o] = mh_lse(1, &one, &rw_tb);
+    }
+  }
+  const double fw = mh_lse(c.n_outer, c.outer_w, of), bw = mh_lse(c.n_outer, c.outer_w, ob);
+  if (!(fw == fw) || !(bw == bw)) { c.error = 4; return; }
+  const double t = (fw == ninf && bw == ninf) ? 0.0 : fw - bw;
+  const double a = prop_p - c.cur_p - t;
+  const bool acc = a > 0.0 || mh_uniform(c.seed, (unsigned long long)c.step, 2) < exp(a);
+  // ---- state, record (host/icp_host.h: [index, status, leaf, log value of the state after the step, theta])
+  if (acc) {
+    for (int j = 0; j < r; ++j) c.theta[10 + j] = cp[j];
+    c.cur_p = prop_p;
+    c.cur_sel ^= 1;
+    ++c.accepted;
+  }
+  if (c.records) {
+    double* rec = c.records + (size_t)(c.step - c.rec_first) * (4 + P);
+    rec[0] = (double)c.step; rec[1] = acc ? 1.0 : 0.0; rec[2] = (double)c.leaf; rec[3] = c.cur_p;
+    for (int j = 0; j < P; ++j) rec[4 + j] = c.theta[j];
+  }
+  // ---- the KL bases of an accepted state's posteriors (both directions), as icp_chain_step_batched starts them
+  for (int i = 0; i < n_icp; ++i) {
+    if (!acc) { c.eig_skip[i] = 1; continue; }
+    const int q = ++c.eig_seq[i];
+    EigenProblem rec = c.eig_alt[c.cur_sel][i];
+    if (((q + 1) & 127) == 0) rec.Vwarm = nullptr;  // every 128th cold (icp_proposal::prepare_eigen)
+    rec.launch_id = 1 + (int)((unsigned)q % (unsigned)c.pw_id_mask);
+    rec.done_value = q;
+    c.eig_live[i] = rec;
+    c.eig_skip[i] = 0;
+  }
+  ++c.step;
+}
+
+// a block of standard normals has arrived: chain b's rows start at base + b·stride, row 0 = the run's step `offset`
+__global__ void k_mh_set_normals(MhChain* __restrict__ chains, int B, const double* base, int stride, int offset) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  chains[b].normals = base + (size_t)b * stride;
+  chains[b].normals_first = chains[b].rec_first + offset;
+}
+void launch_mh_set_normals(hipStream_t st, int B, MhChain* chains, const double* base, int stride, int offset) {
+  if (B > 0) hipLaunchKernelGGL(k_mh_set_normals, dim3((B + 63) / 64), dim3(64), 0, st, chains, B, base, stride, offset);
+}
+void launch_mh_front(hipStream_t st, int B, MhChain* chains) {
+  if (B > 0) hipLaunchKernelGGL(k_mh_front, dim3(B), dim3(64), 0, st, chains);
+}
+void launch_mh_decide(hipStream_t st, int B, MhChain* chains) {
+  if (B > 0) hipLaunchKernelGGL(k_mh_decide, dim3(B), dim3(64), 0, st, chains);
+}
+
 size_t step_batch_bytes(int B) {
   return up16(sizeof(StepBeginArgs) * B) + up16(sizeof(StepSearchArgs) * B) + up16(sizeof(StepRegressionArgs) * B) +
          up16(sizeof(StepFinishArgs) * B);

@@ -102,6 +102,7 @@ struct icp_host_chain {
   icp_ctx* ctx = nullptr;
   int r = 0;
   uint64_t seed = 0;
+  icp_host_chain_config cfg{};  // (as given; the pointers inside are the caller's and are not used after creation)
   std::vector<std::unique_ptr<ProposalGeneratorWithTransition>> owned;
   std::vector<NonRigidIcpProposal*> icp;
   MixtureProposal* root = nullptr;
@@ -181,6 +182,7 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
     ch->ctx = ctx;
     ch->r = icp_ctx_rank(ctx);
     ch->seed = seed;
+    ch->cfg = *cfg;
     auto own = [&](ProposalGeneratorWithTransition* p) { ch->owned.emplace_back(p); return p; };
     // MixedProposalDistributions.mixedProposalICP (MixedProposalDistributions.scala:48-68)
     MixtureProposal* icpMix = nullptr;
@@ -412,9 +414,75 @@ struct LockstepGroup {
 };
 }  // namespace
 
+// -> ICP_OK: the chains have advanced n_steps on the device; anything else: nothing has happened (the caller steps them on the host)
+static int run_on_device(icp_host_chain* const* chains, int32_t n_chains, int32_t n_steps, double* const* records) {
+  static const bool off = std::getenv("ICP_HOST_DEVICE_LOOP") && std::atoi(std::getenv("ICP_HOST_DEVICE_LOOP")) == 0;
+  if (off) return ICP_ERR_INVALID_ARG;
+  icp_host_chain* c0 = chains[0];
+  if (!c0) return ICP_ERR_INVALID_ARG;
+  const size_t n_icp = c0->icp.size();
+  for (int b = 0; b < n_chains; ++b) {
+    icp_host_chain* ch = chains[b];
+    if (!ch || !ch->prefetcher.whole_step || ch->icp.size() != n_icp || n_icp < 1 || n_icp > 2 || ch->r != c0->r) return ICP_ERR_INVALID_ARG;
+    const icp_host_chain_config &a = ch->cfg, &z = c0->cfg;
+    if (a.w_pose > 0 || !(a.w_icp > 0)) return ICP_ERR_INVALID_ARG;  // pose walks: not on the device (see icp_chains_run_on_device)
+    if (a.w_icp != z.w_icp || a.w_rw != z.w_rw || a.rw_sigma != z.rw_sigma) return ICP_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n_icp; ++i)
+      if (a.icp_weight[i] != z.icp_weight[i]) return ICP_ERR_INVALID_ARG;
+  }
+  icp_mh_mixture mix{};
+  for (size_t i = 0; i < n_icp; ++i) mix.icp_weight[i] = c0->cfg.icp_weight[i];
+  mix.w_icp = c0->cfg.w_icp; mix.w_rw = c0->cfg.w_rw; mix.rw_sigma = c0->cfg.rw_sigma;
+  std::vector<icp_evaluator*> ev(n_chains);
+  std::vector<icp_proposal*> props((size_t)n_chains * n_icp);
+  std::vector<uint64_t> seeds(n_chains);
+  std::vector<int64_t> first(n_chains), acc(n_chains, 0);
+  std::vector<std::vector<double>> th(n_chains);
+  std::vector<double*> thp(n_chains);
+  std::vector<double> logp(n_chains);
+  for (int b = 0; b < n_chains; ++b) {
+    icp_host_chain* ch = chains[b];
+    ev[b] = ch->likelihood->h;
+    for (size_t i = 0; i < n_icp; ++i) props[(size_t)b * n_icp + i] = ch->icp[i]->h;
+    seeds[b] = ch->seed;
+    first[b] = ch->logger.index;
+    th[b] = ch->current.allParameters;
+    thp[b] = th[b].data();
+    logp[b] = ch->current_p;
+    (void)icp_chain_step_prelaunch(ch->likelihood->h, 0, nullptr, -1, nullptr, nullptr);  // (a half step launched ahead: dropped)
+  }
+  const int rc = icp_chains_run_on_device(n_chains, ev.data(), (int32_t)n_icp, props.data(), &mix, seeds.data(), first.data(), thp.data(),
+                                          logp.data(), n_steps, records, acc.data());
+  if (rc != ICP_OK) return rc;
+  for (int b = 0; b < n_chains; ++b) {
+    icp_host_chain* ch = chains[b];
+    ch->current.allParameters = th[b];
+    // generatedBy of the state = the proposal that produced the last ACCEPTED sample; the records carry the leaf ids
+    ch->current_p = logp[b];
+    ch->logger.index += n_steps;
+    ch->logger.n_accept += acc[b];
+    ch->mh->cached_current = ch->current;
+    ch->mh->cached_current_p = logp[b];
+    ch->mh->have_current = true;
+    ch->prefetcher.have = false;
+    ch->prefetcher.submitted_index = -1;
+    ch->likelihood->has_prefetch = false;
+    for (auto* p : ch->icp) { p->prefetched[0].valid = false; p->prefetched[1].valid = false; }
+    ch->ahead_step = ~0ull; ch->ahead2_step = ~0ull;
+  }
+  return ICP_OK;
+}
+
 int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains, int32_t n_steps, double* const* records) {
   // a lone chain is better off with the pipelined single-chain step (launches of the next step issued ahead)
   if (chains && n_chains == 1 && chains[0]) return icp_host_chain_run(chains[0], n_steps, records ? records[0] : nullptr);
+  // pose-free mixtures: the whole loop on the device (icp_chains_run_on_device: mixture draw, proposals' inputs, MetropolisHastings.next
+  // and the records by kernels of the step's own stream; the host only enqueues).  What it does not cover comes back with
+  // ICP_ERR_INVALID_ARG and takes the lockstep path below; ICP_HOST_DEVICE_LOOP=0 keeps everything on that path.
+  if (chains && n_chains >= 1 && n_steps > 0) {
+    const int rc_dev = run_on_device(chains, n_chains, n_steps, records);
+    if (rc_dev == ICP_OK) return ICP_OK;
+  }
   constexpr int kMaxGroups = 4;
   LockstepGroup groups[kMaxGroups];
   int rc = host_guard([&] {

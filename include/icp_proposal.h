@@ -309,6 +309,33 @@ ICP_API int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator *const 
 ICP_API int icp_chain_step_batched_collect(icp_step_ticket *ticket);
 ICP_API int icp_chain_step_batched_abandon(icp_step_ticket *ticket);
 
+/* ---------------------------------------------------------------- the whole Metropolis–Hastings loop on the device
+ * n_steps steps of n_chains independent chains WITHOUT a host round trip per step: beside the five merged launches of
+ * icp_chain_step_batched, a small kernel at the head of every step draws the mixture component and makes the step's proposal input
+ * (Scalismo MixtureProposal.propose; api/sampling/proposals/RandomShapeUpdateProposal.scala:31-35), and one behind launch 5 is
+ * MetropolisHastings.next (api/sampling/SamplingRegistration.scala:52-58): ModelPriorEvaluator × likelihood, the mixture's transition
+ * ratio by log-sum-exp over all leaves, accept/reject, the step's record; the KL bases of accepted states follow in the same stream.
+ * The host only enqueues launches and streams the standard normals in ahead.
+ *   Mixture: (w_icp: the n_props ICP proposals with icp_weight) + (w_rw: shape random walk of rw_sigma) in the reference's order
+ *   (apps/femur/IcpProposalRegistration.scala:70-72); product evaluator = shape prior × `evaluator`.  Pose walks are NOT covered
+ *   (their rotation matrices would need the host's sines and cosines bit for bit): such chains step through icp_chain_step[_batched].
+ *   Random numbers: the counter-based generator of the C++ harness (host/icp_host.hpp StepRandom, shared bit for bit with the oracle):
+ *   stream (seeds[b], step, lane), steps first_step[b] .. first_step[b] + n_steps − 1.
+ *   theta[b] (in/out): the chain's current state; log_value[b] (in/out): its product log value (as MetropolisHastings carries it).
+ *   records[b] (may be NULL): n_steps rows [index, accepted, leaf id (0/1 ICP proposal, 2 shape walk), log value, theta].
+ * Covered: what the merged launches cover (closed target or no boundary-aware branch, ranks <= 64, one context per chain, one
+ * device); otherwise ICP_ERR_INVALID_ARG and nothing has run.  Results are those of icp_chain_step_batched driven by the harness,
+ * chain by chain (tests/test_gpu_chain.py::test_device_loop_*). */
+typedef struct {
+  double icp_weight[2];
+  double w_icp, w_rw;
+  double rw_sigma;
+} icp_mh_mixture;
+ICP_API int icp_chains_run_on_device(int32_t n_chains, icp_evaluator *const *evaluators, int32_t n_props, icp_proposal *const *props,
+                                     const icp_mh_mixture *mixture, const uint64_t *seeds, const int64_t *first_step,
+                                     double *const *theta, double *log_value, int32_t n_steps, double *const *records,
+                                     int64_t *accepted);
+
 /* ---------------------------------------------------------------- instrumentation (bench.py's roofline leg)
  * Between start and stop every kernel the context launches is bracketed by HIP events on the context stream;
  * stop returns one row per kernel name.  Off by default (adds nothing to the launch path). */
