@@ -434,12 +434,13 @@ def main():
             mctx = [pkg.IcpContext(model, target, device=local_rank) for _ in range(nB)]
             mch = [pkg.SamplingRegistration(mctx[i], setup, wl["init"](i), seed=1024 + i) for i in range(nB)]
             pkg.run_chains_batched(mch, 40, want_records=False)
-            n_m = 300
+            n_m = 1000
             t1 = time.perf_counter()
             pkg.run_chains_batched(mch, n_m, want_records=False)
             mdt = time.perf_counter() - t1
             line["many_chains"] = {"chains_per_gpu": nB, "value": nB * n_m / mdt, "unit": "iterations/s", "steps_per_chain": n_m,
-                                   "entry_point": "icp_chain_step_batched"}
+                                   "entry_point": "icp_chains_run_on_device (the whole MH loop on the device: DESIGN §5.1c) from 48 chains on, "
+                                                  "icp_chain_step_batched below"}
             for ch in mch:
                 ch.close()
             for cx in mctx:

@@ -3456,8 +3456,12 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       DBuf<EigenProblem> eig_live;
       DBuf<int> eig_skip;
       DBuf<double> normals[2], theta, rec;
+      DBuf<double> res;   // per chain 32 doubles: [0..7] launch 4's reductions, [8..11] the tails fwd_i / bwd_i — in DEVICE memory
+      DBuf<int> stat;     // per chain 16 ints: [0..3] the tails' status, [8..9] the factorisations' (the decide kernel reads them: pinned
+                          // host memory, where the host-stepped paths want them, would cost it a bus round trip per number)
       double* h_normals[2] = {nullptr, nullptr};
       hipEvent_t ev_copy[2] = {nullptr, nullptr};
+      hipEvent_t ev_big = nullptr;  // recorded behind launch 4: the next group's chip-wide launches may start
     };
     std::vector<Group> groups(n_groups);
     constexpr int kChunk = 64;  // steps per block of standard normals
@@ -3470,6 +3474,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
             if (gr.h_normals[k]) (void)hipHostFree(gr.h_normals[k]);
             if (gr.ev_copy[k]) (void)hipEventDestroy(gr.ev_copy[k]);
           }
+          if (gr.ev_big) (void)hipEventDestroy(gr.ev_big);
         }
       }
     } group_guard{groups};
@@ -3479,7 +3484,10 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       Group& gr = groups[g];
       gr.b0 = (int)((long long)g * n_chains / n_groups);
       gr.B = (int)((long long)(g + 1) * n_chains / n_groups) - gr.b0;
-      gr.st = chains[gr.b0].e->ctx->stream;  // the group's first context's stream (every chain has a context, hence a stream, of its own)
+      // the first chain's two step streams: created side by side with the context, they sit on different hardware queues and run
+      // beside each other (streams of DIFFERENT contexts may share a queue: the runtime multiplexes streams onto a handful of them,
+      // and two groups on one queue alternate in ~55 µs slices — every kernel of the step then "takes" a multiple of that)
+      gr.st = g == 0 ? lead.stream : lead.front_stream;
       const int B = gr.B;
       gr.begin_alt.alloc(2 * B); gr.begin_live.alloc(B);
       gr.search_alt.alloc(2 * B); gr.search_live.alloc(B);
@@ -3489,6 +3497,9 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       gr.eig_live.alloc((size_t)B * n_props);
       gr.eig_skip.alloc((size_t)B * n_props);
       gr.theta.alloc((size_t)B * P);
+      gr.res.alloc((size_t)B * 32); gr.res.fill_bytes(0);
+      gr.stat.alloc((size_t)B * 16); gr.stat.fill_bytes(0);
+      HIP_OK(hipEventCreateWithFlags(&gr.ev_big, hipEventDisableTiming));
       gr.rec.alloc(records ? (size_t)B * std::max(n_steps, 1) * (4 + P) : 1);
       for (int k = 0; k < 2; ++k) {
         gr.normals[k].alloc((size_t)B * kChunk * r);
@@ -3526,17 +3537,18 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
               f.Mpart[i] = F.mpart[i]; f.splits[i] = F.splits[i];
               f.M[i] = F.ep[i]->M.p; f.alpha[i] = F.ep[i]->alpha.p;
               f.status[i] = p->status.p + F.ep[i]->status_off;
-              f.host_status[i] = c.h_status + 8 + i;
+              f.host_status[i] = gr.stat.p + (size_t)k * 16 + 8 + i;
               f.fwd[i] = TransitionTailIO{F.ec[i]->alpha.p, F.ec[i]->M.p, F.ec[i]->coeffs.p, F.ep[i]->coeffs.p, p->prm.step_length,
-                                          c.h_res + 8 + 2 * i, c.h_status + 2 * i};
+                                          gr.res.p + (size_t)k * 32 + 8 + 2 * i, gr.stat.p + (size_t)k * 16 + 2 * i};
               f.bwd[i] = TransitionTailIO{F.ep[i]->alpha.p, F.ep[i]->M.p, F.ep[i]->coeffs.p, F.ec[i]->coeffs.p, p->prm.step_length,
-                                          c.h_res + 9 + 2 * i, c.h_status + 2 * i + 1};
+                                          gr.res.p + (size_t)k * 32 + 9 + 2 * i, gr.stat.p + (size_t)k * 16 + 2 * i + 1};
             }
             f.done_counter = c.d_done.p; f.host_flag = c.h_flag; f.seq = 0;
             f.ready_flag = nullptr;
             launch_step_finish(c.stream, f);  // (captured; finalised by the launcher)
           }
           cap.begin.wait_flag = nullptr; cap.begin.wait2_flag = nullptr; cap.begin.wait_ticks = nullptr; cap.begin.hold_regs = 0;
+          cap.regression.red_out = gr.res.p + (size_t)k * 32;  // (device memory instead of the context's pinned area)
           {  // (launch 1's matvec layout: set by enqueue_front only when it knows the generator)
             int t = 0;
             while (t < 6 && (r << (t + 1)) <= 256 && (r >> (t + 1)) >= 8) ++t;
@@ -3592,10 +3604,10 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
         m.gauss_logn = std::log(std::sqrt(2.0 * M_PI)) + std::log(ep.gauss_sigma);
         m.exp_rate = ep.exp_rate; m.exp_lograte = std::log(ep.exp_rate);
         m.coeff_prop = ch.slot->coeffs.p;
-        m.red = c.h_res + kReduceArea;  // (parity 0)
-        m.tails = c.h_res + 8;
-        m.tail_status = c.h_status;
-        m.chol_status = c.h_status + 8;
+        m.red = gr.res.p + (size_t)k * 32;
+        m.tails = gr.res.p + (size_t)k * 32 + 8;
+        m.tail_status = gr.stat.p + (size_t)k * 16;
+        m.chol_status = gr.stat.p + (size_t)k * 16 + 8;
         m.normals = nullptr; m.normals_first = 0;
         m.records = records && records[gr.b0 + k] ? gr.rec.p + (size_t)k * n_steps * (4 + P) : nullptr;
         m.rec_first = first_step[gr.b0 + k];
@@ -3638,10 +3650,23 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
         HIP_OK(hipEventRecord(gr.ev_copy[buf], gr.st));
         launch_mh_set_normals(gr.st, gr.B, gr.mh.p, gr.normals[buf].p, kChunk * r, s0);
       }
+      // The chip-wide launches of two groups side by side slow each other down more than the overlap gains; what
+      // should run beside a group's chip-wide launches 1-4 is the OTHER group's small ones (launch 5 on four CUs per chain, the
+      // decide kernel, the decompositions on five CUs each).  So launches 1-4 pass a token from group to group: a group's first
+      // launch waits for the event behind the previous group's launch 4.
       for (int s_ = 0; s_ < ns; ++s_)
-        for (auto& gr : groups) {
+        for (int g = 0; g < n_groups; ++g) {
+          Group& gr = groups[g];
+          if (n_groups > 1) {
+            Group& prev = groups[(g + n_groups - 1) % n_groups];
+            if (blk > 0 || s_ > 0 || g > 0) HIP_OK(hipStreamWaitEvent(gr.st, prev.ev_big, 0));
+          }
           launch_mh_front(gr.st, gr.B, gr.mh.p);
-          launch_step_batch_resident(gr.st, gr.B, gr.grid, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p);
+          int g4[5] = {gr.grid[0], gr.grid[1], gr.grid[2], gr.grid[3], 0};
+          launch_step_batch_resident(gr.st, gr.B, g4, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p);
+          if (n_groups > 1) HIP_OK(hipEventRecord(gr.ev_big, gr.st));
+          int g5[5] = {0, 0, 0, 0, gr.grid[4]};
+          launch_step_batch_resident(gr.st, gr.B, g5, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p);
           launch_mh_decide(gr.st, gr.B, gr.mh.p);
           launch_posterior_eigen_resident(gr.st, r, gr.B * n_props, gr.eig_live.p, gr.eig_skip.p, root);
         }

@@ -621,20 +621,34 @@ __global__ void __launch_bounds__(64) k_mh_front(MhChain* __restrict__ chains) {
   }
 }
 
-// tail of a step: MetropolisHastings.next with the device results (one lane per chain: O(r) sequential sums in the host's order)
+// tail of a step: MetropolisHastings.next with the device results.  One wave per chain: lane j holds coefficient j of the proposed and
+// of the current state; the O(r) sums run in the host's order (ascending j, one rounding per operation) over values broadcast from the
+// lanes — every lane computes the same numbers, the decision is uniform — and the state, the record and the decomposition records
+// are written by all lanes together (a single lane walking through global memory took 30-45 µs per step).
+__device__ __forceinline__ double mh_bcast(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) {
   MhChain& c = chains[blockIdx.x];
-  if (threadIdx.x != 0 || c.error) return;
+  if (c.error) return;
+  const int lane = threadIdx.x;
   const int r = c.r, P = 10 + r, n_icp = c.n_icp;
-  const double* cp = c.coeff_prop;
   const double ninf = -__builtin_inf();
+  const double cpj = lane < r ? c.coeff_prop[lane] : 0.0;   // proposed coefficients (launch 1's copy in the state slot)
+  const double thj = lane < r ? c.theta[10 + lane] : 0.0;   // current ones
+  int err = 0;
   for (int i = 0; i < n_icp; ++i) {
-    if (c.chol_status[i] != 0) { c.error = 3; return; }
-    if (c.tail_status[2 * i] != 0 || c.tail_status[2 * i + 1] != 0) { c.error = 2; return; }
+    if (c.chol_status[i] != 0) err = 3;
+    else if (c.tail_status[2 * i] != 0 || c.tail_status[2 * i + 1] != 0) err = err ? err : 2;
   }
   // ---- evaluators: ModelPriorEvaluator (:24-31), the likelihood from launch 4's reductions (finish_eval), ProductEvaluator
-  double nn = 0.0;
-  for (int j = 0; j < r; ++j) nn += cp[j] * cp[j];
+  double nn = 0.0, dd = 0.0, dd_b = 0.0;
+  for (int j = 0; j < r; ++j) {
+    const double cj = mh_bcast(cpj, j), tj = mh_bcast(thj, j);
+    nn += cj * cj;
+    const double d = cj - tj; dd += d * d;        // RandomShapeUpdateProposal.scala:37-45, to − from
+    const double e = tj - cj; dd_b += e * e;      // … and the other way
+  }
   const double prior = -0.5 * nn - c.prior_c;
   const double* res = c.red;
   double lik;
@@ -648,27 +662,23 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
     if (c.eval_mode == 0) { a = a0; h = h0; empty = res[2] == 0.0; }
     else if (c.eval_mode == 1) { a = a1; h = h1; empty = res[6] == 0.0; }
     else { a = 0.5 * a0 + 0.5 * a1; h = h0 > h1 ? h0 : h1; empty = res[2] == 0.0 || res[6] == 0.0; }
-    if (empty) { c.error = 5; return; }
+    if (empty && !err) err = 5;
     const double d = (a - c.gauss_mean) / c.gauss_sigma;
     lik = (-d * d / 2.0 - c.gauss_logn) + (-c.exp_rate * h + c.exp_lograte);
   }
-  if (!(lik == lik)) { c.error = 4; return; }
+  if (!(lik == lik) && !err) err = 4;
   double prop_p = 0.0;
   prop_p += prior;
   prop_p += lik;
   // ---- transition ratio: every leaf's density both ways, log-sum-exp through the mixture tree
-  double fw_i[2], bw_i[2];
+  double fw_i[2] = {ninf, ninf}, bw_i[2] = {ninf, ninf};
   for (int i = 0; i < n_icp; ++i) {
     fw_i[i] = c.tails[2 * i]; bw_i[i] = c.tails[2 * i + 1];
-    if (!(fw_i[i] == fw_i[i]) || !(bw_i[i] == bw_i[i])) { c.error = 4; return; }
+    if ((!(fw_i[i] == fw_i[i]) || !(bw_i[i] == bw_i[i])) && !err) err = 4;
   }
-  double dd = 0.0;  // RandomShapeUpdateProposal.scala:37-45: MVN(0, σ²I).logpdf(to − from), the same number both ways
-  for (int j = 0; j < r; ++j) { const double d = cp[j] - c.theta[10 + j]; dd += d * d; }
   const double rw_t = -0.5 * dd / (c.rw_sigma * c.rw_sigma) - c.rw_logc;
-  double dd_b = 0.0;
-  for (int j = 0; j < r; ++j) { const double d = c.theta[10 + j] - cp[j]; dd_b += d * d; }
   const double rw_tb = -0.5 * dd_b / (c.rw_sigma * c.rw_sigma) - c.rw_logc;
-  double of[2], ob[2];
+  double of[2] = {ninf, ninf}, ob[2] = {ninf, ninf};
   for (int o = 0; o < c.n_outer; ++o) {
     if (c.outer_kind[o] == 1) { of[o] = mh_lse(n_icp, c.icp_w, fw_i); ob[o] = mh_lse(n_icp, c.icp_w, bw_i); }
     else {  // mixedRandomShapeProposal: a one-component mixture (weight 0.5 / 0.5 = 1)
@@ -677,34 +687,44 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
     }
   }
   const double fw = mh_lse(c.n_outer, c.outer_w, of), bw = mh_lse(c.n_outer, c.outer_w, ob);
-  if (!(fw == fw) || !(bw == bw)) { c.error = 4; return; }
+  if ((!(fw == fw) || !(bw == bw)) && !err) err = 4;
+  if (err) {  // (uniform) the chain needs the host: it stands still from here on
+    if (lane == 0) c.error = err;
+    return;
+  }
   const double t = (fw == ninf && bw == ninf) ? 0.0 : fw - bw;
   const double a = prop_p - c.cur_p - t;
-  const bool acc = a > 0.0 || mh_uniform(c.seed, (unsigned long long)c.step, 2) < exp(a);
+  const long long step = c.step;
+  const bool acc = a > 0.0 || mh_uniform(c.seed, (unsigned long long)step, 2) < exp(a);
   // ---- state, record (host/icp_host.h: [index, status, leaf, log value of the state after the step, theta])
-  if (acc) {
-    for (int j = 0; j < r; ++j) c.theta[10 + j] = cp[j];
-    c.cur_p = prop_p;
-    c.cur_sel ^= 1;
-    ++c.accepted;
-  }
+  const double new_p = acc ? prop_p : c.cur_p;
+  const int new_sel = acc ? c.cur_sel ^ 1 : c.cur_sel;
+  if (acc && lane < r) c.theta[10 + lane] = cpj;
   if (c.records) {
-    double* rec = c.records + (size_t)(c.step - c.rec_first) * (4 + P);
-    rec[0] = (double)c.step; rec[1] = acc ? 1.0 : 0.0; rec[2] = (double)c.leaf; rec[3] = c.cur_p;
-    for (int j = 0; j < P; ++j) rec[4 + j] = c.theta[j];
+    double* rec = c.records + (size_t)(step - c.rec_first) * (4 + P);
+    if (lane == 0) { rec[0] = (double)step; rec[1] = acc ? 1.0 : 0.0; rec[2] = (double)c.leaf; rec[3] = new_p; }
+    if (lane < 10) rec[4 + lane] = c.theta[lane];
+    if (lane < r) rec[14 + lane] = acc ? cpj : thj;
   }
   // ---- the KL bases of an accepted state's posteriors (both directions), as icp_chain_step_batched starts them
-  for (int i = 0; i < n_icp; ++i) {
-    if (!acc) { c.eig_skip[i] = 1; continue; }
-    const int q = ++c.eig_seq[i];
-    EigenProblem rec = c.eig_alt[c.cur_sel][i];
-    if (((q + 1) & 127) == 0) rec.Vwarm = nullptr;  // every 128th cold (icp_proposal::prepare_eigen)
-    rec.launch_id = 1 + (int)((unsigned)q % (unsigned)c.pw_id_mask);
-    rec.done_value = q;
-    c.eig_live[i] = rec;
-    c.eig_skip[i] = 0;
+  if (lane < n_icp) {
+    const int i = lane;
+    if (!acc) c.eig_skip[i] = 1;
+    else {
+      const int q = c.eig_seq[i] + 1;
+      c.eig_seq[i] = q;
+      EigenProblem rec = c.eig_alt[new_sel][i];
+      if (((q + 1) & 127) == 0) rec.Vwarm = nullptr;  // every 128th cold (icp_proposal::prepare_eigen)
+      rec.launch_id = 1 + (int)((unsigned)q % (unsigned)c.pw_id_mask);
+      rec.done_value = q;
+      c.eig_live[i] = rec;
+      c.eig_skip[i] = 0;
+    }
   }
-  ++c.step;
+  if (lane == 0) {
+    if (acc) { c.cur_p = prop_p; c.cur_sel = new_sel; ++c.accepted; }
+    c.step = step + 1;
+  }
 }
 
 // a block of standard normals has arrived: chain b's rows start at base + b·stride, row 0 = the run's step `offset`

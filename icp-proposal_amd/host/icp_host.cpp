@@ -416,8 +416,12 @@ struct LockstepGroup {
 
 // -> ICP_OK: the chains have advanced n_steps on the device; anything else: nothing has happened (the caller steps them on the host)
 static int run_on_device(icp_host_chain* const* chains, int32_t n_chains, int32_t n_steps, double* const* records) {
-  static const bool off = std::getenv("ICP_HOST_DEVICE_LOOP") && std::atoi(std::getenv("ICP_HOST_DEVICE_LOOP")) == 0;
-  if (off) return ICP_ERR_INVALID_ARG;
+  // ICP_HOST_DEVICE_LOOP: 0 never, 1 whenever covered, unset: from 48 chains on — a group's step is a serial chain of ≈ 350 µs on the
+  // device whatever its size (launches 1-5, the decide kernel, the decompositions of the chains that moved), which two groups overlap:
+  // 64 chains 162-174k it/s against 143-146k host-stepped, 128 chains 197-209k; 32 chains 112k either way, 16 chains 65k against 72k
+  // (the host-stepped form lets every chain's first launch wait for its own decomposition only)
+  static const int mode = std::getenv("ICP_HOST_DEVICE_LOOP") ? std::atoi(std::getenv("ICP_HOST_DEVICE_LOOP")) : -1;
+  if (mode == 0 || (mode < 0 && n_chains < 48)) return ICP_ERR_INVALID_ARG;
   icp_host_chain* c0 = chains[0];
   if (!c0) return ICP_ERR_INVALID_ARG;
   const size_t n_icp = c0->icp.size();
@@ -477,8 +481,8 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
   // a lone chain is better off with the pipelined single-chain step (launches of the next step issued ahead)
   if (chains && n_chains == 1 && chains[0]) return icp_host_chain_run(chains[0], n_steps, records ? records[0] : nullptr);
   // pose-free mixtures: the whole loop on the device (icp_chains_run_on_device: mixture draw, proposals' inputs, MetropolisHastings.next
-  // and the records by kernels of the step's own stream; the host only enqueues).  What it does not cover comes back with
-  // ICP_ERR_INVALID_ARG and takes the lockstep path below; ICP_HOST_DEVICE_LOOP=0 keeps everything on that path.
+  // and the records by kernels of the step's own stream; the host only enqueues).  What it does not cover (and, by default, fewer
+  // than 48 chains: see run_on_device) comes back with ICP_ERR_INVALID_ARG and takes the lockstep path below.
   if (chains && n_chains >= 1 && n_steps > 0) {
     const int rc_dev = run_on_device(chains, n_chains, n_steps, records);
     if (rc_dev == ICP_OK) return ICP_OK;

@@ -532,3 +532,61 @@ def test_no_fallback_in_normal_runs(pkg, femur50):
     [c.close() for c in chains]; [c.close() for c in ctxs]
     after = pkg._native.runtime_stats()
     assert after == before, (before, after)
+
+
+_DEVICE_LOOP_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import __graft_entry__ as graft
+pkg = graft.load_package()
+model, target = pkg.data.load_femur_model_and_target(50)
+kind = {kind!r}
+def make_setup():
+    if kind == "metric":      # apps/femur/IcpProposalRegistration.scala:59-85: two ICP directions + shape walk, independent evaluator
+        s = pkg.femur_icp_proposal_registration(model, target, fused=2)
+    elif kind == "root":      # the same with the opt-in Cholesky-root sampler
+        s = pkg.femur_icp_proposal_registration(model, target, fused=2); s.sampler = "cholesky-root"
+    else:                     # ONE ICP direction, no shape walk, collective evaluator (model-to-target) on the closed target
+        s = pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2)
+        s.eval["mode"] = 0; s.w_pose = 0.0; s.w_icp, s.w_rw = 1.0, 0.0
+    return s
+B = {B}
+ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
+chains = [pkg.SamplingRegistration(ctxs[i], make_setup(), pkg.random_initial_parameters(model, i), seed=300 + i) for i in range(B)]
+a = pkg.run_chains_batched(chains, {n1})
+single = chains[0].run(7)                       # a chain goes on by itself (host-stepped) from where the device loop left it …
+b = pkg.run_chains_batched(chains[1:], {n2})    # … and the others through a second run
+states = [c.state() for c in chains]
+np.savez({out!r}, a=np.stack(a), single=single, b=np.stack(b), theta=np.stack([s[0] for s in states]), logp=np.array([s[1] for s in states]),
+         n=np.array([s[2] for s in states]), acc=np.array([s[3] for s in states]), stats=np.array(list(pkg._native.runtime_stats().values())))
+[c.close() for c in chains]; [c.close() for c in ctxs]
+"""
+
+
+@pytest.mark.parametrize("kind,B,n1,n2", [("metric", 9, 150, 40), ("metric", 50, 140, 30), ("root", 9, 60, 20), ("one-direction", 5, 60, 20)])
+def test_device_loop_matches_host_stepped_chains(kind, B, n1, n2, tmp_path):
+    """the whole Metropolis–Hastings loop on the device (icp_chains_run_on_device — mixture draw, the proposals'
+    inputs, MetropolisHastings.next and the records by kernels of the step's own stream) against the same chains stepped by the host
+    harness through icp_chain_step_batched: IDENTICAL records — every decision, every mixture component, states and log values bit
+    for bit — over 140-150 steps (more than 128 decompositions per proposal: the cold restart is on the same step), with chains that
+    go on afterwards on either path, for two ICP directions + shape walk, one direction alone, and the Cholesky-root sampler."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / f"dl_{mode}.npz")
+        script = _DEVICE_LOOP_SCRIPT.format(root=ROOT, kind=kind, B=B, n1=n1, n2=n2, out=path)
+        subprocess.run([sys.executable, "-c", script], check=True, env={**os.environ, "ICP_HOST_DEVICE_LOOP": mode}, timeout=600)
+        out[mode] = np.load(path)
+    dev, host = out["1"], out["0"]
+    for key in ("a", "single", "b", "theta", "logp", "n", "acc"):
+        assert np.array_equal(dev[key], host[key]), key
+    assert np.all(dev["stats"] == 0) and np.all(host["stats"] == 0)
+    a = dev["a"]
+    assert a.shape == (B, n1, 14 + 51) and np.array_equal(a[:, :, 0], np.tile(np.arange(n1), (B, 1)))
+    assert 0.2 < a[:, :, 1].mean() < 0.95
+    leaves = set(a[:, :, 2].astype(int).ravel())
+    assert leaves == ({0, 1, 2} if kind != "one-direction" else {0})
+    assert np.all(dev["n"][1:] == n1 + n2) and dev["n"][0] == n1 + 7
