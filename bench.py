@@ -596,7 +596,11 @@ def roofline_leg(pkg, args, wl, ctx, chains, B, rate, line):
     for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile) and B == 1:
-            traffic = json.load(open(tfile)).get("config%d" % args.config, {}).get(dominant, {}).get("hbm_bytes_per_launch")
+            per_kernel = json.load(open(tfile)).get("config%d" % args.config, {})
+            traffic = per_kernel.get(dominant, {}).get("hbm_bytes_per_launch")
+            if traffic is None and dominant == "k_posterior_eigen" and "k_tridiag" in per_kernel:
+                # ranks above 64: "k_posterior_eigen" of the event timing is the tridiagonal route's launch sequence
+                traffic = sum(per_kernel[k]["hbm_bytes_per_launch"] * (3 if k == "k_tri_gemm" else 1) for k in ("k_tridiag", "k_tri_solve", "k_tri_gemm") if k in per_kernel)
             if traffic is not None:
                 break
     has_boundary = bool(pkg.data.boundary_vertex_flags(target).any())

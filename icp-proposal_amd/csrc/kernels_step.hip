@@ -435,7 +435,9 @@ FinishPlan finish_plan(int r) {
   const size_t budget = (size_t)kLdsDoubles - 4700;  // static LDS of factor_reg_body + tail_body
   if (w > budget) return p;
   if (tiles <= 256) { p.E = 1; p.NT = 256; }
-  else if (tiles <= 1024) { p.E = 1; p.NT = 1024; }
+  // (up to 1024 tiles: two per thread on 512 threads — 1024 threads leave 128 VGPRs per lane and the tiles' bookkeeping spilled 156 B
+  // of scratch, ISA of round 2; 512 threads have 256)
+  else if (tiles <= 1024) { p.E = 2; p.NT = 512; }
   else if (tiles <= 2048) { p.E = 2; p.NT = 1024; }
   else return p;
   p.n_lds = 2 * one <= budget ? 2 : (one <= budget ? 1 : 0);
@@ -509,7 +511,7 @@ void launch_step_finish(hipStream_t st, const StepFinishArgs& a_in) {
   if (t_capture) { t_capture->finish = a; t_capture->grid[4] = 2 * a.n; return; }
   ProfScope _ps(st, KID_STEP_FINISH);
   if (p.E == 1 && p.NT == 256) launch_finish<1, 256>(st, a, p.shmem);
-  else if (p.E == 1 && p.NT == 1024) launch_finish<1, 1024>(st, a, p.shmem);
+  else if (p.E == 2 && p.NT == 512) launch_finish<2, 512>(st, a, p.shmem);
   else launch_finish<2, 1024>(st, a, p.shmem);
 }
 
@@ -536,7 +538,7 @@ void launch_step_batch_resident(hipStream_t st, int B, const int gx[5], int r, c
   if (gx[4] > 0) {
     const FinishPlan p = finish_plan(r);
     if (p.E == 1 && p.NT == 256) launch_finish_batch<1, 256>(st, finish, gx[4], B, p.shmem);
-    else if (p.E == 1 && p.NT == 1024) launch_finish_batch<1, 1024>(st, finish, gx[4], B, p.shmem);
+    else if (p.E == 2 && p.NT == 512) launch_finish_batch<2, 512>(st, finish, gx[4], B, p.shmem);
     else launch_finish_batch<2, 1024>(st, finish, gx[4], B, p.shmem);
   }
 }
@@ -791,7 +793,7 @@ void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pin
     ProfScope _ps(st, KID_STEP_FINISH);
     const StepFinishArgs* fb = (const StepFinishArgs*)(d + o3);
     if (p.E == 1 && p.NT == 256) launch_finish_batch<1, 256>(st, fb, gx[4], B, p.shmem);
-    else if (p.E == 1 && p.NT == 1024) launch_finish_batch<1, 1024>(st, fb, gx[4], B, p.shmem);
+    else if (p.E == 2 && p.NT == 512) launch_finish_batch<2, 512>(st, fb, gx[4], B, p.shmem);
     else launch_finish_batch<2, 1024>(st, fb, gx[4], B, p.shmem);
   }
 }
