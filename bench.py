@@ -402,6 +402,11 @@ def main():
                 line["extra_configs"]["config%d" % cfg_i] = extra_config_leg(pkg, args, cfg_i, local_rank)
             except Exception as e:
                 line["extra_configs"]["config%d" % cfg_i] = {"error": str(e)[:200]}
+            if cfg_i == 3 and args.root_sampler_leg:  # … and with the opt-in Cholesky-root sampler (not the reference's arithmetic, §5.7)
+                try:
+                    line["extra_configs"]["config3_cholesky_root"] = extra_config_leg(pkg, args, cfg_i, local_rank, sampler="cholesky-root")
+                except Exception as e:
+                    line["extra_configs"]["config3_cholesky_root"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and B == 1 and args.config == 1 and args.root_sampler_leg:
         # ---- not the headline and NOT the reference's arithmetic: the same chain with the opt-in Cholesky-root sampler
         # (icp_proposal_set_sampler) — what the accepted path costs when the reference's SVD convention for posterior.sample() is not required
@@ -455,9 +460,10 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_config_leg(pkg, args, cfg_i, device):
+def extra_config_leg(pkg, args, cfg_i, device, sampler="eigen"):
     """A short chain of another configuration (2: 400 steps, 3: 200 steps after 40 / 20 of warm-up) on the same GPU."""
     wl = build_workload(pkg, cfg_i, args.subdiv, args.fused, args)
+    wl["setup"].sampler = sampler
     ctx = pkg.IcpContext(wl["model"], wl["target"], device=device)
     chain = pkg.SamplingRegistration(ctx, wl["setup"], wl["init"](0), seed=1024)
     n_w, n = (40, 400) if cfg_i == 2 else (20, 200)
@@ -466,7 +472,7 @@ def extra_config_leg(pkg, args, cfg_i, device):
     rec = chain.run(n)
     dt = time.perf_counter() - t0
     out = {"value": n / dt, "unit": "iterations/s", "steps": n, "warmup": n_w, "ms_per_step": 1e3 * dt / n, "accepted": int(rec[:, 1].sum()),
-           "icp_proposals": int((rec[:, 2] < 2).sum()), "workload": wl["name"], "runtime_stats": ctx.runtime_stats()}
+           "icp_proposals": int((rec[:, 2] < 2).sum()), "workload": wl["name"], "runtime_stats": ctx.runtime_stats(), "sampler": sampler}
     if cfg_i == 2 and out["accepted"] == 0:
         out["note"] = ("no step accepted: with all 1,622 model points as correspondences the ICP posterior is so narrow that the reference's own "
                        "transition ratio rejects (almost) every proposal — GPU and oracle agree on every decision "

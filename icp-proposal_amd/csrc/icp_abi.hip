@@ -80,6 +80,7 @@ constexpr int kStateSlots = 8;
 constexpr int kPosteriorMemo = 20;  // NonRigidIcpProposal.scala:49
 constexpr int kEvalMemo = 3;        // evaluators/EvaluationCaching.scala:32
 constexpr int kMaxRank = 500;
+constexpr int kCholMaxRankAbi = 256;  // (= kCholMaxRank of kernels_posterior.hip: ranks whose factorisation hands the factor out)
 
 // ---- host-side mesh preprocessing (one-off, at context creation)
 
@@ -870,6 +871,10 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipS
   double* parts = mpart_for_write(0, c.stream);
   launch_regression(c.stream, K, r, c.Q.p, e.corr(), wt, kappa, parts, &splits);
   PosteriorFactorIO io{parts, splits, e.M.p, e.alpha.p, status.p + e.status_off, fscratch.p};
+  // the Cholesky-root sampler at ranks above 64 (below, k_posterior_root runs where the decomposition would): the factorisation
+  // itself hands the factor out — V := L, S := 1/diag(L) — and nothing is decomposed at all
+  const bool root_here = sampler == ICP_SAMPLER_CHOLESKY_ROOT && !eigen_speculation_supported(r);
+  if (root_here) { io.Lout = e.V.p; io.Sout = e.S.p; }
   if (side) {
     HIP_OK(hipEventRecord(c.ev_ready, c.stream));
     HIP_OK(hipStreamWaitEvent(side, c.ev_ready, 0));
@@ -883,6 +888,16 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipS
     side_factor_pending = true;
   } else {
     launch_posterior_factor(c.stream, r, 1, &io);
+  }
+  if (root_here) {  // "decomposed" as soon as the factorisation is through: an event behind it stands for the basis
+    if (!e.eig_done) HIP_OK(hipEventCreateWithFlags(&e.eig_done, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(e.eig_done, side ? side : c.stream));
+    e.eig_done_shared = nullptr; e.eig_shared_gen = nullptr;
+    e.eig_event_valid = true;
+    e.done_value = 0;
+    e.eig_valid = true;
+    e.eig_checked = false;
+    h_eig[e.status_off / 3] = 0;
   }
   return e;
 }
@@ -1820,7 +1835,7 @@ int icp_proposal_set_sampler(icp_proposal* p, int32_t sampler) {
     require(p != nullptr, "null argument");
     require(sampler == ICP_SAMPLER_EIGEN || sampler == ICP_SAMPLER_CHOLESKY_ROOT, "unknown sampler");
     icp_ctx& c = *p->ctx;
-    require(sampler == ICP_SAMPLER_EIGEN || eigen_speculation_supported(c.r), "the Cholesky-root sampler covers ranks 3..64");
+    require(sampler == ICP_SAMPLER_EIGEN || c.r <= kCholMaxRankAbi, "the Cholesky-root sampler covers ranks up to 256");
     std::lock_guard<std::recursive_mutex> lk(c.mu);
     if (p->sampler == sampler) return;
     Bound _b(&c);
@@ -2344,6 +2359,8 @@ bool step_pipeline_covers(icp_evaluator* e, int n_props, icp_proposal* const* pr
   for (int i = 0; i < n_props; ++i) {
     const icp_proposal* p = props[i];
     if (p->K < 1) return false;
+    // (the Cholesky-root sampler above rank 64 gets its factor from the per-stage factorisation: icp_proposal::posterior)
+    if (p->sampler == ICP_SAMPLER_CHOLESKY_ROOT && !eigen_speculation_supported(c.r)) return false;
     if (p->prm.direction == ICP_MODEL_SAMPLING) {
       if (p->prm.boundary_aware && c.target.n_boundary > 0) return false;  // needs the nearest-vertex pass (:98-99)
       ++n_model;

@@ -576,36 +576,51 @@ __device__ __forceinline__ void propose_body(int r, const ProposeIn& in, double*
   __shared__ double s_px[512], s_py[512], s_pw[512];
   const int tid = threadIdx.x, nt = blockDim.x;
   if (in.root) {
-    // Cholesky-root sampler (ranks <= 64): u = L⁻ᵀ z by ONE wave — lane i carries u_i, rows of L (in.V, row-major) arrive four
-    // steps ahead, the chain per step is readlane -> multiply -> fma (the back substitution of factor_reg_body, with z as the
-    // right-hand side); w = α + u
-    if (tid < 64) {
-      const int i = tid, ic = i < r ? i : r - 1;  // lanes past r mirror lane r-1 (their result is discarded)
-      double x = in.z[ic];
-      constexpr int kA = 4;
-      double lq[kA], dq[kA];
-#pragma unroll
-      for (int a = 0; a < kA; ++a) {
-        const int jj = max(r - 1 - a, 0);
-        lq[a] = in.V[(size_t)jj * r + ic];
-        dq[a] = in.S[jj];
-      }
-      for (int j0 = r - 1; j0 >= 0; j0 -= kA) {
+    // Cholesky-root sampler: u = L⁻ᵀ z (in.V = L row-major, in.S = 1/diag L), 64 unknowns at a time from the bottom.  A block's
+    // triangle by ONE wave — lane i carries u_i, rows of L arrive four steps ahead, the chain per step is readlane -> multiply ->
+    // fma (the back substitution of factor_reg_body with z as the right-hand side) — then every thread takes the block's
+    // contribution off the unknowns above it.  Ranks <= 64 are one block.  w = α + u.
+    for (int i = tid; i < r; i += nt) s_pw[i] = in.z[i];
+    __syncthreads();
+    for (int b1 = r; b1 > 0; b1 -= 64) {
+      const int b0 = b1 > 64 ? b1 - 64 : 0, nb = b1 - b0;
+      if (tid < 64) {
+        const int i = tid, ic = i < nb ? i : nb - 1;  // lanes past the block mirror its last lane (their result is discarded)
+        double x = s_pw[b0 + ic];
+        constexpr int kA = 4;
+        double lq[kA], dq[kA];
 #pragma unroll
         for (int a = 0; a < kA; ++a) {
-          const int j = j0 - a;                       // (steps with j < 0, the padding of the last group, change nothing)
-          const double lij = lq[a], dj = dq[a];
-          const int jn = max(j - kA, 0);
-          lq[a] = in.V[(size_t)jn * r + ic];
-          dq[a] = in.S[jn];
-          const int lo = __builtin_amdgcn_readlane(__double2loint(x), j & 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), j & 63);
-          const double xj = __hiloint2double(hi, lo) * dj;
-          const double upd = fma(-lij, xj, x);
-          x = j < 0 ? x : (i == j ? xj : (i < j ? upd : x));
+          const int jj = max(nb - 1 - a, 0);
+          lq[a] = in.V[(size_t)(b0 + jj) * r + b0 + ic];
+          dq[a] = in.S[b0 + jj];
         }
+        for (int j0 = nb - 1; j0 >= 0; j0 -= kA) {
+#pragma unroll
+          for (int a = 0; a < kA; ++a) {
+            const int j = j0 - a;                       // (steps with j < 0, the padding of the last group, change nothing)
+            const double lij = lq[a], dj = dq[a];
+            const int jn = max(j - kA, 0);
+            lq[a] = in.V[(size_t)(b0 + jn) * r + b0 + ic];
+            dq[a] = in.S[b0 + jn];
+            const int lo = __builtin_amdgcn_readlane(__double2loint(x), j & 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), j & 63);
+            const double xj = __hiloint2double(hi, lo) * dj;
+            const double upd = fma(-lij, xj, x);
+            x = j < 0 ? x : (i == j ? xj : (i < j ? upd : x));
+          }
+        }
+        if (i < nb) s_pw[b0 + i] = x;
       }
-      if (i < r) s_pw[i] = x + in.alpha[i];
+      __syncthreads();
+      for (int i = tid; i < b0; i += nt) {  // the unknowns above lose this block's contribution (row b0 + j of L, coalesced over i)
+        double acc = s_pw[i];
+#pragma unroll 8
+        for (int j = 0; j < nb; ++j) acc = fma(-in.V[(size_t)(b0 + j) * r + i], s_pw[b0 + j], acc);
+        s_pw[i] = acc;
+      }
+      __syncthreads();
     }
+    for (int i = tid; i < r; i += nt) s_pw[i] += in.alpha[i];
     __syncthreads();
   } else {
     for (int j = tid; j < r; j += nt) s_px[j] = sqrt(in.S[j]) * in.z[j];

@@ -188,7 +188,8 @@ void launch_regression(hipStream_t st, int K, int r, const double* Q, const Corr
                        double kappa, double* Mpart, int* splits_out);
 
 // K5b, up to 4 posteriors per launch: M = I + Σ partials, alpha = M^-1 b (Cholesky); status[0] != 0 if M is not SPD.
-struct PosteriorFactorIO { const double* Mpart; int splits; double* M; double* alpha; int* status; double* scratch /* (r+1)·r, large ranks only */; };
+struct PosteriorFactorIO { const double* Mpart; int splits; double* M; double* alpha; int* status; double* scratch /* (r+1)·r, large ranks only */;
+                           double* Lout = nullptr; double* Sout = nullptr; /* optional: the factor L (r × r, zero upper triangle) and 1/diag(L) */ };
 void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io);
 // Σ of one posterior's split-K partials into its first partial, on many CUs (what the factor kernels do themselves otherwise; with
 // it done, they take splits = 1), and M = I + that sum, both triangles, from the summed partial — the start of a decomposition

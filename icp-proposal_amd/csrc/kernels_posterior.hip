@@ -65,7 +65,26 @@ struct FactorArgs {  // up to 4 posteriors per launch (both ICP directions of on
   double* alpha[4];
   int* status[4];
   double* scratch[4];  // (r+1)·r doubles, used only when the matrix does not fit in LDS
+  // (optional, the Cholesky-root sampler at ranks above 64: icp_proposal_set_sampler) the factor itself: L row-major r × r with a zero
+  // upper triangle, and 1/diag(L) — what k_posterior_root writes at ranks <= 64
+  double* Lout[4];
+  double* Sout[4];
 };
+
+// the factor out of the root-free form W (w_ij = l_ij·d_j, w_jj = d_j; row stride ld): L_ij = w_ij / sqrt(d_j), L_jj = sqrt(d_j)
+__device__ __forceinline__ void emit_factor_rootfree(int r, const double* W, int ld, double* __restrict__ Lout, double* __restrict__ Sout) {
+  for (int e = threadIdx.x; e < r * r; e += blockDim.x) {
+    const int i = e / r, j = e - i * r;
+    double v = 0.0;
+    if (j <= i) {
+      const double d = W[(size_t)j * ld + j], ri = fast_rsqrt(d);
+      v = j == i ? d * ri : W[(size_t)i * ld + j] * ri;
+    }
+    Lout[e] = v;
+  }
+  if (Sout)
+    for (int j = threadIdx.x; j < r; j += blockDim.x) Sout[j] = fast_rsqrt(W[(size_t)j * ld + j]);
+}
 
 constexpr int kFactorThreads = 256;
 
@@ -92,6 +111,7 @@ __global__ void __launch_bounds__(kFactorThreads) k_posterior_factor_generic(int
   const bool ok = block_cholesky_rootfree(W, r, ld, 1, 4);
   if (tid == 0) fa.status[p][0] = ok ? 0 : 1;
   if (!ok) return;
+  if (fa.Lout[p]) emit_factor_rootfree(r, W, ld, fa.Lout[p], fa.Sout[p]);
   // y = L⁻¹ b sits (unscaled) in row r: y_j = W[r][j]·dinv_j
   for (int j = tid; j < r; j += nt) {
     const double d = fast_rsqrt(W[(size_t)j * ld + j]);
@@ -127,7 +147,8 @@ __global__ void __launch_bounds__(kFactorThreads) k_posterior_factor_generic(int
 template <int TPT, int NT>
 __global__ void __launch_bounds__(NT) k_posterior_factor_reg(int r, FactorArgs fa) {
   const int p = blockIdx.x;
-  factor_reg_body<TPT, NT>(r, fa.Mpart[p], fa.splits[p], fa.M[p], fa.alpha[p], fa.status[p]);
+  const bool ok = factor_reg_body<TPT, NT>(r, fa.Mpart[p], fa.splits[p], fa.M[p], fa.alpha[p], fa.status[p]);
+  if (ok && fa.Lout[p]) emit_factor_rootfree(r, s_dyn, r | 1, fa.Lout[p], fa.Sout[p]);  // (W of factor_reg_body: s_dyn, row stride r | 1)
 }
 
 // ---------------------------------------------------------------- K5b for ranks whose factor does not fit one CU's LDS (128..256)
@@ -362,6 +383,15 @@ __global__ void __launch_bounds__(1024) k_posterior_factor_blocked(int r, Factor
   }
   for (int j = tid; j < r; j += nt) fa.alpha[p][j] = s_y[j];
   if (tid == 0) fa.status[p][0] = 0;
+  if (fa.Lout[p]) {  // (W holds the scaled factor here: diagonal sqrt(d), columns divided by it)
+    double* __restrict__ Lo = fa.Lout[p];
+    for (int e = tid; e < r * r; e += nt) {
+      const int i = e / r, j = e - i * r;
+      Lo[e] = j <= i ? W[e] : 0.0;
+    }
+    if (fa.Sout[p])
+      for (int j = tid; j < r; j += nt) fa.Sout[p][j] = fast_rcp(W[(size_t)j * r + j]);
+  }
 #ifdef ICP_EIGEN_TIMING
   if (tid == 0 && blockIdx.x == 0) g_eigen_stamps[29] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1905,6 +1935,7 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
   for (int p = 0; p < n_post; ++p) {
     fa.Mpart[p] = io[p].Mpart; fa.splits[p] = io[p].splits; fa.M[p] = io[p].M; fa.alpha[p] = io[p].alpha;
     fa.status[p] = io[p].status; fa.scratch[p] = io[p].scratch;
+    fa.Lout[p] = io[p].Lout; fa.Sout[p] = io[p].Sout;
   }
   const int ld = r | 1;
   const size_t tiles = (size_t)factor_tile_count(r);

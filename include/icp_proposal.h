@@ -184,7 +184,8 @@ ICP_API int icp_proposal_log_transition(icp_proposal *p, const double *theta_fro
  *                                 and logTransitionProbability (which does not depend on the root) is unchanged — the chain
  *                                 is a different realisation of the same Markov kernel.  No eigen-decomposition at all: D^-1 W z = L^-T z
  *                                 is one back substitution per proposal.  The diagnostic view then returns V = L (row-major lower
- *                                 triangle) and S = 1 / diag(L).  Ranks <= 64.
+ *                                 triangle) and S = 1 / diag(L).  Ranks <= 256 (up to 64: a kernel of its own where the decomposition
+ *                                 would run; above: the posterior's factorisation hands its factor out).
  * Call before the proposal's first use, or any time: posteriors already decomposed the other way are decomposed again. */
 typedef enum { ICP_SAMPLER_EIGEN = 0, ICP_SAMPLER_CHOLESKY_ROOT = 1 } icp_sampler;
 ICP_API int icp_proposal_set_sampler(icp_proposal *p, int32_t sampler);

@@ -402,3 +402,41 @@ def test_step_schedule_at_large_ranks_does_not_change_the_chain(rank, evaluator,
         recs.append(np.load(out))
     a, b = recs
     assert a[:, 1].sum() > 20 and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("rank", [72, 110, 150, 200])
+def test_cholesky_root_sampler_at_large_ranks(pkg, rank):
+    """The opt-in sampler above rank 64: the posterior's own factorisation hands its factor out (register-tiled kernel up to rank
+    ~116, blocked kernel above), nothing is decomposed, and the proposal is a blocked back substitution: L·Lᵀ = M, the proposal is
+    the closed form, logTransitionProbability is the eigen form's, and the BfmFittingPartial chain runs on it."""
+    model = pkg.data.synthetic_face_model(grid=41, rank=rank)
+    target = pkg.data.synthetic_partial_target(model, n_remove=90)
+    ctx = pkg.IcpContext(model, target, device=0)
+    r = rank
+    Q = model.basis * np.sqrt(model.variance)[None, :]
+    P = np.linalg.inv(Q.T @ Q + 1e-5 * np.eye(r))
+    pe = pkg.NonRigidIcpProposal(ctx, 0.1, 6.0, 3.0, 2 * r, "ModelSampling", True)
+    pr = pkg.NonRigidIcpProposal(ctx, 0.1, 6.0, 3.0, 2 * r, "ModelSampling", True).setSampler("cholesky-root")
+    rng = np.random.default_rng(rank)
+    for seed in (5, 6):
+        theta = face_theta(model, seed)
+        a, b = pe.icpPosterior(theta), pr.icpPosterior(theta)
+        assert np.array_equal(a.alpha, b.alpha) and np.array_equal(a.M, b.M) and np.array_equal(a.corr_id, b.corr_id)
+        L = b.V
+        assert np.allclose(np.tril(L), L) and np.abs(b.S * np.diag(L) - 1.0).max() <= 1e-13
+        assert np.abs(L @ L.T - a.M).max() <= 1e-12 * np.abs(a.M).max()
+        z = rng.normal(size=r)
+        got = pr.propose(theta, z)
+        w = a.alpha + np.linalg.solve(np.linalg.cholesky(0.5 * (a.M + a.M.T)).T, z)
+        want = theta[10:] + 0.1 * ((w - 1e-5 * (P @ w)) - theta[10:])
+        assert np.abs(got[10:] - want).max() <= 1e-8 * np.abs(want).max()
+        assert pe.logTransitionProbability(theta, got) == pr.logTransitionProbability(theta, got)
+    pe.close(); pr.close()
+    setup = pkg.bfm_fitting_partial(model, target, evaluator="collective")
+    setup.sampler = "cholesky-root"
+    chain = pkg.SamplingRegistration(ctx, setup, pkg.initial_parameters(model), seed=9)
+    rec = chain.run(80)
+    assert np.all(np.isfinite(rec)) and 10 < rec[:, 1].sum() < 80 and (rec[:, 2] == 0).sum() > 20
+    assert rec[-1, 3] > rec[0, 3]
+    assert all(v == 0 for v in ctx.runtime_stats().values())
+    chain.close(); ctx.close()
