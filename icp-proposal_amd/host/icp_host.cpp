@@ -415,7 +415,7 @@ struct LockstepGroup {
 }  // namespace
 
 // -> ICP_OK: the chains have advanced n_steps on the device; anything else: nothing has happened (the caller steps them on the host)
-static int run_on_device(icp_host_chain* const* chains, int32_t n_chains, int32_t n_steps, double* const* records) {
+static int run_on_device(icp_host_chain* const* chains, int32_t n_chains, int32_t n_steps, double* const* records, int32_t* steps_done_out) {
   // ICP_HOST_DEVICE_LOOP: 0 never, 1 whenever covered, unset: from 48 chains on — a group's step is a serial chain of ≈ 350 µs on the
   // device whatever its size (launches 1-5, the decide kernel, the decompositions of the chains that moved), which two groups overlap:
   // 64 chains 162-174k it/s against 143-146k host-stepped, 128 chains 197-209k; 32 chains 112k either way, 16 chains 65k against 72k
@@ -455,15 +455,33 @@ static int run_on_device(icp_host_chain* const* chains, int32_t n_chains, int32_
     logp[b] = ch->current_p;
     (void)icp_chain_step_prelaunch(ch->likelihood->h, 0, nullptr, -1, nullptr, nullptr);  // (a half step launched ahead: dropped)
   }
-  const int rc = icp_chains_run_on_device(n_chains, ev.data(), (int32_t)n_icp, props.data(), &mix, seeds.data(), first.data(), thp.data(),
-                                          logp.data(), n_steps, records, acc.data());
-  if (rc != ICP_OK) return rc;
+  // (in pieces of at most 4,096 steps: the run keeps its records — 14 + r doubles per chain and step — in device memory until it ends)
+  constexpr int32_t kPiece = 4096;
+  std::vector<double*> recp(n_chains, nullptr);
+  for (int32_t done = 0; done < n_steps; done += kPiece) {
+    const int32_t n = std::min(kPiece, n_steps - done);
+    std::vector<int64_t> acc_piece(n_chains, 0);
+    if (records)
+      for (int b = 0; b < n_chains; ++b) recp[b] = records[b] ? records[b] + (size_t)done * (ICP_HOST_RECORD_HEADER + 10 + c0->r) : nullptr;
+    const int rc = icp_chains_run_on_device(n_chains, ev.data(), (int32_t)n_icp, props.data(), &mix, seeds.data(), first.data(), thp.data(),
+                                            logp.data(), n, records ? recp.data() : nullptr, acc_piece.data());
+    if (rc != ICP_OK) {
+      if (done == 0) return rc;  // nothing has happened: the caller steps the chains on the host
+      // a later piece stopped (a tail that did not contract, say): the chains stand where the last complete piece left them;
+      // book that, and let the host path take the rest
+      n_steps = done;
+      break;
+    }
+    for (int b = 0; b < n_chains; ++b) { first[b] += n; acc[b] += acc_piece[b]; }
+  }
+  const int32_t steps_done = n_steps;
+  *steps_done_out = steps_done;
   for (int b = 0; b < n_chains; ++b) {
     icp_host_chain* ch = chains[b];
     ch->current.allParameters = th[b];
     // generatedBy of the state = the proposal that produced the last ACCEPTED sample; the records carry the leaf ids
     ch->current_p = logp[b];
-    ch->logger.index += n_steps;
+    ch->logger.index += steps_done;
     ch->logger.n_accept += acc[b];
     ch->mh->cached_current = ch->current;
     ch->mh->cached_current_p = logp[b];
@@ -483,9 +501,20 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
   // pose-free mixtures: the whole loop on the device (icp_chains_run_on_device: mixture draw, proposals' inputs, MetropolisHastings.next
   // and the records by kernels of the step's own stream; the host only enqueues).  What it does not cover (and, by default, fewer
   // than 48 chains: see run_on_device) comes back with ICP_ERR_INVALID_ARG and takes the lockstep path below.
+  std::vector<double*> rest;  // (records of the steps the device loop did not take)
   if (chains && n_chains >= 1 && n_steps > 0) {
-    const int rc_dev = run_on_device(chains, n_chains, n_steps, records);
-    if (rc_dev == ICP_OK) return ICP_OK;
+    int32_t n_dev = 0;
+    const int rc_dev = run_on_device(chains, n_chains, n_steps, records, &n_dev);
+    if (rc_dev == ICP_OK) {
+      if (n_dev >= n_steps) return ICP_OK;
+      if (records) {
+        rest.assign(records, records + n_chains);
+        for (int b = 0; b < n_chains; ++b)
+          if (rest[b]) rest[b] += (size_t)n_dev * (ICP_HOST_RECORD_HEADER + 10 + chains[b]->r);
+        records = rest.data();
+      }
+      n_steps -= n_dev;
+    }
   }
   constexpr int kMaxGroups = 4;
   LockstepGroup groups[kMaxGroups];

@@ -23,7 +23,10 @@ ctx.close()
 model = pkg.data.synthetic_face_model()
 target = pkg.data.synthetic_partial_target(model, seed=7)
 ctx = pkg.IcpContext(model, target, device=0)
-for ev in ("collective", "hausdorff"):
-    r, a = rate(ctx, pkg.bfm_fitting_partial(model, target, evaluator=ev), pkg.initial_parameters(model), 10, 100)
-    print(f"configs[3] face stand-in (N = {model.n_points}, rank {model.rank}), {ev} evaluator: {r:8.1f} it/s, acceptance {a:.2f}", flush=True)
+for sampler in ("eigen", "cholesky-root"):
+    for ev in ("collective", "hausdorff"):
+        setup = pkg.bfm_fitting_partial(model, target, evaluator=ev)
+        setup.sampler = sampler
+        r, a = rate(ctx, setup, pkg.initial_parameters(model), 10, 200)
+        print(f"configs[3] face stand-in (N = {model.n_points}, rank {model.rank}), {ev} evaluator, {sampler} sampler: {r:8.1f} it/s, acceptance {a:.2f}", flush=True)
 ctx.close()
