@@ -3625,7 +3625,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
         m.tails = gr.res.p + (size_t)k * 32 + 8;
         m.tail_status = gr.stat.p + (size_t)k * 16;
         m.chol_status = gr.stat.p + (size_t)k * 16 + 8;
-        m.normals = nullptr; m.normals_first = 0;
+        m.normals = nullptr; m.normals_first = 0; m.normals_rows = 0;
         m.records = records && records[gr.b0 + k] ? gr.rec.p + (size_t)k * n_steps * (4 + P) : nullptr;
         m.rec_first = first_step[gr.b0 + k];
         m.theta = gr.theta.p + (size_t)k * P;
@@ -3665,7 +3665,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
         draw_block(gr, blk, buf);
         HIP_OK(hipMemcpyAsync(gr.normals[buf].p, gr.h_normals[buf], sizeof(double) * (size_t)gr.B * kChunk * r, hipMemcpyHostToDevice, gr.st));
         HIP_OK(hipEventRecord(gr.ev_copy[buf], gr.st));
-        launch_mh_set_normals(gr.st, gr.B, gr.mh.p, gr.normals[buf].p, kChunk * r, s0);
+        launch_mh_set_normals(gr.st, gr.B, gr.mh.p, gr.normals[buf].p, kChunk * r, s0, ns);
       }
       // The chip-wide launches of two groups side by side slow each other down more than the overlap gains; what
       // should run beside a group's chip-wide launches 1-4 is the OTHER group's small ones (launch 5 on four CUs per chain, the
@@ -3678,7 +3678,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
             Group& prev = groups[(g + n_groups - 1) % n_groups];
             if (blk > 0 || s_ > 0 || g > 0) HIP_OK(hipStreamWaitEvent(gr.st, prev.ev_big, 0));
           }
-          launch_mh_front(gr.st, gr.B, gr.mh.p);
+          if (s_ == 0) launch_mh_front(gr.st, gr.B, gr.mh.p);  // (later steps of the block: prepared by the decide kernel of the step before)
           int g4[5] = {gr.grid[0], gr.grid[1], gr.grid[2], gr.grid[3], 0};
           launch_step_batch_resident(gr.st, gr.B, g4, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p);
           if (n_groups > 1) HIP_OK(hipEventRecord(gr.ev_big, gr.st));

@@ -448,6 +448,7 @@ struct MhChain {
   const int* chol_status;                // [n_icp]
   const double* normals;                 // [steps][r] standard normals of this chain, row = step − normals_first
   long long normals_first;
+  int normals_rows;                      // rows of the block in `normals` (k_mh_decide prepares the NEXT step itself while its normals are there)
   double* records;                       // [steps][4 + 10 + r], row = step − rec_first
   long long rec_first;
   // -- chain state
@@ -457,7 +458,7 @@ struct MhChain {
   int cur_sel, gen, leaf, error;         // error != 0: the chain needs the host (non-contracting tail, non-finite value, …) and stands still
   int eig_seq[2];                        // decompositions of proposal i so far (cold every 128th, as the host path)
 };
-void launch_mh_set_normals(hipStream_t st, int B, MhChain* chains, const double* base, int stride, int offset);
+void launch_mh_set_normals(hipStream_t st, int B, MhChain* chains, const double* base, int stride, int offset, int rows);
 void launch_mh_front(hipStream_t st, int B, MhChain* chains);
 void launch_mh_decide(hipStream_t st, int B, MhChain* chains);
 // the five merged launches for B chains from DEVICE-RESIDENT argument arrays (no copy kernel, no gate: one stream, in order)

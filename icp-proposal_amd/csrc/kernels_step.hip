@@ -585,11 +585,10 @@ __device__ __forceinline__ void mh_copy(T* dst, const T* src, int tid, int nt) {
 }
 }  // namespace
 
-// head of a step: mixture draw (MixtureProposal.propose: outer draw on lane 0, inner on lane 1), the step's arguments
-__global__ void __launch_bounds__(64) k_mh_front(MhChain* __restrict__ chains) {
-  MhChain& c = chains[blockIdx.x];
-  if (c.error) return;
-  const int tid = threadIdx.x, r = c.r;
+// head of a step: mixture draw (MixtureProposal.propose: outer draw on lane 0, inner on lane 1), the step's arguments.
+// One wave per chain; called by k_mh_front (first step of a block of normals) and by k_mh_decide for the step behind its own.
+__device__ __forceinline__ void mh_front_body(MhChain& c, const int tid) {
+  const int r = c.r;
   __shared__ int s_gen;
   if (tid == 0) {
     const unsigned long long step = (unsigned long long)c.step;
@@ -621,6 +620,11 @@ __global__ void __launch_bounds__(64) k_mh_front(MhChain* __restrict__ chains) {
     // (RandomShapeUpdateProposal.scala:31-35)
     b.zin[tid] = gen >= 0 ? z[tid] : c.theta[10 + tid] + c.rw_sigma * z[tid];
   }
+}
+__global__ void __launch_bounds__(64) k_mh_front(MhChain* __restrict__ chains) {
+  MhChain& c = chains[blockIdx.x];
+  if (c.error) return;
+  mh_front_body(c, threadIdx.x);
 }
 
 // tail of a step: MetropolisHastings.next with the device results.  One wave per chain: lane j holds coefficient j of the proposed and
@@ -727,17 +731,25 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
     if (acc) { c.cur_p = prop_p; c.cur_sel = new_sel; ++c.accepted; }
     c.step = step + 1;
   }
+  // ---- the head of the NEXT step, while its normals are on the device (one launch and its boundary less per step)
+  const bool has_next = step + 1 - c.normals_first < (long long)c.normals_rows;  // (uniform)
+  if (has_next) {
+    __threadfence_block();
+    __syncthreads();
+    mh_front_body(c, lane);
+  }
 }
 
 // a block of standard normals has arrived: chain b's rows start at base + b·stride, row 0 = the run's step `offset`
-__global__ void k_mh_set_normals(MhChain* __restrict__ chains, int B, const double* base, int stride, int offset) {
+__global__ void k_mh_set_normals(MhChain* __restrict__ chains, int B, const double* base, int stride, int offset, int rows) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   chains[b].normals = base + (size_t)b * stride;
   chains[b].normals_first = chains[b].rec_first + offset;
+  chains[b].normals_rows = rows;
 }
-void launch_mh_set_normals(hipStream_t st, int B, MhChain* chains, const double* base, int stride, int offset) {
-  if (B > 0) hipLaunchKernelGGL(k_mh_set_normals, dim3((B + 63) / 64), dim3(64), 0, st, chains, B, base, stride, offset);
+void launch_mh_set_normals(hipStream_t st, int B, MhChain* chains, const double* base, int stride, int offset, int rows) {
+  if (B > 0) hipLaunchKernelGGL(k_mh_set_normals, dim3((B + 63) / 64), dim3(64), 0, st, chains, B, base, stride, offset, rows);
 }
 void launch_mh_front(hipStream_t st, int B, MhChain* chains) {
   if (B > 0) hipLaunchKernelGGL(k_mh_front, dim3(B), dim3(64), 0, st, chains);
