@@ -443,7 +443,27 @@ def main():
             t1 = time.perf_counter()
             pkg.run_chains_batched(mch, n_m, want_records=False)
             mdt = time.perf_counter() - t1
-            line["many_chains"] = {"chains_per_gpu": nB, "value": nB * n_m / mdt, "unit": "iterations/s", "steps_per_chain": n_m,
+            # the distance kernel with many chains per launch (north_star: "HBM GB/s on the distance kernel"): HIP events around the
+            # launches of a short extra run (the first chain's context carries the group's launches)
+            dk = None
+            try:
+                mctx[0].profile_start(max_launches=40000)
+                n_p = 100
+                pkg.run_chains_batched(mch, n_p, want_records=False)
+                pst = mctx[0].profile_stop()
+                if "k_step_filter" in pst:
+                    f = pst["k_step_filter"]
+                    per_launch = nB * n_p / max(f["calls"], 1)
+                    dalg = kernel_algorithmic_bytes("k_step_filter", model, target, setup) * per_launch
+                    dk = {"kernel": "k_step_filter (batched)", "chains_per_launch": per_launch, "avg_launch_us": f["avg_us"], "launches": f["calls"],
+                          "algorithmic_bytes": dalg, "achieved_GBs": dalg / (f["avg_us"] * 1e-6) / 1e9,
+                          "frac_hbm": dalg / (f["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "kernel_us_per_launch": {k: round(v["avg_us"], 2) for k, v in pst.items()},
+                          "note": "algorithmic bytes per chain x chains per launch / launch duration; the chains of a launch search the SAME target, so the "
+                                  "bytes that actually leave HBM are fewer (the target's spheres stay in L2 between the chains' workgroups)"}
+            except Exception as e:
+                dk = {"error": str(e)[:200]}
+            line["many_chains"] = {"chains_per_gpu": nB, "value": nB * n_m / mdt, "unit": "iterations/s", "steps_per_chain": n_m, "distance_kernel": dk,
                                    "entry_point": "icp_chains_run_on_device (the whole MH loop on the device: DESIGN §5.1c) from 48 chains on, "
                                                   "icp_chain_step_batched below"}
             for ch in mch:

@@ -3658,6 +3658,8 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       }
     };
     const int n_blocks = (n_steps + kChunk - 1) / kChunk;
+    // (per-kernel event timing, if the first chain's context is being profiled: icp_ctx_profile_start — its event pool, both streams)
+    struct ProfBind { ProfBind(icp_ctx& c) { g_prof = c.profiling ? &c.prof : nullptr; } ~ProfBind() { g_prof = nullptr; } } prof_bind(lead);
     for (int blk = 0; blk < n_blocks; ++blk) {
       const int buf = blk & 1, s0 = blk * kChunk, ns = std::min(kChunk, n_steps - s0);
       for (auto& gr : groups) {

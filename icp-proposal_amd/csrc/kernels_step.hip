@@ -531,11 +531,12 @@ inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 void launch_step_batch_resident(hipStream_t st, int B, const int gx[5], int r, const StepBeginArgs* begin, const StepSearchArgs* search,
                                 const StepRegressionArgs* regression, const StepFinishArgs* finish) {
   if (B <= 0) return;
-  if (gx[0] > 0) hipLaunchKernelGGL(k_step_begin_batch, dim3(gx[0], B), dim3(kStepBlock), 0, st, begin);
-  if (gx[1] > 0) hipLaunchKernelGGL(k_step_filter_batch, dim3(gx[1], B), dim3(kSearchBlock), 0, st, search);
-  if (gx[2] > 0) hipLaunchKernelGGL(k_step_resolve_batch, dim3(gx[2], B), dim3(64), 0, st, search);
-  if (gx[3] > 0) hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, regression);
+  if (gx[0] > 0) { ProfScope _ps(st, KID_STEP_BEGIN); hipLaunchKernelGGL(k_step_begin_batch, dim3(gx[0], B), dim3(kStepBlock), 0, st, begin); }
+  if (gx[1] > 0) { ProfScope _ps(st, KID_STEP_FILTER); hipLaunchKernelGGL(k_step_filter_batch, dim3(gx[1], B), dim3(kSearchBlock), 0, st, search); }
+  if (gx[2] > 0) { ProfScope _ps(st, KID_STEP_RESOLVE); hipLaunchKernelGGL(k_step_resolve_batch, dim3(gx[2], B), dim3(64), 0, st, search); }
+  if (gx[3] > 0) { ProfScope _ps(st, KID_STEP_REGRESSION); hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, regression); }
   if (gx[4] > 0) {
+    ProfScope _ps(st, KID_STEP_FINISH);
     const FinishPlan p = finish_plan(r);
     if (p.E == 1 && p.NT == 256) launch_finish_batch<1, 256>(st, finish, gx[4], B, p.shmem);
     else if (p.E == 2 && p.NT == 512) launch_finish_batch<2, 512>(st, finish, gx[4], B, p.shmem);

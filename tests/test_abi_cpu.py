@@ -108,6 +108,19 @@ def test_batched_step_rejects_bad_arguments_before_device(pkg):
     assert lib.icp_ctx_set_rotation(None, None, None) == -1
 
 
+def test_round3_entry_points_reject_bad_arguments_before_device(pkg):
+    """icp_chains_run_on_device, icp_proposal_set_sampler, icp_ctx_profile_search_counters: null / empty argument lists come back with
+    ICP_ERR_INVALID_ARG and touch no device (this runs without a GPU)."""
+    lib, nat = pkg._native.lib(), pkg._native
+    mix = nat.MhMixture((ctypes.c_double * 2)(0.5, 0.5), 0.9, 0.1, 0.1)
+    assert lib.icp_chains_run_on_device(0, None, 1, None, ctypes.byref(mix), None, None, None, None, 10, None, None) == -1
+    assert lib.icp_chains_run_on_device(1, None, 1, None, None, None, None, None, None, 10, None, None) == -1
+    assert b"null argument" in lib.icp_last_error()
+    assert lib.icp_proposal_set_sampler(None, 1) == -1
+    assert lib.icp_ctx_profile_search_counters(None, 1) == -1
+    assert ctypes.sizeof(nat.MhMixture) == 40
+
+
 def test_synthetic_target_sizes(pkg):
     """BASELINE.json configs[1]: 6-way subdivision of the femur target -> 58,322 vertices / 116,640 triangles."""
     _, big = pkg.data.synthetic_femur_target()
