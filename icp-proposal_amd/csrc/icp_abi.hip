@@ -657,7 +657,20 @@ struct icp_proposal {
                        const int* ready, int ready_seq, EigenSpec* spec_out, EigenRequest* rq_out);
   void resolve_speculation(const double* theta_cur);
   DBuf<int> status;       // 3 ints per memo entry: {chol(M), chol(G+σ²M), eigen}
-  std::vector<int> h_status;
+  // (pinned: the copy of `status` into it is a true asynchronous copy — into a pageable vector it was a synchronising one, 20-30 µs
+  // per step of the per-stage paths)
+  struct PinnedInts {
+    int* p = nullptr; size_t n = 0;
+    void assign(size_t count, int v) {
+      if (p) (void)hipHostFree(p);
+      HIP_OK(hipHostMalloc((void**)&p, sizeof(int) * count, hipHostMallocDefault));
+      n = count;
+      for (size_t i = 0; i < count; ++i) p[i] = v;
+    }
+    int& operator[](size_t i) { return p[i]; }
+    int* data() { return p; }
+    ~PinnedInts() { if (p) (void)hipHostFree(p); }
+  } h_status;
   std::unique_ptr<PosteriorEntry[]> memo;
   uint64_t clock = 0;
 
@@ -3446,8 +3459,9 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       HIP_OK(hipStreamSynchronize(c.stream));
       HIP_OK(hipStreamSynchronize(c.front_stream));
       sync_eigen(c);
+      for (int i = 0; i < n_props; ++i) sync_proposal_status(ch.props[i]);
+      HIP_OK(hipStreamSynchronize(c.stream));
       for (int i = 0; i < n_props; ++i) {
-        sync_proposal_status(ch.props[i]);
         ch.props[i]->check_status(*ch.set[0][i]);
         if (ch.props[i]->h_eig[ch.set[0][i]->status_off / 3] != 0) fail(ICP_ERR_NOT_FINITE, "posterior eigen-decomposition did not converge");
       }
