@@ -182,8 +182,83 @@ __global__ void __launch_bounds__(256) k_sum_partials(PartialSumArgs a) {
 constexpr int kCholNB = 64;
 constexpr int kCholMaxRank = 256;
 
+// Blocked back substitution Lᵀ α = y on the SCALED factor in global memory (row-major, ld = r; rows 0..r-1: L with its diagonal,
+// row r: y = L⁻¹b), block by block from the end, then α, the status and — Cholesky-root sampler — L and 1/diag(L) handed out.
+// A block's triangle goes into LDS first (coalesced), then ONE wave runs its 64 steps out of registers: lane i carries α_i and
+// 1/l_ii, a step is two readlane pairs, a multiply and a multiply-add, the rows of L come from LDS four steps ahead (the same chain
+// as factor_reg_body's; a __shfl per step — an LDS round trip — made 5 µs of a block, loads from L2 four ahead 8 µs).  The
+// unknowns above then lose the block's contribution with every thread at work: four groups of 256 threads take 16 of its
+// columns each.
+// D: [kCholNB][kCholNB + 1] doubles of LDS; s_y: 512 doubles; s_part: 4 × 256 doubles.
+__device__ __forceinline__ void factor_backsolve_emit(int r, const double* __restrict__ W, double* D, double* s_y, double* s_part,
+                                                      const FactorArgs& fa, int p) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  constexpr int ldd = kCholNB + 1;
+  for (int j = tid; j < r; j += nt) s_y[j] = W[(size_t)r * r + j];
+  const int last_kb = ((r - 1) / kCholNB) * kCholNB;
+  for (int kb = last_kb; kb >= 0; kb -= kCholNB) {
+    const int nbk = min(kCholNB, r - kb);
+    for (int e = tid; e < kCholNB * kCholNB; e += nt) {
+      const int i = e >> 6, j = e & 63;
+      if (j <= i && i < nbk) D[i * ldd + j] = W[(size_t)(kb + i) * r + kb + j];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int i = tid, ic = i < nbk ? i : nbk - 1;  // lanes past the block mirror its last lane (their result is discarded)
+      double x = s_y[kb + ic];
+      const double di = fast_rcp(D[ic * ldd + ic]);
+      constexpr int kA = 4;
+      double lq[kA];
+#pragma unroll
+      for (int a = 0; a < kA; ++a) lq[a] = D[max(nbk - 1 - a, ic) * ldd + ic];  // (row >= column: the triangle that was staged)
+      for (int j0 = nbk - 1; j0 >= 0; j0 -= kA) {
+#pragma unroll
+        for (int a = 0; a < kA; ++a) {
+          const int j = j0 - a;                         // (steps with j < 0, the padding of the last group, change nothing)
+          const double lij = lq[a];
+          lq[a] = D[max(j - kA, ic) * ldd + ic];
+          const int js = j & 63;
+          const double xr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), js), __builtin_amdgcn_readlane(__double2loint(x), js));
+          const double dj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(di), js), __builtin_amdgcn_readlane(__double2loint(di), js));
+          const double xj = xr * dj;
+          const double upd = fma(-lij, xj, x);
+          x = j < 0 ? x : (i == j ? xj : (i < j ? upd : x));
+        }
+      }
+      if (i < nbk) s_y[kb + i] = x;
+    }
+    __syncthreads();
+    if (kb > 0) {  // the unknowns further up lose this block's contribution (kb <= 192 of them: thread = (column group, unknown))
+      const int g = tid >> 8, i = tid & 255;
+      if (i < kb) {
+        double acc = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const int j = 16 * g + jj;
+          acc = j < nbk ? fma(W[(size_t)(kb + j) * r + i], s_y[kb + j], acc) : acc;
+        }
+        s_part[g * 256 + i] = acc;
+      }
+      __syncthreads();
+      if (tid < kb) s_y[tid] -= (s_part[tid] + s_part[256 + tid]) + (s_part[512 + tid] + s_part[768 + tid]);
+      __syncthreads();
+    }
+  }
+  for (int j = tid; j < r; j += nt) fa.alpha[p][j] = s_y[j];
+  if (tid == 0) fa.status[p][0] = 0;
+  if (fa.Lout[p]) {  // (W holds the scaled factor here: diagonal sqrt(d), columns divided by it)
+    double* __restrict__ Lo = fa.Lout[p];
+    for (int e = tid; e < r * r; e += nt) {
+      const int i = e / r, j = e - i * r;
+      Lo[e] = j <= i ? W[e] : 0.0;
+    }
+    if (fa.Sout[p])
+      for (int j = tid; j < r; j += nt) fa.Sout[p][j] = fast_rcp(W[(size_t)j * r + j]);
+  }
+}
+
 __global__ void __launch_bounds__(1024) k_posterior_factor_blocked(int r, FactorArgs fa) {
-  __shared__ double s_y[512], s_dinv[kCholNB];
+  __shared__ double s_y[512], s_dinv[kCholNB], s_part[1024];
   __shared__ int s_fail;
   const int tid = threadIdx.x, nt = blockDim.x, n = r + 1, p = blockIdx.x;
   const double* __restrict__ Mpart = fa.Mpart[p];
@@ -349,52 +424,124 @@ __global__ void __launch_bounds__(1024) k_posterior_factor_blocked(int r, Factor
     if (tid == 0) fa.status[p][0] = 1;
     return;
   }
-  // ---- back substitution Lᵀ α = y (y = row r of W), block by block from the end
-  for (int j = tid; j < r; j += nt) s_y[j] = W[(size_t)r * r + j];
-  __syncthreads();
-  const int last_kb = ((r - 1) / kCholNB) * kCholNB;
-  for (int kb = last_kb; kb >= 0; kb -= kCholNB) {
-    const int nbk = min(kCholNB, r - kb);
-    for (int e = tid; e < nbk * nbk; e += nt) {
-      const int i = e / nbk, j = e - i * nbk;
-      if (j <= i) D[i * ldd + j] = W[(size_t)(kb + i) * r + kb + j];
-    }
-    __syncthreads();
-    if (tid < nbk) s_dinv[tid] = fast_rcp(D[tid * ldd + tid]);
-    __syncthreads();
-    if (tid < 64) {  // one wave: α_j = (y_j − Σ_{i>j} l_ij α_i) / l_jj, from the block's last unknown to its first
-      const int i = tid;
-      double v = i < nbk ? s_y[kb + i] : 0.0;
-      const double* dd = s_dinv;
-      for (int j = nbk - 1; j >= 0; --j) {
-        const double aj = __shfl(v, j, 64) * dd[j];
-        if (i == j) v = aj;
-        else if (i < j) v = fma(-D[j * ldd + i], aj, v);
-      }
-      if (i < nbk) s_y[kb + i] = v;
-    }
-    __syncthreads();
-    for (int i = tid; i < kb; i += nt) {  // the unknowns further up lose this block's contribution
-      double acc = 0.0;
-      for (int j = 0; j < nbk; ++j) acc = fma(W[(size_t)(kb + j) * r + i], s_y[kb + j], acc);
-      s_y[i] -= acc;
-    }
-    __syncthreads();
-  }
-  for (int j = tid; j < r; j += nt) fa.alpha[p][j] = s_y[j];
-  if (tid == 0) fa.status[p][0] = 0;
-  if (fa.Lout[p]) {  // (W holds the scaled factor here: diagonal sqrt(d), columns divided by it)
-    double* __restrict__ Lo = fa.Lout[p];
-    for (int e = tid; e < r * r; e += nt) {
-      const int i = e / r, j = e - i * r;
-      Lo[e] = j <= i ? W[e] : 0.0;
-    }
-    if (fa.Sout[p])
-      for (int j = tid; j < r; j += nt) fa.Sout[p][j] = fast_rcp(W[(size_t)j * r + j]);
-  }
+  factor_backsolve_emit(r, W, D, s_y, s_part, fa, p);
 #ifdef ICP_EIGEN_TIMING
   if (tid == 0 && blockIdx.x == 0) g_eigen_stamps[29] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// ---------------------------------------------------------------- K5c ranks 117..~250: the whole factorisation in REGISTERS
+// The register-tiled right-looking elimination of factor_reg_body (2 × 4 tiles, one barrier per column, the pivot column passed
+// through a double buffer in LDS) does not need the factor in LDS at all — only the finished columns went there, for the back
+// substitution.  Here they go to global scratch (fire-and-forget stores of the SCALED column: l_ij = u_ij·rsqrt(u_jj), written by
+// the threads 0..n/2 from the pivot-column buffer every thread reads anyway), TPT = 3 or 4 tiles per thread cover ranks up to 250
+// (48-64 registers of matrix per thread), and the blocked back substitution above reads the factor back from L2.
+// Tiles are dealt COLUMN-major: a thread's slots die one after the other as the elimination passes their columns, the whole
+// workgroup skips a dead slot (its loads from the column buffer and its eight multiply-adds) — 57 % of the work at rank 200.
+// 200 columns × ≈ 0.3 µs instead of the blocked kernel's diagonal blocks + panels + trailing updates (187 µs).
+static __host__ __device__ inline int factor_tile_rows(int r) { return (r + 2) >> 1; }  // over the r+1 rows (M and bᵀ)
+constexpr int kFactorAsmGroups = 4;  // workgroups beside the factorising one that write M
+
+template <int TPT>
+__global__ void __launch_bounds__(1024) k_posterior_factor_tiles(int r, FactorArgs fa) {
+  __shared__ __attribute__((aligned(16))) double s_col[2][520];
+  __shared__ double s_y[512], s_part[1024];
+  constexpr int NT = 1024;
+  const int tid = threadIdx.x, n = r + 1, p = blockIdx.x;
+  const double* __restrict__ Mpart = fa.Mpart[p];   // one (summed) partial, (r+1) × (r+1)
+  double* __restrict__ W = fa.scratch[p];            // (r+1) × r: the scaled factor, row r = y
+  double* __restrict__ M = fa.M[p];
+  if (blockIdx.y > 0) {
+    // M = I + the summed partial, both triangles, for the kernels that follow (tails, decomposition): by workgroups of their own,
+    // coalesced — written from the tiles (a row per lane: one memory transaction per element) it took 17 of the kernel's first 22 µs
+    for (int e = (blockIdx.y - 1) * NT + tid; e < r * r; e += (gridDim.y - 1) * NT) {
+      const int i = e / r, j = e - i * r;
+      M[e] = Mpart[(size_t)max(i, j) * n + min(i, j)] + (i == j ? 1.0 : 0.0);
+    }
+    return;
+  }
+  FAC_STAMP(16);
+  const int tr = factor_tile_rows(r), n_tiles = factor_tile_count(r);
+  double v[TPT][2][4];
+  int R0[TPT], C0[TPT];
+#pragma unroll
+  for (int t = 0; t < TPT; ++t) {
+    const int e = tid + NT * t;
+    int tc = 0, base = 0;  // tile column tc holds the tile rows 2·tc … tr−1
+    if (e < n_tiles) {
+      while (base + (tr - 2 * tc) <= e) { base += tr - 2 * tc; ++tc; }
+    }
+    R0[t] = e < n_tiles ? 2 * (2 * tc + (e - base)) : -2;  // -2: slot unused
+    C0[t] = e < n_tiles ? 4 * tc : -8;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {  // every load of the thread in flight before the first store below
+        const int i = R0[t] + a, k = C0[t] + c;
+        const bool live = R0[t] >= 0 && i < n && k < r && k <= i;
+        v[t][a][c] = live ? Mpart[(size_t)i * n + k] : 0.0;
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < TPT; ++t) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = R0[t] + a, k = C0[t] + c;
+        const bool live = R0[t] >= 0 && i < n && k < r && k <= i;
+        if (live) {
+          if (i < r && i == k) v[t][a][c] += 1.0;
+          if (k == 0) s_col[0][i] = v[t][a][c];
+        }
+      }
+  }
+  __syncthreads();
+  FAC_STAMP(17);
+  bool ok = true;
+  for (int j4 = 0; j4 < r && ok; j4 += 4) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int j = j4 + cc;
+      if (j >= r) break;                       // uniform
+      const double* cur = s_col[cc & 1];      // j & 1 == cc & 1
+      double* nxt = s_col[(cc + 1) & 1];
+      const double ajj = cur[j];
+      if (!(ajj > 0.0)) { ok = false; break; }  // same value in every thread: uniform exit
+      const double inv = fast_rcp(ajj);
+      const int kp = j + 1;                      // the column that becomes final in this step
+      if (2 * tid < n) {                         // column j of the scaled factor, rows j … r
+        const double rs = fast_rsqrt(ajj);
+        const dense2 cj = *(const dense2*)&cur[2 * tid];
+        const int i0 = 2 * tid;
+        if (i0 >= j) W[(size_t)i0 * r + j] = cj.x * rs;
+        if (i0 + 1 >= j && i0 + 1 < n) W[(size_t)(i0 + 1) * r + j] = cj.y * rs;
+      }
+#pragma unroll
+      for (int t = 0; t < TPT; ++t) {
+        if (C0[t] + 3 < j4) continue;            // every column of this tile is final (slots die workgroup-wide, a few columns apart)
+        const dense2 u = *(const dense2*)&cur[R0[t]];
+        const dense2 k01 = *(const dense2*)&cur[C0[t]];
+        const dense2 k23 = *(const dense2*)&cur[C0[t] + 2];
+        const double m0 = -(u.x * inv), m1 = -(u.y * inv);
+        v[t][0][0] = fma(m0, k01.x, v[t][0][0]); v[t][0][1] = fma(m0, k01.y, v[t][0][1]);
+        v[t][0][2] = fma(m0, k23.x, v[t][0][2]); v[t][0][3] = fma(m0, k23.y, v[t][0][3]);
+        v[t][1][0] = fma(m1, k01.x, v[t][1][0]); v[t][1][1] = fma(m1, k01.y, v[t][1][1]);
+        v[t][1][2] = fma(m1, k23.x, v[t][1][2]); v[t][1][3] = fma(m1, k23.y, v[t][1][3]);
+        if (kp < r && C0[t] == (kp & ~3))        // this tile holds column kp at tile column (cc+1)&3
+          *(dense2*)&nxt[R0[t]] = dense2{v[t][0][(cc + 1) & 3], v[t][1][(cc + 1) & 3]};
+      }
+      __syncthreads();
+    }
+  }
+  if (!ok) {
+    if (tid == 0) fa.status[p][0] = 1;
+    return;
+  }
+  FAC_STAMP(18);
+  FAC_STAMP(19);
+  factor_backsolve_emit(r, W, s_dyn, s_y, s_part, fa, p);
+  FAC_STAMP(20);
 }
 
 struct TailArgs {
@@ -1961,7 +2108,16 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
   if (w_fits && tiles <= 256) launch_factor_reg<1, 256>(st, r, n_post, fa);
   else if (w_fits && tiles <= 1024) launch_factor_reg<1, 1024>(st, r, n_post, fa);
   else if (w_fits && tiles <= 2048) launch_factor_reg<2, 1024>(st, r, n_post, fa);
-  else if (r <= kCholMaxRank) {  // blocked, matrix in `scratch`, block columns through LDS
+  else if (tiles <= 4096 && !dev_env("ICP_FACTOR_BLOCKED")) {  // ranks 117..~250: register tiles, the factor to global scratch
+    const size_t shmem = sizeof(double) * (size_t)kCholNB * (kCholNB + 1);
+    if (tiles <= 3072) {
+      set_dyn_lds((const void*)k_posterior_factor_tiles<3>, shmem);
+      hipLaunchKernelGGL(k_posterior_factor_tiles<3>, dim3(n_post, 1 + kFactorAsmGroups), dim3(1024), shmem, st, r, fa);
+    } else {
+      set_dyn_lds((const void*)k_posterior_factor_tiles<4>, shmem);
+      hipLaunchKernelGGL(k_posterior_factor_tiles<4>, dim3(n_post, 1 + kFactorAsmGroups), dim3(1024), shmem, st, r, fa);
+    }
+  } else if (r <= kCholMaxRank) {  // blocked, matrix in `scratch`, block columns through LDS
     const size_t shmem = sizeof(double) * ((size_t)kCholNB * (kCholNB + 1) + (size_t)(r + 1) * (kCholNB + 1));
     static size_t lds_granted = 0;
     if (shmem > lds_granted) { set_dyn_lds((const void*)k_posterior_factor_blocked, shmem); lds_granted = shmem; }
