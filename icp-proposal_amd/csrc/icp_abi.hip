@@ -315,10 +315,15 @@ struct icp_ctx {
   double* h_stage = nullptr;  // pinned
   DBuf<double> d_stage;
   size_t stage_cap = 0, stage_used = 0;
-  double* h_res = nullptr;    // pinned results
-  DBuf<double> d_res;
-  int* h_status = nullptr;
-  DBuf<int> d_status;
+  // results of one API call: [64 status ints | res_cap doubles] in ONE device block and one pinned block of the same layout, so
+  // that a call's statuses and results come back in a single copy (finish)
+  static constexpr size_t kStatusDoubles = 32;
+  double* h_out = nullptr;    // pinned
+  DBuf<double> d_out;
+  double* h_res = nullptr;    // = h_out + kStatusDoubles
+  DBuf<double> d_res;         // view
+  int* h_status = nullptr;    // = (int*)h_out
+  DBuf<int> d_status;         // view
   DBuf<int> d_done;            // [0] completion counter of the step's last launch; [1] counter and [2] "partials ready" word
                                // of its regression launch
   int* h_flag = nullptr;       // pinned: sequence number of the last finished step
@@ -395,9 +400,18 @@ struct icp_ctx {
     return d;
   }
 
+  // same, into a device buffer of the caller's (one copy instead of staging + device-to-device)
+  void stage_to(double* dst, const double* src, size_t count) {
+    if (stage_used + count > stage_cap) fail(ICP_ERR_INVALID_ARG, "internal: staging area exhausted");
+    double* h = h_stage + stage_used;
+    std::memcpy(h, src, sizeof(double) * count);
+    HIP_OK(hipMemcpyAsync(dst, h, sizeof(double) * count, hipMemcpyHostToDevice, stream));
+    stage_used += count;
+  }
+
   void finish(size_t n_res, size_t n_status) {
-    if (n_res) HIP_OK(hipMemcpyAsync(h_res, d_res.p, sizeof(double) * n_res, hipMemcpyDeviceToHost, stream));
-    if (n_status) HIP_OK(hipMemcpyAsync(h_status, d_status.p, sizeof(int) * n_status, hipMemcpyDeviceToHost, stream));
+    if (n_status) HIP_OK(hipMemcpyAsync(h_out, d_out.p, sizeof(double) * (kStatusDoubles + n_res), hipMemcpyDeviceToHost, stream));
+    else if (n_res) HIP_OK(hipMemcpyAsync(h_res, d_res.p, sizeof(double) * n_res, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     stage_used = 0;
   }
@@ -499,8 +513,7 @@ StateSlot& icp_ctx::state(const double* theta) {
   s.valid = true;
   s.stamp = ++clock;
   s.pose = pose_of(theta);
-  const double* dc = stage(theta + 10, r);
-  HIP_OK(hipMemcpyAsync(s.coeffs.p, dc, sizeof(double) * r, hipMemcpyDeviceToDevice, stream));
+  stage_to(s.coeffs.p, theta + 10, r);
   launch_instance(stream, N, r, Qp.p, ref.p, mean.p, s.pose, s.coeffs.p, s.x.p);  // ModelFittingParameters.scala:108-110
   return s;
 }
@@ -680,6 +693,7 @@ struct icp_proposal {
   bool side_asm_pending = false;     // … and a decomposition's first launch on the eigen stream the summed partials
   double* side_parts = nullptr;      // the summed partials of the latest posterior(…, side), until the next regression …
   const PosteriorEntry* side_parts_entry = nullptr;  // … and the entry they belong to
+  void issue_factor(PosteriorEntry& e, PosteriorFactorIO io, double* parts, int splits, hipStream_t side, bool root_here);
   PosteriorEntry* find_entry(const double* theta);
   PosteriorEntry& fresh_entry();
   void alloc_entry(PosteriorEntry& e);
@@ -850,14 +864,13 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipS
   e.valid = true;
   e.stamp = ++clock;
   StateSlot& s = c.state(theta);  // :141 currentMesh
-  HIP_OK(hipMemcpyAsync(e.coeffs.p, s.coeffs.p, sizeof(double) * r, hipMemcpyDeviceToDevice, c.stream));
-  HIP_OK(hipMemsetAsync(status.p + e.status_off, 0, sizeof(int) * 3, c.stream));  // {chol, eigen sweeps (diagnostic), eigen}
+  const EntryInit init{s.coeffs.p, e.coeffs.p, r, status.p + e.status_off};  // (status: {chol, eigen sweeps (diagnostic), eigen})
   if (prm.direction == ICP_TARGET_SAMPLING) {
     // :117-118 nearest vertex of the current mesh for every decimated-target point
     QueryBuffers qb = c.query_scratch(K, c.N);
     launch_vertex_query(c.stream, c.N, s.x.p, K, target_pts.p, hint_nn.p, qb, nullptr, nn_id.p);
     launch_correspond_target(c.stream, K, s.x.p, target_pts.p, nn_id.p, c.boundary.p, prm.boundary_aware, s.pose, c.ref.p,
-                             c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, e.corr());
+                             c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, e.corr(), init);
   } else {
     // :94-99 closest surface point of the target for model ids 0 until K; nearest target vertex only when the
     // boundary test can change anything (the target has boundary vertices) or the caller asked for it
@@ -865,7 +878,7 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipS
     const bool need_nnv = want_aux || (prm.boundary_aware && c.target.n_boundary > 0);
     if (need_nnv) c.ensure_nnv_prefix(s, K);
     launch_correspond_model(c.stream, K, s.x.p, s.surf_cp.p, need_nnv ? s.surf_nnv.p : nullptr, c.target.boundary.p,
-                            prm.boundary_aware, s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, e.corr());
+                            prm.boundary_aware, s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, e.corr(), init);
   }
   // :152 interpolatedModel.posterior(uncertainDisplacements)
   const double wt = 1.0 / (prm.tangential_noise * prm.tangential_noise);
@@ -891,6 +904,17 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipS
   if (side) {
     HIP_OK(hipEventRecord(c.ev_ready, c.stream));
     HIP_OK(hipStreamWaitEvent(side, c.ev_ready, 0));
+  }
+  issue_factor(e, io, parts, splits, side, root_here);
+  return e;
+}
+
+// the one-workgroup part of a posterior — sum of the split-K partials, factorisation — on `side` (the caller has made it wait
+// for the regression) or on the context stream
+void icp_proposal::issue_factor(PosteriorEntry& e, PosteriorFactorIO io, double* parts, int splits, hipStream_t side, bool root_here) {
+  icp_ctx& c = *ctx;
+  const int r = c.r;
+  if (side) {
     launch_sum_partials(side, r, parts, splits);
     io.splits = 1;
     HIP_OK(hipEventRecord(c.ev_sum, side));
@@ -912,7 +936,6 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipS
     e.eig_checked = false;
     h_eig[e.status_off / 3] = 0;
   }
-  return e;
 }
 
 void sync_eigen(icp_ctx& c);
@@ -1393,10 +1416,12 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     HIP_OK(hipHostMalloc((void**)&ctx->h_stage, sizeof(double) * ctx->stage_cap, hipHostMallocDefault));
     ctx->d_stage.alloc(ctx->stage_cap);
     const size_t res_cap = std::max<size_t>(2048, 3 * (size_t)N + 64);
-    HIP_OK(hipHostMalloc((void**)&ctx->h_res, sizeof(double) * res_cap, hipHostMallocDefault));
-    ctx->d_res.alloc(res_cap);
-    HIP_OK(hipHostMalloc((void**)&ctx->h_status, sizeof(int) * 64, hipHostMallocDefault));
-    ctx->d_status.alloc(64);
+    HIP_OK(hipHostMalloc((void**)&ctx->h_out, sizeof(double) * (icp_ctx::kStatusDoubles + res_cap), hipHostMallocDefault));
+    ctx->d_out.alloc(icp_ctx::kStatusDoubles + res_cap);
+    ctx->h_status = (int*)ctx->h_out;
+    ctx->h_res = ctx->h_out + icp_ctx::kStatusDoubles;
+    ctx->d_status.p = (int*)ctx->d_out.p; ctx->d_status.n = 64; ctx->d_status.owned = false;
+    ctx->d_res.p = ctx->d_out.p + icp_ctx::kStatusDoubles; ctx->d_res.n = res_cap; ctx->d_res.owned = false;
     HIP_OK(hipHostMalloc((void**)&ctx->h_flag, sizeof(int) * 16, hipHostMallocDefault));
     ctx->h_flag[0] = 0;
     ctx->d_done.alloc(4);
@@ -1464,8 +1489,7 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   g_batch_timing.report();
   for (auto& r : ctx->prof.pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-  if (ctx->h_res) (void)hipHostFree(ctx->h_res);
-  if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+  if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
   for (void* bp : ctx->batch_pinned)
     if (bp) (void)hipHostFree(bp);
@@ -2253,6 +2277,7 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
     PosteriorEntry* ep[8];
     TransitionTailIO tails[16];
     int n_tails = 0;
+    bool eval_enqueued = false;
     // (… and so do the one-workgroup factorisations and the tails: they go to a stream of their own, behind the regression; the
     // decomposition follows them on the eigen stream; this stream goes on with the searches and waits for the tails before the
     // results are copied)
@@ -2296,19 +2321,29 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         ++n_tails;
         if (!side) sync_proposal_status(p);
       }
-      if (side) {  // (the staged coefficients and — for entries found in the memo — everything else the tails read: all behind ev_ready)
+      if (side) {
+        // (the staged coefficients and — for entries found in the memo — everything else the tails read: all behind ev_ready)
         HIP_OK(hipEventRecord(c.ev_ready, c.stream));
         HIP_OK(hipStreamWaitEvent(side, c.ev_ready, 0));
+        // Order of issue (the host needs 3-6 µs per launch): factorisation (inside posterior) -> decomposition -> the evaluator's ten
+        // launches -> the tails.  The tails run behind the factorisation whenever they are issued (0.1-0.3 ms of slack); the
+        // evaluator's searches, as long a chain as factorisation + tails at rank 200, used to start 70 µs after the regression had
+        // ended because they were issued last.
+        decompose_ahead(props[0], *ep[0]);
+        if (need_eval) {
+          StateSlot& s = c.state(theta_prop);
+          enqueue_eval(e, s, 0);
+          eval_enqueued = true;
+        }
       }
       for (int t0 = 0; t0 < n_tails; t0 += 8)
         launch_transition_tails(side ? side : c.stream, r, std::min(8, n_tails - t0), tails + t0, c.Ginv.p, kSigma2);
       if (side) {
         HIP_OK(hipEventRecord(c.ev_side, side));
         props[0]->side_factor_pending = false;  // (this stream waits for ev_side below)
-        decompose_ahead(props[0], *ep[0]);
       }
     }
-    if (need_eval && (spec_big || spec_pose)) {
+    if (need_eval && (spec_big || spec_pose) && !eval_enqueued) {
       StateSlot& s = c.state(theta_prop);
       enqueue_eval(e, s, 0);
     }

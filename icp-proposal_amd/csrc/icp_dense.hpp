@@ -572,10 +572,73 @@ __device__ __forceinline__ void tail_body(int r, const double* __restrict__ alph
 // ---------------------------------------------------------------- a8 propose (one workgroup)
 // c_new = (G + σ²I)⁻¹ G w = w − σ² P w with P = (G + σ²I)⁻¹ precomputed;  w = α + D⁻¹ V (√S ∘ z);  c' = c + step·(c_new − c).
 // c_out may be LDS or global; ends with a barrier.
+// kStaged (k_propose only; blockDim a multiple of 256): the Cholesky-root branch stages each 64 × 64 triangle of L in LDS before its
+// one-wave chain (rows from L2 four steps ahead were 8 µs of a block, from LDS 1 µs) and splits the update of the unknowns above a
+// block over blockDim/256 thread groups.  One block (ranks <= 64): the same operations in the same order as the unstaged form.
+template <bool kStaged = false>
 __device__ __forceinline__ void propose_body(int r, const ProposeIn& in, double* c_out, int tpr_log2) {
   __shared__ double s_px[512], s_py[512], s_pw[512];
   const int tid = threadIdx.x, nt = blockDim.x;
-  if (in.root) {
+  if (kStaged && in.root) {
+    __shared__ double s_blk[64 * 65], s_part[4 * 256];
+    constexpr int ldd = 65;
+    for (int i = tid; i < r; i += nt) s_pw[i] = in.z[i];
+    for (int b1 = r; b1 > 0; b1 -= 64) {
+      const int b0 = b1 > 64 ? b1 - 64 : 0, nb = b1 - b0;
+      for (int e = tid; e < 64 * 64; e += nt) {
+        const int i = e >> 6, j = e & 63;
+        if (j <= i && i < nb) s_blk[i * ldd + j] = in.V[(size_t)(b0 + i) * r + b0 + j];
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int i = tid, ic = i < nb ? i : nb - 1;  // lanes past the block mirror its last lane (their result is discarded)
+        double x = s_pw[b0 + ic];
+        const double di = in.S[b0 + ic];
+        constexpr int kA = 4;
+        double lq[kA];
+#pragma unroll
+        for (int a = 0; a < kA; ++a) lq[a] = s_blk[max(nb - 1 - a, ic) * ldd + ic];
+        for (int j0 = nb - 1; j0 >= 0; j0 -= kA) {
+#pragma unroll
+          for (int a = 0; a < kA; ++a) {
+            const int j = j0 - a;                       // (steps with j < 0, the padding of the last group, change nothing)
+            const double lij = lq[a];
+            lq[a] = s_blk[max(j - kA, ic) * ldd + ic];
+            const int js = j & 63;
+            const double xr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), js), __builtin_amdgcn_readlane(__double2loint(x), js));
+            const double dj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(di), js), __builtin_amdgcn_readlane(__double2loint(di), js));
+            const double xj = xr * dj;
+            const double upd = fma(-lij, xj, x);
+            x = j < 0 ? x : (i == j ? xj : (i < j ? upd : x));
+          }
+        }
+        if (i < nb) s_pw[b0 + i] = x;
+      }
+      __syncthreads();
+      if (b0 > 0) {  // the unknowns above lose this block's contribution: thread = (group of the block's columns, unknown)
+        const int G = nt >> 8, g = tid >> 8, per = (nb + G - 1) / G;
+        for (int i0 = 0; i0 < b0; i0 += 256) {
+          const int i = i0 + (tid & 255);
+          if (i < b0) {
+            double acc = 0.0;
+            const int j1 = min(nb, (g + 1) * per);
+#pragma unroll 16
+            for (int j = g * per; j < j1; ++j) acc = fma(in.V[(size_t)(b0 + j) * r + i], s_pw[b0 + j], acc);
+            s_part[g * 256 + (tid & 255)] = acc;
+          }
+          __syncthreads();
+          if (g == 0 && i < b0) {
+            double t = 0.0;
+            for (int q = 0; q < G; ++q) t += s_part[q * 256 + tid];
+            s_pw[i] -= t;
+          }
+          __syncthreads();
+        }
+      }
+    }
+    for (int i = tid; i < r; i += nt) s_pw[i] += in.alpha[i];
+    __syncthreads();
+  } else if (in.root) {
     // Cholesky-root sampler: u = L⁻ᵀ z (in.V = L row-major, in.S = 1/diag L), 64 unknowns at a time from the bottom.  A block's
     // triangle by ONE wave — lane i carries u_i, rows of L arrive four steps ahead, the chain per step is readlane -> multiply ->
     // fma (the back substitution of factor_reg_body with z as the right-hand side) — then every thread takes the block's

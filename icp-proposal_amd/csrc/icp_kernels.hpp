@@ -170,16 +170,18 @@ struct CorrTask {  // everything one correspondence needs besides its search res
   const int* adj;
 };
 
+// optional extra of the correspondence launches: the memo entry's coefficient copy and cleared status words (coeffs_dst == nullptr: none)
+struct EntryInit { const double* coeffs_src = nullptr; double* coeffs_dst = nullptr; int r = 0; int* status = nullptr; };
 // NonRigidIcpProposal.scala:89-110 (ModelSampling): ids 0..K-1, surface points cp, optional nearest-vertex ids
 void launch_correspond_model(hipStream_t st, int K, const double* x, const double* cp, const int* nnv,
                              const unsigned char* tgt_boundary, int boundary_aware, const Pose& pose,
                              const double* ref, const double* mean, const int* tris, const int* adj_off,
-                             const int* adj, const CorrBuffers& cb);
+                             const int* adj, const CorrBuffers& cb, const EntryInit& init = EntryInit{});
 // NonRigidIcpProposal.scala:112-131 (TargetSampling): target points + nearest model vertex ids
 void launch_correspond_target(hipStream_t st, int K, const double* x, const double* tpts, const int* nn_id,
                               const unsigned char* model_boundary, int boundary_aware, const Pose& pose,
                               const double* ref, const double* mean, const int* tris, const int* adj_off,
-                              const int* adj, const CorrBuffers& cb);
+                              const int* adj, const CorrBuffers& cb, const EntryInit& init = EntryInit{});
 
 // K5a (f64 MFMA): partial sums Mpart[s][(r+1)x(r+1)] of Σ_kept [Q_i | e_i]^T Σ_i^-1 [Q_i | e_i]; *splits_out = number of partials.
 // Mpart must hold regression_splits(K)·(r+1)² doubles.

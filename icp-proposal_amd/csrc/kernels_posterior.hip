@@ -43,12 +43,22 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------- correspondences (one thread per correspondence)
 
-__global__ void __launch_bounds__(kBlock) k_correspond_model(CorrTask c, const double* __restrict__ cp) {
+// (init: the memo entry's copy of the state's coefficients and its cleared status words, by the launch's first workgroup — as
+// runtime copy / fill operations they were two more dependent submissions of ≈ 5 µs each on every posterior's path)
+__device__ __forceinline__ void entry_init(const EntryInit& init) {
+  if (blockIdx.x != 0 || !init.coeffs_dst) return;
+  for (int i = threadIdx.x; i < init.r; i += blockDim.x) init.coeffs_dst[i] = init.coeffs_src[i];
+  if (threadIdx.x < 3) init.status[threadIdx.x] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock) k_correspond_model(CorrTask c, const double* __restrict__ cp, EntryInit init) {
+  entry_init(init);
   int k = blockIdx.x * kBlock + threadIdx.x;
   if (k < c.K) correspond_model_one(c, k, ld3(cp + 3 * k));
 }
 
-__global__ void __launch_bounds__(kBlock) k_correspond_target(CorrTask c, const int* __restrict__ nn_id) {
+__global__ void __launch_bounds__(kBlock) k_correspond_target(CorrTask c, const int* __restrict__ nn_id, EntryInit init) {
+  entry_init(init);
   int k = blockIdx.x * kBlock + threadIdx.x;
   if (k < c.K) correspond_target_one(c, k, nn_id[k]);
 }
@@ -555,8 +565,9 @@ struct TailArgs {
   int* status[8];
 };
 
-__global__ void __launch_bounds__(256) k_transition_tails(int r, TailArgs ta, const double* __restrict__ Ginv, double sigma2,
-                                                           int n_lds, int tpr_log2) {
+template <int NT>
+__global__ void __launch_bounds__(NT) k_transition_tails(int r, TailArgs ta, const double* __restrict__ Ginv, double sigma2,
+                                                          int n_lds, int tpr_log2) {
   const int t = blockIdx.x;
   tail_body(r, ta.alpha[t], ta.M[t], ta.c_from[t], ta.c_to[t], ta.step[t], ta.out[t], ta.status[t], Ginv, sigma2, n_lds, tpr_log2);
 }
@@ -1877,8 +1888,9 @@ __global__ void __launch_bounds__(64) k_eigen_big_finish(int r, const double* __
 // ---------------------------------------------------------------- a8 propose
 // c_new = (G + σ²I)⁻¹ G w = w − σ² P w with P = (G + σ²I)⁻¹ precomputed;  w = α + D⁻¹ V (√S ∘ z)
 
-__global__ void __launch_bounds__(256) k_propose(int r, ProposeIn in, double* __restrict__ c_out, int tpr_log2) {
-  propose_body(r, in, c_out, tpr_log2);
+template <int NT>
+__global__ void __launch_bounds__(NT) k_propose(int r, ProposeIn in, double* __restrict__ c_out, int tpr_log2) {
+  propose_body<true>(r, in, c_out, tpr_log2);
 }
 
 // ---------------------------------------------------------------- deterministic ICP helpers
@@ -2005,21 +2017,21 @@ __global__ void __launch_bounds__(1024) k_dist_max(int K, const double* __restri
 void launch_correspond_model(hipStream_t st, int K, const double* x, const double* cp, const int* nnv,
                              const unsigned char* tgt_boundary, int boundary_aware, const Pose& pose,
                              const double* ref, const double* mean, const int* tris, const int* adj_off,
-                             const int* adj, const CorrBuffers& cb) {
+                             const int* adj, const CorrBuffers& cb, const EntryInit& init) {
   if (K <= 0) return;
   CorrTask c{K, cb, x, nullptr, tgt_boundary, nnv, boundary_aware, pose, ref, mean, tris, adj_off, adj};
   ProfScope _ps(st, KID_CORRESPOND);
-  hipLaunchKernelGGL(k_correspond_model, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, c, cp);
+  hipLaunchKernelGGL(k_correspond_model, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, c, cp, init);
 }
 
 void launch_correspond_target(hipStream_t st, int K, const double* x, const double* tpts, const int* nn_id,
                               const unsigned char* model_boundary, int boundary_aware, const Pose& pose,
                               const double* ref, const double* mean, const int* tris, const int* adj_off,
-                              const int* adj, const CorrBuffers& cb) {
+                              const int* adj, const CorrBuffers& cb, const EntryInit& init) {
   if (K <= 0) return;
   CorrTask c{K, cb, x, tpts, model_boundary, nullptr, boundary_aware, pose, ref, mean, tris, adj_off, adj};
   ProfScope _ps(st, KID_CORRESPOND);
-  hipLaunchKernelGGL(k_correspond_target, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, c, nn_id);
+  hipLaunchKernelGGL(k_correspond_target, dim3(cdiv(K, kBlock)), dim3(kBlock), 0, st, c, nn_id, init);
 }
 
 int regression_splits(int K) {
@@ -2141,9 +2153,15 @@ void launch_transition_tails(hipStream_t st, int r, int n, const TransitionTailI
   const size_t one = (size_t)r * ld;
   const int n_lds = 2 * one <= (size_t)kLdsDoubles - 2560 ? 2 : (one <= (size_t)kLdsDoubles - 2560 ? 1 : 0);
   const size_t shmem = sizeof(double) * one * n_lds;
-  set_dyn_lds((const void*)k_transition_tails, shmem);
-  { ProfScope _ps(st, KID_TAIL);
-    hipLaunchKernelGGL(k_transition_tails, dim3(n), dim3(256), shmem, st, r, ta, Ginv, sigma2, n_lds, matvec_tpr_log2(r, 256)); }
+  ProfScope _ps(st, KID_TAIL);
+  if (n_lds == 0) {
+    // neither matrix fits LDS (ranks above 134): every product of the iteration streams 8·r² bytes from L2, 1024 threads keep four
+    // times the loads in flight (50 -> ≈ 20 µs at rank 200).  Below, 256 threads: the arithmetic of the merged step's own tails.
+    hipLaunchKernelGGL(k_transition_tails<1024>, dim3(n), dim3(1024), 0, st, r, ta, Ginv, sigma2, 0, 4);  // (16 lanes per row: 128-byte segments)
+  } else {
+    set_dyn_lds((const void*)k_transition_tails<256>, shmem);
+    hipLaunchKernelGGL(k_transition_tails<256>, dim3(n), dim3(256), shmem, st, r, ta, Ginv, sigma2, n_lds, matvec_tpr_log2(r, 256));
+  }
 }
 
 void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO& io, const double* G, double sigma2, double* work) {
@@ -2544,7 +2562,9 @@ void launch_propose(hipStream_t st, int r, const double* alpha, const double* V,
                     const double* z, double step, double* c_out, int root) {
   { ProfScope _ps(st, KID_PROPOSE);
     ProposeIn in{alpha, V, S, inv_sqrt_lambda, P, c, z, sigma2, step, root};
-    hipLaunchKernelGGL(k_propose, dim3(1), dim3(256), 0, st, r, in, c_out, matvec_tpr_log2(r, 256)); }
+    // (ranks <= 64: 256 threads, the arithmetic of the merged step's own copy of the proposal; above, only this kernel proposes)
+    if (root && r > 64) hipLaunchKernelGGL(k_propose<1024>, dim3(1), dim3(1024), 0, st, r, in, c_out, matvec_tpr_log2(r, 1024));
+    else hipLaunchKernelGGL(k_propose<256>, dim3(1), dim3(256), 0, st, r, in, c_out, matvec_tpr_log2(r, 256)); }
 }
 
 void launch_gather_points(hipStream_t st, int K, const double* x, const int* ids, double* P) {
