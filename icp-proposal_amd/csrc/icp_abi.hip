@@ -200,6 +200,7 @@ struct SharedModel {
   DBuf<int> tris, adj_off, adj, tri_order;
   DBuf<uint8_t> boundary;
   int n_boundary = 0;
+  int device = 0;
 };
 struct SharedTarget {
   DeviceMesh mesh;
@@ -218,14 +219,37 @@ struct SharedKey {
 std::mutex g_shared_mu;
 std::map<SharedKey, std::weak_ptr<SharedModel>> g_shared_models;
 std::map<SharedKey, std::weak_ptr<SharedTarget>> g_shared_targets;
+// The two most recently used models stay alive between contexts (icp_release_cached_models drops them): a batch registration
+// builds one context per target, one after the other, over the SAME model — whose derived data (Q in two layouts, the Gram
+// matrix QᵀQ on the host, two r × r inverses: 0.35 s at N = 28,561, rank 200) was rebuilt for every target once the previous
+// target's context, its last user, had been destroyed.
+// (on the heap and never destroyed: at process exit the runtime may be gone before this library's static objects are)
+std::shared_ptr<SharedModel>* const g_model_keep = new std::shared_ptr<SharedModel>[2];
+int g_model_keep_next = 0;
 
-uint64_t hash_words(uint64_t h, const void* data, size_t bytes) {  // word-wise multiply-xor (identity of the arrays, not security)
+// word-wise multiply-xor (identity of the arrays, not security); four independent lanes: one lane's dependent multiply chain
+// made 35 ms of every context creation at the face model's 137 MB of basis
+uint64_t hash_words(uint64_t h, const void* data, size_t bytes) {
   const unsigned char* p = (const unsigned char*)data;
+  constexpr uint64_t kMul = 0x9E3779B97F4A7C15ull;
+  uint64_t a = h, b = h ^ 0x243F6A8885A308D3ull, c = h ^ 0x13198A2E03707344ull, d = h ^ 0xA4093822299F31D0ull;
   size_t i = 0;
+  for (; i + 32 <= bytes; i += 32) {
+    uint64_t w[4];
+    std::memcpy(w, p + i, 32);
+    a = (a ^ w[0]) * kMul; a ^= a >> 29;
+    b = (b ^ w[1]) * kMul; b ^= b >> 29;
+    c = (c ^ w[2]) * kMul; c ^= c >> 29;
+    d = (d ^ w[3]) * kMul; d ^= d >> 29;
+  }
+  h = a;
+  h = (h ^ b) * kMul; h ^= h >> 29;
+  h = (h ^ c) * kMul; h ^= h >> 29;
+  h = (h ^ d) * kMul; h ^= h >> 29;
   for (; i + 8 <= bytes; i += 8) {
     uint64_t w;
     std::memcpy(&w, p + i, 8);
-    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    h = (h ^ w) * kMul;
     h ^= h >> 29;
   }
   for (; i < bytes; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
@@ -1319,6 +1343,7 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     std::shared_ptr<SharedModel> sm = g_shared_models[mkey].lock();
     if (!sm) {
       sm = std::make_shared<SharedModel>();
+      sm->device = device;
       // Q = Φ·diag(√λ) in two layouts, Gram matrix G = QᵀQ and chol(G + σ²I) (one-off host work)
       std::vector<double> Q((size_t)3 * N * r), Qp((size_t)3 * N * r), sl(r), isl(r);
       for (int j = 0; j < r; ++j) { sl[j] = std::sqrt(model->variance[j]); isl[j] = 1.0 / sl[j]; }
@@ -1371,6 +1396,10 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
       g_shared_models[mkey] = sm;
     }
     ctx->shared_model = sm;
+    if (g_model_keep[0] != sm && g_model_keep[1] != sm) {
+      g_model_keep[g_model_keep_next] = sm;
+      g_model_keep_next ^= 1;
+    }
     ctx->n_boundary = sm->n_boundary;
     ctx->ref.alias(sm->ref); ctx->mean.alias(sm->mean); ctx->Q.alias(sm->Q); ctx->Qp.alias(sm->Qp);
     ctx->sqrt_lambda.alias(sm->sqrt_lambda); ctx->inv_sqrt_lambda.alias(sm->inv_sqrt_lambda);
@@ -1438,6 +1467,14 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     icp_ctx_destroy(ctx);
   }
   return rc;
+}
+
+void icp_release_cached_models(void) {
+  std::lock_guard<std::mutex> lk(g_shared_mu);
+  for (int i = 0; i < 2; ++i) {
+    if (g_model_keep[i]) (void)hipSetDevice(g_model_keep[i]->device);
+    g_model_keep[i].reset();
+  }
 }
 
 void icp_ctx_destroy(icp_ctx* ctx) {

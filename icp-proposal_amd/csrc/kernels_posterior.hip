@@ -470,6 +470,8 @@ __global__ void __launch_bounds__(1024) k_posterior_factor_tiles(int r, FactorAr
     }
     return;
   }
+  // (the evaluator's searches fill the chip while this workgroup runs: 137-181 µs beside them, 113 alone — its waves issue first)
+  __builtin_amdgcn_s_setprio(3);
   FAC_STAMP(16);
   const int tr = factor_tile_rows(r), n_tiles = factor_tile_count(r);
   double v[TPT][2][4];
@@ -569,6 +571,7 @@ template <int NT>
 __global__ void __launch_bounds__(NT) k_transition_tails(int r, TailArgs ta, const double* __restrict__ Ginv, double sigma2,
                                                           int n_lds, int tpr_log2) {
   const int t = blockIdx.x;
+  if (NT == 1024) __builtin_amdgcn_s_setprio(3);  // (ranks above 134: beside the evaluator's searches, like the factorisation)
   tail_body(r, ta.alpha[t], ta.M[t], ta.c_from[t], ta.c_to[t], ta.step[t], ta.out[t], ta.status[t], Ginv, sigma2, n_lds, tpr_log2);
 }
 

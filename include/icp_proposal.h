@@ -368,6 +368,13 @@ typedef struct {
 } icp_runtime_stats;
 ICP_API int icp_ctx_runtime_stats(const icp_ctx *ctx, icp_runtime_stats *out);
 
+/* ---- model cache.  Contexts made from the same model arrays share its derived device data (the scaled basis in two layouts, the
+ * Gram matrix and its inverses: 0.35 s of host work and 2 x 137 MB of uploads at N = 28,561, rank 200).  The library keeps the two
+ * most recently used models alive after their last context is destroyed, so that a job which builds one context per target over one
+ * model (BASELINE.json configs[4]) pays for the model once; this call drops them (their device memory is freed as soon as no context
+ * uses them). */
+ICP_API void icp_release_cached_models(void);
+
 /* ---- idle hook (optional).  icp_chain_step spends most of a step waiting for the device.  A caller that has host
  * work which does not depend on the step's outcome — drawing the random numbers of the NEXT step, say — registers it
  * here: `fn(arg)` is called once per icp_chain_step, on the calling thread, after the step's launches have been issued
