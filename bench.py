@@ -261,6 +261,9 @@ def main():
                     help="host<->device call pattern per step: 0 per-method calls, 1 propose + icp_chain_eval_step, 2 one icp_chain_step")
     ap.add_argument("--root-sampler-leg", type=int, default=1,
                     help="default run (N = 1, config 1): extra leg with the opt-in Cholesky-root sampler, reported as `cholesky_root_sampler` (0 = skip)")
+    ap.add_argument("--sampler", type=str, default="eigen", choices=["eigen", "cholesky-root"],
+                    help="posterior.sample() of the timed chain: the reference's KL basis (default, the parity path) or the opt-in Cholesky-root "
+                         "sampler (NOT the reference's arithmetic: DESIGN.md §5.7; the line then carries \"sampler\": \"cholesky-root\")")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -296,6 +299,7 @@ def main():
     # ---- workload (identical on every rank; synthetic, built from the bundled femur data or procedurally)
     wl = build_workload(pkg, args.config, args.subdiv, args.fused, args)
     model, target, setup = wl["model"], wl["target"], wl["setup"]
+    setup.sampler = args.sampler
     r = model.rank
     B = max(1, args.chains_per_gpu)
     ctxs = [pkg.IcpContext(model, target, device=local_rank) for _ in range(B)]  # (a context holds one chain's scratch)
@@ -372,6 +376,7 @@ def main():
             "log_gather_ms": 1e3 * t_gather,
             "accepted": n_acc,
             "icp_proposals": n_icp,
+            "sampler": args.sampler,
         },
         "roofline": None,
         "cpu_baseline": None,
