@@ -96,6 +96,30 @@ def test_tridiagonal_route_configurations_match_oracle(pkg, oracle, rank):
     ctx.close()
 
 
+@pytest.mark.parametrize("rank", [120, 128, 230])
+def test_register_tiled_factorisation_ranks(pkg, oracle, rank):
+    """Ranks 117..250 are factored entirely in registers (k_posterior_factor_tiles: three 2 x 4 tiles per thread up to rank 221, four
+    above; finished columns to global scratch, staged back substitution).  The posterior mean and the transition density — both
+    straight out of that factorisation — against the oracle at the first rank past the LDS form, at a block boundary of the back
+    substitution and in the four-tile configuration (ranks 150, 193 and 200 are covered by the tests above and the full-face chains)."""
+    model = pkg.data.synthetic_face_model(grid=41, rank=rank)
+    target = pkg.data.synthetic_partial_target(model, n_remove=90)
+    ctx = pkg.IcpContext(model, target, device=0)
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    pp = oracle.proposal_params(0.1, 6.0, 3.0, oracle.MODEL_SAMPLING, True, n_model_ids=2 * rank)
+    prop = pkg.NonRigidIcpProposal(ctx, 0.1, 6.0, 3.0, 2 * rank, "ModelSampling", True)
+    for seed in (5, 6):
+        theta, theta2 = face_theta(model, seed), face_theta(model, seed)
+        theta2[10:] += 0.01 * np.random.default_rng(seed).normal(size=rank)
+        post, po = prop.icpPosterior(theta), oracle.icp_posterior(om, ot, pp, theta)
+        assert np.array_equal(post.corr_id, po.corr_id) and np.array_equal(post.keep, po.keep)
+        assert np.abs(post.alpha - po.alpha).max() <= 1e-9 * np.abs(po.alpha).max()
+        got, want = prop.logTransitionProbability(theta, theta2), oracle.log_transition(om, ot, pp, theta, theta2)
+        assert np.isfinite(want) and abs(got - want) <= 1e-6 * abs(want)
+    prop.close()
+    ctx.close()
+
+
 def test_multiple_eigenvalues_take_the_jacobi_fall_back(pkg, oracle):
     """Ranks above 64 are decomposed by tridiagonalisation + multisection + twisted factorisation, which needs eigenvalues it can
     tell apart.  The stand-in's variances come in equal pairs (modes (p, q) and (q, p)): without correspondences — and with a
