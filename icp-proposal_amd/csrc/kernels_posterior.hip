@@ -2566,7 +2566,10 @@ void launch_propose(hipStream_t st, int r, const double* alpha, const double* V,
   { ProfScope _ps(st, KID_PROPOSE);
     ProposeIn in{alpha, V, S, inv_sqrt_lambda, P, c, z, sigma2, step, root};
     // (ranks <= 64: 256 threads, the arithmetic of the merged step's own copy of the proposal; above, only this kernel proposes)
+    // (ranks above 134 — no matrix of the proposal fits LDS and no merged step exists —: 1,024 threads, 16 lanes per row of the two
+    // products with V and P, whose rows come from L2: 30 -> 14 µs at rank 200)
     if (root && r > 64) hipLaunchKernelGGL(k_propose<1024>, dim3(1), dim3(1024), 0, st, r, in, c_out, matvec_tpr_log2(r, 1024));
+    else if (r > 134) hipLaunchKernelGGL(k_propose<1024>, dim3(1), dim3(1024), 0, st, r, in, c_out, 4);
     else hipLaunchKernelGGL(k_propose<256>, dim3(1), dim3(256), 0, st, r, in, c_out, matvec_tpr_log2(r, 256)); }
 }
 
