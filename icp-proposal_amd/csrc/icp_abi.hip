@@ -274,6 +274,8 @@ struct StateSlot {
   uint64_t stamp = 0;
   Pose pose;
   DBuf<double> coeffs, x;
+  DBuf<double> defo;        // per point mean + Q·c (icp_ctx::state: a pose move re-poses these instead of reading the basis again)
+  bool defo_valid = false;
   DBuf<float4> spheres;
   bool spheres_valid = false;
   int n_surf = 0;  // model ids [0, n_surf) already projected onto the target surface
@@ -501,6 +503,7 @@ void icp_ctx::alloc_slot(StateSlot& s) {
   if (s.x.p) return;
   s.coeffs.alloc(r);
   s.x.alloc(3 * (size_t)N);
+  s.defo.alloc(3 * (size_t)N);
   s.spheres.alloc(sphere_floats4(T));
   s.surf_cp.alloc(3 * (size_t)N);
   s.surf_d2.alloc(N);
@@ -520,6 +523,7 @@ StateSlot& icp_ctx::fresh_state() {
   StateSlot& s = *lru;
   alloc_slot(s);
   s.valid = false;
+  s.defo_valid = false;
   s.spheres_valid = false;
   s.n_surf = 0;
   s.n_nnv = 0;
@@ -532,13 +536,21 @@ StateSlot& icp_ctx::state(const double* theta) {
     hit->stamp = ++clock;
     return *hit;
   }
+  // a pose move (PoseProposals.scala: 0.4 of the configs[3]/[4] mixture) leaves the coefficients alone: the points are the kept
+  // deformations of a state with the same coefficients under the new pose — 0.7 MB instead of the basis' 137 MB at N = 28,561, rank 200
+  StateSlot* same = nullptr;
+  for (auto& o : slots)
+    if (o.valid && o.defo_valid && std::memcmp(o.theta.data() + 10, theta + 10, sizeof(double) * r) == 0) { same = &o; break; }
+  if (same) same->stamp = ++clock;  // (not the one recycled below, unless every other slot is reserved: in place works, too)
   StateSlot& s = fresh_state();
   s.theta.assign(theta, theta + P);
   s.valid = true;
   s.stamp = ++clock;
   s.pose = pose_of(theta);
   stage_to(s.coeffs.p, theta + 10, r);
-  launch_instance(stream, N, r, Qp.p, ref.p, mean.p, s.pose, s.coeffs.p, s.x.p);  // ModelFittingParameters.scala:108-110
+  if (same) launch_instance_pose(stream, N, ref.p, s.pose, same->defo.p, s.x.p, s.defo.p);
+  else launch_instance_keep(stream, N, r, Qp.p, ref.p, mean.p, s.pose, s.coeffs.p, s.x.p, s.defo.p);  // ModelFittingParameters.scala:108-110
+  s.defo_valid = true;
   return s;
 }
 

@@ -55,6 +55,10 @@ struct ProfScope {  // RAII: events around one kernel launch
 // K1: x = s(R(x̄ + μ + Q c − ctr) + ctr + t).  Qp = scaled basis in planes [(j*3+d)*N + i]; coeffs on device.
 void launch_instance(hipStream_t st, int N, int r, const double* Qp, const double* ref, const double* mean,
                      const Pose& pose, const double* coeffs, double* x);
+// … keeping every point's deformation mean + Q·c, and a state that differs in its pose only from those (bit-identical points)
+void launch_instance_keep(hipStream_t st, int N, int r, const double* Qp, const double* ref, const double* mean,
+                          const Pose& pose, const double* coeffs, double* x, double* defo);
+void launch_instance_pose(hipStream_t st, int N, const double* ref, const Pose& pose, const double* defo_in, double* x, double* defo_out);
 
 // K2: all vertex normals (diagnostic entry point; the posterior kernels compute normals on demand)
 void launch_vertex_normals(hipStream_t st, int N, const double* x, const int* tris, const int* adj_off,

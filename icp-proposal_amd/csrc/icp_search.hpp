@@ -438,5 +438,25 @@ __device__ __forceinline__ void instance_vertex(int i, int N, int r, const doubl
   const d3 p = instance_point(i, N, r, Qp, ref, mean, pose, coeffs);
   x[3 * i] = p.x; x[3 * i + 1] = p.y; x[3 * i + 2] = p.z;
 }
+// the same, and the point's deformation mean + Q·c kept (`defo`): a state that differs from this one in its pose only is
+// instance_pose of the kept deformation — the same operations on the same values, without the 24·r bytes of basis per point
+__device__ __forceinline__ void instance_vertex_keep(int i, int N, int r, const double* __restrict__ Qp, const double* __restrict__ ref,
+                                                     const double* __restrict__ mean, const Pose& pose, const double* coeffs,
+                                                     double* __restrict__ x, double* __restrict__ defo) {
+  double a0 = mean[3 * i], a1 = mean[3 * i + 1], a2 = mean[3 * i + 2];
+  const double* q = Qp + i;
+  int j = 0;
+  instance_batch<25>(q, N, r, coeffs, j, a0, a1, a2);
+  instance_batch<10>(q, N, r, coeffs, j, a0, a1, a2);
+  for (; j < r; ++j) {
+    double c = coeffs[j];
+    a0 = a0 + q[(size_t)(3 * j) * N] * c;
+    a1 = a1 + q[(size_t)(3 * j + 1) * N] * c;
+    a2 = a2 + q[(size_t)(3 * j + 2) * N] * c;
+  }
+  defo[3 * i] = a0; defo[3 * i + 1] = a1; defo[3 * i + 2] = a2;
+  const d3 p = instance_pose(i, ref, pose, a0, a1, a2);
+  x[3 * i] = p.x; x[3 * i + 1] = p.y; x[3 * i + 2] = p.z;
+}
 
 }  // namespace icp

@@ -53,6 +53,23 @@ __global__ void __launch_bounds__(kBlock) k_instance(int N, int r, const double*
   if (i < N) instance_vertex(i, N, r, Qp, ref, mean, pose, coeffs, x);
 }
 
+__global__ void __launch_bounds__(kBlock) k_instance_keep(int N, int r, const double* __restrict__ Qp, const double* __restrict__ ref,
+                                                           const double* __restrict__ mean, Pose pose, const double* __restrict__ coeffs,
+                                                           double* __restrict__ x, double* __restrict__ defo) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < N) instance_vertex_keep(i, N, r, Qp, ref, mean, pose, coeffs, x, defo);
+}
+// a state with the coefficients of another one: its points from that state's kept deformations (defo_in may equal defo_out)
+__global__ void __launch_bounds__(kBlock) k_instance_pose(int N, const double* __restrict__ ref, Pose pose, const double* defo_in,
+                                                           double* __restrict__ x, double* defo_out) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const double a0 = defo_in[3 * i], a1 = defo_in[3 * i + 1], a2 = defo_in[3 * i + 2];
+  defo_out[3 * i] = a0; defo_out[3 * i + 1] = a1; defo_out[3 * i + 2] = a2;
+  const d3 p = instance_pose(i, ref, pose, a0, a1, a2);
+  x[3 * i] = p.x; x[3 * i + 1] = p.y; x[3 * i + 2] = p.z;
+}
+
 __global__ void __launch_bounds__(kBlock) k_vertex_normals(int N, const double* __restrict__ x, const int* __restrict__ tris,
                                                             const int* __restrict__ adj_off, const int* __restrict__ adj,
                                                             double* __restrict__ normals) {
@@ -152,6 +169,16 @@ void launch_instance(hipStream_t st, int N, int r, const double* Qp, const doubl
                      const Pose& pose, const double* coeffs, double* x) {
   ProfScope _ps(st, KID_INSTANCE);
   hipLaunchKernelGGL(k_instance, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, st, N, r, Qp, ref, mean, pose, coeffs, x);
+}
+
+void launch_instance_keep(hipStream_t st, int N, int r, const double* Qp, const double* ref, const double* mean,
+                          const Pose& pose, const double* coeffs, double* x, double* defo) {
+  ProfScope _ps(st, KID_INSTANCE);
+  hipLaunchKernelGGL(k_instance_keep, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, st, N, r, Qp, ref, mean, pose, coeffs, x, defo);
+}
+void launch_instance_pose(hipStream_t st, int N, const double* ref, const Pose& pose, const double* defo_in, double* x, double* defo_out) {
+  ProfScope _ps(st, KID_INSTANCE);
+  hipLaunchKernelGGL(k_instance_pose, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, st, N, ref, pose, defo_in, x, defo_out);
 }
 
 void launch_vertex_normals(hipStream_t st, int N, const double* x, const int* tris, const int* adj_off,

@@ -34,6 +34,27 @@ def test_transformed_mesh_bit_exact(ctx50, femur50, femur50_oracle):
         assert np.array_equal(ctx50.transformedMesh(theta), om.instance(theta))
 
 
+def test_pose_move_reposes_the_kept_deformations_bit_exact(ctx50, femur50, femur50_oracle):
+    """A state that differs from a cached one in its pose only is not instantiated from the basis again: the kept deformations
+    mean + Q·c of the cached state are posed anew (icp_ctx::state).  Same points as the oracle's instance, bit for bit — for pose
+    moves off a state, for chains of them (every slot recycled) and for a shape move in between."""
+    model, _ = femur50
+    om, _ = femur50_oracle
+    rng = np.random.default_rng(5)
+    theta = make_theta(model, 4)
+    assert np.array_equal(ctx50.transformedMesh(theta), om.instance(theta))
+    for k in range(12):
+        t = theta.copy()
+        t[0] = 1.0 + 0.01 * rng.normal() if k % 4 == 3 else t[0]
+        t[1:4] += rng.normal(size=3)
+        t[4:7] += 0.02 * rng.normal(size=3)
+        t[7:10] += rng.normal(size=3) if k % 5 == 4 else 0.0
+        if k == 6:
+            t[10:] += 0.05 * rng.normal(size=model.rank)   # a shape move: from the basis again
+        assert np.array_equal(ctx50.transformedMesh(t), om.instance(t)), k
+        theta = t
+
+
 def test_vertex_normals(ctx50, femur50, femur50_oracle):
     model, _ = femur50
     om, _ = femur50_oracle
