@@ -736,7 +736,10 @@ struct icp_proposal {
   void prepare_eigen(PosteriorEntry& e, EigenRequest* rq);
   void ensure_eigen(PosteriorEntry& e);  // enqueue on the context's eigen stream (no-op if done or in flight)
   // … or on `es` (eig_stream / eig_stream2) with that stream's work buffer; the caller has made `es` wait for the entry's M
-  void ensure_eigen_on(PosteriorEntry& e, hipStream_t es);
+  // part: as launch_posterior_eigen's — 1 issues the chain's head, 2 what follows it and the event behind everything
+  void ensure_eigen_on(PosteriorEntry& e, hipStream_t es, int part = 0);
+  EigenRequest pending_rq{};
+  PosteriorEntry* pending_entry = nullptr;
   DBuf<double> work2;  // eig_stream2's (ranks above 64)
   unsigned eig_flip = 0;
   void await_eigen(PosteriorEntry& e);   // make the context stream wait for it
@@ -1061,14 +1064,21 @@ void icp_proposal::ensure_eigen(PosteriorEntry& e) {
   e.eig_event_valid = true;
 }
 
-void icp_proposal::ensure_eigen_on(PosteriorEntry& e, hipStream_t es) {
-  if (e.eig_valid) return;
+void icp_proposal::ensure_eigen_on(PosteriorEntry& e, hipStream_t es, int part) {
   icp_ctx& c = *ctx;
-  EigenRequest rq;
-  prepare_eigen(e, &rq);
-  if (es == c.eig_stream2) rq.work = work2.p;  // (allocated and zeroed with the proposal: a memset issued here could land in the kernels)
-  e.done_value = 0;
-  launch_posterior_eigen(es, c.r, rq.M, c.sqrt_lambda.p, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.work, rq.status, nullptr, rq.host_status);
+  if (part != 2) {
+    if (e.eig_valid) return;
+    prepare_eigen(e, &pending_rq);
+    if (es == c.eig_stream2) pending_rq.work = work2.p;  // (allocated and zeroed with the proposal: a memset issued here could land in the kernels)
+    e.done_value = 0;
+    pending_entry = &e;
+  } else if (pending_entry != &e) {
+    return;  // (part 1 found the basis on record: nothing was started)
+  }
+  const EigenRequest& rq = pending_rq;
+  launch_posterior_eigen(es, c.r, rq.M, c.sqrt_lambda.p, rq.Vwarm, rq.V, rq.Vt, rq.S, rq.work, rq.status, nullptr, rq.host_status, part);
+  if (part == 1) return;
+  pending_entry = nullptr;
   HIP_OK(hipEventRecord(e.eig_done, es));
   e.eig_done_shared = nullptr;
   e.eig_shared_gen = nullptr;
@@ -2334,11 +2344,17 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
     // the decomposition of a posterior whose factorisation has just gone to the side stream: behind that — or, if the posterior was
     // computed just now, beside it: M = I + the summed partials is written by a launch at the head of the decomposition as well
     // (the same values the factorisation's assembly writes)
-    auto decompose_ahead = [&](icp_proposal* p, PosteriorEntry& en) {
+    hipStream_t es_ahead = nullptr;  // the stream part 1 of a decomposition went to (part 2 follows it there)
+    auto decompose_ahead = [&](icp_proposal* p, PosteriorEntry& en, int part = 0) {
+      if (part == 2) {
+        if (es_ahead) p->ensure_eigen_on(en, es_ahead, 2);
+        return;
+      }
       if (en.eig_valid) return;
       if (c.eig_last && c.eig_last != c.eig_stream) (void)eigen_stream_for(c, c.eig_stream);  // (a batch's stream was in use: drained)
       c.eig_last = c.eig_stream;
       const hipStream_t es = (c.eig_stream2 && (p->eig_flip++ & 1)) ? c.eig_stream2 : c.eig_stream;  // two under way at a time
+      es_ahead = es;
       HIP_OK(hipEventRecord(c.ev_ready, c.stream));  // (whatever of this entry is still in flight on the context stream)
       HIP_OK(hipStreamWaitEvent(es, c.ev_ready, 0));
       if (p->side_parts && p->side_parts_entry == &en) {
@@ -2349,11 +2365,13 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
       } else {
         HIP_OK(hipStreamWaitEvent(es, c.ev_side, 0));
       }
-      p->ensure_eigen_on(en, es);
+      p->ensure_eigen_on(en, es, part);
     };
+    PosteriorEntry* pose_entry = nullptr;
     if (spec_pose) {
       PosteriorEntry& en = props[0]->posterior(theta_prop, false, side);
-      decompose_ahead(props[0], en);
+      decompose_ahead(props[0], en, 1);  // (its other launches: behind the evaluator's, below)
+      pose_entry = &en;
     }
     if (shape_only && n_props > 0) {
       const double* d_cur = c.stage(theta_cur + 10, r);
@@ -2374,16 +2392,17 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         // (the staged coefficients and — for entries found in the memo — everything else the tails read: all behind ev_ready)
         HIP_OK(hipEventRecord(c.ev_ready, c.stream));
         HIP_OK(hipStreamWaitEvent(side, c.ev_ready, 0));
-        // Order of issue (the host needs 3-6 µs per launch): factorisation (inside posterior) -> decomposition -> the evaluator's ten
-        // launches -> the tails.  The tails run behind the factorisation whenever they are issued (0.1-0.3 ms of slack); the
-        // evaluator's searches, as long a chain as factorisation + tails at rank 200, used to start 70 µs after the regression had
-        // ended because they were issued last.
-        decompose_ahead(props[0], *ep[0]);
+        // Order of issue (the host needs 3-6 µs per launch): factorisation (inside posterior) -> the HEAD of the decomposition (the
+        // reduction to tridiagonal form, 0.48 ms on one workgroup) -> the evaluator's ten launches -> the decomposition's other ten
+        // launches (they run behind the reduction whenever they are issued) -> the tails (behind the factorisation: 0.1-0.3 ms of
+        // slack).  The evaluator's searches used to start 70-120 µs after the regression had ended because they were issued last.
+        decompose_ahead(props[0], *ep[0], 1);
         if (need_eval) {
           StateSlot& s = c.state(theta_prop);
           enqueue_eval(e, s, 0);
           eval_enqueued = true;
         }
+        decompose_ahead(props[0], *ep[0], 2);
       }
       for (int t0 = 0; t0 < n_tails; t0 += 8)
         launch_transition_tails(side ? side : c.stream, r, std::min(8, n_tails - t0), tails + t0, c.Ginv.p, kSigma2);
@@ -2396,6 +2415,7 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
       StateSlot& s = c.state(theta_prop);
       enqueue_eval(e, s, 0);
     }
+    if (pose_entry) decompose_ahead(props[0], *pose_entry, 2);
     if (side && shape_only && n_props > 0) {
       HIP_OK(hipStreamWaitEvent(c.stream, c.ev_side, 0));
       sync_proposal_status(props[0]);

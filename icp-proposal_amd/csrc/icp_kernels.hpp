@@ -257,7 +257,10 @@ void library_release_stream(hipStream_t st);  // drops the library handle kept f
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
                             double* Vt, double* S, double* work /* eigen_work_doubles(r) */, int* status,
                             const EigenSpec* spec = nullptr, int* host_status = nullptr /* pinned copy of *status; honoured
-                            when eigen_speculation_supported(r) */);
+                            when eigen_speculation_supported(r) */,
+                            int part = 0 /* 0: every launch; 1: the reduction to tridiagonal form only (ranks 65..200: the long
+                            one-workgroup launch at the head of the chain), 2: the launches behind it — a caller with other work
+                            to issue puts it between the two (a launch costs the host 3-6 µs, the chain has eleven) */);
 
 // a8: c' = c + step·((G+σ²I)^-1 G (α + D^-1 V √S z) − c), with P = (G+σ²I)^-1
 void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,

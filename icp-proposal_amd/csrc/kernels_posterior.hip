@@ -2200,7 +2200,7 @@ static bool tridiag_route(int r) {
 static void launch_eigen_big(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V, double* Vt,
                              double* S, double* work, int* status, int* host_status, const int* gate);
 static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const double* sqrt_lambda, double* V, double* Vt, double* S, double* work,
-                                 int* status, int* host_status, int* done_word, int done_value) {
+                                 int* status, int* host_status, int* done_word, int done_value, int part = 0) {
   double* base = work + jacobi_work_doubles(r);
   double *d = base, *e = base + tri::kTriMaxN, *beta = base + 2 * tri::kTriMaxN, *mu = base + 3 * tri::kTriMaxN;
   int* sync = (int*)(base + 4 * tri::kTriMaxN);
@@ -2211,19 +2211,17 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   tri::TridiagIO ti{r, M, sqrt_lambda, d, e, beta, Hv, Nm};
   tri::TriSolveIO so{r, d, e, beta, Hv, X, Xt, S, mu, sync, status, nullptr, nullptr, 0};
   const int nwg = (r + 3) / 4;
-  if (r <= 64) {
-    hipLaunchKernelGGL((tri::k_tridiag<4, 1, 16, 0>), dim3(1), dim3(256), 0, st, ti);
-    hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), 0, st, so, so);
-  } else if (r <= 128) {
-    hipLaunchKernelGGL((tri::k_tridiag<4, 2, 32, 0>), dim3(1), dim3(256), 0, st, ti);
-    hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), 0, st, so, so);
-  } else if (r <= 192) {
-    hipLaunchKernelGGL((tri::k_tridiag<8, 3, 24, 0>), dim3(1), dim3(512), 0, st, ti);
-    hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg), dim3(256), 0, st, so, so);
-  } else {
-    hipLaunchKernelGGL((tri::k_tridiag<8, 4, 25, 7>), dim3(1), dim3(512), 0, st, ti);
-    hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), 0, st, so, so);
+  if (part != 2) {  // the reduction
+    if (r <= 64) hipLaunchKernelGGL((tri::k_tridiag<4, 1, 16, 0>), dim3(1), dim3(256), 0, st, ti);
+    else if (r <= 128) hipLaunchKernelGGL((tri::k_tridiag<4, 2, 32, 0>), dim3(1), dim3(256), 0, st, ti);
+    else if (r <= 192) hipLaunchKernelGGL((tri::k_tridiag<8, 3, 24, 0>), dim3(1), dim3(512), 0, st, ti);
+    else hipLaunchKernelGGL((tri::k_tridiag<8, 4, 25, 7>), dim3(1), dim3(512), 0, st, ti);
   }
+  if (part == 1) return;
+  if (r <= 64) hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), 0, st, so, so);
+  else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), 0, st, so, so);
+  else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg), dim3(256), 0, st, so, so);
+  else hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), 0, st, so, so);
   // one refinement step: T = N·X and R = I − XᵀX, S = XᵀT, E, then V = X + X·E (and Vt)
   const int nt = (r + 15) / 16;
   const tri::TriGemm gT{Nm, X, T, 0, nullptr, nullptr}, gR{X, X, R, 1, nullptr, nullptr}, gS{X, T, Sm, 0, nullptr, nullptr};
@@ -2532,8 +2530,14 @@ int launch_posterior_eigen_many(hipStream_t st, int r, int n, const EigenRequest
 }
 
 void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double* sqrt_lambda, const double* Vwarm, double* V,
-                            double* Vt, double* S, double* work, int* status, const EigenSpec* spec, int* host_status) {
-  if (!(tridiag_route(r) && spec == nullptr)) {
+                            double* Vt, double* S, double* work, int* status, const EigenSpec* spec, int* host_status, int part) {
+  if (tridiag_route(r) && spec == nullptr) {
+    ProfScope _ps(st, KID_EIGEN);
+    launch_eigen_tridiag(st, r, M, sqrt_lambda, V, Vt, S, work, status, host_status, nullptr, 0, part);
+    return;
+  }
+  if (part == 2) return;  // (the other routes are not split: part 1 has issued all of them)
+  {
     const EigenRequest rq{M, Vwarm, V, Vt, S, work, status, spec, host_status, nullptr, 0};
     if (launch_posterior_eigen_pair(st, r, sqrt_lambda, 1, &rq)) return;
   }
