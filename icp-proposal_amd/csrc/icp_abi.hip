@@ -343,7 +343,7 @@ struct icp_ctx {
   size_t stage_cap = 0, stage_used = 0;
   // results of one API call: [64 status ints | res_cap doubles] in ONE device block and one pinned block of the same layout, so
   // that a call's statuses and results come back in a single copy (finish)
-  static constexpr size_t kStatusDoubles = 32;
+  static constexpr size_t kStatusDoubles = 48;  // 96 status ints: [0,16) the tails' own, [16,64) their posteriors' (relayed), [64] the direct tail's
   double* h_out = nullptr;    // pinned
   DBuf<double> d_out;
   double* h_res = nullptr;    // = h_out + kStatusDoubles
@@ -1471,7 +1471,7 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->d_out.alloc(icp_ctx::kStatusDoubles + res_cap);
     ctx->h_status = (int*)ctx->h_out;
     ctx->h_res = ctx->h_out + icp_ctx::kStatusDoubles;
-    ctx->d_status.p = (int*)ctx->d_out.p; ctx->d_status.n = 64; ctx->d_status.owned = false;
+    ctx->d_status.p = (int*)ctx->d_out.p; ctx->d_status.n = 2 * icp_ctx::kStatusDoubles; ctx->d_status.owned = false;
     ctx->d_res.p = ctx->d_out.p + icp_ctx::kStatusDoubles; ctx->d_res.n = res_cap; ctx->d_res.owned = false;
     HIP_OK(hipHostMalloc((void**)&ctx->h_flag, sizeof(int) * 16, hipHostMallocDefault));
     ctx->h_flag[0] = 0;
@@ -1955,12 +1955,13 @@ int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, 
     std::lock_guard<std::recursive_mutex> lk(c.mu);
     Bound _b(&c);
     const int r = c.r;
+    const double* dz = c.stage(z, r);                 // :55 the caller's standard normals (on their way before the wait for the basis)
     PosteriorEntry& e = p->posterior(theta, false);  // NonRigidIcpProposal.scala:54
     p->ensure_eigen(e);
     p->await_eigen(e);
-    const double* dz = c.stage(z, r);                 // :55 the caller's standard normals
+    // (the entry's status words travel with the proposal: one result copy, not two)
     launch_propose(c.stream, r, e.alpha.p, e.V.p, e.S.p, c.inv_sqrt_lambda.p, c.P.p, kSigma2, e.coeffs.p, dz,
-                   p->prm.step_length, c.d_res.p, p->sampler == ICP_SAMPLER_CHOLESKY_ROOT);
+                   p->prm.step_length, c.d_res.p, p->sampler == ICP_SAMPLER_CHOLESKY_ROOT, p->status.p + e.status_off, c.d_status.p);
     std::vector<int> ids;
     std::vector<uint8_t> keep;
     if (corr_id_out && p->K > 0) {
@@ -1969,8 +1970,8 @@ int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, 
       HIP_OK(hipMemcpyAsync(ids.data(), e.id.p, sizeof(int) * p->K, hipMemcpyDeviceToHost, c.stream));
       HIP_OK(hipMemcpyAsync(keep.data(), e.keep.p, p->K, hipMemcpyDeviceToHost, c.stream));
     }
-    sync_proposal_status(p);
-    c.finish(r, 0);
+    c.finish(r, 3);
+    for (int k = 0; k < 3; ++k) p->h_status.data()[e.status_off + k] = c.h_status[k];
     p->check_status(e);
     static const bool dbg = dev_env("ICP_DEBUG_EIGEN") != nullptr;
     if (dbg) std::fprintf(stderr, "eigen sweeps %d\n", p->h_status[e.status_off + 1]);
@@ -2380,13 +2381,13 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         icp_proposal* p = props[i];
         ec[i] = &p->posterior(theta_cur, false, side);
         ep[i] = &p->posterior(theta_prop, false, side);
+        // (each tail passes its posterior's status words on to d_status[16 + 3·tail …]: they come back with the step's results)
         tails[n_tails] = TransitionTailIO{ec[i]->alpha.p, ec[i]->M.p, d_cur, d_prop, p->prm.step_length, c.d_res.p + 8 + n_tails,
-                                          c.d_status.p + n_tails};
+                                          c.d_status.p + n_tails, p->status.p + ec[i]->status_off, c.d_status.p + 16 + 3 * n_tails};
         ++n_tails;
         tails[n_tails] = TransitionTailIO{ep[i]->alpha.p, ep[i]->M.p, d_prop, d_cur, p->prm.step_length, c.d_res.p + 8 + n_tails,
-                                          c.d_status.p + n_tails};
+                                          c.d_status.p + n_tails, p->status.p + ep[i]->status_off, c.d_status.p + 16 + 3 * n_tails};
         ++n_tails;
-        if (!side) sync_proposal_status(p);
       }
       if (side) {
         // (the staged coefficients and — for entries found in the memo — everything else the tails read: all behind ev_ready)
@@ -2416,10 +2417,7 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
       enqueue_eval(e, s, 0);
     }
     if (pose_entry) decompose_ahead(props[0], *pose_entry, 2);
-    if (side && shape_only && n_props > 0) {
-      HIP_OK(hipStreamWaitEvent(c.stream, c.ev_side, 0));
-      sync_proposal_status(props[0]);
-    }
+    if (side && shape_only && n_props > 0) HIP_OK(hipStreamWaitEvent(c.stream, c.ev_side, 0));
     e->last_prop.assign(theta_prop, theta_prop + 10 + r);
     c.finish(8 + (size_t)n_tails, (size_t)n_tails);
     for (int t = 0; t < n_tails; ++t)
@@ -2430,11 +2428,12 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         io.c_from = c.stage((t % 2 == 0 ? theta_cur : theta_prop) + 10, r);
         io.c_to = c.stage((t % 2 == 0 ? theta_prop : theta_cur) + 10, r);
         io.out = c.d_res.p;
-        io.status = c.d_status.p + 32;
+        io.status = c.d_status.p + 64;
+        io.relay_in = nullptr; io.relay_out = nullptr;
         sync_eigen(c);  // (the direct form borrows the eigen work buffer)
         launch_transition_tail_direct(c.stream, r, io, c.G.p, kSigma2, p->work.p);
-        c.finish(1, 64);
-        if (c.h_status[32] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
+        c.finish(1, 96);
+        if (c.h_status[64] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
         saved[8 + t] = c.h_res[0];
         std::memcpy(c.h_res, saved.data(), sizeof(double) * saved.size());
       }
@@ -2446,6 +2445,10 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
     status = m->status;
     for (int i = 0; i < n_props; ++i) {
       if (!shape_only) { fwd[i] = -INFINITY; bwd[i] = -INFINITY; continue; }
+      for (int k = 0; k < 3; ++k) {
+        props[i]->h_status.data()[ec[i]->status_off + k] = c.h_status[16 + 3 * (2 * i) + k];
+        props[i]->h_status.data()[ep[i]->status_off + k] = c.h_status[16 + 3 * (2 * i + 1) + k];
+      }
       props[i]->check_status(*ec[i]);
       props[i]->check_status(*ep[i]);
       fwd[i] = c.h_res[8 + 2 * i];

@@ -205,7 +205,12 @@ void launch_assemble_posterior_matrix(hipStream_t st, int r, const double* Mpart
 
 // a9 tails, up to 8 per launch: out = −½ γ^T M γ − (r/2) ln 2π with (G + σ²M) γ = G (c_from + (c_to − c_from)/step − α).
 // Iterative (needs Ginv = G^-1); status[0] != 0 = did not contract -> use the direct kernel.
-struct TransitionTailIO { const double* alpha; const double* M; const double* c_from; const double* c_to; double step; double* out; int* status; };
+struct TransitionTailIO {
+  const double* alpha; const double* M; const double* c_from; const double* c_to; double step; double* out; int* status;
+  // (optional) the three status words of the posterior this tail belongs to, passed on to `relay_out` — next to the step's other
+  // results, so that they reach the host in the step's ONE result copy instead of a copy of their own
+  const int* relay_in = nullptr; int* relay_out = nullptr;
+};
 void launch_transition_tails(hipStream_t st, int r, int n, const TransitionTailIO* io, const double* Ginv, double sigma2);
 void launch_transition_tail_direct(hipStream_t st, int r, const TransitionTailIO& io, const double* G, double sigma2, double* work /* r*r */);
 
@@ -265,7 +270,8 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
 // a8: c' = c + step·((G+σ²I)^-1 G (α + D^-1 V √S z) − c), with P = (G+σ²I)^-1
 void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,
                     const double* inv_sqrt_lambda, const double* P, double sigma2, const double* c,
-                    const double* z, double step, double* c_out, int root = 0);
+                    const double* z, double step, double* c_out, int root = 0,
+                    const int* relay_in = nullptr /* three status words passed on to … */, int* relay_out = nullptr);
 
 // ---- deterministic ICP (api/other/IcpBasedSurfaceFitting.scala:46-126)
 // P[k] = x[ids[k]] (:72)

@@ -558,6 +558,8 @@ __global__ void __launch_bounds__(1024) k_posterior_factor_tiles(int r, FactorAr
 
 struct TailArgs {
   int n;
+  const int* relay_in[8];
+  int* relay_out[8];
   const double* alpha[8];
   const double* M[8];
   const double* c_from[8];
@@ -571,6 +573,7 @@ template <int NT>
 __global__ void __launch_bounds__(NT) k_transition_tails(int r, TailArgs ta, const double* __restrict__ Ginv, double sigma2,
                                                           int n_lds, int tpr_log2) {
   const int t = blockIdx.x;
+  if (ta.relay_in[t] && threadIdx.x < 3) ta.relay_out[t][threadIdx.x] = ta.relay_in[t][threadIdx.x];
   if (NT == 1024) __builtin_amdgcn_s_setprio(3);  // (ranks above 134: beside the evaluator's searches, like the factorisation)
   tail_body(r, ta.alpha[t], ta.M[t], ta.c_from[t], ta.c_to[t], ta.step[t], ta.out[t], ta.status[t], Ginv, sigma2, n_lds, tpr_log2);
 }
@@ -1892,7 +1895,9 @@ __global__ void __launch_bounds__(64) k_eigen_big_finish(int r, const double* __
 // c_new = (G + σ²I)⁻¹ G w = w − σ² P w with P = (G + σ²I)⁻¹ precomputed;  w = α + D⁻¹ V (√S ∘ z)
 
 template <int NT>
-__global__ void __launch_bounds__(NT) k_propose(int r, ProposeIn in, double* __restrict__ c_out, int tpr_log2) {
+__global__ void __launch_bounds__(NT) k_propose(int r, ProposeIn in, double* __restrict__ c_out, int tpr_log2, const int* relay_in,
+                                                int* relay_out) {
+  if (relay_in && threadIdx.x < 3) relay_out[threadIdx.x] = relay_in[threadIdx.x];
   propose_body<true>(r, in, c_out, tpr_log2);
 }
 
@@ -2151,6 +2156,7 @@ void launch_transition_tails(hipStream_t st, int r, int n, const TransitionTailI
   for (int t = 0; t < n; ++t) {
     ta.alpha[t] = io[t].alpha; ta.M[t] = io[t].M; ta.c_from[t] = io[t].c_from; ta.c_to[t] = io[t].c_to;
     ta.step[t] = io[t].step; ta.out[t] = io[t].out; ta.status[t] = io[t].status;
+    ta.relay_in[t] = io[t].relay_in; ta.relay_out[t] = io[t].relay_out;
   }
   const int ld = r | 1;
   const size_t one = (size_t)r * ld;
@@ -2566,15 +2572,15 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
 
 void launch_propose(hipStream_t st, int r, const double* alpha, const double* V, const double* S,
                     const double* inv_sqrt_lambda, const double* P, double sigma2, const double* c,
-                    const double* z, double step, double* c_out, int root) {
+                    const double* z, double step, double* c_out, int root, const int* relay_in, int* relay_out) {
   { ProfScope _ps(st, KID_PROPOSE);
     ProposeIn in{alpha, V, S, inv_sqrt_lambda, P, c, z, sigma2, step, root};
     // (ranks <= 64: 256 threads, the arithmetic of the merged step's own copy of the proposal; above, only this kernel proposes)
     // (ranks above 134 — no matrix of the proposal fits LDS and no merged step exists —: 1,024 threads, 16 lanes per row of the two
     // products with V and P, whose rows come from L2: 30 -> 14 µs at rank 200)
-    if (root && r > 64) hipLaunchKernelGGL(k_propose<1024>, dim3(1), dim3(1024), 0, st, r, in, c_out, matvec_tpr_log2(r, 1024));
-    else if (r > 134) hipLaunchKernelGGL(k_propose<1024>, dim3(1), dim3(1024), 0, st, r, in, c_out, 4);
-    else hipLaunchKernelGGL(k_propose<256>, dim3(1), dim3(256), 0, st, r, in, c_out, matvec_tpr_log2(r, 256)); }
+    if (root && r > 64) hipLaunchKernelGGL(k_propose<1024>, dim3(1), dim3(1024), 0, st, r, in, c_out, matvec_tpr_log2(r, 1024), relay_in, relay_out);
+    else if (r > 134) hipLaunchKernelGGL(k_propose<1024>, dim3(1), dim3(1024), 0, st, r, in, c_out, 4, relay_in, relay_out);
+    else hipLaunchKernelGGL(k_propose<256>, dim3(1), dim3(256), 0, st, r, in, c_out, matvec_tpr_log2(r, 256), relay_in, relay_out); }
 }
 
 void launch_gather_points(hipStream_t st, int K, const double* x, const int* ids, double* P) {
