@@ -2375,8 +2375,12 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
       pose_entry = &en;
     }
     if (shape_only && n_props > 0) {
-      const double* d_cur = c.stage(theta_cur + 10, r);
-      const double* d_prop = c.stage(theta_prop + 10, r);
+      // the two coefficient vectors the tails read: the states' own copies on the device (the current state's slot is kept from
+      // being recycled for the proposed one), staged from the host only for a current state that has no slot any more
+      StateSlot* sc = c.find_state(theta_cur);
+      if (sc) sc->stamp = ++c.clock;
+      const double* d_cur = sc ? sc->coeffs.p : c.stage(theta_cur + 10, r);
+      const double* d_prop = c.state(theta_prop).coeffs.p;
       for (int i = 0; i < n_props; ++i) {
         icp_proposal* p = props[i];
         ec[i] = &p->posterior(theta_cur, false, side);
