@@ -170,6 +170,57 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
     }
     const bool owner = w == (cnext & (NW - 1));
     const int tc = cnext / NW - TOFF;
+    // Eight waves (ranks above 128): the entries of v, w, x' at the wave's columns are LDS broadcast reads, requested ONE GROUP AHEAD of
+    // the multiply-adds that use them (two buffers by group parity) — with two waves per SIMD nobody else covers their latency.  Read
+    // where they are used (ranks up to 192, round 2) the reduction took 304 µs at rank 150, as v_readlane pairs into SGPRs — which they
+    // overflow: the four-slot configuration's form until round 3 — 300 and 477-489 µs at rank 200; one group ahead: 234 µs at rank 150.
+    // The four-slot configuration (ranks 193..200) has no registers for two groups' values while three or four row slots are alive: it
+    // takes this path once two are finished (rank 200: 411 µs; from one finished slot on 451, always 554, only with one live slot 426)
+    // and v_readlane before.  (Measured WITHOUT the cycle counters of ICP_TRI_CYCLES: their waits for the LDS queue penalise this.)
+#ifndef ICP_TRI_LDS_LIVE4
+#define ICP_TRI_LDS_LIVE4 2
+#endif
+    constexpr int kLdsLive = SI <= 3 ? SI : ICP_TRI_LDS_LIVE4;  // (developer sweep: -DICP_TRI_LDS_LIVE4=1..4)
+    if constexpr (LEAD && VLDS && SI - S0 <= kLdsLive) {
+      double vj[2][CH], wj[2][CH], xj[2][CH];
+      bool prev_live = false;
+#pragma unroll
+      for (int c0 = 0; c0 < NT; c0 += CH) {
+        const int b = (c0 / CH) & 1;
+        const bool live = NW * (c0 + CH + TOFF) > kdone + 1;  // (uniform; once a group is live every later one is)
+        if (live) {
+          if (!prev_live) {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+              const int j = w + NW * ((c0 + q < NT ? c0 + q : NT - 1) + TOFF);
+              xj[b][q] = vb[xpar * LD + j];
+              if constexpr (UPD) { vj[b][q] = vb[vpar * LD + j]; wj[b][q] = wb[j]; }
+            }
+          }
+          if (c0 + CH < NT) {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+              const int j = w + NW * ((c0 + CH + q < NT ? c0 + CH + q : NT - 1) + TOFF);
+              xj[b ^ 1][q] = vb[xpar * LD + j];
+              if constexpr (UPD) { vj[b ^ 1][q] = vb[vpar * LD + j]; wj[b ^ 1][q] = wb[j]; }
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < CH; ++q) {
+            const int t = c0 + q;
+            if (t < NT) {
+              if constexpr (UPD) {
+#pragma unroll
+                for (int s = S0; s < SI; ++s) A[s][t] = fma(-vs[s], wj[b][q], fma(-ws[s], vj[b][q], A[s][t]));
+              }
+#pragma unroll
+              for (int s = S0; s < SI; ++s) acc[s] = fma(A[s][t], xj[b][q], acc[s]);
+            }
+          }
+        }
+        prev_live = live;
+      }
+    } else
 #pragma unroll
     for (int c0 = 0; c0 < NT; c0 += CH) {
       if (SI == 1 || NW * (c0 + CH + TOFF) > kdone + 1) {
