@@ -155,7 +155,7 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
                   const double (&xr)[SI]) {
     constexpr int S0 = decltype(s0tag)::value;
     constexpr bool UPD = decltype(updtag)::value != 0;
-    constexpr int CH = 4;
+    constexpr int CH = LEAD ? 2 : 4;  // columns per group (eight waves: two — 413 -> 403 µs at rank 200, 227 -> 218 at 150; one or three: slower)
     double acc[SI], vs[SI], ws[SI], xl[SI];
 #pragma unroll
     for (int s = 0; s < SI; ++s) {
