@@ -2263,7 +2263,9 @@ static void launch_eigen_big(hipStream_t st, int r, const double* M, const doubl
   double* rotlog = mu + n2;
   int* meta = (int*)(rotlog + (size_t)kEigenMaxSweeps * (n2 - 1) * n2);
   const int eb = (int)((rr + 255) / 256);
-  hipLaunchKernelGGL(k_eigen_big_prepare, dim3(eb), dim3(256), 0, st, r, M, sqrt_lambda, A0, gate);
+  // (as the tridiagonal route's fall-back — `gate` — the matrix is in place already: k_tridiag has written N = D⁻¹MD⁻¹, entry by
+  // entry the values of the launch below, to the head of `work` for its refinement step, which only reads it)
+  if (!gate) hipLaunchKernelGGL(k_eigen_big_prepare, dim3(eb), dim3(256), 0, st, r, M, sqrt_lambda, A0, gate);
   if (Vwarm) {  // A0 <- Vwarmᵀ·A0·Vwarm
     hipLaunchKernelGGL(k_eigen_big_warm, dim3(eb), dim3(256), 0, st, r, (const double*)A0, Vwarm, T, 0);
     hipLaunchKernelGGL(k_eigen_big_warm, dim3(eb), dim3(256), 0, st, r, (const double*)T, Vwarm, A0, 1);
