@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1)
     if (round + 1 < kTriRounds) wave_lds_sync();
   }
   TRI_STAMP(11);
-  // ---- back-transformation: z ← H_0 H_1 ··· H_{n−3} z, one row slot per lane, reflectors fetched four ahead
+  // ---- back-transformation: z ← H_0 H_1 ··· H_{n−3} z, one row slot per lane, reflectors fetched eight ahead
   double zs[SI];
   {
     const double sc = 1.0 / sqrt(znorm2);
@@ -833,7 +833,7 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1)
     for (int s = 0; s < SI; ++s) zs[s] = l + 64 * s >= off ? zb[l + 64 * s - off] * sc : 0.0;
   }
   {
-    constexpr int PF = 4;
+    constexpr int PF = 8;  // (reflectors in flight from L2: 2 -> 46 µs of back-transformation at rank 200, 4 -> 42, 8 and 16 -> 37)
     double vq[PF][SI];
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
