@@ -120,6 +120,47 @@ def test_register_tiled_factorisation_ranks(pkg, oracle, rank):
     ctx.close()
 
 
+def test_failed_factorisation_is_reported_through_the_relayed_status(pkg):
+    """A state whose coefficients overflow the instance makes the posterior's normal equations non-finite; the factorisation says so in
+    the posterior's status words, which the proposal kernel and the transition tails pass on to the call's result block (no status copy
+    of their own): icp_proposal_propose and icp_chain_eval_step must both come back with an error, and the objects stay usable."""
+    model = pkg.data.synthetic_face_model(grid=41, rank=150)
+    target = pkg.data.synthetic_partial_target(model, n_remove=90)
+    ctx = pkg.IcpContext(model, target, device=0)
+    prop = pkg.NonRigidIcpProposal(ctx, 0.1, 6.0, 3.0, 300, "ModelSampling", True)
+    ev = pkg.HausdorffDistanceEvaluator(ctx, 1.0)
+    good = face_theta(model, 3)
+    bad = good.copy()
+    bad[10:] = 1e200
+    z = np.random.default_rng(0).normal(size=model.rank)
+    with pytest.raises(pkg._native.IcpNativeError):
+        prop.propose(bad, z)
+    with pytest.raises(pkg._native.IcpNativeError):
+        pkg.api.chain_eval_step(ev, [prop], good, bad)
+    out = prop.propose(good, z)                       # … and the next good call is served
+    val, fwd, bwd = pkg.api.chain_eval_step(ev, [prop], good, out)
+    assert np.all(np.isfinite(out)) and np.isfinite(val) and np.isfinite(fwd[0]) and np.isfinite(bwd[0])
+    prop.close(); ev.close(); ctx.close()
+
+
+def test_model_cache_serves_contexts_made_one_after_the_other(pkg, oracle):
+    """The derived data of a model stays alive between contexts built one after the other (configs[4]: one context per target), and
+    icp_release_cached_models drops it: results before, between and after are the same."""
+    model = pkg.data.synthetic_face_model(grid=41, rank=40)
+    theta = face_theta(model, 9)
+    vals = []
+    for rnd in range(3):
+        target = pkg.data.synthetic_partial_target(model, seed=7, n_remove=90)
+        ctx = pkg.IcpContext(model, target, device=0)
+        hd = pkg.HausdorffDistanceEvaluator(ctx, 1.0)
+        vals.append((hd.logValue(theta), ctx.transformedMesh(theta).copy()))
+        hd.close(); ctx.close()
+        if rnd == 1:
+            pkg._native.lib().icp_release_cached_models()
+    assert vals[0][0] == vals[1][0] == vals[2][0]
+    assert np.array_equal(vals[0][1], vals[1][1]) and np.array_equal(vals[0][1], vals[2][1])
+
+
 def test_multiple_eigenvalues_take_the_jacobi_fall_back(pkg, oracle):
     """Ranks above 64 are decomposed by tridiagonalisation + multisection + twisted factorisation, which needs eigenvalues it can
     tell apart.  The stand-in's variances come in equal pairs (modes (p, q) and (q, p)): without correspondences — and with a
