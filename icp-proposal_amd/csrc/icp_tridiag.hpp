@@ -626,8 +626,12 @@ struct TriSolveIO {
   int done_value;
 };
 
-constexpr int kTriPasses = 5;       // multisection passes of 64 points: the bracket shrinks 65× per pass
-constexpr int kTriRounds = 2;       // twisted factorisations (each followed by a Rayleigh-quotient correction)
+// Seven multisection passes and ONE twisted factorisation (round 2: five and two): a factorisation is two chains of n − 1 dependent
+// divisions, ≈ 12 µs at rank 200, a pass 4.4 µs; with the bracket 65² times narrower the first factorisation's vector is as good as
+// the second one's was (posteriors with relative gaps down to 1e-6: orthogonality 2e-13..2e-12, |ΔV| against the oracle ≤ 3.5e-12 either
+// way, `tools/r3_eigen_margins.py`) and the refinement step squares what is left.  −32 µs per decomposition at rank 200.
+constexpr int kTriPasses = 7;       // multisection passes of 64 points: the bracket shrinks 65× per pass
+constexpr int kTriRounds = 1;       // twisted factorisations (each followed by a Rayleigh-quotient correction)
 constexpr int kTriMaxN = 256;
 
 // number of eigenvalues of the (scaled) tridiagonal matrix below x: sign changes of the leading principal minors, by the
