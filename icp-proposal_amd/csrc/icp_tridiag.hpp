@@ -350,13 +350,15 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
 #pragma unroll
       for (int s = 0; s < SI; ++s) { vs[s] = 0.0; ws[s] = 0.0; xnew[s] = 0.0; }
       if (lead) {
-      // every LDS value of this section is requested before the first one is used (−2…4 % of the reduction at ranks 100 and 150)
+      // every LDS value of this section is requested before the first one is used (−2…4 % of the reduction at ranks 100 and 150) —
+      // where the registers allow: not with four live row slots (ranks 193..200, first eight steps: the matrix alone takes 200 VGPRs)
+      constexpr bool kHoist = SI - S0 <= 3;
       double sm_[SI], c_[SI], xi_[SI];
 #pragma unroll
       for (int s = 0; s < SI; ++s) {
         const int i = l + 64 * s;
         sm_[s] = 0.0; c_[s] = 0.0; xi_[s] = 0.0;
-        if (s < S0) continue;
+        if (!kHoist || s < S0) continue;
         if constexpr (TWO) {
           sm_[s] = psum[i];
         } else {
@@ -414,7 +416,24 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
           if (keeper) hv[i] = 0.0;
           continue;
         }
-        const double sm = sm_[s], c = c_[s], xi = xi_[s];
+        double sm = sm_[s], c = c_[s], xi = xi_[s];
+        if constexpr (!kHoist) {
+          if constexpr (TWO) {
+            sm = psum[i];
+          } else {
+            const double* pp = part + par * NW * LD + i;
+            double tq[NW];
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) tq[ww] = pp[ww * LD];
+#pragma unroll
+            for (int h = NW / 2; h > 0; h >>= 1)
+#pragma unroll
+              for (int ww = 0; ww < h; ++ww) tq[ww] += tq[ww + h];
+            sm = tq[0];
+          }
+          c = colbuf[par * LD + i];
+          if constexpr (VLDS) xi = vb[par * LD + i]; else xi = xs[s];
+        }
         const double vi = i == k1 ? vk1 : xi;
         const double wi = i > k ? fma(-K, vi, beta * fma(-alpha, c, sm)) : 0.0;
         const double xw = i > k1 ? fma(-vi, wk1, fma(-wi, vk1, c)) : 0.0;
