@@ -313,6 +313,10 @@ struct icp_ctx {
   hipEvent_t ev_sum = nullptr;                   // front_stream -> eig_stream: the partials of the latest posterior are summed
   hipEvent_t ev_asm = nullptr;                   // eig_stream -> stream: … and read (the next regression may overwrite them)
   hipEvent_t ev_join = nullptr;                  // stream -> front_stream, when another entry point has used `stream`
+  hipEvent_t ev_inst = nullptr;                  // stream -> side: "the state's points are complete" (a posterior whose searches run on the side stream)
+  hipEvent_t ev_front = nullptr;                 // side -> stream: "… and so are its searches' results" (the evaluator's reductions read them)
+  bool front_on_side = false;                    // ev_front is on record and nobody has waited for it yet
+  int front_side_K = 0;                          // … the model ids 0..K whose surface search is part of that front (0: none)
   bool front_stream_used = false;                // a step is (or may still be) on front_stream: other entry points drain it first
   // ICP_NO_PIPELINE=1, or a first launch once timed out on its word (a tool that lets one kernel run at a time, in an order
   // of its own): every step on `stream`, nothing launched ahead, no device-side waits
@@ -399,6 +403,7 @@ struct icp_ctx {
     QueryScratch& scratch = which == 1 ? scratch_v : (which == 2 ? scratch_t : this->scratch);
     if (K > scratch.cap) {
       HIP_OK(hipStreamSynchronize(stream));
+      if (front_stream) HIP_OK(hipStreamSynchronize(front_stream));
       size_t cap = std::max<size_t>(K, 4096);
       scratch.thr2.alloc(cap + 8);
       scratch.qrec.alloc(cap + 8);
@@ -409,6 +414,7 @@ struct icp_ctx {
     const size_t want = std::min(kMaxCandidates, std::max<size_t>((K + 4) * std::min<size_t>(std::max<size_t>(n_elems, 1), (size_t)kCandStrideMax), 1));
     if (want > scratch.cand_cap) {
       HIP_OK(hipStreamSynchronize(stream));
+      if (front_stream) HIP_OK(hipStreamSynchronize(front_stream));
       scratch.cand.alloc(want);
       scratch.cand_cap = want;
     }
@@ -457,8 +463,9 @@ struct icp_ctx {
   StateSlot& fresh_state();
   void alloc_slot(StateSlot& s);
   void ensure_model_spheres(StateSlot& s);
-  void ensure_surface_prefix(StateSlot& s, int K);
-  void ensure_nnv_prefix(StateSlot& s, int K);
+  // (st / which: the stream and the scratch set of the search — the context stream and set 0 unless a posterior runs its searches aside)
+  void ensure_surface_prefix(StateSlot& s, int K, hipStream_t st = nullptr, int which = 0);
+  void ensure_nnv_prefix(StateSlot& s, int K, hipStream_t st = nullptr, int which = 0);
 };
 
 namespace {
@@ -562,23 +569,23 @@ void icp_ctx::ensure_model_spheres(StateSlot& s) {
 
 // target.operations.closestPointOnSurface(currentMesh.point(id)) for id in [0, K) (NonRigidIcpProposal.scala:96-97,
 // IndependentPointDistanceEvaluator.scala:41-43): shared by every proposal / evaluator of this context.
-void icp_ctx::ensure_surface_prefix(StateSlot& s, int K) {
+void icp_ctx::ensure_surface_prefix(StateSlot& s, int K, hipStream_t st, int which) {
   if (K > N) fail(ICP_ERR_INVALID_ARG, "model id count exceeds the number of model points");
   if (K <= s.n_surf) return;
   const int k0 = s.n_surf, n = K - k0;
-  QueryBuffers qb = query_scratch(n, target.T);
-  launch_surface_query(stream, target.T, target.verts.p, target.tris.p, target.spheres.p, n, s.x.p + 3 * (size_t)k0,
+  QueryBuffers qb = query_scratch(n, target.T, which);
+  launch_surface_query(st ? st : stream, target.T, target.verts.p, target.tris.p, target.spheres.p, n, s.x.p + 3 * (size_t)k0,
                        hint_surf.p + k0, qb, s.surf_cp.p + 3 * (size_t)k0, s.surf_d2.p + k0, s.surf_tri.p + k0);
   s.n_surf = K;
 }
 
 // target.pointSet.findClosestPoint(targetPoint).id (NonRigidIcpProposal.scala:98)
-void icp_ctx::ensure_nnv_prefix(StateSlot& s, int K) {
-  ensure_surface_prefix(s, K);
+void icp_ctx::ensure_nnv_prefix(StateSlot& s, int K, hipStream_t st, int which) {
+  ensure_surface_prefix(s, K, st, which);
   if (K <= s.n_nnv) return;
   const int k0 = s.n_nnv, n = K - k0;
-  QueryBuffers qb = query_scratch(n, target.V);
-  launch_vertex_query(stream, target.V, target.verts.p, n, s.surf_cp.p + 3 * (size_t)k0, hint_nnv.p + k0, qb, nullptr,
+  QueryBuffers qb = query_scratch(n, target.V, which);
+  launch_vertex_query(st ? st : stream, target.V, target.verts.p, n, s.surf_cp.p + 3 * (size_t)k0, hint_nnv.p + k0, qb, nullptr,
                       s.surf_nnv.p + k0);
   s.n_nnv = K;
 }
@@ -894,29 +901,38 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipS
     }
     return e;
   }
+  // With a side stream the WHOLE posterior goes there — searches, correspondences, regression and (as before) the factorisation —
+  // behind the state's instance: the caller's evaluator searches the same state on the context stream at the same time (its own
+  // query range, its own scratch set) instead of 65 µs later.  fs / sw: the stream and the scratch set of this posterior's front.
+  const hipStream_t fs = side ? side : c.stream;
+  const int sw = side ? 1 : 0;
   PosteriorEntry& e = fresh_entry();
   if (e.eig_event_valid && e.eigen_event()) {  // a decomposition that may still read this entry's M (started ahead, its state not kept)
-    HIP_OK(hipStreamWaitEvent(c.stream, e.eigen_event(), 0));
+    HIP_OK(hipStreamWaitEvent(fs, e.eigen_event(), 0));
     e.eig_event_valid = false;
   }
   e.theta.assign(theta, theta + P);
   e.valid = true;
   e.stamp = ++clock;
   StateSlot& s = c.state(theta);  // :141 currentMesh
+  if (side) {  // (the points, the slot's coefficients: launched or copied on the context stream, possibly just now)
+    HIP_OK(hipEventRecord(c.ev_inst, c.stream));
+    HIP_OK(hipStreamWaitEvent(side, c.ev_inst, 0));
+  }
   const EntryInit init{s.coeffs.p, e.coeffs.p, r, status.p + e.status_off};  // (status: {chol, eigen sweeps (diagnostic), eigen})
   if (prm.direction == ICP_TARGET_SAMPLING) {
     // :117-118 nearest vertex of the current mesh for every decimated-target point
-    QueryBuffers qb = c.query_scratch(K, c.N);
-    launch_vertex_query(c.stream, c.N, s.x.p, K, target_pts.p, hint_nn.p, qb, nullptr, nn_id.p);
-    launch_correspond_target(c.stream, K, s.x.p, target_pts.p, nn_id.p, c.boundary.p, prm.boundary_aware, s.pose, c.ref.p,
+    QueryBuffers qb = c.query_scratch(K, c.N, sw);
+    launch_vertex_query(fs, c.N, s.x.p, K, target_pts.p, hint_nn.p, qb, nullptr, nn_id.p);
+    launch_correspond_target(fs, K, s.x.p, target_pts.p, nn_id.p, c.boundary.p, prm.boundary_aware, s.pose, c.ref.p,
                              c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, e.corr(), init);
   } else {
     // :94-99 closest surface point of the target for model ids 0 until K; nearest target vertex only when the
     // boundary test can change anything (the target has boundary vertices) or the caller asked for it
-    c.ensure_surface_prefix(s, K);
+    c.ensure_surface_prefix(s, K, fs, sw);
     const bool need_nnv = want_aux || (prm.boundary_aware && c.target.n_boundary > 0);
-    if (need_nnv) c.ensure_nnv_prefix(s, K);
-    launch_correspond_model(c.stream, K, s.x.p, s.surf_cp.p, need_nnv ? s.surf_nnv.p : nullptr, c.target.boundary.p,
+    if (need_nnv) c.ensure_nnv_prefix(s, K, fs, sw);
+    launch_correspond_model(fs, K, s.x.p, s.surf_cp.p, need_nnv ? s.surf_nnv.p : nullptr, c.target.boundary.p,
                             prm.boundary_aware, s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, e.corr(), init);
   }
   // :152 interpolatedModel.posterior(uncertainDisplacements)
@@ -924,27 +940,28 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipS
   const double kappa = 1.0 / (prm.noise_along_normal * prm.noise_along_normal) - wt;
   int splits = 1;
   if (side_factor_pending) {  // the partials and the factor scratch are still being read / written over there
-    HIP_OK(hipStreamWaitEvent(c.stream, c.ev_side, 0));
+    if (!side) HIP_OK(hipStreamWaitEvent(c.stream, c.ev_side, 0));  // (on the side stream itself: stream order)
     side_factor_pending = false;
   }
   if (side_asm_pending) {
-    HIP_OK(hipStreamWaitEvent(c.stream, c.ev_asm, 0));
+    HIP_OK(hipStreamWaitEvent(fs, c.ev_asm, 0));
     side_asm_pending = false;
   }
   side_parts = nullptr;
   side_parts_entry = nullptr;
-  double* parts = mpart_for_write(0, c.stream);
-  launch_regression(c.stream, K, r, c.Q.p, e.corr(), wt, kappa, parts, &splits);
+  double* parts = mpart_for_write(0, fs);
+  launch_regression(fs, K, r, c.Q.p, e.corr(), wt, kappa, parts, &splits);
+  if (side) {  // what the state's slot now holds of this front (surface points, distances, nearest vertices of ids 0..K) is complete
+    HIP_OK(hipEventRecord(c.ev_front, side));
+    c.front_on_side = true;
+    c.front_side_K = prm.direction == ICP_TARGET_SAMPLING ? 0 : K;
+  }
   PosteriorFactorIO io{parts, splits, e.M.p, e.alpha.p, status.p + e.status_off, fscratch.p};
   // the Cholesky-root sampler at ranks above 64 (below, k_posterior_root runs where the decomposition would): the factorisation
   // itself hands the factor out — V := L, S := 1/diag(L) — and nothing is decomposed at all
   const bool root_here = sampler == ICP_SAMPLER_CHOLESKY_ROOT && !eigen_speculation_supported(r);
   if (root_here) { io.Lout = e.V.p; io.Sout = e.S.p; }
-  if (side) {
-    HIP_OK(hipEventRecord(c.ev_ready, c.stream));
-    HIP_OK(hipStreamWaitEvent(side, c.ev_ready, 0));
-  }
-  issue_factor(e, io, parts, splits, side, root_here);
+  issue_factor(e, io, parts, splits, side, root_here);  // (behind the regression in stream order, on either stream)
   return e;
 }
 
@@ -1170,8 +1187,19 @@ void enqueue_eval(icp_evaluator* ev, StateSlot& s, int base) {
   const bool m2t = p.kind == ICP_EVAL_HAUSDORFF || p.mode != ICP_TARGET_TO_MODEL;
   const bool t2m = p.kind == ICP_EVAL_HAUSDORFF || p.mode != ICP_MODEL_TO_TARGET;
   const int Km = p.kind == ICP_EVAL_HAUSDORFF ? c.N : p.n_model_ids;
+  // a posterior of this state whose searches run on the side stream right now fills the slot's ids 0..K: the searches below take the
+  // ids behind them at the same time, the reductions wait for both
+  auto join_front = [&] {
+    if (c.front_on_side) { HIP_OK(hipStreamWaitEvent(c.stream, c.ev_front, 0)); c.front_on_side = false; }
+  };
+  if (!m2t) join_front();
   if (m2t) {
     c.ensure_surface_prefix(s, Km);
+    if (p.kind == ICP_EVAL_COLLECTIVE_AVG_HAUSDORFF_BOUNDARY_AWARE && c.target.n_boundary > 0) {
+      if (s.n_nnv < c.front_side_K) join_front();  // (the nearest-vertex search below would start at ids whose surface points are still on their way)
+      c.ensure_nnv_prefix(s, Km);
+    }
+    join_front();
     if (p.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE) {
       launch_sum_gauss_logpdf(c.stream, Km, s.surf_d2.p, p.gauss_mean, p.gauss_sigma, out + 0);  // IndependentPointDistanceEvaluator.scala:40-46
     } else if (p.kind == ICP_EVAL_HAUSDORFF) {
@@ -1351,6 +1379,8 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_sum, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ctx->ev_inst, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
     HIP_OK(hipHostMalloc((void**)&ctx->h_wait_error, sizeof(int) * 16, hipHostMallocDefault));
     ctx->h_wait_error[0] = 0;
 
@@ -1540,6 +1570,8 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream);
   }
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_inst) (void)hipEventDestroy(ctx->ev_inst);
+  if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
   if (ctx->h_wait_error) (void)hipHostFree(ctx->h_wait_error);
   if (ctx->h_gate_error) (void)hipHostFree(ctx->h_gate_error);
   for (void* bp : ctx->batch_eig_rec)
