@@ -283,6 +283,9 @@ struct StateSlot {
   DBuf<int> surf_tri;
   int n_nnv = 0;   // ... and their surface points already matched to the nearest target vertex
   DBuf<int> surf_nnv;
+  // … plus one detached range each, [lo, hi): searched ahead of ids that were left to another stream (ensure_*_prefix(…, reserve));
+  // joined to the prefix as soon as that reaches lo
+  int lo_surf = 0, hi_surf = 0, lo_nnv = 0, hi_nnv = 0;
 };
 
 }  // namespace
@@ -314,6 +317,7 @@ struct icp_ctx {
   hipEvent_t ev_asm = nullptr;                   // eig_stream -> stream: … and read (the next regression may overwrite them)
   hipEvent_t ev_join = nullptr;                  // stream -> front_stream, when another entry point has used `stream`
   hipEvent_t ev_inst = nullptr;                  // stream -> side: "the state's points are complete" (a posterior whose searches run on the side stream)
+  const void* ev_inst_slot = nullptr;            // … the state slot it was recorded for by the caller of posterior(…, side), if any
   hipEvent_t ev_front = nullptr;                 // side -> stream: "… and so are its searches' results" (the evaluator's reductions read them)
   bool front_on_side = false;                    // ev_front is on record and nobody has waited for it yet
   int front_side_K = 0;                          // … the model ids 0..K whose surface search is part of that front (0: none)
@@ -464,8 +468,10 @@ struct icp_ctx {
   void alloc_slot(StateSlot& s);
   void ensure_model_spheres(StateSlot& s);
   // (st / which: the stream and the scratch set of the search — the context stream and set 0 unless a posterior runs its searches aside)
-  void ensure_surface_prefix(StateSlot& s, int K, hipStream_t st = nullptr, int which = 0);
-  void ensure_nnv_prefix(StateSlot& s, int K, hipStream_t st = nullptr, int which = 0);
+  // reserve > prefix: the ids between them are left to somebody else (a posterior's searches on the side stream, issued next); what
+  // lies behind them is searched now, as a detached range
+  void ensure_surface_prefix(StateSlot& s, int K, hipStream_t st = nullptr, int which = 0, int reserve = 0);
+  void ensure_nnv_prefix(StateSlot& s, int K, hipStream_t st = nullptr, int which = 0, int reserve = 0);
 };
 
 namespace {
@@ -534,6 +540,7 @@ StateSlot& icp_ctx::fresh_state() {
   s.spheres_valid = false;
   s.n_surf = 0;
   s.n_nnv = 0;
+  s.lo_surf = s.hi_surf = s.lo_nnv = s.hi_nnv = 0;
   return s;
 }
 
@@ -569,25 +576,51 @@ void icp_ctx::ensure_model_spheres(StateSlot& s) {
 
 // target.operations.closestPointOnSurface(currentMesh.point(id)) for id in [0, K) (NonRigidIcpProposal.scala:96-97,
 // IndependentPointDistanceEvaluator.scala:41-43): shared by every proposal / evaluator of this context.
-void icp_ctx::ensure_surface_prefix(StateSlot& s, int K, hipStream_t st, int which) {
+void icp_ctx::ensure_surface_prefix(StateSlot& s, int K, hipStream_t st, int which, int reserve) {
   if (K > N) fail(ICP_ERR_INVALID_ARG, "model id count exceeds the number of model points");
+  auto join = [&] { if (s.hi_surf > 0 && s.n_surf >= s.lo_surf) { s.n_surf = std::max(s.n_surf, s.hi_surf); s.lo_surf = s.hi_surf = 0; } };
+  auto search = [&](int k0, int k1) {
+    const int n = k1 - k0;
+    QueryBuffers qb = query_scratch(n, target.T, which);
+    launch_surface_query(st ? st : stream, target.T, target.verts.p, target.tris.p, target.spheres.p, n, s.x.p + 3 * (size_t)k0,
+                         hint_surf.p + k0, qb, s.surf_cp.p + 3 * (size_t)k0, s.surf_d2.p + k0, s.surf_tri.p + k0);
+  };
+  join();
   if (K <= s.n_surf) return;
-  const int k0 = s.n_surf, n = K - k0;
-  QueryBuffers qb = query_scratch(n, target.T, which);
-  launch_surface_query(st ? st : stream, target.T, target.verts.p, target.tris.p, target.spheres.p, n, s.x.p + 3 * (size_t)k0,
-                       hint_surf.p + k0, qb, s.surf_cp.p + 3 * (size_t)k0, s.surf_d2.p + k0, s.surf_tri.p + k0);
-  s.n_surf = K;
+  if (reserve > s.n_surf) {  // ids [prefix, reserve) are somebody else's: [reserve, K) detached (once)
+    if (s.hi_surf == 0 && reserve < K) { search(reserve, K); s.lo_surf = reserve; s.hi_surf = K; }
+    return;
+  }
+  while (s.n_surf < K) {
+    const int k1 = s.hi_surf > 0 ? std::min(K, s.lo_surf) : K;  // (up to a detached range, which then joins)
+    if (k1 > s.n_surf) search(s.n_surf, k1);
+    s.n_surf = std::max(s.n_surf, k1);
+    join();
+  }
 }
 
 // target.pointSet.findClosestPoint(targetPoint).id (NonRigidIcpProposal.scala:98)
-void icp_ctx::ensure_nnv_prefix(StateSlot& s, int K, hipStream_t st, int which) {
-  ensure_surface_prefix(s, K, st, which);
+void icp_ctx::ensure_nnv_prefix(StateSlot& s, int K, hipStream_t st, int which, int reserve) {
+  ensure_surface_prefix(s, K, st, which, reserve);
+  auto join = [&] { if (s.hi_nnv > 0 && s.n_nnv >= s.lo_nnv) { s.n_nnv = std::max(s.n_nnv, s.hi_nnv); s.lo_nnv = s.hi_nnv = 0; } };
+  auto search = [&](int k0, int k1) {
+    const int n = k1 - k0;
+    QueryBuffers qb = query_scratch(n, target.V, which);
+    launch_vertex_query(st ? st : stream, target.V, target.verts.p, n, s.surf_cp.p + 3 * (size_t)k0, hint_nnv.p + k0, qb, nullptr,
+                        s.surf_nnv.p + k0);
+  };
+  join();
   if (K <= s.n_nnv) return;
-  const int k0 = s.n_nnv, n = K - k0;
-  QueryBuffers qb = query_scratch(n, target.V, which);
-  launch_vertex_query(st ? st : stream, target.V, target.verts.p, n, s.surf_cp.p + 3 * (size_t)k0, hint_nnv.p + k0, qb, nullptr,
-                      s.surf_nnv.p + k0);
-  s.n_nnv = K;
+  if (reserve > s.n_nnv) {
+    if (s.hi_nnv == 0 && reserve < K) { search(reserve, K); s.lo_nnv = reserve; s.hi_nnv = K; }
+    return;
+  }
+  while (s.n_nnv < K) {
+    const int k1 = s.hi_nnv > 0 ? std::min(K, s.lo_nnv) : K;
+    if (k1 > s.n_nnv) search(s.n_nnv, k1);
+    s.n_nnv = std::max(s.n_nnv, k1);
+    join();
+  }
 }
 
 namespace {
@@ -916,7 +949,7 @@ PosteriorEntry& icp_proposal::posterior(const double* theta, bool want_aux, hipS
   e.stamp = ++clock;
   StateSlot& s = c.state(theta);  // :141 currentMesh
   if (side) {  // (the points, the slot's coefficients: launched or copied on the context stream, possibly just now)
-    HIP_OK(hipEventRecord(c.ev_inst, c.stream));
+    if (c.ev_inst_slot != (const void*)&s) HIP_OK(hipEventRecord(c.ev_inst, c.stream));  // (else: on record already, ahead of launches that need not be waited for)
     HIP_OK(hipStreamWaitEvent(side, c.ev_inst, 0));
   }
   const EntryInit init{s.coeffs.p, e.coeffs.p, r, status.p + e.status_off};  // (status: {chol, eigen sweeps (diagnostic), eigen})
@@ -1178,8 +1211,11 @@ void sync_proposal_status_if(icp_proposal* p, bool needed) {
 
 // ===================================================================== evaluators
 
-// enqueue everything logValue(theta) needs; partial results land in d_res[base .. base+8)
-void enqueue_eval(icp_evaluator* ev, StateSlot& s, int base) {
+// enqueue everything logValue(theta) needs; partial results land in d_res[base .. base+8).  In two parts, so that a caller can put a
+// posterior of the same state on the side stream between them (icp_chain_eval_step): the searches — with the model ids below
+// `reserve` (`reserve_nnv` for their nearest target vertices) left to that posterior's own searches — and the whole target-to-model
+// half first; the model-to-target reductions, which read what both streams' searches have written, behind the side stream's event.
+void enqueue_eval_searches(icp_evaluator* ev, StateSlot& s, int base, int reserve = 0, int reserve_nnv = 0) {
   icp_ctx& c = *ev->ctx;
   const icp_evaluator_params& p = ev->prm;
   double* out = c.d_res.p + base;
@@ -1187,28 +1223,15 @@ void enqueue_eval(icp_evaluator* ev, StateSlot& s, int base) {
   const bool m2t = p.kind == ICP_EVAL_HAUSDORFF || p.mode != ICP_TARGET_TO_MODEL;
   const bool t2m = p.kind == ICP_EVAL_HAUSDORFF || p.mode != ICP_MODEL_TO_TARGET;
   const int Km = p.kind == ICP_EVAL_HAUSDORFF ? c.N : p.n_model_ids;
-  // a posterior of this state whose searches run on the side stream right now fills the slot's ids 0..K: the searches below take the
-  // ids behind them at the same time, the reductions wait for both
-  auto join_front = [&] {
-    if (c.front_on_side) { HIP_OK(hipStreamWaitEvent(c.stream, c.ev_front, 0)); c.front_on_side = false; }
-  };
-  if (!m2t) join_front();
   if (m2t) {
-    c.ensure_surface_prefix(s, Km);
+    c.ensure_surface_prefix(s, Km, nullptr, 0, reserve);
     if (p.kind == ICP_EVAL_COLLECTIVE_AVG_HAUSDORFF_BOUNDARY_AWARE && c.target.n_boundary > 0) {
-      if (s.n_nnv < c.front_side_K) join_front();  // (the nearest-vertex search below would start at ids whose surface points are still on their way)
-      c.ensure_nnv_prefix(s, Km);
-    }
-    join_front();
-    if (p.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE) {
-      launch_sum_gauss_logpdf(c.stream, Km, s.surf_d2.p, p.gauss_mean, p.gauss_sigma, out + 0);  // IndependentPointDistanceEvaluator.scala:40-46
-    } else if (p.kind == ICP_EVAL_HAUSDORFF) {
-      launch_dist_max(c.stream, Km, s.surf_d2.p, out + 1);  // (finish_eval reads the maxima only: res[1], res[5])
-    } else {
-      const bool flags = c.target.n_boundary > 0;  // Collective…Evaluator.scala:44-48
-      if (flags) c.ensure_nnv_prefix(s, Km);
-      launch_dist_stats(c.stream, Km, s.surf_d2.p, flags ? c.target.boundary.p : nullptr, flags ? s.surf_nnv.p : nullptr,
-                        c.target.V, out + 0);
+      // (a front already on the side stream that leaves the nearest vertices of its ids to this search: wait for its surface points)
+      if (c.front_on_side && s.n_nnv < c.front_side_K && reserve_nnv <= s.n_nnv) {
+        HIP_OK(hipStreamWaitEvent(c.stream, c.ev_front, 0));
+        c.front_on_side = false;
+      }
+      c.ensure_nnv_prefix(s, Km, nullptr, 0, reserve_nnv);
     }
   }
   if (t2m) {
@@ -1233,6 +1256,31 @@ void enqueue_eval(icp_evaluator* ev, StateSlot& s, int base) {
                         c.target.V, out + 4);
     }
   }
+}
+void enqueue_eval_reductions(icp_evaluator* ev, StateSlot& s, int base) {
+  icp_ctx& c = *ev->ctx;
+  const icp_evaluator_params& p = ev->prm;
+  double* out = c.d_res.p + base;
+  // a posterior of this state whose searches ran on the side stream has filled the slot's ids 0..K: the reductions wait for it
+  if (c.front_on_side) { HIP_OK(hipStreamWaitEvent(c.stream, c.ev_front, 0)); c.front_on_side = false; }
+  const bool m2t = p.kind == ICP_EVAL_HAUSDORFF || p.mode != ICP_TARGET_TO_MODEL;
+  const int Km = p.kind == ICP_EVAL_HAUSDORFF ? c.N : p.n_model_ids;
+  if (!m2t) return;
+  if (s.n_surf < Km) fail(ICP_ERR_DEVICE, "internal: the evaluator's model ids were not all searched");
+  if (p.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE) {
+    launch_sum_gauss_logpdf(c.stream, Km, s.surf_d2.p, p.gauss_mean, p.gauss_sigma, out + 0);  // IndependentPointDistanceEvaluator.scala:40-46
+  } else if (p.kind == ICP_EVAL_HAUSDORFF) {
+    launch_dist_max(c.stream, Km, s.surf_d2.p, out + 1);  // (finish_eval reads the maxima only: res[1], res[5])
+  } else {
+    const bool flags = c.target.n_boundary > 0;  // Collective…Evaluator.scala:44-48
+    if (flags && s.n_nnv < Km) fail(ICP_ERR_DEVICE, "internal: the evaluator's nearest vertices were not all searched");
+    launch_dist_stats(c.stream, Km, s.surf_d2.p, flags ? c.target.boundary.p : nullptr, flags ? s.surf_nnv.p : nullptr,
+                      c.target.V, out + 0);
+  }
+}
+void enqueue_eval(icp_evaluator* ev, StateSlot& s, int base) {
+  enqueue_eval_searches(ev, s, base);
+  enqueue_eval_reductions(ev, s, base);
 }
 
 double gauss_logpdf(double x, double mu, double sigma) {  // Breeze Gaussian.logPdf
@@ -2388,31 +2436,60 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
       c.eig_last = c.eig_stream;
       const hipStream_t es = (c.eig_stream2 && (p->eig_flip++ & 1)) ? c.eig_stream2 : c.eig_stream;  // two under way at a time
       es_ahead = es;
-      HIP_OK(hipEventRecord(c.ev_ready, c.stream));  // (whatever of this entry is still in flight on the context stream)
-      HIP_OK(hipStreamWaitEvent(es, c.ev_ready, 0));
       if (p->side_parts && p->side_parts_entry == &en) {
+        // (computed just now, all of it on the side stream: nothing of this entry is on the context stream — which carries the
+        // evaluator's searches by now, and the decomposition must not wait for those)
         HIP_OK(hipStreamWaitEvent(es, c.ev_sum, 0));
         launch_assemble_posterior_matrix(es, r, p->side_parts, en.M.p);
         HIP_OK(hipEventRecord(c.ev_asm, es));
         p->side_asm_pending = true;
       } else {
+        HIP_OK(hipEventRecord(c.ev_ready, c.stream));  // (whatever of this entry is still in flight on the context stream)
+        HIP_OK(hipStreamWaitEvent(es, c.ev_ready, 0));
         HIP_OK(hipStreamWaitEvent(es, c.ev_side, 0));
       }
       p->ensure_eigen_on(en, es, part);
+    };
+    // Order of issue on this path (the host needs 3-6 µs per launch, the context stream is idle until it gets the evaluator's):
+    // the proposed state's instance -> the evaluator's searches (the model ids the posterior's own searches will cover — 0..K — left
+    // out: StateSlot's detached ranges) and its target-to-model half -> the posterior on the side stream (searches of ids 0..K,
+    // correspondences, regression, factorisation) -> the head of the decomposition -> the evaluator's model-to-target reductions,
+    // behind the side stream's searches -> the decomposition's other launches -> the tails.
+    // the two coefficient vectors the tails read: the states' own copies on the device (the current state's slot is kept from
+    // being recycled for the proposed one), staged from the host only for a current state that has no slot any more — here, ahead of
+    // the evaluator's launches: ev_inst covers them
+    const double *d_cur = nullptr, *d_prop = nullptr;
+    if (shape_only && n_props > 0) {
+      StateSlot* sc = c.find_state(theta_cur);
+      if (sc) sc->stamp = ++c.clock;
+      d_cur = sc ? sc->coeffs.p : c.stage(theta_cur + 10, r);
+      d_prop = c.state(theta_prop).coeffs.p;
+    }
+    bool split_eval = false;
+    if (side && need_eval && n_props == 1) {
+      icp_proposal* p0 = props[0];
+      PosteriorEntry* known = p0->find_entry(theta_prop);
+      if (known) known->stamp = ++p0->clock;  // (not the one a posterior of the current state, computed first, recycles)
+      const int R = (!known && p0->prm.direction == ICP_MODEL_SAMPLING) ? p0->K : 0;
+      const int Rn = (R > 0 && p0->prm.boundary_aware && c.target.n_boundary > 0) ? R : 0;
+      StateSlot& s = c.state(theta_prop);
+      HIP_OK(hipEventRecord(c.ev_inst, c.stream));
+      c.ev_inst_slot = &s;
+      enqueue_eval_searches(e, s, 0, R, Rn);
+      split_eval = true;
+    }
+    struct InstGuard { icp_ctx& c; ~InstGuard() { c.ev_inst_slot = nullptr; } } inst_guard{c};
+    auto eval_reductions = [&] {
+      if (split_eval && !eval_enqueued) { enqueue_eval_reductions(e, c.state(theta_prop), 0); eval_enqueued = true; }
     };
     PosteriorEntry* pose_entry = nullptr;
     if (spec_pose) {
       PosteriorEntry& en = props[0]->posterior(theta_prop, false, side);
       decompose_ahead(props[0], en, 1);  // (its other launches: behind the evaluator's, below)
       pose_entry = &en;
+      eval_reductions();
     }
     if (shape_only && n_props > 0) {
-      // the two coefficient vectors the tails read: the states' own copies on the device (the current state's slot is kept from
-      // being recycled for the proposed one), staged from the host only for a current state that has no slot any more
-      StateSlot* sc = c.find_state(theta_cur);
-      if (sc) sc->stamp = ++c.clock;
-      const double* d_cur = sc ? sc->coeffs.p : c.stage(theta_cur + 10, r);
-      const double* d_prop = c.state(theta_prop).coeffs.p;
       for (int i = 0; i < n_props; ++i) {
         icp_proposal* p = props[i];
         ec[i] = &p->posterior(theta_cur, false, side);
@@ -2426,15 +2503,21 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         ++n_tails;
       }
       if (side) {
-        // (the staged coefficients and — for entries found in the memo — everything else the tails read: all behind ev_ready)
-        HIP_OK(hipEventRecord(c.ev_ready, c.stream));
-        HIP_OK(hipStreamWaitEvent(side, c.ev_ready, 0));
+        // (the staged coefficients and — for entries found in the memo — everything else the tails read: behind ev_inst, which was
+        // recorded ahead of the evaluator's searches, or behind ev_ready)
+        if (split_eval) {
+          HIP_OK(hipStreamWaitEvent(side, c.ev_inst, 0));
+        } else {
+          HIP_OK(hipEventRecord(c.ev_ready, c.stream));
+          HIP_OK(hipStreamWaitEvent(side, c.ev_ready, 0));
+        }
         // Order of issue (the host needs 3-6 µs per launch): factorisation (inside posterior) -> the HEAD of the decomposition (the
         // reduction to tridiagonal form, 0.48 ms on one workgroup) -> the evaluator's ten launches -> the decomposition's other ten
         // launches (they run behind the reduction whenever they are issued) -> the tails (behind the factorisation: 0.1-0.3 ms of
         // slack).  The evaluator's searches used to start 70-120 µs after the regression had ended because they were issued last.
         decompose_ahead(props[0], *ep[0], 1);
-        if (need_eval) {
+        eval_reductions();
+        if (need_eval && !eval_enqueued) {
           StateSlot& s = c.state(theta_prop);
           enqueue_eval(e, s, 0);
           eval_enqueued = true;
@@ -2448,6 +2531,7 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         props[0]->side_factor_pending = false;  // (this stream waits for ev_side below)
       }
     }
+    eval_reductions();
     if (need_eval && (spec_big || spec_pose) && !eval_enqueued) {
       StateSlot& s = c.state(theta_prop);
       enqueue_eval(e, s, 0);
