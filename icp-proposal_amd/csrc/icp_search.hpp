@@ -7,6 +7,16 @@
 namespace icp {
 
 constexpr int kSearchBlock = 256;
+#ifdef ICP_FILTER_STAMPS  // developer aid: time (100 MHz ticks) per part of a surface-filter workgroup, summed over the workgroups
+static __device__ unsigned long long g_filter_stamps[16];  // (one per translation unit)
+#define FLT_T() ((long long)__builtin_amdgcn_s_memrealtime())
+#define FLT_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")  // (a part ends when its loads / stores have come back)
+#define FLT_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_filter_stamps[i], (unsigned long long)(v)); } while (0)
+#else
+#define FLT_T() 0ll
+#define FLT_DRAIN()
+#define FLT_ADD(i, v) (void)(v)
+#endif
 constexpr double kAbsSlack = 3.0 / 8388608.0;  // 3·2^-23 per unit of |coordinate|: covers rounding a point to f32
 constexpr int kQU = 4;                         // queries per unrolled filter iteration
 
@@ -139,6 +149,7 @@ constexpr int kSurfaceTile = 512;  // … surface filter: a whole chunk (split_s
 __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int by) {
   __shared__ float4 s_q[kSurfaceTile];
   __shared__ float s_thr[kSurfaceTile];
+  const long long ft0 = FLT_T();
   const int t0 = (bx * kSearchBlock + threadIdx.x) * kSpheresPerLane;
   const bool v0 = t0 < q.T, v1 = t0 + 1 < q.T;
   // out-of-range lanes: centre NaN — their squared distance is NaN and passes no threshold, not even an infinite one
@@ -167,6 +178,9 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
   const int k0 = by * q.kchunk;
   const int k1 = min(q.Kpad, k0 + q.kchunk);
   ParkedHits ph;
+  FLT_DRAIN();
+  const long long ft1 = FLT_T();
+  long long ft_stage = 0, ft_test = 0;
   const int first = (bx * kSearchBlock + (threadIdx.x & ~63)) * kSpheresPerLane;  // list position of lane 0's first sphere
                                                                                   // (candidates are named by position: see surface_resolve)
   const int lane = threadIdx.x & 63;
@@ -174,6 +188,7 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
   for (int kt = k0; kt < k1; kt += kSurfaceTile) {
     // this workgroup's queries go through LDS: one coalesced read per tile; the loops below never wait for global memory
     const int nq = min(kSurfaceTile, k1 - kt);
+    const long long fa = FLT_T();
     if (kt != k0) __syncthreads();
     if (q.thrA) {
       for (int i = threadIdx.x; i < nq; i += kSearchBlock) { s_q[i] = q.qrec[kt + i]; s_thr[i] = q.thrA[kt + i]; }
@@ -187,6 +202,8 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
       }
     }
     __syncthreads();
+    const long long fb = FLT_T();
+    ft_stage += fb - fa;
     if (!wave_live) continue;
     for (int g = 0; g < nq; g += 64) {
       bool near = false;
@@ -215,8 +232,14 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
         }
       }
     }
+    ft_test += FLT_T() - fb;
   }
+  const long long ft2 = FLT_T();
   settle_hits(ph, q.cnt, q.cand, q.stride, first, kSpheresPerLane);
+  FLT_DRAIN();
+  const long long ft3 = FLT_T();
+  FLT_ADD(0, 1); FLT_ADD(1, ft1 - ft0); FLT_ADD(2, ft_stage); FLT_ADD(3, ft_test); FLT_ADD(4, ft3 - ft2); FLT_ADD(5, ft3 - ft0);
+  FLT_ADD(6, n_ball); FLT_ADD(7, n_sphere);
   if (q.stats && lane == 0) {
     atomicAdd(q.stats + 0, (unsigned long long)n_ball);
     atomicAdd(q.stats + 1, (unsigned long long)n_sphere * 64ull * kSpheresPerLane);

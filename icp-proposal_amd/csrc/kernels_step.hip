@@ -221,6 +221,13 @@ template <int RMAX>
 __global__ void __launch_bounds__(kStepBlock) k_step_begin_reg(StepBeginArgs a) { step_begin_body_reg<RMAX>(a, blockIdx.x); }
 
 // ---------------------------------------------------------------- 2: filters of every search
+#ifdef ICP_FILTER_STAMPS
+extern "C" __attribute__((visibility("default"))) void icp_debug_filter_stamps(unsigned long long* out, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_filter_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_stamps), z, sizeof(z)); }
+}
+#endif
 
 __device__ __forceinline__ void step_filter_body(const StepSearchArgs& a, const int b) {
   int task = 0;
