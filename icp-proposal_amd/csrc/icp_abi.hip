@@ -3708,6 +3708,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       int grid[5] = {0, 0, 0, 0, 0};
       DBuf<StepBeginArgs> begin_alt, begin_live;
       DBuf<StepSearchArgs> search_alt, search_live;
+      bool filter_prepared = true;  // (step_filter_prepared of every captured step)
       DBuf<StepRegressionArgs> regression_alt, regression_live;
       DBuf<StepFinishArgs> finish_alt, finish_live;
       DBuf<MhChain> mh;
@@ -3815,6 +3816,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
           hb[(size_t)sel * B + k] = cap.begin; hs[(size_t)sel * B + k] = cap.search; hr[(size_t)sel * B + k] = cap.regression;
           hf[(size_t)sel * B + k] = cap.finish;
           for (int q = 0; q < 5; ++q) gr.grid[q] = std::max(gr.grid[q], cap.grid[q]);
+          gr.filter_prepared = gr.filter_prepared && step_filter_prepared(cap.search);
           m.begin_alt[sel] = gr.begin_alt.p + (size_t)sel * B + k;
           m.search_alt[sel] = gr.search_alt.p + (size_t)sel * B + k;
           m.regression_alt[sel] = gr.regression_alt.p + (size_t)sel * B + k;
@@ -3923,7 +3925,8 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
           }
           if (s_ == 0) launch_mh_front(gr.st, gr.B, gr.mh.p);  // (later steps of the block: prepared by the decide kernel of the step before)
           int g4[5] = {gr.grid[0], gr.grid[1], gr.grid[2], gr.grid[3], 0};
-          launch_step_batch_resident(gr.st, gr.B, g4, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p);
+          launch_step_batch_resident(gr.st, gr.B, g4, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p,
+                                     gr.filter_prepared);
           if (n_groups > 1) HIP_OK(hipEventRecord(gr.ev_big, gr.st));
           int g5[5] = {0, 0, 0, 0, gr.grid[4]};
           launch_step_batch_resident(gr.st, gr.B, g5, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p);

@@ -354,6 +354,13 @@ struct StepSearchArgs {  // launches 2 (filter) and 3 (resolve + correspondences
   CorrTask corr[2];
 };
 
+// every surface task of the step comes with resident spheres and bounds taken by launch 1 (the light form of the batched filter launch)
+inline bool step_filter_prepared(const StepSearchArgs& a) {
+  for (int i = 0; i < a.n_surf; ++i)
+    if (a.s[i].spheres == nullptr || a.s[i].thrA == nullptr) return false;
+  return true;
+}
+
 // 16×16 output tiles of the lower triangle of the (r+1)×(r+1) normal matrix (see regression_tile)
 __host__ __device__ inline int regression_tiles(int r) { const int nt = (r + 1 + 15) >> 4; return nt * (nt + 1) / 2; }
 
@@ -478,7 +485,7 @@ void launch_mh_front(hipStream_t st, int B, MhChain* chains);
 void launch_mh_decide(hipStream_t st, int B, MhChain* chains);
 // the five merged launches for B chains from DEVICE-RESIDENT argument arrays (no copy kernel, no gate: one stream, in order)
 void launch_step_batch_resident(hipStream_t st, int B, const int grid[5], int r, const StepBeginArgs* begin, const StepSearchArgs* search,
-                                const StepRegressionArgs* regression, const StepFinishArgs* finish);
+                                const StepRegressionArgs* regression, const StepFinishArgs* finish, bool filter_prepared = false);
 
 SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const float4* spheres, int K, const double* P,
                               int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);

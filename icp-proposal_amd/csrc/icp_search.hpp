@@ -8,10 +8,11 @@ namespace icp {
 
 constexpr int kSearchBlock = 256;
 #ifdef ICP_FILTER_STAMPS  // developer aid: time (100 MHz ticks) per part of a surface-filter workgroup, summed over the workgroups
-static __device__ unsigned long long g_filter_stamps[16];  // (one per translation unit)
+constexpr int kFltSlots = 2048;  // (sums spread over many lines: thousands of workgroups adding to ONE line would time their own atomics)
+static __device__ unsigned long long g_filter_stamps[kFltSlots][8];  // (one per translation unit)
 #define FLT_T() ((long long)__builtin_amdgcn_s_memrealtime())
 #define FLT_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")  // (a part ends when its loads / stores have come back)
-#define FLT_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_filter_stamps[i], (unsigned long long)(v)); } while (0)
+#define FLT_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_filter_stamps[(blockIdx.x + 977u * blockIdx.y) % kFltSlots][i], (unsigned long long)(v)); } while (0)
 #else
 #define FLT_T() 0ll
 #define FLT_DRAIN()
@@ -146,6 +147,10 @@ constexpr int kSurfaceTile = 512;  // … surface filter: a whole chunk (split_s
 // that survive: 2 % of the (wave, query) pairs on the 58k-vertex target.  Every pair is still decided, the set of
 // candidates is the one the plain double loop gives; a wave whose triangles are scattered over the surface just keeps
 // (almost) all queries.
+// kPrepared: the caller vouches for q.spheres and q.thrA (a search of a mesh whose spheres are resident, its bounds taken by an
+// earlier launch) — the f64 paths that make spheres and bounds here are compiled out, and with them two thirds of the kernel's
+// registers (102 -> under 64: eight workgroups per CU instead of five; the batched filter launch lives on that)
+template <bool kPrepared = false>
 __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int by) {
   __shared__ float4 s_q[kSurfaceTile];
   __shared__ float s_thr[kSurfaceTile];
@@ -155,8 +160,12 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
   // out-of-range lanes: centre NaN — their squared distance is NaN and passes no threshold, not even an infinite one
   // (a query without a usable hint has bound +inf: everything in range is a candidate)
   f2_t cx = {__builtin_nanf(""), __builtin_nanf("")}, cy = cx, cz = cx, R = {0.f, 0.f};
-  if (v0) { const float4 s = q.spheres ? q.spheres[t0] : tri_sphere(q.verts, q.tris, q.order[t0]); cx.x = s.x; cy.x = s.y; cz.x = s.z; R.x = s.w; }
-  if (v1) { const float4 s = q.spheres ? q.spheres[t0 + 1] : tri_sphere(q.verts, q.tris, q.order[t0 + 1]); cx.y = s.x; cy.y = s.y; cz.y = s.z; R.y = s.w; }
+  auto sphere_at = [&](int t) {
+    if constexpr (kPrepared) return q.spheres[t];
+    else return q.spheres ? q.spheres[t] : tri_sphere(q.verts, q.tris, q.order[t]);
+  };
+  if (v0) { const float4 s = sphere_at(t0); cx.x = s.x; cy.x = s.y; cz.x = s.z; R.x = s.w; }
+  if (v1) { const float4 s = sphere_at(t0 + 1); cx.y = s.x; cy.y = s.y; cz.y = s.z; R.y = s.w; }
   // ---- the wave's ball (a sphere that is not finite — a triangle with a non-finite corner — passes no test by itself
   // and must not spoil the ball of its neighbours)
   auto finite4 = [](float a, float b, float c, float d) { return fabsf(a) + fabsf(b) + fabsf(c) + fabsf(d) <= 3.0e38f; };
@@ -190,9 +199,9 @@ __device__ __forceinline__ void surface_filter(const SurfaceTask& q, int bx, int
     const int nq = min(kSurfaceTile, k1 - kt);
     const long long fa = FLT_T();
     if (kt != k0) __syncthreads();
-    if (q.thrA) {
+    if (kPrepared || q.thrA) {
       for (int i = threadIdx.x; i < nq; i += kSearchBlock) { s_q[i] = q.qrec[kt + i]; s_thr[i] = q.thrA[kt + i]; }
-    } else {  // the bounds are taken here (the searched mesh was not complete when the step's first launch ran)
+    } else if constexpr (!kPrepared) {  // the bounds are taken here (the searched mesh was not complete when the step's first launch ran)
       for (int i = threadIdx.x; i < nq; i += kSearchBlock) {
         const int k = kt + i;
         float4 rec = make_float4(1e30f, 1e30f, 1e30f, 0.f);

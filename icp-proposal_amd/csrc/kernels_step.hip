@@ -23,6 +23,7 @@
 // it draws from.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "icp_kernels.hpp"
 #include "icp_search.hpp"
@@ -224,11 +225,14 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin_reg(StepBeginArgs a) 
 #ifdef ICP_FILTER_STAMPS
 extern "C" __attribute__((visibility("default"))) void icp_debug_filter_stamps(unsigned long long* out, int reset) {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_filter_stamps), sizeof(unsigned long long) * 16);
-  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_stamps), z, sizeof(z)); }
+  static unsigned long long h[kFltSlots][8];
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_filter_stamps), sizeof(h));
+  for (int i = 0; i < 8; ++i) { out[i] = 0; for (int s = 0; s < kFltSlots; ++s) out[i] += h[s][i]; }
+  if (reset) { std::memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_stamps), h, sizeof(h)); }
 }
 #endif
 
+template <bool kPrepared = false>
 __device__ __forceinline__ void step_filter_body(const StepSearchArgs& a, const int b) {
   int task = 0;
   while (task + 1 < a.n_surf + a.n_vert && b >= a.fstart[task + 1]) ++task;
@@ -236,7 +240,7 @@ __device__ __forceinline__ void step_filter_body(const StepSearchArgs& a, const 
   const int ksplit = task < a.n_surf ? a.s[task].ksplit : a.v[task - a.n_surf].ksplit;
   const int bx = l / (8 * ksplit) * 8 + (l & 7), by = (l % (8 * ksplit)) >> 3;  // see filter_grid_blocks
   if (task < a.n_surf) {
-    if (bx < a.s[task].tblocks) surface_filter(a.s[task], bx, by);
+    if (bx < a.s[task].tblocks) surface_filter<kPrepared>(a.s[task], bx, by);
   } else {
     if (bx < a.v[task - a.n_surf].vblocks) vertex_filter(a.v[task - a.n_surf], bx, by);
   }
@@ -404,10 +408,13 @@ __global__ void __launch_bounds__(kStepBlock) k_step_begin_batch_reg(const StepB
   if ((int)blockIdx.x >= step_begin_grid(a)) return;
   step_begin_body_reg<RMAX>(a, blockIdx.x);
 }
-__global__ void __launch_bounds__(kSearchBlock) k_step_filter_batch(const StepSearchArgs* __restrict__ batch) {
+// kPrepared: every surface task of every chain of the batch comes with its spheres and bounds (step_filter_prepared, checked by the
+// launcher on the host's copy of the arguments) — see surface_filter
+template <bool kPrepared>
+__global__ void __launch_bounds__(kSearchBlock, kPrepared ? 8 : 1) k_step_filter_batch(const StepSearchArgs* __restrict__ batch) {
   const StepSearchArgs& a = batch[blockIdx.y];
   if ((int)blockIdx.x >= a.fstart[a.n_surf + a.n_vert]) return;
-  step_filter_body(a, blockIdx.x);
+  step_filter_body<kPrepared>(a, blockIdx.x);
 }
 __global__ void __launch_bounds__(64) k_step_resolve_batch(const StepSearchArgs* __restrict__ batch) {
   const StepSearchArgs& a = batch[blockIdx.y];
@@ -536,10 +543,14 @@ inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 }  // namespace
 
 void launch_step_batch_resident(hipStream_t st, int B, const int gx[5], int r, const StepBeginArgs* begin, const StepSearchArgs* search,
-                                const StepRegressionArgs* regression, const StepFinishArgs* finish) {
+                                const StepRegressionArgs* regression, const StepFinishArgs* finish, bool filter_prepared) {
   if (B <= 0) return;
   if (gx[0] > 0) { ProfScope _ps(st, KID_STEP_BEGIN); hipLaunchKernelGGL(k_step_begin_batch, dim3(gx[0], B), dim3(kStepBlock), 0, st, begin); }
-  if (gx[1] > 0) { ProfScope _ps(st, KID_STEP_FILTER); hipLaunchKernelGGL(k_step_filter_batch, dim3(gx[1], B), dim3(kSearchBlock), 0, st, search); }
+  if (gx[1] > 0) {
+    ProfScope _ps(st, KID_STEP_FILTER);
+    if (filter_prepared) hipLaunchKernelGGL(k_step_filter_batch<true>, dim3(gx[1], B), dim3(kSearchBlock), 0, st, search);
+    else hipLaunchKernelGGL(k_step_filter_batch<false>, dim3(gx[1], B), dim3(kSearchBlock), 0, st, search);
+  }
   if (gx[2] > 0) { ProfScope _ps(st, KID_STEP_RESOLVE); hipLaunchKernelGGL(k_step_resolve_batch, dim3(gx[2], B), dim3(64), 0, st, search); }
   if (gx[3] > 0) { ProfScope _ps(st, KID_STEP_REGRESSION); hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, regression); }
   if (gx[4] > 0) {
@@ -798,7 +809,13 @@ void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pin
     else if (hold && r >= 32 && r <= 64 && !no_reg) hipLaunchKernelGGL(k_step_begin_batch_reg<64>, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d);
     else hipLaunchKernelGGL(k_step_begin_batch, dim3(gx[0], B), dim3(kStepBlock), 0, st, (const StepBeginArgs*)d);
   }
-  if (gx[1] > 0) { ProfScope _ps(st, KID_STEP_FILTER); hipLaunchKernelGGL(k_step_filter_batch, dim3(gx[1], B), dim3(kSearchBlock), 0, st, (const StepSearchArgs*)(d + o1)); }
+  if (gx[1] > 0) {
+    ProfScope _ps(st, KID_STEP_FILTER);
+    bool prepared = true;
+    for (int b = 0; b < B; ++b) prepared = prepared && step_filter_prepared(caps[b].search);
+    if (prepared) hipLaunchKernelGGL(k_step_filter_batch<true>, dim3(gx[1], B), dim3(kSearchBlock), 0, st, (const StepSearchArgs*)(d + o1));
+    else hipLaunchKernelGGL(k_step_filter_batch<false>, dim3(gx[1], B), dim3(kSearchBlock), 0, st, (const StepSearchArgs*)(d + o1));
+  }
   if (gx[2] > 0) { ProfScope _ps(st, KID_STEP_RESOLVE); hipLaunchKernelGGL(k_step_resolve_batch, dim3(gx[2], B), dim3(64), 0, st, (const StepSearchArgs*)(d + o1)); }
   if (gx[3] > 0) { ProfScope _ps(st, KID_STEP_REGRESSION); hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, (const StepRegressionArgs*)(d + o2)); }
   if (gx[4] > 0) {
