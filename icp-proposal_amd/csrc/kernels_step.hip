@@ -22,6 +22,7 @@
 // previous step raises when it starts (StepBeginArgs::wait_flag), and for the completion word of the eigen-decomposition
 // it draws from.
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 
@@ -653,19 +654,84 @@ __global__ void __launch_bounds__(64) k_mh_front(MhChain* __restrict__ chains) {
 __device__ __forceinline__ double mh_bcast(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// The kernel is one wave walking through memory it alone uses, so its time is the number of DEPENDENT trips there: everything the step's
+// outcome does not decide — the results, the state, the next step's mixture draw and normals, and the OTHER set's launch arguments and
+// decomposition records, which an accepted step switches to — is requested up front, behind the chain record's own words (two trips);
+// the outcome then only selects what is stored.  The arguments of the next step are written once, with the step's own entries
+// (propose / prop / zin) already in them; a rejected step, whose live arguments are those of its set already, writes only those.
 __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) {
+  typedef unsigned long long u64;
   MhChain& c = chains[blockIdx.x];
   if (c.error) return;
   const int lane = threadIdx.x;
-  const int r = c.r, P = 10 + r, n_icp = c.n_icp;
+  const int r = c.r, P = 10 + r, n_icp = c.n_icp, cur_sel = c.cur_sel, other = cur_sel ^ 1;
+  const long long step = c.step;
+  const u64 seed = c.seed;
+  const double cur_p = c.cur_p, rw_sigma = c.rw_sigma;
   const double ninf = -__builtin_inf();
+  const bool has_next = step + 1 - c.normals_first < (long long)c.normals_rows;  // (uniform) the next step's normals are on the device
+  // the NEXT step's mixture draw (MixtureProposal.propose, as mh_front_body): an integer hash of the step number
+  int gen_n = -1, leaf_n = 2;
+  {
+    const int o = mh_pick(c.n_outer, c.outer_w, mh_uniform(seed, (u64)(step + 1), 0));
+    if (c.outer_kind[o] == 1) { gen_n = mh_pick(n_icp, c.icp_w, mh_uniform(seed, (u64)(step + 1), 1)); leaf_n = gen_n; }
+  }
+  // ---- the step's results and the chain's state
   const double cpj = lane < r ? c.coeff_prop[lane] : 0.0;   // proposed coefficients (launch 1's copy in the state slot)
   const double thj = lane < r ? c.theta[10 + lane] : 0.0;   // current ones
-  int err = 0;
-  for (int i = 0; i < n_icp; ++i) {
-    if (c.chol_status[i] != 0) err = 3;
-    else if (c.tail_status[2 * i] != 0 || c.tail_status[2 * i + 1] != 0) err = err ? err : 2;
+  const double thp = lane < 10 ? c.theta[lane] : 0.0;       // the pose (never changes here)
+  const int st_chol = lane < n_icp ? c.chol_status[lane] : 0;
+  const int st_tail = lane < 2 * n_icp ? c.tail_status[lane] : 0;
+  const double resv = lane < 8 ? c.red[lane] : 0.0;
+  const double tlv = lane < 2 * n_icp ? c.tails[lane] : 0.0;
+  const int seqv = lane < n_icp ? c.eig_seq[lane] : 0;
+  const double zn = (has_next && lane < r) ? c.normals[(size_t)(step + 1 - c.normals_first) * r + lane] : 0.0;
+  // ---- the other set's records, by 8-byte words
+  constexpr int kWB = sizeof(StepBeginArgs) / 8, kWS = sizeof(StepSearchArgs) / 8, kWR = sizeof(StepRegressionArgs) / 8, kWF = sizeof(StepFinishArgs) / 8;
+  constexpr int kPB = (kWB + 63) / 64, kPS = (kWS + 63) / 64, kPR = (kWR + 63) / 64, kPF = (kWF + 63) / 64;
+  constexpr int kWE = sizeof(EigenProblem) / 8, kWP = sizeof(ProposeIn) / 8;
+  static_assert(sizeof(StepBeginArgs) % 8 == 0 && sizeof(StepSearchArgs) % 8 == 0 && sizeof(StepRegressionArgs) % 8 == 0 && sizeof(StepFinishArgs) % 8 == 0 &&
+                sizeof(EigenProblem) % 8 == 0 && sizeof(ProposeIn) % 8 == 0, "records are moved in 8-byte words");
+  static_assert(2 * kWE <= 64 && 4 * kWP <= 64, "one lane per word of the decomposition records / proposal inputs");
+  constexpr int kOffPropose = offsetof(StepBeginArgs, propose) / 8, kOffProp = offsetof(StepBeginArgs, prop) / 8, kOffZin = offsetof(StepBeginArgs, zin) / 8;
+  static_assert(offsetof(StepBeginArgs, propose) % 8 == 0 && offsetof(StepBeginArgs, prop) == offsetof(StepBeginArgs, propose) + 8 &&
+                offsetof(StepBeginArgs, zin) % 8 == 0 && offsetof(StepBeginArgs, prop) % 8 == 0, "layout of the per-step entries of StepBeginArgs");
+  constexpr int kOffVwarm = offsetof(EigenProblem, Vwarm) / 8, kOffLaunch = offsetof(EigenProblem, launch_id) / 8, kOffDone = offsetof(EigenProblem, done_value) / 8;
+  static_assert(offsetof(EigenProblem, launch_id) % 8 == 0 && offsetof(EigenProblem, done_value) % 8 == 0, "the two ints lead their words");
+  u64 wb[kPB], ws[kPS], wr[kPR], wf[kPF];
+  if (has_next) {
+    const u64* sb = (const u64*)c.begin_alt[other];
+    const u64* ss = (const u64*)c.search_alt[other];
+    const u64* sr = (const u64*)c.regression_alt[other];
+    const u64* sf = (const u64*)c.finish_alt[other];
+#pragma unroll
+    for (int p = 0; p < kPB; ++p) wb[p] = lane + 64 * p < kWB ? sb[lane + 64 * p] : 0ull;
+#pragma unroll
+    for (int p = 0; p < kPS; ++p) ws[p] = lane + 64 * p < kWS ? ss[lane + 64 * p] : 0ull;
+#pragma unroll
+    for (int p = 0; p < kPR; ++p) wr[p] = lane + 64 * p < kWR ? sr[lane + 64 * p] : 0ull;
+#pragma unroll
+    for (int p = 0; p < kPF; ++p) wf[p] = lane + 64 * p < kWF ? sf[lane + 64 * p] : 0ull;
+  } else {
+#pragma unroll
+    for (int p = 0; p < kPB; ++p) wb[p] = 0ull;
+#pragma unroll
+    for (int p = 0; p < kPS; ++p) ws[p] = 0ull;
+#pragma unroll
+    for (int p = 0; p < kPR; ++p) wr[p] = 0ull;
+#pragma unroll
+    for (int p = 0; p < kPF; ++p) wf[p] = 0ull;
   }
+  const int ei = lane / kWE, ew = lane - ei * kWE;  // lane -> (decomposition record, word)
+  const u64 eigw = ei < n_icp ? ((const u64*)&c.eig_alt[other][ei])[ew] : 0ull;
+  // proposal inputs of the next step: blocks 0, 1 = prop_alt[set][its proposal]; 2, 3 = the entry the set's own arguments carry (a
+  // step that proposes by the random walk leaves that one in place)
+  const int pb = lane / kWP, pw = lane - pb * kWP;
+  u64 propw = 0ull;
+  if (has_next && pb < 4) propw = pb < 2 ? ((const u64*)&c.prop_alt[pb][gen_n < 0 ? 0 : gen_n])[pw] : ((const u64*)&c.begin_alt[pb - 2]->prop)[pw];
+
+  const unsigned long long bad_chol = __ballot(st_chol != 0), bad_tail = __ballot(st_tail != 0);
+  int err = bad_chol ? 3 : (bad_tail ? 2 : 0);
   // ---- evaluators: ModelPriorEvaluator (:24-31), the likelihood from launch 4's reductions (finish_eval), ProductEvaluator
   double nn = 0.0, dd = 0.0, dd_b = 0.0;
   for (int j = 0; j < r; ++j) {
@@ -675,7 +741,9 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
     const double e = tj - cj; dd_b += e * e;      // … and the other way
   }
   const double prior = -0.5 * nn - c.prior_c;
-  const double* res = c.red;
+  double res[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) res[k] = mh_bcast(resv, k);
   double lik;
   if (c.eval_kind == 0) {  // IndependentPointDistanceEvaluator.scala:60-64
     const double m2t = res[0], t2m = res[4];
@@ -698,11 +766,11 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   // ---- transition ratio: every leaf's density both ways, log-sum-exp through the mixture tree
   double fw_i[2] = {ninf, ninf}, bw_i[2] = {ninf, ninf};
   for (int i = 0; i < n_icp; ++i) {
-    fw_i[i] = c.tails[2 * i]; bw_i[i] = c.tails[2 * i + 1];
+    fw_i[i] = mh_bcast(tlv, 2 * i); bw_i[i] = mh_bcast(tlv, 2 * i + 1);
     if ((!(fw_i[i] == fw_i[i]) || !(bw_i[i] == bw_i[i])) && !err) err = 4;
   }
-  const double rw_t = -0.5 * dd / (c.rw_sigma * c.rw_sigma) - c.rw_logc;
-  const double rw_tb = -0.5 * dd_b / (c.rw_sigma * c.rw_sigma) - c.rw_logc;
+  const double rw_t = -0.5 * dd / (rw_sigma * rw_sigma) - c.rw_logc;
+  const double rw_tb = -0.5 * dd_b / (rw_sigma * rw_sigma) - c.rw_logc;
   double of[2] = {ninf, ninf}, ob[2] = {ninf, ninf};
   for (int o = 0; o < c.n_outer; ++o) {
     if (c.outer_kind[o] == 1) { of[o] = mh_lse(n_icp, c.icp_w, fw_i); ob[o] = mh_lse(n_icp, c.icp_w, bw_i); }
@@ -718,44 +786,69 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
     return;
   }
   const double t = (fw == ninf && bw == ninf) ? 0.0 : fw - bw;
-  const double a = prop_p - c.cur_p - t;
-  const long long step = c.step;
-  const bool acc = a > 0.0 || mh_uniform(c.seed, (unsigned long long)step, 2) < exp(a);
+  const double a = prop_p - cur_p - t;
+  const bool acc = a > 0.0 || mh_uniform(seed, (u64)step, 2) < exp(a);
   // ---- state, record (host/icp_host.h: [index, status, leaf, log value of the state after the step, theta])
-  const double new_p = acc ? prop_p : c.cur_p;
-  const int new_sel = acc ? c.cur_sel ^ 1 : c.cur_sel;
+  const double new_p = acc ? prop_p : cur_p;
+  const int new_sel = acc ? other : cur_sel;
   if (acc && lane < r) c.theta[10 + lane] = cpj;
   if (c.records) {
     double* rec = c.records + (size_t)(step - c.rec_first) * (4 + P);
     if (lane == 0) { rec[0] = (double)step; rec[1] = acc ? 1.0 : 0.0; rec[2] = (double)c.leaf; rec[3] = new_p; }
-    if (lane < 10) rec[4 + lane] = c.theta[lane];
+    if (lane < 10) rec[4 + lane] = thp;
     if (lane < r) rec[14 + lane] = acc ? cpj : thj;
   }
   // ---- the KL bases of an accepted state's posteriors (both directions), as icp_chain_step_batched starts them
-  if (lane < n_icp) {
-    const int i = lane;
-    if (!acc) c.eig_skip[i] = 1;
-    else {
-      const int q = c.eig_seq[i] + 1;
-      c.eig_seq[i] = q;
-      EigenProblem rec = c.eig_alt[new_sel][i];
-      if (((q + 1) & 127) == 0) rec.Vwarm = nullptr;  // every 128th cold (icp_proposal::prepare_eigen)
-      rec.launch_id = 1 + (int)((unsigned)q % (unsigned)c.pw_id_mask);
-      rec.done_value = q;
-      c.eig_live[i] = rec;
-      c.eig_skip[i] = 0;
+  {
+    const int q = __shfl(seqv, ei < n_icp ? ei : 0, 64) + 1;  // this lane's record: its decomposition number
+    if (acc && ei < n_icp) {
+      u64 v = eigw;
+      if (ew == kOffVwarm && ((q + 1) & 127) == 0) v = 0ull;  // every 128th cold (icp_proposal::prepare_eigen)
+      if (ew == kOffLaunch) v = (v & 0xffffffff00000000ull) | (u64)(unsigned)(1 + (int)((unsigned)q % (unsigned)c.pw_id_mask));
+      if (ew == kOffDone) v = (v & 0xffffffff00000000ull) | (u64)(unsigned)q;
+      ((u64*)&c.eig_live[ei])[ew] = v;
+    }
+    if (lane < n_icp) {
+      c.eig_skip[lane] = acc ? 0 : 1;
+      if (acc) c.eig_seq[lane] = seqv + 1;
     }
   }
   if (lane == 0) {
     if (acc) { c.cur_p = prop_p; c.cur_sel = new_sel; ++c.accepted; }
     c.step = step + 1;
   }
-  // ---- the head of the NEXT step, while its normals are on the device (one launch and its boundary less per step)
-  const bool has_next = step + 1 - c.normals_first < (long long)c.normals_rows;  // (uniform)
+  // ---- the head of the NEXT step, while its normals are on the device (one launch and its boundary less per step): mh_front_body with
+  // everything in registers already
   if (has_next) {
-    __threadfence_block();
-    __syncthreads();
-    mh_front_body(c, lane);
+    if (lane == 0) { c.gen = gen_n; c.leaf = leaf_n; }
+    // ICP: posterior.sample()'s standard normals (NonRigidIcpProposal.scala:55); shape walk: the sample itself, c + σ·z
+    // (RandomShapeUpdateProposal.scala:31-35)
+    const double zval = gen_n >= 0 ? zn : (acc ? cpj : thj) + rw_sigma * zn;
+    const int pbase = (gen_n >= 0 ? new_sel : 2 + new_sel) * kWP;  // where this step's proposal inputs sit among the lanes
+    u64* db = (u64*)c.begin_live;
+#pragma unroll
+    for (int p = 0; p < kPB; ++p) {
+      const int w = lane + 64 * p;
+      const bool is_prop = w >= kOffProp && w < kOffProp + kWP, is_z = w >= kOffZin && w < kOffZin + r, is_flag = w == kOffPropose;
+      const u64 pv = __shfl(propw, is_prop ? pbase + (w - kOffProp) : 0, 64);
+      const double zv = __shfl(zval, is_z ? w - kOffZin : 0, 64);
+      u64 v = wb[p];
+      if (is_prop) v = pv;
+      if (is_z) v = (u64)__double_as_longlong(zv);
+      if (is_flag) v = (u64)(unsigned)(gen_n >= 0 ? 1 : 0);
+      if (w < kWB && (acc || is_prop || is_z || is_flag)) db[w] = v;
+    }
+    if (acc) {  // (uniform) the other set's searches, regression and finish
+      u64* ds = (u64*)c.search_live;
+      u64* dr = (u64*)c.regression_live;
+      u64* df = (u64*)c.finish_live;
+#pragma unroll
+      for (int p = 0; p < kPS; ++p) if (lane + 64 * p < kWS) ds[lane + 64 * p] = ws[p];
+#pragma unroll
+      for (int p = 0; p < kPR; ++p) if (lane + 64 * p < kWR) dr[lane + 64 * p] = wr[p];
+#pragma unroll
+      for (int p = 0; p < kPF; ++p) if (lane + 64 * p < kWF) df[lane + 64 * p] = wf[p];
+    }
   }
 }
 
