@@ -91,7 +91,10 @@ __global__ void __launch_bounds__(kBlock) k_tri_spheres(int T, const double* __r
 }
 
 __global__ void __launch_bounds__(kBlock) k_surface_init(SurfaceTask q) { surface_init(q, blockIdx.x * kBlock + threadIdx.x); }
-__global__ void __launch_bounds__(kBlock) k_surface_filter(SurfaceTask q) { surface_filter(q, blockIdx.x, blockIdx.y); }
+// kPrepared: resident spheres, bounds taken by k_surface_init (every query of this file's launcher that hands spheres in): the form of
+// the filter without the f64 sphere / bound paths — 38 registers instead of 96, eight workgroups per CU (see surface_filter)
+template <bool kPrepared>
+__global__ void __launch_bounds__(kBlock, kPrepared ? 8 : 1) k_surface_filter(SurfaceTask q) { surface_filter<kPrepared>(q, blockIdx.x, blockIdx.y); }
 __global__ void __launch_bounds__(64) k_surface_resolve(SurfaceTask q) {
   double best; int tri; d3 cp;
   surface_resolve(q, blockIdx.x, &best, &tri, &cp);
@@ -252,7 +255,8 @@ void launch_surface_query(hipStream_t st, int T, const double* verts, const int*
       hipLaunchKernelGGL(k_surface_init, dim3(cdiv(q.Kpad, kBlock)), dim3(kBlock), 0, st, q); }
     if (T > 0) {
       ProfScope _ps(st, KID_SURFACE_FILTER);
-      hipLaunchKernelGGL(k_surface_filter, dim3(q.tblocks, q.ksplit), dim3(kBlock), 0, st, q);
+      if (q.spheres != nullptr && q.thrA != nullptr) hipLaunchKernelGGL(k_surface_filter<true>, dim3(q.tblocks, q.ksplit), dim3(kBlock), 0, st, q);
+      else hipLaunchKernelGGL(k_surface_filter<false>, dim3(q.tblocks, q.ksplit), dim3(kBlock), 0, st, q);
     }
     { ProfScope _ps(st, KID_SURFACE_RESOLVE);
       hipLaunchKernelGGL(k_surface_resolve, dim3(kb), dim3(64), 0, st, q); }
