@@ -3913,9 +3913,12 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
         launch_mh_set_normals(gr.st, gr.B, gr.mh.p, gr.normals[buf].p, kChunk * r, s0, ns);
       }
       // The chip-wide launches of two groups side by side slow each other down more than the overlap gains; what
-      // should run beside a group's chip-wide launches 1-4 is the OTHER group's small ones (launch 5 on four CUs per chain, the
-      // decide kernel, the decompositions on five CUs each).  So launches 1-4 pass a token from group to group: a group's first
-      // launch waits for the event behind the previous group's launch 4.
+      // should run beside a group's chip-wide launches is the OTHER group's small ones (launch 5 on four CUs per chain, the
+      // decide kernel, the decompositions on three CUs each).  So the launches pass a token from group to group: a group's first
+      // launch waits for an event of the previous group's.  Which one: behind launch 4 while the filter launch held five workgroups per
+      // CU; with eight (§5.1c) behind launch 2 — the other group's begin and filter beside this group's resolve and regression, two
+      // chains of latencies that leave the CUs room — measures best with 32 chains per group (202.0k it/s at 64 chains against 197.3k
+      // behind launch 4, 199.0k without a token), behind launch 1 with 64 per group (249.5k at 128 chains against 244.7k / 241.5k).
       for (int s_ = 0; s_ < ns; ++s_)
         for (int g = 0; g < n_groups; ++g) {
           Group& gr = groups[g];
@@ -3924,10 +3927,16 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
             if (blk > 0 || s_ > 0 || g > 0) HIP_OK(hipStreamWaitEvent(gr.st, prev.ev_big, 0));
           }
           if (s_ == 0) launch_mh_front(gr.st, gr.B, gr.mh.p);  // (later steps of the block: prepared by the decide kernel of the step before)
-          int g4[5] = {gr.grid[0], gr.grid[1], gr.grid[2], gr.grid[3], 0};
-          launch_step_batch_resident(gr.st, gr.B, g4, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p,
-                                     gr.filter_prepared);
-          if (n_groups > 1) HIP_OK(hipEventRecord(gr.ev_big, gr.st));
+          const int token_at = gr.B >= 64 ? 1 : 2;
+          {
+            int ga[5] = {0, 0, 0, 0, 0}, gb[5] = {0, 0, 0, 0, 0};
+            for (int q = 0; q < 4; ++q) (q < token_at ? ga : gb)[q] = gr.grid[q];
+            if (token_at > 0)
+              launch_step_batch_resident(gr.st, gr.B, ga, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p, gr.filter_prepared);
+            if (n_groups > 1) HIP_OK(hipEventRecord(gr.ev_big, gr.st));
+            if (token_at < 4)
+              launch_step_batch_resident(gr.st, gr.B, gb, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p, gr.filter_prepared);
+          }
           int g5[5] = {0, 0, 0, 0, gr.grid[4]};
           launch_step_batch_resident(gr.st, gr.B, g5, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p);
           launch_mh_decide(gr.st, gr.B, gr.mh.p);
