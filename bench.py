@@ -469,7 +469,7 @@ def main():
             except Exception as e:
                 dk = {"error": str(e)[:200]}
             line["many_chains"] = {"chains_per_gpu": nB, "value": nB * n_m / mdt, "unit": "iterations/s", "steps_per_chain": n_m, "distance_kernel": dk,
-                                   "entry_point": "icp_chains_run_on_device (the whole MH loop on the device: DESIGN §5.1c) from 48 chains on, "
+                                   "entry_point": "icp_chains_run_on_device (the whole MH loop on the device: DESIGN §5.1c) from 24 chains on, "
                                                   "icp_chain_step_batched below"}
             for ch in mch:
                 ch.close()

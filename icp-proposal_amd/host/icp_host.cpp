@@ -416,12 +416,12 @@ struct LockstepGroup {
 
 // -> ICP_OK: the chains have advanced n_steps on the device; anything else: nothing has happened (the caller steps them on the host)
 static int run_on_device(icp_host_chain* const* chains, int32_t n_chains, int32_t n_steps, double* const* records, int32_t* steps_done_out) {
-  // ICP_HOST_DEVICE_LOOP: 0 never, 1 whenever covered, unset: from 48 chains on — a group's step is a serial chain of ≈ 350 µs on the
+  // ICP_HOST_DEVICE_LOOP: 0 never, 1 whenever covered, unset: from 24 chains on — a group's step is a serial chain of ≈ 300 µs on the
   // device whatever its size (launches 1-5, the decide kernel, the decompositions of the chains that moved), which two groups overlap:
-  // 64 chains 162-174k it/s against 143-146k host-stepped, 128 chains 197-209k; 32 chains 112k either way, 16 chains 65k against 72k
-  // (the host-stepped form lets every chain's first launch wait for its own decomposition only)
+  // 64 chains ≈ 200k it/s against ≈ 150k host-stepped, 128 chains ≈ 245k, 32 chains 128k against 113k; 16 chains 75k against 74k, 8 chains
+  // 41k against 43k (the host-stepped form lets every chain's first launch wait for its own decomposition only)
   static const int mode = std::getenv("ICP_HOST_DEVICE_LOOP") ? std::atoi(std::getenv("ICP_HOST_DEVICE_LOOP")) : -1;
-  if (mode == 0 || (mode < 0 && n_chains < 48)) return ICP_ERR_INVALID_ARG;
+  if (mode == 0 || (mode < 0 && n_chains < 24)) return ICP_ERR_INVALID_ARG;
   icp_host_chain* c0 = chains[0];
   if (!c0) return ICP_ERR_INVALID_ARG;
   const size_t n_icp = c0->icp.size();
@@ -500,7 +500,7 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
   if (chains && n_chains == 1 && chains[0]) return icp_host_chain_run(chains[0], n_steps, records ? records[0] : nullptr);
   // pose-free mixtures: the whole loop on the device (icp_chains_run_on_device: mixture draw, proposals' inputs, MetropolisHastings.next
   // and the records by kernels of the step's own stream; the host only enqueues).  What it does not cover (and, by default, fewer
-  // than 48 chains: see run_on_device) comes back with ICP_ERR_INVALID_ARG and takes the lockstep path below.
+  // than 24 chains: see run_on_device) comes back with ICP_ERR_INVALID_ARG and takes the lockstep path below.
   std::vector<double*> rest;  // (records of the steps the device loop did not take)
   if (chains && n_chains >= 1 && n_steps > 0) {
     int32_t n_dev = 0;
