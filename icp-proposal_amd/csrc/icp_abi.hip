@@ -3700,8 +3700,12 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       ch.busy = true;
       ch.lk.unlock();
     }
-    // ---- groups: each its own stream, everything of a group in order on it; two groups overlap each other's small launches
-    const int n_groups = n_chains >= 16 ? 2 : 1;
+    // ---- groups: each its own stream, everything of a group in order on it; the groups overlap each other's launches
+    // (three since the token moved forward, §5.1c: 64 chains 202k it/s in two groups, 211k in three; 128 chains 251k / 257k; 32 chains 130k /
+    // 135k; 24 chains 104k / 108k.  Four — a fourth stream made with every context — measured 218k / 266k / 137k / 109k, but the extra
+    // stream shifts every context's streams over the runtime's hardware queues, and the host-stepped lockstep path's decompositions, which
+    // wait on the device for launches of other streams, then ran into their time-outs: 15 of them in a 50-chain test.  Not adopted.)
+    const int n_groups = n_chains >= 16 ? 3 : 1;
     struct Group {
       int b0 = 0, B = 0;
       hipStream_t st = nullptr;
@@ -3743,10 +3747,11 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       Group& gr = groups[g];
       gr.b0 = (int)((long long)g * n_chains / n_groups);
       gr.B = (int)((long long)(g + 1) * n_chains / n_groups) - gr.b0;
-      // the first chain's two step streams: created side by side with the context, they sit on different hardware queues and run
-      // beside each other (streams of DIFFERENT contexts may share a queue: the runtime multiplexes streams onto a handful of them,
-      // and two groups on one queue alternate in ~55 µs slices — every kernel of the step then "takes" a multiple of that)
-      gr.st = g == 0 ? lead.stream : lead.front_stream;
+      // the first chain's three streams: created one after the other with the context, they sit on different hardware queues and run
+      // beside each other (streams of DIFFERENT contexts, or streams made later, may share a queue: the runtime multiplexes streams
+      // onto a handful of them, and two groups on one queue alternate in ~55 µs slices — every kernel of the step then "takes" a
+      // multiple of that: eight streams made for the purpose on first use ran two groups at 116k it/s instead of 202k)
+      gr.st = g == 0 ? lead.stream : g == 1 ? lead.front_stream : lead.eig_stream;
       const int B = gr.B;
       gr.begin_alt.alloc(2 * B); gr.begin_live.alloc(B);
       gr.search_alt.alloc(2 * B); gr.search_live.alloc(B);
@@ -3917,8 +3922,9 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       // decide kernel, the decompositions on three CUs each).  So the launches pass a token from group to group: a group's first
       // launch waits for an event of the previous group's.  Which one: behind launch 4 while the filter launch held five workgroups per
       // CU; with eight (§5.1c) behind launch 2 — the other group's begin and filter beside this group's resolve and regression, two
-      // chains of latencies that leave the CUs room — measures best with 32 chains per group (202.0k it/s at 64 chains against 197.3k
-      // behind launch 4, 199.0k without a token), behind launch 1 with 64 per group (249.5k at 128 chains against 244.7k / 241.5k).
+      // chains of latencies that leave the CUs room — measures best (two groups of 32 chains: 202.0k it/s against 197.3k behind launch
+      // 4, 199.0k without a token; four groups of 16, on a build with a fourth stream: 216.2k against 215.0k behind launch 1, 206.3k
+      // without, 199.6k behind launch 3, 167.9k behind launch 4); behind launch 1 with 64 per group (two groups of 64: 249.5k against 244.7k / 241.5k).
       for (int s_ = 0; s_ < ns; ++s_)
         for (int g = 0; g < n_groups; ++g) {
           Group& gr = groups[g];
