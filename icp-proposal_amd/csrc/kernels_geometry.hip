@@ -91,6 +91,15 @@ __global__ void __launch_bounds__(kBlock) k_tri_spheres(int T, const double* __r
 }
 
 __global__ void __launch_bounds__(kBlock) k_surface_init(SurfaceTask q) { surface_init(q, blockIdx.x * kBlock + threadIdx.x); }
+#ifdef ICP_FILTER_STAMPS  // (developer aid, see icp_search.hpp: this translation unit's sums — the per-stage surface queries)
+extern "C" __attribute__((visibility("default"))) void icp_debug_filter_stamps_geometry(unsigned long long* out, int reset) {
+  (void)hipDeviceSynchronize();
+  static unsigned long long h[kFltSlots][8];
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_filter_stamps), sizeof(h));
+  for (int i = 0; i < 8; ++i) { out[i] = 0; for (int s = 0; s < kFltSlots; ++s) out[i] += h[s][i]; }
+  if (reset) { for (auto& row : h) for (auto& v : row) v = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_stamps), h, sizeof(h)); }
+}
+#endif
 // kPrepared: resident spheres, bounds taken by k_surface_init (every query of this file's launcher that hands spheres in): the form of
 // the filter without the f64 sphere / bound paths — 38 registers instead of 96, eight workgroups per CU (see surface_filter)
 template <bool kPrepared>
