@@ -1497,8 +1497,14 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     }
     ctx->shared_model = sm;
     if (g_model_keep[0] != sm && g_model_keep[1] != sm) {
+      std::shared_ptr<SharedModel> evicted = std::move(g_model_keep[g_model_keep_next]);
       g_model_keep[g_model_keep_next] = sm;
       g_model_keep_next ^= 1;
+      if (evicted && evicted.use_count() == 1 && evicted->device != device) {  // its last owner: freed under its own device
+        (void)hipSetDevice(evicted->device);
+        evicted.reset();
+        (void)hipSetDevice(device);
+      }
     }
     ctx->n_boundary = sm->n_boundary;
     ctx->ref.alias(sm->ref); ctx->mean.alias(sm->mean); ctx->Q.alias(sm->Q); ctx->Qp.alias(sm->Qp);
@@ -1571,10 +1577,13 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
 
 void icp_release_cached_models(void) {
   std::lock_guard<std::mutex> lk(g_shared_mu);
+  int caller_device = -1;  // (a model's buffers are freed under ITS device; the caller's current device is put back afterwards)
+  const bool have_device = hipGetDevice(&caller_device) == hipSuccess;
   for (int i = 0; i < 2; ++i) {
     if (g_model_keep[i]) (void)hipSetDevice(g_model_keep[i]->device);
     g_model_keep[i].reset();
   }
+  if (have_device) (void)hipSetDevice(caller_device);
 }
 
 void icp_ctx_destroy(icp_ctx* ctx) {
@@ -2020,7 +2029,16 @@ int icp_proposal_set_sampler(icp_proposal* p, int32_t sampler) {
     sync_eigen(c);
     for (icp_evaluator* ev : c.evaluators)
       if (ev->front.valid && (ev->front.props[0] == p || ev->front.props[1] == p)) release_front(ev->front);
-    for (int i = 0; i < kPosteriorMemo; ++i) { p->memo[i].eig_valid = false; p->memo[i].eig_checked = false; }
+    // Ranks above 64 have no decomposition of the root kind: there the posterior's own factorisation hands the factor out
+    // (PosteriorFactorIO::Lout / Sout, written only when the posterior is computed), and the eigen route has no `root` form.  A
+    // memoised posterior would be a memo hit that never rewrites V / S the new way — the sampler would draw from one kind of
+    // buffer read as the other.  Those entries are forgotten altogether: the next use recomputes the posterior under the new sampler.
+    const bool refactor = !eigen_speculation_supported(c.r);
+    for (int i = 0; i < kPosteriorMemo; ++i) {
+      p->memo[i].eig_valid = false; p->memo[i].eig_checked = false; p->memo[i].eig_event_valid = false;
+      if (refactor) p->memo[i].valid = false;
+    }
+    p->side_parts = nullptr; p->side_parts_entry = nullptr;
     p->spec_entry = nullptr;
     p->warm_valid = false;
     p->sampler = sampler;
@@ -3972,8 +3990,26 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       }
       fail(first_error == 3 ? ICP_ERR_NOT_SPD : first_error == 5 ? ICP_ERR_EMPTY : ICP_ERR_NOT_FINITE,
            first_error == 2 ? "on-device loop: a transition tail did not contract (step these chains through icp_chain_step_batched)"
-                            : "on-device loop: a chain stopped on a non-finite, empty or non-positive-definite result");
+           : first_error == 6 ? "on-device loop: posterior eigen-decomposition did not converge"
+                              : "on-device loop: a chain stopped on a non-finite, empty or non-positive-definite result");
     }
+    // the decompositions behind the LAST step's decisions have no decide kernel behind them: their status (pinned, written by the
+    // decomposition itself) is looked at here, before the sets are booked as decomposed and checked
+    for (int g = 0; g < n_groups; ++g)
+      for (int k = 0; k < groups[g].B; ++k) {
+        Chain& ch = chains[groups[g].b0 + k];
+        const MhChain& m = hms[g][k];
+        for (int i = 0; i < n_props; ++i) {
+          const int st = ch.props[i]->h_eig[ch.set[m.cur_sel][i]->status_off / 3];
+          if (st != 0) {
+            std::lock_guard<std::recursive_mutex> lk(ch.e->ctx->mu);
+            for (int sel = 0; sel < 2; ++sel) { ch.set[sel][i]->valid = false; ch.set[sel][i]->eig_valid = false; ch.set[sel][i]->eig_checked = false; }
+            ch.props[i]->warm_valid = false;
+            ch.props[i]->spec_entry = nullptr;
+            fail(ICP_ERR_NOT_FINITE, "on-device loop: posterior eigen-decomposition did not converge");
+          }
+        }
+      }
     for (int g = 0; g < n_groups; ++g) {
       Group& gr = groups[g];
       std::vector<double> hth((size_t)gr.B * P);

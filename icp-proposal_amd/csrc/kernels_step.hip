@@ -685,6 +685,10 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   const double resv = lane < 8 ? c.red[lane] : 0.0;
   const double tlv = lane < 2 * n_icp ? c.tails[lane] : 0.0;
   const int seqv = lane < n_icp ? c.eig_seq[lane] : 0;
+  // the status word of the decomposition the CURRENT state's posteriors went through (written by the launch behind an earlier step's
+  // decision, ahead of this kernel in stream order; 2 = the iteration did not converge): proposals drawn from such a basis are not
+  // the reference's — the chain stops, as the host-stepped path does (chain_step_record -> check_status)
+  const int st_eig = lane < n_icp ? c.eig_alt[cur_sel][lane].status[0] : 0;
   const double zn = (has_next && lane < r) ? c.normals[(size_t)(step + 1 - c.normals_first) * r + lane] : 0.0;
   // ---- the other set's records, by 8-byte words
   constexpr int kWB = sizeof(StepBeginArgs) / 8, kWS = sizeof(StepSearchArgs) / 8, kWR = sizeof(StepRegressionArgs) / 8, kWF = sizeof(StepFinishArgs) / 8;
@@ -732,6 +736,7 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
 
   const unsigned long long bad_chol = __ballot(st_chol != 0), bad_tail = __ballot(st_tail != 0);
   int err = bad_chol ? 3 : (bad_tail ? 2 : 0);
+  if (__ballot(st_eig != 0) && !err) err = 6;
   // ---- evaluators: ModelPriorEvaluator (:24-31), the likelihood from launch 4's reductions (finish_eval), ProductEvaluator
   double nn = 0.0, dd = 0.0, dd_b = 0.0;
   for (int j = 0; j < r; ++j) {
