@@ -72,6 +72,35 @@ def launch_ranks(args, argv):
         raise SystemExit("rank processes failed: " + ", ".join(f"rank {rk} -> exit {rc}" for rk, rc in bad))
 
 
+def rank_report(dist, torch, rank, world, local_rank, chain_ms, gather_ms, cpu=False):
+    """What every rank of the job held and how long it took, gathered over the job's own communicator: `rccl_ranks` is the size the
+    COMMUNICATOR reports (not the launcher's environment), `ranks` one entry per rank with its device ordinal, an identity of the
+    physical GPU (uuid, or PCI address where the build has none), its chain and gather times.  Two ranks on one physical device
+    fail the run: a scaling curve measured that way is not one."""
+    if dist is None:
+        ident = device_identity(torch, local_rank, cpu)
+        return {"rccl_ranks": 1, "backend": None, "ranks": [dict(rank=0, local_rank=local_rank, chain_ms=chain_ms, log_gather_ms=gather_ms, **ident)]}
+    mine = dict(rank=rank, local_rank=local_rank, chain_ms=chain_ms, log_gather_ms=gather_ms, **device_identity(torch, local_rank, cpu))
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    gpus = [e["gpu"] for e in everyone]
+    if len(set(gpus)) != len(gpus):
+        raise SystemExit("two ranks hold the same device: " + json.dumps(everyone))
+    if dist.get_world_size() != world:
+        raise SystemExit("the communicator has %d ranks, the launcher announced %d" % (dist.get_world_size(), world))
+    return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "ranks": everyone}
+
+
+def device_identity(torch, local_rank, cpu=False):
+    if cpu or torch is None:
+        return {"device": "cpu", "gpu": "cpu-process-%d" % os.getpid(), "name": "host"}
+    pr = torch.cuda.get_device_properties(local_rank)
+    ident = getattr(pr, "uuid", None)
+    if ident is None or not str(ident).strip("0-"):  # (builds without a uuid, or an all-zero one: the PCI address)
+        ident = "pci-%s:%s:%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", "?"))
+    return {"device": "cuda:%d" % torch.cuda.current_device(), "gpu": str(ident), "name": pr.name}
+
+
 def selftest_launcher_rank():
     """Body of a rank under --selftest-launcher (CPU, gloo): exercises the launcher's environment, the barrier-bracketed timing
     and the gather; prints the same kind of line from rank 0.  Used by tests/test_bench_launcher_cpu.py (no GPU there)."""
@@ -92,8 +121,9 @@ def selftest_launcher_rank():
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     ok = all(float(o[0, 0]) == float(k) for k, o in enumerate(out))
+    rep = rank_report(dist, None, rank, world, int(os.environ.get("LOCAL_RANK", "0")), 1e3 * float(dt.item()), 0.0, cpu=True)
     if rank == 0:
-        print(json.dumps({"selftest": "launcher", "n_gpus": world, "gather_ok": ok, "max_s": float(dt.item())}))
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "gather_ok": ok, "max_s": float(dt.item()), "multi_gpu": rep}))
     dist.destroy_process_group()
     if not ok:
         raise SystemExit(3)
@@ -121,9 +151,10 @@ def selftest_config4(dist, rank, world):
         for b in bl:
             got[int(b[0, 0])] = (rk, b)
     ok = sorted(got) == list(range(n_targets * n_chains)) and all(got[k][0] == next(r for r in range(world) if k in assign[r]) for k in got)
+    rep = rank_report(dist, None, rank, world, int(os.environ.get("LOCAL_RANK", "0")), 0.0, gather_ms, cpu=True)
     if rank == 0:
         print(json.dumps({"selftest": "config4", "n_gpus": world, "gather_ok": bool(ok), "items_per_rank": [len(a) for a in assign],
-                          "targets_per_rank": [len(set(k // n_chains for k in a)) for a in assign], "gather_ms": gather_ms}))
+                          "targets_per_rank": [len(set(k // n_chains for k in a)) for a in assign], "gather_ms": gather_ms, "multi_gpu": rep}))
     dist.barrier()
     dist.destroy_process_group()
     if not ok:
@@ -353,6 +384,7 @@ def main():
     n_acc = int(rec[:, 1].sum())
     n_icp = int((rec[:, 2] < 2).sum())
     rate = world * B * args.steps / dt
+    multi_gpu = rank_report(dist, torch, rank, world, local_rank, 1e3 * t_chain, 1e3 * t_gather)
 
     line = {
         "metric": METRIC,
@@ -380,6 +412,7 @@ def main():
         },
         "roofline": None,
         "cpu_baseline": None,
+        "multi_gpu": multi_gpu,
     }
 
     if rank == 0 and world == 1:
@@ -539,6 +572,7 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
         per_rank = [[stats["contexts_built"], stats["items"], stats["gather_ms"], stats["chain_ms"]]]
     n_items = len(items)
     assert all(r is not None and r.shape == (args.steps, 14 + model.rank) for r in recs), "a work item's records are missing"
+    multi_gpu = rank_report(dist, torch, rank, world, local_rank, stats["chain_ms"], stats["gather_ms"])
     if rank == 0:
         best = max(range(n_items), key=lambda k: recs[k][:, 3].max())
         line = {"metric": METRIC, "value": n_items * args.steps / dt, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
@@ -553,7 +587,7 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
                            "gather_ms_per_rank": [round(p[2], 3) for p in per_rank], "chain_ms_per_rank": [round(p[3], 1) for p in per_rank],
                            "chains_per_launch": max(1, args.chains_per_gpu), "best_item": [int(v) for v in items[best]],
                            "accepted": int(sum(r[:, 1].sum() for r in recs))},
-                "roofline": None, "cpu_baseline": None, "runtime_stats": pkg._native.runtime_stats()}
+                "roofline": None, "cpu_baseline": None, "multi_gpu": multi_gpu, "runtime_stats": pkg._native.runtime_stats()}
         print(json.dumps(line))
 
 
