@@ -107,6 +107,7 @@ SIGNATURES = {
     "icp_chain_step_batched_abandon": (C.c_int, [C.c_void_p]),
     "icp_ctx_set_rotation": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "icp_ctx_runtime_stats": (C.c_int, [C.c_void_p, C.POINTER(RuntimeStats)]),
+    "icp_ctx_step_paths": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "icp_release_cached_models": (None, []),
     "icp_chains_run_on_device": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(MhMixture),
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(c_double_p), c_double_p, C.c_int32,
@@ -146,6 +147,13 @@ def check(status, where):
         L = lib()
         detail = (L.icp_last_error() or b"").decode() or (L.icp_status_string(status) or b"").decode()
         raise IcpNativeError(status, where, detail)
+
+
+def step_paths(ctx_handle=None) -> dict:
+    """icp_ctx_step_paths: how many chain steps took which path (of one context, or of the process)."""
+    out = (C.c_int64 * 4)()
+    check(lib().icp_ctx_step_paths(ctx_handle, out), "icp_ctx_step_paths")
+    return {"merged": int(out[0]), "wide": int(out[1]), "per_stage": int(out[2]), "device_loop": int(out[3])}
 
 
 def runtime_stats(ctx_handle=None) -> dict:

@@ -120,6 +120,10 @@ class IcpContext:
         """Fall-back counters of this context (icp_ctx_runtime_stats): all zero in a normal run."""
         return nat.runtime_stats(self.h)
 
+    def step_paths(self) -> dict:
+        """How many chain steps of this context took which path (icp_ctx_step_paths)."""
+        return nat.step_paths(self.h)
+
     def profile_start(self, max_launches: int = 200000, count_searches: bool = False):
         """count_searches: also count the tests the searches execute (rows "count.*" of profile_stop; slows the filter launches
         down — for a short leg of its own, not for timing)."""

@@ -295,10 +295,15 @@ struct RuntimeStats {
   std::atomic<int64_t> wait_timeouts{0}, speculation_giveups{0}, pipeline_fallbacks{0}, step_redos{0}, gate_timeouts{0};
 };
 RuntimeStats g_runtime_stats;
+// which path the chain steps took (icp_ctx_step_paths): [0] the five merged launches, [1] the wide step, [2] per-stage kernels,
+// [3] steps inside icp_chains_run_on_device
+struct StepPaths { std::atomic<int64_t> n[4] = {{0}, {0}, {0}, {0}}; };
+StepPaths g_step_paths;
 
 struct icp_ctx {
   int device = 0;
   RuntimeStats stats;
+  StepPaths paths;
   hipStream_t stream = nullptr;
   // icp_chain_step alternates between two streams: the five launches of a step go to one of them in order, the next step's
   // to the other.  Launches 1-3 of a step do not depend on the finish launch of the step before it and run beside it; what
@@ -345,6 +350,8 @@ struct icp_ctx {
   QueryScratch scratch;
   QueryScratch scratch_v;  // second scratch: the merged step launches run a surface and a vertex search side by side
   QueryScratch scratch_t;  // third: … and the evaluator's target -> model surface search
+  QueryScratch scratch_n;  // the wide step's second search stage: nearest target vertices of the model-side surface points …
+  QueryScratch scratch_tn; // … and nearest model vertices of the evaluator's target-side surface points (their own candidate counters)
   // staging for small host<->device transfers of one API call
   double* h_stage = nullptr;  // pinned
   DBuf<double> d_stage;
@@ -384,6 +391,14 @@ struct icp_ctx {
   DBuf<unsigned char> batch_device[kBatchRing];
   size_t batch_bytes[kBatchRing] = {0, 0, 0, 0};
   int batch_turn = 0;
+  // the wide step (kernels_wide.hip) led by this context: per-chain records (pinned + device copy), events stream -> side streams
+  void* wide_pinned[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
+  DBuf<unsigned char> wide_device[kBatchRing];
+  size_t wide_bytes[kBatchRing] = {0, 0, 0, 0};
+  hipEvent_t ev_wide_sum[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};   // stream -> eigen / finish streams: the partials are summed
+  hipEvent_t ev_wide_fac[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};   // finish stream -> eigen stream: M is complete (ranks <= 64)
+  int wide_turn = 0;
+  double* h_wide_z = nullptr;  // pinned: the coefficients a wide step is GIVEN (random-walk / pose proposals), read by its first launch
   // … and of their decompositions: the records of launch_posterior_eigen_many (pinned, read in place by the kernel), the counter
   // its workgroups announce themselves in and what it will hold once every workgroup launched so far has started (the gate of
   // launch_step_batch) and the gate's pinned error word
@@ -404,7 +419,7 @@ struct icp_ctx {
 
   // scratch for K queries against a set of n_elems elements (every query may list every element as a candidate)
   QueryBuffers query_scratch(size_t K, size_t n_elems, int which = 0) {
-    QueryScratch& scratch = which == 1 ? scratch_v : (which == 2 ? scratch_t : this->scratch);
+    QueryScratch& scratch = which == 1 ? scratch_v : which == 2 ? scratch_t : which == 3 ? scratch_n : which == 4 ? scratch_tn : this->scratch;
     if (K > scratch.cap) {
       HIP_OK(hipStreamSynchronize(stream));
       if (front_stream) HIP_OK(hipStreamSynchronize(front_stream));
@@ -1630,6 +1645,13 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   if (ctx->ev_inst) (void)hipEventDestroy(ctx->ev_inst);
   if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
   if (ctx->h_wait_error) (void)hipHostFree(ctx->h_wait_error);
+  if (ctx->h_wide_z) (void)hipHostFree(ctx->h_wide_z);
+  for (void* bp : ctx->wide_pinned)
+    if (bp) (void)hipHostFree(bp);
+  for (hipEvent_t ev : ctx->ev_wide_sum)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : ctx->ev_wide_fac)
+    if (ev) (void)hipEventDestroy(ev);
   if (ctx->h_gate_error) (void)hipHostFree(ctx->h_gate_error);
   for (void* bp : ctx->batch_eig_rec)
     if (bp) (void)hipHostFree(bp);
@@ -1733,6 +1755,13 @@ int icp_ctx_runtime_stats(const icp_ctx* ctx, icp_runtime_stats* out) {
   out->pipeline_fallbacks = s.pipeline_fallbacks.load();
   out->step_redos = s.step_redos.load();
   out->gate_timeouts = s.gate_timeouts.load();
+  return ICP_OK;
+}
+
+int icp_ctx_step_paths(const icp_ctx* ctx, int64_t* out) {
+  if (!out) return ICP_ERR_INVALID_ARG;
+  const StepPaths& p = ctx ? ctx->paths : g_step_paths;
+  for (int k = 0; k < 4; ++k) out[k] = p.n[k].load(std::memory_order_relaxed);
   return ICP_OK;
 }
 
@@ -3042,6 +3071,9 @@ bool front_matches(const StepFront& F, int n_props, icp_proposal* const* props, 
          std::memcmp(F.key.data(), key, sizeof(double) * F.key.size()) == 0;
 }
 
+bool wide_chain_covered(icp_evaluator* e, int n_props, icp_proposal* const* props, int generator, const double* theta_cur,
+                        const double* theta_prop_in);  // (the wide step: further down)
+
 // shared argument checks of icp_chain_step and icp_chain_step_prelaunch; -> the merged launches cover this call
 bool chain_step_covered(icp_evaluator* e, int n_props, icp_proposal* const* props, int generator, const double* theta_cur,
                         const double* theta_prop_in) {
@@ -3101,7 +3133,8 @@ int icp_chain_step_prelaunch(icp_evaluator* e, int32_t n_props, icp_proposal* co
 int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props, int32_t generator, const double* theta_cur,
                    const double* z, double* theta_prop, double* log_value_prop, double* fwd, double* bwd) {
   int status = ICP_OK;
-  bool per_stage = false, redo = false;
+  bool per_stage = false, redo = false, wide = false;
+  static thread_local int wide_depth = 0;  // (a wide step that has to be repeated comes back through this entry point: bounded)
   int rc = guard([&] {
     require(e && theta_cur && theta_prop && log_value_prop, "null argument");
     require(n_props >= 0 && n_props <= 8 && (n_props == 0 || (props && fwd && bwd)), "bad proposal list");
@@ -3120,7 +3153,12 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     const bool reuse = n_props <= 2 && front_matches(e->front, n_props, props, generator, theta_cur, key, r);
     if (e->front.valid && !reuse) drop_front(e);  // pre-launched for another outcome: dropped
     per_stage = !reuse && !chain_step_covered(e, n_props, props, generator, theta_cur, theta_prop);
-    if (per_stage) return;
+    if (per_stage) {
+      // what the five merged launches do not cover as a configuration takes the wide step (a batch of one chain)
+      wide = wide_depth < 2 && n_props >= 1 && n_props <= 2 && !step_pipeline_covers(e, n_props, props) &&
+             wide_chain_covered(e, n_props, props, generator, theta_cur, theta_prop);
+      return;
+    }
     Bound _b(&c, true);
     g_host_timing.start();
 
@@ -3245,13 +3283,25 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
     s.reserved = false;
     for (int i = 0; i < n_props; ++i) ep[i]->reserved = false;
     front_guard.f = nullptr;
+    ++c.paths.n[0]; ++g_step_paths.n[0];
     e->last_prop.assign(theta_prop, theta_prop + 10 + r);
     g_host_timing.mark(4);
     g_host_timing.end();
   });
   if (rc != ICP_OK) return rc;
   if (redo) return icp_chain_step(e, n_props, props, generator, theta_cur, z, theta_prop, log_value_prop, fwd, bwd);
+  if (per_stage && wide) {
+    int32_t gen = generator, st = ICP_OK;
+    const double* tc = theta_cur;
+    const double* zz = z;
+    double* tp = theta_prop;
+    ++wide_depth;
+    rc = icp_chain_step_batched(1, &e, n_props, props, &gen, &tc, generator >= 0 ? &zz : nullptr, &tp, log_value_prop, fwd, bwd, &st);
+    --wide_depth;
+    return rc != ICP_OK ? rc : st;
+  }
   if (per_stage) {  // same results through the per-stage kernels
+    ++e->ctx->paths.n[2]; ++g_step_paths.n[2];
     if (generator >= 0) {
       rc = icp_proposal_propose(props[generator], theta_cur, z, theta_prop, nullptr);
       if (rc != ICP_OK) return rc;
@@ -3287,12 +3337,90 @@ static inline double harness_normal(uint64_t seed, uint64_t step, uint64_t lane)
   return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
 }
 
+// ===================================================================== the wide step (kernels_wide.hip; icp_kernels.hpp "the wide step")
+// One Metropolis–Hastings step of the configurations the five merged launches do not cover — reference:
+// apps/bfm/BfmFittingPartial.scala:62-83 (open target, boundary-aware ModelSampling, collective / full-mesh Hausdorff evaluator, rank
+// 200, pose walks) — without a host round trip inside the step and for B chains per launch sequence.  Host side per chain: the
+// choices enqueue_front makes (posterior entries of the current and of the proposed state, the proposed state's slot), the arguments
+// of every launch; then ONE sequence of launches for all chains on the launch context's stream, the one-workgroup kernels
+// (factorisation, tails) on its second stream, the proposed states' decompositions on the batch's eigen stream.
+namespace {
+
+struct WideItem {
+  bool on = false;          // the chain takes the wide step of this ticket
+  bool shape_only = false;  // only the shape differs between the current and the proposed state (transition densities exist)
+  bool do_post = false;     // the proposed state's posteriors are computed (always for a shape move; ahead, for a pose move)
+  bool do_spec = false;     // … and decomposed ahead
+  bool eigen_first_use = false;
+  StateSlot* s = nullptr;
+  PosteriorEntry* ec[2] = {nullptr, nullptr};
+  PosteriorEntry* ep[2] = {nullptr, nullptr};
+  int Ksurf = 0, Knnv = 0;
+  bool spheres = false;     // the new instance's bounding spheres are made (a target -> model search)
+  int seq = 0;
+  int n_tails = 0;
+  TransitionTailIO tails[4];  // fwd_0, bwd_0, fwd_1, bwd_1 (as recorded: for the rare direct-tail fall-back)
+};
+
+// the rank-dependent kernels of a wide step exist for this rank and sampler
+bool wide_rank_covered(int r, int sampler) {
+  if (r < 3 || r > 256) return false;
+  if (sampler == ICP_SAMPLER_CHOLESKY_ROOT) return r <= kCholMaxRankAbi;
+  return eigen_speculation_supported(r) || eigen_tridiag_many_supported(r);
+}
+
+// the configuration (proposal set + evaluator) is one a wide step covers
+bool wide_pipeline_covers(icp_evaluator* e, int n_props, icp_proposal* const* props) {
+  icp_ctx& c = *e->ctx;
+  if (n_props < 1 || n_props > 2) return false;
+  const icp_evaluator_params& ep = e->prm;
+  const bool hd = ep.kind == ICP_EVAL_HAUSDORFF;
+  const bool m2t = hd || ep.mode != ICP_TARGET_TO_MODEL, t2m = hd || ep.mode != ICP_MODEL_TO_TARGET;
+  const int Km = hd ? c.N : ep.n_model_ids;
+  if (m2t && Km < 1) return false;
+  if (t2m && (e->Kt < 1 || c.T < 1)) return false;
+  if (c.target.T < 1 || c.target.V < 1) return false;
+  int n_model = 0, n_target = 0, ksurf = m2t ? Km : 0;
+  for (int i = 0; i < n_props; ++i) {
+    const icp_proposal* p = props[i];
+    if (p->K < 1) return false;
+    if (!wide_rank_covered(c.r, p->sampler)) return false;
+    if (p->sampler != props[0]->sampler) return false;
+    if (p->prm.direction == ICP_MODEL_SAMPLING) { ++n_model; ksurf = std::max(ksurf, p->K); }
+    else {
+      ++n_target;
+      if ((size_t)(p->K + 8) * (size_t)kCandStride > kMaxCandidates) return false;
+    }
+  }
+  if (n_model > 1 || n_target > 1) return false;
+  if ((size_t)(ksurf + 8) * (size_t)kCandStride > kMaxCandidates) return false;
+  if (t2m && (size_t)(e->Kt + 8) * (size_t)kCandStride > kMaxCandidates) return false;
+  return true;
+}
+
+// … and so is this call (a proposed state the caches already know has nothing to compute: the per-stage entry points answer it)
+bool wide_chain_covered(icp_evaluator* e, int n_props, icp_proposal* const* props, int generator, const double* theta_cur,
+                        const double* theta_prop_in) {
+  if (!wide_pipeline_covers(e, n_props, props)) return false;
+  if (generator < 0) {
+    icp_ctx& c = *e->ctx;
+    if (c.find_state(theta_prop_in) || eval_lookup(e, theta_prop_in)) return false;
+    for (int i = 0; i < n_props; ++i)
+      if (props[i]->find_entry(theta_prop_in)) return false;
+  }
+  return true;
+}
+
+}  // namespace
+
 struct BatchItem {
   icp_evaluator* e = nullptr;
   icp_proposal* const* props = nullptr;
   int generator = -1;
   const double* key = nullptr;
   bool batched = false, issued = false, redo = false;
+  bool wide = false;  // takes the wide step (kernels_wide.hip) instead of the five merged launches
+  WideItem W;
   StepFront F;
   StepFinishArgs f{};
   std::unique_lock<std::recursive_mutex> lk;
@@ -3302,6 +3430,7 @@ struct icp_step_ticket {
   int n_chains = 0, n_props = 0, nb = 0;
   icp_ctx* lead = nullptr;
   hipStream_t finish_stream = nullptr;  // where the batch's last launch went, if not lead->stream
+  hipStream_t wide_streams[2] = {nullptr, nullptr};  // the streams of the ticket's wide step, if it has one
   std::vector<BatchItem> items;
   std::vector<StepCapture> caps;
   std::vector<icp_proposal*> props;
@@ -3314,24 +3443,552 @@ struct icp_step_ticket {
 };
 
 namespace {
+void wide_release(BatchItem& it, bool recorded = false);
 // whatever happened, nothing stays reserved or locked; a failed batch leaves its launches to drain
 void batch_release(icp_step_ticket& t) {
   for (auto& it : t.items) {
-    if (!it.batched || !it.e) continue;
+    if ((!it.batched && !it.wide) || !it.e) continue;
     icp_ctx& c = *it.e->ctx;
     if (!it.lk.owns_lock()) it.lk = std::unique_lock<std::recursive_mutex>(c.mu);
     if (it.issued) {
       (void)hipSetDevice(c.device);
       if (t.lead) (void)hipStreamSynchronize(t.lead->stream);
       if (t.finish_stream) (void)hipStreamSynchronize(t.finish_stream);
-      release_front(it.F);
+      for (hipStream_t ws : t.wide_streams)
+        if (ws) (void)hipStreamSynchronize(ws);
+      if (it.wide) wide_release(it);
+      else release_front(it.F);
       it.issued = false;
+    } else if (it.wide) {
+      wide_release(it);
     }
     c.batch_busy = false;
     it.lk.unlock();
   }
 }
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the wide step's host side: wide_issue (everything onto the device) / wide_collect (results, bookkeeping), called by
+// icp_chain_step_batched_issue / _collect for the items marked `wide`
+namespace {
+
+void wide_release(BatchItem& it, bool recorded) {  // gives back what the item holds (recorded: its step has been booked)
+  WideItem& w = it.W;
+  if (w.s) w.s->reserved = false;
+  for (int i = 0; i < 2; ++i)
+    if (w.ep[i]) w.ep[i]->reserved = false;
+  if (!recorded && w.on && w.eigen_first_use && it.generator >= 0 && w.ec[it.generator]) w.ec[it.generator]->eig_checked = false;
+  w.on = false; w.s = nullptr;
+  w.ec[0] = w.ec[1] = w.ep[0] = w.ep[1] = nullptr;
+}
+
+// `S` waits for the decomposition `en` may still be the subject of (an event), or the host does (none on record)
+void wide_await_entry(icp_ctx& c, icp_proposal* p, PosteriorEntry& en, hipStream_t S, std::vector<hipEvent_t>& waited) {
+  // (a finished decomposition has left its status in pinned memory, −1 while in flight: nothing to wait for then)
+  if (!en.eig_valid || *(volatile int*)(p->h_eig + en.status_off / 3) != -1) return;
+  if (hipEvent_t ev = en.eigen_event()) {
+    if (std::find(waited.begin(), waited.end(), ev) == waited.end()) {
+      HIP_OK(hipStreamWaitEvent(S, ev, 0));
+      waited.push_back(ev);
+    }
+  } else if (en.eig_valid && (en.eig_event_valid || en.done_value != 0)) {
+    sync_eigen(c);  // (started by another kind of step without an event, or its event slot has been handed out again)
+  }
+}
+
+void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
+  const int n_props = t.n_props;
+  std::vector<int> idx;
+  for (int b = 0; b < t.n_chains; ++b)
+    if (t.items[b].wide) idx.push_back(b);
+  if (idx.empty()) return;
+  const int r = elead.r, nW = (int)idx.size();
+  std::lock_guard<std::recursive_mutex> lead_lk(lead.mu);  // (its streams, its record ring)
+  const hipStream_t S = lead.stream, S2 = lead.front_stream;
+  const hipStream_t E = batch_eigen_stream(lead, &elead);
+  const int turn = (lead.wide_turn = (lead.wide_turn + 1) % icp_ctx::kBatchRing);
+  {
+    Bound _b(&lead, true, true);
+    if (!lead.ev_wide_sum[turn]) HIP_OK(hipEventCreateWithFlags(&lead.ev_wide_sum[turn], hipEventDisableTiming));
+    if (!lead.ev_wide_fac[turn]) HIP_OK(hipEventCreateWithFlags(&lead.ev_wide_fac[turn], hipEventDisableTiming));
+    const size_t bytes = wide_batch_bytes(nW);
+    if (bytes > lead.wide_bytes[turn]) {
+      // (the slot's previous reader was the batch four tickets ago: collected, its launches finished)
+      if (lead.wide_pinned[turn]) { HIP_OK(hipHostFree(lead.wide_pinned[turn])); lead.wide_pinned[turn] = nullptr; }
+      const size_t cap = std::max(bytes, wide_batch_bytes(kWideMaxChains));
+      HIP_OK(hipHostMalloc(&lead.wide_pinned[turn], cap, hipHostMallocDefault));
+      lead.wide_device[turn].alloc(cap);
+      lead.wide_bytes[turn] = cap;
+    }
+  }
+  std::vector<hipEvent_t> waited;
+  std::vector<WideProposeItem> prop_items;
+  std::vector<WideChainArgs> chain_args(nW);
+  std::vector<double*> sum_parts; std::vector<int> sum_splits;
+  std::vector<PosteriorFactorIO> factors;
+  std::vector<PosteriorEntry*> root_entries;  // (Cholesky-root sampler above rank 64: the factorisation hands the "basis" out)
+  std::vector<icp_proposal*> root_props;
+  std::vector<TransitionTailIO> tails;
+  std::vector<EigenRequest> spec_rq; std::vector<const double*> spec_parts; std::vector<PosteriorEntry*> spec_entries;
+  std::vector<EigenRequest> pre_rq; std::vector<PosteriorEntry*> pre_entries;
+  std::vector<WideDoneItem> dones;
+  WideLaunchPlan plan{};
+  plan.B = nW; plan.N = elead.N; plan.r = r; plan.Qp = elead.Qp.p; plan.ref = elead.ref.p; plan.mean = elead.mean.p;
+  plan.f1_prepared = true;
+  const int spec_mode = speculation_mode();
+
+  for (int k = 0; k < nW; ++k) {
+    BatchItem& it = t.items[idx[k]];
+    WideItem& w = it.W;
+    icp_evaluator* e = it.e;
+    icp_ctx& c = *e->ctx;
+    const double* theta_cur = t.theta_cur[idx[k]];
+    double* theta_prop = t.theta_prop[idx[k]];
+    const int generator = it.generator;
+    Bound _b(&c, true);
+    w = WideItem{};
+    w.on = true;
+    if (!e->last_prop.empty()) {  // did the caller keep the state the previous step proposed?
+      const bool accepted = std::memcmp(e->last_prop.data(), theta_cur, sizeof(double) * (10 + (size_t)r)) == 0;
+      e->acc_ema = 0.9 * e->acc_ema + (accepted ? 0.1 : 0.0);
+    }
+    for (int i = 0; i < n_props; ++i) it.props[i]->resolve_speculation(theta_cur);  // (a merged step's speculation, if the chain changed paths)
+    w.shape_only = generator >= 0 || pose_equal(theta_cur, theta_prop);
+    const bool spec = (spec_mode == 1 || (spec_mode == 2 && e->acc_ema >= 0.1)) && !c.speculation_off;
+    // a pose move changes the state too: if it is kept, the next ICP proposal draws from the posterior at the NEW state, which
+    // nothing else on this path would compute (the transition densities across a pose change are −∞): started here, ahead
+    w.do_post = w.shape_only || spec;
+    w.do_spec = w.do_post && spec;
+    const bool root = it.props[0]->sampler == ICP_SAMPLER_CHOLESKY_ROOT;
+    const bool root_here = root && !eigen_speculation_supported(r);  // (the factorisation itself hands the factor out)
+
+    // ---- cached side: the current state's posteriors (a shape move's tails and proposal read them)
+    PosteriorEntry** ec = w.ec;
+    PosteriorEntry** ep = w.ep;
+    if (w.shape_only) {
+      bool missing = false;
+      for (int i = 0; i < n_props; ++i) missing = missing || !it.props[i]->find_entry(theta_cur);
+      for (int i = 0; i < n_props; ++i) ec[i] = &it.props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76 (the per-stage way if not on record)
+      if (missing || c.stream_used_elsewhere) { HIP_OK(hipStreamSynchronize(c.stream)); c.stream_used_elsewhere = false; c.stage_used = 0; }
+      for (int i = 0; i < n_props; ++i) { ec[i]->reserved = true; }  // (not to be recycled for the proposed state's entries below)
+    }
+    if (generator >= 0) {
+      icp_proposal* pg = it.props[generator];
+      PosteriorEntry& g = *ec[generator];
+      if (!g.eig_valid) {
+        if (root_here) fail(ICP_ERR_DEVICE, "internal: a posterior of the Cholesky-root sampler without its factor");
+        EigenRequest rq;
+        pg->prepare_eigen(g, &rq);
+        rq.sqrt_lambda = c.sqrt_lambda.p;
+        g.eig_event_valid = false; g.eig_done_shared = nullptr; g.eig_shared_gen = nullptr;
+        (void)eigen_stream_for(c, E);
+        pre_rq.push_back(rq);
+        pre_entries.push_back(&g);
+      } else {
+        wide_await_entry(c, pg, g, S, waited);
+      }
+      w.eigen_first_use = !g.eig_checked;
+      g.eig_checked = true;
+    }
+
+    // ---- new side: one state slot, one memo entry per proposal
+    StateSlot* same = nullptr;  // a pose move: a state with these coefficients whose deformations are kept
+    if (generator < 0 && !w.shape_only)
+      for (auto& o : c.slots)
+        if (o.valid && o.defo_valid && std::memcmp(o.theta.data() + 10, theta_prop + 10, sizeof(double) * r) == 0) { same = &o; break; }
+    if (same) { same->stamp = ++c.clock; same->reserved = true; }
+    StateSlot& s = c.fresh_state();
+    if (same) same->reserved = false;
+    s.reserved = true;
+    w.s = &s;
+    s.pose = c.pose_of(generator >= 0 ? theta_cur : theta_prop);
+    if (w.do_post)
+      for (int i = 0; i < n_props; ++i) {
+        ep[i] = &it.props[i]->fresh_entry();
+        ep[i]->reserved = true;
+        wide_await_entry(c, it.props[i], *ep[i], S, waited);  // (a decomposition started ahead for a state that was not kept may still read / write it)
+        ep[i]->eig_event_valid = false;
+        ep[i]->done_value = 0;
+      }
+    if (w.shape_only)
+      for (int i = 0; i < n_props; ++i) ec[i]->reserved = false;
+
+    // ---- W1: coefficients of the proposed state
+    WideProposeItem pi{};
+    if (generator >= 0) {
+      PosteriorEntry& g = *ec[generator];
+      if (!c.h_wide_z) HIP_OK(hipHostMalloc((void**)&c.h_wide_z, sizeof(double) * kMaxRank, hipHostMallocDefault));
+      std::memcpy(c.h_wide_z, t.z[idx[k]], sizeof(double) * r);  // posterior.sample()'s standard normals (:55)
+      pi.kind = 1;
+      pi.in = ProposeIn{g.alpha.p, g.V.p, g.S.p, c.inv_sqrt_lambda.p, c.P.p, g.coeffs.p, c.h_wide_z, kSigma2,
+                        it.props[generator]->prm.step_length, root ? 1 : 0};
+    } else {
+      if (!c.h_wide_z) HIP_OK(hipHostMalloc((void**)&c.h_wide_z, sizeof(double) * kMaxRank, hipHostMallocDefault));
+      std::memcpy(c.h_wide_z, theta_prop + 10, sizeof(double) * r);
+      pi.kind = 0;
+      pi.src = c.h_wide_z;
+    }
+    pi.n_out = 0;
+    pi.out[pi.n_out++] = s.coeffs.p;
+    if (w.do_post)
+      for (int i = 0; i < n_props; ++i) pi.out[pi.n_out++] = ep[i]->coeffs.p;
+    pi.out[pi.n_out++] = c.h_res + 16;
+    prop_items.push_back(pi);
+
+    // ---- searches
+    const icp_evaluator_params& evp = e->prm;
+    const bool hd = evp.kind == ICP_EVAL_HAUSDORFF, coll = evp.kind == ICP_EVAL_COLLECTIVE_AVG_HAUSDORFF_BOUNDARY_AWARE;
+    const bool ev_m2t = hd || evp.mode != ICP_TARGET_TO_MODEL, ev_t2m = hd || evp.mode != ICP_MODEL_TO_TARGET;
+    const int Km = hd ? c.N : evp.n_model_ids, Kt = e->Kt;
+    icp_proposal* pm = nullptr; icp_proposal* pt = nullptr;
+    int im = -1, itx = -1;
+    if (w.do_post)
+      for (int i = 0; i < n_props; ++i) {
+        if (it.props[i]->prm.direction == ICP_MODEL_SAMPLING) { pm = it.props[i]; im = i; }
+        else { pt = it.props[i]; itx = i; }
+      }
+    const bool open_target = c.target.n_boundary > 0;
+    const int Ksurf = std::max(ev_m2t ? Km : 0, pm ? pm->K : 0);
+    const bool prop_nnv = pm && pm->prm.boundary_aware && open_target;      // NonRigidIcpProposal.scala:98-99
+    const bool eval_nnv = coll && open_target && ev_m2t;                     // Collective…Evaluator.scala:44-48
+    const bool t2m_nnv = coll && open_target && ev_t2m;                      // :56-60
+    const int Knnv = std::max(prop_nnv ? pm->K : 0, eval_nnv ? Km : 0);
+    require(Ksurf <= c.N, "model id count exceeds the number of model points");
+    w.Ksurf = Ksurf; w.Knnv = Knnv; w.spheres = ev_t2m;
+    QueryBuffers qs{}, qv{}, qt{}, qn{}, qtn{};
+    if (Ksurf > 0) qs = c.query_scratch(Ksurf, c.target.T, 0);
+    if (pt) qv = c.query_scratch(pt->K, c.N, 1);
+    if (ev_t2m) qt = c.query_scratch(Kt, c.T, 2);
+    if (Knnv > 0) qn = c.query_scratch(Knnv, c.target.V, 3);
+    if (t2m_nnv) qtn = c.query_scratch(Kt, c.N, 4);
+
+    WideChainArgs& A = chain_args[k];
+    std::memset(&A, 0, sizeof(A));
+    SurfaceTask st_surf{}, st_t2m{};
+    VertexTask st_vert{}, st_nnv{}, st_tnn{};
+    if (Ksurf > 0)
+      st_surf = make_surface_task(c.target.T, c.target.verts.p, c.target.tris.p, c.target.spheres.p, Ksurf, s.x.p, c.hint_surf.p, qs,
+                                  s.surf_cp.p, s.surf_d2.p, s.surf_tri.p);
+    if (ev_t2m)
+      st_t2m = make_surface_task(c.T, s.x.p, c.tris.p, s.spheres.p, Kt, e->d_tpts, e->hint_tri.p, qt, e->t2m_cp.p, e->t2m_d2.p, e->t2m_tri.p);
+    if (pt) { st_vert = make_vertex_task(c.N, s.x.p, pt->K, pt->target_pts.p, pt->hint_nn.p, qv, nullptr, pt->nn_id.p); st_vert.thr2 = nullptr; }
+    if (Knnv > 0) { st_nnv = make_vertex_task(c.target.V, c.target.verts.p, Knnv, s.surf_cp.p, c.hint_nnv.p, qn, nullptr, s.surf_nnv.p); st_nnv.thr2 = nullptr; }
+    if (t2m_nnv) { st_tnn = make_vertex_task(c.N, s.x.p, Kt, e->t2m_cp.p, e->hint_nnv.p, qtn, nullptr, e->t2m_nnv.p); st_tnn.thr2 = nullptr; }
+
+    // W2
+    A.inst.kind = same ? 1 : 0;
+    A.inst.coeffs = s.coeffs.p;
+    A.inst.defo_src = same ? same->defo.p : nullptr;
+    A.inst.pose = s.pose;
+    A.inst.x = s.x.p; A.inst.defo = s.defo.p;
+    A.inst.has_surf = Ksurf > 0 ? 1 : 0; A.inst.surf = st_surf;
+    // W3
+    A.prep.T = ev_t2m ? c.T : 0; A.prep.x = s.x.p; A.prep.tris = c.tris.p; A.prep.order = c.tri_order.p; A.prep.spheres = s.spheres.p;
+    A.prep.has_t2m = ev_t2m ? 1 : 0; A.prep.t2m = st_t2m;
+    A.prep.n_cnt = 0;
+    if (pt) { A.prep.cnt[A.prep.n_cnt] = st_vert.cnt; A.prep.cnt_n[A.prep.n_cnt++] = st_vert.Kpad; }
+    if (Knnv > 0) { A.prep.cnt[A.prep.n_cnt] = st_nnv.cnt; A.prep.cnt_n[A.prep.n_cnt++] = st_nnv.Kpad; }
+    if (t2m_nnv) { A.prep.cnt[A.prep.n_cnt] = st_tnn.cnt; A.prep.cnt_n[A.prep.n_cnt++] = st_tnn.Kpad; }
+    A.prep.zero_d = c.d_res.p; A.prep.n_zero_d = 8;
+    // W4/W5: stage 1
+    StepSearchArgs& q1 = A.s1;
+    q1.s_corr[0] = q1.s_corr[1] = q1.v_corr[0] = q1.v_corr[1] = -1;
+    int nt = 0, n_corr = 0;
+    q1.fstart[0] = 0; q1.rstart[0] = 0;
+    if (Ksurf > 0) {
+      q1.s[q1.n_surf] = st_surf;
+      q1.fstart[nt + 1] = q1.fstart[nt] + filter_grid_blocks(st_surf.tblocks, st_surf.ksplit);
+      q1.rstart[nt + 1] = q1.rstart[nt] + Ksurf;
+      if (pm && !prop_nnv) {
+        q1.corr[n_corr] = CorrTask{pm->K, ep[im]->corr(), s.x.p, nullptr, c.target.boundary.p, nullptr, pm->prm.boundary_aware,
+                                   s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, nullptr};
+        q1.s_corr[q1.n_surf] = n_corr++;
+      }
+      ++q1.n_surf; ++nt;
+    }
+    if (ev_t2m) {
+      q1.s[q1.n_surf] = st_t2m;
+      q1.fstart[nt + 1] = q1.fstart[nt] + filter_grid_blocks(st_t2m.tblocks, st_t2m.ksplit);
+      q1.rstart[nt + 1] = q1.rstart[nt] + Kt;
+      ++q1.n_surf; ++nt;
+    }
+    if (pt) {
+      q1.v[0] = st_vert;
+      q1.fstart[nt + 1] = q1.fstart[nt] + filter_grid_blocks(st_vert.vblocks, st_vert.ksplit);
+      q1.rstart[nt + 1] = q1.rstart[nt] + pt->K;
+      q1.corr[n_corr] = CorrTask{pt->K, ep[itx]->corr(), s.x.p, pt->target_pts.p, c.boundary.p, nullptr, pt->prm.boundary_aware,
+                                 s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, nullptr};
+      q1.v_corr[0] = n_corr++;
+      q1.n_vert = 1; ++nt;
+    }
+    for (int u = nt + 1; u < 5; ++u) { q1.fstart[u] = q1.fstart[nt]; q1.rstart[u] = q1.rstart[nt]; }
+    // W6/W7: stage 2 (nearest vertices of the surface points)
+    StepSearchArgs& q2 = A.s2;
+    q2.s_corr[0] = q2.s_corr[1] = q2.v_corr[0] = q2.v_corr[1] = -1;
+    int nt2 = 0, n_corr2 = 0;
+    q2.fstart[0] = 0; q2.rstart[0] = 0;
+    if (Knnv > 0) {
+      q2.v[q2.n_vert] = st_nnv;
+      q2.fstart[nt2 + 1] = q2.fstart[nt2] + filter_grid_blocks(st_nnv.vblocks, st_nnv.ksplit);
+      q2.rstart[nt2 + 1] = q2.rstart[nt2] + Knnv;
+      if (prop_nnv) {
+        q2.corr[n_corr2] = CorrTask{pm->K, ep[im]->corr(), s.x.p, nullptr, c.target.boundary.p, nullptr, pm->prm.boundary_aware,
+                                    s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, s.surf_cp.p};
+        q2.v_corr[q2.n_vert] = n_corr2++;
+      }
+      ++q2.n_vert; ++nt2;
+    }
+    if (t2m_nnv) {
+      q2.v[q2.n_vert] = st_tnn;
+      q2.fstart[nt2 + 1] = q2.fstart[nt2] + filter_grid_blocks(st_tnn.vblocks, st_tnn.ksplit);
+      q2.rstart[nt2 + 1] = q2.rstart[nt2] + Kt;
+      ++q2.n_vert; ++nt2;
+    }
+    for (int u = nt2 + 1; u < 5; ++u) { q2.fstart[u] = q2.fstart[nt2]; q2.rstart[u] = q2.rstart[nt2]; }
+    // W8: regressions + the likelihood's reductions
+    StepRegressionArgs& g = A.reg.reg;
+    g.n = w.do_post ? n_props : 0; g.r = r; g.ntiles = regression_tiles(r); g.Q = c.Q.p;
+    g.ustart[0] = 0; g.ustart[1] = 0; g.ustart[2] = 0;
+    int splits[2] = {1, 1};
+    double* parts[2] = {nullptr, nullptr};
+    for (int i = 0; i < g.n; ++i) {
+      icp_proposal* p = it.props[i];
+      splits[i] = regression_splits(p->K);
+      g.K[i] = p->K;
+      g.kchunk[i] = std::max(1, (p->K + splits[i] - 1) / splits[i]);
+      g.cb[i] = ep[i]->corr();
+      g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
+      g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];
+      if (p->side_factor_pending || p->side_asm_pending) {  // (a per-stage step of this proposal left work on its side streams)
+        HIP_OK(hipStreamSynchronize(c.front_stream)); sync_eigen(c);
+        p->side_factor_pending = false; p->side_asm_pending = false;
+      }
+      p->side_parts = nullptr; p->side_parts_entry = nullptr;
+      p->mpart_half = (p->mpart_half + 1) % icp_proposal::kMpartRing;
+      parts[i] = g.Mpart[i] = p->mpart_for_write(p->mpart_half, S);
+      g.status[i] = p->status.p + ep[i]->status_off;
+      g.ustart[i + 1] = g.ustart[i] + g.ntiles * splits[i];
+    }
+    if (g.n == 1) g.ustart[2] = g.ustart[1];
+    A.reg.eval_kind = evp.kind; A.reg.eval_m2t = ev_m2t ? 1 : 0; A.reg.eval_t2m = ev_t2m ? 1 : 0;
+    A.reg.Km = Km; A.reg.d2m = s.surf_d2.p;
+    A.reg.flags_m = eval_nnv ? c.target.boundary.p : nullptr; A.reg.idx_m = eval_nnv ? s.surf_nnv.p : nullptr;
+    A.reg.Kt = Kt; A.reg.d2t = e->t2m_d2.p;
+    A.reg.flags_t = t2m_nnv ? c.target.boundary.p : nullptr; A.reg.idx_t = t2m_nnv ? e->t2m_nnv.p : nullptr;  // (sic: SURVEY App. D5)
+    A.reg.n_flags = c.target.V;
+    A.reg.mean = evp.gauss_mean; A.reg.sigma = evp.gauss_sigma;
+    A.reg.red_out = c.d_res.p;
+    plan.grid_prep = std::max(plan.grid_prep, wide_prep_grid(A.prep));
+    plan.grid_f1 = std::max(plan.grid_f1, q1.fstart[nt]);
+    plan.grid_r1 = std::max(plan.grid_r1, q1.rstart[nt]);
+    plan.grid_f2 = std::max(plan.grid_f2, q2.fstart[nt2]);
+    plan.grid_r2 = std::max(plan.grid_r2, q2.rstart[nt2]);
+    plan.grid_reg = std::max(plan.grid_reg, wide_reg_blocks(A.reg));
+
+    // ---- W9..W12
+    for (int i = 0; i < 16; ++i) c.h_res[i] = 0.0;
+    for (int i = 0; i < 16; ++i) c.h_status[i] = 0;
+    w.seq = ++c.step_seq;
+    WideDoneItem di{};
+    di.red_src = c.d_res.p; di.red_dst = c.h_res;
+    di.host_flag = c.h_flag; di.seq = w.seq;
+    for (int i = 0; i < g.n; ++i) {
+      icp_proposal* p = it.props[i];
+      if (splits[i] > 1) { sum_parts.push_back(parts[i]); sum_splits.push_back(splits[i]); }
+      PosteriorFactorIO io{parts[i], 1, ep[i]->M.p, ep[i]->alpha.p, p->status.p + ep[i]->status_off, p->fscratch.p};
+      if (root_here) { io.Lout = ep[i]->V.p; io.Sout = ep[i]->S.p; root_entries.push_back(ep[i]); root_props.push_back(p); }
+      factors.push_back(io);
+      di.st_src[i] = p->status.p + ep[i]->status_off; di.st_dst[i] = c.h_status + 8 + i;
+      if (w.shape_only) {
+        w.tails[2 * i] = TransitionTailIO{ec[i]->alpha.p, ec[i]->M.p, ec[i]->coeffs.p, ep[i]->coeffs.p, p->prm.step_length,
+                                          c.h_res + 8 + 2 * i, c.h_status + 2 * i};
+        w.tails[2 * i + 1] = TransitionTailIO{ep[i]->alpha.p, ep[i]->M.p, ep[i]->coeffs.p, ec[i]->coeffs.p, p->prm.step_length,
+                                              c.h_res + 9 + 2 * i, c.h_status + 2 * i + 1};
+        tails.push_back(w.tails[2 * i]); tails.push_back(w.tails[2 * i + 1]);
+        w.n_tails = 2 * (i + 1);
+      }
+      if (w.do_spec && !root_here) {
+        EigenRequest rq;
+        p->prepare_eigen(*ep[i], &rq);
+        rq.sqrt_lambda = c.sqrt_lambda.p;
+        ep[i]->eig_checked = false;
+        ep[i]->eig_event_valid = false; ep[i]->eig_done_shared = nullptr; ep[i]->eig_shared_gen = nullptr;
+        p->mpart_reader[p->mpart_half] = ep[i];
+        (void)eigen_stream_for(c, E);
+        spec_rq.push_back(rq);
+        spec_parts.push_back(parts[i]);
+        spec_entries.push_back(ep[i]);
+      }
+    }
+    dones.push_back(di);
+    it.issued = true;
+  }
+
+  // ---- one sequence of launches for all of them
+  Bound _b(&lead, true, true);
+  BatchEventSlot* ev_pre = nullptr;
+  if (!pre_rq.empty()) {  // KL bases of current states that have none yet (a chain's first ICP proposal; speculation off)
+    if (eigen_tridiag_many_supported(r)) launch_posterior_eigen_tridiag_many(E, r, (int)pre_rq.size(), pre_rq.data(), nullptr);
+    else
+      for (auto& rq : pre_rq)
+        if (!launch_posterior_eigen_pair(E, r, rq.sqrt_lambda, 1, &rq)) fail(ICP_ERR_DEVICE, "internal: wide step at a rank without a decomposition kernel");
+    ev_pre = &next_batch_event(elead.device);
+    HIP_OK(hipEventRecord(ev_pre->ev, E));
+    HIP_OK(hipStreamWaitEvent(S, ev_pre->ev, 0));
+    for (PosteriorEntry* en : pre_entries) {
+      en->eig_done_shared = ev_pre->ev; en->eig_shared_gen = &ev_pre->gen; en->eig_shared_gen_value = ev_pre->gen;
+      en->eig_event_valid = true; en->done_value = 0;
+    }
+  }
+  for (size_t p0 = 0; p0 < prop_items.size(); p0 += kWideMaxChains) {
+    WideProposeArgs pa{};
+    pa.n = (int)std::min<size_t>(kWideMaxChains, prop_items.size() - p0);
+    for (int i = 0; i < pa.n; ++i) pa.it[i] = prop_items[p0 + i];
+    launch_wide_propose(S, r, pa);
+  }
+  launch_wide_front(S, plan, chain_args.data(), lead.wide_pinned[turn], lead.wide_device[turn].p);
+  for (size_t p0 = 0; p0 < sum_parts.size(); p0 += kWideMaxChains)
+    launch_sum_partials_many(S, r, (int)std::min<size_t>(kWideMaxChains, sum_parts.size() - p0), sum_parts.data() + p0, sum_splits.data() + p0);
+  HIP_OK(hipEventRecord(lead.ev_wide_sum[turn], S));
+  // the one-workgroup kernels on the second stream: the next batch's chip-wide launches on `S` run beside them
+  HIP_OK(hipStreamWaitEvent(S2, lead.ev_wide_sum[turn], 0));
+  const bool jacobi_spec = !spec_rq.empty() && !eigen_tridiag_many_supported(r);  // (ranks <= 64: the iteration reads the finished M)
+  if (!spec_rq.empty() && !jacobi_spec) {
+    // the proposed states' KL bases BESIDE their factorisations: M = I + the summed partials is written at the head of the
+    // decomposition as well (the values the factorisation's own assembly writes)
+    HIP_OK(hipStreamWaitEvent(E, lead.ev_wide_sum[turn], 0));
+    launch_posterior_eigen_tridiag_many(E, r, (int)spec_rq.size(), spec_rq.data(), spec_parts.data());
+  }
+  for (size_t p0 = 0; p0 < factors.size(); p0 += kWideMaxChains)
+    launch_posterior_factor(S2, r, (int)std::min<size_t>(kWideMaxChains, factors.size() - p0), factors.data() + p0);
+  if (!root_entries.empty()) {  // "decomposed" as soon as the factorisation is through: an event behind it stands for the basis
+    BatchEventSlot& done = next_batch_event(elead.device);
+    HIP_OK(hipEventRecord(done.ev, S2));
+    for (size_t q = 0; q < root_entries.size(); ++q) {
+      PosteriorEntry* en = root_entries[q];
+      en->eig_done_shared = done.ev; en->eig_shared_gen = &done.gen; en->eig_shared_gen_value = done.gen;
+      en->eig_event_valid = true; en->done_value = 0; en->eig_valid = true; en->eig_checked = false;
+      root_props[q]->h_eig[en->status_off / 3] = 0;
+    }
+  }
+  if (jacobi_spec) {
+    HIP_OK(hipEventRecord(lead.ev_wide_fac[turn], S2));
+    HIP_OK(hipStreamWaitEvent(E, lead.ev_wide_fac[turn], 0));
+    for (size_t q = 0; q < spec_rq.size(); ++q)
+      if (!launch_posterior_eigen_pair(E, r, spec_rq[q].sqrt_lambda, 1, &spec_rq[q])) fail(ICP_ERR_DEVICE, "internal: wide step at a rank without a decomposition kernel");
+  }
+  if (!spec_rq.empty()) {
+    BatchEventSlot& done = next_batch_event(elead.device);
+    HIP_OK(hipEventRecord(done.ev, E));
+    for (PosteriorEntry* en : spec_entries) {
+      en->eig_done_shared = done.ev; en->eig_shared_gen = &done.gen; en->eig_shared_gen_value = done.gen;
+      en->eig_event_valid = true; en->done_value = 0;
+    }
+  }
+  for (size_t t0 = 0; t0 < tails.size(); t0 += 2 * kWideMaxChains)
+    launch_transition_tails(S2, r, (int)std::min<size_t>(2 * kWideMaxChains, tails.size() - t0), tails.data() + t0, elead.Ginv.p, kSigma2);
+  for (size_t p0 = 0; p0 < dones.size(); p0 += kWideMaxChains) {
+    WideDoneArgs da{};
+    da.n = (int)std::min<size_t>(kWideMaxChains, dones.size() - p0);
+    for (int i = 0; i < da.n; ++i) da.it[i] = dones[p0 + i];
+    launch_wide_done(S2, da);
+  }
+  t.wide_streams[0] = S; t.wide_streams[1] = S2;
+}
+
+// results of one wide item (its flag has been waited for) -> false: the step has to be done again
+bool wide_record(icp_step_ticket& t, int b, double* log_value_prop, double* fwd, double* bwd, int* status) {
+  BatchItem& it = t.items[b];
+  WideItem& w = it.W;
+  icp_evaluator* e = it.e;
+  icp_ctx& c = *e->ctx;
+  const int r = c.r, n_props = t.n_props, generator = it.generator;
+  const size_t P = 10 + (size_t)r;
+  const double* theta_cur = t.theta_cur[b];
+  double* theta_prop = t.theta_prop[b];
+  PosteriorEntry** ec = w.ec;
+  PosteriorEntry** ep = w.ep;
+  if (w.eigen_first_use) {  // this step drew from a basis whose status nobody has looked at yet (the decomposition left it in pinned memory)
+    icp_proposal* p = it.props[generator];
+    PosteriorEntry& g = *ec[generator];
+    int st = p->h_eig[g.status_off / 3];
+    if (st != 0) {
+      // the multisection could not separate the spectrum (or the iteration did not converge): the per-stage decomposition, which
+      // has the Jacobi fall-back in its launch sequence, takes over, and the step is done again from the basis it leaves
+      g.eig_valid = false; g.eig_checked = false; g.eig_event_valid = false;
+      p->warm_valid = false;
+      p->ensure_eigen(g);
+      sync_eigen(c);
+      st = p->h_eig[g.status_off / 3];
+      if (st != 0) {
+        p->h_status[g.status_off + 2] = st;
+        p->check_status(g);  // throws
+      }
+      return false;
+    }
+    p->h_status[g.status_off + 2] = 0;
+  }
+  const double* h_coeffs = c.h_res + 16;
+  if (generator >= 0) {
+    std::memcpy(theta_prop, theta_cur, sizeof(double) * 10);  // NonRigidIcpProposal.scala:64-66: only the shape changes
+    for (int j = 0; j < r; ++j) {
+      if (!std::isfinite(h_coeffs[j])) fail(ICP_ERR_NOT_FINITE, "proposed coefficients are not finite");
+      theta_prop[10 + j] = h_coeffs[j];
+    }
+  }
+  StateSlot& s = *w.s;
+  s.theta.assign(theta_prop, theta_prop + P);
+  s.valid = true;
+  s.stamp = ++c.clock;
+  s.defo_valid = true;
+  s.spheres_valid = w.spheres;
+  s.n_surf = w.Ksurf;
+  s.n_nnv = w.Knnv;
+  s.lo_surf = s.hi_surf = s.lo_nnv = s.hi_nnv = 0;
+  if (w.do_post)
+    for (int i = 0; i < n_props; ++i) {
+      icp_proposal* p = it.props[i];
+      ep[i]->theta.assign(theta_prop, theta_prop + P);
+      ep[i]->valid = true;
+      ep[i]->stamp = ++p->clock;
+      p->h_status[ep[i]->status_off] = c.h_status[8 + i];
+      p->h_status[ep[i]->status_off + 1] = 0;
+      p->h_status[ep[i]->status_off + 2] = 0;
+      if (w.shape_only) p->check_status(*ec[i]);
+      p->check_status(*ep[i]);
+    }
+  for (int tl = 0; tl < w.n_tails; ++tl)
+    if (c.h_status[tl] != 0) {  // rare: the fixed-point tail did not contract -> direct kernel
+      std::vector<double> saved(c.h_res, c.h_res + 16);
+      icp_proposal* p = it.props[tl / 2];
+      TransitionTailIO io = w.tails[tl];
+      io.out = c.d_res.p;
+      io.status = c.d_status.p + 32;
+      sync_eigen(c);  // (the direct form borrows the eigen work buffer)
+      launch_transition_tail_direct(c.stream, r, io, c.G.p, kSigma2, p->work.p);
+      c.finish(1, 64);
+      if (c.h_status[32] != 0) fail(ICP_ERR_NOT_SPD, "G + sigma^2 M is not positive definite");
+      saved[8 + tl] = c.h_res[0];
+      std::memcpy(c.h_res, saved.data(), sizeof(double) * saved.size());
+    }
+  icp_evaluator::Memo* m = eval_store(e, theta_prop);
+  m->status = finish_eval(e, c.h_res, &m->value, m->aux);
+  *log_value_prop = m->value;
+  *status = m->status;
+  for (int i = 0; i < n_props; ++i) {
+    if (!w.shape_only) { fwd[i] = -INFINITY; bwd[i] = -INFINITY; continue; }
+    fwd[i] = c.h_res[8 + 2 * i];
+    bwd[i] = c.h_res[9 + 2 * i];
+    if (std::isnan(fwd[i]) || std::isnan(bwd[i])) fail(ICP_ERR_NOT_FINITE, "NaN transition probability");
+  }
+  e->last_prop.assign(theta_prop, theta_prop + P);
+  ++c.paths.n[1]; ++g_step_paths.n[1];
+  return true;
+}
+
+}  // namespace
+
 
 extern "C" {
 
@@ -3385,7 +4042,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
     require(lead.device == elead.device, "launch context on another device");
     t.lead = &lead;
     // ---- which chains share the launches
-    int n_batched = 0;
+    int n_batched = 0, wide_first = -1;
     for (int b = 0; b < n_chains; ++b) {
       Item& it = items[b];
       icp_ctx& c = *it.e->ctx;
@@ -3401,7 +4058,19 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
         HIP_OK(hipStreamSynchronize(c.front_stream));
         c.front_stream_used = false;
       }
-      if (!chain_step_covered(it.e, n_props, it.props, it.generator, theta_cur[b], theta_prop[b])) { it.lk.unlock(); continue; }
+      if (!chain_step_covered(it.e, n_props, it.props, it.generator, theta_cur[b], theta_prop[b])) {
+        // what the five merged launches do not cover takes the wide step (open targets, the Hausdorff evaluator, ranks up to 200, pose
+        // moves), side by side with the other such chains of the batch that share the first one's model
+        const bool same_model = wide_first < 0 || items[wide_first].e->ctx->Qp.p == c.Qp.p;
+        if (!step_pipeline_covers(it.e, n_props, it.props) && same_model &&
+            wide_chain_covered(it.e, n_props, it.props, it.generator, theta_cur[b], theta_prop[b])) {
+          it.wide = true;
+          if (wide_first < 0) wide_first = b;
+          continue;  // (its lock stays held until the end of this call, as the batched chains')
+        }
+        it.lk.unlock();
+        continue;
+      }
       it.batched = true;
       ++n_batched;
     }
@@ -3528,6 +4197,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
     }
     t.nb = nb;
     t.lead = &lead;
+    if (wide_first >= 0) wide_issue(t, lead, *items[wide_first].e->ctx);
     g_batch_timing.mark(1);
     // no mutex is held across the API boundary: the member contexts are marked busy instead (other entry points fail with
     // ICP_ERR_BUSY until the ticket is collected or abandoned — by any thread)
@@ -3602,9 +4272,38 @@ int icp_chain_step_batched_collect(icp_step_ticket* tk) {
       if (it.redo) { ++c.stats.step_redos; ++g_runtime_stats.step_redos; }
       if (it.redo) release_front(it.F);
       else {
+        ++c.paths.n[0]; ++g_step_paths.n[0];
         it.F.s->reserved = false;
         for (int i = 0; i < n_props; ++i) it.F.ep[i]->reserved = false;
       }
+      it.issued = false;
+      c.batch_busy = false;
+      it.lk.unlock();
+    }
+    // ---- the chains that took the wide step
+    for (int b = 0; b < n_chains; ++b) {
+      Item& it = items[b];
+      if (!it.wide) continue;
+      icp_ctx& c = *it.e->ctx;
+      it.lk = std::unique_lock<std::recursive_mutex>(c.mu);
+      Bound _b(&c, true, true);
+      volatile int* flag = c.h_flag;
+      const auto t_start = std::chrono::steady_clock::now();
+      long spins = 0;
+      while (*flag != it.W.seq) {
+        if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(5)) break;
+      }
+      if (*flag != it.W.seq) {
+        for (hipStream_t ws : t.wide_streams)
+          if (ws) HIP_OK(hipStreamSynchronize(ws));
+        if (*flag != it.W.seq) fail(ICP_ERR_DEVICE, "internal: a wide step's completion flag did not arrive");
+      }
+      c.stage_used = 0;
+      int st = ICP_OK;
+      it.redo = !wide_record(t, b, log_value_prop + b, fwd + (size_t)b * n_props, bwd + (size_t)b * n_props, &st);
+      status[b] = st;
+      if (it.redo) { ++c.stats.step_redos; ++g_runtime_stats.step_redos; }
+      wide_release(it, !it.redo);
       it.issued = false;
       c.batch_busy = false;
       it.lk.unlock();
@@ -3618,7 +4317,7 @@ int icp_chain_step_batched_collect(icp_step_ticket* tk) {
   int first_bad = ICP_OK;
   for (int b = 0; b < n_chains; ++b) {
     Item& it = items[b];
-    if (it.batched && !it.redo) continue;
+    if ((it.batched || it.wide) && !it.redo) continue;
     if (g_batch_timing.on) ++g_batch_timing.stepped_alone;
     const int st = icp_chain_step(it.e, n_props, it.props, it.generator, theta_cur[b], it.generator >= 0 ? z[b] : nullptr, theta_prop[b],
                                   log_value_prop + b, fwd + (size_t)b * n_props, bwd + (size_t)b * n_props);
@@ -4045,6 +4744,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
         }
         ch.slot->valid = false;
         ch.e->last_prop.clear();
+        c.paths.n[3] += n_steps; g_step_paths.n[3] += n_steps;
       }
     }
   });

@@ -172,6 +172,9 @@ struct CorrTask {  // everything one correspondence needs besides its search res
   const int* tris;
   const int* adj_off;
   const int* adj;
+  // (the wide step) non-null: this task hangs behind a NEAREST-VERTEX search of the surface points `cp` (NonRigidIcpProposal.scala:98):
+  // the resolve wave of query k builds the ModelSampling correspondence of model id k from cp[k] and the vertex it has just found
+  const double* cp = nullptr;
 };
 
 // optional extra of the correspondence launches: the memo entry's coefficient copy and cleared status words (coeffs_dst == nullptr: none)
@@ -193,7 +196,7 @@ int regression_splits(int K);
 void launch_regression(hipStream_t st, int K, int r, const double* Q, const CorrBuffers& cb, double w_tangent,
                        double kappa, double* Mpart, int* splits_out);
 
-// K5b, up to 4 posteriors per launch: M = I + Σ partials, alpha = M^-1 b (Cholesky); status[0] != 0 if M is not SPD.
+// K5b, up to kWideMaxChains (16) posteriors per launch: M = I + Σ partials, alpha = M^-1 b (Cholesky); status[0] != 0 if M is not SPD.
 struct PosteriorFactorIO { const double* Mpart; int splits; double* M; double* alpha; int* status; double* scratch /* (r+1)·r, large ranks only */;
                            double* Lout = nullptr; double* Sout = nullptr; /* optional: the factor L (r × r, zero upper triangle) and 1/diag(L) */ };
 void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io);
@@ -203,7 +206,7 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
 void launch_sum_partials(hipStream_t st, int r, double* Mpart, int splits);
 void launch_assemble_posterior_matrix(hipStream_t st, int r, const double* Mpart_summed, double* M);
 
-// a9 tails, up to 8 per launch: out = −½ γ^T M γ − (r/2) ln 2π with (G + σ²M) γ = G (c_from + (c_to − c_from)/step − α).
+// a9 tails, up to 2·kWideMaxChains (32) per launch: out = −½ γ^T M γ − (r/2) ln 2π with (G + σ²M) γ = G (c_from + (c_to − c_from)/step − α).
 // Iterative (needs Ginv = G^-1); status[0] != 0 = did not contract -> use the direct kernel.
 struct TransitionTailIO {
   const double* alpha; const double* M; const double* c_from; const double* c_to; double step; double* out; int* status;
@@ -486,6 +489,85 @@ void launch_mh_decide(hipStream_t st, int B, MhChain* chains);
 // the five merged launches for B chains from DEVICE-RESIDENT argument arrays (no copy kernel, no gate: one stream, in order)
 void launch_step_batch_resident(hipStream_t st, int B, const int grid[5], int r, const StepBeginArgs* begin, const StepSearchArgs* search,
                                 const StepRegressionArgs* regression, const StepFinishArgs* finish, bool filter_prepared = false);
+
+// ---- the wide step (kernels_wide.hip): one Metropolis–Hastings step of B chains for the configurations the five merged launches
+// above do not cover — targets WITH boundary (the nearest-vertex pass of NonRigidIcpProposal.scala:98-99 and of
+// CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:44-63 as a second filter/resolve stage), the full-mesh Hausdorff
+// evaluator (HausdorffDistanceEvaluator.scala:31-35), ranks up to 200 (factorisation, tails and decomposition as launches of their own:
+// none of them fits the one-workgroup finish launch), pose moves (PoseProposals.scala:31-90: the instance is the kept deformations
+// under the new pose).  Same device bodies as the per-stage kernels, no host round trip inside the step, B chains side by side:
+//
+//   W1  propose            one workgroup per chain               (a8; or the given coefficients handed on)
+//   W2  instance           points × chain groups                 (the basis is read ONCE per group of up to 8 chains) + bounds of the
+//                                                                  model -> target queries
+//   W3  prepare            spheres of the new instance, bounds of the target -> model queries, counters
+//   W4/W5  filter / resolve, stage 1   (surface searches both ways, TargetSampling's vertex search, correspondences without a flag test)
+//   W6/W7  filter / resolve, stage 2   (nearest vertices of the surface points; ModelSampling correspondences with their boundary flag)
+//   W8  regression + likelihood reductions
+//   W9  sum of the split-K partials -> [eigen stream: assemble, reduce to tridiagonal form, solve, refine]
+//   W10 factorisation    W11 transition tails    W12 results and completion flag into pinned host memory
+constexpr int kWideMaxChains = 16;  // chains per launch sequence (several kernels take their per-chain arguments by value)
+
+struct WideProposeItem {   // W1
+  int kind;                // 1: a8 from `in` (in.z: the step's standard normals); 0: the coefficients are given (`src`)
+  ProposeIn in;
+  const double* src;
+  int n_out; double* out[5];   // copies: the state slot, the new posterior entries, the pinned result
+};
+struct WideProposeArgs { int n; WideProposeItem it[kWideMaxChains]; };
+void launch_wide_propose(hipStream_t st, int r, const WideProposeArgs& a);
+
+struct WideInstArgs {      // W2, per chain (device memory)
+  int kind;                // 0: x = pose(ref + mean + Q·c), deformations kept; 1: x = pose(ref + defo_src) (a pose move)
+  const double* coeffs;
+  const double* defo_src;
+  Pose pose;
+  double* x; double* defo;
+  int has_surf; SurfaceTask surf;   // model ids 0..K-1 of the new instance against the target surface: bounds from the hints
+};
+struct WidePrepArgs {      // W3, per chain (device memory)
+  int T; const double* x; const int* tris; const int* order; float4* spheres;   // T = 0: no search of the new instance's surface
+  int has_t2m; SurfaceTask t2m;
+  int n_cnt; int* cnt[3]; int cnt_n[3];   // candidate counters of the vertex searches (their bounds are taken by the filter)
+  double* zero_d; int n_zero_d;           // reduction outputs that accumulate (atomic maxima)
+};
+struct WideRegArgs {       // W8, per chain (device memory)
+  StepRegressionArgs reg;  // (reduce_kind unused: the reductions below)
+  int eval_kind, eval_m2t, eval_t2m;      // icp_eval_kind; which directions are evaluated
+  int Km; const double* d2m; const unsigned char* flags_m; const int* idx_m;   // model -> target (flags null: nothing is dropped)
+  int Kt; const double* d2t; const unsigned char* flags_t; const int* idx_t;   // target -> model
+  int n_flags;
+  double mean, sigma;
+  double* red_out;         // [8] device: the layout finish_eval reads
+};
+struct WideDoneItem {      // W12
+  const double* red_src; double* red_dst;      // 8 doubles
+  const int* st_src[4]; int* st_dst[4];        // single status words (factorisations): device -> pinned
+  int* host_flag; int seq;
+};
+struct WideDoneArgs { int n; WideDoneItem it[kWideMaxChains]; };
+
+size_t wide_batch_bytes(int B);
+struct WideLaunchPlan {    // what the host has worked out for a batch: common model data, grids
+  int B, N, r;
+  const double* Qp; const double* ref; const double* mean;
+  int grid_prep, grid_f1, grid_r1, grid_f2, grid_r2, grid_reg;
+  bool f1_prepared;
+};
+struct WideChainArgs { WideInstArgs inst; WidePrepArgs prep; StepSearchArgs s1, s2; WideRegArgs reg; };
+// copies the chains' records into `pinned` (wide_batch_bytes(B)), launches the copy to `device` and W2..W8 on `st`
+void launch_wide_front(hipStream_t st, const WideLaunchPlan& plan, const WideChainArgs* chains, void* pinned, void* device);
+int wide_reg_blocks(const WideRegArgs& a);
+int wide_prep_grid(const WidePrepArgs& a);
+void launch_wide_done(hipStream_t st, const WideDoneArgs& a);
+// Σ of the split-K partials of n posteriors into their first partial (as launch_sum_partials)
+void launch_sum_partials_many(hipStream_t st, int r, int n, double* const* Mpart, const int* splits);
+// the tridiagonal route (ranks 65..200) for n decompositions side by side; assemble != 0: M = I + summed partial is written first
+// (launch_assemble_posterior_matrix) from rq[i].spec... no: from `parts[i]`.  Every request needs its own `work`.  No Jacobi fall-back
+// inside the sequence: a spectrum the multisection cannot separate ends with status 2 in the request's status words, and the caller
+// decomposes that posterior again through launch_posterior_eigen.
+bool eigen_tridiag_many_supported(int r);
+void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n, const EigenRequest* rq, const double* const* parts /* may be null */);
 
 SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const float4* spheres, int K, const double* P,
                               int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);

@@ -489,7 +489,7 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
 }
 
 template <int NW, int SI, int NT, int TOFF>
-__global__ void __launch_bounds__(NW * 64) k_tridiag(TridiagIO a) {
+__device__ __forceinline__ void tridiag_kernel_body(const TridiagIO& a) {
   constexpr int LD = 64 * SI;
   __shared__ double lds[TridiagLds<NW, SI>::doubles];
   const int n = a.n, off = LD - n;
@@ -514,6 +514,16 @@ __global__ void __launch_bounds__(NW * 64) k_tridiag(TridiagIO a) {
   EIG_STAMP(0);
   tridiagonalise<NW, SI, NT, TOFF>(a, A, col0, d0, lds);
   EIG_STAMP(1);
+}
+template <int NW, int SI, int NT, int TOFF>
+__global__ void __launch_bounds__(NW * 64) k_tridiag(TridiagIO a) { tridiag_kernel_body<NW, SI, NT, TOFF>(a); }
+// the same for up to kTriMany matrices side by side, one workgroup each (the chains of a wide step: kernels_wide.hip)
+constexpr int kTriMany = 16;
+struct TridiagMany { TridiagIO p[kTriMany]; };
+template <int NW, int SI, int NT, int TOFF>
+__global__ void __launch_bounds__(NW * 64) k_tridiag_many(TridiagMany m) {
+  const TridiagIO a = m.p[blockIdx.x];  // (a copy: scalar registers, as a by-value kernel argument)
+  tridiag_kernel_body<NW, SI, NT, TOFF>(a);
 }
 
 // Ranks <= 64, up to two decompositions per launch (one workgroup each), with the front end of a decomposition that was
@@ -700,8 +710,7 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const 
 }
 
 template <int SI>
-__global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1) {
-  const TriSolveIO& a = blockIdx.y ? a1 : a0;  // (up to two decompositions side by side: the two ICP directions of a chain step)
+__device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
   constexpr int LD = 64 * SI;
   const int off = LD - a.n;  // position of index 0 (see tridiagonalise)
   __shared__ double ds[kTriMaxN], es[kTriMaxN], e2[kTriMaxN], bet[kTriMaxN];
@@ -946,6 +955,16 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1)
     if (a.done_word) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+template <int SI>
+__global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1) {
+  tri_solve_body<SI>(blockIdx.y ? a1 : a0);  // (up to two decompositions side by side: the two ICP directions of a chain step)
+}
+struct TriSolveMany { TriSolveIO p[kTriMany]; };
+template <int SI>
+__global__ void __launch_bounds__(256) k_tri_solve_many(TriSolveMany m) {
+  const TriSolveIO a = m.p[blockIdx.y];
+  tri_solve_body<SI>(a);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // One refinement step (Ogita & Aishima 2018) on the eigenvector matrix X of the step before: eigenvectors of close eigenvalues
@@ -963,8 +982,7 @@ struct TriGemm {
   const double* X;
   double* Ct;
 };
-__global__ void __launch_bounds__(64) k_tri_gemm(int n, TriGemm g0, TriGemm g1) {
-  const TriGemm g = blockIdx.z ? g1 : g0;
+__device__ __forceinline__ void tri_gemm_body(int n, const TriGemm& g) {
   const int l = threadIdx.x, l15 = l & 15, l4 = l >> 4;
   const int i0 = 16 * blockIdx.y, j0 = 16 * blockIdx.x;
   const bool vi = i0 + l15 < n, vj = j0 + l15 < n;
@@ -993,6 +1011,15 @@ __global__ void __launch_bounds__(64) k_tri_gemm(int n, TriGemm g0, TriGemm g1) 
     }
   }
 }
+__global__ void __launch_bounds__(64) k_tri_gemm(int n, TriGemm g0, TriGemm g1) {
+  const TriGemm g = blockIdx.z ? g1 : g0;
+  tri_gemm_body(n, g);
+}
+struct TriGemmMany { TriGemm g[2 * kTriMany]; };  // blockIdx.z = product
+__global__ void __launch_bounds__(64) k_tri_gemm_many(int n, TriGemmMany m) {
+  const TriGemm g = m.g[blockIdx.z];
+  tri_gemm_body(n, g);
+}
 __global__ void __launch_bounds__(256) k_tri_correction(int n, const double* __restrict__ S, const double* __restrict__ R, double* __restrict__ E,
                                                         double* __restrict__ Sout) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -1009,6 +1036,40 @@ __global__ void __launch_bounds__(256) k_tri_correction(int n, const double* __r
     v = fabs(den) > 1e-11 * (fabs(mi) + fabs(mj)) ? fma(mj, R[e], S[e]) / den : 0.5 * R[e];
   }
   E[e] = v;
+}
+struct TriCorrMany { const double* S[kTriMany]; const double* R[kTriMany]; double* E[kTriMany]; double* Sout[kTriMany]; };
+__global__ void __launch_bounds__(256) k_tri_correction_many(int n, TriCorrMany m) {
+  const int e = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
+  if (e >= n * n) return;
+  const double* __restrict__ S = m.S[q];
+  const double* __restrict__ R = m.R[q];
+  const int i = e / n, j = e - i * n;
+  const double rii = R[(size_t)i * n + i], rjj = R[(size_t)j * n + j];
+  const double mi = S[(size_t)i * n + i] / (1.0 - rii), mj = S[(size_t)j * n + j] / (1.0 - rjj);
+  double v;
+  if (i == j) {
+    v = 0.5 * rii;
+    m.Sout[q][i] = 1.0 / mi;
+  } else {
+    const double den = mj - mi;
+    v = fabs(den) > 1e-11 * (fabs(mi) + fabs(mj)) ? fma(mj, R[e], S[e]) / den : 0.5 * R[e];
+  }
+  m.E[q][e] = v;
+}
+struct TriDoneMany { const int* status[kTriMany]; int* host_status[kTriMany]; int* done_word[kTriMany]; int done_value[kTriMany]; };
+__global__ void k_tri_done_many(TriDoneMany m) {
+  const int q = blockIdx.x;
+  if (m.host_status[q]) __hip_atomic_store(m.host_status[q], m.status[q][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (m.done_word[q]) __hip_atomic_store(m.done_word[q], m.done_value[q], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// M = I + the summed split-K partial of a posterior, both triangles (k_assemble_posterior_matrix), for up to kTriMany posteriors
+struct AssembleMany { const double* P[kTriMany]; double* M[kTriMany]; };
+__global__ void __launch_bounds__(256) k_assemble_many(int r, AssembleMany m) {
+  const int e = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
+  if (e >= r * r || !m.P[q]) return;
+  const int i = e / r, j = e - i * r;
+  const int hi = max(i, j), lo = min(i, j);
+  m.M[q][e] = m.P[q][(size_t)hi * (r + 1) + lo] + (i == j ? 1.0 : 0.0);
 }
 __global__ void k_tri_done(const int* status, int* host_status, int* done_word, int done_value) {
   if (host_status) __hip_atomic_store(host_status, status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -68,17 +68,18 @@ __global__ void __launch_bounds__(64) k_regression_mfma(int K, int kchunk, int r
   regression_tile(blockIdx.x, blockIdx.y, K, kchunk, r, Q, cb, wt, kappa, Mpart);
 }
 
-struct FactorArgs {  // up to 4 posteriors per launch (both ICP directions of one or two states)
-  const double* Mpart[4];
-  int splits[4];
-  double* M[4];
-  double* alpha[4];
-  int* status[4];
-  double* scratch[4];  // (r+1)·r doubles, used only when the matrix does not fit in LDS
+constexpr int kFactorMax = kWideMaxChains;  // posteriors per launch: both ICP directions of one or two states — or one per chain of a wide step
+struct FactorArgs {
+  const double* Mpart[kFactorMax];
+  int splits[kFactorMax];
+  double* M[kFactorMax];
+  double* alpha[kFactorMax];
+  int* status[kFactorMax];
+  double* scratch[kFactorMax];  // (r+1)·r doubles, used only when the matrix does not fit in LDS
   // (optional, the Cholesky-root sampler at ranks above 64: icp_proposal_set_sampler) the factor itself: L row-major r × r with a zero
   // upper triangle, and 1/diag(L) — what k_posterior_root writes at ranks <= 64
-  double* Lout[4];
-  double* Sout[4];
+  double* Lout[kFactorMax];
+  double* Sout[kFactorMax];
 };
 
 // the factor out of the root-free form W (w_ij = l_ij·d_j, w_jj = d_j; row stride ld): L_ij = w_ij / sqrt(d_j), L_jj = sqrt(d_j)
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(NT) k_posterior_factor_reg(int r, FactorArgs f
 // 3.3 ms).
 // Σ of the split-K partials of up to two posteriors into their first partial, on many CUs, in split order (the order of the
 // factor kernels' own loops)
-struct PartialSumArgs { int n; int nn; double* Mpart[2]; int splits[2]; };
+struct PartialSumArgs { int n; int nn; double* Mpart[kFactorMax]; int splits[kFactorMax]; };
 __global__ void __launch_bounds__(256) k_sum_partials(PartialSumArgs a) {
   const int which = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
   if (which >= a.n || e >= a.nn) return;
@@ -556,17 +557,18 @@ __global__ void __launch_bounds__(1024) k_posterior_factor_tiles(int r, FactorAr
   FAC_STAMP(20);
 }
 
+constexpr int kTailMax = 2 * kWideMaxChains;  // tails per launch (a wide step: forward and backward of every chain)
 struct TailArgs {
   int n;
-  const int* relay_in[8];
-  int* relay_out[8];
-  const double* alpha[8];
-  const double* M[8];
-  const double* c_from[8];
-  const double* c_to[8];
-  double step[8];
-  double* out[8];
-  int* status[8];
+  const int* relay_in[kTailMax];
+  int* relay_out[kTailMax];
+  const double* alpha[kTailMax];
+  const double* M[kTailMax];
+  const double* c_from[kTailMax];
+  const double* c_to[kTailMax];
+  double step[kTailMax];
+  double* out[kTailMax];
+  int* status[kTailMax];
 };
 
 template <int NT>
@@ -2093,6 +2095,13 @@ void launch_sum_partials(hipStream_t st, int r, double* Mpart, int splits) {
   ra.splits[0] = splits;
   hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(ra.nn, 256), 1), dim3(256), 0, st, ra);
 }
+void launch_sum_partials_many(hipStream_t st, int r, int n, double* const* Mpart, const int* splits) {
+  PartialSumArgs ra{};
+  ra.nn = (r + 1) * (r + 1);
+  for (int i = 0; i < n && i < kFactorMax; ++i)
+    if (splits[i] > 1) { ra.Mpart[ra.n] = Mpart[i]; ra.splits[ra.n] = splits[i]; ++ra.n; }
+  if (ra.n) hipLaunchKernelGGL(k_sum_partials, dim3(cdiv(ra.nn, 256), ra.n), dim3(256), 0, st, ra);
+}
 void launch_assemble_posterior_matrix(hipStream_t st, int r, const double* Mpart_summed, double* M) {
   hipLaunchKernelGGL(k_assemble_posterior_matrix, dim3(cdiv(r * r, 256)), dim3(256), 0, st, r, Mpart_summed, M);
 }
@@ -2111,10 +2120,10 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
   if (blocked) {
     // the split-K partials are summed by a launch of their own, on many CUs, into the first one (same order of summation as the
     // kernel's own loop, which one workgroup's share of the memory system made 44 us of at rank 200)
-    for (int p0 = 0; p0 < n_post; p0 += 2) {
+    for (int p0 = 0; p0 < n_post; p0 += kFactorMax) {
       PartialSumArgs ra{};
       ra.nn = (r + 1) * (r + 1);
-      for (int p = p0; p < std::min(n_post, p0 + 2); ++p)
+      for (int p = p0; p < std::min(n_post, p0 + kFactorMax); ++p)
         if (fa.splits[p] > 1) {
           ra.Mpart[ra.n] = const_cast<double*>(fa.Mpart[p]);
           ra.splits[ra.n] = fa.splits[p];
@@ -2241,6 +2250,58 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   // return at once otherwise
   if (r > 64) launch_eigen_big(st, r, M, sqrt_lambda, nullptr, V, Vt, S, work, status, nullptr, status);
   if (host_status || done_word) hipLaunchKernelGGL(tri::k_tri_done, dim3(1), dim3(1), 0, st, (const int*)status, host_status, done_word, done_value);
+}
+
+// The same route for n decompositions side by side (the chains of a wide step): every launch of the sequence takes all of them —
+// the one-workgroup reductions run on n CUs at once.  No gated Jacobi fall-back in the sequence (see icp_kernels.hpp).
+bool eigen_tridiag_many_supported(int r) { return r > 64 && r <= kTriMaxRank; }
+void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const EigenRequest* rq_all, const double* const* parts_all) {
+  const size_t rr = (size_t)r * r;
+  const int nwg = (r + 3) / 4, nt = (r + 15) / 16;
+  for (int q0 = 0; q0 < n_all; q0 += tri::kTriMany) {
+    const int n = std::min(tri::kTriMany, n_all - q0);
+    const EigenRequest* rq = rq_all + q0;
+    tri::TridiagMany tm{};
+    tri::TriSolveMany sm{};
+    tri::TriGemmMany g1{}, g2{}, g3{};
+    tri::TriCorrMany cm{};
+    tri::TriDoneMany dm{};
+    tri::AssembleMany am{};
+    bool assemble = false;
+    for (int q = 0; q < n; ++q) {
+      double* work = rq[q].work;
+      double* base = work + jacobi_work_doubles(r);
+      double *d = base, *e = base + tri::kTriMaxN, *beta = base + 2 * tri::kTriMaxN, *mu = base + 3 * tri::kTriMaxN;
+      int* sync = (int*)(base + 4 * tri::kTriMaxN);
+      double* Hv = base + 4 * tri::kTriMaxN + 8;
+      double *Nm = work, *X = work + rr, *Xt = work + 2 * rr, *T = work + 3 * rr, *Sm = work + 4 * rr, *R = work + 5 * rr;
+      const double* sl = rq[q].sqrt_lambda;
+      tm.p[q] = tri::TridiagIO{r, rq[q].M, sl, d, e, beta, Hv, Nm};
+      sm.p[q] = tri::TriSolveIO{r, d, e, beta, Hv, X, Xt, rq[q].S, mu, sync, rq[q].status, nullptr, nullptr, 0};
+      g1.g[2 * q] = tri::TriGemm{Nm, X, T, 0, nullptr, nullptr};
+      g1.g[2 * q + 1] = tri::TriGemm{X, X, R, 1, nullptr, nullptr};
+      g2.g[q] = tri::TriGemm{X, T, Sm, 0, nullptr, nullptr};
+      cm.S[q] = Sm; cm.R[q] = R; cm.E[q] = T; cm.Sout[q] = rq[q].S;
+      g3.g[q] = tri::TriGemm{Xt, T, rq[q].V, 2, X, rq[q].Vt};
+      dm.status[q] = rq[q].status; dm.host_status[q] = rq[q].host_status; dm.done_word[q] = rq[q].done_word; dm.done_value[q] = rq[q].done_value;
+      am.P[q] = parts_all ? parts_all[q0 + q] : nullptr;
+      am.M[q] = const_cast<double*>(rq[q].M);
+      assemble = assemble || am.P[q] != nullptr;
+    }
+    ProfScope _ps(st, KID_EIGEN);
+    if (assemble) hipLaunchKernelGGL(tri::k_assemble_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, am);
+    if (r <= 128) hipLaunchKernelGGL((tri::k_tridiag_many<4, 2, 32, 0>), dim3(n), dim3(256), 0, st, tm);
+    else if (r <= 192) hipLaunchKernelGGL((tri::k_tridiag_many<8, 3, 24, 0>), dim3(n), dim3(512), 0, st, tm);
+    else hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 25, 7>), dim3(n), dim3(512), 0, st, tm);
+    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg, n), dim3(256), 0, st, sm);
+    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve_many<3>, dim3(nwg, n), dim3(256), 0, st, sm);
+    else hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg, n), dim3(256), 0, st, sm);
+    hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, 2 * n), dim3(64), 0, st, r, g1);
+    hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, n), dim3(64), 0, st, r, g2);
+    hipLaunchKernelGGL(tri::k_tri_correction_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, cm);
+    hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, n), dim3(64), 0, st, r, g3);
+    hipLaunchKernelGGL(tri::k_tri_done_many, dim3(n), dim3(1), 0, st, dm);
+  }
 }
 
 // N = D⁻¹ M D⁻¹ (symmetrised) for the in-place kernel

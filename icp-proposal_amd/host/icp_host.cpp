@@ -360,8 +360,14 @@ struct LockstepGroup {
       } else if (auto* rw = dynamic_cast<RandomShapeUpdateProposal*>(leaf)) {
         g = -1;
         prop[b] = rw->propose(ch->current, rnd[b], 0).allParameters;
+      } else if (auto* gp = dynamic_cast<GaussianAxisPoseProposal*>(leaf)) {
+        // PoseProposals.scala:31-90: the proposed state is the current one with one pose parameter moved — submitted with the others
+        // (the library's wide step takes pose moves side by side with the chains' ICP proposals; configurations it does not cover
+        // are stepped one after the other by the same call)
+        g = -1;
+        prop[b] = gp->propose(ch->current, rnd[b], 0).allParameters;
       }
-      if (g == -2 || n_icp == 0) continue;  // pose proposals: MetropolisHastings::next submits them itself
+      if (g == -2 || n_icp == 0) continue;  // anything else: MetropolisHastings::next submits it itself
       member.push_back((int)b);
       ev.push_back(ch->likelihood->h);
       for (auto* p : ch->icp) props.push_back(p->h);
@@ -397,7 +403,11 @@ struct LockstepGroup {
         ModelFittingParameters& pr = scratch_prop;  // (keeps its storage from chain to chain)
         pr.allParameters = prop[member[k]];
         if (gen[k] >= 0) pr.generatedBy = ch->icp[gen[k]]->generatedBy;
-        else pr.generatedBy = static_cast<RandomShapeUpdateProposal*>(ch->root->peek(rnd[member[k]], 0))->generatedBy;
+        else {
+          ProposalGeneratorWithTransition* leaf = ch->root->peek(rnd[member[k]], 0);
+          if (auto* rw = dynamic_cast<RandomShapeUpdateProposal*>(leaf)) pr.generatedBy = rw->generatedBy;
+          else if (auto* gp = dynamic_cast<GaussianAxisPoseProposal*>(leaf)) pr.generatedBy = gp->generatedBy;
+        }
         ch->prefetcher.park(ch->current, pr, status[k], value[k], fwd.data() + k * n_icp, bwd.data() + k * n_icp);
         if (gen[k] >= 0) { ch->prefetcher.submitted_index = gen[k]; ch->prefetcher.submitted_z = z[member[k]]; }
       }

@@ -368,6 +368,12 @@ typedef struct {
 } icp_runtime_stats;
 ICP_API int icp_ctx_runtime_stats(const icp_ctx *ctx, icp_runtime_stats *out);
 
+/* ---- which path the chain steps took (diagnostic: the results do not depend on it).  Counts since the context was created or, with
+ * ctx == NULL, of the process: out[0] the five merged launches (icp_chain_step[_batched]), out[1] the wide step (targets with a
+ * boundary, the Hausdorff evaluator, ranks up to 200, pose moves: DESIGN.md), out[2] per-stage kernels, out[3] steps taken inside
+ * icp_chains_run_on_device. */
+ICP_API int icp_ctx_step_paths(const icp_ctx *ctx, int64_t out[4]);
+
 /* ---- model cache.  Contexts made from the same model arrays share its derived device data (the scaled basis in two layouts, the
  * Gram matrix and its inverses: 0.35 s of host work and 2 x 137 MB of uploads at N = 28,561, rank 200).  The library keeps the two
  * most recently used models alive after their last context is destroyed, so that a job which builds one context per target over one

