@@ -282,9 +282,10 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=300, help="steps of the HIP-event roofline leg (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=96, help="steps of the B2 leg of the CPU baseline (B1 runs 4x as many; 0 = skip)")
     ap.add_argument("--subdiv", type=int, default=6, help="edge subdivision of the synthetic femur target (6 -> 58,322 vertices)")
-    ap.add_argument("--chains-per-gpu", type=int, default=1,
-                    help="independent chains per GPU, stepped in lockstep through icp_chain_step_batched (default 1 = the BASELINE.json "
-                         "configuration; more is the RunMHRandomInitComparison-style many-chains job on fewer GPUs)")
+    ap.add_argument("--chains-per-gpu", type=int, default=0,
+                    help="independent chains per GPU, stepped in lockstep through icp_chain_step_batched (0 = default: 1 for --config 1-3, the "
+                         "BASELINE.json configuration — more is the RunMHRandomInitComparison-style many-chains job on fewer GPUs; --config 4: "
+                         "all chains of a target side by side, 1 = one after the other)")
     ap.add_argument("--many-chains", type=int, default=64,
                     help="extra leg after the timed region (1 GPU, 1 chain per GPU, config 1 only): aggregate rate of this many chains on the GPU "
                          "stepped through icp_chain_step_batched, reported as `many_chains` (0 = skip)")
@@ -549,6 +550,8 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
     model = face_model(pkg, args)
     targets = [pkg.data.synthetic_partial_target(model, seed=100 + t) for t in range(args.targets)]
     make_setup = lambda m, t: pkg.bfm_fitting_partial(m, t, evaluator="collective", fused=args.fused)
+    # chains of one target side by side (the wide step): all of them unless --chains-per-gpu says otherwise (1 = one after the other)
+    cpl = args.chains if args.chains_per_gpu <= 0 else args.chains_per_gpu
     # warm-up: one item per rank (builds the communicator, pages the kernels in)
     pkg.sharding.run_batch(pkg, model, targets[:1], n_chains=world, n_steps=max(1, args.warmup), make_setup=make_setup, dist=dist,
                            device_index=local_rank)
@@ -556,7 +559,7 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     items, recs, stats = pkg.sharding.run_batch(pkg, model, targets, n_chains=args.chains, n_steps=args.steps, make_setup=make_setup, dist=dist,
-                                                device_index=local_rank, chains_per_launch=max(1, args.chains_per_gpu), return_stats=True)
+                                                device_index=local_rank, chains_per_launch=cpl, return_stats=True)
     if dist is not None:
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -585,7 +588,7 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
                            "baseline_config_index": 4, "items": n_items, "items_per_s": n_items / dt, "job_s": dt,
                            "items_per_rank": [int(p[1]) for p in per_rank], "contexts_built_per_rank": [int(p[0]) for p in per_rank],
                            "gather_ms_per_rank": [round(p[2], 3) for p in per_rank], "chain_ms_per_rank": [round(p[3], 1) for p in per_rank],
-                           "chains_per_launch": max(1, args.chains_per_gpu), "best_item": [int(v) for v in items[best]],
+                           "chains_per_launch": cpl, "best_item": [int(v) for v in items[best]],
                            "accepted": int(sum(r[:, 1].sum() for r in recs))},
                 "roofline": None, "cpu_baseline": None, "multi_gpu": multi_gpu, "runtime_stats": pkg._native.runtime_stats()}
         print(json.dumps(line))

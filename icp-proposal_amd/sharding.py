@@ -112,15 +112,16 @@ def gather_ragged(blocks, dist=None, device=None):
 
 
 def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist=None, device_index: int = 0, base_seed: int = 1024,
-              chains_per_launch: int = 1, return_stats: bool = False):
+              chains_per_launch: int = 0, return_stats: bool = False):
     """Batch registration (BASELINE.json configs[4]; reference: the 10-way target pool × per-target chain loop of
     apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala:106-163): work items = (target, chain) pairs, dealt target-major
     over the ranks (assign_target_major); a rank keeps ONE context per target it meets; chains never communicate; the per-step
     records of all items are exchanged with a single all_gather at the end.  Returns (items, records): items[k] = (target index,
     chain index) and records[k] = [n_steps, 14 + rank] for every item of the whole job, in item order, on every rank.
-    chains_per_launch > 1: the rank steps that many of its chains OF ONE TARGET in lockstep through icp_chain_step_batched (one
-    context per chain — model and target are shared between them on the device; SURVEY.md §8e "within a GPU, batch B chains per
-    launch") — same records, chain by chain.
+    chains_per_launch = B > 1: the rank steps B of its chains OF ONE TARGET side by side through icp_chain_step_batched (one context
+    per chain — model and target are shared between them on the device; SURVEY.md §8e "within a GPU, batch B chains per launch") —
+    same records, chain by chain.  0 (default): all chains the rank holds of a target (the one-workgroup factorisations and
+    decompositions of B chains then run on B CUs instead of one after the other); 1: one context per target, its chains one by one.
     return_stats: a third value, this rank's {items, contexts_built, targets_met, chain_ms, gather_ms}."""
     import time
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
@@ -129,6 +130,8 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
     mine = assign_target_major(len(targets), n_chains, world)[rank]
     blocks = []
     contexts_built = 0
+    if chains_per_launch <= 0:
+        chains_per_launch = max(1, n_chains)
     t_start = time.perf_counter()
     my_targets = sorted(set(items[k][0] for k in mine))
     for t in my_targets:
