@@ -314,6 +314,7 @@ struct icp_ctx {
   // decompositions of one proposal never overlap each other; the two directions of a step share ONE launch)
   hipStream_t eig_stream = nullptr;
   hipStream_t eig_stream2 = nullptr;  // ranks above 64: decompositions started ahead alternate between the two (each with a work buffer of its own)
+  hipStream_t eig_last2 = nullptr; // (the wide step's second eigen stream, see batch_eig2)
   hipStream_t eig_last = nullptr;  // where this context's latest decompositions were launched: eig_stream, or the eigen stream
                                    // of the first context of a batch (see eigen_stream_for)
   hipEvent_t ev_ready = nullptr;                 // stream -> eig_stream: "M is complete"
@@ -412,6 +413,7 @@ struct icp_ctx {
   // together, so that the runtime spreads them over different hardware queues — the member contexts' own eigen streams
   // collide on one queue for some batch sizes (24 chains in three groups: 49k instead of 70k it/s)
   hipStream_t batch_eig[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t batch_eig2[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};  // … and a second one each (the wide step alternates: two decompositions of a chain in flight)
   const void* batch_eig_owner[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
   int batch_eig_evict = 0;
 
@@ -1078,21 +1080,24 @@ void icp_proposal::prepare_eigen(PosteriorEntry& e, EigenRequest* rq) {
 }
 
 // the eigen stream of the batch whose first chain lives on `owner`, out of the launch context's pool
-hipStream_t batch_eigen_stream(icp_ctx& lead, const void* owner) {
+hipStream_t batch_eigen_stream(icp_ctx& lead, const void* owner, int second = 0) {
   if (!lead.batch_eig[0]) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
-    for (int k = 0; k < icp_ctx::kBatchRing; ++k) {
+    for (int k = 0; k < icp_ctx::kBatchRing; ++k) {  // (a batch's two streams made one after the other: neighbours among the hardware queues)
       HIP_OK(hipStreamCreateWithFlags(&lead.batch_eig[k], hipStreamNonBlocking));
       g_eig_streams.insert(lead.batch_eig[k]);
+      HIP_OK(hipStreamCreateWithFlags(&lead.batch_eig2[k], hipStreamNonBlocking));
+      g_eig_streams.insert(lead.batch_eig2[k]);
     }
   }
+  hipStream_t* pool = second ? lead.batch_eig2 : lead.batch_eig;
   for (int k = 0; k < icp_ctx::kBatchRing; ++k)
-    if (lead.batch_eig_owner[k] == owner) return lead.batch_eig[k];
+    if (lead.batch_eig_owner[k] == owner) return pool[k];
   for (int k = 0; k < icp_ctx::kBatchRing; ++k)
-    if (!lead.batch_eig_owner[k]) { lead.batch_eig_owner[k] = owner; return lead.batch_eig[k]; }
+    if (!lead.batch_eig_owner[k]) { lead.batch_eig_owner[k] = owner; return pool[k]; }
   const int k = (lead.batch_eig_evict = (lead.batch_eig_evict + 1) % icp_ctx::kBatchRing);  // (more than four batches: shared)
   lead.batch_eig_owner[k] = owner;
-  return lead.batch_eig[k];
+  return pool[k];
 }
 
 // waits for every decomposition of this context that may still be running
@@ -1100,6 +1105,10 @@ void sync_eigen(icp_ctx& c) {
   if (c.eig_last && c.eig_last != c.eig_stream) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     if (g_eig_streams.count(c.eig_last)) HIP_OK(hipStreamSynchronize(c.eig_last));
+  }
+  if (c.eig_last2 && c.eig_last2 != c.eig_stream2) {
+    std::lock_guard<std::mutex> lk(g_eig_streams_mu);
+    if (g_eig_streams.count(c.eig_last2)) HIP_OK(hipStreamSynchronize(c.eig_last2));
   }
   HIP_OK(hipStreamSynchronize(c.eig_stream));
   if (c.eig_stream2) HIP_OK(hipStreamSynchronize(c.eig_stream2));
@@ -1109,6 +1118,12 @@ hipStream_t eigen_stream_for(icp_ctx& c, hipStream_t want) {
   if (c.eig_last && c.eig_last != want) sync_eigen(c);
   c.eig_last = want;
   return want;
+}
+// the wide step's pair of eigen streams (the second one only carries decompositions that use the proposals' second work buffer)
+void eigen_streams_for(icp_ctx& c, hipStream_t e0, hipStream_t e1) {
+  if ((c.eig_last && c.eig_last != e0) || (c.eig_last2 && c.eig_last2 != e1)) sync_eigen(c);
+  c.eig_last = e0;
+  c.eig_last2 = e1;
 }
 
 void icp_proposal::ensure_eigen(PosteriorEntry& e) {
@@ -1608,14 +1623,19 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     if (g_eig_streams.count(ctx->eig_last)) (void)hipStreamSynchronize(ctx->eig_last);
   }
-  for (hipStream_t& bs : ctx->batch_eig)
-    if (bs) {
-      std::lock_guard<std::mutex> lk(g_eig_streams_mu);
-      g_eig_streams.erase(bs);
-      (void)hipStreamSynchronize(bs);
-      (void)hipStreamDestroy(bs);
-      bs = nullptr;
-    }
+  if (ctx->eig_last2 && ctx->eig_last2 != ctx->eig_stream2) {
+    std::lock_guard<std::mutex> lk(g_eig_streams_mu);
+    if (g_eig_streams.count(ctx->eig_last2)) (void)hipStreamSynchronize(ctx->eig_last2);
+  }
+  for (hipStream_t* pool : {ctx->batch_eig, ctx->batch_eig2})
+    for (int k = 0; k < icp_ctx::kBatchRing; ++k)
+      if (pool[k]) {
+        std::lock_guard<std::mutex> lk(g_eig_streams_mu);
+        g_eig_streams.erase(pool[k]);
+        (void)hipStreamSynchronize(pool[k]);
+        (void)hipStreamDestroy(pool[k]);
+        pool[k] = nullptr;
+      }
   if (ctx->eig_stream2) {
     (void)hipStreamSynchronize(ctx->eig_stream2);
     (void)hipStreamDestroy(ctx->eig_stream2);
@@ -1813,6 +1833,8 @@ int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity,
     sync_eigen(*ctx);
     for (hipStream_t bs : ctx->batch_eig)
       if (bs) HIP_OK(hipStreamSynchronize(bs));  // (decompositions of batches this context carried)
+    for (hipStream_t bs : ctx->batch_eig2)
+      if (bs) HIP_OK(hipStreamSynchronize(bs));
     ctx->profiling = false;
     std::vector<icp_kernel_stat> acc(KID_COUNT);
     for (int i = 0; i < KID_COUNT; ++i) {
@@ -3506,7 +3528,16 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   const int r = elead.r, nW = (int)idx.size();
   std::lock_guard<std::recursive_mutex> lead_lk(lead.mu);  // (its streams, its record ring)
   const hipStream_t S = lead.stream, S2 = lead.front_stream;
-  const hipStream_t E = batch_eigen_stream(lead, &elead);
+  // Two eigen streams: the decompositions of a chain's consecutive steps alternate between them (and between the proposal's two work
+  // buffers), so that one started ahead for a state that was then not kept — or whose successor was a pose move that did not wait
+  // for it — does not hold the next one back: at rank 200 a decomposition takes 0.6-0.7 ms, a step that does not wait for one half
+  // of that.  A lone chain uses its context's own pair (made with the context, on hardware queues of their own), a batch the launch
+  // context's pool.  (Ranks <= 64: one stream — the Jacobi iteration is warm-started from the decomposition before it.)
+  const bool two_eig = eigen_tridiag_many_supported(r) && elead.eig_stream2 != nullptr;
+  const bool lone = t.n_chains == 1 && &lead == &elead;
+  hipStream_t Es[2];
+  Es[0] = lone ? elead.eig_stream : batch_eigen_stream(lead, &elead, 0);
+  Es[1] = !two_eig ? Es[0] : (lone ? elead.eig_stream2 : batch_eigen_stream(lead, &elead, 1));
   const int turn = (lead.wide_turn = (lead.wide_turn + 1) % icp_ctx::kBatchRing);
   {
     Bound _b(&lead, true, true);
@@ -3530,8 +3561,8 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   std::vector<PosteriorEntry*> root_entries;  // (Cholesky-root sampler above rank 64: the factorisation hands the "basis" out)
   std::vector<icp_proposal*> root_props;
   std::vector<TransitionTailIO> tails;
-  std::vector<EigenRequest> spec_rq; std::vector<const double*> spec_parts; std::vector<PosteriorEntry*> spec_entries;
-  std::vector<EigenRequest> pre_rq; std::vector<PosteriorEntry*> pre_entries;
+  std::vector<EigenRequest> spec_rq[2]; std::vector<const double*> spec_parts[2]; std::vector<PosteriorEntry*> spec_entries[2];
+  std::vector<EigenRequest> pre_rq[2]; std::vector<PosteriorEntry*> pre_entries[2];
   std::vector<WideDoneItem> dones;
   WideLaunchPlan plan{};
   plan.B = nW; plan.N = elead.N; plan.r = r; plan.Qp = elead.Qp.p; plan.ref = elead.ref.p; plan.mean = elead.mean.p;
@@ -3582,9 +3613,11 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
         pg->prepare_eigen(g, &rq);
         rq.sqrt_lambda = c.sqrt_lambda.p;
         g.eig_event_valid = false; g.eig_done_shared = nullptr; g.eig_shared_gen = nullptr;
-        (void)eigen_stream_for(c, E);
-        pre_rq.push_back(rq);
-        pre_entries.push_back(&g);
+        eigen_streams_for(c, Es[0], Es[1]);
+        const int fl = two_eig ? (int)(pg->eig_flip++ & 1) : 0;
+        if (fl) rq.work = pg->work2.p;
+        pre_rq[fl].push_back(rq);
+        pre_entries[fl].push_back(&g);
       } else {
         wide_await_entry(c, pg, g, S, waited);
       }
@@ -3815,10 +3848,12 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
         ep[i]->eig_checked = false;
         ep[i]->eig_event_valid = false; ep[i]->eig_done_shared = nullptr; ep[i]->eig_shared_gen = nullptr;
         p->mpart_reader[p->mpart_half] = ep[i];
-        (void)eigen_stream_for(c, E);
-        spec_rq.push_back(rq);
-        spec_parts.push_back(parts[i]);
-        spec_entries.push_back(ep[i]);
+        eigen_streams_for(c, Es[0], Es[1]);
+        const int fl = two_eig ? (int)(p->eig_flip++ & 1) : 0;
+        if (fl) rq.work = p->work2.p;
+        spec_rq[fl].push_back(rq);
+        spec_parts[fl].push_back(parts[i]);
+        spec_entries[fl].push_back(ep[i]);
       }
     }
     dones.push_back(di);
@@ -3827,16 +3862,17 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
 
   // ---- one sequence of launches for all of them
   Bound _b(&lead, true, true);
-  BatchEventSlot* ev_pre = nullptr;
-  if (!pre_rq.empty()) {  // KL bases of current states that have none yet (a chain's first ICP proposal; speculation off)
-    if (eigen_tridiag_many_supported(r)) launch_posterior_eigen_tridiag_many(E, r, (int)pre_rq.size(), pre_rq.data(), nullptr);
+  for (int fl = 0; fl < 2; ++fl) {
+    if (pre_rq[fl].empty()) continue;  // KL bases of current states that have none yet (a chain's first ICP proposal; speculation off)
+    const hipStream_t E = Es[fl];
+    if (eigen_tridiag_many_supported(r)) launch_posterior_eigen_tridiag_many(E, r, (int)pre_rq[fl].size(), pre_rq[fl].data(), nullptr);
     else
-      for (auto& rq : pre_rq)
+      for (auto& rq : pre_rq[fl])
         if (!launch_posterior_eigen_pair(E, r, rq.sqrt_lambda, 1, &rq)) fail(ICP_ERR_DEVICE, "internal: wide step at a rank without a decomposition kernel");
-    ev_pre = &next_batch_event(elead.device);
+    BatchEventSlot* ev_pre = &next_batch_event(elead.device);
     HIP_OK(hipEventRecord(ev_pre->ev, E));
     HIP_OK(hipStreamWaitEvent(S, ev_pre->ev, 0));
-    for (PosteriorEntry* en : pre_entries) {
+    for (PosteriorEntry* en : pre_entries[fl]) {
       en->eig_done_shared = ev_pre->ev; en->eig_shared_gen = &ev_pre->gen; en->eig_shared_gen_value = ev_pre->gen;
       en->eig_event_valid = true; en->done_value = 0;
     }
@@ -3853,13 +3889,16 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   HIP_OK(hipEventRecord(lead.ev_wide_sum[turn], S));
   // the one-workgroup kernels on the second stream: the next batch's chip-wide launches on `S` run beside them
   HIP_OK(hipStreamWaitEvent(S2, lead.ev_wide_sum[turn], 0));
-  const bool jacobi_spec = !spec_rq.empty() && !eigen_tridiag_many_supported(r);  // (ranks <= 64: the iteration reads the finished M)
-  if (!spec_rq.empty() && !jacobi_spec) {
-    // the proposed states' KL bases BESIDE their factorisations: M = I + the summed partials is written at the head of the
-    // decomposition as well (the values the factorisation's own assembly writes)
-    HIP_OK(hipStreamWaitEvent(E, lead.ev_wide_sum[turn], 0));
-    launch_posterior_eigen_tridiag_many(E, r, (int)spec_rq.size(), spec_rq.data(), spec_parts.data());
-  }
+  const bool any_spec = !spec_rq[0].empty() || !spec_rq[1].empty();
+  const bool jacobi_spec = any_spec && !eigen_tridiag_many_supported(r);  // (ranks <= 64: the iteration reads the finished M)
+  if (any_spec && !jacobi_spec)
+    for (int fl = 0; fl < 2; ++fl) {
+      if (spec_rq[fl].empty()) continue;
+      // the proposed states' KL bases BESIDE their factorisations: M = I + the summed partials is written at the head of the
+      // decomposition as well (the values the factorisation's own assembly writes)
+      HIP_OK(hipStreamWaitEvent(Es[fl], lead.ev_wide_sum[turn], 0));
+      launch_posterior_eigen_tridiag_many(Es[fl], r, (int)spec_rq[fl].size(), spec_rq[fl].data(), spec_parts[fl].data());
+    }
   for (size_t p0 = 0; p0 < factors.size(); p0 += kWideMaxChains)
     launch_posterior_factor(S2, r, (int)std::min<size_t>(kWideMaxChains, factors.size() - p0), factors.data() + p0);
   if (!root_entries.empty()) {  // "decomposed" as soon as the factorisation is through: an event behind it stands for the basis
@@ -3874,14 +3913,15 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   }
   if (jacobi_spec) {
     HIP_OK(hipEventRecord(lead.ev_wide_fac[turn], S2));
-    HIP_OK(hipStreamWaitEvent(E, lead.ev_wide_fac[turn], 0));
-    for (size_t q = 0; q < spec_rq.size(); ++q)
-      if (!launch_posterior_eigen_pair(E, r, spec_rq[q].sqrt_lambda, 1, &spec_rq[q])) fail(ICP_ERR_DEVICE, "internal: wide step at a rank without a decomposition kernel");
+    HIP_OK(hipStreamWaitEvent(Es[0], lead.ev_wide_fac[turn], 0));
+    for (size_t q = 0; q < spec_rq[0].size(); ++q)
+      if (!launch_posterior_eigen_pair(Es[0], r, spec_rq[0][q].sqrt_lambda, 1, &spec_rq[0][q])) fail(ICP_ERR_DEVICE, "internal: wide step at a rank without a decomposition kernel");
   }
-  if (!spec_rq.empty()) {
+  for (int fl = 0; fl < 2; ++fl) {
+    if (spec_rq[fl].empty()) continue;
     BatchEventSlot& done = next_batch_event(elead.device);
-    HIP_OK(hipEventRecord(done.ev, E));
-    for (PosteriorEntry* en : spec_entries) {
+    HIP_OK(hipEventRecord(done.ev, Es[fl]));
+    for (PosteriorEntry* en : spec_entries[fl]) {
       en->eig_done_shared = done.ev; en->eig_shared_gen = &done.gen; en->eig_shared_gen_value = done.gen;
       en->eig_event_valid = true; en->done_value = 0;
     }
