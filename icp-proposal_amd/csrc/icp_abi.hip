@@ -353,6 +353,7 @@ struct icp_ctx {
   QueryScratch scratch_t;  // third: … and the evaluator's target -> model surface search
   QueryScratch scratch_n;  // the wide step's second search stage: nearest target vertices of the model-side surface points …
   QueryScratch scratch_tn; // … and nearest model vertices of the evaluator's target-side surface points (their own candidate counters)
+  QueryScratch scratch_p;  // the proposal's own model ids where the evaluator's searches run as a sequence of their own (the wide step, Hausdorff)
   // staging for small host<->device transfers of one API call
   double* h_stage = nullptr;  // pinned
   DBuf<double> d_stage;
@@ -398,6 +399,8 @@ struct icp_ctx {
   size_t wide_bytes[kBatchRing] = {0, 0, 0, 0};
   hipEvent_t ev_wide_sum[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};   // stream -> eigen / finish streams: the partials are summed
   hipEvent_t ev_wide_fac[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};   // finish stream -> eigen stream: M is complete (ranks <= 64)
+  hipEvent_t ev_wide_head[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};  // stream -> second stream: the new instances are complete
+  hipEvent_t ev_wide_eval[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};  // stream -> second stream: the evaluator's own sequence is through
   int wide_turn = 0;
   double* h_wide_z = nullptr;  // pinned: the coefficients a wide step is GIVEN (random-walk / pose proposals), read by its first launch
   // … and of their decompositions: the records of launch_posterior_eigen_many (pinned, read in place by the kernel), the counter
@@ -421,7 +424,7 @@ struct icp_ctx {
 
   // scratch for K queries against a set of n_elems elements (every query may list every element as a candidate)
   QueryBuffers query_scratch(size_t K, size_t n_elems, int which = 0) {
-    QueryScratch& scratch = which == 1 ? scratch_v : which == 2 ? scratch_t : which == 3 ? scratch_n : which == 4 ? scratch_tn : this->scratch;
+    QueryScratch& scratch = which == 1 ? scratch_v : which == 2 ? scratch_t : which == 3 ? scratch_n : which == 4 ? scratch_tn : which == 5 ? scratch_p : this->scratch;
     if (K > scratch.cap) {
       HIP_OK(hipStreamSynchronize(stream));
       if (front_stream) HIP_OK(hipStreamSynchronize(front_stream));
@@ -1671,6 +1674,10 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   for (hipEvent_t ev : ctx->ev_wide_sum)
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : ctx->ev_wide_fac)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : ctx->ev_wide_head)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : ctx->ev_wide_eval)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->h_gate_error) (void)hipHostFree(ctx->h_gate_error);
   for (void* bp : ctx->batch_eig_rec)
@@ -3543,6 +3550,8 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     Bound _b(&lead, true, true);
     if (!lead.ev_wide_sum[turn]) HIP_OK(hipEventCreateWithFlags(&lead.ev_wide_sum[turn], hipEventDisableTiming));
     if (!lead.ev_wide_fac[turn]) HIP_OK(hipEventCreateWithFlags(&lead.ev_wide_fac[turn], hipEventDisableTiming));
+    if (!lead.ev_wide_head[turn]) HIP_OK(hipEventCreateWithFlags(&lead.ev_wide_head[turn], hipEventDisableTiming));
+    if (!lead.ev_wide_eval[turn]) HIP_OK(hipEventCreateWithFlags(&lead.ev_wide_eval[turn], hipEventDisableTiming));
     const size_t bytes = wide_batch_bytes(nW);
     if (bytes > lead.wide_bytes[turn]) {
       // (the slot's previous reader was the batch four tickets ago: collected, its launches finished)
@@ -3567,6 +3576,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   WideLaunchPlan plan{};
   plan.B = nW; plan.N = elead.N; plan.r = r; plan.Qp = elead.Qp.p; plan.ref = elead.ref.p; plan.mean = elead.mean.p;
   plan.f1_prepared = true;
+  bool any_split = false;
   const int spec_mode = speculation_mode();
 
   for (int k = 0; k < nW; ++k) {
@@ -3689,8 +3699,16 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     const int Knnv = std::max(prop_nnv ? pm->K : 0, eval_nnv ? Km : 0);
     require(Ksurf <= c.N, "model id count exceeds the number of model points");
     w.Ksurf = Ksurf; w.Knnv = Knnv; w.spheres = ev_t2m;
-    QueryBuffers qs{}, qv{}, qt{}, qn{}, qtn{};
-    if (Ksurf > 0) qs = c.query_scratch(Ksurf, c.target.T, 0);
+    // The full-mesh Hausdorff evaluator (every model vertex against the target surface, every target vertex against the model's:
+    // 0.2 ms of chip-wide searches) beside a proposal whose own chain — its K model ids, their nearest vertices, the regression, then
+    // the one-workgroup factorisation and tails, 0.2 ms — needs none of that: two sequences on two streams.  The proposal's ids
+    // 0..Kp are then a surface task of their own, the evaluator takes the ids behind them.
+    const bool split = hd && w.do_post;
+    const int Kp = split ? (pm ? pm->K : 0) : 0;
+    any_split = any_split || split;
+    QueryBuffers qs{}, qv{}, qt{}, qn{}, qtn{}, qp{};
+    if (Ksurf - Kp > 0) qs = c.query_scratch(Ksurf - Kp, c.target.T, 0);
+    if (split && Kp > 0) qp = c.query_scratch(Kp, c.target.T, 5);
     if (pt) qv = c.query_scratch(pt->K, c.N, 1);
     if (ev_t2m) qt = c.query_scratch(Kt, c.T, 2);
     if (Knnv > 0) qn = c.query_scratch(Knnv, c.target.V, 3);
@@ -3698,11 +3716,14 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
 
     WideChainArgs& A = chain_args[k];
     std::memset(&A, 0, sizeof(A));
-    SurfaceTask st_surf{}, st_t2m{};
+    SurfaceTask st_surf{}, st_t2m{}, st_surfp{};
     VertexTask st_vert{}, st_nnv{}, st_tnn{};
-    if (Ksurf > 0)
-      st_surf = make_surface_task(c.target.T, c.target.verts.p, c.target.tris.p, c.target.spheres.p, Ksurf, s.x.p, c.hint_surf.p, qs,
-                                  s.surf_cp.p, s.surf_d2.p, s.surf_tri.p);
+    if (Ksurf - Kp > 0)  // (ids Kp..Ksurf; Kp = 0 unless the evaluator has a sequence of its own)
+      st_surf = make_surface_task(c.target.T, c.target.verts.p, c.target.tris.p, c.target.spheres.p, Ksurf - Kp, s.x.p + 3 * (size_t)Kp,
+                                  c.hint_surf.p + Kp, qs, s.surf_cp.p + 3 * (size_t)Kp, s.surf_d2.p + Kp, s.surf_tri.p + Kp);
+    if (split && Kp > 0)
+      st_surfp = make_surface_task(c.target.T, c.target.verts.p, c.target.tris.p, c.target.spheres.p, Kp, s.x.p, c.hint_surf.p, qp,
+                                   s.surf_cp.p, s.surf_d2.p, s.surf_tri.p);
     if (ev_t2m)
       st_t2m = make_surface_task(c.T, s.x.p, c.tris.p, s.spheres.p, Kt, e->d_tpts, e->hint_tri.p, qt, e->t2m_cp.p, e->t2m_d2.p, e->t2m_tri.p);
     if (pt) { st_vert = make_vertex_task(c.N, s.x.p, pt->K, pt->target_pts.p, pt->hint_nn.p, qv, nullptr, pt->nn_id.p); st_vert.thr2 = nullptr; }
@@ -3715,7 +3736,12 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     A.inst.defo_src = same ? same->defo.p : nullptr;
     A.inst.pose = s.pose;
     A.inst.x = s.x.p; A.inst.defo = s.defo.p;
-    A.inst.has_surf = Ksurf > 0 ? 1 : 0; A.inst.surf = st_surf;
+    if (split) {
+      A.inst.has_surf = Kp > 0 ? 1 : 0; A.inst.surf = st_surfp;
+      A.inst.has_surf2 = Ksurf - Kp > 0 ? 1 : 0; A.inst.surf2 = st_surf;
+    } else {
+      A.inst.has_surf = Ksurf > 0 ? 1 : 0; A.inst.surf = st_surf;
+    }
     // W3
     A.prep.T = ev_t2m ? c.T : 0; A.prep.x = s.x.p; A.prep.tris = c.tris.p; A.prep.order = c.tri_order.p; A.prep.spheres = s.spheres.p;
     A.prep.has_t2m = ev_t2m ? 1 : 0; A.prep.t2m = st_t2m;
@@ -3724,15 +3750,16 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     if (Knnv > 0) { A.prep.cnt[A.prep.n_cnt] = st_nnv.cnt; A.prep.cnt_n[A.prep.n_cnt++] = st_nnv.Kpad; }
     if (t2m_nnv) { A.prep.cnt[A.prep.n_cnt] = st_tnn.cnt; A.prep.cnt_n[A.prep.n_cnt++] = st_tnn.Kpad; }
     A.prep.zero_d = c.d_res.p; A.prep.n_zero_d = 8;
-    // W4/W5: stage 1
+    // W4/W5: stage 1 — the main sequence: every search of the step, or (split) only the proposal's
     StepSearchArgs& q1 = A.s1;
     q1.s_corr[0] = q1.s_corr[1] = q1.v_corr[0] = q1.v_corr[1] = -1;
     int nt = 0, n_corr = 0;
     q1.fstart[0] = 0; q1.rstart[0] = 0;
-    if (Ksurf > 0) {
-      q1.s[q1.n_surf] = st_surf;
-      q1.fstart[nt + 1] = q1.fstart[nt] + filter_grid_blocks(st_surf.tblocks, st_surf.ksplit);
-      q1.rstart[nt + 1] = q1.rstart[nt] + Ksurf;
+    const SurfaceTask& st_first = split ? st_surfp : st_surf;
+    if (st_first.K > 0) {
+      q1.s[q1.n_surf] = st_first;
+      q1.fstart[nt + 1] = q1.fstart[nt] + filter_grid_blocks(st_first.tblocks, st_first.ksplit);
+      q1.rstart[nt + 1] = q1.rstart[nt] + st_first.K;
       if (pm && !prop_nnv) {
         q1.corr[n_corr] = CorrTask{pm->K, ep[im]->corr(), s.x.p, nullptr, c.target.boundary.p, nullptr, pm->prm.boundary_aware,
                                    s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, nullptr};
@@ -3740,7 +3767,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
       }
       ++q1.n_surf; ++nt;
     }
-    if (ev_t2m) {
+    if (ev_t2m && !split) {
       q1.s[q1.n_surf] = st_t2m;
       q1.fstart[nt + 1] = q1.fstart[nt] + filter_grid_blocks(st_t2m.tblocks, st_t2m.ksplit);
       q1.rstart[nt + 1] = q1.rstart[nt] + Kt;
@@ -3756,6 +3783,26 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
       q1.n_vert = 1; ++nt;
     }
     for (int u = nt + 1; u < 5; ++u) { q1.fstart[u] = q1.fstart[nt]; q1.rstart[u] = q1.rstart[nt]; }
+    // … and the evaluator's own sequence (split): the model ids behind the proposal's, the target -> model direction
+    StepSearchArgs& q1b = A.s1b;
+    q1b.s_corr[0] = q1b.s_corr[1] = q1b.v_corr[0] = q1b.v_corr[1] = -1;
+    int ntb = 0;
+    q1b.fstart[0] = 0; q1b.rstart[0] = 0;
+    if (split) {
+      if (st_surf.K > 0) {
+        q1b.s[q1b.n_surf] = st_surf;
+        q1b.fstart[ntb + 1] = q1b.fstart[ntb] + filter_grid_blocks(st_surf.tblocks, st_surf.ksplit);
+        q1b.rstart[ntb + 1] = q1b.rstart[ntb] + st_surf.K;
+        ++q1b.n_surf; ++ntb;
+      }
+      if (ev_t2m) {
+        q1b.s[q1b.n_surf] = st_t2m;
+        q1b.fstart[ntb + 1] = q1b.fstart[ntb] + filter_grid_blocks(st_t2m.tblocks, st_t2m.ksplit);
+        q1b.rstart[ntb + 1] = q1b.rstart[ntb] + Kt;
+        ++q1b.n_surf; ++ntb;
+      }
+    }
+    for (int u = ntb + 1; u < 5; ++u) { q1b.fstart[u] = q1b.fstart[ntb]; q1b.rstart[u] = q1b.rstart[ntb]; }
     // W6/W7: stage 2 (nearest vertices of the surface points)
     StepSearchArgs& q2 = A.s2;
     q2.s_corr[0] = q2.s_corr[1] = q2.v_corr[0] = q2.v_corr[1] = -1;
@@ -3806,12 +3853,24 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     if (g.n == 1) g.ustart[2] = g.ustart[1];
     A.reg.eval_kind = evp.kind; A.reg.eval_m2t = ev_m2t ? 1 : 0; A.reg.eval_t2m = ev_t2m ? 1 : 0;
     A.reg.Km = Km; A.reg.d2m = s.surf_d2.p;
+    if (split) {  // (the maxima are order-independent: the proposal's ids by the main sequence, the rest by the evaluator's own)
+      A.reg.eval_m2t = Kp > 0 ? 1 : 0; A.reg.Km = Kp; A.reg.eval_t2m = 0;
+      A.regb = A.reg;
+      A.regb.reg.n = 0; A.regb.reg.ustart[0] = A.regb.reg.ustart[1] = A.regb.reg.ustart[2] = 0;
+      A.regb.eval_m2t = Km - Kp > 0 ? 1 : 0; A.regb.Km = Km - Kp; A.regb.d2m = s.surf_d2.p + Kp;
+      A.regb.eval_t2m = ev_t2m ? 1 : 0;
+    }
     A.reg.flags_m = eval_nnv ? c.target.boundary.p : nullptr; A.reg.idx_m = eval_nnv ? s.surf_nnv.p : nullptr;
     A.reg.Kt = Kt; A.reg.d2t = e->t2m_d2.p;
     A.reg.flags_t = t2m_nnv ? c.target.boundary.p : nullptr; A.reg.idx_t = t2m_nnv ? e->t2m_nnv.p : nullptr;  // (sic: SURVEY App. D5)
     A.reg.n_flags = c.target.V;
     A.reg.mean = evp.gauss_mean; A.reg.sigma = evp.gauss_sigma;
     A.reg.red_out = c.d_res.p;
+    if (split) { A.regb.Kt = Kt; A.regb.d2t = e->t2m_d2.p; A.regb.flags_t = nullptr; A.regb.idx_t = nullptr; A.regb.flags_m = nullptr; A.regb.idx_m = nullptr;
+                 A.regb.n_flags = c.target.V; A.regb.mean = evp.gauss_mean; A.regb.sigma = evp.gauss_sigma; A.regb.red_out = c.d_res.p; }
+    plan.grid_f1b = std::max(plan.grid_f1b, q1b.fstart[ntb]);
+    plan.grid_r1b = std::max(plan.grid_r1b, q1b.rstart[ntb]);
+    if (split) plan.grid_regb = std::max(plan.grid_regb, wide_reg_blocks(A.regb));
     plan.grid_prep = std::max(plan.grid_prep, wide_prep_grid(A.prep));
     plan.grid_f1 = std::max(plan.grid_f1, q1.fstart[nt]);
     plan.grid_r1 = std::max(plan.grid_r1, q1.rstart[nt]);
@@ -3883,12 +3942,25 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     for (int i = 0; i < pa.n; ++i) pa.it[i] = prop_items[p0 + i];
     launch_wide_propose(S, r, pa);
   }
-  launch_wide_front(S, plan, chain_args.data(), lead.wide_pinned[turn], lead.wide_device[turn].p);
+  launch_wide_head(S, plan, chain_args.data(), lead.wide_pinned[turn], lead.wide_device[turn].p);
+  // the step's searches, regressions and reductions: on `S` — or, where the evaluator's searches are a sequence of their own, those
+  // on `S` and the proposals' chain (searches of their K ids, regression, then factorisation and tails) on the second stream beside them
+  const hipStream_t Sm = any_split ? S2 : S;
+  if (any_split) {
+    HIP_OK(hipEventRecord(lead.ev_wide_head[turn], S));
+    HIP_OK(hipStreamWaitEvent(S2, lead.ev_wide_head[turn], 0));
+  }
+  launch_wide_main(Sm, plan, lead.wide_device[turn].p);
   for (size_t p0 = 0; p0 < sum_parts.size(); p0 += kWideMaxChains)
-    launch_sum_partials_many(S, r, (int)std::min<size_t>(kWideMaxChains, sum_parts.size() - p0), sum_parts.data() + p0, sum_splits.data() + p0);
-  HIP_OK(hipEventRecord(lead.ev_wide_sum[turn], S));
-  // the one-workgroup kernels on the second stream: the next batch's chip-wide launches on `S` run beside them
-  HIP_OK(hipStreamWaitEvent(S2, lead.ev_wide_sum[turn], 0));
+    launch_sum_partials_many(Sm, r, (int)std::min<size_t>(kWideMaxChains, sum_parts.size() - p0), sum_parts.data() + p0, sum_splits.data() + p0);
+  HIP_OK(hipEventRecord(lead.ev_wide_sum[turn], Sm));
+  if (any_split) {
+    launch_wide_eval(S, plan, lead.wide_device[turn].p);
+    HIP_OK(hipEventRecord(lead.ev_wide_eval[turn], S));
+  } else {
+    // the one-workgroup kernels on the second stream: the next batch's chip-wide launches on `S` run beside them
+    HIP_OK(hipStreamWaitEvent(S2, lead.ev_wide_sum[turn], 0));
+  }
   const bool any_spec = !spec_rq[0].empty() || !spec_rq[1].empty();
   const bool jacobi_spec = any_spec && !eigen_tridiag_many_supported(r);  // (ranks <= 64: the iteration reads the finished M)
   if (any_spec && !jacobi_spec)
@@ -3928,6 +4000,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   }
   for (size_t t0 = 0; t0 < tails.size(); t0 += 2 * kWideMaxChains)
     launch_transition_tails(S2, r, (int)std::min<size_t>(2 * kWideMaxChains, tails.size() - t0), tails.data() + t0, elead.Ginv.p, kSigma2);
+  if (any_split) HIP_OK(hipStreamWaitEvent(S2, lead.ev_wide_eval[turn], 0));  // (the reductions of the evaluator's own sequence)
   for (size_t p0 = 0; p0 < dones.size(); p0 += kWideMaxChains) {
     WideDoneArgs da{};
     da.n = (int)std::min<size_t>(kWideMaxChains, dones.size() - p0);

@@ -524,6 +524,8 @@ struct WideInstArgs {      // W2, per chain (device memory)
   Pose pose;
   double* x; double* defo;
   int has_surf; SurfaceTask surf;   // model ids 0..K-1 of the new instance against the target surface: bounds from the hints
+  // (a step whose evaluator searches run beside the proposal's: the ids from surf.K on are a task of their own, query k = id surf.K + k)
+  int has_surf2; SurfaceTask surf2;
 };
 struct WidePrepArgs {      // W3, per chain (device memory)
   int T; const double* x; const int* tris; const int* order; float4* spheres;   // T = 0: no search of the new instance's surface
@@ -552,11 +554,19 @@ struct WideLaunchPlan {    // what the host has worked out for a batch: common m
   int B, N, r;
   const double* Qp; const double* ref; const double* mean;
   int grid_prep, grid_f1, grid_r1, grid_f2, grid_r2, grid_reg;
+  int grid_f1b, grid_r1b, grid_regb;  // the evaluator's own sequence (s1b, regb), if any chain of the batch has one
   bool f1_prepared;
 };
-struct WideChainArgs { WideInstArgs inst; WidePrepArgs prep; StepSearchArgs s1, s2; WideRegArgs reg; };
-// copies the chains' records into `pinned` (wide_batch_bytes(B)), launches the copy to `device` and W2..W8 on `st`
-void launch_wide_front(hipStream_t st, const WideLaunchPlan& plan, const WideChainArgs* chains, void* pinned, void* device);
+// s1 / s2 / reg: the step's searches and reductions — or, where the evaluator's searches are heavy (the full-mesh Hausdorff distance:
+// every model vertex against the target surface, every target vertex against the model's), only what the PROPOSAL needs (its K model
+// ids, their nearest vertices, the regression), the evaluator's searches and reductions being a sequence of their own (s1b, regb) that
+// the host puts on another stream: 0.2 ms of chip-wide searches beside 0.2 ms of one-workgroup factorisation and tails
+struct WideChainArgs { WideInstArgs inst; WidePrepArgs prep; StepSearchArgs s1, s2; WideRegArgs reg; StepSearchArgs s1b; WideRegArgs regb; };
+// copies the chains' records into `pinned` (wide_batch_bytes(B)); launches the copy to `device`, the instances and W3 on `st`
+void launch_wide_head(hipStream_t st, const WideLaunchPlan& plan, const WideChainArgs* chains, void* pinned, void* device);
+// W4..W8 of the records in `device` (launch_wide_head): the main sequence, the evaluator's own
+void launch_wide_main(hipStream_t st, const WideLaunchPlan& plan, void* device);
+void launch_wide_eval(hipStream_t st, const WideLaunchPlan& plan, void* device);
 int wide_reg_blocks(const WideRegArgs& a);
 int wide_prep_grid(const WidePrepArgs& a);
 void launch_wide_done(hipStream_t st, const WideDoneArgs& a);

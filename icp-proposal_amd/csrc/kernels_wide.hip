@@ -42,8 +42,11 @@ __global__ void __launch_bounds__(NT) k_wide_propose(int r, WideProposeArgs a, i
 // the operations of instance_vertex_keep, so every chain's points are bit-identical to its own k_instance_keep launch.  A chain
 // that only changes its pose (kind 1) takes its kept deformations instead (k_instance_pose).  137 MB of basis at N = 28,561 /
 // rank 200: read once per group of chains instead of once per chain.
-constexpr int kWideInstBlock = 128;
-constexpr int kWideInstU = 8;  // basis columns (× 3 rows) in flight per batch of loads
+// One WAVE per workgroup and many loads in flight per lane: at N = 28,561 that is 447 waves for 1,024 SIMDs — every wave has a SIMD
+// to itself and the kernel is the latency of its ⌈r/16⌉ batches of 48 loads (128-thread workgroups with 24 loads in flight left
+// most CUs idle: 157 µs for a group of five chains where one chain's own launch took 23)
+constexpr int kWideInstBlock = 64;
+constexpr int kWideInstU = 16;  // basis columns (× 3 rows) in flight per batch of loads
 constexpr int kWideMaxRankLds = 256;
 
 template <int G>
@@ -107,6 +110,11 @@ __global__ void __launch_bounds__(kWideInstBlock) k_wide_instance(int B, int N, 
     if (a.has_surf) {
       if (i < a.surf.K) surface_init_with(a.surf, i, p, load_hint_triangle(a.surf, i));  // query i = model point i (NonRigidIcpProposal.scala:96)
       if (i < kQU && a.surf.K + i < a.surf.Kpad) surface_init_at(a.surf, a.surf.K + i, d3{0.0, 0.0, 0.0});  // sentinel slots
+    }
+    if (a.has_surf2) {
+      const int k = i - (a.has_surf ? a.surf.K : 0);  // the ids behind the first task's
+      if (k >= 0 && k < a.surf2.K) surface_init_with(a.surf2, k, p, load_hint_triangle(a.surf2, k));
+      if (i < kQU && a.surf2.K + i < a.surf2.Kpad) surface_init_at(a.surf2, a.surf2.K + i, d3{0.0, 0.0, 0.0});
     }
   }
 }
@@ -312,24 +320,39 @@ void launch_wide_propose(hipStream_t st, int r, const WideProposeArgs& a) {
 }
 
 size_t wide_batch_bytes(int B) {
-  return up16(sizeof(WideInstArgs) * B) + up16(sizeof(WidePrepArgs) * B) + 2 * up16(sizeof(StepSearchArgs) * B) + up16(sizeof(WideRegArgs) * B);
+  return up16(sizeof(WideInstArgs) * B) + up16(sizeof(WidePrepArgs) * B) + 3 * up16(sizeof(StepSearchArgs) * B) + 2 * up16(sizeof(WideRegArgs) * B);
 }
+namespace {
+struct WideOffsets { size_t prep, s1, s2, reg, s1b, regb, total; };
+WideOffsets wide_offsets(int B) {
+  WideOffsets o;
+  o.prep = up16(sizeof(WideInstArgs) * B);
+  o.s1 = o.prep + up16(sizeof(WidePrepArgs) * B);
+  o.s2 = o.s1 + up16(sizeof(StepSearchArgs) * B);
+  o.reg = o.s2 + up16(sizeof(StepSearchArgs) * B);
+  o.s1b = o.reg + up16(sizeof(WideRegArgs) * B);
+  o.regb = o.s1b + up16(sizeof(StepSearchArgs) * B);
+  o.total = o.regb + up16(sizeof(WideRegArgs) * B);
+  return o;
+}
+}  // namespace
 
-void launch_wide_front(hipStream_t st, const WideLaunchPlan& plan, const WideChainArgs* chains, void* pinned, void* device) {
+void launch_wide_head(hipStream_t st, const WideLaunchPlan& plan, const WideChainArgs* chains, void* pinned, void* device) {
   const int B = plan.B;
   if (B <= 0) return;
-  const size_t o1 = up16(sizeof(WideInstArgs) * B), o2 = o1 + up16(sizeof(WidePrepArgs) * B), o3 = o2 + up16(sizeof(StepSearchArgs) * B),
-               o4 = o3 + up16(sizeof(StepSearchArgs) * B), total = wide_batch_bytes(B);
+  const WideOffsets o = wide_offsets(B);
   char* h = (char*)pinned;
   char* d = (char*)device;
   for (int b = 0; b < B; ++b) {
     ((WideInstArgs*)h)[b] = chains[b].inst;
-    ((WidePrepArgs*)(h + o1))[b] = chains[b].prep;
-    ((StepSearchArgs*)(h + o2))[b] = chains[b].s1;
-    ((StepSearchArgs*)(h + o3))[b] = chains[b].s2;
-    ((WideRegArgs*)(h + o4))[b] = chains[b].reg;
+    ((WidePrepArgs*)(h + o.prep))[b] = chains[b].prep;
+    ((StepSearchArgs*)(h + o.s1))[b] = chains[b].s1;
+    ((StepSearchArgs*)(h + o.s2))[b] = chains[b].s2;
+    ((WideRegArgs*)(h + o.reg))[b] = chains[b].reg;
+    ((StepSearchArgs*)(h + o.s1b))[b] = chains[b].s1b;
+    ((WideRegArgs*)(h + o.regb))[b] = chains[b].regb;
   }
-  const int n16 = (int)(total / 16);
+  const int n16 = (int)(o.total / 16);
   hipLaunchKernelGGL(k_wide_args, dim3(cdiv(n16, 256)), dim3(256), 0, st, (const uint4*)h, (uint4*)d, n16);
   {
     ProfScope _ps(st, KID_INSTANCE);
@@ -344,28 +367,46 @@ void launch_wide_front(hipStream_t st, const WideLaunchPlan& plan, const WideCha
   }
   if (plan.grid_prep > 0) {
     ProfScope _ps(st, KID_TRI_SPHERES);
-    hipLaunchKernelGGL(k_wide_prepare, dim3(plan.grid_prep, B), dim3(kSearchBlock), 0, st, (const WidePrepArgs*)(d + o1));
+    hipLaunchKernelGGL(k_wide_prepare, dim3(plan.grid_prep, B), dim3(kSearchBlock), 0, st, (const WidePrepArgs*)(d + o.prep));
   }
-  if (plan.grid_f1 > 0) {
-    ProfScope _ps(st, KID_STEP_FILTER);
-    if (plan.f1_prepared) hipLaunchKernelGGL(k_wide_filter<true>, dim3(plan.grid_f1, B), dim3(kSearchBlock), 0, st, (const StepSearchArgs*)(d + o2));
-    else hipLaunchKernelGGL(k_wide_filter<false>, dim3(plan.grid_f1, B), dim3(kSearchBlock), 0, st, (const StepSearchArgs*)(d + o2));
+}
+
+namespace {
+void launch_wide_searches(hipStream_t st, int B, int gf, int gr, bool prepared, const StepSearchArgs* a, int kid_f, int kid_r) {
+  if (gf > 0) {
+    ProfScope _ps(st, kid_f);
+    if (prepared) hipLaunchKernelGGL(k_wide_filter<true>, dim3(gf, B), dim3(kSearchBlock), 0, st, a);
+    else hipLaunchKernelGGL(k_wide_filter<false>, dim3(gf, B), dim3(kSearchBlock), 0, st, a);
   }
-  if (plan.grid_r1 > 0) {
-    ProfScope _ps(st, KID_STEP_RESOLVE);
-    hipLaunchKernelGGL(k_wide_resolve, dim3(plan.grid_r1, B), dim3(64), 0, st, (const StepSearchArgs*)(d + o2));
+  if (gr > 0) {
+    ProfScope _ps(st, kid_r);
+    hipLaunchKernelGGL(k_wide_resolve, dim3(gr, B), dim3(64), 0, st, a);
   }
-  if (plan.grid_f2 > 0) {
-    ProfScope _ps(st, KID_VERTEX_FILTER);
-    hipLaunchKernelGGL(k_wide_filter<true>, dim3(plan.grid_f2, B), dim3(kSearchBlock), 0, st, (const StepSearchArgs*)(d + o3));
-  }
-  if (plan.grid_r2 > 0) {
-    ProfScope _ps(st, KID_VERTEX_RESOLVE);
-    hipLaunchKernelGGL(k_wide_resolve, dim3(plan.grid_r2, B), dim3(64), 0, st, (const StepSearchArgs*)(d + o3));
-  }
+}
+}  // namespace
+
+void launch_wide_main(hipStream_t st, const WideLaunchPlan& plan, void* device) {
+  const int B = plan.B;
+  if (B <= 0) return;
+  const WideOffsets o = wide_offsets(B);
+  char* d = (char*)device;
+  launch_wide_searches(st, B, plan.grid_f1, plan.grid_r1, plan.f1_prepared, (const StepSearchArgs*)(d + o.s1), KID_STEP_FILTER, KID_STEP_RESOLVE);
+  launch_wide_searches(st, B, plan.grid_f2, plan.grid_r2, true, (const StepSearchArgs*)(d + o.s2), KID_VERTEX_FILTER, KID_VERTEX_RESOLVE);
   if (plan.grid_reg > 0) {
     ProfScope _ps(st, KID_STEP_REGRESSION);
-    hipLaunchKernelGGL(k_wide_regression, dim3(plan.grid_reg, B), dim3(kWideRegBlock), 0, st, (const WideRegArgs*)(d + o4));
+    hipLaunchKernelGGL(k_wide_regression, dim3(plan.grid_reg, B), dim3(kWideRegBlock), 0, st, (const WideRegArgs*)(d + o.reg));
+  }
+}
+
+void launch_wide_eval(hipStream_t st, const WideLaunchPlan& plan, void* device) {
+  const int B = plan.B;
+  if (B <= 0) return;
+  const WideOffsets o = wide_offsets(B);
+  char* d = (char*)device;
+  launch_wide_searches(st, B, plan.grid_f1b, plan.grid_r1b, plan.f1_prepared, (const StepSearchArgs*)(d + o.s1b), KID_SURFACE_FILTER, KID_SURFACE_RESOLVE);
+  if (plan.grid_regb > 0) {
+    ProfScope _ps(st, KID_REDUCE);
+    hipLaunchKernelGGL(k_wide_regression, dim3(plan.grid_regb, B), dim3(kWideRegBlock), 0, st, (const WideRegArgs*)(d + o.regb));
   }
 }
 
