@@ -6,6 +6,7 @@
 // context stream and synchronises ONCE, when results are copied back.  No CPU fallback exists: without a HIP
 // device icp_ctx_create fails.
 #include "../../include/icp_proposal.h"
+#include "../../include/icp_sincos.h"
 
 #include <algorithm>
 #include <atomic>
@@ -168,16 +169,11 @@ void check_triangles(int V, int T, const int32_t* tris, const char* what) {
     if (tris[i] < 0 || tris[i] >= V) fail(ICP_ERR_INVALID_ARG, std::string(what) + ": triangle vertex id out of range");
 }
 
-// Rotation(phi,theta,psi,centre) = Rz(phi)·Ry(theta)·Rx(psi); host libm so every kernel sees
-// the same matrix a CPU evaluation of the reference's transform would use.
+// Rotation(phi,theta,psi,centre) = Rz(phi)·Ry(theta)·Rx(psi), with the sines and cosines of
+// include/icp_sincos.h: plain arithmetic, the same bits here, on the device (the pose walks of the on-device chain loop) and in the oracle
 Pose pose_from_theta(const double* th) {
   Pose p;
-  double phi = th[4], theta = th[5], psi = th[6];
-  double cph = std::cos(phi), sph = std::sin(phi), cth = std::cos(theta), sth = std::sin(theta), cps = std::cos(psi),
-         sps = std::sin(psi);
-  p.R[0] = cth * cph; p.R[1] = sps * sth * cph - cps * sph; p.R[2] = sps * sph + cps * sth * cph;
-  p.R[3] = cth * sph; p.R[4] = cps * cph + sps * sth * sph; p.R[5] = cps * sth * sph - sps * cph;
-  p.R[6] = -sth;      p.R[7] = sps * cth;                   p.R[8] = cps * cth;
+  icp_rotation_matrix(th[4], th[5], th[6], p.R);
   for (int d = 0; d < 3; ++d) { p.t[d] = th[1 + d]; p.ctr[d] = th[7 + d]; }
   p.s = th[0];
   return p;

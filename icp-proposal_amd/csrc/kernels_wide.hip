@@ -77,6 +77,9 @@ __global__ void __launch_bounds__(kWideInstBlock) k_wide_instance(int B, int N, 
       double v[3 * kWideInstU];
 #pragma unroll
       for (int u = 0; u < 3 * kWideInstU; ++u) v[u] = q[(size_t)(3 * j + u) * N];
+      // (all of them requested before the first multiply: left alone, the scheduler sinks each load to its use to save registers —
+      // one load in flight per lane, and a group of five chains took 150 µs where one chain's launch takes 23)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < kWideInstU; ++u)
 #pragma unroll

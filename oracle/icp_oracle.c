@@ -18,6 +18,7 @@
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).  No FMA contraction: the reference
  * runs on the JVM, whose a*b+c is two roundings.
  */
+#include "../include/icp_sincos.h"
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -171,12 +172,10 @@ ORC_API void orc_mesh_boundary(const orc_mesh *m, unsigned char *out) { memcpy(o
  * theta = [s | t(3) | phi,theta,psi | centre(3) | c(r)]   ref: api/sampling/ModelFittingParameters.scala:27-36,64 */
 
 /* Scalismo Rotation(phi,theta,psi,centre): R = Rz(phi)·Ry(theta)·Rx(psi)  [SCALISMO-UNVERIFIED, SURVEY App. B8] */
-ORC_API void orc_rotation_matrix(double phi, double theta, double psi, double *R) {
-  double cph = cos(phi), sph = sin(phi), cth = cos(theta), sth = sin(theta), cps = cos(psi), sps = sin(psi);
-  R[0] = cth * cph; R[1] = sps * sth * cph - cps * sph; R[2] = sps * sph + cps * sth * cph;
-  R[3] = cth * sph; R[4] = cps * cph + sps * sth * sph; R[5] = cps * sth * sph - sps * cph;
-  R[6] = -sth;      R[7] = sps * cth;                   R[8] = cps * cth;
-}
+/* sines and cosines: include/icp_sincos.h — ONE plain-arithmetic implementation shared with the library's host and device code, so
+ * that the three rotation matrices of an Euler triple are the same bits (the device's libm is not the host's) */
+ORC_API void orc_rotation_matrix(double phi, double theta, double psi, double *R) { icp_rotation_matrix(phi, theta, psi, R); }
+ORC_API void orc_sincos(double x, double *s, double *c) { icp_sincos(x, s, c); }
 
 /* ref: ModelFittingParameters.scala:79-110 — x = scale(pose(shape(x̄))).
  * shape: x̄ + (μ + Σ_j Q_ij c_j) accumulated in basis order (GP instance via NearestNeighborInterpolator
