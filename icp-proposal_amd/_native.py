@@ -55,7 +55,8 @@ class KernelStat(C.Structure):
 
 
 class MhMixture(C.Structure):
-    _fields_ = [("icp_weight", C.c_double * 2), ("w_icp", C.c_double), ("w_rw", C.c_double), ("rw_sigma", C.c_double)]
+    _fields_ = [("icp_weight", C.c_double * 2), ("w_icp", C.c_double), ("w_rw", C.c_double), ("rw_sigma", C.c_double),
+                ("w_pose", C.c_double), ("pose_rot_sigma", C.c_double * 3), ("pose_trans_sigma", C.c_double * 3)]
 
 
 class RuntimeStats(C.Structure):

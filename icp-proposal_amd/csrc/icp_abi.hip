@@ -4474,7 +4474,9 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
   int rc = guard([&] {
     require(n_chains >= 1 && evaluators && props_in && mix && seeds && first_step && theta && log_value && n_steps >= 0, "null argument");
     require(n_props >= 1 && n_props <= 2, "the on-device loop takes one or two ICP proposals per chain");
-    require(mix->w_icp > 0.0 && mix->w_rw >= 0.0 && mix->rw_sigma > 0.0, "bad mixture");
+    require(mix->w_icp > 0.0 && mix->w_rw >= 0.0 && mix->rw_sigma > 0.0 && mix->w_pose >= 0.0, "bad mixture");
+    if (mix->w_pose > 0.0)
+      for (int a = 0; a < 3; ++a) require(mix->pose_rot_sigma[a] > 0.0 && mix->pose_trans_sigma[a] > 0.0, "pose walk sigmas must be positive");
     chains.resize(n_chains);
     icp_ctx& lead = *evaluators[0]->ctx;
     const int r = lead.r, P = 10 + r;
@@ -4496,6 +4498,8 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       ch.lk = std::unique_lock<std::recursive_mutex>(c.mu);
       if (c.batch_busy) fail(ICP_ERR_BUSY, "a chain's context already belongs to a batch in flight");
       require(step_pipeline_covers(ch.e, n_props, ch.props), "configuration not covered by the merged launches");
+      if (mix->w_pose > 0.0)  // (the device makes the proposed pose's matrix with the library's own convention)
+        for (const auto& re : c.rotations) require(!re.valid, "pose walks on the device: the context has caller-supplied rotation matrices");
       Bound _b(&c);
       if (ch.e->front.valid) release_front(ch.e->front);
       for (int i = 0; i < n_props; ++i) {
@@ -4676,14 +4680,29 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
           double ws = 0.0;
           for (int i = 0; i < n_props; ++i) ws += mix->icp_weight[i];
           for (int i = 0; i < n_props; ++i) m.icp_w[i] = mix->icp_weight[i] / ws;
-          double raw[2];
+          double raw[3];
           int no = 0;
+          if (mix->w_pose > 0.0) { m.outer_kind[no] = 0; raw[no++] = mix->w_pose; }  // (BfmFittingPartial.scala:70: pose, ICP, shape walk)
           m.outer_kind[no] = 1; raw[no++] = mix->w_icp;
           if (mix->w_rw > 0.0) { m.outer_kind[no] = 2; raw[no++] = mix->w_rw; }
           double wsum = 0.0;
           for (int o = 0; o < no; ++o) wsum += raw[o];
           for (int o = 0; o < no; ++o) m.outer_w[o] = raw[o] / wsum;
           m.n_outer = no;
+        }
+        if (mix->w_pose > 0.0) {  // MixedProposalDistributions.scala:29-39 / host/icp_host.cpp: mixed_random_pose_proposal
+          static const int param_index[6] = {6, 5, 4, 1, 2, 3};  // yaw = rotation._3, pitch = _2, roll = _1 (PoseProposals.scala:39-41); x, y, z
+          m.n_pose = 6;
+          double wsum = 0.0;
+          for (int a = 0; a < 6; ++a) wsum += 0.5;
+          for (int a = 0; a < 6; ++a) {
+            const double sd = a < 3 ? mix->pose_rot_sigma[a] : mix->pose_trans_sigma[a - 3];
+            m.pose_index[a] = param_index[a];
+            m.pose_w[a] = 0.5 / wsum;
+            m.pose_sigma[a] = sd;
+            m.pose_logc[a] = std::log(std::sqrt(2.0 * M_PI)) + std::log(sd);  // breeze Gaussian(0, σ).logPdf's normaliser
+          }
+          m.front_every_step = 1;
         }
         m.rw_sigma = mix->rw_sigma;
         m.rw_logc = 0.5 * (r * std::log(2.0 * M_PI) + r * std::log(mix->rw_sigma * mix->rw_sigma));
@@ -4758,7 +4777,9 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
             Group& prev = groups[(g + n_groups - 1) % n_groups];
             if (blk > 0 || s_ > 0 || g > 0) HIP_OK(hipStreamWaitEvent(gr.st, prev.ev_big, 0));
           }
-          if (s_ == 0) launch_mh_front(gr.st, gr.B, gr.mh.p);  // (later steps of the block: prepared by the decide kernel of the step before)
+          // (later steps of a block: prepared by the decide kernel of the step before — except with pose walks, whose proposed pose is
+          // made by the front kernel)
+          if (s_ == 0 || mix->w_pose > 0.0) launch_mh_front(gr.st, gr.B, gr.mh.p);
           const int token_at = gr.B >= 64 ? 1 : 2;
           {
             int ga[5] = {0, 0, 0, 0, 0}, gb[5] = {0, 0, 0, 0, 0};

@@ -450,8 +450,16 @@ struct MhChain {
   // -- fixed for the run
   unsigned long long seed;
   int r, n_icp;
-  int n_outer, outer_kind[2];            // outer mixture in the reference's order; kind 1 = the ICP mixture, 2 = the shape random walk
-  double outer_w[2];                     // normalised weights
+  int n_outer, outer_kind[3];            // outer mixture in the reference's order (apps/bfm/BfmFittingPartial.scala:70: pose, ICP, shape walk);
+                                         // kind 0 = the pose mixture, 1 = the ICP mixture, 2 = the shape random walk
+  double outer_w[3];                     // normalised weights
+  // the six pose walks (api/sampling/proposals/PoseProposals.scala:31-90; MixedProposalDistributions.scala:29-39: yaw, pitch, roll,
+  // x, y, z, weight 0.5 each), leaf ids 3..8: the parameter each perturbs, its σ, log √(2π) + log σ
+  int n_pose, pose_index[6];
+  double pose_w[6], pose_sigma[6], pose_logc[6];
+  int front_every_step;                  // (mixtures with pose walks: every step's head by k_mh_front — the proposed pose is made there)
+  int pose_move;                         // this step's proposal is a pose walk (its leaf: `leaf`)
+  double prop_pose[10];                  // … the proposed state's first ten parameters
   double icp_w[2];                       // normalised inner weights of the ICP mixture
   double rw_sigma, rw_logc;              // rw_logc = 0.5·(r·log 2π + r·log σ²)
   double prior_c;                        // 0.5·r·log 2π

@@ -29,6 +29,7 @@
 #include "icp_kernels.hpp"
 #include "icp_search.hpp"
 #include "icp_dense.hpp"
+#include "../../include/icp_sincos.h"
 
 namespace icp {
 
@@ -609,17 +610,20 @@ __device__ __forceinline__ void mh_copy(T* dst, const T* src, int tid, int nt) {
 // One wave per chain; called by k_mh_front (first step of a block of normals) and by k_mh_decide for the step behind its own.
 __device__ __forceinline__ void mh_front_body(MhChain& c, const int tid) {
   const int r = c.r;
-  __shared__ int s_gen;
+  __shared__ int s_gen, s_pose_leaf;
   if (tid == 0) {
     const unsigned long long step = (unsigned long long)c.step;
     const int o = mh_pick(c.n_outer, c.outer_w, mh_uniform(c.seed, step, 0));
-    int gen = -1, leaf = 2;  // the shape random walk (RandomShapeUpdateProposal) = leaf 2
+    int gen = -1, leaf = 2, pose_leaf = -1;  // the shape random walk (RandomShapeUpdateProposal) = leaf 2
     if (c.outer_kind[o] == 1) {
       gen = mh_pick(c.n_icp, c.icp_w, mh_uniform(c.seed, step, 1));
       leaf = gen;
+    } else if (c.outer_kind[o] == 0) {  // mixedRandomPoseProposal: the inner draw picks one of the six walks
+      pose_leaf = mh_pick(c.n_pose, c.pose_w, mh_uniform(c.seed, step, 1));
+      leaf = 3 + pose_leaf;
     }
-    c.gen = gen; c.leaf = leaf;
-    s_gen = gen;
+    c.gen = gen; c.leaf = leaf; c.pose_move = pose_leaf >= 0 ? 1 : 0;
+    s_gen = gen; s_pose_leaf = pose_leaf;
   }
   const int sel = c.cur_sel;
   mh_copy(c.begin_live, c.begin_alt[sel], tid, 64);
@@ -635,10 +639,28 @@ __device__ __forceinline__ void mh_front_body(MhChain& c, const int tid) {
     b.propose = gen >= 0 ? 1 : 0;
     if (gen >= 0) b.prop = c.prop_alt[sel][gen];
   }
+  const int pose_leaf = s_pose_leaf;
   if (tid < r) {
     // ICP: posterior.sample()'s standard normals (NonRigidIcpProposal.scala:55); shape walk: the sample itself, c + σ·z
-    // (RandomShapeUpdateProposal.scala:31-35)
-    b.zin[tid] = gen >= 0 ? z[tid] : c.theta[10 + tid] + c.rw_sigma * z[tid];
+    // (RandomShapeUpdateProposal.scala:31-35); pose walk: the coefficients stay
+    b.zin[tid] = gen >= 0 ? z[tid] : (pose_leaf >= 0 ? c.theta[10 + tid] : c.theta[10 + tid] + c.rw_sigma * z[tid]);
+  }
+  if (c.n_pose > 0 && tid == 0) {
+    // The step's pose: the chain's current one — or, for a pose walk, the current one with ONE parameter moved by σ·z₀
+    // (PoseProposals.scala:39-41, :72-74).  The rotation matrix from include/icp_sincos.h: the bits the host's pose_from_theta and the
+    // oracle's orc_rotation_matrix give for these angles.  It goes where the step's kernels read it: the instance (launch 1) and the
+    // correspondences' inverse rigid transform (launch 3).
+    double th[10];
+    for (int k = 0; k < 10; ++k) th[k] = c.theta[k];
+    if (pose_leaf >= 0) th[c.pose_index[pose_leaf]] = th[c.pose_index[pose_leaf]] + c.pose_sigma[pose_leaf] * z[0];
+    for (int k = 0; k < 10; ++k) c.prop_pose[k] = th[k];
+    Pose P;
+    icp_rotation_matrix(th[4], th[5], th[6], P.R);
+    for (int d = 0; d < 3; ++d) { P.t[d] = th[1 + d]; P.ctr[d] = th[7 + d]; }
+    P.s = th[0];
+    b.pose = P;
+    c.search_live->corr[0].pose = P;
+    c.search_live->corr[1].pose = P;
   }
 }
 __global__ void __launch_bounds__(64) k_mh_front(MhChain* __restrict__ chains) {
@@ -669,7 +691,9 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   const u64 seed = c.seed;
   const double cur_p = c.cur_p, rw_sigma = c.rw_sigma;
   const double ninf = -__builtin_inf();
-  const bool has_next = step + 1 - c.normals_first < (long long)c.normals_rows;  // (uniform) the next step's normals are on the device
+  // (uniform) the next step's normals are on the device — and its head is not k_mh_front's business (mixtures with pose walks)
+  const bool has_next = !c.front_every_step && step + 1 - c.normals_first < (long long)c.normals_rows;
+  const int pose_move = c.pose_move, leaf_now = c.leaf;
   // the NEXT step's mixture draw (MixtureProposal.propose, as mh_front_body): an integer hash of the step number
   int gen_n = -1, leaf_n = 2;
   {
@@ -679,7 +703,8 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   // ---- the step's results and the chain's state
   const double cpj = lane < r ? c.coeff_prop[lane] : 0.0;   // proposed coefficients (launch 1's copy in the state slot)
   const double thj = lane < r ? c.theta[10 + lane] : 0.0;   // current ones
-  const double thp = lane < 10 ? c.theta[lane] : 0.0;       // the pose (never changes here)
+  const double thp = lane < 10 ? c.theta[lane] : 0.0;       // the current pose …
+  const double thq = lane < 10 ? (c.n_pose > 0 ? c.prop_pose[lane] : thp) : 0.0;  // … and the proposed state's (a pose walk moves one of its parameters)
   const int st_chol = lane < n_icp ? c.chol_status[lane] : 0;
   const int st_tail = lane < 2 * n_icp ? c.tail_status[lane] : 0;
   const double resv = lane < 8 ? c.red[lane] : 0.0;
@@ -771,14 +796,32 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   // ---- transition ratio: every leaf's density both ways, log-sum-exp through the mixture tree
   double fw_i[2] = {ninf, ninf}, bw_i[2] = {ninf, ninf};
   for (int i = 0; i < n_icp; ++i) {
-    fw_i[i] = mh_bcast(tlv, 2 * i); bw_i[i] = mh_bcast(tlv, 2 * i + 1);
+    // (across a pose change the ICP proposals' densities are −∞: NonRigidIcpProposal.scala:72-74; what the tails computed is not looked at)
+    fw_i[i] = pose_move ? ninf : mh_bcast(tlv, 2 * i); bw_i[i] = pose_move ? ninf : mh_bcast(tlv, 2 * i + 1);
     if ((!(fw_i[i] == fw_i[i]) || !(bw_i[i] == bw_i[i])) && !err) err = 4;
   }
-  const double rw_t = -0.5 * dd / (rw_sigma * rw_sigma) - c.rw_logc;
-  const double rw_tb = -0.5 * dd_b / (rw_sigma * rw_sigma) - c.rw_logc;
-  double of[2] = {ninf, ninf}, ob[2] = {ninf, ninf};
+  // RandomShapeUpdateProposal.scala:38-40: −∞ unless only the shape differs
+  const double rw_t = pose_move ? ninf : -0.5 * dd / (rw_sigma * rw_sigma) - c.rw_logc;
+  const double rw_tb = pose_move ? ninf : -0.5 * dd_b / (rw_sigma * rw_sigma) - c.rw_logc;
+  // the six pose walks (PoseProposals.scala:46-60, :77-88): −∞ when anything OUTSIDE the walk's own group (rotation triple / translation)
+  // differs — the shape, for an ICP or shape-walk proposal; the other group, for a pose walk — else the Gaussian density of the
+  // walk's own parameter's residual (zero for the other walks of the moved group)
+  double pose_f[6] = {ninf, ninf, ninf, ninf, ninf, ninf}, pose_b[6] = {ninf, ninf, ninf, ninf, ninf, ninf};
+  if (pose_move) {
+    const int moved = c.pose_index[leaf_now - 3], grp = moved >= 4 ? 4 : 1;
+    const double from = mh_bcast(thp, moved), to = mh_bcast(thq, moved);
+    for (int a = 0; a < c.n_pose; ++a) {
+      const int idx = c.pose_index[a];
+      if ((idx >= 4 ? 4 : 1) != grp) continue;
+      const double df = (idx == moved ? to - from : 0.0) / c.pose_sigma[a], db = (idx == moved ? from - to : 0.0) / c.pose_sigma[a];
+      pose_f[a] = -df * df / 2.0 - c.pose_logc[a];
+      pose_b[a] = -db * db / 2.0 - c.pose_logc[a];
+    }
+  }
+  double of[3] = {ninf, ninf, ninf}, ob[3] = {ninf, ninf, ninf};
   for (int o = 0; o < c.n_outer; ++o) {
     if (c.outer_kind[o] == 1) { of[o] = mh_lse(n_icp, c.icp_w, fw_i); ob[o] = mh_lse(n_icp, c.icp_w, bw_i); }
+    else if (c.outer_kind[o] == 0) { of[o] = mh_lse(c.n_pose, c.pose_w, pose_f); ob[o] = mh_lse(c.n_pose, c.pose_w, pose_b); }
     else {  // mixedRandomShapeProposal: a one-component mixture (weight 0.5 / 0.5 = 1)
       const double one = 1.0;
       of[o] = mh_lse(1, &one, &rw_t); ob[o] = mh_lse(1, &one, &rw_tb);
@@ -797,10 +840,11 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   const double new_p = acc ? prop_p : cur_p;
   const int new_sel = acc ? other : cur_sel;
   if (acc && lane < r) c.theta[10 + lane] = cpj;
+  if (acc && pose_move && lane < 10) c.theta[lane] = thq;
   if (c.records) {
     double* rec = c.records + (size_t)(step - c.rec_first) * (4 + P);
-    if (lane == 0) { rec[0] = (double)step; rec[1] = acc ? 1.0 : 0.0; rec[2] = (double)c.leaf; rec[3] = new_p; }
-    if (lane < 10) rec[4 + lane] = thp;
+    if (lane == 0) { rec[0] = (double)step; rec[1] = acc ? 1.0 : 0.0; rec[2] = (double)leaf_now; rec[3] = new_p; }
+    if (lane < 10) rec[4 + lane] = acc ? thq : thp;
     if (lane < r) rec[14 + lane] = acc ? cpj : thj;
   }
   // ---- the KL bases of an accepted state's posteriors (both directions), as icp_chain_step_batched starts them

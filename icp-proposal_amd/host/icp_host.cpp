@@ -439,14 +439,18 @@ static int run_on_device(icp_host_chain* const* chains, int32_t n_chains, int32_
     icp_host_chain* ch = chains[b];
     if (!ch || !ch->prefetcher.whole_step || ch->icp.size() != n_icp || n_icp < 1 || n_icp > 2 || ch->r != c0->r) return ICP_ERR_INVALID_ARG;
     const icp_host_chain_config &a = ch->cfg, &z = c0->cfg;
-    if (a.w_pose > 0 || !(a.w_icp > 0)) return ICP_ERR_INVALID_ARG;  // pose walks: not on the device (see icp_chains_run_on_device)
-    if (a.w_icp != z.w_icp || a.w_rw != z.w_rw || a.rw_sigma != z.rw_sigma) return ICP_ERR_INVALID_ARG;
+    if (!(a.w_icp > 0)) return ICP_ERR_INVALID_ARG;
+    if (a.w_icp != z.w_icp || a.w_rw != z.w_rw || a.rw_sigma != z.rw_sigma || a.w_pose != z.w_pose) return ICP_ERR_INVALID_ARG;
+    for (int k = 0; k < 3 && a.w_pose > 0; ++k)
+      if (a.pose_rot_sigma[k] != z.pose_rot_sigma[k] || a.pose_trans_sigma[k] != z.pose_trans_sigma[k]) return ICP_ERR_INVALID_ARG;
     for (size_t i = 0; i < n_icp; ++i)
       if (a.icp_weight[i] != z.icp_weight[i]) return ICP_ERR_INVALID_ARG;
   }
   icp_mh_mixture mix{};
   for (size_t i = 0; i < n_icp; ++i) mix.icp_weight[i] = c0->cfg.icp_weight[i];
   mix.w_icp = c0->cfg.w_icp; mix.w_rw = c0->cfg.w_rw; mix.rw_sigma = c0->cfg.rw_sigma;
+  mix.w_pose = c0->cfg.w_pose > 0 ? c0->cfg.w_pose : 0.0;  // (the six pose walks: on the device too, include/icp_sincos.h)
+  for (int k = 0; k < 3; ++k) { mix.pose_rot_sigma[k] = c0->cfg.pose_rot_sigma[k]; mix.pose_trans_sigma[k] = c0->cfg.pose_trans_sigma[k]; }
   std::vector<icp_evaluator*> ev(n_chains);
   std::vector<icp_proposal*> props((size_t)n_chains * n_icp);
   std::vector<uint64_t> seeds(n_chains);

@@ -318,12 +318,14 @@ ICP_API int icp_chain_step_batched_abandon(icp_step_ticket *ticket);
  * ratio by log-sum-exp over all leaves, accept/reject, the step's record; the KL bases of accepted states follow in the same stream.
  * The host only enqueues launches and streams the standard normals in ahead.
  *   Mixture: (w_icp: the n_props ICP proposals with icp_weight) + (w_rw: shape random walk of rw_sigma) in the reference's order
- *   (apps/femur/IcpProposalRegistration.scala:70-72); product evaluator = shape prior × `evaluator`.  Pose walks are NOT covered
- *   (their rotation matrices would need the host's sines and cosines bit for bit): such chains step through icp_chain_step[_batched].
+ *   (apps/femur/IcpProposalRegistration.scala:70-72), optionally behind the six pose walks (w_pose > 0: apps/bfm/BfmFittingPartial.scala:70;
+ *   the proposed pose's rotation matrix is made on the device with include/icp_sincos.h, the sines and cosines the host side and the
+ *   oracle use — contexts with caller-supplied rotation matrices, icp_ctx_set_rotation, are not covered); product evaluator = shape
+ *   prior × `evaluator`.
  *   Random numbers: the counter-based generator of the C++ harness (host/icp_host.hpp StepRandom, shared bit for bit with the oracle):
  *   stream (seeds[b], step, lane), steps first_step[b] .. first_step[b] + n_steps − 1.
  *   theta[b] (in/out): the chain's current state; log_value[b] (in/out): its product log value (as MetropolisHastings carries it).
- *   records[b] (may be NULL): n_steps rows [index, accepted, leaf id (0/1 ICP proposal, 2 shape walk), log value, theta].
+ *   records[b] (may be NULL): n_steps rows [index, accepted, leaf id (0/1 ICP proposal, 2 shape walk, 3..8 pose walks), log value, theta].
  * Covered: what the merged launches cover (closed target or no boundary-aware branch, ranks <= 64, one context per chain, one
  * device); otherwise ICP_ERR_INVALID_ARG and nothing has run.  Results are those of icp_chain_step_batched driven by the harness,
  * chain by chain (tests/test_gpu_chain.py::test_device_loop_*). */
@@ -331,6 +333,11 @@ typedef struct {
   double icp_weight[2];
   double w_icp, w_rw;
   double rw_sigma;
+  /* (round 4) the six pose walks of MixedProposalDistributions.mixedRandomPoseProposal (MixedProposalDistributions.scala:29-39;
+   * PoseProposals.scala:31-90), first in the outer mixture as in apps/bfm/BfmFittingPartial.scala:70: w_pose = 0 -> none.
+   * pose_rot_sigma = (yaw, pitch, roll), pose_trans_sigma = (x, y, z): the argument order of :29. */
+  double w_pose;
+  double pose_rot_sigma[3], pose_trans_sigma[3];
 } icp_mh_mixture;
 ICP_API int icp_chains_run_on_device(int32_t n_chains, icp_evaluator *const *evaluators, int32_t n_props, icp_proposal *const *props,
                                      const icp_mh_mixture *mixture, const uint64_t *seeds, const int64_t *first_step,

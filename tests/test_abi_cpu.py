@@ -118,7 +118,7 @@ def test_round3_entry_points_reject_bad_arguments_before_device(pkg):
     assert b"null argument" in lib.icp_last_error()
     assert lib.icp_proposal_set_sampler(None, 1) == -1
     assert lib.icp_ctx_profile_search_counters(None, 1) == -1
-    assert ctypes.sizeof(nat.MhMixture) == 40
+    assert ctypes.sizeof(nat.MhMixture) == 96  # (round 4: + w_pose and the six pose walks' sigmas)
 
 
 def test_synthetic_target_sizes(pkg):

@@ -591,3 +591,74 @@ def test_device_loop_matches_host_stepped_chains(kind, B, n1, n2, tmp_path):
     leaves = set(a[:, :, 2].astype(int).ravel())
     assert leaves == ({0, 1, 2} if kind != "one-direction" else {0, 2})
     assert np.all(dev["n"][1:] == n1 + n2) and dev["n"][0] == n1 + 7
+
+
+_DEVICE_LOOP_ORACLE_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import __graft_entry__ as graft
+pkg = graft.load_package()
+model, target = pkg.data.load_femur_model_and_target(50)
+kind = {kind!r}
+def make_setup():
+    if kind == "femur":   # apps/femur/IcpProposalRegistration.scala:59-85: two ICP directions + shape walk, independent evaluator
+        return pkg.femur_icp_proposal_registration(model, target, fused=2)
+    # apps/bfm/BfmFittingPartial.scala:62-83 on the (closed) femur target: pose walks + one ICP direction + shape walk, collective evaluator
+    s = pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2)
+    s.pose_rot_sigma = (0.01, 0.012, 0.008); s.pose_trans_sigma = (0.1, 0.15, 0.08); s.rw_sigma = 0.02
+    return s
+B = {B}
+ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
+chains = [pkg.SamplingRegistration(ctxs[i], make_setup(), pkg.random_initial_parameters(model, i), seed=500 + i) for i in range(B)]
+rec = pkg.run_chains_batched(chains, {n})
+paths = [c.step_paths() for c in ctxs]
+np.savez({out!r}, rec=np.stack(rec), loop=np.array([p["device_loop"] for p in paths]), other=np.array([p["merged"] + p["wide"] + p["per_stage"] for p in paths]),
+         stats=np.array(list(pkg._native.runtime_stats().values())))
+[c.close() for c in chains]; [c.close() for c in ctxs]
+"""
+
+
+@pytest.mark.parametrize("kind,B,n", [("femur", 4, 70), ("pose", 4, 90)])
+def test_device_loop_matches_oracle_chain(pkg, femur50, femur50_oracle, oracle, kind, B, n, tmp_path):
+    """The on-device Metropolis–Hastings loop (icp_chains_run_on_device) DIRECTLY against the oracle's chain (orc_run_chain: the same
+    counter-based random numbers bit for bit) — api/sampling/SamplingRegistration.scala:52-85 semantics: every decision and mixture
+    component identical, states within 1e-5, log values within 1e-6 — for the femur mixture (two ICP directions + shape walk,
+    apps/femur/IcpProposalRegistration.scala:70-72) and for the mixture WITH the six pose walks (api/sampling/proposals/PoseProposals.scala:31-90
+    in the order of apps/bfm/BfmFittingPartial.scala:70), whose proposed pose is made on the device with include/icp_sincos.h — the
+    sines and cosines the oracle uses."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    model, target = femur50
+    om, ot = femur50_oracle
+    path = str(tmp_path / "dlo.npz")
+    script = _DEVICE_LOOP_ORACLE_SCRIPT.format(root=ROOT, kind=kind, B=B, n=n, out=path)
+    subprocess.run([sys.executable, "-c", script], check=True, env={**os.environ, "ICP_HOST_DEVICE_LOOP": "1"}, timeout=900)
+    got = np.load(path)
+    assert np.all(got["loop"] == n) and np.all(got["other"] == 0), "the chains did not run inside the on-device loop"
+    assert np.all(got["stats"] == 0)
+    if kind == "femur":
+        setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+    else:
+        setup = pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2)
+        setup.pose_rot_sigma = (0.01, 0.012, 0.008); setup.pose_trans_sigma = (0.1, 0.15, 0.08); setup.rw_sigma = 0.02
+    cfg = oracle_chain_config(oracle, setup)
+    leaves = set()
+    for b in range(B):
+        theta0 = pkg.random_initial_parameters(model, b)
+        acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, cfg, theta0, 500 + b, n)
+        rec = got["rec"][b]
+        assert np.array_equal(rec[:, 0], np.arange(n))
+        assert np.array_equal(rec[:, 1].astype(np.uint8), acc_o), f"chain {b}: accept/reject sequences differ"
+        assert np.array_equal(rec[:, 2].astype(np.int32), comp_o), f"chain {b}: mixture components differ"
+        scale = np.abs(states_o[:, 10:]).max()
+        assert np.abs(rec[:, 4 + 10:] - states_o[:, 10:]).max() <= 1e-5 * scale
+        assert np.abs(rec[:, 4:14] - states_o[:, :10]).max() <= 1e-12 * max(1.0, np.abs(states_o[:, :10]).max())
+        assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
+        assert acc_o.sum() > 3
+        leaves |= set(comp_o.tolist())
+    if kind == "pose":
+        assert leaves & {3, 4, 5} and leaves & {6, 7, 8} and 0 in leaves, leaves  # rotations, translations and ICP proposals all occurred
+        moved = [b for b in range(B) if np.abs(got["rec"][b][-1, 4:14] - pkg.random_initial_parameters(model, b)[:10]).max() > 0]
+        assert moved, "no pose walk was accepted in any chain"
