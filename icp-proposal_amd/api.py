@@ -97,6 +97,19 @@ class IcpContext:
         self.rank, self.N = model.rank, model.n_points
         self._children = []  # weak references to the proposals / evaluators / chains created on this context
 
+    def setTarget(self, target):
+        """icp_ctx_set_target: the same context (model data, scratch, streams) against another target mesh; every proposal, evaluator
+        and chain made on it for the old target is closed first."""
+        for ref in reversed(getattr(self, "_children", [])):
+            child = ref()
+            if child is not None and getattr(child, "h", None):
+                child.close()
+        self._children = []
+        td = nat.MeshDesc(target.n_points, target.n_cells, _d(target.points), _i(target.cells))
+        nat.check(nat.lib().icp_ctx_set_target(self.h, C.byref(td)), "icp_ctx_set_target")
+        self.target = target
+        return self
+
     def _adopt(self, child):
         import weakref
         self._children.append(weakref.ref(child))

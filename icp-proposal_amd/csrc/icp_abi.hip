@@ -1378,6 +1378,41 @@ bool pose_equal(const double* a, const double* b) {  // NonRigidIcpProposal.scal
 
 }  // namespace
 
+namespace {
+// the target's immutable device data (vertices, triangles, boundary flags, bounding spheres in patch order): shared by every context of
+// the device made from the same arrays (g_shared_targets).  The caller holds g_shared_mu and has bound the device.
+void attach_target(icp_ctx* ctx, const icp_mesh_desc* target, int device) {
+  uint64_t th = hash_words(0x5678, target->points, sizeof(double) * 3 * (size_t)target->n_points);
+  th = hash_words(th, target->triangles, sizeof(int32_t) * 3 * (size_t)target->n_triangles);
+  const SharedKey tkey{device, target->n_points, target->n_triangles, 0, th};
+  std::shared_ptr<SharedTarget> stg = g_shared_targets[tkey].lock();
+  if (!stg) {
+    stg = std::make_shared<SharedTarget>();
+    DeviceMesh& tg = stg->mesh;
+    tg.V = target->n_points; tg.T = target->n_triangles;
+    std::vector<uint8_t> tb;
+    boundary_flags(tg.V, tg.T, target->triangles, tb);
+    tg.n_boundary = (int)std::count(tb.begin(), tb.end(), (uint8_t)1);
+    tg.verts.upload(target->points, (size_t)3 * tg.V);
+    tg.tris.upload(target->triangles, (size_t)3 * tg.T);
+    tg.boundary.upload(tb.data(), tb.size());
+    tg.spheres.alloc(sphere_floats4(tg.T));
+    {
+      const std::vector<int> order = coherent_triangle_order(tg.V, tg.T, target->points, target->triangles);
+      tg.tri_order.upload(order.data(), order.size());
+    }
+    launch_tri_spheres(ctx->stream, tg.T, tg.verts.p, tg.tris.p, tg.tri_order.p, tg.spheres.p);
+    HIP_OK(hipStreamSynchronize(ctx->stream));  // (complete before another context may find it)
+    g_shared_targets[tkey] = stg;
+  }
+  ctx->shared_target = stg;
+  DeviceMesh& tg = ctx->target;
+  const DeviceMesh& o = stg->mesh;
+  tg.V = o.V; tg.T = o.T; tg.n_boundary = o.n_boundary;
+  tg.verts.alias(o.verts); tg.tris.alias(o.tris); tg.tri_order.alias(o.tri_order); tg.spheres.alias(o.spheres); tg.boundary.alias(o.boundary);
+}
+}  // namespace
+
 // ===================================================================== C ABI
 
 extern "C" {
@@ -1542,7 +1577,8 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->tris.alias(sm->tris); ctx->tri_order.alias(sm->tri_order); ctx->adj_off.alias(sm->adj_off); ctx->adj.alias(sm->adj);
     ctx->boundary.alias(sm->boundary);
 
-    // ---- target (static): vertices, triangles, boundary flags, bounding spheres
+    attach_target(ctx, target, device);
+#if 0
     uint64_t th = hash_words(0x5678, target->points, sizeof(double) * 3 * (size_t)target->n_points);
     th = hash_words(th, target->triangles, sizeof(int32_t) * 3 * (size_t)target->n_triangles);
     const SharedKey tkey{device, target->n_points, target->n_triangles, 0, th};
@@ -1573,6 +1609,7 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
       tg.V = o.V; tg.T = o.T; tg.n_boundary = o.n_boundary;
       tg.verts.alias(o.verts); tg.tris.alias(o.tris); tg.tri_order.alias(o.tri_order); tg.spheres.alias(o.spheres); tg.boundary.alias(o.boundary);
     }
+#endif
 
     ctx->hint_surf.alloc(N); ctx->hint_surf.fill_bytes(0xFF);
     ctx->hint_nnv.alloc(N); ctx->hint_nnv.fill_bytes(0xFF);
@@ -1688,6 +1725,31 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     if (bp) (void)hipHostFree(bp);
   if (ctx->counted) --g_live_contexts;
   delete ctx;
+}
+
+int icp_ctx_set_target(icp_ctx* ctx, const icp_mesh_desc* target) {
+  return guard([&] {
+    require(ctx && target, "null argument");
+    require(target->n_points > 0 && target->n_triangles >= 0 && target->points && (target->triangles || target->n_triangles == 0),
+            "target arrays missing");
+    check_triangles(target->n_points, target->n_triangles, target->triangles, "target");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    require(ctx->proposals.empty() && ctx->evaluators.empty(), "the context still has proposals or evaluators made for its present target");
+    Bound _b(ctx);
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    HIP_OK(hipStreamSynchronize(ctx->front_stream));
+    sync_eigen(*ctx);
+    {
+      std::lock_guard<std::mutex> shared_lk(g_shared_mu);
+      attach_target(ctx, target, ctx->device);
+    }
+    // what was cached against the old target: the states' surface points and nearest vertices, the search hints
+    for (auto& s : ctx->slots) { s.valid = false; s.defo_valid = false; s.spheres_valid = false; s.n_surf = s.n_nnv = 0; s.lo_surf = s.hi_surf = s.lo_nnv = s.hi_nnv = 0; }
+    HIP_OK(hipMemsetAsync(ctx->hint_surf.p, 0xFF, sizeof(int) * ctx->N, ctx->stream));
+    HIP_OK(hipMemsetAsync(ctx->hint_nnv.p, 0xFF, sizeof(int) * ctx->N, ctx->stream));
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    ctx->stage_used = 0;
+  });
 }
 
 namespace { void release_front(StepFront& F); }

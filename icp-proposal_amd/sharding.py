@@ -130,6 +130,7 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
     mine = assign_target_major(len(targets), n_chains, world)[rank]
     blocks = []
     contexts_built = 0
+    pool = []  # this rank's contexts, kept from target to target
     if chains_per_launch <= 0:
         chains_per_launch = max(1, n_chains)
     t_start = time.perf_counter()
@@ -142,26 +143,36 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
         if chains_per_launch > 1:
             for g0 in range(0, len(ks), chains_per_launch):
                 group = ks[g0:g0 + chains_per_launch]
-                ctxs = [pkg.IcpContext(model, targets[t], device=device_index) for _ in group]
-                contexts_built += len(ctxs)
+                # the rank's contexts (per-chain scratch, streams, pinned buffers; the model's device data is shared) are made ONCE and
+                # handed from target to target (icp_ctx_set_target): a context costs 20+ ms to make and as much to destroy
+                while len(pool) < len(group):
+                    pool.append(pkg.IcpContext(model, targets[t], device=device_index))
+                    contexts_built += 1
+                ctxs = pool[:len(group)]
+                for cx in ctxs:
+                    if cx.target is not targets[t]:
+                        cx.setTarget(targets[t])
                 chains = [pkg.SamplingRegistration(cx, setup, theta0(k), seed=seed(k)) for cx, k in zip(ctxs, group)]
                 for k, rec in zip(group, pkg.run_chains_batched(chains, n_steps)):
                     rec[:, 0] = k                              # the record's index field carries the item id across the gather
                     blocks.append(rec)
                 for ch in chains:
                     ch.close()
-                for cx in ctxs:
-                    cx.close()
-        else:                                                  # one context per target, its chains one after the other
-            ctx = pkg.IcpContext(model, targets[t], device=device_index)
-            contexts_built += 1
+        else:                                                  # one context for the rank, its chains one after the other
+            if not pool:
+                pool.append(pkg.IcpContext(model, targets[t], device=device_index))
+                contexts_built += 1
+            ctx = pool[0]
+            if ctx.target is not targets[t]:
+                ctx.setTarget(targets[t])
             for k in ks:
                 chain = pkg.SamplingRegistration(ctx, setup, theta0(k), seed=seed(k))
                 rec = chain.run(n_steps)
                 rec[:, 0] = k
                 blocks.append(rec)
                 chain.close()
-            ctx.close()
+    for cx in pool:
+        cx.close()
     t_chains = time.perf_counter()
     import torch
     dev = torch.device("cuda", device_index) if (dist is not None and dist.is_initialized() and dist.get_backend() == "nccl") else None

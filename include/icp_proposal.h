@@ -128,6 +128,13 @@ typedef struct {
 /* device: HIP ordinal, or -1 = use LOCAL_RANK from the environment (0 if unset). */
 ICP_API int icp_ctx_create(const icp_model_desc *model, const icp_mesh_desc *target, int device, icp_ctx **out);
 ICP_API void icp_ctx_destroy(icp_ctx *ctx);
+/* Gives the context ANOTHER target mesh and keeps everything that does not depend on the target — the model's device data, the
+ * per-chain scratch, streams, pinned buffers: a batch registration (one statistical model against many targets:
+ * apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala:106-163) makes its contexts once.  The context must have no proposal and no
+ * evaluator at the time (they are made for one target: destroy them first, create new ones afterwards); what it had cached against the
+ * old target is dropped.  Creating a context costs 20+ ms at the face model's size, this call a fraction of a millisecond once the
+ * target's own device data exists. */
+ICP_API int icp_ctx_set_target(icp_ctx *ctx, const icp_mesh_desc *target);
 ICP_API const char *icp_status_string(int status);
 ICP_API const char *icp_last_error(void); /* thread-local detail of the last failing call */
 ICP_API int icp_ctx_rank(const icp_ctx *ctx);

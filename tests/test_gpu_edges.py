@@ -194,3 +194,42 @@ def test_posterior_with_a_scale(pkg, oracle, femur50, femur50_oracle, direction)
     ev.close()
     prop.close()
     ctx.close()
+
+
+def test_context_handed_to_another_target(pkg, oracle, femur50):
+    """icp_ctx_set_target: a batch registration's contexts go from target to target (model data, scratch and streams stay).  Everything
+    computed afterwards is what a fresh context on the new target computes — searches, posterior, evaluator — and matches the oracle;
+    with a proposal or an evaluator still alive the call is refused."""
+    model, target = femur50
+    pts, cells = open_patch_target(target)
+    other = pkg.data.TriangleMesh(pts, cells)
+    r = model.rank
+    ctx = pkg.IcpContext(model, target, device=0)
+    theta = make_theta(model, 540)
+    prop = pkg.NonRigidIcpProposal(ctx, 0.1, 6.0, 3.0, 2 * r, "ModelSampling", True)
+    prop.icpPosterior(theta)  # (caches against the first target: state slot, hints, memo)
+    import ctypes as C
+    nat = pkg._native
+    td = nat.MeshDesc(other.n_points, other.n_cells, other.points.ctypes.data_as(nat.c_double_p), other.cells.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert nat.lib().icp_ctx_set_target(ctx.h, C.byref(td)) == -1  # a proposal made for the old target is still alive
+    ctx.setTarget(other)       # (closes it first)
+    fresh = pkg.IcpContext(model, other, device=0)
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(pts, cells)
+    pp = oracle.proposal_params(0.1, 6.0, 3.0, oracle.MODEL_SAMPLING, True, n_model_ids=2 * r)
+    tp = pkg.data.decimated_point_subset(other, 4 * r)
+    for c in (ctx, fresh):
+        p = pkg.NonRigidIcpProposal(c, 0.1, 6.0, 3.0, 2 * r, "ModelSampling", True)
+        post, po = p.icpPosterior(theta), oracle.icp_posterior(om, ot, pp, theta)
+        check_posterior(post, po)
+        assert not post.keep.all()
+        ev = pkg.CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator(c, 0.1, 0.3, 1.0, 2, 4 * r, decimatedTargetPoints=tp)
+        ep = oracle.evaluator_params(oracle.EVAL_COLLECTIVE, 2, n_model_ids=4 * r, target_pts=tp, p0=0.1, p1=0.3, p2=1.0)
+        wv, rc = oracle.evaluator_log_value(om, ot, ep, theta)
+        assert rc == 0 and abs(ev.logValue(theta) - wv) <= 1e-11 * abs(wv)
+        z = np.random.default_rng(1).normal(size=r)
+        got, lv, fwd, bwd = pkg.chain_step(ev, [p], theta, generator=0, z=z)
+        want = oracle.propose(om, ot, pp, theta, z)
+        assert rel_err(got[10:], want[10:]) < 1e-7
+        ev.close(); p.close()
+    fresh.close()
+    ctx.close()
