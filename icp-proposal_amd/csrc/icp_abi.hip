@@ -4944,6 +4944,16 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
   return rc;
 }
 
+int icp_chain_step_path(icp_evaluator* e, int32_t n_props, icp_proposal* const* props) {
+  if (!e || n_props < 0 || (n_props > 0 && !props)) return ICP_ERR_INVALID_ARG;
+  for (int i = 0; i < n_props; ++i)
+    if (!props[i] || props[i]->ctx != e->ctx) return ICP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(e->ctx->mu);
+  if (step_pipeline_covers(e, n_props, props)) return 0;
+  if (n_props >= 1 && n_props <= 2 && wide_pipeline_covers(e, n_props, props)) return 1;
+  return 2;
+}
+
 int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props,
                            const int32_t* generator, const double* const* theta_cur, const double* const* z,
                            double* const* theta_prop, double* log_value_prop, double* fwd, double* bwd, int32_t* status) {

@@ -544,14 +544,19 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
     // Several groups a fraction of a step apart: while one group's launches run, the other groups' decompositions do, and
     // the host prepares their submissions (a step's first launch waits ≈ 100 µs for the decompositions of the chains that
     // moved).  Few chains stay in one group: the launches of a part of them would not fill the device.
-    #ifdef ICP_DEV_SWITCHES
-    static const int forced = std::getenv("ICP_LOCKSTEP_GROUPS") ? std::atoi(std::getenv("ICP_LOCKSTEP_GROUPS")) : 0;
-#else
-    static const int forced = 0;  // (developer A/B switch: -DICP_DEV_SWITCHES)
-#endif
+    static const int forced = std::getenv("ICP_LOCKSTEP_GROUPS") ? std::atoi(std::getenv("ICP_LOCKSTEP_GROUPS")) : 0;  // (operational switch)
     // (measured, tools/ab_groups64.sh: two groups from 8 chains to 64 — 16 chains: 70k against 56k it/s with one or three, 32: 108k against
     // 90k with three, 64: 134k against 117k; beyond that groups of about 32: 96 chains 135k, 128 chains 142k with four)
     int n_groups = forced > 0 ? forced : (n_chains > 80 ? (n_chains + 31) / 32 : n_chains >= 8 ? 2 : 1);
+    // Chains that take the WIDE step (open targets, the Hausdorff evaluator, rank 200, pose walks: a step of 0.5-1.5 ms whose
+    // one-workgroup factorisations and decompositions run side by side for all chains of a submission) are better off in ONE group
+    // per 16 chains: 10 chains of the face configuration 6.65k it/s in one group, 5.6k in two, 4.9k in three, 4.1k in four — every
+    // launch costs the same whatever it carries, and the groups' chip-wide launches share one stream anyway.
+    if (forced <= 0 && !chains[0]->icp.empty()) {
+      std::vector<icp_proposal*> hs;
+      for (auto* p : chains[0]->icp) hs.push_back(p->h);
+      if (icp_chain_step_path(chains[0]->likelihood->h, (int)hs.size(), hs.data()) == 1) n_groups = (n_chains + 15) / 16;
+    }
     n_groups = std::max(1, std::min(std::min(n_groups, kMaxGroups), n_chains));
     for (int b = 0; b < n_chains; ++b) groups[(size_t)b * n_groups / n_chains].chains.push_back(chains[b]);
     for (int g = 0; g < n_groups; ++g) groups[g].init();

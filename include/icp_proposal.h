@@ -388,6 +388,11 @@ ICP_API int icp_ctx_runtime_stats(const icp_ctx *ctx, icp_runtime_stats *out);
  * icp_chains_run_on_device. */
 ICP_API int icp_ctx_step_paths(const icp_ctx *ctx, int64_t out[4]);
 
+/* Which path icp_chain_step[_batched] takes for this proposal set and evaluator (a property of the configuration, not of a state):
+ * 0 the five merged launches, 1 the wide step, 2 per-stage kernels.  A caller that steps many chains uses it to size its batches:
+ * the merged launches are short and want several groups of chains in flight, a wide step is long and wants one. */
+ICP_API int icp_chain_step_path(icp_evaluator *e, int32_t n_props, icp_proposal *const *props);
+
 /* ---- model cache.  Contexts made from the same model arrays share its derived device data (the scaled basis in two layouts, the
  * Gram matrix and its inverses: 0.35 s of host work and 2 x 137 MB of uploads at N = 28,561, rank 200).  The library keeps the two
  * most recently used models alive after their last context is destroyed, so that a job which builds one context per target over one
