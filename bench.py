@@ -202,7 +202,7 @@ def build_workload(pkg, config, subdiv, fused, args=None):
         if gid > 0:  # apps/femur/RandomSamplesFromModel.scala:28-35: chain i > 0 starts from c ~ N(0, 0.1·I)
             th[10:] = np.random.default_rng(1024 + gid).normal(size=model.rank) * np.sqrt(0.1)
         return th
-    return dict(model=model, target=target, setup=setup, name=name, init=init)
+    return dict(model=model, target=target, setup=setup, name=name, init=init, config=config)
 
 
 def algorithmic_step(model, target, setup, target_has_boundary):
@@ -258,10 +258,23 @@ def kernel_algorithmic_bytes(name, model, target, setup):
             return r * r * 8 * 5 + r * 8
         # ranks <= 64, per launch (both directions): M, warm basis in, V, Vt, S out, rotation log out and in
         return dirs * (r * r * 8 * 4 + 3 * 51 * (r + 1) * 8 * 2)
-    if name == "k_surface_filter":
+    hd = e["kind"] == 1
+    if name == "k_surface_filter":   # per-stage launch, or the wide step's evaluator sequence (Hausdorff: both full-mesh directions)
+        if hd:
+            return 3 * M * 8 + 3 * Tt * 4 + 3 * N * 8 + 3 * T * 4 + (N + M) * 24
         return 3 * M * 8 + 3 * Tt * 4 + Ksurf * 24
+    if name == "k_surface_resolve":
+        return (N + M) * (24 + 72 + 40) if hd else Ksurf * (24 + 72 + 40)
     if name == "k_vertex_filter":
         return 3 * M * 8 + Ksurf * 24
+    if name == "k_instance":         # scaled basis + reference + mean in; instance and kept deformations out
+        return 3 * N * r * 8 + 3 * N * 8 * 4
+    if name == "k_posterior_factor": # summed partial in, M out, the scaled factor out and back in (ranks whose factor lives in global scratch)
+        return n1 * 8 + r * r * 8 + (2 * (r + 1) * r * 8 if r > 116 else 0)
+    if name == "k_transition_tail":  # M and G^-1 per tail (two tails per posterior)
+        return 2 * dirs * 2 * r * r * 8
+    if name == "k_propose":
+        return 2 * r * r * 8
     return None
 
 
@@ -495,11 +508,19 @@ def main():
                     per_launch = nB * n_p / max(f["calls"], 1)
                     dalg = kernel_algorithmic_bytes("k_step_filter", model, target, setup) * per_launch
                     dk = {"kernel": "k_step_filter (batched)", "chains_per_launch": per_launch, "avg_launch_us": f["avg_us"], "launches": f["calls"],
-                          "algorithmic_bytes": dalg, "achieved_GBs": dalg / (f["avg_us"] * 1e-6) / 1e9,
-                          "frac_hbm": dalg / (f["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "algorithmic_bytes": dalg, "algorithmic_GBs": dalg / (f["avg_us"] * 1e-6) / 1e9,
+                          "frac_hbm_algorithmic": dalg / (f["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                           "kernel_us_per_launch": {k: round(v["avg_us"], 2) for k, v in pst.items()},
                           "note": "algorithmic bytes per chain x chains per launch / launch duration; the chains of a launch search the SAME target, so the "
-                                  "bytes that actually leave HBM are fewer (the target's spheres stay in L2 between the chains' workgroups)"}
+                                  "bytes that actually leave HBM are fewer (the target's spheres stay in L2 between the chains' workgroups): "
+                                  "`counter_*` = FETCH_SIZE x 2 + WRITE_SIZE of the same kernel in the same regime (profiles/r04_pmc_traffic.json)"}
+                    tfile = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+                    if os.path.exists(tfile):
+                        ctr = json.load(open(tfile)).get("many_chains", {}).get("k_step_filter", {}).get("hbm_bytes_per_launch")
+                        if ctr is not None:
+                            dk["counter_bytes_per_launch"] = ctr
+                            dk["counter_GBs"] = ctr / (f["avg_us"] * 1e-6) / 1e9
+                            dk["frac_hbm_counter"] = dk["counter_GBs"] / HBM_PEAK_GBS
             except Exception as e:
                 dk = {"error": str(e)[:200]}
             line["many_chains"] = {"chains_per_gpu": nB, "value": nB * n_m / mdt, "unit": "iterations/s", "steps_per_chain": n_m, "distance_kernel": dk,
@@ -534,14 +555,77 @@ def extra_config_leg(pkg, args, cfg_i, device, sampler="eigen"):
     dt = time.perf_counter() - t0
     out = {"value": n / dt, "unit": "iterations/s", "steps": n, "warmup": n_w, "ms_per_step": 1e3 * dt / n, "accepted": int(rec[:, 1].sum()),
            "icp_proposals": int((rec[:, 2] < 2).sum()), "workload": wl["name"], "runtime_stats": ctx.runtime_stats(), "sampler": sampler}
+    try:
+        out["roofline"] = leg_roofline(pkg, ctx, chain, wl, 100 if cfg_i == 3 else 60, out["value"], out["accepted"] / n, out["icp_proposals"] / n)
+    except Exception as e:
+        out["roofline_error"] = str(e)[:200]
+    out["step_paths"] = ctx.step_paths()
     if cfg_i == 2 and out["accepted"] == 0:
         out["note"] = ("no step accepted: with all 1,622 model points as correspondences the ICP posterior is so narrow that the reference's own "
                        "transition ratio rejects (almost) every proposal — GPU and oracle agree on every decision "
                        "(tests/test_gpu_chain.py::test_femur100_all_points_symmetric_58k_target_matches_oracle), but the oracle is not pinned to "
                        "Scalismo (DESIGN §2), so whether the reference's chain moves here cannot be adjudicated; the rate is that of the REJECTED path")
     chain.close()
+    if cfg_i == 2:
+        # the same chain started where the reference's experiments start it — next to the posterior mean, from the deterministic ICP fit
+        # (apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala:148): there about one proposal in ten is accepted, and the accepted
+        # rank-101 step (decomposition of the new posterior on the tridiagonal route, then the next proposal) is timed
+        try:
+            n_pts = wl["model"].n_points
+            fit = pkg.IcpBasedSurfaceFitting(ctx, 1.0, "ModelSampling", modelPointIds=np.arange(n_pts, dtype=np.int32)).runfitting(
+                10, initialModelParameters=wl["init"](3))
+            ch2 = pkg.SamplingRegistration(ctx, wl["setup"], fit, seed=1024)
+            ch2.run(n_w, want_records=False)
+            t1 = time.perf_counter()
+            rec2 = ch2.run(n)
+            dt2 = time.perf_counter() - t1
+            out["from_deterministic_fit"] = {"value": n / dt2, "unit": "iterations/s", "steps": n, "ms_per_step": 1e3 * dt2 / n,
+                                             "accepted": int(rec2[:, 1].sum()),
+                                             "note": "start = IcpBasedSurfaceFitting(all model points, 10 iterations x 3 noise levels) from the random shape 3"}
+            ch2.close()
+        except Exception as e:
+            out["from_deterministic_fit"] = {"error": str(e)[:200]}
     ctx.close()
     return out
+
+
+def leg_roofline(pkg, ctx, chain, wl, n_prof, rate, accepted_share, icp_share):
+    """The roofline block of a short leg: the time-dominant kernel of a profiled stretch of the same chain (HIP events on the launch
+    streams), its algorithmic bytes per launch against its average duration, and the latency floor of the step's launch structure."""
+    model, target, setup = wl["model"], wl["target"], wl["setup"]
+    ctx.profile_start(max_launches=160 * n_prof + 4096)
+    chain.run(n_prof, want_records=False)
+    stats = {k: v for k, v in ctx.profile_stop().items() if not k.startswith("count.") and not k.endswith(".device_wait")}
+    if not stats:
+        return None
+    dominant = max(stats, key=lambda k: stats[k]["total_ms"])
+    k = stats[dominant]
+    alg = kernel_algorithmic_bytes(dominant, model, target, setup)
+    one_cu = dominant.startswith(SINGLE_WORKGROUP)
+    has_boundary = bool(pkg.data.boundary_vertex_flags(target).any())
+    bytes_step, flops_step = algorithmic_step(model, target, setup, has_boundary)
+    lat = latency_floor_model(model, setup, icp_share, accepted_share, bytes_step, flops_step)
+    lat["measured_us_per_step"] = 1e6 / rate
+    lat["frac"] = lat["floor_us_per_step"] / lat["measured_us_per_step"]
+    roof = {"bound": "latency" if one_cu else "hbm", "kernel": dominant, "avg_launch_us": k["avg_us"], "launches": k["calls"],
+            "algorithmic_bytes": alg, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "latency": lat, "whole_step": {"algorithmic_bytes_per_step": bytes_step, "hbm_frac": bytes_step * rate / (HBM_PEAK_GBS * 1e9)},
+            "kernel_us_per_step": {name: round(v["total_ms"] * 1e3 / n_prof, 2) for name, v in stats.items()}}
+    if alg is not None:
+        roof["achieved"] = alg / (k["avg_us"] * 1e-6) / 1e9
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+        tfile = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tfile):
+            per_kernel = json.load(open(tfile)).get("config%d" % wl["config"], {})
+            t = per_kernel.get(dominant, {}).get("hbm_bytes_per_launch")
+            if t is None and dominant == "k_posterior_eigen" and "k_tridiag" in per_kernel:
+                t = sum(per_kernel[q]["hbm_bytes_per_launch"] * (3 if q == "k_tri_gemm" else 1) for q in ("k_tridiag", "k_tri_solve", "k_tri_gemm") if q in per_kernel)
+            if t is not None:
+                roof["traffic"] = t
+                roof["traffic_source"] = "profiles/" + tname
+                break
+    return roof
 
 
 def run_config4(pkg, args, dist, torch, rank, world, local_rank):
@@ -663,7 +747,7 @@ def roofline_leg(pkg, args, wl, ctx, chains, B, rate, line):
         chains_per_launch = B * args.profile_steps / max(k["calls"], 1)
         alg = alg * chains_per_launch if alg is not None else None
     traffic = None
-    for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile) and B == 1:
             per_kernel = json.load(open(tfile)).get("config%d" % args.config, {})

@@ -662,3 +662,38 @@ def test_device_loop_matches_oracle_chain(pkg, femur50, femur50_oracle, oracle, 
         assert leaves & {3, 4, 5} and leaves & {6, 7, 8} and 0 in leaves, leaves  # rotations, translations and ICP proposals all occurred
         moved = [b for b in range(B) if np.abs(got["rec"][b][-1, 4:14] - pkg.random_initial_parameters(model, b)[:10]).max() > 0]
         assert moved, "no pose walk was accepted in any chain"
+
+
+def test_femur100_chain_from_the_deterministic_fit_accepts_and_matches_oracle(pkg, oracle):
+    """BASELINE.json configs[2] with ACCEPTED steps.  From a random start this chain (K = N = 1622 correspondences, rank 101) rejects
+    every ICP proposal under the reference's own transition ratio: the backward density evaluates (2 − step)·(c − α) against a posterior
+    of precision M, log T_fwd − log T_bwd ≈ ½(2 − step)²·(c − α)ᵀM(c − α) − ½‖z‖² — 1,026 at a random start against a likelihood gain of
+    349.  The reference's experiments start such chains next to α: the deterministic ICP fit
+    (apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala:148, IcpRegistration.fitting with all model points).  From there (c − α)ᵀM(c − α)
+    is ≈ 5 and about one proposal in ten is accepted: >= 20 accepted rank-101 steps, decision for decision against the oracle."""
+    model, target = pkg.data.load_femur_model_and_target(100)
+    r, n = model.rank, model.n_points
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    oracle.set_search_backend(oracle.SEARCH_TREES)  # (bit-identical to the scans: tests/test_oracle.py)
+    try:
+        setup = pkg.femur_random_init_comparison(model, target)
+        ctx = pkg.IcpContext(model, target, device=0)
+        start = pkg.random_initial_parameters(model, chain_index=3)
+        fit = pkg.IcpBasedSurfaceFitting(ctx, 1.0, "ModelSampling", modelPointIds=np.arange(n, dtype=np.int32)).runfitting(10, initialModelParameters=start)
+        fit_o = oracle.fit_deterministic(om, ot, start, 10, direction=oracle.MODEL_SAMPLING, model_ids=np.arange(n, dtype=np.int32))
+        assert np.abs(fit - fit_o).max() <= 1e-7 * np.abs(fit_o[10:]).max()
+        n_steps, seed = 260, 1024
+        acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), fit, seed, n_steps)
+        assert acc_o.sum() >= 20, acc_o.sum()
+        chain = pkg.SamplingRegistration(ctx, setup, fit, seed)
+        rec = chain.run(n_steps)
+        assert np.array_equal(rec[:, 1].astype(np.uint8), acc_o), "accept/reject sequences differ"
+        assert np.array_equal(rec[:, 2].astype(np.int32), comp_o)
+        scale = np.abs(states_o[:, 10:]).max()
+        assert np.abs(rec[:, 14:] - states_o[:, 10:]).max() <= 1e-5 * scale
+        assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
+        assert ctx.step_paths()["merged"] == n_steps  # (the merged symmetric step of rank 101)
+        chain.close()
+        ctx.close()
+    finally:
+        oracle.set_search_backend(oracle.SEARCH_BRUTE)

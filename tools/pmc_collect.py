@@ -4,7 +4,8 @@ passes, both in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request -> the r
 usage: pmc_collect.py <out.json> <config-name>=<fetch.csv>,<write.csv> ...   (merges into out.json if it exists)"""
 import collections, csv, json, os, statistics, sys
 
-SHORT = ["k_step_begin", "k_step_filter", "k_step_resolve", "k_step_regression", "k_step_finish", "k_posterior_eigen", "k_posterior_root",
+SHORT = ["k_wide_instance", "k_wide_filter", "k_wide_resolve", "k_wide_regression", "k_wide_propose", "k_wide_prepare", "k_sum_partials",
+         "k_mh_decide", "k_mh_front", "k_step_begin", "k_step_filter", "k_step_resolve", "k_step_regression", "k_step_finish", "k_posterior_eigen", "k_posterior_root",
          "k_tridiag", "k_tri_solve", "k_tri_gemm", "k_posterior_factor", "k_surface_filter", "k_surface_resolve", "k_vertex_filter",
          "k_transition_tails", "k_instance", "k_regression_mfma", "k_dist_stats", "k_propose"]
 
