@@ -4944,6 +4944,17 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
   return rc;
 }
 
+int icp_proposal_basis_state(icp_proposal* p, const double* theta) {
+  if (!p || !theta) return ICP_ERR_INVALID_ARG;
+  icp_ctx& c = *p->ctx;
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (c.batch_busy) return 1;  // (its context is part of a batch in flight: whatever it is doing, it is not ready)
+  PosteriorEntry* e = p->find_entry(theta);
+  if (!e) return 0;
+  if (!e->eig_valid) return 0;
+  return *(volatile int*)(p->h_eig + e->status_off / 3) == -1 ? 1 : 2;
+}
+
 int icp_chain_step_path(icp_evaluator* e, int32_t n_props, icp_proposal* const* props) {
   if (!e || n_props < 0 || (n_props > 0 && !props)) return ICP_ERR_INVALID_ARG;
   for (int i = 0; i < n_props; ++i)

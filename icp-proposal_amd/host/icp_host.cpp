@@ -326,8 +326,21 @@ struct LockstepGroup {
   icp_step_ticket* ticket = nullptr;
   ModelFittingParameters scratch_prop;
   icp_ctx* launch_ctx = nullptr;  // whose stream carries the group's launches (nullptr: the first member's)
+  // Chains are independent, so they need not advance at the same pace: a chain whose next ICP proposal would wait for a KL basis
+  // that is still being computed on the device (icp_proposal_basis_state: started ahead by the step that proposed its state, 0.6-0.7 ms
+  // at rank 200) sits out the round instead of holding the whole submission back, for at most kMaxDefer rounds and never when no
+  // other chain could step.  Enabled for chains of the wide step (icp_host_chains_run_batched).
+  bool defer_waiting = false;
+  static constexpr int kMaxDefer = 3;
+  std::vector<int> left, sat_out;   // steps this run still owes per chain; consecutive rounds the chain has sat out
+  std::vector<char> active;         // takes part in the round in flight
+  bool in_flight = false;
+  bool any_left() const { for (int v : left) if (v > 0) return true; return false; }
 
-  void init() {
+  void init(int n_steps) {
+    left.assign(chains.size(), n_steps);
+    sat_out.assign(chains.size(), 0);
+    active.assign(chains.size(), 0);
     const size_t B = chains.size();
     n_icp = chains[0]->icp.size();
     r = chains[0]->r;
@@ -344,7 +357,28 @@ struct LockstepGroup {
   // the next step of every member: random numbers, proposal kind, arguments; submission of those that share launches
   void issue() {
     member.clear(); ev.clear(); props.clear(); gen.clear(); cur_p.clear(); z_p.clear(); prop_p.clear();
+    in_flight = true;
+    // ---- who takes part in this round
+    int n_ready = 0;
+    std::vector<char> waiting(chains.size(), 0);
     for (size_t b = 0; b < chains.size(); ++b) {
+      active[b] = left[b] > 0;
+      if (!active[b]) continue;
+      icp_host_chain* ch = chains[b];
+      if (defer_waiting) {
+        const StepRandom r0{ch->seed, (uint64_t)ch->logger.index};
+        if (auto* ip = dynamic_cast<NonRigidIcpProposal*>(ch->root->peek(r0, 0)))
+          waiting[b] = icp_proposal_basis_state(ip->h, ch->current.data()) == 1;
+      }
+      if (!waiting[b]) ++n_ready;
+    }
+    for (size_t b = 0; b < chains.size(); ++b)
+      if (active[b] && waiting[b]) {
+        if (n_ready > 0 && sat_out[b] < kMaxDefer) { active[b] = 0; ++sat_out[b]; }
+        else sat_out[b] = 0;
+      } else if (active[b]) sat_out[b] = 0;
+    for (size_t b = 0; b < chains.size(); ++b) {
+      if (!active[b]) continue;
       icp_host_chain* ch = chains[b];
       rnd[b] = StepRandom{ch->seed, (uint64_t)ch->logger.index};
       ch->prefetcher.submitted_index = -1;
@@ -387,7 +421,7 @@ struct LockstepGroup {
   }
   // the normals of every member's next step, while this one is on the device
   void draw_ahead() {
-    if (!ahead.th.joinable() || !ahead.ready()) return;
+    if (!ahead.th.joinable() || !ahead.ready() || defer_waiting) return;
     for (size_t b = 0; b < chains.size(); ++b) { ahead.seed[b] = chains[b]->seed; ahead.step[b] = (uint64_t)chains[b]->logger.index + 1; }
     ahead.request();
   }
@@ -413,10 +447,13 @@ struct LockstepGroup {
       }
     }
     for (size_t b = 0; b < chains.size(); ++b) {
+      if (!active[b]) continue;  // (sat this round out, or has taken all its steps)
       icp_host_chain* ch = chains[b];
       ch->current = ch->mh->next(ch->current, rnd[b], &ch->logger);
       ch->current_p = ch->mh->cached_current_p;
+      --left[b];
     }
+    in_flight = false;
   }
   void abandon() {  // after a failure elsewhere: the submission in flight is waited for and dropped
     if (ticket) { (void)icp_chain_step_batched_collect(ticket); ticket = nullptr; }
@@ -548,18 +585,20 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
     // (measured, tools/ab_groups64.sh: two groups from 8 chains to 64 — 16 chains: 70k against 56k it/s with one or three, 32: 108k against
     // 90k with three, 64: 134k against 117k; beyond that groups of about 32: 96 chains 135k, 128 chains 142k with four)
     int n_groups = forced > 0 ? forced : (n_chains > 80 ? (n_chains + 31) / 32 : n_chains >= 8 ? 2 : 1);
+    bool wide = false;
     // Chains that take the WIDE step (open targets, the Hausdorff evaluator, rank 200, pose walks: a step of 0.5-1.5 ms whose
     // one-workgroup factorisations and decompositions run side by side for all chains of a submission) are better off in ONE group
     // per 16 chains: 10 chains of the face configuration 6.65k it/s in one group, 5.6k in two, 4.9k in three, 4.1k in four — every
     // launch costs the same whatever it carries, and the groups' chip-wide launches share one stream anyway.
-    if (forced <= 0 && !chains[0]->icp.empty()) {
+    if (!chains[0]->icp.empty()) {
       std::vector<icp_proposal*> hs;
       for (auto* p : chains[0]->icp) hs.push_back(p->h);
-      if (icp_chain_step_path(chains[0]->likelihood->h, (int)hs.size(), hs.data()) == 1) n_groups = (n_chains + 15) / 16;
+      wide = icp_chain_step_path(chains[0]->likelihood->h, (int)hs.size(), hs.data()) == 1;
+      if (wide && forced <= 0) n_groups = (n_chains + 15) / 16;
     }
     n_groups = std::max(1, std::min(std::min(n_groups, kMaxGroups), n_chains));
     for (int b = 0; b < n_chains; ++b) groups[(size_t)b * n_groups / n_chains].chains.push_back(chains[b]);
-    for (int g = 0; g < n_groups; ++g) groups[g].init();
+    for (int g = 0; g < n_groups; ++g) groups[g].init(n_steps);
     // all groups' launches on ONE stream, one group behind the other: side by side the big launches of two groups slow each
     // other down more than the overlap gains (regression 18 -> 80 µs beside the other group's filter); the decompositions
     // keep their own streams
@@ -568,13 +607,17 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
     // was tried — the kernel trace shows the launch stream idle a third of the time at 64 chains: sequences of 152 µs every 236 µs,
     // the host needs ≈ 7 µs per chain and step — and measured slower at every size, 16 chains 58k against 71k it/s, 64 chains 126k
     // against 129k: the threads' launches and their waits meet in the runtime.)
+    static const bool no_defer = std::getenv("ICP_NO_DEFERRAL") != nullptr;  // (operational switch: every chain steps every round)
+    for (int g = 0; g < n_groups; ++g) groups[g].defer_waiting = wide && !no_defer && groups[g].chains.size() > 1;
     if (n_steps > 0)
       for (int g = 0; g < n_groups; ++g) groups[g].issue();
-    for (int s = 0; s < n_steps; ++s)
+    for (bool busy = n_steps > 0; busy;) {  // (rounds: a group's chains may advance at different paces, see LockstepGroup::defer_waiting)
+      busy = false;
       for (int g = 0; g < n_groups; ++g) {
-        groups[g].finish();
-        if (s + 1 < n_steps) groups[g].issue();
+        if (groups[g].in_flight) groups[g].finish();
+        if (groups[g].any_left()) { groups[g].issue(); busy = true; }
       }
+    }
   });
   for (auto& g : groups) g.abandon();
   if (chains)

@@ -388,6 +388,12 @@ ICP_API int icp_ctx_runtime_stats(const icp_ctx *ctx, icp_runtime_stats *out);
  * icp_chains_run_on_device. */
 ICP_API int icp_ctx_step_paths(const icp_ctx *ctx, int64_t out[4]);
 
+/* Is the KL basis the proposal would draw from at `theta` ready?  2: the posterior of theta is on record and decomposed (or needs no
+ * decomposition); 1: its decomposition is still on the device (started ahead by the step that proposed theta) — an ICP proposal from
+ * theta would wait for it; 0: nothing on record (a step from theta computes it).  Never blocks.  A caller that steps many independent
+ * chains uses it to let a chain whose basis is still under way sit out a round instead of holding the others back. */
+ICP_API int icp_proposal_basis_state(icp_proposal *p, const double *theta);
+
 /* Which path icp_chain_step[_batched] takes for this proposal set and evaluator (a property of the configuration, not of a state):
  * 0 the five merged launches, 1 the wide step, 2 per-stage kernels.  A caller that steps many chains uses it to size its batches:
  * the merged launches are short and want several groups of chains in flight, a wide step is long and wants one. */
