@@ -329,7 +329,7 @@ struct LockstepGroup {
   // Chains are independent, so they need not advance at the same pace: a chain whose next ICP proposal would wait for a KL basis
   // that is still being computed on the device (icp_proposal_basis_state: started ahead by the step that proposed its state, 0.6-0.7 ms
   // at rank 200) sits out the round instead of holding the whole submission back, for at most kMaxDefer rounds and never when no
-  // other chain could step.  Enabled for chains of the wide step (icp_host_chains_run_batched).
+  // other chain could step.  Opt-in (ICP_DEFERRAL=1) for chains of the wide step: measured neutral to harmful, see icp_host_chains_run_batched.
   bool defer_waiting = false;
   static constexpr int kMaxDefer = 3;
   std::vector<int> left, sat_out;   // steps this run still owes per chain; consecutive rounds the chain has sat out
@@ -607,8 +607,11 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
     // was tried — the kernel trace shows the launch stream idle a third of the time at 64 chains: sequences of 152 µs every 236 µs,
     // the host needs ≈ 7 µs per chain and step — and measured slower at every size, 16 chains 58k against 71k it/s, 64 chains 126k
     // against 129k: the threads' launches and their waits meet in the runtime.)
-    static const bool no_defer = std::getenv("ICP_NO_DEFERRAL") != nullptr;  // (operational switch: every chain steps every round)
-    for (int g = 0; g < n_groups; ++g) groups[g].defer_waiting = wide && !no_defer && groups[g].chains.size() > 1;
+    // (measured, tools/r4_defer.sh, 10 chains of the face configuration: 6.5-6.9k it/s either way in the steady state, 4.0k against 6.5k
+    // over a chain's first 50 steps, where most chains wait most rounds and the rounds of the few that do not cost as much as full ones —
+    // a round's cost is its launches, not its chains.  Off unless asked for.)
+    static const bool defer = std::getenv("ICP_DEFERRAL") != nullptr && std::atoi(std::getenv("ICP_DEFERRAL")) != 0;
+    for (int g = 0; g < n_groups; ++g) groups[g].defer_waiting = wide && defer && groups[g].chains.size() > 1;
     if (n_steps > 0)
       for (int g = 0; g < n_groups; ++g) groups[g].issue();
     for (bool busy = n_steps > 0; busy;) {  // (rounds: a group's chains may advance at different paces, see LockstepGroup::defer_waiting)
