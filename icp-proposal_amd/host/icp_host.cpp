@@ -567,7 +567,7 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
       n_steps -= n_dev;
     }
   }
-  constexpr int kMaxGroups = 4;
+  constexpr int kMaxGroups = 8;
   LockstepGroup groups[kMaxGroups];
   int rc = host_guard([&] {
     if (!chains || n_chains < 1 || n_steps < 0) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chains_run_batched");
@@ -594,7 +594,8 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
       std::vector<icp_proposal*> hs;
       for (auto* p : chains[0]->icp) hs.push_back(p->h);
       wide = icp_chain_step_path(chains[0]->likelihood->h, (int)hs.size(), hs.data()) == 1;
-      if (wide && forced <= 0) n_groups = (n_chains + 15) / 16;
+      static const int wide_group = std::getenv("ICP_WIDE_GROUP") ? std::max(1, std::atoi(std::getenv("ICP_WIDE_GROUP"))) : 16;
+      if (wide && forced <= 0) n_groups = (n_chains + wide_group - 1) / wide_group;
     }
     n_groups = std::max(1, std::min(std::min(n_groups, kMaxGroups), n_chains));
     for (int b = 0; b < n_chains; ++b) groups[(size_t)b * n_groups / n_chains].chains.push_back(chains[b]);
