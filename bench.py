@@ -643,7 +643,7 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
     targets = [pkg.data.synthetic_partial_target(model, seed=100 + t) for t in range(args.targets)]
     make_setup = lambda m, t: pkg.bfm_fitting_partial(m, t, evaluator="collective", fused=args.fused)
     # chains of one target side by side (the wide step): all of them unless --chains-per-gpu says otherwise (1 = one after the other)
-    cpl = args.chains if args.chains_per_gpu <= 0 else args.chains_per_gpu
+    cpl = args.chains_per_gpu if args.chains_per_gpu > 0 else 0  # (0: sharding.run_batch's default — three targets' chains per submission)
     # warm-up: one item per rank (builds the communicator, pages the kernels in)
     pkg.sharding.run_batch(pkg, model, targets[:1], n_chains=world, n_steps=max(1, args.warmup), make_setup=make_setup, dist=dist,
                            device_index=local_rank)
@@ -680,7 +680,7 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
                            "baseline_config_index": 4, "items": n_items, "items_per_s": n_items / dt, "job_s": dt,
                            "items_per_rank": [int(p[1]) for p in per_rank], "contexts_built_per_rank": [int(p[0]) for p in per_rank],
                            "gather_ms_per_rank": [round(p[2], 3) for p in per_rank], "chain_ms_per_rank": [round(p[3], 1) for p in per_rank],
-                           "chains_per_launch": cpl, "best_item": [int(v) for v in items[best]],
+                           "chains_per_launch": cpl if cpl > 0 else max(1, min(32, 3 * args.chains)), "best_item": [int(v) for v in items[best]],
                            "accepted": int(sum(r[:, 1].sum() for r in recs))},
                 "roofline": None, "cpu_baseline": None, "multi_gpu": multi_gpu, "runtime_stats": pkg._native.runtime_stats()}
         print(json.dumps(line))

@@ -588,13 +588,14 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
     bool wide = false;
     // Chains that take the WIDE step (open targets, the Hausdorff evaluator, rank 200, pose walks: a step of 0.5-1.5 ms whose
     // one-workgroup factorisations and decompositions run side by side for all chains of a submission) are better off in ONE group
-    // per 16 chains: 10 chains of the face configuration 6.65k it/s in one group, 5.6k in two, 4.9k in three, 4.1k in four — every
-    // launch costs the same whatever it carries, and the groups' chip-wide launches share one stream anyway.
+    // per 32 chains: 10 chains of the face configuration 6.65k it/s in one group, 5.6k in two, 4.9k in three, 4.1k in four — every
+    // launch costs the same whatever it carries, and the groups' chip-wide launches share one stream anyway (20 chains in one group
+    // 9.1k it/s, 30: 10.5k, 40 in two groups of 20: 10.3k; tools/r4_many.sh).
     if (!chains[0]->icp.empty()) {
       std::vector<icp_proposal*> hs;
       for (auto* p : chains[0]->icp) hs.push_back(p->h);
       wide = icp_chain_step_path(chains[0]->likelihood->h, (int)hs.size(), hs.data()) == 1;
-      static const int wide_group = std::getenv("ICP_WIDE_GROUP") ? std::max(1, std::atoi(std::getenv("ICP_WIDE_GROUP"))) : 16;
+      static const int wide_group = std::getenv("ICP_WIDE_GROUP") ? std::max(1, std::atoi(std::getenv("ICP_WIDE_GROUP"))) : 32;
       if (wide && forced <= 0) n_groups = (n_chains + wide_group - 1) / wide_group;
     }
     n_groups = std::max(1, std::min(std::min(n_groups, kMaxGroups), n_chains));

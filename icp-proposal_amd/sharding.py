@@ -120,8 +120,9 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
     chain index) and records[k] = [n_steps, 14 + rank] for every item of the whole job, in item order, on every rank.
     chains_per_launch = B > 1: the rank steps B of its chains OF ONE TARGET side by side through icp_chain_step_batched (one context
     per chain — model and target are shared between them on the device; SURVEY.md §8e "within a GPU, batch B chains per launch") —
-    same records, chain by chain.  0 (default): all chains the rank holds of a target (the one-workgroup factorisations and
-    decompositions of B chains then run on B CUs instead of one after the other); 1: one context per target, its chains one by one.
+    same records, chain by chain.  0 (default): three targets' worth of chains, at most 32 (the one-workgroup factorisations and
+    decompositions of B chains then run on B CUs instead of one after the other; chains of DIFFERENT targets share a submission as
+    well: the step only needs them to share the model); 1: one context, the chains one by one.
     return_stats: a third value, this rank's {items, contexts_built, targets_met, chain_ms, gather_ms}."""
     import time
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
@@ -132,33 +133,42 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
     contexts_built = 0
     pool = []  # this rank's contexts, kept from target to target
     if chains_per_launch <= 0:
-        chains_per_launch = max(1, n_chains)
+        # (measured on one MI355X, face configuration: 10 chains per submission 6.7k it/s, 20: 9.1k, 30: 10.5k, 40: 10.3k — a round costs
+        # its launches and the slowest chain's decomposition, whatever it carries: tools/r4_many.sh)
+        chains_per_launch = max(1, min(32, 3 * n_chains))
     t_start = time.perf_counter()
     my_targets = sorted(set(items[k][0] for k in mine))
-    for t in my_targets:
-        ks = [k for k in mine if items[k][0] == t]
-        setup = make_setup(model, targets[t])
-        theta0 = lambda k: pkg.random_initial_parameters(model, items[k][1], base_seed)
-        seed = lambda k: base_seed + 1000 * t + items[k][1]
-        if chains_per_launch > 1:
-            for g0 in range(0, len(ks), chains_per_launch):
-                group = ks[g0:g0 + chains_per_launch]
-                # the rank's contexts (per-chain scratch, streams, pinned buffers; the model's device data is shared) are made ONCE and
-                # handed from target to target (icp_ctx_set_target): a context costs 20+ ms to make and as much to destroy
-                while len(pool) < len(group):
-                    pool.append(pkg.IcpContext(model, targets[t], device=device_index))
-                    contexts_built += 1
-                ctxs = pool[:len(group)]
-                for cx in ctxs:
-                    if cx.target is not targets[t]:
-                        cx.setTarget(targets[t])
-                chains = [pkg.SamplingRegistration(cx, setup, theta0(k), seed=seed(k)) for cx, k in zip(ctxs, group)]
-                for k, rec in zip(group, pkg.run_chains_batched(chains, n_steps)):
-                    rec[:, 0] = k                              # the record's index field carries the item id across the gather
-                    blocks.append(rec)
-                for ch in chains:
-                    ch.close()
-        else:                                                  # one context for the rank, its chains one after the other
+    theta0 = lambda k: pkg.random_initial_parameters(model, items[k][1], base_seed)
+    seed = lambda k: base_seed + 1000 * items[k][0] + items[k][1]
+    setups = {}
+    def setup_of(t):
+        if t not in setups:
+            setups[t] = make_setup(model, targets[t])
+        return setups[t]
+    if chains_per_launch > 1:
+        # `chains_per_launch` work items side by side, in item order (target-major): the chains of one target and — the wide step only
+        # needs its chains to share the MODEL — of the targets behind it.  The rank's contexts (per-chain scratch, streams, pinned
+        # buffers; the model's device data is shared) are made ONCE and handed from target to target (icp_ctx_set_target): a context
+        # costs 20+ ms to make and as much to destroy.
+        order = sorted(mine)
+        for g0 in range(0, len(order), chains_per_launch):
+            group = order[g0:g0 + chains_per_launch]
+            while len(pool) < len(group):
+                pool.append(pkg.IcpContext(model, targets[items[group[len(pool)]][0]], device=device_index))
+                contexts_built += 1
+            ctxs = pool[:len(group)]
+            for cx, k in zip(ctxs, group):
+                if cx.target is not targets[items[k][0]]:
+                    cx.setTarget(targets[items[k][0]])
+            chains = [pkg.SamplingRegistration(cx, setup_of(items[k][0]), theta0(k), seed=seed(k)) for cx, k in zip(ctxs, group)]
+            for k, rec in zip(group, pkg.run_chains_batched(chains, n_steps)):
+                rec[:, 0] = k                              # the record's index field carries the item id across the gather
+                blocks.append(rec)
+            for ch in chains:
+                ch.close()
+    else:                                                  # one context for the rank, its chains one after the other
+        for t in my_targets:
+            ks = [k for k in mine if items[k][0] == t]
             if not pool:
                 pool.append(pkg.IcpContext(model, targets[t], device=device_index))
                 contexts_built += 1
@@ -166,7 +176,7 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
             if ctx.target is not targets[t]:
                 ctx.setTarget(targets[t])
             for k in ks:
-                chain = pkg.SamplingRegistration(ctx, setup, theta0(k), seed=seed(k))
+                chain = pkg.SamplingRegistration(ctx, setup_of(t), theta0(k), seed=seed(k))
                 rec = chain.run(n_steps)
                 rec[:, 0] = k
                 blocks.append(rec)
