@@ -20,6 +20,7 @@
 #include <mutex>
 #include <string>
 #include <set>
+#include <thread>
 #include <vector>
 
 #include "icp_kernels.hpp"
@@ -223,9 +224,29 @@ std::map<SharedKey, std::weak_ptr<SharedTarget>> g_shared_targets;
 std::shared_ptr<SharedModel>* const g_model_keep = new std::shared_ptr<SharedModel>[2];
 int g_model_keep_next = 0;
 
+uint64_t hash_words_serial(uint64_t h, const void* data, size_t bytes);
+// … and large arrays in pieces on several threads, the pieces' hashes hashed in order (the same value whatever the thread count:
+// the pieces are fixed 8 MiB): 137 MB of basis in ≈ 1.5 ms instead of 9 — per context created (a batch registration makes dozens)
+uint64_t hash_words(uint64_t h, const void* data, size_t bytes) {
+  constexpr size_t kPiece = (size_t)8 << 20;
+  if (bytes < 2 * kPiece) return hash_words_serial(h, data, bytes);
+  const size_t n = (bytes + kPiece - 1) / kPiece;
+  std::vector<uint64_t> part(n);
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::thread> th;
+  std::atomic<size_t> next{0};
+  auto work = [&] {
+    for (size_t i; (i = next.fetch_add(1)) < n;)
+      part[i] = hash_words_serial(0x9E3779B97F4A7C15ull + i, (const unsigned char*)data + i * kPiece, std::min(kPiece, bytes - i * kPiece));
+  };
+  for (unsigned t = 1; t < hw; ++t) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+  return hash_words_serial(h, part.data(), sizeof(uint64_t) * n);
+}
 // word-wise multiply-xor (identity of the arrays, not security); four independent lanes: one lane's dependent multiply chain
 // made 35 ms of every context creation at the face model's 137 MB of basis
-uint64_t hash_words(uint64_t h, const void* data, size_t bytes) {
+uint64_t hash_words_serial(uint64_t h, const void* data, size_t bytes) {
   const unsigned char* p = (const unsigned char*)data;
   constexpr uint64_t kMul = 0x9E3779B97F4A7C15ull;
   uint64_t a = h, b = h ^ 0x243F6A8885A308D3ull, c = h ^ 0x13198A2E03707344ull, d = h ^ 0xA4093822299F31D0ull;

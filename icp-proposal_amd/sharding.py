@@ -135,7 +135,8 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
     if chains_per_launch <= 0:
         # (measured on one MI355X, face configuration: 10 chains per submission 6.7k it/s, 20: 9.1k, 30: 10.5k, 40: 10.3k — a round costs
         # its launches and the slowest chain's decomposition, whatever it carries: tools/r4_many.sh)
-        chains_per_launch = max(1, min(32, 3 * n_chains))
+        # Short chains: one target's worth — making (and re-targeting) 30 contexts costs more than 50 steps take.
+        chains_per_launch = max(1, min(32, 3 * n_chains)) if n_steps >= 200 else max(1, min(32, n_chains))
     t_start = time.perf_counter()
     my_targets = sorted(set(items[k][0] for k in mine))
     theta0 = lambda k: pkg.random_initial_parameters(model, items[k][1], base_seed)
