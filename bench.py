@@ -92,8 +92,10 @@ def rank_report(dist, torch, rank, world, local_rank, chain_ms, gather_ms, cpu=F
 
 
 def device_identity(torch, local_rank, cpu=False):
-    if cpu or torch is None:
+    if cpu:
         return {"device": "cpu", "gpu": "cpu-process-%d" % os.getpid(), "name": "host"}
+    if torch is None:  # (a single process outside a launcher never imports torch: the library's own HIP ordinal)
+        return {"device": "hip:%d" % local_rank, "gpu": "hip-ordinal-%d-of-process-%d" % (local_rank, os.getpid()), "name": "MI355X (not queried: no torch in this process)"}
     pr = torch.cuda.get_device_properties(local_rank)
     ident = getattr(pr, "uuid", None)
     if ident is None or not str(ident).strip("0-"):  # (builds without a uuid, or an all-zero one: the PCI address)
