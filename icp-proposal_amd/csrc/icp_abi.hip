@@ -426,8 +426,8 @@ struct icp_ctx {
   void* batch_eig_rec[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
   size_t batch_eig_rec_bytes[kBatchRing] = {0, 0, 0, 0};
   int batch_eig_turn = 0;
-  DBuf<int> batch_gate;
-  int batch_gate_expected = 0;
+  DBuf<int> batch_gate;                                   // one counter word per ring slot (a later batch's workgroups must not open an earlier batch's gate)
+  int batch_gate_expected[kBatchRing] = {0, 0, 0, 0};
   int* h_gate_error = nullptr;
   // eigen streams of the batches this context carries, one per batch in flight (keyed by the batch's first chain): created
   // together, so that the runtime spreads them over different hardware queues — the member contexts' own eigen streams
@@ -4303,13 +4303,15 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
         HIP_OK(hipMemset(lead.batch_gate.p, 0, sizeof(int) * 16));
         HIP_OK(hipHostMalloc((void**)&lead.h_gate_error, sizeof(int) * 16, hipHostMallocDefault));
         lead.h_gate_error[0] = 0;
-        lead.batch_gate_expected = 0;
+        for (int k = 0; k < icp_ctx::kBatchRing; ++k) lead.batch_gate_expected[k] = 0;
       }
+      // (the slot's own counter word: up to kBatchRing batches are in flight per launch context, and the workgroups of a LATER batch's
+      // decompositions counting into one shared word could open an earlier batch's gate before its own decompositions are resident)
       const int wgs = launch_posterior_eigen_many(eigens.stream, elead.r, (int)eigens.rq.size(), eigens.rq.data(), lead.batch_eig_rec[turn],
-                                                  lead.batch_gate.p);
+                                                  lead.batch_gate.p + turn);
       require(wgs > 0, "internal: batched decompositions at a rank the kernel does not cover");
-      lead.batch_gate_expected = (int)((unsigned)lead.batch_gate_expected + (unsigned)wgs);  // (wraps with the counter)
-      gate = StepBatchGate{lead.batch_gate.p, lead.batch_gate_expected, lead.h_gate_error};
+      lead.batch_gate_expected[turn] = (int)((unsigned)lead.batch_gate_expected[turn] + (unsigned)wgs);  // (wraps with the counter)
+      gate = StepBatchGate{lead.batch_gate.p + turn, lead.batch_gate_expected[turn], lead.h_gate_error};
       // test hook (tools/r3_timeout_repro.py: round 2's schedule, for the record): the launch sequence is not held back
       static const bool no_gate = dev_env("ICP_TEST_NO_GATE") != nullptr;
       if (no_gate) gate = StepBatchGate{};
