@@ -370,7 +370,8 @@ struct icp_ctx {
   QueryScratch scratch_t;  // third: … and the evaluator's target -> model surface search
   QueryScratch scratch_n;  // the wide step's second search stage: nearest target vertices of the model-side surface points …
   QueryScratch scratch_tn; // … and nearest model vertices of the evaluator's target-side surface points (their own candidate counters)
-  QueryScratch scratch_p;  // the proposal's own model ids where the evaluator's searches run as a sequence of their own (the wide step, Hausdorff)
+  QueryScratch scratch_p;  // the proposal's own model ids where the evaluator's searches run as a sequence of their own (the wide step)
+  QueryScratch scratch_en; // … and the nearest vertices of the evaluator's own ids in that case
   // staging for small host<->device transfers of one API call
   double* h_stage = nullptr;  // pinned
   DBuf<double> d_stage;
@@ -441,7 +442,7 @@ struct icp_ctx {
 
   // scratch for K queries against a set of n_elems elements (every query may list every element as a candidate)
   QueryBuffers query_scratch(size_t K, size_t n_elems, int which = 0) {
-    QueryScratch& scratch = which == 1 ? scratch_v : which == 2 ? scratch_t : which == 3 ? scratch_n : which == 4 ? scratch_tn : which == 5 ? scratch_p : this->scratch;
+    QueryScratch& scratch = which == 1 ? scratch_v : which == 2 ? scratch_t : which == 3 ? scratch_n : which == 4 ? scratch_tn : which == 5 ? scratch_p : which == 6 ? scratch_en : this->scratch;
     if (K > scratch.cap) {
       HIP_OK(hipStreamSynchronize(stream));
       if (front_stream) HIP_OK(hipStreamSynchronize(front_stream));
@@ -3656,6 +3657,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   plan.B = nW; plan.N = elead.N; plan.r = r; plan.Qp = elead.Qp.p; plan.ref = elead.ref.p; plan.mean = elead.mean.p;
   plan.f1_prepared = true;
   bool any_split = false;
+  const bool concurrent = t.items[idx[0]].e->prm.kind == ICP_EVAL_HAUSDORFF;  // (how a split step's two sequences are scheduled: below)
   const int spec_mode = speculation_mode();
 
   for (int k = 0; k < nW; ++k) {
@@ -3778,25 +3780,36 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     const int Knnv = std::max(prop_nnv ? pm->K : 0, eval_nnv ? Km : 0);
     require(Ksurf <= c.N, "model id count exceeds the number of model points");
     w.Ksurf = Ksurf; w.Knnv = Knnv; w.spheres = ev_t2m;
-    // The full-mesh Hausdorff evaluator (every model vertex against the target surface, every target vertex against the model's:
-    // 0.2 ms of chip-wide searches) beside a proposal whose own chain — its K model ids, their nearest vertices, the regression, then
-    // the one-workgroup factorisation and tails, 0.2 ms — needs none of that: two sequences on two streams.  The proposal's ids
-    // 0..Kp are then a surface task of their own, the evaluator takes the ids behind them.
-    const bool split = hd && w.do_post;
-    const int Kp = split ? (pm ? pm->K : 0) : 0;
+    // Split: the PROPOSAL's chain — its K model ids -> their nearest vertices -> correspondences -> regression -> partial sums: what the
+    // factorisation, the tails and the decomposition wait for — is the MAIN sequence; the evaluator's searches and reductions are a
+    // sequence of their own behind (or beside) it:
+    //   concurrent (the batch's evaluator is the full-mesh Hausdorff distance: every model vertex against the target surface, every
+    //     target vertex against the model's, 0.2 ms of chip-wide searches): the evaluator's sequence on S BESIDE the main one on the
+    //     second stream; the maxima are order-independent, each sequence reduces its own range (atomic maxima);
+    //   serial (any other evaluator): main first, the evaluator's sequence behind it on the same stream — the side streams
+    //     (factorisation + tails, decomposition) start as soon as the partial sums exist instead of behind every search of the step
+    //     (10 chains of the face configuration: ≈ 0.2 ms earlier); the reductions run at the end, over all ids.
+    const bool split = w.do_post && (concurrent ? hd : true);
+    const int Kp = split ? (pm ? std::min(pm->K, Ksurf) : 0) : 0;
     any_split = any_split || split;
-    QueryBuffers qs{}, qv{}, qt{}, qn{}, qtn{}, qp{};
+    int nnv_main = Knnv, nnv_lo = 0, nnv_hi = 0;  // nearest vertices: ids [0, nnv_main) by the main sequence, [nnv_lo, nnv_hi) by the evaluator's
+    if (split) {
+      nnv_main = prop_nnv ? pm->K : 0;
+      if (eval_nnv) { nnv_lo = prop_nnv ? std::min(pm->K, Km) : 0; nnv_hi = Km; }
+    }
+    QueryBuffers qs{}, qv{}, qt{}, qn{}, qtn{}, qp{}, qen{};
     if (Ksurf - Kp > 0) qs = c.query_scratch(Ksurf - Kp, c.target.T, 0);
     if (split && Kp > 0) qp = c.query_scratch(Kp, c.target.T, 5);
     if (pt) qv = c.query_scratch(pt->K, c.N, 1);
     if (ev_t2m) qt = c.query_scratch(Kt, c.T, 2);
-    if (Knnv > 0) qn = c.query_scratch(Knnv, c.target.V, 3);
+    if (nnv_main > 0) qn = c.query_scratch(nnv_main, c.target.V, 3);
+    if (nnv_hi > nnv_lo) qen = c.query_scratch(nnv_hi - nnv_lo, c.target.V, 6);
     if (t2m_nnv) qtn = c.query_scratch(Kt, c.N, 4);
 
     WideChainArgs& A = chain_args[k];
     std::memset(&A, 0, sizeof(A));
     SurfaceTask st_surf{}, st_t2m{}, st_surfp{};
-    VertexTask st_vert{}, st_nnv{}, st_tnn{};
+    VertexTask st_vert{}, st_nnv{}, st_ennv{}, st_tnn{};
     if (Ksurf - Kp > 0)  // (ids Kp..Ksurf; Kp = 0 unless the evaluator has a sequence of its own)
       st_surf = make_surface_task(c.target.T, c.target.verts.p, c.target.tris.p, c.target.spheres.p, Ksurf - Kp, s.x.p + 3 * (size_t)Kp,
                                   c.hint_surf.p + Kp, qs, s.surf_cp.p + 3 * (size_t)Kp, s.surf_d2.p + Kp, s.surf_tri.p + Kp);
@@ -3806,7 +3819,12 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     if (ev_t2m)
       st_t2m = make_surface_task(c.T, s.x.p, c.tris.p, s.spheres.p, Kt, e->d_tpts, e->hint_tri.p, qt, e->t2m_cp.p, e->t2m_d2.p, e->t2m_tri.p);
     if (pt) { st_vert = make_vertex_task(c.N, s.x.p, pt->K, pt->target_pts.p, pt->hint_nn.p, qv, nullptr, pt->nn_id.p); st_vert.thr2 = nullptr; }
-    if (Knnv > 0) { st_nnv = make_vertex_task(c.target.V, c.target.verts.p, Knnv, s.surf_cp.p, c.hint_nnv.p, qn, nullptr, s.surf_nnv.p); st_nnv.thr2 = nullptr; }
+    if (nnv_main > 0) { st_nnv = make_vertex_task(c.target.V, c.target.verts.p, nnv_main, s.surf_cp.p, c.hint_nnv.p, qn, nullptr, s.surf_nnv.p); st_nnv.thr2 = nullptr; }
+    if (nnv_hi > nnv_lo) {
+      st_ennv = make_vertex_task(c.target.V, c.target.verts.p, nnv_hi - nnv_lo, s.surf_cp.p + 3 * (size_t)nnv_lo, c.hint_nnv.p + nnv_lo, qen, nullptr,
+                                 s.surf_nnv.p + nnv_lo);
+      st_ennv.thr2 = nullptr;
+    }
     if (t2m_nnv) { st_tnn = make_vertex_task(c.N, s.x.p, Kt, e->t2m_cp.p, e->hint_nnv.p, qtn, nullptr, e->t2m_nnv.p); st_tnn.thr2 = nullptr; }
 
     // W2
@@ -3825,86 +3843,53 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     A.prep.T = ev_t2m ? c.T : 0; A.prep.x = s.x.p; A.prep.tris = c.tris.p; A.prep.order = c.tri_order.p; A.prep.spheres = s.spheres.p;
     A.prep.has_t2m = ev_t2m ? 1 : 0; A.prep.t2m = st_t2m;
     A.prep.n_cnt = 0;
-    if (pt) { A.prep.cnt[A.prep.n_cnt] = st_vert.cnt; A.prep.cnt_n[A.prep.n_cnt++] = st_vert.Kpad; }
-    if (Knnv > 0) { A.prep.cnt[A.prep.n_cnt] = st_nnv.cnt; A.prep.cnt_n[A.prep.n_cnt++] = st_nnv.Kpad; }
-    if (t2m_nnv) { A.prep.cnt[A.prep.n_cnt] = st_tnn.cnt; A.prep.cnt_n[A.prep.n_cnt++] = st_tnn.Kpad; }
+    auto reset_cnt = [&](const VertexTask& v) { A.prep.cnt[A.prep.n_cnt] = v.cnt; A.prep.cnt_n[A.prep.n_cnt++] = v.Kpad; };
+    if (pt) reset_cnt(st_vert);
+    if (nnv_main > 0) reset_cnt(st_nnv);
+    if (nnv_hi > nnv_lo) reset_cnt(st_ennv);
+    if (t2m_nnv) reset_cnt(st_tnn);
     A.prep.zero_d = c.d_res.p; A.prep.n_zero_d = 8;
-    // W4/W5: stage 1 — the main sequence: every search of the step, or (split) only the proposal's
-    StepSearchArgs& q1 = A.s1;
-    q1.s_corr[0] = q1.s_corr[1] = q1.v_corr[0] = q1.v_corr[1] = -1;
-    int nt = 0, n_corr = 0;
-    q1.fstart[0] = 0; q1.rstart[0] = 0;
+    // ---- the search sequences: tasks are appended to a StepSearchArgs (surface tasks first)
+    struct Seq { StepSearchArgs* q; int nt = 0, n_corr = 0; };
+    auto seq_init = [](StepSearchArgs& q) { q.s_corr[0] = q.s_corr[1] = q.v_corr[0] = q.v_corr[1] = -1; q.fstart[0] = 0; q.rstart[0] = 0; return Seq{&q}; };
+    auto add_surface = [&](Seq& sq, const SurfaceTask& t, const CorrTask* corr) {
+      StepSearchArgs& q = *sq.q;
+      q.s[q.n_surf] = t;
+      q.fstart[sq.nt + 1] = q.fstart[sq.nt] + filter_grid_blocks(t.tblocks, t.ksplit);
+      q.rstart[sq.nt + 1] = q.rstart[sq.nt] + t.K;
+      if (corr) { q.corr[sq.n_corr] = *corr; q.s_corr[q.n_surf] = sq.n_corr++; }
+      ++q.n_surf; ++sq.nt;
+    };
+    auto add_vertex = [&](Seq& sq, const VertexTask& t, const CorrTask* corr) {
+      StepSearchArgs& q = *sq.q;
+      q.v[q.n_vert] = t;
+      q.fstart[sq.nt + 1] = q.fstart[sq.nt] + filter_grid_blocks(t.vblocks, t.ksplit);
+      q.rstart[sq.nt + 1] = q.rstart[sq.nt] + t.K;
+      if (corr) { q.corr[sq.n_corr] = *corr; q.v_corr[q.n_vert] = sq.n_corr++; }
+      ++q.n_vert; ++sq.nt;
+    };
+    auto seq_close = [](Seq& sq) { for (int u = sq.nt + 1; u < 5; ++u) { sq.q->fstart[u] = sq.q->fstart[sq.nt]; sq.q->rstart[u] = sq.q->rstart[sq.nt]; } };
+    CorrTask corr_m{}, corr_t{};
+    if (pm) corr_m = CorrTask{pm->K, ep[im]->corr(), s.x.p, nullptr, c.target.boundary.p, nullptr, pm->prm.boundary_aware,
+                              s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, prop_nnv ? s.surf_cp.p : nullptr};
+    if (pt) corr_t = CorrTask{pt->K, ep[itx]->corr(), s.x.p, pt->target_pts.p, c.boundary.p, nullptr, pt->prm.boundary_aware,
+                              s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, nullptr};
+    // main, stage 1 (W4/W5) and stage 2 (W6/W7: nearest vertices of the surface points, ModelSampling correspondences with their flag)
+    Seq m1 = seq_init(A.s1), m2 = seq_init(A.s2), e1 = seq_init(A.s1b), e2 = seq_init(A.s2b);
     const SurfaceTask& st_first = split ? st_surfp : st_surf;
-    if (st_first.K > 0) {
-      q1.s[q1.n_surf] = st_first;
-      q1.fstart[nt + 1] = q1.fstart[nt] + filter_grid_blocks(st_first.tblocks, st_first.ksplit);
-      q1.rstart[nt + 1] = q1.rstart[nt] + st_first.K;
-      if (pm && !prop_nnv) {
-        q1.corr[n_corr] = CorrTask{pm->K, ep[im]->corr(), s.x.p, nullptr, c.target.boundary.p, nullptr, pm->prm.boundary_aware,
-                                   s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, nullptr};
-        q1.s_corr[q1.n_surf] = n_corr++;
-      }
-      ++q1.n_surf; ++nt;
-    }
-    if (ev_t2m && !split) {
-      q1.s[q1.n_surf] = st_t2m;
-      q1.fstart[nt + 1] = q1.fstart[nt] + filter_grid_blocks(st_t2m.tblocks, st_t2m.ksplit);
-      q1.rstart[nt + 1] = q1.rstart[nt] + Kt;
-      ++q1.n_surf; ++nt;
-    }
-    if (pt) {
-      q1.v[0] = st_vert;
-      q1.fstart[nt + 1] = q1.fstart[nt] + filter_grid_blocks(st_vert.vblocks, st_vert.ksplit);
-      q1.rstart[nt + 1] = q1.rstart[nt] + pt->K;
-      q1.corr[n_corr] = CorrTask{pt->K, ep[itx]->corr(), s.x.p, pt->target_pts.p, c.boundary.p, nullptr, pt->prm.boundary_aware,
-                                 s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, nullptr};
-      q1.v_corr[0] = n_corr++;
-      q1.n_vert = 1; ++nt;
-    }
-    for (int u = nt + 1; u < 5; ++u) { q1.fstart[u] = q1.fstart[nt]; q1.rstart[u] = q1.rstart[nt]; }
-    // … and the evaluator's own sequence (split): the model ids behind the proposal's, the target -> model direction
-    StepSearchArgs& q1b = A.s1b;
-    q1b.s_corr[0] = q1b.s_corr[1] = q1b.v_corr[0] = q1b.v_corr[1] = -1;
-    int ntb = 0;
-    q1b.fstart[0] = 0; q1b.rstart[0] = 0;
+    if (st_first.K > 0) add_surface(m1, st_first, (pm && !prop_nnv) ? &corr_m : nullptr);
+    if (ev_t2m && !split) add_surface(m1, st_t2m, nullptr);
+    if (pt) add_vertex(m1, st_vert, &corr_t);
+    if (nnv_main > 0) add_vertex(m2, st_nnv, prop_nnv ? &corr_m : nullptr);
+    if (t2m_nnv && !split) add_vertex(m2, st_tnn, nullptr);
+    // the evaluator's own sequence (split): the model ids behind the proposal's, the target -> model direction, their nearest vertices
     if (split) {
-      if (st_surf.K > 0) {
-        q1b.s[q1b.n_surf] = st_surf;
-        q1b.fstart[ntb + 1] = q1b.fstart[ntb] + filter_grid_blocks(st_surf.tblocks, st_surf.ksplit);
-        q1b.rstart[ntb + 1] = q1b.rstart[ntb] + st_surf.K;
-        ++q1b.n_surf; ++ntb;
-      }
-      if (ev_t2m) {
-        q1b.s[q1b.n_surf] = st_t2m;
-        q1b.fstart[ntb + 1] = q1b.fstart[ntb] + filter_grid_blocks(st_t2m.tblocks, st_t2m.ksplit);
-        q1b.rstart[ntb + 1] = q1b.rstart[ntb] + Kt;
-        ++q1b.n_surf; ++ntb;
-      }
+      if (st_surf.K > 0) add_surface(e1, st_surf, nullptr);
+      if (ev_t2m) add_surface(e1, st_t2m, nullptr);
+      if (nnv_hi > nnv_lo) add_vertex(e2, st_ennv, nullptr);
+      if (t2m_nnv) add_vertex(e2, st_tnn, nullptr);
     }
-    for (int u = ntb + 1; u < 5; ++u) { q1b.fstart[u] = q1b.fstart[ntb]; q1b.rstart[u] = q1b.rstart[ntb]; }
-    // W6/W7: stage 2 (nearest vertices of the surface points)
-    StepSearchArgs& q2 = A.s2;
-    q2.s_corr[0] = q2.s_corr[1] = q2.v_corr[0] = q2.v_corr[1] = -1;
-    int nt2 = 0, n_corr2 = 0;
-    q2.fstart[0] = 0; q2.rstart[0] = 0;
-    if (Knnv > 0) {
-      q2.v[q2.n_vert] = st_nnv;
-      q2.fstart[nt2 + 1] = q2.fstart[nt2] + filter_grid_blocks(st_nnv.vblocks, st_nnv.ksplit);
-      q2.rstart[nt2 + 1] = q2.rstart[nt2] + Knnv;
-      if (prop_nnv) {
-        q2.corr[n_corr2] = CorrTask{pm->K, ep[im]->corr(), s.x.p, nullptr, c.target.boundary.p, nullptr, pm->prm.boundary_aware,
-                                    s.pose, c.ref.p, c.mean.p, c.tris.p, c.adj_off.p, c.adj.p, s.surf_cp.p};
-        q2.v_corr[q2.n_vert] = n_corr2++;
-      }
-      ++q2.n_vert; ++nt2;
-    }
-    if (t2m_nnv) {
-      q2.v[q2.n_vert] = st_tnn;
-      q2.fstart[nt2 + 1] = q2.fstart[nt2] + filter_grid_blocks(st_tnn.vblocks, st_tnn.ksplit);
-      q2.rstart[nt2 + 1] = q2.rstart[nt2] + Kt;
-      ++q2.n_vert; ++nt2;
-    }
-    for (int u = nt2 + 1; u < 5; ++u) { q2.fstart[u] = q2.fstart[nt2]; q2.rstart[u] = q2.rstart[nt2]; }
+    seq_close(m1); seq_close(m2); seq_close(e1); seq_close(e2);
     // W8: regressions + the likelihood's reductions
     StepRegressionArgs& g = A.reg.reg;
     g.n = w.do_post ? n_props : 0; g.r = r; g.ntiles = regression_tiles(r); g.Q = c.Q.p;
@@ -3930,32 +3915,40 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
       g.ustart[i + 1] = g.ustart[i] + g.ntiles * splits[i];
     }
     if (g.n == 1) g.ustart[2] = g.ustart[1];
-    A.reg.eval_kind = evp.kind; A.reg.eval_m2t = ev_m2t ? 1 : 0; A.reg.eval_t2m = ev_t2m ? 1 : 0;
-    A.reg.Km = Km; A.reg.d2m = s.surf_d2.p;
-    if (split) {  // (the maxima are order-independent: the proposal's ids by the main sequence, the rest by the evaluator's own)
+    // the likelihood's reductions over ALL ids (the layout finish_eval reads) …
+    WideRegArgs full{};
+    full.eval_kind = evp.kind; full.eval_m2t = ev_m2t ? 1 : 0; full.eval_t2m = ev_t2m ? 1 : 0;
+    full.Km = Km; full.d2m = s.surf_d2.p;
+    full.flags_m = eval_nnv ? c.target.boundary.p : nullptr; full.idx_m = eval_nnv ? s.surf_nnv.p : nullptr;
+    full.Kt = Kt; full.d2t = e->t2m_d2.p;
+    full.flags_t = t2m_nnv ? c.target.boundary.p : nullptr; full.idx_t = t2m_nnv ? e->t2m_nnv.p : nullptr;  // (sic: SURVEY App. D5)
+    full.n_flags = c.target.V;
+    full.mean = evp.gauss_mean; full.sigma = evp.gauss_sigma;
+    full.red_out = c.d_res.p;
+    const StepRegressionArgs reg_only = g;
+    if (!split) {                 // … behind every search of the one sequence
+      A.reg = full; A.reg.reg = reg_only;
+    } else if (concurrent) {      // … each sequence its own range (the Hausdorff maxima are order-independent: atomic maxima into one word)
+      A.reg = full; A.reg.reg = reg_only;
       A.reg.eval_m2t = Kp > 0 ? 1 : 0; A.reg.Km = Kp; A.reg.eval_t2m = 0;
-      A.regb = A.reg;
-      A.regb.reg.n = 0; A.regb.reg.ustart[0] = A.regb.reg.ustart[1] = A.regb.reg.ustart[2] = 0;
+      A.regb = full;
       A.regb.eval_m2t = Km - Kp > 0 ? 1 : 0; A.regb.Km = Km - Kp; A.regb.d2m = s.surf_d2.p + Kp;
-      A.regb.eval_t2m = ev_t2m ? 1 : 0;
+    } else {                      // … at the end of the evaluator's sequence, which runs behind the main one on the same stream
+      A.reg = full; A.reg.reg = reg_only;
+      A.reg.eval_m2t = 0; A.reg.eval_t2m = 0;
+      A.regb = full;
     }
-    A.reg.flags_m = eval_nnv ? c.target.boundary.p : nullptr; A.reg.idx_m = eval_nnv ? s.surf_nnv.p : nullptr;
-    A.reg.Kt = Kt; A.reg.d2t = e->t2m_d2.p;
-    A.reg.flags_t = t2m_nnv ? c.target.boundary.p : nullptr; A.reg.idx_t = t2m_nnv ? e->t2m_nnv.p : nullptr;  // (sic: SURVEY App. D5)
-    A.reg.n_flags = c.target.V;
-    A.reg.mean = evp.gauss_mean; A.reg.sigma = evp.gauss_sigma;
-    A.reg.red_out = c.d_res.p;
-    if (split) { A.regb.Kt = Kt; A.regb.d2t = e->t2m_d2.p; A.regb.flags_t = nullptr; A.regb.idx_t = nullptr; A.regb.flags_m = nullptr; A.regb.idx_m = nullptr;
-                 A.regb.n_flags = c.target.V; A.regb.mean = evp.gauss_mean; A.regb.sigma = evp.gauss_sigma; A.regb.red_out = c.d_res.p; }
-    plan.grid_f1b = std::max(plan.grid_f1b, q1b.fstart[ntb]);
-    plan.grid_r1b = std::max(plan.grid_r1b, q1b.rstart[ntb]);
-    if (split) plan.grid_regb = std::max(plan.grid_regb, wide_reg_blocks(A.regb));
     plan.grid_prep = std::max(plan.grid_prep, wide_prep_grid(A.prep));
-    plan.grid_f1 = std::max(plan.grid_f1, q1.fstart[nt]);
-    plan.grid_r1 = std::max(plan.grid_r1, q1.rstart[nt]);
-    plan.grid_f2 = std::max(plan.grid_f2, q2.fstart[nt2]);
-    plan.grid_r2 = std::max(plan.grid_r2, q2.rstart[nt2]);
+    plan.grid_f1 = std::max(plan.grid_f1, A.s1.fstart[m1.nt]);
+    plan.grid_r1 = std::max(plan.grid_r1, A.s1.rstart[m1.nt]);
+    plan.grid_f2 = std::max(plan.grid_f2, A.s2.fstart[m2.nt]);
+    plan.grid_r2 = std::max(plan.grid_r2, A.s2.rstart[m2.nt]);
     plan.grid_reg = std::max(plan.grid_reg, wide_reg_blocks(A.reg));
+    plan.grid_f1b = std::max(plan.grid_f1b, A.s1b.fstart[e1.nt]);
+    plan.grid_r1b = std::max(plan.grid_r1b, A.s1b.rstart[e1.nt]);
+    plan.grid_f2b = std::max(plan.grid_f2b, A.s2b.fstart[e2.nt]);
+    plan.grid_r2b = std::max(plan.grid_r2b, A.s2b.rstart[e2.nt]);
+    if (split) plan.grid_regb = std::max(plan.grid_regb, wide_reg_blocks(A.regb));
 
     // ---- W9..W12
     for (int i = 0; i < 16; ++i) c.h_res[i] = 0.0;
@@ -4024,8 +4017,8 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   launch_wide_head(S, plan, chain_args.data(), lead.wide_pinned[turn], lead.wide_device[turn].p);
   // the step's searches, regressions and reductions: on `S` — or, where the evaluator's searches are a sequence of their own, those
   // on `S` and the proposals' chain (searches of their K ids, regression, then factorisation and tails) on the second stream beside them
-  const hipStream_t Sm = any_split ? S2 : S;
-  if (any_split) {
+  const hipStream_t Sm = (any_split && concurrent) ? S2 : S;
+  if (any_split && concurrent) {
     HIP_OK(hipEventRecord(lead.ev_wide_head[turn], S));
     HIP_OK(hipStreamWaitEvent(S2, lead.ev_wide_head[turn], 0));
   }
@@ -4033,12 +4026,11 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   for (size_t p0 = 0; p0 < sum_parts.size(); p0 += kWideMaxChains)
     launch_sum_partials_many(Sm, r, (int)std::min<size_t>(kWideMaxChains, sum_parts.size() - p0), sum_parts.data() + p0, sum_splits.data() + p0);
   HIP_OK(hipEventRecord(lead.ev_wide_sum[turn], Sm));
+  // the one-workgroup kernels on the second stream: the evaluator's sequence and the next batch's chip-wide launches on `S` run beside them
+  if (Sm != S2) HIP_OK(hipStreamWaitEvent(S2, lead.ev_wide_sum[turn], 0));
   if (any_split) {
     launch_wide_eval(S, plan, lead.wide_device[turn].p);
     HIP_OK(hipEventRecord(lead.ev_wide_eval[turn], S));
-  } else {
-    // the one-workgroup kernels on the second stream: the next batch's chip-wide launches on `S` run beside them
-    HIP_OK(hipStreamWaitEvent(S2, lead.ev_wide_sum[turn], 0));
   }
   const bool any_spec = !spec_rq[0].empty() || !spec_rq[1].empty();
   const bool jacobi_spec = any_spec && !eigen_tridiag_many_supported(r);  // (ranks <= 64: the iteration reads the finished M)

@@ -538,7 +538,7 @@ struct WideInstArgs {      // W2, per chain (device memory)
 struct WidePrepArgs {      // W3, per chain (device memory)
   int T; const double* x; const int* tris; const int* order; float4* spheres;   // T = 0: no search of the new instance's surface
   int has_t2m; SurfaceTask t2m;
-  int n_cnt; int* cnt[3]; int cnt_n[3];   // candidate counters of the vertex searches (their bounds are taken by the filter)
+  int n_cnt; int* cnt[4]; int cnt_n[4];   // candidate counters of the vertex searches (their bounds are taken by the filter)
   double* zero_d; int n_zero_d;           // reduction outputs that accumulate (atomic maxima)
 };
 struct WideRegArgs {       // W8, per chain (device memory)
@@ -562,14 +562,14 @@ struct WideLaunchPlan {    // what the host has worked out for a batch: common m
   int B, N, r;
   const double* Qp; const double* ref; const double* mean;
   int grid_prep, grid_f1, grid_r1, grid_f2, grid_r2, grid_reg;
-  int grid_f1b, grid_r1b, grid_regb;  // the evaluator's own sequence (s1b, regb), if any chain of the batch has one
+  int grid_f1b, grid_r1b, grid_f2b, grid_r2b, grid_regb;  // the evaluator's own sequence (s1b, s2b, regb), if any chain of the batch has one
   bool f1_prepared;
 };
-// s1 / s2 / reg: the step's searches and reductions — or, where the evaluator's searches are heavy (the full-mesh Hausdorff distance:
-// every model vertex against the target surface, every target vertex against the model's), only what the PROPOSAL needs (its K model
-// ids, their nearest vertices, the regression), the evaluator's searches and reductions being a sequence of their own (s1b, regb) that
-// the host puts on another stream: 0.2 ms of chip-wide searches beside 0.2 ms of one-workgroup factorisation and tails
-struct WideChainArgs { WideInstArgs inst; WidePrepArgs prep; StepSearchArgs s1, s2; WideRegArgs reg; StepSearchArgs s1b; WideRegArgs regb; };
+// s1 / s2 / reg: the step's searches and reductions — or only what the PROPOSAL needs (its K model ids, their nearest vertices, the
+// regression: what the factorisation, the tails and the decomposition wait for), the evaluator's searches and reductions being a
+// sequence of their own (s1b, s2b, regb) that the host puts behind the main one — or, for the full-mesh Hausdorff distance (0.2 ms of
+// chip-wide searches), beside it on another stream
+struct WideChainArgs { WideInstArgs inst; WidePrepArgs prep; StepSearchArgs s1, s2; WideRegArgs reg; StepSearchArgs s1b, s2b; WideRegArgs regb; };
 // copies the chains' records into `pinned` (wide_batch_bytes(B)); launches the copy to `device`, the instances and W3 on `st`
 void launch_wide_head(hipStream_t st, const WideLaunchPlan& plan, const WideChainArgs* chains, void* pinned, void* device);
 // W4..W8 of the records in `device` (launch_wide_head): the main sequence, the evaluator's own

@@ -323,10 +323,10 @@ void launch_wide_propose(hipStream_t st, int r, const WideProposeArgs& a) {
 }
 
 size_t wide_batch_bytes(int B) {
-  return up16(sizeof(WideInstArgs) * B) + up16(sizeof(WidePrepArgs) * B) + 3 * up16(sizeof(StepSearchArgs) * B) + 2 * up16(sizeof(WideRegArgs) * B);
+  return up16(sizeof(WideInstArgs) * B) + up16(sizeof(WidePrepArgs) * B) + 4 * up16(sizeof(StepSearchArgs) * B) + 2 * up16(sizeof(WideRegArgs) * B);
 }
 namespace {
-struct WideOffsets { size_t prep, s1, s2, reg, s1b, regb, total; };
+struct WideOffsets { size_t prep, s1, s2, reg, s1b, s2b, regb, total; };
 WideOffsets wide_offsets(int B) {
   WideOffsets o;
   o.prep = up16(sizeof(WideInstArgs) * B);
@@ -334,7 +334,8 @@ WideOffsets wide_offsets(int B) {
   o.s2 = o.s1 + up16(sizeof(StepSearchArgs) * B);
   o.reg = o.s2 + up16(sizeof(StepSearchArgs) * B);
   o.s1b = o.reg + up16(sizeof(WideRegArgs) * B);
-  o.regb = o.s1b + up16(sizeof(StepSearchArgs) * B);
+  o.s2b = o.s1b + up16(sizeof(StepSearchArgs) * B);
+  o.regb = o.s2b + up16(sizeof(StepSearchArgs) * B);
   o.total = o.regb + up16(sizeof(WideRegArgs) * B);
   return o;
 }
@@ -353,6 +354,7 @@ void launch_wide_head(hipStream_t st, const WideLaunchPlan& plan, const WideChai
     ((StepSearchArgs*)(h + o.s2))[b] = chains[b].s2;
     ((WideRegArgs*)(h + o.reg))[b] = chains[b].reg;
     ((StepSearchArgs*)(h + o.s1b))[b] = chains[b].s1b;
+    ((StepSearchArgs*)(h + o.s2b))[b] = chains[b].s2b;
     ((WideRegArgs*)(h + o.regb))[b] = chains[b].regb;
   }
   const int n16 = (int)(o.total / 16);
@@ -407,6 +409,7 @@ void launch_wide_eval(hipStream_t st, const WideLaunchPlan& plan, void* device) 
   const WideOffsets o = wide_offsets(B);
   char* d = (char*)device;
   launch_wide_searches(st, B, plan.grid_f1b, plan.grid_r1b, plan.f1_prepared, (const StepSearchArgs*)(d + o.s1b), KID_SURFACE_FILTER, KID_SURFACE_RESOLVE);
+  launch_wide_searches(st, B, plan.grid_f2b, plan.grid_r2b, true, (const StepSearchArgs*)(d + o.s2b), KID_VERTEX_FILTER, KID_VERTEX_RESOLVE);
   if (plan.grid_regb > 0) {
     ProfScope _ps(st, KID_REDUCE);
     hipLaunchKernelGGL(k_wide_regression, dim3(plan.grid_regb, B), dim3(kWideRegBlock), 0, st, (const WideRegArgs*)(d + o.regb));
