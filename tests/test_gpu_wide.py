@@ -188,3 +188,73 @@ def test_sampler_switch_at_large_rank_refactors_memoised_posteriors(pkg, oracle)
     assert np.abs(again - first).max() <= 1e-12 * np.abs(first[10:]).max()
     assert u.shape == (r,)
     close_all(sets)
+
+
+def test_two_direction_mixture_on_an_open_target_matches_oracle_chain(pkg, oracle, femur50):
+    """The femur mixture (TWO ICP proposals, ModelSampling + TargetSampling, + shape walk: apps/femur/IcpProposalRegistration.scala:70-72)
+    against a target WITH boundary: two posteriors per state through the wide step (two regressions, factorisations, four tails, both
+    decompositions of the warm-started iteration at rank 51), decision for decision against the oracle's chain."""
+    import sys
+    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    from test_gpu_chain import oracle_chain_config
+    from conftest import open_patch_target
+    model, target = femur50
+    pts, cells = open_patch_target(target)
+    tgt = pkg.data.TriangleMesh(pts, cells)
+    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(pts, cells)
+    setup = pkg.femur_icp_proposal_registration(model, tgt, fused=2)
+    n_steps, seed = 60, 77
+    theta0 = pkg.initial_parameters(model)
+    acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), theta0, seed, n_steps)
+    ctx = pkg.IcpContext(model, tgt, device=0)
+    chain = pkg.SamplingRegistration(ctx, setup, theta0, seed)
+    rec = chain.run(n_steps)
+    assert np.array_equal(rec[:, 1].astype(np.uint8), acc_o), "accept/reject sequences differ"
+    assert np.array_equal(rec[:, 2].astype(np.int32), comp_o), "mixture components differ"
+    assert acc_o.sum() > 5 and {0, 1, 2} <= set(comp_o.tolist())
+    scale = np.abs(states_o[:, 10:]).max()
+    assert np.abs(rec[:, 14:] - states_o[:, 10:]).max() <= 1e-5 * scale
+    assert np.abs(rec[:, 3] - logp_o).max() <= 1e-6 * np.abs(logp_o).max()
+    p = ctx.step_paths()
+    assert p["wide"] == n_steps and p["merged"] == 0 and p["per_stage"] == 0, p
+    assert all(v == 0 for v in ctx.runtime_stats().values())
+    chain.close()
+    ctx.close()
+
+
+_GROUPS_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import __graft_entry__ as graft
+pkg = graft.load_package()
+model = pkg.data.synthetic_face_model(grid=41, rank=100)
+targets = [pkg.data.synthetic_partial_target(model, n_remove=90, seed=7 + t) for t in range(2)]
+ctxs, chains = [], []
+for t in range(2):
+    setup = pkg.bfm_fitting_partial(model, targets[t], evaluator="collective", fused=2)
+    for k in range(3):
+        cx = pkg.IcpContext(model, targets[t], device=0); ctxs.append(cx)
+        chains.append(pkg.SamplingRegistration(cx, setup, pkg.random_initial_parameters(model, k), seed=40 + 10 * t + k))
+rec = pkg.run_chains_batched(chains, {n})
+np.savez({out!r}, rec=np.stack(rec), wide=np.array([c.step_paths()["wide"] for c in ctxs]), stats=np.array(list(pkg._native.runtime_stats().values())))
+[c.close() for c in chains]; [c.close() for c in ctxs]
+"""
+
+
+def test_wide_chains_in_groups_and_across_targets_give_the_same_records(tmp_path):
+    """Chains of TWO targets in one submission, and the same chains as two groups in flight on one launch context (tickets of the ring:
+    pinned records, events, eigen streams per group): identical records either way, every step through the wide step."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = {}
+    for groups in ("1", "2"):
+        path = str(tmp_path / f"g{groups}.npz")
+        subprocess.run([sys.executable, "-c", _GROUPS_SCRIPT.format(root=ROOT, n=40, out=path)], check=True,
+                       env={**os.environ, "ICP_LOCKSTEP_GROUPS": groups}, timeout=900)
+        out[groups] = np.load(path)
+    assert np.array_equal(out["1"]["rec"], out["2"]["rec"])
+    assert np.all(out["1"]["wide"] == 40) and np.all(out["2"]["wide"] == 40)
+    assert np.all(out["1"]["stats"] == 0) and np.all(out["2"]["stats"] == 0)
+    assert 0.1 < out["1"]["rec"][:, :, 1].mean() < 0.99
