@@ -4028,12 +4028,12 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   HIP_OK(hipEventRecord(lead.ev_wide_sum[turn], Sm));
   // the one-workgroup kernels on the second stream: the evaluator's sequence and the next batch's chip-wide launches on `S` run beside them
   if (Sm != S2) HIP_OK(hipStreamWaitEvent(S2, lead.ev_wide_sum[turn], 0));
-  if (any_split) {
-    launch_wide_eval(S, plan, lead.wide_device[turn].p);
-    HIP_OK(hipEventRecord(lead.ev_wide_eval[turn], S));
-  }
   const bool any_spec = !spec_rq[0].empty() || !spec_rq[1].empty();
   const bool jacobi_spec = any_spec && !eigen_tridiag_many_supported(r);  // (ranks <= 64: the iteration reads the finished M)
+  // The decompositions and factorisations of this step — the critical path — are handed to the device BEFORE the evaluator's own
+  // sequence (chip-wide launches on `S`, which they then run beside), the factorisations in one launch (two took 200 + 880 µs in a
+  // 30-chain step: the second one started among the evaluator's searches).  configs[4], 30 chains a step: 11.2k -> 12.6k it/s with
+  // the tridiagonalisation's load prologue (icp_tridiag.hpp: tridiag_kernel_body), tools/r4_trace_c4.sh.
   if (any_spec && !jacobi_spec)
     for (int fl = 0; fl < 2; ++fl) {
       if (spec_rq[fl].empty()) continue;
@@ -4042,8 +4042,15 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
       HIP_OK(hipStreamWaitEvent(Es[fl], lead.ev_wide_sum[turn], 0));
       launch_posterior_eigen_tridiag_many(Es[fl], r, (int)spec_rq[fl].size(), spec_rq[fl].data(), spec_parts[fl].data());
     }
-  for (size_t p0 = 0; p0 < factors.size(); p0 += kWideMaxChains)
-    launch_posterior_factor(S2, r, (int)std::min<size_t>(kWideMaxChains, factors.size() - p0), factors.data() + p0);
+  {
+    const size_t fmax = (size_t)posterior_factor_max();
+    for (size_t p0 = 0; p0 < factors.size(); p0 += fmax)
+      launch_posterior_factor(S2, r, (int)std::min(fmax, factors.size() - p0), factors.data() + p0);
+  }
+  if (any_split) {
+    launch_wide_eval(S, plan, lead.wide_device[turn].p);
+    HIP_OK(hipEventRecord(lead.ev_wide_eval[turn], S));
+  }
   if (!root_entries.empty()) {  // "decomposed" as soon as the factorisation is through: an event behind it stands for the basis
     BatchEventSlot& done = next_batch_event(elead.device);
     HIP_OK(hipEventRecord(done.ev, S2));

@@ -200,6 +200,7 @@ void launch_regression(hipStream_t st, int K, int r, const double* Q, const Corr
 struct PosteriorFactorIO { const double* Mpart; int splits; double* M; double* alpha; int* status; double* scratch /* (r+1)·r, large ranks only */;
                            double* Lout = nullptr; double* Sout = nullptr; /* optional: the factor L (r × r, zero upper triangle) and 1/diag(L) */ };
 void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io);
+int posterior_factor_max();  // posteriors per launch
 // Σ of one posterior's split-K partials into its first partial, on many CUs (what the factor kernels do themselves otherwise; with
 // it done, they take splits = 1), and M = I + that sum, both triangles, from the summed partial — the start of a decomposition
 // that does not wait for the factorisation (icp_chain_eval_step)

@@ -495,22 +495,43 @@ __device__ __forceinline__ void tridiag_kernel_body(const TridiagIO& a) {
   const int n = a.n, off = LD - n;
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  auto entry = [&](int i, int j) {  // N_ij, by index
-    return 0.5 * (a.M[(size_t)j * n + i] + a.M[(size_t)i * n + j]) / (a.sqrt_lambda[i] * a.sqrt_lambda[j]);
-  };
-  double A[SI][NT], col0[SI];
+  // N_ij = ½(M_ij + M_ji) / (sqrt_lambda_i · sqrt_lambda_j).  M is EXACTLY symmetric — every kernel that assembles it writes both
+  // triangles from the lower triangle of the summed partials (k_assemble_many, k_assemble_posterior_matrix, the factor kernels) — so
+  // ½(M_ij + M_ji) is M_ji bit for bit, and one read does: row j, the lanes along i (coalesced; the mirrored read M[i·n + j] put every
+  // lane on a cache line of its own).  All reads are issued BEFORE the first value is used: left to itself the compiler waited for
+  // each entry's loads in turn — 105 round trips to L2 one after the other, 0.1 ms of the launch alone and three times that beside
+  // the evaluator's chip-wide searches (a wide step's second decomposition launch: 810 µs instead of 455, tools/r4_trace_c4.sh).
+  double A[SI][NT], col0[SI], sli[SI], slj[NT];
 #pragma unroll
   for (int s = 0; s < SI; ++s) {
     const int i = l + 64 * s - off;
-    col0[s] = i >= 0 ? entry(i, 0) : 0.0;
+    sli[s] = i >= 0 ? a.sqrt_lambda[i] : 1.0;
+    col0[s] = i >= 0 ? a.M[i] : 0.0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int j = w + NW * (t + TOFF) - off;
-      A[s][t] = i >= 0 && j >= 0 ? entry(i, j) : 0.0;
+      A[s][t] = i >= 0 && j >= 0 ? a.M[(size_t)j * n + i] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = w + NW * (t + TOFF) - off;
+    slj[t] = j >= 0 ? a.sqrt_lambda[j] : 1.0;
+  }
+  const double sl0 = a.sqrt_lambda[0], m00 = a.M[0];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < SI; ++s) {
+    const int i = l + 64 * s - off;
+    col0[s] = i >= 0 ? col0[s] / (sli[s] * sl0) : 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = w + NW * (t + TOFF) - off;
+      A[s][t] = i >= 0 && j >= 0 ? A[s][t] / (sli[s] * slj[t]) : 0.0;
       if (a.Nout && i >= 0 && j >= 0) a.Nout[(size_t)j * n + i] = A[s][t];
     }
   }
-  const double d0 = entry(0, 0);
+  const double d0 = m00 / (sl0 * sl0);
   EIG_STAMP(0);
   tridiagonalise<NW, SI, NT, TOFF>(a, A, col0, d0, lds);
   EIG_STAMP(1);
@@ -962,6 +983,8 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1)
 struct TriSolveMany { TriSolveIO p[kTriMany]; };
 template <int SI>
 __global__ void __launch_bounds__(256) k_tri_solve_many(TriSolveMany m) {
+  // (no s_setprio here: raised to 3 for the critical path's sake, beside the evaluator's searches of a 30-chain wide step the device
+  // hung — measured once, not understood, not repeated)
   const TriSolveIO a = m.p[blockIdx.y];
   tri_solve_body<SI>(a);
 }

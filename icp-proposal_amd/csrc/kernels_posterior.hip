@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64) k_regression_mfma(int K, int kchunk, int r
   regression_tile(blockIdx.x, blockIdx.y, K, kchunk, r, Q, cb, wt, kappa, Mpart);
 }
 
-constexpr int kFactorMax = kWideMaxChains;  // posteriors per launch: both ICP directions of one or two states — or one per chain of a wide step
+constexpr int kFactorMax = 2 * kWideMaxChains;  // posteriors per launch: both ICP directions of one or two states — or one per chain of a wide step
 struct FactorArgs {
   const double* Mpart[kFactorMax];
   int splits[kFactorMax];
@@ -2105,6 +2105,8 @@ void launch_sum_partials_many(hipStream_t st, int r, int n, double* const* Mpart
 void launch_assemble_posterior_matrix(hipStream_t st, int r, const double* Mpart_summed, double* M) {
   hipLaunchKernelGGL(k_assemble_posterior_matrix, dim3(cdiv(r * r, 256)), dim3(256), 0, st, r, Mpart_summed, M);
 }
+
+int posterior_factor_max() { return kFactorMax; }
 
 void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorFactorIO* io) {
   FactorArgs fa{};
