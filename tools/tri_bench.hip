@@ -34,8 +34,45 @@ static void host_jacobi(int n, std::vector<double> a, std::vector<double>& w, st
   for (int i = 0; i < n; ++i) w[i] = a[(size_t)i * n + i];
 }
 
+// A chip-wide launch to run BESIDE the decomposition (argv[2]): what of a busy chip slows the one-workgroup kernels down?
+// 1 = multiply-adds in registers, 2 = loads that miss the L1 (a 64 MiB buffer, L2 / fabric), 3 = LDS traffic, 4 = stores,
+// 5 = f64 matrix instructions; every workgroup runs until `until` (s_memrealtime, 100 MHz)
+__global__ void __launch_bounds__(256) k_hog(int kind, unsigned long long ticks, double* buf, size_t n, double* sink) {
+  __shared__ double lds[4096];
+  const unsigned long long until = __builtin_amdgcn_s_memrealtime() + ticks;
+  const int tid = threadIdx.x;
+  double x = tid * 1e-3, y = 1.0;
+  size_t pos = ((size_t)blockIdx.x * 256 + tid) * 8 % n;
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 acc = {0, 0, 0, 0};
+  lds[tid] = x;
+  __syncthreads();
+  while (__builtin_amdgcn_s_memrealtime() < until) {
+    if (kind == 1) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) { x = fma(x, 1.0000001, y); y = fma(y, 0.9999999, x); }
+    } else if (kind == 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { x += buf[pos]; pos = (pos + 256 * 1031) % n; }
+    } else if (kind == 3) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) { x += lds[(tid * 17 + i * 33) & 4095]; }
+      lds[(tid + 1) & 4095] = x;
+    } else if (kind == 4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { buf[pos] = x; pos = (pos + 256 * 1031) % n; }
+    } else if (kind == 5) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc, 0, 0, 0);
+    }
+  }
+  if (x + y + acc[0] == 12345.678) sink[0] = x;
+}
+
 int main(int argc, char** argv) {
   const int r = argc > 1 ? atoi(argv[1]) : 200;
+  const int hog = argc > 2 ? atoi(argv[2]) : 0;
+  const int hog_blocks = argc > 3 ? atoi(argv[3]) : 2048;
   std::mt19937_64 rng(7);
   std::normal_distribution<double> nd;
   const int K = 6 * r;
@@ -102,6 +139,23 @@ int main(int argc, char** argv) {
   long long s[64]; hipMemcpyFromSymbol(s, HIP_SYMBOL(icp::g_eigen_stamps), sizeof(s));
   printf("%.1f us per decomposition (cold) | stamps: reduction %.1f | solve: setup %.1f multisection %.1f vectors %.1f back-transformation %.1f output %.1f\n", ms * 1000 / reps,
          (s[1] - s[0]) * 0.01, (s[9] - s[8]) * 0.01, (s[10] - s[9]) * 0.01, (s[11] - s[10]) * 0.01, (s[12] - s[11]) * 0.01, (s[13] - s[12]) * 0.01);
+  if (hog) {
+    double *hbuf, *sink; const size_t hn = (size_t)8 << 20;
+    CK(hipMalloc(&hbuf, 8 * hn)); CK(hipMemset(hbuf, 0, 8 * hn)); CK(hipMalloc(&sink, 64));
+    hipStream_t st2; CK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipDeviceSynchronize());
+      hipEventRecord(a, st);
+      icp::launch_posterior_eigen(st, r, dM, dsl, nullptr, dV, dVt, dS, dwork, dstat + 1);
+      hipEventRecord(b, st);
+      hipLaunchKernelGGL(k_hog, dim3(hog_blocks), dim3(256), 0, st2, hog, 150000ull /* 1.5 ms */, hbuf, hn, sink);
+      hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+      CK(hipDeviceSynchronize());
+      hipMemcpyFromSymbol(s, HIP_SYMBOL(icp::g_eigen_stamps), sizeof(s));
+      printf("beside hog %d (%d workgroups): %.1f us | reduction %.1f | solve: setup %.1f multisection %.1f vectors %.1f back-transformation %.1f output %.1f\n", hog, hog_blocks,
+             ms * 1000, (s[1] - s[0]) * 0.01, (s[9] - s[8]) * 0.01, (s[10] - s[9]) * 0.01, (s[11] - s[10]) * 0.01, (s[12] - s[11]) * 0.01, (s[13] - s[12]) * 0.01);
+    }
+  }
   if (r <= 64) {  // the speculative form of the same decomposition: split-K partials, ready word raised, cancel word in pinned memory
     const int n1 = r + 1, SP = 13;
     std::vector<double> Mp((size_t)SP * n1 * n1, 0.0);
