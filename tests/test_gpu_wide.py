@@ -118,12 +118,12 @@ def test_wide_step_pose_move_then_icp_proposal(pkg, oracle):
     close_all(sets)
 
 
-@pytest.mark.parametrize("rank,kind", [(40, "collective"), (100, "hausdorff")])
-def test_wide_step_batched_equals_one_by_one(pkg, oracle, rank, kind):
+@pytest.mark.parametrize("rank,kind,B", [(40, "collective", 5), (100, "hausdorff", 5), (100, "collective", 18)])
+def test_wide_step_batched_equals_one_by_one(pkg, oracle, rank, kind, B):
     """B chains in ONE launch sequence (icp_chain_step_batched -> the wide step: instance synthesis from one pass over the basis,
     the searches, factorisations and decompositions of all chains side by side) against the same chains stepped one by one on
-    contexts of their own: every number identical, over several steps with ICP, random-walk and pose proposals mixed in the batch."""
-    B = 5
+    contexts of their own: every number identical, over several steps with ICP, random-walk and pose proposals mixed in the batch.
+    (18 chains: more than the 16 records one launch of the proposals, decompositions, partial sums and results carries.)"""
     model, target, sets, om, ot, pp, ep = build(pkg, oracle, rank, kind, n_ctx=2 * B)
     batch, alone = sets[:B], sets[B:]
     r = model.rank
