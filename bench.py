@@ -670,6 +670,46 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
     n_items = len(items)
     assert all(r is not None and r.shape == (args.steps, 14 + model.rank) for r in recs), "a work item's records are missing"
     multi_gpu = rank_report(dist, torch, rank, world, local_rank, stats["chain_ms"], stats["gather_ms"])
+    roofline = None
+    if rank == 0 and world == 1:
+        # ---- outside the timed region: the launches of one submission's steps under HIP events (the lead context carries them)
+        try:
+            setup0 = make_setup(model, targets[0])
+            nB = max(1, min(args.chains, 10))
+            pctx = [pkg.IcpContext(model, targets[0], device=local_rank) for _ in range(nB)]
+            pch = [pkg.SamplingRegistration(pctx[i], setup0, pkg.random_initial_parameters(model, i), seed=1024 + i) for i in range(nB)]
+            pkg.run_chains_batched(pch, 30, want_records=False)
+            n_p = 60
+            pctx[0].profile_start(max_launches=200 * n_p + 4096)
+            t1 = time.perf_counter()
+            pkg.run_chains_batched(pch, n_p, want_records=False)
+            pdt = time.perf_counter() - t1
+            raw = pctx[0].profile_stop()
+            pst = {k: v for k, v in raw.items() if not k.startswith("count.") and not k.endswith(".device_wait")}
+            if pst:
+                dominant = max(pst, key=lambda k: pst[k]["total_ms"])
+                k = pst[dominant]
+                per_launch = nB * n_p / max(k["calls"], 1)
+                alg1 = kernel_algorithmic_bytes(dominant, model, targets[0], setup0)
+                has_boundary = bool(pkg.data.boundary_vertex_flags(targets[0]).any())
+                bytes_step, _ = algorithmic_step(model, targets[0], setup0, has_boundary)
+                lat = latency_floor_model(model, setup0, 0.55, 0.7, bytes_step, 0.0)
+                lat["measured_us_per_round"] = 1e6 * pdt / n_p
+                lat["note"] = "floor of ONE chain's step; a round steps %d chains side by side in one launch sequence" % nB
+                lat["frac"] = lat["floor_us_per_step"] / lat["measured_us_per_round"]
+                roofline = {"bound": "latency" if dominant.startswith(SINGLE_WORKGROUP) else "hbm", "kernel": dominant, "avg_launch_us": k["avg_us"],
+                            "launches": k["calls"], "chains_per_launch": per_launch,
+                            "algorithmic_bytes": None if alg1 is None else alg1 * per_launch, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": None, "traffic": None, "latency": lat,
+                            "sample": "%d chains of target 0 in one submission per step, %d steps (%.0f it/s in this stretch)" % (nB, n_p, nB * n_p / pdt),
+                            "kernel_us_per_round": {name: round(v["total_ms"] * 1e3 / n_p, 2) for name, v in pst.items()}}
+                if alg1 is not None:
+                    roofline["achieved"] = alg1 * per_launch / (k["avg_us"] * 1e-6) / 1e9
+                    roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+            for c in pch: c.close()
+            for c in pctx: c.close()
+        except Exception as e:  # (the leg is a report, not the measurement)
+            roofline = {"error": str(e)[:300]}
     if rank == 0:
         best = max(range(n_items), key=lambda k: recs[k][:, 3].max())
         line = {"metric": METRIC, "value": n_items * args.steps / dt, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
@@ -684,7 +724,7 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
                            "gather_ms_per_rank": [round(p[2], 3) for p in per_rank], "chain_ms_per_rank": [round(p[3], 1) for p in per_rank],
                            "chains_per_launch": cpl if cpl > 0 else max(1, min(32, (3 if args.steps >= 200 else 1) * args.chains)), "best_item": [int(v) for v in items[best]],
                            "accepted": int(sum(r[:, 1].sum() for r in recs))},
-                "roofline": None, "cpu_baseline": None, "multi_gpu": multi_gpu, "runtime_stats": pkg._native.runtime_stats()}
+                "roofline": roofline, "cpu_baseline": None, "multi_gpu": multi_gpu, "runtime_stats": pkg._native.runtime_stats()}
         print(json.dumps(line))
 
 
@@ -701,7 +741,7 @@ def latency_floor_model(model, setup, icp_share, accept_share, bytes_step, flops
       accepted : + the KL basis of the new state, which the next proposal draws from: one boundary + the iteration's dependent
                  chain: sweeps x (n - 1) rounds x (barrier ~50 clk + LDS round trip ~77 clk + the rotation's ~14 dependent f64
                  operations at 6-7.5 clk) (ranks <= 64); Householder: (n - 2) steps x (barrier + LDS round trip + wave reduction
-                 + a dependent pass of n/waves multiply-adds) (ranks > 64)
+                 + the step's multiply-adds on the one workgroup that holds the matrix in registers) (ranks > 64)
     plus the step's algorithmic bytes and flops at the peaks (sub-microsecond at femur size)."""
     r = model.rank
     stream_us = max(bytes_step / (HBM_PEAK_GBS * 1e9), flops_step / (F32_VECTOR_TFLOPS * 1e12)) * 1e6
@@ -711,7 +751,11 @@ def latency_floor_model(model, setup, icp_share, accept_share, bytes_step, flops
         round_clk = 50 + 77 + 14 * 7
         eig = 2 * (((r + 1) & ~1) - 1) * round_clk / (SHADER_GHZ * 1e3)
     else:
-        step_clk = 50 + 77 + 60 + 7.5 * max(r // 8, 8)
+        # the matrix lives in the registers of ONE workgroup (8 waves, two per SIMD): ceil(r/64)·ceil(r/8) entries per lane, three
+        # f64 multiply-adds each per step (rank-2 update + the next product) at 4 clk per wave instruction, two waves sharing a SIMD,
+        # the live part of the matrix shrinking to nothing over the steps (a third on average)
+        entries = ((r + 63) // 64) * ((r + 7) // 8)
+        step_clk = 50 + 77 + 60 + entries * 3 * 4 * 2 / 3.0
         eig = (r - 2) * step_clk / (SHADER_GHZ * 1e3) + LAUNCH_BOUNDARY_US  # (reduction + the solve launch behind it)
     accepted = rejected + LAUNCH_BOUNDARY_US + eig
     a = accept_share * icp_share   # share of steps whose accepted proposal needs a new KL basis
