@@ -4104,6 +4104,11 @@ bool wide_record(icp_step_ticket& t, int b, double* log_value_prop, double* fwd,
     icp_proposal* p = it.props[generator];
     PosteriorEntry& g = *ec[generator];
     int st = p->h_eig[g.status_off / 3];
+    {  // (test-hooks build only: the n-th such look pretends the decomposition reported 2 — tests/test_gpu_wide.py)
+      static const int pretend_at = dev_env("ICP_TEST_WIDE_EIGEN_STATUS") ? std::atoi(dev_env("ICP_TEST_WIDE_EIGEN_STATUS")) : 0;
+      static std::atomic<int> looks{0};
+      if (pretend_at > 0 && st == 0 && ++looks == pretend_at) st = 2;
+    }
     if (st != 0) {
       // the multisection could not separate the spectrum (or the iteration did not converge): the per-stage decomposition, which
       // has the Jacobi fall-back in its launch sequence, takes over, and the step is done again from the basis it leaves

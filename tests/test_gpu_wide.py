@@ -258,3 +258,41 @@ def test_wide_chains_in_groups_and_across_targets_give_the_same_records(tmp_path
     assert np.all(out["1"]["wide"] == 40) and np.all(out["2"]["wide"] == 40)
     assert np.all(out["1"]["stats"] == 0) and np.all(out["2"]["stats"] == 0)
     assert 0.1 < out["1"]["rec"][:, :, 1].mean() < 0.99
+
+
+_REDO_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import __graft_entry__ as graft
+pkg = graft.load_package()
+model = pkg.data.synthetic_face_model(grid=41, rank=100)
+target = pkg.data.synthetic_partial_target(model, n_remove=90, seed=7)
+setup = pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2)
+ctx = pkg.IcpContext(model, target, device=0)
+chain = pkg.SamplingRegistration(ctx, setup, pkg.initial_parameters(model), seed=11)
+rec = chain.run(40)
+np.savez({out!r}, rec=rec, wide=ctx.step_paths()["wide"], redos=ctx.runtime_stats()["step_redos"])
+chain.close(); ctx.close()
+"""
+
+
+def test_wide_step_is_done_again_when_its_basis_reports_trouble(tmp_path):
+    """A wide step draws from a decomposition that was started ahead; its status is looked at when the step's results arrive.  A status
+    other than 0 (a spectrum the multisection could not separate) hands that posterior to the per-stage decomposition and repeats the
+    step.  The test-hooks build pretends status 2 at the third such look: the chain's records must be those of the undisturbed run,
+    and the repeat must have been counted."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    hooks = os.path.join(ROOT, "icp-proposal_amd", "libicp_proposal_amd_testhooks.so")
+    assert os.path.exists(hooks), "build the test-hooks library (python -c 'import __graft_entry__ as g; g.build()')"
+    out = {}
+    for tag, env in (("plain", {"ICP_LIBRARY_PATH": hooks}), ("disturbed", {"ICP_LIBRARY_PATH": hooks, "ICP_TEST_WIDE_EIGEN_STATUS": "3"})):
+        path = str(tmp_path / (tag + ".npz"))
+        subprocess.run([sys.executable, "-c", _REDO_SCRIPT.format(root=ROOT, out=path)], check=True, env={**os.environ, **env}, timeout=600)
+        out[tag] = np.load(path)
+    assert out["plain"]["redos"] == 0 and out["disturbed"]["redos"] >= 1
+    assert out["plain"]["wide"] >= 40 and out["disturbed"]["wide"] >= 40
+    assert np.array_equal(out["plain"]["rec"], out["disturbed"]["rec"])
+    assert 0.1 < out["plain"]["rec"][:, 1].mean() < 0.99
