@@ -291,7 +291,7 @@ def main():
     ap.add_argument("--chains", type=int, default=10, help="--config 4: random-init chains per target")
     ap.add_argument("--face-grid", type=int, default=0, help="--config 3/4: side of the synthetic face grid (0 = 169: N = 28,561)")
     ap.add_argument("--face-rank", type=int, default=0, help="--config 3/4: rank of the synthetic face model (0 = 200)")
-    ap.add_argument("--extra-configs", type=str, default="2,3",
+    ap.add_argument("--extra-configs", type=str, default="2,3,4",
                     help="default run (N = 1, config 1): short legs of these other configurations after the timed region, reported as "
                          "`extra_configs` (not the headline; '' = none)")
     ap.add_argument("--profile-steps", type=int, default=300, help="steps of the HIP-event roofline leg (0 = skip)")
@@ -452,6 +452,12 @@ def main():
         # ---- not the headline: short legs of the other single-GPU configurations, so that the driver's default run times them too
         line["extra_configs"] = {}
         for cfg_i in [int(x) for x in args.extra_configs.split(",") if x.strip()]:
+            if cfg_i == 4:
+                try:
+                    line["extra_configs"]["config4"] = config4_leg(pkg, args, local_rank)
+                except Exception as e:
+                    line["extra_configs"]["config4"] = {"error": str(e)[:200]}
+                continue
             try:
                 line["extra_configs"]["config%d" % cfg_i] = extra_config_leg(pkg, args, cfg_i, local_rank)
             except Exception as e:
@@ -540,6 +546,29 @@ def main():
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def config4_leg(pkg, args, device):
+    """configs[4] in small: 3 targets x 10 random-init chains through sharding.run_batch on this GPU, with chains of 50 steps (the size
+    round 3's 1,320-1,450 it/s was quoted on) and of 300; whole job each (contexts, chains, steps, records).  `--config 4` runs the
+    full 10 x 10 job."""
+    model = face_model(pkg, args)
+    targets = [pkg.data.synthetic_partial_target(model, seed=100 + t) for t in range(3)]
+    make_setup = lambda m, t: pkg.bfm_fitting_partial(m, t, evaluator="collective", fused=args.fused)
+    pkg.sharding.run_batch(pkg, model, targets[:1], n_chains=1, n_steps=5, make_setup=make_setup, dist=None, device_index=device)
+    out = {"unit": "iterations/s", "targets": 3, "chains": 10,
+           "workload": "BASELINE.json configs[4] in small: 3 targets x 10 random-init chains on the BFM-sized stand-in (N=%d, rank %d; 0.4 pose + "
+                       "0.55 ICP + 0.05 random walk, collective boundary-aware evaluator), whole job on one GPU" % (model.n_points, model.rank)}
+    for n_steps in (50, 300):
+        t0 = time.perf_counter()
+        items, recs, stats = pkg.sharding.run_batch(pkg, model, targets, n_chains=10, n_steps=n_steps, make_setup=make_setup, dist=None,
+                                                    device_index=device, return_stats=True)
+        dt = time.perf_counter() - t0
+        out["steps_%d" % n_steps] = {"value": len(items) * n_steps / dt, "job_s": dt, "items": len(items), "accepted": int(sum(r[:, 1].sum() for r in recs)),
+                                     "contexts_built": int(stats["contexts_built"])}
+    out["value"] = out["steps_300"]["value"]
+    out["runtime_stats"] = pkg._native.runtime_stats()
+    return out
 
 
 def extra_config_leg(pkg, args, cfg_i, device, sampler="eigen"):

@@ -702,6 +702,109 @@ struct BatchTiming {  // ICP_HOST_TIMING: where a batched step's host time goes 
 };
 BatchTiming g_batch_timing;
 
+// Streams and pinned blocks of destroyed contexts, proposals and evaluators are kept for the next ones.  A batch registration makes
+// its contexts and chains anew for every job (and chains for every target): hipStreamCreate* takes 3.3 ms, hipStreamDestroy 2.3 ms,
+// hipHostFree 0.2 ms — 4 + 8 streams and a dozen pinned blocks per context, a third of the wall time of a 10 targets x 10 chains x 50
+// steps job (rocprofv3 --hip-runtime-trace, tools/r4_setup_trace.sh).  Streams are kept per device and priority class (a stream keeps
+// the hardware queue it was created on), pinned blocks by size (handed out zeroed); icp_release_cached_models() empties both,
+// ICP_NO_POOL=1 switches the pools off.
+struct ResourcePool {
+  std::mutex mu;
+  static constexpr int kDevices = 16, kStreamsPerClass = 96;
+  std::vector<hipStream_t> streams[kDevices][2];      // [device][0 = default priority, 1 = greatest]
+  std::map<hipStream_t, int> stream_class;            // every pooled or handed-out stream: device * 2 + class
+  std::multimap<size_t, void*> pinned;                // free blocks by size
+  std::map<void*, size_t> pinned_size;                // every block of the pool, handed out or free
+  size_t pinned_free_bytes = 0;
+  static constexpr size_t kPinnedCap = (size_t)64 << 20;
+  bool on = std::getenv("ICP_NO_POOL") == nullptr;
+};
+ResourcePool g_pool;
+
+hipStream_t take_stream(int device, bool greatest, int priority) {
+  if (device >= 0 && device < ResourcePool::kDevices) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto& v = g_pool.streams[device][greatest ? 1 : 0];
+    if (g_pool.on && !v.empty()) {
+      hipStream_t s = v.back();
+      v.pop_back();
+      return s;
+    }
+  }
+  hipStream_t s = nullptr;
+  HIP_OK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
+  if (device >= 0 && device < ResourcePool::kDevices) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    g_pool.stream_class[s] = device * 2 + (greatest ? 1 : 0);
+  }
+  return s;
+}
+// (the caller has synchronised with the stream's work or does not care: the stream is synchronised here)
+void give_stream(hipStream_t s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s);
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.stream_class.find(s);
+    if (g_pool.on && it != g_pool.stream_class.end()) {
+      auto& v = g_pool.streams[it->second / 2][it->second & 1];
+      if ((int)v.size() < ResourcePool::kStreamsPerClass) { v.push_back(s); return; }
+    }
+    if (it != g_pool.stream_class.end()) g_pool.stream_class.erase(it);
+  }
+  (void)hipStreamDestroy(s);
+}
+void pinned_alloc(void** out, size_t bytes) {
+  const size_t size = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.pinned.find(size);
+    if (g_pool.on && it != g_pool.pinned.end()) {
+      *out = it->second;
+      g_pool.pinned.erase(it);
+      g_pool.pinned_free_bytes -= size;
+      std::memset(*out, 0, size);
+      return;
+    }
+  }
+  HIP_OK(hipHostMalloc(out, size, hipHostMallocDefault));
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  g_pool.pinned_size[*out] = size;
+}
+void pinned_free(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.pinned_size.find(p);
+    if (g_pool.on && it != g_pool.pinned_size.end() && g_pool.pinned_free_bytes + it->second <= ResourcePool::kPinnedCap) {
+      // (hipHostFree waits for the device's work; a block that goes back to the pool waits the same way: nothing still writes to it)
+      (void)hipDeviceSynchronize();
+      g_pool.pinned.emplace(it->second, p);
+      g_pool.pinned_free_bytes += it->second;
+      return;
+    }
+    if (it != g_pool.pinned_size.end()) g_pool.pinned_size.erase(it);
+  }
+  (void)hipHostFree(p);
+}
+void drain_pools() {
+  std::vector<hipStream_t> ss;
+  std::vector<void*> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (auto& dev : g_pool.streams)
+      for (auto& v : dev) {
+        for (hipStream_t s : v) { ss.push_back(s); g_pool.stream_class.erase(s); }
+        v.clear();
+      }
+    for (auto& kv : g_pool.pinned) { blocks.push_back(kv.second); g_pool.pinned_size.erase(kv.second); }
+    g_pool.pinned.clear();
+    g_pool.pinned_free_bytes = 0;
+  }
+  for (hipStream_t s : ss) (void)hipStreamDestroy(s);
+  for (void* b : blocks) (void)hipHostFree(b);
+}
+
 // Contexts alive in this process.  The speculative decompositions of icp_chain_step keep a few workgroups waiting on the
 // device and put three streams per context to work; the runtime multiplexes streams onto four hardware queues, and beyond
 // two contexts (measured: tools/multichain.py) the waiting kernels cost the other chains more than they gain.
@@ -789,14 +892,14 @@ struct icp_proposal {
   struct PinnedInts {
     int* p = nullptr; size_t n = 0;
     void assign(size_t count, int v) {
-      if (p) (void)hipHostFree(p);
-      HIP_OK(hipHostMalloc((void**)&p, sizeof(int) * count, hipHostMallocDefault));
+      if (p) pinned_free(p);
+      pinned_alloc((void**)&p, sizeof(int) * count);
       n = count;
       for (size_t i = 0; i < count; ++i) p[i] = v;
     }
     int& operator[](size_t i) { return p[i]; }
     int* data() { return p; }
-    ~PinnedInts() { if (p) (void)hipHostFree(p); }
+    ~PinnedInts() { if (p) pinned_free(p); }
   } h_status;
   std::unique_ptr<PosteriorEntry[]> memo;
   uint64_t clock = 0;
@@ -1105,9 +1208,9 @@ hipStream_t batch_eigen_stream(icp_ctx& lead, const void* owner, int second = 0)
   if (!lead.batch_eig[0]) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     for (int k = 0; k < icp_ctx::kBatchRing; ++k) {  // (a batch's two streams made one after the other: neighbours among the hardware queues)
-      HIP_OK(hipStreamCreateWithFlags(&lead.batch_eig[k], hipStreamNonBlocking));
+      lead.batch_eig[k] = take_stream(lead.device, false, 0);
       g_eig_streams.insert(lead.batch_eig[k]);
-      HIP_OK(hipStreamCreateWithFlags(&lead.batch_eig2[k], hipStreamNonBlocking));
+      lead.batch_eig2[k] = take_stream(lead.device, false, 0);
       g_eig_streams.insert(lead.batch_eig2[k]);
     }
   }
@@ -1501,12 +1604,14 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     if (const char* sp = dev_env("ICP_STREAM_PRIORITY")) {  // A/B switch: 0 = default priority everywhere
       if (std::atoi(sp) == 0) prio_greatest = 0;
     }
-    HIP_OK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest));
-    HIP_OK(hipStreamCreateWithPriority(&ctx->front_stream, hipStreamNonBlocking, prio_greatest));
-    HIP_OK(hipStreamCreateWithPriority(&ctx->eig_stream, hipStreamNonBlocking, prio_greatest));
+    // (out of the pool of streams of destroyed contexts where it has any of that priority class: take_stream)
+    const bool greatest = prio_greatest != 0;
+    ctx->stream = take_stream(device, greatest, prio_greatest);
+    ctx->front_stream = take_stream(device, greatest, prio_greatest);
+    ctx->eig_stream = take_stream(device, greatest, prio_greatest);
     // (ranks above 64 only: a stream costs a few MB of the runtime's own memory; created HERE, next to its sibling, and not on first
     // use: the runtime maps streams to its hardware queues in creation order, and a latecomer shared one with the context stream)
-    if (ctx->r > 64) HIP_OK(hipStreamCreateWithPriority(&ctx->eig_stream2, hipStreamNonBlocking, prio_greatest));
+    if (ctx->r > 64) ctx->eig_stream2 = take_stream(device, greatest, prio_greatest);
     { std::lock_guard<std::mutex> lk(g_eig_streams_mu); g_eig_streams.insert(ctx->eig_stream); }
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
@@ -1515,7 +1620,7 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_inst, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
-    HIP_OK(hipHostMalloc((void**)&ctx->h_wait_error, sizeof(int) * 16, hipHostMallocDefault));
+    pinned_alloc((void**)&ctx->h_wait_error, sizeof(int) * 16);
     ctx->h_wait_error[0] = 0;
 
     // ---- model and target: the immutable device data is shared between the contexts of a device made from the same arrays
@@ -1636,16 +1741,16 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->hint_surf.alloc(N); ctx->hint_surf.fill_bytes(0xFF);
     ctx->hint_nnv.alloc(N); ctx->hint_nnv.fill_bytes(0xFF);
     ctx->stage_cap = 64 * (size_t)(10 + r) + 4096;
-    HIP_OK(hipHostMalloc((void**)&ctx->h_stage, sizeof(double) * ctx->stage_cap, hipHostMallocDefault));
+    pinned_alloc((void**)&ctx->h_stage, sizeof(double) * ctx->stage_cap);
     ctx->d_stage.alloc(ctx->stage_cap);
     const size_t res_cap = std::max<size_t>(2048, 3 * (size_t)N + 64);
-    HIP_OK(hipHostMalloc((void**)&ctx->h_out, sizeof(double) * (icp_ctx::kStatusDoubles + res_cap), hipHostMallocDefault));
+    pinned_alloc((void**)&ctx->h_out, sizeof(double) * (icp_ctx::kStatusDoubles + res_cap));
     ctx->d_out.alloc(icp_ctx::kStatusDoubles + res_cap);
     ctx->h_status = (int*)ctx->h_out;
     ctx->h_res = ctx->h_out + icp_ctx::kStatusDoubles;
     ctx->d_status.p = (int*)ctx->d_out.p; ctx->d_status.n = 2 * icp_ctx::kStatusDoubles; ctx->d_status.owned = false;
     ctx->d_res.p = ctx->d_out.p + icp_ctx::kStatusDoubles; ctx->d_res.n = res_cap; ctx->d_res.owned = false;
-    HIP_OK(hipHostMalloc((void**)&ctx->h_flag, sizeof(int) * 16, hipHostMallocDefault));
+    pinned_alloc((void**)&ctx->h_flag, sizeof(int) * 16);
     ctx->h_flag[0] = 0;
     ctx->d_done.alloc(4);
     ctx->d_done.fill_bytes(0);
@@ -1672,6 +1777,7 @@ void icp_release_cached_models(void) {
     g_model_keep[i].reset();
   }
   if (have_device) (void)hipSetDevice(caller_device);
+  drain_pools();
 }
 
 void icp_ctx_destroy(icp_ctx* ctx) {
@@ -1690,20 +1796,18 @@ void icp_ctx_destroy(icp_ctx* ctx) {
       if (pool[k]) {
         std::lock_guard<std::mutex> lk(g_eig_streams_mu);
         g_eig_streams.erase(pool[k]);
-        (void)hipStreamSynchronize(pool[k]);
-        (void)hipStreamDestroy(pool[k]);
+        give_stream(pool[k]);
         pool[k] = nullptr;
       }
   if (ctx->eig_stream2) {
-    (void)hipStreamSynchronize(ctx->eig_stream2);
-    (void)hipStreamDestroy(ctx->eig_stream2);
+    give_stream(ctx->eig_stream2);
   }
   if (ctx->eig_stream) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     g_eig_streams.erase(ctx->eig_stream);
     (void)hipStreamSynchronize(ctx->eig_stream);
     library_release_stream(ctx->eig_stream);
-    (void)hipStreamDestroy(ctx->eig_stream);
+    give_stream(ctx->eig_stream);
   }
   if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
   if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
@@ -1712,20 +1816,20 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   if (ctx->front_stream) {
     (void)hipStreamSynchronize(ctx->front_stream);
     library_release_stream(ctx->front_stream);
-    (void)hipStreamDestroy(ctx->front_stream);
+    give_stream(ctx->front_stream);
   }
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
     library_release_stream(ctx->stream);
-    (void)hipStreamDestroy(ctx->stream);
+    give_stream(ctx->stream);
   }
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_inst) (void)hipEventDestroy(ctx->ev_inst);
   if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
-  if (ctx->h_wait_error) (void)hipHostFree(ctx->h_wait_error);
-  if (ctx->h_wide_z) (void)hipHostFree(ctx->h_wide_z);
+  if (ctx->h_wait_error) pinned_free(ctx->h_wait_error);
+  if (ctx->h_wide_z) pinned_free(ctx->h_wide_z);
   for (void* bp : ctx->wide_pinned)
-    if (bp) (void)hipHostFree(bp);
+    if (bp) pinned_free(bp);
   for (hipEvent_t ev : ctx->ev_wide_sum)
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : ctx->ev_wide_fac)
@@ -1734,17 +1838,17 @@ void icp_ctx_destroy(icp_ctx* ctx) {
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : ctx->ev_wide_eval)
     if (ev) (void)hipEventDestroy(ev);
-  if (ctx->h_gate_error) (void)hipHostFree(ctx->h_gate_error);
+  if (ctx->h_gate_error) pinned_free(ctx->h_gate_error);
   for (void* bp : ctx->batch_eig_rec)
-    if (bp) (void)hipHostFree(bp);
+    if (bp) pinned_free(bp);
   g_host_timing.report();
   g_batch_timing.report();
   for (auto& r : ctx->prof.pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-  if (ctx->h_out) (void)hipHostFree(ctx->h_out);
-  if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+  if (ctx->h_stage) pinned_free(ctx->h_stage);
+  if (ctx->h_out) pinned_free(ctx->h_out);
+  if (ctx->h_flag) pinned_free(ctx->h_flag);
   for (void* bp : ctx->batch_pinned)
-    if (bp) (void)hipHostFree(bp);
+    if (bp) pinned_free(bp);
   if (ctx->counted) --g_live_contexts;
   delete ctx;
 }
@@ -2112,9 +2216,9 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     p->mpart_half_doubles = (size_t)regression_splits(std::max(p->K, 1)) * (ctx->r + 1) * (ctx->r + 1);
     p->Mpart.alloc(icp_proposal::kMpartRing * p->mpart_half_doubles);
     p->fscratch.alloc((size_t)(ctx->r + 1) * ctx->r + 8);
-    HIP_OK(hipHostMalloc((void**)&p->h_cancel, sizeof(int) * 16, hipHostMallocDefault));
+    pinned_alloc((void**)&p->h_cancel, sizeof(int) * 16);
     for (int i = 0; i < 16; ++i) p->h_cancel[i] = 0;
-    HIP_OK(hipHostMalloc((void**)&p->h_eig, sizeof(int) * kPosteriorMemo, hipHostMallocDefault));
+    pinned_alloc((void**)&p->h_eig, sizeof(int) * kPosteriorMemo);
     for (int i = 0; i < kPosteriorMemo; ++i) p->h_eig[i] = 0;
     p->status.alloc(3 * kPosteriorMemo);
     p->status.fill_bytes(0);
@@ -2143,8 +2247,8 @@ void icp_proposal_destroy(icp_proposal* p) {
     for (icp_evaluator* ev : p->ctx->evaluators)  // a half step launched ahead with this proposal holds entries of it
       if (ev->front.valid && (ev->front.props[0] == p || ev->front.props[1] == p)) release_front(ev->front);
     if (g_host_timing.on && eigen_speculation_supported(p->ctx->r)) eigen_debug_dump(p->work.p, p->ctx->r);
-    if (p->h_cancel) (void)hipHostFree(p->h_cancel);
-    if (p->h_eig) (void)hipHostFree(p->h_eig);
+    if (p->h_cancel) pinned_free(p->h_cancel);
+    if (p->h_eig) pinned_free(p->h_eig);
     auto& live = p->ctx->proposals;
     live.erase(std::remove(live.begin(), live.end(), p), live.end());
     delete p;
@@ -3635,9 +3739,9 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     const size_t bytes = wide_batch_bytes(nW);
     if (bytes > lead.wide_bytes[turn]) {
       // (the slot's previous reader was the batch four tickets ago: collected, its launches finished)
-      if (lead.wide_pinned[turn]) { HIP_OK(hipHostFree(lead.wide_pinned[turn])); lead.wide_pinned[turn] = nullptr; }
+      if (lead.wide_pinned[turn]) { pinned_free(lead.wide_pinned[turn]); lead.wide_pinned[turn] = nullptr; }
       const size_t cap = std::max(bytes, wide_batch_bytes(kWideMaxChains));
-      HIP_OK(hipHostMalloc(&lead.wide_pinned[turn], cap, hipHostMallocDefault));
+      pinned_alloc((void**)&lead.wide_pinned[turn], cap);
       lead.wide_device[turn].alloc(cap);
       lead.wide_bytes[turn] = cap;
     }
@@ -3742,13 +3846,13 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     WideProposeItem pi{};
     if (generator >= 0) {
       PosteriorEntry& g = *ec[generator];
-      if (!c.h_wide_z) HIP_OK(hipHostMalloc((void**)&c.h_wide_z, sizeof(double) * kMaxRank, hipHostMallocDefault));
+      if (!c.h_wide_z) pinned_alloc((void**)&c.h_wide_z, sizeof(double) * kMaxRank);
       std::memcpy(c.h_wide_z, t.z[idx[k]], sizeof(double) * r);  // posterior.sample()'s standard normals (:55)
       pi.kind = 1;
       pi.in = ProposeIn{g.alpha.p, g.V.p, g.S.p, c.inv_sqrt_lambda.p, c.P.p, g.coeffs.p, c.h_wide_z, kSigma2,
                         it.props[generator]->prm.step_length, root ? 1 : 0};
     } else {
-      if (!c.h_wide_z) HIP_OK(hipHostMalloc((void**)&c.h_wide_z, sizeof(double) * kMaxRank, hipHostMallocDefault));
+      if (!c.h_wide_z) pinned_alloc((void**)&c.h_wide_z, sizeof(double) * kMaxRank);
       std::memcpy(c.h_wide_z, theta_prop + 10, sizeof(double) * r);
       pi.kind = 0;
       pi.src = c.h_wide_z;
@@ -4297,15 +4401,15 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       const size_t bytes = eigen_many_record_bytes((int)eigens.rq.size());
       if (bytes > lead.batch_eig_rec_bytes[turn]) {
         // (the slot's previous reader was the batch four tickets ago: collected, its launches finished)
-        if (lead.batch_eig_rec[turn]) { HIP_OK(hipHostFree(lead.batch_eig_rec[turn])); lead.batch_eig_rec[turn] = nullptr; }
+        if (lead.batch_eig_rec[turn]) { pinned_free(lead.batch_eig_rec[turn]); lead.batch_eig_rec[turn] = nullptr; }
         const size_t cap_bytes = std::max(bytes, eigen_many_record_bytes(128));
-        HIP_OK(hipHostMalloc(&lead.batch_eig_rec[turn], cap_bytes, hipHostMallocDefault));
+        pinned_alloc((void**)&lead.batch_eig_rec[turn], cap_bytes);
         lead.batch_eig_rec_bytes[turn] = cap_bytes;
       }
       if (!lead.batch_gate.p) {
         lead.batch_gate.alloc(16);
         HIP_OK(hipMemset(lead.batch_gate.p, 0, sizeof(int) * 16));
-        HIP_OK(hipHostMalloc((void**)&lead.h_gate_error, sizeof(int) * 16, hipHostMallocDefault));
+        pinned_alloc((void**)&lead.h_gate_error, sizeof(int) * 16);
         lead.h_gate_error[0] = 0;
         for (int k = 0; k < icp_ctx::kBatchRing; ++k) lead.batch_gate_expected[k] = 0;
       }
@@ -4382,9 +4486,9 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       const int turn = (lead.batch_turn = (lead.batch_turn + 1) % icp_ctx::kBatchRing);
       if (bytes > lead.batch_bytes[turn]) {
         HIP_OK(hipStreamSynchronize(lead.stream));
-        if (lead.batch_pinned[turn]) { HIP_OK(hipHostFree(lead.batch_pinned[turn])); lead.batch_pinned[turn] = nullptr; }
+        if (lead.batch_pinned[turn]) { pinned_free(lead.batch_pinned[turn]); lead.batch_pinned[turn] = nullptr; }
         const size_t cap_bytes = std::max(bytes, step_batch_bytes(16));
-        HIP_OK(hipHostMalloc(&lead.batch_pinned[turn], cap_bytes, hipHostMallocDefault));
+        pinned_alloc((void**)&lead.batch_pinned[turn], cap_bytes);
         lead.batch_device[turn].alloc(cap_bytes);
         lead.batch_bytes[turn] = cap_bytes;
       }
@@ -4653,7 +4757,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       ~GroupGuard() {
         for (auto& gr : g) {
           for (int k = 0; k < 2; ++k) {
-            if (gr.h_normals[k]) (void)hipHostFree(gr.h_normals[k]);
+            if (gr.h_normals[k]) pinned_free(gr.h_normals[k]);
             if (gr.ev_copy[k]) (void)hipEventDestroy(gr.ev_copy[k]);
           }
           if (gr.ev_big) (void)hipEventDestroy(gr.ev_big);
@@ -4686,7 +4790,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       gr.rec.alloc(records ? (size_t)B * std::max(n_steps, 1) * (4 + P) : 1);
       for (int k = 0; k < 2; ++k) {
         gr.normals[k].alloc((size_t)B * kChunk * r);
-        HIP_OK(hipHostMalloc((void**)&gr.h_normals[k], sizeof(double) * (size_t)B * kChunk * r, hipHostMallocDefault));
+        pinned_alloc((void**)&gr.h_normals[k], sizeof(double) * (size_t)B * kChunk * r);
         HIP_OK(hipEventCreateWithFlags(&gr.ev_copy[k], hipEventDisableTiming));
       }
       std::vector<StepBeginArgs> hb(2 * B);
