@@ -403,7 +403,11 @@ ICP_API int icp_chain_step_path(icp_evaluator *e, int32_t n_props, icp_proposal 
  * Gram matrix and its inverses: 0.35 s of host work and 2 x 137 MB of uploads at N = 28,561, rank 200).  The library keeps the two
  * most recently used models alive after their last context is destroyed, so that a job which builds one context per target over one
  * model (BASELINE.json configs[4]) pays for the model once; this call drops them (their device memory is freed as soon as no context
- * uses them). */
+ * uses them).
+ * Likewise the streams, pinned host blocks and device buffers of destroyed contexts, proposals and evaluators are kept for the next
+ * ones (a job that makes its chains anew for every target spent a third of its time creating and destroying them): up to 96 streams
+ * per device and priority class, 64 MiB of pinned memory, 6 GiB of device memory in blocks of at most 64 MiB.  This call gives all
+ * of that back as well; the environment variable ICP_NO_POOL=1 (read when the library is loaded) switches the pools off. */
 ICP_API void icp_release_cached_models(void);
 
 /* ---- idle hook (optional).  icp_chain_step spends most of a step waiting for the device.  A caller that has host
