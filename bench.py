@@ -751,8 +751,8 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
                            "baseline_config_index": 4, "items": n_items, "items_per_s": n_items / dt, "job_s": dt,
                            "items_per_rank": [int(p[1]) for p in per_rank], "contexts_built_per_rank": [int(p[0]) for p in per_rank],
                            "gather_ms_per_rank": [round(p[2], 3) for p in per_rank], "chain_ms_per_rank": [round(p[3], 1) for p in per_rank],
-                           "chains_per_launch": cpl if cpl > 0 else max(1, min(32, (3 if args.steps >= 200 else 1) * args.chains)), "best_item": [int(v) for v in items[best]],
-                           "accepted": int(sum(r[:, 1].sum() for r in recs))},
+                           "chains_per_launch": cpl if cpl > 0 else max(1, min(32, (3 if args.steps >= 150 else 2 if args.steps >= 30 else 1) * args.chains)), "best_item": [int(v) for v in items[best]],
+                           "accepted": int(sum(r[:, 1].sum() for r in recs)), "phase_ms_rank0": stats.get("phase_ms")},
                 "roofline": roofline, "cpu_baseline": None, "multi_gpu": multi_gpu, "runtime_stats": pkg._native.runtime_stats()}
         print(json.dumps(line))
 

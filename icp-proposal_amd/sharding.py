@@ -135,9 +135,13 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
     if chains_per_launch <= 0:
         # (measured on one MI355X, face configuration: 10 chains per submission 6.7k it/s, 20: 9.1k, 30: 10.5k, 40: 10.3k — a round costs
         # its launches and the slowest chain's decomposition, whatever it carries: tools/r4_many.sh)
-        # Short chains: one target's worth — making (and re-targeting) 30 contexts costs more than 50 steps take.
-        chains_per_launch = max(1, min(32, 3 * n_chains)) if n_steps >= 200 else max(1, min(32, n_chains))
+        # Short chains: fewer — a context costs ≈ 14 ms to make the first time (four streams), a submission of 20 chains saves 0.8 ms
+        # per step against two of 10, one of 30 another 0.85 ms against 20 + 10 (10 x 10 x 50 steps: 4,390 it/s with 10 per submission,
+        # 4,765 with 20, 3,560 with 30).
+        per_target = 3 if n_steps >= 150 else 2 if n_steps >= 30 else 1
+        chains_per_launch = max(1, min(32, per_target * n_chains))
     t_start = time.perf_counter()
+    phase = dict(contexts=0.0, set_target=0.0, setups=0.0, chains=0.0, steps=0.0, close=0.0)  # where a rank's wall time goes (seconds)
     my_targets = sorted(set(items[k][0] for k in mine))
     theta0 = lambda k: pkg.random_initial_parameters(model, items[k][1], base_seed)
     seed = lambda k: base_seed + 1000 * items[k][0] + items[k][1]
@@ -154,19 +158,27 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
         order = sorted(mine)
         for g0 in range(0, len(order), chains_per_launch):
             group = order[g0:g0 + chains_per_launch]
+            tp = time.perf_counter()
             while len(pool) < len(group):
                 pool.append(pkg.IcpContext(model, targets[items[group[len(pool)]][0]], device=device_index))
                 contexts_built += 1
             ctxs = pool[:len(group)]
+            phase["contexts"] += time.perf_counter() - tp; tp = time.perf_counter()
             for cx, k in zip(ctxs, group):
                 if cx.target is not targets[items[k][0]]:
                     cx.setTarget(targets[items[k][0]])
-            chains = [pkg.SamplingRegistration(cx, setup_of(items[k][0]), theta0(k), seed=seed(k)) for cx, k in zip(ctxs, group)]
+            phase["set_target"] += time.perf_counter() - tp; tp = time.perf_counter()
+            sets = [setup_of(items[k][0]) for k in group]
+            phase["setups"] += time.perf_counter() - tp; tp = time.perf_counter()
+            chains = [pkg.SamplingRegistration(cx, st, theta0(k), seed=seed(k)) for cx, st, k in zip(ctxs, sets, group)]
+            phase["chains"] += time.perf_counter() - tp; tp = time.perf_counter()
             for k, rec in zip(group, pkg.run_chains_batched(chains, n_steps)):
                 rec[:, 0] = k                              # the record's index field carries the item id across the gather
                 blocks.append(rec)
+            phase["steps"] += time.perf_counter() - tp; tp = time.perf_counter()
             for ch in chains:
                 ch.close()
+            phase["close"] += time.perf_counter() - tp
     else:                                                  # one context for the rank, its chains one after the other
         for t in my_targets:
             ks = [k for k in mine if items[k][0] == t]
@@ -182,8 +194,10 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
                 rec[:, 0] = k
                 blocks.append(rec)
                 chain.close()
+    tp = time.perf_counter()
     for cx in pool:
         cx.close()
+    phase["close"] += time.perf_counter() - tp
     t_chains = time.perf_counter()
     import torch
     dev = torch.device("cuda", device_index) if (dist is not None and dist.is_initialized() and dist.get_backend() == "nccl") else None
@@ -195,5 +209,6 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
             out[int(b[0, 0])] = b
     if return_stats:
         return items, out, dict(items=len(mine), contexts_built=contexts_built, targets_met=len(my_targets),
-                                chain_ms=1e3 * (t_chains - t_start), gather_ms=1e3 * (t_gather - t_chains))
+                                chain_ms=1e3 * (t_chains - t_start), gather_ms=1e3 * (t_gather - t_chains),
+                                phase_ms={k: round(1e3 * v, 1) for k, v in phase.items()})
     return items, out
