@@ -726,8 +726,8 @@ struct ResourcePool {
   static constexpr int kDevices = 16, kStreamsPerClass = 96;
   std::vector<hipStream_t> streams[kDevices][2];      // [device][0 = default priority, 1 = greatest]
   std::map<hipStream_t, int> stream_class;            // every pooled or handed-out stream: device * 2 + class
-  std::multimap<size_t, void*> pinned;                // free blocks by size
-  std::map<void*, size_t> pinned_size;                // every block of the pool, handed out or free
+  std::multimap<std::pair<int, size_t>, void*> pinned;        // free blocks by (device they were pinned under, size)
+  std::map<void*, std::pair<int, size_t>> pinned_size;        // every block of the pool, handed out or free
   size_t pinned_free_bytes = 0;
   static constexpr size_t kPinnedCap = (size_t)64 << 20;
   bool on = std::getenv("ICP_NO_POOL") == nullptr;
@@ -769,9 +769,11 @@ void give_stream(hipStream_t s) {
 }
 void pinned_alloc(void** out, size_t bytes) {
   const size_t size = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+  int dev = -1;
+  (void)hipGetDevice(&dev);
   {
     std::lock_guard<std::mutex> lk(g_pool.mu);
-    auto it = g_pool.pinned.find(size);
+    auto it = g_pool.pinned.find({dev, size});
     if (g_pool.on && it != g_pool.pinned.end()) {
       *out = it->second;
       g_pool.pinned.erase(it);
@@ -782,18 +784,18 @@ void pinned_alloc(void** out, size_t bytes) {
   }
   HIP_OK(hipHostMalloc(out, size, hipHostMallocDefault));
   std::lock_guard<std::mutex> lk(g_pool.mu);
-  g_pool.pinned_size[*out] = size;
+  g_pool.pinned_size[*out] = {dev, size};
 }
 void pinned_free(void* p) {
   if (!p) return;
   {
     std::lock_guard<std::mutex> lk(g_pool.mu);
     auto it = g_pool.pinned_size.find(p);
-    if (g_pool.on && it != g_pool.pinned_size.end() && g_pool.pinned_free_bytes + it->second <= ResourcePool::kPinnedCap) {
+    if (g_pool.on && it != g_pool.pinned_size.end() && g_pool.pinned_free_bytes + it->second.second <= ResourcePool::kPinnedCap) {
       // (hipHostFree waits for the device's work; a block that goes back to the pool waits the same way: nothing still writes to it)
       (void)hipDeviceSynchronize();
       g_pool.pinned.emplace(it->second, p);
-      g_pool.pinned_free_bytes += it->second;
+      g_pool.pinned_free_bytes += it->second.second;
       return;
     }
     if (it != g_pool.pinned_size.end()) g_pool.pinned_size.erase(it);
