@@ -549,15 +549,15 @@ def main():
 
 
 def config4_leg(pkg, args, device):
-    """configs[4] in small: 3 targets x 10 random-init chains through sharding.run_batch on this GPU, with chains of 50 steps (the size
-    round 3's 1,320-1,450 it/s was quoted on) and of 300; whole job each (contexts, chains, steps, records).  `--config 4` runs the
-    full 10 x 10 job."""
+    """configs[4] with short chains: 10 targets x 10 random-init chains through sharding.run_batch on this GPU, chains of 50 steps (the
+    size round 3's 1,320-1,450 it/s was quoted on) and of 300; whole job each (contexts, chains, steps, records) — what `--config 4
+    --steps 50|300` times.  (`--config 4 --steps 3000`: the reference-sized chains, 30 s.)"""
     model = face_model(pkg, args)
-    targets = [pkg.data.synthetic_partial_target(model, seed=100 + t) for t in range(3)]
+    targets = [pkg.data.synthetic_partial_target(model, seed=100 + t) for t in range(10)]
     make_setup = lambda m, t: pkg.bfm_fitting_partial(m, t, evaluator="collective", fused=args.fused)
     pkg.sharding.run_batch(pkg, model, targets[:1], n_chains=1, n_steps=5, make_setup=make_setup, dist=None, device_index=device)
-    out = {"unit": "iterations/s", "targets": 3, "chains": 10,
-           "workload": "BASELINE.json configs[4] in small: 3 targets x 10 random-init chains on the BFM-sized stand-in (N=%d, rank %d; 0.4 pose + "
+    out = {"unit": "iterations/s", "targets": 10, "chains": 10,
+           "workload": "BASELINE.json configs[4] with short chains: 10 targets x 10 random-init chains on the BFM-sized stand-in (N=%d, rank %d; 0.4 pose + "
                        "0.55 ICP + 0.05 random walk, collective boundary-aware evaluator), whole job on one GPU" % (model.n_points, model.rank)}
     for n_steps in (50, 300):
         t0 = time.perf_counter()
@@ -565,7 +565,7 @@ def config4_leg(pkg, args, device):
                                                     device_index=device, return_stats=True)
         dt = time.perf_counter() - t0
         out["steps_%d" % n_steps] = {"value": len(items) * n_steps / dt, "job_s": dt, "items": len(items), "accepted": int(sum(r[:, 1].sum() for r in recs)),
-                                     "contexts_built": int(stats["contexts_built"])}
+                                     "contexts_built": int(stats["contexts_built"]), "phase_ms": stats.get("phase_ms")}
     out["value"] = out["steps_300"]["value"]
     out["runtime_stats"] = pkg._native.runtime_stats()
     return out
