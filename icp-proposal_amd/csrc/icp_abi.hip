@@ -87,7 +87,14 @@ struct DBuf {
     alloc(count);
     if (count) HIP_OK(hipMemcpy(p, src, sizeof(T) * count, hipMemcpyHostToDevice));
   }
-  void fill_bytes(int v) { HIP_OK(hipMemset(p, v, sizeof(T) * (n ? n : 1))); }
+  // (hipMemset may return before the device has filled device memory, and what it enqueues on the null stream is not ordered against
+  // this library's non-blocking streams: a launch issued right behind it could see — or, worse, count into — the buffer before the
+  // fill lands.  Seen once the device was busy with another thread's batches: a batch gate's arrival counter zeroed AFTER the first
+  // arrivals, every later gate of that slot two seconds late.  The null stream is waited for here.)
+  void fill_bytes(int v) {
+    HIP_OK(hipMemset(p, v, sizeof(T) * (n ? n : 1)));
+    HIP_OK(hipStreamSynchronize(nullptr));
+  }
 };
 
 constexpr double kSigma2 = 1e-5;  // regularisation of Scalismo's DiscreteLowRankGaussianProcess.coefficients
@@ -1275,23 +1282,28 @@ void icp_proposal::prepare_eigen(PosteriorEntry& e, EigenRequest* rq) {
 
 // the eigen stream of the batch whose first chain lives on `owner`, out of the launch context's pool
 hipStream_t batch_eigen_stream(icp_ctx& lead, const void* owner, int second = 0) {
-  if (!lead.batch_eig[0]) {
-    std::lock_guard<std::mutex> lk(g_eig_streams_mu);
-    for (int k = 0; k < icp_ctx::kBatchRing; ++k) {  // (a batch's two streams made one after the other: neighbours among the hardware queues)
+  // A slot's streams are made when the slot is first handed out — the second one only at ranks above 64, where a wide step's
+  // decompositions alternate between two —, not all eight with the first batch: most launch contexts carry one batch at a time, a
+  // stream takes 3.3 ms to make, and every stream more makes it likelier that two of them share one of the runtime's hardware queues.
+  auto slot = [&](int k) {
+    if (!lead.batch_eig[k]) {
+      std::lock_guard<std::mutex> lk(g_eig_streams_mu);
       lead.batch_eig[k] = take_stream(lead.device, false, 0);
       g_eig_streams.insert(lead.batch_eig[k]);
-      lead.batch_eig2[k] = take_stream(lead.device, false, 0);
-      g_eig_streams.insert(lead.batch_eig2[k]);
+      if (lead.r > 64) {  // (the two made one after the other: neighbours among the hardware queues)
+        lead.batch_eig2[k] = take_stream(lead.device, false, 0);
+        g_eig_streams.insert(lead.batch_eig2[k]);
+      }
     }
-  }
-  hipStream_t* pool = second ? lead.batch_eig2 : lead.batch_eig;
+    return (second && lead.batch_eig2[k]) ? lead.batch_eig2[k] : lead.batch_eig[k];
+  };
   for (int k = 0; k < icp_ctx::kBatchRing; ++k)
-    if (lead.batch_eig_owner[k] == owner) return pool[k];
+    if (lead.batch_eig_owner[k] == owner) return slot(k);
   for (int k = 0; k < icp_ctx::kBatchRing; ++k)
-    if (!lead.batch_eig_owner[k]) { lead.batch_eig_owner[k] = owner; return pool[k]; }
+    if (!lead.batch_eig_owner[k]) { lead.batch_eig_owner[k] = owner; return slot(k); }
   const int k = (lead.batch_eig_evict = (lead.batch_eig_evict + 1) % icp_ctx::kBatchRing);  // (more than four batches: shared)
   lead.batch_eig_owner[k] = owner;
-  return pool[k];
+  return slot(k);
 }
 
 // waits for every decomposition of this context that may still be running
@@ -4481,7 +4493,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       }
       if (!lead.batch_gate.p) {
         lead.batch_gate.alloc(16);
-        HIP_OK(hipMemset(lead.batch_gate.p, 0, sizeof(int) * 16));
+        lead.batch_gate.fill_bytes(0);  // (… and waits for the fill: the decompositions launched below count into it)
         pinned_alloc((void**)&lead.h_gate_error, sizeof(int) * 16);
         lead.h_gate_error[0] = 0;
         for (int k = 0; k < icp_ctx::kBatchRing; ++k) lead.batch_gate_expected[k] = 0;
@@ -4491,6 +4503,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       const int wgs = launch_posterior_eigen_many(eigens.stream, elead.r, (int)eigens.rq.size(), eigens.rq.data(), lead.batch_eig_rec[turn],
                                                   lead.batch_gate.p + turn);
       require(wgs > 0, "internal: batched decompositions at a rank the kernel does not cover");
+      HIP_OK(hipGetLastError());  // (a launch that failed would leave the gate below waiting for arrivals that never come)
       lead.batch_gate_expected[turn] = (int)((unsigned)lead.batch_gate_expected[turn] + (unsigned)wgs);  // (wraps with the counter)
       gate = StepBatchGate{lead.batch_gate.p + turn, lead.batch_gate_expected[turn], lead.h_gate_error};
       // test hook (tools/r3_timeout_repro.py: round 2's schedule, for the record): the launch sequence is not held back

@@ -697,3 +697,52 @@ def test_femur100_chain_from_the_deterministic_fit_accepts_and_matches_oracle(pk
         ctx.close()
     finally:
         oracle.set_search_backend(oracle.SEARCH_BRUTE)
+
+
+_TWO_THREADS_SCRIPT = r"""
+import sys, threading, numpy as np
+sys.path.insert(0, {root!r})
+import __graft_entry__ as graft
+pkg = graft.load_package()
+model, target = pkg.data.synthetic_femur_target()
+B = 32
+ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
+setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+chains = [pkg.SamplingRegistration(ctxs[i], setup, pkg.random_initial_parameters(model, i), seed=1024 + i) for i in range(B)]
+recs = [None] * B
+def work(k):
+    mine = list(range(k, B, 2))
+    parts = [pkg.run_chains_batched([chains[i] for i in mine], n) for n in (3, 17)]   # (two calls: a first submission and a continuation)
+    for j, i in enumerate(mine):
+        recs[i] = np.concatenate([p[j] for p in parts])
+ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+[t.start() for t in ths]; [t.join() for t in ths]
+np.savez({out!r}, rec=np.stack(recs), stats=np.array(list(pkg._native.runtime_stats().values())))
+[c.close() for c in chains]; [c.close() for c in ctxs]
+"""
+
+
+def test_two_host_threads_with_a_batch_each_in_a_fresh_process(pkg, tmp_path):
+    """Two host threads, each stepping its own batch of 16 metric-configuration chains on one GPU, from the first call of a fresh process
+    on — the device is busy with the other thread's launches while a launch context makes its buffers.  (Round 4: a batch gate's arrival
+    counter was zeroed by a hipMemset that landed AFTER the first arrivals — hipMemset does not wait for the device, and the null stream
+    is not ordered against non-blocking streams — and every later gate of that ring slot opened two seconds late.)  No fall-back
+    counter may move, and the chains — independent of each other — must give the records of the same chains stepped by one thread."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = str(tmp_path / "two.npz")
+    subprocess.run([sys.executable, "-c", _TWO_THREADS_SCRIPT.format(root=ROOT, out=out)], check=True, env=dict(os.environ), timeout=600)
+    got = np.load(out)
+    assert np.all(got["stats"] == 0), got["stats"]
+    model, target = pkg.data.synthetic_femur_target()
+    setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
+    idx = [0, 1, 14, 31]
+    ctxs = [pkg.IcpContext(model, target, device=0) for _ in idx]
+    chains = [pkg.SamplingRegistration(cx, setup, pkg.random_initial_parameters(model, i), seed=1024 + i) for cx, i in zip(ctxs, idx)]
+    want = [np.concatenate([pkg.run_chains_batched([ch], n)[0] for n in (3, 17)]) for ch in chains]
+    for w, i in zip(want, idx):
+        assert np.array_equal(got["rec"][i], w), i
+    for ch in chains: ch.close()
+    for cx in ctxs: cx.close()

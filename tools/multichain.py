@@ -26,3 +26,4 @@ for mode in modes:
             t0 = time.perf_counter(); [t.start() for t in ths]; [t.join() for t in ths]; dt = time.perf_counter() - t0
         print(f"{mode:9s} B={B:2d}: {B * n / dt:9.0f} it/s total, {n / dt:8.0f} per chain, {1e6 * dt / n:7.1f} us per lockstep step", flush=True)
         [c.close() for c in chains]; [c.close() for c in ctxs]
+print("runtime stats:", pkg._native.runtime_stats(), flush=True)
