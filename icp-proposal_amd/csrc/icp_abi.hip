@@ -85,7 +85,10 @@ struct DBuf {
   }
   void upload(const T* src, size_t count) {
     alloc(count);
-    if (count) HIP_OK(hipMemcpy(p, src, sizeof(T) * count, hipMemcpyHostToDevice));
+    if (count) {
+      HIP_OK(hipMemcpy(p, src, sizeof(T) * count, hipMemcpyHostToDevice));
+      HIP_OK(hipStreamSynchronize(nullptr));  // (as fill_bytes: the copy has reached the device before any launch can read it)
+    }
   }
   // (hipMemset may return before the device has filled device memory, and what it enqueues on the null stream is not ordered against
   // this library's non-blocking streams: a launch issued right behind it could see — or, worse, count into — the buffer before the
