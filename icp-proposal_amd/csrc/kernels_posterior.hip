@@ -65,7 +65,9 @@ __global__ void __launch_bounds__(kBlock) k_correspond_target(CorrTask c, const 
 
 __global__ void __launch_bounds__(64) k_regression_mfma(int K, int kchunk, int r, const double* __restrict__ Q, CorrBuffers cb,
                                                          double wt, double kappa, double* __restrict__ Mpart) {
-  regression_tile(blockIdx.x, blockIdx.y, K, kchunk, r, Q, cb, wt, kappa, Mpart);
+  // (blockIdx.x = split, .y = tile: with 64 splits every tile of a split runs on the XCD "split mod 8" — workgroups go to the XCDs
+  // round robin by linear index — and the split's gathered basis rows are fetched into ONE L2; see step_regression_body)
+  regression_tile(blockIdx.y, blockIdx.x, K, kchunk, r, Q, cb, wt, kappa, Mpart);
 }
 
 constexpr int kFactorMax = 2 * kWideMaxChains;  // posteriors per launch: both ICP directions of one or two states — or one per chain of a wide step
@@ -2056,7 +2058,7 @@ void launch_regression(hipStream_t st, int K, int r, const double* Q, const Corr
   if (kchunk < 1) kchunk = 1;
   *splits_out = S;
   { ProfScope _ps(st, KID_REGRESSION);
-    hipLaunchKernelGGL(k_regression_mfma, dim3(regression_tiles(r), S), dim3(64), 0, st, K, kchunk, r, Q, cb, w_tangent, kappa, Mpart); }
+    hipLaunchKernelGGL(k_regression_mfma, dim3(S, regression_tiles(r)), dim3(64), 0, st, K, kchunk, r, Q, cb, w_tangent, kappa, Mpart); }
 }
 
 static void set_dyn_lds(const void* fn, size_t bytes) {

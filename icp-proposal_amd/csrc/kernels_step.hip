@@ -291,12 +291,20 @@ __device__ __forceinline__ void dist_stats_body(int K, const double* __restrict_
   if (threadIdx.x == 0) { out[0] = sum; out[1] = mx; out[2] = cnt; }
 }
 
+// Units and XCDs.  Workgroups are dealt to the eight XCDs round robin by their index, and every XCD has an L2 of its own: with the
+// units in their natural order — the tiles of a split side by side — a split's gathered basis rows were fetched into seven or eight
+// L2s (configs[2], K = 1,622, rank 100: 23 MB fetched per launch for 3.9 MB of rows, profiles/r04_pmc_traffic.json).  The
+// workgroups of one XCD (index ≡ x mod 8) therefore take a CONTIGUOUS range of units — whole splits: `step_regression_blocks`
+// workgroups (a multiple of 8), workgroup bx works as logical block (bx mod 8)·per + bx div 8.
+__host__ __device__ inline int step_regression_blocks(int n_units) { return 8 * ((((n_units + 3) >> 2) + 7) >> 3); }
 __device__ __forceinline__ void step_regression_body(const StepRegressionArgs& a, const int bx) {
   const int n_units = a.ustart[a.n];
   const int n_blocks = (n_units + 3) >> 2;  // one wave per (tile, split) unit, four per workgroup
-  if (bx < n_blocks) {
-    const int u = bx * 4 + (threadIdx.x >> 6);
-    if (u < n_units) {
+  const int n_grid = step_regression_blocks(n_units);
+  if (bx < n_grid) {
+    const int lb = (bx & 7) * (n_grid >> 3) + (bx >> 3);
+    const int u = lb * 4 + (threadIdx.x >> 6);
+    if (lb < n_blocks && u < n_units) {
       const int which = u < a.ustart[1] ? 0 : 1;
       const int l = u - (which ? a.ustart[1] : 0), tile = l % a.ntiles, split = l / a.ntiles;
       if (tile == 0 && split == 0 && (threadIdx.x & 63) == 0) { a.status[which][1] = 0; a.status[which][2] = 0; }
@@ -316,7 +324,7 @@ __device__ __forceinline__ void step_regression_body(const StepRegressionArgs& a
   }
 }
 __device__ __forceinline__ int step_regression_grid(const StepRegressionArgs& a) {
-  return (a.ustart[a.n] + 3) / 4 + (a.reduce_kind ? 1 : 0);
+  return step_regression_blocks(a.ustart[a.n]) + (a.reduce_kind ? 1 : 0);
 }
 
 __global__ void __launch_bounds__(kStepBlock) k_step_regression(StepRegressionArgs a) { step_regression_body(a, blockIdx.x); }
@@ -505,7 +513,7 @@ void launch_step_resolve(hipStream_t st, const StepSearchArgs& a) {
 }
 
 void launch_step_regression(hipStream_t st, const StepRegressionArgs& a) {
-  const int blocks = (a.ustart[a.n] + 3) / 4 + (a.reduce_kind ? 1 : 0);
+  const int blocks = step_regression_blocks(a.ustart[a.n]) + (a.reduce_kind ? 1 : 0);
   if (t_capture) { t_capture->regression = a; t_capture->grid[3] = blocks; return; }
   if (blocks <= 0) return;
   ProfScope _ps(st, KID_STEP_REGRESSION);

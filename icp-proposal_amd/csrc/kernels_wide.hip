@@ -249,7 +249,8 @@ __device__ __forceinline__ void dist_max_body(int K, const double* __restrict__ 
 }
 
 constexpr int kWideRegBlock = 256;
-__device__ __forceinline__ int wide_reg_units_blocks(const StepRegressionArgs& a) { return (a.ustart[a.n] + 3) >> 2; }
+// (a multiple of 8 workgroups, the workgroups of one XCD on a contiguous range of units: see step_regression_body, kernels_step.hip)
+__host__ __device__ inline int wide_reg_units_blocks(const StepRegressionArgs& a) { return 8 * ((((a.ustart[a.n] + 3) >> 2) + 7) >> 3); }
 __host__ __device__ inline int wide_red_blocks(const WideRegArgs& a, int dir /* 0: model -> target, 1: target -> model */) {
   const bool on = dir == 0 ? a.eval_m2t != 0 : a.eval_t2m != 0;
   if (!on) return 0;
@@ -263,7 +264,8 @@ __global__ void __launch_bounds__(kWideRegBlock) k_wide_regression(const WideReg
   const int nb = a.n > 0 ? wide_reg_units_blocks(a) : 0;
   if (b < nb) {
     const int n_units = a.ustart[a.n];
-    const int u = b * 4 + (threadIdx.x >> 6);
+    const int lb = (b & 7) * (nb >> 3) + (b >> 3);
+    const int u = lb * 4 + (threadIdx.x >> 6);
     if (u < n_units) {
       const int which = u < a.ustart[1] ? 0 : 1;
       const int l = u - (which ? a.ustart[1] : 0), tile = l % a.ntiles, split = l / a.ntiles;
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(256) k_wide_args(const uint4* __restrict__ src
 }  // namespace
 
 int wide_reg_blocks(const WideRegArgs& a) {
-  return (a.reg.n > 0 ? (a.reg.ustart[a.reg.n] + 3) / 4 : 0) + wide_red_blocks(a, 0) + wide_red_blocks(a, 1);
+  return (a.reg.n > 0 ? wide_reg_units_blocks(a.reg) : 0) + wide_red_blocks(a, 0) + wide_red_blocks(a, 1);
 }
 
 void launch_wide_propose(hipStream_t st, int r, const WideProposeArgs& a) {
