@@ -191,9 +191,25 @@ __device__ void block_matvec(int r, const double* A, int lda, const double* x, d
     const int row = row0 + (tid >> tpr_log2);
     double acc = 0.0;
     if (row < r) {
+      // sixteen matrix entries in flight per lane, requested BEFORE the first one is used (left to itself the compiler keeps a load
+      // next to its multiply-add: one round trip to L2 per entry — 50 in a row for a rank-200 row shared by four lanes); the sum
+      // runs over the entries in their order either way
       const double* a = A + (size_t)row * lda;
-#pragma unroll 8
-      for (int j = sub; j < r; j += tpr) acc = fma(a[j], x[j], acc);
+      constexpr int CH = 16;
+      for (int j0 = sub; j0 < r; j0 += CH * tpr) {
+        double av[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          const int j = j0 + q * tpr;
+          av[q] = j < r ? a[j] : 0.0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          const int j = j0 + q * tpr;
+          if (j < r) acc = fma(av[q], x[j], acc);
+        }
+      }
     }
     for (int o = tpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (row < r && sub == 0) y[row] = acc;
