@@ -88,6 +88,19 @@ JNIEXPORT void JNICALL Java_api_gpu_NativeIcp_00024_setRotation(JNIEnv *env, job
   throw_status(env, st);
 }
 
+/* icp_ctx_rotation_convention: [verified, mismatched] — did every matrix registered so far agree with the library's Rz·Ry·Rx? */
+JNIEXPORT jlongArray JNICALL Java_api_gpu_NativeIcp_00024_rotationConvention(JNIEnv *env, jobject self, jlong ctx) {
+  (void)self;
+  int64_t v[2] = {0, 0};
+  int st = icp_ctx_rotation_convention(PTR(icp_ctx, ctx), &v[0], &v[1]);
+  if (st != ICP_OK) { throw_status(env, st); return 0; }
+  jlongArray out = (*env)->NewLongArray(env, 2);
+  if (!out) return 0;
+  const jlong jv[2] = {(jlong)v[0], (jlong)v[1]};
+  (*env)->SetLongArrayRegion(env, out, 0, 2, jv);
+  return out;
+}
+
 JNIEXPORT jlong JNICALL Java_api_gpu_NativeIcp_00024_proposalCreate(JNIEnv *env, jobject self, jlong ctx, jdouble step, jdouble sigma_t,
                                                                     jdouble sigma_n, jint direction, jboolean boundary_aware,
                                                                     jint n_model_ids, jdoubleArray target_pts) {

@@ -16,6 +16,10 @@ object NativeIcp {
   /** Scalismo's own rotation matrix (row-major 3×3) for a triple of Euler angles: keeps Rotation(phi, theta, psi, center)'s convention
     * on the Scala side (ModelFittingParameters.scala:79-86).  rot == null withdraws the entry. */
   @native def setRotation(ctx: Long, angles: Array[Double], rot: Array[Double]): Unit
+  /** (verified, mismatched): how many of the matrices registered so far agreed, to rounding, with the native side's own Rz·Ry·Rx.
+    * mismatched == 0 after the first few steps of a chain says Scalismo's Rotation(phi, theta, psi, center) IS that convention, and the
+    * whole chain loop — pose walks included — may then run on the device (icp_chains_run_on_device). */
+  @native def rotationConvention(ctx: Long): Array[Long]
 
   @native def proposalCreate(ctx: Long, step: Double, sigmaT: Double, sigmaN: Double, direction: Int, boundaryAware: Boolean,
                              nModelIds: Int, targetPts: Array[Double]): Long

@@ -55,7 +55,7 @@ class KernelStat(C.Structure):
 
 
 class MhMixture(C.Structure):
-    _fields_ = [("icp_weight", C.c_double * 2), ("w_icp", C.c_double), ("w_rw", C.c_double), ("rw_sigma", C.c_double),
+    _fields_ = [("struct_size", C.c_uint64), ("icp_weight", C.c_double * 2), ("w_icp", C.c_double), ("w_rw", C.c_double), ("rw_sigma", C.c_double),
                 ("w_pose", C.c_double), ("pose_rot_sigma", C.c_double * 3), ("pose_trans_sigma", C.c_double * 3)]
 
 
@@ -108,6 +108,7 @@ SIGNATURES = {
     "icp_chain_step_batched_collect": (C.c_int, [C.c_void_p]),
     "icp_chain_step_batched_abandon": (C.c_int, [C.c_void_p]),
     "icp_ctx_set_rotation": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "icp_ctx_rotation_convention": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "icp_ctx_runtime_stats": (C.c_int, [C.c_void_p, C.POINTER(RuntimeStats)]),
     "icp_ctx_step_paths": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "icp_chain_step_path": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),

@@ -162,6 +162,13 @@ class IcpContext:
         m = _f64(R).reshape(9) if R is not None else None
         nat.check(nat.lib().icp_ctx_set_rotation(self.h, _d(a), _d(m) if m is not None else None), "icp_ctx_set_rotation")
 
+    def rotationConvention(self) -> dict:
+        """icp_ctx_rotation_convention: how many matrices handed to setRotation agreed with the library's Rz·Ry·Rx (to rounding) and
+        how many did not; with mismatched == 0 the on-device loop takes mixtures with pose walks for this context."""
+        v, m = C.c_int64(0), C.c_int64(0)
+        nat.check(nat.lib().icp_ctx_rotation_convention(self.h, C.byref(v), C.byref(m)), "icp_ctx_rotation_convention")
+        return {"verified": v.value, "mismatched": m.value}
+
     def transformedMesh(self, theta) -> np.ndarray:
         """ModelFittingParameters.transformedMesh (ModelFittingParameters.scala:108-110) -> points [N,3]."""
         th = _theta(theta)

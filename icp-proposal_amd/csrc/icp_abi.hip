@@ -429,36 +429,39 @@ struct icp_ctx {
   bool count_searches = false;                 // icp_ctx_profile_search_counters
   // argument arrays of the icp_chain_step_batched launches led by this context: pinned copy, device copy
   // (kBatchRing of each, used in turn: a caller may keep that many batches in flight on this context's stream)
-  static constexpr int kBatchRing = 4;
-  void* batch_pinned[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int kBatchRing = ICP_MAX_BATCHES_IN_FLIGHT;
+  // tickets issued on this launch context and not yet collected / abandoned: one more than the ring holds would rewrite the pinned
+  // argument slot, the eigen records and the gate word of a batch still on the device — refused with ICP_ERR_BUSY (icp_chain_step_batched_issue)
+  std::atomic<int> tickets_in_flight{0};
+  void* batch_pinned[kBatchRing] = {};
   DBuf<unsigned char> batch_device[kBatchRing];
-  size_t batch_bytes[kBatchRing] = {0, 0, 0, 0};
+  size_t batch_bytes[kBatchRing] = {};
   int batch_turn = 0;
   // the wide step (kernels_wide.hip) led by this context: per-chain records (pinned + device copy), events stream -> side streams
-  void* wide_pinned[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
+  void* wide_pinned[kBatchRing] = {};
   DBuf<unsigned char> wide_device[kBatchRing];
-  size_t wide_bytes[kBatchRing] = {0, 0, 0, 0};
-  hipEvent_t ev_wide_sum[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};   // stream -> eigen / finish streams: the partials are summed
-  hipEvent_t ev_wide_fac[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};   // finish stream -> eigen stream: M is complete (ranks <= 64)
-  hipEvent_t ev_wide_head[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};  // stream -> second stream: the new instances are complete
-  hipEvent_t ev_wide_eval[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};  // stream -> second stream: the evaluator's own sequence is through
+  size_t wide_bytes[kBatchRing] = {};
+  hipEvent_t ev_wide_sum[kBatchRing] = {};   // stream -> eigen / finish streams: the partials are summed
+  hipEvent_t ev_wide_fac[kBatchRing] = {};   // finish stream -> eigen stream: M is complete (ranks <= 64)
+  hipEvent_t ev_wide_head[kBatchRing] = {};  // stream -> second stream: the new instances are complete
+  hipEvent_t ev_wide_eval[kBatchRing] = {};  // stream -> second stream: the evaluator's own sequence is through
   int wide_turn = 0;
   double* h_wide_z = nullptr;  // pinned: the coefficients a wide step is GIVEN (random-walk / pose proposals), read by its first launch
   // … and of their decompositions: the records of launch_posterior_eigen_many (pinned, read in place by the kernel), the counter
   // its workgroups announce themselves in and what it will hold once every workgroup launched so far has started (the gate of
   // launch_step_batch) and the gate's pinned error word
-  void* batch_eig_rec[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
-  size_t batch_eig_rec_bytes[kBatchRing] = {0, 0, 0, 0};
+  void* batch_eig_rec[kBatchRing] = {};
+  size_t batch_eig_rec_bytes[kBatchRing] = {};
   int batch_eig_turn = 0;
   DBuf<int> batch_gate;                                   // one counter word per ring slot (a later batch's workgroups must not open an earlier batch's gate)
-  int batch_gate_expected[kBatchRing] = {0, 0, 0, 0};
+  int batch_gate_expected[kBatchRing] = {};
   int* h_gate_error = nullptr;
   // eigen streams of the batches this context carries, one per batch in flight (keyed by the batch's first chain): created
   // together, so that the runtime spreads them over different hardware queues — the member contexts' own eigen streams
   // collide on one queue for some batch sizes (24 chains in three groups: 49k instead of 70k it/s)
-  hipStream_t batch_eig[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
-  hipStream_t batch_eig2[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};  // … and a second one each (the wide step alternates: two decompositions of a chain in flight)
-  const void* batch_eig_owner[kBatchRing] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t batch_eig[kBatchRing] = {};
+  hipStream_t batch_eig2[kBatchRing] = {};  // … and a second one each (the wide step alternates: two decompositions of a chain in flight)
+  const void* batch_eig_owner[kBatchRing] = {};
   int batch_eig_evict = 0;
 
   void bind() { HIP_OK(hipSetDevice(device)); }
@@ -521,6 +524,13 @@ struct icp_ctx {
   static constexpr int kRotationEntries = 32;
   RotationEntry rotations[kRotationEntries];
   uint64_t rotation_clock = 0;
+  // Convention check (icp_ctx_set_rotation): every supplied matrix is compared with the library's own Rz(phi)·Ry(theta)·Rx(psi)
+  // (include/icp_sincos.h).  A host whose matrices all agree to rounding (kRotationTol per entry) has the library's convention —
+  // Scalismo's Rotation(phi, theta, psi, centre) of ModelFittingParameters.scala:79-86, if the host is the Scala adapter — and the pose
+  // walks of the on-device loop, which make the proposed pose's matrix on the device, are open to it; one disagreement closes them
+  // for this context for good (icp_chains_run_on_device; icp_ctx_rotation_convention reports both counts).
+  static constexpr double kRotationTol = 2e-15;
+  int64_t rotations_verified = 0, rotations_mismatched = 0;
   Pose pose_of(const double* theta);
 
   StateSlot& state(const double* theta);
@@ -796,38 +806,82 @@ void pinned_alloc(void** out, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_pool.mu);
   g_pool.pinned_size[*out] = {dev, size};
 }
+struct DevicePool {
+  std::mutex mu;
+  std::map<std::pair<int, size_t>, std::vector<void*>> free;  // (device, bytes) -> blocks
+  std::map<void*, int> owner;                                 // every block handed out or kept: the device it was allocated on
+  size_t free_bytes = 0;
+  // what the pool may keep: 6 GiB, at most an eighth of the device's memory (ICP_POOL_CAP_MB overrides); blocks above 64 MiB are never kept
+  static constexpr size_t kMaxBlock = (size_t)64 << 20;
+  size_t cap = 0;
+  size_t capacity() {
+    if (cap) return cap;
+    cap = (size_t)6 << 30;
+    if (const char* e = std::getenv("ICP_POOL_CAP_MB")) cap = std::max<size_t>(1, (size_t)std::atoll(e)) << 20;
+    else {
+      size_t fr = 0, total = 0;
+      if (hipMemGetInfo(&fr, &total) == hipSuccess && total / 8 < cap) cap = std::max<size_t>(total / 8, (size_t)64 << 20);
+    }
+    return cap;
+  }
+};
+DevicePool g_dpool;
+thread_local int tl_quiesce_depth = 0;
+
 void pinned_free(void* p) {
   if (!p) return;
   {
-    std::lock_guard<std::mutex> lk(g_pool.mu);
+    std::unique_lock<std::mutex> lk(g_pool.mu);
     auto it = g_pool.pinned_size.find(p);
     if (g_pool.on && it != g_pool.pinned_size.end() && g_pool.pinned_free_bytes + it->second.second <= ResourcePool::kPinnedCap) {
-      // (hipHostFree waits for the device's work; a block that goes back to the pool waits the same way: nothing still writes to it)
-      (void)hipDeviceSynchronize();
-      g_pool.pinned.emplace(it->second, p);
-      g_pool.pinned_free_bytes += it->second.second;
-      return;
+      // (hipHostFree waits for the device's work; a block that goes back to the pool waits the same way: nothing still writes to it.
+      // Inside a DeviceQuiesce scope that wait has happened; otherwise it happens here, on the device the block was pinned under and
+      // WITHOUT the pool's lock — another host thread's take_stream / pinned_alloc must not wait for this thread's device)
+      const std::pair<int, size_t> key = it->second;
+      if (tl_quiesce_depth == 0) {
+        lk.unlock();
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (key.first >= 0 && key.first != cur) (void)hipSetDevice(key.first);
+        (void)hipDeviceSynchronize();
+        if (key.first >= 0 && key.first != cur && cur >= 0) (void)hipSetDevice(cur);
+        lk.lock();
+      }
+      if (g_pool.pinned_free_bytes + key.second <= ResourcePool::kPinnedCap) {
+        g_pool.pinned.emplace(key, p);
+        g_pool.pinned_free_bytes += key.second;
+        return;
+      }
+      it = g_pool.pinned_size.find(p);
     }
     if (it != g_pool.pinned_size.end()) g_pool.pinned_size.erase(it);
   }
   (void)hipHostFree(p);
 }
-struct DevicePool {
-  std::mutex mu;
-  std::map<std::pair<int, size_t>, std::vector<void*>> free;  // (device, bytes) -> blocks
-  size_t free_bytes = 0;
-  static constexpr size_t kCap = (size_t)6 << 30, kMaxBlock = (size_t)64 << 20;
-};
-DevicePool g_dpool;
-thread_local int tl_quiesce_depth = 0;
 
 DeviceQuiesce::DeviceQuiesce() {
   if (tl_quiesce_depth++ == 0 && g_pool.on) (void)hipDeviceSynchronize();
 }
 DeviceQuiesce::~DeviceQuiesce() { --tl_quiesce_depth; }
+// frees every block the device pool keeps (all devices); -> bytes released
+size_t drain_device_pool() {
+  std::vector<void*> blocks;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_dpool.mu);
+    for (auto& kv : g_dpool.free)
+      for (void* b : kv.second) { blocks.push_back(b); g_dpool.owner.erase(b); }
+    g_dpool.free.clear();
+    bytes = g_dpool.free_bytes;
+    g_dpool.free_bytes = 0;
+  }
+  for (void* b : blocks) (void)hipFree(b);
+  return bytes;
+}
 void* device_alloc(size_t bytes) {
   int dev = 0;
-  if (g_pool.on && bytes <= DevicePool::kMaxBlock && hipGetDevice(&dev) == hipSuccess && dev < ResourcePool::kDevices) {
+  const bool have_dev = hipGetDevice(&dev) == hipSuccess;
+  if (g_pool.on && bytes <= DevicePool::kMaxBlock && have_dev) {
     std::lock_guard<std::mutex> lk(g_dpool.mu);
     auto it = g_dpool.free.find({dev, bytes});
     if (it != g_dpool.free.end() && !it->second.empty()) {
@@ -838,36 +892,57 @@ void* device_alloc(size_t bytes) {
     }
   }
   void* p = nullptr;
-  HIP_OK(hipMalloc(&p, bytes));
+  hipError_t e = hipMalloc(&p, bytes);
+  // test hook (tests/test_gpu_edges.py): the n-th allocation of the process "fails" as if the device were full while the pool holds blocks
+  static const long fail_at = dev_env("ICP_TEST_FAIL_MALLOC_AT") ? std::atol(dev_env("ICP_TEST_FAIL_MALLOC_AT")) : 0;
+  static std::atomic<long> n_malloc{0};
+  if (fail_at > 0 && e == hipSuccess && ++n_malloc == fail_at) { (void)hipFree(p); p = nullptr; e = hipErrorOutOfMemory; }
+  if (e != hipSuccess) {
+    // Blocks are kept by exact size: after a change of model, K, rank or scratch size the kept ones fit nothing and only take the
+    // room this allocation needs — they are given back to the runtime, and the allocation is tried once more
+    (void)hipGetLastError();
+    if (drain_device_pool() > 0) e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) fail(ICP_ERR_DEVICE, std::string("hipMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+  }
+  if (g_pool.on && have_dev) {
+    std::lock_guard<std::mutex> lk(g_dpool.mu);
+    g_dpool.owner[p] = dev;  // (the device that owns the block: where it is filed when it comes back, whatever device is current then)
+  }
   return p;
 }
 void device_free(void* p, size_t bytes) {
   if (!p) return;
-  int dev = 0;
-  if (g_pool.on && bytes <= DevicePool::kMaxBlock && hipGetDevice(&dev) == hipSuccess && dev < ResourcePool::kDevices) {
-    // (outside a DeviceQuiesce scope — a buffer that grows in the middle of a run — the device is waited for here, as hipFree would)
-    if (tl_quiesce_depth == 0) (void)hipDeviceSynchronize();
-    std::lock_guard<std::mutex> lk(g_dpool.mu);
-    if (g_dpool.free_bytes + bytes <= DevicePool::kCap) {
-      g_dpool.free[{dev, bytes}].push_back(p);
-      g_dpool.free_bytes += bytes;
-      return;
+  if (g_pool.on) {
+    int dev = -1;
+    {
+      std::lock_guard<std::mutex> lk(g_dpool.mu);
+      auto it = g_dpool.owner.find(p);
+      if (it != g_dpool.owner.end()) dev = it->second;
     }
+    if (dev >= 0 && bytes <= DevicePool::kMaxBlock) {
+      // (outside a DeviceQuiesce scope — a buffer that grows in the middle of a run — the owning device is waited for here, as hipFree would)
+      if (tl_quiesce_depth == 0) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();
+        if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
+      }
+      std::lock_guard<std::mutex> lk(g_dpool.mu);
+      if (g_dpool.free_bytes + bytes <= g_dpool.capacity()) {
+        g_dpool.free[{dev, bytes}].push_back(p);
+        g_dpool.free_bytes += bytes;
+        return;
+      }
+    }
+    std::lock_guard<std::mutex> lk(g_dpool.mu);
+    g_dpool.owner.erase(p);
   }
   (void)hipFree(p);
 }
 
 void drain_pools() {
-  {
-    std::vector<void*> dblocks;
-    {
-      std::lock_guard<std::mutex> lk(g_dpool.mu);
-      for (auto& kv : g_dpool.free) for (void* b : kv.second) dblocks.push_back(b);
-      g_dpool.free.clear();
-      g_dpool.free_bytes = 0;
-    }
-    for (void* b : dblocks) (void)hipFree(b);
-  }
+  (void)drain_device_pool();
   std::vector<hipStream_t> ss;
   std::vector<void*> blocks;
   {
@@ -1304,7 +1379,7 @@ hipStream_t batch_eigen_stream(icp_ctx& lead, const void* owner, int second = 0)
     if (lead.batch_eig_owner[k] == owner) return slot(k);
   for (int k = 0; k < icp_ctx::kBatchRing; ++k)
     if (!lead.batch_eig_owner[k]) { lead.batch_eig_owner[k] = owner; return slot(k); }
-  const int k = (lead.batch_eig_evict = (lead.batch_eig_evict + 1) % icp_ctx::kBatchRing);  // (more than four batches: shared)
+  const int k = (lead.batch_eig_evict = (lead.batch_eig_evict + 1) % icp_ctx::kBatchRing);  // (more batches than the ring holds — not through icp_chain_step_batched_issue, which refuses them: shared)
   lead.batch_eig_owner[k] = owner;
   return slot(k);
 }
@@ -1595,6 +1670,9 @@ void attach_target(icp_ctx* ctx, const icp_mesh_desc* target, int device) {
   uint64_t th = hash_words(0x5678, target->points, sizeof(double) * 3 * (size_t)target->n_points);
   th = hash_words(th, target->triangles, sizeof(int32_t) * 3 * (size_t)target->n_triangles);
   const SharedKey tkey{device, target->n_points, target->n_triangles, 0, th};
+  // (a batch registration attaches one target after the other: the entries of targets nobody holds any more are dropped)
+  for (auto it = g_shared_targets.begin(); it != g_shared_targets.end();)
+    it = it->second.expired() ? g_shared_targets.erase(it) : std::next(it);
   std::shared_ptr<SharedTarget> stg = g_shared_targets[tkey].lock();
   if (!stg) {
     stg = std::make_shared<SharedTarget>();
@@ -1790,38 +1868,6 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->boundary.alias(sm->boundary);
 
     attach_target(ctx, target, device);
-#if 0
-    uint64_t th = hash_words(0x5678, target->points, sizeof(double) * 3 * (size_t)target->n_points);
-    th = hash_words(th, target->triangles, sizeof(int32_t) * 3 * (size_t)target->n_triangles);
-    const SharedKey tkey{device, target->n_points, target->n_triangles, 0, th};
-    std::shared_ptr<SharedTarget> stg = g_shared_targets[tkey].lock();
-    if (!stg) {
-      stg = std::make_shared<SharedTarget>();
-      DeviceMesh& tg = stg->mesh;
-      tg.V = target->n_points; tg.T = target->n_triangles;
-      std::vector<uint8_t> tb;
-      boundary_flags(tg.V, tg.T, target->triangles, tb);
-      tg.n_boundary = (int)std::count(tb.begin(), tb.end(), (uint8_t)1);
-      tg.verts.upload(target->points, (size_t)3 * tg.V);
-      tg.tris.upload(target->triangles, (size_t)3 * tg.T);
-      tg.boundary.upload(tb.data(), tb.size());
-      tg.spheres.alloc(sphere_floats4(tg.T));
-      {
-        const std::vector<int> order = coherent_triangle_order(tg.V, tg.T, target->points, target->triangles);
-        tg.tri_order.upload(order.data(), order.size());
-      }
-      launch_tri_spheres(ctx->stream, tg.T, tg.verts.p, tg.tris.p, tg.tri_order.p, tg.spheres.p);
-      HIP_OK(hipStreamSynchronize(ctx->stream));  // (complete before another context may find it)
-      g_shared_targets[tkey] = stg;
-    }
-    ctx->shared_target = stg;
-    {
-      DeviceMesh& tg = ctx->target;
-      const DeviceMesh& o = stg->mesh;
-      tg.V = o.V; tg.T = o.T; tg.n_boundary = o.n_boundary;
-      tg.verts.alias(o.verts); tg.tris.alias(o.tris); tg.tri_order.alias(o.tri_order); tg.spheres.alias(o.spheres); tg.boundary.alias(o.boundary);
-    }
-#endif
 
     ctx->hint_surf.alloc(N); ctx->hint_surf.fill_bytes(0xFF);
     ctx->hint_nnv.alloc(N); ctx->hint_nnv.fill_bytes(0xFF);
@@ -2023,6 +2069,13 @@ int icp_ctx_set_rotation(icp_ctx* ctx, const double* angles, const double* R) {
       }
     const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
     require(det > 0.0, "R is a reflection, not a rotation");
+    {  // the convention check: does the caller's matrix agree with the library's Rz·Ry·Rx for these angles?
+      double own[9];
+      icp_rotation_matrix(angles[0], angles[1], angles[2], own);
+      double dmax = 0.0;
+      for (int k = 0; k < 9; ++k) dmax = std::max(dmax, std::fabs(own[k] - R[k]));
+      if (dmax <= icp_ctx::kRotationTol) ++ctx->rotations_verified; else ++ctx->rotations_mismatched;
+    }
     if (slot) {  // replacement: only if the matrix really differs
       bool differs = false;
       for (int k = 0; k < 9; ++k) differs = differs || slot->R[k] != R[k];
@@ -2041,6 +2094,14 @@ int icp_ctx_set_rotation(icp_ctx* ctx, const double* angles, const double* R) {
     slot->valid = true;
     slot->stamp = ++ctx->rotation_clock;
   });
+}
+
+int icp_ctx_rotation_convention(icp_ctx* ctx, int64_t* verified, int64_t* mismatched) {
+  if (!ctx) return ICP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  if (verified) *verified = ctx->rotations_verified;
+  if (mismatched) *mismatched = ctx->rotations_mismatched;
+  return ICP_OK;
 }
 
 int icp_ctx_runtime_stats(const icp_ctx* ctx, icp_runtime_stats* out) {
@@ -3730,6 +3791,7 @@ struct BatchItem {
 struct icp_step_ticket {
   int n_chains = 0, n_props = 0, nb = 0;
   icp_ctx* lead = nullptr;
+  bool counted = false;  // included in lead->tickets_in_flight
   hipStream_t finish_stream = nullptr;  // where the batch's last launch went, if not lead->stream
   hipStream_t wide_streams[2] = {nullptr, nullptr};  // the streams of the ticket's wide step, if it has one
   std::vector<BatchItem> items;
@@ -3747,6 +3809,7 @@ namespace {
 void wide_release(BatchItem& it, bool recorded = false);
 // whatever happened, nothing stays reserved or locked; a failed batch leaves its launches to drain
 void batch_release(icp_step_ticket& t) {
+  if (t.counted && t.lead) { --t.lead->tickets_in_flight; t.counted = false; }
   for (auto& it : t.items) {
     if ((!it.batched && !it.wide) || !it.e) continue;
     icp_ctx& c = *it.e->ctx;
@@ -3826,7 +3889,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     if (!lead.ev_wide_eval[turn]) HIP_OK(hipEventCreateWithFlags(&lead.ev_wide_eval[turn], hipEventDisableTiming));
     const size_t bytes = wide_batch_bytes(nW);
     if (bytes > lead.wide_bytes[turn]) {
-      // (the slot's previous reader was the batch four tickets ago: collected, its launches finished)
+      // (the slot's previous reader was the batch kBatchRing tickets ago: collected — tickets_in_flight —, its launches finished)
       if (lead.wide_pinned[turn]) { pinned_free(lead.wide_pinned[turn]); lead.wide_pinned[turn] = nullptr; }
       const size_t cap = std::max(bytes, wide_batch_bytes(kWideMaxChains));
       pinned_alloc((void**)&lead.wide_pinned[turn], cap);
@@ -4429,6 +4492,13 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
     icp_ctx& lead = launch_ctx ? *launch_ctx : elead;
     require(lead.device == elead.device, "launch context on another device");
     t.lead = &lead;
+    // (the launch context's rings hold kBatchRing batches: argument slots, eigen records, gate words, events — a ticket more would
+    // rewrite what a batch still on the device reads)
+    if (lead.tickets_in_flight.fetch_add(1) >= icp_ctx::kBatchRing) {
+      --lead.tickets_in_flight;
+      fail(ICP_ERR_BUSY, "the launch context already carries ICP_MAX_BATCHES_IN_FLIGHT uncollected batches: collect or abandon one first");
+    }
+    t.counted = true;
     // ---- which chains share the launches
     int n_batched = 0, wide_first = -1;
     for (int b = 0; b < n_chains; ++b) {
@@ -4488,7 +4558,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       const int turn = (lead.batch_eig_turn = (lead.batch_eig_turn + 1) % icp_ctx::kBatchRing);
       const size_t bytes = eigen_many_record_bytes((int)eigens.rq.size());
       if (bytes > lead.batch_eig_rec_bytes[turn]) {
-        // (the slot's previous reader was the batch four tickets ago: collected, its launches finished)
+        // (the slot's previous reader was the batch kBatchRing tickets ago: collected — tickets_in_flight —, its launches finished)
         if (lead.batch_eig_rec[turn]) { pinned_free(lead.batch_eig_rec[turn]); lead.batch_eig_rec[turn] = nullptr; }
         const size_t cap_bytes = std::max(bytes, eigen_many_record_bytes(128));
         pinned_alloc((void**)&lead.batch_eig_rec[turn], cap_bytes);
@@ -4756,6 +4826,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
   int rc = guard([&] {
     require(n_chains >= 1 && evaluators && props_in && mix && seeds && first_step && theta && log_value && n_steps >= 0, "null argument");
     require(n_props >= 1 && n_props <= 2, "the on-device loop takes one or two ICP proposals per chain");
+    require(mix->struct_size == sizeof(icp_mh_mixture), "icp_mh_mixture::struct_size does not match this library's header");
     require(mix->w_icp > 0.0 && mix->w_rw >= 0.0 && mix->rw_sigma > 0.0 && mix->w_pose >= 0.0, "bad mixture");
     if (mix->w_pose > 0.0)
       for (int a = 0; a < 3; ++a) require(mix->pose_rot_sigma[a] > 0.0 && mix->pose_trans_sigma[a] > 0.0, "pose walk sigmas must be positive");
@@ -4780,8 +4851,10 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       ch.lk = std::unique_lock<std::recursive_mutex>(c.mu);
       if (c.batch_busy) fail(ICP_ERR_BUSY, "a chain's context already belongs to a batch in flight");
       require(step_pipeline_covers(ch.e, n_props, ch.props), "configuration not covered by the merged launches");
-      if (mix->w_pose > 0.0)  // (the device makes the proposed pose's matrix with the library's own convention)
-        for (const auto& re : c.rotations) require(!re.valid, "pose walks on the device: the context has caller-supplied rotation matrices");
+      // (the device makes the proposed pose's matrix with the library's own convention: open to a host whose supplied matrices have
+      // all agreed with it — icp_ctx_set_rotation's check —, closed to one whose convention is another)
+      if (mix->w_pose > 0.0)
+        require(c.rotations_mismatched == 0, "pose walks on the device: a caller-supplied rotation matrix disagreed with the library's Rz·Ry·Rx (icp_ctx_rotation_convention)");
       Bound _b(&c);
       if (ch.e->front.valid) release_front(ch.e->front);
       for (int i = 0; i < n_props; ++i) {
@@ -5019,6 +5092,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       HIP_OK(hipMemcpy(gr.theta.p, hth.data(), sizeof(double) * hth.size(), hipMemcpyHostToDevice));
       // (normals: the two buffers are addressed through MhChain::normals / normals_first, re-pointed per block of steps below)
       HIP_OK(hipMemcpy(gr.mh.p, hm.data(), sizeof(MhChain) * hm.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipStreamSynchronize(nullptr));  // (as DBuf::upload: the copies have reached the device before a non-blocking stream's launch reads them)
     }
     // ---- the loop: per block of kChunk steps the chains' standard normals (the harness' own expression, drawn here on the host
     // while the device works on the block before), then per step and group eight launches, nothing waited for

@@ -767,7 +767,9 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   u64 propw = 0ull;
   if (has_next && pb < 4) propw = pb < 2 ? ((const u64*)&c.prop_alt[pb][gen_n < 0 ? 0 : gen_n])[pw] : ((const u64*)&c.begin_alt[pb - 2]->prop)[pw];
 
-  const unsigned long long bad_chol = __ballot(st_chol != 0), bad_tail = __ballot(st_tail != 0);
+  // (a pose move's transition tails are discarded — fw_i = bw_i = −∞, NonRigidIcpProposal.scala:69-71: the reference and the
+  // host-stepped wide step never look at them, so a tail that fell back on such a step must not stop the chain)
+  const unsigned long long bad_chol = __ballot(st_chol != 0), bad_tail = pose_move ? 0ull : __ballot(st_tail != 0);
   int err = bad_chol ? 3 : (bad_tail ? 2 : 0);
   if (__ballot(st_eig != 0) && !err) err = 6;
   // ---- evaluators: ModelPriorEvaluator (:24-31), the likelihood from launch 4's reductions (finish_eval), ProductEvaluator

@@ -484,6 +484,7 @@ static int run_on_device(icp_host_chain* const* chains, int32_t n_chains, int32_
       if (a.icp_weight[i] != z.icp_weight[i]) return ICP_ERR_INVALID_ARG;
   }
   icp_mh_mixture mix{};
+  mix.struct_size = sizeof(icp_mh_mixture);
   for (size_t i = 0; i < n_icp; ++i) mix.icp_weight[i] = c0->cfg.icp_weight[i];
   mix.w_icp = c0->cfg.w_icp; mix.w_rw = c0->cfg.w_rw; mix.rw_sigma = c0->cfg.rw_sigma;
   mix.w_pose = c0->cfg.w_pose > 0 ? c0->cfg.w_pose : 0.0;  // (the six pose walks: on the device too, include/icp_sincos.h)
@@ -567,7 +568,8 @@ int icp_host_chains_run_batched(icp_host_chain* const* chains, int32_t n_chains,
       n_steps -= n_dev;
     }
   }
-  constexpr int kMaxGroups = 8;
+  // (every group submits through groups[0]'s launch context, whose rings hold ICP_MAX_BATCHES_IN_FLIGHT batches: never more groups)
+  constexpr int kMaxGroups = ICP_MAX_BATCHES_IN_FLIGHT;
   LockstepGroup groups[kMaxGroups];
   int rc = host_guard([&] {
     if (!chains || n_chains < 1 || n_steps < 0) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chains_run_batched");

@@ -149,6 +149,13 @@ ICP_API int icp_ctx_device(const icp_ctx *ctx);
  * cached under thetas with these angles (instances, posteriors of every proposal, memoised likelihood values) is dropped, so a
  * later call recomputes it with the new matrix; registering before the first use of a triple costs nothing. */
 ICP_API int icp_ctx_set_rotation(icp_ctx *ctx, const double angles[3], const double R[9]);
+/* The convention check behind it: every matrix handed to icp_ctx_set_rotation is compared with the library's own
+ * Rz(phi)·Ry(theta)·Rx(psi) for the same angles (include/icp_sincos.h).  *verified counts the matrices that agreed to rounding
+ * (2e-15 per entry), *mismatched the ones that did not (either may be NULL).  A host with mismatched == 0 — the Scala adapter, if
+ * Scalismo's Rotation(phi, theta, psi, centre) is Rz·Ry·Rx as SURVEY App. B8 assumes — may run mixtures WITH pose walks through
+ * icp_chains_run_on_device, where the proposed pose's matrix is made on the device; one mismatch closes that path for the context
+ * (ICP_ERR_INVALID_ARG there; every host-stepped entry point keeps using the caller's matrices as before). */
+ICP_API int icp_ctx_rotation_convention(icp_ctx *ctx, int64_t *verified, int64_t *mismatched);
 
 /* ModelFittingParameters.transformedMesh (ModelFittingParameters.scala:108-110): points_out [N*3]. */
 ICP_API int icp_transformed_mesh(icp_ctx *ctx, const double *theta, double *points_out);
@@ -307,7 +314,9 @@ ICP_API int icp_chain_step_batched(int32_t n_chains, icp_evaluator *const *evalu
  * ICP_ERR_BUSY.  _abandon waits for the batch's launches and drops the step (nothing of it is recorded).  launch_ctx (may be NULL: the
  * first chain's context) names the context whose stream carries the launches: two batches given the SAME launch_ctx run
  * their launches one behind the other while the decompositions of the second run beside the launches of the first — at
- * most four tickets per launch_ctx at a time, collected in the order they were issued. */
+ * most ICP_MAX_BATCHES_IN_FLIGHT tickets per launch_ctx at a time (one more: ICP_ERR_BUSY, nothing issued), collected in the
+ * order they were issued. */
+#define ICP_MAX_BATCHES_IN_FLIGHT 8
 typedef struct icp_step_ticket icp_step_ticket;
 ICP_API int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator *const *evaluators, int32_t n_props,
                                          icp_proposal *const *props, const int32_t *generator,
@@ -327,7 +336,8 @@ ICP_API int icp_chain_step_batched_abandon(icp_step_ticket *ticket);
  *   Mixture: (w_icp: the n_props ICP proposals with icp_weight) + (w_rw: shape random walk of rw_sigma) in the reference's order
  *   (apps/femur/IcpProposalRegistration.scala:70-72), optionally behind the six pose walks (w_pose > 0: apps/bfm/BfmFittingPartial.scala:70;
  *   the proposed pose's rotation matrix is made on the device with include/icp_sincos.h, the sines and cosines the host side and the
- *   oracle use — contexts with caller-supplied rotation matrices, icp_ctx_set_rotation, are not covered); product evaluator = shape
+ *   oracle use — a context whose caller-supplied rotation matrices, icp_ctx_set_rotation, have all agreed with that convention is
+ *   covered, one that ever supplied a different matrix is not: icp_ctx_rotation_convention); product evaluator = shape
  *   prior × `evaluator`.
  *   Random numbers: the counter-based generator of the C++ harness (host/icp_host.hpp StepRandom, shared bit for bit with the oracle):
  *   stream (seeds[b], step, lane), steps first_step[b] .. first_step[b] + n_steps − 1.
@@ -337,6 +347,9 @@ ICP_API int icp_chain_step_batched_abandon(icp_step_ticket *ticket);
  * device); otherwise ICP_ERR_INVALID_ARG and nothing has run.  Results are those of icp_chain_step_batched driven by the harness,
  * chain by chain (tests/test_gpu_chain.py::test_device_loop_*). */
 typedef struct {
+  /* = sizeof(icp_mh_mixture) of the header the caller was compiled against; anything else is refused with ICP_ERR_INVALID_ARG (the
+   * structure grew in round 4: a caller built against the shorter one must not have its memory read past its end) */
+  uint64_t struct_size;
   double icp_weight[2];
   double w_icp, w_rw;
   double rw_sigma;

@@ -112,13 +112,13 @@ def test_round3_entry_points_reject_bad_arguments_before_device(pkg):
     """icp_chains_run_on_device, icp_proposal_set_sampler, icp_ctx_profile_search_counters: null / empty argument lists come back with
     ICP_ERR_INVALID_ARG and touch no device (this runs without a GPU)."""
     lib, nat = pkg._native.lib(), pkg._native
-    mix = nat.MhMixture((ctypes.c_double * 2)(0.5, 0.5), 0.9, 0.1, 0.1)
+    mix = nat.MhMixture(ctypes.sizeof(nat.MhMixture), (ctypes.c_double * 2)(0.5, 0.5), 0.9, 0.1, 0.1)
     assert lib.icp_chains_run_on_device(0, None, 1, None, ctypes.byref(mix), None, None, None, None, 10, None, None) == -1
     assert lib.icp_chains_run_on_device(1, None, 1, None, None, None, None, None, None, 10, None, None) == -1
     assert b"null argument" in lib.icp_last_error()
     assert lib.icp_proposal_set_sampler(None, 1) == -1
     assert lib.icp_ctx_profile_search_counters(None, 1) == -1
-    assert ctypes.sizeof(nat.MhMixture) == 96  # (round 4: + w_pose and the six pose walks' sigmas)
+    assert ctypes.sizeof(nat.MhMixture) == 104  # (round 4: + w_pose and the six pose walks' sigmas; round 5: struct_size in front)
 
 
 def test_synthetic_target_sizes(pkg):
