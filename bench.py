@@ -47,6 +47,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 F32_VECTOR_TFLOPS = 157.3  # same guide: peak FP32 vector (the filters run on packed f32; the exact resolves in f64)
 F64_VECTOR_TFLOPS = 78.6   # AMD's public MI355X figure for vector FP64 (not in the local guide; SURVEY.md §8d uses it)
+F64_MATRIX_TFLOPS = 78.6   # … and for matrix FP64 (v_mfma_f64_16x16x4: 1,024 multiply-adds in 32 cycles per SIMD = the vector rate)
+N_SIMD = 256 * 4           # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+N_XCD = 8
 METRIC = "ICP-proposal MH iterations/sec (femur GPMM r=50, ~50k-vtx target)"
 
 
@@ -280,6 +283,137 @@ def kernel_algorithmic_bytes(name, model, target, setup):
     return None
 
 
+
+# ---------------------------------------------------------------------------------------------- CPU baseline: the reference's own parallelism
+def oracle_chain_setup(O, wl):
+    """the oracle's model / target / chain configuration of a workload (cpu_baseline legs only)"""
+    model, target, setup = wl["model"], wl["target"], wl["setup"]
+    om, ot = O.OracleModel.from_model(model), O.OracleMesh(target.points, target.cells)
+    icp = [O.proposal_params(p["step"], p["sigma_t"], p["sigma_n"], p["direction"], p.get("boundary_aware", True),
+                             n_model_ids=p.get("n_model_ids", 0), target_pts=p.get("target_pts")) for p in setup.icp]
+    e = setup.eval
+    ep = O.evaluator_params(e["kind"], e["mode"], n_model_ids=e["n_model_ids"], target_pts=e["target_pts"],
+                            p0=e["gauss_mean"] if e["kind"] != 1 else e["exp_rate"], p1=e["gauss_sigma"], p2=e["exp_rate"])
+    cfg = O.chain_config(icp, [p.get("weight", 0.5) for p in setup.icp], setup.w_icp, setup.w_rw, setup.rw_sigma, ep, w_pose=setup.w_pose,
+                         pose_rot_sigma=setup.pose_rot_sigma, pose_trans_sigma=setup.pose_trans_sigma)
+    return om, ot, cfg
+
+
+def b1_child(args):
+    """One of the processes of `b1_parallel` (never touches a GPU): a B1 chain of its own — oracle/, KD-tree + BVH, one thread — of the
+    named configuration's workload.  Protocol over stdin/stdout: prints {"ready": seconds per step of a two-step probe} once its data and
+    the static target's structures exist, reads "go <n>", runs n steps, prints {"steps": n, "seconds": ...}."""
+    import __graft_entry__ as graft
+    pkg = graft.load_package()  # (numpy side only: the HIP library is loaded on first use, and nothing here uses it)
+    from oracle import oracle as O
+    cfg_i, gid = args.b1_child
+    if cfg_i == 4:    # one (target, chain) item of the batch registration: target gid // 10, random start gid % 10
+        model = face_model(pkg, args)
+        target = pkg.data.synthetic_partial_target(model, seed=100 + gid // 10)
+        wl = dict(model=model, target=target, setup=pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=args.fused),
+                  init=lambda g: pkg.random_initial_parameters(model, g % 10))
+    else:
+        wl = build_workload(pkg, cfg_i, args.subdiv, args.fused, args)
+    om, ot, cfg = oracle_chain_setup(O, wl)
+    theta0 = wl["init"](gid)
+    O.set_search_backend(O.SEARCH_TREES)
+    O.run_chain(om, ot, cfg, theta0, 1024 + gid, 1)  # (builds the static target's structures, as the reference does once)
+    t = time.perf_counter()
+    O.run_chain(om, ot, cfg, theta0, 1024 + gid, 2)
+    print(json.dumps({"ready": (time.perf_counter() - t) / 2}), flush=True)
+    word = sys.stdin.readline().split()
+    n = int(word[1]) if len(word) == 2 and word[0] == "go" else 0
+    if n <= 0:
+        return
+    t = time.perf_counter()
+    O.run_chain(om, ot, cfg, theta0, 1024 + gid, n)
+    print(json.dumps({"steps": n, "seconds": time.perf_counter() - t}), flush=True)
+
+
+def b1_parallel(args, cfg_i, n_chains, budget_s, max_procs=64):
+    """The reference's own CPU parallelism (RunMHRandomInitComparison.scala:66 `.par` over chains,
+    StdIcpVsChainICPrandomInitComparisonAll.scala:106-108 over targets): P = min(chains, cores this process may use, max_procs)
+    INDEPENDENT B1 chains — one single-threaded process each — running at the same time; value = steps of all of them / the longest
+    one's wall time.  The chains start together (a "go" after every process has its data) and take about `budget_s` seconds."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    P = max(1, min(n_chains, avail, max_procs))
+    base = [sys.executable, os.path.abspath(__file__), "--subdiv", str(args.subdiv), "--fused", str(args.fused),
+            "--face-grid", str(args.face_grid), "--face-rank", str(args.face_rank)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen(base + ["--b1-child", str(cfg_i), str(g)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env) for g in range(P)]
+    try:
+        probes = [json.loads(p.stdout.readline())["ready"] for p in procs]
+        probe = sorted(probes)[len(probes) // 2]
+        n = int(max(1, min(400, budget_s / max(probe, 1e-6))))
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go %d\n" % n)
+            p.stdin.flush()
+        res = [json.loads(p.stdout.readline()) for p in procs]
+        wall = time.perf_counter() - t0
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in procs:
+            p.wait()
+    longest = max(r["seconds"] for r in res)
+    return {"value": P * n / max(longest, 1e-9), "unit": "iterations/s", "cores": P, "chains": P, "steps_per_chain": n,
+            "longest_chain_s": longest, "wall_s": wall, "per_chain_it_s": [round(r["steps"] / r["seconds"], 2) for r in res][:8],
+            "host_logical_cores": os.cpu_count() or 0, "cores_available_to_this_process": avail,
+            "what": "%d independent B1 chains (oracle/, KD-tree + BVH, one thread each, one process each) at the same time — the reference's own "
+                    "parallelism over chains / targets (RunMHRandomInitComparison.scala:66, StdIcpVsChainICPrandomInitComparisonAll.scala:106-108); "
+                    "value = all their steps / the longest chain's time" % P,
+            "sample": "%d chains x %d MH steps of BASELINE.json configs[%d]" % (P, n, cfg_i)}
+
+
+def mfma_block(config_key, kernels, live_us, flops):
+    """MFMA utilisation of the projection kernels (north_star: "MFMA utilisation on the projection … against gfx950 peak"), two ways:
+      counter: SQ_VALU_MFMA_BUSY_CYCLES / (N_SIMD x GRBM_GUI_ACTIVE / N_XCD) per launch, both counters from ONE rocprofv3 --pmc pass
+               (profiles/r05_pmc_mfma.json; SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, summed over the chip's 1,024 SIMDs;
+               rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs — MI355X_MICROARCH.md "DVFS give-back" —, so /8 = the launch's
+               cycles);
+      flops:   algorithmic f64 multiply-add flops of one launch / the launch's duration measured in THIS run (HIP events) / the dense
+               matrix-f64 peak."""
+    out = {"peak_TFLOPs": F64_MATRIX_TFLOPS,
+           "formula": "busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (%d SIMDs x GRBM_GUI_ACTIVE / %d XCDs); flops_frac = algorithmic f64 flops per launch / "
+                      "avg launch duration (HIP events, this run) / %.1f TFLOP/s" % (N_SIMD, N_XCD, F64_MATRIX_TFLOPS), "kernels": {}}
+    pmc = {}
+    for tname in ("r05_pmc_mfma.json", "r04_pmc_mfma.json"):
+        tfile = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tfile):
+            pmc = json.load(open(tfile)).get(config_key, {})
+            out["counter_source"] = "profiles/" + tname + " (a tracked file from a rocprofv3 --pmc pass of the same command, NOT measured in this run)"
+            if pmc:
+                break
+    for k in kernels:
+        row = {}
+        c = pmc.get(k, {})
+        busy, act = c.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("median"), c.get("GRBM_GUI_ACTIVE", {}).get("median")
+        if busy is not None and act:
+            row.update(SQ_VALU_MFMA_BUSY_CYCLES=busy, GRBM_GUI_ACTIVE=act, busy_frac=busy / (N_SIMD * act / N_XCD))
+        if k in live_us and flops.get(k):
+            row.update(avg_launch_us=live_us[k], algorithmic_f64_flops=flops[k], achieved_TFLOPs=flops[k] / (live_us[k] * 1e-6) / 1e12,
+                       flops_frac=flops[k] / (live_us[k] * 1e-6) / 1e12 / F64_MATRIX_TFLOPS)
+        if row:
+            out["kernels"][k] = row
+    return out
+
+
+def projection_flops(model, setup):
+    """algorithmic f64 flops of ONE regression launch (all of the step's posteriors): per correspondence four rank-1 terms (the three
+    rows of Q_i and Q_i^T n_i) on the lower triangle incl. diagonal of the (r+1) x (r+1) normal equations, 2 flops per multiply-add"""
+    r = model.rank
+    tri = (r + 1) * (r + 2) // 2
+    tot = 0
+    for p in setup.icp:
+        K = p.get("n_model_ids", 0) if p["direction"] == 0 else np.asarray(p.get("target_pts", np.zeros((0, 3)))).reshape(-1, 3).shape[0]
+        tot += 2 * 4 * K * tri
+    return float(tot)
+
+
 # ---------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -311,8 +445,16 @@ def main():
     ap.add_argument("--sampler", type=str, default="eigen", choices=["eigen", "cholesky-root"],
                     help="posterior.sample() of the timed chain: the reference's KL basis (default, the parity path) or the opt-in Cholesky-root "
                          "sampler (NOT the reference's arithmetic: DESIGN.md §5.7; the line then carries \"sampler\": \"cholesky-root\")")
+    ap.add_argument("--parallel-cpu-budget", type=float, default=8.0,
+                    help="seconds of the B1_parallel leg of the CPU baseline (min(chains, cores) independent one-thread oracle chains at once; 0 = skip)")
+    ap.add_argument("--events-out", type=str, default="",
+                    help="also write the per-kernel HIP-event table of the roofline leg (durations WITHOUT device-side waits, the waits beside them) to this json file")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--b1-child", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.b1_child is not None:
+        b1_child(args)
+        return
 
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not under_launcher and args.gpus > 1:
@@ -568,6 +710,14 @@ def config4_leg(pkg, args, device):
                                      "contexts_built": int(stats["contexts_built"]), "phase_ms": stats.get("phase_ms")}
     out["value"] = out["steps_300"]["value"]
     out["runtime_stats"] = pkg._native.runtime_stats()
+    out["step_paths_process"] = pkg._native.step_paths() if hasattr(pkg._native, "step_paths") else None
+    if args.parallel_cpu_budget > 0 and args.cpu_steps > 0:
+        # the batch job on the host cores, the reference's way: one single-threaded B1 chain per work item, as many at a time as there
+        # are cores (bounded: 32 processes of ~0.5 GB each)
+        try:
+            out["cpu_baseline"] = dict(b1_parallel(args, 4, 100, args.parallel_cpu_budget, max_procs=32), kind="port")
+        except Exception as e:
+            out["cpu_baseline"] = {"error": str(e)[:300]}
     return out
 
 
@@ -653,7 +803,11 @@ def leg_roofline(pkg, ctx, chain, wl, n_prof, rate, accepted_share, icp_share):
     if alg is not None:
         roof["achieved"] = alg / (k["avg_us"] * 1e-6) / 1e9
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    reg = "k_step_regression"
+    if reg in stats:
+        flops = {reg: projection_flops(model, setup), "k_tri_gemm": 2.0 * model.rank ** 3}
+        roof["mfma"] = mfma_block("config%d" % wl["config"], [reg] + (["k_tri_gemm"] if model.rank > 64 else []), {reg: stats[reg]["avg_us"]}, flops)
+    for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile):
             per_kernel = json.load(open(tfile)).get("config%d" % wl["config"], {})
@@ -829,8 +983,8 @@ def roofline_leg(pkg, args, wl, ctx, chains, B, rate, line):
     if B > 1:
         chains_per_launch = B * args.profile_steps / max(k["calls"], 1)
         alg = alg * chains_per_launch if alg is not None else None
-    traffic = None
-    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    traffic = traffic_source = None
+    for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile) and B == 1:
             per_kernel = json.load(open(tfile)).get("config%d" % args.config, {})
@@ -839,6 +993,8 @@ def roofline_leg(pkg, args, wl, ctx, chains, B, rate, line):
                 # ranks above 64: "k_posterior_eigen" of the event timing is the tridiagonal route's launch sequence
                 traffic = sum(per_kernel[k]["hbm_bytes_per_launch"] * (3 if k == "k_tri_gemm" else 1) for k in ("k_tridiag", "k_tri_solve", "k_tri_gemm") if k in per_kernel)
             if traffic is not None:
+                traffic_source = ("profiles/" + tname + ": 2 x FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass of this command, a TRACKED FILE — "
+                                  "not measured in this run (counter passes cannot share a run with the timing)")
                 break
     has_boundary = bool(pkg.data.boundary_vertex_flags(target).any())
     bytes_step, flops_step = algorithmic_step(model, target, setup, has_boundary)
@@ -846,7 +1002,7 @@ def roofline_leg(pkg, args, wl, ctx, chains, B, rate, line):
     accept_share = line["config"]["accepted"] / max(args.steps * B, 1)
     one_cu = dominant.startswith(SINGLE_WORKGROUP)
     roof = {"bound": "latency" if one_cu else "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
-            "kernel": dominant, "avg_launch_us": avg_us, "launches": k["calls"], "algorithmic_bytes": alg,
+            "traffic_source": traffic_source, "kernel": dominant, "avg_launch_us": avg_us, "launches": k["calls"], "algorithmic_bytes": alg,
             "chains_per_launch": chains_per_launch,
             "selection": "time-dominant kernel of this run: largest sum of launch durations (HIP events on the launch streams), "
                          "WITHOUT the time a launch waits on the device for another stream's word (k_step_begin: the previous step's "
@@ -901,6 +1057,30 @@ def roofline_leg(pkg, args, wl, ctx, chains, B, rate, line):
             roof["distance_kernel"] = {"kernel": dk, "avg_launch_us": davg, "launches": stats[dk]["calls"], "algorithmic_bytes": dalg,
                                        "achieved_GBs": dalg / (davg * 1e-6) / 1e9, "frac_hbm": dalg / (davg * 1e-6) / 1e9 / HBM_PEAK_GBS}
             break
+    # the projection on the matrix cores (north_star): counter-based busy fraction + algorithmic flops against the matrix-f64 peak
+    reg = "k_step_regression"
+    if reg in stats:
+        per_launch = B * args.profile_steps / max(stats[reg]["calls"], 1) if B > 1 else 1.0
+        roof["mfma"] = mfma_block("config%d" % args.config if B == 1 else "many_chains", [reg], {reg: stats[reg]["avg_us"]},
+                                  {reg: projection_flops(model, setup) * per_launch})
+    if args.events_out:
+        # per-kernel durations of this leg, device-side waiting taken out (the rocprof average of a launch that spins on the
+        # device for its input contains the wait; these do not) — copied into profiles/ by tools/r5_profiles.sh
+        table = {}
+        for name, s_ in stats.items():
+            w = waits.get(name)
+            wait_ms = w["total_ms"] if w is not None else 0.0
+            table[name] = {"calls": s_["calls"], "avg_us_with_device_wait": s_["avg_us"], "device_wait_avg_us": 1e3 * wait_ms / max(s_["calls"], 1),
+                           "avg_us": 1e3 * max(s_["total_ms"] - wait_ms, 0.0) / max(s_["calls"], 1), "min_us": s_["min_us"], "max_us": s_["max_us"],
+                           "algorithmic_bytes_per_launch": kernel_algorithmic_bytes(name, model, target, setup)}
+            ab = table[name]["algorithmic_bytes_per_launch"]
+            if ab and table[name]["avg_us"] > 0:
+                table[name]["algorithmic_GBs"] = ab / (table[name]["avg_us"] * 1e-6) / 1e9
+                table[name]["frac_hbm"] = table[name]["algorithmic_GBs"] / HBM_PEAK_GBS
+        json.dump({"command": "python3 " + " ".join(sys.argv), "source": "HIP events around every launch on its own stream (icp_ctx_profile_*), "
+                   "%d steps after the timed region; `avg_us` excludes the time a launch waits ON THE DEVICE for another stream's word "
+                   "(k_step_begin: the decomposition it draws from; k_posterior_eigen: its input when started ahead)" % args.profile_steps,
+                   "steps": args.profile_steps, "iterations_per_s": rate, "dominant": dominant, "kernels": table}, open(args.events_out, "w"), indent=1)
     line["kernel_us_per_step"] = {name: round(s["total_ms"] * 1e3 / args.profile_steps, 2) for name, s in stats.items()}
     for name, w in waits.items():
         if w is not None:
@@ -919,15 +1099,7 @@ def cpu_baseline_leg(pkg, args, wl, ctx):
     (tests/test_oracle.py::test_chain_identical_under_every_search_backend); the first GPU records are checked against B1 here."""
     from oracle import oracle as O
     model, target, setup = wl["model"], wl["target"], wl["setup"]
-    om, ot = O.OracleModel.from_model(model), O.OracleMesh(target.points, target.cells)
-    icp = [O.proposal_params(p["step"], p["sigma_t"], p["sigma_n"], p["direction"], p.get("boundary_aware", True),
-                             n_model_ids=p.get("n_model_ids", 0), target_pts=p.get("target_pts")) for p in setup.icp]
-    e = setup.eval
-    ep = O.evaluator_params(e["kind"], e["mode"], n_model_ids=e["n_model_ids"], target_pts=e["target_pts"],
-                            p0=e["gauss_mean"] if e["kind"] != 1 else e["exp_rate"], p1=e["gauss_sigma"], p2=e["exp_rate"])
-    # the whole mixture, pose walks included (the oracle's chain has them since round 3)
-    cfg = O.chain_config(icp, [p.get("weight", 0.5) for p in setup.icp], setup.w_icp, setup.w_rw, setup.rw_sigma, ep, w_pose=setup.w_pose,
-                         pose_rot_sigma=setup.pose_rot_sigma, pose_trans_sigma=setup.pose_trans_sigma)
+    om, ot, cfg = oracle_chain_setup(O, wl)  # (the whole mixture, pose walks included: the oracle's chain has them since round 3)
     theta0 = wl["init"](0)
     # cores this process may run on (a container's CPU set, not the machine's count); the B2 scans run per query, so beyond a
     # few dozen threads the fork/join of every scan costs more than it spreads (measured: 256 threads on 116k triangles: 125 s per step)
@@ -967,7 +1139,14 @@ def cpu_baseline_leg(pkg, args, wl, ctx):
     same = bool(np.array_equal(crec[:, 1].astype(np.uint8), acc_o)) and bool(np.array_equal(crec[:, 2].astype(np.int32), comp_o)) and \
         float(np.abs(crec[:, 14:] - states_o[:, 10:]).max()) <= 1e-5 * max(float(np.abs(states_o[:, 10:]).max()), 1e-30)
     chk.close()
-    return {"value": out["B1"]["value"], "unit": "iterations/s", "cores": 1, "kind": "port",
+    b1p = None
+    if args.parallel_cpu_budget > 0 and args.config == 1:
+        # the many-chains leg's counterpart on the host: one B1 chain per core (the reference's `.par` over chains), as many as that leg steps
+        try:
+            b1p = b1_parallel(args, args.config, max(args.many_chains, 1), args.parallel_cpu_budget)
+        except Exception as e:
+            b1p = {"error": str(e)[:300]}
+    return {"value": out["B1"]["value"], "unit": "iterations/s", "cores": 1, "kind": "port", "B1_parallel": b1p,
             "sample": "B1 of BASELINE.md §3 (the baseline the >= 50x target is defined on): %s of the same workload, one thread; host has %d logical cores%s"
                       % (out["B1"]["sample"], os.cpu_count() or 0, ""),
             "B1": out["B1"], "B2": out["B2"], "gpu_matches_oracle_on_sample": same}
