@@ -393,7 +393,11 @@ def mfma_block(config_key, kernels, live_us, flops):
         c = pmc.get(k, {})
         busy, act = c.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("median"), c.get("GRBM_GUI_ACTIVE", {}).get("median")
         if busy is not None and act:
-            row.update(SQ_VALU_MFMA_BUSY_CYCLES=busy, GRBM_GUI_ACTIVE=act, busy_frac=busy / (N_SIMD * act / N_XCD))
+            row.update(SQ_VALU_MFMA_BUSY_CYCLES=busy, GRBM_GUI_ACTIVE=act,
+                       busy_frac=c.get("busy_frac_median") if c.get("busy_frac_median") is not None else busy / (N_SIMD * act / N_XCD))
+            if c.get("median_us") is not None and flops.get(k) and k not in live_us:  # (no event id of its own: the counter pass's dispatch timestamps)
+                row.update(avg_launch_us=c["median_us"], duration_source="the counter pass", algorithmic_f64_flops=flops[k],
+                           flops_frac=flops[k] / (c["median_us"] * 1e-6) / 1e12 / F64_MATRIX_TFLOPS)
         if k in live_us and flops.get(k):
             row.update(avg_launch_us=live_us[k], algorithmic_f64_flops=flops[k], achieved_TFLOPs=flops[k] / (live_us[k] * 1e-6) / 1e12,
                        flops_frac=flops[k] / (live_us[k] * 1e-6) / 1e12 / F64_MATRIX_TFLOPS)

@@ -896,12 +896,15 @@ void* device_alloc(size_t bytes) {
   // test hook (tests/test_gpu_edges.py): the n-th allocation of the process "fails" as if the device were full while the pool holds blocks
   static const long fail_at = dev_env("ICP_TEST_FAIL_MALLOC_AT") ? std::atol(dev_env("ICP_TEST_FAIL_MALLOC_AT")) : 0;
   static std::atomic<long> n_malloc{0};
-  if (fail_at > 0 && e == hipSuccess && ++n_malloc == fail_at) { (void)hipFree(p); p = nullptr; e = hipErrorOutOfMemory; }
+  const bool forced = fail_at > 0 && e == hipSuccess && ++n_malloc == fail_at;
+  if (forced) { (void)hipFree(p); p = nullptr; e = hipErrorOutOfMemory; }
   if (e != hipSuccess) {
     // Blocks are kept by exact size: after a change of model, K, rank or scratch size the kept ones fit nothing and only take the
     // room this allocation needs — they are given back to the runtime, and the allocation is tried once more
     (void)hipGetLastError();
-    if (drain_device_pool() > 0) e = hipMalloc(&p, bytes);
+    const size_t drained = drain_device_pool();
+    if (forced) std::fprintf(stderr, "[icp test hook] hipMalloc #%ld failed on purpose; the pool gave back %zu bytes\n", fail_at, drained);
+    if (drained > 0) e = hipMalloc(&p, bytes);
     if (e != hipSuccess) fail(ICP_ERR_DEVICE, std::string("hipMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
   }
   if (g_pool.on && have_dev) {

@@ -152,9 +152,12 @@ def test_device_pool_is_drained_and_the_allocation_retried(pkg, tmp_path):
     res = {}
     for tag, env in (("plain", {}), ("failing", {"ICP_TEST_FAIL_MALLOC_AT": "600"})):
         path = str(tmp_path / (tag + ".npz"))
-        subprocess.run([sys.executable, "-c", _POOL_SCRIPT.format(root=ROOT, out=path)], check=True,
-                       env={**os.environ, "ICP_LIBRARY_PATH": hooks, **env}, timeout=600)
+        done = subprocess.run([sys.executable, "-c", _POOL_SCRIPT.format(root=ROOT, out=path)], check=True, capture_output=True, text=True,
+                              env={**os.environ, "ICP_LIBRARY_PATH": hooks, **env}, timeout=600)
         res[tag] = np.load(path)
+        if env:  # the forced failure happened, and with blocks in the pool (they were given back before the retry)
+            hook = [ln for ln in done.stderr.splitlines() if "[icp test hook] hipMalloc" in ln]
+            assert hook and int(hook[0].split("gave back")[1].split()[0]) > 0, done.stderr[-2000:]
     for k in ("a", "b", "c"):
         assert np.array_equal(res["plain"][k], res["failing"][k]), k
     assert np.array_equal(res["plain"]["a"], res["plain"]["b"])
