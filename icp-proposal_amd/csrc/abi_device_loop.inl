@@ -1,0 +1,478 @@
+// abi_device_loop.inl — part of icp_abi.hip (one translation unit; included there, in order).
+// C ABI: icp_chains_run_on_device (the whole MH loop on the device) and the remaining queries
+extern "C" {
+// --------------------------------------------------------------------- the whole MH loop on the device (MhChain, kernels_step.hip)
+int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props_in,
+                             const icp_mh_mixture* mix, const uint64_t* seeds, const int64_t* first_step, double* const* theta,
+                             double* log_value, int32_t n_steps, double* const* records, int64_t* accepted) {
+  struct Chain {
+    icp_evaluator* e = nullptr;
+    icp_proposal* props[2] = {nullptr, nullptr};
+    PosteriorEntry* set[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [sel][proposal]
+    StateSlot* slot = nullptr;
+    std::unique_lock<std::recursive_mutex> lk;
+    bool busy = false;
+  };
+  std::vector<Chain> chains;
+  auto release = [&]() {
+    for (auto& ch : chains) {
+      if (!ch.e) continue;
+      icp_ctx& c = *ch.e->ctx;
+      if (!ch.lk.owns_lock()) ch.lk = std::unique_lock<std::recursive_mutex>(c.mu);
+      for (int sel = 0; sel < 2; ++sel)
+        for (int i = 0; i < 2; ++i)
+          if (ch.set[sel][i]) ch.set[sel][i]->reserved = false;
+      if (ch.slot) ch.slot->reserved = false;
+      if (ch.busy) c.batch_busy = false;
+      ch.lk.unlock();
+    }
+  };
+  int rc = guard([&] {
+    require(n_chains >= 1 && evaluators && props_in && mix && seeds && first_step && theta && log_value && n_steps >= 0, "null argument");
+    require(n_props >= 1 && n_props <= 2, "the on-device loop takes one or two ICP proposals per chain");
+    require(mix->struct_size == sizeof(icp_mh_mixture), "icp_mh_mixture::struct_size does not match this library's header");
+    require(mix->w_icp > 0.0 && mix->w_rw >= 0.0 && mix->rw_sigma > 0.0 && mix->w_pose >= 0.0, "bad mixture");
+    if (mix->w_pose > 0.0)
+      for (int a = 0; a < 3; ++a) require(mix->pose_rot_sigma[a] > 0.0 && mix->pose_trans_sigma[a] > 0.0, "pose walk sigmas must be positive");
+    chains.resize(n_chains);
+    icp_ctx& lead = *evaluators[0]->ctx;
+    const int r = lead.r, P = 10 + r;
+    require(eigen_speculation_supported(r), "the on-device loop covers ranks 3..64");
+    // ---- claim the chains' contexts, fix their posterior entries and state slot
+    for (int b = 0; b < n_chains; ++b) {
+      Chain& ch = chains[b];
+      require(evaluators[b] && theta[b], "null argument");
+      icp_ctx& c = *evaluators[b]->ctx;
+      require(c.device == lead.device && c.r == r, "chains of one run share a device and a rank");
+      for (int a = 0; a < b; ++a) require(chains[a].e->ctx != &c, "every chain needs a context of its own");
+      ch.e = evaluators[b];
+      for (int i = 0; i < n_props; ++i) {
+        ch.props[i] = props_in[(size_t)b * n_props + i];
+        require(ch.props[i] && ch.props[i]->ctx == &c, "proposal belongs to another context");
+        require(ch.props[i]->sampler == ch.props[0]->sampler && ch.props[i]->sampler == chains[0].props[0]->sampler, "one sampler per run");
+      }
+      check_theta_finite(&c, theta[b]);
+      ch.lk = std::unique_lock<std::recursive_mutex>(c.mu);
+      if (c.batch_busy) fail(ICP_ERR_BUSY, "a chain's context already belongs to a batch in flight");
+      require(step_pipeline_covers(ch.e, n_props, ch.props), "configuration not covered by the merged launches");
+      // (the device makes the proposed pose's matrix with the library's own convention: open to a host whose supplied matrices have
+      // all agreed with it — icp_ctx_set_rotation's check —, closed to one whose convention is another)
+      if (mix->w_pose > 0.0)
+        require(c.rotations_mismatched == 0, "pose walks on the device: a caller-supplied rotation matrix disagreed with the library's Rz·Ry·Rx (icp_ctx_rotation_convention)");
+      Bound _b(&c);
+      if (ch.e->front.valid) release_front(ch.e->front);
+      for (int i = 0; i < n_props; ++i) {
+        icp_proposal* p = ch.props[i];
+        p->resolve_speculation(theta[b]);
+        PosteriorEntry& cur = p->posterior(theta[b], false);  // the current state's posterior and its basis, the ordinary way
+        p->ensure_eigen(cur);
+        cur.reserved = true;
+        ch.set[0][i] = &cur;
+        PosteriorEntry& other = p->fresh_entry();
+        other.reserved = true;
+        ch.set[1][i] = &other;
+      }
+      HIP_OK(hipStreamSynchronize(c.stream));
+      HIP_OK(hipStreamSynchronize(c.front_stream));
+      sync_eigen(c);
+      for (int i = 0; i < n_props; ++i) sync_proposal_status(ch.props[i]);
+      HIP_OK(hipStreamSynchronize(c.stream));
+      for (int i = 0; i < n_props; ++i) {
+        ch.props[i]->check_status(*ch.set[0][i]);
+        if (ch.props[i]->h_eig[ch.set[0][i]->status_off / 3] != 0) fail(ICP_ERR_NOT_FINITE, "posterior eigen-decomposition did not converge");
+      }
+      StateSlot& s = c.fresh_state();
+      s.reserved = true;
+      s.pose = c.pose_of(theta[b]);
+      ch.slot = &s;
+      c.batch_busy = true;
+      ch.busy = true;
+      ch.lk.unlock();
+    }
+    // ---- groups: each its own stream, everything of a group in order on it; the groups overlap each other's launches
+    // (three since the token moved forward, §5.1c: 64 chains 202k it/s in two groups, 211k in three; 128 chains 251k / 257k; 32 chains 130k /
+    // 135k; 24 chains 104k / 108k.  Four — a fourth stream made with every context — measured 218k / 266k / 137k / 109k, but the extra
+    // stream shifts every context's streams over the runtime's hardware queues, and the host-stepped lockstep path's decompositions, which
+    // wait on the device for launches of other streams, then ran into their time-outs: 15 of them in a 50-chain test.  Not adopted.)
+    const int n_groups = n_chains >= 16 ? 3 : 1;
+    struct Group {
+      int b0 = 0, B = 0;
+      hipStream_t st = nullptr;
+      int grid[5] = {0, 0, 0, 0, 0};
+      DBuf<StepBeginArgs> begin_alt, begin_live;
+      DBuf<StepSearchArgs> search_alt, search_live;
+      bool filter_prepared = true;  // (step_filter_prepared of every captured step)
+      DBuf<StepRegressionArgs> regression_alt, regression_live;
+      DBuf<StepFinishArgs> finish_alt, finish_live;
+      DBuf<MhChain> mh;
+      DBuf<EigenProblem> eig_live;
+      DBuf<int> eig_skip;
+      DBuf<double> normals[2], theta, rec;
+      DBuf<double> res;   // per chain 32 doubles: [0..7] launch 4's reductions, [8..11] the tails fwd_i / bwd_i — in DEVICE memory
+      DBuf<int> stat;     // per chain 16 ints: [0..3] the tails' status, [8..9] the factorisations' (the decide kernel reads them: pinned
+                          // host memory, where the host-stepped paths want them, would cost it a bus round trip per number)
+      double* h_normals[2] = {nullptr, nullptr};
+      hipEvent_t ev_copy[2] = {nullptr, nullptr};
+      hipEvent_t ev_big = nullptr;  // recorded behind launch 4: the next group's chip-wide launches may start
+    };
+    std::vector<Group> groups(n_groups);
+    constexpr int kChunk = 64;  // steps per block of standard normals
+    const int root = chains[0].props[0]->sampler == ICP_SAMPLER_CHOLESKY_ROOT;
+    struct GroupGuard {
+      std::vector<Group>& g;
+      ~GroupGuard() {
+        for (auto& gr : g) {
+          for (int k = 0; k < 2; ++k) {
+            if (gr.h_normals[k]) pinned_free(gr.h_normals[k]);
+            if (gr.ev_copy[k]) (void)hipEventDestroy(gr.ev_copy[k]);
+          }
+          if (gr.ev_big) (void)hipEventDestroy(gr.ev_big);
+        }
+      }
+    } group_guard{groups};
+    lead.bind();
+    std::vector<double> zero_key(P, 0.0);
+    for (int g = 0; g < n_groups; ++g) {
+      Group& gr = groups[g];
+      gr.b0 = (int)((long long)g * n_chains / n_groups);
+      gr.B = (int)((long long)(g + 1) * n_chains / n_groups) - gr.b0;
+      // the first chain's three streams: created one after the other with the context, they sit on different hardware queues and run
+      // beside each other (streams of DIFFERENT contexts, or streams made later, may share a queue: the runtime multiplexes streams
+      // onto a handful of them, and two groups on one queue alternate in ~55 µs slices — every kernel of the step then "takes" a
+      // multiple of that: eight streams made for the purpose on first use ran two groups at 116k it/s instead of 202k)
+      gr.st = g == 0 ? lead.stream : g == 1 ? lead.front_stream : lead.eig_stream;
+      const int B = gr.B;
+      gr.begin_alt.alloc(2 * B); gr.begin_live.alloc(B);
+      gr.search_alt.alloc(2 * B); gr.search_live.alloc(B);
+      gr.regression_alt.alloc(2 * B); gr.regression_live.alloc(B);
+      gr.finish_alt.alloc(2 * B); gr.finish_live.alloc(B);
+      gr.mh.alloc(B);
+      gr.eig_live.alloc((size_t)B * n_props);
+      gr.eig_skip.alloc((size_t)B * n_props);
+      gr.theta.alloc((size_t)B * P);
+      gr.res.alloc((size_t)B * 32); gr.res.fill_bytes(0);
+      gr.stat.alloc((size_t)B * 16); gr.stat.fill_bytes(0);
+      HIP_OK(hipEventCreateWithFlags(&gr.ev_big, hipEventDisableTiming));
+      gr.rec.alloc(records ? (size_t)B * std::max(n_steps, 1) * (4 + P) : 1);
+      for (int k = 0; k < 2; ++k) {
+        gr.normals[k].alloc((size_t)B * kChunk * r);
+        pinned_alloc((void**)&gr.h_normals[k], sizeof(double) * (size_t)B * kChunk * r);
+        HIP_OK(hipEventCreateWithFlags(&gr.ev_copy[k], hipEventDisableTiming));
+      }
+      std::vector<StepBeginArgs> hb(2 * B);
+      std::vector<StepSearchArgs> hs(2 * B);
+      std::vector<StepRegressionArgs> hr(2 * B);
+      std::vector<StepFinishArgs> hf(2 * B);
+      std::vector<MhChain> hm(B);
+      std::vector<int> hskip((size_t)B * n_props, 1);
+      std::vector<double> hth((size_t)B * P);
+      for (int k = 0; k < B; ++k) {
+        Chain& ch = chains[gr.b0 + k];
+        icp_ctx& c = *ch.e->ctx;
+        std::lock_guard<std::recursive_mutex> lk(c.mu);
+        Bound _b(&c, true, true);
+        MhChain& m = hm[k];
+        std::memset(&m, 0, sizeof(m));
+        for (int sel = 0; sel < 2; ++sel) {
+          // the step's launches with the current state in set `sel` and the proposed one in the other, captured
+          StepCapture cap;
+          std::memset(cap.grid, 0, sizeof(cap.grid));
+          StepFront F;
+          F.n_props = n_props; F.generator = -1; F.parity = 0; F.stream = c.stream; F.s = ch.slot;
+          for (int i = 0; i < n_props; ++i) { F.props[i] = ch.props[i]; F.ec[i] = ch.set[sel][i]; F.ep[i] = ch.set[1 - sel][i]; }
+          {
+            struct CaptureScope { CaptureScope(StepCapture* cp) { step_capture(cp); } ~CaptureScope() { step_capture(nullptr); } } scope(&cap);
+            front_launches(ch.e, n_props, ch.props, -1, zero_key.data(), F, true, false);
+            StepFinishArgs f{};
+            f.n = n_props; f.r = r; f.Ginv = c.Ginv.p; f.sigma2 = kSigma2;
+            for (int i = 0; i < n_props; ++i) {
+              icp_proposal* p = ch.props[i];
+              f.Mpart[i] = F.mpart[i]; f.splits[i] = F.splits[i];
+              f.M[i] = F.ep[i]->M.p; f.alpha[i] = F.ep[i]->alpha.p;
+              f.status[i] = p->status.p + F.ep[i]->status_off;
+              f.host_status[i] = gr.stat.p + (size_t)k * 16 + 8 + i;
+              f.fwd[i] = TransitionTailIO{F.ec[i]->alpha.p, F.ec[i]->M.p, F.ec[i]->coeffs.p, F.ep[i]->coeffs.p, p->prm.step_length,
+                                          gr.res.p + (size_t)k * 32 + 8 + 2 * i, gr.stat.p + (size_t)k * 16 + 2 * i};
+              f.bwd[i] = TransitionTailIO{F.ep[i]->alpha.p, F.ep[i]->M.p, F.ep[i]->coeffs.p, F.ec[i]->coeffs.p, p->prm.step_length,
+                                          gr.res.p + (size_t)k * 32 + 9 + 2 * i, gr.stat.p + (size_t)k * 16 + 2 * i + 1};
+            }
+            f.done_counter = c.d_done.p; f.host_flag = c.h_flag; f.seq = 0;
+            f.ready_flag = nullptr;
+            launch_step_finish(c.stream, f);  // (captured; finalised by the launcher)
+          }
+          cap.begin.wait_flag = nullptr; cap.begin.wait2_flag = nullptr; cap.begin.wait_ticks = nullptr; cap.begin.hold_regs = 0;
+          cap.regression.red_out = gr.res.p + (size_t)k * 32;  // (device memory instead of the context's pinned area)
+          {  // (launch 1's matvec layout: set by enqueue_front only when it knows the generator)
+            int t = 0;
+            while (t < 6 && (r << (t + 1)) <= 256 && (r >> (t + 1)) >= 8) ++t;
+            cap.begin.tpr_log2 = t;
+          }
+          hb[(size_t)sel * B + k] = cap.begin; hs[(size_t)sel * B + k] = cap.search; hr[(size_t)sel * B + k] = cap.regression;
+          hf[(size_t)sel * B + k] = cap.finish;
+          for (int q = 0; q < 5; ++q) gr.grid[q] = std::max(gr.grid[q], cap.grid[q]);
+          gr.filter_prepared = gr.filter_prepared && step_filter_prepared(cap.search);
+          m.begin_alt[sel] = gr.begin_alt.p + (size_t)sel * B + k;
+          m.search_alt[sel] = gr.search_alt.p + (size_t)sel * B + k;
+          m.regression_alt[sel] = gr.regression_alt.p + (size_t)sel * B + k;
+          m.finish_alt[sel] = gr.finish_alt.p + (size_t)sel * B + k;
+          for (int i = 0; i < n_props; ++i) {
+            icp_proposal* p = ch.props[i];
+            PosteriorEntry& cur = *ch.set[sel][i];
+            m.prop_alt[sel][i] = ProposeIn{cur.alpha.p, cur.V.p, cur.S.p, c.inv_sqrt_lambda.p, c.P.p, cur.coeffs.p, nullptr, kSigma2,
+                                           p->prm.step_length, root};
+            // the decomposition of set `sel`'s posterior (an accepted state arrives there), warm-started from the other set's basis
+            PosteriorEntry& other = *ch.set[1 - sel][i];
+            EigenRequest rq{cur.M.p, root ? nullptr : other.V.p, cur.V.p, cur.Vt.p, cur.S.p, p->work.p, p->status.p + cur.status_off + 2, nullptr,
+                            p->h_eig + cur.status_off / 3, p->eig_words.p + cur.status_off / 3, 0, c.sqrt_lambda.p};
+            rq.root = root != 0;
+            m.eig_alt[sel][i] = eigen_problem_of(r, rq);
+          }
+        }
+        m.begin_live = gr.begin_live.p + k; m.search_live = gr.search_live.p + k;
+        m.regression_live = gr.regression_live.p + k; m.finish_live = gr.finish_live.p + k;
+        m.eig_live = gr.eig_live.p + (size_t)k * n_props;
+        m.eig_skip = gr.eig_skip.p + (size_t)k * n_props;
+        m.pw_id_mask = 2046;
+        m.seed = seeds[gr.b0 + k];
+        m.r = r; m.n_icp = n_props;
+        {  // MixtureProposal weights, normalised as the harness normalises them (host/icp_host.hpp: pick_component)
+          double ws = 0.0;
+          for (int i = 0; i < n_props; ++i) ws += mix->icp_weight[i];
+          for (int i = 0; i < n_props; ++i) m.icp_w[i] = mix->icp_weight[i] / ws;
+          double raw[3];
+          int no = 0;
+          if (mix->w_pose > 0.0) { m.outer_kind[no] = 0; raw[no++] = mix->w_pose; }  // (BfmFittingPartial.scala:70: pose, ICP, shape walk)
+          m.outer_kind[no] = 1; raw[no++] = mix->w_icp;
+          if (mix->w_rw > 0.0) { m.outer_kind[no] = 2; raw[no++] = mix->w_rw; }
+          double wsum = 0.0;
+          for (int o = 0; o < no; ++o) wsum += raw[o];
+          for (int o = 0; o < no; ++o) m.outer_w[o] = raw[o] / wsum;
+          m.n_outer = no;
+        }
+        if (mix->w_pose > 0.0) {  // MixedProposalDistributions.scala:29-39 / host/icp_host.cpp: mixed_random_pose_proposal
+          static const int param_index[6] = {6, 5, 4, 1, 2, 3};  // yaw = rotation._3, pitch = _2, roll = _1 (PoseProposals.scala:39-41); x, y, z
+          m.n_pose = 6;
+          double wsum = 0.0;
+          for (int a = 0; a < 6; ++a) wsum += 0.5;
+          for (int a = 0; a < 6; ++a) {
+            const double sd = a < 3 ? mix->pose_rot_sigma[a] : mix->pose_trans_sigma[a - 3];
+            m.pose_index[a] = param_index[a];
+            m.pose_w[a] = 0.5 / wsum;
+            m.pose_sigma[a] = sd;
+            m.pose_logc[a] = std::log(std::sqrt(2.0 * M_PI)) + std::log(sd);  // breeze Gaussian(0, σ).logPdf's normaliser
+          }
+          m.front_every_step = 1;
+        }
+        m.rw_sigma = mix->rw_sigma;
+        m.rw_logc = 0.5 * (r * std::log(2.0 * M_PI) + r * std::log(mix->rw_sigma * mix->rw_sigma));
+        m.prior_c = 0.5 * r * std::log(2.0 * M_PI);
+        const icp_evaluator_params& ep = ch.e->prm;
+        m.eval_kind = ep.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE ? 0 : 2;
+        m.eval_mode = ep.mode;
+        m.gauss_mean = ep.gauss_mean; m.gauss_sigma = ep.gauss_sigma;
+        m.gauss_logn = std::log(std::sqrt(2.0 * M_PI)) + std::log(ep.gauss_sigma);
+        m.exp_rate = ep.exp_rate; m.exp_lograte = std::log(ep.exp_rate);
+        m.coeff_prop = ch.slot->coeffs.p;
+        m.red = gr.res.p + (size_t)k * 32;
+        m.tails = gr.res.p + (size_t)k * 32 + 8;
+        m.tail_status = gr.stat.p + (size_t)k * 16;
+        m.chol_status = gr.stat.p + (size_t)k * 16 + 8;
+        m.normals = nullptr; m.normals_first = 0; m.normals_rows = 0;
+        m.records = records && records[gr.b0 + k] ? gr.rec.p + (size_t)k * n_steps * (4 + P) : nullptr;
+        m.rec_first = first_step[gr.b0 + k];
+        m.theta = gr.theta.p + (size_t)k * P;
+        m.cur_p = log_value[gr.b0 + k];
+        m.step = first_step[gr.b0 + k];
+        m.accepted = 0; m.cur_sel = 0; m.gen = -1; m.leaf = -1; m.error = 0;
+        for (int i = 0; i < n_props; ++i) m.eig_seq[i] = ch.props[i]->eig_seq;
+        std::memcpy(hth.data() + (size_t)k * P, theta[gr.b0 + k], sizeof(double) * P);
+        for (int i = 0; i < 16; ++i) { c.h_res[i] = 0.0; c.h_status[i] = 0; }
+      }
+      HIP_OK(hipMemcpy(gr.begin_alt.p, hb.data(), sizeof(StepBeginArgs) * hb.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(gr.search_alt.p, hs.data(), sizeof(StepSearchArgs) * hs.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(gr.regression_alt.p, hr.data(), sizeof(StepRegressionArgs) * hr.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(gr.finish_alt.p, hf.data(), sizeof(StepFinishArgs) * hf.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(gr.eig_skip.p, hskip.data(), sizeof(int) * hskip.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(gr.theta.p, hth.data(), sizeof(double) * hth.size(), hipMemcpyHostToDevice));
+      // (normals: the two buffers are addressed through MhChain::normals / normals_first, re-pointed per block of steps below)
+      HIP_OK(hipMemcpy(gr.mh.p, hm.data(), sizeof(MhChain) * hm.size(), hipMemcpyHostToDevice));
+      HIP_OK(hipStreamSynchronize(nullptr));  // (as DBuf::upload: the copies have reached the device before a non-blocking stream's launch reads them)
+    }
+    // ---- the loop: per block of kChunk steps the chains' standard normals (the harness' own expression, drawn here on the host
+    // while the device works on the block before), then per step and group eight launches, nothing waited for
+    auto draw_block = [&](Group& gr, int blk, int buf) {
+      const int s0 = blk * kChunk, ns = std::min(kChunk, n_steps - s0);
+      double* out = gr.h_normals[buf];
+      for (int k = 0; k < gr.B; ++k) {
+        const uint64_t seed = seeds[gr.b0 + k];
+        const uint64_t f0 = (uint64_t)first_step[gr.b0 + k] + (uint64_t)s0;
+        for (int s_ = 0; s_ < ns; ++s_)
+          for (int j = 0; j < r; ++j) out[((size_t)k * kChunk + s_) * r + j] = harness_normal(seed, f0 + (uint64_t)s_, (uint64_t)j);
+      }
+    };
+    const int n_blocks = (n_steps + kChunk - 1) / kChunk;
+    // (per-kernel event timing, if the first chain's context is being profiled: icp_ctx_profile_start — its event pool, both streams)
+    struct ProfBind { ProfBind(icp_ctx& c) { g_prof = c.profiling ? &c.prof : nullptr; } ~ProfBind() { g_prof = nullptr; } } prof_bind(lead);
+    for (int blk = 0; blk < n_blocks; ++blk) {
+      const int buf = blk & 1, s0 = blk * kChunk, ns = std::min(kChunk, n_steps - s0);
+      for (auto& gr : groups) {
+        HIP_OK(hipEventSynchronize(gr.ev_copy[buf]));  // (the staging buffer's previous upload has left it)
+        draw_block(gr, blk, buf);
+        HIP_OK(hipMemcpyAsync(gr.normals[buf].p, gr.h_normals[buf], sizeof(double) * (size_t)gr.B * kChunk * r, hipMemcpyHostToDevice, gr.st));
+        HIP_OK(hipEventRecord(gr.ev_copy[buf], gr.st));
+        launch_mh_set_normals(gr.st, gr.B, gr.mh.p, gr.normals[buf].p, kChunk * r, s0, ns);
+      }
+      // The chip-wide launches of two groups side by side slow each other down more than the overlap gains; what
+      // should run beside a group's chip-wide launches is the OTHER group's small ones (launch 5 on four CUs per chain, the
+      // decide kernel, the decompositions on three CUs each).  So the launches pass a token from group to group: a group's first
+      // launch waits for an event of the previous group's.  Which one: behind launch 4 while the filter launch held five workgroups per
+      // CU; with eight (§5.1c) behind launch 2 — the other group's begin and filter beside this group's resolve and regression, two
+      // chains of latencies that leave the CUs room — measures best (two groups of 32 chains: 202.0k it/s against 197.3k behind launch
+      // 4, 199.0k without a token; four groups of 16, on a build with a fourth stream: 216.2k against 215.0k behind launch 1, 206.3k
+      // without, 199.6k behind launch 3, 167.9k behind launch 4); behind launch 1 with 64 per group (two groups of 64: 249.5k against 244.7k / 241.5k).
+      for (int s_ = 0; s_ < ns; ++s_)
+        for (int g = 0; g < n_groups; ++g) {
+          Group& gr = groups[g];
+          if (n_groups > 1) {
+            Group& prev = groups[(g + n_groups - 1) % n_groups];
+            if (blk > 0 || s_ > 0 || g > 0) HIP_OK(hipStreamWaitEvent(gr.st, prev.ev_big, 0));
+          }
+          // (later steps of a block: prepared by the decide kernel of the step before — except with pose walks, whose proposed pose is
+          // made by the front kernel)
+          if (s_ == 0 || mix->w_pose > 0.0) launch_mh_front(gr.st, gr.B, gr.mh.p);
+          const int token_at = gr.B >= 64 ? 1 : 2;
+          {
+            int ga[5] = {0, 0, 0, 0, 0}, gb[5] = {0, 0, 0, 0, 0};
+            for (int q = 0; q < 4; ++q) (q < token_at ? ga : gb)[q] = gr.grid[q];
+            if (token_at > 0)
+              launch_step_batch_resident(gr.st, gr.B, ga, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p, gr.filter_prepared);
+            if (n_groups > 1) HIP_OK(hipEventRecord(gr.ev_big, gr.st));
+            if (token_at < 4)
+              launch_step_batch_resident(gr.st, gr.B, gb, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p, gr.filter_prepared);
+          }
+          int g5[5] = {0, 0, 0, 0, gr.grid[4]};
+          launch_step_batch_resident(gr.st, gr.B, g5, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p);
+          launch_mh_decide(gr.st, gr.B, gr.mh.p);
+          launch_posterior_eigen_resident(gr.st, r, gr.B * n_props, gr.eig_live.p, gr.eig_skip.p, root);
+        }
+    }
+    // ---- results: nothing is handed out unless every chain came through
+    std::vector<std::vector<MhChain>> hms(n_groups);
+    int first_error = 0;
+    for (int g = 0; g < n_groups; ++g) {
+      Group& gr = groups[g];
+      HIP_OK(hipStreamSynchronize(gr.st));
+      hms[g].resize(gr.B);
+      HIP_OK(hipMemcpy(hms[g].data(), gr.mh.p, sizeof(MhChain) * hms[g].size(), hipMemcpyDeviceToHost));
+      for (const MhChain& m : hms[g])
+        if (m.error != 0 && first_error == 0) first_error = m.error;
+    }
+    if (first_error != 0) {
+      for (auto& ch : chains) {  // whatever the sets hold now belongs to no state on record
+        std::lock_guard<std::recursive_mutex> lk(ch.e->ctx->mu);
+        for (int i = 0; i < n_props; ++i) {
+          for (int sel = 0; sel < 2; ++sel) { ch.set[sel][i]->valid = false; ch.set[sel][i]->eig_valid = false; ch.set[sel][i]->eig_checked = false; }
+          ch.props[i]->warm_valid = false;
+          ch.props[i]->spec_entry = nullptr;
+        }
+        ch.slot->valid = false;
+      }
+      fail(first_error == 3 ? ICP_ERR_NOT_SPD : first_error == 5 ? ICP_ERR_EMPTY : ICP_ERR_NOT_FINITE,
+           first_error == 2 ? "on-device loop: a transition tail did not contract (step these chains through icp_chain_step_batched)"
+           : first_error == 6 ? "on-device loop: posterior eigen-decomposition did not converge"
+                              : "on-device loop: a chain stopped on a non-finite, empty or non-positive-definite result");
+    }
+    // the decompositions behind the LAST step's decisions have no decide kernel behind them: their status (pinned, written by the
+    // decomposition itself) is looked at here, before the sets are booked as decomposed and checked
+    for (int g = 0; g < n_groups; ++g)
+      for (int k = 0; k < groups[g].B; ++k) {
+        Chain& ch = chains[groups[g].b0 + k];
+        const MhChain& m = hms[g][k];
+        for (int i = 0; i < n_props; ++i) {
+          const int st = ch.props[i]->h_eig[ch.set[m.cur_sel][i]->status_off / 3];
+          if (st != 0) {
+            std::lock_guard<std::recursive_mutex> lk(ch.e->ctx->mu);
+            for (int sel = 0; sel < 2; ++sel) { ch.set[sel][i]->valid = false; ch.set[sel][i]->eig_valid = false; ch.set[sel][i]->eig_checked = false; }
+            ch.props[i]->warm_valid = false;
+            ch.props[i]->spec_entry = nullptr;
+            fail(ICP_ERR_NOT_FINITE, "on-device loop: posterior eigen-decomposition did not converge");
+          }
+        }
+      }
+    for (int g = 0; g < n_groups; ++g) {
+      Group& gr = groups[g];
+      std::vector<double> hth((size_t)gr.B * P);
+      HIP_OK(hipMemcpy(hth.data(), gr.theta.p, sizeof(double) * hth.size(), hipMemcpyDeviceToHost));
+      for (int k = 0; k < gr.B; ++k) {
+        const int b = gr.b0 + k;
+        Chain& ch = chains[b];
+        icp_ctx& c = *ch.e->ctx;
+        const MhChain& m = hms[g][k];
+        std::memcpy(theta[b], hth.data() + (size_t)k * P, sizeof(double) * P);
+        log_value[b] = m.cur_p;
+        if (accepted) accepted[b] = m.accepted;
+        if (records && records[b] && n_steps > 0)
+          HIP_OK(hipMemcpy(records[b], gr.rec.p + (size_t)k * n_steps * (4 + P), sizeof(double) * (size_t)n_steps * (4 + P), hipMemcpyDeviceToHost));
+        // the contexts' own bookkeeping: the set that holds the current state is on record again, decomposed
+        std::lock_guard<std::recursive_mutex> lk(c.mu);
+        for (int i = 0; i < n_props; ++i) {
+          icp_proposal* p = ch.props[i];
+          for (int sel = 0; sel < 2; ++sel) {
+            PosteriorEntry& en = *ch.set[sel][i];
+            const bool cur = sel == m.cur_sel;
+            en.valid = cur; en.eig_valid = cur; en.eig_checked = cur; en.eig_event_valid = false; en.done_value = 0;
+            if (cur) {
+              en.theta.assign(theta[b], theta[b] + P);
+              en.stamp = ++p->clock;
+              p->h_eig[en.status_off / 3] = 0;
+              p->warm_ptr = en.V.p;
+              p->warm_valid = true;
+            }
+          }
+          p->eig_seq = m.eig_seq[i];
+          p->spec_entry = nullptr;
+        }
+        ch.slot->valid = false;
+        ch.e->last_prop.clear();
+        c.paths.n[3] += n_steps; g_step_paths.n[3] += n_steps;
+      }
+    }
+  });
+  release();
+  return rc;
+}
+
+int icp_proposal_basis_state(icp_proposal* p, const double* theta) {
+  if (!p || !theta) return ICP_ERR_INVALID_ARG;
+  icp_ctx& c = *p->ctx;
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (c.batch_busy) return 1;  // (its context is part of a batch in flight: whatever it is doing, it is not ready)
+  PosteriorEntry* e = p->find_entry(theta);
+  if (!e) return 0;
+  if (!e->eig_valid) return 0;
+  return *(volatile int*)(p->h_eig + e->status_off / 3) == -1 ? 1 : 2;
+}
+
+int icp_chain_step_path(icp_evaluator* e, int32_t n_props, icp_proposal* const* props) {
+  if (!e || n_props < 0 || (n_props > 0 && !props)) return ICP_ERR_INVALID_ARG;
+  for (int i = 0; i < n_props; ++i)
+    if (!props[i] || props[i]->ctx != e->ctx) return ICP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(e->ctx->mu);
+  if (step_pipeline_covers(e, n_props, props)) return 0;
+  if (n_props >= 1 && n_props <= 2 && wide_pipeline_covers(e, n_props, props)) return 1;
+  return 2;
+}
+
+int icp_chain_step_batched(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props,
+                           const int32_t* generator, const double* const* theta_cur, const double* const* z,
+                           double* const* theta_prop, double* log_value_prop, double* fwd, double* bwd, int32_t* status) {
+  icp_step_ticket* tk = nullptr;
+  const int rc = icp_chain_step_batched_issue(n_chains, evaluators, n_props, props, generator, theta_cur, z, theta_prop, log_value_prop, fwd,
+                                              bwd, status, nullptr, &tk);
+  if (rc != ICP_OK) return rc;
+  return icp_chain_step_batched_collect(tk);
+}
+
+
+
+}  // extern "C"
