@@ -72,7 +72,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
         if (it.e->front.valid) release_front(it.e->front);
         c.bind();
         HIP_OK(hipStreamSynchronize(c.stream));
-        HIP_OK(hipStreamSynchronize(c.front_stream));
+        c.front_stream.sync();
         c.front_stream_used = false;
       }
       if (!chain_step_covered(it.e, n_props, it.props, it.generator, theta_cur[b], theta_prop[b])) {
@@ -212,8 +212,8 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       }
       static const bool finish_aside = dev_env("ICP_BATCH_FINISH_INLINE") == nullptr;  // (A/B switch)
       launch_step_batch(lead.stream, nb, caps.data(), lead.batch_pinned[turn], lead.batch_device[turn].p,
-                        finish_aside ? lead.front_stream : nullptr, lead.ev_join, gate);
-      if (finish_aside) t.finish_stream = lead.front_stream;
+                        finish_aside ? lead.front_stream.get() : nullptr, lead.ev_join, gate);
+      if (finish_aside) t.finish_stream = lead.front_stream.get();
     }
     t.nb = nb;
     t.lead = &lead;

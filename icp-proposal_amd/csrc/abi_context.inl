@@ -107,12 +107,16 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     // (out of the pool of streams of destroyed contexts where it has any of that priority class: take_stream)
     const bool greatest = prio_greatest != 0;
     ctx->stream = take_stream(device, greatest, prio_greatest);
-    ctx->front_stream = take_stream(device, greatest, prio_greatest);
-    ctx->eig_stream = take_stream(device, greatest, prio_greatest);
-    // (ranks above 64 only: a stream costs a few MB of the runtime's own memory; created HERE, next to its sibling, and not on first
-    // use: the runtime maps streams to its hardware queues in creation order, and a latecomer shared one with the context stream)
-    if (ctx->r > 64) ctx->eig_stream2 = take_stream(device, greatest, prio_greatest);
-    { std::lock_guard<std::mutex> lk(g_eig_streams_mu); g_eig_streams.insert(ctx->eig_stream); }
+    // The side streams: made HERE, next to the context stream, for the first two contexts alive in the process (the runtime maps streams
+    // to its hardware queues in creation order, and a latecomer shared one with the context stream); from the third context on — the
+    // members of a batch registration's pool, the chains of a many-chains job, all stepped through a launch context's streams — on
+    // first use (LazyStream).  ICP_EAGER_STREAMS=1: always here.
+    static const bool eager_always = std::getenv("ICP_EAGER_STREAMS") != nullptr;
+    const bool now = eager_always || g_live_contexts.load(std::memory_order_relaxed) < 2;
+    ctx->front_stream.arm(device, greatest, prio_greatest, false, now);
+    ctx->eig_stream.arm(device, greatest, prio_greatest, true, now);
+    // (ranks above 64 only: a stream costs a few MB of the runtime's own memory)
+    if (ctx->r > 64) ctx->eig_stream2.arm(device, greatest, prio_greatest, false, now);
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&ctx->ev_sum, hipEventDisableTiming));
@@ -252,11 +256,11 @@ void icp_ctx_destroy(icp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   DeviceQuiesce _q;  // (its device buffers go back to the pool: device_free)
-  if (ctx->eig_last && ctx->eig_last != ctx->eig_stream) {  // decompositions of this context on a batch's stream
+  if (ctx->eig_last && ctx->eig_last != ctx->eig_stream.peek()) {  // decompositions of this context on a batch's stream
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     if (g_eig_streams.count(ctx->eig_last)) (void)hipStreamSynchronize(ctx->eig_last);
   }
-  if (ctx->eig_last2 && ctx->eig_last2 != ctx->eig_stream2) {
+  if (ctx->eig_last2 && ctx->eig_last2 != ctx->eig_stream2.peek()) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     if (g_eig_streams.count(ctx->eig_last2)) (void)hipStreamSynchronize(ctx->eig_last2);
   }
@@ -268,24 +272,22 @@ void icp_ctx_destroy(icp_ctx* ctx) {
         give_stream(pool[k]);
         pool[k] = nullptr;
       }
-  if (ctx->eig_stream2) {
-    give_stream(ctx->eig_stream2);
-  }
-  if (ctx->eig_stream) {
+  if (hipStream_t s2 = ctx->eig_stream2.release()) give_stream(s2);
+  if (hipStream_t s1 = ctx->eig_stream.release()) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
-    g_eig_streams.erase(ctx->eig_stream);
-    (void)hipStreamSynchronize(ctx->eig_stream);
-    library_release_stream(ctx->eig_stream);
-    give_stream(ctx->eig_stream);
+    g_eig_streams.erase(s1);
+    (void)hipStreamSynchronize(s1);
+    library_release_stream(s1);
+    give_stream(s1);
   }
   if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
   if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
   if (ctx->ev_sum) (void)hipEventDestroy(ctx->ev_sum);
   if (ctx->ev_asm) (void)hipEventDestroy(ctx->ev_asm);
-  if (ctx->front_stream) {
-    (void)hipStreamSynchronize(ctx->front_stream);
-    library_release_stream(ctx->front_stream);
-    give_stream(ctx->front_stream);
+  if (hipStream_t fs = ctx->front_stream.release()) {
+    (void)hipStreamSynchronize(fs);
+    library_release_stream(fs);
+    give_stream(fs);
   }
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -332,7 +334,7 @@ int icp_ctx_set_target(icp_ctx* ctx, const icp_mesh_desc* target) {
     require(ctx->proposals.empty() && ctx->evaluators.empty(), "the context still has proposals or evaluators made for its present target");
     Bound _b(ctx);
     HIP_OK(hipStreamSynchronize(ctx->stream));
-    HIP_OK(hipStreamSynchronize(ctx->front_stream));
+    ctx->front_stream.sync();
     sync_eigen(*ctx);
     {
       std::lock_guard<std::mutex> shared_lk(g_shared_mu);
@@ -375,7 +377,7 @@ int icp_ctx_set_rotation(icp_ctx* ctx, const double* angles, const double* R) {
       if (ctx->batch_busy) throw IcpError{ICP_ERR_BUSY, "the context belongs to a batch in flight"};
       ctx->bind();
       HIP_OK(hipStreamSynchronize(ctx->stream));
-      HIP_OK(hipStreamSynchronize(ctx->front_stream));
+      ctx->front_stream.sync();
       sync_eigen(*ctx);
       for (icp_evaluator* ev : ctx->evaluators) {
         if (ev->front.valid) release_front(ev->front);
@@ -504,7 +506,7 @@ int icp_ctx_profile_stop(icp_ctx* ctx, icp_kernel_stat* stats, int32_t capacity,
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     ctx->bind();
     HIP_OK(hipStreamSynchronize(ctx->stream));
-    HIP_OK(hipStreamSynchronize(ctx->front_stream));
+    ctx->front_stream.sync();
     sync_eigen(*ctx);
     for (hipStream_t bs : ctx->batch_eig)
       if (bs) HIP_OK(hipStreamSynchronize(bs));  // (decompositions of batches this context carried)

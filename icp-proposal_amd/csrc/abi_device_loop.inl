@@ -73,7 +73,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
         ch.set[1][i] = &other;
       }
       HIP_OK(hipStreamSynchronize(c.stream));
-      HIP_OK(hipStreamSynchronize(c.front_stream));
+      c.front_stream.sync();
       sync_eigen(c);
       for (int i = 0; i < n_props; ++i) sync_proposal_status(ch.props[i]);
       HIP_OK(hipStreamSynchronize(c.stream));
@@ -140,7 +140,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       // beside each other (streams of DIFFERENT contexts, or streams made later, may share a queue: the runtime multiplexes streams
       // onto a handful of them, and two groups on one queue alternate in ~55 µs slices — every kernel of the step then "takes" a
       // multiple of that: eight streams made for the purpose on first use ran two groups at 116k it/s instead of 202k)
-      gr.st = g == 0 ? lead.stream : g == 1 ? lead.front_stream : lead.eig_stream;
+      gr.st = g == 0 ? lead.stream : g == 1 ? lead.front_stream.get() : lead.eig_stream.get();
       const int B = gr.B;
       gr.begin_alt.alloc(2 * B); gr.begin_live.alloc(B);
       gr.search_alt.alloc(2 * B); gr.search_live.alloc(B);

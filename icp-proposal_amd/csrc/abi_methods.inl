@@ -13,6 +13,7 @@ int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_pro
     require(params->tangential_noise > 0.0 && params->noise_along_normal > 0.0, "noise standard deviations must be positive");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     Bound _b(ctx);
+    NullStreamBatch _fills;  // (nothing is launched in here: the uploads and fills are waited for together, when the call returns)
     p = new icp_proposal();
     p->ctx = ctx;
     p->prm = *params;
@@ -63,7 +64,7 @@ void icp_proposal_destroy(icp_proposal* p) {
     std::lock_guard<std::recursive_mutex> lk(p->ctx->mu);
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    (void)hipStreamSynchronize(p->ctx->front_stream);
+    p->ctx->front_stream.sync_quiet();
     try { sync_eigen(*p->ctx); } catch (...) {}
     DeviceQuiesce _q;
     for (icp_evaluator* ev : p->ctx->evaluators)  // a half step launched ahead with this proposal holds entries of it
@@ -218,6 +219,7 @@ int icp_evaluator_create(icp_ctx* ctx, const icp_evaluator_params* params, icp_e
     require(params->kind == ICP_EVAL_HAUSDORFF || (params->mode >= 0 && params->mode <= 2), "unknown evaluation mode");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     Bound _b(ctx);
+    NullStreamBatch _fills;  // (nothing is launched in here: the uploads and fills are waited for together, when the call returns)
     ev = new icp_evaluator();
     ev->ctx = ctx;
     ev->prm = *params;
@@ -504,7 +506,7 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
     // (… and so do the one-workgroup factorisations and the tails: they go to a stream of their own, behind the regression; the
     // decomposition follows them on the eigen stream; this stream goes on with the searches and waits for the tails before the
     // results are copied)
-    const hipStream_t side = spec_big || spec_pose ? c.front_stream : nullptr;  // (the merged step's second stream: idle on this path)
+    const hipStream_t side = spec_big || spec_pose ? c.front_stream.get() : nullptr;  // (the merged step's second stream: idle on this path)
     // the decomposition of a posterior whose factorisation has just gone to the side stream: behind that — or, if the posterior was
     // computed just now, beside it: M = I + the summed partials is written by a launch at the head of the decomposition as well
     // (the same values the factorisation's assembly writes)
@@ -515,9 +517,9 @@ int icp_chain_eval_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* 
         return;
       }
       if (en.eig_valid) return;
-      if (c.eig_last && c.eig_last != c.eig_stream) (void)eigen_stream_for(c, c.eig_stream);  // (a batch's stream was in use: drained)
-      c.eig_last = c.eig_stream;
-      const hipStream_t es = (c.eig_stream2 && (p->eig_flip++ & 1)) ? c.eig_stream2 : c.eig_stream;  // two under way at a time
+      if (c.eig_last && c.eig_last != c.eig_stream.get()) (void)eigen_stream_for(c, c.eig_stream.get());  // (a batch's stream was in use: drained)
+      c.eig_last = c.eig_stream.get();
+      const hipStream_t es = (c.eig_stream2 && (p->eig_flip++ & 1)) ? c.eig_stream2.get() : c.eig_stream.get();  // two under way at a time
       es_ahead = es;
       if (p->side_parts && p->side_parts_entry == &en) {
         // (computed just now, all of it on the side stream: nothing of this entry is on the context stream — which carries the

@@ -282,3 +282,19 @@ std::atomic<int> g_live_contexts{0};
 std::mutex g_eig_streams_mu;
 std::set<hipStream_t> g_eig_streams;
 }  // namespace
+
+hipStream_t LazyStream::get() {
+  if (s || device < 0) return s;
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  if (cur != device) HIP_OK(hipSetDevice(device));
+  s = take_stream(device, greatest, priority);
+  if (eigen) { std::lock_guard<std::mutex> lk(g_eig_streams_mu); g_eig_streams.insert(s); }
+  if (cur != device && cur >= 0) (void)hipSetDevice(cur);
+  return s;
+}
+void LazyStream::arm(int dev, bool great, int prio, bool is_eigen, bool now) {
+  device = dev; greatest = great; priority = prio; eigen = is_eigen;
+  if (now) (void)get();
+}
+void LazyStream::sync() { if (s) HIP_OK(hipStreamSynchronize(s)); }

@@ -414,16 +414,16 @@ hipStream_t batch_eigen_stream(icp_ctx& lead, const void* owner, int second = 0)
 
 // waits for every decomposition of this context that may still be running
 void sync_eigen(icp_ctx& c) {
-  if (c.eig_last && c.eig_last != c.eig_stream) {
+  if (c.eig_last && c.eig_last != c.eig_stream.peek()) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     if (g_eig_streams.count(c.eig_last)) HIP_OK(hipStreamSynchronize(c.eig_last));
   }
-  if (c.eig_last2 && c.eig_last2 != c.eig_stream2) {
+  if (c.eig_last2 && c.eig_last2 != c.eig_stream2.peek()) {
     std::lock_guard<std::mutex> lk(g_eig_streams_mu);
     if (g_eig_streams.count(c.eig_last2)) HIP_OK(hipStreamSynchronize(c.eig_last2));
   }
-  HIP_OK(hipStreamSynchronize(c.eig_stream));
-  if (c.eig_stream2) HIP_OK(hipStreamSynchronize(c.eig_stream2));
+  c.eig_stream.sync();
+  c.eig_stream2.sync();
 }
 // the stream the next decompositions of this context go to (see g_eig_streams)
 hipStream_t eigen_stream_for(icp_ctx& c, hipStream_t want) {
@@ -444,7 +444,7 @@ void icp_proposal::ensure_eigen(PosteriorEntry& e) {
   EigenRequest rq;
   prepare_eigen(e, &rq);
   HIP_OK(hipEventRecord(c.ev_ready, c.stream));  // M of this entry may still be in flight on the context stream
-  const hipStream_t es = eigen_stream_for(c, c.eig_stream);
+  const hipStream_t es = eigen_stream_for(c, c.eig_stream.get());
   HIP_OK(hipStreamWaitEvent(es, c.ev_ready, 0));
   if (!launch_posterior_eigen_pair(es, c.r, c.sqrt_lambda.p, 1, &rq)) {  // ranks > 64: no completion word
     e.done_value = 0;
@@ -461,7 +461,7 @@ void icp_proposal::ensure_eigen_on(PosteriorEntry& e, hipStream_t es, int part) 
   if (part != 2) {
     if (e.eig_valid) return;
     prepare_eigen(e, &pending_rq);
-    if (es == c.eig_stream2) pending_rq.work = work2.p;  // (allocated and zeroed with the proposal: a memset issued here could land in the kernels)
+    if (es && es == c.eig_stream2.peek()) pending_rq.work = work2.p;  // (allocated and zeroed with the proposal: a memset issued here could land in the kernels)
     e.done_value = 0;
     pending_entry = &e;
   } else if (pending_entry != &e) {

@@ -78,7 +78,7 @@ void start_decompositions(icp_ctx& c, int n_props, icp_proposal* const* props, P
     for (int i = 0; i < nn; ++i) collect->all.push_back(need[i]);
     return;
   }
-  const hipStream_t es = eigen_stream_for(c, c.eig_stream);
+  const hipStream_t es = eigen_stream_for(c, c.eig_stream.get());
   // M of these entries is complete when they were recorded by a finished chain step (the host has seen its results);
   // only work another entry point has put on `stream` may still be writing them
   if (m_in_flight) {
@@ -128,18 +128,18 @@ void enqueue_front(icp_evaluator* e, int n_props, icp_proposal* const* props, in
   bool missing = false;
   for (int i = 0; i < n_props; ++i) missing = missing || !props[i]->find_entry(theta_cur);
   if (missing && c.front_stream_used) {  // the posteriors are computed on `stream` with the scratch a step in flight may still use
-    HIP_OK(hipStreamSynchronize(c.front_stream));
+    c.front_stream.sync();
     c.front_stream_used = false;
   }
   for (int i = 0; i < n_props; ++i) ec[i] = &props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76
   if (missing) c.stream_used_elsewhere = true;  // … and this step reads them
   const bool m_in_flight = c.stream_used_elsewhere;  // `stream` may still be writing what the decompositions below read
   const bool two_streams = !c.pipeline_off && !batched && device_side_waits_allowed();
-  F.stream = (F.parity && two_streams) ? c.front_stream : c.stream;
-  if (F.stream == c.front_stream) {
+  F.stream = (F.parity && two_streams) ? c.front_stream.get() : c.stream;
+  if (F.stream == c.front_stream.peek()) {
     if (c.stream_used_elsewhere) {  // another entry point has work on `stream` that this step may depend on: join once
       HIP_OK(hipEventRecord(c.ev_join, c.stream));
-      HIP_OK(hipStreamWaitEvent(c.front_stream, c.ev_join, 0));
+      HIP_OK(hipStreamWaitEvent(c.front_stream.get(), c.ev_join, 0));
     }
     c.front_stream_used = true;
   }
@@ -562,7 +562,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       // completion word the two launches take ≈ 110 µs, the iteration with its replay beside it ≈ 100 even at four sweeps.)
       static const double direct_above = dev_env("ICP_DIRECT_ABOVE") ? std::atof(dev_env("ICP_DIRECT_ABOVE")) : 2.0;
       for (int i = 0; i < n_props; ++i) rqs[i].direct = e->acc_ema >= direct_above;
-      const hipStream_t es = eigen_stream_for(c, c.eig_stream);
+      const hipStream_t es = eigen_stream_for(c, c.eig_stream.get());
       launch_posterior_eigen_pair(es, r, c.sqrt_lambda.p, n_props, rqs);  // (no event: completion words, see start_decompositions)
     }
     // the caller's outcome-independent host work runs beside the device — first of all the pre-launch of the next step's
@@ -596,7 +596,7 @@ int icp_chain_step(icp_evaluator* e, int32_t n_props, icp_proposal* const* props
       // that lets one kernel run at a time in an order of its own (rocprofv3 --pmc): drain everything, switch the pipelining
       // off for this context, and do the step again — nothing of it has been recorded.
       HIP_OK(hipStreamSynchronize(c.stream));
-      HIP_OK(hipStreamSynchronize(c.front_stream));  // (a half step launched ahead may time out here, too)
+      c.front_stream.sync();  // (a half step launched ahead may time out here, too)
       sync_eigen(c);
       c.h_wait_error[0] = 0;
       ++c.stats.wait_timeouts; ++g_runtime_stats.wait_timeouts;

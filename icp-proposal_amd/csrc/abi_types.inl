@@ -51,6 +51,15 @@ struct DeviceQuiesce {  // scope of an object's destruction: ONE wait for the de
   DeviceQuiesce();
   ~DeviceQuiesce();
 };
+// Scope of an object's CREATION: the fills and uploads of its new buffers (DBuf::fill_bytes / upload: null-stream work, which is not
+// ordered against this library's non-blocking streams) are waited for ONCE, when the scope ends — before the creating call returns
+// and anybody can launch on the buffers — instead of once per buffer (a proposal makes five, an evaluator four: 40 µs each).
+struct NullStreamBatch {
+  static thread_local int depth;
+  NullStreamBatch() { ++depth; }
+  ~NullStreamBatch() { if (--depth == 0) (void)hipStreamSynchronize(nullptr); }
+};
+thread_local int NullStreamBatch::depth = 0;
 
 template <class T>
 struct DBuf {
@@ -82,7 +91,7 @@ struct DBuf {
     alloc(count);
     if (count) {
       HIP_OK(hipMemcpy(p, src, sizeof(T) * count, hipMemcpyHostToDevice));
-      HIP_OK(hipStreamSynchronize(nullptr));  // (as fill_bytes: the copy has reached the device before any launch can read it)
+      if (NullStreamBatch::depth == 0) HIP_OK(hipStreamSynchronize(nullptr));  // (as fill_bytes: the copy has reached the device before any launch can read it)
     }
   }
   // (hipMemset may return before the device has filled device memory, and what it enqueues on the null stream is not ordered against
@@ -91,7 +100,7 @@ struct DBuf {
   // arrivals, every later gate of that slot two seconds late.  The null stream is waited for here.)
   void fill_bytes(int v) {
     HIP_OK(hipMemset(p, v, sizeof(T) * (n ? n : 1)));
-    HIP_OK(hipStreamSynchronize(nullptr));
+    if (NullStreamBatch::depth == 0) HIP_OK(hipStreamSynchronize(nullptr));
   }
 };
 
@@ -335,6 +344,27 @@ RuntimeStats g_runtime_stats;
 struct StepPaths { std::atomic<int64_t> n[4] = {{0}, {0}, {0}, {0}}; };
 StepPaths g_step_paths;
 
+// One of a context's side streams (the merged step's second stream, the eigen streams), made on first use where the context asks for
+// that: hipStreamCreateWithPriority takes 3-4 ms, a context has three of them beside its own stream, and a context that is only ever
+// stepped as a MEMBER of batches (icp_chain_step_batched / the on-device loop: the launch context's streams carry everything) never
+// enqueues on them — 57 of the 80 stream creations of a 10 targets x 10 chains job, a fifth of its wall time with chains of 50 steps.
+// The first two contexts alive in a process make theirs at creation, next to the context stream (the runtime maps streams to its
+// hardware queues in creation order: a latecomer shared a queue with the context stream, NOTES round 2).  No implicit conversion:
+// get() where something is enqueued, peek() where a stream is compared, sync() where one is drained (a stream never made has nothing).
+struct LazyStream {
+  hipStream_t s = nullptr;
+  int device = -1, priority = 0;
+  bool greatest = false, eigen = false;
+  void arm(int dev, bool great, int prio, bool is_eigen, bool now);
+  hipStream_t get();
+  hipStream_t peek() const { return s; }
+  bool armed() const { return device >= 0; }
+  explicit operator bool() const { return armed(); }  // "the context has such a stream"
+  void sync();                                        // HIP_OK(hipStreamSynchronize) if it exists
+  void sync_quiet() { if (s) (void)hipStreamSynchronize(s); }
+  hipStream_t release() { hipStream_t r = s; s = nullptr; device = -1; return r; }
+};
+
 struct icp_ctx {
   int device = 0;
   RuntimeStats stats;
@@ -344,11 +374,11 @@ struct icp_ctx {
   // to the other.  Launches 1-3 of a step do not depend on the finish launch of the step before it and run beside it; what
   // they must not overtake is that step's searches (same scratch, same hints), so launch 1 waits on the device for the word
   // the finish launch of that step raises when it starts (StepBeginArgs::wait_flag).  No event crosses the two streams.
-  hipStream_t front_stream = nullptr;            // the second of the two (`stream` is the first, and everybody else's)
+  LazyStream front_stream;                       // the second of the two (`stream` is the first, and everybody else's)
   // every eigen-decomposition of the context runs on this stream, beside the chain (launch order = execution order, so the
   // decompositions of one proposal never overlap each other; the two directions of a step share ONE launch)
-  hipStream_t eig_stream = nullptr;
-  hipStream_t eig_stream2 = nullptr;  // ranks above 64: decompositions started ahead alternate between the two (each with a work buffer of its own)
+  LazyStream eig_stream;
+  LazyStream eig_stream2;  // ranks above 64: decompositions started ahead alternate between the two (each with a work buffer of its own)
   hipStream_t eig_last2 = nullptr; // (the wide step's second eigen stream, see batch_eig2)
   hipStream_t eig_last = nullptr;  // where this context's latest decompositions were launched: eig_stream, or the eigen stream
                                    // of the first context of a batch (see eigen_stream_for)
@@ -466,7 +496,7 @@ struct icp_ctx {
     QueryScratch& scratch = which == 1 ? scratch_v : which == 2 ? scratch_t : which == 3 ? scratch_n : which == 4 ? scratch_tn : which == 5 ? scratch_p : which == 6 ? scratch_en : this->scratch;
     if (K > scratch.cap) {
       HIP_OK(hipStreamSynchronize(stream));
-      if (front_stream) HIP_OK(hipStreamSynchronize(front_stream));
+      front_stream.sync();
       size_t cap = std::max<size_t>(K, 4096);
       scratch.thr2.alloc(cap + 8);
       scratch.qrec.alloc(cap + 8);
@@ -477,7 +507,7 @@ struct icp_ctx {
     const size_t want = std::min(kMaxCandidates, std::max<size_t>((K + 4) * std::min<size_t>(std::max<size_t>(n_elems, 1), (size_t)kCandStrideMax), 1));
     if (want > scratch.cand_cap) {
       HIP_OK(hipStreamSynchronize(stream));
-      if (front_stream) HIP_OK(hipStreamSynchronize(front_stream));
+      front_stream.sync();
       scratch.cand.alloc(want);
       scratch.cand_cap = want;
     }
@@ -549,7 +579,7 @@ struct Bound {  // selects the context's device and (if enabled) its profiler fo
     c->bind();
     g_prof = c->profiling ? &c->prof : nullptr;
     if (!chain_path) {
-      if (c->front_stream_used) { (void)hipStreamSynchronize(c->front_stream); c->front_stream_used = false; }
+      if (c->front_stream_used) { c->front_stream.sync_quiet(); c->front_stream_used = false; }
       c->stream_used_elsewhere = true;
     }
   }

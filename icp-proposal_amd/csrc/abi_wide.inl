@@ -170,17 +170,17 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   if (idx.empty()) return;
   const int r = elead.r, nW = (int)idx.size();
   std::lock_guard<std::recursive_mutex> lead_lk(lead.mu);  // (its streams, its record ring)
-  const hipStream_t S = lead.stream, S2 = lead.front_stream;
+  const hipStream_t S = lead.stream, S2 = lead.front_stream.get();
   // Two eigen streams: the decompositions of a chain's consecutive steps alternate between them (and between the proposal's two work
   // buffers), so that one started ahead for a state that was then not kept — or whose successor was a pose move that did not wait
   // for it — does not hold the next one back: at rank 200 a decomposition takes 0.6-0.7 ms, a step that does not wait for one half
   // of that.  A lone chain uses its context's own pair (made with the context, on hardware queues of their own), a batch the launch
   // context's pool.  (Ranks <= 64: one stream — the Jacobi iteration is warm-started from the decomposition before it.)
-  const bool two_eig = eigen_tridiag_many_supported(r) && elead.eig_stream2 != nullptr;
+  const bool two_eig = eigen_tridiag_many_supported(r) && elead.eig_stream2.armed();
   const bool lone = t.n_chains == 1 && &lead == &elead;
   hipStream_t Es[2];
-  Es[0] = lone ? elead.eig_stream : batch_eigen_stream(lead, &elead, 0);
-  Es[1] = !two_eig ? Es[0] : (lone ? elead.eig_stream2 : batch_eigen_stream(lead, &elead, 1));
+  Es[0] = lone ? elead.eig_stream.get() : batch_eigen_stream(lead, &elead, 0);
+  Es[1] = !two_eig ? Es[0] : (lone ? elead.eig_stream2.get() : batch_eigen_stream(lead, &elead, 1));
   const int turn = (lead.wide_turn = (lead.wide_turn + 1) % icp_ctx::kBatchRing);
   {
     Bound _b(&lead, true, true);
@@ -461,7 +461,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
       g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
       g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];
       if (p->side_factor_pending || p->side_asm_pending) {  // (a per-stage step of this proposal left work on its side streams)
-        HIP_OK(hipStreamSynchronize(c.front_stream)); sync_eigen(c);
+        c.front_stream.sync(); sync_eigen(c);
         p->side_factor_pending = false; p->side_asm_pending = false;
       }
       p->side_parts = nullptr; p->side_parts_entry = nullptr;

@@ -79,6 +79,48 @@ __device__ __forceinline__ double wave_sum(double v) {
   return readlane_f64(v, 63);
 }
 
+// NV sums over the 64 lanes at once, the same totals in every lane: the four in-row DPP exchanges stage by stage for all values (NV
+// independent chains in flight instead of one: a lone wave_sum is ≈ 250 cycles of dependent DPP steps and their hazards), then
+// every value's four row totals meet in ONE register — lane 16g + q takes value q's total of row g —, two cross-row steps on that
+// register (lane-wise exchanges with the rows 16 and 32 lanes away), and lane q holds value q's sum.  Call with all lanes active; NV <= 16.
+template <int NV> __device__ __forceinline__ void wave_sum_many(double (&v)[NV]) {
+  static_assert(NV >= 1 && NV <= 16, "one lane of a row of 16 per value");
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] += dpp_f64<0xB1>(v[q]);
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] += dpp_f64<0x4E>(v[q]);
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] += dpp_f64<0x141>(v[q]);
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] += dpp_f64<0x140>(v[q]);
+  const int lq = threadIdx.x & 15;
+  double t = 0.0;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) t = lq == q ? v[q] : t;
+  t += __shfl_xor(t, 16, 64);  // (lane by lane across the rows: the row-broadcast DPP forms hand on ONE lane's value)
+  t += __shfl_xor(t, 32, 64);  // every lane 16g + q now holds value q's sum
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = readlane_f64(t, q);
+}
+
+// a number as mantissa × 2^exponent (products of hundreds of factors — the eigenvector entries of the twisted factorisation — without
+// overflow or underflow along the way)
+struct ScaledF64 {
+  double m;
+  int e;
+};
+__device__ __forceinline__ ScaledF64 scaled_of(double x) {
+  const int ex = __builtin_amdgcn_frexp_exp(x);
+  return ScaledF64{ldexp(x, -ex), ex};
+}
+__device__ __forceinline__ ScaledF64 scaled_mul(const ScaledF64& a, const ScaledF64& b) {
+  const double m = a.m * b.m;
+  const int ex = __builtin_amdgcn_frexp_exp(m);
+  return ScaledF64{ldexp(m, -ex), a.e + b.e + ex};
+}
+__device__ __forceinline__ ScaledF64 scaled_shfl_up(const ScaledF64& a, int d) { return ScaledF64{__shfl_up(a.m, d, 64), __shfl_up(a.e, d, 64)}; }
+__device__ __forceinline__ ScaledF64 scaled_shfl_down(const ScaledF64& a, int d) { return ScaledF64{__shfl_down(a.m, d, 64), __shfl_down(a.e, d, 64)}; }
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Tridiagonalisation.  NW waves; lane l of wave w holds A[i][j] for i = l + 64·s (s < SI), j = w + NW·t (t < NT), the FULL
 // symmetric matrix: a product A·x accumulates inside a thread over its wave's columns, and the NW partial sums per row meet
@@ -668,6 +710,7 @@ struct TriSolveIO {
   double* Vt;         // n×n: row `rank`
   double* S;          // [n] = 1/mu, descending
   double* mu;         // [n] scratch: the eigenvalues, ascending (the last wave checks the gaps)
+  const double* wy;   // [ceil((n−2)/8)][64] T factors of the reflector blocks (k_tri_wy), row-major 8×8, upper triangles
   int* sync;          // [3] {waves finished, trouble flags, skip: 1 = cancelled, 2 = its input never came}: zero between launches
   int* status;        // status[0]: 0 ok, 2 = not trustworthy (gaps below resolution / non-finite); status[-1]: 0
   // (ranks <= 64, where nothing follows this launch) published by the last wave:
@@ -683,6 +726,7 @@ struct TriSolveIO {
 constexpr int kTriPasses = 7;       // multisection passes of 64 points: the bracket shrinks 65× per pass
 constexpr int kTriRounds = 1;       // twisted factorisations (each followed by a Rayleigh-quotient correction)
 constexpr int kTriMaxN = 256;
+constexpr int kWyBlock = 8;         // reflectors per compact-WY block of the back-transformation
 
 // number of eigenvalues of the (scaled) tridiagonal matrix below x: sign changes of the leading principal minors, by the
 // three-term recurrence (one dependent fma per row), rescaled every eighth row
@@ -730,13 +774,80 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const 
   return cnt;
 }
 
+// The reflectors in blocks of eight, compact WY (dlarft, forward / columnwise): H_k0 ··· H_k0+7 = I − V·T·Vᵀ with T upper triangular,
+// T_ii = β_i, T_{0:i,i} = −β_i · T_{0:i,0:i} · (V_{:,0:i}ᵀ v_i).  One wave per block (28 inner products, reduced seven at a time); the
+// eigenpair waves of the solve launch then apply EIGHT reflectors per round of reductions (tri_solve_body).  Runs between the
+// reduction and the solve.
+struct TriWyIO {
+  int n;
+  const double* beta;
+  const double* Hv;   // [n][64·SI]
+  double* wy;         // [ceil((n−2)/8)][64]
+  const int* sync;    // sync[2] != 0: the decomposition was dropped — nothing to do
+};
+template <int SI>
+__device__ __forceinline__ void tri_wy_body(const TriWyIO& a) {
+  constexpr int LD = 64 * SI;
+  const int n = a.n, l = threadIdx.x, blk = blockIdx.x;
+  const int k0 = blk * kWyBlock;
+  if (k0 >= n - 2) return;
+  if (__hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  double v[kWyBlock][SI], bet[kWyBlock];
+#pragma unroll
+  for (int q = 0; q < kWyBlock; ++q) {
+    bet[q] = k0 + q < n - 2 ? a.beta[k0 + q] : 0.0;
+#pragma unroll
+    for (int s = 0; s < SI; ++s) v[q][s] = k0 + q < n - 2 ? a.Hv[(size_t)(k0 + q) * LD + l + 64 * s] : 0.0;
+  }
+  double T[kWyBlock][kWyBlock];
+#pragma unroll
+  for (int i = 0; i < kWyBlock; ++i) {
+    double g[kWyBlock - 1];
+#pragma unroll
+    for (int jj = 0; jj < kWyBlock - 1; ++jj) {
+      g[jj] = 0.0;
+      if (jj < i) {
+#pragma unroll
+        for (int s = 0; s < SI; ++s) g[jj] = fma(v[jj][s], v[i][s], g[jj]);
+      }
+    }
+    if (i > 0) wave_sum_many<kWyBlock - 1>(g);
+#pragma unroll
+    for (int jj = 0; jj < i; ++jj) {
+      double t = 0.0;
+#pragma unroll
+      for (int m = jj; m < i; ++m) t = fma(T[jj][m], g[m], t);
+      T[jj][i] = -bet[i] * t;
+    }
+    T[i][i] = bet[i];
+  }
+  double* out = a.wy + (size_t)blk * kWyBlock * kWyBlock;
+  if (l == 0) {
+#pragma unroll
+    for (int jj = 0; jj < kWyBlock; ++jj)
+#pragma unroll
+      for (int i = 0; i < kWyBlock; ++i) out[jj * kWyBlock + i] = i >= jj ? T[jj][i] : 0.0;
+  }
+}
+template <int SI>
+__global__ void __launch_bounds__(64) k_tri_wy(TriWyIO a0, TriWyIO a1) { tri_wy_body<SI>(blockIdx.y ? a1 : a0); }
+struct TriWyMany { TriWyIO p[kTriMany]; };
+template <int SI>
+__global__ void __launch_bounds__(64) k_tri_wy_many(TriWyMany m) {
+  const TriWyIO a = m.p[blockIdx.y];
+  tri_wy_body<SI>(a);
+}
+
 template <int SI>
 __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
   constexpr int LD = 64 * SI;
   const int off = LD - a.n;  // position of index 0 (see tridiagonalise)
-  __shared__ double ds[kTriMaxN], es[kTriMaxN], e2[kTriMaxN], bet[kTriMaxN];
-  __shared__ double scr[4][4 * kTriMaxN];
+  __shared__ double ds[kTriMaxN + 8], es[kTriMaxN], e2[kTriMaxN + 8], bet[kTriMaxN];
+  __shared__ double scr[4][4 * kTriMaxN + 16];
   __shared__ double red[8];
+  __shared__ double dsr[kTriMaxN + 8], e2r[kTriMaxN + 8];           // the matrix bottom-up (the second chain of the factorisation reads forward, too)
+  __shared__ double carry[4][2][kTriMaxN / 8 + 1];                    // per wave and chain: the rescaled value a group of eight rows hands to the next
+  __shared__ double wy[(kTriMaxN / kWyBlock) * kWyBlock * kWyBlock];  // T factors of the reflector blocks
   const int n = a.n;
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -779,7 +890,12 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     es[i] = ee;
     e2[i] = fmax(ee * ee, 1e-280);
     bet[i] = i < n - 2 ? a.beta[i] : 0.0;
+    dsr[n - 1 - i] = a.d[i] * inv;
+    if (i < n - 1) e2r[n - 2 - i] = fmax(ee * ee, 1e-280);
   }
+  if (tid < 8) { ds[n + tid] = 0.0; e2[n + tid] = 0.0; dsr[n + tid] = 0.0; e2r[n - 1 + tid] = 0.0; }  // (read, never used, by the chains' last group)
+  const int nblk = (n - 2 + kWyBlock - 1) / kWyBlock;
+  for (int i = tid; i < nblk * kWyBlock * kWyBlock; i += 256) wy[i] = a.wy[i];
   __syncthreads();
   if (j >= n) return;  // (no barrier below)
   TRI_STAMP(9);
@@ -799,10 +915,18 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     }
   }
   TRI_STAMP(10);
-  // ---- eigenvector of T by twisted factorisation: lane 0 factors T − λI from the top, lane 1 from the bottom (the same
-  // instruction stream), the twist goes where |γ| is smallest; (T − λI) z = γ_r e_r, and γ_r/‖z‖² corrects λ
-  double* Dq = scr[w];               // [2][n]: D⁺ | D⁻
-  double* Lq = scr[w] + 2 * n;       // [2][n]: L⁺ | U⁻
+  // ---- eigenvector of T by twisted factorisation, (T − λI) z = γ_r e_r with the twist r where |γ| is smallest; γ_r/‖z‖² corrects λ.
+  // Round 5: the two pivot sequences D⁺ (from the top) and D⁻ (from the bottom) as RATIOS of the three-term recurrence's values,
+  // p_m = (d_m − λ)·p_{m−1} − e²·p_{m−2}, D_m = p_m / p_{m−1} — the numbers of the pivot recurrence D_m = (d_m − λ) − e²/D_{m−1}, each step
+  // perturbing d_m − λ and e² by an ulp as that one does — so that the chain of n − 1 dependent steps is one multiply-add per row
+  // instead of a division (it was 144 cycles per row, 12 µs at rank 200), lane 0 on the matrix and lane 1 on its bottom-up copy with
+  // one instruction stream; all divisions follow at once, a few per lane.  The vector's entries are products of the multipliers
+  // away from the twist: an exclusive product scan over the lanes (four consecutive rows per lane, mantissa and exponent apart —
+  // a partial product far from the twist may leave the range of a double where the entry itself is harmless) instead of two chains
+  // of up to n − 1 dependent multiplications.  36 → 5 µs per eigenpair wave at rank 200.
+  double* Dq = scr[w];               // [2][n]: D⁺ | D⁻ by row
+  double* Pc = scr[w] + 2 * n;       // [2][n + 8]: the chains' values in chain order (top-down | bottom-up; a group of eight is filed whole)
+  const int np = n + 8;
   double* zb = Dq;                   // z overwrites D⁺ once γ is known
   double lam = 0.5 * (lo + hi);
   double znorm2 = 1.0;
@@ -810,32 +934,51 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
   for (int round = 0; round < kTriRounds; ++round) {
     if (l < 2) {
       const int dir = l;
-      int i = dir ? n - 1 : 0;
-      const int st = dir ? -1 : 1;
-      double D = ds[i] - lam;
-      Dq[dir * n + i] = D;
-      double ee = es[dir ? i - 1 : i], dnr = ds[i + st];  // the next step's coefficients are fetched a step ahead (used, raw, a step later:
-      for (int k = 0; k < n - 1; ++k) {                    // nothing waits for the fetch where it is issued)
-        const double dn = dnr - lam;
-        const int ie = dir ? i - 1 : i;
-        // (no guard against a vanishing pivot in the chain: an exact zero turns the vector into NaNs, which the norm test below
-        // reports; the reciprocal is the hardware seed and one Newton step — 1e-15, and λ is corrected afterwards anyway)
-        double y = __builtin_amdgcn_rcp(D);
-        y = fma(y, fma(-D, y, 1.0), y);
-        const double L = ee * y;
-        const double Dn = fma(-L, ee, dn);
-        i += st;
-        // (fetched unconditionally: past the ends the arrays are padded, and nothing uses what comes back)
-        const int inext = max(min(i + st, n - 1), 0), ienext = max(dir ? i - 1 : i, 0);
-        const double ee_next = es[ienext];
-        dnr = ds[inext];
-        Lq[dir * n + ie] = L;
-        Dq[dir * n + i] = Dn;
-        D = Dn;
-        ee = ee_next;
+      const double* dd_ = dir ? dsr : ds;
+      const double* ee_ = dir ? e2r : e2;
+      double* pc = Pc + dir * np;
+      double* cg = carry[w][dir];
+      double p0 = 1.0, p1 = dd_[0] - lam;
+      pc[0] = p1;
+      int g = 0;
+      for (int m0 = 1; m0 < n; m0 += 8, ++g) {  // rows m0 .. m0+7 of the chain (past the end: padded coefficients, results unused)
+        double dd[8], ee[8];  // (fetched where they are used: requested a group ahead the loop was SLOWER — 6.5 → 8.6 µs at rank 200; a lone
+        // wave's f64 instructions issue every eight cycles, the loop is bound by their number, not by the LDS round trip)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { dd[u] = dd_[m0 + u] - lam; ee[u] = ee_[m0 + u - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double p2 = fma(dd[u], p1, -(ee[u] * p0));
+          pc[m0 + u] = p2;
+          p0 = p1;
+          p1 = p2;
+        }
+        // rescaled by a power of two (both values: the recurrence is linear); the next group's first ratio divides by the rescaled value
+        const int ex = max(__builtin_amdgcn_frexp_exp(p0), __builtin_amdgcn_frexp_exp(p1));
+        p0 = ldexp(p0, -ex);
+        p1 = ldexp(p1, -ex);
+        cg[g] = p1;
       }
     }
     wave_lds_sync();
+    TRI_STAMP(30);
+    // D by row: chain position m of the top-down chain is row m, of the bottom-up chain row n − 1 − m; the denominator of a group's first
+    // row is the value the group before handed over
+#pragma unroll
+    for (int s = 0; s < SI; ++s) {
+      const int m = l + 64 * s;
+      if (m < n) {
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+          const double* pc = Pc + dir * np;
+          const double den = m == 0 ? 1.0 : (((m - 1) & 7) == 0 && m > 1) ? carry[w][dir][(m - 1) / 8 - 1] : pc[m - 1];
+          const double D = pc[m] / den;
+          Dq[dir * n + (dir ? n - 1 - m : m)] = D;
+        }
+      }
+    }
+    wave_lds_sync();
+    TRI_STAMP(31);
     double gbest = 1e300;
     int ibest = 0;
     for (int i = l; i < n; i += 64) {
@@ -849,26 +992,42 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     }
     const int rt = ibest;
     const double gamma = (Dq[rt] + Dq[n + rt]) - (ds[rt] - lam);
-    wave_lds_sync();
-    if (l < 2) {
-      const int dir = l;
-      const int cnt = dir ? n - 1 - rt : rt;
-      double zc = 1.0;
-      int idx = rt;
-      const int stp = dir ? 1 : -1;
-      const double* lq = Lq + dir * n + (dir ? 0 : -1);  // the multiplier of the step from idx: lq[idx]
-      double l0 = cnt > 0 ? lq[idx] : 0.0, l1 = cnt > 1 ? lq[idx + stp] : 0.0;  // fetched two steps ahead
-      for (int k = 0; k < cnt; ++k) {
-        const double l2 = k + 2 < cnt ? lq[idx + 2 * stp] : 0.0;
-        zc = -(l0 * zc);
-        idx += stp;
-        zb[idx] = zc;
-        l0 = l1;
-        l1 = l2;
+    TRI_STAMP(32);
+    // z_rt = 1; above the twist z_i = −(e_i / D⁺_i)·z_{i+1}, below it z_i = −(e_{i−1} / D⁻_i)·z_{i−1}: lane l takes rows SI·l .. SI·l + SI − 1
+    {
+      double fa[SI], fb[SI];  // the row's factor towards the twist from below (prefix side) / from above (suffix side); 1 elsewhere
+#pragma unroll
+      for (int s = 0; s < SI; ++s) {
+        const int i = SI * l + s;
+        fa[s] = (i > rt && i < n) ? -(es[i - 1] / Dq[n + i]) : 1.0;
+        fb[s] = (i < rt) ? -(es[i] / Dq[i]) : 1.0;
       }
-      if (dir == 0) zb[rt] = 1.0;
+      double pa[SI], pb[SI];  // inclusive products inside the lane: from its first row down / from its last row up
+      pa[0] = fa[0];
+#pragma unroll
+      for (int s = 1; s < SI; ++s) pa[s] = pa[s - 1] * fa[s];
+      pb[SI - 1] = fb[SI - 1];
+#pragma unroll
+      for (int s = SI - 2; s >= 0; --s) pb[s] = pb[s + 1] * fb[s];
+      ScaledF64 xa = scaled_of(pa[SI - 1]), xb = scaled_of(pb[0]);
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {  // inclusive scans over the lanes (up for the prefix side, down for the suffix side)
+        const ScaledF64 oa = scaled_shfl_up(xa, d), ob = scaled_shfl_down(xb, d);
+        if (l >= d) xa = scaled_mul(xa, oa);
+        if (l + d < 64) xb = scaled_mul(xb, ob);
+      }
+      ScaledF64 ea = scaled_shfl_up(xa, 1), eb = scaled_shfl_down(xb, 1);  // exclusive: what lies before / behind this lane
+      if (l == 0) ea = ScaledF64{1.0, 0};
+      if (l == 63) eb = ScaledF64{1.0, 0};
+      wave_lds_sync();  // (every lane has read the pivots: z overwrites D⁺)
+#pragma unroll
+      for (int s = 0; s < SI; ++s) {
+        const int i = SI * l + s;
+        if (i < n) zb[i] = ldexp((ea.m * pa[s]) * (eb.m * pb[s]), ea.e + eb.e);
+      }
     }
     wave_lds_sync();
+    TRI_STAMP(33);
     double zz = 0.0;
     for (int i = l; i < n; i += 64) zz = fma(zb[i], zb[i], zz);
     znorm2 = wave_sum(zz);
@@ -886,32 +1045,53 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     for (int s = 0; s < SI; ++s) zs[s] = l + 64 * s >= off ? zb[l + 64 * s - off] * sc : 0.0;
   }
   {
-    constexpr int PF = 8;  // (reflectors in flight from L2: 2 -> 46 µs of back-transformation at rank 200, 4 -> 42, 8 and 16 -> 37)
-    double vq[PF][SI];
+    // in blocks of eight reflectors, z ← (I − V·T·Vᵀ) z with the T factors of k_tri_wy, last block first: eight inner products reduced
+    // together (wave_sum_many) instead of eight dependent (dot product → wave reduction → update) rounds; the next block's
+    // reflectors are requested a block ahead (L2: ≈ 500 cycles)
+    // (two register sets, one in use while the other is on its way: every load is unconditional — a clamped row, zeroed afterwards
+    // where the block runs past the last reflector — and issued before the block in hand is touched)
+    double va[kWyBlock][SI], vb2[kWyBlock][SI];
+    auto fetch = [&](double (&dst)[kWyBlock][SI], int blk) {
+      const int b = max(blk, 0);
 #pragma unroll
-    for (int q = 0; q < PF; ++q) {
-      const int k = n - 3 - q;
+      for (int q = 0; q < kWyBlock; ++q) {
+        const int k = min(b * kWyBlock + q, n - 3);
 #pragma unroll
-      for (int s = 0; s < SI; ++s) vq[q][s] = k >= 0 ? a.Hv[(size_t)k * LD + l + 64 * s] : 0.0;
-    }
-    for (int kb = n - 3; kb >= 0; kb -= PF) {
+        for (int s = 0; s < SI; ++s) dst[q][s] = a.Hv[(size_t)k * LD + l + 64 * s];
+      }
+    };
+    auto apply = [&](double (&v)[kWyBlock][SI], int blk) {
+      const double* Tb = wy + blk * kWyBlock * kWyBlock;
+      double u[kWyBlock];
 #pragma unroll
-      for (int q = 0; q < PF; ++q) {
-        const int k = kb - q;
-        double v[SI];
+      for (int q = 0; q < kWyBlock; ++q) {
+        const bool live = blk * kWyBlock + q < n - 2;
+        u[q] = 0.0;
 #pragma unroll
-        for (int s = 0; s < SI; ++s) v[s] = vq[q][s];
-        const int kn = k - PF;
-#pragma unroll
-        for (int s = 0; s < SI; ++s) vq[q][s] = kn >= 0 ? a.Hv[(size_t)kn * LD + l + 64 * s] : 0.0;
-        if (k >= 0) {
-          double dp = 0.0;
-#pragma unroll
-          for (int s = 0; s < SI; ++s) dp = fma(v[s], zs[s], dp);
-          const double f = bet[k] * wave_sum(dp);
-#pragma unroll
-          for (int s = 0; s < SI; ++s) zs[s] = fma(-f, v[s], zs[s]);
+        for (int s = 0; s < SI; ++s) {
+          v[q][s] = live ? v[q][s] : 0.0;
+          u[q] = fma(v[q][s], zs[s], u[q]);
         }
+      }
+      wave_sum_many<kWyBlock>(u);  // u = Vᵀz
+#pragma unroll
+      for (int jj = 0; jj < kWyBlock; ++jj) {  // t = T·u (upper triangle), then z −= V·t
+        double t = 0.0;
+#pragma unroll
+        for (int i = jj; i < kWyBlock; ++i) t = fma(Tb[jj * kWyBlock + i], u[i], t);
+#pragma unroll
+        for (int s = 0; s < SI; ++s) zs[s] = fma(-t, v[jj][s], zs[s]);
+      }
+    };
+    fetch(va, nblk - 1);
+    for (int blk = nblk - 1; blk >= 0; blk -= 2) {
+      fetch(vb2, blk - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      apply(va, blk);
+      if (blk - 1 >= 0) {
+        fetch(va, blk - 2);
+        __builtin_amdgcn_sched_barrier(0);
+        apply(vb2, blk - 1);
       }
     }
   }

@@ -2228,8 +2228,10 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   const size_t rr = (size_t)r * r;
   double *Nm = work, *X = work + rr, *Xt = work + 2 * rr, *T = work + 3 * rr, *Sm = work + 4 * rr, *R = work + 5 * rr;
   tri::TridiagIO ti{r, M, sqrt_lambda, d, e, beta, Hv, Nm};
-  tri::TriSolveIO so{r, d, e, beta, Hv, X, Xt, S, mu, sync, status, nullptr, nullptr, 0};
-  const int nwg = (r + 3) / 4;
+  // (the reflector blocks' T factors live where the refinement's R will be: written behind the solve)
+  tri::TriSolveIO so{r, d, e, beta, Hv, X, Xt, S, mu, R, sync, status, nullptr, nullptr, 0};
+  const tri::TriWyIO wyio{r, beta, Hv, R, sync};
+  const int nwg = (r + 3) / 4, nwy = (r - 2 + tri::kWyBlock - 1) / tri::kWyBlock;
   if (part != 2) {  // the reduction
     if (r <= 64) hipLaunchKernelGGL((tri::k_tridiag<4, 1, 16, 0>), dim3(1), dim3(256), 0, st, ti);
     else if (r <= 128) hipLaunchKernelGGL((tri::k_tridiag<4, 2, 32, 0>), dim3(1), dim3(256), 0, st, ti);
@@ -2237,6 +2239,10 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
     else hipLaunchKernelGGL((tri::k_tridiag<8, 4, 25, 7>), dim3(1), dim3(512), 0, st, ti);
   }
   if (part == 1) return;
+  if (r <= 64) hipLaunchKernelGGL(tri::k_tri_wy<1>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
+  else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_wy<2>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
+  else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_wy<3>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
+  else hipLaunchKernelGGL(tri::k_tri_wy<4>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
   if (r <= 64) hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), 0, st, so, so);
   else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), 0, st, so, so);
   else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg), dim3(256), 0, st, so, so);
@@ -2267,6 +2273,7 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
     const EigenRequest* rq = rq_all + q0;
     tri::TridiagMany tm{};
     tri::TriSolveMany sm{};
+    tri::TriWyMany wm{};
     tri::TriGemmMany g1{}, g2{}, g3{};
     tri::TriCorrMany cm{};
     tri::TriDoneMany dm{};
@@ -2281,7 +2288,8 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
       double *Nm = work, *X = work + rr, *Xt = work + 2 * rr, *T = work + 3 * rr, *Sm = work + 4 * rr, *R = work + 5 * rr;
       const double* sl = rq[q].sqrt_lambda;
       tm.p[q] = tri::TridiagIO{r, rq[q].M, sl, d, e, beta, Hv, Nm};
-      sm.p[q] = tri::TriSolveIO{r, d, e, beta, Hv, X, Xt, rq[q].S, mu, sync, rq[q].status, nullptr, nullptr, 0};
+      sm.p[q] = tri::TriSolveIO{r, d, e, beta, Hv, X, Xt, rq[q].S, mu, R, sync, rq[q].status, nullptr, nullptr, 0};
+      wm.p[q] = tri::TriWyIO{r, beta, Hv, R, sync};
       g1.g[2 * q] = tri::TriGemm{Nm, X, T, 0, nullptr, nullptr};
       g1.g[2 * q + 1] = tri::TriGemm{X, X, R, 1, nullptr, nullptr};
       g2.g[q] = tri::TriGemm{X, T, Sm, 0, nullptr, nullptr};
@@ -2297,6 +2305,10 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
     if (r <= 128) hipLaunchKernelGGL((tri::k_tridiag_many<4, 2, 32, 0>), dim3(n), dim3(256), 0, st, tm);
     else if (r <= 192) hipLaunchKernelGGL((tri::k_tridiag_many<8, 3, 24, 0>), dim3(n), dim3(512), 0, st, tm);
     else hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 25, 7>), dim3(n), dim3(512), 0, st, tm);
+    const int nwy = (r - 2 + tri::kWyBlock - 1) / tri::kWyBlock;
+    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_wy_many<2>, dim3(nwy, n), dim3(64), 0, st, wm);
+    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_wy_many<3>, dim3(nwy, n), dim3(64), 0, st, wm);
+    else hipLaunchKernelGGL(tri::k_tri_wy_many<4>, dim3(nwy, n), dim3(64), 0, st, wm);
     if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg, n), dim3(256), 0, st, sm);
     else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve_many<3>, dim3(nwg, n), dim3(256), 0, st, sm);
     else hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg, n), dim3(256), 0, st, sm);
@@ -2521,6 +2533,7 @@ static void launch_eigen_tridiag_small(hipStream_t st, int r, const double* sqrt
   tri::TriSmallBatch b{};
   b.r = r;
   tri::TriSolveIO so[2] = {};
+  tri::TriWyIO wy[2] = {};
   for (int i = 0; i < n; ++i) {
     double* base = rq[i].work + jacobi_work_doubles(r);
     double *d = base, *e = base + tri::kTriMaxN, *beta = base + 2 * tri::kTriMaxN, *mu = base + 3 * tri::kTriMaxN;
@@ -2537,12 +2550,15 @@ static void launch_eigen_tridiag_small(hipStream_t st, int r, const double* sqrt
     p.sqrt_lambda = rq[i].sqrt_lambda ? rq[i].sqrt_lambda : sqrt_lambda;
     p.out = tri::TridiagIO{r, nullptr, nullptr, d, e, beta, Hv, nullptr};
     p.sync = sync;
-    so[i] = tri::TriSolveIO{r, d, e, beta, Hv, rq[i].V, rq[i].Vt, rq[i].S, mu, sync, rq[i].status, rq[i].host_status, rq[i].done_word,
+    // (the reflector blocks' T factors: at the head of `work`, the Jacobi kernels' area, which this route leaves alone)
+    so[i] = tri::TriSolveIO{r, d, e, beta, Hv, rq[i].V, rq[i].Vt, rq[i].S, mu, rq[i].work, sync, rq[i].status, rq[i].host_status, rq[i].done_word,
                             rq[i].done_value};
+    wy[i] = tri::TriWyIO{r, beta, Hv, rq[i].work, sync};
   }
-  if (n == 1) { b.p[1] = b.p[0]; so[1] = so[0]; }
+  if (n == 1) { b.p[1] = b.p[0]; so[1] = so[0]; wy[1] = wy[0]; }
   ProfScope _ps(st, KID_EIGEN);
   hipLaunchKernelGGL(tri::k_tridiag_small, dim3(n), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(tri::k_tri_wy<1>, dim3((r - 2 + tri::kWyBlock - 1) / tri::kWyBlock, n), dim3(64), 0, st, wy[0], wy[1]);
   hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3((r + 3) / 4, n), dim3(256), 0, st, so[0], so[1]);
 }
 

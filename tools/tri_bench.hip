@@ -139,6 +139,8 @@ int main(int argc, char** argv) {
   long long s[64]; hipMemcpyFromSymbol(s, HIP_SYMBOL(icp::g_eigen_stamps), sizeof(s));
   printf("%.1f us per decomposition (cold) | stamps: reduction %.1f | solve: setup %.1f multisection %.1f vectors %.1f back-transformation %.1f output %.1f\n", ms * 1000 / reps,
          (s[1] - s[0]) * 0.01, (s[9] - s[8]) * 0.01, (s[10] - s[9]) * 0.01, (s[11] - s[10]) * 0.01, (s[12] - s[11]) * 0.01, (s[13] - s[12]) * 0.01);
+  printf("vectors in detail: p-chains %.1f | ratios %.1f | twist search %.1f | z scan %.1f | norm %.1f\n", (s[30] - s[10]) * 0.01, (s[31] - s[30]) * 0.01,
+         (s[32] - s[31]) * 0.01, (s[33] - s[32]) * 0.01, (s[11] - s[33]) * 0.01);
   if (hog) {
     double *hbuf, *sink; const size_t hn = (size_t)8 << 20;
     CK(hipMalloc(&hbuf, 8 * hn)); CK(hipMemset(hbuf, 0, 8 * hn)); CK(hipMalloc(&sink, 64));
