@@ -719,14 +719,22 @@ struct TriSolveIO {
   int done_value;
 };
 
-// Seven multisection passes and ONE twisted factorisation (round 2: five and two): a factorisation is two chains of n − 1 dependent
-// divisions, ≈ 12 µs at rank 200, a pass 4.4 µs; with the bracket 65² times narrower the first factorisation's vector is as good as
-// the second one's was (posteriors with relative gaps down to 1e-6: orthogonality 2e-13..2e-12, |ΔV| against the oracle ≤ 3.5e-12 either
-// way, `tools/r3_eigen_margins.py`) and the refinement step squares what is left.  −32 µs per decomposition at rank 200.
-constexpr int kTriPasses = 7;       // multisection passes of 64 points: the bracket shrinks 65× per pass
-constexpr int kTriRounds = 1;       // twisted factorisations (each followed by a Rayleigh-quotient correction)
+// Seven multisection passes and TWO twisted factorisations.  Round 3 had dropped the second factorisation (two chains of n − 1
+// dependent divisions, 12 µs each at rank 200) and left what remained to the refinement step; round 5 made a factorisation cheap (the
+// pivots as ratios of the three-term recurrence, the vector by a product scan: 10 µs with everything around it) and brought the second
+// one back: with the eigenvalue corrected by the first round's Rayleigh quotient the second round's vector is accurate to eps·‖T‖/gap
+// (rank 200, gaps down to 1e-4 of the norm: |ΔV| 5e-13, orthogonality 2e-13 WITHOUT the refinement step — after one round 4e-10 and
+// 2e-9), and the refinement launches run only where a gap is narrow (kTriRefineGap).
+constexpr int kTriPasses = 7;       // multisection passes of 64 points: the bracket shrinks 65× per pass (five left the vectors of a pair 1e-4 apart 1e-10 off, and would leave one 1e-6 apart 1e-6 off: tri_bench)
+constexpr int kTriRounds = 2;       // twisted factorisations (each followed by a Rayleigh-quotient correction): round 5, two again — see kTriRefineGap
 constexpr int kTriMaxN = 256;
 constexpr int kWyBlock = 8;         // reflectors per compact-WY block of the back-transformation
+// The refinement step behind the solve launch (Ogita & Aishima, below) exists for eigenvectors of CLOSE eigenvalues: out of the twisted
+// factorisation a vector is accurate to eps·‖T‖/gap, and two vectors are orthogonal to each other only that far.  With every gap above
+// this fraction of the norm that is 1e-10 — a thousandth of what the parity tests allow (V to 1e-7, the north star 1e-5) — and the
+// four launches of the step (three r³ products, one elementwise pass: 40 µs at rank 200, 90 µs for 16 posteriors side by side) return at
+// once, the last one handing X on as V.  Smaller gaps: the step runs as before.
+constexpr double kTriRefineGap = 1e-6;
 
 // number of eigenvalues of the (scaled) tridiagonal matrix below x: sign changes of the leading principal minors, by the
 // three-term recurrence (one dependent fma per row), rescaled every eighth row
@@ -1138,13 +1146,15 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
   last = __builtin_amdgcn_readfirstlane(last);
   if (!last) return;
   __threadfence();
-  int bad = 0;
+  int bad = 0, close = 0;
   for (int i = l; i < n - 1; i += 64) {
     const double m0 = __hip_atomic_load(a.mu + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double m1 = __hip_atomic_load(a.mu + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!(m1 - m0 > 1e-10 * anorm)) bad = 1;
+    if (!(m1 - m0 > kTriRefineGap * anorm)) close = 1;
   }
   bad = __any(bad);
+  close = __any(close);
   if (l == 0) {
     if (__hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) bad = 1;
     const int st = bad ? 2 : 0;
@@ -1152,6 +1162,9 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     a.status[-1] = 0;
     a.sync[0] = 0;
     a.sync[1] = 0;
+    // the refinement launches behind this one look at sync[3]: 0 = refine, 1 = every gap is wide enough for the vectors as they are
+    // (hand X on as V), written anew by every solve launch
+    a.sync[3] = (close || bad) ? 0 : 1;
     if (a.host_status) __hip_atomic_store(a.host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (a.done_word) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1184,11 +1197,26 @@ struct TriGemm {
   int mode;          // 0: C = PᵀQ; 1: C = I − PᵀQ; 2: C = X + PᵀQ, and Ct = Cᵀ
   const double* X;
   double* Ct;
+  const int* skip;   // (optional) the solve launch's sync[3]: 1 = no refinement — modes 0, 1 return, mode 2 writes C = X, Ct = Xᵀ
 };
 __device__ __forceinline__ void tri_gemm_body(int n, const TriGemm& g) {
   const int l = threadIdx.x, l15 = l & 15, l4 = l >> 4;
   const int i0 = 16 * blockIdx.y, j0 = 16 * blockIdx.x;
   const bool vi = i0 + l15 < n, vj = j0 + l15 < n;
+  if (g.skip && __hip_atomic_load(g.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) {  // (uniform over the launch)
+    if (g.mode == 2) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int i = i0 + l4 + 4 * r4, j = j0 + l15;
+        if (i < n && j < n) {
+          const double v = g.X[(size_t)i * n + j];
+          g.C[(size_t)i * n + j] = v;
+          g.Ct[(size_t)j * n + i] = v;
+        }
+      }
+    }
+    return;
+  }
   const double* p = g.P + i0 + l15;
   const double* q = g.Q + j0 + l15;
   tri_d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -1224,9 +1252,10 @@ __global__ void __launch_bounds__(64) k_tri_gemm_many(int n, TriGemmMany m) {
   tri_gemm_body(n, g);
 }
 __global__ void __launch_bounds__(256) k_tri_correction(int n, const double* __restrict__ S, const double* __restrict__ R, double* __restrict__ E,
-                                                        double* __restrict__ Sout) {
+                                                        double* __restrict__ Sout, const int* __restrict__ skip) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n * n) return;
+  if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) return;  // (S stays the solve launch's)
   const int i = e / n, j = e - i * n;
   const double rii = R[(size_t)i * n + i], rjj = R[(size_t)j * n + j];
   const double mi = S[(size_t)i * n + i] / (1.0 - rii), mj = S[(size_t)j * n + j] / (1.0 - rjj);
@@ -1240,10 +1269,11 @@ __global__ void __launch_bounds__(256) k_tri_correction(int n, const double* __r
   }
   E[e] = v;
 }
-struct TriCorrMany { const double* S[kTriMany]; const double* R[kTriMany]; double* E[kTriMany]; double* Sout[kTriMany]; };
+struct TriCorrMany { const double* S[kTriMany]; const double* R[kTriMany]; double* E[kTriMany]; double* Sout[kTriMany]; const int* skip[kTriMany]; };
 __global__ void __launch_bounds__(256) k_tri_correction_many(int n, TriCorrMany m) {
   const int e = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
   if (e >= n * n) return;
+  if (m.skip[q] && __hip_atomic_load(m.skip[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) return;
   const double* __restrict__ S = m.S[q];
   const double* __restrict__ R = m.R[q];
   const int i = e / n, j = e - i * n;

@@ -2249,11 +2249,12 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   else hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), 0, st, so, so);
   // one refinement step: T = N·X and R = I − XᵀX, S = XᵀT, E, then V = X + X·E (and Vt)
   const int nt = (r + 15) / 16;
-  const tri::TriGemm gT{Nm, X, T, 0, nullptr, nullptr}, gR{X, X, R, 1, nullptr, nullptr}, gS{X, T, Sm, 0, nullptr, nullptr};
+  const int* skip = sync + 3;  // (written by the solve launch: 1 = every gap wide enough, the refinement's launches return at once)
+  const tri::TriGemm gT{Nm, X, T, 0, nullptr, nullptr, skip}, gR{X, X, R, 1, nullptr, nullptr, skip}, gS{X, T, Sm, 0, nullptr, nullptr, skip};
   hipLaunchKernelGGL(tri::k_tri_gemm, dim3(nt, nt, 2), dim3(64), 0, st, r, gT, gR);
   hipLaunchKernelGGL(tri::k_tri_gemm, dim3(nt, nt, 1), dim3(64), 0, st, r, gS, gS);
-  hipLaunchKernelGGL(tri::k_tri_correction, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, st, r, (const double*)Sm, (const double*)R, T, S);
-  const tri::TriGemm gV{Xt, T, V, 2, X, Vt};
+  hipLaunchKernelGGL(tri::k_tri_correction, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, st, r, (const double*)Sm, (const double*)R, T, S, skip);
+  const tri::TriGemm gV{Xt, T, V, 2, X, Vt, skip};
   hipLaunchKernelGGL(tri::k_tri_gemm, dim3(nt, nt, 1), dim3(64), 0, st, r, gV, gV);
   // eigenvalues that multisection could not tell apart (status 2: a spectrum with (near-)multiple eigenvalues, e.g. a posterior without
   // correspondences over a model with equal variances): the Jacobi iteration takes over, cold, in the same stream — its launches
@@ -2290,11 +2291,12 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
       tm.p[q] = tri::TridiagIO{r, rq[q].M, sl, d, e, beta, Hv, Nm};
       sm.p[q] = tri::TriSolveIO{r, d, e, beta, Hv, X, Xt, rq[q].S, mu, R, sync, rq[q].status, nullptr, nullptr, 0};
       wm.p[q] = tri::TriWyIO{r, beta, Hv, R, sync};
-      g1.g[2 * q] = tri::TriGemm{Nm, X, T, 0, nullptr, nullptr};
-      g1.g[2 * q + 1] = tri::TriGemm{X, X, R, 1, nullptr, nullptr};
-      g2.g[q] = tri::TriGemm{X, T, Sm, 0, nullptr, nullptr};
-      cm.S[q] = Sm; cm.R[q] = R; cm.E[q] = T; cm.Sout[q] = rq[q].S;
-      g3.g[q] = tri::TriGemm{Xt, T, rq[q].V, 2, X, rq[q].Vt};
+      const int* skip = sync + 3;
+      g1.g[2 * q] = tri::TriGemm{Nm, X, T, 0, nullptr, nullptr, skip};
+      g1.g[2 * q + 1] = tri::TriGemm{X, X, R, 1, nullptr, nullptr, skip};
+      g2.g[q] = tri::TriGemm{X, T, Sm, 0, nullptr, nullptr, skip};
+      cm.S[q] = Sm; cm.R[q] = R; cm.E[q] = T; cm.Sout[q] = rq[q].S; cm.skip[q] = skip;
+      g3.g[q] = tri::TriGemm{Xt, T, rq[q].V, 2, X, rq[q].Vt, skip};
       dm.status[q] = rq[q].status; dm.host_status[q] = rq[q].host_status; dm.done_word[q] = rq[q].done_word; dm.done_value[q] = rq[q].done_value;
       am.P[q] = parts_all ? parts_all[q0 + q] : nullptr;
       am.M[q] = const_cast<double*>(rq[q].M);
