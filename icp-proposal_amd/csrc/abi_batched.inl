@@ -152,6 +152,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
       g_batch_timing.mark(5);
     }
     int nb = 0;
+    struct FoldScope { FoldScope(int n) { tl_regression_posteriors = n; } ~FoldScope() { tl_regression_posteriors = 1; } } fold_scope(std::max(1, n_batched * n_props));
     for (int b = 0; b < n_chains; ++b) {
       Item& it = items[b];
       if (!it.batched) continue;

@@ -142,6 +142,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       // multiple of that: eight streams made for the purpose on first use ran two groups at 116k it/s instead of 202k)
       gr.st = g == 0 ? lead.stream : g == 1 ? lead.front_stream.get() : lead.eig_stream.get();
       const int B = gr.B;
+      struct FoldScope { FoldScope(int n) { tl_regression_posteriors = n; } ~FoldScope() { tl_regression_posteriors = 1; } } fold_scope(std::max(1, B * n_props));
       gr.begin_alt.alloc(2 * B); gr.begin_live.alloc(B);
       gr.search_alt.alloc(2 * B); gr.search_live.alloc(B);
       gr.regression_alt.alloc(2 * B); gr.regression_live.alloc(B);

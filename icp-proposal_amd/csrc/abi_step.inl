@@ -2,6 +2,10 @@
 // the merged step (five launches): fronts, speculative decompositions, icp_chain_step / _prelaunch
 namespace {
 
+// posteriors the regression launch being prepared will carry over all its chains (set by the batched issuers around their per-chain
+// preparation; 1 for a lone chain): decides regression_fold
+thread_local int tl_regression_posteriors = 1;
+
 // give back what a front holds without recording anything (its launches, if any, are harmless: they wrote to a state
 // slot and memo entries that nobody refers to, to the search scratch and to the hints, which may be stale by design)
 void release_front(StepFront& F);
@@ -286,9 +290,12 @@ void front_launches(icp_evaluator* e, int n_props, icp_proposal* const* props, i
   int* splits = F.splits;
   for (int i = 0; i < n_props; ++i) {
     icp_proposal* p = props[i];
-    splits[i] = regression_splits(p->K);
+    const int leaves = regression_splits(p->K);
     g.K[i] = p->K;
-    g.kchunk[i] = std::max(1, (p->K + splits[i] - 1) / splits[i]);
+    g.kchunk[i] = std::max(1, (p->K + leaves - 1) / leaves);
+    // (chains stepped side by side fold a posterior's leaves into one partial: tl_regression_posteriors = posteriors in the launch)
+    g.fold[i] = regression_fold(p->K, r, tl_regression_posteriors);
+    splits[i] = leaves / g.fold[i];  // (fold is 1 or `leaves`)
     g.cb[i] = ep[i]->corr();
     g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
     g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];

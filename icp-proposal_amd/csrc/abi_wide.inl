@@ -454,9 +454,11 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     double* parts[2] = {nullptr, nullptr};
     for (int i = 0; i < g.n; ++i) {
       icp_proposal* p = it.props[i];
-      splits[i] = regression_splits(p->K);
+      const int leaves = regression_splits(p->K);
       g.K[i] = p->K;
-      g.kchunk[i] = std::max(1, (p->K + splits[i] - 1) / splits[i]);
+      g.kchunk[i] = std::max(1, (p->K + leaves - 1) / leaves);
+      g.fold[i] = regression_fold(p->K, r, nW * n_props);
+      splits[i] = leaves / g.fold[i];
       g.cb[i] = ep[i]->corr();
       g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
       g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];

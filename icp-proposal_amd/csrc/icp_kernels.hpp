@@ -193,6 +193,10 @@ void launch_correspond_target(hipStream_t st, int K, const double* x, const doub
 // K5a (f64 MFMA): partial sums Mpart[s][(r+1)x(r+1)] of Σ_kept [Q_i | e_i]^T Σ_i^-1 [Q_i | e_i]; *splits_out = number of partials.
 // Mpart must hold regression_splits(K)·(r+1)² doubles.
 int regression_splits(int K);
+// How many of a posterior's regression_splits(K) leaves one wave folds into its partial: 1 (every leaf a wave and a partial of its own:
+// a lone chain needs the parallelism) or all of them (one partial per posterior: no split-K traffic, no summing launch) — decided by
+// how many output tiles the launch carries across all its chains.  Either way the summed matrix has the same bits.
+int regression_fold(int K, int r, int n_posteriors_in_launch);
 void launch_regression(hipStream_t st, int K, int r, const double* Q, const CorrBuffers& cb, double w_tangent,
                        double kappa, double* Mpart, int* splits_out);
 
@@ -372,6 +376,7 @@ struct StepRegressionArgs {  // launch 4: normal-equation partial sums of every 
   int n, r, ntiles;          // posteriors; tiles per (r+1)x(r+1) matrix
   int ustart[3];             // first work unit (tile x split) of each posterior; ustart[n] = number of units
   int K[2], kchunk[2];
+  int fold[2];               // leaves of kchunk correspondences a unit takes (regression_tile): 1, or all of a posterior's (one partial)
   const double* Q;
   CorrBuffers cb[2];
   double wt[2], kappa[2];

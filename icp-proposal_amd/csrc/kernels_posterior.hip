@@ -2051,6 +2051,17 @@ int regression_splits(int K) {
   return s < 1 ? 1 : (s > 64 ? 64 : s);
 }
 
+int regression_fold(int K, int r, int n_posteriors_in_launch) {
+  // (developer switches: ICP_REGRESSION_FOLD_TILES = output tiles from which a launch folds, ICP_REGRESSION_FOLD_K = … or posteriors of at
+  // most this many correspondences fold whatever the launch carries)
+  static const int min_tiles = dev_env("ICP_REGRESSION_FOLD_TILES") ? std::atoi(dev_env("ICP_REGRESSION_FOLD_TILES")) : 512;
+  static const int small_k = dev_env("ICP_REGRESSION_FOLD_K") ? std::atoi(dev_env("ICP_REGRESSION_FOLD_K")) : 0;
+  const int S = regression_splits(K);
+  if (S <= 1) return 1;
+  const long tiles = (long)regression_tiles(r) * std::max(n_posteriors_in_launch, 1);
+  return (tiles >= min_tiles || K <= small_k) ? S : 1;
+}
+
 void launch_regression(hipStream_t st, int K, int r, const double* Q, const CorrBuffers& cb, double w_tangent,
                        double kappa, double* Mpart, int* splits_out) {
   const int S = regression_splits(K);

@@ -308,8 +308,8 @@ __device__ __forceinline__ void step_regression_body(const StepRegressionArgs& a
       const int which = u < a.ustart[1] ? 0 : 1;
       const int l = u - (which ? a.ustart[1] : 0), tile = l % a.ntiles, split = l / a.ntiles;
       if (tile == 0 && split == 0 && (threadIdx.x & 63) == 0) { a.status[which][1] = 0; a.status[which][2] = 0; }
-      if (which == 0) regression_tile(tile, split, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0]);
-      else regression_tile(tile, split, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1]);
+      if (which == 0) regression_tile(tile, split, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0], a.fold[0]);
+      else regression_tile(tile, split, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1], a.fold[1]);
     }
   } else {
     // the last workgroup: likelihood reduction over the surface distances of the evaluator's model ids (results 0-3) and, for a
