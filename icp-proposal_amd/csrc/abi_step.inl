@@ -295,6 +295,7 @@ void front_launches(icp_evaluator* e, int n_props, icp_proposal* const* props, i
     g.kchunk[i] = std::max(1, (p->K + leaves - 1) / leaves);
     // (chains stepped side by side fold a posterior's leaves into one partial: tl_regression_posteriors = posteriors in the launch)
     g.fold[i] = regression_fold(p->K, r, tl_regression_posteriors);
+    g.macro[i] = regression_macro(r, g.fold[i]);
     splits[i] = leaves / g.fold[i];  // (fold is 1 or `leaves`)
     g.cb[i] = ep[i]->corr();
     g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
@@ -302,7 +303,7 @@ void front_launches(icp_evaluator* e, int n_props, icp_proposal* const* props, i
     p->mpart_half = (p->mpart_half + 1) % icp_proposal::kMpartRing;
     g.Mpart[i] = p->mpart_for_write(p->mpart_half, F.stream);
     g.status[i] = p->status.p + ep[i]->status_off;
-    g.ustart[i + 1] = g.ustart[i] + g.ntiles * splits[i];
+    g.ustart[i + 1] = g.ustart[i] + regression_units(r, leaves, g.fold[i], g.macro[i]);
   }
   if (n_props == 1) g.ustart[2] = g.ustart[1];
   g.reduce_kind = evp.kind == ICP_EVAL_INDEPENDENT_POINT_DISTANCE ? 1 : 2;

@@ -458,7 +458,9 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
       g.K[i] = p->K;
       g.kchunk[i] = std::max(1, (p->K + leaves - 1) / leaves);
       g.fold[i] = regression_fold(p->K, r, nW * n_props);
+      g.macro[i] = regression_macro(r, g.fold[i]);
       splits[i] = leaves / g.fold[i];
+      const int units_i = regression_units(r, leaves, g.fold[i], g.macro[i]);
       g.cb[i] = ep[i]->corr();
       g.wt[i] = 1.0 / (p->prm.tangential_noise * p->prm.tangential_noise);
       g.kappa[i] = 1.0 / (p->prm.noise_along_normal * p->prm.noise_along_normal) - g.wt[i];
@@ -470,7 +472,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
       p->mpart_half = (p->mpart_half + 1) % icp_proposal::kMpartRing;
       parts[i] = g.Mpart[i] = p->mpart_for_write(p->mpart_half, S);
       g.status[i] = p->status.p + ep[i]->status_off;
-      g.ustart[i + 1] = g.ustart[i] + g.ntiles * splits[i];
+      g.ustart[i + 1] = g.ustart[i] + units_i;
     }
     if (g.n == 1) g.ustart[2] = g.ustart[1];
     // the likelihood's reductions over ALL ids (the layout finish_eval reads) …

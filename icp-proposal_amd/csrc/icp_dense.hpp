@@ -156,6 +156,100 @@ __device__ __forceinline__ void regression_tile(int tile, int split, int K, int 
   }
 }
 
+// MACRO TILES (round 5; folded launches only).  A wave that owns MT x MT neighbouring output tiles gathers, per correspondence, the basis
+// rows of MT row blocks and MT column blocks ONCE — 6·MT gathered values for MT² matrix instructions instead of 6 per instruction:
+// the launch is bound by its gathers (30 face-model chains: 8.2 M wave loads, 0.4 ms), not by the matrix cores.  Every tile is
+// accumulated exactly as regression_tile accumulates it (its leaves from zero in correspondence order, the leaves' sums added in order
+// from 0.0): the same bits, whatever the tiling.  mtile = index into the lower triangle of the grid of macro tiles; tiles of a
+// diagonal macro tile that lie above the diagonal, and tiles beyond the matrix, are skipped.
+__host__ __device__ inline int regression_macro_tiles(int r, int MT) {
+  const int nt = (r + 1 + 15) >> 4, nm = (nt + MT - 1) / MT;
+  return nm * (nm + 1) / 2;
+}
+template <int MT>
+__device__ __forceinline__ void regression_macro_fold(int mtile, int leaves, int K, int kchunk, int r, const double* __restrict__ Q,
+                                                      const CorrBuffers& cb, double wt, double kappa, double* __restrict__ Mpart) {
+  const int n = r + 1, nt = (n + 15) >> 4;
+  int mi = 0;
+  while ((mi + 1) * (mi + 2) / 2 <= mtile) ++mi;
+  const int mj = mtile - mi * (mi + 1) / 2;
+  const int l = threadIdx.x & 63, i16 = l & 15, kk = l >> 4;
+  int ca[MT], cbi[MT];
+  double ma[MT], mb[MT], ea[MT], eb[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) {
+    const int a = 16 * (MT * mi + p) + i16, b = 16 * (MT * mj + p) + i16;
+    ca[p] = a < r ? a : 0; cbi[p] = b < r ? b : 0;
+    ma[p] = a < r ? 1.0 : 0.0; mb[p] = b < r ? 1.0 : 0.0;
+    ea[p] = a == r ? 1.0 : 0.0; eb[p] = b == r ? 1.0 : 0.0;
+  }
+  bool on[MT][MT];  // (uniform) tile (MT·mi + p, MT·mj + q) exists and lies in the lower triangle
+#pragma unroll
+  for (int p = 0; p < MT; ++p)
+#pragma unroll
+    for (int q = 0; q < MT; ++q) on[p][q] = MT * mi + p < nt && MT * mj + q <= MT * mi + p;
+  d4_t acc[MT][MT], run[MT][MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p)
+#pragma unroll
+    for (int q = 0; q < MT; ++q) run[p][q] = d4_t{0.0, 0.0, 0.0, 0.0};
+  constexpr int G = MT >= 3 ? 2 : 4;  // correspondences whose gathers are in flight together
+  for (int f = 0; f < leaves; ++f) {
+    const int k0 = f * kchunk, k1 = min(K, k0 + kchunk);
+#pragma unroll
+    for (int p = 0; p < MT; ++p)
+#pragma unroll
+      for (int q = 0; q < MT; ++q) acc[p][q] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int kb = k0; kb < k1; kb += G) {
+      double A_op[G][MT], B_op[G][MT];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int k = min(kb + u, k1 - 1);  // (past the leaf's end: a repeated load, its products not issued)
+        const double* q_ = Q + (size_t)3 * cb.id[k] * r;
+        const double e0 = cb.e[3 * k], e1 = cb.e[3 * k + 1], e2 = cb.e[3 * k + 2];
+        const double n0 = cb.nhat[3 * k], n1 = cb.nhat[3 * k + 1], n2 = cb.nhat[3 * k + 2];
+        const double w = (kk == 3 ? kappa : wt) * (cb.keep[k] ? 1.0 : 0.0);
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+          const double a0 = fma(ma[p], q_[ca[p]], ea[p] * e0), a1 = fma(ma[p], q_[r + ca[p]], ea[p] * e1), a2 = fma(ma[p], q_[2 * r + ca[p]], ea[p] * e2);
+          const double b0 = fma(mb[p], q_[cbi[p]], eb[p] * e0), b1 = fma(mb[p], q_[r + cbi[p]], eb[p] * e1), b2 = fma(mb[p], q_[2 * r + cbi[p]], eb[p] * e2);
+          const double va = fma(a2, n2, fma(a1, n1, a0 * n0));
+          const double vb = fma(b2, n2, fma(b1, n1, b0 * n0));
+          A_op[u][p] = kk == 0 ? a0 : kk == 1 ? a1 : kk == 2 ? a2 : va;
+          B_op[u][p] = (kk == 0 ? b0 : kk == 1 ? b1 : kk == 2 ? b2 : vb) * w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (kb + u < k1) {
+#pragma unroll
+          for (int p = 0; p < MT; ++p)
+#pragma unroll
+            for (int q = 0; q < MT; ++q)
+              if (on[p][q]) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_op[u][p], B_op[u][q], acc[p][q], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < MT; ++p)
+#pragma unroll
+      for (int q = 0; q < MT; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) run[p][q][g] += acc[p][q][g];
+  }
+#pragma unroll
+  for (int p = 0; p < MT; ++p)
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      if (!on[p][q]) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 16 * (MT * mi + p) + kk + 4 * g, col = 16 * (MT * mj + q) + i16;
+        if (row < n && col < n) Mpart[(size_t)row * n + col] = run[p][q][g];
+      }
+    }
+}
+
 // ---------------------------------------------------------------- dense helpers (one workgroup, matrix behind a generic pointer)
 
 __device__ double block_sum(double v, double* s_red) {

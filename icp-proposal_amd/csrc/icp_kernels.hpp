@@ -197,6 +197,8 @@ int regression_splits(int K);
 // a lone chain needs the parallelism) or all of them (one partial per posterior: no split-K traffic, no summing launch) — decided by
 // how many output tiles the launch carries across all its chains.  Either way the summed matrix has the same bits.
 int regression_fold(int K, int r, int n_posteriors_in_launch);
+int regression_macro(int r, int fold);          // macro-tile edge of a folded posterior's units (1: single tiles)
+int regression_units(int r, int leaves, int fold, int macro);  // work units (waves) of one posterior in a regression launch
 void launch_regression(hipStream_t st, int K, int r, const double* Q, const CorrBuffers& cb, double w_tangent,
                        double kappa, double* Mpart, int* splits_out);
 
@@ -377,6 +379,7 @@ struct StepRegressionArgs {  // launch 4: normal-equation partial sums of every 
   int ustart[3];             // first work unit (tile x split) of each posterior; ustart[n] = number of units
   int K[2], kchunk[2];
   int fold[2];               // leaves of kchunk correspondences a unit takes (regression_tile): 1, or all of a posterior's (one partial)
+  int macro[2];              // folded posteriors only: a unit owns macro x macro neighbouring tiles (regression_macro_fold); 0 / 1: single tiles
   const double* Q;
   CorrBuffers cb[2];
   double wt[2], kappa[2];

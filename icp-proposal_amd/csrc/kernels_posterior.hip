@@ -2062,6 +2062,20 @@ int regression_fold(int K, int r, int n_posteriors_in_launch) {
   return (tiles >= min_tiles || K <= small_k) ? S : 1;
 }
 
+int regression_macro(int r, int fold) {
+  static const int forced = dev_env("ICP_REGRESSION_MACRO") ? std::atoi(dev_env("ICP_REGRESSION_MACRO")) : 0;  // (developer switch: 1, 2, 3)
+  if (fold <= 1) return 1;
+  const int nt = (r + 1 + 15) >> 4;
+  if (forced >= 1 && forced <= 3) return nt >= forced ? forced : 1;
+  // (measured, 30 face-model chains a launch — 13 x 13 tiles, K = 400: single tiles 361 µs, 2 x 2 macro tiles 206 µs, 3 x 3 336 µs (few waves,
+  // each a long chain of gathers); femur-size matrices (4 x 4 tiles) stay with single tiles: three macro units per posterior are too few waves)
+  return nt >= 6 ? 2 : 1;
+}
+int regression_units(int r, int leaves, int fold, int macro) {
+  if (fold > 1 && macro > 1) return regression_macro_tiles(r, macro);
+  return regression_tiles(r) * (leaves / std::max(fold, 1));
+}
+
 void launch_regression(hipStream_t st, int K, int r, const double* Q, const CorrBuffers& cb, double w_tangent,
                        double kappa, double* Mpart, int* splits_out) {
   const int S = regression_splits(K);

@@ -269,8 +269,11 @@ __global__ void __launch_bounds__(kWideRegBlock) k_wide_regression(const WideReg
     if (u < n_units) {
       const int which = u < a.ustart[1] ? 0 : 1;
       const int l = u - (which ? a.ustart[1] : 0), tile = l % a.ntiles, split = l / a.ntiles;
-      if (tile == 0 && split == 0 && (threadIdx.x & 63) == 0) { a.status[which][1] = 0; a.status[which][2] = 0; }
-      if (which == 0) regression_tile(tile, split, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0], a.fold[0]);
+      if (l == 0 && (threadIdx.x & 63) == 0) { a.status[which][1] = 0; a.status[which][2] = 0; }
+      if (a.macro[which] > 1) {  // a folded posterior in macro tiles: unit l = macro tile l (uniform over the wave)
+        if (a.macro[which] == 2) regression_macro_fold<2>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
+        else regression_macro_fold<3>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
+      } else if (which == 0) regression_tile(tile, split, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0], a.fold[0]);
       else regression_tile(tile, split, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1], a.fold[1]);
     }
     return;
