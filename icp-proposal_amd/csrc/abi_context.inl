@@ -139,6 +139,8 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     if (!sm) {
       sm = std::make_shared<SharedModel>();
       sm->device = device;
+      static uint64_t next_uid = 0;  // (under g_shared_mu)
+      sm->uid = ++next_uid;
       // Q = Φ·diag(√λ) in two layouts, Gram matrix G = QᵀQ and chol(G + σ²I) (one-off host work)
       std::vector<double> Q((size_t)3 * N * r), Qp((size_t)3 * N * r), sl(r), isl(r);
       for (int j = 0; j < r; ++j) { sl[j] = std::sqrt(model->variance[j]); isl[j] = 1.0 / sl[j]; }
@@ -210,8 +212,10 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
 
     attach_target(ctx, target, device);
 
-    ctx->hint_surf.alloc(N); ctx->hint_surf.fill_bytes(0xFF);
-    ctx->hint_nnv.alloc(N); ctx->hint_nnv.fill_bytes(0xFF);
+    ctx->hint_surf.alloc(N);
+    ctx->hint_nnv.alloc(N);
+    seed_context_hints(*ctx, true);  // (the pair's filed hints, or none; g_shared_mu is held here)
+    HIP_OK(hipStreamSynchronize(ctx->stream));
     ctx->stage_cap = 64 * (size_t)(10 + r) + 4096;
     pinned_alloc((void**)&ctx->h_stage, sizeof(double) * ctx->stage_cap);
     ctx->d_stage.alloc(ctx->stage_cap);
@@ -342,8 +346,7 @@ int icp_ctx_set_target(icp_ctx* ctx, const icp_mesh_desc* target) {
     }
     // what was cached against the old target: the states' surface points and nearest vertices, the search hints
     for (auto& s : ctx->slots) { s.valid = false; s.defo_valid = false; s.spheres_valid = false; s.n_surf = s.n_nnv = 0; s.lo_surf = s.hi_surf = s.lo_nnv = s.hi_nnv = 0; }
-    HIP_OK(hipMemsetAsync(ctx->hint_surf.p, 0xFF, sizeof(int) * ctx->N, ctx->stream));
-    HIP_OK(hipMemsetAsync(ctx->hint_nnv.p, 0xFF, sizeof(int) * ctx->N, ctx->stream));
+    seed_context_hints(*ctx);  // (the new pair's filed hints, or none)
     HIP_OK(hipStreamSynchronize(ctx->stream));
     ctx->stage_used = 0;
   });

@@ -235,11 +235,14 @@ int icp_evaluator_create(icp_ctx* ctx, const icp_evaluator_params* params, icp_e
       ev->Kt = params->n_target_points;
       ev->target_pts.upload(params->target_points, 3 * (size_t)ev->Kt);
       ev->d_tpts = ev->target_pts.p;
+      ev->points_hash = hash_words(0x9abc, params->target_points, sizeof(double) * 3 * (size_t)ev->Kt) | 1;
     }
     ev->prm.target_points = nullptr;
     const size_t Ka = std::max(ev->Kt, 1);
-    ev->hint_tri.alloc(Ka); ev->hint_tri.fill_bytes(0xFF);
-    ev->hint_nnv.alloc(Ka); ev->hint_nnv.fill_bytes(0xFF);
+    ev->hint_tri.alloc(Ka);
+    ev->hint_nnv.alloc(Ka);
+    seed_evaluator_hints(ev);  // (another evaluator's winners for the same points against the same pair, or none)
+    HIP_OK(hipStreamSynchronize(ctx->stream));
     ev->t2m_tri.alloc(Ka); ev->t2m_nnv.alloc(Ka);
     ev->t2m_cp.alloc(3 * Ka); ev->t2m_d2.alloc(Ka);
     ctx->evaluators.push_back(ev);
@@ -272,9 +275,11 @@ int icp_evaluator_log_value(icp_evaluator* e, const double* theta, double* out, 
     Bound _b(&c);
     icp_evaluator::Memo* m = eval_lookup(e, theta);  // evaluators/EvaluationCaching.scala:32-36
     if (!m) {
+      adopt_hints(e);  // (hints another chain of this model and target has filed since this context was made)
       StateSlot& s = c.state(theta);
       enqueue_eval(e, s, 0);
       c.finish(8, 0);
+      file_hints(e);  // (once per context / evaluator: the first completed evaluation's winners start the next chains' searches)
       m = eval_store(e, theta);
       m->status = finish_eval(e, c.h_res, &m->value, m->aux);
     }

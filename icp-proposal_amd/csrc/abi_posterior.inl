@@ -147,6 +147,8 @@ struct icp_evaluator {
   int Kt = 0;              // number of target-side query points (decimated target, or all target vertices for Hausdorff)
   const double* d_tpts = nullptr;
   DBuf<int> hint_tri, hint_nnv, t2m_tri, t2m_nnv;
+  uint64_t points_hash = 0;   // of its target-side query points (HintSeed::Eval)
+  bool hints_filed = false;   // … its hints have been offered to the target's seed (or came from it)
   DBuf<double> t2m_cp, t2m_d2;
   struct Memo {
     std::vector<double> theta;

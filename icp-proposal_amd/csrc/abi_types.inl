@@ -219,7 +219,21 @@ struct DeviceMesh {
 // Immutable device data of one statistical model / one target mesh, shared by every context of a device that was created from
 // the same arrays (64 chains on one GPU have 64 contexts — per-chain scratch, caches, streams — but ONE copy of the basis and of
 // the target; the BFM-sized model is 2 x 137 MB).  Contexts hold them through shared_ptr and address them through aliasing DBufs.
+// Search hints to start from (round 5).  A search's hint — the previous winner of each query — is only an upper bound: any valid
+// element index gives exact results, a good one gives them after a handful of tests.  A context's FIRST searches have none: every
+// query lists thousands of candidates, overflows its list and scans the whole mesh (0.4-3 ms per search at the face model's size; a
+// batch registration paid it for each of its 100 chains when the chain's initial state is evaluated: 2 ms per chain object).  The first
+// evaluation that completes against a (model, target) pair therefore files its hints with the target's shared data, and every later
+// context / evaluator of the same pair starts from a copy: another chain's shape is a few millimetres from this one's, its winners are
+// tight bounds.  Immutable once filed.
+struct HintSeed {
+  uint64_t model_uid = 0;
+  DBuf<int> surf, nnv;      // [N]: icp_ctx::hint_surf / hint_nnv after a first evaluation
+  struct Eval { int Kt; uint64_t points_hash; DBuf<int> tri, nnv; };
+  std::vector<std::unique_ptr<Eval>> evals;  // per evaluator point set: icp_evaluator::hint_tri / hint_nnv
+};
 struct SharedModel {
+  uint64_t uid = 0;  // (unique per process: the key of a target's HintSeed)
   DBuf<double> ref, mean, Q, Qp, sqrt_lambda, inv_sqrt_lambda, G, Ginv, P;
   DBuf<int> tris, adj_off, adj, tri_order;
   DBuf<uint8_t> boundary;
@@ -228,6 +242,7 @@ struct SharedModel {
 };
 struct SharedTarget {
   DeviceMesh mesh;
+  std::vector<std::unique_ptr<HintSeed>> seeds;  // one per model that has searched this target (guarded by g_shared_mu)
 };
 struct SharedKey {
   int device, a, b, c;
@@ -409,6 +424,7 @@ struct icp_ctx {
   DeviceMesh target;
   std::shared_ptr<SharedModel> shared_model;    // owners of what the members above alias (ref … boundary; target.*)
   std::shared_ptr<SharedTarget> shared_target;
+  bool hints_filed = false;  // this context's hints have been offered to the target's HintSeed (or came from it)
   DBuf<int> hint_surf;  // [N] last target triangle of model id i
   DBuf<int> hint_nnv;   // [N] last nearest target vertex of that surface point
   StateSlot slots[kStateSlots];

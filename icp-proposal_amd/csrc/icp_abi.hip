@@ -11,6 +11,7 @@
 #include "abi_state.inl"  // icp_ctx: state slots (instances) and the search prefixes shared by proposals and evaluators
 #include "abi_pools.inl"  // pools and caches: streams, pinned blocks, device buffers of destroyed objects; live-context and eigen-stream registries
 #include "abi_posterior.inl"  // posterior memo entries, icp_proposal / icp_evaluator and their methods (NonRigidIcpProposal.scala:88-153, the evaluators)
+#include "abi_hints.inl"  // search hints handed from the first evaluation of a (model, target) pair to the contexts and evaluators that follow
 #include "abi_context.inl"  // C ABI: contexts — create / destroy / set_target / set_rotation, counters, profiling, geometry entry points
 #include "abi_methods.inl"  // C ABI: per-method entry points — proposals, evaluators, deterministic fit, variability maps, metrics, icp_chain_eval_step
 #include "abi_step.inl"  // the merged step (five launches): fronts, speculative decompositions, icp_chain_step / _prelaunch

@@ -1,6 +1,7 @@
 // icp_host.cpp — SamplingRegistration.runfitting mirrored over the C ABI (see icp_host.hpp / icp_host.h).
 #include "icp_host.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -178,6 +179,9 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
   icp_host_chain* ch = nullptr;
   int rc = host_guard([&] {
     if (!ctx || !cfg || !theta0 || !out || cfg->n_icp < 0 || cfg->n_icp > 2) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chain_create");
+    static const bool timing = std::getenv("ICP_CREATE_TIMING") != nullptr;  // (developer aid: where a chain object's creation goes)
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_prop = t_begin, t_eval = t_begin;
     ch = new icp_host_chain();
     ch->ctx = ctx;
     ch->r = icp_ctx_rank(ctx);
@@ -218,7 +222,9 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
     if (ch->root->generators.empty()) throw NativeError(ICP_ERR_INVALID_ARG, "icp_host_chain_create: no proposals");
     // ProductEvaluators.proximityAnd* (ProductEvaluators.scala:38-94): prior × likelihood
     ch->prior.reset(new ModelPriorEvaluator(ch->r));
+    t_prop = std::chrono::steady_clock::now();
     ch->likelihood.reset(new NativeLikelihoodEvaluator(ctx, cfg->eval));
+    t_eval = std::chrono::steady_clock::now();
     ch->product.parts = {ch->prior.get(), ch->likelihood.get()};
     ch->mh.reset(new MetropolisHastings(ch->root, &ch->product));
     if (cfg->fused) {
@@ -235,6 +241,11 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
     ch->current.allParameters.assign(theta0, theta0 + 10 + ch->r);
     ch->logger.P = 10 + ch->r;
     ch->current_p = ch->product.logValue(ch->current);
+    if (timing) {
+      const auto t_end = std::chrono::steady_clock::now();
+      auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      std::fprintf(stderr, "[icp create timing] proposals + walks %.0f us, evaluator %.0f us, initial log value %.0f us\n", us(t_begin, t_prop), us(t_prop, t_eval), us(t_eval, t_end));
+    }
     *out = ch;
   });
   if (rc != ICP_OK && ch) delete ch;
