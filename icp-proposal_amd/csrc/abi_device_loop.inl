@@ -102,6 +102,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       DBuf<StepBeginArgs> begin_alt, begin_live;
       DBuf<StepSearchArgs> search_alt, search_live;
       bool filter_prepared = true;  // (step_filter_prepared of every captured step)
+      bool reg_folded = false;      // (the captured regressions fold their leaves: regression_fold)
       DBuf<StepRegressionArgs> regression_alt, regression_live;
       DBuf<StepFinishArgs> finish_alt, finish_live;
       DBuf<MhChain> mh;
@@ -212,6 +213,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
           hf[(size_t)sel * B + k] = cap.finish;
           for (int q = 0; q < 5; ++q) gr.grid[q] = std::max(gr.grid[q], cap.grid[q]);
           gr.filter_prepared = gr.filter_prepared && step_filter_prepared(cap.search);
+          gr.reg_folded = cap.regression.fold[0] > 1;
           m.begin_alt[sel] = gr.begin_alt.p + (size_t)sel * B + k;
           m.search_alt[sel] = gr.search_alt.p + (size_t)sel * B + k;
           m.regression_alt[sel] = gr.regression_alt.p + (size_t)sel * B + k;
@@ -346,10 +348,10 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
             int ga[5] = {0, 0, 0, 0, 0}, gb[5] = {0, 0, 0, 0, 0};
             for (int q = 0; q < 4; ++q) (q < token_at ? ga : gb)[q] = gr.grid[q];
             if (token_at > 0)
-              launch_step_batch_resident(gr.st, gr.B, ga, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p, gr.filter_prepared);
+              launch_step_batch_resident(gr.st, gr.B, ga, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p, gr.filter_prepared, gr.reg_folded);
             if (n_groups > 1) HIP_OK(hipEventRecord(gr.ev_big, gr.st));
             if (token_at < 4)
-              launch_step_batch_resident(gr.st, gr.B, gb, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p, gr.filter_prepared);
+              launch_step_batch_resident(gr.st, gr.B, gb, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p, gr.filter_prepared, gr.reg_folded);
           }
           int g5[5] = {0, 0, 0, 0, gr.grid[4]};
           launch_step_batch_resident(gr.st, gr.B, g5, r, gr.begin_live.p, gr.search_live.p, gr.regression_live.p, gr.finish_live.p);

@@ -459,6 +459,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
       g.kchunk[i] = std::max(1, (p->K + leaves - 1) / leaves);
       g.fold[i] = regression_fold(p->K, r, nW * n_props);
       g.macro[i] = regression_macro(r, g.fold[i]);
+      plan.reg_folded = plan.reg_folded || g.fold[i] > 1;
       splits[i] = leaves / g.fold[i];
       const int units_i = regression_units(r, leaves, g.fold[i], g.macro[i]);
       g.cb[i] = ep[i]->corr();

@@ -106,15 +106,51 @@ __device__ __forceinline__ d4_t regression_mac(int k, const CorrBuffers& cb, con
 
 // tile = index into the LOWER triangle (tile row ti >= tile column tj, row-major: regression_tiles(r) of them) of the grid of
 // 16×16 output tiles — the matrix is symmetric and every reader of the partial sums takes entries (i, k <= i) —
-// split = which slice of the correspondence list; one wave.
+// split = which slice of the correspondence list; one wave
+__device__ __forceinline__ void regression_tile(int tile, int split, int K, int kchunk, int r, const double* __restrict__ Q,
+                                                const CorrBuffers& cb, double wt, double kappa, double* __restrict__ Mpart) {
+  const int n = r + 1;
+  int ti = 0;
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const int l = threadIdx.x & 63, i16 = l & 15, kk = l >> 4;
+  const int a = 16 * ti + i16, b = 16 * tj + i16;
+  const int ca = a < r ? a : 0, cbi = b < r ? b : 0;
+  const double ma = a < r ? 1.0 : 0.0, mb = b < r ? 1.0 : 0.0;      // basis column?
+  const double ea = a == r ? 1.0 : 0.0, eb = b == r ? 1.0 : 0.0;    // the appended observation column?
+  const int k0 = split * kchunk, k1 = min(K, k0 + kchunk);
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+  int k = k0;
+  for (; k + 4 <= k1; k += 4) {
+    double xa[4][3], xb[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) regression_load(k + u, r, Q, cb, ca, cbi, ma, mb, ea, eb, xa[u], xb[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = regression_mac(k + u, cb, xa[u], xb[u], kk, wt, kappa, acc);
+  }
+  for (; k < k1; ++k) {
+    double xa[3], xb[3];
+    regression_load(k, r, Q, cb, ca, cbi, ma, mb, ea, eb, xa, xb);
+    acc = regression_mac(k, cb, xa, xb, kk, wt, kappa, acc);
+  }
+  double* out = Mpart + (size_t)split * n * n;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int row = 16 * ti + kk + 4 * g, col = 16 * tj + i16;
+    if (row < n && col < n) out[(size_t)row * n + col] = acc[g];
+  }
+}
+
+// The folded form of regression_tile (kept apart: the single-leaf function above is the one every lone chain's step runs, and a loop
+// and a second accumulator around its body cost configs[2] 7 % — measured against the round-4 build on one box).
 // fold > 1 (round 5): the wave takes `fold` consecutive slices — leaves of kchunk correspondences, each accumulated from zero on the
 // matrix cores exactly as a lone slice is — and adds the leaves' sums IN ORDER, from 0.0, as every reader of the partials does: with
 // fold = the number of slices the one partial it writes (slot `split`) holds, bit for bit, what the readers' sum over all slices would.
 // Chains side by side bring parallelism of their own (30 chains x 91 tiles of the face model: 2,730 waves without any split-K): the
 // 50 partials per tile — 9 MB per posterior written, read again and summed by a launch of its own, 280 MB and a third of a millisecond
 // per 30-chain step — shrink to one.
-__device__ __forceinline__ void regression_tile(int tile, int split, int K, int kchunk, int r, const double* __restrict__ Q,
-                                                const CorrBuffers& cb, double wt, double kappa, double* __restrict__ Mpart, int fold = 1) {
+__device__ __forceinline__ void regression_tile_fold(int tile, int split, int K, int kchunk, int r, const double* __restrict__ Q,
+                                                     const CorrBuffers& cb, double wt, double kappa, double* __restrict__ Mpart, int fold) {
   const int n = r + 1;
   int ti = 0;
   while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
@@ -166,6 +202,9 @@ __host__ __device__ inline int regression_macro_tiles(int r, int MT) {
   const int nt = (r + 1 + 15) >> 4, nm = (nt + MT - 1) / MT;
   return nm * (nm + 1) / 2;
 }
+#ifndef ICP_REG_MACRO_G
+#define ICP_REG_MACRO_G 3
+#endif
 template <int MT>
 __device__ __forceinline__ void regression_macro_fold(int mtile, int leaves, int K, int kchunk, int r, const double* __restrict__ Q,
                                                       const CorrBuffers& cb, double wt, double kappa, double* __restrict__ Mpart) {
@@ -193,7 +232,7 @@ __device__ __forceinline__ void regression_macro_fold(int mtile, int leaves, int
   for (int p = 0; p < MT; ++p)
 #pragma unroll
     for (int q = 0; q < MT; ++q) run[p][q] = d4_t{0.0, 0.0, 0.0, 0.0};
-  constexpr int G = MT >= 3 ? 2 : 4;  // correspondences whose gathers are in flight together
+  constexpr int G = ICP_REG_MACRO_G;  // correspondences whose gathers are in flight together (4: 288 registers per lane, one wave per SIMD)
   for (int f = 0; f < leaves; ++f) {
     const int k0 = f * kchunk, k1 = min(K, k0 + kchunk);
 #pragma unroll

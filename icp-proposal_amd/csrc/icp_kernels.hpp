@@ -505,7 +505,8 @@ void launch_mh_front(hipStream_t st, int B, MhChain* chains);
 void launch_mh_decide(hipStream_t st, int B, MhChain* chains);
 // the five merged launches for B chains from DEVICE-RESIDENT argument arrays (no copy kernel, no gate: one stream, in order)
 void launch_step_batch_resident(hipStream_t st, int B, const int grid[5], int r, const StepBeginArgs* begin, const StepSearchArgs* search,
-                                const StepRegressionArgs* regression, const StepFinishArgs* finish, bool filter_prepared = false);
+                                const StepRegressionArgs* regression, const StepFinishArgs* finish, bool filter_prepared = false,
+                                bool reg_folded = false /* the records' regression_fold > 1: the folded regression kernel */);
 
 // ---- the wide step (kernels_wide.hip): one Metropolis–Hastings step of B chains for the configurations the five merged launches
 // above do not cover — targets WITH boundary (the nearest-vertex pass of NonRigidIcpProposal.scala:98-99 and of
@@ -567,7 +568,8 @@ struct WideDoneItem {      // W12
 struct WideDoneArgs { int n; WideDoneItem it[kWideMaxChains]; };
 
 size_t wide_batch_bytes(int B);
-struct WideLaunchPlan {    // what the host has worked out for a batch: common model data, grids
+struct WideLaunchPlan {
+  bool reg_folded = false;  // the chains' posteriors fold their split-K leaves (StepRegressionArgs::fold > 1): the folded regression kernel    // what the host has worked out for a batch: common model data, grids
   int B, N, r;
   const double* Qp; const double* ref; const double* mean;
   int grid_prep, grid_f1, grid_r1, grid_f2, grid_r2, grid_reg;

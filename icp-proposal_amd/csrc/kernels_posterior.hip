@@ -2058,15 +2058,19 @@ int regression_fold(int K, int r, int n_posteriors_in_launch) {
   static const int small_k = dev_env("ICP_REGRESSION_FOLD_K") ? std::atoi(dev_env("ICP_REGRESSION_FOLD_K")) : 0;
   const int S = regression_splits(K);
   if (S <= 1) return 1;
+  // femur-size matrices (4 x 4 tiles, 13 leaves) keep their split-K: 64 chains a launch measured 186k it/s folded against 204k split
+  // (same box, alternating) — their partials are small, and 16,640 one-leaf waves hide the gathers' latency better than 1,280 thirteen-leaf ones
+  static const int min_rank_tiles = dev_env("ICP_REGRESSION_FOLD_RANK_TILES") ? std::atoi(dev_env("ICP_REGRESSION_FOLD_RANK_TILES")) : 6;
+  if (((r + 1 + 15) >> 4) < min_rank_tiles && K > small_k) return 1;
   const long tiles = (long)regression_tiles(r) * std::max(n_posteriors_in_launch, 1);
   return (tiles >= min_tiles || K <= small_k) ? S : 1;
 }
 
 int regression_macro(int r, int fold) {
-  static const int forced = dev_env("ICP_REGRESSION_MACRO") ? std::atoi(dev_env("ICP_REGRESSION_MACRO")) : 0;  // (developer switch: 1, 2, 3)
+  static const int forced = dev_env("ICP_REGRESSION_MACRO") ? std::atoi(dev_env("ICP_REGRESSION_MACRO")) : 0;  // (developer switch: 1, 2)
   if (fold <= 1) return 1;
   const int nt = (r + 1 + 15) >> 4;
-  if (forced >= 1 && forced <= 3) return nt >= forced ? forced : 1;
+  if (forced >= 1 && forced <= 2) return nt >= forced ? forced : 1;
   // (measured, 30 face-model chains a launch — 13 x 13 tiles, K = 400: single tiles 361 µs, 2 x 2 macro tiles 206 µs, 3 x 3 336 µs (few waves,
   // each a long chain of gathers); femur-size matrices (4 x 4 tiles) stay with single tiles: three macro units per posterior are too few waves)
   return nt >= 6 ? 2 : 1;

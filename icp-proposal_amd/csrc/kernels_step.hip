@@ -297,6 +297,7 @@ __device__ __forceinline__ void dist_stats_body(int K, const double* __restrict_
 // workgroups of one XCD (index ≡ x mod 8) therefore take a CONTIGUOUS range of units — whole splits: `step_regression_blocks`
 // workgroups (a multiple of 8), workgroup bx works as logical block (bx mod 8)·per + bx div 8.
 __host__ __device__ inline int step_regression_blocks(int n_units) { return 8 * ((((n_units + 3) >> 2) + 7) >> 3); }
+template <bool kFolded = false>
 __device__ __forceinline__ void step_regression_body(const StepRegressionArgs& a, const int bx) {
   const int n_units = a.ustart[a.n];
   const int n_blocks = (n_units + 3) >> 2;  // one wave per (tile, split) unit, four per workgroup
@@ -308,11 +309,13 @@ __device__ __forceinline__ void step_regression_body(const StepRegressionArgs& a
       const int which = u < a.ustart[1] ? 0 : 1;
       const int l = u - (which ? a.ustart[1] : 0), tile = l % a.ntiles, split = l / a.ntiles;
       if (l == 0 && (threadIdx.x & 63) == 0) { a.status[which][1] = 0; a.status[which][2] = 0; }
-      if (a.macro[which] > 1) {  // a folded posterior in macro tiles: unit l = macro tile l (uniform over the wave)
-        if (a.macro[which] == 2) regression_macro_fold<2>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
-        else regression_macro_fold<3>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
-      } else if (which == 0) regression_tile(tile, split, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0], a.fold[0]);
-      else regression_tile(tile, split, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1], a.fold[1]);
+      if constexpr (kFolded) {
+        // (a kernel of its own: inside the plain one these bodies' registers — two accumulator sets per tile, four tiles — took its occupancy
+        // from 152 to 328 registers per lane, and every lone chain's regression with it: configs[2] −7 %, 64 femur chains −8 %)
+        if (a.macro[which] > 1) regression_macro_fold<2>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
+        else regression_tile_fold(tile, split, a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which], a.fold[which]);
+      } else if (which == 0) regression_tile(tile, split, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0]);
+      else regression_tile(tile, split, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1]);
     }
   } else {
     // the last workgroup: likelihood reduction over the surface distances of the evaluator's model ids (results 0-3) and, for a
@@ -439,6 +442,12 @@ __global__ void __launch_bounds__(kStepBlock) k_step_regression_batch(const Step
   if ((int)blockIdx.x >= step_regression_grid(a)) return;
   step_regression_body(a, blockIdx.x);
 }
+// … with the posteriors' split-K leaves folded into one partial each (StepRegressionArgs::fold > 1 for the whole launch)
+__global__ void __launch_bounds__(kStepBlock) k_step_regression_batch_fold(const StepRegressionArgs* __restrict__ batch) {
+  const StepRegressionArgs& a = batch[blockIdx.y];
+  if ((int)blockIdx.x >= step_regression_grid(a)) return;
+  step_regression_body<true>(a, blockIdx.x);
+}
 template <int E, int NT>
 __global__ void __launch_bounds__(NT) k_step_finish_batch(const StepFinishArgs* __restrict__ batch) {
   const StepFinishArgs& a = batch[blockIdx.y];
@@ -556,7 +565,7 @@ inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 }  // namespace
 
 void launch_step_batch_resident(hipStream_t st, int B, const int gx[5], int r, const StepBeginArgs* begin, const StepSearchArgs* search,
-                                const StepRegressionArgs* regression, const StepFinishArgs* finish, bool filter_prepared) {
+                                const StepRegressionArgs* regression, const StepFinishArgs* finish, bool filter_prepared, bool reg_folded) {
   if (B <= 0) return;
   if (gx[0] > 0) { ProfScope _ps(st, KID_STEP_BEGIN); hipLaunchKernelGGL(k_step_begin_batch, dim3(gx[0], B), dim3(kStepBlock), 0, st, begin); }
   if (gx[1] > 0) {
@@ -565,7 +574,11 @@ void launch_step_batch_resident(hipStream_t st, int B, const int gx[5], int r, c
     else hipLaunchKernelGGL(k_step_filter_batch<false>, dim3(gx[1], B), dim3(kSearchBlock), 0, st, search);
   }
   if (gx[2] > 0) { ProfScope _ps(st, KID_STEP_RESOLVE); hipLaunchKernelGGL(k_step_resolve_batch, dim3(gx[2], B), dim3(64), 0, st, search); }
-  if (gx[3] > 0) { ProfScope _ps(st, KID_STEP_REGRESSION); hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, regression); }
+  if (gx[3] > 0) {
+    ProfScope _ps(st, KID_STEP_REGRESSION);
+    if (reg_folded) hipLaunchKernelGGL(k_step_regression_batch_fold, dim3(gx[3], B), dim3(kStepBlock), 0, st, regression);
+    else hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, regression);
+  }
   if (gx[4] > 0) {
     ProfScope _ps(st, KID_STEP_FINISH);
     const FinishPlan p = finish_plan(r);
@@ -972,7 +985,12 @@ void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pin
     else hipLaunchKernelGGL(k_step_filter_batch<false>, dim3(gx[1], B), dim3(kSearchBlock), 0, st, (const StepSearchArgs*)(d + o1));
   }
   if (gx[2] > 0) { ProfScope _ps(st, KID_STEP_RESOLVE); hipLaunchKernelGGL(k_step_resolve_batch, dim3(gx[2], B), dim3(64), 0, st, (const StepSearchArgs*)(d + o1)); }
-  if (gx[3] > 0) { ProfScope _ps(st, KID_STEP_REGRESSION); hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, (const StepRegressionArgs*)(d + o2)); }
+  if (gx[3] > 0) {
+    ProfScope _ps(st, KID_STEP_REGRESSION);
+    const bool reg_folded = caps[0].regression.fold[0] > 1;  // (one policy for the launch: regression_fold)
+    if (reg_folded) hipLaunchKernelGGL(k_step_regression_batch_fold, dim3(gx[3], B), dim3(kStepBlock), 0, st, (const StepRegressionArgs*)(d + o2));
+    else hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, (const StepRegressionArgs*)(d + o2));
+  }
   if (gx[4] > 0) {
     const FinishPlan p = finish_plan(caps[0].finish.r);  // (one rank per batch: checked by the caller)
     // launch 5 keeps four CUs per chain busy for 30 µs whatever the batch: on a stream of its own it runs beside the first

@@ -257,7 +257,8 @@ __host__ __device__ inline int wide_red_blocks(const WideRegArgs& a, int dir /* 
   const int K = dir == 0 ? a.Km : a.Kt;
   return a.eval_kind == 1 ? (K + kWideRegBlock - 1) / kWideRegBlock : 1;
 }
-__global__ void __launch_bounds__(kWideRegBlock) k_wide_regression(const WideRegArgs* __restrict__ batch) {
+template <bool kFolded>
+__device__ __forceinline__ void wide_regression_body(const WideRegArgs* __restrict__ batch) {
   const WideRegArgs& w = batch[blockIdx.y];
   const StepRegressionArgs& a = w.reg;
   int b = blockIdx.x;
@@ -270,11 +271,11 @@ __global__ void __launch_bounds__(kWideRegBlock) k_wide_regression(const WideReg
       const int which = u < a.ustart[1] ? 0 : 1;
       const int l = u - (which ? a.ustart[1] : 0), tile = l % a.ntiles, split = l / a.ntiles;
       if (l == 0 && (threadIdx.x & 63) == 0) { a.status[which][1] = 0; a.status[which][2] = 0; }
-      if (a.macro[which] > 1) {  // a folded posterior in macro tiles: unit l = macro tile l (uniform over the wave)
-        if (a.macro[which] == 2) regression_macro_fold<2>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
-        else regression_macro_fold<3>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
-      } else if (which == 0) regression_tile(tile, split, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0], a.fold[0]);
-      else regression_tile(tile, split, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1], a.fold[1]);
+      if constexpr (kFolded) {  // (a kernel of its own: see step_regression_body, kernels_step.hip)
+        if (a.macro[which] > 1) regression_macro_fold<2>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
+        else regression_tile_fold(tile, split, a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which], a.fold[which]);
+      } else if (which == 0) regression_tile(tile, split, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0]);
+      else regression_tile(tile, split, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1]);
     }
     return;
   }
@@ -293,6 +294,9 @@ __global__ void __launch_bounds__(kWideRegBlock) k_wide_regression(const WideReg
     b -= nr;
   }
 }
+__global__ void __launch_bounds__(kWideRegBlock) k_wide_regression(const WideRegArgs* __restrict__ batch) { wide_regression_body<false>(batch); }
+// … with the posteriors' split-K leaves folded into one partial each, in 2 x 2 macro tiles at ranks >= 80 (WideLaunchPlan::reg_folded)
+__global__ void __launch_bounds__(kWideRegBlock) k_wide_regression_fold(const WideRegArgs* __restrict__ batch) { wide_regression_body<true>(batch); }
 
 // ---------------------------------------------------------------- W12: results and completion flags into pinned host memory
 __global__ void __launch_bounds__(64) k_wide_done(WideDoneArgs a) {
@@ -404,7 +408,8 @@ void launch_wide_main(hipStream_t st, const WideLaunchPlan& plan, void* device) 
   launch_wide_searches(st, B, plan.grid_f2, plan.grid_r2, true, (const StepSearchArgs*)(d + o.s2), KID_VERTEX_FILTER, KID_VERTEX_RESOLVE);
   if (plan.grid_reg > 0) {
     ProfScope _ps(st, KID_STEP_REGRESSION);
-    hipLaunchKernelGGL(k_wide_regression, dim3(plan.grid_reg, B), dim3(kWideRegBlock), 0, st, (const WideRegArgs*)(d + o.reg));
+    if (plan.reg_folded) hipLaunchKernelGGL(k_wide_regression_fold, dim3(plan.grid_reg, B), dim3(kWideRegBlock), 0, st, (const WideRegArgs*)(d + o.reg));
+    else hipLaunchKernelGGL(k_wide_regression, dim3(plan.grid_reg, B), dim3(kWideRegBlock), 0, st, (const WideRegArgs*)(d + o.reg));
   }
 }
 
