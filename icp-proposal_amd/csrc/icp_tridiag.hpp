@@ -846,17 +846,37 @@ __global__ void __launch_bounds__(64) k_tri_wy_many(TriWyMany m) {
   tri_wy_body<SI>(a);
 }
 
+struct TriSolveLds {  // the solve launch's dynamic LDS (doubles): offsets for an n x n problem
+  int oDs, oE2, oDsr, oE2r, oEs, oRed, oWy, oScr, scr_stride, oCarry, carry_stride, total;
+  __host__ __device__ explicit TriSolveLds(int n) {
+    const int np = n + 8, nblk = (n - 2 + kWyBlock - 1) / kWyBlock;
+    oDs = 0; oE2 = np; oDsr = 2 * np; oE2r = 3 * np; oEs = 4 * np; oRed = oEs + n; oWy = oRed + 8;
+    oScr = oWy + (nblk > 0 ? nblk : 0) * kWyBlock * kWyBlock;
+    scr_stride = 2 * n + 2 * np;       // per wave: D⁺ | D⁻ by row, then the two chains' values (a group of eight filed whole)
+    oCarry = oScr + 4 * scr_stride;
+    carry_stride = n / 8 + 2;
+    total = oCarry + 8 * carry_stride;
+  }
+};
+inline size_t tri_solve_lds_bytes(int n) { return sizeof(double) * (size_t)TriSolveLds(n).total; }
+
 template <int SI>
 __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
   constexpr int LD = 64 * SI;
   const int off = LD - a.n;  // position of index 0 (see tridiagonalise)
-  __shared__ double ds[kTriMaxN + 8], es[kTriMaxN], e2[kTriMaxN + 8], bet[kTriMaxN];
-  __shared__ double scr[4][4 * kTriMaxN + 16];
-  __shared__ double red[8];
-  __shared__ double dsr[kTriMaxN + 8], e2r[kTriMaxN + 8];           // the matrix bottom-up (the second chain of the factorisation reads forward, too)
-  __shared__ double carry[4][2][kTriMaxN / 8 + 1];                    // per wave and chain: the rescaled value a group of eight rows hands to the next
-  __shared__ double wy[(kTriMaxN / kWyBlock) * kWyBlock * kWyBlock];  // T factors of the reflector blocks
+  // LDS sized by n, not by the largest rank (round 5: 64 KB of static arrays let two workgroups share a compute unit; at rank 200 the
+  // arrays below take 49 KB and three do — the launch of 16 posteriors side by side, 800 workgroups of four f64-issue-bound waves,
+  // is a throughput kernel): tri_solve_lds_bytes(n) of dynamic shared memory
+  extern __shared__ double tri_dyn[];
   const int n = a.n;
+  const TriSolveLds L(n);
+  double* ds = tri_dyn + L.oDs;      // [n + 8] diagonal (scaled); the eight entries past the end are read, never used, by a chain's last group
+  double* e2 = tri_dyn + L.oE2;      // [n + 8] squared off-diagonal
+  double* dsr = tri_dyn + L.oDsr;    // [n + 8] … and bottom-up (the second chain of the factorisation reads forward, too)
+  double* e2r = tri_dyn + L.oE2r;
+  double* es = tri_dyn + L.oEs;      // [n] off-diagonal
+  double* red = tri_dyn + L.oRed;    // [8]
+  double* wy = tri_dyn + L.oWy;      // T factors of the reflector blocks
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = blockIdx.x * 4 + w;  // this wave's eigenvalue (ascending), rank j of the output
@@ -897,7 +917,6 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     const double ee = i < n - 1 ? a.e[i] * inv : 0.0;
     es[i] = ee;
     e2[i] = fmax(ee * ee, 1e-280);
-    bet[i] = i < n - 2 ? a.beta[i] : 0.0;
     dsr[n - 1 - i] = a.d[i] * inv;
     if (i < n - 1) e2r[n - 2 - i] = fmax(ee * ee, 1e-280);
   }
@@ -932,8 +951,8 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
   // away from the twist: an exclusive product scan over the lanes (four consecutive rows per lane, mantissa and exponent apart —
   // a partial product far from the twist may leave the range of a double where the entry itself is harmless) instead of two chains
   // of up to n − 1 dependent multiplications.  36 → 5 µs per eigenpair wave at rank 200.
-  double* Dq = scr[w];               // [2][n]: D⁺ | D⁻ by row
-  double* Pc = scr[w] + 2 * n;       // [2][n + 8]: the chains' values in chain order (top-down | bottom-up; a group of eight is filed whole)
+  double* Dq = tri_dyn + L.oScr + w * L.scr_stride;  // [2][n]: D⁺ | D⁻ by row
+  double* Pc = Dq + 2 * n;       // [2][n + 8]: the chains' values in chain order (top-down | bottom-up; a group of eight is filed whole)
   const int np = n + 8;
   double* zb = Dq;                   // z overwrites D⁺ once γ is known
   double lam = 0.5 * (lo + hi);
@@ -945,7 +964,7 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
       const double* dd_ = dir ? dsr : ds;
       const double* ee_ = dir ? e2r : e2;
       double* pc = Pc + dir * np;
-      double* cg = carry[w][dir];
+      double* cg = tri_dyn + L.oCarry + (w * 2 + dir) * L.carry_stride;  // per wave and chain: the rescaled value a group of eight rows hands on
       double p0 = 1.0, p1 = dd_[0] - lam;
       pc[0] = p1;
       int g = 0;
@@ -979,7 +998,7 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
           const double* pc = Pc + dir * np;
-          const double den = m == 0 ? 1.0 : (((m - 1) & 7) == 0 && m > 1) ? carry[w][dir][(m - 1) / 8 - 1] : pc[m - 1];
+          const double den = m == 0 ? 1.0 : (((m - 1) & 7) == 0 && m > 1) ? (tri_dyn + L.oCarry + (w * 2 + dir) * L.carry_stride)[(m - 1) / 8 - 1] : pc[m - 1];
           const double D = pc[m] / den;
           Dq[dir * n + (dir ? n - 1 - m : m)] = D;
         }

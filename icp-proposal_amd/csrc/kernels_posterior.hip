@@ -2272,10 +2272,10 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_wy<2>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
   else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_wy<3>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
   else hipLaunchKernelGGL(tri::k_tri_wy<4>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
-  if (r <= 64) hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), 0, st, so, so);
-  else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), 0, st, so, so);
-  else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg), dim3(256), 0, st, so, so);
-  else hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), 0, st, so, so);
+  if (r <= 64) hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
+  else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
+  else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
+  else hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
   // one refinement step: T = N·X and R = I − XᵀX, S = XᵀT, E, then V = X + X·E (and Vt)
   const int nt = (r + 15) / 16;
   const int* skip = sync + 3;  // (written by the solve launch: 1 = every gap wide enough, the refinement's launches return at once)
@@ -2340,9 +2340,9 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
     if (r <= 128) hipLaunchKernelGGL(tri::k_tri_wy_many<2>, dim3(nwy, n), dim3(64), 0, st, wm);
     else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_wy_many<3>, dim3(nwy, n), dim3(64), 0, st, wm);
     else hipLaunchKernelGGL(tri::k_tri_wy_many<4>, dim3(nwy, n), dim3(64), 0, st, wm);
-    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg, n), dim3(256), 0, st, sm);
-    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve_many<3>, dim3(nwg, n), dim3(256), 0, st, sm);
-    else hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg, n), dim3(256), 0, st, sm);
+    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm);
+    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve_many<3>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm);
+    else hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm);
     hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, 2 * n), dim3(64), 0, st, r, g1);
     hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, n), dim3(64), 0, st, r, g2);
     hipLaunchKernelGGL(tri::k_tri_correction_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, cm);
@@ -2590,7 +2590,7 @@ static void launch_eigen_tridiag_small(hipStream_t st, int r, const double* sqrt
   ProfScope _ps(st, KID_EIGEN);
   hipLaunchKernelGGL(tri::k_tridiag_small, dim3(n), dim3(256), 0, st, b);
   hipLaunchKernelGGL(tri::k_tri_wy<1>, dim3((r - 2 + tri::kWyBlock - 1) / tri::kWyBlock, n), dim3(64), 0, st, wy[0], wy[1]);
-  hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3((r + 3) / 4, n), dim3(256), 0, st, so[0], so[1]);
+  hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3((r + 3) / 4, n), dim3(256), tri::tri_solve_lds_bytes(r), st, so[0], so[1]);
 }
 
 bool launch_posterior_eigen_pair(hipStream_t st, int r, const double* sqrt_lambda, int n, const EigenRequest* rq) {
