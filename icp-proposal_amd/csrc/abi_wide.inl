@@ -162,7 +162,21 @@ void wide_await_entry(icp_ctx& c, icp_proposal* p, PosteriorEntry& en, hipStream
   }
 }
 
-void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
+// What wide_issue has worked out for its chains, handed back INSTEAD of being launched: the on-device loop (abi_device_loop.inl)
+// uploads the records once and replays the launches step after step, the per-step entries (proposal inputs, poses) set by its own
+// front kernel.  Every chain's step is captured as an ICP move (shape only, posteriors of the proposed state computed, no
+// decomposition ahead).
+struct WideCapture {
+  WideLaunchPlan plan{};
+  bool any_split = false;
+  std::vector<WideChainArgs> chain_args;
+  std::vector<WideProposeItem> prop_items;
+  std::vector<double*> sum_parts; std::vector<int> sum_splits;
+  std::vector<PosteriorFactorIO> factors;  // n_props per chain
+  std::vector<TransitionTailIO> tails;     // 2·n_props per chain: fwd_0, bwd_0, fwd_1, bwd_1
+};
+
+void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead, WideCapture* capture = nullptr) {
   const int n_props = t.n_props;
   std::vector<int> idx;
   for (int b = 0; b < t.n_chains; ++b)
@@ -181,8 +195,8 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
   hipStream_t Es[2];
   Es[0] = lone ? elead.eig_stream.get() : batch_eigen_stream(lead, &elead, 0);
   Es[1] = !two_eig ? Es[0] : (lone ? elead.eig_stream2.get() : batch_eigen_stream(lead, &elead, 1));
-  const int turn = (lead.wide_turn = (lead.wide_turn + 1) % icp_ctx::kBatchRing);
-  {
+  const int turn = capture ? lead.wide_turn : (lead.wide_turn = (lead.wide_turn + 1) % icp_ctx::kBatchRing);
+  if (!capture) {
     Bound _b(&lead, true, true);
     if (!lead.ev_wide_sum[turn]) HIP_OK(hipEventCreateWithFlags(&lead.ev_wide_sum[turn], hipEventDisableTiming));
     if (!lead.ev_wide_fac[turn]) HIP_OK(hipEventCreateWithFlags(&lead.ev_wide_fac[turn], hipEventDisableTiming));
@@ -227,13 +241,13 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
     Bound _b(&c, true);
     w = WideItem{};
     w.on = true;
-    if (!e->last_prop.empty()) {  // did the caller keep the state the previous step proposed?
+    if (!e->last_prop.empty() && !capture) {  // did the caller keep the state the previous step proposed?
       const bool accepted = std::memcmp(e->last_prop.data(), theta_cur, sizeof(double) * (10 + (size_t)r)) == 0;
       e->acc_ema = 0.9 * e->acc_ema + (accepted ? 0.1 : 0.0);
     }
     for (int i = 0; i < n_props; ++i) it.props[i]->resolve_speculation(theta_cur);  // (a merged step's speculation, if the chain changed paths)
     w.shape_only = generator >= 0 || pose_equal(theta_cur, theta_prop);
-    const bool spec = (spec_mode == 1 || (spec_mode == 2 && e->acc_ema >= 0.1)) && !c.speculation_off;
+    const bool spec = !capture && (spec_mode == 1 || (spec_mode == 2 && e->acc_ema >= 0.1)) && !c.speculation_off;
     // a pose move changes the state too: if it is kept, the next ICP proposal draws from the posterior at the NEW state, which
     // nothing else on this path would compute (the transition densities across a pose change are −∞): started here, ahead
     w.do_post = w.shape_only || spec;
@@ -568,6 +582,13 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead) {
       en->eig_done_shared = ev_pre->ev; en->eig_shared_gen = &ev_pre->gen; en->eig_shared_gen_value = ev_pre->gen;
       en->eig_event_valid = true; en->done_value = 0;
     }
+  }
+  if (capture) {  // (nothing launched; what the chains hold stays reserved until the caller's wide_release)
+    capture->plan = plan; capture->any_split = any_split;
+    capture->chain_args = std::move(chain_args); capture->prop_items = std::move(prop_items);
+    capture->sum_parts = std::move(sum_parts); capture->sum_splits = std::move(sum_splits);
+    capture->factors = std::move(factors); capture->tails = std::move(tails);
+    return;
   }
   for (size_t p0 = 0; p0 < prop_items.size(); p0 += kWideMaxChains) {
     WideProposeArgs pa{};

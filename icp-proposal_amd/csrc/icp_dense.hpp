@@ -688,16 +688,19 @@ __device__ __forceinline__ bool factor_reg_body(int r, const double* __restrict_
       }
       __syncthreads();
       if (b0 > 0) {
-        constexpr int G = NT / 64;
+        // (EIGHT groups whatever the block size: the grouping decides how the sums are rounded, and the merged step's copy of this
+        // body — 512 threads at ranks 65..116 — and the factor launch's — 1,024 — must give the same alpha bit for bit; with sixteen
+        // groups in the latter they differed in the last place, found by the on-device loop of those ranks, round 5)
+        constexpr int G = NT / 64 < 8 ? NT / 64 : 8;
         const int g = tid >> 6, li = tid & 63, per = (nb + G - 1) / G;
         for (int i0 = 0; i0 < b0; i0 += 64) {
           const int i = i0 + li;
           double acc = 0.0;
-          if (i < b0) {
+          if (i < b0 && g < G) {
             const int j1 = min(nb, (g + 1) * per);
             for (int j = g * per; j < j1; ++j) acc = fma(W[(size_t)(b0 + j) * ld + i], s_v[b0 + j], acc);
           }
-          s_bp[g * 64 + li] = acc;
+          if (g < G) s_bp[g * 64 + li] = acc;
           __syncthreads();
           if (g == 0 && i < b0) {
             double t = 0.0;

@@ -455,6 +455,19 @@ void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pin
 // posteriors.  Random numbers: the harness' counter-based generator (host/icp_host.hpp: splitmix64 over (seed, step, lane)) — the
 // uniforms are integer arithmetic and are drawn on the device, bit for bit the host's; the standard normals need log / cos and are
 // drawn on the host with the harness' own expression and streamed in ahead of the steps that use them.
+struct WideProposeItem;
+struct WideInstArgs;
+// … of a chain that takes the WIDE step (kernels_wide.hip) inside the loop: its launch records live in device memory and are the same
+// every step — an accepted state's posterior is COPIED into the current state's entries (k_mhw_adopt) instead of the two sets
+// changing roles — but for what the step's head sets: the proposal's inputs and the proposed state's pose
+struct MhWide {
+  WideProposeItem* item;      // the chain's W1 record: kind / in / src
+  ProposeIn prop_in[2];       // a8 from the CURRENT state's posterior, per ICP proposal (z: set per step)
+  double* given;              // [r] coefficients of a proposal that does not draw them from a posterior (shape walk: c + σ·z; pose walk: c)
+  WideInstArgs* inst;         // W2 record: the proposed state's pose
+  StepSearchArgs* search[2];  // W4-W7 records of the main sequence: the correspondences' inverse rigid transform
+  const int* chol[2];         // the factorisation's status word of the proposed state's posterior, per ICP proposal
+};
 struct MhChain {
   // -- fixed for the run
   unsigned long long seed;
@@ -499,10 +512,24 @@ struct MhChain {
   long long step, accepted;
   int cur_sel, gen, leaf, error;         // error != 0: the chain needs the host (non-contracting tail, non-finite value, …) and stands still
   int eig_seq[2];                        // decompositions of proposal i so far (cold every 128th, as the host path)
+  MhWide* wide;                          // (fixed for the run) non-null: the chain takes the wide step — k_mhw_front / k_mh_decide_wide
 };
 void launch_mh_set_normals(hipStream_t st, int B, MhChain* chains, const double* base, int stride, int offset, int rows);
 void launch_mh_front(hipStream_t st, int B, MhChain* chains);
 void launch_mh_decide(hipStream_t st, int B, MhChain* chains);
+// the wide step's head and tail (ranks up to 256; every step's head by the front kernel); then, per posterior q of the launch (chain-major,
+// n_icp per chain), the proposed state's M, alpha and coefficients into the current state's entries where eig_skip[q] == 0
+void launch_mhw_front(hipStream_t st, int B, MhChain* chains);
+void launch_mhw_decide(hipStream_t st, int B, int r, MhChain* chains);
+struct MhAdopt {
+  const double* M_from; double* M_to; const double* alpha_from; double* alpha_to; const double* c_from; double* c_to;
+  // (ranks above 64: the proposed state's posterior has been decomposed AHEAD of the decision, beside the factorisation and the
+  // evaluator's searches — its basis and the decomposition's status word move too; null: decomposed in place afterwards)
+  const double* V_from; double* V_to; const double* Vt_from; double* Vt_to; const double* S_from; double* S_to; const int* st_from; int* st_to;
+  // the correspondence records of the posterior (what icp_proposal_posterior hands out for the state)
+  const unsigned char* corr_from[6]; unsigned char* corr_to[6]; int corr_bytes[6];
+};
+void launch_mhw_adopt(hipStream_t st, int r, int n, const MhAdopt* records, const int* skip);
 // the five merged launches for B chains from DEVICE-RESIDENT argument arrays (no copy kernel, no gate: one stream, in order)
 void launch_step_batch_resident(hipStream_t st, int B, const int grid[5], int r, const StepBeginArgs* begin, const StepSearchArgs* search,
                                 const StepRegressionArgs* regression, const StepFinishArgs* finish, bool filter_prepared = false,
@@ -534,6 +561,8 @@ struct WideProposeItem {   // W1
 };
 struct WideProposeArgs { int n; WideProposeItem it[kWideMaxChains]; };
 void launch_wide_propose(hipStream_t st, int r, const WideProposeArgs& a);
+// … of n records that live in device memory (the on-device loop; KL-basis sampler above rank 64)
+void launch_wide_propose_resident(hipStream_t st, int r, int n, const WideProposeItem* items);
 
 struct WideInstArgs {      // W2, per chain (device memory)
   int kind;                // 0: x = pose(ref + mean + Q·c), deformations kept; 1: x = pose(ref + defo_src) (a pose move)
@@ -583,6 +612,12 @@ struct WideLaunchPlan {
 struct WideChainArgs { WideInstArgs inst; WidePrepArgs prep; StepSearchArgs s1, s2; WideRegArgs reg; StepSearchArgs s1b, s2b; WideRegArgs regb; };
 // copies the chains' records into `pinned` (wide_batch_bytes(B)); launches the copy to `device`, the instances and W3 on `st`
 void launch_wide_head(hipStream_t st, const WideLaunchPlan& plan, const WideChainArgs* chains, void* pinned, void* device);
+// the same records laid out in host memory `dst` (wide_batch_bytes(B)) / W2 and W3 from records already in `device`
+void wide_pack_args(int B, const WideChainArgs* chains, void* dst);
+void launch_wide_head_resident(hipStream_t st, const WideLaunchPlan& plan, void* device);
+// where chain b's records sit inside such a block
+WideInstArgs* wide_inst_record(void* block, int B, int b);
+StepSearchArgs* wide_search_record(void* block, int B, int stage /* 0: s1, 1: s2 */, int b);
 // W4..W8 of the records in `device` (launch_wide_head): the main sequence, the evaluator's own
 void launch_wide_main(hipStream_t st, const WideLaunchPlan& plan, void* device);
 void launch_wide_eval(hipStream_t st, const WideLaunchPlan& plan, void* device);
@@ -596,7 +631,8 @@ void launch_sum_partials_many(hipStream_t st, int r, int n, double* const* Mpart
 // inside the sequence: a spectrum the multisection cannot separate ends with status 2 in the request's status words, and the caller
 // decomposes that posterior again through launch_posterior_eigen.
 bool eigen_tridiag_many_supported(int r);
-void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n, const EigenRequest* rq, const double* const* parts /* may be null */);
+void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n, const EigenRequest* rq, const double* const* parts /* may be null */,
+                                         const int* skip = nullptr /* device, [n]: != 0 leaves request i alone (the on-device loop) */);
 
 SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const float4* spheres, int K, const double* P,
                               int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);

@@ -389,6 +389,7 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
         lds_barrier();
       }
       double vs[SI], ws[SI], xnew[SI];
+      double lead_loc = 0.0;
 #pragma unroll
       for (int s = 0; s < SI; ++s) { vs[s] = 0.0; ws[s] = 0.0; xnew[s] = 0.0; }
       if (lead) {
@@ -495,15 +496,30 @@ __device__ __forceinline__ void tridiagonalise(const TridiagIO& a, double (&A)[S
       }
       if constexpr (VLDS && !LEAD) wave_lds_sync();
       TRI_CYC(3);
-      {
+      // The next column's first entry and norm — what the NEXT step's reflector starts from.  Where one wave carries the scalar chain
+      // (LEAD) they are taken BEHIND the barrier that releases the other waves into the pass (round 5): the lead reaches the next
+      // step's first barrier ≈ 1,200 cycles ahead of the others anyway (tri_bench -DICP_TRI_CYCLES: "barrier 1,194"), the wave
+      // reduction (≈ 300 cycles) was on every step's critical path for nothing.
+      if constexpr (!LEAD) {
         double t = xnew[S0];
 #pragma unroll
         for (int s = S0 + 1; s < SI; ++s) t = ((k1 + 1) >> 6) == s ? xnew[s] : t;
         x0 = readlane_f64(t, (k1 + 1) & 63);
+        sig2 = wave_sum(loc);
+      } else {
+        lead_loc = loc;
       }
-      sig2 = wave_sum(loc);
       }  // lead
-      if constexpr (LEAD) lds_barrier();  // v, w, x' of this step are in LDS
+      if constexpr (LEAD) {
+        lds_barrier();  // v, w, x' of this step are in LDS
+        if (lead) {
+          double t = xnew[S0];
+#pragma unroll
+          for (int s = S0 + 1; s < SI; ++s) t = ((k1 + 1) >> 6) == s ? xnew[s] : t;
+          x0 = readlane_f64(t, (k1 + 1) & 63);
+          sig2 = wave_sum(lead_loc);
+        }
+      }
       TRI_CYC(4);
       pass(s0tag, Tag<1>{}, par, par ^ 1, k1 + 1, k, vs, ws, xnew);
 #pragma unroll
@@ -584,7 +600,8 @@ __global__ void __launch_bounds__(NW * 64) k_tridiag(TridiagIO a) { tridiag_kern
 constexpr int kTriMany = 16;
 struct TridiagMany { TridiagIO p[kTriMany]; };
 template <int NW, int SI, int NT, int TOFF>
-__global__ void __launch_bounds__(NW * 64) k_tridiag_many(TridiagMany m) {
+__global__ void __launch_bounds__(NW * 64) k_tridiag_many(TridiagMany m, const int* __restrict__ skip_all) {
+  if (skip_all && skip_all[blockIdx.x] != 0) return;  // (the on-device loop: a chain that did not move)
   const TridiagIO a = m.p[blockIdx.x];  // (a copy: scalar registers, as a by-value kernel argument)
   tridiag_kernel_body<NW, SI, NT, TOFF>(a);
 }
@@ -841,7 +858,8 @@ template <int SI>
 __global__ void __launch_bounds__(64) k_tri_wy(TriWyIO a0, TriWyIO a1) { tri_wy_body<SI>(blockIdx.y ? a1 : a0); }
 struct TriWyMany { TriWyIO p[kTriMany]; };
 template <int SI>
-__global__ void __launch_bounds__(64) k_tri_wy_many(TriWyMany m) {
+__global__ void __launch_bounds__(64) k_tri_wy_many(TriWyMany m, const int* __restrict__ skip_all) {
+  if (skip_all && skip_all[blockIdx.y] != 0) return;
   const TriWyIO a = m.p[blockIdx.y];
   tri_wy_body<SI>(a);
 }
@@ -1194,7 +1212,8 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1)
 }
 struct TriSolveMany { TriSolveIO p[kTriMany]; };
 template <int SI>
-__global__ void __launch_bounds__(256) k_tri_solve_many(TriSolveMany m) {
+__global__ void __launch_bounds__(256) k_tri_solve_many(TriSolveMany m, const int* __restrict__ skip_all) {
+  if (skip_all && skip_all[blockIdx.y] != 0) return;
   // (no s_setprio here: raised to 3 for the critical path's sake, beside the evaluator's searches of a 30-chain wide step the device
   // hung — measured once, not understood, not repeated)
   const TriSolveIO a = m.p[blockIdx.y];
@@ -1266,7 +1285,8 @@ __global__ void __launch_bounds__(64) k_tri_gemm(int n, TriGemm g0, TriGemm g1) 
   tri_gemm_body(n, g);
 }
 struct TriGemmMany { TriGemm g[2 * kTriMany]; };  // blockIdx.z = product
-__global__ void __launch_bounds__(64) k_tri_gemm_many(int n, TriGemmMany m) {
+__global__ void __launch_bounds__(64) k_tri_gemm_many(int n, TriGemmMany m, const int* __restrict__ skip_all, int per_problem) {
+  if (skip_all && skip_all[blockIdx.z / per_problem] != 0) return;
   const TriGemm g = m.g[blockIdx.z];
   tri_gemm_body(n, g);
 }
@@ -1289,9 +1309,10 @@ __global__ void __launch_bounds__(256) k_tri_correction(int n, const double* __r
   E[e] = v;
 }
 struct TriCorrMany { const double* S[kTriMany]; const double* R[kTriMany]; double* E[kTriMany]; double* Sout[kTriMany]; const int* skip[kTriMany]; };
-__global__ void __launch_bounds__(256) k_tri_correction_many(int n, TriCorrMany m) {
+__global__ void __launch_bounds__(256) k_tri_correction_many(int n, TriCorrMany m, const int* __restrict__ skip_all) {
   const int e = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
   if (e >= n * n) return;
+  if (skip_all && skip_all[q] != 0) return;
   if (m.skip[q] && __hip_atomic_load(m.skip[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) return;
   const double* __restrict__ S = m.S[q];
   const double* __restrict__ R = m.R[q];
@@ -1309,16 +1330,18 @@ __global__ void __launch_bounds__(256) k_tri_correction_many(int n, TriCorrMany 
   m.E[q][e] = v;
 }
 struct TriDoneMany { const int* status[kTriMany]; int* host_status[kTriMany]; int* done_word[kTriMany]; int done_value[kTriMany]; };
-__global__ void k_tri_done_many(TriDoneMany m) {
+__global__ void k_tri_done_many(TriDoneMany m, const int* __restrict__ skip_all) {
   const int q = blockIdx.x;
+  if (skip_all && skip_all[q] != 0) return;
   if (m.host_status[q]) __hip_atomic_store(m.host_status[q], m.status[q][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (m.done_word[q]) __hip_atomic_store(m.done_word[q], m.done_value[q], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 // M = I + the summed split-K partial of a posterior, both triangles (k_assemble_posterior_matrix), for up to kTriMany posteriors
 struct AssembleMany { const double* P[kTriMany]; double* M[kTriMany]; };
-__global__ void __launch_bounds__(256) k_assemble_many(int r, AssembleMany m) {
+__global__ void __launch_bounds__(256) k_assemble_many(int r, AssembleMany m, const int* __restrict__ skip_all) {
   const int e = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
   if (e >= r * r || !m.P[q]) return;
+  if (skip_all && skip_all[q] != 0) return;
   const int i = e / r, j = e - i * r;
   const int hi = max(i, j), lo = min(i, j);
   m.M[q][e] = m.P[q][(size_t)hi * (r + 1) + lo] + (i == j ? 1.0 : 0.0);

@@ -2295,12 +2295,14 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
 // The same route for n decompositions side by side (the chains of a wide step): every launch of the sequence takes all of them —
 // the one-workgroup reductions run on n CUs at once.  No gated Jacobi fall-back in the sequence (see icp_kernels.hpp).
 bool eigen_tridiag_many_supported(int r) { return r > 64 && r <= kTriMaxRank; }
-void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const EigenRequest* rq_all, const double* const* parts_all) {
+void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const EigenRequest* rq_all, const double* const* parts_all,
+                                         const int* skip_all) {
   const size_t rr = (size_t)r * r;
   const int nwg = (r + 3) / 4, nt = (r + 15) / 16;
   for (int q0 = 0; q0 < n_all; q0 += tri::kTriMany) {
     const int n = std::min(tri::kTriMany, n_all - q0);
     const EigenRequest* rq = rq_all + q0;
+    const int* skip = skip_all ? skip_all + q0 : nullptr;
     tri::TridiagMany tm{};
     tri::TriSolveMany sm{};
     tri::TriWyMany wm{};
@@ -2332,22 +2334,22 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
       assemble = assemble || am.P[q] != nullptr;
     }
     ProfScope _ps(st, KID_EIGEN);
-    if (assemble) hipLaunchKernelGGL(tri::k_assemble_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, am);
-    if (r <= 128) hipLaunchKernelGGL((tri::k_tridiag_many<4, 2, 32, 0>), dim3(n), dim3(256), 0, st, tm);
-    else if (r <= 192) hipLaunchKernelGGL((tri::k_tridiag_many<8, 3, 24, 0>), dim3(n), dim3(512), 0, st, tm);
-    else hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 25, 7>), dim3(n), dim3(512), 0, st, tm);
+    if (assemble) hipLaunchKernelGGL(tri::k_assemble_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, am, skip);
+    if (r <= 128) hipLaunchKernelGGL((tri::k_tridiag_many<4, 2, 32, 0>), dim3(n), dim3(256), 0, st, tm, skip);
+    else if (r <= 192) hipLaunchKernelGGL((tri::k_tridiag_many<8, 3, 24, 0>), dim3(n), dim3(512), 0, st, tm, skip);
+    else hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 25, 7>), dim3(n), dim3(512), 0, st, tm, skip);
     const int nwy = (r - 2 + tri::kWyBlock - 1) / tri::kWyBlock;
-    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_wy_many<2>, dim3(nwy, n), dim3(64), 0, st, wm);
-    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_wy_many<3>, dim3(nwy, n), dim3(64), 0, st, wm);
-    else hipLaunchKernelGGL(tri::k_tri_wy_many<4>, dim3(nwy, n), dim3(64), 0, st, wm);
-    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm);
-    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve_many<3>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm);
-    else hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm);
-    hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, 2 * n), dim3(64), 0, st, r, g1);
-    hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, n), dim3(64), 0, st, r, g2);
-    hipLaunchKernelGGL(tri::k_tri_correction_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, cm);
-    hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, n), dim3(64), 0, st, r, g3);
-    hipLaunchKernelGGL(tri::k_tri_done_many, dim3(n), dim3(1), 0, st, dm);
+    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_wy_many<2>, dim3(nwy, n), dim3(64), 0, st, wm, skip);
+    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_wy_many<3>, dim3(nwy, n), dim3(64), 0, st, wm, skip);
+    else hipLaunchKernelGGL(tri::k_tri_wy_many<4>, dim3(nwy, n), dim3(64), 0, st, wm, skip);
+    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
+    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve_many<3>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
+    else hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
+    hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, 2 * n), dim3(64), 0, st, r, g1, skip, 2);
+    hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, n), dim3(64), 0, st, r, g2, skip, 1);
+    hipLaunchKernelGGL(tri::k_tri_correction_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, cm, skip);
+    hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, n), dim3(64), 0, st, r, g3, skip, 1);
+    hipLaunchKernelGGL(tri::k_tri_done_many, dim3(n), dim3(1), 0, st, dm, skip);
   }
 }
 

@@ -630,25 +630,41 @@ __device__ __forceinline__ void mh_copy(T* dst, const T* src, int tid, int nt) {
 }
 }  // namespace
 
-// head of a step: mixture draw (MixtureProposal.propose: outer draw on lane 0, inner on lane 1), the step's arguments.
+// the step's mixture draw (MixtureProposal.propose: outer draw on lane 0, inner on lane 1), by one thread
+__device__ __forceinline__ void mh_draw(MhChain& c, int* gen_out, int* pose_leaf_out) {
+  const unsigned long long step = (unsigned long long)c.step;
+  const int o = mh_pick(c.n_outer, c.outer_w, mh_uniform(c.seed, step, 0));
+  int gen = -1, leaf = 2, pose_leaf = -1;  // the shape random walk (RandomShapeUpdateProposal) = leaf 2
+  if (c.outer_kind[o] == 1) {
+    gen = mh_pick(c.n_icp, c.icp_w, mh_uniform(c.seed, step, 1));
+    leaf = gen;
+  } else if (c.outer_kind[o] == 0) {  // mixedRandomPoseProposal: the inner draw picks one of the six walks
+    pose_leaf = mh_pick(c.n_pose, c.pose_w, mh_uniform(c.seed, step, 1));
+    leaf = 3 + pose_leaf;
+  }
+  c.gen = gen; c.leaf = leaf; c.pose_move = pose_leaf >= 0 ? 1 : 0;
+  *gen_out = gen; *pose_leaf_out = pose_leaf;
+}
+// the pose the step's kernels work with: the chain's current one — or, for a pose walk, the current one with ONE parameter moved by
+// σ·z₀ (PoseProposals.scala:39-41, :72-74).  The rotation matrix from include/icp_sincos.h: the bits the host's pose_from_theta and the
+// oracle's orc_rotation_matrix give for these angles.
+__device__ __forceinline__ Pose mh_step_pose(MhChain& c, int pose_leaf, double z0) {
+  double th[10];
+  for (int k = 0; k < 10; ++k) th[k] = c.theta[k];
+  if (pose_leaf >= 0) th[c.pose_index[pose_leaf]] = th[c.pose_index[pose_leaf]] + c.pose_sigma[pose_leaf] * z0;
+  for (int k = 0; k < 10; ++k) c.prop_pose[k] = th[k];
+  Pose P;
+  icp_rotation_matrix(th[4], th[5], th[6], P.R);
+  for (int d = 0; d < 3; ++d) { P.t[d] = th[1 + d]; P.ctr[d] = th[7 + d]; }
+  P.s = th[0];
+  return P;
+}
+// head of a step: mixture draw, the step's arguments.
 // One wave per chain; called by k_mh_front (first step of a block of normals) and by k_mh_decide for the step behind its own.
 __device__ __forceinline__ void mh_front_body(MhChain& c, const int tid) {
   const int r = c.r;
   __shared__ int s_gen, s_pose_leaf;
-  if (tid == 0) {
-    const unsigned long long step = (unsigned long long)c.step;
-    const int o = mh_pick(c.n_outer, c.outer_w, mh_uniform(c.seed, step, 0));
-    int gen = -1, leaf = 2, pose_leaf = -1;  // the shape random walk (RandomShapeUpdateProposal) = leaf 2
-    if (c.outer_kind[o] == 1) {
-      gen = mh_pick(c.n_icp, c.icp_w, mh_uniform(c.seed, step, 1));
-      leaf = gen;
-    } else if (c.outer_kind[o] == 0) {  // mixedRandomPoseProposal: the inner draw picks one of the six walks
-      pose_leaf = mh_pick(c.n_pose, c.pose_w, mh_uniform(c.seed, step, 1));
-      leaf = 3 + pose_leaf;
-    }
-    c.gen = gen; c.leaf = leaf; c.pose_move = pose_leaf >= 0 ? 1 : 0;
-    s_gen = gen; s_pose_leaf = pose_leaf;
-  }
+  if (tid == 0) mh_draw(c, &s_gen, &s_pose_leaf);
   const int sel = c.cur_sel;
   mh_copy(c.begin_live, c.begin_alt[sel], tid, 64);
   mh_copy(c.search_live, c.search_alt[sel], tid, 64);
@@ -670,18 +686,8 @@ __device__ __forceinline__ void mh_front_body(MhChain& c, const int tid) {
     b.zin[tid] = gen >= 0 ? z[tid] : (pose_leaf >= 0 ? c.theta[10 + tid] : c.theta[10 + tid] + c.rw_sigma * z[tid]);
   }
   if (c.n_pose > 0 && tid == 0) {
-    // The step's pose: the chain's current one — or, for a pose walk, the current one with ONE parameter moved by σ·z₀
-    // (PoseProposals.scala:39-41, :72-74).  The rotation matrix from include/icp_sincos.h: the bits the host's pose_from_theta and the
-    // oracle's orc_rotation_matrix give for these angles.  It goes where the step's kernels read it: the instance (launch 1) and the
-    // correspondences' inverse rigid transform (launch 3).
-    double th[10];
-    for (int k = 0; k < 10; ++k) th[k] = c.theta[k];
-    if (pose_leaf >= 0) th[c.pose_index[pose_leaf]] = th[c.pose_index[pose_leaf]] + c.pose_sigma[pose_leaf] * z[0];
-    for (int k = 0; k < 10; ++k) c.prop_pose[k] = th[k];
-    Pose P;
-    icp_rotation_matrix(th[4], th[5], th[6], P.R);
-    for (int d = 0; d < 3; ++d) { P.t[d] = th[1 + d]; P.ctr[d] = th[7 + d]; }
-    P.s = th[0];
+    // the step's pose goes where its kernels read it: the instance (launch 1) and the correspondences' inverse rigid transform (launch 3)
+    const Pose P = mh_step_pose(c, pose_leaf, z[0]);
     b.pose = P;
     c.search_live->corr[0].pose = P;
     c.search_live->corr[1].pose = P;
@@ -691,6 +697,38 @@ __global__ void __launch_bounds__(64) k_mh_front(MhChain* __restrict__ chains) {
   MhChain& c = chains[blockIdx.x];
   if (c.error) return;
   mh_front_body(c, threadIdx.x);
+}
+
+// … of a chain that takes the wide step (MhWide): its launch records are the same every step but for the proposal's inputs (W1) and the
+// proposed state's pose (W2's instance, the correspondences of W5 / W7).  A pose walk's instance is made from the coefficients like any
+// other (the operations of the kept deformations: bit-identical points).  Ranks up to 256.
+__global__ void __launch_bounds__(64) k_mhw_front(MhChain* __restrict__ chains) {
+  MhChain& c = chains[blockIdx.x];
+  if (c.error) return;
+  const int tid = threadIdx.x, r = c.r;
+  MhWide& w = *c.wide;
+  __shared__ int s_gen, s_pose_leaf;
+  if (tid == 0) mh_draw(c, &s_gen, &s_pose_leaf);
+  __syncthreads();
+  const int gen = s_gen, pose_leaf = s_pose_leaf;
+  const double* z = c.normals + (size_t)(c.step - c.normals_first) * r;
+  if (tid == 0) {
+    WideProposeItem& it = *w.item;
+    it.kind = gen >= 0 ? 1 : 0;
+    if (gen >= 0) {  // ICP: posterior.sample()'s standard normals (NonRigidIcpProposal.scala:55)
+      ProposeIn in = w.prop_in[gen];
+      in.z = z;
+      it.in = in;
+    }
+    it.src = w.given;
+  }
+  // shape walk: the sample itself, c + σ·z (RandomShapeUpdateProposal.scala:31-35); pose walk: the coefficients stay
+  for (int j = tid; j < r; j += 64) w.given[j] = pose_leaf >= 0 ? c.theta[10 + j] : c.theta[10 + j] + c.rw_sigma * z[j];
+  if (c.n_pose > 0 && tid == 0) {
+    const Pose P = mh_step_pose(c, pose_leaf, z[0]);
+    w.inst->pose = P;
+    for (int k = 0; k < 2; ++k) { w.search[k]->corr[0].pose = P; w.search[k]->corr[1].pose = P; }
+  }
 }
 
 // tail of a step: MetropolisHastings.next with the device results.  One wave per chain: lane j holds coefficient j of the proposed and
@@ -705,10 +743,11 @@ __device__ __forceinline__ double mh_bcast(double v, int lane) {
 // decomposition records, which an accepted step switches to — is requested up front, behind the chain record's own words (two trips);
 // the outcome then only selects what is stored.  The arguments of the next step are written once, with the step's own entries
 // (propose / prop / zin) already in them; a rejected step, whose live arguments are those of its set already, writes only those.
-__global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) {
+// kWide: a chain of the wide step (MhWide) — NS coefficients per lane (ranks up to 64·NS), the full-mesh Hausdorff evaluator as well, the
+// next step's head left to k_mhw_front; its records do not change with the outcome (k_mhw_adopt moves the accepted posterior instead).
+template <int NS, bool kWide>
+__device__ __forceinline__ void mh_decide_body(MhChain& c) {
   typedef unsigned long long u64;
-  MhChain& c = chains[blockIdx.x];
-  if (c.error) return;
   const int lane = threadIdx.x;
   const int r = c.r, P = 10 + r, n_icp = c.n_icp, cur_sel = c.cur_sel, other = cur_sel ^ 1;
   const long long step = c.step;
@@ -716,7 +755,7 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   const double cur_p = c.cur_p, rw_sigma = c.rw_sigma;
   const double ninf = -__builtin_inf();
   // (uniform) the next step's normals are on the device — and its head is not k_mh_front's business (mixtures with pose walks)
-  const bool has_next = !c.front_every_step && step + 1 - c.normals_first < (long long)c.normals_rows;
+  const bool has_next = !kWide && !c.front_every_step && step + 1 - c.normals_first < (long long)c.normals_rows;
   const int pose_move = c.pose_move, leaf_now = c.leaf;
   // the NEXT step's mixture draw (MixtureProposal.propose, as mh_front_body): an integer hash of the step number
   int gen_n = -1, leaf_n = 2;
@@ -725,11 +764,18 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
     if (c.outer_kind[o] == 1) { gen_n = mh_pick(n_icp, c.icp_w, mh_uniform(seed, (u64)(step + 1), 1)); leaf_n = gen_n; }
   }
   // ---- the step's results and the chain's state
-  const double cpj = lane < r ? c.coeff_prop[lane] : 0.0;   // proposed coefficients (launch 1's copy in the state slot)
-  const double thj = lane < r ? c.theta[10 + lane] : 0.0;   // current ones
+  double cpj[NS], thj[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    cpj[s] = lane + 64 * s < r ? c.coeff_prop[lane + 64 * s] : 0.0;   // proposed coefficients (launch 1's copy in the state slot)
+    thj[s] = lane + 64 * s < r ? c.theta[10 + lane + 64 * s] : 0.0;   // current ones
+  }
   const double thp = lane < 10 ? c.theta[lane] : 0.0;       // the current pose …
   const double thq = lane < 10 ? (c.n_pose > 0 ? c.prop_pose[lane] : thp) : 0.0;  // … and the proposed state's (a pose walk moves one of its parameters)
-  const int st_chol = lane < n_icp ? c.chol_status[lane] : 0;
+  int st_chol = 0;
+  if (lane < n_icp) {
+    if constexpr (kWide) st_chol = c.wide->chol[lane][0]; else st_chol = c.chol_status[lane];
+  }
   const int st_tail = lane < 2 * n_icp ? c.tail_status[lane] : 0;
   const double resv = lane < 8 ? c.red[lane] : 0.0;
   const double tlv = lane < 2 * n_icp ? c.tails[lane] : 0.0;
@@ -790,12 +836,14 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   if (__ballot(st_eig != 0) && !err) err = 6;
   // ---- evaluators: ModelPriorEvaluator (:24-31), the likelihood from launch 4's reductions (finish_eval), ProductEvaluator
   double nn = 0.0, dd = 0.0, dd_b = 0.0;
-  for (int j = 0; j < r; ++j) {
-    const double cj = mh_bcast(cpj, j), tj = mh_bcast(thj, j);
-    nn += cj * cj;
-    const double d = cj - tj; dd += d * d;        // RandomShapeUpdateProposal.scala:37-45, to − from
-    const double e = tj - cj; dd_b += e * e;      // … and the other way
-  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    for (int j = 0; j < 64 && 64 * s + j < r; ++j) {
+      const double cj = mh_bcast(cpj[s], j), tj = mh_bcast(thj[s], j);
+      nn += cj * cj;
+      const double d = cj - tj; dd += d * d;        // RandomShapeUpdateProposal.scala:37-45, to − from
+      const double e = tj - cj; dd_b += e * e;      // … and the other way
+    }
   const double prior = -0.5 * nn - c.prior_c;
   double res[8];
 #pragma unroll
@@ -804,7 +852,10 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   if (c.eval_kind == 0) {  // IndependentPointDistanceEvaluator.scala:60-64
     const double m2t = res[0], t2m = res[4];
     lik = c.eval_mode == 0 ? m2t : c.eval_mode == 1 ? t2m : 0.5 * m2t + 0.5 * t2m;
-  } else {                 // CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:66-78 (closed target)
+  } else if (kWide && c.eval_kind == 1) {  // HausdorffDistanceEvaluator.scala:33-34 (finish_eval)
+    const double hd = res[1] > res[5] ? res[1] : res[5];
+    lik = -c.exp_rate * hd + c.exp_lograte;
+  } else {                 // CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:66-78 (on an open target: the reductions drop the flagged ids)
     const double a0 = res[0] / res[2], h0 = res[1], a1 = res[4] / res[6], h1 = res[5];
     double a, h;
     bool empty;
@@ -865,13 +916,17 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   // ---- state, record (host/icp_host.h: [index, status, leaf, log value of the state after the step, theta])
   const double new_p = acc ? prop_p : cur_p;
   const int new_sel = acc ? other : cur_sel;
-  if (acc && lane < r) c.theta[10 + lane] = cpj;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (acc && lane + 64 * s < r) c.theta[10 + lane + 64 * s] = cpj[s];
   if (acc && pose_move && lane < 10) c.theta[lane] = thq;
   if (c.records) {
     double* rec = c.records + (size_t)(step - c.rec_first) * (4 + P);
     if (lane == 0) { rec[0] = (double)step; rec[1] = acc ? 1.0 : 0.0; rec[2] = (double)leaf_now; rec[3] = new_p; }
     if (lane < 10) rec[4 + lane] = acc ? thq : thp;
-    if (lane < r) rec[14 + lane] = acc ? cpj : thj;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (lane + 64 * s < r) rec[14 + lane + 64 * s] = acc ? cpj[s] : thj[s];
   }
   // ---- the KL bases of an accepted state's posteriors (both directions), as icp_chain_step_batched starts them
   {
@@ -898,7 +953,7 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
     if (lane == 0) { c.gen = gen_n; c.leaf = leaf_n; }
     // ICP: posterior.sample()'s standard normals (NonRigidIcpProposal.scala:55); shape walk: the sample itself, c + σ·z
     // (RandomShapeUpdateProposal.scala:31-35)
-    const double zval = gen_n >= 0 ? zn : (acc ? cpj : thj) + rw_sigma * zn;
+    const double zval = gen_n >= 0 ? zn : (acc ? cpj[0] : thj[0]) + rw_sigma * zn;
     const int pbase = (gen_n >= 0 ? new_sel : 2 + new_sel) * kWP;  // where this step's proposal inputs sit among the lanes
     u64* db = (u64*)c.begin_live;
 #pragma unroll
@@ -927,6 +982,40 @@ __global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) 
   }
 }
 
+__global__ void __launch_bounds__(64) k_mh_decide(MhChain* __restrict__ chains) {
+  MhChain& c = chains[blockIdx.x];
+  if (c.error) return;
+  mh_decide_body<1, false>(c);
+}
+template <int NS>
+__global__ void __launch_bounds__(64) k_mhw_decide(MhChain* __restrict__ chains) {
+  MhChain& c = chains[blockIdx.x];
+  if (c.error) return;
+  mh_decide_body<NS, true>(c);
+}
+// an accepted state's posterior becomes the current state's: M, alpha and the coefficients of the proposed state's entry are copied
+// into the current state's (record q of the launch; skip[q] != 0: the chain did not move).  r² + 2r doubles — 0.3 MB at rank 200.
+__global__ void __launch_bounds__(256) k_mhw_adopt(int r, const MhAdopt* __restrict__ records, const int* __restrict__ skip) {
+  const int q = blockIdx.y;
+  if (skip[q] != 0) return;
+  const MhAdopt a = records[q];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < r * r) a.M_to[e] = a.M_from[e];
+  if (e < r) { a.alpha_to[e] = a.alpha_from[e]; a.c_to[e] = a.c_from[e]; }
+  if (a.V_from) {
+    if (e < r * r) { a.V_to[e] = a.V_from[e]; a.Vt_to[e] = a.Vt_from[e]; }
+    if (e < r) a.S_to[e] = a.S_from[e];
+    if (e == 0) a.st_to[0] = a.st_from[0];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int nb = a.corr_bytes[k], nw = nb >> 3;
+    if (e < nw) ((unsigned long long*)a.corr_to[k])[e] = ((const unsigned long long*)a.corr_from[k])[e];
+    if (e == nw)
+      for (int t = 8 * nw; t < nb; ++t) a.corr_to[k][t] = a.corr_from[k][t];
+  }
+}
+
 // a block of standard normals has arrived: chain b's rows start at base + b·stride, row 0 = the run's step `offset`
 __global__ void k_mh_set_normals(MhChain* __restrict__ chains, int B, const double* base, int stride, int offset, int rows) {
   const int b = blockIdx.x * 64 + threadIdx.x;
@@ -943,6 +1032,18 @@ void launch_mh_front(hipStream_t st, int B, MhChain* chains) {
 }
 void launch_mh_decide(hipStream_t st, int B, MhChain* chains) {
   if (B > 0) hipLaunchKernelGGL(k_mh_decide, dim3(B), dim3(64), 0, st, chains);
+}
+void launch_mhw_front(hipStream_t st, int B, MhChain* chains) {
+  if (B > 0) hipLaunchKernelGGL(k_mhw_front, dim3(B), dim3(64), 0, st, chains);
+}
+void launch_mhw_decide(hipStream_t st, int B, int r, MhChain* chains) {
+  if (B <= 0) return;
+  if (r <= 64) hipLaunchKernelGGL(k_mhw_decide<1>, dim3(B), dim3(64), 0, st, chains);
+  else if (r <= 128) hipLaunchKernelGGL(k_mhw_decide<2>, dim3(B), dim3(64), 0, st, chains);
+  else hipLaunchKernelGGL(k_mhw_decide<4>, dim3(B), dim3(64), 0, st, chains);
+}
+void launch_mhw_adopt(hipStream_t st, int r, int n, const MhAdopt* records, const int* skip) {
+  if (n > 0) hipLaunchKernelGGL(k_mhw_adopt, dim3((r * r + 255) / 256, n), dim3(256), 0, st, r, records, skip);
 }
 
 size_t step_batch_bytes(int B) {

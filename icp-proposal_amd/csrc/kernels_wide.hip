@@ -36,6 +36,23 @@ __global__ void __launch_bounds__(NT) k_wide_propose(int r, WideProposeArgs a, i
   }
 }
 
+// … from records in device memory (the on-device loop: k_mhw_front sets kind / in / src per step)
+template <int NT>
+__global__ void __launch_bounds__(NT) k_wide_propose_resident(int r, const WideProposeItem* __restrict__ items, int tpr_log2) {
+  __shared__ double s_c[512];
+  const WideProposeItem& it = items[blockIdx.x];
+  if (it.kind == 1) {
+    propose_body<true>(r, it.in, s_c, tpr_log2);
+  } else {
+    for (int j = threadIdx.x; j < r; j += NT) s_c[j] = it.src[j];
+    __syncthreads();
+  }
+  for (int j = threadIdx.x; j < r; j += NT) {
+    const double c = s_c[j];
+    for (int o = 0; o < it.n_out; ++o) it.out[o][j] = c;
+  }
+}
+
 // ---------------------------------------------------------------- W2: instances of up to G chains from ONE pass over the basis
 // x_b = pose_b(x̄ + μ + Q c_b) for the chains b of a group: thread = model point, the 3·r basis values of the point are fetched once
 // and multiplied with every chain's coefficients (LDS), each chain's sums in basis order with separately rounded multiply and add —
@@ -331,6 +348,14 @@ void launch_wide_propose(hipStream_t st, int r, const WideProposeArgs& a) {
   else hipLaunchKernelGGL(k_wide_propose<256>, dim3(a.n), dim3(256), 0, st, r, a, matvec_tpr_log2(r, 256));
 }
 
+void launch_wide_propose_resident(hipStream_t st, int r, int n, const WideProposeItem* items) {
+  if (n <= 0) return;
+  ProfScope _ps(st, KID_PROPOSE);
+  // (launch_wide_propose's choice for the KL-basis sampler — and for the Cholesky-root sampler up to rank 64)
+  if (r > 134) hipLaunchKernelGGL(k_wide_propose_resident<1024>, dim3(n), dim3(1024), 0, st, r, items, 4);
+  else hipLaunchKernelGGL(k_wide_propose_resident<256>, dim3(n), dim3(256), 0, st, r, items, matvec_tpr_log2(r, 256));
+}
+
 size_t wide_batch_bytes(int B) {
   return up16(sizeof(WideInstArgs) * B) + up16(sizeof(WidePrepArgs) * B) + 4 * up16(sizeof(StepSearchArgs) * B) + 2 * up16(sizeof(WideRegArgs) * B);
 }
@@ -350,12 +375,15 @@ WideOffsets wide_offsets(int B) {
 }
 }  // namespace
 
-void launch_wide_head(hipStream_t st, const WideLaunchPlan& plan, const WideChainArgs* chains, void* pinned, void* device) {
-  const int B = plan.B;
-  if (B <= 0) return;
+WideInstArgs* wide_inst_record(void* block, int B, int b) { (void)B; return (WideInstArgs*)block + b; }
+StepSearchArgs* wide_search_record(void* block, int B, int stage, int b) {
   const WideOffsets o = wide_offsets(B);
-  char* h = (char*)pinned;
-  char* d = (char*)device;
+  return (StepSearchArgs*)((char*)block + (stage == 0 ? o.s1 : o.s2)) + b;
+}
+
+void wide_pack_args(int B, const WideChainArgs* chains, void* dst) {
+  const WideOffsets o = wide_offsets(B);
+  char* h = (char*)dst;
   for (int b = 0; b < B; ++b) {
     ((WideInstArgs*)h)[b] = chains[b].inst;
     ((WidePrepArgs*)(h + o.prep))[b] = chains[b].prep;
@@ -366,8 +394,22 @@ void launch_wide_head(hipStream_t st, const WideLaunchPlan& plan, const WideChai
     ((StepSearchArgs*)(h + o.s2b))[b] = chains[b].s2b;
     ((WideRegArgs*)(h + o.regb))[b] = chains[b].regb;
   }
-  const int n16 = (int)(o.total / 16);
-  hipLaunchKernelGGL(k_wide_args, dim3(cdiv(n16, 256)), dim3(256), 0, st, (const uint4*)h, (uint4*)d, n16);
+}
+
+void launch_wide_head(hipStream_t st, const WideLaunchPlan& plan, const WideChainArgs* chains, void* pinned, void* device) {
+  const int B = plan.B;
+  if (B <= 0) return;
+  wide_pack_args(B, chains, pinned);
+  const int n16 = (int)(wide_offsets(B).total / 16);
+  hipLaunchKernelGGL(k_wide_args, dim3(cdiv(n16, 256)), dim3(256), 0, st, (const uint4*)pinned, (uint4*)device, n16);
+  launch_wide_head_resident(st, plan, device);
+}
+
+void launch_wide_head_resident(hipStream_t st, const WideLaunchPlan& plan, void* device) {
+  const int B = plan.B;
+  if (B <= 0) return;
+  const WideOffsets o = wide_offsets(B);
+  char* d = (char*)device;
   {
     ProfScope _ps(st, KID_INSTANCE);
     const dim3 block(kWideInstBlock);

@@ -478,10 +478,20 @@ static int run_on_device(icp_host_chain* const* chains, int32_t n_chains, int32_
   // device whatever its size (launches 1-5, the decide kernel, the decompositions of the chains that moved), which two groups overlap:
   // 64 chains ≈ 200k it/s against ≈ 150k host-stepped, 128 chains ≈ 245k, 32 chains 128k against 113k; 16 chains 75k against 74k, 8 chains
   // 41k against 43k (the host-stepped form lets every chain's first launch wait for its own decomposition only)
+  // Chains of the five merged launches ABOVE rank 64 (apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala at rank 101) take the
+  // loop from two chains on: host-stepped, each of their steps waits for a decomposition the batch cannot start ahead (3 chains at rank
+  // 100: 3.7k it/s in the loop, 2.5k host-stepped; 24 chains 7.3k against 5.0k — tools/r5_wide_loop.py).  Chains of the wide step (open
+  // targets, rank 200): 30 chains 1.7 ms per step in the loop against 2.0 host-stepped, 10 chains 5.2k it/s against 6.8k — from 24 on.
   static const int mode = std::getenv("ICP_HOST_DEVICE_LOOP") ? std::atoi(std::getenv("ICP_HOST_DEVICE_LOOP")) : -1;
-  if (mode == 0 || (mode < 0 && n_chains < 24)) return ICP_ERR_INVALID_ARG;
   icp_host_chain* c0 = chains[0];
   if (!c0) return ICP_ERR_INVALID_ARG;
+  int from = 24;
+  if (mode < 0 && c0->r > 64 && !c0->icp.empty()) {
+    std::vector<icp_proposal*> hs;
+    for (auto* p : c0->icp) hs.push_back(p->h);
+    if (icp_chain_step_path(c0->likelihood->h, (int)hs.size(), hs.data()) == 0) from = 2;
+  }
+  if (mode == 0 || (mode < 0 && n_chains < from)) return ICP_ERR_INVALID_ARG;
   const size_t n_icp = c0->icp.size();
   for (int b = 0; b < n_chains; ++b) {
     icp_host_chain* ch = chains[b];

@@ -140,6 +140,12 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
         # 4,765 with 20, 3,560 with 30).
         per_target = 3 if n_steps >= 150 else 2 if n_steps >= 30 else 1
         chains_per_launch = max(1, min(32, per_target * n_chains))
+        # … in submissions of EQUAL size (100 items: 4 x 25, not 3 x 30 + 10): from 24 chains on a submission of wide-step chains runs
+        # as the on-device loop (icp_chains_run_on_device: 1.7 ms per step of 30 face chains against 2.0 host-stepped), a remainder of 10
+        # would be stepped by the host at 6.8k it/s
+        if len(mine) > chains_per_launch:
+            n_sub = -(-len(mine) // chains_per_launch)
+            chains_per_launch = -(-len(mine) // n_sub)
     t_start = time.perf_counter()
     phase = dict(contexts=0.0, set_target=0.0, setups=0.0, chains=0.0, steps=0.0, close=0.0)  # where a rank's wall time goes (seconds)
     my_targets = sorted(set(items[k][0] for k in mine))
