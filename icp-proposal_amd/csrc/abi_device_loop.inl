@@ -16,6 +16,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
     icp_proposal* props[2] = {nullptr, nullptr};
     PosteriorEntry* cur[2] = {nullptr, nullptr};
     bool busy = false;
+    bool unfilled = false;  // the current state's posteriors are not on record: filled by the run's first pass
   };
   struct Group {
     int b0 = 0, B = 0;
@@ -122,11 +123,18 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
       for (int i = 0; i < n_props; ++i) {
         icp_proposal* p = ch.props[i];
         p->resolve_speculation(theta[b]);
+        // Above rank 64 a state whose posterior is not on record is NOT computed here, chain after chain the per-stage way (2.5 ms each
+        // at rank 200): the captured step gets an empty entry for it, and one pass of the run's own launches fills the entries of all
+        // chains at once (below: "restate")
+        if (!jacobi && !p->find_entry(theta[b])) { ch.unfilled = true; continue; }
         PosteriorEntry& cur = p->posterior(theta[b], false);
         p->ensure_eigen(cur);
         cur.reserved = true;
         ch.cur[i] = &cur;
       }
+      if (ch.unfilled)
+        for (int i = 0; i < n_props; ++i)
+          if (ch.cur[i]) { ch.cur[i]->reserved = false; ch.cur[i] = nullptr; }  // (all of the chain's entries the same way)
     }
     // (… every chain's work is on its own streams by now, side by side: waited for and looked at chain by chain)
     for (int b = 0; b < n_chains; ++b) {
@@ -137,6 +145,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
       HIP_OK(hipStreamSynchronize(c.stream));
       c.front_stream.sync();
       sync_eigen(c);
+      if (ch.unfilled) continue;
       for (int i = 0; i < n_props; ++i) sync_proposal_status(ch.props[i]);
       HIP_OK(hipStreamSynchronize(c.stream));
       for (int i = 0; i < n_props; ++i) {
@@ -195,6 +204,11 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
         locks.emplace_back(ch.e->ctx->mu);
       }
       icp_ctx& glead = *chains[gr.b0].e->ctx;
+      for (int k = 0; k < B; ++k)  // (entries of a chain that is filled below: not to be handed out as another's proposed-state entry)
+        if (chains[gr.b0 + k].unfilled)
+          for (int i = 0; i < n_props; ++i)
+            if (PosteriorEntry* en = chains[gr.b0 + k].props[i]->find_entry(theta[gr.b0 + k])) { en->valid = false; en->eig_valid = false; }
+      gr.cap.allow_unfilled = !jacobi;
       wide_issue(t, glead, glead, &gr.cap);
       WideCapture& cap = gr.cap;
       phase("capture");
@@ -204,7 +218,8 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
         Chain& ch = chains[gr.b0 + k];
         WideItem& w = t.items[k].W;
         for (int i = 0; i < n_props; ++i) {
-          require(w.ec[i] == ch.cur[i] && w.ep[i] && w.ep[i] != w.ec[i], "internal: captured wide step lost the current state's posterior");
+          if (ch.unfilled) ch.cur[i] = w.ec[i];
+          require(w.ec[i] && w.ec[i] == ch.cur[i] && w.ep[i] && w.ep[i] != w.ec[i], "internal: captured wide step lost the current state's posterior");
           ch.cur[i]->reserved = true;
         }
         ch.e->ctx->batch_busy = true;
@@ -369,6 +384,42 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
       HIP_OK(hipMemcpy(gr.mh.p, hm.data(), sizeof(MhChain) * hm.size(), hipMemcpyHostToDevice));
       HIP_OK(hipStreamSynchronize(nullptr));
       phase("records");
+      // -- "restate": the current states' posteriors and bases of a group with unfilled entries, by the step's own launches — the
+      // proposal is the current state itself, its posterior lands in the proposed state's entries, is decomposed there and handed over
+      // like an accepted state's (every chain of the group: the values of an entry that was on record are computed again, the same)
+      if (cap.any_unfilled) {
+        const hipStream_t S = gr.st;
+        const int nq = B * n_props;
+        launch_mhw_front(S, B, gr.mh.p, 1);
+        launch_wide_propose_resident(S, r, B, gr.items.p);
+        launch_wide_head_resident(S, cap.plan, gr.wide_dev.p);
+        launch_wide_main(S, cap.plan, gr.wide_dev.p);
+        for (size_t p0 = 0; p0 < cap.sum_parts.size(); p0 += kWideMaxChains)
+          launch_sum_partials_many(S, r, (int)std::min<size_t>(kWideMaxChains, cap.sum_parts.size() - p0), cap.sum_parts.data() + p0, cap.sum_splits.data() + p0);
+        HIP_OK(hipEventRecord(gr.ev_sum, S));
+        int used = 0;
+        for (int q0 = 0; q0 < nq; q0 += 16, ++used) {
+          const hipStream_t E = gr.side[1 + (used & 1)];
+          if (used < 2) HIP_OK(hipStreamWaitEvent(E, gr.ev_sum, 0));
+          launch_posterior_eigen_tridiag_many(E, r, std::min(16, nq - q0), gr.rqs.data() + q0, gr.spec_parts.data() + q0, nullptr);
+        }
+        for (int u = 0; u < std::min(used, 2); ++u) HIP_OK(hipEventRecord(gr.ev_eig[u], gr.side[1 + u]));
+        const size_t fmax0 = (size_t)posterior_factor_max();
+        for (size_t p0 = 0; p0 < cap.factors.size(); p0 += fmax0)
+          launch_posterior_factor(S, r, (int)std::min(fmax0, cap.factors.size() - p0), cap.factors.data() + p0);
+        for (int u = 0; u < std::min(used, 2); ++u) HIP_OK(hipStreamWaitEvent(S, gr.ev_eig[u], 0));
+        launch_mhw_adopt(S, r, nq, gr.adopt.p, nullptr);
+        HIP_OK(hipStreamSynchronize(S));
+        // the factorisations' and decompositions' status words, as the per-stage path would have looked at them
+        for (int k = 0; k < B; ++k)
+          for (int i = 0; i < n_props; ++i) {
+            int st[3] = {0, 0, 0};
+            HIP_OK(hipMemcpy(st, cap.factors[(size_t)k * n_props + i].status, sizeof(int) * 3, hipMemcpyDeviceToHost));
+            if (st[0] != 0) fail(ICP_ERR_NOT_SPD, "posterior matrix is not positive definite");
+            if (st[2] != 0) fail(ICP_ERR_NOT_FINITE, "posterior eigen-decomposition did not converge");
+          }
+        phase("restate (current states' posteriors, all chains at once)");
+      }
     }
     auto draw_block = [&](Group& gr, int blk, int buf) {
       const int s0 = blk * kChunk, ns = std::min(kChunk, n_steps - s0);

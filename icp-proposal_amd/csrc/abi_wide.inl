@@ -174,6 +174,9 @@ struct WideCapture {
   std::vector<double*> sum_parts; std::vector<int> sum_splits;
   std::vector<PosteriorFactorIO> factors;  // n_props per chain
   std::vector<TransitionTailIO> tails;     // 2·n_props per chain: fwd_0, bwd_0, fwd_1, bwd_1
+  // in: a current state whose posterior is not on record gets an EMPTY entry instead of being computed the per-stage way (2.5 ms per
+  // chain at rank 200, one chain after the other) — the caller fills it itself, for all chains at once (out: whether any chain has one)
+  bool allow_unfilled = false, any_unfilled = false;
 };
 
 void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead, WideCapture* capture = nullptr) {
@@ -261,14 +264,26 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead, WideCapture* 
     if (w.shape_only) {
       bool missing = false;
       for (int i = 0; i < n_props; ++i) missing = missing || !it.props[i]->find_entry(theta_cur);
-      for (int i = 0; i < n_props; ++i) ec[i] = &it.props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76 (the per-stage way if not on record)
+      for (int i = 0; i < n_props; ++i) {
+        if (capture && capture->allow_unfilled && !it.props[i]->find_entry(theta_cur)) {
+          PosteriorEntry& f = it.props[i]->fresh_entry();
+          f.valid = false; f.eig_valid = false; f.eig_checked = false; f.eig_event_valid = false; f.done_value = 0;
+          f.reserved = true;
+          ec[i] = &f;
+          capture->any_unfilled = true;
+          continue;
+        }
+        ec[i] = &it.props[i]->posterior(theta_cur, false);  // NonRigidIcpProposal.scala:54,76 (the per-stage way if not on record)
+      }
       if (missing || c.stream_used_elsewhere) { HIP_OK(hipStreamSynchronize(c.stream)); c.stream_used_elsewhere = false; c.stage_used = 0; }
       for (int i = 0; i < n_props; ++i) { ec[i]->reserved = true; }  // (not to be recycled for the proposed state's entries below)
     }
     if (generator >= 0) {
       icp_proposal* pg = it.props[generator];
       PosteriorEntry& g = *ec[generator];
-      if (!g.eig_valid) {
+      if (!g.eig_valid && capture && capture->allow_unfilled) {
+        // (decomposed by the caller: with the entry's posterior, if that is not on record, or ahead of the loop)
+      } else if (!g.eig_valid) {
         if (root_here) fail(ICP_ERR_DEVICE, "internal: a posterior of the Cholesky-root sampler without its factor");
         EigenRequest rq;
         pg->prepare_eigen(g, &rq);

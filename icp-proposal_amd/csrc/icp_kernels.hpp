@@ -519,7 +519,7 @@ void launch_mh_front(hipStream_t st, int B, MhChain* chains);
 void launch_mh_decide(hipStream_t st, int B, MhChain* chains);
 // the wide step's head and tail (ranks up to 256; every step's head by the front kernel); then, per posterior q of the launch (chain-major,
 // n_icp per chain), the proposed state's M, alpha and coefficients into the current state's entries where eig_skip[q] == 0
-void launch_mhw_front(hipStream_t st, int B, MhChain* chains);
+void launch_mhw_front(hipStream_t st, int B, MhChain* chains, int restate = 0 /* != 0: the "proposal" is the current state itself */);
 void launch_mhw_decide(hipStream_t st, int B, int r, MhChain* chains);
 struct MhAdopt {
   const double* M_from; double* M_to; const double* alpha_from; double* alpha_to; const double* c_from; double* c_to;
@@ -529,7 +529,7 @@ struct MhAdopt {
   // the correspondence records of the posterior (what icp_proposal_posterior hands out for the state)
   const unsigned char* corr_from[6]; unsigned char* corr_to[6]; int corr_bytes[6];
 };
-void launch_mhw_adopt(hipStream_t st, int r, int n, const MhAdopt* records, const int* skip);
+void launch_mhw_adopt(hipStream_t st, int r, int n, const MhAdopt* records, const int* skip /* null: every record */);
 // the five merged launches for B chains from DEVICE-RESIDENT argument arrays (no copy kernel, no gate: one stream, in order)
 void launch_step_batch_resident(hipStream_t st, int B, const int grid[5], int r, const StepBeginArgs* begin, const StepSearchArgs* search,
                                 const StepRegressionArgs* regression, const StepFinishArgs* finish, bool filter_prepared = false,

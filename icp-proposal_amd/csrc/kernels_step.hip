@@ -702,16 +702,21 @@ __global__ void __launch_bounds__(64) k_mh_front(MhChain* __restrict__ chains) {
 // … of a chain that takes the wide step (MhWide): its launch records are the same every step but for the proposal's inputs (W1) and the
 // proposed state's pose (W2's instance, the correspondences of W5 / W7).  A pose walk's instance is made from the coefficients like any
 // other (the operations of the kept deformations: bit-identical points).  Ranks up to 256.
-__global__ void __launch_bounds__(64) k_mhw_front(MhChain* __restrict__ chains) {
+// (restate != 0: no proposal — the "proposed" state is the chain's current one, whose posterior the launches behind this one then
+// compute into the proposed state's entries: how a run fills the current states' entries that were not on record, for all chains at once)
+__global__ void __launch_bounds__(64) k_mhw_front(MhChain* __restrict__ chains, int restate) {
   MhChain& c = chains[blockIdx.x];
   if (c.error) return;
   const int tid = threadIdx.x, r = c.r;
   MhWide& w = *c.wide;
   __shared__ int s_gen, s_pose_leaf;
-  if (tid == 0) mh_draw(c, &s_gen, &s_pose_leaf);
+  if (tid == 0) {
+    if (restate) { s_gen = -1; s_pose_leaf = -2; }
+    else mh_draw(c, &s_gen, &s_pose_leaf);
+  }
   __syncthreads();
-  const int gen = s_gen, pose_leaf = s_pose_leaf;
-  const double* z = c.normals + (size_t)(c.step - c.normals_first) * r;
+  const int gen = s_gen, pose_leaf = s_pose_leaf == -2 ? 0 : s_pose_leaf;  // (restate: the coefficients stay, as for a pose walk …
+  const double* z = restate ? c.theta : c.normals + (size_t)(c.step - c.normals_first) * r;  // (… never read as normals)
   if (tid == 0) {
     WideProposeItem& it = *w.item;
     it.kind = gen >= 0 ? 1 : 0;
@@ -725,7 +730,7 @@ __global__ void __launch_bounds__(64) k_mhw_front(MhChain* __restrict__ chains) 
   // shape walk: the sample itself, c + σ·z (RandomShapeUpdateProposal.scala:31-35); pose walk: the coefficients stay
   for (int j = tid; j < r; j += 64) w.given[j] = pose_leaf >= 0 ? c.theta[10 + j] : c.theta[10 + j] + c.rw_sigma * z[j];
   if (c.n_pose > 0 && tid == 0) {
-    const Pose P = mh_step_pose(c, pose_leaf, z[0]);
+    const Pose P = mh_step_pose(c, restate ? -1 : pose_leaf, z[0]);  // (… and so does the pose)
     w.inst->pose = P;
     for (int k = 0; k < 2; ++k) { w.search[k]->corr[0].pose = P; w.search[k]->corr[1].pose = P; }
   }
@@ -997,7 +1002,7 @@ __global__ void __launch_bounds__(64) k_mhw_decide(MhChain* __restrict__ chains)
 // into the current state's (record q of the launch; skip[q] != 0: the chain did not move).  r² + 2r doubles — 0.3 MB at rank 200.
 __global__ void __launch_bounds__(256) k_mhw_adopt(int r, const MhAdopt* __restrict__ records, const int* __restrict__ skip) {
   const int q = blockIdx.y;
-  if (skip[q] != 0) return;
+  if (skip && skip[q] != 0) return;
   const MhAdopt a = records[q];
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < r * r) a.M_to[e] = a.M_from[e];
@@ -1033,8 +1038,8 @@ void launch_mh_front(hipStream_t st, int B, MhChain* chains) {
 void launch_mh_decide(hipStream_t st, int B, MhChain* chains) {
   if (B > 0) hipLaunchKernelGGL(k_mh_decide, dim3(B), dim3(64), 0, st, chains);
 }
-void launch_mhw_front(hipStream_t st, int B, MhChain* chains) {
-  if (B > 0) hipLaunchKernelGGL(k_mhw_front, dim3(B), dim3(64), 0, st, chains);
+void launch_mhw_front(hipStream_t st, int B, MhChain* chains, int restate) {
+  if (B > 0) hipLaunchKernelGGL(k_mhw_front, dim3(B), dim3(64), 0, st, chains, restate);
 }
 void launch_mhw_decide(hipStream_t st, int B, int r, MhChain* chains) {
   if (B <= 0) return;

@@ -343,9 +343,17 @@ ICP_API int icp_chain_step_batched_abandon(icp_step_ticket *ticket);
  *   stream (seeds[b], step, lane), steps first_step[b] .. first_step[b] + n_steps − 1.
  *   theta[b] (in/out): the chain's current state; log_value[b] (in/out): its product log value (as MetropolisHastings carries it).
  *   records[b] (may be NULL): n_steps rows [index, accepted, leaf id (0/1 ICP proposal, 2 shape walk, 3..8 pose walks), log value, theta].
- * Covered: what the merged launches cover (closed target or no boundary-aware branch, ranks <= 64, one context per chain, one
- * device); otherwise ICP_ERR_INVALID_ARG and nothing has run.  Results are those of icp_chain_step_batched driven by the harness,
- * chain by chain (tests/test_gpu_chain.py::test_device_loop_*). */
+ * Covered (one context per chain, one device, one rank and sampler per run; otherwise ICP_ERR_INVALID_ARG and nothing has run):
+ *   - what the five merged launches cover at ranks <= 64 (closed target or no boundary-aware branch): their launches, from
+ *     device-resident records that change roles when a state is accepted;
+ *   - (round 5) everything the WIDE step covers — targets with a boundary, the full-mesh Hausdorff evaluator, ranks up to 200, the femur
+ *     mixture at ranks 65..116 (apps/bfm/BfmFittingPartial.scala:62-96, apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala) — with
+ *     the chains of a run sharing one model: the wide step's own launches replayed from device-resident records, an accepted state's
+ *     posterior copied into the current state's entries; above rank 64 the proposed state is decomposed ahead of the decision, beside
+ *     the factorisation and the evaluator's searches (KL-basis sampler; the Cholesky-root sampler up to rank 64).
+ * Results are those of icp_chain_step_batched driven by the harness, chain by chain — bit for bit, except that the warm-started
+ * Jacobi iteration of a wide step at ranks <= 64 starts from another basis than the host-stepped one's (states equal to 1e-11)
+ * (tests/test_gpu_chain.py::test_device_loop_*, tests/test_gpu_wide_loop.py). */
 typedef struct {
   /* = sizeof(icp_mh_mixture) of the header the caller was compiled against; anything else is refused with ICP_ERR_INVALID_ARG (the
    * structure grew in round 4: a caller built against the shorter one must not have its memory read past its end) */

@@ -17,6 +17,10 @@ def child(kind, B, n, out):
         model = pkg.data.synthetic_face_model(grid=41, rank=200)
         target = pkg.data.synthetic_partial_target(model, n_remove=90, seed=7)
         mk = lambda: pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2)
+    elif kind == "facefull":   # configs[3] / configs[4] size: N = 28,561, rank 200
+        model = pkg.data.synthetic_face_model()
+        target = pkg.data.synthetic_partial_target(model, seed=100)
+        mk = lambda: pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2)
     elif kind == "hausdorff":
         model = pkg.data.synthetic_face_model(grid=41, rank=100)
         target = pkg.data.synthetic_partial_target(model, n_remove=90, seed=7)
