@@ -878,7 +878,10 @@ struct TriSolveLds {  // the solve launch's dynamic LDS (doubles): offsets for a
 };
 inline size_t tri_solve_lds_bytes(int n) { return sizeof(double) * (size_t)TriSolveLds(n).total; }
 
-template <int SI>
+// kBack: the back-transformation inside this launch, eigenvector by eigenvector (one row slot per lane: ranks <= 64, where the launch's
+// last wave also publishes the completion words).  Otherwise the wave hands the tridiagonal matrix's eigenvector on as row j of Vt, and
+// k_tri_back — sixteen vectors per wave on the matrix cores — takes it from there.
+template <int SI, bool kBack>
 __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
   constexpr int LD = 64 * SI;
   const int off = LD - a.n;  // position of index 0 (see tridiagonalise)
@@ -908,6 +911,7 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     if (l == 0) last = atomicAdd(a.sync, 1) == a.n - 1;
     if (last) {
       a.sync[0] = 0; a.sync[1] = 0; a.sync[2] = 0;
+      a.sync[4] = 1;  // (no vectors: k_tri_back has nothing to do)
       if (skip == 2) {  // timed out: tell the host, and mark the basis that was never written so that nothing starts from it
         if (a.host_status) __hip_atomic_store(a.host_status, 3 /* kEigenGaveUp */, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         a.V[0] = __builtin_nan("");
@@ -1082,6 +1086,14 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     if (round + 1 < kTriRounds) wave_lds_sync();
   }
   TRI_STAMP(11);
+  const double muj = lam * anorm;
+  if constexpr (!kBack) {
+    // the vector of T, normalised, as row j of Vt (contiguous); back-transformation, sign and the transposed copy: k_tri_back
+    const double sc = 1.0 / sqrt(znorm2);
+    for (int i = l; i < n; i += 64) a.Vt[(size_t)j * n + i] = zb[i] * sc;
+    if (!(muj > 0.0)) trouble = true;
+    if (l == 0) { a.S[j] = 1.0 / muj; a.mu[j] = muj; }
+  } else {
   // ---- back-transformation: z ← H_0 H_1 ··· H_{n−3} z, one row slot per lane, reflectors fetched eight ahead
   double zs[SI];
   {
@@ -1160,7 +1172,6 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
   for (int s = 1; s < SI; ++s) lead = (bi >> 6) == s ? zs[s] : lead;
   lead = readlane_f64(lead, bi & 63);
   const double sgn = lead < 0.0 ? -1.0 : 1.0;
-  const double muj = lam * anorm;
   if (!(bv >= 0.0) || !(muj > 0.0)) trouble = true;
 #pragma unroll
   for (int s = 0; s < SI; ++s) {
@@ -1172,6 +1183,7 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     }
   }
   if (l == 0) { a.S[j] = 1.0 / muj; a.mu[j] = muj; }
+  }  // kBack
   TRI_STAMP(13);
   // ---- the last wave to finish checks that the eigenvalues are told apart and publishes the status
   __threadfence();
@@ -1202,13 +1214,14 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     // the refinement launches behind this one look at sync[3]: 0 = refine, 1 = every gap is wide enough for the vectors as they are
     // (hand X on as V), written anew by every solve launch
     a.sync[3] = (close || bad) ? 0 : 1;
+    a.sync[4] = 0;
     if (a.host_status) __hip_atomic_store(a.host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (a.done_word) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 template <int SI>
 __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1) {
-  tri_solve_body<SI>(blockIdx.y ? a1 : a0);  // (up to two decompositions side by side: the two ICP directions of a chain step)
+  tri_solve_body<SI, SI == 1>(blockIdx.y ? a1 : a0);  // (up to two decompositions side by side: the two ICP directions of a chain step)
 }
 struct TriSolveMany { TriSolveIO p[kTriMany]; };
 template <int SI>
@@ -1217,7 +1230,208 @@ __global__ void __launch_bounds__(256) k_tri_solve_many(TriSolveMany m, const in
   // (no s_setprio here: raised to 3 for the critical path's sake, beside the evaluator's searches of a 30-chain wide step the device
   // hung — measured once, not understood, not repeated)
   const TriSolveIO a = m.p[blockIdx.y];
-  tri_solve_body<SI>(a);
+  tri_solve_body<SI, SI == 1>(a);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Back-transformation on the matrix cores (round 5; ranks above 64): X = H_0 H_1 ··· H_{n−3} Z for SIXTEEN eigenvectors per wave.
+// The vectors sit in the wave's registers as 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4 (rows = positions of the
+// index space of tridiagonalise, columns = eigenvectors; tile t, register g of lane l: row 16t + (l >> 4) + 4g, column l & 15) —
+// which is also the layout of the B operand of a product's k-step (B[k = l >> 4][j = l & 15]: register g IS k-step g).  Per block of
+// eight reflectors, last block first:  U = V_bᵀ Z (four instructions per tile, A = the reflectors' entries straight from Hv),
+// W = T_b U (two), Z −= V_b W (two per tile).  An eigenvector at a time (tri_solve_body<·, true>) a block is eight inner products, a
+// wave reduction and eight updates per vector — 2,700 cycles; here ≈ 80 matrix instructions for sixteen vectors.  With 30 decompositions
+// side by side the solve launch is the chip's throughput kernel (6,000 eigenpair waves, 510 µs); a third of that was this.
+// Then the canonical sign (largest-|.| component positive, the first among equals), X and its transpose.
+typedef double tri_d4 __attribute__((ext_vector_type(4)));
+struct TriBackIO {
+  int n;
+  const double* Hv;   // [n][64·SI]
+  const double* wy;   // [ceil((n−2)/8)][64] T factors (k_tri_wy)
+  double* X;          // [n][n] out: eigenvectors in columns
+  double* Xt;         // [n][n] in: the tridiagonal matrix's eigenvectors in rows (the solve launch); out: the transpose of X
+  int* status;        // status[0] = 2 if a vector is not finite
+  int* sync;          // sync[4] != 0: the solve launch computed nothing
+};
+// A workgroup = four waves = SIXTEEN eigenvectors: wave w owns the row tiles t ≡ w (mod 4) of the sixteen — as the blocks proceed
+// (last block first) the reflectors reach further up, and the live tiles stay spread over the four waves — so that one decomposition
+// by itself is 4·⌈n/16⌉ waves at work, not ⌈n/16⌉ (v_mfma_f64_16x16x4 takes 64 cycles on gfx950: the f64 matrix peak is the vector
+// peak; one wave per sixteen vectors measured 90 µs at rank 200 where the eigenvector-at-a-time form takes 28).  Per block: every wave
+// multiplies its tiles into a partial U, the four partials meet in LDS (summed in wave order by everybody), W = T·U by every wave,
+// each updates its own tiles.  A block's eight reflectors (and its T factor) are staged in LDS by all 256 threads — row stride LD + 4:
+// the two access patterns of the A operands then meet no more than two ways in a bank —, requested two blocks ahead.
+template <int SI> struct TriBackLds {
+  static constexpr int LD = 64 * SI, P = LD + 4;
+  static constexpr int oT = 2 * kWyBlock * P;      // [2][64] T factors
+  static constexpr int oU = oT + 2 * 64;           // [2][4 waves][4][64] partial products
+  static constexpr int doubles = oU + 2 * 4 * 256;
+};
+template <int SI>
+__device__ __forceinline__ void tri_back_body(const TriBackIO& a) {
+  constexpr int LD = 64 * SI, P = TriBackLds<SI>::P;
+  constexpr int PER = kWyBlock * LD / 256;  // staged entries per thread and block
+  __shared__ double s_v[TriBackLds<SI>::doubles];
+  double* s_t = s_v + TriBackLds<SI>::oT;
+  double* s_u = s_v + TriBackLds<SI>::oU;
+  const int n = a.n, off = LD - n;
+  const int tid = threadIdx.x, l = tid & 63, jl = l & 15, kq = l >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jc = blockIdx.x * 16 + jl;
+  if (__hip_atomic_load(a.sync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // (uniform per workgroup)
+  // this wave's tiles: t = 4·i + w, i < SI; rows 16t + (l >> 4) + 4g of the position space, the matrix from position `off` on
+  tri_d4 Z[SI];
+#pragma unroll
+  for (int i = 0; i < SI; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * (4 * i + w) + kq + 4 * g - off;
+      Z[i][g] = (row >= 0 && jc < n) ? a.Xt[(size_t)jc * n + row] : 0.0;
+    }
+  }
+  const int nblk = (n - 2 + kWyBlock - 1) / kWyBlock;
+  // staging: thread tid carries entries tid, tid + 256, … of a block's 8 x LD reflector entries (reflectors past the last one: a clamped
+  // row — their rows and columns of T are zero) and, the first 64 threads, one entry of its T factor.  The reflectors were written by
+  // ONE compute unit (the reduction): most workgroups fetch them through another XCD's L2, so a block's entries are requested TWO
+  // blocks ahead (three register sets in turn) and put into LDS one block ahead.
+  struct Stage { double v[PER]; double t; };
+  auto fetch = [&](Stage& st, int blk) {
+    const int b = max(blk, 0), k0 = b * kWyBlock;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + 256 * u, q = e / LD, pos = e - q * LD;
+      st.v[u] = a.Hv[(size_t)min(k0 + q, n - 3) * LD + pos];
+    }
+    st.t = a.wy[(size_t)b * kWyBlock * kWyBlock + (tid & 63)];
+  };
+  auto put = [&](const Stage& st, int blk) {
+    if (blk < 0) return;  // (uniform)
+    const int buf = blk & 1;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + 256 * u, q = e / LD, pos = e - q * LD;
+      s_v[(buf * kWyBlock + q) * P + pos] = st.v[u];
+    }
+    if (tid < 64) s_t[buf * 64 + tid] = st.t;
+  };
+  // one block: U's part, exchange, W, update.  `nxt`: the register set to put into LDS for the block after this one.
+  auto block = [&](int blk, const Stage& nxt) {
+    if (blk < 0) return;  // (uniform)
+    const int par = blk & 1;
+    const double* vb = s_v + par * kWyBlock * P;
+    const double* tb = s_t + par * 64;
+    const int tmin = (blk * kWyBlock + off + 1) >> 4;  // reflector k is zero at the positions up to k + off
+    // A operands: U's — lane (q = l & 15, k = l >> 4): entry 16t + 4s + k of reflector k0 + q (q < 8); the update's — lane (i = l & 15,
+    // k = l >> 4): entry 16t + i of reflector k0 + 4s + k; T's — lane (jj = l & 15, k): T[jj][4s + k]
+    const double qmask = jl < 8 ? 1.0 : 0.0;
+    const double* hq = vb + (jl & 7) * P + kq;
+    const double* hu0 = vb + kq * P + jl;
+    const double* hu1 = vb + (4 + kq) * P + jl;
+    double av[SI][4], uv[SI][2];
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+      const int t = 4 * i + w;
+#pragma unroll
+      for (int sgm = 0; sgm < 4; ++sgm) av[i][sgm] = hq[16 * t + 4 * sgm] * qmask;
+      uv[i][0] = -hu0[16 * t]; uv[i][1] = -hu1[16 * t];
+    }
+    const double ta0 = tb[(jl & 7) * kWyBlock + kq] * qmask, ta1 = tb[(jl & 7) * kWyBlock + 4 + kq] * qmask;
+    tri_d4 U0 = {0.0, 0.0, 0.0, 0.0}, U1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+      if (4 * i + w < tmin) continue;  // (uniform per wave)
+      U0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i][0], Z[i][0], U0, 0, 0, 0);
+      U1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i][1], Z[i][1], U1, 0, 0, 0);
+      U0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i][2], Z[i][2], U0, 0, 0, 0);
+      U1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i][3], Z[i][3], U1, 0, 0, 0);
+    }
+    double* mine = s_u + (par * 4 + w) * 256;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) mine[g * 64 + l] = U0[g] + U1[g];
+    __syncthreads();
+    tri_d4 U;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const double* pu = s_u + par * 4 * 256 + g * 64 + l;
+      U[g] = ((pu[0] + pu[256]) + pu[512]) + pu[768];  // (wave order: the same sum in every wave)
+    }
+    tri_d4 W = {0.0, 0.0, 0.0, 0.0};
+    W = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0, U[0], W, 0, 0, 0);  // rows 0..3 of U
+    W = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1, U[1], W, 0, 0, 0);  // rows 4..7
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+      if (4 * i + w < tmin) continue;
+      Z[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(uv[i][0], W[0], Z[i], 0, 0, 0);
+      Z[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(uv[i][1], W[1], Z[i], 0, 0, 0);
+    }
+    put(nxt, blk - 1);
+    __syncthreads();
+  };
+  Stage sa, sb, sc;
+  fetch(sa, nblk - 1);
+  fetch(sb, nblk - 2);
+  fetch(sc, nblk - 3);
+  put(sa, nblk - 1);
+  __syncthreads();
+  for (int blk = nblk - 1; blk >= 0; blk -= 3) {
+    fetch(sa, blk - 3); block(blk, sb);
+    fetch(sb, blk - 4); block(blk - 1, sc);
+    fetch(sc, blk - 5); block(blk - 2, sa);
+  }
+  // ---- canonical sign per column: the largest-|.| component positive, the first among equals — over the four waves' rows
+  double bv = -1.0, lv = 0.0;
+  int bi = 0x7fffffff;
+  bool nan = false;
+#pragma unroll
+  for (int i = 0; i < SI; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * (4 * i + w) + kq + 4 * g - off;
+      const double av = fabs(Z[i][g]);
+      if (row >= 0 && !(av >= 0.0)) nan = true;
+      if (row >= 0 && (av > bv || (av == bv && row < bi))) { bv = av; bi = row; lv = Z[i][g]; }
+    }
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    const double ov = __shfl_xor(bv, o, 64), olv = __shfl_xor(lv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; lv = olv; }
+  }
+  // (the exchange area is free: [wave][16 columns] of (|v|, index, v))
+  double* sx = s_u;
+  if (kq == 0) { sx[(w * 16 + jl) * 3] = bv; sx[(w * 16 + jl) * 3 + 1] = (double)bi; sx[(w * 16 + jl) * 3 + 2] = lv; }
+  __syncthreads();
+#pragma unroll
+  for (int ww = 0; ww < 4; ++ww) {
+    const double ov = sx[(ww * 16 + jl) * 3], olv = sx[(ww * 16 + jl) * 3 + 2];
+    const int oi = (int)sx[(ww * 16 + jl) * 3 + 1];
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; lv = olv; }
+  }
+  const double sgn = lv < 0.0 ? -1.0 : 1.0;
+  if (__any(nan && jc < n)) {
+    if (l == 0) { a.status[0] = 2; a.sync[3] = 0; }
+  }
+  if (jc < n) {
+#pragma unroll
+    for (int i = 0; i < SI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 16 * (4 * i + w) + kq + 4 * g - off;
+        if (row >= 0) {
+          const double v = Z[i][g] * sgn;
+          a.X[(size_t)row * n + jc] = v;
+          a.Xt[(size_t)jc * n + row] = v;
+        }
+      }
+  }
+}
+template <int SI>
+__global__ void __launch_bounds__(256) k_tri_back(TriBackIO a0, TriBackIO a1) { tri_back_body<SI>(blockIdx.y ? a1 : a0); }
+struct TriBackMany { TriBackIO p[kTriMany]; };
+template <int SI>
+__global__ void __launch_bounds__(256) k_tri_back_many(TriBackMany m, const int* __restrict__ skip_all) {
+  if (skip_all && skip_all[blockIdx.y] != 0) return;
+  const TriBackIO a = m.p[blockIdx.y];
+  tri_back_body<SI>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1227,7 +1441,6 @@ __global__ void __launch_bounds__(256) k_tri_solve_many(TriSolveMany m, const in
 // X' = X + X·E converges quadratically — one step takes orthogonality and residual to working precision.  Four small products
 // on the f64 matrix cores (one 16×16 tile per wave, operands straight from L2: lane l supplies P[k = l>>4][i = l&15] and
 // Q[k][j = l&15], result register g is C[(l>>4) + 4g][l&15]) and one elementwise launch.
-typedef double tri_d4 __attribute__((ext_vector_type(4)));
 struct TriGemm {
   const double* P;   // [n][n] row-major: C = PᵀQ (+ mode)
   const double* Q;

@@ -2276,6 +2276,13 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
   else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
   else hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
+  if (r > 64) {  // (ranks above 64: the back-transformation is a launch of its own, sixteen eigenvectors per wave on the matrix cores)
+    const tri::TriBackIO bk{r, Hv, R, X, Xt, status, sync};
+    const int nb16 = (r + 15) / 16;
+    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_back<2>, dim3(nb16), dim3(256), 0, st, bk, bk);
+    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_back<3>, dim3(nb16), dim3(256), 0, st, bk, bk);
+    else hipLaunchKernelGGL(tri::k_tri_back<4>, dim3(nb16), dim3(256), 0, st, bk, bk);
+  }
   // one refinement step: T = N·X and R = I − XᵀX, S = XᵀT, E, then V = X + X·E (and Vt)
   const int nt = (r + 15) / 16;
   const int* skip = sync + 3;  // (written by the solve launch: 1 = every gap wide enough, the refinement's launches return at once)
@@ -2306,6 +2313,7 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
     tri::TridiagMany tm{};
     tri::TriSolveMany sm{};
     tri::TriWyMany wm{};
+    tri::TriBackMany bm{};
     tri::TriGemmMany g1{}, g2{}, g3{};
     tri::TriCorrMany cm{};
     tri::TriDoneMany dm{};
@@ -2322,6 +2330,7 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
       tm.p[q] = tri::TridiagIO{r, rq[q].M, sl, d, e, beta, Hv, Nm};
       sm.p[q] = tri::TriSolveIO{r, d, e, beta, Hv, X, Xt, rq[q].S, mu, R, sync, rq[q].status, nullptr, nullptr, 0};
       wm.p[q] = tri::TriWyIO{r, beta, Hv, R, sync};
+      bm.p[q] = tri::TriBackIO{r, Hv, R, X, Xt, rq[q].status, sync};
       const int* skip = sync + 3;
       g1.g[2 * q] = tri::TriGemm{Nm, X, T, 0, nullptr, nullptr, skip};
       g1.g[2 * q + 1] = tri::TriGemm{X, X, R, 1, nullptr, nullptr, skip};
@@ -2345,6 +2354,9 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
     if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
     else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve_many<3>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
     else hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
+    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_back_many<2>, dim3(nt, n), dim3(256), 0, st, bm, skip);
+    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_back_many<3>, dim3(nt, n), dim3(256), 0, st, bm, skip);
+    else hipLaunchKernelGGL(tri::k_tri_back_many<4>, dim3(nt, n), dim3(256), 0, st, bm, skip);
     hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, 2 * n), dim3(64), 0, st, r, g1, skip, 2);
     hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, n), dim3(64), 0, st, r, g2, skip, 1);
     hipLaunchKernelGGL(tri::k_tri_correction_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, cm, skip);
