@@ -28,6 +28,13 @@ ICP_HOST_DEVICE_LOOP=1 timeout 900 rocprofv3 --kernel-trace --stats --output-for
 f=$(find $O/$n -name '*kernel_stats.csv' | head -1)
 python3 tools/stats_md.py $f "ICP_HOST_DEVICE_LOOP=1 rocprofv3 --kernel-trace --stats -- python3 tools/r3_device_loop.py 64 300 eigen" > $O/r05_${n}_kernel_stats.md
 find $O/$n -name '*kernel_trace.csv' -delete; tail -1 $O/$n.log | cut -c1-160
+# ---- the wide step's on-device loop: 25 chains of the configs[4] size (N = 28,561, rank 200), 200 steps
+n=wide_loop25
+ICP_HOST_DEVICE_LOOP=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -o s -- python3 tools/r5_wide_loop.py facefull 25 200 /tmp/x.npz > $O/$n.log 2> $O/$n.err
+f=$(find $O/$n -name '*kernel_stats.csv' | head -1)
+python3 tools/stats_md.py $f "ICP_HOST_DEVICE_LOOP=1 rocprofv3 --kernel-trace --stats -- python3 tools/r5_wide_loop.py facefull 25 200" > $O/r05_${n}_kernel_stats.md
+python3 tools/trace_overlap.py $(find $O/$n -name '*kernel_trace.csv' | head -1) 0.5 > $O/r05_${n}_queue_overlap.txt
+find $O/$n -name '*kernel_trace.csv' -delete; tail -1 $O/$n.log | cut -c1-160
 # ---- wait-free per-kernel durations (HIP events on the launch streams, device-side waits taken out): un-profiled runs
 E="--many-chains 0 --cpu-steps 0 --extra-configs= --root-sampler-leg 0"
 python3 bench.py --steps 20 --warmup 5 --profile-steps 300 $E --events-out $O/r05_bench_event_durations.json > $O/ev_bench20.json 2> $O/ev_bench20.err
