@@ -11,7 +11,7 @@ dispatches shorter than about 0.3 ms — these are 5-50 µs —, which makes bus
 usage: pmc_mfma.py <out.json> <config-name>=<counter_collection.csv> ...   (merges into out.json if it exists)"""
 import collections, csv, json, os, statistics, sys
 
-KERNELS = ["k_step_regression", "k_wide_regression", "k_regression_mfma", "k_tri_gemm", "k_posterior_eigen"]
+KERNELS = ["k_step_regression", "k_wide_regression", "k_regression_mfma", "k_tri_gemm", "k_tri_back", "k_posterior_eigen"]
 N_SIMD, N_XCD = 1024, 8
 
 
