@@ -39,8 +39,6 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
     std::vector<std::vector<double>> theta_prop_scratch;
     // (ranks above 64) the streams of the step's independent branches — the group's first chain's own — and the events between them
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipStream_t eval_stream = nullptr;  // the evaluator's own searches beside the proposal's (the group's second chain's stream)
-    hipEvent_t ev_head = nullptr, ev_search = nullptr, ev_eval = nullptr;
     hipEvent_t ev_sum = nullptr, ev_tails = nullptr, ev_eig[2] = {nullptr, nullptr};
     int n_eig_streams = 0;
   };
@@ -73,8 +71,6 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           if (gp->ev_copy[k]) (void)hipEventDestroy(gp->ev_copy[k]);
           if (gp->ev_eig[k]) (void)hipEventDestroy(gp->ev_eig[k]);
         }
-        for (hipEvent_t e : {gp->ev_head, gp->ev_search, gp->ev_eval})
-          if (e) (void)hipEventDestroy(e);
         if (gp->ev_sum) (void)hipEventDestroy(gp->ev_sum);
         if (gp->ev_tails) (void)hipEventDestroy(gp->ev_tails);
       }
@@ -186,11 +182,6 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
         HIP_OK(hipEventCreateWithFlags(&gr.ev_sum, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&gr.ev_tails, hipEventDisableTiming));
         for (auto& e : gr.ev_eig) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        static const bool eval_beside = !dev_env("ICP_WIDE_LOOP_EVAL_BEHIND");  // (developer A/B)
-        if (gr.B >= 2 && eval_beside) {
-          gr.eval_stream = chains[gr.b0 + 1].e->ctx->stream;
-          for (hipEvent_t* e : {&gr.ev_head, &gr.ev_search, &gr.ev_eval}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        }
       }
       const int B = gr.B;
       // -- the step of every chain of the group, captured: an ICP move from the current state
@@ -464,22 +455,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           launch_mhw_front(S, gr.B, gr.mh.p);
           launch_wide_propose_resident(S, r, gr.B, gr.items.p);
           launch_wide_head_resident(S, cap.plan, gr.wide_dev.p);
-          // The evaluator's own searches need the new instance only: on a stream of their own BESIDE the proposal's searches and the
-          // regression — not behind them, where their chip-wide launches ran beside the decompositions (the step's critical path) —;
-          // their reductions read the proposal's distances too and follow the main sequence's searches.
-          const bool eval_beside = cap.any_split && gr.eval_stream != nullptr;
-          if (eval_beside) {
-            HIP_OK(hipEventRecord(gr.ev_head, S));
-            HIP_OK(hipStreamWaitEvent(gr.eval_stream, gr.ev_head, 0));
-            launch_wide_eval(gr.eval_stream, cap.plan, gr.wide_dev.p, 1);
-          }
           launch_wide_main(S, cap.plan, gr.wide_dev.p);
-          if (eval_beside) {
-            HIP_OK(hipEventRecord(gr.ev_search, S));
-            HIP_OK(hipStreamWaitEvent(gr.eval_stream, gr.ev_search, 0));
-            launch_wide_eval(gr.eval_stream, cap.plan, gr.wide_dev.p, 2);
-            HIP_OK(hipEventRecord(gr.ev_eval, gr.eval_stream));
-          }
           for (size_t p0 = 0; p0 < cap.sum_parts.size(); p0 += kWideMaxChains)
             launch_sum_partials_many(S, r, (int)std::min<size_t>(kWideMaxChains, cap.sum_parts.size() - p0), cap.sum_parts.data() + p0, cap.sum_splits.data() + p0);
           // what the summed partials feed does not depend on each other: the factorisations and tails (one-workgroup kernels) on a second
@@ -504,8 +480,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           for (size_t t0 = 0; t0 < cap.tails.size(); t0 += 2 * kWideMaxChains)
             launch_transition_tails(S2, r, (int)std::min<size_t>(2 * kWideMaxChains, cap.tails.size() - t0), cap.tails.data() + t0, lead.Ginv.p, kSigma2);
           if (S2 != S) HIP_OK(hipEventRecord(gr.ev_tails, S2));
-          if (cap.any_split && !eval_beside) launch_wide_eval(S, cap.plan, gr.wide_dev.p);
-          if (eval_beside) HIP_OK(hipStreamWaitEvent(S, gr.ev_eval, 0));
+          if (cap.any_split) launch_wide_eval(S, cap.plan, gr.wide_dev.p);
           if (S2 != S) HIP_OK(hipStreamWaitEvent(S, gr.ev_tails, 0));
           launch_mhw_decide(S, gr.B, r, gr.mh.p);
           for (int u = 0; u < gr.n_eig_streams; ++u) HIP_OK(hipStreamWaitEvent(S, gr.ev_eig[u], 0));

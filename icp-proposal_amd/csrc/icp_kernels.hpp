@@ -620,7 +620,7 @@ WideInstArgs* wide_inst_record(void* block, int B, int b);
 StepSearchArgs* wide_search_record(void* block, int B, int stage /* 0: s1, 1: s2 */, int b);
 // W4..W8 of the records in `device` (launch_wide_head): the main sequence, the evaluator's own
 void launch_wide_main(hipStream_t st, const WideLaunchPlan& plan, void* device);
-void launch_wide_eval(hipStream_t st, const WideLaunchPlan& plan, void* device, int part = 0 /* 1: the searches only, 2: the reductions only */);
+void launch_wide_eval(hipStream_t st, const WideLaunchPlan& plan, void* device);
 int wide_reg_blocks(const WideRegArgs& a);
 int wide_prep_grid(const WidePrepArgs& a);
 void launch_wide_done(hipStream_t st, const WideDoneArgs& a);

@@ -455,16 +455,14 @@ void launch_wide_main(hipStream_t st, const WideLaunchPlan& plan, void* device) 
   }
 }
 
-void launch_wide_eval(hipStream_t st, const WideLaunchPlan& plan, void* device, int part) {
+void launch_wide_eval(hipStream_t st, const WideLaunchPlan& plan, void* device) {
   const int B = plan.B;
   if (B <= 0) return;
   const WideOffsets o = wide_offsets(B);
   char* d = (char*)device;
-  if (part != 2) {
-    launch_wide_searches(st, B, plan.grid_f1b, plan.grid_r1b, plan.f1_prepared, (const StepSearchArgs*)(d + o.s1b), KID_SURFACE_FILTER, KID_SURFACE_RESOLVE);
-    launch_wide_searches(st, B, plan.grid_f2b, plan.grid_r2b, true, (const StepSearchArgs*)(d + o.s2b), KID_VERTEX_FILTER, KID_VERTEX_RESOLVE);
-  }
-  if (part != 1 && plan.grid_regb > 0) {
+  launch_wide_searches(st, B, plan.grid_f1b, plan.grid_r1b, plan.f1_prepared, (const StepSearchArgs*)(d + o.s1b), KID_SURFACE_FILTER, KID_SURFACE_RESOLVE);
+  launch_wide_searches(st, B, plan.grid_f2b, plan.grid_r2b, true, (const StepSearchArgs*)(d + o.s2b), KID_VERTEX_FILTER, KID_VERTEX_RESOLVE);
+  if (plan.grid_regb > 0) {
     ProfScope _ps(st, KID_REDUCE);
     hipLaunchKernelGGL(k_wide_regression, dim3(plan.grid_regb, B), dim3(kWideRegBlock), 0, st, (const WideRegArgs*)(d + o.regb));
   }
