@@ -67,6 +67,7 @@ class RuntimeStats(C.Structure):
 # every symbol include/icp_proposal.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "icp_ctx_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(MeshDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "icp_ctx_create_keyed": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(MeshDesc), C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
     "icp_ctx_destroy": (None, [C.c_void_p]),
     "icp_ctx_set_target": (C.c_int, [C.c_void_p, C.POINTER(MeshDesc)]),
     "icp_status_string": (C.c_char_p, [C.c_int]),

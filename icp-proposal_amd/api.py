@@ -19,6 +19,7 @@ standard normals of `posterior.sample()` are passed in explicitly (`propose(thet
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import dataclasses
 import math
 
@@ -82,6 +83,31 @@ def initial_parameters(model) -> np.ndarray:
     return theta
 
 
+_model_keys = itertools.count(1)
+
+
+def _model_key(model) -> int:
+    """icp_ctx_create_keyed's model_key: taken ONCE per model object — a content hash of the basis (xxhash, ≈ 10 ms for the face
+    model's 137 MB) where that is importable, the object's number otherwise — so that the contexts of a batch registration (one per
+    chain) do not each hash the basis again (6.6 ms per context).  A model whose arrays are changed in place afterwards needs a new
+    StatisticalMeshModel object."""
+    key = getattr(model, "_icp_model_key", None)
+    if key is None:
+        try:
+            import xxhash
+            hx = xxhash.xxh3_64()
+            for arr in (model.basis, model.variance, model.ref_points, model.mean_def):
+                hx.update(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).data)
+            key = (hx.intdigest() & 0xFFFFFFFFFFFFFFFF) or 1
+        except Exception:
+            key = (next(_model_keys) << 20) | 0x5A5A5
+        try:
+            model._icp_model_key = key
+        except Exception:
+            pass
+    return key
+
+
 class IcpContext:
     """One StatisticalMeshModel + one target TriangleMesh3D resident on one MI355X (icp_ctx)."""
 
@@ -92,7 +118,7 @@ class IcpContext:
                            _d(model.basis), _d(model.variance), _i(model.cells))
         td = nat.MeshDesc(target.n_points, target.n_cells, _d(target.points), _i(target.cells))
         h = C.c_void_p()
-        nat.check(L.icp_ctx_create(C.byref(md), C.byref(td), device, C.byref(h)), "icp_ctx_create")
+        nat.check(L.icp_ctx_create_keyed(C.byref(md), C.byref(td), device, _model_key(model), C.byref(h)), "icp_ctx_create_keyed")
         self.h = h
         self.rank, self.N = model.rank, model.n_points
         self._children = []  # weak references to the proposals / evaluators / chains created on this context

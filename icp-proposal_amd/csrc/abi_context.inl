@@ -61,6 +61,10 @@ int icp_ctx_rank(const icp_ctx* ctx) { return ctx ? ctx->r : ICP_ERR_INVALID_ARG
 int icp_ctx_device(const icp_ctx* ctx) { return ctx ? ctx->device : ICP_ERR_INVALID_ARG; }
 
 int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int device, icp_ctx** out) {
+  return icp_ctx_create_keyed(model, target, device, 0, out);
+}
+
+int icp_ctx_create_keyed(const icp_model_desc* model, const icp_mesh_desc* target, int device, uint64_t model_key, icp_ctx** out) {
   if (out) *out = nullptr;
   icp_ctx* ctx = nullptr;
   int rc = guard([&] {
@@ -87,10 +91,19 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     }
     require(device < ndev, "device ordinal out of range");
 
+    static const bool create_timing = std::getenv("ICP_CREATE_TIMING") != nullptr;  // (operational: where a context's creation goes)
+    auto t_mark = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+      if (!create_timing) return;
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[icp create timing] context: %s %.0f us\n", what, std::chrono::duration<double, std::micro>(now - t_mark).count());
+      t_mark = now;
+    };
     ctx = new icp_ctx();
     ctx->device = device;
     ctx->N = N; ctx->T = T; ctx->r = r;
     ctx->bind();
+    mark("checks, bind");
     // The runtime multiplexes streams onto a small pool of hardware queues PER PRIORITY (four by default), and two
     // streams on one hardware queue run one kernel at a time: with other streams alive in the process (torch's,
     // RCCL's: default priority) the two step streams ended up sharing a queue and a step cost 15 % more (measured under
@@ -127,13 +140,28 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     pinned_alloc((void**)&ctx->h_wait_error, sizeof(int) * 16);
     ctx->h_wait_error[0] = 0;
 
+    mark("streams, events");
     // ---- model and target: the immutable device data is shared between the contexts of a device made from the same arrays
     std::lock_guard<std::mutex> shared_lk(g_shared_mu);
+    // Which model this is: a hash of its arrays — 137 MB of basis at the face model's size, 6.6 ms of every context's creation (20
+    // contexts of a batch registration: 130 ms) —, or, if the caller vouches for it (model_key != 0: equal keys mean equal arrays,
+    // icp_ctx_create_keyed), the key, the small arrays and a few thousand basis values spread over the array
     uint64_t mh = hash_words(0x1234, model->ref_points, sizeof(double) * 3 * N);
-    mh = hash_words(mh, model->basis, sizeof(double) * 3 * N * r);
+    if (model_key == 0) {
+      mh = hash_words(mh, model->basis, sizeof(double) * 3 * N * r);
+    } else {
+      mh = hash_words(mh ^ 0x6b657965646d6f64ull, &model_key, sizeof(model_key));
+      const size_t nb = (size_t)3 * N * r, stride = std::max<size_t>(1, nb / 4096);
+      std::vector<double> sample;
+      sample.reserve(4100);
+      for (size_t i = 0; i < nb; i += stride) sample.push_back(model->basis[i]);
+      sample.push_back(model->basis[nb - 1]);
+      mh = hash_words(mh, sample.data(), sizeof(double) * sample.size());
+    }
     mh = hash_words(mh, model->variance, sizeof(double) * r);
     if (model->mean_deformation) mh = hash_words(mh, model->mean_deformation, sizeof(double) * 3 * N);
     mh = hash_words(mh, model->triangles, sizeof(int32_t) * 3 * T);
+    mark("model hash");
     const SharedKey mkey{device, N, T, r, mh};
     std::shared_ptr<SharedModel> sm = g_shared_models[mkey].lock();
     if (!sm) {
@@ -210,7 +238,9 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->tris.alias(sm->tris); ctx->tri_order.alias(sm->tri_order); ctx->adj_off.alias(sm->adj_off); ctx->adj.alias(sm->adj);
     ctx->boundary.alias(sm->boundary);
 
+    mark("shared model");
     attach_target(ctx, target, device);
+    mark("target");
 
     ctx->hint_surf.alloc(N);
     ctx->hint_nnv.alloc(N);
@@ -232,8 +262,10 @@ int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int
     ctx->d_done.fill_bytes(0);
     ctx->d_wait_ticks.alloc(2);
     ctx->d_wait_ticks.fill_bytes(0);
+    mark("hints, pinned result areas");
     for (auto& sl : ctx->slots) ctx->alloc_slot(sl);
     HIP_OK(hipStreamSynchronize(ctx->stream));
+    mark("state slots");
     ++g_live_contexts;
     ctx->counted = true;
     *out = ctx;
