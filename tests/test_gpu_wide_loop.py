@@ -4,7 +4,7 @@ full-mesh Hausdorff evaluator, ranks 65..200, pose walks — apps/bfm/BfmFitting
 device-resident records; mixture draw, proposals' inputs, MetropolisHastings.next and the records are kernels of the step's stream.
 
 Compared (a) with the SAME chains stepped by the host harness through icp_chain_step_batched — identical records wherever the
-decomposition has no warm start (ranks above 64), identical decisions and states to 1e-9 where it has (the host-stepped wide step
+decomposition has no warm start (ranks above 64), identical decisions and states to 1e-8 where it has (the host-stepped wide step
 decomposes ahead, also states that are then rejected: its Jacobi iteration starts from another basis) —, (b) with the oracle's chain
 (orc_run_chain) decision for decision, at a reduced size over 80 steps and at the full configs[3] size.
 The harness reads ICP_HOST_DEVICE_LOOP once per process: every run is a process of its own."""
@@ -46,6 +46,18 @@ elif kind == "face40":      # rank <= 64 on an open target: the warm-started Jac
 elif kind == "femur100":    # closed target, two ICP directions + shape walk at rank 101: the five merged launches host-stepped
     model, target = pkg.data.load_femur_model_and_target(100)
     mk = lambda: pkg.femur_icp_proposal_registration(model, target, fused=2)
+elif kind == "femur50open": # TWO ICP directions (ModelSampling + TargetSampling) against a target WITH boundary, rank 51
+    sys.path.insert(0, {root!r} + "/tests")
+    from conftest import open_patch_target
+    model, closed = pkg.data.load_femur_model_and_target(50)
+    pts, cells = open_patch_target(closed)
+    target = pkg.data.TriangleMesh(pts, cells)
+    mk = lambda: pkg.femur_icp_proposal_registration(model, target, fused=2)
+elif kind == "face40root":  # the opt-in Cholesky-root sampler inside the wide loop (ranks <= 64)
+    model = pkg.data.synthetic_face_model(grid=31, rank=40)
+    target = pkg.data.synthetic_partial_target(model, n_remove=60, seed=7)
+    def mk():
+        s = pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2); s.sampler = "cholesky-root"; return s
 B, n1, n2 = {B}, {n1}, {n2}
 ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
 chains = [pkg.SamplingRegistration(ctxs[i], mk(), pkg.random_initial_parameters(model, i), seed=300 + i) for i in range(B)]
@@ -62,7 +74,8 @@ np.savez({out!r}, a=np.stack(a), single=single, b=np.stack(b), theta=np.stack([s
 
 
 @pytest.mark.parametrize("kind,B,n1,n2,exact", [("face100", 4, 70, 12, True), ("hausdorff", 3, 40, 8, True), ("face200", 18, 30, 6, True),
-                                                ("face40", 13, 140, 10, False), ("femur100", 3, 70, 12, True)])
+                                                ("face40", 13, 140, 10, False), ("femur100", 3, 70, 12, True),
+                                                ("femur50open", 3, 60, 10, False), ("face40root", 3, 60, 10, True)])
 def test_wide_loop_matches_host_stepped_chains(kind, B, n1, n2, exact, tmp_path):
     out = {}
     for mode in ("1", "0"):
@@ -80,18 +93,20 @@ def test_wide_loop_matches_host_stepped_chains(kind, B, n1, n2, exact, tmp_path)
         if exact:
             assert np.array_equal(d, h), key
         else:
-            assert np.abs(d[..., 4:] - h[..., 4:]).max() <= 1e-9 * np.abs(h[..., 14:]).max(), key
-            assert np.abs(d[..., 3] - h[..., 3]).max() <= 1e-9 * np.abs(h[..., 3]).max(), key
+            dmax, scale = np.abs(d[..., 4:] - h[..., 4:]).max(), np.abs(h[..., 14:]).max()
+            assert dmax <= 1e-8 * scale, (key, dmax, scale)
+            pmax, pscale = np.abs(d[..., 3] - h[..., 3]).max(), np.abs(h[..., 3]).max()
+            assert pmax <= 1e-8 * pscale, (key, pmax, pscale)
     assert np.array_equal(dev["n"], host["n"]) and np.array_equal(dev["acc"], host["acc"])
     a = dev["a"]
     assert a.shape == (B, n1, 14 + model_rank(kind)) and np.array_equal(a[:, :, 0], np.tile(np.arange(n1), (B, 1)))
     assert 0.05 < a[:, :, 1].mean() < 0.97
     leaves = set(a[:, :, 2].astype(int).ravel())
-    assert leaves == ({0, 1, 2} if kind == "femur100" else {0, 2, 3, 4, 5, 6, 7, 8}), leaves
+    assert leaves == ({0, 1, 2} if kind.startswith("femur") else {0, 2, 3, 4, 5, 6, 7, 8}), leaves
 
 
 def model_rank(kind):
-    return {"face100": 100, "hausdorff": 100, "face200": 200, "face40": 40, "femur100": 101}[kind]
+    return {"face100": 100, "hausdorff": 100, "face200": 200, "face40": 40, "femur100": 101, "femur50open": 51, "face40root": 40}[kind]
 
 
 _ORACLE_SCRIPT = r"""
