@@ -811,9 +811,9 @@ struct TriWyIO {
   const int* sync;    // sync[2] != 0: the decomposition was dropped — nothing to do
 };
 template <int SI>
-__device__ __forceinline__ void tri_wy_body(const TriWyIO& a) {
+__device__ __forceinline__ void tri_wy_body(const TriWyIO& a, const int blk) {  // (one wave: threadIdx.x < 64)
   constexpr int LD = 64 * SI;
-  const int n = a.n, l = threadIdx.x, blk = blockIdx.x;
+  const int n = a.n, l = threadIdx.x;
   const int k0 = blk * kWyBlock;
   if (k0 >= n - 2) return;
   if (__hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
@@ -855,13 +855,13 @@ __device__ __forceinline__ void tri_wy_body(const TriWyIO& a) {
   }
 }
 template <int SI>
-__global__ void __launch_bounds__(64) k_tri_wy(TriWyIO a0, TriWyIO a1) { tri_wy_body<SI>(blockIdx.y ? a1 : a0); }
+__global__ void __launch_bounds__(64) k_tri_wy(TriWyIO a0, TriWyIO a1) { tri_wy_body<SI>(blockIdx.y ? a1 : a0, blockIdx.x); }
 struct TriWyMany { TriWyIO p[kTriMany]; };
 template <int SI>
 __global__ void __launch_bounds__(64) k_tri_wy_many(TriWyMany m, const int* __restrict__ skip_all) {
   if (skip_all && skip_all[blockIdx.y] != 0) return;
   const TriWyIO a = m.p[blockIdx.y];
-  tri_wy_body<SI>(a);
+  tri_wy_body<SI>(a, blockIdx.x);
 }
 
 struct TriSolveLds {  // the solve launch's dynamic LDS (doubles): offsets for an n x n problem
@@ -944,7 +944,9 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
   }
   if (tid < 8) { ds[n + tid] = 0.0; e2[n + tid] = 0.0; dsr[n + tid] = 0.0; e2r[n - 1 + tid] = 0.0; }  // (read, never used, by the chains' last group)
   const int nblk = (n - 2 + kWyBlock - 1) / kWyBlock;
-  for (int i = tid; i < nblk * kWyBlock * kWyBlock; i += 256) wy[i] = a.wy[i];
+  if constexpr (kBack) {
+    for (int i = tid; i < nblk * kWyBlock * kWyBlock; i += 256) wy[i] = a.wy[i];
+  }
   __syncthreads();
   if (j >= n) return;  // (no barrier below)
   TRI_STAMP(9);
@@ -1219,9 +1221,22 @@ __device__ __forceinline__ void tri_solve_body(const TriSolveIO& a) {
     if (a.done_word) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+// Ranks above 64 (the back-transformation is k_tri_back's): the reflector blocks' T factors are nobody's input inside this launch, so the
+// workgroups behind the eigenpairs' — one wave each — are k_tri_wy's: one launch and its boundary less per decomposition.
+template <int SI>
+__device__ __forceinline__ void tri_solve_or_wy(const TriSolveIO& a) {
+  const int nwg = (a.n + 3) / 4;
+  if constexpr (SI > 1) {
+    if ((int)blockIdx.x >= nwg) {
+      if (threadIdx.x < 64) tri_wy_body<SI>(TriWyIO{a.n, a.beta, a.Hv, const_cast<double*>(a.wy), a.sync}, (int)blockIdx.x - nwg);
+      return;
+    }
+  }
+  tri_solve_body<SI, SI == 1>(a);
+}
 template <int SI>
 __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1) {
-  tri_solve_body<SI, SI == 1>(blockIdx.y ? a1 : a0);  // (up to two decompositions side by side: the two ICP directions of a chain step)
+  tri_solve_or_wy<SI>(blockIdx.y ? a1 : a0);  // (up to two decompositions side by side: the two ICP directions of a chain step)
 }
 struct TriSolveMany { TriSolveIO p[kTriMany]; };
 template <int SI>
@@ -1230,7 +1245,7 @@ __global__ void __launch_bounds__(256) k_tri_solve_many(TriSolveMany m, const in
   // (no s_setprio here: raised to 3 for the critical path's sake, beside the evaluator's searches of a 30-chain wide step the device
   // hung — measured once, not understood, not repeated)
   const TriSolveIO a = m.p[blockIdx.y];
-  tri_solve_body<SI, SI == 1>(a);
+  tri_solve_or_wy<SI>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

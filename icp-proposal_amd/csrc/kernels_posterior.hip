@@ -2268,14 +2268,12 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
     else hipLaunchKernelGGL((tri::k_tridiag<8, 4, 25, 7>), dim3(1), dim3(512), 0, st, ti);
   }
   if (part == 1) return;
+  // (ranks above 64: the T factors by the solve launch's own trailing workgroups — tri_solve_or_wy)
   if (r <= 64) hipLaunchKernelGGL(tri::k_tri_wy<1>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
-  else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_wy<2>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
-  else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_wy<3>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
-  else hipLaunchKernelGGL(tri::k_tri_wy<4>, dim3(nwy), dim3(64), 0, st, wyio, wyio);
   if (r <= 64) hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
-  else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
-  else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
-  else hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
+  else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg + nwy), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
+  else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg + nwy), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
+  else hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg + nwy), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
   if (r > 64) {  // (ranks above 64: the back-transformation is a launch of its own, sixteen eigenvectors per wave on the matrix cores)
     const tri::TriBackIO bk{r, Hv, R, X, Xt, status, sync};
     const int nb16 = (r + 15) / 16;
@@ -2312,7 +2310,6 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
     const int* skip = skip_all ? skip_all + q0 : nullptr;
     tri::TridiagMany tm{};
     tri::TriSolveMany sm{};
-    tri::TriWyMany wm{};
     tri::TriBackMany bm{};
     tri::TriGemmMany g1{}, g2{}, g3{};
     tri::TriCorrMany cm{};
@@ -2329,7 +2326,6 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
       const double* sl = rq[q].sqrt_lambda;
       tm.p[q] = tri::TridiagIO{r, rq[q].M, sl, d, e, beta, Hv, Nm};
       sm.p[q] = tri::TriSolveIO{r, d, e, beta, Hv, X, Xt, rq[q].S, mu, R, sync, rq[q].status, nullptr, nullptr, 0};
-      wm.p[q] = tri::TriWyIO{r, beta, Hv, R, sync};
       bm.p[q] = tri::TriBackIO{r, Hv, R, X, Xt, rq[q].status, sync};
       const int* skip = sync + 3;
       g1.g[2 * q] = tri::TriGemm{Nm, X, T, 0, nullptr, nullptr, skip};
@@ -2348,12 +2344,10 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
     else if (r <= 192) hipLaunchKernelGGL((tri::k_tridiag_many<8, 3, 24, 0>), dim3(n), dim3(512), 0, st, tm, skip);
     else hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 25, 7>), dim3(n), dim3(512), 0, st, tm, skip);
     const int nwy = (r - 2 + tri::kWyBlock - 1) / tri::kWyBlock;
-    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_wy_many<2>, dim3(nwy, n), dim3(64), 0, st, wm, skip);
-    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_wy_many<3>, dim3(nwy, n), dim3(64), 0, st, wm, skip);
-    else hipLaunchKernelGGL(tri::k_tri_wy_many<4>, dim3(nwy, n), dim3(64), 0, st, wm, skip);
-    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
-    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve_many<3>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
-    else hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
+    // (the reflector blocks' T factors: the solve launch's trailing workgroups — tri_solve_or_wy)
+    if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg + nwy, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
+    else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve_many<3>, dim3(nwg + nwy, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
+    else hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg + nwy, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
     if (r <= 128) hipLaunchKernelGGL(tri::k_tri_back_many<2>, dim3(nt, n), dim3(256), 0, st, bm, skip);
     else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_back_many<3>, dim3(nt, n), dim3(256), 0, st, bm, skip);
     else hipLaunchKernelGGL(tri::k_tri_back_many<4>, dim3(nt, n), dim3(256), 0, st, bm, skip);
