@@ -2,11 +2,15 @@
 // C ABI: icp_chains_run_on_device (the whole MH loop on the device) and the remaining queries
 // --------------------------------------------------------------------- the whole MH loop on the device, WIDE step (MhWide)
 // Chains whose step is the wide one (open targets, the Hausdorff evaluator, ranks 65..200: apps/bfm/BfmFittingPartial.scala:62-96,
-// apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala at rank 101).  Per group of chains ONE stream and, per step, the wide step's
-// own launches from records that live in device memory and are the same every step: the current state's posteriors stay in the entries
-// they are in — an accepted state's M, alpha and coefficients are copied there (k_mhw_adopt: 0.3 MB at rank 200) and decomposed in
-// place —, the proposed state always has the same slot and entries.  What changes per step (the proposal's inputs, the proposed state's
-// pose) is set by k_mhw_front; k_mhw_decide is MetropolisHastings.next.  The records are wide_issue's own, captured (WideCapture).
+// apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala at rank 101).  Per step the wide step's own launches, from records that live
+// in device memory and are the same every step: the current state's posteriors stay in the entries they are in — an accepted state's
+// M, alpha, coefficients and correspondence records are copied there (k_mhw_adopt) —, the proposed state always has the same slot and
+// entries.  What changes per step (the proposal's inputs, the proposed state's pose) is set by k_mhw_front; k_mhw_decide is
+// MetropolisHastings.next.  The records are wide_issue's own, captured (WideCapture).
+//   ranks <= 64: groups of chains, each in order on one stream; the warm-started Jacobi iteration in place behind the decision;
+//   ranks above: ONE group; behind the summed partials the step forks — factorisations + tails | the PROPOSED states' decompositions
+//   (tridiagonal route, started ahead of the decision; an accepted state's basis is copied with its posterior) | the evaluator's
+//   searches — and joins at the decision (tails) and at the hand-over (decompositions).  DESIGN.md §5.3b.
 namespace {
 int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators, int32_t n_props, icp_proposal* const* props_in,
                               const icp_mh_mixture* mix, const uint64_t* seeds, const int64_t* first_step, double* const* theta,
