@@ -171,6 +171,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
     groups.resize(n_groups);
     GroupGuard group_guard{groups};
     constexpr int kChunk = 64;  // steps per block of standard normals
+    constexpr int tri_chunk = 16;  // (tri::kTriMany: requests per launch of the tridiagonal route)
     std::vector<double> zero_z(r, 0.0);
     lead.bind();
     for (int g = 0; g < n_groups; ++g) {
@@ -402,10 +403,10 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           launch_sum_partials_many(S, r, (int)std::min<size_t>(kWideMaxChains, cap.sum_parts.size() - p0), cap.sum_parts.data() + p0, cap.sum_splits.data() + p0);
         HIP_OK(hipEventRecord(gr.ev_sum, S));
         int used = 0;
-        for (int q0 = 0; q0 < nq; q0 += 16, ++used) {
+        for (int q0 = 0; q0 < nq; q0 += tri_chunk, ++used) {
           const hipStream_t E = gr.side[1 + (used & 1)];
           if (used < 2) HIP_OK(hipStreamWaitEvent(E, gr.ev_sum, 0));
-          launch_posterior_eigen_tridiag_many(E, r, std::min(16, nq - q0), gr.rqs.data() + q0, gr.spec_parts.data() + q0, nullptr);
+          launch_posterior_eigen_tridiag_many(E, r, std::min(tri_chunk, nq - q0), gr.rqs.data() + q0, gr.spec_parts.data() + q0, nullptr);
         }
         for (int u = 0; u < std::min(used, 2); ++u) HIP_OK(hipEventRecord(gr.ev_eig[u], gr.side[1 + u]));
         const size_t fmax0 = (size_t)posterior_factor_max();
@@ -438,7 +439,6 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
     const int n_blocks = (n_steps + kChunk - 1) / kChunk;
     struct ProfBind { ProfBind(icp_ctx& c) { g_prof = c.profiling ? &c.prof : nullptr; } ~ProfBind() { g_prof = nullptr; } } prof_bind(lead);
     const size_t fmax = (size_t)posterior_factor_max();
-    constexpr int tri_chunk = 16;  // (tri::kTriMany: requests per launch of the tridiagonal route)
     const auto t_loop0 = std::chrono::steady_clock::now();
     for (int blk = 0; blk < n_blocks; ++blk) {
       const int buf = blk & 1, s0 = blk * kChunk, ns = std::min(kChunk, n_steps - s0);
