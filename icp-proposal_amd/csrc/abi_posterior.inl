@@ -39,6 +39,7 @@ struct icp_proposal {
   DBuf<int> hint_nn;      // TargetSampling: last nearest model vertex of each target point
   DBuf<int> nn_id;
   DBuf<double> work;      // r*r scratch of the eigen / direct-tail kernels
+  DBuf<double> xrows;     // (wide step, folded regression) the correspondences' operand rows: K · 4 · 16·⌈(r + 1)/16⌉ values (StepRegressionArgs::X)
   DBuf<double> Mpart;     // split-K partial normal matrices of the regression kernel, two halves: the merged step alternates
                           // between them so that a speculative decomposition can still read the previous step's
   size_t mpart_half_doubles = 0;

@@ -489,6 +489,15 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead, WideCapture* 
       g.fold[i] = regression_fold(p->K, r, nW * n_props);
       g.macro[i] = regression_macro(r, g.fold[i]);
       plan.reg_folded = plan.reg_folded || g.fold[i] > 1;
+      g.X[i] = nullptr;
+      if (g.fold[i] > 1 && g.macro[i] > 1) {  // the operand rows of the posterior's correspondences, made ahead of the regression launch
+        const int xrs = 16 * ((r + 1 + 15) / 16);
+        const size_t need = (size_t)std::max(p->K, 1) * 4 * xrs;
+        if (p->xrows.n < need) p->xrows.alloc(need);
+        g.X[i] = p->xrows.p;
+        g.xrs = xrs;
+        plan.grid_xrows = std::max(plan.grid_xrows, (int)(((size_t)p->K * xrs + 255) / 256));
+      }
       splits[i] = leaves / g.fold[i];
       const int units_i = regression_units(r, leaves, g.fold[i], g.macro[i]);
       g.cb[i] = ep[i]->corr();

@@ -289,6 +289,103 @@ __device__ __forceinline__ void regression_macro_fold(int mtile, int leaves, int
     }
 }
 
+// … from the correspondences' OPERAND ROWS (StepRegressionArgs::X, k_wide_xrows).  regression_macro_fold gathers, per macro tile and
+// correspondence, three basis rows at 2 x 32 columns behind the correspondence's model id — every lane all three rows, because the
+// fourth operand row is their combination with the normal —: 1.7 GB through L2 for 25 face chains, which IS the launch's 280 µs, and
+// two dependent loads (id, then rows) per round of a wave's chain.  With the four operand rows of a correspondence laid out once
+// (2.6 MB per posterior), lane (column, j) loads ONE value per tile row / column block — a third of the traffic, every byte of a
+// 512-byte request used —, no id in between, and six correspondences in flight instead of three.  Same values into the same matrix
+// instructions in the same order: the bits of regression_tile.
+template <int MT>
+__device__ __forceinline__ void regression_macro_fold_x(int mtile, int leaves, int K, int kchunk, int r, const double* __restrict__ X, int xrs,
+                                                        const CorrBuffers& cb, double wt, double kappa, double* __restrict__ Mpart) {
+  const int n = r + 1, nt = (n + 15) >> 4;
+  int mi = 0;
+  while ((mi + 1) * (mi + 2) / 2 <= mtile) ++mi;
+  const int mj = mtile - mi * (mi + 1) / 2;
+  const int l = threadIdx.x & 63, i16 = l & 15, kk = l >> 4;
+  int ca[MT], cbi[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) {
+    ca[p] = MT * mi + p < nt ? 16 * (MT * mi + p) + i16 : 0;
+    cbi[p] = MT * mj + p < nt ? 16 * (MT * mj + p) + i16 : 0;
+  }
+  bool on[MT][MT];  // (uniform) tile (MT·mi + p, MT·mj + q) exists and lies in the lower triangle
+#pragma unroll
+  for (int p = 0; p < MT; ++p)
+#pragma unroll
+    for (int q = 0; q < MT; ++q) on[p][q] = MT * mi + p < nt && MT * mj + q <= MT * mi + p;
+  d4_t acc[MT][MT], run[MT][MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p)
+#pragma unroll
+    for (int q = 0; q < MT; ++q) run[p][q] = d4_t{0.0, 0.0, 0.0, 0.0};
+  const double wbase = kk == 3 ? kappa : wt;
+  const double* xl = X + (size_t)kk * xrs;  // this lane's operand row of correspondence 0
+  constexpr int G = 8;  // correspondences whose loads are in flight together (a leaf of the usual eight: one round of loads)
+  for (int f = 0; f < leaves; ++f) {
+    const int k0 = f * kchunk, k1 = min(K, k0 + kchunk);
+#pragma unroll
+    for (int p = 0; p < MT; ++p)
+#pragma unroll
+      for (int q = 0; q < MT; ++q) acc[p][q] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int kb = k0; kb < k1; kb += G) {
+      double A_op[G][MT], B_op[G][MT];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int k = min(kb + u, k1 - 1);  // (past the leaf's end: a repeated load, its products not issued)
+        const double* xk = xl + (size_t)k * 4 * xrs;
+        const double w = wbase * (cb.keep[k] ? 1.0 : 0.0);
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+          A_op[u][p] = xk[ca[p]];
+          B_op[u][p] = xk[cbi[p]] * w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (kb + u < k1) {
+#pragma unroll
+          for (int p = 0; p < MT; ++p)
+#pragma unroll
+            for (int q = 0; q < MT; ++q)
+              if (on[p][q]) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_op[u][p], B_op[u][q], acc[p][q], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < MT; ++p)
+#pragma unroll
+      for (int q = 0; q < MT; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) run[p][q][g] += acc[p][q][g];
+  }
+#pragma unroll
+  for (int p = 0; p < MT; ++p)
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      if (!on[p][q]) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 16 * (MT * mi + p) + kk + 4 * g, col = 16 * (MT * mj + q) + i16;
+        if (row < n && col < n) Mpart[(size_t)row * n + col] = run[p][q][g];
+      }
+    }
+}
+// the operand rows of one correspondence, one thread per (correspondence, column): the values regression_load / regression_mac form
+__device__ __forceinline__ void regression_xrows(int e, int K, int r, int xrs, const double* __restrict__ Q, const CorrBuffers& cb, double* __restrict__ X) {
+  const int k = e / xrs, col = e - k * xrs;
+  if (k >= K) return;
+  const double* q = Q + (size_t)3 * cb.id[k] * r;
+  const double ma = col < r ? 1.0 : 0.0, ea = col == r ? 1.0 : 0.0;
+  const int cc = col < r ? col : 0;
+  const double e0 = cb.e[3 * k], e1 = cb.e[3 * k + 1], e2 = cb.e[3 * k + 2];
+  const double a0 = fma(ma, q[cc], ea * e0), a1 = fma(ma, q[r + cc], ea * e1), a2 = fma(ma, q[2 * r + cc], ea * e2);
+  const double n0 = cb.nhat[3 * k], n1 = cb.nhat[3 * k + 1], n2 = cb.nhat[3 * k + 2];
+  double* x = X + (size_t)k * 4 * xrs + col;
+  x[0] = a0; x[xrs] = a1; x[2 * (size_t)xrs] = a2; x[3 * (size_t)xrs] = fma(a2, n2, fma(a1, n1, a0 * n0));
+}
+
 // ---------------------------------------------------------------- dense helpers (one workgroup, matrix behind a generic pointer)
 
 __device__ double block_sum(double v, double* s_red) {

@@ -385,6 +385,11 @@ struct StepRegressionArgs {  // launch 4: normal-equation partial sums of every 
   double wt[2], kappa[2];
   double* Mpart[2];
   int* status[2];            // the new entries' 3 status ints: {-, eigen sweeps, eigen} are cleared here
+  // (folded posteriors of the wide step) the correspondences' operand rows, made by a launch of its own ahead of the regression
+  // (k_wide_xrows): X[(k·4 + j)·xrs + col] = row j of [Q_i | e_i] for j < 3, n̂ᵀ[Q_i | e_i] for j = 3, zeros behind column r — what
+  // regression_load / regression_mac work out per tile and correspondence.  null: gathered from the basis (regression_macro_fold)
+  double* X[2];
+  int xrs, xpad_;
 
   int reduce_kind;           // 0 none, 1 Σ log N(d; mean, sigma), 2 {Σ d, max d, count}
   int Kred;                  // model -> target distances (0: that direction is not evaluated)
@@ -598,6 +603,7 @@ struct WideDoneArgs { int n; WideDoneItem it[kWideMaxChains]; };
 
 size_t wide_batch_bytes(int B);
 struct WideLaunchPlan {
+  int grid_xrows = 0;       // … and read their operand rows from StepRegressionArgs::X: workgroups of the launch that makes them (per chain and posterior)
   bool reg_folded = false;  // the chains' posteriors fold their split-K leaves (StepRegressionArgs::fold > 1): the folded regression kernel    // what the host has worked out for a batch: common model data, grids
   int B, N, r;
   const double* Qp; const double* ref; const double* mean;

@@ -289,7 +289,8 @@ __device__ __forceinline__ void wide_regression_body(const WideRegArgs* __restri
       const int l = u - (which ? a.ustart[1] : 0), tile = l % a.ntiles, split = l / a.ntiles;
       if (l == 0 && (threadIdx.x & 63) == 0) { a.status[which][1] = 0; a.status[which][2] = 0; }
       if constexpr (kFolded) {  // (a kernel of its own: see step_regression_body, kernels_step.hip)
-        if (a.macro[which] > 1) regression_macro_fold<2>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
+        if (a.macro[which] > 1 && a.X[which]) regression_macro_fold_x<2>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.X[which], a.xrs, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
+        else if (a.macro[which] > 1) regression_macro_fold<2>(l, a.fold[which], a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which]);
         else regression_tile_fold(tile, split, a.K[which], a.kchunk[which], a.r, a.Q, a.cb[which], a.wt[which], a.kappa[which], a.Mpart[which], a.fold[which]);
       } else if (which == 0) regression_tile(tile, split, a.K[0], a.kchunk[0], a.r, a.Q, a.cb[0], a.wt[0], a.kappa[0], a.Mpart[0]);
       else regression_tile(tile, split, a.K[1], a.kchunk[1], a.r, a.Q, a.cb[1], a.wt[1], a.kappa[1], a.Mpart[1]);
@@ -314,6 +315,14 @@ __device__ __forceinline__ void wide_regression_body(const WideRegArgs* __restri
 __global__ void __launch_bounds__(kWideRegBlock) k_wide_regression(const WideRegArgs* __restrict__ batch) { wide_regression_body<false>(batch); }
 // … with the posteriors' split-K leaves folded into one partial each, in 2 x 2 macro tiles at ranks >= 80 (WideLaunchPlan::reg_folded)
 __global__ void __launch_bounds__(kWideRegBlock) k_wide_regression_fold(const WideRegArgs* __restrict__ batch) { wide_regression_body<true>(batch); }
+
+// the folded posteriors' operand rows (StepRegressionArgs::X), ahead of W8: blockIdx.y = chain, blockIdx.z = posterior of the chain
+__global__ void __launch_bounds__(256) k_wide_xrows(const WideRegArgs* __restrict__ batch) {
+  const StepRegressionArgs& a = batch[blockIdx.y].reg;
+  const int which = blockIdx.z;
+  if (which >= a.n || !a.X[which] || a.fold[which] <= 1) return;
+  regression_xrows(blockIdx.x * 256 + threadIdx.x, a.K[which], a.r, a.xrs, a.Q, a.cb[which], a.X[which]);
+}
 
 // ---------------------------------------------------------------- W12: results and completion flags into pinned host memory
 __global__ void __launch_bounds__(64) k_wide_done(WideDoneArgs a) {
@@ -448,6 +457,8 @@ void launch_wide_main(hipStream_t st, const WideLaunchPlan& plan, void* device) 
   char* d = (char*)device;
   launch_wide_searches(st, B, plan.grid_f1, plan.grid_r1, plan.f1_prepared, (const StepSearchArgs*)(d + o.s1), KID_STEP_FILTER, KID_STEP_RESOLVE);
   launch_wide_searches(st, B, plan.grid_f2, plan.grid_r2, true, (const StepSearchArgs*)(d + o.s2), KID_VERTEX_FILTER, KID_VERTEX_RESOLVE);
+  if (plan.grid_reg > 0 && plan.reg_folded && plan.grid_xrows > 0)
+    hipLaunchKernelGGL(k_wide_xrows, dim3(plan.grid_xrows, B, 2), dim3(256), 0, st, (const WideRegArgs*)(d + o.reg));
   if (plan.grid_reg > 0) {
     ProfScope _ps(st, KID_STEP_REGRESSION);
     if (plan.reg_folded) hipLaunchKernelGGL(k_wide_regression_fold, dim3(plan.grid_reg, B), dim3(kWideRegBlock), 0, st, (const WideRegArgs*)(d + o.reg));
