@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B on one box: this tree against the round-4 tree (git worktree under _old/, built beforehand): the default bench's legs
+# A/B on one box: this tree against the round-4 tree: the default bench's legs.  Needs the old tree under _old/, built:
+#   git worktree add _old aa25e50 && python -c 'import sys; sys.path.insert(0, "_old"); import __graft_entry__ as g; g.build()'   (remove it afterwards: it travels with every gpurun)
 cd $GRAFT_REPO_ROOT
 leg() { (cd $1 && python3 bench.py --steps 20 --warmup 5 --cpu-steps 0 --profile-steps 0 --root-sampler-leg 0 --extra-configs=2,3 --many-chains 64 2>/dev/null | python3 -c "
 import sys,json
