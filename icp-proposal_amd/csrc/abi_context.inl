@@ -165,6 +165,8 @@ int icp_ctx_create_keyed(const icp_model_desc* model, const icp_mesh_desc* targe
     const SharedKey mkey{device, N, T, r, mh};
     std::shared_ptr<SharedModel> sm = g_shared_models[mkey].lock();
     if (!sm) {
+      // (the first context of a model the caller will make many contexts of: their streams are made meanwhile — abi_pools.inl)
+      if (model_key != 0) prewarm_streams(device, 24);
       sm = std::make_shared<SharedModel>();
       sm->device = device;
       static uint64_t next_uid = 0;  // (under g_shared_mu)

@@ -250,7 +250,45 @@ void device_free(void* p, size_t bytes) {
   (void)hipFree(p);
 }
 
+// A host that announces many contexts of one model (icp_ctx_create_keyed) gets its later contexts' streams made AHEAD, by a helper
+// thread, while the first context's one-off host work (the model's Gram matrix and factorisations: ≈ 0.5 s at the face model's size)
+// keeps the calling thread busy: hipStreamCreateWithPriority takes 2.4 ms, three quarters of what a further context costs.  Streams of
+// the default priority class (what every context after the first takes), straight into the pool; at most once per device.
+struct StreamPrewarm {
+  std::mutex mu;
+  std::thread worker;
+  bool done[ResourcePool::kDevices] = {};
+  void join() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (worker.joinable()) worker.join();
+  }
+  ~StreamPrewarm() { if (worker.joinable()) worker.join(); }
+};
+StreamPrewarm g_prewarm;
+void prewarm_streams(int device, int n) {
+  if (!g_pool.on || device < 0 || device >= ResourcePool::kDevices) return;
+  static const bool off = std::getenv("ICP_NO_STREAM_PREWARM") != nullptr;  // (operational switch)
+  if (off) return;
+  std::lock_guard<std::mutex> lk(g_prewarm.mu);
+  if (g_prewarm.done[device]) return;
+  g_prewarm.done[device] = true;
+  if (g_prewarm.worker.joinable()) g_prewarm.worker.join();
+  g_prewarm.worker = std::thread([device, n] {
+    if (hipSetDevice(device) != hipSuccess) return;
+    for (int i = 0; i < n; ++i) {
+      hipStream_t s = nullptr;
+      if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, 0) != hipSuccess) return;
+      std::lock_guard<std::mutex> plk(g_pool.mu);
+      auto& v = g_pool.streams[device][0];
+      if ((int)v.size() >= ResourcePool::kStreamsPerClass) { (void)hipStreamDestroy(s); return; }
+      g_pool.stream_class[s] = device * 2;
+      v.push_back(s);
+    }
+  });
+}
+
 void drain_pools() {
+  g_prewarm.join();
   (void)drain_device_pool();
   std::vector<hipStream_t> ss;
   std::vector<void*> blocks;

@@ -130,7 +130,9 @@ ICP_API int icp_ctx_create(const icp_model_desc *model, const icp_mesh_desc *tar
 /* The same for a caller that makes MANY contexts from one model (one per chain of a batch registration: SURVEY.md §8e).  Contexts of a
  * device made from the same model share its device data; icp_ctx_create recognises the model by hashing its arrays — 137 MB of basis at
  * the face model's size, 6.6 ms per context.  model_key != 0: the caller vouches that equal keys mean equal model arrays (an object
- * id, a hash taken once); the library then hashes the key, the small arrays and a sample of the basis only (0.3 ms).  0 = icp_ctx_create. */
+ * id, a hash taken once); the library then hashes the key, the small arrays and a sample of the basis only (0.3 ms), and while the FIRST
+ * context of a keyed model does its one-off host work a helper thread makes two dozen streams for the contexts to come
+ * (hipStreamCreateWithPriority: 2.4 ms each; ICP_NO_STREAM_PREWARM=1: not).  0 = icp_ctx_create. */
 ICP_API int icp_ctx_create_keyed(const icp_model_desc *model, const icp_mesh_desc *target, int device, uint64_t model_key, icp_ctx **out);
 ICP_API void icp_ctx_destroy(icp_ctx *ctx);
 /* Gives the context ANOTHER target mesh and keeps everything that does not depend on the target — the model's device data, the
