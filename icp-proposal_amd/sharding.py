@@ -135,10 +135,11 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
     if chains_per_launch <= 0:
         # (measured on one MI355X, face configuration: 10 chains per submission 6.7k it/s, 20: 9.1k, 30: 10.5k, 40: 10.3k — a round costs
         # its launches and the slowest chain's decomposition, whatever it carries: tools/r4_many.sh)
-        # Short chains: fewer — a context costs ≈ 14 ms to make the first time (four streams), a submission of 20 chains saves 0.8 ms
-        # per step against two of 10, one of 30 another 0.85 ms against 20 + 10 (10 x 10 x 50 steps: 4,390 it/s with 10 per submission,
-        # 4,765 with 20, 3,560 with 30).
-        per_target = 3 if n_steps >= 150 else 2 if n_steps >= 30 else 1
+        # Short chains: round 4 took fewer — a context cost ≈ 14 ms to make the first time (four streams; 10 x 10 x 50 steps: 4,390 it/s
+        # with 10 per submission, 4,765 with 20, 3,560 with 30).  Round 5: side streams on first use, a keyed model, the main streams made
+        # ahead by a helper thread — a further context is 1.1-2 ms —, and from 24 chains on a submission runs inside the on-device loop:
+        # 6,960 it/s with 20 per submission, 7,300-7,540 with 25.
+        per_target = 3 if n_steps >= 30 else 1   # (round 5: a further context costs 1.1 ms, not 14: also short chains in submissions of ~25)
         chains_per_launch = max(1, min(32, per_target * n_chains))
         # … in submissions of EQUAL size (100 items: 4 x 25, not 3 x 30 + 10): from 24 chains on a submission of wide-step chains runs
         # as the on-device loop (icp_chains_run_on_device: 1.7 ms per step of 30 face chains against 2.0 host-stepped), a remainder of 10
