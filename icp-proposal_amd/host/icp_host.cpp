@@ -481,15 +481,24 @@ static int run_on_device(icp_host_chain* const* chains, int32_t n_chains, int32_
   // Chains of the five merged launches ABOVE rank 64 (apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala at rank 101) take the
   // loop from two chains on: host-stepped, each of their steps waits for a decomposition the batch cannot start ahead (3 chains at rank
   // 100: 3.7k it/s in the loop, 2.5k host-stepped; 24 chains 7.3k against 5.0k — tools/r5_wide_loop.py).  Chains of the wide step (open
-  // targets, rank 200): 30 chains 1.7 ms per step in the loop against 2.0 host-stepped, 10 chains 5.2k it/s against 6.8k — from 24 on.
+  // targets, rank 200): 30 chains 1.7 ms per step in the loop against 2.0 host-stepped, 10 chains 5.2k it/s against 6.8k — at first from 24 on.
   static const int mode = std::getenv("ICP_HOST_DEVICE_LOOP") ? std::atoi(std::getenv("ICP_HOST_DEVICE_LOOP")) : -1;
   icp_host_chain* c0 = chains[0];
   if (!c0) return ICP_ERR_INVALID_ARG;
+  // (… measured again at the end of round 5 — restate pass, operand-row regression, matrix-core back-transformation —, 200 steps, whole
+  // runs: the face configuration at N = 28,561 2 chains 2.5k it/s in the loop against 2.0k host-stepped, 3: 3.5k / 3.3k, 4: 4.4k / 4.7k,
+  // 6: 6.0k / 4.4k, 10: 8.8k / 6.6k, 16: 11.7k / 11.9k, 20: 13.1k / 11.3k; an open target at rank 40: 4 chains 16.9k / 7.4k, 10 chains
+  // 34.8k / 12.3k.)
   int from = 24;
-  if (mode < 0 && c0->r > 64 && !c0->icp.empty()) {
+  if (mode < 0 && !c0->icp.empty()) {
     std::vector<icp_proposal*> hs;
     for (auto* p : c0->icp) hs.push_back(p->h);
-    if (icp_chain_step_path(c0->likelihood->h, (int)hs.size(), hs.data()) == 0) from = 2;
+    const int path = icp_chain_step_path(c0->likelihood->h, (int)hs.size(), hs.data());
+    // (ranks <= 64 on the wide step: from eight — the loop's warm-started Jacobi iteration starts from another basis than the
+    // host-stepped step's, which decomposes ahead: states equal to 1e-11, not bit for bit, and small submissions are what the tests
+    // compare chain by chain)
+    if (c0->r > 64 && (path == 0 || path == 1)) from = 2;
+    else if (path == 1) from = 8;
   }
   if (mode == 0 || (mode < 0 && n_chains < from)) return ICP_ERR_INVALID_ARG;
   const size_t n_icp = c0->icp.size();

@@ -251,8 +251,10 @@ def test_wide_chains_in_groups_and_across_targets_give_the_same_records(tmp_path
     out = {}
     for groups in ("1", "2"):
         path = str(tmp_path / f"g{groups}.npz")
+        # (host-stepped on purpose: from two chains on the harness would hand these rank-100 chains to the on-device loop —
+        # tests/test_gpu_wide_loop.py — and this test is about the tickets of the host-stepped groups)
         subprocess.run([sys.executable, "-c", _GROUPS_SCRIPT.format(root=ROOT, n=40, out=path)], check=True,
-                       env={**os.environ, "ICP_LOCKSTEP_GROUPS": groups}, timeout=900)
+                       env={**os.environ, "ICP_LOCKSTEP_GROUPS": groups, "ICP_HOST_DEVICE_LOOP": "0"}, timeout=900)
         out[groups] = np.load(path)
     assert np.array_equal(out["1"]["rec"], out["2"]["rec"])
     assert np.all(out["1"]["wide"] == 40) and np.all(out["2"]["wide"] == 40)
