@@ -288,8 +288,9 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           // state's entry, started as soon as the summed partials exist, beside the factorisation, the tails and the evaluator's
           // searches (as the host-stepped wide step decomposes ahead); an accepted state's basis moves with its posterior.
           PosteriorEntry& de = jacobi ? cur : prop;
+          // (ranks above 64: no host status, no completion word — the loop looks at the status words on the device, in stream order)
           EigenRequest rq{de.M.p, (root || !jacobi) ? nullptr : cur.V.p, de.V.p, de.Vt.p, de.S.p, p->work.p, p->status.p + de.status_off + 2, nullptr,
-                          p->h_eig + de.status_off / 3, p->eig_words.p + de.status_off / 3, 0, c.sqrt_lambda.p};
+                          jacobi ? p->h_eig + de.status_off / 3 : nullptr, jacobi ? p->eig_words.p + de.status_off / 3 : nullptr, 0, c.sqrt_lambda.p};
           rq.root = root != 0;
           gr.rqs[(size_t)k * n_props + i] = rq;
           EigenProblem ep{};

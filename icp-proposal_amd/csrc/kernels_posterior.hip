@@ -2355,7 +2355,9 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
     hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, n), dim3(64), 0, st, r, g2, skip, 1);
     hipLaunchKernelGGL(tri::k_tri_correction_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, cm, skip);
     hipLaunchKernelGGL(tri::k_tri_gemm_many, dim3(nt, nt, n), dim3(64), 0, st, r, g3, skip, 1);
-    hipLaunchKernelGGL(tri::k_tri_done_many, dim3(n), dim3(1), 0, st, dm, skip);
+    bool any_done = false;  // (nobody to tell — the on-device loop reads the status words on the device —: no launch)
+    for (int q = 0; q < n; ++q) any_done = any_done || dm.host_status[q] || dm.done_word[q];
+    if (any_done) hipLaunchKernelGGL(tri::k_tri_done_many, dim3(n), dim3(1), 0, st, dm, skip);
   }
 }
 
