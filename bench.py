@@ -442,8 +442,12 @@ def main():
     ap.add_argument("--many-chains", type=int, default=64,
                     help="extra leg after the timed region (1 GPU, 1 chain per GPU, config 1 only): aggregate rate of this many chains on the GPU "
                          "stepped through icp_chain_step_batched, reported as `many_chains` (0 = skip)")
-    ap.add_argument("--fused", type=int, default=2, choices=[0, 1, 2],
-                    help="host<->device call pattern per step: 0 per-method calls, 1 propose + icp_chain_eval_step, 2 one icp_chain_step")
+    ap.add_argument("--fused", type=int, default=2, choices=[0, 1, 2, 3],
+                    help="host<->device call pattern per step: 0 per-method calls, 1 propose + icp_chain_eval_step, 2 one icp_chain_step, "
+                         "3 per-method calls over a chain bound with icp_chain_bind (the drop-in path)")
+    ap.add_argument("--dropin-leg", type=int, default=1,
+                    help="default run (N = 1, config 1): extra legs `dropin_per_method` — configs[1] and configs[3] stepped method by method "
+                         "(Scalismo's call pattern), unbound and bound with icp_chain_bind, beside icp_chain_step (0 = skip)")
     ap.add_argument("--root-sampler-leg", type=int, default=1,
                     help="default run (N = 1, config 1): extra leg with the opt-in Cholesky-root sampler, reported as `cholesky_root_sampler` (0 = skip)")
     ap.add_argument("--sampler", type=str, default="eigen", choices=["eigen", "cholesky-root"],
@@ -464,7 +468,12 @@ def main():
         import __graft_entry__ as graft
         pkg = graft.load_package()
         name, _, sampler = args.leg.partition(":")
-        out = config4_leg(pkg, args, 0) if name == "config4" else extra_config_leg(pkg, args, int(name[len("config"):]), 0, sampler=sampler or "eigen")
+        if name == "config4":
+            out = config4_leg(pkg, args, 0)
+        elif name.startswith("dropin"):
+            out = dropin_leg(pkg, args, int(name[len("dropin"):]), 0)
+        else:
+            out = extra_config_leg(pkg, args, int(name[len("config"):]), 0, sampler=sampler or "eigen")
         print(json.dumps(out))
         return
 
@@ -573,7 +582,7 @@ def main():
             "workload": wl["name"] + "; %d chain%s per GPU" % (B, "" if B == 1 else "s (lockstep, icp_chain_step_batched)"),
             "baseline_config_index": args.config,
             "chains_per_gpu": B,
-            "calls_per_step": {0: "per-method", 1: "propose + icp_chain_eval_step", 2: "icp_chain_step"}[args.fused] if B == 1 else "icp_chain_step_batched",
+            "calls_per_step": {0: "per-method", 1: "propose + icp_chain_eval_step", 2: "icp_chain_step", 3: "per-method over icp_chain_bind"}[args.fused] if B == 1 else "icp_chain_step_batched",
             "chain_ms": 1e3 * t_chain,
             "log_gather_ms": 1e3 * t_gather,
             "accepted": n_acc,
@@ -627,6 +636,15 @@ def main():
                     line["extra_configs"]["config3_cholesky_root"] = child_leg("config3:cholesky-root")
                 except Exception as e:
                     line["extra_configs"]["config3_cholesky_root"] = {"error": str(e)[:200]}
+    if rank == 0 and world == 1 and B == 1 and args.config == 1 and args.dropin_leg and args.extra_configs.strip():
+        # ---- not the headline: the north star's drop-in contract measured — the chain stepped method by method as Scalismo steps it
+        # (unbound, and bound once with icp_chain_bind) beside icp_chain_step, configs[1] and configs[3], a child process each
+        line["dropin_per_method"] = {"how": "python bench.py --leg dropinN (a process of its own per configuration); harness mode fused = 0 / 3 / 2"}
+        for cfg_i in (1, 3):
+            try:
+                line["dropin_per_method"]["config%d" % cfg_i] = child_leg("dropin%d" % cfg_i)
+            except Exception as e:
+                line["dropin_per_method"]["config%d" % cfg_i] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and B == 1 and args.config == 1 and args.root_sampler_leg:
         # ---- not the headline and NOT the reference's arithmetic: the same chain with the opt-in Cholesky-root sampler
         # (icp_proposal_set_sampler) — what the accepted path costs when the reference's SVD convention for posterior.sample() is not required
@@ -785,6 +803,47 @@ def extra_config_leg(pkg, args, cfg_i, device, sampler="eigen"):
         except Exception as e:
             out["from_deterministic_fit"] = {"error": str(e)[:200]}
     ctx.close()
+    return out
+
+
+def dropin_leg(pkg, args, cfg_i, device):
+    """The drop-in contract measured: the chain stepped the way Scalismo's MetropolisHastings.next steps it — logValue(current), propose,
+    logValue(proposal), and through the mixture every ICP proposal's logTransitionProbability both ways, ONE native call each
+    (api/sampling/SamplingRegistration.scala:52-58, MixedProposalDistributions.scala:48-68) — (a) as is (`per_method`: every call a
+    device round trip), (b) over a chain bound once with icp_chain_bind (`per_method_bound`: the first call of a step submits the whole
+    step), beside (c) the harness' own icp_chain_step loop (`icp_chain_step`: the headline's mode, with its next-step pre-launch, which
+    needs the next step's random numbers ahead — something a Scalismo caller cannot give).  Same chain, same seed, same window as the
+    driver's line (20 steps after 5) and a longer stretch; every mode a fresh context."""
+    out = {"unit": "iterations/s", "config": cfg_i}
+    wl = None
+    for key, fused in (("per_method", 0), ("per_method_bound", 3), ("icp_chain_step", 2)):
+        wl = build_workload(pkg, cfg_i, args.subdiv, fused, args)
+        n_long = 1000 if cfg_i == 1 else 300
+        leg = {}
+        for win, n_w, n in (("driver_window", 5, 20), ("long", 100, n_long)):
+            ctx = pkg.IcpContext(wl["model"], wl["target"], device=device)
+            chain = pkg.SamplingRegistration(ctx, wl["setup"], wl["init"](0), seed=1024)
+            chain.run(n_w, want_records=False)
+            c0 = chain.native_calls()
+            t0 = time.perf_counter()
+            rec = chain.run(n)
+            dt = time.perf_counter() - t0
+            c1 = chain.native_calls()
+            leg[win] = {"value": n / dt, "steps": n, "warmup": n_w, "accepted": int(rec[:, 1].sum()),
+                        "native_per_method_calls_per_step": (c1["proposal_calls"] + c1["log_value_calls"] - c0["proposal_calls"] - c0["log_value_calls"]) / n}
+            if fused == 3:
+                leg[win]["whole_steps_submitted_per_step"] = (c1["bound_steps_from_propose"] + c1["bound_steps_from_log_value"]
+                                                              - c0["bound_steps_from_propose"] - c0["bound_steps_from_log_value"]) / n
+                leg[win]["parked_densities_per_step"] = (c1["parked_transition_hits"] - c0["parked_transition_hits"]) / n
+            leg["step_paths"] = ctx.step_paths()
+            leg["runtime_stats"] = ctx.runtime_stats()
+            chain.close()
+            ctx.close()
+        out[key] = leg
+    out["workload"] = wl["name"]
+    for win in ("driver_window", "long"):
+        out["bound_over_chain_step_" + win] = out["per_method_bound"][win]["value"] / out["icp_chain_step"][win]["value"]
+        out["bound_over_unbound_" + win] = out["per_method_bound"][win]["value"] / out["per_method"][win]["value"]
     return out
 
 

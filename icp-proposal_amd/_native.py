@@ -114,6 +114,8 @@ SIGNATURES = {
     "icp_ctx_step_paths": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "icp_chain_step_path": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "icp_proposal_basis_state": (C.c_int, [C.c_void_p, c_double_p]),
+    "icp_chain_bind": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "icp_chain_bind_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "icp_release_cached_models": (None, []),
     "icp_chains_run_on_device": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(MhMixture),
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(c_double_p), c_double_p, C.c_int32,

@@ -9,6 +9,7 @@ reference's src/main/scala/), implemented as thin wrappers over the C ABI (inclu
     HausdorffDistanceEvaluator             api/sampling/evaluators/HausdorffDistanceEvaluator.scala:25-36
     CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator   …/CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:27-79
     ModelPriorEvaluator                    api/sampling/evaluators/ModelPriorEvaluator.scala:24-31
+    AcceptAllEvaluator                     api/sampling/evaluators/AcceptAllEvaluator.scala:22-28
     ModelSampling / TargetSampling / ModelAndTargetSampling    api/other/IcpProjectionDirection.scala:19-25
     ModelToTargetEvaluation / …            api/sampling/evaluators/EvaluationModeType.scala:20-26
 
@@ -348,6 +349,27 @@ class _Evaluator:
         aux = np.zeros(4)
         nat.check(nat.lib().icp_evaluator_log_value(self.h, _d(th), C.byref(out), _d(aux)), "icp_evaluator_log_value")
         return (out.value, aux) if return_aux else out.value
+
+    def bindChain(self, proposals):
+        """icp_chain_bind: this evaluator and the chain's ICP proposals (in the mixture's order) form ONE Metropolis–Hastings chain
+        driven method by method (Scalismo's MetropolisHastings.next, api/sampling/SamplingRegistration.scala:52-58): the first call of
+        a step submits the whole step, the calls behind it find their values parked.  An empty list unbinds."""
+        n = len(proposals)
+        arr = (C.c_void_p * max(n, 1))(*[p.h for p in proposals])
+        nat.check(nat.lib().icp_chain_bind(self.h, n, arr), "icp_chain_bind")
+
+    def bindStats(self) -> dict:
+        out = (C.c_int64 * 3)()
+        nat.check(nat.lib().icp_chain_bind_stats(self.h, out), "icp_chain_bind_stats")
+        return {"steps_from_propose": int(out[0]), "steps_from_log_value": int(out[1]), "parked_transition_hits": int(out[2])}
+
+
+class AcceptAllEvaluator:
+    """api/sampling/evaluators/AcceptAllEvaluator.scala:22-28 — logValue is the constant 0.0 whatever the sample (every proposal
+    whose transition ratio allows it is accepted); no native call."""
+
+    def logValue(self, sample) -> float:
+        return 0.0
 
 
 def _sides(ctx, numberOfPointsForComparison, decimatedTargetPoints, numDecimatedModelPoints):

@@ -812,7 +812,8 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
           hf[(size_t)sel * B + k] = cap.finish;
           for (int q = 0; q < 5; ++q) gr.grid[q] = std::max(gr.grid[q], cap.grid[q]);
           gr.filter_prepared = gr.filter_prepared && step_filter_prepared(cap.search);
-          gr.reg_folded = cap.regression.fold[0] > 1;
+          for (int i = 0; i < cap.regression.n && i < 2; ++i)  // (any folded record of any chain: the folded kernel takes both kinds)
+            gr.reg_folded = gr.reg_folded || cap.regression.fold[i] > 1;
           m.begin_alt[sel] = gr.begin_alt.p + (size_t)sel * B + k;
           m.search_alt[sel] = gr.search_alt.p + (size_t)sel * B + k;
           m.regression_alt[sel] = gr.regression_alt.p + (size_t)sel * B + k;

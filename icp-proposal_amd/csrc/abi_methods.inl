@@ -1,6 +1,96 @@
 // abi_methods.inl — part of icp_abi.hip (one translation unit; included there, in order).
 // C ABI: per-method entry points — proposals, evaluators, deterministic fit, variability maps, metrics, icp_chain_eval_step
+namespace {
+// ---- icp_chain_bind: a whole step submitted on behalf of ONE per-method call (include/icp_proposal.h).  Scalismo's
+// MetropolisHastings.next (built at api/sampling/SamplingRegistration.scala:54) asks for a step's numbers one method at
+// a time — propose, logValue(proposal), and through MixtureProposal.logTransitionProbability (App. B2) every ICP proposal's density
+// both ways: six device round trips.  Bound, the first of these calls submits what icp_chain_step submits and parks the rest.
+thread_local int tl_bound_depth = 0;  // > 0: inside such a step — the entry points it calls itself compute as if unbound
+struct BoundStepScope {
+  BoundStepScope() { ++tl_bound_depth; }
+  ~BoundStepScope() { --tl_bound_depth; }
+};
+
+void unbind_chain(icp_evaluator* e) {
+  for (int i = 0; i < e->bind.n; ++i)
+    if (e->bind.props[i]) { e->bind.props[i]->bound_eval = nullptr; e->bind.props[i]->bound_index = -1; }
+  e->bind = icp_evaluator::ChainBinding{};
+}
+
+void park_bound_step(icp_evaluator* e, const double* cur, const double* prop, const double* fwd, const double* bwd) {
+  const size_t P = 10 + (size_t)e->ctx->r;
+  icp_evaluator::ChainBinding::Parked& k = e->bind.parked[e->bind.next];
+  e->bind.next ^= 1;
+  k.cur.assign(cur, cur + P);
+  k.prop.assign(prop, prop + P);
+  for (int i = 0; i < e->bind.n; ++i) { k.fwd[i] = fwd[i]; k.bwd[i] = bwd[i]; }
+  k.valid = true;
+}
+
+// logTransitionProbability(from, to) of bound proposal `index`, if a parked step holds it
+const double* parked_transition(icp_evaluator* e, int index, const double* from, const double* to) {
+  const size_t bytes = sizeof(double) * (10 + (size_t)e->ctx->r);
+  for (auto& k : e->bind.parked) {
+    if (!k.valid) continue;
+    if (std::memcmp(k.cur.data(), from, bytes) == 0 && std::memcmp(k.prop.data(), to, bytes) == 0) return &k.fwd[index];
+    if (std::memcmp(k.prop.data(), from, bytes) == 0 && std::memcmp(k.cur.data(), to, bytes) == 0) return &k.bwd[index];
+  }
+  return nullptr;
+}
+
+// propose() of a bound proposal: the chain's whole step with this proposal as the generator.  false: not taken (the step failed — the
+// per-method call then reports, or survives, on its own).
+bool bound_propose(icp_proposal* p, const double* theta, const double* z, double* theta_out) {
+  icp_ctx& c = *p->ctx;
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  icp_evaluator* e = p->bound_eval;
+  if (!e || c.batch_busy) return false;
+  double lv = 0.0, fwd[8], bwd[8];
+  int rc;
+  {
+    BoundStepScope _s;
+    rc = icp_chain_step(e, e->bind.n, e->bind.props, p->bound_index, theta, z, theta_out, &lv, fwd, bwd);
+  }
+  if (rc != ICP_OK && rc != ICP_ERR_EMPTY) return false;  // (EMPTY is the likelihood's: memoised with the state, logValue reports it)
+  park_bound_step(e, theta, theta_out, fwd, bwd);
+  ++e->bind.steps_from_propose;
+  return true;
+}
+}  // namespace
+
 extern "C" {
+// --------------------------------------------------------------------- chain binding
+
+int icp_chain_bind(icp_evaluator* e, int32_t n_props, icp_proposal* const* props) {
+  return guard([&] {
+    require(e != nullptr, "null argument");
+    require(n_props >= 0 && n_props <= 8 && (n_props == 0 || props), "bad proposal list");
+    icp_ctx& c = *e->ctx;
+    for (int i = 0; i < n_props; ++i) {
+      require(props[i] && props[i]->ctx == &c, "proposal belongs to another context");
+      for (int j = 0; j < i; ++j) require(props[j] != props[i], "a proposal is listed twice");
+    }
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    unbind_chain(e);
+    for (int i = 0; i < n_props; ++i) {
+      if (props[i]->bound_eval) unbind_chain(props[i]->bound_eval);  // (a proposal is a component of ONE chain's mixture)
+      props[i]->bound_eval = e;
+      props[i]->bound_index = i;
+      e->bind.props[i] = props[i];
+    }
+    e->bind.n = n_props;
+  });
+}
+
+int icp_chain_bind_stats(const icp_evaluator* e, int64_t out[3]) {
+  if (!e || !out) return ICP_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lk(e->ctx->mu);
+  out[0] = e->bind.steps_from_propose;
+  out[1] = e->bind.steps_from_log_value;
+  out[2] = e->bind.parked_hits;
+  return ICP_OK;
+}
+
 // --------------------------------------------------------------------- proposal
 
 int icp_proposal_create(icp_ctx* ctx, const icp_proposal_params* params, icp_proposal** out) {
@@ -67,6 +157,7 @@ void icp_proposal_destroy(icp_proposal* p) {
     p->ctx->front_stream.sync_quiet();
     try { sync_eigen(*p->ctx); } catch (...) {}
     DeviceQuiesce _q;
+    if (p->bound_eval) unbind_chain(p->bound_eval);
     for (icp_evaluator* ev : p->ctx->evaluators)  // a half step launched ahead with this proposal holds entries of it
       if (ev->front.valid && (ev->front.props[0] == p || ev->front.props[1] == p)) release_front(ev->front);
     if (g_host_timing.on && eigen_speculation_supported(p->ctx->r)) eigen_debug_dump(p->work.p, p->ctx->r);
@@ -111,6 +202,14 @@ int icp_proposal_set_sampler(icp_proposal* p, int32_t sampler) {
 }
 
 int icp_proposal_propose(icp_proposal* p, const double* theta, const double* z, double* theta_out, int32_t* corr_id_out) {
+  // (icp_chain_bind) the whole step in this call; a caller that also wants the correspondence ids gets them from the per-method path
+  // below — a memo hit on the posterior, the same z: the same numbers
+  if (p && p->bound_eval && tl_bound_depth == 0 && theta && z && theta_out) {
+    bool finite = true;
+    for (int i = 0; i < 10 + p->ctx->r && finite; ++i) finite = std::isfinite(theta[i]);
+    for (int j = 0; j < p->ctx->r && finite; ++j) finite = std::isfinite(z[j]);
+    if (finite && bound_propose(p, theta, z, theta_out) && !corr_id_out) return ICP_OK;
+  }
   return guard([&] {
     require(p && z && theta_out, "null argument");
     icp_ctx& c = *p->ctx;
@@ -159,6 +258,14 @@ int icp_proposal_log_transition(icp_proposal* p, const double* theta_from, const
       return;
     }
     std::lock_guard<std::recursive_mutex> lk(c.mu);
+    if (p->bound_eval && tl_bound_depth == 0) {  // (icp_chain_bind) the step that proposed `to` from `from`, or the reverse, has it
+      if (const double* v = parked_transition(p->bound_eval, p->bound_index, theta_from, theta_to)) {
+        ++p->bound_eval->bind.parked_hits;
+        if (std::isnan(*v)) fail(ICP_ERR_NOT_FINITE, "NaN transition probability");
+        *out = *v;
+        return;
+      }
+    }
     Bound _b(&c);
     PosteriorEntry& e = p->posterior(theta_from, false);  // :76
     const double* dto = c.stage(theta_to + 10, c.r);
@@ -258,6 +365,7 @@ void icp_evaluator_destroy(icp_evaluator* e) {
   (void)hipSetDevice(e->ctx->device);
   (void)hipStreamSynchronize(e->ctx->stream);
   DeviceQuiesce _q;
+  unbind_chain(e);
   // a pre-launched half step holds a state slot of the context and memo entries of its proposals
   if (e->front.valid) release_front(e->front);
   auto& evs = e->ctx->evaluators;
@@ -272,9 +380,29 @@ int icp_evaluator_log_value(icp_evaluator* e, const double* theta, double* out, 
     icp_ctx& c = *e->ctx;
     check_theta_finite(&c, theta);
     std::lock_guard<std::recursive_mutex> lk(c.mu);
-    Bound _b(&c);
-    icp_evaluator::Memo* m = eval_lookup(e, theta);  // evaluators/EvaluationCaching.scala:32-36
+    if (c.batch_busy) fail(ICP_ERR_BUSY, "the context belongs to a batch in flight (icp_chain_step_batched_issue): collect or abandon it first");
+    icp_evaluator::Memo* m = eval_lookup(e, theta);  // evaluators/EvaluationCaching.scala:32-36 (a hit touches no stream)
+    const size_t P = 10 + (size_t)c.r;
+    const bool bound = e->bind.n > 0 && tl_bound_depth == 0;
+    if (!m && bound && !e->bind.last_theta.empty() && std::memcmp(e->bind.last_theta.data(), theta, sizeof(double) * P) != 0) {
+      // (icp_chain_bind) a state made on the host — a random-walk or pose proposal — from the state of the previous logValue call
+      // (MetropolisHastings.next evaluates the current state, proposes, evaluates the proposal): the chain's whole step now
+      std::vector<double> cur(e->bind.last_theta), prop(theta, theta + P);
+      double lv = 0.0, fwd[8], bwd[8];
+      int st;
+      {
+        BoundStepScope _s;
+        st = icp_chain_step(e, e->bind.n, e->bind.props, -1, cur.data(), nullptr, prop.data(), &lv, fwd, bwd);
+      }
+      if (st == ICP_OK || st == ICP_ERR_EMPTY) {
+        park_bound_step(e, cur.data(), theta, fwd, bwd);
+        ++e->bind.steps_from_log_value;
+        m = eval_lookup(e, theta);
+      }
+    }
+    if (bound) e->bind.last_theta.assign(theta, theta + P);
     if (!m) {
+      Bound _b(&c);
       adopt_hints(e);  // (hints another chain of this model and target has filed since this context was made)
       StateSlot& s = c.state(theta);
       enqueue_eval(e, s, 0);

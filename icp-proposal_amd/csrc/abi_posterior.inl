@@ -105,6 +105,10 @@ struct icp_proposal {
   void ensure_eigen_on(PosteriorEntry& e, hipStream_t es, int part = 0);
   EigenRequest pending_rq{};
   PosteriorEntry* pending_entry = nullptr;
+  // icp_chain_bind: the evaluator of the chain this proposal is a component of, and its place in that chain's proposal list; a bound
+  // proposal's propose() submits the chain's WHOLE step and parks the values the per-method calls behind it ask for (ChainBinding)
+  icp_evaluator* bound_eval = nullptr;
+  int bound_index = -1;
   DBuf<double> work2;  // eig_stream2's (ranks above 64)
   unsigned eig_flip = 0;
   void await_eigen(PosteriorEntry& e);   // make the context stream wait for it
@@ -159,6 +163,21 @@ struct icp_evaluator {
     int status = 0;
   } memo[kEvalMemo];
   uint64_t clock = 0;
+  // icp_chain_bind (include/icp_proposal.h): the chain's ICP proposals in the caller's order, the state of the latest logValue call
+  // (MetropolisHastings.next evaluates the current state before it proposes: SURVEY App. B1), and the transition densities of the two
+  // latest whole steps submitted on behalf of a per-method call, keyed by the exact (current, proposed) vectors
+  struct ChainBinding {
+    int n = 0;
+    icp_proposal* props[8] = {};
+    std::vector<double> last_theta;  // empty: no logValue call yet
+    struct Parked {
+      bool valid = false;
+      std::vector<double> cur, prop;
+      double fwd[8] = {}, bwd[8] = {};
+    } parked[2];
+    int next = 0;
+    int64_t steps_from_propose = 0, steps_from_log_value = 0, parked_hits = 0;  // icp_chain_bind_stats
+  } bind;
 };
 
 namespace {

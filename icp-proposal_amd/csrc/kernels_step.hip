@@ -1093,7 +1093,12 @@ void launch_step_batch(hipStream_t st, int B, const StepCapture* caps, void* pin
   if (gx[2] > 0) { ProfScope _ps(st, KID_STEP_RESOLVE); hipLaunchKernelGGL(k_step_resolve_batch, dim3(gx[2], B), dim3(64), 0, st, (const StepSearchArgs*)(d + o1)); }
   if (gx[3] > 0) {
     ProfScope _ps(st, KID_STEP_REGRESSION);
-    const bool reg_folded = caps[0].regression.fold[0] > 1;  // (one policy for the launch: regression_fold)
+    // regression_fold is decided per POSTERIOR (it depends on K: a proposal of at most eight correspondences beside a larger one keeps
+    // fold = 1), the kernel per LAUNCH: the folded kernel takes records of either kind (regression_tile_fold with fold = 1 is the plain
+    // tile), the plain one would read a folded record's units as (tile, split) pairs — so any folded record selects the folded kernel
+    bool reg_folded = false;
+    for (int b = 0; b < B; ++b)
+      for (int i = 0; i < caps[b].regression.n && i < 2; ++i) reg_folded = reg_folded || caps[b].regression.fold[i] > 1;
     if (reg_folded) hipLaunchKernelGGL(k_step_regression_batch_fold, dim3(gx[3], B), dim3(kStepBlock), 0, st, (const StepRegressionArgs*)(d + o2));
     else hipLaunchKernelGGL(k_step_regression_batch, dim3(gx[3], B), dim3(kStepBlock), 0, st, (const StepRegressionArgs*)(d + o2));
   }

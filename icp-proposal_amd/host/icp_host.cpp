@@ -227,7 +227,14 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
     t_eval = std::chrono::steady_clock::now();
     ch->product.parts = {ch->prior.get(), ch->likelihood.get()};
     ch->mh.reset(new MetropolisHastings(ch->root, &ch->product));
-    if (cfg->fused) {
+    if (cfg->fused == 3) {
+      // the drop-in path as Scalismo drives it: per-method calls, every one handed to the native side, over a chain bound ONCE
+      // (icp_chain_bind: the first call of a step submits the whole step, the others find their values parked)
+      std::vector<icp_proposal*> hs;
+      for (auto* p : ch->icp) hs.push_back(p->h);
+      check(icp_chain_bind(ch->likelihood->h, (int)hs.size(), hs.data()), "icp_chain_bind");
+      ch->mh->pass_current_through = true;
+    } else if (cfg->fused) {
       ch->prefetcher.evaluator = ch->likelihood.get();
       ch->prefetcher.icp = ch->icp;
       ch->prefetcher.whole_step = cfg->fused >= 2;
@@ -237,7 +244,7 @@ int icp_host_chain_create(icp_ctx* ctx, const icp_host_chain_config* cfg, const 
     }
     ch->ahead.assign(ch->r, 0.0);
     ch->ahead2.assign(ch->r, 0.0);
-    if (cfg->fused >= 2) check(icp_ctx_set_idle_hook(ctx, &icp_host_chain::draw_ahead, ch), "icp_ctx_set_idle_hook");
+    if (cfg->fused == 2) check(icp_ctx_set_idle_hook(ctx, &icp_host_chain::draw_ahead, ch), "icp_ctx_set_idle_hook");
     ch->current.allParameters.assign(theta0, theta0 + 10 + ch->r);
     ch->logger.P = 10 + ch->r;
     ch->current_p = ch->product.logValue(ch->current);
@@ -716,6 +723,16 @@ int icp_host_chain_state(icp_host_chain* ch, double* theta_out, double* logp_out
   if (logp_out) *logp_out = ch->current_p;
   if (steps_done) *steps_done = ch->logger.index;
   if (accepted) *accepted = ch->logger.n_accept;
+  return ICP_OK;
+}
+
+int icp_host_chain_native_calls(icp_host_chain* ch, int64_t* out) {
+  if (!ch || !out) return ICP_ERR_INVALID_ARG;
+  out[0] = out[1] = 0;
+  for (auto* p : ch->icp) out[0] += p->native_calls;
+  if (ch->likelihood) out[1] = ch->likelihood->native_calls;
+  out[2] = out[3] = out[4] = 0;
+  if (ch->likelihood && ch->cfg.fused == 3) (void)icp_chain_bind_stats(ch->likelihood->h, out + 2);
   return ICP_OK;
 }
 

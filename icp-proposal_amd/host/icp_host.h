@@ -25,7 +25,9 @@ typedef struct {
   double pose_trans_sigma[3];    /* x/y/z stdevs (0.1) */
   icp_evaluator_params eval;     /* likelihood; the shape prior is always multiplied in (ProductEvaluators.scala:38-55) */
   int32_t fused;                 /* 0 = per-method calls; 1 = icp_chain_eval_step prefetch after propose; 2 = the whole step
-                                    (propose + evaluation) as ONE icp_chain_step submission */
+                                    (propose + evaluation) as ONE icp_chain_step submission; 3 = per-method calls as Scalismo's
+                                    MetropolisHastings.next makes them (every logValue handed to the native side) over a chain bound
+                                    once with icp_chain_bind — the drop-in path of INTEGRATION.md §2 */
   int32_t sampler;               /* icp_sampler of the ICP proposals: 0 = eigen (the reference's posterior.sample()), 1 = opt-in
                                     Cholesky root (same distribution, no eigen-decomposition; NOT the reference's arithmetic) */
 } icp_host_chain_config;
@@ -49,6 +51,9 @@ ICP_API int icp_host_chains_run_batched(icp_host_chain *const *chains, int32_t n
                                         double *const *records);
 ICP_API int icp_host_chain_state(icp_host_chain *chain, double *theta_out, double *logp_out, int64_t *steps_done,
                                  int64_t *accepted);
+/* per-method native calls the chain's adapters have made so far: out[0] icp_proposal_propose + icp_proposal_log_transition,
+ * out[1] icp_evaluator_log_value, out[2..4] icp_chain_bind_stats (fused = 3; else zeros) */
+ICP_API int icp_host_chain_native_calls(icp_host_chain *chain, int64_t *out /* [5] */);
 /* the chain's whole proposal mixture: MixtureProposal.logTransitionProbability(from, to) = log-sum-exp over every leaf */
 ICP_API int icp_host_chain_log_transition(icp_host_chain *chain, const double *theta_from, const double *theta_to, double *out);
 /* MixedProposalDistributions.mixedRandomPoseProposal (MixedProposalDistributions.scala:29-39) by itself — host arithmetic only, no

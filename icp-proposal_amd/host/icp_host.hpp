@@ -133,10 +133,12 @@ struct NativeLikelihoodEvaluator : DistributionEvaluator {
   double logValue(const ModelFittingParameters& sample) override {
     if (has_prefetch && prefetched_for == sample) return prefetched_value;
     double out;
+    ++native_calls;
     check(icp_evaluator_log_value(h, sample.data(), &out, nullptr), "icp_evaluator_log_value");
     return out;
   }
   icp_evaluator* h = nullptr;
+  int64_t native_calls = 0;  // icp_evaluator_log_value calls made (bench.py: calls per step of the per-method modes)
   bool has_prefetch = false;
   ModelFittingParameters prefetched_for;
   double prefetched_value = 0.0;
@@ -166,10 +168,12 @@ struct NonRigidIcpProposal : ProposalGeneratorWithTransition {  // NonRigidIcpPr
     for (auto& pf : prefetched)
       if (pf.valid && pf.from == from && pf.to == to) return pf.value;
     double out;
+    ++native_calls;
     check(icp_proposal_log_transition(h, from.data(), to.data(), &out), "icp_proposal_log_transition");
     return out;
   }
   icp_proposal* h = nullptr;
+  int64_t native_calls = 0;  // icp_proposal_propose + icp_proposal_log_transition calls made
   std::string generatedBy;
   ChainPrefetcher* stepper = nullptr;  // set: propose() submits the WHOLE step (icp_chain_step) and parks the other results
   int stepperIndex = -1;
@@ -365,6 +369,7 @@ inline ModelFittingParameters NonRigidIcpProposal::propose(const ModelFittingPar
   if (stepper) return stepper->step(stepperIndex, theta, z.data());
   ModelFittingParameters out;
   out.allParameters.resize(theta.allParameters.size());
+  ++native_calls;
   check(icp_proposal_propose(h, theta.data(), z.data(), out.allParameters.data(), nullptr), "icp_proposal_propose");
   out.generatedBy = generatedBy;  // :66
   return out;
@@ -376,7 +381,9 @@ struct MetropolisHastings {
       : generator(generator), evaluator(evaluator) {}
   ModelFittingParameters next(const ModelFittingParameters& current, const StepRandom& rnd, AcceptRejectLogger* logger,
                               bool* accepted_out = nullptr) {
-    const double currentP = have_current && cached_current == current ? cached_current_p : evaluator->logValue(current);
+    // (pass_current_through: the Scala adapters hand EVERY logValue to the native side, whose Memoize(3) answers for the current state
+    // — bindings/scala/api/gpu/GpuLikelihoodEvaluator.scala; a chain bound with icp_chain_bind relies on seeing that call)
+    const double currentP = !pass_current_through && have_current && cached_current == current ? cached_current_p : evaluator->logValue(current);
     ModelFittingParameters proposal = generator->propose(current, rnd, 0);
     if (prefetcher) prefetcher->prefetch(current, proposal);
     const double proposalP = evaluator->logValue(proposal);
@@ -397,6 +404,7 @@ struct MetropolisHastings {
   ProposalGeneratorWithTransition* generator;
   DistributionEvaluator* evaluator;
   ChainPrefetcher* prefetcher = nullptr;
+  bool pass_current_through = false;
   // the reference gets this from Memoize(computeLogValue, 3) (evaluators/EvaluationCaching.scala:32)
   bool have_current = false;
   ModelFittingParameters cached_current;

@@ -42,6 +42,8 @@ def host_lib():
         L.icp_host_chains_run_batched.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.POINTER(nat.c_double_p)]
         L.icp_host_chain_state.restype = C.c_int
         L.icp_host_chain_state.argtypes = [C.c_void_p, nat.c_double_p, nat.c_double_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.icp_host_chain_native_calls.restype = C.c_int
+        L.icp_host_chain_native_calls.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.icp_host_chain_destroy.restype = None
         L.icp_host_chain_destroy.argtypes = [C.c_void_p]
         L.icp_host_last_error.restype = C.c_char_p
@@ -109,7 +111,9 @@ class ChainSetup:
         self.pose_rot_sigma = (0.01, 0.01, 0.01)
         self.pose_trans_sigma = (0.1, 0.1, 0.1)
         self.eval = dict(kind=0, mode=0, n_model_ids=0, target_pts=np.zeros((0, 3)), gauss_mean=0.0, gauss_sigma=1.0, exp_rate=1.0)
-        self.fused = 2  # 0 per-method calls, 1 icp_chain_eval_step prefetch, 2 whole step in one icp_chain_step submission
+        # 0 per-method calls, 1 icp_chain_eval_step prefetch, 2 whole step in one icp_chain_step submission, 3 per-method calls as
+        # Scalismo's MetropolisHastings.next makes them over a chain bound with icp_chain_bind (the drop-in path)
+        self.fused = 2
         self.sampler = "eigen"  # or "cholesky-root" (opt-in, not the reference's arithmetic: NonRigidIcpProposal.setSampler)
 
     @staticmethod
@@ -284,6 +288,13 @@ class SamplingRegistration:
         if st != 0:
             raise nat.IcpNativeError(st, "icp_host_chain_log_transition", (host_lib().icp_host_last_error() or b"").decode())
         return out.value
+
+    def native_calls(self) -> dict:
+        """Per-method native calls the chain's adapters have made (fused = 0 / 3: what a Scalismo-driven chain costs at the boundary)."""
+        out = (C.c_int64 * 5)()
+        host_lib().icp_host_chain_native_calls(self.h, out)
+        return {"proposal_calls": int(out[0]), "log_value_calls": int(out[1]), "bound_steps_from_propose": int(out[2]),
+                "bound_steps_from_log_value": int(out[3]), "parked_transition_hits": int(out[4])}
 
     def state(self):
         theta = np.zeros(self.P)

@@ -333,6 +333,31 @@ ICP_API int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator *const 
 ICP_API int icp_chain_step_batched_collect(icp_step_ticket *ticket);
 ICP_API int icp_chain_step_batched_abandon(icp_step_ticket *ticket);
 
+/* ---------------------------------------------------------------- the per-method entry points as ONE submission per step (round 6)
+ * The drop-in contract is "Scalismo's chain, unchanged": MetropolisHastings.next (constructed at
+ * api/sampling/SamplingRegistration.scala:52-58) calls  logValue(current) [memoised] → propose(current) → logValue(proposal) →
+ * logTransitionRatio(current, proposal), and the MixtureProposal of api/sampling/MixedProposalDistributions.scala:48-68 turns the last
+ * into logTransitionProbability(current, proposal) and (proposal, current) of EVERY ICP proposal (App. B2): with two ICP proposals six
+ * device round trips per step where icp_chain_step has one.  A caller that cannot change that loop binds the chain's likelihood
+ * evaluator and its ICP proposals (in the mixture's order) ONCE.  From then on
+ *   - icp_proposal_propose of a bound proposal submits the WHOLE step — what icp_chain_step submits: the proposal, the proposed state's
+ *     instance, its searches, every bound proposal's posterior there, the likelihood, all transition densities both ways — and returns
+ *     when it is complete;
+ *   - icp_evaluator_log_value of the bound evaluator for a state it has no value for (a random-walk or pose proposal made on the host)
+ *     submits the same with the state of the PREVIOUS icp_evaluator_log_value call as the current state (MetropolisHastings.next evaluates
+ *     the current state before it proposes; the Scala adapter passes every logValue through);
+ *   - the calls that follow — logValue(proposal), logTransitionProbability(current, proposal), (proposal, current) — find their values
+ *     on the host: the likelihood in the evaluator's Memoize(3), the densities parked under the exact (from, to) vectors of the two
+ *     latest such steps.  Any other argument computes as before.
+ * Values are those of the unbound calls, bit for bit (same device code, same caches; tests/test_gpu_dropin.py).  A bound step that
+ * fails leaves the per-method call to compute — and report — on its own.  A proposal belongs to one binding at a time (binding it
+ * again moves it); destroying a member dissolves the binding.  n_props == 0 unbinds.  Not for a caller that evaluates unrelated states
+ * through the bound evaluator: every unseen state costs a whole step from the previous one. */
+ICP_API int icp_chain_bind(icp_evaluator *e, int32_t n_props, icp_proposal *const *props);
+/* out[0] whole steps submitted by icp_proposal_propose, out[1] by icp_evaluator_log_value, out[2] transition densities answered from
+ * a parked step, since the binding was made. */
+ICP_API int icp_chain_bind_stats(const icp_evaluator *e, int64_t out[3]);
+
 /* ---------------------------------------------------------------- the whole Metropolis–Hastings loop on the device
  * n_steps steps of n_chains independent chains WITHOUT a host round trip per step: beside the five merged launches of
  * icp_chain_step_batched, a small kernel at the head of every step draws the mixture component and makes the step's proposal input
