@@ -6,7 +6,7 @@ The directory name carries a hyphen (it mirrors the reference repository's name)
 from . import data  # noqa: F401
 from . import _native  # noqa: F401
 from .api import *  # noqa: F401,F403
-from .api import (BatchedStepTicket, chain_eval_step, chain_step, chain_step_batched, chain_step_prelaunch, initial_parameters, posterior_variability,
+from .api import (BatchedStepTicket, expect_contexts, chain_eval_step, chain_step, chain_step_batched, chain_step_prelaunch, initial_parameters, posterior_variability,
                   evaluate_reconstruction_to_ground_truth)  # noqa: F401
 from . import sampling  # noqa: F401
 from .sampling import (SamplingRegistration, ChainSetup, femur_icp_proposal_registration, femur_random_init_comparison,

@@ -69,6 +69,7 @@ SIGNATURES = {
     "icp_ctx_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(MeshDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "icp_ctx_create_keyed": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(MeshDesc), C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
     "icp_ctx_destroy": (None, [C.c_void_p]),
+    "icp_ctx_expect": (C.c_int, [C.c_int, C.c_int32]),
     "icp_ctx_set_target": (C.c_int, [C.c_void_p, C.POINTER(MeshDesc)]),
     "icp_status_string": (C.c_char_p, [C.c_int]),
     "icp_last_error": (C.c_char_p, []),

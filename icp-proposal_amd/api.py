@@ -90,8 +90,8 @@ _model_keys = itertools.count(1)
 def _model_key(model) -> int:
     """icp_ctx_create_keyed's model_key: taken ONCE per model object — a content hash of the basis (xxhash, ≈ 10 ms for the face
     model's 137 MB) where that is importable, the object's number otherwise — so that the contexts of a batch registration (one per
-    chain) do not each hash the basis again (6.6 ms per context).  A model whose arrays are changed in place afterwards needs a new
-    StatisticalMeshModel object."""
+    chain) do not each hash the basis again (6.6 ms per context).  The model's arrays are made read-only when the key is taken: a
+    changed model is a new StatisticalMeshModel object (and a new key)."""
     key = getattr(model, "_icp_model_key", None)
     if key is None:
         try:
@@ -104,9 +104,18 @@ def _model_key(model) -> int:
             key = (next(_model_keys) << 20) | 0x5A5A5
         try:
             model._icp_model_key = key
+            # the key vouches for these arrays (icp_ctx_create_keyed: "equal keys mean equal arrays"): an in-place edit after this
+            # point would silently meet the stale device copy, so the arrays are frozen — a changed model is a new object
+            for arr in (model.basis, model.variance, model.ref_points, model.mean_def, model.cells):
+                arr.flags.writeable = False
         except Exception:
             pass
     return key
+
+
+def expect_contexts(device: int, n_contexts: int) -> None:
+    """icp_ctx_expect: a host about to make n_contexts contexts on `device` (−1: LOCAL_RANK) lets their streams be made ahead."""
+    nat.check(nat.lib().icp_ctx_expect(int(device), int(n_contexts)), "icp_ctx_expect")
 
 
 class IcpContext:

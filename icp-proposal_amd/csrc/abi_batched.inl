@@ -76,7 +76,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
         c.front_stream_used = false;
       }
       if (!chain_step_covered(it.e, n_props, it.props, it.generator, theta_cur[b], theta_prop[b])) {
-        // what the five merged launches do not cover takes the wide step (open targets, the Hausdorff evaluator, ranks up to 200, pose
+        // what the five merged launches do not cover takes the wide step (open targets, the Hausdorff evaluator, ranks up to 256, pose
         // moves), side by side with the other such chains of the batch that share the first one's model
         const bool same_model = wide_first < 0 || items[wide_first].e->ctx->Qp.p == c.Qp.p;
         if (!step_pipeline_covers(it.e, n_props, it.props) && same_model &&

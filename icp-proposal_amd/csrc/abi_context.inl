@@ -60,6 +60,19 @@ const char* icp_last_error(void) { return g_err.c_str(); }
 int icp_ctx_rank(const icp_ctx* ctx) { return ctx ? ctx->r : ICP_ERR_INVALID_ARG; }
 int icp_ctx_device(const icp_ctx* ctx) { return ctx ? ctx->device : ICP_ERR_INVALID_ARG; }
 
+int icp_ctx_expect(int device, int32_t n_contexts) {
+  return guard([&] {
+    require(n_contexts >= 0, "negative count");
+    if (device < 0) {
+      const char* lr = std::getenv("LOCAL_RANK");
+      device = lr ? std::atoi(lr) : 0;
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device >= n_dev) fail(ICP_ERR_DEVICE, "no such HIP device");
+    prewarm_streams(device, std::min(n_contexts, 64));
+  });
+}
+
 int icp_ctx_create(const icp_model_desc* model, const icp_mesh_desc* target, int device, icp_ctx** out) {
   return icp_ctx_create_keyed(model, target, device, 0, out);
 }
@@ -165,8 +178,6 @@ int icp_ctx_create_keyed(const icp_model_desc* model, const icp_mesh_desc* targe
     const SharedKey mkey{device, N, T, r, mh};
     std::shared_ptr<SharedModel> sm = g_shared_models[mkey].lock();
     if (!sm) {
-      // (the first context of a model the caller will make many contexts of: their streams are made meanwhile — abi_pools.inl)
-      if (model_key != 0) prewarm_streams(device, 24);
       sm = std::make_shared<SharedModel>();
       sm->device = device;
       static uint64_t next_uid = 0;  // (under g_shared_mu)

@@ -1,7 +1,7 @@
 // abi_device_loop.inl — part of icp_abi.hip (one translation unit; included there, in order).
 // C ABI: icp_chains_run_on_device (the whole MH loop on the device) and the remaining queries
 // --------------------------------------------------------------------- the whole MH loop on the device, WIDE step (MhWide)
-// Chains whose step is the wide one (open targets, the Hausdorff evaluator, ranks 65..200: apps/bfm/BfmFittingPartial.scala:62-96,
+// Chains whose step is the wide one (open targets, the Hausdorff evaluator, ranks 65..256: apps/bfm/BfmFittingPartial.scala:62-96,
 // apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala at rank 101).  Per step the wide step's own launches, from records that live
 // in device memory and are the same every step: the current state's posteriors stay in the entries they are in — an accepted state's
 // M, alpha, coefficients and correspondence records are copied there (k_mhw_adopt) —, the proposed state always has the same slot and
@@ -101,7 +101,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
       t_phase = now;
     };
     require(jacobi || (eigen_tridiag_many_supported(r) && !root),
-            "the on-device loop of the wide step covers ranks 3..200 (the Cholesky-root sampler up to rank 64)");
+            "the on-device loop of the wide step covers ranks 3..256 (the Cholesky-root sampler up to rank 64)");
     // ---- claim the chains' contexts; the current state's posteriors and their bases, the ordinary way
     for (int b = 0; b < n_chains; ++b) {
       Chain& ch = chains[b];
@@ -123,6 +123,10 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
       if (mix->w_pose > 0.0)
         require(c.rotations_mismatched == 0, "pose walks on the device: a caller-supplied rotation matrix disagreed with the library's Rz·Ry·Rx (icp_ctx_rotation_convention)");
       Bound _b(&c);
+      // the context is this run's from here on (as the merged loop claims it): between this point and the captured step the locks are
+      // released and taken again, and another thread's call on the context must be refused, not let in (release() clears the mark)
+      c.batch_busy = true;
+      ch.busy = true;
       if (ch.e->front.valid) release_front(ch.e->front);
       for (int i = 0; i < n_props; ++i) {
         icp_proposal* p = ch.props[i];
@@ -145,7 +149,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
       Chain& ch = chains[b];
       icp_ctx& c = *ch.e->ctx;
       std::lock_guard<std::recursive_mutex> lk(c.mu);
-      Bound _b(&c);
+      Bound _b(&c, false, true);
       HIP_OK(hipStreamSynchronize(c.stream));
       c.front_stream.sync();
       sync_eigen(c);
@@ -182,6 +186,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
       if (jacobi) gr.st = g == 0 ? lead.stream : g == 1 ? lead.front_stream.get() : lead.eig_stream.get();
       else {
         icp_ctx& gc = *chains[gr.b0].e->ctx;
+        std::lock_guard<std::recursive_mutex> glk(gc.mu);  // (LazyStream::get makes the stream on first use: not without the context's lock)
         gr.st = gc.stream;
         gr.side[0] = gc.front_stream.get(); gr.side[1] = gc.eig_stream.get(); gr.side[2] = gc.eig_stream2.get();
         HIP_OK(hipEventCreateWithFlags(&gr.ev_sum, hipEventDisableTiming));
@@ -212,7 +217,9 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
       for (int k = 0; k < B; ++k)  // (entries of a chain that is filled below: not to be handed out as another's proposed-state entry)
         if (chains[gr.b0 + k].unfilled)
           for (int i = 0; i < n_props; ++i)
-            if (PosteriorEntry* en = chains[gr.b0 + k].props[i]->find_entry(theta[gr.b0 + k])) { en->valid = false; en->eig_valid = false; }
+            if (PosteriorEntry* en = chains[gr.b0 + k].props[i]->find_entry(theta[gr.b0 + k])) {
+              en->valid = false; en->eig_valid = false; en->eig_checked = false; en->eig_event_valid = false; en->done_value = 0;
+            }
       gr.cap.allow_unfilled = !jacobi;
       wide_issue(t, glead, glead, &gr.cap);
       WideCapture& cap = gr.cap;
@@ -227,8 +234,6 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           require(w.ec[i] && w.ec[i] == ch.cur[i] && w.ep[i] && w.ep[i] != w.ec[i], "internal: captured wide step lost the current state's posterior");
           ch.cur[i]->reserved = true;
         }
-        ch.e->ctx->batch_busy = true;
-        ch.busy = true;
       }
       locks.clear();
       lead.bind();
@@ -310,7 +315,6 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
               ad.corr_from[u] = (const unsigned char*)from[u]; ad.corr_to[u] = (unsigned char*)to[u];
               ad.corr_bytes[u] = (from[u] && to[u]) ? (int)bytes[u] : 0;
             }
-            require(bytes[2] / 8 + 1 <= (size_t)r * r || K == 0, "internal: correspondence records larger than the adopt launch");
           }
           had[(size_t)k * n_props + i] = ad;
           hrec[(size_t)k * n_props + i] = ep;

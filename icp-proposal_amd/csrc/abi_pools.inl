@@ -250,32 +250,36 @@ void device_free(void* p, size_t bytes) {
   (void)hipFree(p);
 }
 
-// A host that announces many contexts of one model (icp_ctx_create_keyed) gets its later contexts' streams made AHEAD, by a helper
-// thread, while the first context's one-off host work (the model's Gram matrix and factorisations: ≈ 0.5 s at the face model's size)
-// keeps the calling thread busy: hipStreamCreateWithPriority takes 2.4 ms, three quarters of what a further context costs.  Streams of
-// the default priority class (what every context after the first takes), straight into the pool; at most once per device.
+// A host that is about to make MANY contexts announces it (icp_ctx_expect): their streams are made AHEAD, by a helper thread, while the
+// first context's one-off host work (the model's Gram matrix and factorisations: ≈ 0.5 s at the face model's size) keeps the calling
+// thread busy: hipStreamCreateWithPriority takes 2.4 ms, three quarters of what a further context costs.  Streams of the default
+// priority class (what every context after the first takes), straight into the pool.  Only on that explicit hint (round 6: until then
+// the first keyed context of every model did it — also for the one-chain-per-GPU layout, 24 streams nobody would use).
 struct StreamPrewarm {
   std::mutex mu;
   std::thread worker;
-  bool done[ResourcePool::kDevices] = {};
+  std::atomic<bool> stop{false};
   void join() {
     std::lock_guard<std::mutex> lk(mu);
     if (worker.joinable()) worker.join();
   }
-  ~StreamPrewarm() { if (worker.joinable()) worker.join(); }
+  // (process exit: the worker is told to stop between two streams and waited for, so that it is not inside the runtime afterwards)
+  ~StreamPrewarm() { stop.store(true); if (worker.joinable()) worker.join(); }
 };
 StreamPrewarm g_prewarm;
 void prewarm_streams(int device, int n) {
-  if (!g_pool.on || device < 0 || device >= ResourcePool::kDevices) return;
+  if (!g_pool.on || device < 0 || device >= ResourcePool::kDevices || n <= 0) return;
   static const bool off = std::getenv("ICP_NO_STREAM_PREWARM") != nullptr;  // (operational switch)
   if (off) return;
   std::lock_guard<std::mutex> lk(g_prewarm.mu);
-  if (g_prewarm.done[device]) return;
-  g_prewarm.done[device] = true;
   if (g_prewarm.worker.joinable()) g_prewarm.worker.join();
   g_prewarm.worker = std::thread([device, n] {
     if (hipSetDevice(device) != hipSuccess) return;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n && !g_prewarm.stop.load(std::memory_order_relaxed); ++i) {
+      {  // (never more than the hint asks for, counting what the pool already holds)
+        std::lock_guard<std::mutex> plk(g_pool.mu);
+        if ((int)g_pool.streams[device][0].size() >= std::min(n, (int)ResourcePool::kStreamsPerClass)) return;
+      }
       hipStream_t s = nullptr;
       if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, 0) != hipSuccess) return;
       std::lock_guard<std::mutex> plk(g_pool.mu);

@@ -241,7 +241,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead, WideCapture* 
     const double* theta_cur = t.theta_cur[idx[k]];
     double* theta_prop = t.theta_prop[idx[k]];
     const int generator = it.generator;
-    Bound _b(&c, true);
+    Bound _b(&c, true, capture != nullptr);  // (a captured step belongs to a run that has claimed its contexts already)
     w = WideItem{};
     w.on = true;
     if (!e->last_prop.empty() && !capture) {  // did the caller keep the state the previous step proposed?

@@ -273,7 +273,7 @@ void launch_posterior_eigen(hipStream_t st, int r, const double* M, const double
                             double* Vt, double* S, double* work /* eigen_work_doubles(r) */, int* status,
                             const EigenSpec* spec = nullptr, int* host_status = nullptr /* pinned copy of *status; honoured
                             when eigen_speculation_supported(r) */,
-                            int part = 0 /* 0: every launch; 1: the reduction to tridiagonal form only (ranks 65..200: the long
+                            int part = 0 /* 0: every launch; 1: the reduction to tridiagonal form only (ranks 65..256: the long
                             one-workgroup launch at the head of the chain), 2: the launches behind it — a caller with other work
                             to issue puts it between the two (a launch costs the host 3-6 µs, the chain has eleven) */);
 
@@ -543,7 +543,7 @@ void launch_step_batch_resident(hipStream_t st, int B, const int grid[5], int r,
 // ---- the wide step (kernels_wide.hip): one Metropolis–Hastings step of B chains for the configurations the five merged launches
 // above do not cover — targets WITH boundary (the nearest-vertex pass of NonRigidIcpProposal.scala:98-99 and of
 // CollectiveAverageHausdorffDistanceBoundaryAwareEvaluator.scala:44-63 as a second filter/resolve stage), the full-mesh Hausdorff
-// evaluator (HausdorffDistanceEvaluator.scala:31-35), ranks up to 200 (factorisation, tails and decomposition as launches of their own:
+// evaluator (HausdorffDistanceEvaluator.scala:31-35), ranks up to 256 (factorisation, tails and decomposition as launches of their own:
 // none of them fits the one-workgroup finish launch), pose moves (PoseProposals.scala:31-90: the instance is the kept deformations
 // under the new pose).  Same device bodies as the per-stage kernels, no host round trip inside the step, B chains side by side:
 //
@@ -632,7 +632,7 @@ int wide_prep_grid(const WidePrepArgs& a);
 void launch_wide_done(hipStream_t st, const WideDoneArgs& a);
 // Σ of the split-K partials of n posteriors into their first partial (as launch_sum_partials)
 void launch_sum_partials_many(hipStream_t st, int r, int n, double* const* Mpart, const int* splits);
-// the tridiagonal route (ranks 65..200) for n decompositions side by side; assemble != 0: M = I + summed partial is written first
+// the tridiagonal route (ranks 65..256) for n decompositions side by side; assemble != 0: M = I + summed partial is written first
 // (launch_assemble_posterior_matrix) from rq[i].spec... no: from `parts[i]`.  Every request needs its own `work`.  No Jacobi fall-back
 // inside the sequence: a spectrum the multisection cannot separate ends with status 2 in the request's status words, and the caller
 // decomposes that posterior again through launch_posterior_eigen.

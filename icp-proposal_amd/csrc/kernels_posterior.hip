@@ -643,10 +643,14 @@ __global__ void __launch_bounds__(1024) k_transition_tail_direct(int r, const do
 __global__ void __launch_bounds__(1024) k_posterior_eigen(int r, const double* __restrict__ M, const double* __restrict__ sqrt_lambda,
                                                            const double* __restrict__ Vwarm, double* __restrict__ Vout,
                                                            double* __restrict__ Vtout, double* __restrict__ Sout,
-                                                           double* __restrict__ work, int* __restrict__ status, int a_in_lds, int v_in_lds) {
+                                                           double* __restrict__ work, int* __restrict__ status, int a_in_lds, int v_in_lds,
+                                                           const int* __restrict__ gate = nullptr) {
   __shared__ double s_red[16], s_mu[512], s_sgn[512], s_c[256], s_s[256];
   __shared__ int s_rank[512];
   __shared__ short s_p[256], s_q[256];
+  // (as the tridiagonal route's fall-back above rank 200, where the in-place kernel's triangle no longer fits a CU's LDS: runs only if
+  // the multisection could not separate the spectrum — status 2)
+  if (gate && gate[0] != 2) return;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int lda = a_in_lds ? (r | 1) : r, ldv = v_in_lds ? (r | 1) : r;
   double* A = a_in_lds ? s_dyn : work;
@@ -2179,7 +2183,10 @@ void launch_posterior_factor(hipStream_t st, int r, int n_post, const PosteriorF
       set_dyn_lds((const void*)k_posterior_factor_tiles<4>, shmem);
       hipLaunchKernelGGL(k_posterior_factor_tiles<4>, dim3(n_post, 1 + kFactorAsmGroups), dim3(1024), shmem, st, r, fa);
     }
-  } else if (r <= kCholMaxRank) {  // blocked, matrix in `scratch`, block columns through LDS
+  } else if (r <= kCholMaxRank && sizeof(double) * ((size_t)kCholNB * (kCholNB + 1) + (size_t)(r + 1) * (kCholNB + 1)) <= (size_t)147 * 1024) {
+    // blocked, matrix in `scratch`, block columns through LDS — while the panel fits beside the kernel's 13 KB of static arrays (ranks up
+    // to 224; round 6: ranks 253..256, past the register tiles' 4,096, used to come here with 166 KB of dynamic LDS — a launch that
+    // fails, M never written —: they take the generic kernel below)
     const size_t shmem = sizeof(double) * ((size_t)kCholNB * (kCholNB + 1) + (size_t)(r + 1) * (kCholNB + 1));
     static size_t lds_granted = 0;
     if (shmem > lds_granted) { set_dyn_lds((const void*)k_posterior_factor_blocked, shmem); lds_granted = shmem; }
@@ -2235,7 +2242,8 @@ static size_t jacobi_work_doubles(int r) {
   return log + n2 * 64 + 128 + 256;  // fixed-position variant: log + correction + meta (see launch_eigen_rr)
 }
 // the tridiagonal route's part of `work`, behind the Jacobi kernels': d | e | beta | mu | sync words | reflectors
-constexpr int kTriMaxRank = 200;
+// (round 6: 208 — the reference's own largest model, femur_gp_model_200-components.h5, has 201 components: apps/femur/CreateGPModel.scala:93)
+constexpr int kTriMaxRank = 256;  // = tri::kTriMaxN: four row slots of 64
 static size_t tri_work_doubles(int r) { return r <= kTriMaxRank ? 4 * (size_t)tri::kTriMaxN + 8 + (size_t)r * 256 : 0; }
 size_t eigen_work_doubles(int r) { return jacobi_work_doubles(r) + tri_work_doubles(r); }  // `work` of launch_posterior_eigen
 
@@ -2265,7 +2273,9 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
     if (r <= 64) hipLaunchKernelGGL((tri::k_tridiag<4, 1, 16, 0>), dim3(1), dim3(256), 0, st, ti);
     else if (r <= 128) hipLaunchKernelGGL((tri::k_tridiag<4, 2, 32, 0>), dim3(1), dim3(256), 0, st, ti);
     else if (r <= 192) hipLaunchKernelGGL((tri::k_tridiag<8, 3, 24, 0>), dim3(1), dim3(512), 0, st, ti);
-    else hipLaunchKernelGGL((tri::k_tridiag<8, 4, 25, 7>), dim3(1), dim3(512), 0, st, ti);
+    else if (r <= 200) hipLaunchKernelGGL((tri::k_tridiag<8, 4, 25, 7>), dim3(1), dim3(512), 0, st, ti);
+    else if (r <= 208) hipLaunchKernelGGL((tri::k_tridiag<8, 4, 26, 6>), dim3(1), dim3(512), 0, st, ti);
+    else hipLaunchKernelGGL((tri::k_tridiag<8, 4, 32, 0>), dim3(1), dim3(512), 0, st, ti);
   }
   if (part == 1) return;
   // (ranks above 64: the T factors by the solve launch's own trailing workgroups — tri_solve_or_wy)
@@ -2273,7 +2283,11 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   if (r <= 64) hipLaunchKernelGGL(tri::k_tri_solve<1>, dim3(nwg), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
   else if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve<2>, dim3(nwg + nwy), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
   else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve<3>, dim3(nwg + nwy), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
-  else hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg + nwy), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
+  else {
+    static bool lds_set = false;  // (above rank 201 the launch's dynamic LDS passes 48 KiB: 61 KiB at rank 256)
+    set_dyn_lds_once((const void*)tri::k_tri_solve<4>, tri::tri_solve_lds_bytes(tri::kTriMaxN), &lds_set);
+    hipLaunchKernelGGL(tri::k_tri_solve<4>, dim3(nwg + nwy), dim3(256), tri::tri_solve_lds_bytes(r), st, so, so);
+  }
   if (r > 64) {  // (ranks above 64: the back-transformation is a launch of its own, sixteen eigenvectors per wave on the matrix cores)
     const tri::TriBackIO bk{r, Hv, R, X, Xt, status, sync};
     const int nb16 = (r + 15) / 16;
@@ -2293,7 +2307,10 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
   // eigenvalues that multisection could not tell apart (status 2: a spectrum with (near-)multiple eigenvalues, e.g. a posterior without
   // correspondences over a model with equal variances): the Jacobi iteration takes over, cold, in the same stream — its launches
   // return at once otherwise
-  if (r > 64) launch_eigen_big(st, r, M, sqrt_lambda, nullptr, V, Vt, S, work, status, nullptr, status);
+  if (r > 64 && r <= kBigMaxRank) launch_eigen_big(st, r, M, sqrt_lambda, nullptr, V, Vt, S, work, status, nullptr, status);
+  else if (r > kBigMaxRank)  // (matrix behind L2: `work`'s head, whose refinement matrices a failed multisection has no use for)
+    hipLaunchKernelGGL(k_posterior_eigen, dim3(1), dim3(1024), 0, st, r, M, sqrt_lambda, (const double*)nullptr, V, Vt, S, work, status, 0, 0,
+                       (const int*)status);
   if (host_status || done_word) hipLaunchKernelGGL(tri::k_tri_done, dim3(1), dim3(1), 0, st, (const int*)status, host_status, done_word, done_value);
 }
 
@@ -2342,12 +2359,18 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
     if (assemble) hipLaunchKernelGGL(tri::k_assemble_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, am, skip);
     if (r <= 128) hipLaunchKernelGGL((tri::k_tridiag_many<4, 2, 32, 0>), dim3(n), dim3(256), 0, st, tm, skip);
     else if (r <= 192) hipLaunchKernelGGL((tri::k_tridiag_many<8, 3, 24, 0>), dim3(n), dim3(512), 0, st, tm, skip);
-    else hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 25, 7>), dim3(n), dim3(512), 0, st, tm, skip);
+    else if (r <= 200) hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 25, 7>), dim3(n), dim3(512), 0, st, tm, skip);
+    else if (r <= 208) hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 26, 6>), dim3(n), dim3(512), 0, st, tm, skip);
+    else hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 32, 0>), dim3(n), dim3(512), 0, st, tm, skip);
     const int nwy = (r - 2 + tri::kWyBlock - 1) / tri::kWyBlock;
     // (the reflector blocks' T factors: the solve launch's trailing workgroups — tri_solve_or_wy)
     if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg + nwy, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
     else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_solve_many<3>, dim3(nwg + nwy, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
-    else hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg + nwy, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
+    else {
+      static bool lds_set = false;
+      set_dyn_lds_once((const void*)tri::k_tri_solve_many<4>, tri::tri_solve_lds_bytes(tri::kTriMaxN), &lds_set);
+      hipLaunchKernelGGL(tri::k_tri_solve_many<4>, dim3(nwg + nwy, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);
+    }
     if (r <= 128) hipLaunchKernelGGL(tri::k_tri_back_many<2>, dim3(nt, n), dim3(256), 0, st, bm, skip);
     else if (r <= 192) hipLaunchKernelGGL(tri::k_tri_back_many<3>, dim3(nt, n), dim3(256), 0, st, bm, skip);
     else hipLaunchKernelGGL(tri::k_tri_back_many<4>, dim3(nt, n), dim3(256), 0, st, bm, skip);

@@ -1012,12 +1012,16 @@ __global__ void __launch_bounds__(256) k_mhw_adopt(int r, const MhAdopt* __restr
     if (e < r) a.S_to[e] = a.S_from[e];
     if (e == 0) a.st_to[0] = a.st_from[0];
   }
+  // (grid-stride: the grid is sized by r², a posterior's correspondence records by K — 3K + 1 words may be more than r² threads)
+  const int stride = gridDim.x * 256;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const int nb = a.corr_bytes[k], nw = nb >> 3;
-    if (e < nw) ((unsigned long long*)a.corr_to[k])[e] = ((const unsigned long long*)a.corr_from[k])[e];
-    if (e == nw)
-      for (int t = 8 * nw; t < nb; ++t) a.corr_to[k][t] = a.corr_from[k][t];
+    for (int w = e; w <= nw; w += stride) {
+      if (w < nw) ((unsigned long long*)a.corr_to[k])[w] = ((const unsigned long long*)a.corr_from[k])[w];
+      else
+        for (int t = 8 * nw; t < nb; ++t) a.corr_to[k][t] = a.corr_from[k][t];
+    }
   }
 }
 

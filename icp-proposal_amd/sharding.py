@@ -163,6 +163,8 @@ def run_batch(pkg, model, targets, n_chains: int, n_steps: int, make_setup, dist
         # buffers; the model's device data is shared) are made ONCE and handed from target to target (icp_ctx_set_target): a context
         # costs 20+ ms to make and as much to destroy.
         order = sorted(mine)
+        # (the streams of the contexts to come are made by a helper thread while the first context does the model's one-off host work)
+        pkg.expect_contexts(device_index, min(len(order), chains_per_launch))
         for g0 in range(0, len(order), chains_per_launch):
             group = order[g0:g0 + chains_per_launch]
             tp = time.perf_counter()

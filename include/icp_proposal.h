@@ -131,9 +131,14 @@ ICP_API int icp_ctx_create(const icp_model_desc *model, const icp_mesh_desc *tar
  * device made from the same model share its device data; icp_ctx_create recognises the model by hashing its arrays — 137 MB of basis at
  * the face model's size, 6.6 ms per context.  model_key != 0: the caller vouches that equal keys mean equal model arrays (an object
  * id, a hash taken once); the library then hashes the key, the small arrays and a sample of the basis only (0.3 ms), and while the FIRST
- * context of a keyed model does its one-off host work a helper thread makes two dozen streams for the contexts to come
- * (hipStreamCreateWithPriority: 2.4 ms each; ICP_NO_STREAM_PREWARM=1: not).  0 = icp_ctx_create. */
+ * context of a keyed model does its one-off host work, the streams of the contexts to come can be made by a helper thread
+ * (icp_ctx_expect; hipStreamCreateWithPriority: 2.4 ms each; ICP_NO_STREAM_PREWARM=1: not).  0 = icp_ctx_create. */
 ICP_API int icp_ctx_create_keyed(const icp_model_desc *model, const icp_mesh_desc *target, int device, uint64_t model_key, icp_ctx **out);
+/* Optional hint of a host that is about to make n_contexts contexts on `device` (one per chain of a batch registration, one per chain
+ * thread of a `.par` experiment): their streams — three quarters of what a further context costs — are made ahead by a helper thread
+ * while the caller's first icp_ctx_create_keyed does the model's one-off host work.  Never changes results; at most 64 are made; a
+ * host with one chain per GPU simply does not call it (until round 6 every first keyed context made two dozen unasked). */
+ICP_API int icp_ctx_expect(int device, int32_t n_contexts);
 ICP_API void icp_ctx_destroy(icp_ctx *ctx);
 /* Gives the context ANOTHER target mesh and keeps everything that does not depend on the target — the model's device data, the
  * per-chain scratch, streams, pinned buffers: a batch registration (one statistical model against many targets:
@@ -378,7 +383,8 @@ ICP_API int icp_chain_bind_stats(const icp_evaluator *e, int64_t out[3]);
  * Covered (one context per chain, one device, one rank and sampler per run; otherwise ICP_ERR_INVALID_ARG and nothing has run):
  *   - what the five merged launches cover at ranks <= 64 (closed target or no boundary-aware branch): their launches, from
  *     device-resident records that change roles when a state is accepted;
- *   - (round 5) everything the WIDE step covers — targets with a boundary, the full-mesh Hausdorff evaluator, ranks up to 200, the femur
+ *   - (round 5) everything the WIDE step covers — targets with a boundary, the full-mesh Hausdorff evaluator, ranks up to 256 (round 6;
+ *     200 until then: the reference's femur_gp_model_200-components.h5 has 201 components), the femur
  *     mixture at ranks 65..116 (apps/bfm/BfmFittingPartial.scala:62-96, apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala) — with
  *     the chains of a run sharing one model: the wide step's own launches replayed from device-resident records, an accepted state's
  *     posterior copied into the current state's entries; above rank 64 the proposed state is decomposed ahead of the decision, beside
@@ -437,7 +443,7 @@ ICP_API int icp_ctx_runtime_stats(const icp_ctx *ctx, icp_runtime_stats *out);
 
 /* ---- which path the chain steps took (diagnostic: the results do not depend on it).  Counts since the context was created or, with
  * ctx == NULL, of the process: out[0] the five merged launches (icp_chain_step[_batched]), out[1] the wide step (targets with a
- * boundary, the Hausdorff evaluator, ranks up to 200, pose moves: DESIGN.md), out[2] per-stage kernels, out[3] steps taken inside
+ * boundary, the Hausdorff evaluator, ranks up to 256, pose moves: DESIGN.md), out[2] per-stage kernels, out[3] steps taken inside
  * icp_chains_run_on_device. */
 ICP_API int icp_ctx_step_paths(const icp_ctx *ctx, int64_t out[4]);
 

@@ -20,7 +20,7 @@
 #ifndef ICP_SINCOS_H
 #define ICP_SINCOS_H
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ICP_SINCOS_FN __host__ __device__ static inline
 #else
 #define ICP_SINCOS_FN static inline

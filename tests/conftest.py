@@ -69,3 +69,25 @@ def open_patch_target(target, n_remove=150):
     remap = -np.ones(pts.shape[0], dtype=np.int64)
     remap[used] = np.arange(used.sum())
     return pts[used].copy(), remap[keep_cells].astype(np.int32)
+
+
+def oracle_chains_parallel(oracle, jobs, trees=True):
+    """orc_run_chain for several chains AT ONCE, a host thread each (ctypes releases the GIL; the oracle's search back end and its tree
+    caches are thread-local: oracle/icp_spatial.c).  jobs = [(model, target, cfg, theta0, seed, n_steps), ...] -> the list of
+    oracle.run_chain results in job order.  The oracle stays a single-threaded program per chain — what the CPU baseline times —; the
+    test suite only stops waiting for one chain after the other (verdict r05: 350 s of GPU-suite wall time, most of it oracle time)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(job):
+        om, ot, cfg, theta0, seed, n = job
+        if trees:
+            oracle.set_search_backend(oracle.SEARCH_TREES)  # (bit-identical to the scans: tests/test_oracle.py)
+        try:
+            return oracle.run_chain(om, ot, cfg, theta0, seed, n)
+        finally:
+            oracle.set_search_backend(oracle.SEARCH_BRUTE)
+
+    if len(jobs) <= 1:
+        return [one(j) for j in jobs]
+    with ThreadPoolExecutor(max_workers=min(len(jobs), 16)) as ex:
+        return list(ex.map(one, jobs))

@@ -58,8 +58,8 @@ def main():
         basis = h5_dataset(f, "/model/pcaBasis", "<f4", (3 * N, r))
         var = h5_dataset(f, "/model/pcaVariance", "<f4", (r,))
         noise = h5_dataset(f, "/model/noiseVariance", "<f4", (1,))
-        if n == 200 and "--with-200" not in sys.argv:
-            continue  # 4 MB; not needed by any test/bench config
+        # (round 6: the 200-component model — rank 201, the reference's largest, apps/femur/CreateGPModel.scala:93 — is a fixture as
+        # well: tests/test_gpu_rank201.py, 3.7 MB)
         np.savez_compressed(os.path.join(OUT, f"femur_gp_model_{n}.npz"), points=pts, cells=cells,
                             mean=mean, pcaBasis=basis, pcaVariance=var, noiseVariance=noise)
         print(n, "N", N, "T", cells.shape[0], "rank", r)

@@ -645,9 +645,10 @@ def test_device_loop_matches_oracle_chain(pkg, femur50, femur50_oracle, oracle, 
         setup.pose_rot_sigma = (0.01, 0.012, 0.008); setup.pose_trans_sigma = (0.1, 0.15, 0.08); setup.rw_sigma = 0.02
     cfg = oracle_chain_config(oracle, setup)
     leaves = set()
+    from conftest import oracle_chains_parallel
+    want = oracle_chains_parallel(oracle, [(om, ot, cfg, pkg.random_initial_parameters(model, b), 500 + b, n) for b in range(B)], trees=False)
     for b in range(B):
-        theta0 = pkg.random_initial_parameters(model, b)
-        acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, cfg, theta0, 500 + b, n)
+        acc_o, comp_o, logp_o, states_o = want[b]
         rec = got["rec"][b]
         assert np.array_equal(rec[:, 0], np.arange(n))
         assert np.array_equal(rec[:, 1].astype(np.uint8), acc_o), f"chain {b}: accept/reject sequences differ"

@@ -306,20 +306,27 @@ def test_small_face_pose_chain_matches_oracle(pkg, oracle, small, evaluator):
     chain.close()
 
 
-@pytest.mark.parametrize("evaluator", ["collective", "hausdorff"])
-def test_full_face_pose_chain_matches_oracle(pkg, oracle, full_face, evaluator):
-    """configs[3] at FULL size (N = 28,561, rank 200, K = 400, K_e = 800 / the full-mesh Hausdorff evaluator): the first 12 steps of
-    the BfmFittingPartial chain, decision for decision against the oracle's chain (tree back end, bit-identical to its scans)."""
+@pytest.fixture(scope="module")
+def full_face_oracle_chains(pkg, oracle, full_face):
+    """The oracle's 12-step chains of the two full-size tests below, computed side by side (a host thread each: conftest)."""
+    from conftest import oracle_chains_parallel
     from test_gpu_chain import oracle_chain_config
     model, target, ctx = full_face
     om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+    kinds = ("collective", "hausdorff")
+    jobs = [(om, ot, oracle_chain_config(oracle, pkg.bfm_fitting_partial(model, target, evaluator=k)), pkg.initial_parameters(model), 5, 12)
+            for k in kinds]
+    return dict(zip(kinds, oracle_chains_parallel(oracle, jobs)))
+
+
+@pytest.mark.parametrize("evaluator", ["collective", "hausdorff"])
+def test_full_face_pose_chain_matches_oracle(pkg, oracle, full_face, full_face_oracle_chains, evaluator):
+    """configs[3] at FULL size (N = 28,561, rank 200, K = 400, K_e = 800 / the full-mesh Hausdorff evaluator): the first 12 steps of
+    the BfmFittingPartial chain, decision for decision against the oracle's chain (tree back end, bit-identical to its scans)."""
+    model, target, ctx = full_face
     setup = pkg.bfm_fitting_partial(model, target, evaluator=evaluator)
     theta0, seed, n = pkg.initial_parameters(model), 5, 12
-    try:
-        oracle.set_search_backend(oracle.SEARCH_TREES)
-        acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), theta0, seed, n)
-    finally:
-        oracle.set_search_backend(oracle.SEARCH_BRUTE)
+    acc_o, comp_o, logp_o, states_o = full_face_oracle_chains[evaluator]
     chain = pkg.SamplingRegistration(ctx, setup, theta0, seed)
     rec = chain.run(n)
     compare_chain_with_oracle(rec, acc_o, comp_o, logp_o, states_o)

@@ -143,28 +143,34 @@ def test_wide_loop_matches_oracle_chain(pkg, oracle, size, evaluator, B, n, tmp_
     sys.path.insert(0, os.path.dirname(__file__))
     from test_gpu_chain import oracle_chain_config
     from test_gpu_face import compare_chain_with_oracle
+    from conftest import oracle_chains_parallel
     path = str(tmp_path / "wlo.npz")
     script = _ORACLE_SCRIPT.format(root=ROOT, size=size, evaluator=evaluator, B=B, n=n, out=path)
-    subprocess.run([sys.executable, "-c", script], check=True, env={**os.environ, "ICP_HOST_DEVICE_LOOP": "1"}, timeout=900)
+    # (the GPU chains in a process of their own — the harness reads ICP_HOST_DEVICE_LOOP once — WHILE the oracle's chains run here, a
+    # thread each)
+    gpu = subprocess.Popen([sys.executable, "-c", script], env={**os.environ, "ICP_HOST_DEVICE_LOOP": "1"})
+    try:
+        if size == "small":
+            model = pkg.data.synthetic_face_model(grid=41, rank=100)
+            target = pkg.data.synthetic_partial_target(model, n_remove=90)
+        else:
+            model = pkg.data.synthetic_face_model()
+            target = pkg.data.synthetic_partial_target(model)
+        om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
+        setup = pkg.bfm_fitting_partial(model, target, evaluator=evaluator, fused=2)
+        setup.pose_rot_sigma, setup.pose_trans_sigma = (0.02, 0.01, 0.004), (0.2, 0.1, 0.05)
+        theta0 = [pkg.initial_parameters(model) if i == 0 else pkg.random_initial_parameters(model, i) for i in range(B)]  # (= the script's)
+        cfg = oracle_chain_config(oracle, setup)
+        want = oracle_chains_parallel(oracle, [(om, ot, cfg, theta0[i], 77 + i, n) for i in range(B)])
+    finally:
+        assert gpu.wait(timeout=900) == 0
     got = np.load(path)
     assert np.all(got["loop"] == n) and np.all(got["stats"] == 0)
-    if size == "small":
-        model = pkg.data.synthetic_face_model(grid=41, rank=100)
-        target = pkg.data.synthetic_partial_target(model, n_remove=90)
-    else:
-        model = pkg.data.synthetic_face_model()
-        target = pkg.data.synthetic_partial_target(model)
-    om, ot = oracle.OracleModel.from_model(model), oracle.OracleMesh(target.points, target.cells)
-    setup = pkg.bfm_fitting_partial(model, target, evaluator=evaluator, fused=2)
-    setup.pose_rot_sigma, setup.pose_trans_sigma = (0.02, 0.01, 0.004), (0.2, 0.1, 0.05)
+    assert np.array_equal(got["theta0"], np.stack(theta0))
     seen = set()
     n_acc = 0
     for i in range(B):
-        try:
-            oracle.set_search_backend(oracle.SEARCH_TREES)
-            acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), got["theta0"][i], 77 + i, n)
-        finally:
-            oracle.set_search_backend(oracle.SEARCH_BRUTE)
+        acc_o, comp_o, logp_o, states_o = want[i]
         compare_chain_with_oracle(got["rec"][i], acc_o, comp_o, logp_o, states_o)
         seen |= set(comp_o.tolist())
         n_acc += int(acc_o.sum())
