@@ -153,6 +153,7 @@ int icp_chain_step_batched_issue(int32_t n_chains, icp_evaluator* const* evaluat
     }
     int nb = 0;
     struct FoldScope { FoldScope(int n) { tl_regression_posteriors = n; } ~FoldScope() { tl_regression_posteriors = 1; } } fold_scope(std::max(1, n_batched * n_props));
+    struct SearchHintScope2 { SearchHintScope2(int n) { search_chains_hint(n); } ~SearchHintScope2() { search_chains_hint(1); } } search_hint_scope2(n_batched);
     for (int b = 0; b < n_chains; ++b) {
       Item& it = items[b];
       if (!it.batched) continue;

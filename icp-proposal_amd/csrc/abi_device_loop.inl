@@ -747,6 +747,7 @@ int icp_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators,
       gr.st = g == 0 ? lead.stream : g == 1 ? lead.front_stream.get() : lead.eig_stream.get();
       const int B = gr.B;
       struct FoldScope { FoldScope(int n) { tl_regression_posteriors = n; } ~FoldScope() { tl_regression_posteriors = 1; } } fold_scope(std::max(1, B * n_props));
+    struct SearchHintScope2 { SearchHintScope2(int n) { search_chains_hint(n); } ~SearchHintScope2() { search_chains_hint(1); } } search_hint_scope2(B);
       gr.begin_alt.alloc(2 * B); gr.begin_live.alloc(B);
       gr.search_alt.alloc(2 * B); gr.search_live.alloc(B);
       gr.regression_alt.alloc(2 * B); gr.regression_live.alloc(B);

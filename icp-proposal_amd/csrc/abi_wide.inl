@@ -215,6 +215,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead, WideCapture* 
       lead.wide_bytes[turn] = cap;
     }
   }
+  struct SearchHintScope { SearchHintScope(int n) { search_chains_hint(n); } ~SearchHintScope() { search_chains_hint(1); } } search_hint_scope(nW);
   std::vector<hipEvent_t> waited;
   std::vector<WideProposeItem> prop_items;
   std::vector<WideChainArgs> chain_args(nW);

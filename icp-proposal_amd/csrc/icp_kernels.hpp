@@ -640,6 +640,9 @@ bool eigen_tridiag_many_supported(int r);
 void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n, const EigenRequest* rq, const double* const* parts /* may be null */,
                                          const int* skip = nullptr /* device, [n]: != 0 leaves request i alone (the on-device loop) */);
 
+// the number of chains whose searches share the launch being put together (thread-local; 1 = a lone chain): how far a task's queries are
+// split over workgroups (split_queries, split_surface_queries).  Never changes a result — only the partition of the work.
+void search_chains_hint(int n_chains);
 SurfaceTask make_surface_task(int T, const double* verts, const int* tris, const float4* spheres, int K, const double* P,
                               int* hint, const QueryBuffers& qb, double* cp, double* d2, int* tri);
 VertexTask make_vertex_task(int V, const double* verts, int K, const double* P, int* hint, const QueryBuffers& qb, double* d2, int* idx);

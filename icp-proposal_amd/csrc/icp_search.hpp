@@ -358,42 +358,90 @@ __device__ __forceinline__ double vertex_bound(const VertexTask& q, int k) {
 // compute every hinted vertex a second time.
 __device__ __forceinline__ void vertex_filter(const VertexTask& q, int bx, int by) {
   __shared__ double s_vq[kFilterTile][4];
+  __shared__ float4 s_vf[kFilterTile];  // the same queries in f32 for the ball test: point, and the bound's root rounded up
   const int v = bx * kSearchBlock + threadIdx.x;
   const bool valid = v < q.V;
   d3 e = {0.0, 0.0, 0.0};
   if (valid) e = ld3(q.verts + 3 * v);
+  // Two levels, as the surface filter (round 6; until then every (vertex, query) pair was tested in f64 — 33 M pairs per chain and
+  // step of the face configuration).  A wave holds 64 CONSECUTIVE vertices — a stretch of the mesh: files list neighbouring vertices
+  // together, a grid lists a row — inside their axis-aligned BOX [lo, hi] (f32, widened by the slack of both tests' roundings: what
+  // passes the exact test below passes this one); a query can only have a candidate in the wave if its distance to the box is within
+  // sqrt(bound).  (A box, not a ball: a row of a grid is 64 spacings long and one wide — its ball holds 3,600 grid points, its box
+  // widened by a bound of one or two spacings a few hundred.)  That test runs for 64 queries at a time, one per lane; the exact f64
+  // test — every lane its vertex against ONE query — only for the survivors.  Every pair is still decided: the candidate set is the one
+  // the plain double loop gives.
+  const int lane = threadIdx.x & 63;
+  const bool fin = valid && fabs(e.x) + fabs(e.y) + fabs(e.z) <= 3.0e38;  // (a non-finite vertex passes no exact test against a finite bound, and must not spoil the box)
+  const float big = 3.0e38f;
+  float lox = fin ? (float)e.x : big, loy = fin ? (float)e.y : big, loz = fin ? (float)e.z : big;
+  float hix = fin ? (float)e.x : -big, hiy = fin ? (float)e.y : -big, hiz = fin ? (float)e.z : -big;
+  for (int o = 32; o > 0; o >>= 1) {
+    lox = fminf(lox, __shfl_xor(lox, o, 64)); loy = fminf(loy, __shfl_xor(loy, o, 64)); loz = fminf(loz, __shfl_xor(loz, o, 64));
+    hix = fmaxf(hix, __shfl_xor(hix, o, 64)); hiy = fmaxf(hiy, __shfl_xor(hiy, o, 64)); hiz = fmaxf(hiz, __shfl_xor(hiz, o, 64));
+  }
+  const bool wave_live = lox <= hix;  // (uniform: at least one finite vertex)
+  {  // slack: a few hundred ulps of the largest magnitudes involved (the vertices' rounding to f32, the test's own errors)
+    const float sl = 2e-5f * (fmaxf(fabsf(lox), fabsf(hix)) + fmaxf(fabsf(loy), fabsf(hiy)) + fmaxf(fabsf(loz), fabsf(hiz)));
+    lox -= sl; loy -= sl; loz -= sl; hix += sl; hiy += sl; hiz += sl;
+  }
+  // (a wave that holds a non-finite vertex beside finite ones: that vertex can only pass against an INFINITE bound, whose query passes
+  // the box test whatever the box — handled by the exact test as before)
   const int k0 = by * q.kchunk;
   const int k1 = min(q.Kpad, k0 + q.kchunk);
   ParkedHits ph;
   const int first = bx * kSearchBlock + (threadIdx.x & ~63);
+  unsigned n_exact = 0;  // (wave-uniform; reported only when profiling)
   for (int kt = k0; kt < k1; kt += kFilterTile) {
     const int nq = min(kFilterTile, k1 - kt);  // multiple of kQU
     if (kt != k0) __syncthreads();
     if ((int)threadIdx.x < nq) {
       const int k = kt + threadIdx.x, kk = min(k, q.K - 1);  // sentinel slots re-read the last real query; their bound is -1
-      s_vq[threadIdx.x][0] = q.P[3 * kk]; s_vq[threadIdx.x][1] = q.P[3 * kk + 1]; s_vq[threadIdx.x][2] = q.P[3 * kk + 2];
-      s_vq[threadIdx.x][3] = q.thr2 ? q.thr2[k] : vertex_bound(q, k);
+      const double px = q.P[3 * kk], py = q.P[3 * kk + 1], pz = q.P[3 * kk + 2];
+      const double b2 = q.thr2 ? q.thr2[k] : vertex_bound(q, k);
+      s_vq[threadIdx.x][0] = px; s_vq[threadIdx.x][1] = py; s_vq[threadIdx.x][2] = pz;
+      s_vq[threadIdx.x][3] = b2;
+      // (a sentinel's bound −1 has no root: NaN, which passes no comparison; +inf — no usable hint — passes every one)
+      s_vf[threadIdx.x] = make_float4((float)px, (float)py, (float)pz, round_up_f32(sqrt(b2) * (1.0 + 2e-6)));
     }
     __syncthreads();
-    for (int k = 0; k < nq; k += kQU) {
-      unsigned long long m[kQU];
-#pragma unroll
-      for (int u = 0; u < kQU; ++u) {
-        const d3 p = {s_vq[k + u][0], s_vq[k + u][1], s_vq[k + u][2]};
-        d3 d = sub(p, e);
-        const double d2 = dot(d, d);  // (dx·dx + dy·dy) + dz·dz, unfused — the value the argmin is defined on
-        m[u] = __ballot(valid && d2 <= s_vq[k + u][3]);
+    if (!wave_live) continue;
+    for (int g = 0; g < nq; g += 64) {
+      bool near = false;
+      if (g + lane < nq) {  // lane l: query g + l against the wave's box
+        const float4 qq = s_vf[g + lane];
+        const float dx = fmaxf(fmaxf(lox - qq.x, qq.x - hix), 0.f), dy = fmaxf(fmaxf(loy - qq.y, qq.y - hiy), 0.f),
+                    dz = fmaxf(fmaxf(loz - qq.z, qq.z - hiz), 0.f);
+        const float lim = qq.w + 2e-5f * (fabsf(qq.x) + fabsf(qq.y) + fabsf(qq.z));
+        near = dx * dx + dy * dy + dz * dz <= lim * lim;  // (a NaN query or a sentinel's NaN bound: false; an infinite bound: true)
       }
-#pragma unroll
-      for (int u = 0; u < kQU; ++u)
-        if (m[u] != 0ull) {
-          park_hits(ph, kt + k + u, m[u], 0ull);
+      unsigned long long todo = __ballot(near);
+      n_exact += (unsigned)__popcll(todo);
+      while (todo) {  // wave-uniform: the surviving queries, two at a time (their records' LDS reads in flight together)
+        const int j0 = g + __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const bool two = todo != 0ull;
+        const int j1 = two ? g + __ffsll((long long)todo) - 1 : j0;
+        todo &= todo - 1;  // (0 & anything stays 0)
+        const d3 p0 = {s_vq[j0][0], s_vq[j0][1], s_vq[j0][2]}, p1 = {s_vq[j1][0], s_vq[j1][1], s_vq[j1][2]};
+        const double t0 = s_vq[j0][3], t1 = s_vq[j1][3];
+        const d3 d0 = sub(p0, e), d1 = sub(p1, e);
+        const double a0 = dot(d0, d0), a1 = dot(d1, d1);  // (dx·dx + dy·dy) + dz·dz, unfused — the value the argmin is defined on
+        const unsigned long long m0 = __ballot(valid && a0 <= t0);
+        const unsigned long long m1 = two ? __ballot(valid && a1 <= t1) : 0ull;
+        if (m0 != 0ull) {
+          park_hits(ph, kt + j0, m0, 0ull);
           if (ph.n == 64) settle_hits(ph, q.cnt, q.cand, q.stride, first, 1);
         }
+        if (m1 != 0ull) {
+          park_hits(ph, kt + j1, m1, 0ull);
+          if (ph.n == 64) settle_hits(ph, q.cnt, q.cand, q.stride, first, 1);
+        }
+      }
     }
   }
   settle_hits(ph, q.cnt, q.cand, q.stride, first, 1);
-  if (q.stats && (threadIdx.x & 63) == 0) atomicAdd(q.stats + 3, 64ull * (unsigned long long)(k1 > k0 ? k1 - k0 : 0));
+  if (q.stats && lane == 0) atomicAdd(q.stats + 3, 64ull * (unsigned long long)n_exact);
 }
 
 __device__ __forceinline__ void vertex_resolve(const VertexTask& q, int k, double* best_out, int* idx_out) {

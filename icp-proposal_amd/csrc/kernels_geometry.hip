@@ -117,9 +117,17 @@ __global__ void __launch_bounds__(64) k_vertex_resolve(VertexTask q) {
 
 }  // namespace
 
+// How many chains' searches the launch being put together carries (search_chains_hint: set by the batched / wide step's host side).  A
+// lone chain's filter launch wants many workgroups — it is a chain of latencies — and splits its queries over them; B chains side by
+// side launch B times as many, and then the per-wave set-up (the elements' box or ball, the staging of a query tile) is what the launch
+// consists of: 25 chains of the face configuration, vertex searches split ten ways — 293 instructions per wave, most of them set-up.
+static thread_local int tl_search_chains = 1;
+void search_chains_hint(int n_chains) { tl_search_chains = n_chains > 1 ? n_chains : 1; }
+
 // enough waves to fill 256 CUs, but at least ~8 queries per wave so the element load is amortised; kchunk multiple of kQU
 void split_queries(int n_elem_blocks, int Kpad, int* ksplit, int* kchunk) {
-  static const int target_waves = dev_env("ICP_FILTER_WAVES") ? std::atoi(dev_env("ICP_FILTER_WAVES")) : 4096;
+  static const int target_waves_one = dev_env("ICP_FILTER_WAVES") ? std::atoi(dev_env("ICP_FILTER_WAVES")) : 4096;
+  const int target_waves = std::max(target_waves_one / tl_search_chains, 1);
   int want = cdiv(target_waves, n_elem_blocks * (kBlock / 64));
   int s = want < 1 ? 1 : want;
   int maxs = cdiv(Kpad, 8);
@@ -137,7 +145,8 @@ void split_queries(int n_elem_blocks, int Kpad, int* ksplit, int* kchunk) {
 // to 512 queries per workgroup measure the same for one chain) — so few workgroups: a batch of chains launches B times as
 // many.  256 queries per workgroup: two workgroups per block of spheres for the 308 queries of the femur step.
 void split_surface_queries(int Kpad, int* ksplit, int* kchunk) {
-  static const int tile = dev_env("ICP_SURFACE_CHUNK") ? std::atoi(dev_env("ICP_SURFACE_CHUNK")) : 256;  // (A/B: <= 512)
+  static const int tile_one = dev_env("ICP_SURFACE_CHUNK") ? std::atoi(dev_env("ICP_SURFACE_CHUNK")) : 256;  // (A/B: <= 512)
+  const int tile = tl_search_chains >= 16 ? kSurfaceTile : tile_one;  // (many chains a launch: a whole LDS tile per workgroup — half the waves)
   int kc = Kpad < tile ? Kpad : tile;
   kc = (kc + kQU - 1) / kQU * kQU;
   if (kc < kQU) kc = kQU;

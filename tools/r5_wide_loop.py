@@ -32,6 +32,9 @@ def child(kind, B, n, out):
     elif kind == "femur100":   # apps/femur/StdIcpVsChainICPrandomInitComparisonAll.scala: two ICP directions + shape walk at rank 101 (closed target)
         model, target = pkg.data.load_femur_model_and_target(100)
         mk = lambda: pkg.femur_icp_proposal_registration(model, target, fused=2)
+    elif kind == "femur200":   # the reference's largest model (rank 201: apps/femur/CreateGPModel.scala:93), two ICP directions + shape walk
+        model, target = pkg.data.load_femur_model_and_target(200)
+        mk = lambda: pkg.femur_icp_proposal_registration(model, target, fused=2)
     else:
         raise SystemExit("unknown kind")
     ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
