@@ -374,7 +374,7 @@ def b1_parallel(args, cfg_i, n_chains, budget_s, max_procs=64):
 def mfma_block(config_key, kernels, live_us, flops):
     """MFMA utilisation of the projection kernels (north_star: "MFMA utilisation on the projection … against gfx950 peak"), two ways:
       counter: SQ_VALU_MFMA_BUSY_CYCLES / (N_SIMD x GRBM_GUI_ACTIVE / N_XCD) per launch, both counters from ONE rocprofv3 --pmc pass
-               (profiles/r05_pmc_mfma.json; SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, summed over the chip's 1,024 SIMDs;
+               (profiles/r06_pmc_mfma.json; SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, summed over the chip's 1,024 SIMDs;
                rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs — MI355X_MICROARCH.md "DVFS give-back" —, so /8 = the launch's
                cycles);
       flops:   algorithmic f64 multiply-add flops of one launch / the launch's duration measured in THIS run (HIP events) / the dense
@@ -383,7 +383,7 @@ def mfma_block(config_key, kernels, live_us, flops):
            "formula": "busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (%d SIMDs x GRBM_GUI_ACTIVE / %d XCDs); flops_frac = algorithmic f64 flops per launch / "
                       "avg launch duration (HIP events, this run) / %.1f TFLOP/s" % (N_SIMD, N_XCD, F64_MATRIX_TFLOPS), "kernels": {}}
     pmc = {}
-    for tname in ("r05_pmc_mfma.json", "r04_pmc_mfma.json"):
+    for tname in ("r06_pmc_mfma.json", "r05_pmc_mfma.json", "r04_pmc_mfma.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile):
             pmc = json.load(open(tfile)).get(config_key, {})
@@ -474,6 +474,8 @@ def main():
             out = config4_leg(pkg, args, 0)
         elif name.startswith("dropin"):
             out = dropin_leg(pkg, args, int(name[len("dropin"):]), 0)
+        elif name == "femur200":
+            out = femur200_leg(pkg, args, 0)
         else:
             out = extra_config_leg(pkg, args, int(name[len("config"):]), 0, sampler=sampler or "eigen")
         print(json.dumps(out))
@@ -638,6 +640,11 @@ def main():
                     line["extra_configs"]["config3_cholesky_root"] = child_leg("config3:cholesky-root")
                 except Exception as e:
                     line["extra_configs"]["config3_cholesky_root"] = {"error": str(e)[:200]}
+    if rank == 0 and world == 1 and B == 1 and args.config == 1 and args.extra_configs.strip():
+        try:  # the reference's largest model (rank 201): wide step + on-device loop since round 6
+            line["extra_configs"]["femur200"] = child_leg("femur200")
+        except Exception as e:
+            line["extra_configs"]["femur200"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and B == 1 and args.config == 1 and args.dropin_leg and args.extra_configs.strip():
         # ---- not the headline: the north star's drop-in contract measured — the chain stepped method by method as Scalismo steps it
         # (unbound, and bound once with icp_chain_bind) beside icp_chain_step, configs[1] and configs[3], a child process each
@@ -702,14 +709,18 @@ def main():
                           "kernel_us_per_launch": {k: round(v["avg_us"], 2) for k, v in pst.items()},
                           "note": "algorithmic bytes per chain x chains per launch / launch duration; the chains of a launch search the SAME target, so the "
                                   "bytes that actually leave HBM are fewer (the target's spheres stay in L2 between the chains' workgroups): "
-                                  "`counter_*` = FETCH_SIZE x 2 + WRITE_SIZE of the same kernel in the same regime (profiles/r04_pmc_traffic.json)"}
-                    tfile = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-                    if os.path.exists(tfile):
+                                  "`counter_*` = FETCH_SIZE x 2 + WRITE_SIZE of the same kernel in the same regime (the newest profiles/r0N_pmc_traffic.json)"}
+                    for tname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"):
+                        tfile = os.path.join(ROOT, "profiles", tname)
+                        if not os.path.exists(tfile):
+                            continue
                         ctr = json.load(open(tfile)).get("many_chains", {}).get("k_step_filter", {}).get("hbm_bytes_per_launch")
                         if ctr is not None:
+                            dk["counter_source"] = "profiles/" + tname
                             dk["counter_bytes_per_launch"] = ctr
                             dk["counter_GBs"] = ctr / (f["avg_us"] * 1e-6) / 1e9
                             dk["frac_hbm_counter"] = dk["counter_GBs"] / HBM_PEAK_GBS
+                            break
             except Exception as e:
                 dk = {"error": str(e)[:200]}
             line["many_chains"] = {"chains_per_gpu": nB, "value": nB * n_m / mdt, "unit": "iterations/s", "steps_per_chain": n_m, "distance_kernel": dk,
@@ -727,6 +738,131 @@ def main():
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _tracked_json(names):
+    """the newest tracked profile file of a family (profiles/r06_…, r05_…): (path relative to the repository, content) or (None, {})"""
+    for n in names:
+        f = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(f):
+            return "profiles/" + n, json.load(open(f))
+    return None, {}
+
+
+def config4_roofline(pkg, args, model, target, make_setup, device, n_chains=25, n_steps=60):
+    """The roofline / MFMA block of configs[4]'s steady state: ONE submission of `n_chains` chains of one target stepped inside the
+    on-device loop (what sharding.run_batch submits: 4 x 25 for the 10 x 10 job), its launches under HIP events on the launch streams.
+    Event ids are the step's stages: k_posterior_eigen = one launch sequence of the tridiagonal route for up to 16 posteriors
+    (k_assemble_many -> k_tridiag_many -> k_tri_solve_many -> k_tri_back_many -> 3 x k_tri_gemm_many + correction), k_instance =
+    k_wide_instance<8>, k_step_regression = k_wide_xrows + k_wide_regression_fold, k_step_filter / k_step_resolve = the proposal's searches,
+    k_surface_* / k_vertex_* = the evaluator's.  Counter figures (HBM bytes, MFMA-busy, waves per SIMD) are those of the SAME regime's
+    rocprofv3 --pmc passes (profiles/r06_pmc_*.json, regime wide_loop25: tools/r6_profiles.sh) — tracked files, not measured in this run."""
+    setup = make_setup(model, target)
+    r, N = model.rank, model.n_points
+    pkg.expect_contexts(device, n_chains)
+    ctxs = [pkg.IcpContext(model, target, device=device) for _ in range(n_chains)]
+    chains = [pkg.SamplingRegistration(ctxs[i], setup, pkg.random_initial_parameters(model, i), seed=1024 + i) for i in range(n_chains)]
+    try:
+        pkg.run_chains_batched(chains, 30, want_records=False)
+        ctxs[0].profile_start(max_launches=200 * n_steps + 4096)
+        t1 = time.perf_counter()
+        pkg.run_chains_batched(chains, n_steps, want_records=False)
+        pdt = time.perf_counter() - t1
+        raw = ctxs[0].profile_stop()
+        paths = ctxs[0].step_paths()
+    finally:
+        for c in chains:
+            c.close()
+        for c in ctxs:
+            c.close()
+    pst = {k: v for k, v in raw.items() if not k.startswith("count.") and not k.endswith(".device_wait")}
+    if not pst:
+        return None, None
+    dominant = max(pst, key=lambda k: pst[k]["total_ms"])
+    k = pst[dominant]
+    per_launch = n_chains * n_steps / max(k["calls"], 1)   # posteriors (chains) a launch of the dominant stage carries
+    alg1 = kernel_algorithmic_bytes(dominant, model, target, setup)
+    has_boundary = bool(pkg.data.boundary_vertex_flags(target).any())
+    bytes_step, _ = algorithmic_step(model, target, setup, has_boundary)
+    lat = latency_floor_model(model, setup, 0.55, 0.7, bytes_step, 0.0)
+    lat["measured_us_per_round"] = 1e6 * pdt / n_steps
+    lat["note"] = "floor of ONE chain's step; a round steps %d chains side by side in one launch sequence" % n_chains
+    lat["frac"] = lat["floor_us_per_step"] / lat["measured_us_per_round"]
+    tsrc, traffic = _tracked_json(("r06_pmc_traffic.json",))
+    ssrc, sq = _tracked_json(("r06_pmc_sq.json",))
+    traffic, sq = traffic.get("wide_loop25", {}), sq.get("wide_loop25", {})
+    roof = {"bound": "latency" if dominant.startswith(SINGLE_WORKGROUP) else "hbm", "kernel": dominant, "avg_launch_us": k["avg_us"], "launches": k["calls"],
+            "chains_per_launch": per_launch, "algorithmic_bytes": None if alg1 is None else alg1 * per_launch, "achieved": None, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": None, "traffic": None, "latency": lat,
+            "sample": "%d chains of one target in one submission per step inside icp_chains_run_on_device (step_paths.device_loop = %d), %d steps: "
+                      "%.0f it/s, %.2f ms per round" % (n_chains, paths.get("device_loop", 0), n_steps, n_chains * n_steps / pdt, 1e3 * pdt / n_steps),
+            "value_in_this_stretch": n_chains * n_steps / pdt,
+            "whole_step": {"algorithmic_bytes_per_chain_step": bytes_step, "hbm_frac": bytes_step * (n_chains * n_steps / pdt) / (HBM_PEAK_GBS * 1e9)},
+            "kernel_us_per_round": {name: round(v["total_ms"] * 1e3 / n_steps, 2) for name, v in pst.items()}}
+    if alg1 is not None:
+        roof["achieved"] = alg1 * per_launch / (k["avg_us"] * 1e-6) / 1e9
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+    if dominant.startswith("k_posterior_eigen") and traffic:
+        seq = ("k_assemble_many", "k_tridiag_many", "k_tri_solve_many", "k_tri_back_many", "k_tri_correction_many")
+        t = sum(traffic[q]["hbm_bytes_per_launch"] for q in seq if q in traffic) + 3 * traffic.get("k_tri_gemm_many", {}).get("hbm_bytes_per_launch", 0)
+        roof["traffic"] = t
+        roof["traffic_source"] = tsrc + " (wide_loop25: the sequence's launches summed, 16 posteriors a launch)"
+    # the step's HBM-bound kernels against the roofline (durations of THIS run, counter bytes of the tracked pass)
+    groups = -(-n_chains // 8)
+    hbm = {}
+    if "k_instance" in pst:
+        alg = groups * 3 * N * r * 8 + n_chains * 3 * N * 8 * 4   # the basis once per group of <= 8 chains; reference, mean in, instance + kept deformation out
+        us = pst["k_instance"]["avg_us"]
+        row = {"kernel": "k_wide_instance<8>", "avg_launch_us": us, "algorithmic_bytes": alg, "achieved_GBs": alg / (us * 1e-6) / 1e9,
+               "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "note": "%d passes over the 137 MB basis (groups of <= 8 chains)" % groups}
+        c = traffic.get("k_wide_instance<8>", {}).get("hbm_bytes_per_launch")
+        if c:
+            row.update(counter_bytes_per_launch=c, counter_GBs=c / (us * 1e-6) / 1e9, counter_frac=c / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+        hbm["k_wide_instance"] = row
+    if "k_step_regression" in pst:
+        Km = max([p.get("n_model_ids", 0) for p in setup.icp] + [0])
+        alg = n_chains * (Km * 4 * 16 * ((r + 1 + 15) // 16) * 8 + (r + 1) * (r + 1) * 8 * 0.5)   # operand rows in, ONE partial (lower triangle) out
+        us = pst["k_step_regression"]["avg_us"]
+        row = {"kernel": "k_wide_regression_fold (+ k_wide_xrows)", "avg_launch_us": us, "algorithmic_bytes": alg, "achieved_GBs": alg / (us * 1e-6) / 1e9,
+               "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        c = traffic.get("k_wide_regression_fold", {}).get("hbm_bytes_per_launch")
+        if c:
+            row.update(counter_bytes_per_launch=c, counter_GBs=c / (us * 1e-6) / 1e9, counter_frac=c / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                       note="every macro tile reads its columns of every correspondence's operand rows again: counter bytes = %.1f x algorithmic" % (c / alg))
+        hbm["k_wide_regression_fold"] = row
+    roof["hbm_kernels"] = hbm
+    if sq:
+        roof["occupancy"] = {q: {"avg_waves_per_simd": round(v.get("avg_waves_per_simd", 0.0), 3), "parked_share": round(v.get("parked_share", 0.0), 3),
+                                 "lds_conflict_share": round(v.get("lds_conflict_share", 0.0), 3), "median_us_alone": v.get("median_us")}
+                             for q, v in sq.items() if q in ("k_tridiag_many", "k_tri_solve_many", "k_tri_back_many", "k_tri_gemm_many", "k_wide_regression_fold",
+                                                             "k_wide_instance<8>", "k_wide_filter", "k_wide_resolve", "k_posterior_factor_tiles", "k_wide_xrows")}
+        roof["occupancy_source"] = ssrc + " (one kernel at a time: durations WITHOUT neighbours)"
+    # MFMA utilisation of the projection where it IS GEMM-shaped: the folded regression of a submission's posteriors
+    mfma = None
+    if "k_step_regression" in pst:
+        flops = n_chains * projection_flops(model, setup)
+        us = pst["k_step_regression"]["avg_us"]
+        msrc, mf = _tracked_json(("r06_pmc_mfma.json",))
+        mf = mf.get("wide_loop25", {})
+        mfma = {"peak_TFLOPs": F64_MATRIX_TFLOPS, "kernels": {}, "counter_source": (msrc + " (wide_loop25)") if msrc else None,
+                "formula": "busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (%d SIMDs x GRBM_GUI_ACTIVE / %d XCDs); flops_frac = algorithmic f64 flops per launch / avg "
+                           "launch duration (HIP events, this run) / %.1f TFLOP/s" % (N_SIMD, N_XCD, F64_MATRIX_TFLOPS)}
+        row = {"avg_launch_us": us, "posteriors_per_launch": n_chains, "algorithmic_f64_flops": flops, "achieved_TFLOPs": flops / (us * 1e-6) / 1e12,
+               "flops_frac": flops / (us * 1e-6) / 1e12 / F64_MATRIX_TFLOPS,
+               "note": "event id k_step_regression = k_wide_xrows + k_wide_regression_fold of the submission"}
+        c = mf.get("k_wide_regression_fold", {})
+        if c.get("busy_frac_median") is not None:
+            row.update(busy_frac=c["busy_frac_median"], SQ_VALU_MFMA_BUSY_CYCLES=c["SQ_VALU_MFMA_BUSY_CYCLES"]["median"], GRBM_GUI_ACTIVE=c["GRBM_GUI_ACTIVE"]["median"],
+                       counter_pass_us=c.get("median_us"))
+        mfma["kernels"]["k_wide_regression_fold"] = row
+        for q in ("k_tri_back_many", "k_tri_gemm_many"):
+            c = mf.get(q, {})
+            if c.get("busy_frac_median") is not None:
+                fl = (16 * 2.0 * r ** 3) if q == "k_tri_back_many" else 2.0 * r ** 3   # (back-transformation of 16 problems / one r x r x r product)
+                mfma["kernels"][q] = {"busy_frac": c["busy_frac_median"], "counter_pass_us": c.get("median_us"),
+                                      "flops_frac_in_the_counter_pass": None if not c.get("median_us") else fl / (c["median_us"] * 1e-6) / 1e12 / F64_MATRIX_TFLOPS}
+    return roof, mfma
+
 
 
 def config4_leg(pkg, args, device):
@@ -748,6 +884,10 @@ def config4_leg(pkg, args, device):
         out["steps_%d" % n_steps] = {"value": len(items) * n_steps / dt, "job_s": dt, "items": len(items), "accepted": int(sum(r[:, 1].sum() for r in recs)),
                                      "contexts_built": int(stats["contexts_built"]), "phase_ms": stats.get("phase_ms")}
     out["value"] = out["steps_300"]["value"]
+    try:  # the steady state of one submission under HIP events + the tracked counter passes of the same regime
+        out["roofline"], out["mfma"] = config4_roofline(pkg, args, model, targets[0], make_setup, device)
+    except Exception as e:
+        out["roofline_error"] = str(e)[:300]
     out["runtime_stats"] = pkg._native.runtime_stats()
     out["step_paths_process"] = pkg._native.step_paths() if hasattr(pkg._native, "step_paths") else None
     if args.parallel_cpu_budget > 0 and args.cpu_steps > 0:
@@ -811,6 +951,42 @@ def extra_config_leg(pkg, args, cfg_i, device, sampler="eigen"):
         except Exception as e:
             out["from_deterministic_fit"] = {"error": str(e)[:200]}
     ctx.close()
+    return out
+
+
+def femur200_leg(pkg, args, device):
+    """The reference's largest bundled model, femur_gp_model_200-components.h5 — rank 201 (apps/femur/CreateGPModel.scala:93) — through the
+    femur mixture of apps/femur/IcpProposalRegistration.scala:59-85 against the bundled target: one chain (the wide step: ranks above 116)
+    and five chains inside the on-device loop (RunMHRandomInitComparison.scala:66's five).  Until round 6 rank 201 was one past the
+    tridiagonal route and every posterior took the per-stage generic decomposition."""
+    model, target = pkg.data.load_femur_model_and_target(200)
+    setup = pkg.femur_icp_proposal_registration(model, target, fused=args.fused if args.fused in (2, 3) else 2)
+    out = {"unit": "iterations/s", "workload": "femur 200-component GPMM (N=%d, rank %d) vs the bundled aligned target (M=%d); 0.9 ICP(Target+Model sampling, "
+                                               "K=%d) + 0.1 random walk; prior x independent Gaussian(0,2) on %d points"
+                                               % (model.n_points, model.rank, target.n_points, 2 * model.rank, 4 * model.rank)}
+    ctx = pkg.IcpContext(model, target, device=device)
+    chain = pkg.SamplingRegistration(ctx, setup, pkg.initial_parameters(model), seed=1024)
+    chain.run(40, want_records=False)
+    t0 = time.perf_counter()
+    rec = chain.run(300)
+    dt = time.perf_counter() - t0
+    out["one_chain"] = {"value": 300 / dt, "steps": 300, "warmup": 40, "accepted": int(rec[:, 1].sum()), "step_paths": ctx.step_paths()}
+    chain.close()
+    ctx.close()
+    B = 5
+    ctxs = [pkg.IcpContext(model, target, device=device) for _ in range(B)]
+    chains = [pkg.SamplingRegistration(ctxs[i], setup, pkg.random_initial_parameters(model, i), seed=1024 + i) for i in range(B)]
+    pkg.run_chains_batched(chains, 30, want_records=False)
+    t0 = time.perf_counter()
+    recs = pkg.run_chains_batched(chains, 200)
+    dt = time.perf_counter() - t0
+    out["five_chains"] = {"value": B * 200 / dt, "steps_per_chain": 200, "accepted": int(sum(r[:, 1].sum() for r in recs)), "step_paths": ctxs[0].step_paths()}
+    out["value"] = out["one_chain"]["value"]
+    out["runtime_stats"] = pkg._native.runtime_stats()
+    for c in chains:
+        c.close()
+    for c in ctxs:
+        c.close()
     return out
 
 
@@ -892,7 +1068,7 @@ def leg_roofline(pkg, ctx, chain, wl, n_prof, rate, accepted_share, icp_share):
     if reg in stats:
         flops = {reg: projection_flops(model, setup), "k_tri_gemm": 2.0 * model.rank ** 3}
         roof["mfma"] = mfma_block("config%d" % wl["config"], [reg] + (["k_tri_gemm"] if model.rank > 64 else []), {reg: stats[reg]["avg_us"]}, flops)
-    for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for tname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile):
             per_kernel = json.load(open(tfile)).get("config%d" % wl["config"], {})
@@ -940,42 +1116,11 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
     multi_gpu = rank_report(dist, torch, rank, world, local_rank, stats["chain_ms"], stats["gather_ms"])
     roofline = None
     if rank == 0 and world == 1:
-        # ---- outside the timed region: the launches of one submission's steps under HIP events (the lead context carries them)
+        # ---- outside the timed region: one submission's steady state under HIP events (config4_roofline)
         try:
-            setup0 = make_setup(model, targets[0])
-            nB = max(1, min(args.chains, 10))
-            pctx = [pkg.IcpContext(model, targets[0], device=local_rank) for _ in range(nB)]
-            pch = [pkg.SamplingRegistration(pctx[i], setup0, pkg.random_initial_parameters(model, i), seed=1024 + i) for i in range(nB)]
-            pkg.run_chains_batched(pch, 30, want_records=False)
-            n_p = 60
-            pctx[0].profile_start(max_launches=200 * n_p + 4096)
-            t1 = time.perf_counter()
-            pkg.run_chains_batched(pch, n_p, want_records=False)
-            pdt = time.perf_counter() - t1
-            raw = pctx[0].profile_stop()
-            pst = {k: v for k, v in raw.items() if not k.startswith("count.") and not k.endswith(".device_wait")}
-            if pst:
-                dominant = max(pst, key=lambda k: pst[k]["total_ms"])
-                k = pst[dominant]
-                per_launch = nB * n_p / max(k["calls"], 1)
-                alg1 = kernel_algorithmic_bytes(dominant, model, targets[0], setup0)
-                has_boundary = bool(pkg.data.boundary_vertex_flags(targets[0]).any())
-                bytes_step, _ = algorithmic_step(model, targets[0], setup0, has_boundary)
-                lat = latency_floor_model(model, setup0, 0.55, 0.7, bytes_step, 0.0)
-                lat["measured_us_per_round"] = 1e6 * pdt / n_p
-                lat["note"] = "floor of ONE chain's step; a round steps %d chains side by side in one launch sequence" % nB
-                lat["frac"] = lat["floor_us_per_step"] / lat["measured_us_per_round"]
-                roofline = {"bound": "latency" if dominant.startswith(SINGLE_WORKGROUP) else "hbm", "kernel": dominant, "avg_launch_us": k["avg_us"],
-                            "launches": k["calls"], "chains_per_launch": per_launch,
-                            "algorithmic_bytes": None if alg1 is None else alg1 * per_launch, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": None, "traffic": None, "latency": lat,
-                            "sample": "%d chains of target 0 in one submission per step, %d steps (%.0f it/s in this stretch)" % (nB, n_p, nB * n_p / pdt),
-                            "kernel_us_per_round": {name: round(v["total_ms"] * 1e3 / n_p, 2) for name, v in pst.items()}}
-                if alg1 is not None:
-                    roofline["achieved"] = alg1 * per_launch / (k["avg_us"] * 1e-6) / 1e9
-                    roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
-            for c in pch: c.close()
-            for c in pctx: c.close()
+            roofline, mfma4 = config4_roofline(pkg, args, model, targets[0], make_setup, local_rank)
+            if roofline is not None and mfma4 is not None:
+                roofline["mfma"] = mfma4
         except Exception as e:  # (the leg is a report, not the measurement)
             roofline = {"error": str(e)[:300]}
     if rank == 0:
@@ -1069,7 +1214,7 @@ def roofline_leg(pkg, args, wl, ctx, chains, B, rate, line):
         chains_per_launch = B * args.profile_steps / max(k["calls"], 1)
         alg = alg * chains_per_launch if alg is not None else None
     traffic = traffic_source = None
-    for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for tname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile) and B == 1:
             per_kernel = json.load(open(tfile)).get("config%d" % args.config, {})

@@ -1242,8 +1242,9 @@ struct TriSolveMany { TriSolveIO p[kTriMany]; };
 template <int SI>
 __global__ void __launch_bounds__(256) k_tri_solve_many(TriSolveMany m, const int* __restrict__ skip_all) {
   if (skip_all && skip_all[blockIdx.y] != 0) return;
-  // (no s_setprio here: raised to 3 for the critical path's sake, beside the evaluator's searches of a 30-chain wide step the device
-  // hung — measured once, not understood, not repeated)
+#ifdef ICP_TRI_SETPRIO
+  __builtin_amdgcn_s_setprio(ICP_TRI_SETPRIO);
+#endif
   const TriSolveIO a = m.p[blockIdx.y];
   tri_solve_or_wy<SI>(a);
 }
@@ -1445,6 +1446,9 @@ struct TriBackMany { TriBackIO p[kTriMany]; };
 template <int SI>
 __global__ void __launch_bounds__(256) k_tri_back_many(TriBackMany m, const int* __restrict__ skip_all) {
   if (skip_all && skip_all[blockIdx.y] != 0) return;
+#ifdef ICP_TRI_SETPRIO
+  __builtin_amdgcn_s_setprio(ICP_TRI_SETPRIO);
+#endif
   const TriBackIO a = m.p[blockIdx.y];
   tri_back_body<SI>(a);
 }

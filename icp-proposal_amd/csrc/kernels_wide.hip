@@ -276,13 +276,25 @@ __host__ __device__ inline int wide_red_blocks(const WideRegArgs& a, int dir /* 
 }
 template <bool kFolded>
 __device__ __forceinline__ void wide_regression_body(const WideRegArgs* __restrict__ batch) {
-  const WideRegArgs& w = batch[blockIdx.y];
+  int chain = blockIdx.y, b = blockIdx.x;
+  if constexpr (kFolded) {
+    // XCD-aware (round 6).  Workgroups go to the eight XCDs in turn by their linear index (x fastest), and each XCD has an L2 of its
+    // own: with blockIdx.y = chain, the eight or so workgroups of a posterior sat on eight XCDs and each fetched the posterior's operand
+    // rows (2.6 MB at the face model's size) from HBM again — 317 MB per launch of 25 chains for 65 MB of rows (profiles/r06_pmc_traffic.json
+    // before this change).  Here the launch's (chain, block) pairs are dealt out in order, XCD by XCD: XCD j takes the pairs
+    // [start_j, start_{j+1}) — three or four WHOLE chains, whose rows then come from its L2 after the first touch.
+    const int G = gridDim.x, total = G * (int)gridDim.y, L = (int)blockIdx.y * G + (int)blockIdx.x;
+    const int q = total >> 3, rem = total & 7, j = L & 7;
+    const int wk = j * q + min(j, rem) + (L >> 3);  // (the L-th workgroup is the (L >> 3)-th of XCD j)
+    chain = wk / G;
+    b = wk - chain * G;
+  }
+  const WideRegArgs& w = batch[chain];
   const StepRegressionArgs& a = w.reg;
-  int b = blockIdx.x;
   const int nb = a.n > 0 ? wide_reg_units_blocks(a) : 0;
   if (b < nb) {
     const int n_units = a.ustart[a.n];
-    const int lb = (b & 7) * (nb >> 3) + (b >> 3);
+    const int lb = kFolded ? b : (b & 7) * (nb >> 3) + (b >> 3);
     const int u = lb * 4 + (threadIdx.x >> 6);
     if (u < n_units) {
       const int which = u < a.ustart[1] ? 0 : 1;
@@ -428,6 +440,8 @@ void launch_wide_head_resident(hipStream_t st, const WideLaunchPlan& plan, void*
     else if (B == 2) hipLaunchKernelGGL(k_wide_instance<2>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
     else if (B <= 4) hipLaunchKernelGGL(k_wide_instance<4>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
     else if (B <= 6) hipLaunchKernelGGL(k_wide_instance<6>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
+    // (round 6, tried: groups of thirteen — two passes over the 137 MB basis instead of four for 25 chains — 151 µs against 128: beyond
+    // eight chains a group the wave is bound by its own unfused f64 multiply-adds, 6 per chain and basis column, not by HBM)
     else hipLaunchKernelGGL(k_wide_instance<8>, dim3(gx, cdiv(B, 8)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
   }
   if (plan.grid_prep > 0) {
