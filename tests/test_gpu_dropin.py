@@ -121,7 +121,13 @@ def test_chain_driven_method_by_method_matches_the_whole_step_chain(pkg, femur50
         ctx.close()
     assert np.array_equal(recs[2][:, 1], recs[3][:, 1]) and np.array_equal(recs[2][:, 2], recs[3][:, 2])
     assert recs[2][:, 1].sum() >= 3
-    assert np.array_equal(recs[2], recs[3])
+    if config == "femur50":
+        assert np.array_equal(recs[2], recs[3])
+    else:
+        # (the wide step at ranks <= 64 decomposes ahead with a warm-started Jacobi iteration whose starting basis depends on which
+        # decompositions happened to be complete — tests/test_gpu_wide_loop.py compares such chains the same way: decisions exactly,
+        # states to rounding)
+        assert np.allclose(recs[2][:, 3:], recs[3][:, 3:], rtol=1e-9, atol=1e-10)
     c = calls[3]
     assert c["bound_steps_from_propose"] + c["bound_steps_from_log_value"] == n_steps, c
     # per step: logValue(current) + logValue(proposal) at the boundary, propose (ICP steps) + 4 densities (shape moves)

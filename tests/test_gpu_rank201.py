@@ -54,9 +54,9 @@ def test_femur200_posterior_propose_and_transition_match_oracle(pkg, oracle, fem
 
 def test_femur200_chain_takes_the_wide_step_and_matches_oracle(pkg, oracle, femur200):
     """apps/femur/IcpProposalRegistration.scala:59-85 with the 200-component model: icp_chain_step_path is the wide step (not the
-    per-stage kernels), 40 steps decision for decision the oracle's chain."""
+    per-stage kernels), 24 steps decision for decision the oracle's chain."""
     model, target, om, ot = femur200
-    n_steps, seed = 40, 1024
+    n_steps, seed = 24, 1024
     setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
     theta0 = pkg.random_initial_parameters(model, 1)
     acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), theta0, seed, n_steps)
@@ -79,7 +79,7 @@ def test_femur200_on_device_loop_matches_oracle(pkg, oracle, femur200):
     """Three chains of the 200-component model inside icp_chains_run_on_device (the harness takes the loop from two chains on above
     rank 64): every step counted by the loop, every decision the oracle's."""
     model, target, om, ot = femur200
-    B, n = 3, 24
+    B, n = 3, 16
     setup = pkg.femur_icp_proposal_registration(model, target, fused=2)
     ctxs = [pkg.IcpContext(model, target, device=0) for _ in range(B)]
     theta0 = [pkg.random_initial_parameters(model, 4 + b) for b in range(B)]
@@ -124,7 +124,7 @@ def test_synthetic_ranks_above_201_on_the_wide_step(pkg, oracle, rank):
     assert np.abs(got - want).max() <= 1e-7 * np.abs(want[10:]).max()
     prop.close()
     setup = pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2)
-    n_steps = 16
+    n_steps = 16 if rank < 240 else 6   # (the oracle's own Jacobi iteration at rank 256 is what this test's time consists of)
     acc_o, comp_o, logp_o, states_o = oracle.run_chain(om, ot, oracle_chain_config(oracle, setup), theta, 55, n_steps)
     chain = pkg.SamplingRegistration(ctx, setup, theta, 55)
     rec = chain.run(n_steps)
