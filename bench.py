@@ -872,6 +872,7 @@ def config4_leg(pkg, args, device):
     model = face_model(pkg, args)
     targets = [pkg.data.synthetic_partial_target(model, seed=100 + t) for t in range(10)]
     make_setup = lambda m, t: pkg.bfm_fitting_partial(m, t, evaluator="collective", fused=args.fused)
+    pkg.expect_contexts(device, 25)  # (beside the warm-up item, as in run_config4: the streams of a submission's contexts)
     pkg.sharding.run_batch(pkg, model, targets[:1], n_chains=1, n_steps=5, make_setup=make_setup, dist=None, device_index=device)
     out = {"unit": "iterations/s", "targets": 10, "chains": 10,
            "workload": "BASELINE.json configs[4] with short chains: 10 targets x 10 random-init chains on the BFM-sized stand-in (N=%d, rank %d; 0.4 pose + "
@@ -1090,7 +1091,10 @@ def run_config4(pkg, args, dist, torch, rank, world, local_rank):
     make_setup = lambda m, t: pkg.bfm_fitting_partial(m, t, evaluator="collective", fused=args.fused)
     # chains of one target side by side (the wide step): all of them unless --chains-per-gpu says otherwise (1 = one after the other)
     cpl = args.chains_per_gpu if args.chains_per_gpu > 0 else 0  # (0: sharding.run_batch's default — three targets' chains per submission)
-    # warm-up: one item per rank (builds the communicator, pages the kernels in)
+    # warm-up: one item per rank (builds the communicator, pages the kernels in) — and, as a host that knows it is about to make a
+    # submission's worth of contexts would at its start, the hint that lets their streams be made meanwhile (icp_ctx_expect; until
+    # round 6 the first keyed context of a model did that unasked, i.e. also here)
+    pkg.expect_contexts(local_rank, 25)
     pkg.sharding.run_batch(pkg, model, targets[:1], n_chains=world, n_steps=max(1, args.warmup), make_setup=make_setup, dist=dist,
                            device_index=local_rank)
     if dist is not None:
