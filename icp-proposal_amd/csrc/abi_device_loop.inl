@@ -43,8 +43,9 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
     std::vector<std::vector<double>> theta_prop_scratch;
     // (ranks above 64) the streams of the step's independent branches — the group's first chain's own — and the events between them
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_sum = nullptr, ev_tails = nullptr, ev_eig[2] = {nullptr, nullptr};
+    hipEvent_t ev_sum = nullptr, ev_tails = nullptr, ev_decide = nullptr, ev_eig[2] = {nullptr, nullptr};
     int n_eig_streams = 0;
+    bool eig_split = false;
   };
   std::vector<Chain> chains;
   std::vector<std::unique_ptr<Group>> groups;
@@ -77,6 +78,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
         }
         if (gp->ev_sum) (void)hipEventDestroy(gp->ev_sum);
         if (gp->ev_tails) (void)hipEventDestroy(gp->ev_tails);
+        if (gp->ev_decide) (void)hipEventDestroy(gp->ev_decide);
       }
     }
   };
@@ -191,6 +193,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
         gr.side[0] = gc.front_stream.get(); gr.side[1] = gc.eig_stream.get(); gr.side[2] = gc.eig_stream2.get();
         HIP_OK(hipEventCreateWithFlags(&gr.ev_sum, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&gr.ev_tails, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&gr.ev_decide, hipEventDisableTiming));
         for (auto& e : gr.ev_eig) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       }
       const int B = gr.B;
@@ -475,14 +478,21 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
             S2 = gr.side[0];
             HIP_OK(hipEventRecord(gr.ev_sum, S));
             HIP_OK(hipStreamWaitEvent(S2, gr.ev_sum, 0));
+            // the proposed states' decompositions in two parts (round 6): the reduction to tridiagonal form — one workgroup per posterior,
+            // 0.4 ms at rank 200 — starts here for every chain; the eigenpairs, back-transformation and refinement behind it are issued
+            // BEHIND the decision (which falls while the reduction runs: tails and the evaluator's searches take 0.3 ms) and skip the
+            // chains that did not move — half of them and more: the solve launch is the chip's throughput kernel (6,000 eigenpair waves
+            // for 25 chains), and an accepted state's basis is all anybody will read
+            static const bool no_split = dev_env("ICP_WIDE_LOOP_EIG_SPLIT") && std::atoi(dev_env("ICP_WIDE_LOOP_EIG_SPLIT")) == 0;  // (A/B switch)
             int used = 0;
             for (int q0 = 0; q0 < nq; q0 += tri_chunk, ++used) {
               const hipStream_t E = gr.side[1 + (used & 1)];
               if (used < 2) HIP_OK(hipStreamWaitEvent(E, gr.ev_sum, 0));
-              launch_posterior_eigen_tridiag_many(E, r, std::min(tri_chunk, nq - q0), gr.rqs.data() + q0, gr.spec_parts.data() + q0, nullptr);
+              launch_posterior_eigen_tridiag_many(E, r, std::min(tri_chunk, nq - q0), gr.rqs.data() + q0, gr.spec_parts.data() + q0, nullptr, no_split ? 0 : 1);
             }
             gr.n_eig_streams = std::min(used, 2);
-            for (int u = 0; u < gr.n_eig_streams; ++u) HIP_OK(hipEventRecord(gr.ev_eig[u], gr.side[1 + u]));
+            gr.eig_split = !no_split;
+            if (no_split) for (int u = 0; u < gr.n_eig_streams; ++u) HIP_OK(hipEventRecord(gr.ev_eig[u], gr.side[1 + u]));
           }
           for (size_t p0 = 0; p0 < cap.factors.size(); p0 += fmax)
             launch_posterior_factor(S2, r, (int)std::min(fmax, cap.factors.size() - p0), cap.factors.data() + p0);
@@ -492,6 +502,16 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           if (cap.any_split) launch_wide_eval(S, cap.plan, gr.wide_dev.p);
           if (S2 != S) HIP_OK(hipStreamWaitEvent(S, gr.ev_tails, 0));
           launch_mhw_decide(S, gr.B, r, gr.mh.p);
+          if (gr.n_eig_streams > 0 && gr.eig_split) {  // (ranks above 64) part 2 of the decompositions, for the chains that moved
+            HIP_OK(hipEventRecord(gr.ev_decide, S));
+            int used = 0;
+            for (int q0 = 0; q0 < nq; q0 += tri_chunk, ++used) {
+              const hipStream_t E = gr.side[1 + (used & 1)];
+              if (used < 2) HIP_OK(hipStreamWaitEvent(E, gr.ev_decide, 0));
+              launch_posterior_eigen_tridiag_many(E, r, std::min(tri_chunk, nq - q0), gr.rqs.data() + q0, gr.spec_parts.data() + q0, gr.eig_skip.p + q0, 2);
+            }
+            for (int u = 0; u < gr.n_eig_streams; ++u) HIP_OK(hipEventRecord(gr.ev_eig[u], gr.side[1 + u]));
+          }
           for (int u = 0; u < gr.n_eig_streams; ++u) HIP_OK(hipStreamWaitEvent(S, gr.ev_eig[u], 0));
           launch_mhw_adopt(S, r, nq, gr.adopt.p, gr.eig_skip.p);
           if (jacobi) launch_posterior_eigen_resident(S, r, nq, gr.eig_rec.p, gr.eig_skip.p, root);

@@ -638,7 +638,10 @@ void launch_sum_partials_many(hipStream_t st, int r, int n, double* const* Mpart
 // decomposes that posterior again through launch_posterior_eigen.
 bool eigen_tridiag_many_supported(int r);
 void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n, const EigenRequest* rq, const double* const* parts /* may be null */,
-                                         const int* skip = nullptr /* device, [n]: != 0 leaves request i alone (the on-device loop) */);
+                                         const int* skip = nullptr /* device, [n]: != 0 leaves request i alone (the on-device loop) */,
+                                         int part = 0 /* 0: the whole sequence; 1: M and the reduction to tridiagonal form only; 2: what follows
+                                                         it — the on-device loop issues the two apart: the decision falls while the reduction
+                                                         runs, and part 2 then skips the chains that did not move */);
 
 // the number of chains whose searches share the launch being put together (thread-local; 1 = a lone chain): how far a task's queries are
 // split over workgroups (split_queries, split_surface_queries).  Never changes a result — only the partition of the work.

@@ -2318,7 +2318,7 @@ static void launch_eigen_tridiag(hipStream_t st, int r, const double* M, const d
 // the one-workgroup reductions run on n CUs at once.  No gated Jacobi fall-back in the sequence (see icp_kernels.hpp).
 bool eigen_tridiag_many_supported(int r) { return r > 64 && r <= kTriMaxRank; }
 void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const EigenRequest* rq_all, const double* const* parts_all,
-                                         const int* skip_all) {
+                                         const int* skip_all, int part) {
   const size_t rr = (size_t)r * r;
   const int nwg = (r + 3) / 4, nt = (r + 15) / 16;
   for (int q0 = 0; q0 < n_all; q0 += tri::kTriMany) {
@@ -2356,12 +2356,15 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
       assemble = assemble || am.P[q] != nullptr;
     }
     ProfScope _ps(st, KID_EIGEN);
-    if (assemble) hipLaunchKernelGGL(tri::k_assemble_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, am, skip);
-    if (r <= 128) hipLaunchKernelGGL((tri::k_tridiag_many<4, 2, 32, 0>), dim3(n), dim3(256), 0, st, tm, skip);
-    else if (r <= 192) hipLaunchKernelGGL((tri::k_tridiag_many<8, 3, 24, 0>), dim3(n), dim3(512), 0, st, tm, skip);
-    else if (r <= 200) hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 25, 7>), dim3(n), dim3(512), 0, st, tm, skip);
-    else if (r <= 208) hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 26, 6>), dim3(n), dim3(512), 0, st, tm, skip);
-    else hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 32, 0>), dim3(n), dim3(512), 0, st, tm, skip);
+    if (part != 2) {  // the reduction (part 1 of a split sequence: the long one-workgroup launch, before anybody knows whom to skip)
+      if (assemble) hipLaunchKernelGGL(tri::k_assemble_many, dim3((unsigned)((rr + 255) / 256), n), dim3(256), 0, st, r, am, skip);
+      if (r <= 128) hipLaunchKernelGGL((tri::k_tridiag_many<4, 2, 32, 0>), dim3(n), dim3(256), 0, st, tm, skip);
+      else if (r <= 192) hipLaunchKernelGGL((tri::k_tridiag_many<8, 3, 24, 0>), dim3(n), dim3(512), 0, st, tm, skip);
+      else if (r <= 200) hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 25, 7>), dim3(n), dim3(512), 0, st, tm, skip);
+      else if (r <= 208) hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 26, 6>), dim3(n), dim3(512), 0, st, tm, skip);
+      else hipLaunchKernelGGL((tri::k_tridiag_many<8, 4, 32, 0>), dim3(n), dim3(512), 0, st, tm, skip);
+    }
+    if (part == 1) continue;
     const int nwy = (r - 2 + tri::kWyBlock - 1) / tri::kWyBlock;
     // (the reflector blocks' T factors: the solve launch's trailing workgroups — tri_solve_or_wy)
     if (r <= 128) hipLaunchKernelGGL(tri::k_tri_solve_many<2>, dim3(nwg + nwy, n), dim3(256), tri::tri_solve_lds_bytes(r), st, sm, skip);

@@ -10,6 +10,7 @@ for d in . ${AB:+_old}; do
   f=$(find $O/$tag -name '*kernel_stats.csv' | head -1)
   python3 tools/stats_md.py $f "wide loop $tag" > $O/${tag}_kernel_stats.md
   python3 tools/trace_overlap.py $(find $O/$tag -name '*kernel_trace.csv' | head -1) 0.5 > $O/${tag}_queue_overlap.txt
+  python3 tools/r6_step_timeline.py $(find $O/$tag -name '*kernel_trace.csv' | head -1) > $O/${tag}_step_timeline.txt
   find $O/$tag -name '*kernel_trace.csv' -delete
   tail -1 $O/$tag.log | cut -c1-100
   head -24 $O/${tag}_kernel_stats.md | cut -c1-160
