@@ -749,7 +749,7 @@ def _tracked_json(names):
     return None, {}
 
 
-def config4_roofline(pkg, args, model, target, make_setup, device, n_chains=25, n_steps=60):
+def config4_roofline(pkg, args, model, target, make_setup, device, n_chains=25, n_steps=240):
     """The roofline / MFMA block of configs[4]'s steady state: ONE submission of `n_chains` chains of one target stepped inside the
     on-device loop (what sharding.run_batch submits: 4 x 25 for the 10 x 10 job), its launches under HIP events on the launch streams.
     Event ids are the step's stages: k_posterior_eigen = one launch sequence of the tridiagonal route for up to 16 posteriors
@@ -794,8 +794,9 @@ def config4_roofline(pkg, args, model, target, make_setup, device, n_chains=25, 
     roof = {"bound": "latency" if dominant.startswith(SINGLE_WORKGROUP) else "hbm", "kernel": dominant, "avg_launch_us": k["avg_us"], "launches": k["calls"],
             "chains_per_launch": per_launch, "algorithmic_bytes": None if alg1 is None else alg1 * per_launch, "achieved": None, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": None, "traffic": None, "latency": lat,
-            "sample": "%d chains of one target in one submission per step inside icp_chains_run_on_device (step_paths.device_loop = %d), %d steps: "
-                      "%.0f it/s, %.2f ms per round" % (n_chains, paths.get("device_loop", 0), n_steps, n_chains * n_steps / pdt, 1e3 * pdt / n_steps),
+            "sample": "%d chains of one target in one submission per step inside icp_chains_run_on_device (step_paths.device_loop = %d), ONE call of %d "
+                      "steps incl. its set-up (claim, capture, uploads: ~10 ms): %.0f it/s, %.2f ms per round"
+                      % (n_chains, paths.get("device_loop", 0), n_steps, n_chains * n_steps / pdt, 1e3 * pdt / n_steps),
             "value_in_this_stretch": n_chains * n_steps / pdt,
             "whole_step": {"algorithmic_bytes_per_chain_step": bytes_step, "hbm_frac": bytes_step * (n_chains * n_steps / pdt) / (HBM_PEAK_GBS * 1e9)},
             "kernel_us_per_round": {name: round(v["total_ms"] * 1e3 / n_steps, 2) for name, v in pst.items()}}
@@ -828,7 +829,8 @@ def config4_roofline(pkg, args, model, target, make_setup, device, n_chains=25, 
         c = traffic.get("k_wide_regression_fold", {}).get("hbm_bytes_per_launch")
         if c:
             row.update(counter_bytes_per_launch=c, counter_GBs=c / (us * 1e-6) / 1e9, counter_frac=c / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                       note="every macro tile reads its columns of every correspondence's operand rows again: counter bytes = %.1f x algorithmic" % (c / alg))
+                       note="counter bytes = %.1f x algorithmic (round 6: the launch's (chain, block) pairs are dealt out XCD by XCD, a posterior's operand "
+                            "rows come from ONE L2 after the first touch; with blockIdx.y = chain every XCD fetched them again: 317 MB per launch, 4.5 x)" % (c / alg))
         hbm["k_wide_regression_fold"] = row
     roof["hbm_kernels"] = hbm
     if sq:
