@@ -754,7 +754,7 @@ def config4_roofline(pkg, args, model, target, make_setup, device, n_chains=25, 
     on-device loop (what sharding.run_batch submits: 4 x 25 for the 10 x 10 job), its launches under HIP events on the launch streams.
     Event ids are the step's stages: k_posterior_eigen = one launch sequence of the tridiagonal route for up to 16 posteriors
     (k_assemble_many -> k_tridiag_many -> k_tri_solve_many -> k_tri_back_many -> 3 x k_tri_gemm_many + correction), k_instance =
-    k_wide_instance<8>, k_step_regression = k_wide_xrows + k_wide_regression_fold, k_step_filter / k_step_resolve = the proposal's searches,
+    k_wide_instance<G>, k_step_regression = k_wide_xrows + k_wide_regression_fold, k_step_filter / k_step_resolve = the proposal's searches,
     k_surface_* / k_vertex_* = the evaluator's.  Counter figures (HBM bytes, MFMA-busy, waves per SIMD) are those of the SAME regime's
     rocprofv3 --pmc passes (profiles/r06_pmc_*.json, regime wide_loop25: tools/r6_profiles.sh) — tracked files, not measured in this run."""
     setup = make_setup(model, target)
@@ -810,13 +810,17 @@ def config4_roofline(pkg, args, model, target, make_setup, device, n_chains=25, 
         roof["traffic_source"] = tsrc + " (wide_loop25: the sequence's launches summed, 16 posteriors a launch)"
     # the step's HBM-bound kernels against the roofline (durations of THIS run, counter bytes of the tracked pass)
     groups = -(-n_chains // 8)
+    gsize = -(-n_chains // groups)
     hbm = {}
     if "k_instance" in pst:
-        alg = groups * 3 * N * r * 8 + n_chains * 3 * N * 8 * 4   # the basis once per group of <= 8 chains; reference, mean in, instance + kept deformation out
+        alg = 3 * N * r * 8 + n_chains * 3 * N * 8 * 4   # the basis ONCE (its groups of chains share an XCD's L2); reference, mean in, instance + kept deformation out
         us = pst["k_instance"]["avg_us"]
-        row = {"kernel": "k_wide_instance<8>", "avg_launch_us": us, "algorithmic_bytes": alg, "achieved_GBs": alg / (us * 1e-6) / 1e9,
-               "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "note": "%d passes over the 137 MB basis (groups of <= 8 chains)" % groups}
-        c = traffic.get("k_wide_instance<8>", {}).get("hbm_bytes_per_launch")
+        inst_name = "k_wide_instance<%d>" % min(max(gsize, 5), 8)
+        row = {"kernel": inst_name, "avg_launch_us": us, "algorithmic_bytes": alg, "achieved_GBs": alg / (us * 1e-6) / 1e9,
+               "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+               "note": "%d groups of <= %d chains, each a pass over the 137 MB basis — the groups of one point block on ONE XCD (round 6), so the passes "
+                       "behind the first are L2 hits; the launch is then bound by its waves' unfused f64 multiply-adds (6 per chain and basis column)" % (groups, gsize)}
+        c = traffic.get(inst_name, {}).get("hbm_bytes_per_launch")
         if c:
             row.update(counter_bytes_per_launch=c, counter_GBs=c / (us * 1e-6) / 1e9, counter_frac=c / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
         hbm["k_wide_instance"] = row
@@ -837,7 +841,7 @@ def config4_roofline(pkg, args, model, target, make_setup, device, n_chains=25, 
         roof["occupancy"] = {q: {"avg_waves_per_simd": round(v.get("avg_waves_per_simd", 0.0), 3), "parked_share": round(v.get("parked_share", 0.0), 3),
                                  "lds_conflict_share": round(v.get("lds_conflict_share", 0.0), 3), "median_us_alone": v.get("median_us")}
                              for q, v in sq.items() if q in ("k_tridiag_many", "k_tri_solve_many", "k_tri_back_many", "k_tri_gemm_many", "k_wide_regression_fold",
-                                                             "k_wide_instance<8>", "k_wide_filter", "k_wide_resolve", "k_posterior_factor_tiles", "k_wide_xrows")}
+                                                             "k_wide_instance<8>", "k_wide_instance<7>", "k_wide_filter", "k_wide_resolve", "k_posterior_factor_tiles", "k_wide_xrows")}
         roof["occupancy_source"] = ssrc + " (one kernel at a time: durations WITHOUT neighbours)"
     # MFMA utilisation of the projection where it IS GEMM-shaped: the folded regression of a submission's posteriors
     mfma = None

@@ -92,24 +92,29 @@ def _model_key(model) -> int:
     model's 137 MB) where that is importable, the object's number otherwise — so that the contexts of a batch registration (one per
     chain) do not each hash the basis again (6.6 ms per context).  The model's arrays are made read-only when the key is taken: a
     changed model is a new StatisticalMeshModel object (and a new key)."""
-    key = getattr(model, "_icp_model_key", None)
-    if key is None:
-        try:
-            import xxhash
-            hx = xxhash.xxh3_64()
-            for arr in (model.basis, model.variance, model.ref_points, model.mean_def):
-                hx.update(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).data)
-            key = (hx.intdigest() & 0xFFFFFFFFFFFFFFFF) or 1
-        except Exception:
-            key = (next(_model_keys) << 20) | 0x5A5A5
-        try:
-            model._icp_model_key = key
-            # the key vouches for these arrays (icp_ctx_create_keyed: "equal keys mean equal arrays"): an in-place edit after this
-            # point would silently meet the stale device copy, so the arrays are frozen — a changed model is a new object
-            for arr in (model.basis, model.variance, model.ref_points, model.mean_def, model.cells):
-                arr.flags.writeable = False
-        except Exception:
-            pass
+    arrays = (model.basis, model.variance, model.ref_points, model.mean_def, model.cells)
+    where = tuple(a.__array_interface__["data"][0] for a in arrays)
+    cached = getattr(model, "_icp_model_key", None)
+    # (the key belongs to THESE arrays, frozen: a copy of the model object — copy.deepcopy carries the attribute along — or an array
+    # swapped or made writeable again is hashed anew)
+    if cached is not None and cached[1] == where and not any(a.flags.writeable for a in arrays):
+        return cached[0]
+    try:
+        import xxhash
+        hx = xxhash.xxh3_64()
+        for arr in arrays[:4]:
+            hx.update(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).data)
+        key = (hx.intdigest() & 0xFFFFFFFFFFFFFFFF) or 1
+    except Exception:
+        key = (next(_model_keys) << 20) | 0x5A5A5
+    try:
+        # the key vouches for these arrays (icp_ctx_create_keyed: "equal keys mean equal arrays"): an in-place edit after this
+        # point would silently meet the stale device copy, so the arrays are frozen — a changed model is a new object
+        for arr in arrays:
+            arr.flags.writeable = False
+        model._icp_model_key = (key, where)
+    except Exception:
+        pass
     return key
 
 

@@ -442,7 +442,19 @@ void launch_wide_head_resident(hipStream_t st, const WideLaunchPlan& plan, void*
     else if (B <= 6) hipLaunchKernelGGL(k_wide_instance<6>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
     // (round 6, tried: groups of thirteen — two passes over the 137 MB basis instead of four for 25 chains — 151 µs against 128: beyond
     // eight chains a group the wave is bound by its own unfused f64 multiply-adds, 6 per chain and basis column, not by HBM)
-    else hipLaunchKernelGGL(k_wide_instance<8>, dim3(gx, cdiv(B, 8)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
+    // (round 6: the row of point blocks padded to a multiple of eight, so that the groups of ONE point block — linear workgroup ids a
+    // whole row apart — go to the same XCD: all groups are resident at once, and the basis rows the first fetches are L2 hits for the others)
+    else {
+      // more than eight chains: groups of equal size, at most eight chains each (25 chains: 7 + 7 + 7 + 4, not 8 + 8 + 8 + 1), the row of point
+      // blocks padded to a multiple of eight so that the groups of ONE point block — linear workgroup ids a whole row apart — go to the
+      // same XCD: all groups are resident at once, and the basis rows the first fetches are L2 hits for the others (round 6: 129 -> 99 µs for
+      // 25 chains; HBM bytes per launch from four passes over the 137 MB basis towards one)
+      const int ng = cdiv(B, 8), G = cdiv(B, ng), gx8 = (gx + 7) / 8 * 8;
+      if (G <= 5) hipLaunchKernelGGL(k_wide_instance<5>, dim3(gx8, cdiv(B, 5)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
+      else if (G == 6) hipLaunchKernelGGL(k_wide_instance<6>, dim3(gx8, cdiv(B, 6)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
+      else if (G == 7) hipLaunchKernelGGL(k_wide_instance<7>, dim3(gx8, cdiv(B, 7)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
+      else hipLaunchKernelGGL(k_wide_instance<8>, dim3(gx8, cdiv(B, 8)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
+    }
   }
   if (plan.grid_prep > 0) {
     ProfScope _ps(st, KID_TRI_SPHERES);

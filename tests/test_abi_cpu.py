@@ -121,6 +121,32 @@ def test_round3_entry_points_reject_bad_arguments_before_device(pkg):
     assert ctypes.sizeof(nat.MhMixture) == 104  # (round 4: + w_pose and the six pose walks' sigmas; round 5: struct_size in front)
 
 
+def test_round6_entry_points_reject_bad_arguments_before_device(pkg):
+    """icp_chain_bind / icp_chain_bind_stats / icp_ctx_expect: null handles and bad counts are refused without touching a device; the
+    hint for a device that does not exist says so instead of starting a helper thread."""
+    lib = pkg._native.lib()
+    assert lib.icp_chain_bind(None, 0, None) == -1 and b"null argument" in lib.icp_last_error()
+    out = (ctypes.c_int64 * 3)()
+    assert lib.icp_chain_bind_stats(None, out) == -1
+    assert lib.icp_ctx_expect(0, -1) == -1
+    assert lib.icp_ctx_expect(0, 8) == -2   # ICP_ERR_DEVICE: no HIP device in this container (on a GPU box: 0)
+
+
+def test_model_arrays_are_frozen_once_the_model_key_is_taken(pkg, femur50):
+    """api._model_key vouches for the arrays it hashed (icp_ctx_create_keyed: equal keys mean equal arrays): an in-place edit afterwards
+    would meet the stale device copy, so the arrays go read-only and a changed model has to be a new object (advisor, round 5)."""
+    import copy
+    model = copy.deepcopy(femur50[0])
+    k1 = pkg.api._model_key(model)
+    assert k1 == pkg.api._model_key(model) and not model.basis.flags.writeable
+    with pytest.raises(ValueError):
+        model.basis[0, 0] += 1.0
+    other = copy.deepcopy(femur50[0])
+    other.basis = other.basis.copy()
+    other.basis[0, 0] += 1.0
+    assert pkg.api._model_key(other) != k1
+
+
 def test_synthetic_target_sizes(pkg):
     """BASELINE.json configs[1]: 6-way subdivision of the femur target -> 58,322 vertices / 116,640 triangles."""
     _, big = pkg.data.synthetic_femur_target()
