@@ -23,7 +23,11 @@ class Jvm:
 
     def __init__(self, pkg):
         pkg._native.lib()  # (the C ABI library first: the shim links against it)
-        self.L = C.CDLL(os.path.join(ROOT, "tests", "support", "jni_mock", "libicp_jni_mock.so"))
+        so = os.path.join(ROOT, "tests", "support", "jni_mock", "libicp_jni_mock.so")
+        if not os.path.exists(so):  # (built by __graft_entry__.build(); the box has the same gcc)
+            import subprocess
+            subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "support"), "jni_mock/libicp_jni_mock.so"], check=True)
+        self.L = C.CDLL(so)
         self.L.mock_env.restype = C.c_void_p
         self.L.mock_new_array.restype = C.c_void_p
         self.L.mock_new_array.argtypes = [C.c_int, C.c_int32, C.c_void_p]
