@@ -214,6 +214,15 @@ int icp_ctx_create_keyed(const icp_model_desc* model, const icp_mesh_desc* targe
       std::vector<int> off, adj;
       vertex_adjacency(N, T, model->triangles, off, adj);
       sm->n_boundary = (int)std::count(mb.begin(), mb.end(), (uint8_t)1);
+      {
+        sm->ring_prefix_max.assign((size_t)N, 0);
+        for (int v = 0; v < N; ++v) {
+          int reach = v;
+          for (int a = off[v]; a < off[v + 1]; ++a)
+            for (int q = 0; q < 3; ++q) reach = std::max(reach, (int)model->triangles[3 * (size_t)adj[a] + q]);
+          sm->ring_prefix_max[v] = v > 0 ? std::max(reach, sm->ring_prefix_max[v - 1]) : reach;
+        }
+      }
       sm->ref.upload(model->ref_points, (size_t)3 * N);
       sm->mean.upload(mean.data(), mean.size());
       sm->Q.upload(Q.data(), Q.size());

@@ -43,7 +43,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
     std::vector<std::vector<double>> theta_prop_scratch;
     // (ranks above 64) the streams of the step's independent branches — the group's first chain's own — and the events between them
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_sum = nullptr, ev_tails = nullptr, ev_decide = nullptr, ev_eig[2] = {nullptr, nullptr};
+    hipEvent_t ev_sum = nullptr, ev_tails = nullptr, ev_decide = nullptr, ev_prop = nullptr, ev_inst = nullptr, ev_eig[2] = {nullptr, nullptr};
     int n_eig_streams = 0;
     bool eig_split = false;
   };
@@ -79,6 +79,8 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
         if (gp->ev_sum) (void)hipEventDestroy(gp->ev_sum);
         if (gp->ev_tails) (void)hipEventDestroy(gp->ev_tails);
         if (gp->ev_decide) (void)hipEventDestroy(gp->ev_decide);
+        if (gp->ev_prop) (void)hipEventDestroy(gp->ev_prop);
+        if (gp->ev_inst) (void)hipEventDestroy(gp->ev_inst);
       }
     }
   };
@@ -194,6 +196,8 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
         HIP_OK(hipEventCreateWithFlags(&gr.ev_sum, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&gr.ev_tails, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&gr.ev_decide, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&gr.ev_prop, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&gr.ev_inst, hipEventDisableTiming));
         for (auto& e : gr.ev_eig) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       }
       const int B = gr.B;
@@ -227,6 +231,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
       wide_issue(t, glead, glead, &gr.cap);
       WideCapture& cap = gr.cap;
       phase("capture");
+      if (dev_env("ICP_WIDE_LOOP_TIMING")) std::fprintf(stderr, "[icp wide loop] instance head %d of %d blocks (any_split %d)\n", cap.plan.inst_head_blocks, (cap.plan.N + 63) / 64, (int)cap.any_split);
       require((int)cap.chain_args.size() == B && (int)cap.prop_items.size() == B && (int)cap.factors.size() == B * n_props &&
               (int)cap.tails.size() == 2 * B * n_props, "internal: captured wide step is incomplete");
       for (int k = 0; k < B; ++k) {
@@ -466,7 +471,21 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           const int nq = gr.B * n_props;
           launch_mhw_front(S, gr.B, gr.mh.p);
           launch_wide_propose_resident(S, r, gr.B, gr.items.p);
-          launch_wide_head_resident(S, cap.plan, gr.wide_dev.p);
+          // the proposed states' instances.  The main sequence (the proposals' K model ids against the target, their regression) reads the
+          // first blocks of model points only — the ids and the corners of their triangles (plan.inst_head_blocks: wide_issue) — and goes
+          // ahead after those; the rest of the 28,561 points and the spheres over them (0.1 ms for 25 chains, what the evaluator's
+          // searches read) are beside it on the second stream (round 6)
+          static const bool no_head = dev_env("ICP_WIDE_LOOP_HEAD_SPLIT") && std::atoi(dev_env("ICP_WIDE_LOOP_HEAD_SPLIT")) == 0;  // (A/B switch)
+          const bool head_split = gr.side[0] && cap.any_split && cap.plan.inst_head_blocks > 0 && !no_head;
+          if (head_split) {
+            // (the rest BEHIND the head, not beside it: every wave of this launch walks the same 13 batches of basis rows, and with 1,788
+            // of them resident the head's 36 finish when all do — 97 µs; alone they take a fraction of that)
+            launch_wide_head_resident(S, cap.plan, gr.wide_dev.p, 1);
+            HIP_OK(hipEventRecord(gr.ev_prop, S));
+            HIP_OK(hipStreamWaitEvent(gr.side[0], gr.ev_prop, 0));
+            launch_wide_head_resident(gr.side[0], cap.plan, gr.wide_dev.p, 2);
+            HIP_OK(hipEventRecord(gr.ev_inst, gr.side[0]));
+          } else launch_wide_head_resident(S, cap.plan, gr.wide_dev.p);
           launch_wide_main(S, cap.plan, gr.wide_dev.p);
           for (size_t p0 = 0; p0 < cap.sum_parts.size(); p0 += kWideMaxChains)
             launch_sum_partials_many(S, r, (int)std::min<size_t>(kWideMaxChains, cap.sum_parts.size() - p0), cap.sum_parts.data() + p0, cap.sum_splits.data() + p0);
@@ -499,6 +518,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           for (size_t t0 = 0; t0 < cap.tails.size(); t0 += 2 * kWideMaxChains)
             launch_transition_tails(S2, r, (int)std::min<size_t>(2 * kWideMaxChains, cap.tails.size() - t0), cap.tails.data() + t0, lead.Ginv.p, kSigma2);
           if (S2 != S) HIP_OK(hipEventRecord(gr.ev_tails, S2));
+          if (head_split) HIP_OK(hipStreamWaitEvent(S, gr.ev_inst, 0));
           if (cap.any_split) launch_wide_eval(S, cap.plan, gr.wide_dev.p);
           if (S2 != S) HIP_OK(hipStreamWaitEvent(S, gr.ev_tails, 0));
           launch_mhw_decide(S, gr.B, r, gr.mh.p);

@@ -239,6 +239,9 @@ struct SharedModel {
   DBuf<uint8_t> boundary;
   int n_boundary = 0;
   int device = 0;
+  // host: ring_prefix_max[k] = the largest vertex id among the vertices k' <= k and the corners of their triangles — what the vertex
+  // normals of the model ids 0..k read (the instance launch's head: wide_issue)
+  std::vector<int> ring_prefix_max;
 };
 struct SharedTarget {
   DeviceMesh mesh;

@@ -231,6 +231,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead, WideCapture* 
   plan.B = nW; plan.N = elead.N; plan.r = r; plan.Qp = elead.Qp.p; plan.ref = elead.ref.p; plan.mean = elead.mean.p;
   plan.f1_prepared = true;
   bool any_split = false;
+  int inst_head_points = 0;  // (INT_MAX: some chain's main sequence reads the whole instance)
   const bool concurrent = t.items[idx[0]].e->prm.kind == ICP_EVAL_HAUSDORFF;  // (how a split step's two sequences are scheduled: below)
   const int spec_mode = speculation_mode();
 
@@ -378,6 +379,10 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead, WideCapture* 
     const bool split = w.do_post && (concurrent ? hd : true);
     const int Kp = split ? (pm ? std::min(pm->K, Ksurf) : 0) : 0;
     any_split = any_split || split;
+    // (the instance launch's head: the blocks of model points the MAIN sequence reads — ids below Kp and the corners of their triangles)
+    if (capture && split && pm && !pt && Kp > 0 && (size_t)Kp <= c.shared_model->ring_prefix_max.size())
+      inst_head_points = std::max(inst_head_points, c.shared_model->ring_prefix_max[(size_t)Kp - 1] + 1);
+    else inst_head_points = INT_MAX;
     int nnv_main = Knnv, nnv_lo = 0, nnv_hi = 0;  // nearest vertices: ids [0, nnv_main) by the main sequence, [nnv_lo, nnv_hi) by the evaluator's
     if (split) {
       nnv_main = prop_nnv ? pm->K : 0;
@@ -609,6 +614,11 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead, WideCapture* 
     }
   }
   if (capture) {  // (nothing launched; what the chains hold stays reserved until the caller's wide_release)
+    // the instance launch's head: the main sequence goes ahead after these blocks of 64 points, the rest is beside it (abi_device_loop.inl)
+    if (any_split && inst_head_points > 0 && inst_head_points != INT_MAX) {
+      const int hb = (inst_head_points + 63) / 64, all = (plan.N + 63) / 64;
+      plan.inst_head_blocks = 4 * hb <= all ? hb : 0;
+    }
     capture->plan = plan; capture->any_split = any_split;
     capture->chain_args = std::move(chain_args); capture->prop_items = std::move(prop_items);
     capture->sum_parts = std::move(sum_parts); capture->sum_splits = std::move(sum_splits);

@@ -610,6 +610,11 @@ struct WideLaunchPlan {
   int grid_prep, grid_f1, grid_r1, grid_f2, grid_r2, grid_reg;
   int grid_f1b, grid_r1b, grid_f2b, grid_r2b, grid_regb;  // the evaluator's own sequence (s1b, s2b, regb), if any chain of the batch has one
   bool f1_prepared;
+  // (round 6; the on-device loop) the first blocks of 64 model points of the instance launch that the MAIN sequence reads — the
+  // proposal's K model ids and the corners of their triangles (vertex normals): launch_wide_head_resident part 1 makes these, the main
+  // sequence follows at once, part 2 — the other 98 % of the instance and W3, which only the evaluator's searches read — runs beside it
+  // on another stream.  0: no such split (a TargetSampling proposal searches the whole instance; a mesh whose ids are not local)
+  int inst_head_blocks = 0;
 };
 // s1 / s2 / reg: the step's searches and reductions — or only what the PROPOSAL needs (its K model ids, their nearest vertices, the
 // regression: what the factorisation, the tails and the decomposition wait for), the evaluator's searches and reductions being a
@@ -620,7 +625,8 @@ struct WideChainArgs { WideInstArgs inst; WidePrepArgs prep; StepSearchArgs s1, 
 void launch_wide_head(hipStream_t st, const WideLaunchPlan& plan, const WideChainArgs* chains, void* pinned, void* device);
 // the same records laid out in host memory `dst` (wide_batch_bytes(B)) / W2 and W3 from records already in `device`
 void wide_pack_args(int B, const WideChainArgs* chains, void* dst);
-void launch_wide_head_resident(hipStream_t st, const WideLaunchPlan& plan, void* device);
+void launch_wide_head_resident(hipStream_t st, const WideLaunchPlan& plan, void* device,
+                               int part = 0 /* 1: the instance launch's head (plan.inst_head_blocks); 2: the rest of it and W3; 0: everything */);
 // where chain b's records sit inside such a block
 WideInstArgs* wide_inst_record(void* block, int B, int b);
 StepSearchArgs* wide_search_record(void* block, int B, int stage /* 0: s1, 1: s2 */, int b);

@@ -68,8 +68,9 @@ constexpr int kWideMaxRankLds = 256;
 
 template <int G>
 __global__ void __launch_bounds__(kWideInstBlock) k_wide_instance(int B, int N, int r, const double* __restrict__ Qp, const double* __restrict__ ref,
-                                                                  const double* __restrict__ mean, const WideInstArgs* __restrict__ batch) {
+                                                                  const double* __restrict__ mean, const WideInstArgs* __restrict__ batch, int block0, int nblocks) {
   __shared__ double s_c[G][kWideMaxRankLds];
+  if ((int)blockIdx.x >= nblocks) return;  // (the row is padded to a multiple of eight)
   const int g0 = blockIdx.y * G;
   const int ng = min(G, B - g0);
   const int tid = threadIdx.x;
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(kWideInstBlock) k_wide_instance(int B, int N, 
       for (int j = tid; j < r; j += kWideInstBlock) s_c[g][j] = batch[g0 + g].coeffs[j];
     }
   __syncthreads();
-  const int i = blockIdx.x * kWideInstBlock + tid;
+  const int i = (block0 + (int)blockIdx.x) * kWideInstBlock + tid;  // (block0: a launch that takes the blocks from there on — the instance's head and rest)
   if (i >= N) return;
   double a0[G], a1[G], a2[G];
   const double m0 = mean[3 * i], m1 = mean[3 * i + 1], m2 = mean[3 * i + 2];
@@ -142,10 +143,15 @@ __global__ void __launch_bounds__(kWideInstBlock) k_wide_instance(int B, int N, 
 // ---------------------------------------------------------------- W3: what needs the COMPLETE new instance before the searches
 // bounding spheres of its triangles (the evaluator's target -> model queries search it), the bounds of those queries (distance to
 // each query's previous winner at its new position), the counters of the vertex searches, the accumulating reduction outputs
-__global__ void __launch_bounds__(kSearchBlock) k_wide_prepare(const WidePrepArgs* __restrict__ batch) {
+// mode 0: everything; 1: only what does NOT read the new instance — the counters and the accumulating outputs (the main sequence's
+// nearest-vertex stage waits for these, not for the instance's 28,561 points); 2: only what does (spheres, the t2m queries' bounds)
+__global__ void __launch_bounds__(kSearchBlock) k_wide_prepare(const WidePrepArgs* __restrict__ batch, int mode) {
   const WidePrepArgs& a = batch[blockIdx.y];
   int b = blockIdx.x;
   const int nb_s = (a.T + kSearchBlock - 1) / kSearchBlock;
+  const int nb_q0 = a.has_t2m ? (a.t2m.Kpad + kSearchBlock - 1) / kSearchBlock : 0;
+  if (mode == 1 && b < nb_s + nb_q0) return;
+  if (mode == 2 && b >= nb_s + nb_q0) return;
   if (b < nb_s) {
     const int pos = b * kSearchBlock + threadIdx.x;
     if (pos < a.T) {
@@ -426,39 +432,44 @@ void launch_wide_head(hipStream_t st, const WideLaunchPlan& plan, const WideChai
   launch_wide_head_resident(st, plan, device);
 }
 
-void launch_wide_head_resident(hipStream_t st, const WideLaunchPlan& plan, void* device) {
+void launch_wide_head_resident(hipStream_t st, const WideLaunchPlan& plan, void* device, int part) {
   const int B = plan.B;
   if (B <= 0) return;
   const WideOffsets o = wide_offsets(B);
   char* d = (char*)device;
+  const int gx_all = cdiv(plan.N, kWideInstBlock);
+  const int head = (part != 0 && plan.inst_head_blocks > 0 && plan.inst_head_blocks < gx_all) ? plan.inst_head_blocks : 0;
+  if (part == 1 && head == 0) part = 0;            // (no split in this plan: everything now …
+  if (part == 2 && head == 0) return;              //  … and nothing later)
+  const int block0 = part == 2 ? head : 0;
+  const int gx = part == 1 ? head : gx_all - block0;
   {
     ProfScope _ps(st, KID_INSTANCE);
     const dim3 block(kWideInstBlock);
-    const int gx = cdiv(plan.N, kWideInstBlock);
     const WideInstArgs* ia = (const WideInstArgs*)d;
-    if (B == 1) hipLaunchKernelGGL(k_wide_instance<1>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
-    else if (B == 2) hipLaunchKernelGGL(k_wide_instance<2>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
-    else if (B <= 4) hipLaunchKernelGGL(k_wide_instance<4>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
-    else if (B <= 6) hipLaunchKernelGGL(k_wide_instance<6>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
+    // (the head: a handful of point blocks the main sequence waits for — a wave per chain and block: a wave's time is its own chain of 13 batches
+    // of 48 loads and G x 96 f64 operations each, 81 µs in groups of seven whatever else is resident)
+    if (B == 1 || part == 1) hipLaunchKernelGGL(k_wide_instance<1>, dim3(gx, B), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia, block0, gx);
+    else if (B == 2) hipLaunchKernelGGL(k_wide_instance<2>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia, block0, gx);
+    else if (B <= 4) hipLaunchKernelGGL(k_wide_instance<4>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia, block0, gx);
+    else if (B <= 6) hipLaunchKernelGGL(k_wide_instance<6>, dim3(gx, 1), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia, block0, gx);
     // (round 6, tried: groups of thirteen — two passes over the 137 MB basis instead of four for 25 chains — 151 µs against 128: beyond
     // eight chains a group the wave is bound by its own unfused f64 multiply-adds, 6 per chain and basis column, not by HBM)
-    // (round 6: the row of point blocks padded to a multiple of eight, so that the groups of ONE point block — linear workgroup ids a
-    // whole row apart — go to the same XCD: all groups are resident at once, and the basis rows the first fetches are L2 hits for the others)
     else {
       // more than eight chains: groups of equal size, at most eight chains each (25 chains: 7 + 7 + 7 + 4, not 8 + 8 + 8 + 1), the row of point
       // blocks padded to a multiple of eight so that the groups of ONE point block — linear workgroup ids a whole row apart — go to the
       // same XCD: all groups are resident at once, and the basis rows the first fetches are L2 hits for the others (round 6: 129 -> 99 µs for
       // 25 chains; HBM bytes per launch from four passes over the 137 MB basis towards one)
       const int ng = cdiv(B, 8), G = cdiv(B, ng), gx8 = (gx + 7) / 8 * 8;
-      if (G <= 5) hipLaunchKernelGGL(k_wide_instance<5>, dim3(gx8, cdiv(B, 5)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
-      else if (G == 6) hipLaunchKernelGGL(k_wide_instance<6>, dim3(gx8, cdiv(B, 6)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
-      else if (G == 7) hipLaunchKernelGGL(k_wide_instance<7>, dim3(gx8, cdiv(B, 7)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
-      else hipLaunchKernelGGL(k_wide_instance<8>, dim3(gx8, cdiv(B, 8)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia);
+      if (G <= 5) hipLaunchKernelGGL(k_wide_instance<5>, dim3(gx8, cdiv(B, 5)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia, block0, gx);
+      else if (G == 6) hipLaunchKernelGGL(k_wide_instance<6>, dim3(gx8, cdiv(B, 6)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia, block0, gx);
+      else if (G == 7) hipLaunchKernelGGL(k_wide_instance<7>, dim3(gx8, cdiv(B, 7)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia, block0, gx);
+      else hipLaunchKernelGGL(k_wide_instance<8>, dim3(gx8, cdiv(B, 8)), block, 0, st, B, plan.N, plan.r, plan.Qp, plan.ref, plan.mean, ia, block0, gx);
     }
   }
   if (plan.grid_prep > 0) {
     ProfScope _ps(st, KID_TRI_SPHERES);
-    hipLaunchKernelGGL(k_wide_prepare, dim3(plan.grid_prep, B), dim3(kSearchBlock), 0, st, (const WidePrepArgs*)(d + o.prep));
+    hipLaunchKernelGGL(k_wide_prepare, dim3(plan.grid_prep, B), dim3(kSearchBlock), 0, st, (const WidePrepArgs*)(d + o.prep), part);
   }
 }
 
