@@ -497,7 +497,7 @@ void wide_issue(icp_step_ticket& t, icp_ctx& lead, icp_ctx& elead, WideCapture* 
       plan.reg_folded = plan.reg_folded || g.fold[i] > 1;
       g.X[i] = nullptr;
       if (g.fold[i] > 1 && g.macro[i] > 1) {  // the operand rows of the posterior's correspondences, made ahead of the regression launch
-        const int xrs = 16 * ((r + 1 + 15) / 16);
+        const int xrs = 32 * ((r + 1 + 31) / 32);  // (whole 2 x 16-column macro blocks: the rows are stored interleaved, see StepRegressionArgs::X)
         const size_t need = (size_t)std::max(p->K, 1) * 4 * xrs;
         if (p->xrows.n < need) p->xrows.alloc(need);
         g.X[i] = p->xrows.p;

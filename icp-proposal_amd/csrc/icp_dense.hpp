@@ -296,19 +296,25 @@ __device__ __forceinline__ void regression_macro_fold(int mtile, int leaves, int
 // (2.6 MB per posterior), lane (column, j) loads ONE value per tile row / column block — a third of the traffic, every byte of a
 // 512-byte request used —, no id in between, and six correspondences in flight instead of three.  Same values into the same matrix
 // instructions in the same order: the bits of regression_tile.
+template <int N> struct IntK { static constexpr int value = N; };
 template <int MT>
 __device__ __forceinline__ void regression_macro_fold_x(int mtile, int leaves, int K, int kchunk, int r, const double* __restrict__ X, int xrs,
                                                         const CorrBuffers& cb, double wt, double kappa, double* __restrict__ Mpart) {
+  // (everything but the lane's place in the tile is the same for the whole wave — said so, it lives in scalar registers and the
+  // tests around the matrix instructions are scalar branches instead of exec-mask sequences)
+  mtile = __builtin_amdgcn_readfirstlane(mtile); leaves = __builtin_amdgcn_readfirstlane(leaves); K = __builtin_amdgcn_readfirstlane(K);
+  kchunk = __builtin_amdgcn_readfirstlane(kchunk); r = __builtin_amdgcn_readfirstlane(r); xrs = __builtin_amdgcn_readfirstlane(xrs);
   const int n = r + 1, nt = (n + 15) >> 4;
   int mi = 0;
   while ((mi + 1) * (mi + 2) / 2 <= mtile) ++mi;
   const int mj = mtile - mi * (mi + 1) / 2;
   const int l = threadIdx.x & 63, i16 = l & 15, kk = l >> 4;
-  int ca[MT], cbi[MT];
+  static_assert(MT == 2, "the operand rows are stored for 2 x 2 macro tiles (StepRegressionArgs::X)");
+  int ca[MT], cbi[MT];  // (the two tiles of a macro block interleaved: both operands of a lane side by side; blocks past the rank hold zeros)
 #pragma unroll
   for (int p = 0; p < MT; ++p) {
-    ca[p] = MT * mi + p < nt ? 16 * (MT * mi + p) + i16 : 0;
-    cbi[p] = MT * mj + p < nt ? 16 * (MT * mj + p) + i16 : 0;
+    ca[p] = 32 * mi + 2 * i16 + p;
+    cbi[p] = 32 * mj + 2 * i16 + p;
   }
   bool on[MT][MT];  // (uniform) tile (MT·mi + p, MT·mj + q) exists and lies in the lower triangle
 #pragma unroll
@@ -321,8 +327,86 @@ __device__ __forceinline__ void regression_macro_fold_x(int mtile, int leaves, i
 #pragma unroll
     for (int q = 0; q < MT; ++q) run[p][q] = d4_t{0.0, 0.0, 0.0, 0.0};
   const double wbase = kk == 3 ? kappa : wt;
-  const double* xl = X + (size_t)kk * xrs;  // this lane's operand row of correspondence 0
+  const global_ptr<const double> xl = as_global(X) + (size_t)kk * xrs;  // this lane's operand row of correspondence 0
+  const global_ptr<const unsigned char> keep_g = as_global((const unsigned char*)cb.keep);
+  // (the flags of a whole leaf in one 8-byte load where the leaves are eight long and the array allows it)
+  const bool keep_wide = kchunk == 8 && (__builtin_amdgcn_readfirstlane((int)(uintptr_t)cb.keep) & 7) == 0;
+  const global_ptr<double> Mg = as_global(Mpart);
   constexpr int G = 8;  // correspondences whose loads are in flight together (a leaf of the usual eight: one round of loads)
+#ifndef ICP_FOLD_DEPTH
+#define ICP_FOLD_DEPTH 4
+#endif
+  constexpr int D = ICP_FOLD_DEPTH;
+  if (D > 1 && kchunk <= G) {
+    // Leaves of at most eight correspondences (every posterior of up to 512): a leaf is ONE round of loads and 8 x 4 matrix instructions —
+    // 0.4 µs of matrix pipe behind 2 µs of waiting, 50 times in a row for the face model's 400 correspondences, one wave per SIMD
+    // (profiles/r06_pmc_sq.json: 0.56 waves per SIMD, MFMA busy 17 %).  The operands of the next D − 1 leaves are requested before a
+    // leaf's products are issued (raw values: the weight is applied when they are used — the same product), a ring of D register
+    // buffers; products, their order within an accumulator and the leaf sums are those of the plain loop below: the same bits.
+    typedef double d2v_t __attribute__((ext_vector_type(2)));
+    d2v_t A_raw[D][G], B_raw[D][G];
+    unsigned long long keep_raw[D];  // (byte u: the flag of the leaf's correspondence u)
+    auto request = [&](auto SLOT, int f) {
+      constexpr int sl = decltype(SLOT)::value;
+      const int k0 = f * kchunk, k1 = min(K, k0 + kchunk);
+      if (keep_wide && k0 + 8 <= K) keep_raw[sl] = *(global_ptr<const unsigned long long>)(keep_g + k0);
+      else {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int u = 0; u < G; ++u) m |= (unsigned long long)keep_g[min(k0 + u, k1 - 1)] << (8 * u);
+        keep_raw[sl] = m;
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int k = min(k0 + u, k1 - 1);
+        const global_ptr<const double> xk = xl + (size_t)k * 4 * xrs;
+        A_raw[sl][u] = *(global_ptr<const d2v_t>)(xk + ca[0]);
+        B_raw[sl][u] = *(global_ptr<const d2v_t>)(xk + cbi[0]);
+      }
+    };
+    auto products = [&](auto SLOT, int f) {
+      constexpr int sl = decltype(SLOT)::value;
+      const int k0 = f * kchunk, k1 = min(K, k0 + kchunk);
+#pragma unroll
+      for (int p = 0; p < MT; ++p)
+#pragma unroll
+        for (int q = 0; q < MT; ++q) acc[p][q] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (k0 + u < k1) {
+          const double w = wbase * (((keep_raw[sl] >> (8 * u)) & 0xff) ? 1.0 : 0.0);
+          const double a[MT] = {A_raw[sl][u].x, A_raw[sl][u].y}, b[MT] = {B_raw[sl][u].x * w, B_raw[sl][u].y * w};
+#pragma unroll
+          for (int p = 0; p < MT; ++p)
+#pragma unroll
+            for (int q = 0; q < MT; ++q)
+              if (on[p][q]) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p], b[q], acc[p][q], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < MT; ++p)
+#pragma unroll
+        for (int q = 0; q < MT; ++q)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) run[p][q][g] += acc[p][q][g];
+    };
+    auto phase = [&](auto S, int f0) {
+      constexpr int s = decltype(S)::value;
+      const int f = f0 + s;
+      if (f + D - 1 < leaves) request(IntK<(s + D - 1) % D>{}, f + D - 1);  // (into the buffer the previous phase used up)
+      __builtin_amdgcn_sched_barrier(0);                                    // requested BEFORE this leaf's products, not next to their use
+      if (f < leaves) products(S, f);
+    };
+    if (0 < leaves && D > 1) request(IntK<0>{}, 0);
+    if (1 < leaves && D > 2) request(IntK<1 % D>{}, 1);
+    if (2 < leaves && D > 3) request(IntK<2 % D>{}, 2);
+    for (int f0 = 0; f0 < leaves; f0 += D) {
+      phase(IntK<0>{}, f0);
+      if constexpr (D > 1) phase(IntK<1 % D>{}, f0);
+      if constexpr (D > 2) phase(IntK<2 % D>{}, f0);
+      if constexpr (D > 3) phase(IntK<3 % D>{}, f0);
+    }
+  } else
   for (int f = 0; f < leaves; ++f) {
     const int k0 = f * kchunk, k1 = min(K, k0 + kchunk);
 #pragma unroll
@@ -334,8 +418,8 @@ __device__ __forceinline__ void regression_macro_fold_x(int mtile, int leaves, i
 #pragma unroll
       for (int u = 0; u < G; ++u) {
         const int k = min(kb + u, k1 - 1);  // (past the leaf's end: a repeated load, its products not issued)
-        const double* xk = xl + (size_t)k * 4 * xrs;
-        const double w = wbase * (cb.keep[k] ? 1.0 : 0.0);
+        const global_ptr<const double> xk = xl + (size_t)k * 4 * xrs;
+        const double w = wbase * (keep_g[k] ? 1.0 : 0.0);
 #pragma unroll
         for (int p = 0; p < MT; ++p) {
           A_op[u][p] = xk[ca[p]];
@@ -368,7 +452,7 @@ __device__ __forceinline__ void regression_macro_fold_x(int mtile, int leaves, i
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int row = 16 * (MT * mi + p) + kk + 4 * g, col = 16 * (MT * mj + q) + i16;
-        if (row < n && col < n) Mpart[(size_t)row * n + col] = run[p][q][g];
+        if (row < n && col < n) Mg[(size_t)row * n + col] = run[p][q][g];
       }
     }
 }
@@ -382,7 +466,7 @@ __device__ __forceinline__ void regression_xrows(int e, int K, int r, int xrs, c
   const double e0 = cb.e[3 * k], e1 = cb.e[3 * k + 1], e2 = cb.e[3 * k + 2];
   const double a0 = fma(ma, q[cc], ea * e0), a1 = fma(ma, q[r + cc], ea * e1), a2 = fma(ma, q[2 * r + cc], ea * e2);
   const double n0 = cb.nhat[3 * k], n1 = cb.nhat[3 * k + 1], n2 = cb.nhat[3 * k + 2];
-  double* x = X + (size_t)k * 4 * xrs + col;
+  double* x = X + (size_t)k * 4 * xrs + ((col & ~31) | ((col & 15) << 1) | ((col >> 4) & 1));  // (interleaved: StepRegressionArgs::X)
   x[0] = a0; x[xrs] = a1; x[2 * (size_t)xrs] = a2; x[3 * (size_t)xrs] = fma(a2, n2, fma(a1, n1, a0 * n0));
 }
 

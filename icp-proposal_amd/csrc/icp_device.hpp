@@ -11,6 +11,14 @@
 
 namespace icp {
 
+// A pointer READ FROM A RECORD IN MEMORY (the wide step's resident argument records, the batch records) is a generic pointer to the
+// compiler — only kernel arguments are known to point at global memory — and every access through it a FLAT instruction.  FLAT loads
+// come back in no fixed order against each other (memory vs LDS aperture), so a wait for one of them is `s_waitcnt vmcnt(0) lgkmcnt(0)`:
+// a wait for ALL — no round of loads can stay in flight across the use of an earlier one.  A pointer of type global_ptr<T> states what
+// it points at: global_load / global_store, counted waits.  (A cast to address space 1 and back is folded away: the TYPE has to stay.)
+template <class T> using global_ptr = __attribute__((address_space(1))) T*;
+template <class T> __device__ __forceinline__ global_ptr<T> as_global(T* p) { return (global_ptr<T>)p; }
+
 struct Pose {      // ModelFittingParameters.scala:79-90 — scale ∘ translation ∘ rotation about a centre
   double R[9];     // Rz(phi)·Ry(theta)·Rx(psi), computed on the host (libm sin/cos)
   double t[3];

@@ -386,8 +386,10 @@ struct StepRegressionArgs {  // launch 4: normal-equation partial sums of every 
   double* Mpart[2];
   int* status[2];            // the new entries' 3 status ints: {-, eigen sweeps, eigen} are cleared here
   // (folded posteriors of the wide step) the correspondences' operand rows, made by a launch of its own ahead of the regression
-  // (k_wide_xrows): X[(k·4 + j)·xrs + col] = row j of [Q_i | e_i] for j < 3, n̂ᵀ[Q_i | e_i] for j = 3, zeros behind column r — what
-  // regression_load / regression_mac work out per tile and correspondence.  null: gathered from the basis (regression_macro_fold)
+  // (k_wide_xrows): X[(k·4 + j)·xrs + xcol(col)] = row j of [Q_i | e_i] for j < 3, n̂ᵀ[Q_i | e_i] for j = 3, zeros behind column r — what
+  // regression_load / regression_mac work out per tile and correspondence.  xcol interleaves the two 16-column tiles of a macro block
+  // (column 32·m + 16·p + i at 32·m + 2·i + p): a lane's operands of both tiles are ONE 16-byte load (regression_macro_fold_x).
+  // null: gathered from the basis (regression_macro_fold)
   double* X[2];
   int xrs, xpad_;
 
