@@ -2344,7 +2344,9 @@ void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n_all, const
       tm.p[q] = tri::TridiagIO{r, rq[q].M, sl, d, e, beta, Hv, Nm};
       sm.p[q] = tri::TriSolveIO{r, d, e, beta, Hv, X, Xt, rq[q].S, mu, R, sync, rq[q].status, nullptr, nullptr, 0};
       bm.p[q] = tri::TriBackIO{r, Hv, R, X, Xt, rq[q].status, sync};
-      const int* skip = sync + 3;
+      // (test-hooks build, ICP_TEST_TRI_REFINE_ALWAYS=1: the refinement step whatever the gaps are — it is the rare path otherwise)
+      static const bool refine_always = dev_env("ICP_TEST_TRI_REFINE_ALWAYS") && std::atoi(dev_env("ICP_TEST_TRI_REFINE_ALWAYS")) != 0;
+      const int* skip = refine_always ? nullptr : sync + 3;
       g1.g[2 * q] = tri::TriGemm{Nm, X, T, 0, nullptr, nullptr, skip};
       g1.g[2 * q + 1] = tri::TriGemm{X, X, R, 1, nullptr, nullptr, skip};
       g2.g[q] = tri::TriGemm{X, T, Sm, 0, nullptr, nullptr, skip};

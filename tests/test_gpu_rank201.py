@@ -4,10 +4,14 @@ every posterior of that model fell to the per-stage generic decomposition, outsi
 Round 6: four row slots carry 256 rows (26 column slots per wave up to rank 208, 32 above).  The femur-200 fixture
 (tests/golden/make_fixtures.py) against the oracle: posterior / propose / logTransitionProbability, a host-stepped chain and the
 on-device loop decision for decision; a synthetic rank-256 model for the widest configuration."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
-from conftest import oracle_chains_parallel
+from conftest import ROOT, oracle_chains_parallel
 from test_gpu_chain import oracle_chain_config
 
 pytestmark = pytest.mark.gpu
@@ -134,3 +138,15 @@ def test_synthetic_ranks_above_201_on_the_wide_step(pkg, oracle, rank):
     assert np.abs(rec[:, 4 + 10:] - states_o[:, 10:]).max() <= 1e-5 * np.abs(states_o[:, 10:]).max()
     chain.close()
     ctx.close()
+
+
+def test_refinement_step_of_many_decompositions_a_launch(pkg):
+    """The refinement launches behind the back-transformation (Ogita-Aishima, icp_tridiag.hpp) return at once unless two eigenvalues
+    of a posterior are closer than kTriRefineGap — never, for these models.  Test-hooks build, ICP_TEST_TRI_REFINE_ALWAYS=1: the
+    on-device loop of the femur-200 model with the step taken by every decomposition of every launch, against the oracle as above."""
+    hooks = os.path.join(ROOT, "icp-proposal_amd", "libicp_proposal_amd_testhooks.so")
+    assert os.path.exists(hooks), "build the test-hooks library (python -c 'import __graft_entry__ as g; g.build()')"
+    done = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__) + "::test_femur200_on_device_loop_matches_oracle", "-x", "-q", "-m", "gpu"],
+                          capture_output=True, text=True, cwd=ROOT, timeout=900,
+                          env={**os.environ, "ICP_LIBRARY_PATH": hooks, "ICP_TEST_TRI_REFINE_ALWAYS": "1"})
+    assert done.returncode == 0 and "1 passed" in done.stdout, done.stdout[-3000:] + done.stderr[-2000:]
