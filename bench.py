@@ -48,6 +48,10 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 
 F32_VECTOR_TFLOPS = 157.3  # same guide: peak FP32 vector (the filters run on packed f32; the exact resolves in f64)
 F64_VECTOR_TFLOPS = 78.6   # AMD's public MI355X figure for vector FP64 (not in the local guide; SURVEY.md §8d uses it)
 F64_MATRIX_TFLOPS = 78.6   # … and for matrix FP64 (v_mfma_f64_16x16x4: 1,024 multiply-adds in 32 cycles per SIMD = the vector rate)
+# what the instruction was MEASURED to sustain on this pool (tools/src/mfma_f64_bench.hip, round 6: four independent accumulators per wave,
+# back to back): stated beside the data-sheet peak the fractions are priced against
+F64_MATRIX_MEASURED = {"tool": "tools/src/mfma_f64_bench.hip", "TFLOPs_by_waves_per_simd": {"1": 32.2, "2": 42.5, "4": 46.9},
+                       "ns_per_instruction_one_wave": 60.2}
 N_SIMD = 256 * 4           # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 N_XCD = 8
 METRIC = "ICP-proposal MH iterations/sec (femur GPMM r=50, ~50k-vtx target)"
@@ -379,7 +383,7 @@ def mfma_block(config_key, kernels, live_us, flops):
                cycles);
       flops:   algorithmic f64 multiply-add flops of one launch / the launch's duration measured in THIS run (HIP events) / the dense
                matrix-f64 peak."""
-    out = {"peak_TFLOPs": F64_MATRIX_TFLOPS,
+    out = {"peak_TFLOPs": F64_MATRIX_TFLOPS, "measured_instruction_rate": F64_MATRIX_MEASURED,
            "formula": "busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (%d SIMDs x GRBM_GUI_ACTIVE / %d XCDs); flops_frac = algorithmic f64 flops per launch / "
                       "avg launch duration (HIP events, this run) / %.1f TFLOP/s" % (N_SIMD, N_XCD, F64_MATRIX_TFLOPS), "kernels": {}}
     pmc = {}
@@ -850,7 +854,7 @@ def config4_roofline(pkg, args, model, target, make_setup, device, n_chains=25, 
         us = pst["k_step_regression"]["avg_us"]
         msrc, mf = _tracked_json(("r06_pmc_mfma.json",))
         mf = mf.get("wide_loop25", {})
-        mfma = {"peak_TFLOPs": F64_MATRIX_TFLOPS, "kernels": {}, "counter_source": (msrc + " (wide_loop25)") if msrc else None,
+        mfma = {"peak_TFLOPs": F64_MATRIX_TFLOPS, "measured_instruction_rate": F64_MATRIX_MEASURED, "kernels": {}, "counter_source": (msrc + " (wide_loop25)") if msrc else None,
                 "formula": "busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (%d SIMDs x GRBM_GUI_ACTIVE / %d XCDs); flops_frac = algorithmic f64 flops per launch / avg "
                            "launch duration (HIP events, this run) / %.1f TFLOP/s" % (N_SIMD, N_XCD, F64_MATRIX_TFLOPS)}
         row = {"avg_launch_us": us, "posteriors_per_launch": n_chains, "algorithmic_f64_flops": flops, "achieved_TFLOPs": flops / (us * 1e-6) / 1e12,
