@@ -179,7 +179,7 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
     groups.resize(n_groups);
     GroupGuard group_guard{groups};
     constexpr int kChunk = 64;  // steps per block of standard normals
-    constexpr int tri_chunk = 16;  // (tri::kTriMany: requests per launch of the tridiagonal route)
+    constexpr int tri_chunk = kTriManyMax;  // (requests per launch of the tridiagonal route)
     std::vector<double> zero_z(r, 0.0);
     lead.bind();
     for (int g = 0; g < n_groups; ++g) {
@@ -492,6 +492,47 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           // what the summed partials feed does not depend on each other: the factorisations and tails (one-workgroup kernels) on a second
           // stream, above rank 64 the proposed states' decompositions on two more (16 per launch, the launches side by side), the evaluator's
           // searches and reductions on `S`; the decision waits for the tails, the hand-over of an accepted state for the decompositions
+          // Round 6: the step's critical chain — main sequence, reduction to tridiagonal form, eigenpairs, back-transformation, hand-over —
+          // stays on ONE queue: a dependency that crosses queues costs 20-30 µs between the end of one kernel and the start of the next
+          // (profiles/r06_wide_loop25_step_timeline.txt before: 30 µs at the fork, 20 at the join).  The first launch of decompositions
+          // goes on `S` itself, and what has slack — the evaluator's searches and the decision, 0.1 ms ahead of the reduction's end —
+          // crosses instead: on the first decomposition stream of the older layout (kept below: ICP_WIDE_LOOP_CHAIN_MAIN=0, the A/B switch).
+          static const bool chain_main = !(dev_env("ICP_WIDE_LOOP_CHAIN_MAIN") && std::atoi(dev_env("ICP_WIDE_LOOP_CHAIN_MAIN")) == 0) &&
+                                         !(dev_env("ICP_WIDE_LOOP_EIG_SPLIT") && std::atoi(dev_env("ICP_WIDE_LOOP_EIG_SPLIT")) == 0);
+          if (gr.side[0] && chain_main) {
+            const hipStream_t F = gr.side[0], V = gr.side[1], E1 = gr.side[2];
+            HIP_OK(hipEventRecord(gr.ev_sum, S));
+            HIP_OK(hipStreamWaitEvent(F, gr.ev_sum, 0));
+            HIP_OK(hipStreamWaitEvent(V, gr.ev_sum, 0));
+            int used = 0;
+            for (int q0 = 0; q0 < nq; q0 += tri_chunk, ++used) {  // part 1: the reductions (see below)
+              if (used == 1) HIP_OK(hipStreamWaitEvent(E1, gr.ev_sum, 0));
+              launch_posterior_eigen_tridiag_many((used & 1) ? E1 : S, r, std::min(tri_chunk, nq - q0), gr.rqs.data() + q0, gr.spec_parts.data() + q0, nullptr, 1);
+            }
+            const bool side_eig = used > 1;
+            gr.n_eig_streams = 0; gr.eig_split = true;
+            for (size_t p0 = 0; p0 < cap.factors.size(); p0 += fmax)
+              launch_posterior_factor(F, r, (int)std::min(fmax, cap.factors.size() - p0), cap.factors.data() + p0);
+            for (size_t t0 = 0; t0 < cap.tails.size(); t0 += 2 * kWideMaxChains)
+              launch_transition_tails(F, r, (int)std::min<size_t>(2 * kWideMaxChains, cap.tails.size() - t0), cap.tails.data() + t0, lead.Ginv.p, kSigma2);
+            HIP_OK(hipEventRecord(gr.ev_tails, F));
+            if (head_split) HIP_OK(hipStreamWaitEvent(V, gr.ev_inst, 0));
+            if (cap.any_split) launch_wide_eval(V, cap.plan, gr.wide_dev.p);
+            HIP_OK(hipStreamWaitEvent(V, gr.ev_tails, 0));
+            launch_mhw_decide(V, gr.B, r, gr.mh.p);
+            HIP_OK(hipEventRecord(gr.ev_decide, V));
+            HIP_OK(hipStreamWaitEvent(S, gr.ev_decide, 0));  // (long satisfied when the reduction ends)
+            if (side_eig) HIP_OK(hipStreamWaitEvent(E1, gr.ev_decide, 0));
+            used = 0;
+            for (int q0 = 0; q0 < nq; q0 += tri_chunk, ++used)  // part 2, for the chains that moved
+              launch_posterior_eigen_tridiag_many((used & 1) ? E1 : S, r, std::min(tri_chunk, nq - q0), gr.rqs.data() + q0, gr.spec_parts.data() + q0, gr.eig_skip.p + q0, 2);
+            if (side_eig) {
+              HIP_OK(hipEventRecord(gr.ev_eig[0], E1));
+              HIP_OK(hipStreamWaitEvent(S, gr.ev_eig[0], 0));
+            }
+            launch_mhw_adopt(S, r, nq, gr.adopt.p, gr.eig_skip.p);
+            continue;
+          }
           hipStream_t S2 = S;
           if (gr.side[0]) {
             S2 = gr.side[0];

@@ -645,6 +645,7 @@ void launch_sum_partials_many(hipStream_t st, int r, int n, double* const* Mpart
 // inside the sequence: a spectrum the multisection cannot separate ends with status 2 in the request's status words, and the caller
 // decomposes that posterior again through launch_posterior_eigen.
 bool eigen_tridiag_many_supported(int r);
+constexpr int kTriManyMax = 32;  // posteriors per launch of the tridiagonal route (launch_posterior_eigen_tridiag_many takes any number, in launches of this many)
 void launch_posterior_eigen_tridiag_many(hipStream_t st, int r, int n, const EigenRequest* rq, const double* const* parts /* may be null */,
                                          const int* skip = nullptr /* device, [n]: != 0 leaves request i alone (the on-device loop) */,
                                          int part = 0 /* 0: the whole sequence; 1: M and the reduction to tridiagonal form only; 2: what follows

@@ -597,7 +597,7 @@ __device__ __forceinline__ void tridiag_kernel_body(const TridiagIO& a) {
 template <int NW, int SI, int NT, int TOFF>
 __global__ void __launch_bounds__(NW * 64) k_tridiag(TridiagIO a) { tridiag_kernel_body<NW, SI, NT, TOFF>(a); }
 // the same for up to kTriMany matrices side by side, one workgroup each (the chains of a wide step: kernels_wide.hip)
-constexpr int kTriMany = 16;
+constexpr int kTriMany = kTriManyMax;  // (32, icp_kernels.hpp: the largest of the records below, TriSolveMany, is 3.8 KB of the 4 KB argument segment)
 struct TridiagMany { TridiagIO p[kTriMany]; };
 template <int NW, int SI, int NT, int TOFF>
 __global__ void __launch_bounds__(NW * 64) k_tridiag_many(TridiagMany m, const int* __restrict__ skip_all) {
@@ -1239,6 +1239,7 @@ __global__ void __launch_bounds__(256) k_tri_solve(TriSolveIO a0, TriSolveIO a1)
   tri_solve_or_wy<SI>(blockIdx.y ? a1 : a0);  // (up to two decompositions side by side: the two ICP directions of a chain step)
 }
 struct TriSolveMany { TriSolveIO p[kTriMany]; };
+static_assert(sizeof(TriSolveMany) + 16 <= 4096, "the records of a launch must fit the kernel argument segment");
 template <int SI>
 __global__ void __launch_bounds__(256) k_tri_solve_many(TriSolveMany m, const int* __restrict__ skip_all) {
   if (skip_all && skip_all[blockIdx.y] != 0) return;
@@ -1517,6 +1518,7 @@ __global__ void __launch_bounds__(64) k_tri_gemm(int n, TriGemm g0, TriGemm g1) 
   tri_gemm_body(n, g);
 }
 struct TriGemmMany { TriGemm g[2 * kTriMany]; };  // blockIdx.z = product
+static_assert(sizeof(TriGemmMany) + 32 <= 4096, "the records of a launch must fit the kernel argument segment");
 __global__ void __launch_bounds__(64) k_tri_gemm_many(int n, TriGemmMany m, const int* __restrict__ skip_all, int per_problem) {
   if (skip_all && skip_all[blockIdx.z / per_problem] != 0) return;
   const TriGemm g = m.g[blockIdx.z];
