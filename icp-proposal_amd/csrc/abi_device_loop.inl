@@ -489,9 +489,9 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
           launch_wide_main(S, cap.plan, gr.wide_dev.p);
           for (size_t p0 = 0; p0 < cap.sum_parts.size(); p0 += kWideMaxChains)
             launch_sum_partials_many(S, r, (int)std::min<size_t>(kWideMaxChains, cap.sum_parts.size() - p0), cap.sum_parts.data() + p0, cap.sum_splits.data() + p0);
-          // what the summed partials feed does not depend on each other: the factorisations and tails (one-workgroup kernels) on a second
-          // stream, above rank 64 the proposed states' decompositions on two more (16 per launch, the launches side by side), the evaluator's
-          // searches and reductions on `S`; the decision waits for the tails, the hand-over of an accepted state for the decompositions
+          // what the summed partials feed does not depend on each other: the factorisations and tails (one-workgroup kernels), above rank 64
+          // the proposed states' decompositions, the evaluator's searches and reductions; the decision waits for the tails, the hand-over of
+          // an accepted state for the decompositions.
           // Round 6: the step's critical chain — main sequence, reduction to tridiagonal form, eigenpairs, back-transformation, hand-over —
           // stays on ONE queue: a dependency that crosses queues costs 20-30 µs between the end of one kernel and the start of the next
           // (profiles/r06_wide_loop25_step_timeline.txt before: 30 µs at the fork, 20 at the join).  The first launch of decompositions
@@ -533,6 +533,8 @@ int wide_chains_run_on_device(int32_t n_chains, icp_evaluator* const* evaluators
             launch_mhw_adopt(S, r, nq, gr.adopt.p, gr.eig_skip.p);
             continue;
           }
+          // (the older layout, and ranks <= 64: factorisations and tails on a second stream, the decompositions on two more — kTriManyMax per
+          // launch, the launches side by side —, the evaluator's sequence on `S`)
           hipStream_t S2 = S;
           if (gr.side[0]) {
             S2 = gr.side[0];
