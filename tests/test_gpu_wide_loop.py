@@ -39,6 +39,10 @@ elif kind == "face200":     # rank 200: the four-slot tridiagonalisation, two la
     model = pkg.data.synthetic_face_model(grid=41, rank=200)
     target = pkg.data.synthetic_partial_target(model, n_remove=90, seed=7)
     mk = lambda: pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2)
+elif kind == "facefull":    # configs[3] / configs[4] size (N = 28,561, rank 200): the instance launch's head is a thirtieth of its blocks
+    model = pkg.data.synthetic_face_model()
+    target = pkg.data.synthetic_partial_target(model, seed=100)
+    mk = lambda: pkg.bfm_fitting_partial(model, target, evaluator="collective", fused=2)
 elif kind == "face40":      # rank <= 64 on an open target: the warm-started Jacobi iteration behind the decision, three groups
     model = pkg.data.synthetic_face_model(grid=31, rank=40)
     target = pkg.data.synthetic_partial_target(model, n_remove=60, seed=7)
@@ -104,6 +108,28 @@ def test_wide_loop_matches_host_stepped_chains(kind, B, n1, n2, exact, tmp_path)
     leaves = set(a[:, :, 2].astype(int).ravel())
     assert leaves == ({0, 1, 2} if kind.startswith("femur") else {0, 2, 3, 4, 5, 6, 7, 8}), leaves
 
+
+
+def test_wide_loop_layouts_give_the_same_records(tmp_path):
+    """Round 6 changed WHERE the loop's launches go, not what they compute: the instance launch's head ahead of the rest
+    (ICP_WIDE_LOOP_HEAD_SPLIT), the decompositions in two parts around the decision (ICP_WIDE_LOOP_EIG_SPLIT), the step's critical chain on
+    one queue (ICP_WIDE_LOOP_CHAIN_MAIN).  Test-hooks build: each switched back in turn, six chains of the full-size face model (where the
+    head applies: it is at most a quarter of the instance's blocks) — records bit for bit."""
+    hooks = os.path.join(ROOT, "icp-proposal_amd", "libicp_proposal_amd_testhooks.so")
+    assert os.path.exists(hooks), "build the test-hooks library (python -c 'import __graft_entry__ as g; g.build()')"
+    out = {}
+    for tag, env in (("default", {}), ("no_head", {"ICP_WIDE_LOOP_HEAD_SPLIT": "0"}), ("no_chain_main", {"ICP_WIDE_LOOP_CHAIN_MAIN": "0"}),
+                     ("no_eig_split", {"ICP_WIDE_LOOP_EIG_SPLIT": "0"})):
+        path = str(tmp_path / f"wl_{tag}.npz")
+        script = _SCRIPT.format(root=ROOT, kind="facefull", B=6, n1=16, n2=4, out=path)
+        subprocess.run([sys.executable, "-c", script], check=True, timeout=900,
+                       env={**os.environ, "ICP_HOST_DEVICE_LOOP": "1", "ICP_LIBRARY_PATH": hooks, **env})
+        out[tag] = np.load(path)
+    ref = out["default"]
+    assert np.all(ref["loop"][1:] == 16 + 4) and np.all(ref["stats"] == 0)
+    for tag, got in out.items():
+        for key in ("a", "single", "b", "theta", "logp"):
+            assert np.array_equal(ref[key], got[key]), (tag, key)
 
 def model_rank(kind):
     return {"face100": 100, "hausdorff": 100, "face200": 200, "face40": 40, "femur100": 101, "femur50open": 51, "face40root": 40}[kind]
